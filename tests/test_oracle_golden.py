@@ -1,0 +1,96 @@
+"""CPU: the oracle (oracle/afm_oracle.py) against vectors produced by the reference itself
+(tests/golden/*.npz, generator oracle/make_goldens.py).  This is what pins the oracle."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import afm_oracle as O
+from tests import golden_io as G
+
+CASES = ["model_plain", "model_gated_learned"]
+
+
+@pytest.fixture(scope="module", params=CASES)
+def case(request):
+    t = G.load(request.param)
+    return t, G.model_cfg(t["meta"])
+
+
+def _fwd(t, cfg, i, sd=None):
+    enc, am, dec, dm, labels = O.batch_to_model_inputs(G.batch_of(t, i), "Smiles")
+    return O.model_forward(sd or t["sd"], cfg, t["meta"]["data_config"], "Smiles", enc, am, dec, dm, labels)
+
+
+def test_forward_logits_loss_argmax(case):
+    t, cfg = case
+    for i in range(4):
+        out = _fwd(t, cfg, i)
+        ref = t[f"b{i}"]
+        torch.testing.assert_close(out["logits"], ref["logits"], rtol=1e-5, atol=2e-6)
+        torch.testing.assert_close(out["loss"], ref["loss"], rtol=1e-6, atol=1e-6)
+        assert torch.equal(out["logits"].argmax(-1), ref["argmax"])  # bit-exact token ids
+        torch.testing.assert_close(out["encoder_hidden_states"], ref["encoder_hidden_states"], rtol=1e-5, atol=2e-6)
+        acc = O.token_accuracy(out["logits"], ref["target"].T)
+        torch.testing.assert_close(acc, ref["token_acc"])
+
+
+def test_backward_grads(case):
+    t, cfg = case
+    sd = {k: v.clone().requires_grad_(v.is_floating_point() and not k.endswith("positional_encodings.pos_enc")) for k, v in t["sd"].items()}
+    out = _fwd(t, cfg, 0, sd)
+    out["loss"].backward()
+    for k, g in t["grad0"].items():
+        got = sd[k].grad if sd[k].grad is not None else torch.zeros_like(sd[k])
+        torch.testing.assert_close(got, g, rtol=2e-4, atol=2e-7, msg=lambda m: f"{k}: {m}")
+
+
+def test_two_optimizer_steps(case):
+    t, cfg = case
+    m = t["meta"]
+    tr = O.OracleTrainer(t["sd"], cfg, m["data_config"], "Smiles", lr=m["lr"], total_steps=m["total_steps"],
+                         optimiser=m["optimiser"], weight_decay=m["weight_decay"], acc_batches=m["acc_batches"],
+                         clip=m["clip"])
+    for step in (1, 2):
+        for i in range(4):
+            tr.micro_batch(*O.batch_to_model_inputs(G.batch_of(t, i), "Smiles"))
+        torch.testing.assert_close(tr.last_norm, t[f"step{step}"]["grad_norm"], rtol=1e-5, atol=1e-6)
+        for k, ref in t[f"step{step}"].items():
+            if k == "grad_norm":
+                continue
+            got = tr.sd[k].detach()
+            if k.endswith("in_proj_bias"):
+                # the K-bias gradient is identically zero in exact arithmetic (softmax shift
+                # invariance); Adam normalises its rounding noise to O(lr) moves, so that third
+                # is only bounded by the summed learning rates.
+                d = got.numel() // 3
+                torch.testing.assert_close(got[d:2 * d], ref[d:2 * d], rtol=0, atol=3e-4)
+                got, ref = torch.cat([got[:d], got[2 * d:]]), torch.cat([ref[:d], ref[2 * d:]])
+            torch.testing.assert_close(got, ref, rtol=1e-4, atol=2e-6, msg=lambda s: f"step{step} {k}: {s}")
+
+
+def test_greedy_decode(case):
+    t, cfg = case
+    enc, am, _, _, _ = O.batch_to_model_inputs(G.batch_of(t, 0), "Smiles")
+    ids = O.greedy_decode(t["sd"], cfg, t["meta"]["data_config"], "Smiles", enc, am,
+                          max_length=t["meta"]["greedy_max_length"])
+    assert torch.equal(ids, t["greedy"]["ids"])
+
+
+def test_embed_variants():
+    t = G.load("embed_variants")
+    dc = t["meta"]["data_config"]
+    for pe in ("sin_cos", "learned"):
+        inp = {"A": t[pe]["in"]["A"], "B": t[pe]["in"]["B"], "C": t[pe]["in"]["C"], "D": dict(t[pe]["in"]["D"])}
+        y = O.embed(t[pe]["sd"], dc, inp, True, pe)
+        torch.testing.assert_close(y, t[pe]["out"], rtol=1e-5, atol=2e-6)
+
+
+def test_schedule_and_sincos():
+    t = G.load("schedule")
+    for total in (10, 100):
+        lr = [O.onecycle(s, total, 1e-3)[0] for s in range(total)]
+        b1 = [O.onecycle(s, total, 1e-3)[1] for s in range(total)]
+        np.testing.assert_allclose(lr, t[f"onecycle{total}"]["lr"].numpy(), rtol=1e-12)
+        np.testing.assert_allclose(b1, t[f"onecycle{total}"]["beta1"].numpy(), rtol=1e-12)
+    for d in (64, 128, 30):
+        torch.testing.assert_close(O.sincos_table(d, 40), t["sincos"][str(d)], rtol=0, atol=1e-6)
