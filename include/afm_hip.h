@@ -1,0 +1,222 @@
+/*
+ * afm_hip.h -- C ABI of libafm_hip.so, the MI355X (gfx950 / CDNA4) kernel library behind
+ * the spectra->SMILES training path of `analytical_fm` (rxn4chemistry/MultimodalAnalytical).
+ *
+ * The reference has no native boundary: its hot path is Python calling torch.nn modules.
+ * Each entry point below therefore replaces one torch operator family at the place the
+ * reference invokes it; the reference call site is cited on every declaration
+ * (paths relative to the reference's src/analytical_fm/, "torch:" = the torch wheel).
+ * INTEGRATION.md shows the ctypes binding a maintainer would add on the reference side.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer (HBM) unless its name ends in _host;
+ *   - caller allocates everything; no entry point allocates, frees or synchronises;
+ *   - `stream` is a hipStream_t passed as void*; work is enqueued on it and the call
+ *     returns immediately (safe under hipGraph stream capture);
+ *   - return value: AFM_OK (0) or a negative AFM_ERR_* code; nothing is launched on error;
+ *   - matrices are row-major; `ld*` are row strides in ELEMENTS;
+ *   - dtype codes: AFM_F32 = 0 (float), AFM_BF16 = 1 (bfloat16, round-to-nearest-even).
+ */
+#ifndef AFM_HIP_H
+#define AFM_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AFM_ABI_VERSION 1
+
+enum { AFM_OK = 0, AFM_ERR_ARG = -1, AFM_ERR_UNSUPPORTED = -2, AFM_ERR_LAUNCH = -3 };
+enum { AFM_F32 = 0, AFM_BF16 = 1 };
+enum { AFM_ACT_NONE = 0, AFM_ACT_RELU = 1, AFM_ACT_GELU = 2 };
+enum { AFM_ALGO_AUTO = 0, AFM_ALGO_GENERIC = 1, AFM_ALGO_MFMA = 2 };
+
+int afm_abi_version(void);
+const char* afm_error_string(int code);
+/* Name of the kernel family the last afm_gemm / afm_attn_* call on this thread dispatched to
+ * ("generic", "mfma_nt", "mfma_tn", ...): lets tests assert the fast path really ran. */
+const char* afm_last_algo(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Dropout stream.  Every dropout site of the reference (torch `dropout`/`bernoulli_`,
+ * custom_modeling.py:122-130,169-177) is a counter-based mask: keep(i) is a pure function
+ * of (seed, site, element index i), so backward recomputes it and no mask tensor exists.
+ * p == 0 disables.  Kept values are scaled by 1/(1-p).
+ * ---------------------------------------------------------------------------------------- */
+typedef struct {
+  float p;
+  uint32_t site;
+  uint64_t seed;
+} afm_dropout;
+
+/* ------------------------------------------------------------------------------------------
+ * GEMM with fused epilogue:   T = op(A) . op(B) + bias ; T = act(T) ; T = dropout(T) ;
+ *                             C = T + (residual ? residual : 0) + (accumulate ? C : 0)
+ * op(A) is M x K:  transA == 0 -> A[m*lda + k],  transA == 1 -> A[k*lda + m]
+ * op(B) is K x N:  transB == 0 -> B[k*ldb + n],  transB == 1 -> B[n*ldb + k]
+ * Replaces aten::linear / addmm / mm and their backward:
+ *   forward  y = x W^T + b   (torch:nn/functional.py linear; call sites modeling/utils.py:120-134,
+ *            torch:nn/functional.py:5785 _in_projection_packed, torch:nn/modules/transformer.py:980-982,
+ *            custom_modeling.py:145-149,486)                       transA=0, transB=1
+ *   dgrad    dx = dy W                                              transA=0, transB=0
+ *   wgrad    dW += dy^T x  (accumulate=1: gradient accumulation)    transA=1, transB=0
+ * `pre_act` (optional, dtype/ld of C) receives T before the activation (kept for GELU backward).
+ * bf16 operands take the MFMA path (v_mfma_f32_16x16x32_bf16 / 32x32x16, fp32 accumulate) when
+ * shape/alignment allow; everything else takes the exact-fp32 FMA path.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct {
+  int32_t M, N, K;
+  int32_t transA, transB;
+  int32_t lda, ldb, ldc;
+  int32_t a_dtype, b_dtype, c_dtype;
+  const void* A;
+  const void* B;
+  void* C;
+  const float* bias;      /* N, fp32, nullable */
+  const void* residual;   /* M x N, dtype/ld of C, nullable */
+  void* pre_act;          /* M x N, dtype/ld of C, nullable */
+  int32_t act;            /* AFM_ACT_* */
+  int32_t accumulate;     /* C += ... */
+  int32_t algo;           /* AFM_ALGO_* */
+  int32_t reserved;
+  afm_dropout drop;
+} afm_gemm_desc;
+int afm_gemm(const afm_gemm_desc* d, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Embedding rows.  nn.Embedding forward / embedding_dense_backward (modeling/utils.py:102-106,
+ * 155-162): out[i,:] = table[ids[i],:] * (scale ? scale[i] : 1).  Backward adds
+ * dout[i,:]*scale[i] into dtable[ids[i],:] and skips ids == padding_idx (its row gets no
+ * gradient, as torch).  ids outside [0,V) are clamped (memory safety only).
+ * ---------------------------------------------------------------------------------------- */
+int afm_gather_rows(const int64_t* ids, const float* scale, const float* table, float* out,
+                    int64_t n, int32_t d, int32_t V, void* stream);
+int afm_scatter_add_rows(const int64_t* ids, const float* scale, const float* dout, float* dtable,
+                         int64_t n, int32_t d, int32_t V, int64_t padding_idx, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * LayerNorm over the last dim, eps inside the sqrt, biased variance (aten::native_layer_norm;
+ * call sites modeling/utils.py:165-168,271, torch:nn/modules/transformer.py:946-950,1131-1143,
+ * custom_modeling.py:350,399), with the two layout fusions the embedding needs
+ * (modeling/utils.py:176-180): an optional positional table added AFTER the norm, and a row
+ * remap so each modality writes straight into its slice of the concatenated sequence:
+ *     out_row(r) = (r / seg_len) * out_seg_stride + out_off + (r % seg_len)
+ *     y[out_row(r), :] = LN(x[r, :]) * gamma + beta + (pos ? pos[(out_off + r % seg_len), :] : 0)
+ * seg_len == 0 means identity mapping.  x is fp32 (the residual stream); y is fp32 or bf16.
+ * mean/rstd (rows, fp32) are saved for backward.
+ * Backward: dx[r,:] = (dres ? dres[r,:] : 0) + LN'(dy[out_row(r),:]); dgamma/dbeta are
+ * ACCUMULATED (+=) into fp32 buffers; `partial` is workspace of afm_layernorm_bwd_ws_floats().
+ * ---------------------------------------------------------------------------------------- */
+typedef struct {
+  int64_t rows;
+  int32_t d;
+  int32_t y_dtype;
+  int64_t seg_len, out_seg_stride, out_off;
+  float eps;
+  int32_t reserved;
+} afm_ln_shape;
+int afm_layernorm_fwd(const afm_ln_shape* s, const float* x, const float* gamma, const float* beta,
+                      const float* pos, void* y, float* mean, float* rstd, void* stream);
+int64_t afm_layernorm_bwd_ws_floats(const afm_ln_shape* s);
+int afm_layernorm_bwd(const afm_ln_shape* s, const void* dy, const float* x, const float* gamma,
+                      const float* mean, const float* rstd, const float* dres, float* dx,
+                      float* dgamma, float* dbeta, float* partial, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Masked multi-head attention, flash style (no T_q x T_k tensor in HBM).
+ * F.scaled_dot_product_attention as reached from nn.MultiheadAttention
+ * (torch:nn/functional.py:6206-6640; reference call sites custom_modeling.py:122-130 encoder
+ * self-attention, :169-177 + :308-318 decoder causal self-attention and cross-attention):
+ *     P = softmax(Q K^T * scale + mask) ; O = dropout(P) V
+ * Element (b, t, h, j) of Q lives at Q[(b*Tq + t)*ldq + h*dh + j] (same for K/V with Tk, O with
+ * Tq): packed in-projection outputs are addressed in place.  key_pad (B x Tk, 1 = masked key,
+ * nullable) is src_/tgt_/memory_key_padding_mask; causal != 0 masks key > query
+ * (nn.Transformer.generate_square_subsequent_mask).  A row whose keys are all masked yields
+ * zeros (torch _safe_softmax).  lse (B x H x Tq fp32) = log-sum-exp of the scaled, masked
+ * scores (+inf for an all-masked row), kept for backward.
+ * Backward recomputes P from lse; delta (B x H x Tq fp32) is workspace.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct {
+  int32_t B, H, Tq, Tk, dh;
+  int32_t dtype;
+  int32_t ldq, ldk, ldv, ldo;
+  int32_t causal;
+  int32_t algo;
+  float scale;
+  int32_t reserved;
+  const uint8_t* key_pad;
+  afm_dropout drop;
+} afm_attn_shape;
+int afm_attn_fwd(const afm_attn_shape* s, const void* Q, const void* K, const void* V, void* O,
+                 float* lse, void* stream);
+int afm_attn_bwd(const afm_attn_shape* s, const void* Q, const void* K, const void* V, const void* O,
+                 const void* dO, const float* lse, float* delta, void* dQ, void* dK, void* dV,
+                 int32_t lddq, int32_t lddk, int32_t lddv, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Elementwise pieces of the FFN and the residual branches.
+ * afm_glu_fwd:  g = gelu(u) * (v ? v : 1), then dropout      (torch:nn/modules/transformer.py:980-982,
+ *               custom_modeling.py:145-148,192-195; exact erf GELU)
+ * afm_glu_bwd:  du = dg' * (v ? v : 1) * gelu'(u), dv = dg' * gelu(u), dg' = dropout'(dg)
+ * afm_dropout_cast: y = dropout(x) cast to y_dtype  (backward of the dropout1/2/3 residual branches:
+ *               the fp32 residual gradient masked and handed to the GEMMs in their operand dtype)
+ * u, v, g are rows x f with row strides ld*, dtype `dtype`.
+ * ---------------------------------------------------------------------------------------- */
+int afm_glu_fwd(const void* u, const void* v, void* g, int64_t rows, int32_t f, int32_t ldu,
+                int32_t ldv, int32_t ldg, int32_t dtype, const afm_dropout* drop, void* stream);
+int afm_glu_bwd(const void* u, const void* v, const void* dg, void* du, void* dv, int64_t rows,
+                int32_t f, int32_t ldu, int32_t ldv, int32_t lddg, int32_t lddu, int32_t lddv,
+                int32_t dtype, const afm_dropout* drop, void* stream);
+int afm_dropout_cast(const float* x, void* y, int64_t rows, int32_t n, int32_t ldx, int32_t ldy,
+                     int32_t y_dtype, const afm_dropout* drop, void* stream);
+/* Column sums (bias gradients): out[j] (+)= sum_i x[i*ld + j].  Backward of the bias add of
+ * every aten::linear above. */
+int afm_colsum(const void* x, float* out, int64_t rows, int32_t n, int32_t ld, int32_t dtype,
+               int32_t accumulate, void* stream);
+/* y[i] += x[i] (fp32): e.g. the positional-table gradient summed over the batch. */
+int afm_add_inplace(float* y, const float* x, int64_t n, void* stream);
+/* out[s,:] (+)= sum_b x[(b*S + s),:]  (batch reduction for the learned positional encoding
+ * gradient, modeling/utils.py:267-271). */
+int afm_batch_sum(const float* x, float* out, int32_t B, int64_t S, int32_t d, int32_t accumulate,
+                  void* stream);
+/* fp32 -> bf16 copies of the weights for the MFMA GEMMs: dst (rows x cols) and, when dst_t is
+ * given, the transpose (cols x rows) used by dgrad. */
+int afm_cast_bf16(const float* src, void* dst, void* dst_t, int32_t rows, int32_t cols, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * LM-head loss.  nn.CrossEntropyLoss() over logits.view(-1,V) with ignore_index -100
+ * (custom_modeling.py:490-491) fused with the teacher-forced argmax of
+ * HFWrapper._calc_token_acc (wrapper.py:641-655).
+ * fwd: per row log-sum-exp and argmax (first maximal index, as torch.argmax); stats[0] += sum of
+ *      -log_softmax[label] over labels != -100, stats[1] += number of such labels.
+ * bwd: dlogits = (softmax - onehot(label)) * grad_scale / stats[1] for kept rows, 0 otherwise.
+ * ---------------------------------------------------------------------------------------- */
+int afm_ce_fwd(const float* logits, const int64_t* labels, int64_t rows, int32_t V, int32_t ld,
+               float* row_lse, int64_t* argmax, float* stats, void* stream);
+int afm_ce_bwd(const float* logits, const int64_t* labels, const float* row_lse, const float* stats,
+               float grad_scale, void* dlogits, int32_t dl_dtype, int32_t lddl, int64_t rows,
+               int32_t V, int32_t ld, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Optimiser over ONE flat fp32 parameter buffer (all tensors of the model are views of it).
+ * afm_sumsq:  out[0] += sum g[i]^2   (torch.nn.utils.clip_grad_norm_, Lightning
+ *             gradient_clip_val, trainer/trainer.py:65)
+ * afm_adam_step: torch.optim.Adam / AdamW (wrapper.py:29,333-338) with the clip folded in:
+ *     coef = min(1, max_norm / (sqrt(sumsq[0]) + 1e-6)) * grad_mult ; g = g * coef
+ *     Adam  (decoupled == 0): g += wd * p        AdamW (decoupled == 1): p *= 1 - lr*wd
+ *     m = b1 m + (1-b1) g ; v = b2 v + (1-b2) g^2
+ *     p -= lr / (1 - b1^t) * m / (sqrt(v) / sqrt(1 - b2^t) + eps)
+ * hyper (DEVICE, 10 floats) = { lr, beta1, beta2, eps, weight_decay, 1-beta1^t, 1-beta2^t,
+ *     max_norm (<=0: no clip), grad_mult, decoupled } so a captured graph replays with new
+ * values.  g is zeroed when zero_grad != 0.  p_bf16 (nullable) receives the bf16 copy of p.
+ * ---------------------------------------------------------------------------------------- */
+int afm_sumsq(const float* g, int64_t n, float* out, void* stream);
+int afm_adam_step(float* p, float* g, float* m, float* v, int64_t n, const float* hyper,
+                  const float* sumsq, void* p_bf16, int32_t zero_grad, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AFM_HIP_H */

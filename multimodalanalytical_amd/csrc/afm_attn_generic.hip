@@ -1,0 +1,281 @@
+// Exact-fp32 masked attention (any head size), forward and backward, one 64-lane wave per
+// query row (forward, dQ) or per key row (dK/dV).  Scores never reach HBM: a row of them lives
+// in the wave's LDS slice.  This is the numerics yardstick for the MFMA attention kernels and
+// the path for head sizes they do not take (the tiny test/plumbing configs: dh = 16).
+#include "afm_common.h"
+
+struct AttnArgs {
+  int B, H, Tq, Tk, dh;
+  int ldq, ldk, ldv, ldo;
+  int causal;
+  float scale;
+  const uint8_t* key_pad;
+  DropDev dd;
+};
+
+__device__ __forceinline__ bool attn_masked(const AttnArgs& a, int b, int q, int k) {
+  if (a.causal && k > q) return true;
+  if (a.key_pad && a.key_pad[(int64_t)b * a.Tk + k]) return true;
+  return false;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_attn_fwd_generic(AttnArgs a, const T* __restrict__ Q,
+                                                          const T* __restrict__ K,
+                                                          const T* __restrict__ V, T* __restrict__ O,
+                                                          float* __restrict__ lse) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  float* qv = sm + (size_t)w * (a.dh + a.Tk);
+  float* sc = qv + a.dh;
+  const int64_t row = (int64_t)blockIdx.x * 4 + w;  // (b, h, q) flattened
+  const int64_t nrows = (int64_t)a.B * a.H * a.Tq;
+  if (row >= nrows) return;
+  const int q = (int)(row % a.Tq);
+  const int h = (int)((row / a.Tq) % a.H);
+  const int b = (int)(row / ((int64_t)a.Tq * a.H));
+  const T* qp = Q + ((int64_t)b * a.Tq + q) * a.ldq + (int64_t)h * a.dh;
+  for (int j = lane; j < a.dh; j += 64) qv[j] = ld_f32(qp, j);
+  // scores
+  float mx = -INFINITY;
+  for (int k = lane; k < a.Tk; k += 64) {
+    float s = -INFINITY;
+    if (!attn_masked(a, b, q, k)) {
+      const T* kp = K + ((int64_t)b * a.Tk + k) * a.ldk + (int64_t)h * a.dh;
+      float acc = 0.f;
+      for (int j = 0; j < a.dh; ++j) acc = fmaf(qv[j], ld_f32(kp, j), acc);
+      s = acc * a.scale;
+    }
+    sc[k] = s;
+    mx = fmaxf(mx, s);
+  }
+  mx = wave_max(mx);
+  T* op = O + ((int64_t)b * a.Tq + q) * a.ldo + (int64_t)h * a.dh;
+  if (mx == -INFINITY) {  // every key masked: zeros (torch _safe_softmax)
+    for (int j = lane; j < a.dh; j += 64) st_f32(op, j, 0.f);
+    if (lane == 0) lse[row] = INFINITY;
+    return;
+  }
+  float l = 0.f;
+  for (int k = lane; k < a.Tk; k += 64) {
+    const float p = expf(sc[k] - mx);  // exp(-inf) = 0 for masked keys
+    sc[k] = p;
+    l += p;
+  }
+  l = wave_sum(l);
+  if (lane == 0) lse[row] = mx + logf(l);
+  const float inv_l = 1.0f / l;
+  const uint64_t didx = (uint64_t)row * (uint64_t)a.Tk;
+  for (int j = lane; j < a.dh; j += 64) {
+    float acc = 0.f;
+    for (int k = 0; k < a.Tk; ++k) {
+      const float p = afm_drop(a.dd, didx + k, sc[k]);
+      acc = fmaf(p, ld_f32(V + ((int64_t)b * a.Tk + k) * a.ldv + (int64_t)h * a.dh, j), acc);
+    }
+    st_f32(op, j, acc * inv_l);
+  }
+}
+
+// dQ and delta: wave per query row
+template <typename T>
+__global__ __launch_bounds__(256) void k_attn_bwd_q_generic(
+    AttnArgs a, const T* __restrict__ Q, const T* __restrict__ K, const T* __restrict__ V,
+    const T* __restrict__ O, const T* __restrict__ dO, const float* __restrict__ lse,
+    float* __restrict__ delta, T* __restrict__ dQ, int lddq) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  float* qv = sm + (size_t)w * (2 * a.dh + a.Tk);
+  float* dov = qv + a.dh;
+  float* ds = dov + a.dh;
+  const int64_t row = (int64_t)blockIdx.x * 4 + w;
+  const int64_t nrows = (int64_t)a.B * a.H * a.Tq;
+  if (row >= nrows) return;
+  const int q = (int)(row % a.Tq);
+  const int h = (int)((row / a.Tq) % a.H);
+  const int b = (int)(row / ((int64_t)a.Tq * a.H));
+  const T* qp = Q + ((int64_t)b * a.Tq + q) * a.ldq + (int64_t)h * a.dh;
+  const T* op = O + ((int64_t)b * a.Tq + q) * a.ldo + (int64_t)h * a.dh;
+  const T* dop = dO + ((int64_t)b * a.Tq + q) * a.ldo + (int64_t)h * a.dh;
+  float dl = 0.f;
+  for (int j = lane; j < a.dh; j += 64) {
+    qv[j] = ld_f32(qp, j);
+    const float g = ld_f32(dop, j);
+    dov[j] = g;
+    dl += g * ld_f32(op, j);
+  }
+  dl = wave_sum(dl);
+  if (lane == 0) delta[row] = dl;
+  const float L = lse[row];
+  const uint64_t didx = (uint64_t)row * (uint64_t)a.Tk;
+  for (int k = lane; k < a.Tk; k += 64) {
+    float d = 0.f;
+    if (!attn_masked(a, b, q, k) && L != INFINITY) {
+      const T* kp = K + ((int64_t)b * a.Tk + k) * a.ldk + (int64_t)h * a.dh;
+      const T* vp = V + ((int64_t)b * a.Tk + k) * a.ldv + (int64_t)h * a.dh;
+      float s = 0.f, dp = 0.f;
+      for (int j = 0; j < a.dh; ++j) {
+        s = fmaf(qv[j], ld_f32(kp, j), s);
+        dp = fmaf(dov[j], ld_f32(vp, j), dp);
+      }
+      const float p = expf(s * a.scale - L);
+      dp = afm_drop(a.dd, didx + k, dp);
+      d = p * (dp - dl) * a.scale;
+    }
+    ds[k] = d;
+  }
+  T* dqp = dQ + ((int64_t)b * a.Tq + q) * lddq + (int64_t)h * a.dh;
+  for (int j = lane; j < a.dh; j += 64) {
+    float acc = 0.f;
+    for (int k = 0; k < a.Tk; ++k)
+      acc = fmaf(ds[k], ld_f32(K + ((int64_t)b * a.Tk + k) * a.ldk + (int64_t)h * a.dh, j), acc);
+    st_f32(dqp, j, acc);
+  }
+}
+
+// dK and dV: wave per key row
+template <typename T>
+__global__ __launch_bounds__(256) void k_attn_bwd_kv_generic(
+    AttnArgs a, const T* __restrict__ Q, const T* __restrict__ K, const T* __restrict__ V,
+    const T* __restrict__ dO, const float* __restrict__ lse, const float* __restrict__ delta,
+    T* __restrict__ dK, T* __restrict__ dV, int lddk, int lddv) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  float* kv = sm + (size_t)w * (2 * a.dh + 2 * a.Tq);
+  float* vv = kv + a.dh;
+  float* pd = vv + a.dh;   // dropped probabilities (for dV)
+  float* ds = pd + a.Tq;   // score gradients * scale (for dK)
+  const int64_t row = (int64_t)blockIdx.x * 4 + w;  // (b, h, k)
+  const int64_t nrows = (int64_t)a.B * a.H * a.Tk;
+  if (row >= nrows) return;
+  const int k = (int)(row % a.Tk);
+  const int h = (int)((row / a.Tk) % a.H);
+  const int b = (int)(row / ((int64_t)a.Tk * a.H));
+  const T* kp = K + ((int64_t)b * a.Tk + k) * a.ldk + (int64_t)h * a.dh;
+  const T* vp = V + ((int64_t)b * a.Tk + k) * a.ldv + (int64_t)h * a.dh;
+  for (int j = lane; j < a.dh; j += 64) { kv[j] = ld_f32(kp, j); vv[j] = ld_f32(vp, j); }
+  for (int q = lane; q < a.Tq; q += 64) {
+    float pdv = 0.f, dsv = 0.f;
+    const int64_t qrow = ((int64_t)b * a.H + h) * a.Tq + q;
+    const float L = lse[qrow];
+    if (!attn_masked(a, b, q, k) && L != INFINITY) {
+      const T* qp = Q + ((int64_t)b * a.Tq + q) * a.ldq + (int64_t)h * a.dh;
+      const T* dop = dO + ((int64_t)b * a.Tq + q) * a.ldo + (int64_t)h * a.dh;
+      float s = 0.f, dp = 0.f;
+      for (int j = 0; j < a.dh; ++j) {
+        s = fmaf(ld_f32(qp, j), kv[j], s);
+        dp = fmaf(ld_f32(dop, j), vv[j], dp);
+      }
+      const float p = expf(s * a.scale - L);
+      const uint64_t di = (uint64_t)qrow * (uint64_t)a.Tk + (uint64_t)k;
+      pdv = afm_drop(a.dd, di, p);
+      dp = afm_drop(a.dd, di, dp);
+      dsv = p * (dp - delta[qrow]) * a.scale;
+    }
+    pd[q] = pdv;
+    ds[q] = dsv;
+  }
+  T* dkp = dK + ((int64_t)b * a.Tk + k) * lddk + (int64_t)h * a.dh;
+  T* dvp = dV + ((int64_t)b * a.Tk + k) * lddv + (int64_t)h * a.dh;
+  for (int j = lane; j < a.dh; j += 64) {
+    float ak = 0.f, av = 0.f;
+    for (int q = 0; q < a.Tq; ++q) {
+      const int64_t base = ((int64_t)b * a.Tq + q);
+      ak = fmaf(ds[q], ld_f32(Q + base * a.ldq + (int64_t)h * a.dh, j), ak);
+      av = fmaf(pd[q], ld_f32(dO + base * a.ldo + (int64_t)h * a.dh, j), av);
+    }
+    st_f32(dkp, j, ak);
+    st_f32(dvp, j, av);
+  }
+}
+
+static AttnArgs make_args(const afm_attn_shape* s) {
+  AttnArgs a;
+  a.B = s->B; a.H = s->H; a.Tq = s->Tq; a.Tk = s->Tk; a.dh = s->dh;
+  a.ldq = s->ldq; a.ldk = s->ldk; a.ldv = s->ldv; a.ldo = s->ldo;
+  a.causal = s->causal; a.scale = s->scale; a.key_pad = s->key_pad;
+  a.dd = afm_make_drop(&s->drop);
+  return a;
+}
+
+static int check_shape(const afm_attn_shape* s) {
+  if (!s || s->B <= 0 || s->H <= 0 || s->Tq <= 0 || s->Tk <= 0 || s->dh <= 0) return AFM_ERR_ARG;
+  if (s->dtype != AFM_F32 && s->dtype != AFM_BF16) return AFM_ERR_ARG;
+  const int w = s->H * s->dh;
+  if (s->ldq < w || s->ldk < w || s->ldv < w || s->ldo < w) return AFM_ERR_ARG;
+  return AFM_OK;
+}
+
+// defined in afm_attn_mfma.hip
+int afm_attn_fwd_mfma_try(const afm_attn_shape* s, const void* Q, const void* K, const void* V,
+                          void* O, float* lse, hipStream_t st);
+int afm_attn_bwd_mfma_try(const afm_attn_shape* s, const void* Q, const void* K, const void* V,
+                          const void* O, const void* dO, const float* lse, float* delta, void* dQ,
+                          void* dK, void* dV, int lddq, int lddk, int lddv, hipStream_t st);
+
+extern "C" int afm_attn_fwd(const afm_attn_shape* s, const void* Q, const void* K, const void* V,
+                            void* O, float* lse, void* stream) {
+  int r = check_shape(s);
+  if (r != AFM_OK) return r;
+  if (!Q || !K || !V || !O || !lse) return AFM_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  if (s->algo != AFM_ALGO_GENERIC) {
+    r = afm_attn_fwd_mfma_try(s, Q, K, V, O, lse, st);
+    if (r != AFM_ERR_UNSUPPORTED) return r;
+    if (s->algo == AFM_ALGO_MFMA) return r;
+  }
+  const AttnArgs a = make_args(s);
+  const size_t shm = sizeof(float) * 4 * (size_t)(s->dh + s->Tk);
+  if (shm > 160 * 1024) return AFM_ERR_UNSUPPORTED;
+  const int64_t nrows = (int64_t)s->B * s->H * s->Tq;
+  const dim3 grid((unsigned)((nrows + 3) / 4));
+  if (s->dtype == AFM_F32) {
+    if (shm > 64 * 1024) hipFuncSetAttribute((const void*)k_attn_fwd_generic<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+    hipLaunchKernelGGL(k_attn_fwd_generic<float>, grid, dim3(256), shm, st, a, (const float*)Q,
+                       (const float*)K, (const float*)V, (float*)O, lse);
+  } else {
+    if (shm > 64 * 1024) hipFuncSetAttribute((const void*)k_attn_fwd_generic<bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+    hipLaunchKernelGGL(k_attn_fwd_generic<bf16>, grid, dim3(256), shm, st, a, (const bf16*)Q,
+                       (const bf16*)K, (const bf16*)V, (bf16*)O, lse);
+  }
+  AFM_CHECK_LAUNCH();
+  afm_set_last_algo("attn_generic");
+  return AFM_OK;
+}
+
+extern "C" int afm_attn_bwd(const afm_attn_shape* s, const void* Q, const void* K, const void* V,
+                            const void* O, const void* dO, const float* lse, float* delta, void* dQ,
+                            void* dK, void* dV, int32_t lddq, int32_t lddk, int32_t lddv,
+                            void* stream) {
+  int r = check_shape(s);
+  if (r != AFM_OK) return r;
+  if (!Q || !K || !V || !O || !dO || !lse || !delta || !dQ || !dK || !dV) return AFM_ERR_ARG;
+  const int w = s->H * s->dh;
+  if (lddq < w || lddk < w || lddv < w) return AFM_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  if (s->algo != AFM_ALGO_GENERIC) {
+    r = afm_attn_bwd_mfma_try(s, Q, K, V, O, dO, lse, delta, dQ, dK, dV, lddq, lddk, lddv, st);
+    if (r != AFM_ERR_UNSUPPORTED) return r;
+    if (s->algo == AFM_ALGO_MFMA) return r;
+  }
+  const AttnArgs a = make_args(s);
+  const size_t shm_q = sizeof(float) * 4 * (size_t)(2 * s->dh + s->Tk);
+  const size_t shm_k = sizeof(float) * 4 * (size_t)(2 * s->dh + 2 * s->Tq);
+  if (shm_q > 160 * 1024 || shm_k > 160 * 1024) return AFM_ERR_UNSUPPORTED;
+  const dim3 gq((unsigned)(((int64_t)s->B * s->H * s->Tq + 3) / 4));
+  const dim3 gk((unsigned)(((int64_t)s->B * s->H * s->Tk + 3) / 4));
+#define LAUNCH_BWD(T)                                                                                 \
+  do {                                                                                                \
+    if (shm_q > 64 * 1024) hipFuncSetAttribute((const void*)k_attn_bwd_q_generic<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm_q); \
+    if (shm_k > 64 * 1024) hipFuncSetAttribute((const void*)k_attn_bwd_kv_generic<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm_k); \
+    hipLaunchKernelGGL(k_attn_bwd_q_generic<T>, gq, dim3(256), shm_q, st, a, (const T*)Q, (const T*)K, \
+                       (const T*)V, (const T*)O, (const T*)dO, lse, delta, (T*)dQ, lddq);              \
+    AFM_CHECK_LAUNCH();                                                                               \
+    hipLaunchKernelGGL(k_attn_bwd_kv_generic<T>, gk, dim3(256), shm_k, st, a, (const T*)Q, (const T*)K, \
+                       (const T*)V, (const T*)dO, lse, delta, (T*)dK, (T*)dV, lddk, lddv);             \
+    AFM_CHECK_LAUNCH();                                                                               \
+  } while (0)
+  if (s->dtype == AFM_F32) LAUNCH_BWD(float); else LAUNCH_BWD(bf16);
+#undef LAUNCH_BWD
+  afm_set_last_algo("attn_generic");
+  return AFM_OK;
+}

@@ -1,0 +1,87 @@
+// Shared device/host helpers for libafm_hip.so (gfx950 only; wave = 64).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "afm_hip.h"
+
+typedef __bf16 bf16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+#define AFM_WAVE 64
+
+#define AFM_CHECK_LAUNCH()                                   \
+  do {                                                       \
+    if (hipGetLastError() != hipSuccess) return AFM_ERR_LAUNCH; \
+  } while (0)
+
+// thread-local name of the kernel family last dispatched (afm_last_algo)
+extern "C" void afm_set_last_algo(const char* name);
+
+// ---------------------------------------------------------------- dtype access
+template <typename T> __device__ __forceinline__ float ld_f32(const T* p, int64_t i);
+template <> __device__ __forceinline__ float ld_f32<float>(const float* p, int64_t i) { return p[i]; }
+template <> __device__ __forceinline__ float ld_f32<bf16>(const bf16* p, int64_t i) { return (float)p[i]; }
+template <typename T> __device__ __forceinline__ void st_f32(T* p, int64_t i, float v);
+template <> __device__ __forceinline__ void st_f32<float>(float* p, int64_t i, float v) { p[i] = v; }
+template <> __device__ __forceinline__ void st_f32<bf16>(bf16* p, int64_t i, float v) { p[i] = (bf16)v; }
+
+// ---------------------------------------------------------------- dropout stream
+// keep(i) = lowbias32(lo(i) ^ key ^ hi(i)*phi) >= thresh ; documented in DESIGN.md and
+// re-implemented in tests (numpy) so parity tests run WITH dropout against the oracle.
+struct DropDev {
+  uint32_t key;
+  uint32_t thresh;  // 0 => keep everything
+  float scale;      // 1/(1-p)
+  float pad;
+};
+__host__ __device__ __forceinline__ uint32_t afm_lowbias32(uint32_t x) {
+  x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+  return x;
+}
+static inline DropDev afm_make_drop(const afm_dropout* d) {
+  DropDev r; r.pad = 0.f;
+  if (!d || d->p <= 0.f) { r.key = 0; r.thresh = 0; r.scale = 1.f; return r; }
+  double t = (double)d->p * 4294967296.0;
+  r.thresh = t >= 4294967295.0 ? 4294967295u : (uint32_t)t;
+  r.scale = 1.0f / (1.0f - d->p);
+  uint32_t k = afm_lowbias32((uint32_t)d->seed ^ 0x9E3779B9u);
+  k = afm_lowbias32(k ^ (uint32_t)(d->seed >> 32));
+  k = afm_lowbias32(k ^ (d->site * 0x85EBCA6Bu + 0x1234567u));
+  r.key = k;
+  return r;
+}
+__device__ __forceinline__ bool afm_keep(const DropDev& d, uint64_t idx) {
+  uint32_t h = afm_lowbias32((uint32_t)idx ^ d.key ^ ((uint32_t)(idx >> 32) * 0x9E3779B1u));
+  return h >= d.thresh;
+}
+__device__ __forceinline__ float afm_drop(const DropDev& d, uint64_t idx, float x) {
+  if (d.thresh == 0) return x;
+  return afm_keep(d, idx) ? x * d.scale : 0.f;
+}
+
+// ---------------------------------------------------------------- math
+__device__ __forceinline__ float afm_gelu(float x) {
+  return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+}
+__device__ __forceinline__ float afm_gelu_grad(float x) {
+  // d/dx [x Phi(x)] = Phi(x) + x phi(x)
+  const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+  const float pdf = 0.39894228040143267794f * expf(-0.5f * x * x);
+  return cdf + x * pdf;
+}
+
+// ---------------------------------------------------------------- reductions (wave = 64)
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}

@@ -1,0 +1,290 @@
+// HBM-bound elementwise / gather / reduction kernels of the spectra->SMILES path (gfx950).
+// Each kernel moves every byte once; rows are walked with 64-lane waves on contiguous data.
+#include "afm_common.h"
+
+static thread_local const char* g_last_algo = "none";
+extern "C" void afm_set_last_algo(const char* name) { g_last_algo = name; }
+extern "C" const char* afm_last_algo(void) { return g_last_algo; }
+extern "C" int afm_abi_version(void) { return AFM_ABI_VERSION; }
+extern "C" const char* afm_error_string(int code) {
+  switch (code) {
+    case AFM_OK: return "ok";
+    case AFM_ERR_ARG: return "invalid argument";
+    case AFM_ERR_UNSUPPORTED: return "unsupported shape/dtype for the requested algorithm";
+    case AFM_ERR_LAUNCH: return "kernel launch failed";
+    default: return "unknown error";
+  }
+}
+
+static inline int grid_for(int64_t work, int block, int cap = 256 * 8) {
+  int64_t g = (work + block - 1) / block;
+  if (g < 1) g = 1;
+  return (int)(g > cap ? cap : g);
+}
+
+// ---------------------------------------------------------------- embedding rows
+__global__ void k_gather_rows(const int64_t* __restrict__ ids, const float* __restrict__ scale,
+                              const float* __restrict__ table, float* __restrict__ out, int64_t n,
+                              int d, int V) {
+  // one wave per row, lanes stride the row
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t r = wave; r < n; r += nwaves) {
+    int64_t id = ids[r];
+    id = id < 0 ? 0 : (id >= V ? V - 1 : id);
+    const float s = scale ? scale[r] : 1.0f;
+    const float* src = table + id * (int64_t)d;
+    float* dst = out + r * (int64_t)d;
+    for (int j = lane; j < d; j += 64) dst[j] = src[j] * s;
+  }
+}
+extern "C" int afm_gather_rows(const int64_t* ids, const float* scale, const float* table, float* out,
+                               int64_t n, int32_t d, int32_t V, void* stream) {
+  if (!ids || !table || !out || n < 0 || d <= 0 || V <= 0) return AFM_ERR_ARG;
+  if (n == 0) return AFM_OK;
+  hipLaunchKernelGGL(k_gather_rows, dim3(grid_for(n * 64, 256)), dim3(256), 0, (hipStream_t)stream,
+                     ids, scale, table, out, n, d, V);
+  AFM_CHECK_LAUNCH();
+  return AFM_OK;
+}
+
+__global__ void k_scatter_add_rows(const int64_t* __restrict__ ids, const float* __restrict__ scale,
+                                   const float* __restrict__ dout, float* __restrict__ dtable,
+                                   int64_t n, int d, int V, int64_t pad) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t r = wave; r < n; r += nwaves) {
+    int64_t id = ids[r];
+    if (id == pad) continue;
+    id = id < 0 ? 0 : (id >= V ? V - 1 : id);
+    const float s = scale ? scale[r] : 1.0f;
+    const float* src = dout + r * (int64_t)d;
+    float* dst = dtable + id * (int64_t)d;
+    for (int j = lane; j < d; j += 64) atomicAdd(dst + j, src[j] * s);
+  }
+}
+extern "C" int afm_scatter_add_rows(const int64_t* ids, const float* scale, const float* dout,
+                                    float* dtable, int64_t n, int32_t d, int32_t V,
+                                    int64_t padding_idx, void* stream) {
+  if (!ids || !dout || !dtable || n < 0 || d <= 0 || V <= 0) return AFM_ERR_ARG;
+  if (n == 0) return AFM_OK;
+  hipLaunchKernelGGL(k_scatter_add_rows, dim3(grid_for(n * 64, 256)), dim3(256), 0,
+                     (hipStream_t)stream, ids, scale, dout, dtable, n, d, V, padding_idx);
+  AFM_CHECK_LAUNCH();
+  return AFM_OK;
+}
+
+// ---------------------------------------------------------------- GLU / GELU
+template <typename T>
+__global__ void k_glu_fwd(const T* __restrict__ u, const T* __restrict__ v, T* __restrict__ g,
+                          int64_t rows, int f, int ldu, int ldv, int ldg, DropDev dd) {
+  const int64_t total = rows * (int64_t)f;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / f;
+    const int c = (int)(i - r * f);
+    float x = afm_gelu(ld_f32(u, r * ldu + c));
+    if (v) x *= ld_f32(v, r * ldv + c);
+    st_f32(g, r * ldg + c, afm_drop(dd, (uint64_t)i, x));
+  }
+}
+extern "C" int afm_glu_fwd(const void* u, const void* v, void* g, int64_t rows, int32_t f,
+                           int32_t ldu, int32_t ldv, int32_t ldg, int32_t dtype,
+                           const afm_dropout* drop, void* stream) {
+  if (!u || !g || rows < 0 || f <= 0) return AFM_ERR_ARG;
+  if (rows == 0) return AFM_OK;
+  const DropDev dd = afm_make_drop(drop);
+  const int grid = grid_for(rows * f, 256);
+  if (dtype == AFM_F32)
+    hipLaunchKernelGGL(k_glu_fwd<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream,
+                       (const float*)u, (const float*)v, (float*)g, rows, f, ldu, ldv, ldg, dd);
+  else if (dtype == AFM_BF16)
+    hipLaunchKernelGGL(k_glu_fwd<bf16>, dim3(grid), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16*)u, (const bf16*)v, (bf16*)g, rows, f, ldu, ldv, ldg, dd);
+  else
+    return AFM_ERR_ARG;
+  AFM_CHECK_LAUNCH();
+  return AFM_OK;
+}
+
+template <typename T>
+__global__ void k_glu_bwd(const T* __restrict__ u, const T* __restrict__ v, const T* __restrict__ dg,
+                          T* __restrict__ du, T* __restrict__ dv, int64_t rows, int f, int ldu,
+                          int ldv, int lddg, int lddu, int lddv, DropDev dd) {
+  const int64_t total = rows * (int64_t)f;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / f;
+    const int c = (int)(i - r * f);
+    const float g = afm_drop(dd, (uint64_t)i, ld_f32(dg, r * lddg + c));
+    const float uu = ld_f32(u, r * ldu + c);
+    float gu = g * afm_gelu_grad(uu);
+    if (v) {
+      gu *= ld_f32(v, r * ldv + c);
+      st_f32(dv, r * lddv + c, g * afm_gelu(uu));
+    }
+    st_f32(du, r * lddu + c, gu);
+  }
+}
+extern "C" int afm_glu_bwd(const void* u, const void* v, const void* dg, void* du, void* dv,
+                           int64_t rows, int32_t f, int32_t ldu, int32_t ldv, int32_t lddg,
+                           int32_t lddu, int32_t lddv, int32_t dtype, const afm_dropout* drop,
+                           void* stream) {
+  if (!u || !dg || !du || rows < 0 || f <= 0 || (v && !dv)) return AFM_ERR_ARG;
+  if (rows == 0) return AFM_OK;
+  const DropDev dd = afm_make_drop(drop);
+  const int grid = grid_for(rows * f, 256);
+  if (dtype == AFM_F32)
+    hipLaunchKernelGGL(k_glu_bwd<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream,
+                       (const float*)u, (const float*)v, (const float*)dg, (float*)du, (float*)dv,
+                       rows, f, ldu, ldv, lddg, lddu, lddv, dd);
+  else if (dtype == AFM_BF16)
+    hipLaunchKernelGGL(k_glu_bwd<bf16>, dim3(grid), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16*)u, (const bf16*)v, (const bf16*)dg, (bf16*)du, (bf16*)dv, rows,
+                       f, ldu, ldv, lddg, lddu, lddv, dd);
+  else
+    return AFM_ERR_ARG;
+  AFM_CHECK_LAUNCH();
+  return AFM_OK;
+}
+
+// ---------------------------------------------------------------- dropout + cast
+template <typename T>
+__global__ void k_dropout_cast(const float* __restrict__ x, T* __restrict__ y, int64_t rows, int n,
+                               int ldx, int ldy, DropDev dd) {
+  const int64_t total = rows * (int64_t)n;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / n;
+    const int c = (int)(i - r * n);
+    st_f32(y, r * ldy + c, afm_drop(dd, (uint64_t)i, x[r * ldx + c]));
+  }
+}
+extern "C" int afm_dropout_cast(const float* x, void* y, int64_t rows, int32_t n, int32_t ldx,
+                                int32_t ldy, int32_t y_dtype, const afm_dropout* drop,
+                                void* stream) {
+  if (!x || !y || rows < 0 || n <= 0) return AFM_ERR_ARG;
+  if (rows == 0) return AFM_OK;
+  const DropDev dd = afm_make_drop(drop);
+  const int grid = grid_for(rows * n, 256);
+  if (y_dtype == AFM_F32)
+    hipLaunchKernelGGL(k_dropout_cast<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, x,
+                       (float*)y, rows, n, ldx, ldy, dd);
+  else if (y_dtype == AFM_BF16)
+    hipLaunchKernelGGL(k_dropout_cast<bf16>, dim3(grid), dim3(256), 0, (hipStream_t)stream, x,
+                       (bf16*)y, rows, n, ldx, ldy, dd);
+  else
+    return AFM_ERR_ARG;
+  AFM_CHECK_LAUNCH();
+  return AFM_OK;
+}
+
+// ---------------------------------------------------------------- column sums (bias gradients)
+// grid.x tiles the columns (64 per block), grid.y splits the rows; each block reduces its row
+// range for 64 columns (4 waves x 64 lanes: lane = column, wave = row phase), then one atomic
+// per column.  Lanes of a wave read 64 consecutive elements of a row: coalesced.
+template <typename T>
+__global__ void k_colsum(const T* __restrict__ x, float* __restrict__ out, int64_t rows, int n,
+                         int ld) {
+  __shared__ float part[4][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + lane;
+  const int64_t chunk = (rows + gridDim.y - 1) / gridDim.y;
+  const int64_t r0 = (int64_t)blockIdx.y * chunk;
+  const int64_t r1 = r0 + chunk < rows ? r0 + chunk : rows;
+  float acc = 0.f;
+  if (c < n)
+    for (int64_t r = r0 + w; r < r1; r += 4) acc += ld_f32(x, r * ld + c);
+  part[w][lane] = acc;
+  __syncthreads();
+  if (w == 0 && c < n) atomicAdd(out + c, part[0][lane] + part[1][lane] + part[2][lane] + part[3][lane]);
+}
+extern "C" int afm_colsum(const void* x, float* out, int64_t rows, int32_t n, int32_t ld,
+                          int32_t dtype, int32_t accumulate, void* stream) {
+  if (!x || !out || rows < 0 || n <= 0) return AFM_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  if (!accumulate)
+    if (hipMemsetAsync(out, 0, sizeof(float) * n, st) != hipSuccess) return AFM_ERR_LAUNCH;
+  if (rows == 0) return AFM_OK;
+  const int gx = (n + 63) / 64;
+  int gy = (int)((rows + 255) / 256);
+  const int cap = (2048 + gx - 1) / gx;
+  if (gy > cap) gy = cap;
+  if (gy < 1) gy = 1;
+  if (dtype == AFM_F32)
+    hipLaunchKernelGGL(k_colsum<float>, dim3(gx, gy), dim3(256), 0, st, (const float*)x, out, rows, n, ld);
+  else if (dtype == AFM_BF16)
+    hipLaunchKernelGGL(k_colsum<bf16>, dim3(gx, gy), dim3(256), 0, st, (const bf16*)x, out, rows, n, ld);
+  else
+    return AFM_ERR_ARG;
+  AFM_CHECK_LAUNCH();
+  return AFM_OK;
+}
+
+__global__ void k_add_inplace(float* __restrict__ y, const float* __restrict__ x, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x)
+    y[i] += x[i];
+}
+extern "C" int afm_add_inplace(float* y, const float* x, int64_t n, void* stream) {
+  if (!y || !x || n < 0) return AFM_ERR_ARG;
+  if (n == 0) return AFM_OK;
+  hipLaunchKernelGGL(k_add_inplace, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, y, x, n);
+  AFM_CHECK_LAUNCH();
+  return AFM_OK;
+}
+
+__global__ void k_batch_sum(const float* __restrict__ x, float* __restrict__ out, int B, int64_t S,
+                            int d, int accumulate) {
+  const int64_t total = S * d;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    float acc = accumulate ? out[i] : 0.f;
+    for (int b = 0; b < B; ++b) acc += x[(int64_t)b * total + i];
+    out[i] = acc;
+  }
+}
+extern "C" int afm_batch_sum(const float* x, float* out, int32_t B, int64_t S, int32_t d,
+                             int32_t accumulate, void* stream) {
+  if (!x || !out || B <= 0 || S < 0 || d <= 0) return AFM_ERR_ARG;
+  if (S == 0) return AFM_OK;
+  hipLaunchKernelGGL(k_batch_sum, dim3(grid_for(S * d, 256)), dim3(256), 0, (hipStream_t)stream, x,
+                     out, B, S, d, accumulate);
+  AFM_CHECK_LAUNCH();
+  return AFM_OK;
+}
+
+// ---------------------------------------------------------------- fp32 -> bf16 (+ transpose)
+// 64x64 tiles through LDS so both the row-major copy and the transposed copy are written with
+// consecutive lanes on consecutive addresses.
+__global__ void k_cast_bf16(const float* __restrict__ src, bf16* __restrict__ dst,
+                            bf16* __restrict__ dst_t, int rows, int cols) {
+  __shared__ float tile[64][65];
+  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;  // 4 row phases
+  for (int i = ty; i < 64; i += 4) {
+    const int r = r0 + i, c = c0 + tx;
+    float v = 0.f;
+    if (r < rows && c < cols) {
+      v = src[(int64_t)r * cols + c];
+      if (dst) dst[(int64_t)r * cols + c] = (bf16)v;
+    }
+    tile[i][tx] = v;
+  }
+  if (!dst_t) return;
+  __syncthreads();
+  for (int i = ty; i < 64; i += 4) {
+    const int c = c0 + i, r = r0 + tx;  // transposed: row index of dst_t is the column
+    if (r < rows && c < cols) dst_t[(int64_t)c * rows + r] = (bf16)tile[tx][i];
+  }
+}
+extern "C" int afm_cast_bf16(const float* src, void* dst, void* dst_t, int32_t rows, int32_t cols,
+                             void* stream) {
+  if (!src || (!dst && !dst_t) || rows <= 0 || cols <= 0) return AFM_ERR_ARG;
+  hipLaunchKernelGGL(k_cast_bf16, dim3((cols + 63) / 64, (rows + 63) / 64), dim3(256), 0,
+                     (hipStream_t)stream, src, (bf16*)dst, (bf16*)dst_t, rows, cols);
+  AFM_CHECK_LAUNCH();
+  return AFM_OK;
+}

@@ -1,0 +1,161 @@
+// Exact-fp32 GEMM (FMA path) with the full afm_gemm epilogue, any transpose / stride / dtype.
+// This is the numerics yardstick of the library (fp32 products, fp32 accumulation in k order)
+// and the path for shapes the MFMA kernels do not take (odd K, tiny N such as the SMILES
+// vocabulary, patch sizes 75/125).  64x64 tile, 16-deep k-steps through LDS, 4x4 per thread.
+#include "afm_common.h"
+
+struct GemmArgs {
+  int M, N, K;
+  int64_t sam, sak;  // element strides of op(A)[m][k]
+  int64_t sbk, sbn;  // element strides of op(B)[k][n]
+  int ldc;
+  int a_bf16, b_bf16, c_bf16;
+  const void* A;
+  const void* B;
+  void* C;
+  const float* bias;
+  const void* residual;
+  void* pre_act;
+  int act, accumulate;
+  int splits, kchunk;
+  DropDev dd;
+};
+
+__device__ __forceinline__ float ld_any(const void* p, int is_bf16, int64_t i) {
+  return is_bf16 ? (float)((const bf16*)p)[i] : ((const float*)p)[i];
+}
+__device__ __forceinline__ void st_any(void* p, int is_bf16, int64_t i, float v) {
+  if (is_bf16) ((bf16*)p)[i] = (bf16)v; else ((float*)p)[i] = v;
+}
+
+#define GT 64
+#define GK 16
+
+__global__ __launch_bounds__(256) void k_gemm_generic(GemmArgs g) {
+  __shared__ float As[GK][GT + 4];
+  __shared__ float Bs[GK][GT + 4];
+  const int t = threadIdx.x;
+  const int tx = t & 15, ty = t >> 4;
+  const int m0 = blockIdx.y * GT, n0 = blockIdx.x * GT;
+  const int kbeg = blockIdx.z * g.kchunk;
+  const int kend = min(g.K, kbeg + g.kchunk);
+  float acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
+
+  const bool a_kfast = g.sak == 1;  // k contiguous in memory
+  const bool b_kfast = g.sbk == 1;
+  for (int k0 = kbeg; k0 < kend; k0 += GK) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      int m, k;
+      if (a_kfast) { k = t & 15; m = (t >> 4) + 16 * i; } else { m = t & 63; k = (t >> 6) + 4 * i; }
+      const int gm = m0 + m, gk = k0 + k;
+      As[k][m] = (gm < g.M && gk < kend) ? ld_any(g.A, g.a_bf16, gm * g.sam + gk * g.sak) : 0.f;
+      int n, kb;
+      if (b_kfast) { kb = t & 15; n = (t >> 4) + 16 * i; } else { n = t & 63; kb = (t >> 6) + 4 * i; }
+      const int gn = n0 + n, gkb = k0 + kb;
+      Bs[kb][n] = (gn < g.N && gkb < kend) ? ld_any(g.B, g.b_bf16, gkb * g.sbk + gn * g.sbn) : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < GK; ++k) {
+      const f32x4 a = *(const f32x4*)&As[k][ty * 4];
+      const f32x4 b = *(const f32x4*)&Bs[k][tx * 4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(a[i], b[j], acc[i][j]);
+    }
+    __syncthreads();
+  }
+
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int m = m0 + ty * 4 + i;
+    if (m >= g.M) continue;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = n0 + tx * 4 + j;
+      if (n >= g.N) continue;
+      const int64_t ci = (int64_t)m * g.ldc + n;
+      float v = acc[i][j];
+      if (g.splits > 1) {  // split-K: fp32 atomics into a C the launcher prepared
+        if (blockIdx.z == 0) {
+          if (g.bias) v += g.bias[n];
+          if (g.residual) v += ((const float*)g.residual)[ci];
+        }
+        atomicAdd((float*)g.C + ci, v);
+        continue;
+      }
+      if (g.bias) v += g.bias[n];
+      if (g.pre_act) st_any(g.pre_act, g.c_bf16, ci, v);
+      if (g.act == AFM_ACT_RELU) v = fmaxf(v, 0.f);
+      else if (g.act == AFM_ACT_GELU) v = afm_gelu(v);
+      v = afm_drop(g.dd, (uint64_t)m * (uint64_t)g.N + (uint64_t)n, v);
+      if (g.residual) v += ld_any(g.residual, g.c_bf16, ci);
+      if (g.accumulate) v += ld_any(g.C, g.c_bf16, ci);
+      st_any(g.C, g.c_bf16, ci, v);
+    }
+  }
+}
+
+// defined in afm_gemm_mfma.hip; returns AFM_ERR_UNSUPPORTED when the shape is not eligible
+int afm_gemm_mfma_try(const afm_gemm_desc* d, hipStream_t st);
+
+static int gemm_generic(const afm_gemm_desc* d, hipStream_t st) {
+  GemmArgs g;
+  g.M = d->M; g.N = d->N; g.K = d->K;
+  g.sam = d->transA ? 1 : d->lda; g.sak = d->transA ? d->lda : 1;
+  g.sbk = d->transB ? 1 : d->ldb; g.sbn = d->transB ? d->ldb : 1;
+  g.ldc = d->ldc;
+  g.a_bf16 = d->a_dtype == AFM_BF16; g.b_bf16 = d->b_dtype == AFM_BF16; g.c_bf16 = d->c_dtype == AFM_BF16;
+  g.A = d->A; g.B = d->B; g.C = d->C; g.bias = d->bias; g.residual = d->residual; g.pre_act = d->pre_act;
+  g.act = d->act; g.accumulate = d->accumulate;
+  g.dd = afm_make_drop(&d->drop);
+  const int gx = (d->N + GT - 1) / GT, gy = (d->M + GT - 1) / GT;
+  int splits = 1;
+  const bool can_split = d->c_dtype == AFM_F32 && d->act == AFM_ACT_NONE && !d->pre_act && d->drop.p <= 0.f;
+  if (can_split && (int64_t)gx * gy < 256 && d->K >= 2048) {
+    splits = (int)((512 + (int64_t)gx * gy - 1) / ((int64_t)gx * gy));
+    const int maxs = d->K / 512;
+    if (splits > maxs) splits = maxs;
+    if (splits < 1) splits = 1;
+  }
+  int kchunk = (d->K + splits - 1) / splits;
+  kchunk = (kchunk + GK - 1) / GK * GK;
+  splits = (d->K + kchunk - 1) / kchunk;
+  g.splits = splits; g.kchunk = kchunk;
+  if (splits > 1 && !d->accumulate) {
+    // rows of C may be strided: clear row by row only if needed
+    if (d->ldc == d->N) {
+      if (hipMemsetAsync(d->C, 0, sizeof(float) * (size_t)d->M * d->N, st) != hipSuccess) return AFM_ERR_LAUNCH;
+    } else {
+      if (hipMemset2DAsync(d->C, sizeof(float) * d->ldc, 0, sizeof(float) * d->N, d->M, st) != hipSuccess)
+        return AFM_ERR_LAUNCH;
+    }
+  }
+  hipLaunchKernelGGL(k_gemm_generic, dim3(gx, gy, splits), dim3(256), 0, st, g);
+  AFM_CHECK_LAUNCH();
+  afm_set_last_algo(splits > 1 ? "generic_splitk" : "generic");
+  return AFM_OK;
+}
+
+extern "C" int afm_gemm(const afm_gemm_desc* d, void* stream) {
+  if (!d || !d->A || !d->B || !d->C) return AFM_ERR_ARG;
+  if (d->M < 0 || d->N < 0 || d->K < 0) return AFM_ERR_ARG;
+  if ((d->a_dtype | d->b_dtype | d->c_dtype) & ~1) return AFM_ERR_ARG;
+  if (d->act < AFM_ACT_NONE || d->act > AFM_ACT_GELU) return AFM_ERR_ARG;
+  if (d->ldc < d->N) return AFM_ERR_ARG;
+  if (d->lda < (d->transA ? d->M : d->K) || d->ldb < (d->transB ? d->K : d->N)) return AFM_ERR_ARG;
+  if (d->M == 0 || d->N == 0) return AFM_OK;
+  hipStream_t st = (hipStream_t)stream;
+  if (d->algo != AFM_ALGO_GENERIC) {
+    const int r = afm_gemm_mfma_try(d, st);
+    if (r != AFM_ERR_UNSUPPORTED) return r;
+    if (d->algo == AFM_ALGO_MFMA) return AFM_ERR_UNSUPPORTED;
+  }
+  return gemm_generic(d, st);
+}

@@ -1,0 +1,79 @@
+// Gradient-norm clip + Adam/AdamW over the model's single flat fp32 parameter buffer.
+// HBM-bound: sumsq reads g once (4 B/param); the step reads p,g,m,v and writes p,m,v (+g zero,
+// + bf16 shadow) = 28-34 B/param, 16 B per lane per access.
+#include "afm_common.h"
+
+__global__ __launch_bounds__(256) void k_sumsq(const float* __restrict__ g, int64_t n,
+                                               float* __restrict__ out) {
+  __shared__ float part[4];
+  float acc = 0.f;
+  const int64_t n4 = n >> 2;
+  const f32x4* g4 = (const f32x4*)g;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const f32x4 v = g4[i];
+    acc += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+    const float v = g[(n4 << 2) + threadIdx.x];
+    acc += v * v;
+  }
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(out, part[0] + part[1] + part[2] + part[3]);
+}
+
+extern "C" int afm_sumsq(const float* g, int64_t n, float* out, void* stream) {
+  if (!g || !out || n < 0 || ((uintptr_t)g & 15)) return AFM_ERR_ARG;
+  if (n == 0) return AFM_OK;
+  int64_t blocks = (n / 4 + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(k_sumsq, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, g, n, out);
+  AFM_CHECK_LAUNCH();
+  return AFM_OK;
+}
+
+__global__ __launch_bounds__(256) void k_adam(float* __restrict__ p, float* __restrict__ g,
+                                              float* __restrict__ m, float* __restrict__ v, int64_t n,
+                                              const float* __restrict__ hyper,
+                                              const float* __restrict__ sumsq,
+                                              bf16* __restrict__ p_bf16, int zero_grad) {
+  const float lr = hyper[0], b1 = hyper[1], b2 = hyper[2], eps = hyper[3], wd = hyper[4];
+  const float bc1 = hyper[5], bc2 = hyper[6], max_norm = hyper[7], gmult = hyper[8];
+  const bool decoupled = hyper[9] != 0.f;
+  float coef = gmult;
+  if (max_norm > 0.f && sumsq) {
+    const float c = max_norm / (sqrtf(sumsq[0]) * gmult + 1e-6f);
+    coef *= fminf(c, 1.0f);
+  }
+  const float step = lr / bc1;
+  const float inv_sqrt_bc2 = rsqrtf(bc2);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    float pi = p[i];
+    float gi = g[i] * coef;
+    if (wd != 0.f) {
+      if (decoupled) pi *= 1.0f - lr * wd; else gi += wd * pi;
+    }
+    const float mi = b1 * m[i] + (1.0f - b1) * gi;
+    const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
+    pi -= step * mi / (sqrtf(vi) * inv_sqrt_bc2 + eps);
+    p[i] = pi; m[i] = mi; v[i] = vi;
+    if (zero_grad) g[i] = 0.f;
+    if (p_bf16) p_bf16[i] = (bf16)pi;
+  }
+}
+
+extern "C" int afm_adam_step(float* p, float* g, float* m, float* v, int64_t n, const float* hyper,
+                             const float* sumsq, void* p_bf16, int32_t zero_grad, void* stream) {
+  if (!p || !g || !m || !v || !hyper || n < 0) return AFM_ERR_ARG;
+  if (n == 0) return AFM_OK;
+  int64_t blocks = (n + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(k_adam, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, hyper,
+                     sumsq, (bf16*)p_bf16, zero_grad);
+  AFM_CHECK_LAUNCH();
+  return AFM_OK;
+}

@@ -1,0 +1,510 @@
+"""Hand-scheduled forward / backward of the spectra->SMILES encoder-decoder on libafm_hip.so.
+
+This is the MI355X-native counterpart of `CustomModel.forward` + autograd
+(reference custom_modeling.py:420-508, modeling/utils.py:142-182): the layer schedule is
+written out explicitly (no autograd graph, no torch.nn), every arithmetic step is one call
+into the C ABI (ops.py), activations needed by backward stay resident in HBM (288 GB: nothing
+is recomputed except dropout masks and attention probabilities), the residual stream, LayerNorm
+statistics, logits, loss and all parameter gradients are fp32, GEMM / attention operands are
+`compute_dtype` (bf16 for speed, fp32 for the exact-parity mode).
+
+Row conventions: encoder rows R = B*S, decoder rows Rt = B*T, all tensors batch-first 2-D
+(rows, features) views so a (b, t) token is row b*T + t.
+"""
+from __future__ import annotations
+
+from typing import Any, Dict, List, Optional
+
+import torch
+
+from . import ops
+from .lib import ACT_NONE, ACT_RELU, ALGO_AUTO
+from .params import PATCH_TYPES, TEXT_TYPES, ParamStore, build_specs, patch_layers
+
+
+def sincos_table(d_model: int, max_len: int) -> torch.Tensor:
+    """SincCosPositionalEncoding._positional_encs (modeling/utils.py:226-239): interleaved
+    sin/cos, float32 arithmetic in the reference's order of operations (setup-time, host)."""
+    frac = (torch.arange(0, d_model, 2, dtype=torch.float64) / d_model).float()
+    div = 10000 ** frac
+    pos = torch.arange(max_len, dtype=torch.float32).unsqueeze(1)
+    ang = pos * div.reciprocal()
+    return torch.stack((torch.sin(ang), torch.cos(ang)), dim=2).flatten(1)[:, :d_model].contiguous()
+
+
+class Seq2SeqEngine:
+    """Parameters + explicit fwd/bwd schedule.  `cfg` holds the CustomConfig fields
+    (custom_modeling.py:43-65) as a plain dict."""
+
+    def __init__(self, cfg: Dict[str, Any], data_config: Dict[str, Any], target_modality: str,
+                 vocab_out: int, device="cuda:0", compute_dtype=torch.bfloat16, seed: int = 3247,
+                 algo: int = ALGO_AUTO):
+        self.cfg = dict(cfg)
+        self.cfg.setdefault("multimodal_norm", True)
+        self.cfg.setdefault("gated_linear", False)
+        self.cfg.setdefault("positional_encoding_type", "sin_cos")
+        self.cfg.setdefault("max_position_embeddings", 1024)
+        self.cfg.setdefault("dropout", 0.1)
+        self.dc = data_config
+        self.tm = target_modality
+        self.V = int(vocab_out)
+        self.dev = torch.device(device)
+        self.cd = compute_dtype
+        self.algo = algo
+        self.d = int(cfg["d_model"])
+        self.gated = bool(self.cfg["gated_linear"])
+        self.norm = bool(self.cfg["multimodal_norm"])
+        if not self.norm:
+            raise NotImplementedError("multimodal_norm=False is not on the reference's tested path")
+        self.ps = ParamStore(build_specs(self.cfg, data_config, self.V), self.dev,
+                             with_bf16=compute_dtype == torch.bfloat16)
+        self.ps.init_(seed)
+        if self.cfg["positional_encoding_type"] == "sin_cos":
+            self.pos_enc = sincos_table(self.d, self.cfg["max_position_embeddings"]).to(self.dev)
+        else:
+            self.pos_enc = None
+        self.wt: Dict[str, torch.Tensor] = {}  # transposed bf16 weights for dgrad
+        self.training = True
+        self.dropout_seed = int(seed)
+        self.micro_step = 0
+        self._site_ids: Dict[str, int] = {}
+        self.refresh_shadows()
+
+    # ------------------------------------------------------------------ parameters
+    def _gemm_weight_groups(self):
+        """(first key, rows, cols) of every matrix used as a GEMM B operand."""
+        d, out = self.d, []
+        for side, n, f in (("encoder", self.cfg["encoder_layers"], self.cfg["encoder_ffn_dim"]),
+                           ("decoder", self.cfg["decoder_layers"], self.cfg["decoder_ffn_dim"])):
+            for i in range(n):
+                p = f"{side}.layers.{i}."
+                out.append((p + "self_attn.in_proj_weight", 3 * d, d))
+                out.append((p + "self_attn.out_proj.weight", d, d))
+                if side == "decoder":
+                    out.append((p + "multihead_attn.in_proj_weight", 3 * d, d))
+                    out.append((p + "multihead_attn.out_proj.weight", d, d))
+                out.append((p + "linear1.weight", (2 if self.gated else 1) * f, d))
+                out.append((p + "linear2.weight", d, f))
+        out.append(("token_ff.weight", self.V, d))
+        return out
+
+    def refresh_shadows(self) -> None:
+        """bf16 copies (and transposes, for dgrad) of the GEMM weights; call after any change to
+        the fp32 parameters that did not come from `afm_adam_step` (init, load_state_dict)."""
+        if self.cd != torch.bfloat16:
+            return
+        for name, rows, cols in self._gemm_weight_groups():
+            src = self.ps.span(self.ps.flat, name, rows, cols)
+            dst = self.ps.span(self.ps.bf16, name, rows, cols)
+            if name not in self.wt:
+                self.wt[name] = torch.empty(cols, rows, dtype=torch.bfloat16, device=self.dev)
+            ops.cast_bf16(src, dst, self.wt[name])
+
+    def refresh_transposes(self) -> None:
+        """After an optimiser step (which already wrote the flat bf16 shadow)."""
+        if self.cd != torch.bfloat16:
+            return
+        for name, rows, cols in self._gemm_weight_groups():
+            ops.cast_bf16(self.ps.span(self.ps.flat, name, rows, cols), None, self.wt[name])
+
+    def W(self, name, rows, cols, r0=0, r1=None):
+        """GEMM weight rows [r0:r1) of the (rows x cols) group at `name`, compute dtype."""
+        buf = self.ps.bf16 if self.cd == torch.bfloat16 else self.ps.flat
+        return self.ps.span(buf, name, rows, cols)[r0:r1]
+
+    def G(self, name, rows, cols, r0=0, r1=None):
+        return self.ps.span(self.ps.grad, name, rows, cols)[r0:r1]
+
+    def state_dict(self):
+        sd = self.ps.state_dict()
+        if self.pos_enc is not None:
+            sd["embedding.positional_encodings.pos_enc"] = self.pos_enc.clone()
+        for k in [k for k in sd if k.startswith("embedding.")]:
+            sd["decoder." + k] = sd[k]  # reference alias (custom_modeling.py:268)
+        return sd
+
+    def load_state_dict(self, sd, strict=True):
+        self.ps.load(sd, strict)
+        if self.pos_enc is not None and "embedding.positional_encodings.pos_enc" in sd:
+            self.pos_enc.copy_(sd["embedding.positional_encodings.pos_enc"].to(self.dev))
+        self.refresh_shadows()
+
+    def train(self, mode=True):
+        self.training = mode
+        return self
+
+    def eval(self):
+        return self.train(False)
+
+    # ------------------------------------------------------------------ helpers
+    def _drop(self, site: str):
+        p = float(self.cfg["dropout"]) if self.training else 0.0
+        if p <= 0.0:
+            return ops.NO_DROP
+        sid = self._site_ids.setdefault(site, len(self._site_ids) + 1)
+        return ops.drop(p, self.dropout_seed + 7919 * self.micro_step, sid)
+
+    def _empty(self, rows, cols, dtype=None):
+        return torch.empty(rows, cols, dtype=dtype or self.cd, device=self.dev)
+
+    def _linear(self, x, name, rows, cols, r0=0, r1=None, out=None, out_dtype=None, bias_name=None,
+                residual=None, dropout=ops.NO_DROP, act=ACT_NONE, pre_act=None):
+        w = self.W(name, rows, cols, r0, r1)
+        n = w.shape[0]
+        if out is None:
+            out = self._empty(x.shape[0], n, out_dtype)
+        bias = None
+        if bias_name is not None:
+            s = self.ps.specs[bias_name]
+            bias = self.ps.flat[s.offset + r0: s.offset + r0 + n]
+        return ops.gemm(x, w, out, trans_b=True, bias=bias, residual=residual, dropout=dropout, act=act,
+                        pre_act=pre_act, algo=self.algo)
+
+    def _dgrad(self, dy, name, rows, cols, r0=0, r1=None, out=None, out_dtype=None, accumulate=False):
+        """dx = dy @ W[r0:r1]  (W rows = output features)."""
+        r1 = rows if r1 is None else r1
+        if out is None:
+            out = self._empty(dy.shape[0], cols, out_dtype)
+        if self.cd == torch.bfloat16:
+            wt = self.wt[name][:, r0:r1]  # (cols, n): NT form for the MFMA kernel
+            return ops.gemm(dy, wt, out, trans_b=True, accumulate=accumulate, algo=self.algo)
+        w = self.W(name, rows, cols, r0, r1)
+        return ops.gemm(dy, w, out, trans_b=False, accumulate=accumulate, algo=self.algo)
+
+    def _wgrad(self, dy, x, name, rows, cols, r0=0, r1=None, bias_name=None):
+        """dW[r0:r1] += dy^T x ; db[r0:r1] += colsum(dy)."""
+        gw = self.G(name, rows, cols, r0, r1)
+        ops.gemm(dy, x, gw, trans_a=True, trans_b=False, accumulate=True, algo=self.algo)
+        if bias_name is not None:
+            s = self.ps.specs[bias_name]
+            ops.colsum(dy, self.ps.grad[s.offset + r0: s.offset + r0 + gw.shape[0]], accumulate=True)
+
+    # ------------------------------------------------------------------ embedding
+    def _pos_rows(self, S: int, saved: Optional[dict]):
+        """(S x d) fp32 positional rows added after the per-modality LayerNorm."""
+        if S > self.cfg["max_position_embeddings"]:
+            raise ValueError(f"sequence length {S} exceeds max_position_embeddings")
+        if self.pos_enc is not None:
+            return self.pos_enc[:S]
+        tab = self.ps.p("embedding.positional_encodings.pos_encodings.weight")[:S]
+        pe = torch.empty(S, self.d, dtype=torch.float32, device=self.dev)
+        mean = torch.empty(S, dtype=torch.float32, device=self.dev)
+        rstd = torch.empty(S, dtype=torch.float32, device=self.dev)
+        ops.layernorm_fwd(tab, self.ps.p("embedding.positional_encodings.norm.weight"),
+                          self.ps.p("embedding.positional_encodings.norm.bias"), pe, mean, rstd)
+        if saved is not None:
+            saved["pe_stats"] = (mean, rstd)
+        return pe
+
+    def embed_fwd(self, inputs: Dict[str, Any], saved: Optional[dict]) -> torch.Tensor:
+        """MultimodalEmbedding.forward (modeling/utils.py:142-182) -> (B*S, d) fp32."""
+        lens = []
+        for m, x in inputs.items():
+            t = x["tokenized_input"] if isinstance(x, dict) else x
+            lens.append(int(t.shape[1]))
+            B = int(t.shape[0])
+        S = sum(lens)
+        x_out = torch.empty(B * S, self.d, dtype=torch.float32, device=self.dev)
+        pe = self._pos_rows(S, saved)
+        off = 0
+        mods = []
+        for (m, x), Sm in zip(inputs.items(), lens):
+            mc = self.dc[m]
+            rec = {"name": m, "S": Sm, "off": off}
+            p = f"embedding.embedding_layer_dict.{m}."
+            if mc["type"] in TEXT_TYPES:
+                scale = None
+                if isinstance(x, dict):  # xVal (utils.py:154-160)
+                    scale = x["numerical_values"].to(torch.float32).contiguous().view(-1)
+                    x = x["tokenized_input"]
+                ids = x.contiguous().view(-1)
+                e = torch.empty(B * Sm, self.d, dtype=torch.float32, device=self.dev)
+                ops.gather_rows(ids, self.ps.p(p + "weight"), e, scale)
+                rec.update(ids=ids, scale=scale, pad=int(mc.get("pad_token_id", -1)))
+            elif mc["type"] in PATCH_TYPES:
+                h = x.to(torch.float32).contiguous().view(B * Sm, -1)
+                layers = patch_layers(mc, self.d)
+                acts = [h]
+                for li, (suf, i, o) in enumerate(layers):
+                    out = torch.empty(B * Sm, o, dtype=torch.float32, device=self.dev)
+                    last = li == len(layers) - 1
+                    ops.gemm(h, self.ps.p(p + suf + "weight"), out, trans_b=True,
+                             bias=self.ps.p(p + suf + "bias"), act=ACT_NONE if last else ACT_RELU)
+                    h = out
+                    acts.append(h)
+                e = h
+                rec.update(acts=acts, layers=layers)
+            else:
+                raise NotImplementedError(mc["type"])
+            mean = torch.empty(B * Sm, dtype=torch.float32, device=self.dev)
+            rstd = torch.empty(B * Sm, dtype=torch.float32, device=self.dev)
+            ops.layernorm_fwd(e, self.ps.p(f"embedding.embedding_norm_dict.{m}.weight"),
+                              self.ps.p(f"embedding.embedding_norm_dict.{m}.bias"), x_out, mean, rstd,
+                              pos=pe, seg_len=Sm, out_seg_stride=S, out_off=off)
+            rec.update(e=e, mean=mean, rstd=rstd)
+            mods.append(rec)
+            off += Sm
+        if saved is not None:
+            saved.update(mods=mods, B=B, S=S)
+        return x_out
+
+    def embed_bwd(self, dx: torch.Tensor, saved: dict) -> None:
+        B, S, d = saved["B"], saved["S"], self.d
+        if self.pos_enc is None:  # learned table: d pe = sum over the batch, through its LayerNorm
+            dpe = torch.empty(S, d, dtype=torch.float32, device=self.dev)
+            ops.batch_sum(dx, dpe, B, S, d, accumulate=False)
+            mean, rstd = saved["pe_stats"]
+            name = "embedding.positional_encodings.pos_encodings.weight"
+            tab = self.ps.p(name)[:S]
+            dtab = torch.empty(S, d, dtype=torch.float32, device=self.dev)
+            ws = torch.empty(ops.layernorm_bwd_ws(S, d), dtype=torch.float32, device=self.dev)
+            ops.layernorm_bwd(dpe, tab, self.ps.p("embedding.positional_encodings.norm.weight"), mean, rstd,
+                              dtab, self.ps.g("embedding.positional_encodings.norm.weight"),
+                              self.ps.g("embedding.positional_encodings.norm.bias"), ws)
+            ops.add_inplace(self.ps.g(name)[:S], dtab)
+        for rec in saved["mods"]:
+            m, Sm, off = rec["name"], rec["S"], rec["off"]
+            rows = B * Sm
+            de = torch.empty(rows, d, dtype=torch.float32, device=self.dev)
+            ws = torch.empty(ops.layernorm_bwd_ws(rows, d), dtype=torch.float32, device=self.dev)
+            ops.layernorm_bwd(dx, rec["e"], self.ps.p(f"embedding.embedding_norm_dict.{m}.weight"),
+                              rec["mean"], rec["rstd"], de,
+                              self.ps.g(f"embedding.embedding_norm_dict.{m}.weight"),
+                              self.ps.g(f"embedding.embedding_norm_dict.{m}.bias"), ws,
+                              seg_len=Sm, out_seg_stride=S, out_off=off)
+            p = f"embedding.embedding_layer_dict.{m}."
+            if "ids" in rec:
+                ops.scatter_add_rows(rec["ids"], de, self.ps.g(p + "weight"), rec["scale"], rec["pad"])
+            else:
+                g = de
+                layers, acts = rec["layers"], rec["acts"]
+                for li in range(len(layers) - 1, -1, -1):
+                    suf = layers[li][0]
+                    if li < len(layers) - 1:  # ReLU backward on the hidden activation
+                        g = g * (acts[li + 1] > 0)  # tiny fp32 embedder MLP: torch glue on device
+                    ops.gemm(g, acts[li], self.ps.g(p + suf + "weight"), trans_a=True, trans_b=False,
+                             accumulate=True)
+                    ops.colsum(g, self.ps.g(p + suf + "bias"), accumulate=True)
+                    if li > 0:
+                        gi = torch.empty(rows, layers[li][1], dtype=torch.float32, device=self.dev)
+                        ops.gemm(g, self.ps.p(p + suf + "weight"), gi, trans_b=False)
+                        g = gi
+
+    # ------------------------------------------------------------------ blocks
+    def _ln_fwd(self, x, prefix, saved, key, out_dtype=None):
+        rows = x.shape[0]
+        y = self._empty(rows, self.d, out_dtype)
+        mean = torch.empty(rows, dtype=torch.float32, device=self.dev)
+        rstd = torch.empty(rows, dtype=torch.float32, device=self.dev)
+        ops.layernorm_fwd(x, self.ps.p(prefix + "weight"), self.ps.p(prefix + "bias"), y, mean, rstd)
+        if saved is not None:
+            saved[key] = (x, mean, rstd)
+        return y
+
+    def _ln_bwd(self, dy, prefix, saved, key, dres):
+        x, mean, rstd = saved[key]
+        dx = torch.empty_like(x)
+        ws = torch.empty(ops.layernorm_bwd_ws(x.shape[0], self.d), dtype=torch.float32, device=self.dev)
+        ops.layernorm_bwd(dy, x, self.ps.p(prefix + "weight"), mean, rstd, dx, self.ps.g(prefix + "weight"),
+                          self.ps.g(prefix + "bias"), ws, dres=dres)
+        return dx
+
+    def _self_attn_fwd(self, x, p, B, T, H, key_pad, causal, saved, site):
+        d = self.d
+        h = self._ln_fwd(x, p + "norm1.", saved, "ln1")
+        qkv = self._linear(h, p + "self_attn.in_proj_weight", 3 * d, d, bias_name=p + "self_attn.in_proj_bias")
+        a = self._empty(B * T, d)
+        lse = torch.empty(B * H * T, dtype=torch.float32, device=self.dev)
+        shp = ops.attn_shape(B, H, T, T, d // H, self.cd, 3 * d, 3 * d, 3 * d, d, key_pad, causal,
+                             self._drop(site + "attn"), self.algo)
+        ops.attn_fwd(shp, qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], a, lse)
+        x1 = self._linear(a, p + "self_attn.out_proj.weight", d, d, out_dtype=torch.float32,
+                          bias_name=p + "self_attn.out_proj.bias", residual=x, dropout=self._drop(site + "res"))
+        if saved is not None:
+            saved["sa"] = (h, qkv, a, lse, shp)
+        return x1
+
+    def _self_attn_bwd(self, dx1, p, saved, site_res_drop):
+        """dx1: fp32 grad at the block output.  Returns grad at the block input."""
+        d = self.d
+        h, qkv, a, lse, shp = saved["sa"]
+        rows = h.shape[0]
+        dy = self._empty(rows, d)
+        ops.dropout_cast(dx1, dy, site_res_drop)
+        self._wgrad(dy, a, p + "self_attn.out_proj.weight", d, d, bias_name=p + "self_attn.out_proj.bias")
+        da = self._dgrad(dy, p + "self_attn.out_proj.weight", d, d)
+        dqkv = self._empty(rows, 3 * d)
+        delta = torch.empty_like(lse)
+        ops.attn_bwd(shp, qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], a, da, lse, delta,
+                     dqkv[:, :d], dqkv[:, d:2 * d], dqkv[:, 2 * d:], 3 * d, 3 * d, 3 * d)
+        self._wgrad(dqkv, h, p + "self_attn.in_proj_weight", 3 * d, d, bias_name=p + "self_attn.in_proj_bias")
+        dh = self._dgrad(dqkv, p + "self_attn.in_proj_weight", 3 * d, d)
+        return self._ln_bwd(dh, p + "norm1.", saved, "ln1", dres=dx1)
+
+    def _ffn_fwd(self, x, p, f, norm, saved, site):
+        d, k = self.d, (2 if self.gated else 1)
+        h = self._ln_fwd(x, p + norm, saved, "lnf")
+        uv = self._linear(h, p + "linear1.weight", k * f, d, bias_name=p + "linear1.bias")
+        g = self._empty(x.shape[0], f)
+        dr = self._drop(site + "ffn")
+        ops.glu_fwd(uv[:, :f], uv[:, f:] if self.gated else None, g, dr)
+        x1 = self._linear(g, p + "linear2.weight", d, f, out_dtype=torch.float32, bias_name=p + "linear2.bias",
+                          residual=x, dropout=self._drop(site + "res2"))
+        if saved is not None:
+            saved["ffn"] = (h, uv, g, dr)
+        return x1
+
+    def _ffn_bwd(self, dx1, p, f, norm, saved, site_res_drop):
+        d, k = self.d, (2 if self.gated else 1)
+        h, uv, g, dr = saved["ffn"]
+        rows = h.shape[0]
+        dy = self._empty(rows, d)
+        ops.dropout_cast(dx1, dy, site_res_drop)
+        self._wgrad(dy, g, p + "linear2.weight", d, f, bias_name=p + "linear2.bias")
+        dg = self._dgrad(dy, p + "linear2.weight", d, f)
+        duv = self._empty(rows, k * f)
+        ops.glu_bwd(uv[:, :f], uv[:, f:] if self.gated else None, dg, duv[:, :f],
+                    duv[:, f:] if self.gated else None, dr)
+        self._wgrad(duv, h, p + "linear1.weight", k * f, d, bias_name=p + "linear1.bias")
+        dh = self._dgrad(duv, p + "linear1.weight", k * f, d)
+        return self._ln_bwd(dh, p + norm, saved, "lnf", dres=dx1)
+
+    def _cross_attn_fwd(self, x, mem, p, B, T, S, H, mem_pad, saved, site):
+        d = self.d
+        h = self._ln_fwd(x, p + "norm2.", saved, "ln2")
+        w, bname = p + "multihead_attn.in_proj_weight", p + "multihead_attn.in_proj_bias"
+        q = self._linear(h, w, 3 * d, d, 0, d, bias_name=bname)
+        kv = self._linear(mem, w, 3 * d, d, d, 3 * d, bias_name=bname)
+        a = self._empty(B * T, d)
+        lse = torch.empty(B * H * T, dtype=torch.float32, device=self.dev)
+        shp = ops.attn_shape(B, H, T, S, d // H, self.cd, d, 2 * d, 2 * d, d, mem_pad, False,
+                             self._drop(site + "xattn"), self.algo)
+        ops.attn_fwd(shp, q, kv[:, :d], kv[:, d:], a, lse)
+        x1 = self._linear(a, p + "multihead_attn.out_proj.weight", d, d, out_dtype=torch.float32,
+                          bias_name=p + "multihead_attn.out_proj.bias", residual=x,
+                          dropout=self._drop(site + "xres"))
+        if saved is not None:
+            saved["ca"] = (h, q, kv, a, lse, shp)
+        return x1
+
+    def _cross_attn_bwd(self, dx1, mem, dmem, p, saved, site_res_drop):
+        d = self.d
+        h, q, kv, a, lse, shp = saved["ca"]
+        dy = self._empty(h.shape[0], d)
+        ops.dropout_cast(dx1, dy, site_res_drop)
+        wo, bo = p + "multihead_attn.out_proj.weight", p + "multihead_attn.out_proj.bias"
+        self._wgrad(dy, a, wo, d, d, bias_name=bo)
+        da = self._dgrad(dy, wo, d, d)
+        dq = self._empty(h.shape[0], d)
+        dkv = self._empty(mem.shape[0], 2 * d)
+        delta = torch.empty_like(lse)
+        ops.attn_bwd(shp, q, kv[:, :d], kv[:, d:], a, da, lse, delta, dq, dkv[:, :d], dkv[:, d:], d, 2 * d, 2 * d)
+        w, bname = p + "multihead_attn.in_proj_weight", p + "multihead_attn.in_proj_bias"
+        self._wgrad(dq, h, w, 3 * d, d, 0, d, bias_name=bname)
+        self._wgrad(dkv, mem, w, 3 * d, d, d, 3 * d, bias_name=bname)
+        dh = self._dgrad(dq, w, 3 * d, d, 0, d)
+        self._dgrad(dkv, w, 3 * d, d, d, 3 * d, out=dmem, accumulate=True)  # fp32 accumulator
+        return self._ln_bwd(dh, p + "norm2.", saved, "ln2", dres=dx1)
+
+    # ------------------------------------------------------------------ whole model
+    def encode(self, enc_inputs, attention_mask, saved: Optional[dict] = None):
+        """embed + CustomEncoder.forward (custom_modeling.py:220-243) -> memory (B*S, d)."""
+        x = self.embed_fwd(enc_inputs, None if saved is None else saved.setdefault("emb_enc", {}))
+        B, S = attention_mask.shape
+        assert x.shape[0] == B * S, "attention_mask does not match the concatenated modalities"
+        key_pad = (attention_mask == 0).to(torch.uint8).contiguous()
+        H = self.cfg["encoder_attention_heads"]
+        layers = []
+        for i in range(self.cfg["encoder_layers"]):
+            p = f"encoder.layers.{i}."
+            sv = {} if saved is not None else None
+            x = self._self_attn_fwd(x, p, B, S, H, key_pad, False, sv, f"e{i}")
+            x = self._ffn_fwd(x, p, self.cfg["encoder_ffn_dim"], "norm2.", sv, f"e{i}")
+            layers.append(sv)
+        mem = self._ln_fwd(x, "encoder.norm.", saved, "enc_norm")
+        if saved is not None:
+            saved.update(enc_layers=layers, key_pad=key_pad, B=B, S=S)
+        return mem, key_pad
+
+    def decode(self, dec_ids, mem, mem_pad, dec_attention_mask, S, saved: Optional[dict] = None):
+        """CustomDecoder.forward + token_ff (custom_modeling.py:271-320,486) -> fp32 logits."""
+        B, T = dec_ids.shape
+        x = self.embed_fwd({self.tm: dec_ids}, None if saved is None else saved.setdefault("emb_dec", {}))
+        tgt_pad = None
+        if dec_attention_mask is not None:
+            tgt_pad = (dec_attention_mask == 0).to(torch.uint8).contiguous()
+        H = self.cfg["decoder_attention_heads"]
+        layers = []
+        for i in range(self.cfg["decoder_layers"]):
+            p = f"decoder.layers.{i}."
+            sv = {} if saved is not None else None
+            x = self._self_attn_fwd(x, p, B, T, H, tgt_pad, True, sv, f"d{i}")
+            x = self._cross_attn_fwd(x, mem, p, B, T, S, H, mem_pad, sv, f"d{i}")
+            x = self._ffn_fwd(x, p, self.cfg["decoder_ffn_dim"], "norm3.", sv, f"d{i}")
+            layers.append(sv)
+        hf = self._ln_fwd(x, "decoder.norm.", saved, "dec_norm")
+        logits = self._linear(hf, "token_ff.weight", self.V, self.d, out_dtype=torch.float32,
+                              bias_name="token_ff.bias")
+        if saved is not None:
+            saved.update(dec_layers=layers, hf=hf, T=T)
+        return logits
+
+    def forward(self, enc_inputs, attention_mask, dec_ids, dec_attention_mask=None, labels=None,
+                backward: bool = False, loss_scale: float = 1.0, memory=None):
+        """One pass.  With `backward` the parameter gradients are ACCUMULATED into the flat
+        gradient buffer (scaled by loss_scale, e.g. 1/acc_batches).  Returns a dict with fp32
+        `logits` (B,T,V), `loss` (0-dim device tensor, mean over labels != -100), `argmax`
+        (B,T) int64, `encoder_hidden_states`."""
+        saved = {} if backward else None
+        B, T = dec_ids.shape
+        dec_ids = dec_ids.contiguous()
+        if memory is None:
+            mem, mem_pad = self.encode(enc_inputs, attention_mask, saved)
+        else:
+            mem = memory
+            mem_pad = (attention_mask == 0).to(torch.uint8).contiguous()
+        S = attention_mask.shape[1]
+        logits = self.decode(dec_ids, mem, mem_pad, dec_attention_mask, S, saved)
+        out = {"logits": logits.view(B, T, self.V), "encoder_hidden_states": mem.view(B, S, self.d)}
+        rows = B * T
+        if labels is not None or backward:
+            lab = labels.contiguous().view(-1)
+            row_lse = torch.empty(rows, dtype=torch.float32, device=self.dev)
+            argmax = torch.empty(rows, dtype=torch.int64, device=self.dev)
+            stats = torch.zeros(2, dtype=torch.float32, device=self.dev)
+            ops.ce_fwd(logits, lab, row_lse, argmax, stats)
+            out["loss"] = stats[0] / stats[1]
+            out["argmax"] = argmax.view(B, T)
+            out["loss_stats"] = stats
+            if backward:
+                self._backward(saved, logits, lab, row_lse, stats, loss_scale, mem)
+                self.micro_step += 1
+        return out
+
+    def _backward(self, saved, logits, lab, row_lse, stats, loss_scale, mem):
+        d = self.d
+        B, S, T = saved["B"], saved["S"], saved["T"]
+        dlog = self._empty(B * T, self.V)
+        ops.ce_bwd(logits, lab, row_lse, stats, loss_scale, dlog)
+        hf = saved["hf"]
+        self._wgrad(dlog, hf, "token_ff.weight", self.V, d, bias_name="token_ff.bias")
+        dhf = self._dgrad(dlog, "token_ff.weight", self.V, d)
+        dx = self._ln_bwd(dhf, "decoder.norm.", saved, "dec_norm", dres=None)
+        dmem = torch.zeros(B * S, d, dtype=torch.float32, device=self.dev)
+        p_drop = lambda site: self._drop(site)  # same (seed, site) as the forward of this micro-batch
+        for i in range(self.cfg["decoder_layers"] - 1, -1, -1):
+            p, sv = f"decoder.layers.{i}.", saved["dec_layers"][i]
+            dx = self._ffn_bwd(dx, p, self.cfg["decoder_ffn_dim"], "norm3.", sv, p_drop(f"d{i}res2"))
+            dx = self._cross_attn_bwd(dx, mem, dmem, p, sv, p_drop(f"d{i}xres"))
+            dx = self._self_attn_bwd(dx, p, sv, p_drop(f"d{i}res"))
+        self.embed_bwd(dx, saved["emb_dec"])
+        dmem_c = dmem
+        if self.cd != torch.float32:
+            dmem_c = self._empty(B * S, d)
+            ops.dropout_cast(dmem, dmem_c)
+        dx = self._ln_bwd(dmem_c, "encoder.norm.", saved, "enc_norm", dres=None)
+        for i in range(self.cfg["encoder_layers"] - 1, -1, -1):
+            p, sv = f"encoder.layers.{i}.", saved["enc_layers"][i]
+            dx = self._ffn_bwd(dx, p, self.cfg["encoder_ffn_dim"], "norm2.", sv, p_drop(f"e{i}res2"))
+            dx = self._self_attn_bwd(dx, p, sv, p_drop(f"e{i}res"))
+        self.embed_bwd(dx, saved["emb_enc"])

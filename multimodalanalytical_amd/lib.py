@@ -1,0 +1,128 @@
+"""ctypes binding of libafm_hip.so (the C ABI declared in include/afm_hip.h).
+
+There is no fallback: if the library is missing and cannot be built, or a call returns an
+error code, this raises.  PyTorch is used only as the owner of device memory and streams:
+every argument crossing the boundary is a raw device pointer, an integer or a float.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libafm_hip.so")
+
+AFM_F32, AFM_BF16 = 0, 1
+ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2
+ALGO_AUTO, ALGO_GENERIC, ALGO_MFMA = 0, 1, 2
+
+
+class AfmError(RuntimeError):
+    pass
+
+
+class Dropout(C.Structure):
+    _fields_ = [("p", C.c_float), ("site", C.c_uint32), ("seed", C.c_uint64)]
+
+
+class GemmDesc(C.Structure):
+    _fields_ = [
+        ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32),
+        ("transA", C.c_int32), ("transB", C.c_int32),
+        ("lda", C.c_int32), ("ldb", C.c_int32), ("ldc", C.c_int32),
+        ("a_dtype", C.c_int32), ("b_dtype", C.c_int32), ("c_dtype", C.c_int32),
+        ("A", C.c_void_p), ("B", C.c_void_p), ("C", C.c_void_p),
+        ("bias", C.c_void_p), ("residual", C.c_void_p), ("pre_act", C.c_void_p),
+        ("act", C.c_int32), ("accumulate", C.c_int32), ("algo", C.c_int32), ("reserved", C.c_int32),
+        ("drop", Dropout),
+    ]
+
+
+class LnShape(C.Structure):
+    _fields_ = [
+        ("rows", C.c_int64), ("d", C.c_int32), ("y_dtype", C.c_int32),
+        ("seg_len", C.c_int64), ("out_seg_stride", C.c_int64), ("out_off", C.c_int64),
+        ("eps", C.c_float), ("reserved", C.c_int32),
+    ]
+
+
+class AttnShape(C.Structure):
+    _fields_ = [
+        ("B", C.c_int32), ("H", C.c_int32), ("Tq", C.c_int32), ("Tk", C.c_int32), ("dh", C.c_int32),
+        ("dtype", C.c_int32),
+        ("ldq", C.c_int32), ("ldk", C.c_int32), ("ldv", C.c_int32), ("ldo", C.c_int32),
+        ("causal", C.c_int32), ("algo", C.c_int32), ("scale", C.c_float), ("reserved", C.c_int32),
+        ("key_pad", C.c_void_p),
+        ("drop", Dropout),
+    ]
+
+
+_P = C.c_void_p
+_I32, _I64, _F = C.c_int32, C.c_int64, C.c_float
+_SIGS = {
+    "afm_abi_version": (C.c_int, []),
+    "afm_error_string": (C.c_char_p, [C.c_int]),
+    "afm_last_algo": (C.c_char_p, []),
+    "afm_gemm": (C.c_int, [C.POINTER(GemmDesc), _P]),
+    "afm_gather_rows": (C.c_int, [_P, _P, _P, _P, _I64, _I32, _I32, _P]),
+    "afm_scatter_add_rows": (C.c_int, [_P, _P, _P, _P, _I64, _I32, _I32, _I64, _P]),
+    "afm_layernorm_fwd": (C.c_int, [C.POINTER(LnShape), _P, _P, _P, _P, _P, _P, _P, _P]),
+    "afm_layernorm_bwd_ws_floats": (C.c_int64, [C.POINTER(LnShape)]),
+    "afm_layernorm_bwd": (C.c_int, [C.POINTER(LnShape), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "afm_attn_fwd": (C.c_int, [C.POINTER(AttnShape), _P, _P, _P, _P, _P, _P]),
+    "afm_attn_bwd": (C.c_int, [C.POINTER(AttnShape), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
+                               _I32, _I32, _I32, _P]),
+    "afm_glu_fwd": (C.c_int, [_P, _P, _P, _I64, _I32, _I32, _I32, _I32, _I32, C.POINTER(Dropout), _P]),
+    "afm_glu_bwd": (C.c_int, [_P, _P, _P, _P, _P, _I64, _I32, _I32, _I32, _I32, _I32, _I32, _I32,
+                              C.POINTER(Dropout), _P]),
+    "afm_dropout_cast": (C.c_int, [_P, _P, _I64, _I32, _I32, _I32, _I32, C.POINTER(Dropout), _P]),
+    "afm_colsum": (C.c_int, [_P, _P, _I64, _I32, _I32, _I32, _I32, _P]),
+    "afm_add_inplace": (C.c_int, [_P, _P, _I64, _P]),
+    "afm_batch_sum": (C.c_int, [_P, _P, _I32, _I64, _I32, _I32, _P]),
+    "afm_cast_bf16": (C.c_int, [_P, _P, _P, _I32, _I32, _P]),
+    "afm_ce_fwd": (C.c_int, [_P, _P, _I64, _I32, _I32, _P, _P, _P, _P]),
+    "afm_ce_bwd": (C.c_int, [_P, _P, _P, _P, _F, _P, _I32, _I32, _I64, _I32, _I32, _P]),
+    "afm_sumsq": (C.c_int, [_P, _I64, _P, _P]),
+    "afm_adam_step": (C.c_int, [_P, _P, _P, _P, _I64, _P, _P, _P, _I32, _P]),
+}
+
+_lock = threading.Lock()
+_lib = None
+
+
+def exported_symbols():
+    return sorted(_SIGS)
+
+
+def load(build_if_missing: bool = True):
+    """dlopen libafm_hip.so (building it with hipcc first if absent) and type every symbol."""
+    global _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            if not build_if_missing:
+                raise AfmError(f"{LIB_PATH} is missing; run `python -m multimodalanalytical_amd.csrc.build`")
+            from .csrc import build as _b
+            _b.build()
+        try:
+            lib = C.CDLL(LIB_PATH)
+        except OSError as e:  # no CPU fallback by design
+            raise AfmError(f"cannot load {LIB_PATH}: {e}") from e
+        for name, (res, args) in _SIGS.items():
+            try:
+                fn = getattr(lib, name)
+            except AttributeError as e:
+                raise AfmError(f"{LIB_PATH} does not export {name}") from e
+            fn.restype, fn.argtypes = res, args
+        if lib.afm_abi_version() != 1:
+            raise AfmError("libafm_hip.so ABI version mismatch")
+        _lib = lib
+        return lib
+
+
+def check(code: int, what: str = "") -> None:
+    if code != 0:
+        msg = load().afm_error_string(code).decode()
+        raise AfmError(f"{what or 'libafm_hip'}: {msg} ({code})")

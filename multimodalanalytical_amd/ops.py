@@ -1,0 +1,231 @@
+"""Torch-tensor front end of the C ABI: every function here is one libafm_hip.so call.
+
+Tensors are only pointer + shape carriers.  All calls enqueue on torch's CURRENT stream, so
+they compose with torch.cuda.graph capture and with side streams used for the gradient
+all-reduce.  Nothing here computes on the CPU or through torch ops.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import torch
+
+from . import lib as L
+from .lib import AFM_BF16, AFM_F32, ALGO_AUTO, ACT_NONE, AttnShape, Dropout, GemmDesc, LnShape
+
+_DT = {torch.float32: AFM_F32, torch.bfloat16: AFM_BF16}
+
+
+def _dt(t: torch.Tensor) -> int:
+    try:
+        return _DT[t.dtype]
+    except KeyError:
+        raise L.AfmError(f"unsupported dtype {t.dtype}") from None
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise L.AfmError("libafm_hip operates on device memory only (got a CPU tensor)")
+    return t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ld(t: torch.Tensor) -> int:
+    """Row stride (elements) of a 2-D view whose last dim is contiguous."""
+    if t.dim() != 2 or (t.shape[1] > 1 and t.stride(1) != 1):
+        raise L.AfmError(f"expected a row-major 2-D view, got shape {tuple(t.shape)} stride {t.stride()}")
+    return int(t.stride(0)) if t.shape[0] > 1 else max(int(t.stride(0)), int(t.shape[1]))
+
+
+def drop(p: float = 0.0, seed: int = 0, site: int = 0) -> Dropout:
+    return Dropout(float(p), int(site) & 0xFFFFFFFF, int(seed) & 0xFFFFFFFFFFFFFFFF)
+
+
+NO_DROP = drop()
+
+
+def last_algo() -> str:
+    return L.load().afm_last_algo().decode()
+
+
+def gemm(a: torch.Tensor, b: torch.Tensor, c: torch.Tensor, *, trans_a=False, trans_b=True,
+         bias: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
+         pre_act: Optional[torch.Tensor] = None, act: int = ACT_NONE, accumulate: bool = False,
+         dropout: Dropout = NO_DROP, algo: int = ALGO_AUTO) -> torch.Tensor:
+    """c = epilogue(op(a) @ op(b)); default is the nn.Linear form c = a @ b^T + bias."""
+    M, N = c.shape
+    K = a.shape[0] if trans_a else a.shape[1]
+    d = GemmDesc()
+    d.M, d.N, d.K = M, N, K
+    d.transA, d.transB = int(trans_a), int(trans_b)
+    d.lda, d.ldb, d.ldc = _ld(a), _ld(b), _ld(c)
+    d.a_dtype, d.b_dtype, d.c_dtype = _dt(a), _dt(b), _dt(c)
+    d.A, d.B, d.C = _ptr(a), _ptr(b), _ptr(c)
+    exp_a = (K, M) if trans_a else (M, K)
+    exp_b = (N, K) if trans_b else (K, N)
+    if tuple(a.shape) != exp_a or tuple(b.shape) != exp_b:
+        raise L.AfmError(f"gemm shape mismatch: a {tuple(a.shape)} b {tuple(b.shape)} c {tuple(c.shape)}")
+    if bias is not None:
+        assert bias.dtype == torch.float32 and bias.numel() == N and bias.is_contiguous()
+    d.bias = _ptr(bias)
+    if residual is not None:
+        assert residual.dtype == c.dtype and _ld(residual) == d.ldc and residual.shape == c.shape
+    d.residual = _ptr(residual)
+    if pre_act is not None:
+        assert pre_act.dtype == c.dtype and _ld(pre_act) == d.ldc and pre_act.shape == c.shape
+    d.pre_act = _ptr(pre_act)
+    d.act, d.accumulate, d.algo = int(act), int(accumulate), int(algo)
+    d.drop = dropout
+    L.check(L.load().afm_gemm(C.byref(d), _stream()), "afm_gemm")
+    return c
+
+
+def gather_rows(ids, table, out, scale=None):
+    n = ids.numel()
+    assert ids.dtype == torch.int64 and ids.is_contiguous() and out.is_contiguous()
+    V, d = table.shape
+    L.check(L.load().afm_gather_rows(_ptr(ids), _ptr(scale), _ptr(table), _ptr(out), n, d, V, _stream()),
+            "afm_gather_rows")
+    return out
+
+
+def scatter_add_rows(ids, dout, dtable, scale=None, padding_idx=-1):
+    n = ids.numel()
+    V, d = dtable.shape
+    assert ids.dtype == torch.int64 and ids.is_contiguous() and dout.is_contiguous()
+    L.check(L.load().afm_scatter_add_rows(_ptr(ids), _ptr(scale), _ptr(dout), _ptr(dtable), n, d, V,
+                                          int(padding_idx), _stream()), "afm_scatter_add_rows")
+
+
+def ln_shape(rows, d, y_dtype, seg_len=0, out_seg_stride=0, out_off=0, eps=1e-5) -> LnShape:
+    return LnShape(int(rows), int(d), _DT[y_dtype], int(seg_len), int(out_seg_stride), int(out_off),
+                   float(eps), 0)
+
+
+def layernorm_fwd(x, gamma, beta, y, mean=None, rstd=None, pos=None, seg_len=0, out_seg_stride=0,
+                  out_off=0, eps=1e-5):
+    rows, d = x.shape
+    assert x.dtype == torch.float32 and x.is_contiguous()
+    s = ln_shape(rows, d, y.dtype, seg_len, out_seg_stride, out_off, eps)
+    L.check(L.load().afm_layernorm_fwd(C.byref(s), _ptr(x), _ptr(gamma), _ptr(beta), _ptr(pos), _ptr(y),
+                                       _ptr(mean), _ptr(rstd), _stream()), "afm_layernorm_fwd")
+    return y
+
+
+def layernorm_bwd_ws(rows, d) -> int:
+    s = ln_shape(rows, d, torch.float32)
+    return int(L.load().afm_layernorm_bwd_ws_floats(C.byref(s)))
+
+
+def layernorm_bwd(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, ws, dres=None, seg_len=0,
+                  out_seg_stride=0, out_off=0):
+    rows, d = x.shape
+    s = ln_shape(rows, d, dy.dtype, seg_len, out_seg_stride, out_off)
+    assert ws.numel() >= layernorm_bwd_ws(rows, d)
+    L.check(L.load().afm_layernorm_bwd(C.byref(s), _ptr(dy), _ptr(x), _ptr(gamma), _ptr(mean), _ptr(rstd),
+                                       _ptr(dres), _ptr(dx), _ptr(dgamma), _ptr(dbeta), _ptr(ws), _stream()),
+            "afm_layernorm_bwd")
+    return dx
+
+
+def attn_shape(B, H, Tq, Tk, dh, dtype, ldq, ldk, ldv, ldo, key_pad=None, causal=False,
+               dropout: Dropout = NO_DROP, algo=ALGO_AUTO, scale=None) -> AttnShape:
+    s = AttnShape()
+    s.B, s.H, s.Tq, s.Tk, s.dh = B, H, Tq, Tk, dh
+    s.dtype = _DT[dtype]
+    s.ldq, s.ldk, s.ldv, s.ldo = ldq, ldk, ldv, ldo
+    s.causal, s.algo = int(causal), int(algo)
+    s.scale = float(scale if scale is not None else dh ** -0.5)
+    if key_pad is not None:
+        assert key_pad.dtype in (torch.uint8, torch.bool) and key_pad.is_contiguous()
+        assert key_pad.numel() == B * Tk
+    s.key_pad = _ptr(key_pad)
+    s.drop = dropout
+    return s
+
+
+def attn_fwd(s: AttnShape, q, k, v, o, lse):
+    L.check(L.load().afm_attn_fwd(C.byref(s), _ptr(q), _ptr(k), _ptr(v), _ptr(o), _ptr(lse), _stream()),
+            "afm_attn_fwd")
+    return o
+
+
+def attn_bwd(s: AttnShape, q, k, v, o, do, lse, delta, dq, dk, dv, lddq, lddk, lddv):
+    L.check(L.load().afm_attn_bwd(C.byref(s), _ptr(q), _ptr(k), _ptr(v), _ptr(o), _ptr(do), _ptr(lse),
+                                  _ptr(delta), _ptr(dq), _ptr(dk), _ptr(dv), lddq, lddk, lddv, _stream()),
+            "afm_attn_bwd")
+
+
+def glu_fwd(u, v, g, dropout: Dropout = NO_DROP):
+    rows, f = g.shape
+    L.check(L.load().afm_glu_fwd(_ptr(u), _ptr(v), _ptr(g), rows, f, _ld(u), _ld(v) if v is not None else 0,
+                                 _ld(g), _dt(g), C.byref(dropout), _stream()), "afm_glu_fwd")
+    return g
+
+
+def glu_bwd(u, v, dg, du, dv, dropout: Dropout = NO_DROP):
+    rows, f = dg.shape
+    L.check(L.load().afm_glu_bwd(_ptr(u), _ptr(v), _ptr(dg), _ptr(du), _ptr(dv), rows, f, _ld(u),
+                                 _ld(v) if v is not None else 0, _ld(dg), _ld(du),
+                                 _ld(dv) if dv is not None else 0, _dt(dg), C.byref(dropout), _stream()),
+            "afm_glu_bwd")
+
+
+def dropout_cast(x, y, dropout: Dropout = NO_DROP):
+    rows, n = x.shape
+    assert x.dtype == torch.float32
+    L.check(L.load().afm_dropout_cast(_ptr(x), _ptr(y), rows, n, _ld(x), _ld(y), _dt(y), C.byref(dropout),
+                                      _stream()), "afm_dropout_cast")
+    return y
+
+
+def colsum(x, out, accumulate=True):
+    rows, n = x.shape
+    assert out.dtype == torch.float32 and out.numel() == n
+    L.check(L.load().afm_colsum(_ptr(x), _ptr(out), rows, n, _ld(x), _dt(x), int(accumulate), _stream()),
+            "afm_colsum")
+    return out
+
+
+def add_inplace(y, x):
+    assert y.dtype == torch.float32 and x.dtype == torch.float32 and y.numel() == x.numel()
+    L.check(L.load().afm_add_inplace(_ptr(y), _ptr(x), y.numel(), _stream()), "afm_add_inplace")
+
+
+def batch_sum(x, out, B, S, d, accumulate=True):
+    L.check(L.load().afm_batch_sum(_ptr(x), _ptr(out), B, S, d, int(accumulate), _stream()), "afm_batch_sum")
+
+
+def cast_bf16(src, dst=None, dst_t=None):
+    rows, cols = src.shape
+    assert src.dtype == torch.float32 and src.is_contiguous()
+    L.check(L.load().afm_cast_bf16(_ptr(src), _ptr(dst), _ptr(dst_t), rows, cols, _stream()), "afm_cast_bf16")
+
+
+def ce_fwd(logits, labels, row_lse, argmax, stats):
+    rows, V = logits.shape
+    assert logits.dtype == torch.float32 and labels.dtype == torch.int64
+    L.check(L.load().afm_ce_fwd(_ptr(logits), _ptr(labels), rows, V, _ld(logits), _ptr(row_lse), _ptr(argmax),
+                                _ptr(stats), _stream()), "afm_ce_fwd")
+
+
+def ce_bwd(logits, labels, row_lse, stats, grad_scale, dlogits):
+    rows, V = logits.shape
+    L.check(L.load().afm_ce_bwd(_ptr(logits), _ptr(labels), _ptr(row_lse), _ptr(stats), float(grad_scale),
+                                _ptr(dlogits), _dt(dlogits), _ld(dlogits), rows, V, _ld(logits), _stream()),
+            "afm_ce_bwd")
+
+
+def sumsq(g, out):
+    L.check(L.load().afm_sumsq(_ptr(g), g.numel(), _ptr(out), _stream()), "afm_sumsq")
+
+
+def adam_step(p, g, m, v, hyper, sumsq_buf, p_bf16=None, zero_grad=True):
+    L.check(L.load().afm_adam_step(_ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), _ptr(hyper), _ptr(sumsq_buf),
+                                   _ptr(p_bf16), int(zero_grad), _stream()), "afm_adam_step")

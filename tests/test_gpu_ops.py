@@ -1,0 +1,307 @@
+"""GPU: every C-ABI entry point against the CPU oracle's primitives (oracle/afm_oracle.py) on the
+same seeded inputs.  fp32 paths are held to ~1e-5; bf16 storage paths to bf16 rounding."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import afm_oracle as O  # noqa: E402
+from tests.dropmask import keep_mask  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def ops():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from multimodalanalytical_amd import ops as _ops
+    return _ops
+
+
+DEV = "cuda:0"
+
+
+def dev(t, dtype=None):
+    return t.to(DEV if dtype is None else DEV, dtype=dtype if dtype is not None else t.dtype).contiguous()
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+def close(got, ref, rtol, atol, msg=""):
+    torch.testing.assert_close(got.detach().float().cpu(), ref.float(), rtol=rtol, atol=atol, msg=lambda m: f"{msg}: {m}")
+
+
+# ------------------------------------------------------------------ GEMM
+@pytest.mark.parametrize("M,N,K", [(80, 26, 64), (37, 130, 75), (256, 192, 128), (5, 7, 3), (300, 64, 2048)])
+@pytest.mark.parametrize("ta,tb", [(False, True), (False, False), (True, False), (True, True)])
+def test_gemm_generic_fp32(ops, M, N, K, ta, tb):
+    a = rnd(*((K, M) if ta else (M, K)), seed=1)
+    b = rnd(*((N, K) if tb else (K, N)), seed=2)
+    bias = rnd(N, seed=3)
+    ref = (a.T if ta else a).double() @ (b.T if tb else b).double() + bias.double()
+    c = torch.empty(M, N, device=DEV)
+    ops.gemm(dev(a), dev(b), c, trans_a=ta, trans_b=tb, bias=dev(bias), algo=1)
+    close(c, ref, 1e-5, 1e-4 * math.sqrt(K) / 8, f"gemm {M}x{N}x{K}")
+
+
+def test_gemm_epilogue_and_strides(ops):
+    M, N, K = 96, 48, 40
+    a, w, bias, res = rnd(M, K, seed=1), rnd(N, K, seed=2), rnd(N, seed=3), rnd(M, N, seed=4)
+    p, seed, site = 0.25, 1234567890123, 7
+    big = torch.zeros(M, N + 16, device=DEV)
+    pre = torch.zeros(M, N + 16, device=DEV)
+    resd = torch.zeros(M, N + 16, device=DEV); resd[:, :N] = dev(res)
+    ops.gemm(dev(a), dev(w), big[:, :N], bias=dev(bias), residual=resd[:, :N], pre_act=pre[:, :N], act=2,
+             dropout=ops.drop(p, seed, site), algo=1)
+    t = a.double() @ w.double().T + bias.double()
+    keep = torch.from_numpy(keep_mask(p, seed, site, M * N)).view(M, N)
+    ref = O.gelu(t) * keep / (1 - p) + res.double()
+    close(big[:, :N], ref, 1e-5, 1e-5)
+    close(pre[:, :N], t, 1e-5, 1e-5)
+    assert float(big[:, N:].abs().max()) == 0.0
+    assert abs(float(keep.float().mean()) - 0.75) < 0.03
+    # accumulate + bf16 operands + fp32 out (the wgrad form)
+    dy, x = rnd(200, 24, seed=5), rnd(200, 40, seed=6)
+    acc = rnd(24, 40, seed=7)
+    c = dev(acc).clone()
+    ops.gemm(dev(dy, torch.bfloat16), dev(x, torch.bfloat16), c, trans_a=True, trans_b=False, accumulate=True, algo=1)
+    ref = acc.double() + dy.bfloat16().double().T @ x.bfloat16().double()
+    close(c, ref, 1e-5, 1e-4)
+
+
+def test_gemm_splitk(ops):
+    M, N, K = 64, 48, 8192
+    a, b = rnd(K, M, seed=1, scale=0.1), rnd(K, N, seed=2, scale=0.1)
+    c0 = rnd(M, N, seed=3)
+    c = dev(c0).clone()
+    ops.gemm(dev(a), dev(b), c, trans_a=True, trans_b=False, accumulate=True, algo=1)
+    assert ops.last_algo() == "generic_splitk"
+    close(c, c0.double() + a.double().T @ b.double(), 1e-4, 1e-4)
+
+
+# ------------------------------------------------------------------ embedding rows
+def test_gather_scatter(ops):
+    V, d, n = 45, 64, 300
+    table = rnd(V, d, seed=1)
+    ids = torch.randint(0, V, (n,), generator=torch.Generator().manual_seed(2))
+    scale = rnd(n, seed=3)
+    out = torch.empty(n, d, device=DEV)
+    ops.gather_rows(dev(ids), dev(table), out, dev(scale))
+    close(out, table[ids] * scale[:, None], 0, 0)
+    dout = rnd(n, d, seed=4)
+    dtab = torch.zeros(V, d, device=DEV)
+    ops.scatter_add_rows(dev(ids), dev(dout), dtab, dev(scale), padding_idx=0)
+    ref = torch.zeros(V, d, dtype=torch.float64)
+    keep = ids != 0
+    ref.index_add_(0, ids[keep], (dout * scale[:, None])[keep].double())
+    close(dtab, ref, 1e-5, 1e-5)
+
+
+# ------------------------------------------------------------------ LayerNorm
+@pytest.mark.parametrize("d", [48, 64, 512, 768])
+@pytest.mark.parametrize("ydt", [torch.float32, torch.bfloat16])
+def test_layernorm_fwd_bwd(ops, d, ydt):
+    B, Sm, S, off = 3, 5, 12, 4
+    rows = B * Sm
+    x = rnd(rows, d, seed=1) * 2 + 0.5
+    gam, bet = 1 + 0.1 * rnd(d, seed=2), 0.1 * rnd(d, seed=3)
+    pos = rnd(S, d, seed=4)
+    y = torch.zeros(B * S, d, dtype=ydt, device=DEV)
+    mean = torch.empty(rows, device=DEV); rstd = torch.empty(rows, device=DEV)
+    ops.layernorm_fwd(dev(x), dev(gam), dev(bet), y, mean, rstd, pos=dev(pos), seg_len=Sm, out_seg_stride=S, out_off=off)
+    xr = x.double().requires_grad_(True)
+    gr, br = gam.double().requires_grad_(True), bet.double().requires_grad_(True)
+    ref_rows = O.layer_norm(xr, gr, br).view(B, Sm, d) + pos.double()[off:off + Sm]
+    ref = torch.zeros(B, S, d, dtype=torch.float64)
+    ref[:, off:off + Sm] = ref_rows.detach()
+    tol = dict(rtol=1e-5, atol=1e-5) if ydt == torch.float32 else dict(rtol=1e-2, atol=1e-2)
+    close(y.view(B, S, d), ref, **tol)
+    # backward
+    dy_full = rnd(B * S, d, seed=5)
+    dres = rnd(rows, d, seed=6)
+    dy_dev = dev(dy_full, ydt)
+    dyr = dy_dev.float().cpu().double().view(B, S, d)[:, off:off + Sm]
+    ref_rows.backward(dyr)
+    dx = torch.empty(rows, d, device=DEV)
+    dg = dev(rnd(d, seed=7)); db = dev(rnd(d, seed=8))
+    dg0, db0 = dg.clone().cpu(), db.clone().cpu()
+    ws = torch.empty(ops.layernorm_bwd_ws(rows, d), device=DEV)
+    ops.layernorm_bwd(dy_dev, dev(x), dev(gam), mean, rstd, dx, dg, db, ws, dres=dev(dres), seg_len=Sm,
+                      out_seg_stride=S, out_off=off)
+    close(dx, xr.grad + dres.double(), 1e-4, 1e-5)
+    close(dg, dg0.double() + gr.grad, 1e-4, 1e-5)
+    close(db, db0.double() + br.grad, 1e-4, 1e-5)
+
+
+# ------------------------------------------------------------------ attention
+def _attn_case(B, H, Tq, Tk, dh, causal, pad, seed=0):
+    q, k, v = rnd(B, Tq, H, dh, seed=seed + 1), rnd(B, Tk, H, dh, seed=seed + 2), rnd(B, Tk, H, dh, seed=seed + 3)
+    key_pad = None
+    if pad:
+        key_pad = torch.zeros(B, Tk, dtype=torch.bool)
+        for b in range(B):
+            key_pad[b, Tk - 1 - (b * 3) % max(1, Tk // 2):] = True
+        key_pad[:, 0] = False
+    return q, k, v, key_pad
+
+
+@pytest.mark.parametrize("B,H,Tq,Tk,dh,causal,pad", [
+    (2, 4, 20, 20, 16, True, True), (2, 4, 16, 40, 16, False, True), (1, 2, 70, 70, 64, False, True),
+    (2, 2, 33, 33, 8, True, False), (1, 3, 5, 130, 32, False, False)])
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_attention_generic(ops, B, H, Tq, Tk, dh, causal, pad, dt):
+    q, k, v, key_pad = _attn_case(B, H, Tq, Tk, dh, causal, pad)
+    if dt == torch.bfloat16:
+        q, k, v = q.bfloat16().float(), k.bfloat16().float(), v.bfloat16().float()
+    D = H * dh
+    qd, kd, vd = (dev(t.reshape(t.shape[0], t.shape[1], D).reshape(-1, D), dt) for t in (q, k, v))
+    o = torch.empty(B * Tq, D, dtype=dt, device=DEV)
+    lse = torch.empty(B * H * Tq, device=DEV)
+    kp = None if key_pad is None else dev(key_pad.to(torch.uint8))
+    shp = ops.attn_shape(B, H, Tq, Tk, dh, dt, D, D, D, D, kp, causal, algo=1)
+    ops.attn_fwd(shp, qd, kd, vd, o, lse)
+    qr, kr, vr = (t.double().transpose(1, 2).requires_grad_(True) for t in (q, k, v))
+    ref = O.attention(qr, kr, vr, key_pad, causal)           # (B,H,Tq,dh)
+    ref_o = ref.transpose(1, 2).reshape(B * Tq, D)
+    tol = dict(rtol=1e-5, atol=1e-5) if dt == torch.float32 else dict(rtol=2e-2, atol=2e-2)
+    close(o, ref_o, **tol)
+    do = rnd(B * Tq, D, seed=9)
+    if dt == torch.bfloat16:
+        do = do.bfloat16().float()
+    ref.backward(do.double().view(B, Tq, H, dh).transpose(1, 2))
+    dq, dk, dv = (torch.empty(n, D, dtype=dt, device=DEV) for n in (B * Tq, B * Tk, B * Tk))
+    delta = torch.empty_like(lse)
+    ops.attn_bwd(shp, qd, kd, vd, o, dev(do, dt), lse, delta, dq, dk, dv, D, D, D)
+    for got, r, T in ((dq, qr, Tq), (dk, kr, Tk), (dv, vr, Tk)):
+        close(got, r.grad.transpose(1, 2).reshape(B * T, D), **(dict(rtol=1e-4, atol=1e-5) if dt == torch.float32 else dict(rtol=3e-2, atol=3e-2)))
+
+
+def test_attention_all_masked_row_and_dropout(ops):
+    B, H, Tq, Tk, dh = 2, 2, 6, 9, 16
+    q, k, v, _ = _attn_case(B, H, Tq, Tk, dh, False, False)
+    key_pad = torch.zeros(B, Tk, dtype=torch.bool); key_pad[1] = True   # batch 1: every key masked
+    D = H * dh
+    qd, kd, vd = (dev(t.reshape(-1, D)) for t in (q, k, v))
+    o = torch.full((B * Tq, D), 7.0, device=DEV); lse = torch.empty(B * H * Tq, device=DEV)
+    p, seed, site = 0.3, 99, 5
+    shp = ops.attn_shape(B, H, Tq, Tk, dh, torch.float32, D, D, D, D, dev(key_pad.to(torch.uint8)), False,
+                         ops.drop(p, seed, site), algo=1)
+    ops.attn_fwd(shp, qd, kd, vd, o, lse)
+    assert float(o.view(B, Tq, D)[1].abs().max()) == 0.0           # _safe_softmax zeros
+    assert torch.isinf(lse.view(B, H, Tq)[1]).all()
+    keep = torch.from_numpy(keep_mask(p, seed, site, B * H * Tq * Tk)).view(B, H, Tq, Tk)
+    qr, kr, vr = (t.double().transpose(1, 2).requires_grad_(True) for t in (q, k, v))
+    s = (qr @ kr.transpose(-1, -2)) / math.sqrt(dh)
+    pr = torch.softmax(s, -1) * keep / (1 - p)
+    ref = (pr @ vr)
+    close(o.view(B, Tq, H, dh)[0], ref[0].transpose(0, 1), 1e-5, 1e-5)
+    do = rnd(B * Tq, D, seed=3)
+    ref[0].backward(do.double().view(B, Tq, H, dh).transpose(1, 2)[0])
+    dq, dk, dv = (torch.empty(n, D, device=DEV) for n in (B * Tq, B * Tk, B * Tk))
+    ops.attn_bwd(shp, qd, kd, vd, o, dev(do), lse, torch.empty_like(lse), dq, dk, dv, D, D, D)
+    close(dq.view(B, Tq, H, dh)[0], qr.grad[0].transpose(0, 1), 1e-4, 1e-5)
+    close(dk.view(B, Tk, H, dh)[0], kr.grad[0].transpose(0, 1), 1e-4, 1e-5)
+    close(dv.view(B, Tk, H, dh)[0], vr.grad[0].transpose(0, 1), 1e-4, 1e-5)
+    assert float(dq.view(B, Tq, D)[1].abs().max()) == 0.0 and float(dk.view(B, Tk, D)[1].abs().max()) == 0.0
+
+
+# ------------------------------------------------------------------ GLU, dropout-cast, colsum, casts
+@pytest.mark.parametrize("gated", [False, True])
+def test_glu(ops, gated):
+    rows, f = 37, 72
+    uv = rnd(rows, 2 * f, seed=1)
+    p, seed, site = 0.2, 42, 3
+    g = torch.empty(rows, f, device=DEV)
+    uvd = dev(uv)
+    ops.glu_fwd(uvd[:, :f], uvd[:, f:] if gated else None, g, ops.drop(p, seed, site))
+    ur = uv[:, :f].double().requires_grad_(True); vr = uv[:, f:].double().requires_grad_(True)
+    keep = torch.from_numpy(keep_mask(p, seed, site, rows * f)).view(rows, f)
+    ref = O.gelu(ur) * (vr if gated else 1.0) * keep / (1 - p)
+    close(g, ref, 1e-5, 1e-6)
+    dg = rnd(rows, f, seed=2)
+    ref.backward(dg.double())
+    duv = torch.zeros(rows, 2 * f, device=DEV)
+    ops.glu_bwd(uvd[:, :f], uvd[:, f:] if gated else None, dev(dg), duv[:, :f], duv[:, f:] if gated else None,
+                ops.drop(p, seed, site))
+    close(duv[:, :f], ur.grad, 1e-4, 1e-6)
+    if gated:
+        close(duv[:, f:], vr.grad, 1e-4, 1e-6)
+
+
+def test_dropout_cast_colsum_casts(ops):
+    rows, n = 50, 36
+    x = rnd(rows, n, seed=1)
+    y = torch.empty(rows, n, dtype=torch.bfloat16, device=DEV)
+    ops.dropout_cast(dev(x), y, ops.drop(0.5, 5, 9))
+    keep = torch.from_numpy(keep_mask(0.5, 5, 9, rows * n)).view(rows, n)
+    close(y, (x * keep * 2).bfloat16(), 0, 0)
+    out = dev(rnd(n, seed=2)); out0 = out.cpu().clone()
+    ops.colsum(dev(x), out, accumulate=True)
+    close(out, out0.double() + x.double().sum(0), 1e-5, 1e-5)
+    big = rnd(5000, n, seed=3)
+    ops.colsum(dev(big, torch.bfloat16), out, accumulate=False)
+    close(out, big.bfloat16().double().sum(0), 1e-4, 1e-3)
+    w = rnd(70, 130, seed=4)
+    d1 = torch.empty(70, 130, dtype=torch.bfloat16, device=DEV); d2 = torch.empty(130, 70, dtype=torch.bfloat16, device=DEV)
+    ops.cast_bf16(dev(w), d1, d2)
+    close(d1, w.bfloat16(), 0, 0); close(d2, w.bfloat16().T, 0, 0)
+    xs = rnd(4 * 6, 10, seed=5); o = torch.zeros(6, 10, device=DEV)
+    ops.batch_sum(dev(xs), o, 4, 6, 10, accumulate=False)
+    close(o, xs.view(4, 6, 10).double().sum(0), 1e-6, 1e-6)
+    ops.add_inplace(o, o.clone())
+    close(o, 2 * xs.view(4, 6, 10).double().sum(0), 1e-6, 1e-6)
+
+
+# ------------------------------------------------------------------ loss, optimiser
+@pytest.mark.parametrize("V", [26, 128, 300])
+def test_cross_entropy(ops, V):
+    rows = 90
+    logits = rnd(rows, V, seed=1) * 3
+    logits[3, 5] = logits[3, 9] = logits[3].max() + 1.0   # a tie: first index wins
+    labels = torch.randint(0, V, (rows,), generator=torch.Generator().manual_seed(2))
+    labels[::4] = -100
+    lse = torch.empty(rows, device=DEV); am = torch.empty(rows, dtype=torch.int64, device=DEV)
+    stats = torch.zeros(2, device=DEV)
+    ld = dev(logits)
+    ops.ce_fwd(ld, dev(labels), lse, am, stats)
+    lr = logits.double().requires_grad_(True)
+    ref = O.cross_entropy(lr, labels)
+    close(stats[0] / stats[1], ref.detach(), 1e-5, 1e-6)
+    assert int(stats[1]) == int((labels != -100).sum())
+    assert torch.equal(am.cpu(), logits.argmax(-1))
+    (ref * 0.25).backward()
+    Vp = (V + 7) // 8 * 8
+    dl = torch.full((rows, Vp), 5.0, device=DEV)
+    ops.ce_bwd(ld, dev(labels), lse, stats, 0.25, dl)
+    close(dl[:, :V], lr.grad, 1e-4, 1e-7)
+    assert Vp == V or float(dl[:, V:].abs().max()) == 0.0
+
+
+def test_adam_against_oracle(ops):
+    n = 1000 + 3
+    p, g = rnd(n, seed=1), rnd(n, seed=2) * 3
+    for decoupled in (0.0, 1.0):
+        pd, gd = dev(p).clone(), dev(g).clone()
+        m, v = torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+        pr, mr, vr = p.clone().double(), torch.zeros(n, dtype=torch.float64), torch.zeros(n, dtype=torch.float64)
+        shadow = torch.empty(n, dtype=torch.bfloat16, device=DEV)
+        for t in (1, 2, 3):
+            lr, b1 = O.onecycle(t - 1, 10, 1e-2)
+            gt = g.double() * t
+            gd.copy_(dev(g) * t)
+            norm = float(gt.norm())
+            coef = min(1.0, 1.0 / (norm + 1e-6))
+            O.adam_step(pr, gt * coef, mr, vr, t, lr, b1, 0.999, 1e-8, 0.01, bool(decoupled))
+            hyper = torch.tensor([lr, b1, 0.999, 1e-8, 0.01, 1 - b1 ** t, 1 - 0.999 ** t, 1.0, 1.0, decoupled], device=DEV)
+            ss = torch.zeros(1, device=DEV)
+            ops.sumsq(gd, ss)
+            close(ss[0].sqrt(), torch.tensor(norm), 1e-5, 1e-5)
+            ops.adam_step(pd, gd, m, v, hyper, ss, shadow, zero_grad=True)
+            close(pd, pr, 1e-5, 1e-6, f"adam t={t}")
+            assert float(gd.abs().max()) == 0.0
+            close(shadow, pd.float().cpu().bfloat16(), 0, 0)
