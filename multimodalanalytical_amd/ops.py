@@ -146,6 +146,7 @@ def attn_shape(B, H, Tq, Tk, dh, dtype, ldq, ldk, ldv, ldo, key_pad=None, causal
         assert key_pad.dtype in (torch.uint8, torch.bool) and key_pad.is_contiguous()
         assert key_pad.numel() == B * Tk
     s.key_pad = _ptr(key_pad)
+    s._keepalive = key_pad  # the struct only holds a raw pointer: keep the mask tensor alive with it
     s.drop = dropout
     return s
 
