@@ -68,6 +68,7 @@ class Seq2SeqEngine:
         self.dropout_seed = int(seed)
         self.micro_step = 0
         self._site_ids: Dict[str, int] = {}
+        self.grad_ready_hook = None  # callable(flat_offset): grads at >= offset are final (DDP overlap)
         self.refresh_shadows()
 
     # ------------------------------------------------------------------ parameters
@@ -481,6 +482,12 @@ class Seq2SeqEngine:
                 self.micro_step += 1
         return out
 
+    def _grads_final_from(self, first_name: str) -> None:
+        """Parameters are laid out in forward order, so once a layer's backward is done every
+        gradient from its first tensor to the end of the flat buffer is final."""
+        if self.grad_ready_hook is not None:
+            self.grad_ready_hook(self.ps.specs[first_name].offset)
+
     def _backward(self, saved, logits, lab, row_lse, stats, loss_scale, mem):
         d = self.d
         B, S, T = saved["B"], saved["S"], saved["T"]
@@ -497,6 +504,7 @@ class Seq2SeqEngine:
             dx = self._ffn_bwd(dx, p, self.cfg["decoder_ffn_dim"], "norm3.", sv, p_drop(f"d{i}res2"))
             dx = self._cross_attn_bwd(dx, mem, dmem, p, sv, p_drop(f"d{i}xres"))
             dx = self._self_attn_bwd(dx, p, sv, p_drop(f"d{i}res"))
+            self._grads_final_from(p + "self_attn.in_proj_weight")
         self.embed_bwd(dx, saved["emb_dec"])
         dmem_c = dmem
         if self.cd != torch.float32:
@@ -507,4 +515,5 @@ class Seq2SeqEngine:
             p, sv = f"encoder.layers.{i}.", saved["enc_layers"][i]
             dx = self._ffn_bwd(dx, p, self.cfg["encoder_ffn_dim"], "norm2.", sv, p_drop(f"e{i}res2"))
             dx = self._self_attn_bwd(dx, p, sv, p_drop(f"e{i}res"))
+            self._grads_final_from(p + "self_attn.in_proj_weight")
         self.embed_bwd(dx, saved["emb_enc"])

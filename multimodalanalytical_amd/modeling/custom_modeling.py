@@ -1,0 +1,141 @@
+"""Host-side mirror of `analytical_fm.modeling.custom_modeling` (reference
+modeling/custom_modeling.py): CustomConfig, AlignConfig, CustomModel with the same constructor and
+`forward` keywords, backed by the HIP engine instead of torch.nn.Transformer*."""
+from __future__ import annotations
+
+from typing import Any, Dict, Optional
+
+import torch
+
+from ..engine import Seq2SeqEngine
+from .utils import CustomLMOutput, DeferredEmbedding, MultimodalEmbedding
+
+
+class AlignConfig:
+    """custom_modeling.py:18-37 (alignment head: SURVEY 8f 'next')."""
+
+    def __init__(self, align_network, hidden_dimension, conv_channels, kernel_size, output_dimension,
+                 loss_lambda, loss_function):
+        self.align_network, self.hidden_dimension = align_network, hidden_dimension
+        self.conv_channels, self.kernel_size = conv_channels, kernel_size
+        self.output_dimension, self.loss_lambda, self.loss_function = output_dimension, loss_lambda, loss_function
+
+
+class CustomConfig:
+    """custom_modeling.py:40-105, same fields and defaults.  `from_pretrained(model_name, **kw)` keeps
+    the reference call shape (wrapper.py:153-162) but never touches the HF hub: the only inherited
+    bart-base fields that matter (dropout 0.1, gelu, is_encoder_decoder) equal these defaults."""
+
+    def __init__(self, d_model=512, max_position_embeddings=1024, encoder_layers=6, encoder_attention_heads=8,
+                 encoder_ffn_dim=2048, decoder_layers=6, decoder_attention_heads=8, decoder_ffn_dim=2048,
+                 dropout=0.1, activation_function="gelu", post_layer_normalisation=True, gated_linear=False,
+                 positional_encoding_type="sin_cos", bos_token_id=2, eos_token_id=3, pad_token_id=0,
+                 decoder_start_token_id=2, forced_eos_token_id=3, guided_generation=False, align_config=None,
+                 **kwargs):
+        self.d_model, self.max_position_embeddings = d_model, max_position_embeddings
+        self.encoder_layers, self.encoder_attention_heads, self.encoder_ffn_dim = encoder_layers, encoder_attention_heads, encoder_ffn_dim
+        self.decoder_layers, self.decoder_attention_heads, self.decoder_ffn_dim = decoder_layers, decoder_attention_heads, decoder_ffn_dim
+        self.dropout, self.activation_function = dropout, activation_function
+        self.gated_linear, self.post_layer_normalisation = gated_linear, post_layer_normalisation
+        self.positional_encoding_type = positional_encoding_type
+        self.bos_token_id, self.eos_token_id, self.pad_token_id = bos_token_id, eos_token_id, pad_token_id
+        self.decoder_start_token_id, self.forced_eos_token_id = decoder_start_token_id, forced_eos_token_id
+        self.guided_generation = guided_generation
+        if align_config and not isinstance(align_config, AlignConfig):
+            align_config = AlignConfig(**align_config)
+        self.align_config = align_config
+        self.is_encoder_decoder = True
+        self.extra = kwargs
+        if activation_function != "gelu":
+            raise NotImplementedError("only the reference default activation 'gelu' is built")
+        if not post_layer_normalisation:
+            raise NotImplementedError("post-LN (post_layer_normalisation=False) is not on the reference's path")
+
+    @classmethod
+    def from_pretrained(cls, model_name: str, **kwargs):  # noqa: ARG003 - name kept, no hub lookup
+        return cls(**kwargs)
+
+    def to_dict(self) -> Dict[str, Any]:
+        keys = ("d_model max_position_embeddings encoder_layers encoder_attention_heads encoder_ffn_dim "
+                "decoder_layers decoder_attention_heads decoder_ffn_dim dropout gated_linear "
+                "positional_encoding_type").split()
+        return {k: getattr(self, k) for k in keys}
+
+
+class _EncoderHandle:
+    """`hf_model.encoder(attention_mask=, inputs_embeds=)` (wrapper.py:433-441)."""
+
+    def __init__(self, model):
+        self.model = model
+
+    def __call__(self, inputs_embeds=None, attention_mask=None):
+        eng = self.model.engine
+        assert isinstance(inputs_embeds, DeferredEmbedding)
+        mem, _ = eng.encode(inputs_embeds.token_ids, attention_mask)
+        B, S = attention_mask.shape
+        return {"last_hidden_state": mem.view(B, S, eng.d), "attention_mask": attention_mask}
+
+
+class CustomModel:
+    """custom_modeling.py:323-508."""
+
+    def __init__(self, target_modality, target_tokenizer, config: CustomConfig,
+                 multimodal_embedding_layer: MultimodalEmbedding, device="cuda:0",
+                 compute_dtype=torch.bfloat16, seed: int = 3247):
+        if config.align_config is not None:
+            raise NotImplementedError("encoder alignment head: SURVEY 8f 'next', not built yet")
+        self.config = config
+        self.target_modality = target_modality
+        self.decoder_vocab_size = target_tokenizer.vocab_size
+        self.embedding = multimodal_embedding_layer
+        cfg = config.to_dict()
+        cfg["multimodal_norm"] = multimodal_embedding_layer.embedding_norm
+        self.engine = Seq2SeqEngine(cfg, multimodal_embedding_layer.data_config, target_modality,
+                                    self.decoder_vocab_size, device=device, compute_dtype=compute_dtype, seed=seed)
+        multimodal_embedding_layer.engine = self.engine
+        self.encoder = _EncoderHandle(self)
+        self._grad_enabled, self._loss_scale = False, 1.0
+
+    # -- torch.nn.Module-like conveniences
+    def train(self, mode=True):
+        self.engine.train(mode); return self
+
+    def eval(self):
+        return self.train(False)
+
+    def state_dict(self):
+        return self.engine.state_dict()
+
+    def load_state_dict(self, sd, strict=True):
+        self.engine.load_state_dict(sd, strict)
+
+    def backward_on_forward(self, enabled: bool, loss_scale: float = 1.0):
+        """The engine runs backward inside forward (hand-scheduled, no autograd graph): the training
+        loop arms it for the next call; grads ACCUMULATE in the flat buffer scaled by loss_scale."""
+        self._grad_enabled, self._loss_scale = enabled, loss_scale
+
+    def forward(self, inputs_embeds=None, attention_mask=None, encoder_outputs: Optional[Dict[str, Any]] = None,
+                decoder_input_ids=None, decoder_attention_mask=None, labels=None, use_cache=False,
+                return_dict=False, encoder_align_target=None) -> CustomLMOutput:
+        eng = self.engine
+        generating = isinstance(encoder_outputs, dict)
+        memory, enc_inputs = None, None
+        if generating:
+            hs = encoder_outputs["last_hidden_state"]
+            memory = hs.reshape(-1, eng.d)
+            if memory.dtype != eng.cd:
+                memory = memory.to(eng.cd)
+        else:
+            if not isinstance(inputs_embeds, DeferredEmbedding):
+                raise TypeError("inputs_embeds must come from this model's MultimodalEmbedding")
+            enc_inputs = inputs_embeds.token_ids
+        out = eng.forward(enc_inputs, attention_mask, decoder_input_ids, decoder_attention_mask, labels,
+                          backward=self._grad_enabled and labels is not None and not generating,
+                          loss_scale=self._loss_scale, memory=memory)
+        loss = out.get("loss")
+        loss_dict = None if loss is None else {"model_only_loss": loss, "alignment_loss": None}
+        return CustomLMOutput(loss=loss, logits=out["logits"], decoder_hidden_states=None,
+                              encoder_hidden_states=out["encoder_hidden_states"], loss_dict=loss_dict,
+                              argmax=out.get("argmax"))
+
+    __call__ = forward

@@ -1,0 +1,204 @@
+"""Drop-in boundary: `HFWrapper` + `MODEL_REGISTRY` with the reference's surface
+(reference modeling/wrapper.py:144-180,222-655), minus Lightning / HF / RDKit.
+
+Same constructor keywords, same batch-dict contract (sequence-first tensors, masks True = pad,
+reference data/datamodules.py:201-218), same methods the training loop calls: forward,
+training_step, validation_step, predict_step, configure_optimizers, generate, _calc_token_acc.
+"""
+from __future__ import annotations
+
+from typing import Any, Callable, Dict, List, Optional, Tuple
+
+import numpy as np
+import torch
+
+from ..optim import FusedAdamOneCycle
+from .custom_modeling import AlignConfig, CustomConfig, CustomModel
+from .utils import CustomLMOutput, MultimodalEmbedding
+
+OPTIMISER_REGISTRY = {"adam": "adam", "adamw": "adamw"}  # wrapper.py:29
+
+
+def load_custom_model(model_name: str, target_tokenizer, target_modality: str, data_config: Dict[str, Any],
+                      multimodal_norm: bool, **kwargs) -> Tuple[CustomModel, MultimodalEmbedding]:
+    """wrapper.py:144-180."""
+    engine_kw = {k: kwargs.pop(k) for k in ("device", "compute_dtype", "seed") if k in kwargs}
+    known = CustomConfig.__init__.__code__.co_varnames
+    cfg_kw = {k: v for k, v in kwargs.items() if k in known}
+    model_config = CustomConfig.from_pretrained(
+        model_name, pad_token_id=target_tokenizer.pad_token_id, bos_token_id=target_tokenizer.bos_token_id,
+        eos_token_id=target_tokenizer.eos_token_id, decoder_start_token_id=target_tokenizer.bos_token_id,
+        forced_eos_token_id=target_tokenizer.eos_token_id, **cfg_kw)
+    emb = MultimodalEmbedding(data_config, model_config.d_model, multimodal_norm, do_positional_encodings=True,
+                              positional_encodings_type=model_config.positional_encoding_type,
+                              max_seq_len=model_config.max_position_embeddings)
+    return CustomModel(target_modality, target_tokenizer, model_config, emb, **engine_kw), emb
+
+
+MODEL_REGISTRY: Dict[str, Callable[..., Tuple[CustomModel, MultimodalEmbedding]]] = {
+    "CustomModel": load_custom_model,  # the only loader on the reference's tested path
+}
+
+
+class SimpleTokenizerInfo:
+    """The four attributes of the target tokenizer the model path reads."""
+
+    def __init__(self, vocab_size, pad_token_id=0, bos_token_id=2, eos_token_id=3):
+        self.vocab_size, self.pad_token_id = vocab_size, pad_token_id
+        self.bos_token_id, self.eos_token_id = bos_token_id, eos_token_id
+
+
+class HFWrapper:
+    """wrapper.py:230-655."""
+
+    def __init__(self, data_config: Dict[str, Any], model_type: str, model_name: str, target_tokenizer,
+                 optimiser: str = "adam", num_steps: int = 1000, lr: float = 0.001, weight_decay: float = 0,
+                 adam_beta1: float = 0.9, adam_beta2: float = 0.999, multimodal_norm: bool = True,
+                 modality_dropout: Optional[List[str]] = None, **kwargs) -> None:
+        if isinstance(target_tokenizer, str):
+            raise NotImplementedError("pass a tokenizer object (no HF hub in this build)")
+        self.target_tokenizer = target_tokenizer
+        self.model_type, self.model_name, self.data_config = model_type, model_name, data_config
+        self.multimodal_norm, self.modality_dropout = multimodal_norm, modality_dropout
+        self.guided_generation = kwargs.get("guided_generation", False)
+        self.target_modality = ""
+        for modality, mc in data_config.items():
+            if mc["target"]:
+                self.target_modality = modality
+        self.optimiser, self.lr, self.weight_decay = optimiser, lr, weight_decay
+        self.adam_beta1, self.adam_beta2, self.num_steps = adam_beta1, adam_beta2, num_steps
+        self.validation_step_outputs: List[Dict[str, Any]] = []
+        self.clip_grad = kwargs.pop("clip_grad", 1.0)
+        self.world_size = kwargs.pop("world_size", 1)
+        if model_type not in MODEL_REGISTRY:
+            raise KeyError(f"model_type {model_type!r}: only {list(MODEL_REGISTRY)} are built")
+        self.hf_model, self.multimodal_embedding = MODEL_REGISTRY[model_type](
+            model_name, target_tokenizer, self.target_modality, data_config, multimodal_norm, **kwargs)
+        self.max_length = 128  # generation_config.max_length (wrapper.py:313)
+        self.n_beams = kwargs.get("n_beams", 10)
+        self.training = True
+        self.logged: Dict[str, Any] = {}
+        # _init_params (wrapper.py:320-327) happens in the engine's ParamStore.init_
+
+    # ---- nn.Module-ish
+    def train(self, mode=True):
+        self.training = mode; self.hf_model.train(mode); return self
+
+    def eval(self):
+        return self.train(False)
+
+    def state_dict(self):
+        sd = {}
+        for k, v in self.hf_model.state_dict().items():
+            sd["hf_model." + k] = v
+            if k.startswith("embedding."):
+                sd["multimodal_embedding." + k[len("embedding."):]] = v  # wrapper.py:298 alias
+        return sd
+
+    def load_state_dict(self, sd, strict=True):
+        inner = {k[len("hf_model."):]: v for k, v in sd.items() if k.startswith("hf_model.")}
+        self.hf_model.load_state_dict(inner or sd, strict)
+
+    def log(self, key, value, **_):
+        self.logged[key] = value
+
+    def configure_optimizers(self):
+        """wrapper.py:329-344: optimiser over all params + OneCycleLR stepped per optimiser step."""
+        self.optim = FusedAdamOneCycle(self.hf_model.engine, OPTIMISER_REGISTRY[self.optimiser], lr=self.lr,
+                                       weight_decay=self.weight_decay, adam_beta1=self.adam_beta1,
+                                       adam_beta2=self.adam_beta2, num_steps=self.num_steps,
+                                       clip_grad=self.clip_grad, world_size=self.world_size)
+        return [self.optim], [{"scheduler": self.optim, "interval": "step"}]
+
+    # ---- the hot path
+    def forward(self, batch: Dict[str, Any]) -> CustomLMOutput:
+        """wrapper.py:346-407."""
+        input_ids = {}
+        for modality, ids in batch["encoder_input"].items():
+            input_ids[modality] = ({k: v.transpose(1, 0) for k, v in ids.items()} if isinstance(ids, dict)
+                                   else ids.transpose(1, 0))
+        decoder_input = batch["decoder_input"][self.target_modality].transpose(1, 0)
+        attention_mask = (~batch["encoder_pad_mask"]).int().T
+        decoder_attention_mask = (~batch["decoder_pad_mask"]).int().T
+        labels = batch["target"].T.contiguous().clone()
+        if isinstance(self.modality_dropout, (list, tuple)) and len(self.modality_dropout) and self.training:
+            drop = np.random.choice(self.modality_dropout, np.random.randint(0, len(self.modality_dropout)),
+                                    replace=False)                     # wrapper.py:368-386
+            split, idx = [], 0
+            for modality, ids in input_ids.items():
+                n = (ids["tokenized_input"] if isinstance(ids, dict) else ids).shape[1]
+                if modality not in drop:
+                    split.append(attention_mask[:, idx:idx + n])
+                idx += n
+            for modality in drop:
+                input_ids.pop(modality)
+            attention_mask = torch.concat(split, dim=-1)
+        labels[labels == self.target_tokenizer.pad_token_id] = -100
+        inputs_embeds = self.multimodal_embedding(input_ids)
+        return self.hf_model(inputs_embeds=inputs_embeds, attention_mask=attention_mask.contiguous(),
+                             decoder_input_ids=decoder_input, decoder_attention_mask=decoder_attention_mask.contiguous(),
+                             labels=labels)
+
+    __call__ = forward
+
+    def training_step(self, batch: Dict[str, Any], batch_idx: int, loss_scale: float = 1.0) -> torch.Tensor:
+        """wrapper.py:455-489.  Backward runs inside (the engine is hand-scheduled); gradients
+        accumulate scaled by loss_scale = 1/accumulate_grad_batches as Lightning does."""
+        self.train()
+        self.hf_model.backward_on_forward(True, loss_scale)
+        try:
+            out = self.forward(batch)
+        finally:
+            self.hf_model.backward_on_forward(False)
+        if batch_idx % 10 == 0:
+            self.log("train_loss", out.loss)
+        return out.loss
+
+    def _calc_token_acc(self, batch_input, model_output):
+        """wrapper.py:641-655 incl. its quirk: `target` still holds pad ids, so every position counts."""
+        token_ids = batch_input["target"].T
+        pred = model_output.argmax if model_output.get("argmax") is not None else torch.argmax(model_output.logits, -1)
+        mask = token_ids != -100
+        return ((token_ids == pred) * mask).sum().float() / mask.sum().float()
+
+    def generate(self, batch: Dict[str, Any], n_beams: int = 1, logits_processor=None) -> torch.Tensor:
+        """wrapper.py:409-453 for n_beams == 1: greedy, full-prefix recompute like
+        `use_cache=False`, forced EOS at max_length (KV-cached / beam decode: SURVEY 8f rank 1)."""
+        if n_beams != 1 or logits_processor is not None:
+            raise NotImplementedError("beam search / guided generation: SURVEY 8f, not built yet")
+        tok = self.target_tokenizer
+        input_ids = {m: (v.transpose(1, 0) if not isinstance(v, dict) else {k: t.transpose(1, 0) for k, t in v.items()})
+                     for m, v in batch["encoder_input"].items()}
+        attention_mask = (~batch["encoder_pad_mask"]).int().T.contiguous()
+        was = self.training
+        self.eval()
+        enc = self.hf_model.encoder(attention_mask=attention_mask, inputs_embeds=self.multimodal_embedding(input_ids))
+        B = attention_mask.shape[0]
+        ids = torch.full((B, 1), tok.bos_token_id, dtype=torch.long, device=attention_mask.device)
+        done = torch.zeros(B, dtype=torch.bool, device=ids.device)
+        while ids.shape[1] < self.max_length:
+            lg = self.hf_model(encoder_outputs=enc, attention_mask=attention_mask, decoder_input_ids=ids).logits
+            nxt = lg[:, -1].argmax(-1)
+            if ids.shape[1] == self.max_length - 1:
+                nxt = torch.full_like(nxt, tok.eos_token_id)
+            nxt = torch.where(done, torch.full_like(nxt, tok.pad_token_id), nxt)
+            ids = torch.cat([ids, nxt[:, None]], 1)
+            done = done | (nxt == tok.eos_token_id)
+            if bool(done.all()):
+                break
+        self.train(was)
+        return ids
+
+    def validation_step(self, batch: Dict[str, Any], batch_idx: int) -> Dict[str, Any]:  # noqa: ARG002
+        """wrapper.py:491-525 without the RDKit Top-1 (host chemistry metric, out of scope)."""
+        self.eval()
+        out = self.forward(batch)
+        val = {"val_loss": out.loss, "val_token_acc": self._calc_token_acc(batch, out)}
+        self.validation_step_outputs.append(val)
+        return val
+
+    def predict_step(self, batch, batch_idx):  # noqa: ARG002
+        """wrapper.py:532-578 (greedy ids instead of decoded beam strings)."""
+        self.eval()
+        out = self.forward(batch)
+        return {"loss": out.loss, "predictions": self.generate(batch, n_beams=1), "targets": batch.get("target_smiles")}

@@ -1,0 +1,118 @@
+"""Synthetic "synth-177K" batches (SURVEY.md section 8d / BASELINE.md section 2): seeded, generated
+on the box, no chemistry.  Produces the SAME seq-first batch dict the reference's
+MultiModalDataCollator emits (reference data/datamodules.py:201-218): text modalities (S_m, B)
+int64, patch modalities (P, B, ps) fp32, `encoder_pad_mask` (S, B) bool True = pad,
+`decoder_input` / `target` shifted by one, `decoder_pad_mask`.
+
+Workloads (BASELINE.json `configs`):
+  c1  tiny 2L/d128, IR-only (Formula 12 + 14 patches of 125), T=40, B=8       (plumbing)
+  c2  base 6L/d512/h8/f2048, IR-only: Formula 32 + 992 patches of 2 -> S=1024, T=128
+  c3  base, Formula 32 + IR 24x75 + Multiplets 968 -> S=1024
+  c4  12L/d768/h12/f3072, Formula 32 + IR 24x75 + Multiplets 768 + Carbon 200 -> S=1024
+  c5  base gated, Formula 32 + IR 24x75 -> S=56, T=256 (mixture decode shape)
+"""
+from __future__ import annotations
+
+from typing import Any, Dict, Tuple
+
+import numpy as np
+import torch
+
+PAD, UNK, BOS, EOS = 0, 1, 2, 3  # data/tokenizer.py:22
+
+
+def _text(vocab, target=False):
+    return {"type": "text", "vocab_size": vocab, "pad_token_id": PAD, "target": target}
+
+
+def _patch(ps):
+    return {"type": "1D_patches", "target": False,
+            "preprocessor_arguments": {"patch_size": ps, "interpolation": False, "masking": False}}
+
+
+BASE = dict(d_model=512, encoder_layers=6, decoder_layers=6, encoder_attention_heads=8, decoder_attention_heads=8,
+            encoder_ffn_dim=2048, decoder_ffn_dim=2048, dropout=0.1, gated_linear=False,
+            positional_encoding_type="sin_cos", max_position_embeddings=1024, multimodal_norm=True)
+
+WORKLOADS: Dict[str, Dict[str, Any]] = {
+    "c1": dict(cfg=dict(BASE, d_model=128, encoder_layers=2, decoder_layers=2, encoder_ffn_dim=512, decoder_ffn_dim=512),
+               data={"Formula": _text(64), "IR": _patch(125), "Smiles": _text(128, True)},
+               lens={"Formula": (12, 4, 10), "IR": 14}, T=40, batch=8),
+    "c2": dict(cfg=dict(BASE), data={"Formula": _text(64), "IR": _patch(2), "Smiles": _text(128, True)},
+               lens={"Formula": (32, 6, 20), "IR": 992}, T=128, batch=128),
+    "c3": dict(cfg=dict(BASE), data={"Formula": _text(64), "IR": _patch(75),
+                                     "Multiplets": {**_text(2048), "type": "multiplets"}, "Smiles": _text(128, True)},
+               lens={"Formula": (32, 6, 20), "IR": 24, "Multiplets": (968, 100, 760)}, T=128, batch=128),
+    "c4": dict(cfg=dict(BASE, d_model=768, encoder_layers=12, decoder_layers=12, encoder_attention_heads=12,
+                        decoder_attention_heads=12, encoder_ffn_dim=3072, decoder_ffn_dim=3072, gated_linear=True,
+                        positional_encoding_type="learned"),
+               data={"Formula": _text(64), "IR": _patch(75), "Multiplets": {**_text(2048), "type": "multiplets"},
+                     "Carbon": {**_text(2304), "type": "carbon"}, "Smiles": _text(128, True)},
+               lens={"Formula": (32, 6, 20), "IR": 24, "Multiplets": (768, 100, 760), "Carbon": (200, 20, 190)},
+               T=128, batch=128),
+    "c5": dict(cfg=dict(BASE, gated_linear=True), data={"Formula": _text(64), "IR": _patch(75), "Smiles": _text(128, True)},
+               lens={"Formula": (32, 6, 20), "IR": 24}, T=256, batch=128),
+}
+
+
+def train_flops_per_sample(cfg, S, T, V, patch_flops=0.0) -> float:
+    """3 x forward FLOPs: Le(8Sd^2+4S^2d+gSdf) + Ld(12Td^2+4Sd^2+4T^2d+4TSd+gTdf) + 2TdV."""
+    d, g = cfg["d_model"], (6 if cfg["gated_linear"] else 4)
+    fe, fd = cfg["encoder_ffn_dim"], cfg["decoder_ffn_dim"]
+    enc = cfg["encoder_layers"] * (8 * S * d * d + 4 * S * S * d + g * S * d * fe)
+    dec = cfg["decoder_layers"] * (12 * T * d * d + 4 * S * d * d + 4 * T * T * d + 4 * T * S * d + g * T * d * fd)
+    return 3.0 * (enc + dec + 2 * T * d * V + patch_flops)
+
+
+def make_batch(name: str, batch: int, seed: int, device="cpu") -> Tuple[Dict[str, Any], Dict[str, Any]]:
+    """One seq-first batch dict of workload `name` (+ the workload record)."""
+    w = WORKLOADS[name]
+    rng = np.random.default_rng(seed)
+    enc, masks = {}, []
+    for m, spec in w["lens"].items():
+        mc = w["data"][m]
+        if isinstance(spec, tuple):
+            L, lo, hi = spec
+            V = mc["vocab_size"]
+            n = rng.integers(lo, hi + 1, size=batch) + 2          # + bos/eos
+            ids = rng.integers(4, V, size=(L, batch)).astype(np.int64)
+            pos = np.arange(L)[:, None]
+            ids[0, :] = BOS
+            ids[np.minimum(n - 1, L - 1), np.arange(batch)] = EOS
+            pad = pos >= n[None, :]
+            ids[pad] = PAD
+            enc[m] = torch.from_numpy(ids)
+            masks.append(torch.from_numpy(pad))
+        else:
+            P, ps = spec, mc["preprocessor_arguments"]["patch_size"]
+            x = np.abs(rng.standard_normal((batch, P * ps))).astype(np.float32)
+            k = np.exp(-0.5 * (np.arange(-9, 10) / 3.0) ** 2); k /= k.sum()       # sigma=3 smoothing
+            x = np.apply_along_axis(lambda r: np.convolve(r, k, mode="same"), 1, x)
+            x = (x - x.mean()) / (x.std() + 1e-8)                                  # PatchPreprocessor standardise
+            enc[m] = torch.from_numpy(np.ascontiguousarray(x.reshape(batch, P, ps).transpose(1, 0, 2)).astype(np.float32))
+            masks.append(torch.zeros(P, batch, dtype=torch.bool))
+    T, V = w["T"], w["data"]["Smiles"]["vocab_size"]
+    n = rng.integers(20, min(120, T - 8) + 1, size=batch) + 2
+    ids = rng.integers(4, V, size=(T + 1, batch)).astype(np.int64)
+    ids[0, :] = BOS
+    ids[n - 1, np.arange(batch)] = EOS
+    ids[np.arange(T + 1)[:, None] >= n[None, :]] = PAD
+    ids = torch.from_numpy(ids)
+    b = {
+        "encoder_input": enc,
+        "encoder_pad_mask": torch.cat(masks, 0),
+        "decoder_input": {"Smiles": ids[:-1].contiguous()},
+        "decoder_pad_mask": ids[:-1] == PAD,
+        "target": ids[1:].contiguous(),
+    }
+    if device != "cpu":
+        b = to_device(b, device)
+    return b, w
+
+
+def to_device(b, device):
+    if isinstance(b, dict):
+        return {k: to_device(v, device) for k, v in b.items()}
+    if torch.is_tensor(b):
+        return b.to(device, non_blocking=True)
+    return b
