@@ -37,6 +37,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=2)
+    ap.add_argument("--cpu-threads", type=int, default=32)
     return ap.parse_args()
 
 
@@ -77,13 +78,13 @@ def dominant_kernel_roofline(model, wl, B, dtype):
             "avg_launch_ms": round(ms, 4)}
 
 
-def cpu_baseline(model, wl, name, cpu_batch):
+def cpu_baseline(model, wl, name, cpu_batch, threads):
     """The CPU oracle (oracle/afm_oracle.py, a port of the reference arithmetic) on this host's
     cores: forward + backward + clip + AdamW of ONE micro-batch of `cpu_batch` samples of the same
     workload, same weights."""
     from multimodalanalytical_amd import synth
     from oracle import afm_oracle as O
-    cores = os.cpu_count() or 1
+    cores = max(1, min(threads, os.cpu_count() or 1))   # torch CPU thread pool size actually used
     torch.set_num_threads(cores)
     eng = model.hf_model.engine
     sd = {k: v.detach().float().cpu() for k, v in eng.state_dict().items() if not k.startswith("decoder.embedding.")}
@@ -172,7 +173,7 @@ def main():
         if not args.no_roofline:
             out["roofline"] = dominant_kernel_roofline(model, wl, B, args.dtype)
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(model, wl, args.workload, args.cpu_batch)
+            out["cpu_baseline"] = cpu_baseline(model, wl, args.workload, args.cpu_batch, args.cpu_threads)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -230,14 +230,13 @@ extern "C" int afm_attn_fwd(const afm_attn_shape* s, const void* Q, const void* 
   const dim3 grid((unsigned)((nrows + 3) / 4));
   if (s->dtype == AFM_F32) {
     if (shm > 64 * 1024) hipFuncSetAttribute((const void*)k_attn_fwd_generic<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
-    hipLaunchKernelGGL(k_attn_fwd_generic<float>, grid, dim3(256), shm, st, a, (const float*)Q,
+    AFM_LAUNCH(k_attn_fwd_generic<float>, grid, dim3(256), shm, st, a, (const float*)Q,
                        (const float*)K, (const float*)V, (float*)O, lse);
   } else {
     if (shm > 64 * 1024) hipFuncSetAttribute((const void*)k_attn_fwd_generic<bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
-    hipLaunchKernelGGL(k_attn_fwd_generic<bf16>, grid, dim3(256), shm, st, a, (const bf16*)Q,
+    AFM_LAUNCH(k_attn_fwd_generic<bf16>, grid, dim3(256), shm, st, a, (const bf16*)Q,
                        (const bf16*)K, (const bf16*)V, (bf16*)O, lse);
   }
-  AFM_CHECK_LAUNCH();
   afm_set_last_algo("attn_generic");
   return AFM_OK;
 }
@@ -267,12 +266,10 @@ extern "C" int afm_attn_bwd(const afm_attn_shape* s, const void* Q, const void* 
   do {                                                                                                \
     if (shm_q > 64 * 1024) hipFuncSetAttribute((const void*)k_attn_bwd_q_generic<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm_q); \
     if (shm_k > 64 * 1024) hipFuncSetAttribute((const void*)k_attn_bwd_kv_generic<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm_k); \
-    hipLaunchKernelGGL(k_attn_bwd_q_generic<T>, gq, dim3(256), shm_q, st, a, (const T*)Q, (const T*)K, \
+    AFM_LAUNCH(k_attn_bwd_q_generic<T>, gq, dim3(256), shm_q, st, a, (const T*)Q, (const T*)K, \
                        (const T*)V, (const T*)O, (const T*)dO, lse, delta, (T*)dQ, lddq);              \
-    AFM_CHECK_LAUNCH();                                                                               \
-    hipLaunchKernelGGL(k_attn_bwd_kv_generic<T>, gk, dim3(256), shm_k, st, a, (const T*)Q, (const T*)K, \
+    AFM_LAUNCH(k_attn_bwd_kv_generic<T>, gk, dim3(256), shm_k, st, a, (const T*)Q, (const T*)K, \
                        (const T*)V, (const T*)dO, lse, delta, (T*)dK, (T*)dV, lddk, lddv);             \
-    AFM_CHECK_LAUNCH();                                                                               \
   } while (0)
   if (s->dtype == AFM_F32) LAUNCH_BWD(float); else LAUNCH_BWD(bf16);
 #undef LAUNCH_BWD

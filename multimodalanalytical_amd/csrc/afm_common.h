@@ -13,9 +13,14 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 #define AFM_WAVE 64
 
-#define AFM_CHECK_LAUNCH()                                   \
-  do {                                                       \
-    if (hipGetLastError() != hipSuccess) return AFM_ERR_LAUNCH; \
+// Launch + check.  hipGetLastError() is per-thread and sticky: torch's own runtime calls (e.g. an
+// event query answering hipErrorNotReady) leave stale codes behind, so clear it before launching
+// and only then read it back.
+#define AFM_LAUNCH(kern, grid, block, shm, st, ...)                        \
+  do {                                                                     \
+    (void)hipGetLastError();                                               \
+    hipLaunchKernelGGL(kern, grid, block, shm, st, __VA_ARGS__);           \
+    if (hipGetLastError() != hipSuccess) return AFM_ERR_LAUNCH;            \
   } while (0)
 
 // thread-local name of the kernel family last dispatched (afm_last_algo)

@@ -43,9 +43,8 @@ extern "C" int afm_gather_rows(const int64_t* ids, const float* scale, const flo
                                int64_t n, int32_t d, int32_t V, void* stream) {
   if (!ids || !table || !out || n < 0 || d <= 0 || V <= 0) return AFM_ERR_ARG;
   if (n == 0) return AFM_OK;
-  hipLaunchKernelGGL(k_gather_rows, dim3(grid_for(n * 64, 256)), dim3(256), 0, (hipStream_t)stream,
+  AFM_LAUNCH(k_gather_rows, dim3(grid_for(n * 64, 256)), dim3(256), 0, (hipStream_t)stream,
                      ids, scale, table, out, n, d, V);
-  AFM_CHECK_LAUNCH();
   return AFM_OK;
 }
 
@@ -70,9 +69,8 @@ extern "C" int afm_scatter_add_rows(const int64_t* ids, const float* scale, cons
                                     int64_t padding_idx, void* stream) {
   if (!ids || !dout || !dtable || n < 0 || d <= 0 || V <= 0) return AFM_ERR_ARG;
   if (n == 0) return AFM_OK;
-  hipLaunchKernelGGL(k_scatter_add_rows, dim3(grid_for(n * 64, 256)), dim3(256), 0,
+  AFM_LAUNCH(k_scatter_add_rows, dim3(grid_for(n * 64, 256)), dim3(256), 0,
                      (hipStream_t)stream, ids, scale, dout, dtable, n, d, V, padding_idx);
-  AFM_CHECK_LAUNCH();
   return AFM_OK;
 }
 
@@ -98,14 +96,13 @@ extern "C" int afm_glu_fwd(const void* u, const void* v, void* g, int64_t rows, 
   const DropDev dd = afm_make_drop(drop);
   const int grid = grid_for(rows * f, 256);
   if (dtype == AFM_F32)
-    hipLaunchKernelGGL(k_glu_fwd<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream,
+    AFM_LAUNCH(k_glu_fwd<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream,
                        (const float*)u, (const float*)v, (float*)g, rows, f, ldu, ldv, ldg, dd);
   else if (dtype == AFM_BF16)
-    hipLaunchKernelGGL(k_glu_fwd<bf16>, dim3(grid), dim3(256), 0, (hipStream_t)stream,
+    AFM_LAUNCH(k_glu_fwd<bf16>, dim3(grid), dim3(256), 0, (hipStream_t)stream,
                        (const bf16*)u, (const bf16*)v, (bf16*)g, rows, f, ldu, ldv, ldg, dd);
   else
     return AFM_ERR_ARG;
-  AFM_CHECK_LAUNCH();
   return AFM_OK;
 }
 
@@ -137,16 +134,15 @@ extern "C" int afm_glu_bwd(const void* u, const void* v, const void* dg, void* d
   const DropDev dd = afm_make_drop(drop);
   const int grid = grid_for(rows * f, 256);
   if (dtype == AFM_F32)
-    hipLaunchKernelGGL(k_glu_bwd<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream,
+    AFM_LAUNCH(k_glu_bwd<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream,
                        (const float*)u, (const float*)v, (const float*)dg, (float*)du, (float*)dv,
                        rows, f, ldu, ldv, lddg, lddu, lddv, dd);
   else if (dtype == AFM_BF16)
-    hipLaunchKernelGGL(k_glu_bwd<bf16>, dim3(grid), dim3(256), 0, (hipStream_t)stream,
+    AFM_LAUNCH(k_glu_bwd<bf16>, dim3(grid), dim3(256), 0, (hipStream_t)stream,
                        (const bf16*)u, (const bf16*)v, (const bf16*)dg, (bf16*)du, (bf16*)dv, rows,
                        f, ldu, ldv, lddg, lddu, lddv, dd);
   else
     return AFM_ERR_ARG;
-  AFM_CHECK_LAUNCH();
   return AFM_OK;
 }
 
@@ -170,14 +166,13 @@ extern "C" int afm_dropout_cast(const float* x, void* y, int64_t rows, int32_t n
   const DropDev dd = afm_make_drop(drop);
   const int grid = grid_for(rows * n, 256);
   if (y_dtype == AFM_F32)
-    hipLaunchKernelGGL(k_dropout_cast<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, x,
+    AFM_LAUNCH(k_dropout_cast<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, x,
                        (float*)y, rows, n, ldx, ldy, dd);
   else if (y_dtype == AFM_BF16)
-    hipLaunchKernelGGL(k_dropout_cast<bf16>, dim3(grid), dim3(256), 0, (hipStream_t)stream, x,
+    AFM_LAUNCH(k_dropout_cast<bf16>, dim3(grid), dim3(256), 0, (hipStream_t)stream, x,
                        (bf16*)y, rows, n, ldx, ldy, dd);
   else
     return AFM_ERR_ARG;
-  AFM_CHECK_LAUNCH();
   return AFM_OK;
 }
 
@@ -214,12 +209,11 @@ extern "C" int afm_colsum(const void* x, float* out, int64_t rows, int32_t n, in
   if (gy > cap) gy = cap;
   if (gy < 1) gy = 1;
   if (dtype == AFM_F32)
-    hipLaunchKernelGGL(k_colsum<float>, dim3(gx, gy), dim3(256), 0, st, (const float*)x, out, rows, n, ld);
+    AFM_LAUNCH(k_colsum<float>, dim3(gx, gy), dim3(256), 0, st, (const float*)x, out, rows, n, ld);
   else if (dtype == AFM_BF16)
-    hipLaunchKernelGGL(k_colsum<bf16>, dim3(gx, gy), dim3(256), 0, st, (const bf16*)x, out, rows, n, ld);
+    AFM_LAUNCH(k_colsum<bf16>, dim3(gx, gy), dim3(256), 0, st, (const bf16*)x, out, rows, n, ld);
   else
     return AFM_ERR_ARG;
-  AFM_CHECK_LAUNCH();
   return AFM_OK;
 }
 
@@ -231,8 +225,7 @@ __global__ void k_add_inplace(float* __restrict__ y, const float* __restrict__ x
 extern "C" int afm_add_inplace(float* y, const float* x, int64_t n, void* stream) {
   if (!y || !x || n < 0) return AFM_ERR_ARG;
   if (n == 0) return AFM_OK;
-  hipLaunchKernelGGL(k_add_inplace, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, y, x, n);
-  AFM_CHECK_LAUNCH();
+  AFM_LAUNCH(k_add_inplace, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, y, x, n);
   return AFM_OK;
 }
 
@@ -250,9 +243,8 @@ extern "C" int afm_batch_sum(const float* x, float* out, int32_t B, int64_t S, i
                              int32_t accumulate, void* stream) {
   if (!x || !out || B <= 0 || S < 0 || d <= 0) return AFM_ERR_ARG;
   if (S == 0) return AFM_OK;
-  hipLaunchKernelGGL(k_batch_sum, dim3(grid_for(S * d, 256)), dim3(256), 0, (hipStream_t)stream, x,
+  AFM_LAUNCH(k_batch_sum, dim3(grid_for(S * d, 256)), dim3(256), 0, (hipStream_t)stream, x,
                      out, B, S, d, accumulate);
-  AFM_CHECK_LAUNCH();
   return AFM_OK;
 }
 
@@ -283,8 +275,7 @@ __global__ void k_cast_bf16(const float* __restrict__ src, bf16* __restrict__ ds
 extern "C" int afm_cast_bf16(const float* src, void* dst, void* dst_t, int32_t rows, int32_t cols,
                              void* stream) {
   if (!src || (!dst && !dst_t) || rows <= 0 || cols <= 0) return AFM_ERR_ARG;
-  hipLaunchKernelGGL(k_cast_bf16, dim3((cols + 63) / 64, (rows + 63) / 64), dim3(256), 0,
+  AFM_LAUNCH(k_cast_bf16, dim3((cols + 63) / 64, (rows + 63) / 64), dim3(256), 0,
                      (hipStream_t)stream, src, (bf16*)dst, (bf16*)dst_t, rows, cols);
-  AFM_CHECK_LAUNCH();
   return AFM_OK;
 }

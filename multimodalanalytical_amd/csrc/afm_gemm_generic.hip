@@ -137,8 +137,7 @@ static int gemm_generic(const afm_gemm_desc* d, hipStream_t st) {
         return AFM_ERR_LAUNCH;
     }
   }
-  hipLaunchKernelGGL(k_gemm_generic, dim3(gx, gy, splits), dim3(256), 0, st, g);
-  AFM_CHECK_LAUNCH();
+  AFM_LAUNCH(k_gemm_generic, dim3(gx, gy, splits), dim3(256), 0, st, g);
   afm_set_last_algo(splits > 1 ? "generic_splitk" : "generic");
   return AFM_OK;
 }

@@ -77,11 +77,11 @@ extern "C" int afm_layernorm_fwd(const afm_ln_shape* s, const float* x, const fl
 #define LN_FWD(NV)                                                                                  \
   do {                                                                                              \
     if (s->y_dtype == AFM_F32)                                                                      \
-      hipLaunchKernelGGL((k_ln_fwd<float, NV>), dim3((int)g), dim3(256), 0, st, x, gamma, beta, pos, \
+      AFM_LAUNCH((k_ln_fwd<float, NV>), dim3((int)g), dim3(256), 0, st, x, gamma, beta, pos, \
                          (float*)y, mean, rstd, s->rows, s->d, s->seg_len, s->out_seg_stride,       \
                          s->out_off, s->eps);                                                       \
     else                                                                                            \
-      hipLaunchKernelGGL((k_ln_fwd<bf16, NV>), dim3((int)g), dim3(256), 0, st, x, gamma, beta, pos,  \
+      AFM_LAUNCH((k_ln_fwd<bf16, NV>), dim3((int)g), dim3(256), 0, st, x, gamma, beta, pos,  \
                          (bf16*)y, mean, rstd, s->rows, s->d, s->seg_len, s->out_seg_stride,        \
                          s->out_off, s->eps);                                                       \
   } while (0)
@@ -90,7 +90,6 @@ extern "C" int afm_layernorm_fwd(const afm_ln_shape* s, const float* x, const fl
   else if (nv <= 8) LN_FWD(8); else if (nv <= 12) LN_FWD(12); else if (nv <= 16) LN_FWD(16);
   else LN_FWD(32);
 #undef LN_FWD
-  AFM_CHECK_LAUNCH();
   return AFM_OK;
 }
 
@@ -198,11 +197,11 @@ extern "C" int afm_layernorm_bwd(const afm_ln_shape* s, const void* dy, const fl
 #define LN_BWD(NV)                                                                                   \
   do {                                                                                               \
     if (s->y_dtype == AFM_F32)                                                                       \
-      hipLaunchKernelGGL((k_ln_bwd<float, NV>), dim3(g), dim3(256), shm, st, (const float*)dy, x,     \
+      AFM_LAUNCH((k_ln_bwd<float, NV>), dim3(g), dim3(256), shm, st, (const float*)dy, x,     \
                          gamma, mean, rstd, dres, dx, partial, s->rows, s->d, s->seg_len,            \
                          s->out_seg_stride, s->out_off);                                             \
     else                                                                                             \
-      hipLaunchKernelGGL((k_ln_bwd<bf16, NV>), dim3(g), dim3(256), shm, st, (const bf16*)dy, x, gamma, \
+      AFM_LAUNCH((k_ln_bwd<bf16, NV>), dim3(g), dim3(256), shm, st, (const bf16*)dy, x, gamma, \
                          mean, rstd, dres, dx, partial, s->rows, s->d, s->seg_len,                   \
                          s->out_seg_stride, s->out_off);                                             \
   } while (0)
@@ -211,9 +210,7 @@ extern "C" int afm_layernorm_bwd(const afm_ln_shape* s, const void* dy, const fl
   else if (nv <= 8) LN_BWD(8); else if (nv <= 12) LN_BWD(12); else if (nv <= 16) LN_BWD(16);
   else LN_BWD(32);
 #undef LN_BWD
-  AFM_CHECK_LAUNCH();
-  hipLaunchKernelGGL(k_ln_bwd_reduce, dim3((2 * s->d + 255) / 256), dim3(256), 0, st, partial, dgamma,
+  AFM_LAUNCH(k_ln_bwd_reduce, dim3((2 * s->d + 255) / 256), dim3(256), 0, st, partial, dgamma,
                      dbeta, g, s->d);
-  AFM_CHECK_LAUNCH();
   return AFM_OK;
 }

@@ -53,9 +53,8 @@ extern "C" int afm_ce_fwd(const float* logits, const int64_t* labels, int64_t ro
                           int32_t ld, float* row_lse, int64_t* argmax, float* stats, void* stream) {
   if (!logits || rows < 0 || V <= 0 || ld < V) return AFM_ERR_ARG;
   if (rows == 0) return AFM_OK;
-  hipLaunchKernelGGL(k_ce_fwd, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+  AFM_LAUNCH(k_ce_fwd, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
                      logits, labels, rows, V, ld, row_lse, argmax, stats);
-  AFM_CHECK_LAUNCH();
   return AFM_OK;
 }
 
@@ -91,13 +90,12 @@ extern "C" int afm_ce_bwd(const float* logits, const int64_t* labels, const floa
   if (g > 2048) g = 2048;
   hipStream_t st = (hipStream_t)stream;
   if (dl_dtype == AFM_F32)
-    hipLaunchKernelGGL(k_ce_bwd<float>, dim3((int)g), dim3(256), 0, st, logits, labels, row_lse, stats,
+    AFM_LAUNCH(k_ce_bwd<float>, dim3((int)g), dim3(256), 0, st, logits, labels, row_lse, stats,
                        grad_scale, (float*)dlogits, lddl, rows, V, ld);
   else if (dl_dtype == AFM_BF16)
-    hipLaunchKernelGGL(k_ce_bwd<bf16>, dim3((int)g), dim3(256), 0, st, logits, labels, row_lse, stats,
+    AFM_LAUNCH(k_ce_bwd<bf16>, dim3((int)g), dim3(256), 0, st, logits, labels, row_lse, stats,
                        grad_scale, (bf16*)dlogits, lddl, rows, V, ld);
   else
     return AFM_ERR_ARG;
-  AFM_CHECK_LAUNCH();
   return AFM_OK;
 }

@@ -30,8 +30,7 @@ extern "C" int afm_sumsq(const float* g, int64_t n, float* out, void* stream) {
   int64_t blocks = (n / 4 + 255) / 256;
   if (blocks > 2048) blocks = 2048;
   if (blocks < 1) blocks = 1;
-  hipLaunchKernelGGL(k_sumsq, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, g, n, out);
-  AFM_CHECK_LAUNCH();
+  AFM_LAUNCH(k_sumsq, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, g, n, out);
   return AFM_OK;
 }
 
@@ -72,8 +71,7 @@ extern "C" int afm_adam_step(float* p, float* g, float* m, float* v, int64_t n, 
   if (n == 0) return AFM_OK;
   int64_t blocks = (n + 255) / 256;
   if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(k_adam, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, hyper,
+  AFM_LAUNCH(k_adam, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, hyper,
                      sumsq, (bf16*)p_bf16, zero_grad);
-  AFM_CHECK_LAUNCH();
   return AFM_OK;
 }

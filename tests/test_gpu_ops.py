@@ -305,3 +305,69 @@ def test_adam_against_oracle(ops):
             close(pd, pr, 1e-5, 1e-6, f"adam t={t}")
             assert float(gd.abs().max()) == 0.0
             close(shadow, pd.float().cpu().bfloat16(), 0, 0)
+
+
+# ------------------------------------------------------------------ MFMA GEMMs (bf16 operands, fp32 accumulate)
+@pytest.mark.parametrize("M,N,K", [(256, 256, 128), (100, 200, 72), (1000, 1536, 512), (384, 64, 2048), (129, 24, 64)])
+@pytest.mark.parametrize("cdt", [torch.bfloat16, torch.float32])
+def test_gemm_mfma_nt(ops, M, N, K, cdt):
+    a, w, bias = rnd(M, K, seed=1).bfloat16(), rnd(N, K, seed=2).bfloat16(), rnd(N, seed=3)
+    c = torch.empty(M, N, dtype=cdt, device=DEV)
+    ops.gemm(dev(a), dev(w), c, bias=dev(bias), algo=2)
+    assert ops.last_algo() == "mfma_nt"
+    ref = a.double() @ w.double().T + bias.double()
+    tol = dict(rtol=1e-2, atol=1e-2 * math.sqrt(K) / 4) if cdt == torch.bfloat16 else dict(rtol=1e-4, atol=2e-4 * math.sqrt(K) / 8)
+    close(c, ref, **tol)
+
+
+def test_gemm_mfma_nt_identity_asymmetric(ops):
+    # A = I with an asymmetric B: catches a transposed C write or swapped fragment maps exactly
+    n = 128
+    a = torch.eye(n).bfloat16()
+    w = (torch.arange(n * n).view(n, n) % 251 - 125).float().bfloat16()
+    c = torch.empty(n, n, device=DEV)
+    ops.gemm(dev(a), dev(w), c, algo=2)
+    close(c, w.float().T, 0, 0)
+
+
+def test_gemm_mfma_nt_epilogue(ops):
+    M, N, K = 200, 136, 96
+    a, w, bias, res = rnd(M, K, seed=1).bfloat16(), rnd(N, K, seed=2).bfloat16(), rnd(N, seed=3), rnd(M, N, seed=4)
+    p, seed, site = 0.1, 77, 11
+    c = torch.empty(M, N, device=DEV); pre = torch.empty(M, N, device=DEV)
+    ops.gemm(dev(a), dev(w), c, bias=dev(bias), residual=dev(res), pre_act=pre, act=2, dropout=ops.drop(p, seed, site), algo=2)
+    t = a.double() @ w.double().T + bias.double()
+    keep = torch.from_numpy(keep_mask(p, seed, site, M * N)).view(M, N)
+    close(pre, t, 1e-4, 1e-4)
+    close(c, O.gelu(t) * keep / (1 - p) + res.double(), 1e-4, 1e-4)
+    # strided operands / output (the packed-projection slices) and accumulate
+    big_w = rnd(3 * N, K, seed=5).bfloat16(); wd = dev(big_w)
+    out = torch.zeros(M, 2 * N, dtype=torch.bfloat16, device=DEV)
+    ops.gemm(dev(a), wd[N:2 * N], out[:, N:], algo=2)
+    close(out[:, N:], a.double() @ big_w[N:2 * N].double().T, 1e-2, 3e-2)
+    assert float(out[:, :N].abs().max()) == 0.0
+    acc0 = rnd(M, N, seed=6); cacc = dev(acc0).clone()
+    ops.gemm(dev(a), dev(w), cacc, accumulate=True, algo=2)
+    close(cacc, acc0.double() + a.double() @ w.double().T, 1e-4, 1e-4)
+
+
+@pytest.mark.parametrize("R,M,N", [(512, 128, 128), (1000, 192, 64), (4096, 1536, 512), (777, 24, 64), (8192, 128, 2048)])
+def test_gemm_mfma_tn_wgrad(ops, R, M, N):
+    dy, x = rnd(R, M, seed=1).bfloat16(), rnd(R, N, seed=2).bfloat16()
+    g0 = rnd(M, N, seed=3)
+    g = dev(g0).clone()
+    ops.gemm(dev(dy), dev(x), g, trans_a=True, trans_b=False, accumulate=True, algo=2)
+    assert ops.last_algo().startswith("mfma_tn")
+    close(g, g0.double() + dy.double().T @ x.double(), 1e-4, 2e-4 * math.sqrt(R) / 4)
+    g2 = torch.full((M, N), 3.0, device=DEV)
+    ops.gemm(dev(dy), dev(x), g2, trans_a=True, trans_b=False, accumulate=False, algo=2)
+    close(g2, dy.double().T @ x.double(), 1e-4, 2e-4 * math.sqrt(R) / 4)
+
+
+def test_gemm_mfma_tn_identity(ops):
+    R = 128
+    dy = torch.eye(R).bfloat16()                                    # dy^T x = x
+    x = (torch.arange(R * 64).view(R, 64) % 241 - 120).float().bfloat16()
+    g = torch.zeros(R, 64, device=DEV)
+    ops.gemm(dev(dy), dev(x), g, trans_a=True, trans_b=False, algo=2)
+    close(g, x.float(), 0, 0)

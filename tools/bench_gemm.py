@@ -1,0 +1,33 @@
+"""Micro-benchmark of afm_gemm at the training step's GEMM shapes (HIP events, per-launch average)."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from multimodalanalytical_amd import ops
+
+def t(fn, it=20, warm=3):
+    for _ in range(warm): fn()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize(); a.record()
+    for _ in range(it): fn()
+    b.record(); torch.cuda.synchronize()
+    return a.elapsed_time(b) / it
+
+def main():
+    B, S, T, d, f = 128, 1024, 128, 512, 2048
+    dev = "cuda:0"
+    shapes = [("qkv fwd", B*S, 3*d, d), ("out fwd", B*S, d, d), ("ffn1 fwd", B*S, f, d), ("ffn2 fwd", B*S, d, f),
+              ("dec qkv", B*T, 3*d, d), ("lm head", B*T, 128, d)]
+    for name, M, N, K in shapes:
+        a = torch.randn(M, K, device=dev).bfloat16(); w = torch.randn(N, K, device=dev).bfloat16()
+        for cdt in (torch.bfloat16, torch.float32):
+            c = torch.empty(M, N, dtype=cdt, device=dev)
+            ms = t(lambda: ops.gemm(a, w, c))
+            print(f"NT {name:10s} {M}x{N}x{K} out {str(cdt)[6:]:8s} {ops.last_algo():10s} {ms:8.3f} ms {2*M*N*K/ms/1e9:8.1f} TF/s")
+    for name, R, M, N in [("wgrad qkv", B*S, 3*d, d), ("wgrad out", B*S, d, d), ("wgrad ffn1", B*S, f, d), ("wgrad ffn2", B*S, d, f)]:
+        dy = torch.randn(R, M, device=dev).bfloat16(); x = torch.randn(R, N, device=dev).bfloat16()
+        g = torch.zeros(M, N, device=dev)
+        ms = t(lambda: ops.gemm(dy, x, g, trans_a=True, trans_b=False, accumulate=True))
+        print(f"TN {name:10s} {R}: {M}x{N} {ops.last_algo():14s} {ms:8.3f} ms {2*M*N*R/ms/1e9:8.1f} TF/s")
+
+if __name__ == "__main__":
+    main()
