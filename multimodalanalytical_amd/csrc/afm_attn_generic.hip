@@ -69,7 +69,7 @@ __global__ __launch_bounds__(256) void k_attn_fwd_generic(AttnArgs a, const T* _
   for (int j = lane; j < a.dh; j += 64) {
     float acc = 0.f;
     for (int k = 0; k < a.Tk; ++k) {
-      const float p = afm_drop(a.dd, didx + k, sc[k]);
+      const float p = afm_drop16(a.dd, didx + k, sc[k]);
       acc = fmaf(p, ld_f32(V + ((int64_t)b * a.Tk + k) * a.ldv + (int64_t)h * a.dh, j), acc);
     }
     st_f32(op, j, acc * inv_l);
@@ -118,7 +118,7 @@ __global__ __launch_bounds__(256) void k_attn_bwd_q_generic(
         dp = fmaf(dov[j], ld_f32(vp, j), dp);
       }
       const float p = expf(s * a.scale - L);
-      dp = afm_drop(a.dd, didx + k, dp);
+      dp = afm_drop16(a.dd, didx + k, dp);
       d = p * (dp - dl) * a.scale;
     }
     ds[k] = d;
@@ -167,8 +167,8 @@ __global__ __launch_bounds__(256) void k_attn_bwd_kv_generic(
       }
       const float p = expf(s * a.scale - L);
       const uint64_t di = (uint64_t)qrow * (uint64_t)a.Tk + (uint64_t)k;
-      pdv = afm_drop(a.dd, di, p);
-      dp = afm_drop(a.dd, di, dp);
+      pdv = afm_drop16(a.dd, di, p);
+      dp = afm_drop16(a.dd, di, dp);
       dsv = p * (dp - delta[qrow]) * a.scale;
     }
     pd[q] = pdv;

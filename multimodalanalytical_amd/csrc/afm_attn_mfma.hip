@@ -1,7 +1,491 @@
-// placeholder until the MFMA attention lands (replaced in a later commit)
+// bf16 MFMA flash attention for gfx950, head size 64 (d_model 512/8 and 768/12 of the reference's
+// model yamls), forward and backward, with key-padding / causal masks and attention-probability
+// dropout fused; scores never leave the chip.
+//
+// All products use v_mfma_f32_32x32x16_bf16 in the "swapped" orientation: the score tile is
+// computed TRANSPOSED (S^T = K Q^T), so the softmax axis (keys) runs over a lane's registers and
+// the query sits on the lane.  The row maximum / sum are then register loops plus one exchange
+// with lane^32, the probability tile (an accumulator) is directly the B operand of the next MFMA
+// (O^T = V^T P^T: cdna_hip_programming.md section 3, "an accumulator tile as the next MFMA's
+// operand"), and the per-query rescale of O^T is a per-lane multiply.  V^T fragments come from the
+// row-major V tile in LDS through ds_read_b64_tr_b16.
+//
+// forward:   workgroup = 4 waves x 32 queries = 128 queries of one (batch, head); 64-key tiles.
+// backward:  two kernels, no atomics, deterministic:
+//   dQ   : same geometry as forward; per tile S^T, dP^T = V dO^T, dS^T, dQ^T += K^T dS^T.
+//   dK/dV: workgroup = 4 waves x 32 keys; 64-query tiles; S = Q K^T with the KEY on the lane,
+//          dV^T += dO^T P, dK^T += Q^T dS.
 #include "afm_common.h"
-int afm_attn_fwd_mfma_try(const afm_attn_shape* s, const void* Q, const void* K, const void* V,
-                          void* O, float* lse, hipStream_t st) { return AFM_ERR_UNSUPPORTED; }
-int afm_attn_bwd_mfma_try(const afm_attn_shape* s, const void* Q, const void* K, const void* V,
-                          const void* O, const void* dO, const float* lse, float* delta, void* dQ,
-                          void* dK, void* dV, int lddq, int lddk, int lddv, hipStream_t st) { return AFM_ERR_UNSUPPORTED; }
+
+#define DH 64
+#define KT 64   // keys (or queries, in the dK/dV kernel) per LDS tile
+
+struct AttnM {
+  int B, H, Tq, Tk;
+  int ldq, ldk, ldv, ldo;
+  int lddq, lddk, lddv;
+  int causal;
+  float scale_log2;  // scale * log2(e)
+  float scale;
+  const uint8_t* key_pad;
+  DropDev dd;
+};
+
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+
+__device__ __forceinline__ f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ bf16x4 lds_tr(const unsigned char* p) {
+  const s16x4 r = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p);
+  return __builtin_bit_cast(bf16x4, r);
+}
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
+// LDS images of a [64 rows][64 cols] bf16 tile (128-byte rows, 8 chunks of 16 bytes):
+//   "row image": read by rows with ds_read_b128 (lane = row, 32 rows x one chunk per half-wave)
+//   "tr image" : read transposed with ds_read_b64_tr_b16 (4 rows x 16 columns per 16 lanes)
+__device__ __forceinline__ int img_row(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
+__device__ __forceinline__ int img_tr(int row, int chunk) { return row * 128 + ((chunk ^ (((row >> 1) & 1) << 2)) << 4); }
+
+// accumulator register r of a 32x32 tile <-> row (r&3) + 8*(r>>2) + 4*(lane>>5)
+#define ACC_ROW(r) (((r) & 3) + 8 * ((r) >> 2))
+
+// A-operand fragment "X^T slice": element j of lane-half h <-> tile row R0 + 4h + (j&3) + 8*(j>>2),
+// column C0 + (lane&31); two transposed reads.  R0 = first row of the 16-row k-slice.
+__device__ __forceinline__ bf16x8 frag_tr(const unsigned char* img, int R0, int C0, int lane) {
+  const int g = lane >> 4, qq = (lane >> 2) & 3, p = lane & 3;
+  const int row = R0 + 4 * (g >> 1) + qq;
+  const int col = C0 + 16 * (g & 1) + 4 * p;
+  const int chunk = col >> 3, sub = (col & 7) * 2;
+  const bf16x4 lo = lds_tr(img + img_tr(row, chunk) + sub);
+  const bf16x4 hi = lds_tr(img + img_tr(row + 8, chunk) + sub);
+  return (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+// A-operand fragment by rows: lane holds tile[R0 + (lane&31)][16*s + 8*(lane>>5) .. +7]
+__device__ __forceinline__ bf16x8 frag_row(const unsigned char* img, int R0, int s, int lane) {
+  return *(const bf16x8*)(img + img_row(R0 + (lane & 31), 2 * s + (lane >> 5)));
+}
+__device__ __forceinline__ bf16x8 cvt8(const f32x16& x, int s) {
+  return (bf16x8){(bf16)x[8 * s + 0], (bf16)x[8 * s + 1], (bf16)x[8 * s + 2], (bf16)x[8 * s + 3],
+                  (bf16)x[8 * s + 4], (bf16)x[8 * s + 5], (bf16)x[8 * s + 6], (bf16)x[8 * s + 7]};
+}
+
+// stage a [64][64] bf16 tile of a (rows x ld) matrix: thread t -> rows t>>3 and 32 + t>>3, chunk t&7
+struct Stage2 { uint4 v[2]; };
+__device__ __forceinline__ Stage2 stage_load(const bf16* base, int ld, int row0, int nrows, int t) {
+  Stage2 s;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    int r = row0 + (t >> 3) + 32 * i;
+    r = r < nrows ? r : nrows - 1;  // clamped rows are masked out by the caller
+    s.v[i] = *(const uint4*)(base + (int64_t)r * ld + (t & 7) * 8);
+  }
+  return s;
+}
+template <bool TR>
+__device__ __forceinline__ void stage_store(unsigned char* img, const Stage2& s, int t) {
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int r = (t >> 3) + 32 * i;
+    *(uint4*)(img + (TR ? img_tr(r, t & 7) : img_row(r, t & 7))) = s.v[i];
+  }
+}
+
+// dropout on a 32x32 score block held transposed (rows = keys in registers, query on the lane):
+// keep bits for key pairs (ACC_ROW(r), +1) come from one hash (afm_keep16).
+__device__ __forceinline__ void drop_block(const DropDev& dd, uint64_t rowbase, int key0, int h, f32x16& x) {
+#pragma unroll
+  for (int r = 0; r < 16; r += 2) {
+    const uint64_t idx = rowbase + (uint64_t)(key0 + ACC_ROW(r) + 4 * h);  // even (Tk even, key0 even)
+    const uint32_t hsh = afm_hash_pair(dd, idx >> 1);
+    x[r] = (hsh & 0xFFFFu) >= dd.thresh16 ? x[r] : 0.f;
+    x[r + 1] = (hsh >> 16) >= dd.thresh16 ? x[r + 1] : 0.f;
+  }
+}
+
+// ------------------------------------------------------------------------------------------ forward
+__global__ __launch_bounds__(256) void k_attn_fwd_mfma(AttnM a, const bf16* __restrict__ Q,
+                                                       const bf16* __restrict__ K,
+                                                       const bf16* __restrict__ V, bf16* __restrict__ O,
+                                                       float* __restrict__ lse) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * KT * DH * 2];
+  unsigned char* Kimg = lds;                 // row image
+  unsigned char* Vimg = lds + KT * DH * 2;   // tr image
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6, h = lane >> 5;
+  const int hd = blockIdx.y, b = blockIdx.z;
+  const int q0 = blockIdx.x * 128 + w * 32;          // this wave's first query
+  const int q = q0 + (lane & 31);
+  const int qc = q < a.Tq ? q : a.Tq - 1;
+  const bf16* Kb = K + (int64_t)b * a.Tk * a.ldk + hd * DH;
+  const bf16* Vb = V + (int64_t)b * a.Tk * a.ldv + hd * DH;
+  // Q fragments (B operand of S^T = K Q^T): Q[q][16 s + 8 h ..]
+  bf16x8 qf[4];
+  {
+    const bf16* qp = Q + ((int64_t)b * a.Tq + qc) * a.ldq + hd * DH + 8 * h;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) qf[s] = *(const bf16x8*)(qp + 16 * s);
+  }
+  f32x16 o[2];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { o[0][i] = 0.f; o[1][i] = 0.f; }
+  float m = -INFINITY, l = 0.f;
+  const uint64_t rowbase = ((uint64_t)(b * a.H + hd) * a.Tq + qc) * (uint64_t)a.Tk;
+
+  int kend = a.Tk;
+  if (a.causal) kend = min(a.Tk, blockIdx.x * 128 + 128);  // keys beyond the block's last query are masked
+  const int ntiles = (kend + KT - 1) / KT;
+  Stage2 sk = stage_load(Kb, a.ldk, 0, a.Tk, t), sv = stage_load(Vb, a.ldv, 0, a.Tk, t);
+  for (int kt = 0; kt < ntiles; ++kt) {
+    const int kb = kt * KT;
+    __syncthreads();                       // previous tile fully consumed
+    stage_store<false>(Kimg, sk, t);
+    stage_store<true>(Vimg, sv, t);
+    __syncthreads();
+    if (kt + 1 < ntiles) { sk = stage_load(Kb, a.ldk, kb + KT, a.Tk, t); sv = stage_load(Vb, a.ldv, kb + KT, a.Tk, t); }
+    if (a.causal && kb > q0 + 31) continue;  // wave-uniform: tile entirely above this wave's diagonal
+    // key mask bits of this tile (1 = masked), shifted so bit ACC_ROW(r) + 32 blk is this lane's key
+    const int kk = kb + lane;
+    const bool kmask = kk >= a.Tk || (a.key_pad && a.key_pad[(int64_t)b * a.Tk + kk]);
+    const unsigned long long pad = __ballot(kmask) >> (4 * h);
+    f32x16 s[2];
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) s[blk][i] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) s[blk] = mfma32(frag_row(Kimg, 32 * blk, ks, lane), qf[ks], s[blk]);
+    }
+    float mt = -INFINITY;
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int ko = 32 * blk + ACC_ROW(r);
+        bool msk = (pad >> ko) & 1ull;
+        if (a.causal) msk = msk || (kb + ko + 4 * h > q);
+        const float v = msk ? -INFINITY : s[blk][r] * a.scale_log2;
+        s[blk][r] = v;
+        mt = fmaxf(mt, v);
+      }
+    mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+    const float mn = fmaxf(m, mt);
+    const float ms = mn == -INFINITY ? 0.f : mn;
+    const float alpha = fast_exp2(m - ms);
+    m = mn;
+    float ls = 0.f;
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float p = fast_exp2(s[blk][r] - ms);
+        s[blk][r] = p;
+        ls += p;
+      }
+    l = l * alpha + ls;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { o[0][i] *= alpha; o[1][i] *= alpha; }
+    if (a.dd.thresh16) {
+      drop_block(a.dd, rowbase, kb, h, s[0]);
+      drop_block(a.dd, rowbase, kb + 32, h, s[1]);
+    }
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const bf16x8 pf = cvt8(s[blk], ks);
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+          o[db] = mfma32(frag_tr(Vimg, 32 * blk + 16 * ks, 32 * db, lane), pf, o[db]);
+      }
+  }
+  l += __shfl_xor(l, 32, 64);
+  const float inv = l > 0.f ? a.dd.scale16 / l : 0.f;
+  if (q < a.Tq) {
+    bf16* op = O + ((int64_t)b * a.Tq + q) * a.ldo + hd * DH + 4 * h;
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        bf16x4 v = {(bf16)(o[db][4 * g4 + 0] * inv), (bf16)(o[db][4 * g4 + 1] * inv),
+                    (bf16)(o[db][4 * g4 + 2] * inv), (bf16)(o[db][4 * g4 + 3] * inv)};
+        *(bf16x4*)(op + 32 * db + 8 * g4) = v;
+      }
+    if (h == 0) lse[((int64_t)b * a.H + hd) * a.Tq + q] = l > 0.f ? (m + __log2f(l)) * 0.69314718055994531f : INFINITY;
+  }
+}
+
+// ------------------------------------------------------------------------------------------ dQ
+// Per 64-key tile: S^T and dP^T (keys in registers, query on the lane), then
+// dQ^T[d][q] += sum_key K^T[d][key] dS^T[key][q].  Also writes delta = rowsum(dO * O).
+__global__ __launch_bounds__(256) void k_attn_bwd_dq_mfma(AttnM a, const bf16* __restrict__ Q,
+                                                          const bf16* __restrict__ K,
+                                                          const bf16* __restrict__ V,
+                                                          const bf16* __restrict__ O,
+                                                          const bf16* __restrict__ dO,
+                                                          const float* __restrict__ lse,
+                                                          float* __restrict__ delta, bf16* __restrict__ dQ) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[3 * KT * DH * 2];
+  unsigned char* Krow = lds;
+  unsigned char* Ktr = lds + KT * DH * 2;
+  unsigned char* Vrow = lds + 2 * KT * DH * 2;
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6, h = lane >> 5;
+  const int hd = blockIdx.y, b = blockIdx.z;
+  const int q0 = blockIdx.x * 128 + w * 32;
+  const int q = q0 + (lane & 31);
+  const int qc = q < a.Tq ? q : a.Tq - 1;
+  const bf16* Kb = K + (int64_t)b * a.Tk * a.ldk + hd * DH;
+  const bf16* Vb = V + (int64_t)b * a.Tk * a.ldv + hd * DH;
+  bf16x8 qf[4], dof[4];
+  float dl = 0.f;
+  {
+    const bf16* qp = Q + ((int64_t)b * a.Tq + qc) * a.ldq + hd * DH + 8 * h;
+    const bf16* dop = dO + ((int64_t)b * a.Tq + qc) * a.ldo + hd * DH + 8 * h;
+    const bf16* op = O + ((int64_t)b * a.Tq + qc) * a.ldo + hd * DH + 8 * h;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      qf[s] = *(const bf16x8*)(qp + 16 * s);
+      dof[s] = *(const bf16x8*)(dop + 16 * s);
+      const bf16x8 ov = *(const bf16x8*)(op + 16 * s);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) dl += (float)dof[s][j] * (float)ov[j];
+    }
+  }
+  dl += __shfl_xor(dl, 32, 64);
+  const int64_t lrow = ((int64_t)b * a.H + hd) * a.Tq + qc;
+  if (q < a.Tq && h == 0) delta[lrow] = dl;
+  const float L = lse[lrow];
+  const float L2 = L == INFINITY ? INFINITY : L * 1.4426950408889634f;  // log2 units
+  f32x16 dq[2];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { dq[0][i] = 0.f; dq[1][i] = 0.f; }
+  const uint64_t rowbase = (uint64_t)lrow * (uint64_t)a.Tk;
+
+  int kend = a.Tk;
+  if (a.causal) kend = min(a.Tk, blockIdx.x * 128 + 128);
+  const int ntiles = (kend + KT - 1) / KT;
+  Stage2 sk = stage_load(Kb, a.ldk, 0, a.Tk, t), sv = stage_load(Vb, a.ldv, 0, a.Tk, t);
+  for (int kt = 0; kt < ntiles; ++kt) {
+    const int kb = kt * KT;
+    __syncthreads();
+    stage_store<false>(Krow, sk, t);
+    stage_store<true>(Ktr, sk, t);
+    stage_store<false>(Vrow, sv, t);
+    __syncthreads();
+    if (kt + 1 < ntiles) { sk = stage_load(Kb, a.ldk, kb + KT, a.Tk, t); sv = stage_load(Vb, a.ldv, kb + KT, a.Tk, t); }
+    if (a.causal && kb > q0 + 31) continue;
+    const int kk = kb + lane;
+    const bool kmask = kk >= a.Tk || (a.key_pad && a.key_pad[(int64_t)b * a.Tk + kk]);
+    const unsigned long long pad = __ballot(kmask) >> (4 * h);
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk) {
+      f32x16 s, dp;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { s[i] = 0.f; dp[i] = 0.f; }
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        s = mfma32(frag_row(Krow, 32 * blk, ks, lane), qf[ks], s);
+        dp = mfma32(frag_row(Vrow, 32 * blk, ks, lane), dof[ks], dp);
+      }
+      if (a.dd.thresh16) {
+        drop_block(a.dd, rowbase, kb + 32 * blk, h, dp);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dp[r] *= a.dd.scale16;
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int ko = 32 * blk + ACC_ROW(r);
+        bool msk = (pad >> ko) & 1ull;
+        if (a.causal) msk = msk || (kb + ko + 4 * h > q);
+        const float p = msk ? 0.f : fast_exp2(s[r] * a.scale_log2 - L2);
+        s[r] = p * (dp[r] - dl);   // dS^T (the 1/sqrt(dh) factor is applied once at the end)
+      }
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const bf16x8 dsf = cvt8(s, ks);
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+          dq[db] = mfma32(frag_tr(Ktr, 32 * blk + 16 * ks, 32 * db, lane), dsf, dq[db]);
+      }
+    }
+  }
+  if (q < a.Tq) {
+    bf16* dqp = dQ + ((int64_t)b * a.Tq + q) * a.lddq + hd * DH + 4 * h;
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        bf16x4 v = {(bf16)(dq[db][4 * g4 + 0] * a.scale), (bf16)(dq[db][4 * g4 + 1] * a.scale),
+                    (bf16)(dq[db][4 * g4 + 2] * a.scale), (bf16)(dq[db][4 * g4 + 3] * a.scale)};
+        *(bf16x4*)(dqp + 32 * db + 8 * g4) = v;
+      }
+  }
+}
+
+// ------------------------------------------------------------------------------------------ dK, dV
+// Workgroup = 4 waves x 32 keys; loops over 64-query tiles.  S = Q K^T with the key on the lane
+// (queries in registers), P = exp2(S - lse[q]), dP = dO V^T, dS = P (D dP - delta[q]);
+// dV^T[d][key] += sum_q dO^T[d][q] (D P)[q][key],  dK^T[d][key] += sum_q Q^T[d][q] dS[q][key].
+__global__ __launch_bounds__(256) void k_attn_bwd_dkv_mfma(AttnM a, const bf16* __restrict__ Q,
+                                                           const bf16* __restrict__ K,
+                                                           const bf16* __restrict__ V,
+                                                           const bf16* __restrict__ dO,
+                                                           const float* __restrict__ lse,
+                                                           const float* __restrict__ delta,
+                                                           bf16* __restrict__ dK, bf16* __restrict__ dV) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[4 * KT * DH * 2 + 2 * KT * 4];
+  unsigned char* Qrow = lds;
+  unsigned char* Qtr = lds + KT * DH * 2;
+  unsigned char* Drow = lds + 2 * KT * DH * 2;
+  unsigned char* Dtr = lds + 3 * KT * DH * 2;
+  float* Ls = (float*)(lds + 4 * KT * DH * 2);   // lse (log2 units) of the tile's queries
+  float* Ds = Ls + KT;                           // delta
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6, h = lane >> 5;
+  const int hd = blockIdx.y, b = blockIdx.z;
+  const int k0 = blockIdx.x * 128 + w * 32;
+  const int key = k0 + (lane & 31);
+  const int kc = key < a.Tk ? key : a.Tk - 1;
+  const bool kmasked = key >= a.Tk || (a.key_pad && a.key_pad[(int64_t)b * a.Tk + kc]);
+  const bf16* Qb = Q + (int64_t)b * a.Tq * a.ldq + hd * DH;
+  const bf16* Db = dO + (int64_t)b * a.Tq * a.ldo + hd * DH;
+  bf16x8 kf[4], vf[4];
+  {
+    const bf16* kp = K + ((int64_t)b * a.Tk + kc) * a.ldk + hd * DH + 8 * h;
+    const bf16* vp = V + ((int64_t)b * a.Tk + kc) * a.ldv + hd * DH + 8 * h;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) { kf[s] = *(const bf16x8*)(kp + 16 * s); vf[s] = *(const bf16x8*)(vp + 16 * s); }
+  }
+  f32x16 dk[2], dv[2];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { dk[0][i] = 0.f; dk[1][i] = 0.f; dv[0][i] = 0.f; dv[1][i] = 0.f; }
+
+  int qbeg = 0;
+  if (a.causal) qbeg = (blockIdx.x * 128) / KT * KT;   // queries before the block's first key see none of it
+  const int ntiles = (a.Tq - qbeg + KT - 1) / KT;
+  const int64_t lbase = ((int64_t)b * a.H + hd) * a.Tq;
+  Stage2 sq = stage_load(Qb, a.ldq, qbeg, a.Tq, t), sd = stage_load(Db, a.ldo, qbeg, a.Tq, t);
+  for (int qt = 0; qt < ntiles; ++qt) {
+    const int qb = qbeg + qt * KT;
+    __syncthreads();
+    stage_store<false>(Qrow, sq, t);
+    stage_store<true>(Qtr, sq, t);
+    stage_store<false>(Drow, sd, t);
+    stage_store<true>(Dtr, sd, t);
+    if (t < KT) {
+      const int qq = qb + t;
+      const float L = qq < a.Tq ? lse[lbase + qq] : INFINITY;   // +inf => p = 0 (row out of range / empty)
+      Ls[t] = L == INFINITY ? INFINITY : L * 1.4426950408889634f;
+      Ds[t] = qq < a.Tq ? delta[lbase + qq] : 0.f;
+    }
+    __syncthreads();
+    if (qt + 1 < ntiles) { sq = stage_load(Qb, a.ldq, qb + KT, a.Tq, t); sd = stage_load(Db, a.ldo, qb + KT, a.Tq, t); }
+    if (a.causal && qb + KT - 1 < k0) continue;   // wave-uniform: every query of the tile precedes this wave's keys
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk) {
+      f32x16 s, dp;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { s[i] = 0.f; dp[i] = 0.f; }
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        s = mfma32(frag_row(Qrow, 32 * blk, ks, lane), kf[ks], s);     // S[q][key]
+        dp = mfma32(frag_row(Drow, 32 * blk, ks, lane), vf[ks], dp);   // dP[q][key]
+      }
+      f32x16 pd;
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const int qo = 32 * blk + 8 * g4 + 4 * h;
+        const f32x4 Lq = *(const f32x4*)(Ls + qo);
+        const f32x4 Dq = *(const f32x4*)(Ds + qo);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int r = 4 * g4 + j;
+          const int qq = qb + qo + j;
+          bool msk = kmasked;
+          if (a.causal) msk = msk || (key > qq);
+          float p = msk ? 0.f : fast_exp2(s[r] * a.scale_log2 - Lq[j]);
+          float dpv = dp[r];
+          if (a.dd.thresh16) {
+            const uint64_t idx = ((uint64_t)(lbase + qq)) * (uint64_t)a.Tk + (uint64_t)key;
+            const bool keep = afm_keep16(a.dd, idx);
+            pd[r] = keep ? p * a.dd.scale16 : 0.f;
+            dpv = keep ? dpv * a.dd.scale16 : 0.f;
+          } else {
+            pd[r] = p;
+          }
+          s[r] = p * (dpv - Dq[j]);
+        }
+      }
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const bf16x8 pf = cvt8(pd, ks), dsf = cvt8(s, ks);
+#pragma unroll
+        for (int db = 0; db < 2; ++db) {
+          dv[db] = mfma32(frag_tr(Dtr, 32 * blk + 16 * ks, 32 * db, lane), pf, dv[db]);
+          dk[db] = mfma32(frag_tr(Qtr, 32 * blk + 16 * ks, 32 * db, lane), dsf, dk[db]);
+        }
+      }
+    }
+  }
+  if (key < a.Tk) {
+    bf16* dkp = dK + ((int64_t)b * a.Tk + key) * a.lddk + hd * DH + 4 * h;
+    bf16* dvp = dV + ((int64_t)b * a.Tk + key) * a.lddv + hd * DH + 4 * h;
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        bf16x4 x = {(bf16)(dk[db][4 * g4 + 0] * a.scale), (bf16)(dk[db][4 * g4 + 1] * a.scale),
+                    (bf16)(dk[db][4 * g4 + 2] * a.scale), (bf16)(dk[db][4 * g4 + 3] * a.scale)};
+        bf16x4 y = {(bf16)dv[db][4 * g4 + 0], (bf16)dv[db][4 * g4 + 1], (bf16)dv[db][4 * g4 + 2], (bf16)dv[db][4 * g4 + 3]};
+        *(bf16x4*)(dkp + 32 * db + 8 * g4) = x;
+        *(bf16x4*)(dvp + 32 * db + 8 * g4) = y;
+      }
+  }
+}
+
+// ------------------------------------------------------------------------------------------ dispatch
+static bool eligible(const afm_attn_shape* s, const void* const* ptrs, int nptr, const int* lds, int nld) {
+  if (s->dtype != AFM_BF16 || s->dh != DH) return false;
+  if (s->drop.p > 0.f && (s->Tk & 1)) return false;   // the pair hash needs even rows of the mask
+  for (int i = 0; i < nptr; ++i) if ((uintptr_t)ptrs[i] & 15) return false;
+  for (int i = 0; i < nld; ++i) if (lds[i] & 7) return false;
+  return true;
+}
+static AttnM make_m(const afm_attn_shape* s) {
+  AttnM a;
+  a.B = s->B; a.H = s->H; a.Tq = s->Tq; a.Tk = s->Tk;
+  a.ldq = s->ldq; a.ldk = s->ldk; a.ldv = s->ldv; a.ldo = s->ldo;
+  a.lddq = a.lddk = a.lddv = 0;
+  a.causal = s->causal; a.scale = s->scale; a.scale_log2 = s->scale * 1.4426950408889634f;
+  a.key_pad = s->key_pad; a.dd = afm_make_drop(&s->drop);
+  return a;
+}
+
+int afm_attn_fwd_mfma_try(const afm_attn_shape* s, const void* Q, const void* K, const void* V, void* O,
+                          float* lse, hipStream_t st) {
+  const void* ptrs[] = {Q, K, V, O};
+  const int lds[] = {s->ldq, s->ldk, s->ldv, s->ldo};
+  if (!eligible(s, ptrs, 4, lds, 4)) return AFM_ERR_UNSUPPORTED;
+  const AttnM a = make_m(s);
+  const dim3 grid((s->Tq + 127) / 128, s->H, s->B);
+  AFM_LAUNCH(k_attn_fwd_mfma, grid, dim3(256), 0, st, a, (const bf16*)Q, (const bf16*)K, (const bf16*)V,
+             (bf16*)O, lse);
+  afm_set_last_algo("attn_mfma");
+  return AFM_OK;
+}
+
+int afm_attn_bwd_mfma_try(const afm_attn_shape* s, const void* Q, const void* K, const void* V, const void* O,
+                          const void* dO, const float* lse, float* delta, void* dQ, void* dK, void* dV,
+                          int lddq, int lddk, int lddv, hipStream_t st) {
+  const void* ptrs[] = {Q, K, V, O, dO, dQ, dK, dV};
+  const int lds[] = {s->ldq, s->ldk, s->ldv, s->ldo, lddq, lddk, lddv};
+  if (!eligible(s, ptrs, 8, lds, 7)) return AFM_ERR_UNSUPPORTED;
+  AttnM a = make_m(s);
+  a.lddq = lddq; a.lddk = lddk; a.lddv = lddv;
+  const dim3 gq((s->Tq + 127) / 128, s->H, s->B), gk((s->Tk + 127) / 128, s->H, s->B);
+  AFM_LAUNCH(k_attn_bwd_dq_mfma, gq, dim3(256), 0, st, a, (const bf16*)Q, (const bf16*)K, (const bf16*)V,
+             (const bf16*)O, (const bf16*)dO, lse, delta, (bf16*)dQ);
+  AFM_LAUNCH(k_attn_bwd_dkv_mfma, gk, dim3(256), 0, st, a, (const bf16*)Q, (const bf16*)K, (const bf16*)V,
+             (const bf16*)dO, lse, delta, (bf16*)dK, (bf16*)dV);
+  afm_set_last_algo("attn_mfma");
+  return AFM_OK;
+}

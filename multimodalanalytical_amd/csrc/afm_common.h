@@ -39,20 +39,24 @@ template <> __device__ __forceinline__ void st_f32<bf16>(bf16* p, int64_t i, flo
 // re-implemented in tests (numpy) so parity tests run WITH dropout against the oracle.
 struct DropDev {
   uint32_t key;
-  uint32_t thresh;  // 0 => keep everything
-  float scale;      // 1/(1-p)
-  float pad;
+  uint32_t thresh;    // 0 => keep everything
+  float scale;        // 1/(1-p)
+  uint32_t thresh16;  // attention-probability stream: 16 random bits per element
+  float scale16;      // 1/(1 - thresh16/65536)
 };
 __host__ __device__ __forceinline__ uint32_t afm_lowbias32(uint32_t x) {
   x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
   return x;
 }
 static inline DropDev afm_make_drop(const afm_dropout* d) {
-  DropDev r; r.pad = 0.f;
-  if (!d || d->p <= 0.f) { r.key = 0; r.thresh = 0; r.scale = 1.f; return r; }
+  DropDev r;
+  if (!d || d->p <= 0.f) { r.key = 0; r.thresh = 0; r.scale = 1.f; r.thresh16 = 0; r.scale16 = 1.f; return r; }
   double t = (double)d->p * 4294967296.0;
   r.thresh = t >= 4294967295.0 ? 4294967295u : (uint32_t)t;
   r.scale = 1.0f / (1.0f - d->p);
+  double t16 = (double)d->p * 65536.0 + 0.5;
+  r.thresh16 = t16 >= 65535.0 ? 65535u : (uint32_t)t16;
+  r.scale16 = (float)(1.0 / (1.0 - (double)r.thresh16 / 65536.0));
   uint32_t k = afm_lowbias32((uint32_t)d->seed ^ 0x9E3779B9u);
   k = afm_lowbias32(k ^ (uint32_t)(d->seed >> 32));
   k = afm_lowbias32(k ^ (d->site * 0x85EBCA6Bu + 0x1234567u));
@@ -62,6 +66,19 @@ static inline DropDev afm_make_drop(const afm_dropout* d) {
 __device__ __forceinline__ bool afm_keep(const DropDev& d, uint64_t idx) {
   uint32_t h = afm_lowbias32((uint32_t)idx ^ d.key ^ ((uint32_t)(idx >> 32) * 0x9E3779B1u));
   return h >= d.thresh;
+}
+// Attention probabilities (B*H*Tq*Tk of them per layer) use 16 random bits per element: one hash
+// serves the element pair (2i, 2i+1), halving the integer work inside the attention kernels.
+__device__ __forceinline__ uint32_t afm_hash_pair(const DropDev& d, uint64_t half_idx) {
+  return afm_lowbias32((uint32_t)half_idx ^ d.key ^ ((uint32_t)(half_idx >> 32) * 0x9E3779B1u));
+}
+__device__ __forceinline__ bool afm_keep16(const DropDev& d, uint64_t idx) {
+  const uint32_t h = afm_hash_pair(d, idx >> 1);
+  return ((idx & 1) ? (h >> 16) : (h & 0xFFFFu)) >= d.thresh16;
+}
+__device__ __forceinline__ float afm_drop16(const DropDev& d, uint64_t idx, float x) {
+  if (d.thresh16 == 0) return x;
+  return afm_keep16(d, idx) ? x * d.scale16 : 0.f;
 }
 __device__ __forceinline__ float afm_drop(const DropDev& d, uint64_t idx, float x) {
   if (d.thresh == 0) return x;

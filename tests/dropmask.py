@@ -30,3 +30,17 @@ def keep_mask(p: float, seed: int, site: int, n: int, start: int = 0) -> np.ndar
     lo, hi = idx & M32, idx >> 32
     h = _lowbias32(lo ^ key_of(seed, site) ^ ((hi * 0x9E3779B1) & M32))
     return h >= thresh
+
+
+def keep_mask16(p: float, seed: int, site: int, n: int, start: int = 0):
+    """Attention-probability stream (afm_keep16): 16 random bits per element, one hash per element
+    pair.  Returns (bool[n] keep, scale) with scale = 1/(1 - thresh16/65536)."""
+    if p <= 0:
+        return np.ones(n, dtype=bool), 1.0
+    t16 = min(65535, int(p * 65536.0 + 0.5))
+    idx = np.arange(start, start + n, dtype=np.uint64)
+    half = idx >> np.uint64(1)
+    lo, hi = half & M32, half >> 32
+    h = _lowbias32(lo ^ key_of(seed, site) ^ ((hi * 0x9E3779B1) & M32))
+    v = np.where(idx & 1, h >> 16, h & 0xFFFF)
+    return v >= t16, 1.0 / (1.0 - t16 / 65536.0)

@@ -9,7 +9,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 from oracle import afm_oracle as O  # noqa: E402
-from tests.dropmask import keep_mask  # noqa: E402
+from tests.dropmask import keep_mask, keep_mask16  # noqa: E402
 
 
 @pytest.fixture(scope="module")
@@ -194,10 +194,12 @@ def test_attention_all_masked_row_and_dropout(ops):
     ops.attn_fwd(shp, qd, kd, vd, o, lse)
     assert float(o.view(B, Tq, D)[1].abs().max()) == 0.0           # _safe_softmax zeros
     assert torch.isinf(lse.view(B, H, Tq)[1]).all()
-    keep = torch.from_numpy(keep_mask(p, seed, site, B * H * Tq * Tk)).view(B, H, Tq, Tk)
+    keep, dscale = keep_mask16(p, seed, site, B * H * Tq * Tk)
+    keep = torch.from_numpy(keep).view(B, H, Tq, Tk)
+    assert abs(float(keep.float().mean()) - (1 - p)) < 0.05
     qr, kr, vr = (t.double().transpose(1, 2).requires_grad_(True) for t in (q, k, v))
     s = (qr @ kr.transpose(-1, -2)) / math.sqrt(dh)
-    pr = torch.softmax(s, -1) * keep / (1 - p)
+    pr = torch.softmax(s, -1) * keep * dscale
     ref = (pr @ vr)
     close(o.view(B, Tq, H, dh)[0], ref[0].transpose(0, 1), 1e-5, 1e-5)
     do = rnd(B * Tq, D, seed=3)
@@ -371,3 +373,73 @@ def test_gemm_mfma_tn_identity(ops):
     g = torch.zeros(R, 64, device=DEV)
     ops.gemm(dev(dy), dev(x), g, trans_a=True, trans_b=False, algo=2)
     close(g, x.float(), 0, 0)
+
+
+# ------------------------------------------------------------------ MFMA attention (head size 64)
+def _attn_ref(q, k, v, key_pad, causal, keep=None, dscale=1.0):
+    """fp64 reference incl. the dropout mask; q,k,v (B,T,H,dh) fp32 (already bf16-rounded)."""
+    qr, kr, vr = (t.double().transpose(1, 2).requires_grad_(True) for t in (q, k, v))
+    dh = q.shape[-1]
+    s = (qr @ kr.transpose(-1, -2)) / math.sqrt(dh)
+    masked = torch.zeros(s.shape, dtype=torch.bool)
+    if key_pad is not None:
+        masked |= key_pad[:, None, None, :]
+    if causal:
+        masked |= torch.ones(s.shape[-2], s.shape[-1], dtype=torch.bool).triu(1)
+    p = torch.softmax(s.masked_fill(masked, -1e30), -1).masked_fill(masked, 0.0)
+    if keep is not None:
+        p = p * keep * dscale
+    return qr, kr, vr, p @ vr
+
+
+@pytest.mark.parametrize("B,H,Tq,Tk,causal,pad,pdrop", [
+    (2, 2, 128, 128, True, True, 0.0), (2, 3, 100, 200, False, True, 0.0), (1, 2, 300, 300, False, False, 0.0),
+    (1, 2, 192, 192, True, False, 0.0), (2, 2, 128, 256, False, True, 0.1), (1, 2, 160, 160, True, True, 0.1)])
+def test_attention_mfma(ops, B, H, Tq, Tk, causal, pad, pdrop):
+    dh, dt = 64, torch.bfloat16
+    q, k, v, key_pad = _attn_case(B, H, Tq, Tk, dh, causal, pad, seed=10)
+    q, k, v = q.bfloat16().float(), k.bfloat16().float(), v.bfloat16().float()
+    D = H * dh
+    qd, kd, vd = (dev(t.reshape(-1, D), dt) for t in (q, k, v))
+    kp = None if key_pad is None else dev(key_pad.to(torch.uint8))
+    seed, site = 4242, 3
+    keep, dscale = None, 1.0
+    if pdrop > 0:
+        km, dscale = keep_mask16(pdrop, seed, site, B * H * Tq * Tk)
+        keep = torch.from_numpy(km).view(B, H, Tq, Tk)
+    res = {}
+    for algo in (1, 2):
+        o = torch.empty(B * Tq, D, dtype=dt, device=DEV); lse = torch.empty(B * H * Tq, device=DEV)
+        shp = ops.attn_shape(B, H, Tq, Tk, dh, dt, D, D, D, D, kp, causal, ops.drop(pdrop, seed, site), algo=algo)
+        ops.attn_fwd(shp, qd, kd, vd, o, lse)
+        assert ops.last_algo() == ("attn_generic" if algo == 1 else "attn_mfma")
+        res[algo] = (o, lse, shp)
+    qr, kr, vr, ref = _attn_ref(q, k, v, key_pad, causal, keep, dscale)
+    ref_o = ref.transpose(1, 2).reshape(B * Tq, D)
+    close(res[2][0], ref_o, 2e-2, 2e-2, "mfma fwd vs oracle")
+    close(res[2][1], res[1][1].cpu(), 1e-3, 1e-3, "lse mfma vs generic")
+    do = rnd(B * Tq, D, seed=9).bfloat16().float()
+    ref.backward(do.double().view(B, Tq, H, dh).transpose(1, 2))
+    o, lse, shp = res[2]
+    dq, dk, dv = (torch.empty(n, D, dtype=dt, device=DEV) for n in (B * Tq, B * Tk, B * Tk))
+    ops.attn_bwd(shp, qd, kd, vd, o, dev(do, dt), lse, torch.empty_like(lse), dq, dk, dv, D, D, D)
+    assert ops.last_algo() == "attn_mfma"
+    for name, got, r, T in (("dq", dq, qr, Tq), ("dk", dk, kr, Tk), ("dv", dv, vr, Tk)):
+        want = r.grad.transpose(1, 2).reshape(B * T, D)
+        err = float((got.float().cpu().double() - want).norm() / want.norm())
+        assert err < 2e-2, (name, err)
+        close(got, want, 5e-2, 5e-2 * float(want.abs().max()), name)
+
+
+def test_attention_mfma_strided_packed_qkv(ops):
+    # q/k/v addressed in place inside a packed (rows, 3d) projection, as the engine does
+    B, H, T, dh = 2, 8, 128, 64
+    d = H * dh
+    qkv = rnd(B * T, 3 * d, seed=5).bfloat16()
+    qkvd = dev(qkv)
+    o = torch.empty(B * T, d, dtype=torch.bfloat16, device=DEV); lse = torch.empty(B * H * T, device=DEV)
+    shp = ops.attn_shape(B, H, T, T, dh, torch.bfloat16, 3 * d, 3 * d, 3 * d, d, None, False, algo=2)
+    ops.attn_fwd(shp, qkvd[:, :d], qkvd[:, d:2 * d], qkvd[:, 2 * d:], o, lse)
+    q, k, v = (qkv[:, i * d:(i + 1) * d].float().view(B, T, H, dh) for i in range(3))
+    _, _, _, ref = _attn_ref(q, k, v, None, False)
+    close(o, ref.transpose(1, 2).reshape(B * T, d), 2e-2, 2e-2)
