@@ -63,6 +63,7 @@ typedef struct {
  *   dgrad    dx = dy W                                              transA=0, transB=0
  *   wgrad    dW += dy^T x  (accumulate=1: gradient accumulation)    transA=1, transB=0
  * `pre_act` (optional, dtype/ld of C) receives T before the activation (kept for GELU backward).
+ * `a_colsum` (wgrad form only) accumulates the column sums of A = dy: the bias gradient.
  * bf16 operands take the MFMA path (v_mfma_f32_16x16x32_bf16 / 32x32x16, fp32 accumulate) when
  * shape/alignment allow; everything else takes the exact-fp32 FMA path.
  * ---------------------------------------------------------------------------------------- */
@@ -77,6 +78,8 @@ typedef struct {
   const float* bias;      /* N, fp32, nullable */
   const void* residual;   /* M x N, dtype/ld of C, nullable */
   void* pre_act;          /* M x N, dtype/ld of C, nullable */
+  float* a_colsum;        /* transA only, nullable: a_colsum[m] += sum_k A[k][m]  (the bias gradient
+                             sum_rows dy, produced by the wgrad pass that already streams dy) */
   int32_t act;            /* AFM_ACT_* */
   int32_t accumulate;     /* C += ... */
   int32_t algo;           /* AFM_ALGO_* */

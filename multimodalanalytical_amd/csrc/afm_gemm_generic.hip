@@ -138,6 +138,10 @@ static int gemm_generic(const afm_gemm_desc* d, hipStream_t st) {
     }
   }
   AFM_LAUNCH(k_gemm_generic, dim3(gx, gy, splits), dim3(256), 0, st, g);
+  if (d->a_colsum) {  // bias gradient: column sums of A (K x M, row-major) through the colsum kernel
+    const int r = afm_colsum(d->A, d->a_colsum, d->K, d->M, d->lda, d->a_dtype, 1, (void*)st);
+    if (r != AFM_OK) return r;
+  }
   afm_set_last_algo(splits > 1 ? "generic_splitk" : "generic");
   return AFM_OK;
 }
@@ -149,6 +153,7 @@ extern "C" int afm_gemm(const afm_gemm_desc* d, void* stream) {
   if (d->act < AFM_ACT_NONE || d->act > AFM_ACT_GELU) return AFM_ERR_ARG;
   if (d->ldc < d->N) return AFM_ERR_ARG;
   if (d->lda < (d->transA ? d->M : d->K) || d->ldb < (d->transB ? d->K : d->N)) return AFM_ERR_ARG;
+  if (d->a_colsum && !d->transA) return AFM_ERR_ARG;
   if (d->M == 0 || d->N == 0) return AFM_OK;
   hipStream_t st = (hipStream_t)stream;
   if (d->algo != AFM_ALGO_GENERIC) {

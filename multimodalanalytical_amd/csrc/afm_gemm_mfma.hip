@@ -24,6 +24,7 @@ struct MfmaArgs {
   const float* bias;
   const void* residual;
   void* pre_act;
+  float* a_colsum;
   int act, accumulate;
   int tiles_m, tiles_n;
   int ksplit, kchunk;  // TN only
@@ -87,78 +88,111 @@ __device__ __forceinline__ void epilogue4(const MfmaArgs& g, int m, int n0, f32x
   }
 }
 
+// Same, for a tile known to be entirely inside C with 16-byte aligned rows: no per-lane exits, so
+// every wave issues exactly one store instruction per fragment (the persistent kernel counts on it).
+template <bool C_BF16>
+__device__ __forceinline__ void epilogue4_full(const MfmaArgs& g, int m, int n0, f32x4 v) {
+  const int64_t ci = (int64_t)m * g.ldc + n0;
+  if (g.bias) v += *(const f32x4*)(g.bias + n0);
+  if (g.pre_act) {
+    if (C_BF16) { bf16x4 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]}; *(bf16x4*)((bf16*)g.pre_act + ci) = o; }
+    else *(f32x4*)((float*)g.pre_act + ci) = v;
+  }
+  if (g.act != AFM_ACT_NONE || g.dd.thresh) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float x = v[r];
+      if (g.act == AFM_ACT_RELU) x = fmaxf(x, 0.f);
+      else if (g.act == AFM_ACT_GELU) x = afm_gelu(x);
+      v[r] = afm_drop(g.dd, (uint64_t)m * (uint64_t)g.N + (uint64_t)(n0 + r), x);
+    }
+  }
+  if (g.residual) {
+    if (C_BF16) { const bf16x4 rr = *(const bf16x4*)((const bf16*)g.residual + ci); v[0] += (float)rr[0]; v[1] += (float)rr[1]; v[2] += (float)rr[2]; v[3] += (float)rr[3]; }
+    else v += *(const f32x4*)((const float*)g.residual + ci);
+  }
+  if (g.accumulate) {
+    if (C_BF16) { const bf16x4 rr = *(const bf16x4*)((const bf16*)g.C + ci); v[0] += (float)rr[0]; v[1] += (float)rr[1]; v[2] += (float)rr[2]; v[3] += (float)rr[3]; }
+    else v += *(const f32x4*)((const float*)g.C + ci);
+  }
+  if (C_BF16) { bf16x4 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]}; *(bf16x4*)((bf16*)g.C + ci) = o; }
+  else *(f32x4*)((float*)g.C + ci) = v;
+}
+
 // ------------------------------------------------------------------------------------------ NT
 // LDS tile [128 rows][64 k] bf16 = 128-byte rows of 8 16-byte chunks; chunk c of row r is stored at
 // chunk (c ^ (r & 7)): the 16 lanes of a ds_read_b128 group then hit 16 distinct 16-byte slots.
 __device__ __forceinline__ int nt_off(int row, int chunk) { return row * 128 + ((chunk ^ (row & 7)) << 4); }
 
-template <bool C_BF16>
-__global__ __launch_bounds__(256) void k_gemm_nt(MfmaArgs g) {
-  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * 2 * BM * BK * 2];  // [buf][A|B]
+// WM x WN MFMA fragments (16x16) per wave, NWM x NWN waves per block, BKT-deep k-steps.
+template <bool C_BF16, int WM, int WN, int NWM, int NWN, int BKT>
+__global__ __launch_bounds__(64 * NWM * NWN) void k_gemm_nt(MfmaArgs g) {
+  constexpr int NT = 64 * NWM * NWN;             // threads
+  constexpr int TBM = 16 * WM * NWM, TBN = 16 * WN * NWN;
+  constexpr int CH = BKT / 8;                    // 16-byte chunks per tile row
+  constexpr int ROWB = BKT * 2;                  // bytes per tile row
+  constexpr int RPP = NT / CH;                   // rows staged per pass
+  constexpr int PA = TBM / RPP, PB = TBN / RPP;  // passes
+  static_assert(TBM % RPP == 0 && TBN % RPP == 0, "tile/thread mismatch");
+  constexpr int ABYTES = TBM * ROWB, BBYTES = TBN * ROWB;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];  // [2][A | B]
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
-  const int wm = w >> 1, wn = w & 1;
+  const int wm = w / NWN, wn = w % NWN;
   const int tile = xcd_remap(blockIdx.x, g.tiles_m * g.tiles_n);
-  const int m0 = (tile / g.tiles_n) * BM, n0 = (tile % g.tiles_n) * BN;
+  const int m0 = (tile / g.tiles_n) * TBM, n0 = (tile % g.tiles_n) * TBN;
+  auto off = [](int row, int chunk) { return row * ROWB + ((chunk ^ (row & (CH - 1))) << 4); };
 
-  // staging: thread -> 4 rows x one 16-byte chunk per operand
-  const int srow = t >> 3, sch = t & 7;
-  const bf16* ap[4];
-  const bf16* bp[4];
+  const int srow = t / CH, sch = t % CH;
+  const bf16* ap[PA];
+  const bf16* bp[PB];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int ra = min(m0 + srow + 32 * i, g.M - 1);  // clamp: rows past M are computed, never stored
-    const int rb = min(n0 + srow + 32 * i, g.N - 1);
-    ap[i] = g.A + (int64_t)ra * g.lda + sch * 8;
-    bp[i] = g.B + (int64_t)rb * g.ldb + sch * 8;
-  }
-  uint4 ra_[4], rb_[4];
+  for (int i = 0; i < PA; ++i) ap[i] = g.A + (int64_t)min(m0 + srow + RPP * i, g.M - 1) * g.lda + sch * 8;
+#pragma unroll
+  for (int i = 0; i < PB; ++i) bp[i] = g.B + (int64_t)min(n0 + srow + RPP * i, g.N - 1) * g.ldb + sch * 8;
+  uint4 ra_[PA], rb_[PB];
   auto gload = [&](int k0) {
     const bool in = k0 + sch * 8 < g.K;  // K % 8 == 0: a chunk is entirely inside or outside
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      ra_[i] = in ? *(const uint4*)(ap[i] + k0) : make_uint4(0, 0, 0, 0);
-      rb_[i] = in ? *(const uint4*)(bp[i] + k0) : make_uint4(0, 0, 0, 0);
-    }
+    for (int i = 0; i < PA; ++i) ra_[i] = in ? *(const uint4*)(ap[i] + k0) : make_uint4(0, 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < PB; ++i) rb_[i] = in ? *(const uint4*)(bp[i] + k0) : make_uint4(0, 0, 0, 0);
   };
   auto sstore = [&](int buf) {
-    unsigned char* a = lds + buf * (2 * BM * BK * 2);
-    unsigned char* b = a + BM * BK * 2;
+    unsigned char* a = lds + buf * (ABYTES + BBYTES);
+    unsigned char* b = a + ABYTES;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int r = srow + 32 * i;
-      *(uint4*)(a + nt_off(r, sch)) = ra_[i];
-      *(uint4*)(b + nt_off(r, sch)) = rb_[i];
-    }
+    for (int i = 0; i < PA; ++i) *(uint4*)(a + off(srow + RPP * i, sch)) = ra_[i];
+#pragma unroll
+    for (int i = 0; i < PB; ++i) *(uint4*)(b + off(srow + RPP * i, sch)) = rb_[i];
   };
 
-  f32x4 acc[4][4];  // [jn][im]
+  f32x4 acc[WN][WM];
 #pragma unroll
-  for (int j = 0; j < 4; ++j)
+  for (int j = 0; j < WN; ++j)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) acc[j][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < WM; ++i) acc[j][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  const int nk = (g.K + BK - 1) / BK;
+  const int nk = (g.K + BKT - 1) / BKT;
   gload(0);
   sstore(0);
   __syncthreads();
   const int fr = lane & 15, fq = lane >> 4;
   for (int kt = 0; kt < nk; ++kt) {
     const int buf = kt & 1;
-    if (kt + 1 < nk) gload((kt + 1) * BK);
-    const unsigned char* a = lds + buf * (2 * BM * BK * 2);
-    const unsigned char* b = a + BM * BK * 2;
+    if (kt + 1 < nk) gload((kt + 1) * BKT);
+    const unsigned char* a = lds + buf * (ABYTES + BBYTES);
+    const unsigned char* b = a + ABYTES;
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      bf16x8 af[4], bfr[4];
+    for (int ks = 0; ks < BKT / 32; ++ks) {
+      bf16x8 af[WM], bfr[WN];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        af[i] = *(const bf16x8*)(a + nt_off(wm * 64 + i * 16 + fr, ks * 4 + fq));
-        bfr[i] = *(const bf16x8*)(b + nt_off(wn * 64 + i * 16 + fr, ks * 4 + fq));
-      }
+      for (int i = 0; i < WM; ++i) af[i] = *(const bf16x8*)(a + off(wm * 16 * WM + i * 16 + fr, ks * 4 + fq));
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
+      for (int j = 0; j < WN; ++j) bfr[j] = *(const bf16x8*)(b + off(wn * 16 * WN + j * 16 + fr, ks * 4 + fq));
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+      for (int j = 0; j < WN; ++j)
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
           acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[j][i], 0, 0, 0);
     }
     if (kt + 1 < nk) sstore(buf ^ 1);
@@ -167,10 +201,261 @@ __global__ __launch_bounds__(256) void k_gemm_nt(MfmaArgs g) {
 
   const bool vec_ok = (g.ldc & 3) == 0 && (g.N & 3) == 0;
 #pragma unroll
+  for (int j = 0; j < WN; ++j)
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+      epilogue4<C_BF16>(g, m0 + wm * 16 * WM + i * 16 + fr, n0 + wn * 16 * WN + j * 16 + fq * 4, acc[j][i], vec_ok);
+}
+
+template <bool C_BF16, int WM, int WN, int NWM, int NWN, int BKT>
+static int launch_nt(MfmaArgs& g, hipStream_t st) {
+  constexpr int TBM = 16 * WM * NWM, TBN = 16 * WN * NWN;
+  constexpr int shm = 2 * (TBM + TBN) * BKT * 2;
+  g.tiles_m = (g.M + TBM - 1) / TBM; g.tiles_n = (g.N + TBN - 1) / TBN;
+  auto kern = k_gemm_nt<C_BF16, WM, WN, NWM, NWN, BKT>;
+  if (shm > 64 * 1024) {
+    static bool done = false;  // per instantiation
+    if (!done) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, shm); done = true; }
+  }
+  AFM_LAUNCH(kern, dim3(g.tiles_m * g.tiles_n), dim3(64 * NWM * NWN), shm, st, g);
+  return AFM_OK;
+}
+
+// ------------------------------------------------------------------------------------------ NT, LDS-DMA ring
+// Same tile maths as k_gemm_nt, but operands go HBM -> LDS directly (global_load_lds_dwordx4, no
+// VGPR round trip, no ds_write) into a ring of S stages, with S-1 k-steps in flight: the loads of
+// step kt+S-1 are issued as soon as the barrier of step kt has retired the buffer they overwrite,
+// and each wave waits only for its own pieces of step kt (counted s_waitcnt vmcnt) before that
+// barrier.  One barrier per k-step, never vmcnt(0) inside the loop.  The LDS image of a stage is
+// lane-linear per 1-KiB piece (8 rows x 128 B); the bank swizzle is applied on the SOURCE address
+// (chunk c of row r is fetched by the lane that writes slot c ^ (r & 7)) and again on the read.
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <bool C_BF16, int NWM, int NWN, int S>
+__global__ __launch_bounds__(64 * NWM * NWN) void k_gemm_nt_ring(MfmaArgs g) {
+  constexpr int NW = NWM * NWN;
+  constexpr int TBM = 64 * NWM, TBN = 64 * NWN;
+  constexpr int NI = (TBM + TBN) / 8;      // 1-KiB pieces per stage
+  constexpr int NIW = NI / NW;             // pieces per wave per stage
+  static_assert(NI % NW == 0, "pieces must divide over the waves");
+  constexpr int STAGE = (TBM + TBN) * 128;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  const int t = threadIdx.x, lane = t & 63;
+  const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wm = w / NWN, wn = w % NWN;
+  const int tile = xcd_remap(blockIdx.x, g.tiles_m * g.tiles_n);
+  const int m0 = (tile / g.tiles_n) * TBM, n0 = (tile % g.tiles_n) * TBN;
+
+  // per-lane source pointers of this wave's pieces (k = 0) and their LDS offsets inside a stage
+  const bf16* src[NIW];
+#pragma unroll
+  for (int j = 0; j < NIW; ++j) {
+    const int ii = w + NW * j;
+    const int r8 = lane >> 3, ch = (lane & 7) ^ r8;
+    if (ii < TBM / 8) src[j] = g.A + (int64_t)min(m0 + ii * 8 + r8, g.M - 1) * g.lda + ch * 8;
+    else src[j] = g.B + (int64_t)min(n0 + (ii - TBM / 8) * 8 + r8, g.N - 1) * g.ldb + ch * 8;
+  }
+  auto issue = [&](int kt) {
+    unsigned char* st = lds + (kt % S) * STAGE;
+#pragma unroll
+    for (int j = 0; j < NIW; ++j)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[j] + kt * 64),
+                                       (__attribute__((address_space(3))) void*)(st + (w + NW * j) * 1024), 16, 0, 0);
+  };
+  auto off = [](int row, int chunk) { return row * 128 + ((chunk ^ (row & 7)) << 4); };
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[j][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int nk = g.K / 64;
+#pragma unroll
+  for (int s = 0; s < S - 1; ++s)
+    if (s < nk) issue(s);
+  const int fr = lane & 15, fq = lane >> 4;
+  for (int kt = 0; kt < nk; ++kt) {
+    // pieces of step kt have landed once at most (steps issued after it) * NIW are outstanding
+    const int later = min(S - 2, nk - 1 - kt);
+    if (later >= S - 2) wait_vmcnt<NIW * (S - 2)>();
+    else if (S > 3 && later == S - 3) wait_vmcnt<NIW * (S > 3 ? S - 3 : 0)>();
+    else if (S > 4 && later == S - 4) wait_vmcnt<NIW * (S > 4 ? S - 4 : 0)>();
+    else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    if (kt + S - 1 < nk) issue(kt + S - 1);
+    const unsigned char* a = lds + (kt % S) * STAGE;
+    const unsigned char* b = a + TBM * 128;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 af[4], bfr[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        af[i] = *(const bf16x8*)(a + off(wm * 64 + i * 16 + fr, ks * 4 + fq));
+        bfr[i] = *(const bf16x8*)(b + off(wn * 64 + i * 16 + fr, ks * 4 + fq));
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[j][i], 0, 0, 0);
+    }
+  }
+  const bool vec_ok = (g.ldc & 3) == 0 && (g.N & 3) == 0;
+#pragma unroll
   for (int j = 0; j < 4; ++j)
 #pragma unroll
     for (int i = 0; i < 4; ++i)
       epilogue4<C_BF16>(g, m0 + wm * 64 + i * 16 + fr, n0 + wn * 64 + j * 16 + fq * 4, acc[j][i], vec_ok);
+}
+
+template <bool C_BF16, int NWM, int NWN, int S>
+static int launch_nt_ring(MfmaArgs& g, hipStream_t st) {
+  constexpr int TBM = 64 * NWM, TBN = 64 * NWN;
+  constexpr int shm = S * (TBM + TBN) * 128;
+  static_assert(shm <= 160 * 1024, "ring does not fit the 160 KiB LDS");
+  g.tiles_m = (g.M + TBM - 1) / TBM; g.tiles_n = (g.N + TBN - 1) / TBN;
+  auto kern = k_gemm_nt_ring<C_BF16, NWM, NWN, S>;
+  static bool done = false;  // per instantiation
+  if (!done) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, shm); done = true; }
+  AFM_LAUNCH(kern, dim3(g.tiles_m * g.tiles_n), dim3(64 * NWM * NWN), shm, st, g);
+  return AFM_OK;
+}
+
+// ------------------------------------------------------------------------------------------ NT, persistent ring
+// One workgroup per CU walks a contiguous range of output tiles of its XCD; the LDS-DMA ring keeps
+// running ACROSS tiles (the first k-steps of the next tile are in flight while the current tile
+// finishes and its epilogue stores drain), so the per-tile prologue bubble and the workgroup
+// launch/teardown disappear from the critical path.
+template <bool C_BF16, int NWM, int NWN, int S>
+__global__ __launch_bounds__(64 * NWM * NWN) void k_gemm_nt_pring(MfmaArgs g) {
+  constexpr int NW = NWM * NWN;
+  constexpr int TBM = 64 * NWM, TBN = 64 * NWN;
+  constexpr int NI = (TBM + TBN) / 8, NIW = NI / NW;
+  static_assert(NI % NW == 0, "pieces must divide over the waves");
+  constexpr int STAGE = (TBM + TBN) * 128;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  const int t = threadIdx.x, lane = t & 63;
+  const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wm = w / NWN, wn = w % NWN;
+  const int ntiles = g.tiles_m * g.tiles_n;
+  // XCD x owns tiles [x*tpx, (x+1)*tpx); its blocks (blockIdx % 8 == x) stride through them together
+  const int xcd = blockIdx.x & 7, bx = blockIdx.x >> 3, nbx = gridDim.x >> 3;
+  const int tpx = (ntiles + 7) >> 3;
+  const int tlo = xcd * tpx, thi = min(ntiles, tlo + tpx);
+  auto tile_of = [&](int it) { const int tt = tlo + it * nbx + bx; return tt < thi ? tt : -1; };
+  const int nk = g.K / 64;
+
+  const bf16* src[NIW];
+  auto set_src = [&](int tile) {
+    const int m0 = (tile / g.tiles_n) * TBM, n0 = (tile % g.tiles_n) * TBN;
+#pragma unroll
+    for (int j = 0; j < NIW; ++j) {
+      const int ii = w + NW * j;
+      const int r8 = lane >> 3, ch = (lane & 7) ^ r8;
+      if (ii < TBM / 8) src[j] = g.A + (int64_t)min(m0 + ii * 8 + r8, g.M - 1) * g.lda + ch * 8;
+      else src[j] = g.B + (int64_t)min(n0 + (ii - TBM / 8) * 8 + r8, g.N - 1) * g.ldb + ch * 8;
+    }
+  };
+  int is_it = 0, is_kt = 0, is_slot = 0;       // next step to issue: tile iteration, k-step, ring slot
+  int is_tile = tile_of(0);
+  if (is_tile >= 0) set_src(is_tile);
+  int ahead = 0;                                // steps issued but not yet consumed
+  auto issue_one = [&]() {
+    if (is_tile < 0) return;
+    unsigned char* st = lds + is_slot * STAGE;
+#pragma unroll
+    for (int j = 0; j < NIW; ++j)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[j] + is_kt * 64),
+                                       (__attribute__((address_space(3))) void*)(st + (w + NW * j) * 1024), 16, 0, 0);
+    ++ahead;
+    is_slot = is_slot + 1 == S ? 0 : is_slot + 1;
+    if (++is_kt == nk) {
+      is_kt = 0;
+      is_tile = tile_of(++is_it);
+      if (is_tile >= 0) set_src(is_tile);
+    }
+  };
+  auto off = [](int row, int chunk) { return row * 128 + ((chunk ^ (row & 7)) << 4); };
+#pragma unroll
+  for (int s = 0; s < S - 1; ++s) issue_one();
+
+  const int fr = lane & 15, fq = lane >> 4;
+  const bool vec_ok = (g.ldc & 3) == 0 && (g.N & 3) == 0;
+  int slot = 0;
+  bool prev_full = false;
+  for (int it = 0;; ++it) {
+    const int tile = tile_of(it);
+    if (tile < 0) break;
+    const int m0 = (tile / g.tiles_n) * TBM, n0 = (tile % g.tiles_n) * TBN;
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[j][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int kt = 0; kt < nk; ++kt) {
+      // `ahead` counts the current step too; (ahead-1)*NIW younger pieces may stay in flight.  The
+      // previous tile's epilogue sits in the same in-order counter BEHIND the pieces of this tile's
+      // first S-1 steps: after a full-tile epilogue (exactly 16 stores per wave, plus loads) those
+      // 16 younger operations may stay outstanding too, so the stores drain under the next tile's
+      // MFMAs; after an edge-tile epilogue (store count unknown) drain everything.
+      if (it > 0 && kt < S - 1 && !prev_full) wait_vmcnt<0>();
+      else if (it > 0 && kt < S - 1 && ahead - 1 >= S - 2) wait_vmcnt<NIW * (S - 2) + 16>();
+      else if (ahead - 1 >= S - 2) wait_vmcnt<NIW * (S - 2)>();
+      else if (S > 3 && ahead - 1 == S - 3) wait_vmcnt<NIW * (S > 3 ? S - 3 : 0)>();
+      else wait_vmcnt<0>();
+      __builtin_amdgcn_s_barrier();
+      --ahead;
+      issue_one();
+      const unsigned char* a = lds + slot * STAGE;
+      const unsigned char* b = a + TBM * 128;
+      slot = slot + 1 == S ? 0 : slot + 1;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        bf16x8 af[4], bfr[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          af[i] = *(const bf16x8*)(a + off(wm * 64 + i * 16 + fr, ks * 4 + fq));
+          bfr[i] = *(const bf16x8*)(b + off(wn * 64 + i * 16 + fr, ks * 4 + fq));
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+            acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[j][i], 0, 0, 0);
+      }
+    }
+    prev_full = vec_ok && m0 + TBM <= g.M && n0 + TBN <= g.N;
+    if (prev_full) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          epilogue4_full<C_BF16>(g, m0 + wm * 64 + i * 16 + fr, n0 + wn * 64 + j * 16 + fq * 4, acc[j][i]);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          epilogue4<C_BF16>(g, m0 + wm * 64 + i * 16 + fr, n0 + wn * 64 + j * 16 + fq * 4, acc[j][i], vec_ok);
+    }
+  }
+}
+
+template <bool C_BF16, int NWM, int NWN, int S>
+static int launch_nt_pring(MfmaArgs& g, hipStream_t st, int blocks_per_cu) {
+  constexpr int TBM = 64 * NWM, TBN = 64 * NWN;
+  constexpr int shm = S * (TBM + TBN) * 128;
+  static_assert(shm <= 160 * 1024, "ring does not fit the 160 KiB LDS");
+  g.tiles_m = (g.M + TBM - 1) / TBM; g.tiles_n = (g.N + TBN - 1) / TBN;
+  auto kern = k_gemm_nt_pring<C_BF16, NWM, NWN, S>;
+  static bool done = false;
+  if (!done) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, shm); done = true; }
+  int grid = 256 * blocks_per_cu;                      // 256 CUs; multiple of 8 (XCD ranges)
+  const int ntiles = g.tiles_m * g.tiles_n;
+  if (grid > ((ntiles + 7) / 8) * 8) grid = ((ntiles + 7) / 8) * 8;
+  AFM_LAUNCH(kern, dim3(grid), dim3(64 * NWM * NWN), shm, st, g);
+  return AFM_OK;
 }
 
 // ------------------------------------------------------------------------------------------ TN (wgrad)
@@ -211,6 +496,9 @@ __global__ __launch_bounds__(256) void k_gemm_tn(MfmaArgs g) {
       rb_[i] = (kin && b_in) ? *(const uint4*)(g.B + (int64_t)k * g.ldb + n0 + sch * 8) : make_uint4(0, 0, 0, 0);
     }
   };
+  // bias gradient: the blocks of the first column tile also sum the dy rows they stage
+  const bool do_cs = g.a_colsum != nullptr && (tile % g.tiles_n) == 0;
+  float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   auto sstore = [&](int buf) {
     unsigned char* a = lds + buf * (2 * BK * BM * 2);
     unsigned char* b = a + BK * BM * 2;
@@ -219,6 +507,11 @@ __global__ __launch_bounds__(256) void k_gemm_tn(MfmaArgs g) {
       const int r = srow + 16 * i;
       *(uint4*)(a + tn_off(r, sch)) = ra_[i];
       *(uint4*)(b + tn_off(r, sch)) = rb_[i];
+      if (do_cs) {
+        const bf16x8 v = __builtin_bit_cast(bf16x8, ra_[i]);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) cs[j] += (float)v[j];
+      }
     }
   };
 
@@ -267,6 +560,18 @@ __global__ __launch_bounds__(256) void k_gemm_tn(MfmaArgs g) {
     __syncthreads();
   }
 
+  if (do_cs) {  // 16 row phases x 128 columns of partial sums -> LDS -> one atomic per column
+    float* red = (float*)lds;               // the k-loop ended with a barrier: tiles are dead
+#pragma unroll
+    for (int j = 0; j < 8; ++j) red[srow * 128 + sch * 8 + j] = cs[j];
+    __syncthreads();
+    if (t < 128 && m0 + t < g.M) {
+      float s = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s += red[r * 128 + t];
+      atomicAdd(g.a_colsum + m0 + t, s);
+    }
+  }
   // D[row = fq*4 + r][col = fr] -> C[m = .. + fq*4 + r][n = .. + fr]; fp32 atomics when the
   // reduction is split over blocks (the gradient buffer accumulates anyway), plain += otherwise.
   const int fr = lane & 15, fq = lane >> 4;
@@ -296,7 +601,7 @@ int afm_gemm_mfma_try(const afm_gemm_desc* d, hipStream_t st) {
   MfmaArgs g;
   g.M = d->M; g.N = d->N; g.K = d->K; g.lda = d->lda; g.ldb = d->ldb; g.ldc = d->ldc;
   g.A = (const bf16*)d->A; g.B = (const bf16*)d->B; g.C = d->C;
-  g.bias = d->bias; g.residual = d->residual; g.pre_act = d->pre_act;
+  g.bias = d->bias; g.residual = d->residual; g.pre_act = d->pre_act; g.a_colsum = d->a_colsum;
   g.act = d->act; g.accumulate = d->accumulate;
   g.dd = afm_make_drop(&d->drop);
   g.tiles_m = (d->M + BM - 1) / BM; g.tiles_n = (d->N + BN - 1) / BN;
@@ -307,14 +612,49 @@ int afm_gemm_mfma_try(const afm_gemm_desc* d, hipStream_t st) {
     if (d->bias && !aligned16(d->bias)) return AFM_ERR_UNSUPPORTED;
     if (!aligned16(d->C) || (d->residual && !aligned16(d->residual)) || (d->pre_act && !aligned16(d->pre_act)))
       return AFM_ERR_UNSUPPORTED;
-    const dim3 grid(g.tiles_m * g.tiles_n);
-    if (d->c_dtype == AFM_BF16) AFM_LAUNCH(k_gemm_nt<true>, grid, dim3(256), 0, st, g);
-    else AFM_LAUNCH(k_gemm_nt<false>, grid, dim3(256), 0, st, g);
+    int variant = d->reserved;  // tile-shape experiments (tools/bench_gemm.py); 0 = pick by shape
+    if (variant == 0 && (d->K & 63) == 0) {
+      // persistent LDS-DMA ring: 256x128 tiles when there are enough of them to fill the chip,
+      // otherwise 128x128 at two workgroups per CU; anything with K % 64 != 0 keeps the
+      // register-staged kernel (case 100).
+      const int64_t big_tiles = (int64_t)((d->M + 255) / 256) * ((d->N + 127) / 128);
+      variant = (d->N > 128 && big_tiles >= 256) ? 12 : 13;
+    }
+    int r;
+#define NT_CASE(WM, WN, NWM, NWN, BKT) \
+    (d->c_dtype == AFM_BF16 ? launch_nt<true, WM, WN, NWM, NWN, BKT>(g, st) : launch_nt<false, WM, WN, NWM, NWN, BKT>(g, st))
+    switch (variant) {
+      case 1: r = NT_CASE(8, 4, 2, 2, 64); break;   // 256x128, 4 waves of 128x64
+      case 2: r = NT_CASE(8, 4, 2, 4, 64); break;   // 256x256, 8 waves of 128x64
+      case 3: r = NT_CASE(4, 4, 4, 2, 64); break;   // 256x128, 8 waves of 64x64
+      case 4: r = NT_CASE(4, 4, 2, 2, 32); break;   // 128x128, k-step 32
+      case 5: r = NT_CASE(8, 4, 2, 2, 32); break;   // 256x128, 4 waves, k-step 32
+#define RING_CASE(NWM, NWN, S) \
+    ((d->K & 63) ? AFM_ERR_UNSUPPORTED : (d->c_dtype == AFM_BF16 ? launch_nt_ring<true, NWM, NWN, S>(g, st) : launch_nt_ring<false, NWM, NWN, S>(g, st)))
+      case 6: r = RING_CASE(4, 2, 3); break;        // 256x128, 8 waves, 3-stage LDS-DMA ring
+      case 7: r = RING_CASE(2, 2, 4); break;        // 128x128, 4 waves, 4 stages
+      case 8: r = RING_CASE(2, 2, 3); break;        // 128x128, 4 waves, 3 stages
+      case 9: r = RING_CASE(2, 4, 3); break;        // 128x256, 8 waves, 3 stages
+      case 10: r = RING_CASE(2, 2, 2); break;       // 128x128, 4 waves, 2 stages
+      case 11: r = RING_CASE(4, 1, 4); break;       // 256x64, 4 waves, 4 stages
+#define PRING_CASE(NWM, NWN, S, BPC) \
+    ((d->K & 63) ? AFM_ERR_UNSUPPORTED : (d->c_dtype == AFM_BF16 ? launch_nt_pring<true, NWM, NWN, S>(g, st, BPC) : launch_nt_pring<false, NWM, NWN, S>(g, st, BPC)))
+      case 12: r = PRING_CASE(4, 2, 3, 1); break;   // persistent 256x128, 8 waves, 3 stages
+      case 13: r = PRING_CASE(2, 2, 2, 2); break;   // persistent 128x128, 4 waves, 2 stages, 2 blocks/CU
+      case 14: r = PRING_CASE(2, 4, 3, 1); break;   // persistent 128x256
+      case 15: r = PRING_CASE(2, 2, 3, 1); break;   // persistent 128x128, 3 stages, 1 block/CU
+#undef PRING_CASE
+#undef RING_CASE
+      default: r = NT_CASE(4, 4, 2, 2, 64); break;  // 128x128, 4 waves of 64x64
+    }
+#undef NT_CASE
+    if (r != AFM_OK) return r;
     afm_set_last_algo("mfma_nt");
     return AFM_OK;
   }
   if (d->transA && !d->transB) {  // TN: the wgrad form only
-    if (d->c_dtype != AFM_F32 || d->bias || d->residual || d->pre_act || d->act != AFM_ACT_NONE || d->drop.p > 0.f)
+    if (d->c_dtype != AFM_F32 || d->bias || d->residual || d->pre_act || d->act != AFM_ACT_NONE || d->drop.p > 0.f ||
+        (d->a_colsum && ((uintptr_t)d->a_colsum & 3)))
       return AFM_ERR_UNSUPPORTED;
     if ((d->M & 7) || (d->N & 7) || d->K < 64 || d->M < 16 || d->N < 16) return AFM_ERR_UNSUPPORTED;
     const int tiles = g.tiles_m * g.tiles_n;

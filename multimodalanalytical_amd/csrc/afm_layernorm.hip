@@ -95,7 +95,7 @@ extern "C" int afm_layernorm_fwd(const afm_ln_shape* s, const float* x, const fl
 
 static inline int ln_bwd_blocks(int64_t rows) {
   int64_t g = (rows + 3) / 4;
-  if (g > 1024) g = 1024;
+  if (g > 512) g = 512;   // 2 blocks per CU: enough to stream at HBM rate, few partial rows to reduce
   if (g < 1) g = 1;
   return (int)g;
 }
@@ -172,14 +172,24 @@ __global__ void k_ln_bwd(const TY* __restrict__ dy, const float* __restrict__ x,
   }
 }
 
-__global__ void k_ln_bwd_reduce(const float* __restrict__ partial, float* __restrict__ dgamma,
-                                float* __restrict__ dbeta, int nblocks, int d) {
-  const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= 2 * d) return;
+// 64 columns per block, 4 waves stride the per-block partial rows (lanes = consecutive columns:
+// coalesced), LDS-combine the 4 row phases, one += per column.
+__global__ __launch_bounds__(256) void k_ln_bwd_reduce(const float* __restrict__ partial,
+                                                       float* __restrict__ dgamma,
+                                                       float* __restrict__ dbeta, int nblocks, int d) {
+  __shared__ float sm[4][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int j = blockIdx.x * 64 + lane;
   float acc = 0.f;
-  for (int b = 0; b < nblocks; ++b) acc += partial[(int64_t)b * 2 * d + j];
-  if (j < d) { if (dgamma) dgamma[j] += acc; }
-  else if (dbeta) dbeta[j - d] += acc;
+  if (j < 2 * d)
+    for (int b = w; b < nblocks; b += 4) acc += partial[(int64_t)b * 2 * d + j];
+  sm[w][lane] = acc;
+  __syncthreads();
+  if (w == 0 && j < 2 * d) {
+    const float t = sm[0][lane] + sm[1][lane] + sm[2][lane] + sm[3][lane];
+    if (j < d) { if (dgamma) dgamma[j] += t; }
+    else if (dbeta) dbeta[j - d] += t;
+  }
 }
 
 extern "C" int afm_layernorm_bwd(const afm_ln_shape* s, const void* dy, const float* x,
@@ -210,7 +220,7 @@ extern "C" int afm_layernorm_bwd(const afm_ln_shape* s, const void* dy, const fl
   else if (nv <= 8) LN_BWD(8); else if (nv <= 12) LN_BWD(12); else if (nv <= 16) LN_BWD(16);
   else LN_BWD(32);
 #undef LN_BWD
-  AFM_LAUNCH(k_ln_bwd_reduce, dim3((2 * s->d + 255) / 256), dim3(256), 0, st, partial, dgamma,
+  AFM_LAUNCH(k_ln_bwd_reduce, dim3((2 * s->d + 63) / 64), dim3(256), 0, st, partial, dgamma,
                      dbeta, g, s->d);
   return AFM_OK;
 }

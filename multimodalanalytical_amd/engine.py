@@ -175,10 +175,11 @@ class Seq2SeqEngine:
     def _wgrad(self, dy, x, name, rows, cols, r0=0, r1=None, bias_name=None):
         """dW[r0:r1] += dy^T x ; db[r0:r1] += colsum(dy)."""
         gw = self.G(name, rows, cols, r0, r1)
-        ops.gemm(dy, x, gw, trans_a=True, trans_b=False, accumulate=True, algo=self.algo)
+        gb = None
         if bias_name is not None:
             s = self.ps.specs[bias_name]
-            ops.colsum(dy, self.ps.grad[s.offset + r0: s.offset + r0 + gw.shape[0]], accumulate=True)
+            gb = self.ps.grad[s.offset + r0: s.offset + r0 + gw.shape[0]]
+        ops.gemm(dy, x, gw, trans_a=True, trans_b=False, accumulate=True, algo=self.algo, a_colsum=gb)
 
     # ------------------------------------------------------------------ embedding
     def _pos_rows(self, S: int, saved: Optional[dict]):

@@ -33,7 +33,7 @@ class GemmDesc(C.Structure):
         ("lda", C.c_int32), ("ldb", C.c_int32), ("ldc", C.c_int32),
         ("a_dtype", C.c_int32), ("b_dtype", C.c_int32), ("c_dtype", C.c_int32),
         ("A", C.c_void_p), ("B", C.c_void_p), ("C", C.c_void_p),
-        ("bias", C.c_void_p), ("residual", C.c_void_p), ("pre_act", C.c_void_p),
+        ("bias", C.c_void_p), ("residual", C.c_void_p), ("pre_act", C.c_void_p), ("a_colsum", C.c_void_p),
         ("act", C.c_int32), ("accumulate", C.c_int32), ("algo", C.c_int32), ("reserved", C.c_int32),
         ("drop", Dropout),
     ]

@@ -57,8 +57,10 @@ def last_algo() -> str:
 def gemm(a: torch.Tensor, b: torch.Tensor, c: torch.Tensor, *, trans_a=False, trans_b=True,
          bias: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
          pre_act: Optional[torch.Tensor] = None, act: int = ACT_NONE, accumulate: bool = False,
-         dropout: Dropout = NO_DROP, algo: int = ALGO_AUTO) -> torch.Tensor:
-    """c = epilogue(op(a) @ op(b)); default is the nn.Linear form c = a @ b^T + bias."""
+         dropout: Dropout = NO_DROP, algo: int = ALGO_AUTO, a_colsum: Optional[torch.Tensor] = None,
+         variant: int = 0) -> torch.Tensor:
+    """c = epilogue(op(a) @ op(b)); default is the nn.Linear form c = a @ b^T + bias.
+    a_colsum (trans_a only): a_colsum[m] += sum_k a[k, m], the bias gradient of the wgrad form."""
     M, N = c.shape
     K = a.shape[0] if trans_a else a.shape[1]
     d = GemmDesc()
@@ -80,7 +82,11 @@ def gemm(a: torch.Tensor, b: torch.Tensor, c: torch.Tensor, *, trans_a=False, tr
     if pre_act is not None:
         assert pre_act.dtype == c.dtype and _ld(pre_act) == d.ldc and pre_act.shape == c.shape
     d.pre_act = _ptr(pre_act)
+    if a_colsum is not None:
+        assert trans_a and a_colsum.dtype == torch.float32 and a_colsum.numel() == M and a_colsum.is_contiguous()
+    d.a_colsum = _ptr(a_colsum)
     d.act, d.accumulate, d.algo = int(act), int(accumulate), int(algo)
+    d.reserved = int(variant)
     d.drop = dropout
     L.check(L.load().afm_gemm(C.byref(d), _stream()), "afm_gemm")
     return c

@@ -358,9 +358,14 @@ def test_gemm_mfma_tn_wgrad(ops, R, M, N):
     dy, x = rnd(R, M, seed=1).bfloat16(), rnd(R, N, seed=2).bfloat16()
     g0 = rnd(M, N, seed=3)
     g = dev(g0).clone()
-    ops.gemm(dev(dy), dev(x), g, trans_a=True, trans_b=False, accumulate=True, algo=2)
+    b0 = rnd(M, seed=4); gb = dev(b0).clone()
+    ops.gemm(dev(dy), dev(x), g, trans_a=True, trans_b=False, accumulate=True, algo=2, a_colsum=gb)
     assert ops.last_algo().startswith("mfma_tn")
     close(g, g0.double() + dy.double().T @ x.double(), 1e-4, 2e-4 * math.sqrt(R) / 4)
+    close(gb, b0.double() + dy.double().sum(0), 1e-4, 2e-4 * math.sqrt(R) / 4, "fused bias gradient")
+    gb2 = dev(b0).clone()
+    ops.gemm(dev(dy), dev(x), g.clone(), trans_a=True, trans_b=False, accumulate=True, algo=1, a_colsum=gb2)
+    close(gb2, b0.double() + dy.double().sum(0), 1e-4, 2e-4 * math.sqrt(R) / 4, "generic bias gradient")
     g2 = torch.full((M, N), 3.0, device=DEV)
     ops.gemm(dev(dy), dev(x), g2, trans_a=True, trans_b=False, accumulate=False, algo=2)
     close(g2, dy.double().T @ x.double(), 1e-4, 2e-4 * math.sqrt(R) / 4)
@@ -443,3 +448,12 @@ def test_attention_mfma_strided_packed_qkv(ops):
     q, k, v = (qkv[:, i * d:(i + 1) * d].float().view(B, T, H, dh) for i in range(3))
     _, _, _, ref = _attn_ref(q, k, v, None, False)
     close(o, ref.transpose(1, 2).reshape(B * T, d), 2e-2, 2e-2)
+
+
+@pytest.mark.parametrize("variant", [6, 7, 8, 9, 10, 11, 12, 13, 14, 15])
+@pytest.mark.parametrize("M,N,K", [(512, 256, 512), (1000, 1536, 512), (300, 136, 2048), (129, 24, 64), (70000, 384, 128)])
+def test_gemm_mfma_nt_ring_variants(ops, variant, M, N, K):
+    a, w, bias = rnd(M, K, seed=1).bfloat16(), rnd(N, K, seed=2).bfloat16(), rnd(N, seed=3)
+    c = torch.empty(M, N, device=DEV)
+    ops.gemm(dev(a), dev(w), c, bias=dev(bias), algo=2, variant=variant)
+    close(c, a.double() @ w.double().T + bias.double(), 1e-4, 2e-4 * math.sqrt(K) / 8)

@@ -21,8 +21,11 @@ def main():
         a = torch.randn(M, K, device=dev).bfloat16(); w = torch.randn(N, K, device=dev).bfloat16()
         for cdt in (torch.bfloat16, torch.float32):
             c = torch.empty(M, N, dtype=cdt, device=dev)
-            ms = t(lambda: ops.gemm(a, w, c))
-            print(f"NT {name:10s} {M}x{N}x{K} out {str(cdt)[6:]:8s} {ops.last_algo():10s} {ms:8.3f} ms {2*M*N*K/ms/1e9:8.1f} TF/s")
+            res = []
+            for var in (0, 100, 12, 13):
+                ms = t(lambda: ops.gemm(a, w, c, variant=var))
+                res.append(f"v{var} {2*M*N*K/ms/1e9:6.0f}")
+            print(f"NT {name:10s} {M}x{N}x{K} out {str(cdt)[6:]:8s} TF/s: " + "  ".join(res))
     for name, R, M, N in [("wgrad qkv", B*S, 3*d, d), ("wgrad out", B*S, d, d), ("wgrad ffn1", B*S, f, d), ("wgrad ffn2", B*S, d, f)]:
         dy = torch.randn(R, M, device=dev).bfloat16(); x = torch.randn(R, N, device=dev).bfloat16()
         g = torch.zeros(M, N, device=dev)
