@@ -1,0 +1,45 @@
+"""CPU: the C-ABI library builds/loads and exports every symbol include/afm_hip.h declares.
+No compute calls (no GPU here)."""
+import ctypes
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    src = open(os.path.join(ROOT, "include", "afm_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(afm_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_symbols_are_exported_and_bound():
+    from multimodalanalytical_amd import lib as L
+    handle = L.load()
+    declared = _declared()
+    assert len(declared) >= 20
+    for name in declared:
+        assert hasattr(handle, name), f"libafm_hip.so does not export {name}"
+    assert sorted(L.exported_symbols()) == declared, "lib.py binding and header disagree"
+    assert handle.afm_abi_version() == 1
+    assert handle.afm_error_string(-2) == b"unsupported shape/dtype for the requested algorithm"
+
+
+def test_struct_layouts_match_the_header():
+    from multimodalanalytical_amd import lib as L
+    # 11 int32 (+pad) + 7 pointers + 4 int32 + dropout{float,u32,u64}
+    assert ctypes.sizeof(L.Dropout) == 16
+    assert ctypes.sizeof(L.GemmDesc) == 48 + 7 * 8 + 16 + 16
+    assert L.GemmDesc.A.offset == 48 and L.GemmDesc.a_colsum.offset == 96 and L.GemmDesc.drop.offset == 120
+    assert ctypes.sizeof(L.LnShape) == 48
+    assert L.AttnShape.key_pad.offset == 56 and ctypes.sizeof(L.AttnShape) == 80
+
+
+def test_ops_refuse_cpu_tensors():
+    import pytest
+    import torch
+    from multimodalanalytical_amd import ops
+    from multimodalanalytical_amd.lib import AfmError
+    a = torch.zeros(4, 8)
+    with pytest.raises(AfmError):
+        ops.gemm(a, a, torch.zeros(4, 4))   # the product path has no CPU fallback

@@ -1,0 +1,81 @@
+"""CPU: host-side logic of the product (schedule, step count, parameter layout, synthetic batches)."""
+import numpy as np
+import torch
+
+from tests import golden_io as G
+
+
+def test_onecycle_matches_torch_golden():
+    from multimodalanalytical_amd.optim import onecycle
+    t = G.load("schedule")
+    for total in (10, 100):
+        lr = [onecycle(s, total, 1e-3)[0] for s in range(total)]
+        b1 = [onecycle(s, total, 1e-3)[1] for s in range(total)]
+        np.testing.assert_allclose(lr, t[f"onecycle{total}"]["lr"].numpy(), rtol=1e-12)
+        np.testing.assert_allclose(b1, t[f"onecycle{total}"]["beta1"].numpy(), rtol=1e-12)
+    import pytest
+    with pytest.raises(ValueError):
+        onecycle(10, 10, 1e-3)      # torch raises when stepped past total_steps
+
+
+def test_calculate_training_steps():
+    from multimodalanalytical_amd.trainer import calculate_training_steps
+    assert calculate_training_steps(177000, 128, 4, 60) == 346 * 60          # reference utils.py:156-172
+    assert calculate_training_steps(20, 128, 4, 1) == 1
+    assert calculate_training_steps(177000, 128, 4, 60, world_size=8) == 44 * 60
+
+
+def test_param_layout_equals_reference_state_dict():
+    from multimodalanalytical_amd.params import ParamStore, build_specs
+    for name in ("model_plain", "model_gated_learned"):
+        t = G.load(name)
+        cfg = G.model_cfg(t["meta"])
+        specs = build_specs(cfg, t["meta"]["data_config"], 26)
+        ps = ParamStore(specs, torch.device("cpu"), with_bf16=False)
+        ref = {k: v for k, v in t["sd"].items() if not k.endswith("positional_encodings.pos_enc")}
+        assert set(ps.specs) == set(ref)
+        for k, v in ref.items():
+            assert ps.specs[k].shape == tuple(v.shape), k
+            assert ps.specs[k].offset % 8 == 0
+        ps.load(ref)
+        for k, v in ref.items():
+            assert torch.equal(ps.p(k), v)
+        if cfg["gated_linear"]:   # linear1 | gate must be contiguous for the fused (2f x d) GEMM
+            a, b = ps.specs["encoder.layers.0.linear1.weight"], ps.specs["encoder.layers.0.gate.weight"]
+            assert a.offset + a.numel == b.offset
+        ps.init_(1)
+        w = ps.p("token_ff.weight")
+        bound = (6.0 / (w.shape[0] + w.shape[1])) ** 0.5
+        assert float(w.abs().max()) <= bound and float(w.abs().max()) > 0.5 * bound   # xavier_uniform_
+
+
+def test_sincos_table_matches_reference_golden():
+    from multimodalanalytical_amd.engine import sincos_table
+    t = G.load("schedule")
+    for d in (64, 128, 30):
+        torch.testing.assert_close(sincos_table(d, 40), t["sincos"][str(d)], rtol=0, atol=1e-6)
+
+
+def test_synthetic_workloads_follow_the_collator_contract():
+    from multimodalanalytical_amd import synth
+    for name, S in (("c1", 26), ("c2", 1024), ("c3", 1024), ("c4", 1024), ("c5", 56)):
+        b, w = synth.make_batch(name, 3, seed=5)
+        assert b["encoder_pad_mask"].shape == (S, 3) and b["encoder_pad_mask"].dtype == torch.bool
+        T = w["T"]
+        assert b["target"].shape == (T, 3) and b["decoder_input"]["Smiles"].shape == (T, 3)
+        assert torch.equal(b["decoder_input"]["Smiles"][1:], b["target"][:-1])       # shifted by one
+        assert (b["decoder_input"]["Smiles"][0] == synth.BOS).all()
+        assert torch.equal(b["decoder_pad_mask"], b["decoder_input"]["Smiles"] == synth.PAD)
+        b2, _ = synth.make_batch(name, 3, seed=5)
+        assert torch.equal(b["target"], b2["target"])                                  # seeded
+    assert abs(synth.train_flops_per_sample(synth.WORKLOADS["c2"]["cfg"], 1024, 128, 128) / 1e9 - 196.3) < 0.1
+    assert abs(synth.train_flops_per_sample(synth.WORKLOADS["c4"]["cfg"], 1024, 128, 128) / 1e9 - 1013) < 1
+
+
+def test_dropmask_helpers_are_consistent():
+    from tests.dropmask import keep_mask, keep_mask16
+    k = keep_mask(0.1, 123, 4, 200000)
+    assert abs(k.mean() - 0.9) < 0.005
+    k16, scale = keep_mask16(0.1, 123, 4, 200000)
+    assert abs(k16.mean() - 0.9) < 0.005 and abs(scale - 1 / 0.9) < 1e-3
+    assert keep_mask(0.0, 1, 1, 10).all()
