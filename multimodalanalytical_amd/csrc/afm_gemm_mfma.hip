@@ -51,16 +51,25 @@ __device__ __forceinline__ void epilogue4(const MfmaArgs& g, int m, int n0, f32x
   const int nv = min(4, g.N - n0);
   if (vec_ok && nv == 4) {
     if (g.bias) v += *(const f32x4*)(g.bias + n0);
-    if (g.pre_act) {
-      if (C_BF16) { bf16x4 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]}; *(bf16x4*)((bf16*)g.pre_act + ci) = o; }
-      else *(f32x4*)((float*)g.pre_act + ci) = v;
-    }
+    if (g.act == AFM_ACT_GELU_BWD) {
+      f32x4 u;
+      if (C_BF16) { const bf16x4 uu = *(const bf16x4*)((const bf16*)g.pre_act + ci); u = (f32x4){(float)uu[0], (float)uu[1], (float)uu[2], (float)uu[3]}; }
+      else u = *(const f32x4*)((const float*)g.pre_act + ci);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      float x = v[r];
-      if (g.act == AFM_ACT_RELU) x = fmaxf(x, 0.f);
-      else if (g.act == AFM_ACT_GELU) x = afm_gelu(x);
-      v[r] = afm_drop(g.dd, (uint64_t)m * (uint64_t)g.N + (uint64_t)(n0 + r), x);
+      for (int r = 0; r < 4; ++r)
+        v[r] = afm_drop(g.dd, (uint64_t)m * (uint64_t)g.N + (uint64_t)(n0 + r), v[r]) * afm_gelu_grad(u[r]);
+    } else {
+      if (g.pre_act) {
+        if (C_BF16) { bf16x4 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]}; *(bf16x4*)((bf16*)g.pre_act + ci) = o; }
+        else *(f32x4*)((float*)g.pre_act + ci) = v;
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float x = v[r];
+        if (g.act == AFM_ACT_RELU) x = fmaxf(x, 0.f);
+        else if (g.act == AFM_ACT_GELU) x = afm_gelu(x);
+        v[r] = afm_drop(g.dd, (uint64_t)m * (uint64_t)g.N + (uint64_t)(n0 + r), x);
+      }
     }
     if (g.residual) {
       if (C_BF16) { const bf16x4 rr = *(const bf16x4*)((const bf16*)g.residual + ci); v[0] += (float)rr[0]; v[1] += (float)rr[1]; v[2] += (float)rr[2]; v[3] += (float)rr[3]; }
@@ -78,10 +87,15 @@ __device__ __forceinline__ void epilogue4(const MfmaArgs& g, int m, int n0, f32x
     float x = v[r];
     const int n = n0 + r;
     if (g.bias) x += g.bias[n];
-    if (g.pre_act) { if (C_BF16) ((bf16*)g.pre_act)[ci + r] = (bf16)x; else ((float*)g.pre_act)[ci + r] = x; }
-    if (g.act == AFM_ACT_RELU) x = fmaxf(x, 0.f);
-    else if (g.act == AFM_ACT_GELU) x = afm_gelu(x);
-    x = afm_drop(g.dd, (uint64_t)m * (uint64_t)g.N + (uint64_t)n, x);
+    if (g.act == AFM_ACT_GELU_BWD) {
+      const float u = C_BF16 ? (float)((const bf16*)g.pre_act)[ci + r] : ((const float*)g.pre_act)[ci + r];
+      x = afm_drop(g.dd, (uint64_t)m * (uint64_t)g.N + (uint64_t)n, x) * afm_gelu_grad(u);
+    } else {
+      if (g.pre_act) { if (C_BF16) ((bf16*)g.pre_act)[ci + r] = (bf16)x; else ((float*)g.pre_act)[ci + r] = x; }
+      if (g.act == AFM_ACT_RELU) x = fmaxf(x, 0.f);
+      else if (g.act == AFM_ACT_GELU) x = afm_gelu(x);
+      x = afm_drop(g.dd, (uint64_t)m * (uint64_t)g.N + (uint64_t)n, x);
+    }
     if (g.residual) x += C_BF16 ? (float)((const bf16*)g.residual)[ci + r] : ((const float*)g.residual)[ci + r];
     if (g.accumulate) x += C_BF16 ? (float)((const bf16*)g.C)[ci + r] : ((const float*)g.C)[ci + r];
     if (C_BF16) ((bf16*)g.C)[ci + r] = (bf16)x; else ((float*)g.C)[ci + r] = x;
@@ -94,11 +108,18 @@ template <bool C_BF16>
 __device__ __forceinline__ void epilogue4_full(const MfmaArgs& g, int m, int n0, f32x4 v) {
   const int64_t ci = (int64_t)m * g.ldc + n0;
   if (g.bias) v += *(const f32x4*)(g.bias + n0);
-  if (g.pre_act) {
+  if (g.act == AFM_ACT_GELU_BWD) {
+    f32x4 u;
+    if (C_BF16) { const bf16x4 uu = *(const bf16x4*)((const bf16*)g.pre_act + ci); u = (f32x4){(float)uu[0], (float)uu[1], (float)uu[2], (float)uu[3]}; }
+    else u = *(const f32x4*)((const float*)g.pre_act + ci);
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      v[r] = afm_drop(g.dd, (uint64_t)m * (uint64_t)g.N + (uint64_t)(n0 + r), v[r]) * afm_gelu_grad(u[r]);
+  } else if (g.pre_act) {
     if (C_BF16) { bf16x4 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]}; *(bf16x4*)((bf16*)g.pre_act + ci) = o; }
     else *(f32x4*)((float*)g.pre_act + ci) = v;
   }
-  if (g.act != AFM_ACT_NONE || g.dd.thresh) {
+  if (g.act != AFM_ACT_GELU_BWD && (g.act != AFM_ACT_NONE || g.dd.thresh)) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       float x = v[r];
@@ -327,7 +348,8 @@ static int launch_nt_ring(MfmaArgs& g, hipStream_t st) {
 // running ACROSS tiles (the first k-steps of the next tile are in flight while the current tile
 // finishes and its epilogue stores drain), so the per-tile prologue bubble and the workgroup
 // launch/teardown disappear from the critical path.
-template <bool C_BF16, int NWM, int NWN, int S>
+// ABL (timing experiments only): 1 = skip the LDS reads + MFMAs, 2 = skip the LDS-DMA loads.
+template <bool C_BF16, int NWM, int NWN, int S, int ABL = 0>
 __global__ __launch_bounds__(64 * NWM * NWN) void k_gemm_nt_pring(MfmaArgs g) {
   constexpr int NW = NWM * NWN;
   constexpr int TBM = 64 * NWM, TBN = 64 * NWN;
@@ -364,10 +386,12 @@ __global__ __launch_bounds__(64 * NWM * NWN) void k_gemm_nt_pring(MfmaArgs g) {
   auto issue_one = [&]() {
     if (is_tile < 0) return;
     unsigned char* st = lds + is_slot * STAGE;
+    if (ABL != 2) {
 #pragma unroll
-    for (int j = 0; j < NIW; ++j)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[j] + is_kt * 64),
-                                       (__attribute__((address_space(3))) void*)(st + (w + NW * j) * 1024), 16, 0, 0);
+      for (int j = 0; j < NIW; ++j)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[j] + is_kt * 64),
+                                         (__attribute__((address_space(3))) void*)(st + (w + NW * j) * 1024), 16, 0, 0);
+    }
     ++ahead;
     is_slot = is_slot + 1 == S ? 0 : is_slot + 1;
     if (++is_kt == nk) {
@@ -410,6 +434,7 @@ __global__ __launch_bounds__(64 * NWM * NWN) void k_gemm_nt_pring(MfmaArgs g) {
       const unsigned char* a = lds + slot * STAGE;
       const unsigned char* b = a + TBM * 128;
       slot = slot + 1 == S ? 0 : slot + 1;
+      if (ABL == 1) continue;
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
         bf16x8 af[4], bfr[4];
@@ -442,13 +467,13 @@ __global__ __launch_bounds__(64 * NWM * NWN) void k_gemm_nt_pring(MfmaArgs g) {
   }
 }
 
-template <bool C_BF16, int NWM, int NWN, int S>
+template <bool C_BF16, int NWM, int NWN, int S, int ABL = 0>
 static int launch_nt_pring(MfmaArgs& g, hipStream_t st, int blocks_per_cu) {
   constexpr int TBM = 64 * NWM, TBN = 64 * NWN;
   constexpr int shm = S * (TBM + TBN) * 128;
   static_assert(shm <= 160 * 1024, "ring does not fit the 160 KiB LDS");
   g.tiles_m = (g.M + TBM - 1) / TBM; g.tiles_n = (g.N + TBN - 1) / TBN;
-  auto kern = k_gemm_nt_pring<C_BF16, NWM, NWN, S>;
+  auto kern = k_gemm_nt_pring<C_BF16, NWM, NWN, S, ABL>;
   static bool done = false;
   if (!done) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, shm); done = true; }
   int grid = 256 * blocks_per_cu;                      // 256 CUs; multiple of 8 (XCD ranges)
@@ -643,6 +668,8 @@ int afm_gemm_mfma_try(const afm_gemm_desc* d, hipStream_t st) {
       case 13: r = PRING_CASE(2, 2, 2, 2); break;   // persistent 128x128, 4 waves, 2 stages, 2 blocks/CU
       case 14: r = PRING_CASE(2, 4, 3, 1); break;   // persistent 128x256
       case 15: r = PRING_CASE(2, 2, 3, 1); break;   // persistent 128x128, 3 stages, 1 block/CU
+      case 112: r = launch_nt_pring<true, 4, 2, 3, 1>(g, st, 1); break;   // ablation: no MFMA
+      case 212: r = launch_nt_pring<true, 4, 2, 3, 2>(g, st, 1); break;   // ablation: no loads
 #undef PRING_CASE
 #undef RING_CASE
       default: r = NT_CASE(4, 4, 2, 2, 64); break;  // 128x128, 4 waves of 64x64

@@ -18,7 +18,7 @@ from typing import Any, Dict, List, Optional
 import torch
 
 from . import ops
-from .lib import ACT_NONE, ACT_RELU, ALGO_AUTO
+from .lib import ACT_GELU, ACT_GELU_BWD, ACT_NONE, ACT_RELU, ALGO_AUTO
 from .params import PATCH_TYPES, TEXT_TYPES, ParamStore, build_specs, patch_layers
 
 
@@ -161,16 +161,18 @@ class Seq2SeqEngine:
         return ops.gemm(x, w, out, trans_b=True, bias=bias, residual=residual, dropout=dropout, act=act,
                         pre_act=pre_act, algo=self.algo)
 
-    def _dgrad(self, dy, name, rows, cols, r0=0, r1=None, out=None, out_dtype=None, accumulate=False):
+    def _dgrad(self, dy, name, rows, cols, r0=0, r1=None, out=None, out_dtype=None, accumulate=False,
+               act=ACT_NONE, pre_act=None, dropout=ops.NO_DROP):
         """dx = dy @ W[r0:r1]  (W rows = output features)."""
         r1 = rows if r1 is None else r1
         if out is None:
             out = self._empty(dy.shape[0], cols, out_dtype)
+        kw = dict(accumulate=accumulate, algo=self.algo, act=act, pre_act=pre_act, dropout=dropout)
         if self.cd == torch.bfloat16:
             wt = self.wt[name][:, r0:r1]  # (cols, n): NT form for the MFMA kernel
-            return ops.gemm(dy, wt, out, trans_b=True, accumulate=accumulate, algo=self.algo)
+            return ops.gemm(dy, wt, out, trans_b=True, **kw)
         w = self.W(name, rows, cols, r0, r1)
-        return ops.gemm(dy, w, out, trans_b=False, accumulate=accumulate, algo=self.algo)
+        return ops.gemm(dy, w, out, trans_b=False, **kw)
 
     def _wgrad(self, dy, x, name, rows, cols, r0=0, r1=None, bias_name=None):
         """dW[r0:r1] += dy^T x ; db[r0:r1] += colsum(dy)."""
@@ -346,10 +348,15 @@ class Seq2SeqEngine:
     def _ffn_fwd(self, x, p, f, norm, saved, site):
         d, k = self.d, (2 if self.gated else 1)
         h = self._ln_fwd(x, p + norm, saved, "lnf")
-        uv = self._linear(h, p + "linear1.weight", k * f, d, bias_name=p + "linear1.bias")
-        g = self._empty(x.shape[0], f)
         dr = self._drop(site + "ffn")
-        ops.glu_fwd(uv[:, :f], uv[:, f:] if self.gated else None, g, dr)
+        g = self._empty(x.shape[0], f)
+        if self.gated:
+            uv = self._linear(h, p + "linear1.weight", k * f, d, bias_name=p + "linear1.bias")
+            ops.glu_fwd(uv[:, :f], uv[:, f:], g, dr)
+        else:   # GELU + inner dropout fused into the up-projection's epilogue; u kept for backward
+            uv = self._empty(x.shape[0], f)
+            self._linear(h, p + "linear1.weight", f, d, out=g, bias_name=p + "linear1.bias", act=ACT_GELU,
+                         pre_act=uv, dropout=dr)
         x1 = self._linear(g, p + "linear2.weight", d, f, out_dtype=torch.float32, bias_name=p + "linear2.bias",
                           residual=x, dropout=self._drop(site + "res2"))
         if saved is not None:
@@ -363,10 +370,12 @@ class Seq2SeqEngine:
         dy = self._empty(rows, d)
         ops.dropout_cast(dx1, dy, site_res_drop)
         self._wgrad(dy, g, p + "linear2.weight", d, f, bias_name=p + "linear2.bias")
-        dg = self._dgrad(dy, p + "linear2.weight", d, f)
         duv = self._empty(rows, k * f)
-        ops.glu_bwd(uv[:, :f], uv[:, f:] if self.gated else None, dg, duv[:, :f],
-                    duv[:, f:] if self.gated else None, dr)
+        if self.gated:
+            dg = self._dgrad(dy, p + "linear2.weight", d, f)
+            ops.glu_bwd(uv[:, :f], uv[:, f:], dg, duv[:, :f], duv[:, f:], dr)
+        else:   # du = dropout'(dy W2) * gelu'(u) in the dgrad epilogue: dg never reaches HBM
+            self._dgrad(dy, p + "linear2.weight", d, f, out=duv, act=ACT_GELU_BWD, pre_act=uv, dropout=dr)
         self._wgrad(duv, h, p + "linear1.weight", k * f, d, bias_name=p + "linear1.bias")
         dh = self._dgrad(duv, p + "linear1.weight", k * f, d)
         return self._ln_bwd(dh, p + norm, saved, "lnf", dres=dx1)

@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libafm_hip.so")
 
 AFM_F32, AFM_BF16 = 0, 1
-ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2
+ACT_NONE, ACT_RELU, ACT_GELU, ACT_GELU_BWD = 0, 1, 2, 3
 ALGO_AUTO, ALGO_GENERIC, ALGO_MFMA = 0, 1, 2
 
 

@@ -457,3 +457,21 @@ def test_gemm_mfma_nt_ring_variants(ops, variant, M, N, K):
     c = torch.empty(M, N, device=DEV)
     ops.gemm(dev(a), dev(w), c, bias=dev(bias), algo=2, variant=variant)
     close(c, a.double() @ w.double().T + bias.double(), 1e-4, 2e-4 * math.sqrt(K) / 8)
+
+
+@pytest.mark.parametrize("algo,dt", [(1, torch.float32), (2, torch.bfloat16)])
+def test_gemm_gelu_bwd_epilogue(ops, algo, dt):
+    """du = dropout'(dy W2) * gelu'(u) fused in the dgrad epilogue == separate glu_bwd."""
+    M, f, d = 384, 256, 128
+    dy, w2t, u = rnd(M, d, seed=1), rnd(f, d, seed=2), rnd(M, f, seed=3)
+    if dt == torch.bfloat16:
+        dy, w2t, u = dy.bfloat16().float(), w2t.bfloat16().float(), u.bfloat16().float()
+    p, seed, site = 0.1, 5, 6
+    du = torch.empty(M, f, dtype=dt, device=DEV)
+    ops.gemm(dev(dy, dt), dev(w2t, dt), du, act=3, pre_act=dev(u, dt), dropout=ops.drop(p, seed, site), algo=algo)
+    keep = torch.from_numpy(keep_mask(p, seed, site, M * f)).view(M, f)
+    ur = u.double().requires_grad_(True)
+    O.gelu(ur).backward(torch.ones(M, f, dtype=torch.float64))
+    ref = (dy.double() @ w2t.double().T) * keep / (1 - p) * ur.grad
+    tol = dict(rtol=1e-4, atol=1e-4) if dt == torch.float32 else dict(rtol=2e-2, atol=5e-2)
+    close(du, ref, **tol)
