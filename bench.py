@@ -66,9 +66,15 @@ def dominant_kernel_roofline(model, wl, B, dtype):
     eng = model.hf_model.engine
     x = torch.randn(M, d, device=eng.dev).to(eng.cd)
     w = eng.W("encoder.layers.0.linear1.weight", f, d)
-    bias = eng.ps.p("encoder.layers.0.linear1.bias") if not cfg["gated_linear"] else None
     out = torch.empty(M, f, dtype=eng.cd, device=eng.dev)
-    ms = time_kernel(lambda: ops.gemm(x, w, out, trans_b=True, bias=bias))
+    if cfg["gated_linear"]:      # [u | v] projection, GLU applied by afm_glu_fwd
+        ms = time_kernel(lambda: ops.gemm(x, w, out, trans_b=True))
+    else:                        # exactly the training launch: bias + GELU + dropout epilogue, u kept
+        from multimodalanalytical_amd.lib import ACT_GELU
+        bias = eng.ps.p("encoder.layers.0.linear1.bias")
+        pre = torch.empty_like(out)
+        dr = ops.drop(cfg["dropout"], 1, 1)
+        ms = time_kernel(lambda: ops.gemm(x, w, out, trans_b=True, bias=bias, act=ACT_GELU, pre_act=pre, dropout=dr))
     algo = ops.last_algo()
     flops = 2.0 * M * d * f
     ach = flops / (ms * 1e-3) / 1e12

@@ -94,11 +94,16 @@ __device__ __forceinline__ void stage_store(unsigned char* img, const Stage2& s,
 
 // dropout on a 32x32 score block held transposed (rows = keys in registers, query on the lane):
 // keep bits for key pairs (ACC_ROW(r), +1) come from one hash (afm_keep16).
-__device__ __forceinline__ void drop_block(const DropDev& dd, uint64_t rowbase, int key0, int h, f32x16& x) {
+// The MFMA kernels only run when the whole probability tensor has <= 2^32 elements (eligible()), so
+// the element index fits 32 bits and the high-word term of the hash is zero.
+__device__ __forceinline__ uint32_t hash_pair32(const DropDev& dd, uint32_t half_idx) {
+  return afm_lowbias32(half_idx ^ dd.key);
+}
+__device__ __forceinline__ void drop_block(const DropDev& dd, uint32_t rowbase, int key0, int h, f32x16& x) {
+  const uint32_t base = (rowbase + (uint32_t)(key0 + 4 * h)) >> 1;       // even (Tk even, key0 even)
 #pragma unroll
   for (int r = 0; r < 16; r += 2) {
-    const uint64_t idx = rowbase + (uint64_t)(key0 + ACC_ROW(r) + 4 * h);  // even (Tk even, key0 even)
-    const uint32_t hsh = afm_hash_pair(dd, idx >> 1);
+    const uint32_t hsh = hash_pair32(dd, base + (uint32_t)(ACC_ROW(r) >> 1));
     x[r] = (hsh & 0xFFFFu) >= dd.thresh16 ? x[r] : 0.f;
     x[r + 1] = (hsh >> 16) >= dd.thresh16 ? x[r + 1] : 0.f;
   }
@@ -130,7 +135,7 @@ __global__ __launch_bounds__(256) void k_attn_fwd_mfma(AttnM a, const bf16* __re
 #pragma unroll
   for (int i = 0; i < 16; ++i) { o[0][i] = 0.f; o[1][i] = 0.f; }
   float m = -INFINITY, l = 0.f;
-  const uint64_t rowbase = ((uint64_t)(b * a.H + hd) * a.Tq + qc) * (uint64_t)a.Tk;
+  const uint32_t rowbase = (uint32_t)(((uint64_t)(b * a.H + hd) * a.Tq + qc) * (uint64_t)a.Tk);
 
   int kend = a.Tk;
   if (a.causal) kend = min(a.Tk, blockIdx.x * 128 + 128);  // keys beyond the block's last query are masked
@@ -259,7 +264,7 @@ __global__ __launch_bounds__(256) void k_attn_bwd_dq_mfma(AttnM a, const bf16* _
   f32x16 dq[2];
 #pragma unroll
   for (int i = 0; i < 16; ++i) { dq[0][i] = 0.f; dq[1][i] = 0.f; }
-  const uint64_t rowbase = (uint64_t)lrow * (uint64_t)a.Tk;
+  const uint32_t rowbase = (uint32_t)((uint64_t)lrow * (uint64_t)a.Tk);
 
   int kend = a.Tk;
   if (a.causal) kend = min(a.Tk, blockIdx.x * 128 + 128);
@@ -326,7 +331,7 @@ __global__ __launch_bounds__(256) void k_attn_bwd_dq_mfma(AttnM a, const bf16* _
 // Workgroup = 4 waves x 32 keys; loops over 64-query tiles.  S = Q K^T with the key on the lane
 // (queries in registers), P = exp2(S - lse[q]), dP = dO V^T, dS = P (D dP - delta[q]);
 // dV^T[d][key] += sum_q dO^T[d][q] (D P)[q][key],  dK^T[d][key] += sum_q Q^T[d][q] dS[q][key].
-__global__ __launch_bounds__(256) void k_attn_bwd_dkv_mfma(AttnM a, const bf16* __restrict__ Q,
+__global__ __launch_bounds__(256, 2) void k_attn_bwd_dkv_mfma(AttnM a, const bf16* __restrict__ Q,
                                                            const bf16* __restrict__ K,
                                                            const bf16* __restrict__ V,
                                                            const bf16* __restrict__ dO,
@@ -391,6 +396,23 @@ __global__ __launch_bounds__(256) void k_attn_bwd_dkv_mfma(AttnM a, const bf16* 
         dp = mfma32(frag_row(Drow, 32 * blk, ks, lane), vf[ks], dp);   // dP[q][key]
       }
       f32x16 pd;
+      // Dropout keep bits.  Element (q, key) has index i = (lbase+q)*Tk + key; with Tk even the two
+      // lanes of a key pair (lane, lane^1) share the hash of i>>1 = (lbase+q)*(Tk/2) + key/2 and
+      // take its low / high 16 bits.  The even lane hashes the even register rows, the odd lane
+      // the odd rows, and a quad-permute DPP move hands each lane its partner's hash.
+      uint32_t hv[16];
+      if (a.dd.thresh16) {
+        const uint32_t htk = (uint32_t)a.Tk >> 1;
+        const uint32_t tb = (uint32_t)(lbase + qb + 32 * blk + 4 * h + (lane & 1)) * htk + ((uint32_t)key >> 1);
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+          const uint32_t own = hash_pair32(a.dd, tb + (uint32_t)ACC_ROW(r) * htk);   // row r + (lane&1)
+          const uint32_t oth = (uint32_t)__builtin_amdgcn_mov_dpp((int)own, 0xB1, 0xF, 0xF, true);  // lane^1
+          hv[r] = (lane & 1) ? oth : own;
+          hv[r + 1] = (lane & 1) ? own : oth;
+        }
+      }
+      const uint32_t hshift = (lane & 1) << 4;
 #pragma unroll
       for (int g4 = 0; g4 < 4; ++g4) {
         const int qo = 32 * blk + 8 * g4 + 4 * h;
@@ -405,8 +427,7 @@ __global__ __launch_bounds__(256) void k_attn_bwd_dkv_mfma(AttnM a, const bf16* 
           float p = msk ? 0.f : fast_exp2(s[r] * a.scale_log2 - Lq[j]);
           float dpv = dp[r];
           if (a.dd.thresh16) {
-            const uint64_t idx = ((uint64_t)(lbase + qq)) * (uint64_t)a.Tk + (uint64_t)key;
-            const bool keep = afm_keep16(a.dd, idx);
+            const bool keep = ((hv[r] >> hshift) & 0xFFFFu) >= a.dd.thresh16;
             pd[r] = keep ? p * a.dd.scale16 : 0.f;
             dpv = keep ? dpv * a.dd.scale16 : 0.f;
           } else {
@@ -446,6 +467,7 @@ __global__ __launch_bounds__(256) void k_attn_bwd_dkv_mfma(AttnM a, const bf16* 
 static bool eligible(const afm_attn_shape* s, const void* const* ptrs, int nptr, const int* lds, int nld) {
   if (s->dtype != AFM_BF16 || s->dh != DH) return false;
   if (s->drop.p > 0.f && (s->Tk & 1)) return false;   // the pair hash needs even rows of the mask
+  if (s->drop.p > 0.f && (uint64_t)s->B * s->H * s->Tq * (uint64_t)s->Tk > 0xFFFFFFFFull) return false;  // 32-bit mask index
   for (int i = 0; i < nptr; ++i) if ((uintptr_t)ptrs[i] & 15) return false;
   for (int i = 0; i < nld; ++i) if (lds[i] & 7) return false;
   return true;

@@ -95,7 +95,7 @@ extern "C" int afm_layernorm_fwd(const afm_ln_shape* s, const float* x, const fl
 
 static inline int ln_bwd_blocks(int64_t rows) {
   int64_t g = (rows + 3) / 4;
-  if (g > 512) g = 512;   // 2 blocks per CU: enough to stream at HBM rate, few partial rows to reduce
+  if (g > 1024) g = 1024;  // 4 blocks per CU keep HBM busy; the partial rows are reduced by k_ln_bwd_reduce
   if (g < 1) g = 1;
   return (int)g;
 }
