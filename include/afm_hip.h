@@ -111,6 +111,10 @@ int afm_scatter_add_rows(const int64_t* ids, const float* scale, const float* do
  *     y[out_row(r), :] = LN(x[r, :]) * gamma + beta + (pos ? pos[(out_off + r % seg_len), :] : 0)
  * seg_len == 0 means identity mapping.  x is fp32 (the residual stream); y is fp32 or bf16.
  * mean/rstd (rows, fp32) are saved for backward.
+ * Residual fusion: when `add` is given (rows x d, dtype add_dtype) the kernel first forms
+ * x_sum = x + add, writes it to `x_sum` (fp32, may alias x) and normalises THAT: the residual add
+ * `x + dropout(branch)` of the pre-LN blocks (torch:nn/modules/transformer.py:946-950) rides on
+ * the LayerNorm that reads the stream next, so the projection GEMMs write plain bf16 branches.
  * Backward: dx[r,:] = (dres ? dres[r,:] : 0) + LN'(dy[out_row(r),:]); dgamma/dbeta are
  * ACCUMULATED (+=) into fp32 buffers; `partial` is workspace of afm_layernorm_bwd_ws_floats().
  * ---------------------------------------------------------------------------------------- */
@@ -120,10 +124,11 @@ typedef struct {
   int32_t y_dtype;
   int64_t seg_len, out_seg_stride, out_off;
   float eps;
-  int32_t reserved;
+  int32_t add_dtype;      /* dtype of `add` (forward only) */
 } afm_ln_shape;
 int afm_layernorm_fwd(const afm_ln_shape* s, const float* x, const float* gamma, const float* beta,
-                      const float* pos, void* y, float* mean, float* rstd, void* stream);
+                      const float* pos, void* y, float* mean, float* rstd, const void* add,
+                      float* x_sum, void* stream);
 int64_t afm_layernorm_bwd_ws_floats(const afm_ln_shape* s);
 int afm_layernorm_bwd(const afm_ln_shape* s, const void* dy, const float* x, const float* gamma,
                       const float* mean, const float* rstd, const float* dres, float* dx,

@@ -16,11 +16,11 @@ __device__ __forceinline__ int64_t ln_out_row(int64_t r, int64_t seg_len, int64_
 }
 
 template <typename TY, int NV>
-__global__ void k_ln_fwd(const float* __restrict__ x, const float* __restrict__ gamma,
+__global__ void k_ln_fwd(const float* x, const float* __restrict__ gamma,
                          const float* __restrict__ beta, const float* __restrict__ pos,
                          TY* __restrict__ y, float* __restrict__ mean, float* __restrict__ rstd,
                          int64_t rows, int d, int64_t seg_len, int64_t seg_stride, int64_t off,
-                         float eps) {
+                         float eps, const void* __restrict__ add, int add_bf16, float* x_sum) {
   const int lane = threadIdx.x & 63;
   const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
@@ -33,6 +33,10 @@ __global__ void k_ln_fwd(const float* __restrict__ x, const float* __restrict__ 
     for (int i = 0; i < NV; ++i) {
       const int j = lane + 64 * i;
       v[i] = j < d ? xr[j] : 0.f;
+      if (add && j < d) {   // fused residual add: the stream value is written back once
+        v[i] += add_bf16 ? (float)((const bf16*)add)[r * (int64_t)d + j] : ((const float*)add)[r * (int64_t)d + j];
+        x_sum[r * (int64_t)d + j] = v[i];
+      }
       s += v[i];
     }
     const float mu = wave_sum(s) * inv_d;
@@ -66,8 +70,10 @@ __global__ void k_ln_fwd(const float* __restrict__ x, const float* __restrict__ 
 
 extern "C" int afm_layernorm_fwd(const afm_ln_shape* s, const float* x, const float* gamma,
                                  const float* beta, const float* pos, void* y, float* mean,
-                                 float* rstd, void* stream) {
+                                 float* rstd, const void* add, float* x_sum, void* stream) {
   if (!s || !x || !gamma || !beta || !y || s->rows < 0 || s->d <= 0) return AFM_ERR_ARG;
+  if (add && (!x_sum || (s->add_dtype != AFM_F32 && s->add_dtype != AFM_BF16) || s->seg_len != 0)) return AFM_ERR_ARG;
+  const int add_bf16 = s->add_dtype == AFM_BF16;
   if (s->d > 64 * LN_MAXV) return AFM_ERR_UNSUPPORTED;
   if (s->rows == 0) return AFM_OK;
   int64_t g = (s->rows + 3) / 4;
@@ -79,11 +85,11 @@ extern "C" int afm_layernorm_fwd(const afm_ln_shape* s, const float* x, const fl
     if (s->y_dtype == AFM_F32)                                                                      \
       AFM_LAUNCH((k_ln_fwd<float, NV>), dim3((int)g), dim3(256), 0, st, x, gamma, beta, pos, \
                          (float*)y, mean, rstd, s->rows, s->d, s->seg_len, s->out_seg_stride,       \
-                         s->out_off, s->eps);                                                       \
+                         s->out_off, s->eps, add, add_bf16, x_sum);                                   \
     else                                                                                            \
       AFM_LAUNCH((k_ln_fwd<bf16, NV>), dim3((int)g), dim3(256), 0, st, x, gamma, beta, pos,  \
                          (bf16*)y, mean, rstd, s->rows, s->d, s->seg_len, s->out_seg_stride,        \
-                         s->out_off, s->eps);                                                       \
+                         s->out_off, s->eps, add, add_bf16, x_sum);                                   \
   } while (0)
   const int nv = (s->d + 63) / 64;
   if (nv <= 1) LN_FWD(1); else if (nv <= 2) LN_FWD(2); else if (nv <= 4) LN_FWD(4);

@@ -295,15 +295,23 @@ class Seq2SeqEngine:
                         g = gi
 
     # ------------------------------------------------------------------ blocks
-    def _ln_fwd(self, x, prefix, saved, key, out_dtype=None):
+    def _ln_fwd(self, x, prefix, saved, key, out_dtype=None, pend=None):
+        """y = LN(x + pend).  `pend` is the previous block's (dropped-out) branch output: the residual
+        add is fused here, the summed stream is materialised once (fp32) and returned."""
         rows = x.shape[0]
         y = self._empty(rows, self.d, out_dtype)
         mean = torch.empty(rows, dtype=torch.float32, device=self.dev)
         rstd = torch.empty(rows, dtype=torch.float32, device=self.dev)
-        ops.layernorm_fwd(x, self.ps.p(prefix + "weight"), self.ps.p(prefix + "bias"), y, mean, rstd)
+        if pend is not None:
+            xs = torch.empty_like(x)   # x itself is the saved input of an earlier LayerNorm: keep it
+            ops.layernorm_fwd(x, self.ps.p(prefix + "weight"), self.ps.p(prefix + "bias"), y, mean, rstd,
+                              add=pend, x_sum=xs)
+            x = xs
+        else:
+            ops.layernorm_fwd(x, self.ps.p(prefix + "weight"), self.ps.p(prefix + "bias"), y, mean, rstd)
         if saved is not None:
             saved[key] = (x, mean, rstd)
-        return y
+        return y, x
 
     def _ln_bwd(self, dy, prefix, saved, key, dres):
         x, mean, rstd = saved[key]
@@ -313,20 +321,21 @@ class Seq2SeqEngine:
                           self.ps.g(prefix + "bias"), ws, dres=dres)
         return dx
 
-    def _self_attn_fwd(self, x, p, B, T, H, key_pad, causal, saved, site):
+    def _self_attn_fwd(self, x, pend, p, B, T, H, key_pad, causal, saved, site):
+        """x + pend is the incoming stream; returns (stream, this block's branch to be added)."""
         d = self.d
-        h = self._ln_fwd(x, p + "norm1.", saved, "ln1")
+        h, x = self._ln_fwd(x, p + "norm1.", saved, "ln1", pend=pend)
         qkv = self._linear(h, p + "self_attn.in_proj_weight", 3 * d, d, bias_name=p + "self_attn.in_proj_bias")
         a = self._empty(B * T, d)
         lse = torch.empty(B * H * T, dtype=torch.float32, device=self.dev)
         shp = ops.attn_shape(B, H, T, T, d // H, self.cd, 3 * d, 3 * d, 3 * d, d, key_pad, causal,
                              self._drop(site + "attn"), self.algo)
         ops.attn_fwd(shp, qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], a, lse)
-        x1 = self._linear(a, p + "self_attn.out_proj.weight", d, d, out_dtype=torch.float32,
-                          bias_name=p + "self_attn.out_proj.bias", residual=x, dropout=self._drop(site + "res"))
+        br = self._linear(a, p + "self_attn.out_proj.weight", d, d, bias_name=p + "self_attn.out_proj.bias",
+                          dropout=self._drop(site + "res"))
         if saved is not None:
             saved["sa"] = (h, qkv, a, lse, shp)
-        return x1
+        return x, br
 
     def _self_attn_bwd(self, dx1, p, saved, site_res_drop):
         """dx1: fp32 grad at the block output.  Returns grad at the block input."""
@@ -345,9 +354,9 @@ class Seq2SeqEngine:
         dh = self._dgrad(dqkv, p + "self_attn.in_proj_weight", 3 * d, d)
         return self._ln_bwd(dh, p + "norm1.", saved, "ln1", dres=dx1)
 
-    def _ffn_fwd(self, x, p, f, norm, saved, site):
+    def _ffn_fwd(self, x, pend, p, f, norm, saved, site):
         d, k = self.d, (2 if self.gated else 1)
-        h = self._ln_fwd(x, p + norm, saved, "lnf")
+        h, x = self._ln_fwd(x, p + norm, saved, "lnf", pend=pend)
         dr = self._drop(site + "ffn")
         g = self._empty(x.shape[0], f)
         if self.gated:
@@ -357,11 +366,10 @@ class Seq2SeqEngine:
             uv = self._empty(x.shape[0], f)
             self._linear(h, p + "linear1.weight", f, d, out=g, bias_name=p + "linear1.bias", act=ACT_GELU,
                          pre_act=uv, dropout=dr)
-        x1 = self._linear(g, p + "linear2.weight", d, f, out_dtype=torch.float32, bias_name=p + "linear2.bias",
-                          residual=x, dropout=self._drop(site + "res2"))
+        br = self._linear(g, p + "linear2.weight", d, f, bias_name=p + "linear2.bias", dropout=self._drop(site + "res2"))
         if saved is not None:
             saved["ffn"] = (h, uv, g, dr)
-        return x1
+        return x, br
 
     def _ffn_bwd(self, dx1, p, f, norm, saved, site_res_drop):
         d, k = self.d, (2 if self.gated else 1)
@@ -380,9 +388,9 @@ class Seq2SeqEngine:
         dh = self._dgrad(duv, p + "linear1.weight", k * f, d)
         return self._ln_bwd(dh, p + norm, saved, "lnf", dres=dx1)
 
-    def _cross_attn_fwd(self, x, mem, p, B, T, S, H, mem_pad, saved, site):
+    def _cross_attn_fwd(self, x, pend, mem, p, B, T, S, H, mem_pad, saved, site):
         d = self.d
-        h = self._ln_fwd(x, p + "norm2.", saved, "ln2")
+        h, x = self._ln_fwd(x, p + "norm2.", saved, "ln2", pend=pend)
         w, bname = p + "multihead_attn.in_proj_weight", p + "multihead_attn.in_proj_bias"
         q = self._linear(h, w, 3 * d, d, 0, d, bias_name=bname)
         kv = self._linear(mem, w, 3 * d, d, d, 3 * d, bias_name=bname)
@@ -391,12 +399,11 @@ class Seq2SeqEngine:
         shp = ops.attn_shape(B, H, T, S, d // H, self.cd, d, 2 * d, 2 * d, d, mem_pad, False,
                              self._drop(site + "xattn"), self.algo)
         ops.attn_fwd(shp, q, kv[:, :d], kv[:, d:], a, lse)
-        x1 = self._linear(a, p + "multihead_attn.out_proj.weight", d, d, out_dtype=torch.float32,
-                          bias_name=p + "multihead_attn.out_proj.bias", residual=x,
-                          dropout=self._drop(site + "xres"))
+        br = self._linear(a, p + "multihead_attn.out_proj.weight", d, d,
+                          bias_name=p + "multihead_attn.out_proj.bias", dropout=self._drop(site + "xres"))
         if saved is not None:
             saved["ca"] = (h, q, kv, a, lse, shp)
-        return x1
+        return x, br
 
     def _cross_attn_bwd(self, dx1, mem, dmem, p, saved, site_res_drop):
         d = self.d
@@ -425,14 +432,14 @@ class Seq2SeqEngine:
         assert x.shape[0] == B * S, "attention_mask does not match the concatenated modalities"
         key_pad = (attention_mask == 0).to(torch.uint8).contiguous()
         H = self.cfg["encoder_attention_heads"]
-        layers = []
+        layers, pend = [], None
         for i in range(self.cfg["encoder_layers"]):
             p = f"encoder.layers.{i}."
             sv = {} if saved is not None else None
-            x = self._self_attn_fwd(x, p, B, S, H, key_pad, False, sv, f"e{i}")
-            x = self._ffn_fwd(x, p, self.cfg["encoder_ffn_dim"], "norm2.", sv, f"e{i}")
+            x, pend = self._self_attn_fwd(x, pend, p, B, S, H, key_pad, False, sv, f"e{i}")
+            x, pend = self._ffn_fwd(x, pend, p, self.cfg["encoder_ffn_dim"], "norm2.", sv, f"e{i}")
             layers.append(sv)
-        mem = self._ln_fwd(x, "encoder.norm.", saved, "enc_norm")
+        mem, _ = self._ln_fwd(x, "encoder.norm.", saved, "enc_norm", pend=pend)
         if saved is not None:
             saved.update(enc_layers=layers, key_pad=key_pad, B=B, S=S)
         return mem, key_pad
@@ -445,15 +452,15 @@ class Seq2SeqEngine:
         if dec_attention_mask is not None:
             tgt_pad = (dec_attention_mask == 0).to(torch.uint8).contiguous()
         H = self.cfg["decoder_attention_heads"]
-        layers = []
+        layers, pend = [], None
         for i in range(self.cfg["decoder_layers"]):
             p = f"decoder.layers.{i}."
             sv = {} if saved is not None else None
-            x = self._self_attn_fwd(x, p, B, T, H, tgt_pad, True, sv, f"d{i}")
-            x = self._cross_attn_fwd(x, mem, p, B, T, S, H, mem_pad, sv, f"d{i}")
-            x = self._ffn_fwd(x, p, self.cfg["decoder_ffn_dim"], "norm3.", sv, f"d{i}")
+            x, pend = self._self_attn_fwd(x, pend, p, B, T, H, tgt_pad, True, sv, f"d{i}")
+            x, pend = self._cross_attn_fwd(x, pend, mem, p, B, T, S, H, mem_pad, sv, f"d{i}")
+            x, pend = self._ffn_fwd(x, pend, p, self.cfg["decoder_ffn_dim"], "norm3.", sv, f"d{i}")
             layers.append(sv)
-        hf = self._ln_fwd(x, "decoder.norm.", saved, "dec_norm")
+        hf, _ = self._ln_fwd(x, "decoder.norm.", saved, "dec_norm", pend=pend)
         logits = self._linear(hf, "token_ff.weight", self.V, self.d, out_dtype=torch.float32,
                               bias_name="token_ff.bias")
         if saved is not None:

@@ -43,7 +43,7 @@ class LnShape(C.Structure):
     _fields_ = [
         ("rows", C.c_int64), ("d", C.c_int32), ("y_dtype", C.c_int32),
         ("seg_len", C.c_int64), ("out_seg_stride", C.c_int64), ("out_off", C.c_int64),
-        ("eps", C.c_float), ("reserved", C.c_int32),
+        ("eps", C.c_float), ("add_dtype", C.c_int32),
     ]
 
 
@@ -67,7 +67,7 @@ _SIGS = {
     "afm_gemm": (C.c_int, [C.POINTER(GemmDesc), _P]),
     "afm_gather_rows": (C.c_int, [_P, _P, _P, _P, _I64, _I32, _I32, _P]),
     "afm_scatter_add_rows": (C.c_int, [_P, _P, _P, _P, _I64, _I32, _I32, _I64, _P]),
-    "afm_layernorm_fwd": (C.c_int, [C.POINTER(LnShape), _P, _P, _P, _P, _P, _P, _P, _P]),
+    "afm_layernorm_fwd": (C.c_int, [C.POINTER(LnShape), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "afm_layernorm_bwd_ws_floats": (C.c_int64, [C.POINTER(LnShape)]),
     "afm_layernorm_bwd": (C.c_int, [C.POINTER(LnShape), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "afm_attn_fwd": (C.c_int, [C.POINTER(AttnShape), _P, _P, _P, _P, _P, _P]),

@@ -475,3 +475,19 @@ def test_gemm_gelu_bwd_epilogue(ops, algo, dt):
     ref = (dy.double() @ w2t.double().T) * keep / (1 - p) * ur.grad
     tol = dict(rtol=1e-4, atol=1e-4) if dt == torch.float32 else dict(rtol=2e-2, atol=5e-2)
     close(du, ref, **tol)
+
+
+@pytest.mark.parametrize("adt", [torch.float32, torch.bfloat16])
+def test_layernorm_fused_residual_add(ops, adt):
+    rows, d = 37, 512
+    x, br = rnd(rows, d, seed=1), rnd(rows, d, seed=2)
+    gam, bet = 1 + 0.1 * rnd(d, seed=3), 0.1 * rnd(d, seed=4)
+    brd = dev(br, adt)
+    y = torch.empty(rows, d, dtype=torch.bfloat16, device=DEV); xs = torch.empty(rows, d, device=DEV)
+    mean = torch.empty(rows, device=DEV); rstd = torch.empty(rows, device=DEV)
+    xd = dev(x)
+    ops.layernorm_fwd(xd, dev(gam), dev(bet), y, mean, rstd, add=brd, x_sum=xs)
+    ref_sum = x + brd.float().cpu()
+    close(xs, ref_sum, 0, 0)
+    assert torch.equal(xd.cpu(), x)                       # the input stream is left untouched
+    close(y, O.layer_norm(ref_sum.double(), gam.double(), bet.double()), 1e-2, 1e-2)
