@@ -28,6 +28,7 @@ struct MfmaArgs {
   int act, accumulate;
   int tiles_m, tiles_n;
   int ksplit, kchunk;  // TN only
+  int bias_in_lds;     // persistent NT: staged epilogue enabled (bias vector cached in LDS)
   DropDev dd;
 };
 
@@ -343,24 +344,128 @@ static int launch_nt_ring(MfmaArgs& g, hipStream_t st) {
   return AFM_OK;
 }
 
+// ------------------------------------------------------------------------------------------ staged epilogue
+// Full-tile epilogue of the persistent kernel.  A wave's 64 x 64 accumulator block is transposed
+// through a wave-private LDS patch (16 rows x 64 fp32 at a time, 272-byte rows) so that every global
+// access of the epilogue is 16 bytes per lane on whole 128-byte lines: a store instruction covers
+// 8 complete rows of the tile instead of 16 scattered 32-byte segments (the fragment layout gives
+// a lane 4 columns of one row), which is what bounded the K = 512 GEMMs of this model.
+#define STG_LD 68   // floats per staged row (64 + 4: conflict-free 16-byte writes, 16-byte aligned reads)
+template <bool C_BF16, int WM>
+__device__ __forceinline__ void epilogue_staged(const MfmaArgs& g, float* stg, const float* bias_lds,
+                                                f32x4 (&acc)[4][WM], int mw, int nw, int lane) {
+  const int fr = lane & 15, fq = lane >> 4;
+  if (C_BF16) {
+    const int c8 = (lane & 7) * 8, r8 = lane >> 3;
+    const int n = nw + c8;
+    f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = {0.f, 0.f, 0.f, 0.f};
+    if (g.bias) { b0 = *(const f32x4*)(bias_lds + n); b1 = *(const f32x4*)(bias_lds + n + 4); }
+    bf16x8 uu[2 * WM];
+    if (g.act == AFM_ACT_GELU_BWD) {   // all pre-activation loads first: one wait, before any store
+#pragma unroll
+      for (int q = 0; q < 2 * WM; ++q)
+        uu[q] = *(const bf16x8*)((const bf16*)g.pre_act + (int64_t)(mw + (q >> 1) * 16 + (q & 1) * 8 + r8) * g.ldc + n);
+    }
+#pragma unroll
+    for (int i = 0; i < WM; ++i) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) *(f32x4*)(stg + fr * STG_LD + j * 16 + fq * 4) = acc[j][i];
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf) {
+        const int row = hf * 8 + r8;
+        const int mrow = mw + i * 16 + row;
+        const f32x4 v0 = *(const f32x4*)(stg + row * STG_LD + c8) + b0;
+        const f32x4 v1 = *(const f32x4*)(stg + row * STG_LD + c8 + 4) + b1;
+        float x[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+        const int64_t ci = (int64_t)mrow * g.ldc + n;
+        const uint64_t di = (uint64_t)mrow * (uint64_t)g.N + (uint64_t)n;
+        if (g.act == AFM_ACT_GELU_BWD) {
+          const bf16x8 u = uu[i * 2 + hf];
+#pragma unroll
+          for (int k = 0; k < 8; ++k) x[k] = afm_drop(g.dd, di + k, x[k]) * afm_gelu_grad((float)u[k]);
+        } else {
+          if (g.pre_act) {
+            bf16x8 o = {(bf16)x[0], (bf16)x[1], (bf16)x[2], (bf16)x[3], (bf16)x[4], (bf16)x[5], (bf16)x[6], (bf16)x[7]};
+            *(bf16x8*)((bf16*)g.pre_act + ci) = o;
+          }
+          if (g.act != AFM_ACT_NONE || g.dd.thresh) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+              float y = x[k];
+              if (g.act == AFM_ACT_RELU) y = fmaxf(y, 0.f);
+              else if (g.act == AFM_ACT_GELU) y = afm_gelu(y);
+              x[k] = afm_drop(g.dd, di + k, y);
+            }
+          }
+        }
+        bf16x8 o = {(bf16)x[0], (bf16)x[1], (bf16)x[2], (bf16)x[3], (bf16)x[4], (bf16)x[5], (bf16)x[6], (bf16)x[7]};
+        *(bf16x8*)((bf16*)g.C + ci) = o;
+      }
+    }
+  } else {
+    const int c4 = (lane & 15) * 4, r4 = lane >> 4;
+    const int n = nw + c4;
+    f32x4 b0 = {0.f, 0.f, 0.f, 0.f};
+    if (g.bias) b0 = *(const f32x4*)(bias_lds + n);
+#pragma unroll
+    for (int i = 0; i < WM; ++i) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) *(f32x4*)(stg + fr * STG_LD + j * 16 + fq * 4) = acc[j][i];
+#pragma unroll
+      for (int qq = 0; qq < 4; ++qq) {
+        const int row = qq * 4 + r4;
+        const int mrow = mw + i * 16 + row;
+        f32x4 v = *(const f32x4*)(stg + row * STG_LD + c4) + b0;
+        const int64_t ci = (int64_t)mrow * g.ldc + n;
+        const uint64_t di = (uint64_t)mrow * (uint64_t)g.N + (uint64_t)n;
+        if (g.act == AFM_ACT_GELU_BWD) {
+          const f32x4 u = *(const f32x4*)((const float*)g.pre_act + ci);
+#pragma unroll
+          for (int k = 0; k < 4; ++k) v[k] = afm_drop(g.dd, di + k, v[k]) * afm_gelu_grad(u[k]);
+        } else {
+          if (g.pre_act) *(f32x4*)((float*)g.pre_act + ci) = v;
+          if (g.act != AFM_ACT_NONE || g.dd.thresh) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              float y = v[k];
+              if (g.act == AFM_ACT_RELU) y = fmaxf(y, 0.f);
+              else if (g.act == AFM_ACT_GELU) y = afm_gelu(y);
+              v[k] = afm_drop(g.dd, di + k, y);
+            }
+          }
+        }
+        if (g.residual) v += *(const f32x4*)((const float*)g.residual + ci);
+        if (g.accumulate) v += *(const f32x4*)((const float*)g.C + ci);
+        *(f32x4*)((float*)g.C + ci) = v;
+      }
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------ NT, persistent ring
 // One workgroup per CU walks a contiguous range of output tiles of its XCD; the LDS-DMA ring keeps
 // running ACROSS tiles (the first k-steps of the next tile are in flight while the current tile
 // finishes and its epilogue stores drain), so the per-tile prologue bubble and the workgroup
 // launch/teardown disappear from the critical path.
 // ABL (timing experiments only): 1 = skip the LDS reads + MFMAs, 2 = skip the LDS-DMA loads.
-template <bool C_BF16, int NWM, int NWN, int S, int ABL = 0>
+template <bool C_BF16, int NWM, int NWN, int S, int ABL = 0, int WM = 4>
 __global__ __launch_bounds__(64 * NWM * NWN) void k_gemm_nt_pring(MfmaArgs g) {
   constexpr int NW = NWM * NWN;
-  constexpr int TBM = 64 * NWM, TBN = 64 * NWN;
+  constexpr int TBM = 16 * WM * NWM, TBN = 64 * NWN;
   constexpr int NI = (TBM + TBN) / 8, NIW = NI / NW;
   static_assert(NI % NW == 0, "pieces must divide over the waves");
   constexpr int STAGE = (TBM + TBN) * 128;
+  static_assert(NW * 16 * STG_LD * 4 <= STAGE, "wave-private staging patches must fit one ring slot");
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  float* bias_lds = (float*)(lds + S * STAGE);   // whole bias vector, loaded once (g.bias_in_lds)
   const int t = threadIdx.x, lane = t & 63;
   const int w = __builtin_amdgcn_readfirstlane(t >> 6);
   const int wm = w / NWN, wn = w % NWN;
   const int ntiles = g.tiles_m * g.tiles_n;
+  if (g.bias_in_lds) {   // plain loads, retired (barrier) before the first LDS-DMA piece is issued
+    for (int n = t; n < g.N; n += 64 * NW) bias_lds[n] = g.bias ? g.bias[n] : 0.f;
+    __syncthreads();
+  }
   // XCD x owns tiles [x*tpx, (x+1)*tpx); its blocks (blockIdx % 8 == x) stride through them together
   const int xcd = blockIdx.x & 7, bx = blockIdx.x >> 3, nbx = gridDim.x >> 3;
   const int tpx = (ntiles + 7) >> 3;
@@ -412,19 +517,19 @@ __global__ __launch_bounds__(64 * NWM * NWN) void k_gemm_nt_pring(MfmaArgs g) {
     const int tile = tile_of(it);
     if (tile < 0) break;
     const int m0 = (tile / g.tiles_n) * TBM, n0 = (tile % g.tiles_n) * TBN;
-    f32x4 acc[4][4];
+    f32x4 acc[4][WM];
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) acc[j][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      for (int i = 0; i < WM; ++i) acc[j][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
     for (int kt = 0; kt < nk; ++kt) {
       // `ahead` counts the current step too; (ahead-1)*NIW younger pieces may stay in flight.  The
       // previous tile's epilogue sits in the same in-order counter BEHIND the pieces of this tile's
-      // first S-1 steps: after a full-tile epilogue (exactly 16 stores per wave, plus loads) those
-      // 16 younger operations may stay outstanding too, so the stores drain under the next tile's
+      // first S-1 steps: after a full-tile epilogue (exactly 8 / 16 stores per wave for bf16 / fp32
+      // output, plus loads) those younger operations may stay outstanding too, so the stores drain under the next tile's
       // MFMAs; after an edge-tile epilogue (store count unknown) drain everything.
       if (it > 0 && kt < S - 1 && !prev_full) wait_vmcnt<0>();
-      else if (it > 0 && kt < S - 1 && ahead - 1 >= S - 2) wait_vmcnt<NIW * (S - 2) + 16>();
+      else if (it > 0 && kt < S - 1 && ahead - 1 >= S - 2) wait_vmcnt<NIW * (S - 2) + (C_BF16 ? 2 * WM : 4 * WM)>();
       else if (ahead - 1 >= S - 2) wait_vmcnt<NIW * (S - 2)>();
       else if (S > 3 && ahead - 1 == S - 3) wait_vmcnt<NIW * (S > 3 ? S - 3 : 0)>();
       else wait_vmcnt<0>();
@@ -437,45 +542,52 @@ __global__ __launch_bounds__(64 * NWM * NWN) void k_gemm_nt_pring(MfmaArgs g) {
       if (ABL == 1) continue;
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
-        bf16x8 af[4], bfr[4];
+        bf16x8 af[WM], bfr[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          af[i] = *(const bf16x8*)(a + off(wm * 64 + i * 16 + fr, ks * 4 + fq));
-          bfr[i] = *(const bf16x8*)(b + off(wn * 64 + i * 16 + fr, ks * 4 + fq));
-        }
+        for (int i = 0; i < WM; ++i) af[i] = *(const bf16x8*)(a + off(wm * 16 * WM + i * 16 + fr, ks * 4 + fq));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bfr[j] = *(const bf16x8*)(b + off(wn * 64 + j * 16 + fr, ks * 4 + fq));
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
-          for (int i = 0; i < 4; ++i)
+          for (int i = 0; i < WM; ++i)
             acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[j][i], 0, 0, 0);
       }
     }
-    prev_full = vec_ok && m0 + TBM <= g.M && n0 + TBN <= g.N;
+    prev_full = g.bias_in_lds && m0 + TBM <= g.M && n0 + TBN <= g.N;
     if (prev_full) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-          epilogue4_full<C_BF16>(g, m0 + wm * 64 + i * 16 + fr, n0 + wn * 64 + j * 16 + fq * 4, acc[j][i]);
+      // the slot read by the last k-step is free until the next issue: stage through it
+      __builtin_amdgcn_s_barrier();
+      float* stg = (float*)(lds + (slot == 0 ? S - 1 : slot - 1) * STAGE) + w * (16 * STG_LD);
+      epilogue_staged<C_BF16, WM>(g, stg, bias_lds, acc, m0 + wm * 16 * WM, n0 + wn * 64, lane);
     } else {
 #pragma unroll
       for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-          epilogue4<C_BF16>(g, m0 + wm * 64 + i * 16 + fr, n0 + wn * 64 + j * 16 + fq * 4, acc[j][i], vec_ok);
+        for (int i = 0; i < WM; ++i)
+          epilogue4<C_BF16>(g, m0 + wm * 16 * WM + i * 16 + fr, n0 + wn * 64 + j * 16 + fq * 4, acc[j][i], vec_ok);
     }
   }
 }
 
-template <bool C_BF16, int NWM, int NWN, int S, int ABL = 0>
+template <bool C_BF16, int NWM, int NWN, int S, int ABL = 0, int WM = 4>
 static int launch_nt_pring(MfmaArgs& g, hipStream_t st, int blocks_per_cu) {
-  constexpr int TBM = 64 * NWM, TBN = 64 * NWN;
-  constexpr int shm = S * (TBM + TBN) * 128;
-  static_assert(shm <= 160 * 1024, "ring does not fit the 160 KiB LDS");
+  constexpr int TBM = 16 * WM * NWM, TBN = 64 * NWN;
+  constexpr int ring = S * (TBM + TBN) * 128;
+  static_assert(ring <= 160 * 1024, "ring does not fit the 160 KiB LDS");
   g.tiles_m = (g.M + TBM - 1) / TBM; g.tiles_n = (g.N + TBN - 1) / TBN;
-  auto kern = k_gemm_nt_pring<C_BF16, NWM, NWN, S, ABL>;
-  static bool done = false;
-  if (!done) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, shm); done = true; }
+  // staged epilogue: needs 16-byte rows everywhere and room for the bias vector behind the ring
+  const int bias_bytes = ((g.N * 4 + 15) / 16) * 16;
+  const bool rows16 = (g.N % 8) == 0 && (g.ldc % 8) == 0;
+  const bool modes_ok = C_BF16 ? (!g.residual && !g.accumulate) : true;
+  g.bias_in_lds = rows16 && modes_ok && ring * blocks_per_cu + bias_bytes * blocks_per_cu <= 160 * 1024 ? 1 : 0;
+  const int shm = ring + (g.bias_in_lds ? bias_bytes : 0);
+  auto kern = k_gemm_nt_pring<C_BF16, NWM, NWN, S, ABL, WM>;
+  static int attr_shm = 0;   // per instantiation
+  if (shm > attr_shm) {
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_shm = 160 * 1024;
+  }
   int grid = 256 * blocks_per_cu;                      // 256 CUs; multiple of 8 (XCD ranges)
   const int ntiles = g.tiles_m * g.tiles_n;
   if (grid > ((ntiles + 7) / 8) * 8) grid = ((ntiles + 7) / 8) * 8;
@@ -630,7 +742,7 @@ int afm_gemm_mfma_try(const afm_gemm_desc* d, hipStream_t st) {
   g.act = d->act; g.accumulate = d->accumulate;
   g.dd = afm_make_drop(&d->drop);
   g.tiles_m = (d->M + BM - 1) / BM; g.tiles_n = (d->N + BN - 1) / BN;
-  g.ksplit = 1; g.kchunk = d->K;
+  g.ksplit = 1; g.kchunk = d->K; g.bias_in_lds = 0;
   if (!aligned16(d->A) || !aligned16(d->B) || (d->lda & 7) || (d->ldb & 7)) return AFM_ERR_UNSUPPORTED;
   if (!d->transA && d->transB) {  // NT
     if ((d->K & 7) || d->K < 32 || d->N < 16) return AFM_ERR_UNSUPPORTED;
@@ -668,6 +780,7 @@ int afm_gemm_mfma_try(const afm_gemm_desc* d, hipStream_t st) {
       case 13: r = PRING_CASE(2, 2, 2, 2); break;   // persistent 128x128, 4 waves, 2 stages, 2 blocks/CU
       case 14: r = PRING_CASE(2, 4, 3, 1); break;   // persistent 128x256
       case 15: r = PRING_CASE(2, 2, 3, 1); break;   // persistent 128x128, 3 stages, 1 block/CU
+      case 16: r = (d->K & 63) ? AFM_ERR_UNSUPPORTED : (d->c_dtype == AFM_BF16 ? launch_nt_pring<true, 2, 4, 2, 0, 8>(g, st, 1) : launch_nt_pring<false, 2, 4, 2, 0, 8>(g, st, 1)); break;   // persistent 256x256, 8 waves of 128x64, 2 stages
       case 112: r = launch_nt_pring<true, 4, 2, 3, 1>(g, st, 1); break;   // ablation: no MFMA
       case 212: r = launch_nt_pring<true, 4, 2, 3, 2>(g, st, 1); break;   // ablation: no loads
 #undef PRING_CASE

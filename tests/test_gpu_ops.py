@@ -450,7 +450,7 @@ def test_attention_mfma_strided_packed_qkv(ops):
     close(o, ref.transpose(1, 2).reshape(B * T, d), 2e-2, 2e-2)
 
 
-@pytest.mark.parametrize("variant", [6, 7, 8, 9, 10, 11, 12, 13, 14, 15])
+@pytest.mark.parametrize("variant", [6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16])
 @pytest.mark.parametrize("M,N,K", [(512, 256, 512), (1000, 1536, 512), (300, 136, 2048), (129, 24, 64), (70000, 384, 128)])
 def test_gemm_mfma_nt_ring_variants(ops, variant, M, N, K):
     a, w, bias = rnd(M, K, seed=1).bfloat16(), rnd(N, K, seed=2).bfloat16(), rnd(N, seed=3)
@@ -491,3 +491,38 @@ def test_layernorm_fused_residual_add(ops, adt):
     close(xs, ref_sum, 0, 0)
     assert torch.equal(xd.cpu(), x)                       # the input stream is left untouched
     close(y, O.layer_norm(ref_sum.double(), gam.double(), bet.double()), 1e-2, 1e-2)
+
+
+@pytest.mark.parametrize("cdt", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("mode", ["bias", "gelu_preact_drop", "gelu_bwd", "residual_acc"])
+def test_gemm_persistent_staged_epilogue(ops, cdt, mode):
+    """Full tiles (256x128) + edge tiles through the persistent kernel's LDS-staged epilogue."""
+    M, N, K = 1024 + 77, 512 + 40, 128
+    a, w, bias = rnd(M, K, seed=1).bfloat16(), rnd(N, K, seed=2).bfloat16(), rnd(N, seed=3)
+    t = a.double() @ w.double().T
+    c = torch.zeros(M, N, dtype=cdt, device=DEV)
+    p, seed, site = 0.1, 31, 9
+    keep = torch.from_numpy(keep_mask(p, seed, site, M * N)).view(M, N)
+    tol = dict(rtol=2e-2, atol=3e-2) if cdt == torch.bfloat16 else dict(rtol=1e-4, atol=1e-4)
+    if mode == "bias":
+        ops.gemm(dev(a), dev(w), c, bias=dev(bias), algo=2, variant=12)
+        close(c, t + bias.double(), **tol)
+    elif mode == "gelu_preact_drop":
+        pre = torch.zeros_like(c)
+        ops.gemm(dev(a), dev(w), c, bias=dev(bias), act=2, pre_act=pre, dropout=ops.drop(p, seed, site), algo=2, variant=12)
+        close(pre, t + bias.double(), **tol)
+        close(c, O.gelu(t + bias.double()) * keep / (1 - p), **tol)
+    elif mode == "gelu_bwd":
+        u = rnd(M, N, seed=4)
+        ud = dev(u, cdt)
+        ops.gemm(dev(a), dev(w), c, act=3, pre_act=ud, dropout=ops.drop(p, seed, site), algo=2, variant=12)
+        ur = ud.float().cpu().double().requires_grad_(True)
+        O.gelu(ur).backward(torch.ones(M, N, dtype=torch.float64))
+        close(c, t * keep / (1 - p) * ur.grad, **tol)
+    else:
+        if cdt == torch.bfloat16:
+            pytest.skip("bf16 residual/accumulate take the fragment epilogue (covered elsewhere)")
+        res, c0 = rnd(M, N, seed=5), rnd(M, N, seed=6)
+        c.copy_(dev(c0))
+        ops.gemm(dev(a), dev(w), c, bias=dev(bias), residual=dev(res), accumulate=True, algo=2, variant=12)
+        close(c, t + bias.double() + res.double() + c0.double(), **tol)
