@@ -616,7 +616,9 @@ __global__ __launch_bounds__(256) void k_gemm_tn(MfmaArgs g) {
   const int wm = w >> 1, wn = w & 1;
   const int ntile = g.tiles_m * g.tiles_n;
   const int bid = xcd_remap(blockIdx.x, ntile * g.ksplit);
-  const int tile = bid / g.ksplit, ks_id = bid % g.ksplit;
+  // tile index fastest: the workgroups of one XCD share a k-chunk, so the dy / x rows they stream are
+  // fetched from HBM once and served to the other tiles from that XCD's L2
+  const int tile = bid % ntile, ks_id = bid / ntile;
   const int m0 = (tile / g.tiles_n) * BM, n0 = (tile % g.tiles_n) * BN;
   const int kbeg = ks_id * g.kchunk, kend = min(g.K, kbeg + g.kchunk);
 
@@ -730,6 +732,135 @@ __global__ __launch_bounds__(256) void k_gemm_tn(MfmaArgs g) {
     }
 }
 
+// ------------------------------------------------------------------------------------------ TN, LDS-DMA ring
+// wgrad with the operands streamed HBM -> LDS by LDS-DMA into a 3-stage ring (two 64-row k-steps in
+// flight), 8 waves, 256 x 128 output tile (dy columns x input features), split-K over the token rows
+// with fp32 atomics into the gradient buffer.  Stage image: A rows of 256 columns (512 B) and B rows of
+// 128 columns (256 B), 16-byte chunks XOR-swizzled with tn_swz(row) on the source side; fragments by
+// ds_read_b64_tr_b16 exactly as in k_gemm_tn.  Needs K % 64 == 0 (no zero fill with LDS-DMA).
+template <int ABL>
+__global__ __launch_bounds__(512, 2) void k_gemm_tn_ring(MfmaArgs g) {
+  constexpr int S = 3, TBM = 256, TBN = 128, NW = 8, NIW = 6;
+  constexpr int ABYTES = 64 * TBM * 2, STAGE = 64 * (TBM + TBN) * 2;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  const int t = threadIdx.x, lane = t & 63;
+  const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wm = w >> 1, wn = w & 1;
+  const int ntile = g.tiles_m * g.tiles_n;
+  const int bid = xcd_remap(blockIdx.x, ntile * g.ksplit);
+  // tile index fastest: the workgroups of one XCD share a k-chunk, so the dy / x rows they stream are
+  // fetched from HBM once and served to the other tiles from that XCD's L2
+  const int tile = bid % ntile, ks_id = bid / ntile;
+  const int m0 = (tile / g.tiles_n) * TBM, n0 = (tile % g.tiles_n) * TBN;
+  const int kbeg = ks_id * g.kchunk, kend = min(g.K, kbeg + g.kchunk);
+  const int nk = (kend - kbeg) / 64;
+
+  // this wave's pieces: ii = w + 8 j; ii < 32 -> A rows {2 ii, 2 ii + 1} (512 B each), else B rows 4 (ii-32) ..
+  const bf16* src[NIW];
+  int64_t pitch[NIW];
+#pragma unroll
+  for (int j = 0; j < NIW; ++j) {
+    const int ii = w + NW * j;
+    if (ii < 32) {
+      const int r = ii * 2 + (lane >> 5);
+      const int c = (lane & 31) ^ tn_swz(r);
+      src[j] = g.A + (int64_t)(kbeg + r) * g.lda + min(m0 + c * 8, g.M - 8);
+      pitch[j] = (int64_t)64 * g.lda;
+    } else {
+      const int r = (ii - 32) * 4 + (lane >> 4);
+      const int c = (lane & 15) ^ tn_swz(r);
+      src[j] = g.B + (int64_t)(kbeg + r) * g.ldb + min(n0 + c * 8, g.N - 8);
+      pitch[j] = (int64_t)64 * g.ldb;
+    }
+  }
+  auto issue = [&](int kt) {
+    unsigned char* st = lds + (kt % S) * STAGE;
+    if (ABL == 2) return;
+#pragma unroll
+    for (int j = 0; j < NIW; ++j)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[j] + kt * pitch[j]),
+                                       (__attribute__((address_space(3))) void*)(st + (w + NW * j) * 1024), 16, 0, 0);
+  };
+  auto offA = [](int row, int chunk) { return row * 512 + ((chunk ^ tn_swz(row)) << 4); };
+  auto offB = [](int row, int chunk) { return row * 256 + ((chunk ^ tn_swz(row)) << 4); };
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const bool do_cs = g.a_colsum != nullptr && (tile % g.tiles_n) == 0 && wn == 0;
+  float cs[4] = {0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll
+  for (int s = 0; s < S - 1; ++s)
+    if (s < nk) issue(s);
+  const int grp = lane >> 4, q = (lane >> 2) & 3, p = lane & 3;
+  for (int kt = 0; kt < nk; ++kt) {
+    const int later = min(S - 2, nk - 1 - kt);
+    if (later >= S - 2) wait_vmcnt<NIW * (S - 2)>(); else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    if (kt + S - 1 < nk) issue(kt + S - 1);
+    const unsigned char* a = lds + (kt % S) * STAGE;
+    const unsigned char* b = a + ABYTES;
+    if (ABL == 1) continue;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 af[4], bfr[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int ca = wm * 64 + i * 16, cb = wn * 64 + i * 16;
+        const int r0 = ks * 32 + grp * 8 + q, r1 = r0 + 4;
+        const int cha = (ca >> 3) + (p >> 1), chb = (cb >> 3) + (p >> 1);
+        const bf16x4 a0 = ds_read_tr(a + offA(r0, cha) + ((p & 1) << 3));
+        const bf16x4 a1 = ds_read_tr(a + offA(r1, cha) + ((p & 1) << 3));
+        const bf16x4 b0 = ds_read_tr(b + offB(r0, chb) + ((p & 1) << 3));
+        const bf16x4 b1 = ds_read_tr(b + offB(r1, chb) + ((p & 1) << 3));
+        af[i] = (bf16x8){a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+        bfr[i] = (bf16x8){b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+      }
+      if (do_cs) {   // bias gradient: column sums of dy from the A fragments (lane: column fr, 8 rows)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 8; ++j) cs[i] += (float)af[i][j];
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+    }
+  }
+  const int fr = lane & 15, fq = lane >> 4;
+  if (do_cs) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float s = cs[i];
+      s += __shfl_xor(s, 16, 64);
+      s += __shfl_xor(s, 32, 64);
+      const int mm = m0 + wm * 64 + i * 16 + fr;
+      if (fq == 0 && mm < g.M) atomicAdd(g.a_colsum + mm, s);
+    }
+  }
+  float* C = (float*)g.C;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = n0 + wn * 64 + j * 16 + fr;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int mm = m0 + wm * 64 + i * 16 + fq * 4 + r;
+        if (mm < g.M && n < g.N) {
+          float* c = C + (int64_t)mm * g.ldc + n;
+          if (g.ksplit > 1) atomicAdd(c, acc[i][j][r]);
+          else *c = acc[i][j][r] + (g.accumulate ? *c : 0.f);
+        }
+      }
+    }
+}
+
 // ------------------------------------------------------------------------------------------ dispatch
 static inline bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
@@ -797,6 +928,34 @@ int afm_gemm_mfma_try(const afm_gemm_desc* d, hipStream_t st) {
         (d->a_colsum && ((uintptr_t)d->a_colsum & 3)))
       return AFM_ERR_UNSUPPORTED;
     if ((d->M & 7) || (d->N & 7) || d->K < 64 || d->M < 16 || d->N < 16) return AFM_ERR_UNSUPPORTED;
+    if (d->reserved != 100 && (d->K & 63) == 0 && d->K >= 4096 && d->M >= 64 && d->N >= 64) {
+      // LDS-DMA ring kernel: 256 x 128 tiles, one 8-wave workgroup per CU, split-K to fill the chip
+      g.tiles_m = (d->M + 255) / 256; g.tiles_n = (d->N + 127) / 128;
+      const int tiles = g.tiles_m * g.tiles_n;
+      int ksplit = tiles >= 256 ? 1 : 256 / tiles;   // at most one workgroup per CU, no ragged second wave
+      const int maxs = d->K / 1024;            // >= 16 k-steps per workgroup
+      if (ksplit > maxs) ksplit = maxs;
+      if (ksplit < 1) ksplit = 1;
+      int kchunk = ((d->K / 64 + ksplit - 1) / ksplit) * 64;
+      ksplit = (d->K + kchunk - 1) / kchunk;
+      g.ksplit = ksplit; g.kchunk = kchunk;
+      if (ksplit > 1 && !d->accumulate) {
+        if (hipMemset2DAsync(d->C, sizeof(float) * d->ldc, 0, sizeof(float) * d->N, d->M, st) != hipSuccess)
+          return AFM_ERR_LAUNCH;
+      }
+      static bool attr_done = false;
+      if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)k_gemm_tn_ring<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 64 * 384 * 2);
+        (void)hipFuncSetAttribute((const void*)k_gemm_tn_ring<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 64 * 384 * 2);
+        (void)hipFuncSetAttribute((const void*)k_gemm_tn_ring<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 64 * 384 * 2);
+        attr_done = true;
+      }
+      if (d->reserved == 101) AFM_LAUNCH(k_gemm_tn_ring<1>, dim3(tiles * ksplit), dim3(512), 3 * 64 * 384 * 2, st, g);
+      else if (d->reserved == 102) AFM_LAUNCH(k_gemm_tn_ring<2>, dim3(tiles * ksplit), dim3(512), 3 * 64 * 384 * 2, st, g);
+      else AFM_LAUNCH(k_gemm_tn_ring<0>, dim3(tiles * ksplit), dim3(512), 3 * 64 * 384 * 2, st, g);
+      afm_set_last_algo(ksplit > 1 ? "mfma_tn_ring_splitk" : "mfma_tn_ring");
+      return AFM_OK;
+    }
     const int tiles = g.tiles_m * g.tiles_n;
     int ksplit = 1;
     if (tiles < 512) {

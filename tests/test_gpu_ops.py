@@ -353,7 +353,7 @@ def test_gemm_mfma_nt_epilogue(ops):
     close(cacc, acc0.double() + a.double() @ w.double().T, 1e-4, 1e-4)
 
 
-@pytest.mark.parametrize("R,M,N", [(512, 128, 128), (1000, 192, 64), (4096, 1536, 512), (777, 24, 64), (8192, 128, 2048)])
+@pytest.mark.parametrize("R,M,N", [(512, 128, 128), (1000, 192, 64), (4096, 1536, 512), (777, 24, 64), (8192, 128, 2048), (16384, 520, 200), (4096, 256, 128)])
 def test_gemm_mfma_tn_wgrad(ops, R, M, N):
     dy, x = rnd(R, M, seed=1).bfloat16(), rnd(R, N, seed=2).bfloat16()
     g0 = rnd(M, N, seed=3)

@@ -29,8 +29,10 @@ def main():
     for name, R, M, N in [("wgrad qkv", B*S, 3*d, d), ("wgrad out", B*S, d, d), ("wgrad ffn1", B*S, f, d), ("wgrad ffn2", B*S, d, f)]:
         dy = torch.randn(R, M, device=dev).bfloat16(); x = torch.randn(R, N, device=dev).bfloat16()
         g = torch.zeros(M, N, device=dev)
-        ms = t(lambda: ops.gemm(dy, x, g, trans_a=True, trans_b=False, accumulate=True))
-        print(f"TN {name:10s} {R}: {M}x{N} {ops.last_algo():14s} {ms:8.3f} ms {2*M*N*R/ms/1e9:8.1f} TF/s")
+        gb = torch.zeros(M, device=dev)
+        for var in (0, 101, 102):
+            ms = t(lambda: ops.gemm(dy, x, g, trans_a=True, trans_b=False, accumulate=True, a_colsum=gb, variant=var))
+            print(f"TN {name:10s} {R}: {M}x{N} {ops.last_algo():20s} {ms:8.3f} ms {2*M*N*R/ms/1e9:8.1f} TF/s")
 
 if __name__ == "__main__":
     main()
