@@ -117,6 +117,9 @@ int afm_scatter_add_rows(const int64_t* ids, const float* scale, const float* do
  * the LayerNorm that reads the stream next, so the projection GEMMs write plain bf16 branches.
  * Backward: dx[r,:] = (dres ? dres[r,:] : 0) + LN'(dy[out_row(r),:]); dgamma/dbeta are
  * ACCUMULATED (+=) into fp32 buffers; `partial` is workspace of afm_layernorm_bwd_ws_floats().
+ * `dx_drop` (optional, dtype y_dtype, rows x d): dropout(dx) with stream `drop`, i.e. the gradient
+ * of the dropped-out residual branch that was added in front of this LayerNorm, handed to the
+ * branch's GEMMs in their operand dtype without another pass over dx.
  * ---------------------------------------------------------------------------------------- */
 typedef struct {
   int64_t rows;
@@ -132,7 +135,8 @@ int afm_layernorm_fwd(const afm_ln_shape* s, const float* x, const float* gamma,
 int64_t afm_layernorm_bwd_ws_floats(const afm_ln_shape* s);
 int afm_layernorm_bwd(const afm_ln_shape* s, const void* dy, const float* x, const float* gamma,
                       const float* mean, const float* rstd, const float* dres, float* dx,
-                      float* dgamma, float* dbeta, float* partial, void* stream);
+                      float* dgamma, float* dbeta, float* partial, void* dx_drop,
+                      const afm_dropout* drop, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Masked multi-head attention, flash style (no T_q x T_k tensor in HBM).

@@ -115,7 +115,8 @@ __global__ void k_ln_bwd(const TY* __restrict__ dy, const float* __restrict__ x,
                          const float* __restrict__ gamma, const float* __restrict__ mean,
                          const float* __restrict__ rstd, const float* __restrict__ dres,
                          float* __restrict__ dx, float* __restrict__ partial, int64_t rows, int d,
-                         int64_t seg_len, int64_t seg_stride, int64_t off) {
+                         int64_t seg_len, int64_t seg_stride, int64_t off, TY* __restrict__ dx_drop,
+                         DropDev dd) {
   extern __shared__ __attribute__((aligned(16))) float sm[];  // [4 waves][2][d]
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -159,6 +160,7 @@ __global__ void k_ln_bwd(const TY* __restrict__ dy, const float* __restrict__ x,
         float o = rs * (g[i] - m1 - xh[i] * m2);
         if (drr) o += drr[j];
         dxr[j] = o;
+        if (dx_drop) st_f32(dx_drop, r * (int64_t)d + j, afm_drop(dd, (uint64_t)r * (uint64_t)d + (uint64_t)j, o));
       }
     }
   }
@@ -178,30 +180,33 @@ __global__ void k_ln_bwd(const TY* __restrict__ dy, const float* __restrict__ x,
   }
 }
 
-// 64 columns per block, 4 waves stride the per-block partial rows (lanes = consecutive columns:
-// coalesced), LDS-combine the 4 row phases, one += per column.
+// 64 columns per block (lanes = consecutive columns: coalesced), the partial rows split over
+// gridDim.y chunks and the 4 waves of a block; LDS-combine, then one fp32 atomic per column and chunk.
 __global__ __launch_bounds__(256) void k_ln_bwd_reduce(const float* __restrict__ partial,
                                                        float* __restrict__ dgamma,
                                                        float* __restrict__ dbeta, int nblocks, int d) {
   __shared__ float sm[4][64];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int j = blockIdx.x * 64 + lane;
+  const int per = (nblocks + gridDim.y - 1) / gridDim.y;
+  const int b0 = blockIdx.y * per, b1 = min(nblocks, b0 + per);
   float acc = 0.f;
   if (j < 2 * d)
-    for (int b = w; b < nblocks; b += 4) acc += partial[(int64_t)b * 2 * d + j];
+    for (int b = b0 + w; b < b1; b += 4) acc += partial[(int64_t)b * 2 * d + j];
   sm[w][lane] = acc;
   __syncthreads();
   if (w == 0 && j < 2 * d) {
     const float t = sm[0][lane] + sm[1][lane] + sm[2][lane] + sm[3][lane];
-    if (j < d) { if (dgamma) dgamma[j] += t; }
-    else if (dbeta) dbeta[j - d] += t;
+    if (j < d) { if (dgamma) atomicAdd(dgamma + j, t); }
+    else if (dbeta) atomicAdd(dbeta + j - d, t);
   }
 }
 
 extern "C" int afm_layernorm_bwd(const afm_ln_shape* s, const void* dy, const float* x,
                                  const float* gamma, const float* mean, const float* rstd,
                                  const float* dres, float* dx, float* dgamma, float* dbeta,
-                                 float* partial, void* stream) {
+                                 float* partial, void* dx_drop, const afm_dropout* drop, void* stream) {
+  const DropDev dd = afm_make_drop(drop);
   if (!s || !dy || !x || !gamma || !mean || !rstd || !dx || !partial || s->rows < 0 || s->d <= 0)
     return AFM_ERR_ARG;
   if (s->d > 64 * LN_MAXV) return AFM_ERR_UNSUPPORTED;
@@ -215,18 +220,18 @@ extern "C" int afm_layernorm_bwd(const afm_ln_shape* s, const void* dy, const fl
     if (s->y_dtype == AFM_F32)                                                                       \
       AFM_LAUNCH((k_ln_bwd<float, NV>), dim3(g), dim3(256), shm, st, (const float*)dy, x,     \
                          gamma, mean, rstd, dres, dx, partial, s->rows, s->d, s->seg_len,            \
-                         s->out_seg_stride, s->out_off);                                             \
+                         s->out_seg_stride, s->out_off, (float*)dx_drop, dd);                                             \
     else                                                                                             \
       AFM_LAUNCH((k_ln_bwd<bf16, NV>), dim3(g), dim3(256), shm, st, (const bf16*)dy, x, gamma, \
                          mean, rstd, dres, dx, partial, s->rows, s->d, s->seg_len,                   \
-                         s->out_seg_stride, s->out_off);                                             \
+                         s->out_seg_stride, s->out_off, (bf16*)dx_drop, dd);                                             \
   } while (0)
   const int nv = (s->d + 63) / 64;
   if (nv <= 1) LN_BWD(1); else if (nv <= 2) LN_BWD(2); else if (nv <= 4) LN_BWD(4);
   else if (nv <= 8) LN_BWD(8); else if (nv <= 12) LN_BWD(12); else if (nv <= 16) LN_BWD(16);
   else LN_BWD(32);
 #undef LN_BWD
-  AFM_LAUNCH(k_ln_bwd_reduce, dim3((2 * s->d + 63) / 64), dim3(256), 0, st, partial, dgamma,
+  AFM_LAUNCH(k_ln_bwd_reduce, dim3((2 * s->d + 63) / 64, g >= 64 ? 16 : 1), dim3(256), 0, st, partial, dgamma,
                      dbeta, g, s->d);
   return AFM_OK;
 }

@@ -313,13 +313,20 @@ class Seq2SeqEngine:
             saved[key] = (x, mean, rstd)
         return y, x
 
-    def _ln_bwd(self, dy, prefix, saved, key, dres):
+    def _ln_bwd(self, dy, prefix, saved, key, dres, next_site=None):
+        """Returns (dx, dx_dropped): dx is the fp32 stream gradient; dx_dropped (compute dtype) is
+        dropout'(dx) for the residual branch that precedes this LayerNorm (dropout site `next_site`),
+        produced by the same kernel so dx is not read again."""
         x, mean, rstd = saved[key]
         dx = torch.empty_like(x)
         ws = torch.empty(ops.layernorm_bwd_ws(x.shape[0], self.d), dtype=torch.float32, device=self.dev)
+        dxd, dr = None, ops.NO_DROP
+        if next_site is not None:
+            dxd = self._empty(x.shape[0], self.d, dy.dtype)
+            dr = self._drop(next_site)
         ops.layernorm_bwd(dy, x, self.ps.p(prefix + "weight"), mean, rstd, dx, self.ps.g(prefix + "weight"),
-                          self.ps.g(prefix + "bias"), ws, dres=dres)
-        return dx
+                          self.ps.g(prefix + "bias"), ws, dres=dres, dx_drop=dxd, dropout=dr)
+        return dx, dxd
 
     def _self_attn_fwd(self, x, pend, p, B, T, H, key_pad, causal, saved, site):
         """x + pend is the incoming stream; returns (stream, this block's branch to be added)."""
@@ -337,13 +344,12 @@ class Seq2SeqEngine:
             saved["sa"] = (h, qkv, a, lse, shp)
         return x, br
 
-    def _self_attn_bwd(self, dx1, p, saved, site_res_drop):
-        """dx1: fp32 grad at the block output.  Returns grad at the block input."""
+    def _self_attn_bwd(self, dx1, dy, p, saved, next_site):
+        """dx1: fp32 grad of the stream after this block; dy = dropout'(dx1) in the compute dtype.
+        Returns (grad of the stream before the block, its dropped copy for `next_site`)."""
         d = self.d
         h, qkv, a, lse, shp = saved["sa"]
         rows = h.shape[0]
-        dy = self._empty(rows, d)
-        ops.dropout_cast(dx1, dy, site_res_drop)
         self._wgrad(dy, a, p + "self_attn.out_proj.weight", d, d, bias_name=p + "self_attn.out_proj.bias")
         da = self._dgrad(dy, p + "self_attn.out_proj.weight", d, d)
         dqkv = self._empty(rows, 3 * d)
@@ -352,7 +358,7 @@ class Seq2SeqEngine:
                      dqkv[:, :d], dqkv[:, d:2 * d], dqkv[:, 2 * d:], 3 * d, 3 * d, 3 * d)
         self._wgrad(dqkv, h, p + "self_attn.in_proj_weight", 3 * d, d, bias_name=p + "self_attn.in_proj_bias")
         dh = self._dgrad(dqkv, p + "self_attn.in_proj_weight", 3 * d, d)
-        return self._ln_bwd(dh, p + "norm1.", saved, "ln1", dres=dx1)
+        return self._ln_bwd(dh, p + "norm1.", saved, "ln1", dres=dx1, next_site=next_site)
 
     def _ffn_fwd(self, x, pend, p, f, norm, saved, site):
         d, k = self.d, (2 if self.gated else 1)
@@ -371,12 +377,10 @@ class Seq2SeqEngine:
             saved["ffn"] = (h, uv, g, dr)
         return x, br
 
-    def _ffn_bwd(self, dx1, p, f, norm, saved, site_res_drop):
+    def _ffn_bwd(self, dx1, dy, p, f, norm, saved, next_site):
         d, k = self.d, (2 if self.gated else 1)
         h, uv, g, dr = saved["ffn"]
         rows = h.shape[0]
-        dy = self._empty(rows, d)
-        ops.dropout_cast(dx1, dy, site_res_drop)
         self._wgrad(dy, g, p + "linear2.weight", d, f, bias_name=p + "linear2.bias")
         duv = self._empty(rows, k * f)
         if self.gated:
@@ -386,7 +390,7 @@ class Seq2SeqEngine:
             self._dgrad(dy, p + "linear2.weight", d, f, out=duv, act=ACT_GELU_BWD, pre_act=uv, dropout=dr)
         self._wgrad(duv, h, p + "linear1.weight", k * f, d, bias_name=p + "linear1.bias")
         dh = self._dgrad(duv, p + "linear1.weight", k * f, d)
-        return self._ln_bwd(dh, p + norm, saved, "lnf", dres=dx1)
+        return self._ln_bwd(dh, p + norm, saved, "lnf", dres=dx1, next_site=next_site)
 
     def _cross_attn_fwd(self, x, pend, mem, p, B, T, S, H, mem_pad, saved, site):
         d = self.d
@@ -405,11 +409,9 @@ class Seq2SeqEngine:
             saved["ca"] = (h, q, kv, a, lse, shp)
         return x, br
 
-    def _cross_attn_bwd(self, dx1, mem, dmem, p, saved, site_res_drop):
+    def _cross_attn_bwd(self, dx1, dy, mem, dmem, p, saved, next_site):
         d = self.d
         h, q, kv, a, lse, shp = saved["ca"]
-        dy = self._empty(h.shape[0], d)
-        ops.dropout_cast(dx1, dy, site_res_drop)
         wo, bo = p + "multihead_attn.out_proj.weight", p + "multihead_attn.out_proj.bias"
         self._wgrad(dy, a, wo, d, d, bias_name=bo)
         da = self._dgrad(dy, wo, d, d)
@@ -422,7 +424,7 @@ class Seq2SeqEngine:
         self._wgrad(dkv, mem, w, 3 * d, d, d, 3 * d, bias_name=bname)
         dh = self._dgrad(dq, w, 3 * d, d, 0, d)
         self._dgrad(dkv, w, 3 * d, d, d, 3 * d, out=dmem, accumulate=True)  # fp32 accumulator
-        return self._ln_bwd(dh, p + "norm2.", saved, "ln2", dres=dx1)
+        return self._ln_bwd(dh, p + "norm2.", saved, "ln2", dres=dx1, next_site=next_site)
 
     # ------------------------------------------------------------------ whole model
     def encode(self, enc_inputs, attention_mask, saved: Optional[dict] = None):
@@ -513,24 +515,24 @@ class Seq2SeqEngine:
         hf = saved["hf"]
         self._wgrad(dlog, hf, "token_ff.weight", self.V, d, bias_name="token_ff.bias")
         dhf = self._dgrad(dlog, "token_ff.weight", self.V, d)
-        dx = self._ln_bwd(dhf, "decoder.norm.", saved, "dec_norm", dres=None)
+        Ld, Le = self.cfg["decoder_layers"], self.cfg["encoder_layers"]
+        dx, dy = self._ln_bwd(dhf, "decoder.norm.", saved, "dec_norm", dres=None, next_site=f"d{Ld - 1}res2")
         dmem = torch.zeros(B * S, d, dtype=torch.float32, device=self.dev)
-        p_drop = lambda site: self._drop(site)  # same (seed, site) as the forward of this micro-batch
-        for i in range(self.cfg["decoder_layers"] - 1, -1, -1):
+        for i in range(Ld - 1, -1, -1):
             p, sv = f"decoder.layers.{i}.", saved["dec_layers"][i]
-            dx = self._ffn_bwd(dx, p, self.cfg["decoder_ffn_dim"], "norm3.", sv, p_drop(f"d{i}res2"))
-            dx = self._cross_attn_bwd(dx, mem, dmem, p, sv, p_drop(f"d{i}xres"))
-            dx = self._self_attn_bwd(dx, p, sv, p_drop(f"d{i}res"))
+            dx, dy = self._ffn_bwd(dx, dy, p, self.cfg["decoder_ffn_dim"], "norm3.", sv, f"d{i}xres")
+            dx, dy = self._cross_attn_bwd(dx, dy, mem, dmem, p, sv, f"d{i}res")
+            dx, dy = self._self_attn_bwd(dx, dy, p, sv, f"d{i - 1}res2" if i > 0 else None)
             self._grads_final_from(p + "self_attn.in_proj_weight")
         self.embed_bwd(dx, saved["emb_dec"])
         dmem_c = dmem
         if self.cd != torch.float32:
             dmem_c = self._empty(B * S, d)
             ops.dropout_cast(dmem, dmem_c)
-        dx = self._ln_bwd(dmem_c, "encoder.norm.", saved, "enc_norm", dres=None)
-        for i in range(self.cfg["encoder_layers"] - 1, -1, -1):
+        dx, dy = self._ln_bwd(dmem_c, "encoder.norm.", saved, "enc_norm", dres=None, next_site=f"e{Le - 1}res2")
+        for i in range(Le - 1, -1, -1):
             p, sv = f"encoder.layers.{i}.", saved["enc_layers"][i]
-            dx = self._ffn_bwd(dx, p, self.cfg["encoder_ffn_dim"], "norm2.", sv, p_drop(f"e{i}res2"))
-            dx = self._self_attn_bwd(dx, p, sv, p_drop(f"e{i}res"))
+            dx, dy = self._ffn_bwd(dx, dy, p, self.cfg["encoder_ffn_dim"], "norm2.", sv, f"e{i}res")
+            dx, dy = self._self_attn_bwd(dx, dy, p, sv, f"e{i - 1}res2" if i > 0 else None)
             self._grads_final_from(p + "self_attn.in_proj_weight")
         self.embed_bwd(dx, saved["emb_enc"])

@@ -69,7 +69,7 @@ _SIGS = {
     "afm_scatter_add_rows": (C.c_int, [_P, _P, _P, _P, _I64, _I32, _I32, _I64, _P]),
     "afm_layernorm_fwd": (C.c_int, [C.POINTER(LnShape), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "afm_layernorm_bwd_ws_floats": (C.c_int64, [C.POINTER(LnShape)]),
-    "afm_layernorm_bwd": (C.c_int, [C.POINTER(LnShape), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "afm_layernorm_bwd": (C.c_int, [C.POINTER(LnShape), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.POINTER(Dropout), _P]),
     "afm_attn_fwd": (C.c_int, [C.POINTER(AttnShape), _P, _P, _P, _P, _P, _P]),
     "afm_attn_bwd": (C.c_int, [C.POINTER(AttnShape), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
                                _I32, _I32, _I32, _P]),

@@ -135,12 +135,15 @@ def layernorm_bwd_ws(rows, d) -> int:
 
 
 def layernorm_bwd(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, ws, dres=None, seg_len=0,
-                  out_seg_stride=0, out_off=0):
+                  out_seg_stride=0, out_off=0, dx_drop=None, dropout: Dropout = NO_DROP):
     rows, d = x.shape
     s = ln_shape(rows, d, dy.dtype, seg_len, out_seg_stride, out_off)
     assert ws.numel() >= layernorm_bwd_ws(rows, d)
+    if dx_drop is not None:
+        assert dx_drop.dtype == dy.dtype and dx_drop.shape == x.shape and dx_drop.is_contiguous()
     L.check(L.load().afm_layernorm_bwd(C.byref(s), _ptr(dy), _ptr(x), _ptr(gamma), _ptr(mean), _ptr(rstd),
-                                       _ptr(dres), _ptr(dx), _ptr(dgamma), _ptr(dbeta), _ptr(ws), _stream()),
+                                       _ptr(dres), _ptr(dx), _ptr(dgamma), _ptr(dbeta), _ptr(ws),
+                                       _ptr(dx_drop), C.byref(dropout), _stream()),
             "afm_layernorm_bwd")
     return dx
 

@@ -134,6 +134,15 @@ def test_layernorm_fwd_bwd(ops, d, ydt):
     ops.layernorm_bwd(dy_dev, dev(x), dev(gam), mean, rstd, dx, dg, db, ws, dres=dev(dres), seg_len=Sm,
                       out_seg_stride=S, out_off=off)
     close(dx, xr.grad + dres.double(), 1e-4, 1e-5)
+    # second output: dropout(dx) in the operand dtype (identity row mapping)
+    dxd = torch.empty(rows, d, dtype=ydt, device=DEV)
+    dx2 = torch.empty(rows, d, device=DEV)
+    dy_rows = dev(dy_full.view(B, S, d)[:, off:off + Sm].reshape(rows, d), ydt)
+    ops.layernorm_bwd(dy_rows, dev(x), dev(gam), mean, rstd, dx2, dg.clone(), db.clone(), ws, dres=dev(dres),
+                      dx_drop=dxd, dropout=ops.drop(0.25, 77, 2))
+    keep = torch.from_numpy(keep_mask(0.25, 77, 2, rows * d)).view(rows, d)
+    close(dx2, dx.cpu(), 1e-6, 1e-6)
+    close(dxd, (dx2.cpu() * keep / 0.75).to(ydt), 1e-2 if ydt == torch.bfloat16 else 1e-6, 1e-6)
     close(dg, dg0.double() + gr.grad, 1e-4, 1e-5)
     close(db, db0.double() + br.grad, 1e-4, 1e-5)
 
