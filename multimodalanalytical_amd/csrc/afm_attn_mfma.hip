@@ -109,21 +109,54 @@ __device__ __forceinline__ void drop_block(const DropDev& dd, uint32_t rowbase, 
   }
 }
 
+// ------------------------------------------------------------------------------------------ LDS-DMA tile ring
+// K / V / Q / dO tiles go HBM -> LDS with global_load_lds_dwordx4 (1-KiB pieces = 8 tile rows), the
+// image swizzles applied on the SOURCE chunk index, into a ring of RS stages with RS-1 tiles in
+// flight (counted vmcnt + raw s_barrier, as in the GEMM ring): the tile loads no longer sit on the
+// critical path of each iteration.
+template <int N> __device__ __forceinline__ void attn_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+#define RS 3
+// one piece: rows [8*pi, 8*pi+8) of the 64-row tile starting at global row `row0` of `base`
+template <bool TR>
+__device__ __forceinline__ void dma_piece(unsigned char* img, const bf16* base, int ld, int row0, int nrows,
+                                          int pi, int lane) {
+  const int r = 8 * pi + (lane >> 3), slot = lane & 7;
+  const int chunk = TR ? (slot ^ (((r >> 1) & 1) << 2)) : (slot ^ ((r >> 1) & 7));
+  int gr = row0 + r;
+  gr = gr < nrows ? gr : nrows - 1;   // clamped rows are masked out by the caller
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + (int64_t)gr * ld + chunk * 8),
+                                   (__attribute__((address_space(3))) void*)(img + pi * 1024), 16, 0, 0);
+}
+// key-mask words (bit i of word t = key 64 t + i is padded or past Tk) for one batch row, in LDS
+__device__ __forceinline__ void build_mask_words(unsigned long long* maskw, const uint8_t* key_pad, int b, int Tk,
+                                                 int nwords, int w, int lane) {
+  for (int wd = w; wd < nwords; wd += 4) {
+    const int kk = wd * 64 + lane;
+    const bool msk = kk >= Tk || (key_pad && key_pad[(int64_t)b * Tk + kk]);
+    const unsigned long long word = __ballot(msk);
+    if (lane == 0) maskw[wd] = word;
+  }
+}
+
 // ------------------------------------------------------------------------------------------ forward
-__global__ __launch_bounds__(256) void k_attn_fwd_mfma(AttnM a, const bf16* __restrict__ Q,
-                                                       const bf16* __restrict__ K,
-                                                       const bf16* __restrict__ V, bf16* __restrict__ O,
-                                                       float* __restrict__ lse) {
-  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * KT * DH * 2];
-  unsigned char* Kimg = lds;                 // row image
-  unsigned char* Vimg = lds + KT * DH * 2;   // tr image
-  const int t = threadIdx.x, lane = t & 63, w = t >> 6, h = lane >> 5;
+__global__ __launch_bounds__(256, 2) void k_attn_fwd_mfma(AttnM a, const bf16* __restrict__ Q,
+                                                          const bf16* __restrict__ K,
+                                                          const bf16* __restrict__ V, bf16* __restrict__ O,
+                                                          float* __restrict__ lse) {
+  constexpr int STAGE = 2 * KT * DH * 2;   // K row image + V tr image
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  unsigned long long* maskw = (unsigned long long*)(lds + RS * STAGE);
+  const int t = threadIdx.x, lane = t & 63, h = lane >> 5;
+  const int w = __builtin_amdgcn_readfirstlane(t >> 6);
   const int hd = blockIdx.y, b = blockIdx.z;
   const int q0 = blockIdx.x * 128 + w * 32;          // this wave's first query
   const int q = q0 + (lane & 31);
   const int qc = q < a.Tq ? q : a.Tq - 1;
   const bf16* Kb = K + (int64_t)b * a.Tk * a.ldk + hd * DH;
   const bf16* Vb = V + (int64_t)b * a.Tk * a.ldv + hd * DH;
+  int kend = a.Tk;
+  if (a.causal) kend = min(a.Tk, blockIdx.x * 128 + 128);  // keys beyond the block's last query are masked
+  const int ntiles = (kend + KT - 1) / KT;
   // Q fragments (B operand of S^T = K Q^T): Q[q][16 s + 8 h ..]
   bf16x8 qf[4];
   {
@@ -131,28 +164,33 @@ __global__ __launch_bounds__(256) void k_attn_fwd_mfma(AttnM a, const bf16* __re
 #pragma unroll
     for (int s = 0; s < 4; ++s) qf[s] = *(const bf16x8*)(qp + 16 * s);
   }
+  build_mask_words(maskw, a.key_pad, b, a.Tk, ntiles, w, lane);
+  __syncthreads();   // plain loads above are retired here (vmcnt(0)), before any LDS-DMA is in flight
+  auto issue = [&](int kt) {
+    unsigned char* st = lds + (kt % RS) * STAGE;
+    dma_piece<false>(st, Kb, a.ldk, kt * KT, a.Tk, w, lane);
+    dma_piece<false>(st, Kb, a.ldk, kt * KT, a.Tk, w + 4, lane);
+    dma_piece<true>(st + KT * DH * 2, Vb, a.ldv, kt * KT, a.Tk, w, lane);
+    dma_piece<true>(st + KT * DH * 2, Vb, a.ldv, kt * KT, a.Tk, w + 4, lane);
+  };
   f32x16 o[2];
 #pragma unroll
   for (int i = 0; i < 16; ++i) { o[0][i] = 0.f; o[1][i] = 0.f; }
   float m = -INFINITY, l = 0.f;
   const uint32_t rowbase = (uint32_t)(((uint64_t)(b * a.H + hd) * a.Tq + qc) * (uint64_t)a.Tk);
-
-  int kend = a.Tk;
-  if (a.causal) kend = min(a.Tk, blockIdx.x * 128 + 128);  // keys beyond the block's last query are masked
-  const int ntiles = (kend + KT - 1) / KT;
-  Stage2 sk = stage_load(Kb, a.ldk, 0, a.Tk, t), sv = stage_load(Vb, a.ldv, 0, a.Tk, t);
+#pragma unroll
+  for (int s = 0; s < RS - 1; ++s)
+    if (s < ntiles) issue(s);
   for (int kt = 0; kt < ntiles; ++kt) {
     const int kb = kt * KT;
-    __syncthreads();                       // previous tile fully consumed
-    stage_store<false>(Kimg, sk, t);
-    stage_store<true>(Vimg, sv, t);
-    __syncthreads();
-    if (kt + 1 < ntiles) { sk = stage_load(Kb, a.ldk, kb + KT, a.Tk, t); sv = stage_load(Vb, a.ldv, kb + KT, a.Tk, t); }
+    if (ntiles - 1 - kt >= RS - 2) attn_wait_vmcnt<4 * (RS - 2)>(); else attn_wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    if (kt + RS - 1 < ntiles) issue(kt + RS - 1);
     if (a.causal && kb > q0 + 31) continue;  // wave-uniform: tile entirely above this wave's diagonal
-    // key mask bits of this tile (1 = masked), shifted so bit ACC_ROW(r) + 32 blk is this lane's key
-    const int kk = kb + lane;
-    const bool kmask = kk >= a.Tk || (a.key_pad && a.key_pad[(int64_t)b * a.Tk + kk]);
-    const unsigned long long pad = __ballot(kmask) >> (4 * h);
+    const unsigned char* Kimg = lds + (kt % RS) * STAGE;
+    const unsigned char* Vimg = Kimg + KT * DH * 2;
+    const unsigned long long mword = maskw[kt];
+    const unsigned long long pad = mword >> (4 * h);
     f32x16 s[2];
 #pragma unroll
     for (int blk = 0; blk < 2; ++blk) {
@@ -161,35 +199,42 @@ __global__ __launch_bounds__(256) void k_attn_fwd_mfma(AttnM a, const bf16* __re
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) s[blk] = mfma32(frag_row(Kimg, 32 * blk, ks, lane), qf[ks], s[blk]);
     }
-    float mt = -INFINITY;
+    // masks only where the tile has any (wave-uniform test): most tiles of a padded batch have none
+    const bool diag = a.causal && (kb + KT - 1 > q0);
+    if (mword != 0ull || diag) {
 #pragma unroll
-    for (int blk = 0; blk < 2; ++blk)
+      for (int blk = 0; blk < 2; ++blk)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int ko = 32 * blk + ACC_ROW(r);
-        bool msk = (pad >> ko) & 1ull;
-        if (a.causal) msk = msk || (kb + ko + 4 * h > q);
-        const float v = msk ? -INFINITY : s[blk][r] * a.scale_log2;
-        s[blk][r] = v;
-        mt = fmaxf(mt, v);
-      }
-    mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+        for (int r = 0; r < 16; ++r) {
+          const int ko = 32 * blk + ACC_ROW(r);
+          bool msk = (pad >> ko) & 1ull;
+          if (a.causal) msk = msk || (kb + ko + 4 * h > q);
+          s[blk][r] = msk ? -INFINITY : s[blk][r];
+        }
+    }
+    float mt = fmaxf(s[0][0], s[1][0]);
+#pragma unroll
+    for (int r = 1; r < 16; ++r) mt = fmaxf(mt, fmaxf(s[0][r], s[1][r]));
+    mt = fmaxf(mt, __shfl_xor(mt, 32, 64)) * a.scale_log2;     // scale > 0: max commutes with it
     const float mn = fmaxf(m, mt);
     const float ms = mn == -INFINITY ? 0.f : mn;
     const float alpha = fast_exp2(m - ms);
+    const bool grew = mn > m;
     m = mn;
     float ls = 0.f;
 #pragma unroll
     for (int blk = 0; blk < 2; ++blk)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float p = fast_exp2(s[blk][r] - ms);
+        const float p = fast_exp2(fmaf(s[blk][r], a.scale_log2, -ms));   // exp2(-inf) = 0 for masked keys
         s[blk][r] = p;
         ls += p;
       }
     l = l * alpha + ls;
+    if (__any(grew)) {   // the running maximum moved for some query of this wave: rescale O^T
 #pragma unroll
-    for (int i = 0; i < 16; ++i) { o[0][i] *= alpha; o[1][i] *= alpha; }
+      for (int i = 0; i < 16; ++i) { o[0][i] *= alpha; o[1][i] *= alpha; }
+    }
     if (a.dd.thresh16) {
       drop_block(a.dd, rowbase, kb, h, s[0]);
       drop_block(a.dd, rowbase, kb + 32, h, s[1]);
@@ -223,18 +268,18 @@ __global__ __launch_bounds__(256) void k_attn_fwd_mfma(AttnM a, const bf16* __re
 // ------------------------------------------------------------------------------------------ dQ
 // Per 64-key tile: S^T and dP^T (keys in registers, query on the lane), then
 // dQ^T[d][q] += sum_key K^T[d][key] dS^T[key][q].  Also writes delta = rowsum(dO * O).
-__global__ __launch_bounds__(256) void k_attn_bwd_dq_mfma(AttnM a, const bf16* __restrict__ Q,
+__global__ __launch_bounds__(256, 2) void k_attn_bwd_dq_mfma(AttnM a, const bf16* __restrict__ Q,
                                                           const bf16* __restrict__ K,
                                                           const bf16* __restrict__ V,
                                                           const bf16* __restrict__ O,
                                                           const bf16* __restrict__ dO,
                                                           const float* __restrict__ lse,
                                                           float* __restrict__ delta, bf16* __restrict__ dQ) {
-  __shared__ __attribute__((aligned(16))) unsigned char lds[3 * KT * DH * 2];
-  unsigned char* Krow = lds;
-  unsigned char* Ktr = lds + KT * DH * 2;
-  unsigned char* Vrow = lds + 2 * KT * DH * 2;
-  const int t = threadIdx.x, lane = t & 63, w = t >> 6, h = lane >> 5;
+  constexpr int STAGE = 3 * KT * DH * 2;   // K row image, K tr image, V row image
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  unsigned long long* maskw = (unsigned long long*)(lds + RS * STAGE);
+  const int t = threadIdx.x, lane = t & 63, h = lane >> 5;
+  const int w = __builtin_amdgcn_readfirstlane(t >> 6);
   const int hd = blockIdx.y, b = blockIdx.z;
   const int q0 = blockIdx.x * 128 + w * 32;
   const int q = q0 + (lane & 31);
@@ -269,19 +314,31 @@ __global__ __launch_bounds__(256) void k_attn_bwd_dq_mfma(AttnM a, const bf16* _
   int kend = a.Tk;
   if (a.causal) kend = min(a.Tk, blockIdx.x * 128 + 128);
   const int ntiles = (kend + KT - 1) / KT;
-  Stage2 sk = stage_load(Kb, a.ldk, 0, a.Tk, t), sv = stage_load(Vb, a.ldv, 0, a.Tk, t);
+  build_mask_words(maskw, a.key_pad, b, a.Tk, ntiles, w, lane);
+  __syncthreads();   // retires the plain loads / the delta store before the LDS-DMA ring starts
+  auto issue = [&](int kt) {
+    unsigned char* st = lds + (kt % RS) * STAGE;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      dma_piece<false>(st, Kb, a.ldk, kt * KT, a.Tk, w + 4 * u, lane);
+      dma_piece<true>(st + KT * DH * 2, Kb, a.ldk, kt * KT, a.Tk, w + 4 * u, lane);
+      dma_piece<false>(st + 2 * KT * DH * 2, Vb, a.ldv, kt * KT, a.Tk, w + 4 * u, lane);
+    }
+  };
+#pragma unroll
+  for (int s = 0; s < RS - 1; ++s)
+    if (s < ntiles) issue(s);
   for (int kt = 0; kt < ntiles; ++kt) {
     const int kb = kt * KT;
-    __syncthreads();
-    stage_store<false>(Krow, sk, t);
-    stage_store<true>(Ktr, sk, t);
-    stage_store<false>(Vrow, sv, t);
-    __syncthreads();
-    if (kt + 1 < ntiles) { sk = stage_load(Kb, a.ldk, kb + KT, a.Tk, t); sv = stage_load(Vb, a.ldv, kb + KT, a.Tk, t); }
+    if (ntiles - 1 - kt >= RS - 2) attn_wait_vmcnt<6 * (RS - 2)>(); else attn_wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    if (kt + RS - 1 < ntiles) issue(kt + RS - 1);
     if (a.causal && kb > q0 + 31) continue;
-    const int kk = kb + lane;
-    const bool kmask = kk >= a.Tk || (a.key_pad && a.key_pad[(int64_t)b * a.Tk + kk]);
-    const unsigned long long pad = __ballot(kmask) >> (4 * h);
+    const unsigned char* Krow = lds + (kt % RS) * STAGE;
+    const unsigned char* Ktr = Krow + KT * DH * 2;
+    const unsigned char* Vrow = Krow + 2 * KT * DH * 2;
+    const unsigned long long mword = maskw[kt];
+    const unsigned long long pad = mword >> (4 * h);
 #pragma unroll
     for (int blk = 0; blk < 2; ++blk) {
       f32x16 s, dp;
@@ -297,12 +354,18 @@ __global__ __launch_bounds__(256) void k_attn_bwd_dq_mfma(AttnM a, const bf16* _
 #pragma unroll
         for (int r = 0; r < 16; ++r) dp[r] *= a.dd.scale16;
       }
+      if (mword != 0ull || (a.causal && (kb + KT - 1 > q0))) {   // wave-uniform: tile has masked keys
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int ko = 32 * blk + ACC_ROW(r);
+          bool msk = (pad >> ko) & 1ull;
+          if (a.causal) msk = msk || (kb + ko + 4 * h > q);
+          s[r] = msk ? -INFINITY : s[r];
+        }
+      }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int ko = 32 * blk + ACC_ROW(r);
-        bool msk = (pad >> ko) & 1ull;
-        if (a.causal) msk = msk || (kb + ko + 4 * h > q);
-        const float p = msk ? 0.f : fast_exp2(s[r] * a.scale_log2 - L2);
+        const float p = fast_exp2(fmaf(s[r], a.scale_log2, -L2));   // masked: exp2(-inf) = 0
         s[r] = p * (dp[r] - dl);   // dS^T (the 1/sqrt(dh) factor is applied once at the end)
       }
 #pragma unroll
@@ -338,14 +401,12 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd_dkv_mfma(AttnM a, const bf1
                                                            const float* __restrict__ lse,
                                                            const float* __restrict__ delta,
                                                            bf16* __restrict__ dK, bf16* __restrict__ dV) {
-  __shared__ __attribute__((aligned(16))) unsigned char lds[4 * KT * DH * 2 + 2 * KT * 4];
-  unsigned char* Qrow = lds;
-  unsigned char* Qtr = lds + KT * DH * 2;
-  unsigned char* Drow = lds + 2 * KT * DH * 2;
-  unsigned char* Dtr = lds + 3 * KT * DH * 2;
-  float* Ls = (float*)(lds + 4 * KT * DH * 2);   // lse (log2 units) of the tile's queries
-  float* Ds = Ls + KT;                           // delta
-  const int t = threadIdx.x, lane = t & 63, w = t >> 6, h = lane >> 5;
+  // stage: Q row image, Q tr image, dO row image, dO tr image, lse[64], delta[64]; 2-stage LDS-DMA ring
+  constexpr int STAGE = 4 * KT * DH * 2 + 2 * KT * 4;
+  constexpr int DS = 2;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  const int t = threadIdx.x, lane = t & 63, h = lane >> 5;
+  const int w = __builtin_amdgcn_readfirstlane(t >> 6);
   const int hd = blockIdx.y, b = blockIdx.z;
   const int k0 = blockIdx.x * 128 + w * 32;
   const int key = k0 + (lane & 31);
@@ -368,22 +429,38 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd_dkv_mfma(AttnM a, const bf1
   if (a.causal) qbeg = (blockIdx.x * 128) / KT * KT;   // queries before the block's first key see none of it
   const int ntiles = (a.Tq - qbeg + KT - 1) / KT;
   const int64_t lbase = ((int64_t)b * a.H + hd) * a.Tq;
-  Stage2 sq = stage_load(Qb, a.ldq, qbeg, a.Tq, t), sd = stage_load(Db, a.ldo, qbeg, a.Tq, t);
+  __syncthreads();   // K / V fragment loads retired before the LDS-DMA ring starts
+  auto issue = [&](int qt) {
+    unsigned char* st = lds + (qt % DS) * STAGE;
+    const int row0 = qbeg + qt * KT;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      dma_piece<false>(st, Qb, a.ldq, row0, a.Tq, w + 4 * u, lane);
+      dma_piece<true>(st + KT * DH * 2, Qb, a.ldq, row0, a.Tq, w + 4 * u, lane);
+      dma_piece<false>(st + 2 * KT * DH * 2, Db, a.ldo, row0, a.Tq, w + 4 * u, lane);
+      dma_piece<true>(st + 3 * KT * DH * 2, Db, a.ldo, row0, a.Tq, w + 4 * u, lane);
+    }
+    if (w < 2) {   // lse / delta of the tile's 64 queries: one 4-byte piece each
+      int qq = row0 + lane;
+      qq = qq < a.Tq ? qq : a.Tq - 1;
+      const float* src = (w == 0 ? lse : delta) + lbase + qq;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(st + 4 * KT * DH * 2 + w * KT * 4), 4, 0, 0);
+    }
+  };
+  if (ntiles > 0) issue(0);
   for (int qt = 0; qt < ntiles; ++qt) {
     const int qb = qbeg + qt * KT;
-    __syncthreads();
-    stage_store<false>(Qrow, sq, t);
-    stage_store<true>(Qtr, sq, t);
-    stage_store<false>(Drow, sd, t);
-    stage_store<true>(Dtr, sd, t);
-    if (t < KT) {
-      const int qq = qb + t;
-      const float L = qq < a.Tq ? lse[lbase + qq] : INFINITY;   // +inf => p = 0 (row out of range / empty)
-      Ls[t] = L == INFINITY ? INFINITY : L * 1.4426950408889634f;
-      Ds[t] = qq < a.Tq ? delta[lbase + qq] : 0.f;
-    }
-    __syncthreads();
-    if (qt + 1 < ntiles) { sq = stage_load(Qb, a.ldq, qb + KT, a.Tq, t); sd = stage_load(Db, a.ldo, qb + KT, a.Tq, t); }
+    attn_wait_vmcnt<0>();          // this tile's pieces (the only ones in flight)
+    __builtin_amdgcn_s_barrier();
+    if (qt + 1 < ntiles) issue(qt + 1);
+    const unsigned char* Qrow = lds + (qt % DS) * STAGE;
+    const unsigned char* Qtr = Qrow + KT * DH * 2;
+    const unsigned char* Drow = Qrow + 2 * KT * DH * 2;
+    const unsigned char* Dtr = Qrow + 3 * KT * DH * 2;
+    const float* Ls = (const float*)(Qrow + 4 * KT * DH * 2);   // lse (natural log units)
+    const float* Ds = Ls + KT;
+    const bool ragged = qb + KT > a.Tq;   // wave-uniform: tile holds rows past Tq (clamped duplicates)
     if (a.causal && qb + KT - 1 < k0) continue;   // wave-uniform: every query of the tile precedes this wave's keys
 #pragma unroll
     for (int blk = 0; blk < 2; ++blk) {
@@ -416,15 +493,16 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd_dkv_mfma(AttnM a, const bf1
 #pragma unroll
       for (int g4 = 0; g4 < 4; ++g4) {
         const int qo = 32 * blk + 8 * g4 + 4 * h;
-        const f32x4 Lq = *(const f32x4*)(Ls + qo);
+        const f32x4 Lq = *(const f32x4*)(Ls + qo) * 1.4426950408889634f;   // log2 units; +inf stays +inf
         const f32x4 Dq = *(const f32x4*)(Ds + qo);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const int r = 4 * g4 + j;
           const int qq = qb + qo + j;
-          bool msk = kmasked;
-          if (a.causal) msk = msk || (key > qq);
-          float p = msk ? 0.f : fast_exp2(s[r] * a.scale_log2 - Lq[j]);
+          float sv = s[r];
+          if (a.causal) sv = key > qq ? -INFINITY : sv;
+          if (ragged) sv = qq >= a.Tq ? -INFINITY : sv;
+          float p = fast_exp2(fmaf(sv, a.scale_log2, -Lq[j]));   // masked keys: outputs zeroed at the end
           float dpv = dp[r];
           if (a.dd.thresh16) {
             const bool keep = ((hv[r] >> hshift) & 0xFFFFu) >= a.dd.thresh16;
@@ -446,6 +524,10 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd_dkv_mfma(AttnM a, const bf1
         }
       }
     }
+  }
+  if (kmasked) {   // a padded key took no part in any softmax: its dK / dV rows are zero
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { dk[0][i] = 0.f; dk[1][i] = 0.f; dv[0][i] = 0.f; dv[1][i] = 0.f; }
   }
   if (key < a.Tk) {
     bf16* dkp = dK + ((int64_t)b * a.Tk + key) * a.lddk + hd * DH + 4 * h;
@@ -489,7 +571,9 @@ int afm_attn_fwd_mfma_try(const afm_attn_shape* s, const void* Q, const void* K,
   if (!eligible(s, ptrs, 4, lds, 4)) return AFM_ERR_UNSUPPORTED;
   const AttnM a = make_m(s);
   const dim3 grid((s->Tq + 127) / 128, s->H, s->B);
-  AFM_LAUNCH(k_attn_fwd_mfma, grid, dim3(256), 0, st, a, (const bf16*)Q, (const bf16*)K, (const bf16*)V,
+  const int shm = RS * 2 * KT * DH * 2 + ((s->Tk + KT - 1) / KT) * 8;
+  if (shm > 64 * 1024) return AFM_ERR_UNSUPPORTED;
+  AFM_LAUNCH(k_attn_fwd_mfma, grid, dim3(256), shm, st, a, (const bf16*)Q, (const bf16*)K, (const bf16*)V,
              (bf16*)O, lse);
   afm_set_last_algo("attn_mfma");
   return AFM_OK;
@@ -504,9 +588,16 @@ int afm_attn_bwd_mfma_try(const afm_attn_shape* s, const void* Q, const void* K,
   AttnM a = make_m(s);
   a.lddq = lddq; a.lddk = lddk; a.lddv = lddv;
   const dim3 gq((s->Tq + 127) / 128, s->H, s->B), gk((s->Tk + 127) / 128, s->H, s->B);
-  AFM_LAUNCH(k_attn_bwd_dq_mfma, gq, dim3(256), 0, st, a, (const bf16*)Q, (const bf16*)K, (const bf16*)V,
+  const int shm_q = RS * 3 * KT * DH * 2 + ((s->Tk + KT - 1) / KT) * 8;
+  if (shm_q > 80 * 1024) return AFM_ERR_UNSUPPORTED;
+  static bool attr_q = false;
+  if (!attr_q) { (void)hipFuncSetAttribute((const void*)k_attn_bwd_dq_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); attr_q = true; }
+  AFM_LAUNCH(k_attn_bwd_dq_mfma, gq, dim3(256), shm_q, st, a, (const bf16*)Q, (const bf16*)K, (const bf16*)V,
              (const bf16*)O, (const bf16*)dO, lse, delta, (bf16*)dQ);
-  AFM_LAUNCH(k_attn_bwd_dkv_mfma, gk, dim3(256), 0, st, a, (const bf16*)Q, (const bf16*)K, (const bf16*)V,
+  const int shm_k = 2 * (4 * KT * DH * 2 + 2 * KT * 4);
+  static bool attr_k = false;
+  if (!attr_k) { (void)hipFuncSetAttribute((const void*)k_attn_bwd_dkv_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); attr_k = true; }
+  AFM_LAUNCH(k_attn_bwd_dkv_mfma, gk, dim3(256), shm_k, st, a, (const bf16*)Q, (const bf16*)K, (const bf16*)V,
              (const bf16*)dO, lse, delta, (bf16*)dK, (bf16*)dV);
   afm_set_last_algo("attn_mfma");
   return AFM_OK;
