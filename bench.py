@@ -79,8 +79,15 @@ def dominant_kernel_roofline(model, wl, B, dtype):
     flops = 2.0 * M * d * f
     ach = flops / (ms * 1e-3) / 1e12
     peak = PEAK_BF16_TFLOPS if dtype == "bf16" else 157.3
-    return {"bound": "mfma", "kernel": f"afm_gemm[{algo}] {M}x{f}x{d} (FFN linear1)", "achieved": round(ach, 2),
-            "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None,
+    # HBM bytes per launch of this very kernel/shape from the committed PMC passes (FETCH_SIZE x2 +
+    # WRITE_SIZE, profiles/r01_ffn1_gemm_pmc.json); null when the shape differs from the profiled one
+    traffic = None
+    pmc = os.path.join(ROOT, "profiles", "r01_ffn1_gemm_pmc.json")
+    if os.path.exists(pmc) and (M, f, d) == (131072, 2048, 512) and dtype == "bf16":
+        traffic = json.load(open(pmc)).get("traffic_bytes_per_launch")
+    return {"bound": "mfma", "kernel": f"afm_gemm[{algo}] {M}x{f}x{d} (FFN linear1, fused bias+GELU+dropout)",
+            "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
+            "traffic": traffic, "traffic_unit": "HBM bytes/launch (PMC)", "algorithmic_bytes": 2 * (M * d + f * d) + 2 * 2 * M * f,
             "avg_launch_ms": round(ms, 4)}
 
 
