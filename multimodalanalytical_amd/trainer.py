@@ -78,12 +78,13 @@ class BucketedReducer:
 class TrainLoop:
     """accumulate -> (all-reduce) -> clip + Adam + OneCycle, driving an HFWrapper."""
 
-    def __init__(self, model, acc_batches: int = 4, world_size: int = 1, bucket_elems: int = 16 << 20):
+    def __init__(self, model, acc_batches: int = 4, world_size: int = 1, bucket_elems: int = 16 << 20,
+                 force_reducer: bool = False):
         self.model, self.acc, self.world = model, int(acc_batches), int(world_size)
         (self.optim,), _ = model.configure_optimizers()
         self.micro = 0
         eng = model.hf_model.engine
-        self.reducer = BucketedReducer(eng.ps.grad, bucket_elems) if self.world > 1 else None
+        self.reducer = BucketedReducer(eng.ps.grad, bucket_elems) if (self.world > 1 or force_reducer) else None
         eng.grad_ready_hook = None
 
     def micro_batch(self, batch, batch_idx: Optional[int] = None) -> torch.Tensor:

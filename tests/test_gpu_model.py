@@ -112,3 +112,65 @@ def test_eval_forward_matches_train_forward_without_dropout():
     out2 = eng.forward(*_inputs(t, 0), backward=True)
     assert rel_err(out2["logits"].cpu(), t["b0"]["logits"]) > 1e-3   # dropout really is active
     assert torch.isfinite(eng.ps.grad).all()
+
+
+def _wrapper(t, cfg, dtype, **kw):
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from multimodalanalytical_amd.modeling.wrapper import HFWrapper, SimpleTokenizerInfo
+    m = t["meta"]
+    mk = {k: v for k, v in cfg.items() if k != "multimodal_norm"}
+    mk.update(kw)
+    w = HFWrapper(m["data_config"], "CustomModel", "facebook/bart-base", SimpleTokenizerInfo(26), optimiser=m["optimiser"],
+                  lr=m["lr"], weight_decay=m["weight_decay"], num_steps=m["total_steps"], device=DEV, compute_dtype=dtype, **mk)
+    w.hf_model.load_state_dict(t["sd"])
+    return w
+
+
+def _dev_batch(t, i):
+    from multimodalanalytical_amd.synth import to_device
+    return to_device(G.batch_of(t, i), DEV)
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_wrapper_batch_contract_token_acc_and_greedy_vs_reference_golden(name):
+    """HFWrapper surface (seq-first batch dict in, CustomLMOutput out), `_calc_token_acc` incl. its quirk,
+    and greedy generate against ids produced by looping the REFERENCE's forward."""
+    t = G.load(name); cfg = G.model_cfg(t["meta"])
+    w = _wrapper(t, cfg, torch.float32)
+    w.eval()
+    for i in range(2):
+        b = _dev_batch(t, i)
+        out = w.forward(b)
+        ref = t[f"b{i}"]
+        assert rel_err(out.logits.cpu(), ref["logits"]) < 1e-4
+        torch.testing.assert_close(out.loss.cpu(), ref["loss"], rtol=1e-5, atol=1e-5)
+        torch.testing.assert_close(w._calc_token_acc(b, out).cpu(), ref["token_acc"])
+        assert out.loss_dict["alignment_loss"] is None
+    w.max_length = t["meta"]["greedy_max_length"]
+    ids = w.generate(_dev_batch(t, 0), n_beams=1)
+    assert torch.equal(ids.cpu(), t["greedy"]["ids"])
+
+
+def test_wrapper_training_loop_and_checkpoint_roundtrip():
+    """TrainLoop (accumulate 4 / clip / AdamW / OneCycle) through the wrapper equals the reference after
+    two optimiser steps; state_dict keys carry the reference's names and reload bit-exactly."""
+    from multimodalanalytical_amd.trainer import TrainLoop
+    t = G.load("model_plain"); cfg = G.model_cfg(t["meta"]); m = t["meta"]
+    w = _wrapper(t, cfg, torch.float32)
+    loop = TrainLoop(w, acc_batches=m["acc_batches"])
+    for step in (1, 2):
+        for i in range(4):
+            loop.micro_batch(_dev_batch(t, i))
+    sd = w.state_dict()
+    for k, ref in t["step2"].items():
+        if k == "grad_norm" or k.endswith("in_proj_bias"):
+            continue
+        torch.testing.assert_close(sd["hf_model." + k].cpu(), ref, rtol=2e-4, atol=1e-5, msg=lambda s: f"{k}: {s}")
+    assert "multimodal_embedding.embedding_layer_dict.Smiles.weight" in sd          # wrapper.py:298 alias
+    assert "hf_model.decoder.embedding.embedding_layer_dict.Smiles.weight" in sd    # custom_modeling.py:268 alias
+    w2 = _wrapper(t, cfg, torch.float32)
+    w2.load_state_dict(sd)
+    w.eval(); w2.eval()
+    b = _dev_batch(t, 0)
+    assert torch.equal(w.forward(b).logits, w2.forward(b).logits)
