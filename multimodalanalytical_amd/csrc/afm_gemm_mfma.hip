@@ -243,106 +243,7 @@ static int launch_nt(MfmaArgs& g, hipStream_t st) {
   return AFM_OK;
 }
 
-// ------------------------------------------------------------------------------------------ NT, LDS-DMA ring
-// Same tile maths as k_gemm_nt, but operands go HBM -> LDS directly (global_load_lds_dwordx4, no
-// VGPR round trip, no ds_write) into a ring of S stages, with S-1 k-steps in flight: the loads of
-// step kt+S-1 are issued as soon as the barrier of step kt has retired the buffer they overwrite,
-// and each wave waits only for its own pieces of step kt (counted s_waitcnt vmcnt) before that
-// barrier.  One barrier per k-step, never vmcnt(0) inside the loop.  The LDS image of a stage is
-// lane-linear per 1-KiB piece (8 rows x 128 B); the bank swizzle is applied on the SOURCE address
-// (chunk c of row r is fetched by the lane that writes slot c ^ (r & 7)) and again on the read.
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
-
-template <bool C_BF16, int NWM, int NWN, int S>
-__global__ __launch_bounds__(64 * NWM * NWN) void k_gemm_nt_ring(MfmaArgs g) {
-  constexpr int NW = NWM * NWN;
-  constexpr int TBM = 64 * NWM, TBN = 64 * NWN;
-  constexpr int NI = (TBM + TBN) / 8;      // 1-KiB pieces per stage
-  constexpr int NIW = NI / NW;             // pieces per wave per stage
-  static_assert(NI % NW == 0, "pieces must divide over the waves");
-  constexpr int STAGE = (TBM + TBN) * 128;
-  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-  const int t = threadIdx.x, lane = t & 63;
-  const int w = __builtin_amdgcn_readfirstlane(t >> 6);
-  const int wm = w / NWN, wn = w % NWN;
-  const int tile = xcd_remap(blockIdx.x, g.tiles_m * g.tiles_n);
-  const int m0 = (tile / g.tiles_n) * TBM, n0 = (tile % g.tiles_n) * TBN;
-
-  // per-lane source pointers of this wave's pieces (k = 0) and their LDS offsets inside a stage
-  const bf16* src[NIW];
-#pragma unroll
-  for (int j = 0; j < NIW; ++j) {
-    const int ii = w + NW * j;
-    const int r8 = lane >> 3, ch = (lane & 7) ^ r8;
-    if (ii < TBM / 8) src[j] = g.A + (int64_t)min(m0 + ii * 8 + r8, g.M - 1) * g.lda + ch * 8;
-    else src[j] = g.B + (int64_t)min(n0 + (ii - TBM / 8) * 8 + r8, g.N - 1) * g.ldb + ch * 8;
-  }
-  auto issue = [&](int kt) {
-    unsigned char* st = lds + (kt % S) * STAGE;
-#pragma unroll
-    for (int j = 0; j < NIW; ++j)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[j] + kt * 64),
-                                       (__attribute__((address_space(3))) void*)(st + (w + NW * j) * 1024), 16, 0, 0);
-  };
-  auto off = [](int row, int chunk) { return row * 128 + ((chunk ^ (row & 7)) << 4); };
-
-  f32x4 acc[4][4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j)
-#pragma unroll
-    for (int i = 0; i < 4; ++i) acc[j][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-  const int nk = g.K / 64;
-#pragma unroll
-  for (int s = 0; s < S - 1; ++s)
-    if (s < nk) issue(s);
-  const int fr = lane & 15, fq = lane >> 4;
-  for (int kt = 0; kt < nk; ++kt) {
-    // pieces of step kt have landed once at most (steps issued after it) * NIW are outstanding
-    const int later = min(S - 2, nk - 1 - kt);
-    if (later >= S - 2) wait_vmcnt<NIW * (S - 2)>();
-    else if (S > 3 && later == S - 3) wait_vmcnt<NIW * (S > 3 ? S - 3 : 0)>();
-    else if (S > 4 && later == S - 4) wait_vmcnt<NIW * (S > 4 ? S - 4 : 0)>();
-    else wait_vmcnt<0>();
-    __builtin_amdgcn_s_barrier();
-    if (kt + S - 1 < nk) issue(kt + S - 1);
-    const unsigned char* a = lds + (kt % S) * STAGE;
-    const unsigned char* b = a + TBM * 128;
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      bf16x8 af[4], bfr[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        af[i] = *(const bf16x8*)(a + off(wm * 64 + i * 16 + fr, ks * 4 + fq));
-        bfr[i] = *(const bf16x8*)(b + off(wn * 64 + i * 16 + fr, ks * 4 + fq));
-      }
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-          acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[j][i], 0, 0, 0);
-    }
-  }
-  const bool vec_ok = (g.ldc & 3) == 0 && (g.N & 3) == 0;
-#pragma unroll
-  for (int j = 0; j < 4; ++j)
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-      epilogue4<C_BF16>(g, m0 + wm * 64 + i * 16 + fr, n0 + wn * 64 + j * 16 + fq * 4, acc[j][i], vec_ok);
-}
-
-template <bool C_BF16, int NWM, int NWN, int S>
-static int launch_nt_ring(MfmaArgs& g, hipStream_t st) {
-  constexpr int TBM = 64 * NWM, TBN = 64 * NWN;
-  constexpr int shm = S * (TBM + TBN) * 128;
-  static_assert(shm <= 160 * 1024, "ring does not fit the 160 KiB LDS");
-  g.tiles_m = (g.M + TBM - 1) / TBM; g.tiles_n = (g.N + TBN - 1) / TBN;
-  auto kern = k_gemm_nt_ring<C_BF16, NWM, NWN, S>;
-  static bool done = false;  // per instantiation
-  if (!done) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, shm); done = true; }
-  AFM_LAUNCH(kern, dim3(g.tiles_m * g.tiles_n), dim3(64 * NWM * NWN), shm, st, g);
-  return AFM_OK;
-}
 
 // ------------------------------------------------------------------------------------------ staged epilogue
 // Full-tile epilogue of the persistent kernel.  A wave's 64 x 64 accumulator block is transposed
@@ -891,33 +792,14 @@ int afm_gemm_mfma_try(const afm_gemm_desc* d, hipStream_t st) {
     int r;
 #define NT_CASE(WM, WN, NWM, NWN, BKT) \
     (d->c_dtype == AFM_BF16 ? launch_nt<true, WM, WN, NWM, NWN, BKT>(g, st) : launch_nt<false, WM, WN, NWM, NWN, BKT>(g, st))
-    switch (variant) {
-      case 1: r = NT_CASE(8, 4, 2, 2, 64); break;   // 256x128, 4 waves of 128x64
-      case 2: r = NT_CASE(8, 4, 2, 4, 64); break;   // 256x256, 8 waves of 128x64
-      case 3: r = NT_CASE(4, 4, 4, 2, 64); break;   // 256x128, 8 waves of 64x64
-      case 4: r = NT_CASE(4, 4, 2, 2, 32); break;   // 128x128, k-step 32
-      case 5: r = NT_CASE(8, 4, 2, 2, 32); break;   // 256x128, 4 waves, k-step 32
-#define RING_CASE(NWM, NWN, S) \
-    ((d->K & 63) ? AFM_ERR_UNSUPPORTED : (d->c_dtype == AFM_BF16 ? launch_nt_ring<true, NWM, NWN, S>(g, st) : launch_nt_ring<false, NWM, NWN, S>(g, st)))
-      case 6: r = RING_CASE(4, 2, 3); break;        // 256x128, 8 waves, 3-stage LDS-DMA ring
-      case 7: r = RING_CASE(2, 2, 4); break;        // 128x128, 4 waves, 4 stages
-      case 8: r = RING_CASE(2, 2, 3); break;        // 128x128, 4 waves, 3 stages
-      case 9: r = RING_CASE(2, 4, 3); break;        // 128x256, 8 waves, 3 stages
-      case 10: r = RING_CASE(2, 2, 2); break;       // 128x128, 4 waves, 2 stages
-      case 11: r = RING_CASE(4, 1, 4); break;       // 256x64, 4 waves, 4 stages
 #define PRING_CASE(NWM, NWN, S, BPC) \
-    ((d->K & 63) ? AFM_ERR_UNSUPPORTED : (d->c_dtype == AFM_BF16 ? launch_nt_pring<true, NWM, NWN, S>(g, st, BPC) : launch_nt_pring<false, NWM, NWN, S>(g, st, BPC)))
-      case 12: r = PRING_CASE(4, 2, 3, 1); break;   // persistent 256x128, 8 waves, 3 stages
-      case 13: r = PRING_CASE(2, 2, 2, 2); break;   // persistent 128x128, 4 waves, 2 stages, 2 blocks/CU
-      case 14: r = PRING_CASE(2, 4, 3, 1); break;   // persistent 128x256
-      case 15: r = PRING_CASE(2, 2, 3, 1); break;   // persistent 128x128, 3 stages, 1 block/CU
-      case 16: r = (d->K & 63) ? AFM_ERR_UNSUPPORTED : (d->c_dtype == AFM_BF16 ? launch_nt_pring<true, 2, 4, 2, 0, 8>(g, st, 1) : launch_nt_pring<false, 2, 4, 2, 0, 8>(g, st, 1)); break;   // persistent 256x256, 8 waves of 128x64, 2 stages
-      case 112: r = launch_nt_pring<true, 4, 2, 3, 1>(g, st, 1); break;   // ablation: no MFMA
-      case 212: r = launch_nt_pring<true, 4, 2, 3, 2>(g, st, 1); break;   // ablation: no loads
-#undef PRING_CASE
-#undef RING_CASE
-      default: r = NT_CASE(4, 4, 2, 2, 64); break;  // 128x128, 4 waves of 64x64
+    (d->c_dtype == AFM_BF16 ? launch_nt_pring<true, NWM, NWN, S>(g, st, BPC) : launch_nt_pring<false, NWM, NWN, S>(g, st, BPC))
+    switch (variant) {
+      case 12: r = (d->K & 63) ? AFM_ERR_UNSUPPORTED : PRING_CASE(4, 2, 3, 1); break;   // persistent 256x128, 8 waves, 3 stages
+      case 13: r = (d->K & 63) ? AFM_ERR_UNSUPPORTED : PRING_CASE(2, 2, 2, 2); break;   // persistent 128x128, 4 waves, 2 per CU
+      default: r = NT_CASE(4, 4, 2, 2, 64); break;                                       // register-staged 128x128
     }
+#undef PRING_CASE
 #undef NT_CASE
     if (r != AFM_OK) return r;
     afm_set_last_algo("mfma_nt");

@@ -459,7 +459,7 @@ def test_attention_mfma_strided_packed_qkv(ops):
     close(o, ref.transpose(1, 2).reshape(B * T, d), 2e-2, 2e-2)
 
 
-@pytest.mark.parametrize("variant", [6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16])
+@pytest.mark.parametrize("variant", [12, 13, 100])
 @pytest.mark.parametrize("M,N,K", [(512, 256, 512), (1000, 1536, 512), (300, 136, 2048), (129, 24, 64), (70000, 384, 128)])
 def test_gemm_mfma_nt_ring_variants(ops, variant, M, N, K):
     a, w, bias = rnd(M, K, seed=1).bfloat16(), rnd(N, K, seed=2).bfloat16(), rnd(N, seed=3)

@@ -22,7 +22,7 @@ def main():
         for cdt in (torch.bfloat16, torch.float32):
             c = torch.empty(M, N, dtype=cdt, device=dev)
             res = []
-            for var in (12, 16):
+            for var in (0, 12, 13, 100):
                 ms = t(lambda: ops.gemm(a, w, c, variant=var))
                 res.append(f"v{var} {2*M*N*K/ms/1e9:6.0f}")
             print(f"NT {name:10s} {M}x{N}x{K} out {str(cdt)[6:]:8s} TF/s: " + "  ".join(res))
