@@ -68,6 +68,152 @@ __global__ void k_ln_fwd(const float* x, const float* __restrict__ gamma,
   }
 }
 
+
+// ---------------------------------------------------------------------------------------- vectorised
+// Identity-mapped rows (the transformer-block LayerNorms): every lane owns 8 consecutive features
+// per 512-wide slab, so all traffic is 16 bytes per lane on whole lines (fp32 as 2 x float4, bf16 as
+// one bf16x8): the scalar kernels above reached only ~2.3 TB/s on these 2-4-byte accesses.
+struct F8 { f32x4 lo, hi; };
+__device__ __forceinline__ F8 ld8(const float* p) { return {*(const f32x4*)p, *(const f32x4*)(p + 4)}; }
+__device__ __forceinline__ F8 ld8(const bf16* p) {
+  const bf16x8 v = *(const bf16x8*)p;
+  return {(f32x4){(float)v[0], (float)v[1], (float)v[2], (float)v[3]}, (f32x4){(float)v[4], (float)v[5], (float)v[6], (float)v[7]}};
+}
+__device__ __forceinline__ void st8(float* p, const F8& v) { *(f32x4*)p = v.lo; *(f32x4*)(p + 4) = v.hi; }
+__device__ __forceinline__ void st8(bf16* p, const F8& v) {
+  bf16x8 o = {(bf16)v.lo[0], (bf16)v.lo[1], (bf16)v.lo[2], (bf16)v.lo[3], (bf16)v.hi[0], (bf16)v.hi[1], (bf16)v.hi[2], (bf16)v.hi[3]};
+  *(bf16x8*)p = o;
+}
+__device__ __forceinline__ float hsum8(const F8& v) { return (v.lo[0] + v.lo[1]) + (v.lo[2] + v.lo[3]) + (v.hi[0] + v.hi[1]) + (v.hi[2] + v.hi[3]); }
+
+template <typename TY, typename TA, int NC>
+__global__ __launch_bounds__(256) void k_ln_fwd_vec(const float* x, const float* __restrict__ gamma,
+                                                    const float* __restrict__ beta, TY* __restrict__ y,
+                                                    float* __restrict__ mean, float* __restrict__ rstd,
+                                                    int64_t rows, int d, float eps, const TA* __restrict__ add,
+                                                    float* x_sum) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  const float inv_d = 1.0f / (float)d;
+  F8 gm[NC], bt[NC];
+#pragma unroll
+  for (int i = 0; i < NC; ++i) {
+    const int c = (lane + 64 * i) * 8;
+    if (c < d) { gm[i] = ld8(gamma + c); bt[i] = ld8(beta + c); }
+  }
+  for (int64_t r = wave; r < rows; r += nwaves) {
+    F8 v[NC];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+      const int c = (lane + 64 * i) * 8;
+      if (c < d) {
+        v[i] = ld8(x + r * (int64_t)d + c);
+        if (add) {
+          const F8 a = ld8(add + r * (int64_t)d + c);
+          v[i].lo += a.lo; v[i].hi += a.hi;
+          st8(x_sum + r * (int64_t)d + c, v[i]);
+        }
+        s += hsum8(v[i]);
+      }
+    }
+    const float mu = wave_sum(s) * inv_d;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+      const int c = (lane + 64 * i) * 8;
+      if (c < d) {
+        v[i].lo -= mu; v[i].hi -= mu;
+        F8 sq = {v[i].lo * v[i].lo, v[i].hi * v[i].hi};
+        q += hsum8(sq);
+      }
+    }
+    const float rs = rsqrtf(wave_sum(q) * inv_d + eps);
+    if (lane == 0) {
+      if (mean) mean[r] = mu;
+      if (rstd) rstd[r] = rs;
+    }
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+      const int c = (lane + 64 * i) * 8;
+      if (c < d) {
+        F8 o = {v[i].lo * rs * gm[i].lo + bt[i].lo, v[i].hi * rs * gm[i].hi + bt[i].hi};
+        st8(y + r * (int64_t)d + c, o);
+      }
+    }
+  }
+}
+
+template <typename TY, int NC>
+__global__ __launch_bounds__(256) void k_ln_bwd_vec(const TY* __restrict__ dy, const float* __restrict__ x,
+                                                    const float* __restrict__ gamma,
+                                                    const float* __restrict__ mean,
+                                                    const float* __restrict__ rstd,
+                                                    const float* __restrict__ dres, float* __restrict__ dx,
+                                                    float* __restrict__ partial, int64_t rows, int d,
+                                                    TY* __restrict__ dx_drop, DropDev dd) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];  // [4 waves][2][d]
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  const float inv_d = 1.0f / (float)d;
+  F8 gm[NC], ag[NC], ab[NC];
+#pragma unroll
+  for (int i = 0; i < NC; ++i) {
+    const int c = (lane + 64 * i) * 8;
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    ag[i] = {z, z}; ab[i] = {z, z}; gm[i] = {z, z};
+    if (c < d) gm[i] = ld8(gamma + c);
+  }
+  for (int64_t r = wave; r < rows; r += nwaves) {
+    const float mu = mean[r], rs = rstd[r];
+    F8 xh[NC], g[NC];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+      const int c = (lane + 64 * i) * 8;
+      if (c < d) {
+        const F8 dyv = ld8(dy + r * (int64_t)d + c);
+        const F8 xv = ld8(x + r * (int64_t)d + c);
+        xh[i] = {(xv.lo - mu) * rs, (xv.hi - mu) * rs};
+        g[i] = {dyv.lo * gm[i].lo, dyv.hi * gm[i].hi};
+        ag[i].lo += dyv.lo * xh[i].lo; ag[i].hi += dyv.hi * xh[i].hi;
+        ab[i].lo += dyv.lo; ab[i].hi += dyv.hi;
+        s1 += hsum8(g[i]);
+        F8 gx = {g[i].lo * xh[i].lo, g[i].hi * xh[i].hi};
+        s2 += hsum8(gx);
+      }
+    }
+    const float m1 = wave_sum(s1) * inv_d, m2 = wave_sum(s2) * inv_d;
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+      const int c = (lane + 64 * i) * 8;
+      if (c < d) {
+        F8 o = {rs * (g[i].lo - m1 - xh[i].lo * m2), rs * (g[i].hi - m1 - xh[i].hi * m2)};
+        if (dres) { const F8 dr = ld8(dres + r * (int64_t)d + c); o.lo += dr.lo; o.hi += dr.hi; }
+        st8(dx + r * (int64_t)d + c, o);
+        if (dx_drop) {
+          const uint64_t base = (uint64_t)r * (uint64_t)d + (uint64_t)c;
+          F8 od;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) { od.lo[k] = afm_drop(dd, base + k, o.lo[k]); od.hi[k] = afm_drop(dd, base + 4 + k, o.hi[k]); }
+          st8(dx_drop + r * (int64_t)d + c, od);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < NC; ++i) {
+    const int c = (lane + 64 * i) * 8;
+    if (c < d) { st8(sm + (w * 2 + 0) * d + c, ag[i]); st8(sm + (w * 2 + 1) * d + c, ab[i]); }
+  }
+  __syncthreads();
+  float* pb = partial + (int64_t)blockIdx.x * 2 * d;
+  for (int j = threadIdx.x; j < 2 * d; j += blockDim.x)
+    pb[j] = sm[0 * 2 * d + j] + sm[1 * 2 * d + j] + sm[2 * 2 * d + j] + sm[3 * 2 * d + j];
+}
+
 extern "C" int afm_layernorm_fwd(const afm_ln_shape* s, const float* x, const float* gamma,
                                  const float* beta, const float* pos, void* y, float* mean,
                                  float* rstd, const void* add, float* x_sum, void* stream) {
@@ -80,6 +226,16 @@ extern "C" int afm_layernorm_fwd(const afm_ln_shape* s, const float* x, const fl
   if (g > 2048) g = 2048;
   hipStream_t st = (hipStream_t)stream;
   if (s->y_dtype != AFM_F32 && s->y_dtype != AFM_BF16) return AFM_ERR_ARG;
+  if (s->seg_len == 0 && !pos && (s->d % 8) == 0 && s->d <= 2048 && s->rows >= 64) {   // vectorised path
+#define LN_FV(TY, TA, NC) AFM_LAUNCH((k_ln_fwd_vec<TY, TA, NC>), dim3((int)g), dim3(256), 0, st, x, gamma, beta, (TY*)y, mean, \
+                                     rstd, s->rows, s->d, s->eps, (const TA*)add, x_sum)
+#define LN_FV2(TY, TA) do { if (s->d <= 512) LN_FV(TY, TA, 1); else if (s->d <= 1024) LN_FV(TY, TA, 2); else LN_FV(TY, TA, 4); } while (0)
+    if (s->y_dtype == AFM_BF16) { if (add_bf16) LN_FV2(bf16, bf16); else LN_FV2(bf16, float); }
+    else { if (add_bf16) LN_FV2(float, bf16); else LN_FV2(float, float); }
+#undef LN_FV2
+#undef LN_FV
+    return AFM_OK;
+  }
 #define LN_FWD(NV)                                                                                  \
   do {                                                                                              \
     if (s->y_dtype == AFM_F32)                                                                      \
@@ -215,6 +371,16 @@ extern "C" int afm_layernorm_bwd(const afm_ln_shape* s, const void* dy, const fl
   hipStream_t st = (hipStream_t)stream;
   const size_t shm = sizeof(float) * 8 * s->d;
   if (s->y_dtype != AFM_F32 && s->y_dtype != AFM_BF16) return AFM_ERR_ARG;
+  if (s->seg_len == 0 && (s->d % 8) == 0 && s->d <= 2048 && s->rows >= 64) {   // vectorised path
+#define LN_BV(TY, NC) AFM_LAUNCH((k_ln_bwd_vec<TY, NC>), dim3(g), dim3(256), shm, st, (const TY*)dy, x, gamma, mean, rstd, dres, dx, \
+                                 partial, s->rows, s->d, (TY*)dx_drop, dd)
+#define LN_BV2(TY) do { if (s->d <= 512) LN_BV(TY, 1); else if (s->d <= 1024) LN_BV(TY, 2); else LN_BV(TY, 4); } while (0)
+    if (s->y_dtype == AFM_BF16) LN_BV2(bf16); else LN_BV2(float);
+#undef LN_BV2
+#undef LN_BV
+    AFM_LAUNCH(k_ln_bwd_reduce, dim3((2 * s->d + 63) / 64, g >= 64 ? 16 : 1), dim3(256), 0, st, partial, dgamma, dbeta, g, s->d);
+    return AFM_OK;
+  }
 #define LN_BWD(NV)                                                                                   \
   do {                                                                                               \
     if (s->y_dtype == AFM_F32)                                                                       \
