@@ -162,6 +162,9 @@ typedef struct {
   int32_t reserved;
   const uint8_t* key_pad;
   afm_dropout drop;
+  /* batch strides in ELEMENTS of Q, K, V, O (0 = dense: Tq*ldq, Tk*ldk, Tk*ldv, Tq*ldo).  Non-dense
+   * strides address a KV cache laid out (batch, Tmax, 2d) during incremental decode; forward only. */
+  int64_t sqb, skb, svb, sob;
 } afm_attn_shape;
 int afm_attn_fwd(const afm_attn_shape* s, const void* Q, const void* K, const void* V, void* O,
                  float* lse, void* stream);

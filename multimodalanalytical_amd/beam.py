@@ -1,0 +1,120 @@
+"""Host-side beam bookkeeping for `HFWrapper.generate(n_beams > 1)`.
+
+Restates the control flow HF `GenerationMixin._beam_search` + `BeamSearchScorer` follow when called as
+the reference calls them (reference modeling/wrapper.py:443-451: num_beams = num_return_sequences =
+n_beams, length_penalty 1.0, early_stopping False, forced EOS at max_length, pad id 0): per step
+log-softmax + running beam score, top 2k candidates per sample, EOS candidates inside the top k close
+a hypothesis scored sum_logprobs / generated_len, the first k non-EOS candidates continue; a sample
+is done when it holds k hypotheses and its worst kept score beats best_running / generated_len.
+The arithmetic (decoder, logits) runs on the GPU; this module only moves 2k (score, token, beam)
+triples per sample per step to the host, as HF's Python loop does.
+
+Parity status: UNPINNED.  HF `generate()` cannot run in the build container (transformers 5.x rejects
+the reference's model), so there are no reference beam outputs to pin against; tests check
+invariants (k = 1 equals greedy, KV-cached equals full recompute, scores sorted, forced EOS).
+"""
+from __future__ import annotations
+
+from typing import List, Tuple
+
+import torch
+
+
+class BeamHypotheses:
+    def __init__(self, num_beams: int, length_penalty: float = 1.0):
+        self.num_beams, self.length_penalty = num_beams, length_penalty
+        self.beams: List[Tuple[float, List[int]]] = []
+        self.worst_score = 1e9
+
+    def __len__(self):
+        return len(self.beams)
+
+    def add(self, hyp: List[int], sum_logprobs: float, generated_len: int) -> None:
+        score = sum_logprobs / (generated_len ** self.length_penalty)
+        if len(self) < self.num_beams or score > self.worst_score:
+            self.beams.append((score, hyp))
+            if len(self) > self.num_beams:
+                srt = sorted((s, i) for i, (s, _) in enumerate(self.beams))
+                del self.beams[srt[0][1]]
+                self.worst_score = srt[1][0]
+            else:
+                self.worst_score = min(score, self.worst_score)
+
+    def is_done(self, best_sum_logprobs: float, generated_len: int) -> bool:
+        if len(self) < self.num_beams:
+            return False
+        return self.worst_score >= best_sum_logprobs / (generated_len ** self.length_penalty)
+
+
+def beam_search(step_fn, reorder_fn, B: int, k: int, V: int, max_length: int, bos: int, eos: int, pad: int,
+                device) -> Tuple[torch.Tensor, torch.Tensor]:
+    """step_fn(ids_last (B*k,)) -> fp32 logits (B*k, V) for the next position; reorder_fn(beam_idx (B*k,)).
+    Returns (sequences (B*k, L) int64 best-first per sample, scores (B*k,))."""
+    ids = torch.full((B * k, 1), bos, dtype=torch.long, device=device)
+    beam_scores = torch.zeros(B, k, dtype=torch.float32, device=device)
+    beam_scores[:, 1:] = -1e9
+    beam_scores = beam_scores.view(-1)
+    hyps = [BeamHypotheses(k) for _ in range(B)]
+    done = [False] * B
+    while True:
+        cur_len = ids.shape[1]
+        logits = step_fn(ids[:, -1])
+        logp = torch.log_softmax(logits.float(), dim=-1)
+        if cur_len == max_length - 1:                       # ForcedEOSTokenLogitsProcessor
+            forced = torch.full_like(logp, float("-inf"))
+            forced[:, eos] = 0.0
+            logp = forced
+        scores = (logp + beam_scores[:, None]).view(B, k * V)
+        top_s, top_i = torch.topk(scores, 2 * k, dim=1, largest=True, sorted=True)
+        top_s_h, top_i_h = top_s.cpu(), top_i.cpu()
+        ids_h = ids.cpu()
+        nxt_scores = torch.zeros(B, k)
+        nxt_tokens = torch.zeros(B, k, dtype=torch.long)
+        nxt_index = torch.zeros(B, k, dtype=torch.long)
+        for b in range(B):
+            if done[b]:
+                nxt_tokens[b] = pad
+                nxt_index[b] = b * k
+                continue
+            j = 0
+            for rank in range(2 * k):
+                s, idx = float(top_s_h[b, rank]), int(top_i_h[b, rank])
+                beam, tok = idx // V, idx % V
+                row = b * k + beam
+                if tok == eos:
+                    if rank >= k:
+                        continue
+                    hyps[b].add(ids_h[row].tolist(), s, generated_len=cur_len)   # cur_len+1 tokens, minus the prompt
+                else:
+                    nxt_scores[b, j], nxt_tokens[b, j], nxt_index[b, j] = s, tok, row
+                    j += 1
+                if j == k:
+                    break
+            done[b] = done[b] or hyps[b].is_done(float(top_s_h[b].max()), cur_len)
+        beam_scores = nxt_scores.view(-1).to(device)
+        beam_idx = nxt_index.view(-1).to(device)
+        ids = torch.cat([ids.index_select(0, beam_idx), nxt_tokens.view(-1, 1).to(device)], dim=1)
+        reorder_fn(beam_idx)
+        if all(done) or ids.shape[1] >= max_length:
+            break
+    # finalize: open beams of unfinished samples become hypotheses
+    ids_h, bs_h = ids.cpu(), beam_scores.cpu()
+    for b in range(B):
+        if done[b]:
+            continue
+        for j in range(k):
+            row = b * k + j
+            hyps[b].add(ids_h[row].tolist(), float(bs_h[row]), generated_len=ids_h.shape[1] - 1)
+    best, best_scores = [], []
+    for b in range(B):
+        srt = sorted(hyps[b].beams, key=lambda x: x[0])
+        for _ in range(k):
+            s, h = srt.pop()
+            best.append(h); best_scores.append(s)
+    L = min(max(len(h) for h in best) + 1, max_length)
+    out = torch.full((B * k, L), pad, dtype=torch.long)
+    for i, h in enumerate(best):
+        out[i, :len(h)] = torch.tensor(h)
+        if len(h) < max_length:
+            out[i, len(h)] = eos
+    return out.to(device), torch.tensor(best_scores)

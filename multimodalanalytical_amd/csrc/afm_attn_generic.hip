@@ -7,6 +7,7 @@
 struct AttnArgs {
   int B, H, Tq, Tk, dh;
   int ldq, ldk, ldv, ldo;
+  int64_t sqb, skb, svb, sob;   // batch strides (elements)
   int causal;
   float scale;
   const uint8_t* key_pad;
@@ -34,14 +35,14 @@ __global__ __launch_bounds__(256) void k_attn_fwd_generic(AttnArgs a, const T* _
   const int q = (int)(row % a.Tq);
   const int h = (int)((row / a.Tq) % a.H);
   const int b = (int)(row / ((int64_t)a.Tq * a.H));
-  const T* qp = Q + ((int64_t)b * a.Tq + q) * a.ldq + (int64_t)h * a.dh;
+  const T* qp = Q + ((int64_t)b * a.sqb + (int64_t)q * a.ldq) + (int64_t)h * a.dh;
   for (int j = lane; j < a.dh; j += 64) qv[j] = ld_f32(qp, j);
   // scores
   float mx = -INFINITY;
   for (int k = lane; k < a.Tk; k += 64) {
     float s = -INFINITY;
     if (!attn_masked(a, b, q, k)) {
-      const T* kp = K + ((int64_t)b * a.Tk + k) * a.ldk + (int64_t)h * a.dh;
+      const T* kp = K + ((int64_t)b * a.skb + (int64_t)k * a.ldk) + (int64_t)h * a.dh;
       float acc = 0.f;
       for (int j = 0; j < a.dh; ++j) acc = fmaf(qv[j], ld_f32(kp, j), acc);
       s = acc * a.scale;
@@ -50,7 +51,7 @@ __global__ __launch_bounds__(256) void k_attn_fwd_generic(AttnArgs a, const T* _
     mx = fmaxf(mx, s);
   }
   mx = wave_max(mx);
-  T* op = O + ((int64_t)b * a.Tq + q) * a.ldo + (int64_t)h * a.dh;
+  T* op = O + ((int64_t)b * a.sob + (int64_t)q * a.ldo) + (int64_t)h * a.dh;
   if (mx == -INFINITY) {  // every key masked: zeros (torch _safe_softmax)
     for (int j = lane; j < a.dh; j += 64) st_f32(op, j, 0.f);
     if (lane == 0) lse[row] = INFINITY;
@@ -70,7 +71,7 @@ __global__ __launch_bounds__(256) void k_attn_fwd_generic(AttnArgs a, const T* _
     float acc = 0.f;
     for (int k = 0; k < a.Tk; ++k) {
       const float p = afm_drop16(a.dd, didx + k, sc[k]);
-      acc = fmaf(p, ld_f32(V + ((int64_t)b * a.Tk + k) * a.ldv + (int64_t)h * a.dh, j), acc);
+      acc = fmaf(p, ld_f32(V + ((int64_t)b * a.svb + (int64_t)k * a.ldv) + (int64_t)h * a.dh, j), acc);
     }
     st_f32(op, j, acc * inv_l);
   }
@@ -93,9 +94,9 @@ __global__ __launch_bounds__(256) void k_attn_bwd_q_generic(
   const int q = (int)(row % a.Tq);
   const int h = (int)((row / a.Tq) % a.H);
   const int b = (int)(row / ((int64_t)a.Tq * a.H));
-  const T* qp = Q + ((int64_t)b * a.Tq + q) * a.ldq + (int64_t)h * a.dh;
-  const T* op = O + ((int64_t)b * a.Tq + q) * a.ldo + (int64_t)h * a.dh;
-  const T* dop = dO + ((int64_t)b * a.Tq + q) * a.ldo + (int64_t)h * a.dh;
+  const T* qp = Q + ((int64_t)b * a.sqb + (int64_t)q * a.ldq) + (int64_t)h * a.dh;
+  const T* op = O + ((int64_t)b * a.sob + (int64_t)q * a.ldo) + (int64_t)h * a.dh;
+  const T* dop = dO + ((int64_t)b * a.sob + (int64_t)q * a.ldo) + (int64_t)h * a.dh;
   float dl = 0.f;
   for (int j = lane; j < a.dh; j += 64) {
     qv[j] = ld_f32(qp, j);
@@ -110,8 +111,8 @@ __global__ __launch_bounds__(256) void k_attn_bwd_q_generic(
   for (int k = lane; k < a.Tk; k += 64) {
     float d = 0.f;
     if (!attn_masked(a, b, q, k) && L != INFINITY) {
-      const T* kp = K + ((int64_t)b * a.Tk + k) * a.ldk + (int64_t)h * a.dh;
-      const T* vp = V + ((int64_t)b * a.Tk + k) * a.ldv + (int64_t)h * a.dh;
+      const T* kp = K + ((int64_t)b * a.skb + (int64_t)k * a.ldk) + (int64_t)h * a.dh;
+      const T* vp = V + ((int64_t)b * a.svb + (int64_t)k * a.ldv) + (int64_t)h * a.dh;
       float s = 0.f, dp = 0.f;
       for (int j = 0; j < a.dh; ++j) {
         s = fmaf(qv[j], ld_f32(kp, j), s);
@@ -127,7 +128,7 @@ __global__ __launch_bounds__(256) void k_attn_bwd_q_generic(
   for (int j = lane; j < a.dh; j += 64) {
     float acc = 0.f;
     for (int k = 0; k < a.Tk; ++k)
-      acc = fmaf(ds[k], ld_f32(K + ((int64_t)b * a.Tk + k) * a.ldk + (int64_t)h * a.dh, j), acc);
+      acc = fmaf(ds[k], ld_f32(K + ((int64_t)b * a.skb + (int64_t)k * a.ldk) + (int64_t)h * a.dh, j), acc);
     st_f32(dqp, j, acc);
   }
 }
@@ -150,16 +151,16 @@ __global__ __launch_bounds__(256) void k_attn_bwd_kv_generic(
   const int k = (int)(row % a.Tk);
   const int h = (int)((row / a.Tk) % a.H);
   const int b = (int)(row / ((int64_t)a.Tk * a.H));
-  const T* kp = K + ((int64_t)b * a.Tk + k) * a.ldk + (int64_t)h * a.dh;
-  const T* vp = V + ((int64_t)b * a.Tk + k) * a.ldv + (int64_t)h * a.dh;
+  const T* kp = K + ((int64_t)b * a.skb + (int64_t)k * a.ldk) + (int64_t)h * a.dh;
+  const T* vp = V + ((int64_t)b * a.svb + (int64_t)k * a.ldv) + (int64_t)h * a.dh;
   for (int j = lane; j < a.dh; j += 64) { kv[j] = ld_f32(kp, j); vv[j] = ld_f32(vp, j); }
   for (int q = lane; q < a.Tq; q += 64) {
     float pdv = 0.f, dsv = 0.f;
     const int64_t qrow = ((int64_t)b * a.H + h) * a.Tq + q;
     const float L = lse[qrow];
     if (!attn_masked(a, b, q, k) && L != INFINITY) {
-      const T* qp = Q + ((int64_t)b * a.Tq + q) * a.ldq + (int64_t)h * a.dh;
-      const T* dop = dO + ((int64_t)b * a.Tq + q) * a.ldo + (int64_t)h * a.dh;
+      const T* qp = Q + ((int64_t)b * a.sqb + (int64_t)q * a.ldq) + (int64_t)h * a.dh;
+      const T* dop = dO + ((int64_t)b * a.sob + (int64_t)q * a.ldo) + (int64_t)h * a.dh;
       float s = 0.f, dp = 0.f;
       for (int j = 0; j < a.dh; ++j) {
         s = fmaf(ld_f32(qp, j), kv[j], s);
@@ -179,9 +180,8 @@ __global__ __launch_bounds__(256) void k_attn_bwd_kv_generic(
   for (int j = lane; j < a.dh; j += 64) {
     float ak = 0.f, av = 0.f;
     for (int q = 0; q < a.Tq; ++q) {
-      const int64_t base = ((int64_t)b * a.Tq + q);
-      ak = fmaf(ds[q], ld_f32(Q + base * a.ldq + (int64_t)h * a.dh, j), ak);
-      av = fmaf(pd[q], ld_f32(dO + base * a.ldo + (int64_t)h * a.dh, j), av);
+      ak = fmaf(ds[q], ld_f32(Q + (int64_t)b * a.sqb + (int64_t)q * a.ldq + (int64_t)h * a.dh, j), ak);
+      av = fmaf(pd[q], ld_f32(dO + (int64_t)b * a.sob + (int64_t)q * a.ldo + (int64_t)h * a.dh, j), av);
     }
     st_f32(dkp, j, ak);
     st_f32(dvp, j, av);
@@ -192,6 +192,8 @@ static AttnArgs make_args(const afm_attn_shape* s) {
   AttnArgs a;
   a.B = s->B; a.H = s->H; a.Tq = s->Tq; a.Tk = s->Tk; a.dh = s->dh;
   a.ldq = s->ldq; a.ldk = s->ldk; a.ldv = s->ldv; a.ldo = s->ldo;
+  a.sqb = s->sqb ? s->sqb : (int64_t)s->Tq * s->ldq; a.skb = s->skb ? s->skb : (int64_t)s->Tk * s->ldk;
+  a.svb = s->svb ? s->svb : (int64_t)s->Tk * s->ldv; a.sob = s->sob ? s->sob : (int64_t)s->Tq * s->ldo;
   a.causal = s->causal; a.scale = s->scale; a.key_pad = s->key_pad;
   a.dd = afm_make_drop(&s->drop);
   return a;
@@ -250,6 +252,7 @@ extern "C" int afm_attn_bwd(const afm_attn_shape* s, const void* Q, const void* 
   if (!Q || !K || !V || !O || !dO || !lse || !delta || !dQ || !dK || !dV) return AFM_ERR_ARG;
   const int w = s->H * s->dh;
   if (lddq < w || lddk < w || lddv < w) return AFM_ERR_ARG;
+  if (s->sqb || s->skb || s->svb || s->sob) return AFM_ERR_UNSUPPORTED;   // strided batches: forward (decode) only
   hipStream_t st = (hipStream_t)stream;
   if (s->algo != AFM_ALGO_GENERIC) {
     r = afm_attn_bwd_mfma_try(s, Q, K, V, O, dO, lse, delta, dQ, dK, dV, lddq, lddk, lddv, st);

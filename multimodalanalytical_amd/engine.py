@@ -469,6 +469,77 @@ class Seq2SeqEngine:
             saved.update(dec_layers=layers, hf=hf, T=T)
         return logits
 
+
+    # ------------------------------------------------------------------ incremental decode (KV cache)
+    def decode_init(self, mem: torch.Tensor, attention_mask: torch.Tensor, beams: int = 1, max_len: int = 128):
+        """State for token-by-token decoding against fixed encoder memory (eval semantics): the
+        cross-attention K/V of every decoder layer are projected ONCE, self-attention K/V are
+        appended to a (B*beams, max_len, 2d) cache per layer -- instead of the reference's
+        `use_cache=False` full-prefix recompute (wrapper.py:443-451, custom_modeling.py:279-281)."""
+        B, S = attention_mask.shape
+        d, Ld = self.d, self.cfg["decoder_layers"]
+        st = {"B": B, "S": S, "k": int(beams), "Tmax": int(max_len), "t": 0,
+              "mem_pad": (attention_mask == 0).to(torch.uint8).contiguous()}
+        mem2 = mem.reshape(B * S, d)
+        if mem2.dtype != self.cd:
+            mem2 = mem2.to(self.cd)
+        st["xkv"] = [self._linear(mem2, f"decoder.layers.{i}.multihead_attn.in_proj_weight", 3 * d, d, d, 3 * d,
+                                  bias_name=f"decoder.layers.{i}.multihead_attn.in_proj_bias") for i in range(Ld)]
+        st["cache"] = [torch.zeros(B * beams, max_len, 2 * d, dtype=self.cd, device=self.dev) for _ in range(Ld)]
+        st["pe"] = self._pos_rows(max_len, None).contiguous()
+        return st
+
+    def decode_reorder(self, st, beam_idx: torch.Tensor) -> None:
+        """Beam search bookkeeping: row r of every cache continues beam beam_idx[r]."""
+        st["cache"] = [c.index_select(0, beam_idx) for c in st["cache"]]
+
+    def decode_step(self, st, ids: torch.Tensor) -> torch.Tensor:
+        """Feed token ids (B*beams,) at position st['t']; returns fp32 logits (B*beams, V)."""
+        assert not self.training, "decode runs with eval semantics (no dropout)"
+        B, S, k, Tmax, t = st["B"], st["S"], st["k"], st["Tmax"], st["t"]
+        if t >= Tmax:
+            raise ValueError("decode past max_len")
+        d, Bk = self.d, B * k
+        H, dh = self.cfg["decoder_attention_heads"], self.d // self.cfg["decoder_attention_heads"]
+        m = self.tm
+        e = torch.empty(Bk, d, dtype=torch.float32, device=self.dev)
+        ops.gather_rows(ids.contiguous().view(-1), self.ps.p(f"embedding.embedding_layer_dict.{m}.weight"), e)
+        x = torch.empty(Bk, d, dtype=torch.float32, device=self.dev)
+        ops.layernorm_fwd(e, self.ps.p(f"embedding.embedding_norm_dict.{m}.weight"),
+                          self.ps.p(f"embedding.embedding_norm_dict.{m}.bias"), x, pos=st["pe"][t:t + 1],
+                          seg_len=1, out_seg_stride=1, out_off=0)
+        pend = None
+        for i in range(self.cfg["decoder_layers"]):
+            p = f"decoder.layers.{i}."
+            # causal self-attention over the cache: the new token sees positions 0..t
+            h, x = self._ln_fwd(x, p + "norm1.", None, None, pend=pend)
+            qkv = self._linear(h, p + "self_attn.in_proj_weight", 3 * d, d, bias_name=p + "self_attn.in_proj_bias")
+            cache = st["cache"][i]
+            cache[:, t, :].copy_(qkv[:, d:])
+            a = self._empty(Bk, d)
+            lse = torch.empty(Bk * H, dtype=torch.float32, device=self.dev)
+            shp = ops.attn_shape(Bk, H, 1, t + 1, dh, self.cd, 3 * d, 2 * d, 2 * d, d, None, False, ops.NO_DROP,
+                                 self.algo, batch_strides=(3 * d, Tmax * 2 * d, Tmax * 2 * d, d))
+            c2 = cache.view(Bk * Tmax, 2 * d)
+            ops.attn_fwd(shp, qkv[:, :d], c2[:, :d], c2[:, d:], a, lse)
+            pend = self._linear(a, p + "self_attn.out_proj.weight", d, d, bias_name=p + "self_attn.out_proj.bias")
+            # cross-attention: the k beams of a sample are k query rows against that sample's memory
+            h, x = self._ln_fwd(x, p + "norm2.", None, None, pend=pend)
+            w, bname = p + "multihead_attn.in_proj_weight", p + "multihead_attn.in_proj_bias"
+            q = self._linear(h, w, 3 * d, d, 0, d, bias_name=bname)
+            kv = st["xkv"][i]
+            a = self._empty(Bk, d)
+            lse = torch.empty(Bk * H, dtype=torch.float32, device=self.dev)
+            shp = ops.attn_shape(B, H, k, S, dh, self.cd, d, 2 * d, 2 * d, d, st["mem_pad"], False, ops.NO_DROP, self.algo)
+            ops.attn_fwd(shp, q, kv[:, :d], kv[:, d:], a, lse)
+            pend = self._linear(a, p + "multihead_attn.out_proj.weight", d, d,
+                                bias_name=p + "multihead_attn.out_proj.bias")
+            x, pend = self._ffn_fwd(x, pend, p, self.cfg["decoder_ffn_dim"], "norm3.", None, f"d{i}")
+        hf, _ = self._ln_fwd(x, "decoder.norm.", None, None, pend=pend)
+        logits = self._linear(hf, "token_ff.weight", self.V, d, out_dtype=torch.float32, bias_name="token_ff.bias")
+        st["t"] = t + 1
+        return logits
+
     def forward(self, enc_inputs, attention_mask, dec_ids, dec_attention_mask=None, labels=None,
                 backward: bool = False, loss_scale: float = 1.0, memory=None):
         """One pass.  With `backward` the parameter gradients are ACCUMULATED into the flat

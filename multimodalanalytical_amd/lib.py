@@ -55,6 +55,7 @@ class AttnShape(C.Structure):
         ("causal", C.c_int32), ("algo", C.c_int32), ("scale", C.c_float), ("reserved", C.c_int32),
         ("key_pad", C.c_void_p),
         ("drop", Dropout),
+        ("sqb", C.c_int64), ("skb", C.c_int64), ("svb", C.c_int64), ("sob", C.c_int64),
     ]
 
 

@@ -161,33 +161,62 @@ class HFWrapper:
         mask = token_ids != -100
         return ((token_ids == pred) * mask).sum().float() / mask.sum().float()
 
-    def generate(self, batch: Dict[str, Any], n_beams: int = 1, logits_processor=None) -> torch.Tensor:
-        """wrapper.py:409-453 for n_beams == 1: greedy, full-prefix recompute like
-        `use_cache=False`, forced EOS at max_length (KV-cached / beam decode: SURVEY 8f rank 1)."""
-        if n_beams != 1 or logits_processor is not None:
-            raise NotImplementedError("beam search / guided generation: SURVEY 8f, not built yet")
-        tok = self.target_tokenizer
+    def _encode_for_generation(self, batch):
         input_ids = {m: (v.transpose(1, 0) if not isinstance(v, dict) else {k: t.transpose(1, 0) for k, t in v.items()})
                      for m, v in batch["encoder_input"].items()}
         attention_mask = (~batch["encoder_pad_mask"]).int().T.contiguous()
+        enc = self.hf_model.encoder(attention_mask=attention_mask, inputs_embeds=self.multimodal_embedding(input_ids))
+        return enc, attention_mask
+
+    def generate(self, batch: Dict[str, Any], n_beams: int = 1, logits_processor=None, use_cache: bool = True) -> torch.Tensor:
+        """wrapper.py:409-453.  Encoder once, then greedy (n_beams == 1) or beam search with
+        num_return_sequences = n_beams, max_length 128, forced EOS; returns (B*n_beams, <=128) ids.
+        use_cache=True decodes incrementally on a device-side KV cache (engine.decode_step);
+        use_cache=False reproduces the reference's full-prefix recompute (greedy only) for cross-checks."""
+        if logits_processor is not None:
+            raise NotImplementedError("guided generation (RDKit logits processor) is out of scope (SURVEY 2, row 18)")
+        tok = self.target_tokenizer
         was = self.training
         self.eval()
-        enc = self.hf_model.encoder(attention_mask=attention_mask, inputs_embeds=self.multimodal_embedding(input_ids))
+        enc, attention_mask = self._encode_for_generation(batch)
         B = attention_mask.shape[0]
-        ids = torch.full((B, 1), tok.bos_token_id, dtype=torch.long, device=attention_mask.device)
-        done = torch.zeros(B, dtype=torch.bool, device=ids.device)
-        while ids.shape[1] < self.max_length:
-            lg = self.hf_model(encoder_outputs=enc, attention_mask=attention_mask, decoder_input_ids=ids).logits
-            nxt = lg[:, -1].argmax(-1)
-            if ids.shape[1] == self.max_length - 1:
-                nxt = torch.full_like(nxt, tok.eos_token_id)
-            nxt = torch.where(done, torch.full_like(nxt, tok.pad_token_id), nxt)
-            ids = torch.cat([ids, nxt[:, None]], 1)
-            done = done | (nxt == tok.eos_token_id)
-            if bool(done.all()):
-                break
-        self.train(was)
-        return ids
+        dev = attention_mask.device
+        eng = self.hf_model.engine
+        try:
+            if n_beams == 1 and not use_cache:
+                ids = torch.full((B, 1), tok.bos_token_id, dtype=torch.long, device=dev)
+                done = torch.zeros(B, dtype=torch.bool, device=dev)
+                while ids.shape[1] < self.max_length:
+                    lg = self.hf_model(encoder_outputs=enc, attention_mask=attention_mask, decoder_input_ids=ids).logits
+                    ids, done = self._greedy_pick(lg[:, -1], ids, done)
+                    if bool(done.all()):
+                        break
+                return ids
+            st = eng.decode_init(enc["last_hidden_state"], attention_mask, beams=n_beams, max_len=self.max_length)
+            if n_beams == 1:
+                ids = torch.full((B, 1), tok.bos_token_id, dtype=torch.long, device=dev)
+                done = torch.zeros(B, dtype=torch.bool, device=dev)
+                while ids.shape[1] < self.max_length:
+                    ids, done = self._greedy_pick(eng.decode_step(st, ids[:, -1]), ids, done)
+                    if bool(done.all()):
+                        break
+                return ids
+            from ..beam import beam_search
+            seqs, self.last_beam_scores = beam_search(lambda last: eng.decode_step(st, last),
+                                                      lambda idx: eng.decode_reorder(st, idx), B, n_beams, eng.V,
+                                                      self.max_length, tok.bos_token_id, tok.eos_token_id,
+                                                      tok.pad_token_id, dev)
+            return seqs
+        finally:
+            self.train(was)
+
+    def _greedy_pick(self, last_logits, ids, done):
+        tok = self.target_tokenizer
+        nxt = last_logits.argmax(-1)
+        if ids.shape[1] == self.max_length - 1:
+            nxt = torch.full_like(nxt, tok.eos_token_id)
+        nxt = torch.where(done, torch.full_like(nxt, tok.pad_token_id), nxt)
+        return torch.cat([ids, nxt[:, None]], 1), done | (nxt == tok.eos_token_id)
 
     def validation_step(self, batch: Dict[str, Any], batch_idx: int) -> Dict[str, Any]:  # noqa: ARG002
         """wrapper.py:491-525 without the RDKit Top-1 (host chemistry metric, out of scope)."""
@@ -201,4 +230,4 @@ class HFWrapper:
         """wrapper.py:532-578 (greedy ids instead of decoded beam strings)."""
         self.eval()
         out = self.forward(batch)
-        return {"loss": out.loss, "predictions": self.generate(batch, n_beams=1), "targets": batch.get("target_smiles")}
+        return {"loss": out.loss, "predictions": self.generate(batch, n_beams=self.n_beams), "targets": batch.get("target_smiles")}

@@ -149,7 +149,7 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, ws, dres=None, se
 
 
 def attn_shape(B, H, Tq, Tk, dh, dtype, ldq, ldk, ldv, ldo, key_pad=None, causal=False,
-               dropout: Dropout = NO_DROP, algo=ALGO_AUTO, scale=None) -> AttnShape:
+               dropout: Dropout = NO_DROP, algo=ALGO_AUTO, scale=None, batch_strides=None) -> AttnShape:
     s = AttnShape()
     s.B, s.H, s.Tq, s.Tk, s.dh = B, H, Tq, Tk, dh
     s.dtype = _DT[dtype]
@@ -159,6 +159,8 @@ def attn_shape(B, H, Tq, Tk, dh, dtype, ldq, ldk, ldv, ldo, key_pad=None, causal
     if key_pad is not None:
         assert key_pad.dtype in (torch.uint8, torch.bool) and key_pad.is_contiguous()
         assert key_pad.numel() == B * Tk
+    if batch_strides is not None:   # (sqb, skb, svb, sob) in elements; KV-cache decode
+        s.sqb, s.skb, s.svb, s.sob = (int(v) for v in batch_strides)
     s.key_pad = _ptr(key_pad)
     s._keepalive = key_pad  # the struct only holds a raw pointer: keep the mask tensor alive with it
     s.drop = dropout

@@ -174,3 +174,44 @@ def test_wrapper_training_loop_and_checkpoint_roundtrip():
     w.eval(); w2.eval()
     b = _dev_batch(t, 0)
     assert torch.equal(w.forward(b).logits, w2.forward(b).logits)
+
+
+@pytest.mark.parametrize("name", CASES)
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_kv_cached_decode_equals_full_recompute_and_beam_invariants(name, dtype):
+    t = G.load(name); cfg = G.model_cfg(t["meta"])
+    w = _wrapper(t, cfg, dtype)
+    w.max_length = 14
+    b = _dev_batch(t, 0)
+    greedy_cache = w.generate(b, n_beams=1)
+    greedy_full = w.generate(b, n_beams=1, use_cache=False)
+    if dtype == torch.float32:
+        assert torch.equal(greedy_cache, greedy_full)
+        w.max_length = t["meta"]["greedy_max_length"]
+        assert torch.equal(w.generate(b, n_beams=1).cpu(), t["greedy"]["ids"])      # reference-derived golden ids
+        w.max_length = 14
+    else:   # bf16: a near-tie may flip a token; the prefixes must agree until then
+        same = (greedy_cache[:, :4] == greedy_full[:, :4]).float().mean()
+        assert float(same) > 0.9
+    B = greedy_cache.shape[0]
+    k = 3
+    beams = w.generate(b, n_beams=k)
+    assert beams.shape[0] == B * k and beams.shape[1] <= 14
+    assert (beams[:, 0] == 2).all()
+    sc = w.last_beam_scores.view(B, k)
+    assert (sc[:, :-1] >= sc[:, 1:] - 1e-6).all()                       # best first
+    for r in range(B * k):                                               # every sequence ends with EOS then pads
+        row = beams[r].tolist()
+        assert 3 in row
+        assert all(v == 0 for v in row[row.index(3) + 1:])
+    if dtype == torch.float32:
+        one = w.generate(b, n_beams=1)
+        kb1 = __import__("multimodalanalytical_amd.beam", fromlist=["beam_search"])
+        eng = w.hf_model.engine
+        w.eval()
+        enc, am = w._encode_for_generation(b)
+        st = eng.decode_init(enc["last_hidden_state"], am, beams=1, max_len=14)
+        seq1, _ = kb1.beam_search(lambda last: eng.decode_step(st, last), lambda idx: eng.decode_reorder(st, idx),
+                                  B, 1, eng.V, 14, 2, 3, 0, DEV)
+        n = min(seq1.shape[1], one.shape[1])
+        assert torch.equal(seq1[:, :n], one[:, :n])                      # beam width 1 == greedy
