@@ -38,7 +38,7 @@ class Seq2SeqEngine:
 
     def __init__(self, cfg: Dict[str, Any], data_config: Dict[str, Any], target_modality: str,
                  vocab_out: int, device="cuda:0", compute_dtype=torch.bfloat16, seed: int = 3247,
-                 algo: int = ALGO_AUTO):
+                 algo: int = ALGO_AUTO, side_wgrad: bool = False):
         self.cfg = dict(cfg)
         self.cfg.setdefault("multimodal_norm", True)
         self.cfg.setdefault("gated_linear", False)
@@ -69,6 +69,10 @@ class Seq2SeqEngine:
         self.micro_step = 0
         self._site_ids: Dict[str, int] = {}
         self.grad_ready_hook = None  # callable(flat_offset): grads at >= offset are final (DDP overlap)
+        # weight-gradient GEMMs are off the backward critical path (their outputs are only read by the
+        # optimiser / all-reduce): they run on a side HIP stream and overlap the LDS-free kernels
+        # (LayerNorm backward, casts) of the main stream on the same CUs
+        self.wgrad_stream = torch.cuda.Stream(device=self.dev) if (self.dev.type == "cuda" and side_wgrad) else None
         self.refresh_shadows()
 
     # ------------------------------------------------------------------ parameters
@@ -181,7 +185,14 @@ class Seq2SeqEngine:
         if bias_name is not None:
             s = self.ps.specs[bias_name]
             gb = self.ps.grad[s.offset + r0: s.offset + r0 + gw.shape[0]]
-        ops.gemm(dy, x, gw, trans_a=True, trans_b=False, accumulate=True, algo=self.algo, a_colsum=gb)
+        if self.wgrad_stream is None:
+            ops.gemm(dy, x, gw, trans_a=True, trans_b=False, accumulate=True, algo=self.algo, a_colsum=gb)
+            return
+        side = self.wgrad_stream
+        side.wait_stream(torch.cuda.current_stream())          # dy / x are produced on the main stream
+        with torch.cuda.stream(side):
+            ops.gemm(dy, x, gw, trans_a=True, trans_b=False, accumulate=True, algo=self.algo, a_colsum=gb)
+        dy.record_stream(side); x.record_stream(side)          # keep their memory until the side stream is done
 
     # ------------------------------------------------------------------ embedding
     def _pos_rows(self, S: int, saved: Optional[dict]):
@@ -576,6 +587,8 @@ class Seq2SeqEngine:
         """Parameters are laid out in forward order, so once a layer's backward is done every
         gradient from its first tensor to the end of the flat buffer is final."""
         if self.grad_ready_hook is not None:
+            if self.wgrad_stream is not None:
+                torch.cuda.current_stream().wait_stream(self.wgrad_stream)
             self.grad_ready_hook(self.ps.specs[first_name].offset)
 
     def _backward(self, saved, logits, lab, row_lse, stats, loss_scale, mem):
@@ -607,3 +620,5 @@ class Seq2SeqEngine:
             dx, dy = self._self_attn_bwd(dx, dy, p, sv, f"e{i - 1}res2" if i > 0 else None)
             self._grads_final_from(p + "self_attn.in_proj_weight")
         self.embed_bwd(dx, saved["emb_enc"])
+        if self.wgrad_stream is not None:   # every weight gradient is in before the caller reads the buffer
+            torch.cuda.current_stream().wait_stream(self.wgrad_stream)
