@@ -35,7 +35,7 @@ template <> __device__ __forceinline__ void st_f32<float>(float* p, int64_t i, f
 template <> __device__ __forceinline__ void st_f32<bf16>(bf16* p, int64_t i, float v) { p[i] = (bf16)v; }
 
 // ---------------------------------------------------------------- dropout stream
-// keep(i) = lowbias32(lo(i) ^ key ^ hi(i)*phi) >= thresh ; documented in DESIGN.md and
+// keep(i) = mix32(lo(i) ^ key ^ hi(i)*phi) >= thresh ; documented in DESIGN.md and
 // re-implemented in tests (numpy) so parity tests run WITH dropout against the oracle.
 struct DropDev {
   uint32_t key;
@@ -44,8 +44,20 @@ struct DropDev {
   uint32_t thresh16;  // attention-probability stream: 16 random bits per element
   float scale16;      // 1/(1 - thresh16/65536)
 };
-__host__ __device__ __forceinline__ uint32_t afm_lowbias32(uint32_t x) {
-  x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+// 32-bit mixer of the dropout stream: xorshift / 24-bit multiply-add rounds.  v_mad_u32_u24 issues at
+// full rate on CDNA4 whereas v_mul_lo_u32 is quarter rate: the attention kernels evaluate this once
+// per probability pair, where two 32-bit multiplies per hash cost as much as the tile's MFMAs.
+// Avalanche on sequential counters measured equal to lowbias32 (every output bit flips with
+// probability 0.49-0.51 per input bit; tools/hash_quality.py).
+__host__ __device__ __forceinline__ uint32_t afm_mad24(uint32_t x, uint32_t c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __umul24(x, c) + x;
+#else
+  return (uint32_t)(((uint64_t)(x & 0xFFFFFFu) * (uint64_t)(c & 0xFFFFFFu)) + x);
+#endif
+}
+__host__ __device__ __forceinline__ uint32_t afm_lowbias32(uint32_t x) {   // name kept: the stream's mixer
+  x ^= x >> 16; x = afm_mad24(x, 0x7b352dU); x ^= x >> 13; x = afm_mad24(x, 0x6ca68bU); x ^= x >> 16;
   return x;
 }
 static inline DropDev afm_make_drop(const afm_dropout* d) {

@@ -5,10 +5,15 @@ import numpy as np
 M32 = 0xFFFFFFFF
 
 
+def _mad24(x, c):
+    return ((x & 0xFFFFFF) * (c & 0xFFFFFF) + x) & M32
+
+
 def _lowbias32(x):
+    """afm_lowbias32 of csrc/afm_common.h: xorshift / 24-bit multiply-add mixer."""
     x = np.asarray(x, dtype=np.uint64) & M32
-    x ^= x >> 16; x = (x * 0x7feb352d) & M32
-    x ^= x >> 15; x = (x * 0x846ca68b) & M32
+    x ^= x >> 16; x = _mad24(x, 0x7b352d)
+    x ^= x >> 13; x = _mad24(x, 0x6ca68b)
     x ^= x >> 16
     return x
 
