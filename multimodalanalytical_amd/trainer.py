@@ -101,3 +101,30 @@ class TrainLoop:
                 self.reducer.finish()
             self.optim.step(grads_are_summed_over_ranks=self.reducer is not None)
         return loss
+
+
+def save_checkpoint(path: str, model, loop: "TrainLoop" = None, epoch: int = 0) -> None:
+    """Lightning-shaped checkpoint (reference trainer/trainer.py:31-37, cli/training.py:152-183 read
+    `checkpoint["state_dict"]` with `hf_model.*` / `multimodal_embedding.*` keys): the state dict uses the
+    reference's key names, so files written here load into the reference and vice versa."""
+    ckpt = {"state_dict": {k: v.detach().cpu() for k, v in model.state_dict().items()},
+            "epoch": int(epoch), "global_step": 0 if loop is None else loop.optim.step_count,
+            "pytorch-lightning_version": "2.5.1 (multimodalanalytical_amd writer)"}
+    if loop is not None:
+        opt = loop.optim.state_dict()
+        ckpt["optimizer_states"] = [{"step": opt["step"], "exp_avg": opt["exp_avg"].cpu(), "exp_avg_sq": opt["exp_avg_sq"].cpu(),
+                                     "layout": "flat (params.ParamStore offsets)"}]
+    torch.save(ckpt, path)
+
+
+def load_checkpoint(path: str, model, loop: "TrainLoop" = None, strict: bool = True) -> dict:
+    """Counterpart of `model.load_state_dict(checkpoint["state_dict"])` in the reference CLIs
+    (cli/predict.py:114-115, cli/training.py:152-163: `align_network.*` keys are dropped when unused)."""
+    ckpt = torch.load(path, map_location="cpu", weights_only=False)
+    sd = {k: v for k, v in ckpt["state_dict"].items() if "align_network" not in k}
+    model.load_state_dict(sd, strict=strict)
+    if loop is not None and ckpt.get("optimizer_states") and "exp_avg" in ckpt["optimizer_states"][0]:
+        st = ckpt["optimizer_states"][0]
+        dev = model.hf_model.engine.dev
+        loop.optim.load_state_dict({"step": st["step"], "exp_avg": st["exp_avg"].to(dev), "exp_avg_sq": st["exp_avg_sq"].to(dev)})
+    return ckpt
