@@ -187,6 +187,7 @@ __global__ __launch_bounds__(256, 2) void k_attn_fwd_mfma(AttnM a, const bf16* _
     __builtin_amdgcn_s_barrier();
     if (kt + RS - 1 < ntiles) issue(kt + RS - 1);
     if (a.causal && kb > q0 + 31) continue;  // wave-uniform: tile entirely above this wave's diagonal
+    if (maskw[kt] == ~0ull) continue;         // every key of the tile is padding: contributes nothing
     const unsigned char* Kimg = lds + (kt % RS) * STAGE;
     const unsigned char* Vimg = Kimg + KT * DH * 2;
     const unsigned long long mword = maskw[kt];
@@ -334,6 +335,7 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd_dq_mfma(AttnM a, const bf16
     __builtin_amdgcn_s_barrier();
     if (kt + RS - 1 < ntiles) issue(kt + RS - 1);
     if (a.causal && kb > q0 + 31) continue;
+    if (maskw[kt] == ~0ull) continue;         // all-padding key tile
     const unsigned char* Krow = lds + (kt % RS) * STAGE;
     const unsigned char* Ktr = Krow + KT * DH * 2;
     const unsigned char* Vrow = Krow + 2 * KT * DH * 2;
@@ -424,6 +426,7 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd_dkv_mfma(AttnM a, const bf1
   f32x16 dk[2], dv[2];
 #pragma unroll
   for (int i = 0; i < 16; ++i) { dk[0][i] = 0.f; dk[1][i] = 0.f; dv[0][i] = 0.f; dv[1][i] = 0.f; }
+  const bool wave_all_masked = __all(kmasked);
 
   int qbeg = 0;
   if (a.causal) qbeg = (blockIdx.x * 128) / KT * KT;   // queries before the block's first key see none of it
@@ -462,6 +465,7 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd_dkv_mfma(AttnM a, const bf1
     const float* Ds = Ls + KT;
     const bool ragged = qb + KT > a.Tq;   // wave-uniform: tile holds rows past Tq (clamped duplicates)
     if (a.causal && qb + KT - 1 < k0) continue;   // wave-uniform: every query of the tile precedes this wave's keys
+    if (wave_all_masked) continue;                // this wave's 32 keys are all padding: dK = dV = 0
 #pragma unroll
     for (int blk = 0; blk < 2; ++blk) {
       f32x16 s, dp;

@@ -408,10 +408,15 @@ def _attn_ref(q, k, v, key_pad, causal, keep=None, dscale=1.0):
 
 @pytest.mark.parametrize("B,H,Tq,Tk,causal,pad,pdrop", [
     (2, 2, 128, 128, True, True, 0.0), (2, 3, 100, 200, False, True, 0.0), (1, 2, 300, 300, False, False, 0.0),
-    (1, 2, 192, 192, True, False, 0.0), (2, 2, 128, 256, False, True, 0.1), (1, 2, 160, 160, True, True, 0.1)])
+    (1, 2, 192, 192, True, False, 0.0), (2, 2, 128, 256, False, True, 0.1), (1, 2, 160, 160, True, True, 0.1),
+    (2, 2, 130, 520, False, "blocks", 0.1)])
 def test_attention_mfma(ops, B, H, Tq, Tk, causal, pad, pdrop):
     dh, dt = 64, torch.bfloat16
-    q, k, v, key_pad = _attn_case(B, H, Tq, Tk, dh, causal, pad, seed=10)
+    q, k, v, key_pad = _attn_case(B, H, Tq, Tk, dh, causal, bool(pad), seed=10)
+    if pad == "blocks":   # whole 64-key tiles (and a whole 32-key wave block) of padding, as in multimodal batches
+        key_pad = torch.zeros(B, Tk, dtype=torch.bool)
+        key_pad[0, 64:192] = True; key_pad[0, 300:] = True
+        key_pad[1, 128:160] = True; key_pad[1, 448:512] = True
     q, k, v = q.bfloat16().float(), k.bfloat16().float(), v.bfloat16().float()
     D = H * dh
     qd, kd, vd = (dev(t.reshape(-1, D), dt) for t in (q, k, v))
