@@ -477,46 +477,49 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd_dkv_mfma(AttnM a, const bf1
         dp = mfma32(frag_row(Drow, 32 * blk, ks, lane), vf[ks], dp);   // dP[q][key]
       }
       f32x16 pd;
-      // Dropout keep bits.  Element (q, key) has index i = (lbase+q)*Tk + key; with Tk even the two
-      // lanes of a key pair (lane, lane^1) share the hash of i>>1 = (lbase+q)*(Tk/2) + key/2 and
-      // take its low / high 16 bits.  The even lane hashes the even register rows, the odd lane
-      // the odd rows, and a quad-permute DPP move hands each lane its partner's hash.
-      uint32_t hv[16];
+      // Uniform conditions select whole loops (a branch per score would sit inside the unrolled body).
+      if (a.causal || ragged) {   // rare: diagonal tiles of the decoder / the last, partly filled tile
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int qq = qb + 32 * blk + ACC_ROW(r) + 4 * h;
+          const bool msk = (a.causal && key > qq) || qq >= a.Tq;
+          s[r] = msk ? -INFINITY : s[r];
+        }
+      }
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {   // p = exp2(s*scale - lse[q]); masked keys: outputs zeroed at the end
+        const f32x4 Lq = *(const f32x4*)(Ls + 32 * blk + 8 * g4 + 4 * h) * 1.4426950408889634f;   // log2 units; +inf stays
+#pragma unroll
+        for (int j = 0; j < 4; ++j) pd[4 * g4 + j] = fast_exp2(fmaf(s[4 * g4 + j], a.scale_log2, -Lq[j]));
+      }
       if (a.dd.thresh16) {
+        // Dropout keep bits.  Element (q, key) has index i = (lbase+q)*Tk + key; with Tk even the two
+        // lanes of a key pair (lane, lane^1) share the hash of i>>1 = (lbase+q)*(Tk/2) + key/2 and take
+        // its low / high 16 bits.  The even lane hashes the even register rows, the odd lane the odd
+        // rows, and a quad-permute DPP move hands each lane its partner's hash.
         const uint32_t htk = (uint32_t)a.Tk >> 1;
         const uint32_t tb = (uint32_t)(lbase + qb + 32 * blk + 4 * h + (lane & 1)) * htk + ((uint32_t)key >> 1);
+        const uint32_t hshift = (lane & 1) << 4;
 #pragma unroll
         for (int r = 0; r < 16; r += 2) {
           const uint32_t own = hash_pair32(a.dd, tb + (uint32_t)ACC_ROW(r) * htk);   // row r + (lane&1)
           const uint32_t oth = (uint32_t)__builtin_amdgcn_mov_dpp((int)own, 0xB1, 0xF, 0xF, true);  // lane^1
-          hv[r] = (lane & 1) ? oth : own;
-          hv[r + 1] = (lane & 1) ? own : oth;
+          const uint32_t h0 = (lane & 1) ? oth : own, h1 = (lane & 1) ? own : oth;
+          const float k0 = ((h0 >> hshift) & 0xFFFFu) >= a.dd.thresh16 ? a.dd.scale16 : 0.f;
+          const float k1 = ((h1 >> hshift) & 0xFFFFu) >= a.dd.thresh16 ? a.dd.scale16 : 0.f;
+          dp[r] *= k0; dp[r + 1] *= k1;
+          s[r] = pd[r]; s[r + 1] = pd[r + 1];            // undropped p for dS
+          pd[r] *= k0; pd[r + 1] *= k1;                  // dropped p for dV
         }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] = pd[r];
       }
-      const uint32_t hshift = (lane & 1) << 4;
 #pragma unroll
-      for (int g4 = 0; g4 < 4; ++g4) {
-        const int qo = 32 * blk + 8 * g4 + 4 * h;
-        const f32x4 Lq = *(const f32x4*)(Ls + qo) * 1.4426950408889634f;   // log2 units; +inf stays +inf
-        const f32x4 Dq = *(const f32x4*)(Ds + qo);
+      for (int g4 = 0; g4 < 4; ++g4) {   // dS = p (D dP - delta[q])
+        const f32x4 Dq = *(const f32x4*)(Ds + 32 * blk + 8 * g4 + 4 * h);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int r = 4 * g4 + j;
-          const int qq = qb + qo + j;
-          float sv = s[r];
-          if (a.causal) sv = key > qq ? -INFINITY : sv;
-          if (ragged) sv = qq >= a.Tq ? -INFINITY : sv;
-          float p = fast_exp2(fmaf(sv, a.scale_log2, -Lq[j]));   // masked keys: outputs zeroed at the end
-          float dpv = dp[r];
-          if (a.dd.thresh16) {
-            const bool keep = ((hv[r] >> hshift) & 0xFFFFu) >= a.dd.thresh16;
-            pd[r] = keep ? p * a.dd.scale16 : 0.f;
-            dpv = keep ? dpv * a.dd.scale16 : 0.f;
-          } else {
-            pd[r] = p;
-          }
-          s[r] = p * (dpv - Dq[j]);
-        }
+        for (int j = 0; j < 4; ++j) s[4 * g4 + j] *= dp[4 * g4 + j] - Dq[j];
       }
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
