@@ -240,3 +240,39 @@ def test_lightning_shaped_checkpoint_roundtrip(tmp_path):
         w2.hf_model.engine.micro_step = w.hf_model.engine.micro_step
         a, c = loop.micro_batch(_dev_batch(t, i)), loop2.micro_batch(_dev_batch(t, i))
         torch.testing.assert_close(a, c, rtol=1e-5, atol=1e-5)
+
+
+def test_c2_shape_parity_vs_oracle():
+    """Workload c2's real shapes (6L d512 h8 f2048, S=1024, T=128; B=2 so the CPU oracle finishes in
+    seconds): fp32 mode within 1e-3 relative on logits with bit-exact argmax ids (the north-star bar);
+    bf16 mode (MFMA GEMMs + MFMA flash attention, the benchmarked path) within bf16 operand tolerance."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from multimodalanalytical_amd import ops, synth
+    from multimodalanalytical_amd.engine import Seq2SeqEngine
+    wl = synth.WORKLOADS["c2"]
+    batch, _ = synth.make_batch("c2", 2, seed=11)
+    enc, am, dec, dm, labels = O.batch_to_model_inputs(batch, "Smiles")
+    cfg = dict(wl["cfg"], dropout=0.0)
+    ref = None
+    for dtype in (torch.float32, torch.bfloat16):
+        eng = Seq2SeqEngine(cfg, wl["data"], "Smiles", 128, device=DEV, compute_dtype=dtype, seed=5)
+        if ref is None:
+            sd = {k: v.float().cpu() for k, v in eng.state_dict().items()}
+            torch.set_num_threads(min(32, torch.get_num_threads()))
+            with torch.no_grad():
+                ref = O.model_forward(sd, cfg, wl["data"], "Smiles", enc, am, dec, dm, labels)
+        to = lambda x: {k: to(v) for k, v in x.items()} if isinstance(x, dict) else x.to(DEV)
+        out = eng.forward(to(enc), am.to(DEV), dec.to(DEV), dm.to(DEV), labels.to(DEV))
+        err = rel_err(out["logits"].cpu(), ref["logits"])
+        if dtype == torch.float32:
+            assert err < 1e-3, err
+            assert torch.equal(out["argmax"].cpu(), ref["logits"].argmax(-1))
+            torch.testing.assert_close(out["loss"].cpu(), ref["loss"], rtol=1e-4, atol=1e-4)
+        else:
+            assert ops.last_algo() in ("mfma_nt", "generic")          # the LM head / MFMA path ran
+            assert err < 5e-2, err
+            agree = (out["argmax"].cpu() == ref["logits"].argmax(-1)).float().mean()
+            assert float(agree) > 0.97
+            torch.testing.assert_close(out["loss"].cpu(), ref["loss"], rtol=2e-2, atol=2e-2)
+        print(f"c2-shape parity {dtype}: logits rel err {err:.2e}")
