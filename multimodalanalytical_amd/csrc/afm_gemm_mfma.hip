@@ -696,29 +696,61 @@ __global__ __launch_bounds__(512, 2) void k_gemm_tn_ring(MfmaArgs g) {
 #pragma unroll
   for (int s = 0; s < S - 1; ++s)
     if (s < nk) issue(s);
+  // Transposed-fragment addresses, hoisted: a read is  stage + lane_off[i] + (ks*32 + 4*half) * pitch.
+  // The swizzle of row r = ks*32 + grp*8 + q (+4) is tn_swz(r) = 2q | 8(grp&1): lane-constant, so only
+  // the fragment index i needs its own per-lane offset (8 VGPRs) and the loop issues reads with
+  // immediate offsets instead of recomputing the XOR address (2 VALU ops per read before).
   const int grp = lane >> 4, q = (lane >> 2) & 3, p = lane & 3;
+  int laneA[4], laneB[4];
+  {
+    const int lrow = grp * 8 + q, swz = tn_swz(lrow), sub = (p & 1) << 3;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int cha = ((wm * 64 + i * 16) >> 3) + (p >> 1), chb = ((wn * 64 + i * 16) >> 3) + (p >> 1);
+      laneA[i] = lrow * 512 + ((cha ^ swz) << 4) + sub;
+      laneB[i] = ABYTES + lrow * 256 + ((chb ^ swz) << 4) + sub;
+    }
+  }
   for (int kt = 0; kt < nk; ++kt) {
     const int later = min(S - 2, nk - 1 - kt);
     if (later >= S - 2) wait_vmcnt<NIW * (S - 2)>(); else wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
     if (kt + S - 1 < nk) issue(kt + S - 1);
     const unsigned char* a = lds + (kt % S) * STAGE;
-    const unsigned char* b = a + ABYTES;
     if (ABL == 1) continue;
+    // fragment reads in inline asm: the ds_read_tr builtin makes hipcc drain the whole LDS-DMA ring
+    // (s_waitcnt vmcnt(0)) in front of every k-step; asm reads carry immediate offsets and are waited
+    // for by hand (lgkmcnt(0) + sched_barrier, cdna_hip_programming.md 5.7 form iii)
+    unsigned va[4], vb[4];
+    const unsigned sbase = (unsigned)(uintptr_t)a;
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
+    for (int i = 0; i < 4; ++i) { va[i] = sbase + (unsigned)laneA[i]; vb[i] = sbase + (unsigned)laneB[i]; }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {  // two 32-deep k-slices
+      s16x4 a0[4], a1[4], b0[4], b1[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        if (ks == 0) {
+          asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(a0[i]) : "v"(va[i]));
+          asm volatile("ds_read_b64_tr_b16 %0, %1 offset:2048" : "=v"(a1[i]) : "v"(va[i]));
+          asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(b0[i]) : "v"(vb[i]));
+          asm volatile("ds_read_b64_tr_b16 %0, %1 offset:1024" : "=v"(b1[i]) : "v"(vb[i]));
+        } else {
+          asm volatile("ds_read_b64_tr_b16 %0, %1 offset:16384" : "=v"(a0[i]) : "v"(va[i]));
+          asm volatile("ds_read_b64_tr_b16 %0, %1 offset:18432" : "=v"(a1[i]) : "v"(va[i]));
+          asm volatile("ds_read_b64_tr_b16 %0, %1 offset:8192" : "=v"(b0[i]) : "v"(vb[i]));
+          asm volatile("ds_read_b64_tr_b16 %0, %1 offset:9216" : "=v"(b1[i]) : "v"(vb[i]));
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
       bf16x8 af[4], bfr[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const int ca = wm * 64 + i * 16, cb = wn * 64 + i * 16;
-        const int r0 = ks * 32 + grp * 8 + q, r1 = r0 + 4;
-        const int cha = (ca >> 3) + (p >> 1), chb = (cb >> 3) + (p >> 1);
-        const bf16x4 a0 = ds_read_tr(a + offA(r0, cha) + ((p & 1) << 3));
-        const bf16x4 a1 = ds_read_tr(a + offA(r1, cha) + ((p & 1) << 3));
-        const bf16x4 b0 = ds_read_tr(b + offB(r0, chb) + ((p & 1) << 3));
-        const bf16x4 b1 = ds_read_tr(b + offB(r1, chb) + ((p & 1) << 3));
-        af[i] = (bf16x8){a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
-        bfr[i] = (bf16x8){b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+        const bf16x4 x0 = __builtin_bit_cast(bf16x4, a0[i]), x1 = __builtin_bit_cast(bf16x4, a1[i]);
+        const bf16x4 y0 = __builtin_bit_cast(bf16x4, b0[i]), y1 = __builtin_bit_cast(bf16x4, b1[i]);
+        af[i] = (bf16x8){x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
+        bfr[i] = (bf16x8){y0[0], y0[1], y0[2], y0[3], y1[0], y1[1], y1[2], y1[3]};
       }
       if (do_cs) {   // bias gradient: column sums of dy from the A fragments (lane: column fr, 8 rows)
 #pragma unroll
