@@ -36,10 +36,6 @@ typedef __attribute__((ext_vector_type(4))) short s16x4;
 __device__ __forceinline__ f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
-__device__ __forceinline__ bf16x4 lds_tr(const unsigned char* p) {
-  const s16x4 r = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p);
-  return __builtin_bit_cast(bf16x4, r);
-}
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
 // LDS images of a [64 rows][64 cols] bf16 tile (128-byte rows, 8 chunks of 16 bytes):
@@ -53,14 +49,42 @@ __device__ __forceinline__ int img_tr(int row, int chunk) { return row * 128 + (
 
 // A-operand fragment "X^T slice": element j of lane-half h <-> tile row R0 + 4h + (j&3) + 8*(j>>2),
 // column C0 + (lane&31); two transposed reads.  R0 = first row of the 16-row k-slice.
-__device__ __forceinline__ bf16x8 frag_tr(const unsigned char* img, int R0, int C0, int lane) {
+//
+// The reads are inline asm, not the ds_read_tr builtin: behind the builtin hipcc puts
+// `s_waitcnt vmcnt(0)` in front of the first transposed read of every tile, which drains the LDS-DMA
+// ring (the prefetch of the next tile) in the middle of the tile.  The asm reads are invisible to the
+// compiler's counters, so the consumer waits by hand: tr_wait<N>() = s_waitcnt lgkmcnt(N) + scheduling
+// fence (cdna_hip_programming.md 5.7 form iii).  LDS returns in order, so lgkmcnt(N) with N younger
+// reads outstanding is enough for the older ones (a compiler-issued LGKM op in between only makes the
+// wait stricter).  One quad = the two 32-column halves (db = 0, 1) of a 16-row slice.
+struct TrQuad { s16x4 lo0, hi0, lo1, hi1; };
+#define AFM_TR_RD(dst, addr, OFF) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:" #OFF : "=v"(dst) : "v"(addr))
+// per-lane byte addresses (db = 0 / 1) of slice R0 = 0 inside a tr image; slice R0 adds R0*128 (immediate)
+__device__ __forceinline__ void tr_lane_addr(const unsigned char* img, int lane, unsigned& a0, unsigned& a1) {
   const int g = lane >> 4, qq = (lane >> 2) & 3, p = lane & 3;
-  const int row = R0 + 4 * (g >> 1) + qq;
-  const int col = C0 + 16 * (g & 1) + 4 * p;
-  const int chunk = col >> 3, sub = (col & 7) * 2;
-  const bf16x4 lo = lds_tr(img + img_tr(row, chunk) + sub);
-  const bf16x4 hi = lds_tr(img + img_tr(row + 8, chunk) + sub);
-  return (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  const int row = 4 * (g >> 1) + qq, bsw = (qq >> 1) & 1;        // ((R0 + row) >> 1) & 1 for R0 % 16 == 0
+  const int c = 2 * (g & 1) + (p >> 1), sub = (p & 1) << 3;
+  const unsigned base = (unsigned)(uintptr_t)img + row * 128 + sub;
+  a0 = base + ((4 * bsw + c) << 4);
+  a1 = base + ((4 * (1 ^ bsw) + c) << 4);
+}
+__device__ __forceinline__ TrQuad tr_issue(unsigned a0, unsigned a1, int R0) {
+  TrQuad q;
+  switch (R0) {   // R0 is a constant after unrolling; the offsets must be literals for the asm
+    case 0:  AFM_TR_RD(q.lo0, a0, 0);    AFM_TR_RD(q.hi0, a0, 1024); AFM_TR_RD(q.lo1, a1, 0);    AFM_TR_RD(q.hi1, a1, 1024); break;
+    case 16: AFM_TR_RD(q.lo0, a0, 2048); AFM_TR_RD(q.hi0, a0, 3072); AFM_TR_RD(q.lo1, a1, 2048); AFM_TR_RD(q.hi1, a1, 3072); break;
+    case 32: AFM_TR_RD(q.lo0, a0, 4096); AFM_TR_RD(q.hi0, a0, 5120); AFM_TR_RD(q.lo1, a1, 4096); AFM_TR_RD(q.hi1, a1, 5120); break;
+    default: AFM_TR_RD(q.lo0, a0, 6144); AFM_TR_RD(q.hi0, a0, 7168); AFM_TR_RD(q.lo1, a1, 6144); AFM_TR_RD(q.hi1, a1, 7168); break;
+  }
+  return q;
+}
+template <int N> __device__ __forceinline__ void tr_wait() {
+  asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
+  __builtin_amdgcn_sched_barrier(0);
+}
+__device__ __forceinline__ bf16x8 tr_join(s16x4 lo, s16x4 hi) {
+  const bf16x4 l = __builtin_bit_cast(bf16x4, lo), h = __builtin_bit_cast(bf16x4, hi);
+  return (bf16x8){l[0], l[1], l[2], l[3], h[0], h[1], h[2], h[3]};
 }
 // A-operand fragment by rows: lane holds tile[R0 + (lane&31)][16*s + 8*(lane>>5) .. +7]
 __device__ __forceinline__ bf16x8 frag_row(const unsigned char* img, int R0, int s, int lane) {
@@ -240,15 +264,19 @@ __global__ __launch_bounds__(256, 2) void k_attn_fwd_mfma(AttnM a, const bf16* _
       drop_block(a.dd, rowbase, kb, h, s[0]);
       drop_block(a.dd, rowbase, kb + 32, h, s[1]);
     }
+    // O^T += V^T P^T over the four 16-key slices, the V^T reads one slice ahead of the MFMAs
+    unsigned va0, va1;
+    tr_lane_addr(Vimg, lane, va0, va1);
+    TrQuad vq[2];
+    vq[0] = tr_issue(va0, va1, 0);
 #pragma unroll
-    for (int blk = 0; blk < 2; ++blk)
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        const bf16x8 pf = cvt8(s[blk], ks);
-#pragma unroll
-        for (int db = 0; db < 2; ++db)
-          o[db] = mfma32(frag_tr(Vimg, 32 * blk + 16 * ks, 32 * db, lane), pf, o[db]);
-      }
+    for (int i = 0; i < 4; ++i) {   // slice i = 2 blk + ks
+      if (i < 3) vq[(i + 1) & 1] = tr_issue(va0, va1, 16 * (i + 1));
+      const bf16x8 pf = cvt8(s[i >> 1], i & 1);
+      if (i < 3) tr_wait<4>(); else tr_wait<0>();
+      o[0] = mfma32(tr_join(vq[i & 1].lo0, vq[i & 1].hi0), pf, o[0]);
+      o[1] = mfma32(tr_join(vq[i & 1].lo1, vq[i & 1].hi1), pf, o[1]);
+    }
   }
   l += __shfl_xor(l, 32, 64);
   const float inv = l > 0.f ? a.dd.scale16 / l : 0.f;
@@ -341,6 +369,8 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd_dq_mfma(AttnM a, const bf16
     const unsigned char* Vrow = Krow + 2 * KT * DH * 2;
     const unsigned long long mword = maskw[kt];
     const unsigned long long pad = mword >> (4 * h);
+    unsigned ka0, ka1;
+    tr_lane_addr(Ktr, lane, ka0, ka1);
 #pragma unroll
     for (int blk = 0; blk < 2; ++blk) {
       f32x16 s, dp;
@@ -370,12 +400,15 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd_dq_mfma(AttnM a, const bf16
         const float p = fast_exp2(fmaf(s[r], a.scale_log2, -L2));   // masked: exp2(-inf) = 0
         s[r] = p * (dp[r] - dl);   // dS^T (the 1/sqrt(dh) factor is applied once at the end)
       }
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        const bf16x8 dsf = cvt8(s, ks);
-#pragma unroll
-        for (int db = 0; db < 2; ++db)
-          dq[db] = mfma32(frag_tr(Ktr, 32 * blk + 16 * ks, 32 * db, lane), dsf, dq[db]);
+      {
+        const TrQuad k0q = tr_issue(ka0, ka1, 32 * blk), k1q = tr_issue(ka0, ka1, 32 * blk + 16);
+        const bf16x8 ds0 = cvt8(s, 0), ds1 = cvt8(s, 1);
+        tr_wait<4>();
+        dq[0] = mfma32(tr_join(k0q.lo0, k0q.hi0), ds0, dq[0]);
+        dq[1] = mfma32(tr_join(k0q.lo1, k0q.hi1), ds0, dq[1]);
+        tr_wait<0>();
+        dq[0] = mfma32(tr_join(k1q.lo0, k1q.hi0), ds1, dq[0]);
+        dq[1] = mfma32(tr_join(k1q.lo1, k1q.hi1), ds1, dq[1]);
       }
     }
   }
@@ -466,6 +499,9 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd_dkv_mfma(AttnM a, const bf1
     const bool ragged = qb + KT > a.Tq;   // wave-uniform: tile holds rows past Tq (clamped duplicates)
     if (a.causal && qb + KT - 1 < k0) continue;   // wave-uniform: every query of the tile precedes this wave's keys
     if (wave_all_masked) continue;                // this wave's 32 keys are all padding: dK = dV = 0
+    unsigned qa0, qa1, da0, da1;
+    tr_lane_addr(Qtr, lane, qa0, qa1);
+    tr_lane_addr(Dtr, lane, da0, da1);
 #pragma unroll
     for (int blk = 0; blk < 2; ++blk) {
       f32x16 s, dp;
@@ -521,14 +557,20 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd_dkv_mfma(AttnM a, const bf1
 #pragma unroll
         for (int j = 0; j < 4; ++j) s[4 * g4 + j] *= dp[4 * g4 + j] - Dq[j];
       }
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        const bf16x8 pf = cvt8(pd, ks), dsf = cvt8(s, ks);
-#pragma unroll
-        for (int db = 0; db < 2; ++db) {
-          dv[db] = mfma32(frag_tr(Dtr, 32 * blk + 16 * ks, 32 * db, lane), pf, dv[db]);
-          dk[db] = mfma32(frag_tr(Qtr, 32 * blk + 16 * ks, 32 * db, lane), dsf, dk[db]);
-        }
+      {
+        const TrQuad d0 = tr_issue(da0, da1, 32 * blk), q0f = tr_issue(qa0, qa1, 32 * blk);
+        const TrQuad d1 = tr_issue(da0, da1, 32 * blk + 16), q1f = tr_issue(qa0, qa1, 32 * blk + 16);
+        const bf16x8 pf0 = cvt8(pd, 0), dsf0 = cvt8(s, 0), pf1 = cvt8(pd, 1), dsf1 = cvt8(s, 1);
+        tr_wait<8>();
+        dv[0] = mfma32(tr_join(d0.lo0, d0.hi0), pf0, dv[0]);
+        dv[1] = mfma32(tr_join(d0.lo1, d0.hi1), pf0, dv[1]);
+        dk[0] = mfma32(tr_join(q0f.lo0, q0f.hi0), dsf0, dk[0]);
+        dk[1] = mfma32(tr_join(q0f.lo1, q0f.hi1), dsf0, dk[1]);
+        tr_wait<0>();
+        dv[0] = mfma32(tr_join(d1.lo0, d1.hi0), pf1, dv[0]);
+        dv[1] = mfma32(tr_join(d1.lo1, d1.hi1), pf1, dv[1]);
+        dk[0] = mfma32(tr_join(q1f.lo0, q1f.hi0), dsf1, dk[0]);
+        dk[1] = mfma32(tr_join(q1f.lo1, q1f.hi1), dsf1, dk[1]);
       }
     }
   }
