@@ -29,6 +29,7 @@ struct MfmaArgs {
   int tiles_m, tiles_n;
   int ksplit, kchunk;  // TN only
   int bias_in_lds;     // persistent NT: staged epilogue enabled (bias vector cached in LDS)
+  unsigned long long* stamps;   // ablation builds: per-workgroup phase time stamps (wall_clock64), else null
   DropDev dd;
 };
 
@@ -343,12 +344,83 @@ __device__ __forceinline__ void epilogue_staged(const MfmaArgs& g, float* stg, c
   }
 }
 
+// Compile-time epilogue kinds of the bf16 staged epilogue (the training step's four fused forms): the
+// generic one above tests act / dropout / pre_act per element group at run time, which costs scalar
+// branches between every eight elements and keeps the compiler from scheduling across them.
+//   EPI_PLAIN     C = acc + bias
+//   EPI_DROP      C = dropout(acc + bias)
+//   EPI_GELU      pre_act = acc + bias (if kept);  C = dropout(gelu(acc + bias))
+//   EPI_GELU_BWD  C = dropout(acc) * gelu'(pre_act)
+// Dropout indices are 32-bit here (the dispatcher requires M*N <= 2^32, where the stream's high-word
+// term is zero), which also removes a 64-bit multiply-add chain per element group.
+enum { EPI_GENERIC = 0, EPI_PLAIN = 1, EPI_DROP = 2, EPI_GELU = 3, EPI_GELU_BWD = 4 };
+__device__ __forceinline__ float afm_drop32(const DropDev& d, uint32_t idx, float x) {
+  return afm_lowbias32(idx ^ d.key) >= d.thresh ? x * d.scale : 0.f;
+}
+template <int WM, int EPI>
+__device__ __forceinline__ void epilogue_staged_bf16(const MfmaArgs& g, float* stg, const float* bias_lds,
+                                                     f32x4 (&acc)[4][WM], int mw, int nw, int lane) {
+  const int fr = lane & 15, fq = lane >> 4;
+  const int c8 = (lane & 7) * 8, r8 = lane >> 3;
+  const int n = nw + c8;
+  f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = {0.f, 0.f, 0.f, 0.f};
+  if (EPI != EPI_GELU_BWD && g.bias) { b0 = *(const f32x4*)(bias_lds + n); b1 = *(const f32x4*)(bias_lds + n + 4); }
+  const bool drop_on = g.dd.thresh != 0;   // wave-uniform
+  bf16* const cbase = (bf16*)g.C + (int64_t)(mw + r8) * g.ldc + n;
+  bf16* const pbase = (bf16*)g.pre_act + (int64_t)(mw + r8) * g.ldc + n;
+  const uint32_t dbase = (uint32_t)(mw + r8) * (uint32_t)g.N + (uint32_t)n;
+  bf16x8 uu[2 * WM];
+  if (EPI == EPI_GELU_BWD) {   // all pre-activation loads first: one wait, before any store
+#pragma unroll
+    for (int q = 0; q < 2 * WM; ++q) uu[q] = *(const bf16x8*)(pbase + (int64_t)(q * 8) * g.ldc);
+  }
+#pragma unroll
+  for (int i = 0; i < WM; ++i) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) *(f32x4*)(stg + fr * STG_LD + j * 16 + fq * 4) = acc[j][i];
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {
+      const int q = i * 2 + hf;                       // 8-row group of the wave's 16*WM rows
+      const int row = hf * 8 + r8;
+      const f32x4 v0 = *(const f32x4*)(stg + row * STG_LD + c8) + b0;
+      const f32x4 v1 = *(const f32x4*)(stg + row * STG_LD + c8 + 4) + b1;
+      float x[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+      const int64_t ro = (int64_t)(q * 8) * g.ldc;
+      const uint32_t di = dbase + (uint32_t)(q * 8) * (uint32_t)g.N;
+      if (EPI == EPI_GELU) {
+        if (g.pre_act) {
+          bf16x8 o = {(bf16)x[0], (bf16)x[1], (bf16)x[2], (bf16)x[3], (bf16)x[4], (bf16)x[5], (bf16)x[6], (bf16)x[7]};
+          *(bf16x8*)(pbase + ro) = o;
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) x[k] = afm_gelu(x[k]);
+      }
+      if (EPI == EPI_GELU_BWD) {
+        const bf16x8 u = uu[q];
+        if (drop_on) {
+#pragma unroll
+          for (int k = 0; k < 8; ++k) x[k] = afm_drop32(g.dd, di + k, x[k]) * afm_gelu_grad((float)u[k]);
+        } else {
+#pragma unroll
+          for (int k = 0; k < 8; ++k) x[k] *= afm_gelu_grad((float)u[k]);
+        }
+      } else if (EPI == EPI_DROP || (EPI == EPI_GELU && drop_on)) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) x[k] = afm_drop32(g.dd, di + k, x[k]);
+      }
+      bf16x8 o = {(bf16)x[0], (bf16)x[1], (bf16)x[2], (bf16)x[3], (bf16)x[4], (bf16)x[5], (bf16)x[6], (bf16)x[7]};
+      *(bf16x8*)(cbase + ro) = o;
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------ NT, persistent ring
 // One workgroup per CU walks a contiguous range of output tiles of its XCD; the LDS-DMA ring keeps
 // running ACROSS tiles (the first k-steps of the next tile are in flight while the current tile
 // finishes and its epilogue stores drain), so the per-tile prologue bubble and the workgroup
 // launch/teardown disappear from the critical path.
-// ABL (timing experiments only): 1 = skip the LDS reads + MFMAs, 2 = skip the LDS-DMA loads.
+// ABL (timing experiments only, bit mask): 1 = skip the LDS reads + MFMAs, 2 = skip the LDS-DMA loads,
+// 4 = skip the epilogue.
 template <bool C_BF16, int NWM, int NWN, int S, int ABL = 0, int WM = 4>
 __global__ __launch_bounds__(64 * NWM * NWN) void k_gemm_nt_pring(MfmaArgs g) {
   constexpr int NW = NWM * NWN;
@@ -392,7 +464,7 @@ __global__ __launch_bounds__(64 * NWM * NWN) void k_gemm_nt_pring(MfmaArgs g) {
   auto issue_one = [&]() {
     if (is_tile < 0) return;
     unsigned char* st = lds + is_slot * STAGE;
-    if (ABL != 2) {
+    if (!(ABL & 2)) {
 #pragma unroll
       for (int j = 0; j < NIW; ++j)
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[j] + is_kt * 64),
@@ -418,6 +490,9 @@ __global__ __launch_bounds__(64 * NWM * NWN) void k_gemm_nt_pring(MfmaArgs g) {
     const int tile = tile_of(it);
     if (tile < 0) break;
     const int m0 = (tile / g.tiles_n) * TBM, n0 = (tile % g.tiles_n) * TBN;
+#ifdef AFM_GEMM_ABLATIONS
+    if (g.stamps && t == 0 && it < 16) g.stamps[(blockIdx.x * 16 + it) * 4 + 0] = wall_clock64();
+#endif
     f32x4 acc[4][WM];
 #pragma unroll
     for (int j = 0; j < 4; ++j)
@@ -429,18 +504,32 @@ __global__ __launch_bounds__(64 * NWM * NWN) void k_gemm_nt_pring(MfmaArgs g) {
       // first S-1 steps: after a full-tile epilogue (exactly 8 / 16 stores per wave for bf16 / fp32
       // output, plus loads) those younger operations may stay outstanding too, so the stores drain under the next tile's
       // MFMAs; after an edge-tile epilogue (store count unknown) drain everything.
+#ifdef AFM_GEMM_ABLATIONS
+      const bool stampk = g.stamps && lane == 0 && it == 5 && blockIdx.x < 64;
+      unsigned long long* sk = g.stamps + 512 * 64 + ((blockIdx.x * 12 + w) * 8 + kt) * 5;
+      if (stampk) sk[0] = clock64();
+#endif
       if (it > 0 && kt < S - 1 && !prev_full) wait_vmcnt<0>();
       else if (it > 0 && kt < S - 1 && ahead - 1 >= S - 2) wait_vmcnt<NIW * (S - 2) + (C_BF16 ? 2 * WM : 4 * WM)>();
       else if (ahead - 1 >= S - 2) wait_vmcnt<NIW * (S - 2)>();
       else if (S > 3 && ahead - 1 == S - 3) wait_vmcnt<NIW * (S > 3 ? S - 3 : 0)>();
       else wait_vmcnt<0>();
+#ifdef AFM_GEMM_ABLATIONS
+      if (stampk) sk[1] = clock64();
+#endif
       __builtin_amdgcn_s_barrier();
+#ifdef AFM_GEMM_ABLATIONS
+      if (stampk) sk[2] = clock64();
+#endif
       --ahead;
       issue_one();
+#ifdef AFM_GEMM_ABLATIONS
+      if (stampk) sk[3] = clock64();
+#endif
       const unsigned char* a = lds + slot * STAGE;
       const unsigned char* b = a + TBM * 128;
       slot = slot + 1 == S ? 0 : slot + 1;
-      if (ABL == 1) continue;
+      if (ABL & 1) continue;
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
         bf16x8 af[WM], bfr[4];
@@ -454,9 +543,18 @@ __global__ __launch_bounds__(64 * NWM * NWN) void k_gemm_nt_pring(MfmaArgs g) {
           for (int i = 0; i < WM; ++i)
             acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[j][i], 0, 0, 0);
       }
+#ifdef AFM_GEMM_ABLATIONS
+      if (stampk) sk[4] = clock64();
+#endif
     }
+#ifdef AFM_GEMM_ABLATIONS
+    if (g.stamps && t == 0 && it < 16) g.stamps[(blockIdx.x * 16 + it) * 4 + 1] = wall_clock64();
+#endif
     prev_full = g.bias_in_lds && m0 + TBM <= g.M && n0 + TBN <= g.N;
-    if (prev_full) {
+    if (ABL & 4) {
+      if (acc[0][0][0] == 123.456f) ((float*)g.C)[0] = 1.f;   // keep the accumulators alive
+      prev_full = false;
+    } else if (prev_full) {
       // the slot read by the last k-step is free until the next issue: stage through it
       __builtin_amdgcn_s_barrier();
       float* stg = (float*)(lds + (slot == 0 ? S - 1 : slot - 1) * STAGE) + w * (16 * STG_LD);
@@ -468,6 +566,9 @@ __global__ __launch_bounds__(64 * NWM * NWN) void k_gemm_nt_pring(MfmaArgs g) {
         for (int i = 0; i < WM; ++i)
           epilogue4<C_BF16>(g, m0 + wm * 16 * WM + i * 16 + fr, n0 + wn * 64 + j * 16 + fq * 4, acc[j][i], vec_ok);
     }
+#ifdef AFM_GEMM_ABLATIONS
+    if (g.stamps && t == 0 && it < 16) g.stamps[(blockIdx.x * 16 + it) * 4 + 2] = wall_clock64();
+#endif
   }
 }
 
@@ -493,6 +594,216 @@ static int launch_nt_pring(MfmaArgs& g, hipStream_t st, int blocks_per_cu) {
   const int ntiles = g.tiles_m * g.tiles_n;
   if (grid > ((ntiles + 7) / 8) * 8) grid = ((ntiles + 7) / 8) * 8;
   AFM_LAUNCH(kern, dim3(grid), dim3(64 * NWM * NWN), shm, st, g);
+  return AFM_OK;
+}
+
+// ------------------------------------------------------------------------------------------ NT, loader waves
+// Same tile walk and LDS ring as k_gemm_nt_pring, but the LDS-DMA pieces are issued by NL extra
+// "loader" waves.  Measured on the all-waves-issue kernel (in-kernel stamps, tools/stamp_gemm.py): a
+// global_load_lds wave-instruction holds its wave for ~20 ns (the CU takes in ~50 GB/s, one 1-KiB
+// piece at a time), so the 48 pieces of a k-step cost every compute wave 0.5-1 us of issue time in
+// front of 0.95 us of LDS reads + MFMAs, and the per-step barrier makes all of them wait for the
+// last issuer: fill and compute ran strictly one after the other (2.5 us per k-step).  Loader waves
+// take the issue time (and the counted vmcnt waits) off the MFMA waves; the workgroup barrier of each
+// k-step publishes a landed slot and frees the one read a step earlier.  The compute waves issue no
+// LDS-DMA at all, so their epilogue stores need no counted waits.
+template <bool C_BF16, int NL, int ABL = 0, int EPI = EPI_GENERIC>
+__global__ __launch_bounds__(64 * (8 + NL)) void k_gemm_nt_ws(MfmaArgs g) {
+  constexpr int NWN = 2, NW = 8, WM = 4, S = 3;
+  constexpr int TBM = 256, TBN = 128;
+  constexpr int NI = (TBM + TBN) / 8, NIL = NI / NL;   // 1-KiB pieces per k-step, per loader wave
+  static_assert(NI % NL == 0, "pieces must divide over the loader waves");
+  constexpr int STAGE = (TBM + TBN) * 128;
+  static_assert(NW * 16 * STG_LD * 4 <= STAGE, "wave-private staging patches must fit one ring slot");
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  float* bias_lds = (float*)(lds + S * STAGE);
+  const int t = threadIdx.x, lane = t & 63;
+  const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int ntiles = g.tiles_m * g.tiles_n;
+  if (g.bias_in_lds) {   // plain loads, retired (barrier) before the first LDS-DMA piece is issued
+    for (int n = t; n < g.N; n += 64 * (NW + NL)) bias_lds[n] = g.bias ? g.bias[n] : 0.f;
+    __syncthreads();
+  }
+  const int xcd = blockIdx.x & 7, bx = blockIdx.x >> 3, nbx = gridDim.x >> 3;
+  const int tpx = (ntiles + 7) >> 3;
+  const int tlo = xcd * tpx, thi = min(ntiles, tlo + tpx);
+  auto tile_of = [&](int it) { const int tt = tlo + it * nbx + bx; return tt < thi ? tt : -1; };
+  auto tile_full = [&](int tile) {
+    const int m0 = (tile / g.tiles_n) * TBM, n0 = (tile % g.tiles_n) * TBN;
+    return g.bias_in_lds && m0 + TBM <= g.M && n0 + TBN <= g.N;
+  };
+  const int nk = g.K / 64;
+
+  if (w >= NW) {
+    // ---------------------------------------------------------------- loader wave
+    const int lw = w - NW;
+    const bf16* src[NIL];
+    auto set_src = [&](int tile) {
+      const int m0 = (tile / g.tiles_n) * TBM, n0 = (tile % g.tiles_n) * TBN;
+#pragma unroll
+      for (int j = 0; j < NIL; ++j) {
+        const int ii = lw + NL * j;
+        const int r8 = lane >> 3, ch = (lane & 7) ^ r8;
+        if (ii < TBM / 8) src[j] = g.A + (int64_t)min(m0 + ii * 8 + r8, g.M - 1) * g.lda + ch * 8;
+        else src[j] = g.B + (int64_t)min(n0 + (ii - TBM / 8) * 8 + r8, g.N - 1) * g.ldb + ch * 8;
+      }
+    };
+    int is_it = 0, is_kt = 0, is_slot = 0;
+    int is_tile = tile_of(0);
+    if (is_tile >= 0) set_src(is_tile);
+    int ahead = 0;   // steps issued and not yet published
+    auto issue_one = [&]() {
+      if (is_tile < 0) return;
+      unsigned char* st = lds + is_slot * STAGE;
+      if (!(ABL & 2)) {
+#pragma unroll
+        for (int j = 0; j < NIL; ++j)
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[j] + is_kt * 64),
+                                           (__attribute__((address_space(3))) void*)(st + (lw + NL * j) * 1024), 16, 0, 0);
+      }
+      ++ahead;
+      is_slot = is_slot + 1 == S ? 0 : is_slot + 1;
+      if (++is_kt == nk) {
+        is_kt = 0;
+        is_tile = tile_of(++is_it);
+        if (is_tile >= 0) set_src(is_tile);
+      }
+    };
+#pragma unroll
+    for (int s = 0; s < S - 1; ++s) issue_one();
+    for (int it = 0;; ++it) {
+      const int tile = tile_of(it);
+      if (tile < 0) break;
+      for (int kt = 0; kt < nk; ++kt) {
+        // publish this step: its pieces must have landed; the step issued after it may stay in flight
+#ifdef AFM_GEMM_ABLATIONS
+        const bool stampk = g.stamps && lane == 0 && it == 5 && blockIdx.x < 64 && w < 12;
+        unsigned long long* sk = g.stamps + 512 * 64 + ((blockIdx.x * 12 + w) * 8 + kt) * 5;
+        if (stampk) sk[0] = clock64();
+#endif
+        if (ahead - 1 >= S - 2) wait_vmcnt<NIL*(S - 2)>(); else wait_vmcnt<0>();
+#ifdef AFM_GEMM_ABLATIONS
+        if (stampk) sk[1] = clock64();
+#endif
+        __builtin_amdgcn_s_barrier();
+#ifdef AFM_GEMM_ABLATIONS
+        if (stampk) sk[2] = clock64();
+#endif
+        --ahead;
+        issue_one();   // into the slot every compute wave finished reading before this barrier
+#ifdef AFM_GEMM_ABLATIONS
+        if (stampk) { sk[3] = clock64(); sk[4] = sk[3]; }
+#endif
+      }
+      if (tile_full(tile)) __builtin_amdgcn_s_barrier();   // the compute waves' pre-epilogue barrier
+    }
+    return;
+  }
+
+  // ------------------------------------------------------------------ compute wave
+  const int wm = w / NWN, wn = w % NWN;
+  auto off = [](int row, int chunk) { return row * 128 + ((chunk ^ (row & 7)) << 4); };
+  const int fr = lane & 15, fq = lane >> 4;
+  const bool vec_ok = (g.ldc & 3) == 0 && (g.N & 3) == 0;
+  int slot = 0;
+  for (int it = 0;; ++it) {
+    const int tile = tile_of(it);
+    if (tile < 0) break;
+    const int m0 = (tile / g.tiles_n) * TBM, n0 = (tile % g.tiles_n) * TBN;
+    f32x4 acc[4][WM];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int i = 0; i < WM; ++i) acc[j][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#ifdef AFM_GEMM_ABLATIONS
+    if (g.stamps && t == 0 && it < 16) g.stamps[(blockIdx.x * 16 + it) * 4 + 0] = wall_clock64();
+#endif
+    for (int kt = 0; kt < nk; ++kt) {
+#ifdef AFM_GEMM_ABLATIONS
+      const bool stampk = g.stamps && lane == 0 && it == 5 && blockIdx.x < 64;
+      unsigned long long* sk = g.stamps + 512 * 64 + ((blockIdx.x * 12 + w) * 8 + kt) * 5;
+      if (stampk) { sk[0] = clock64(); sk[1] = sk[0]; }
+#endif
+      __builtin_amdgcn_s_barrier();
+#ifdef AFM_GEMM_ABLATIONS
+      if (stampk) { sk[2] = clock64(); sk[3] = sk[2]; }
+#endif
+      const unsigned char* a = lds + slot * STAGE;
+      const unsigned char* b = a + TBM * 128;
+      slot = slot + 1 == S ? 0 : slot + 1;
+      if (ABL & 1) continue;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        bf16x8 af[WM], bfr[4];
+#pragma unroll
+        for (int i = 0; i < WM; ++i) af[i] = *(const bf16x8*)(a + off(wm * 16 * WM + i * 16 + fr, ks * 4 + fq));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bfr[j] = *(const bf16x8*)(b + off(wn * 64 + j * 16 + fr, ks * 4 + fq));
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int i = 0; i < WM; ++i)
+            acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[j][i], 0, 0, 0);
+      }
+#ifdef AFM_GEMM_ABLATIONS
+      if (stampk) sk[4] = clock64();
+#endif
+    }
+#ifdef AFM_GEMM_ABLATIONS
+    if (g.stamps && t == 0 && it < 16) g.stamps[(blockIdx.x * 16 + it) * 4 + 1] = wall_clock64();
+#endif
+    if (ABL & 4) {   // timing only: keep every accumulator alive, store nothing
+      float sacc = 0.f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < WM; ++i) sacc += acc[j][i][0] + acc[j][i][1] + acc[j][i][2] + acc[j][i][3];
+      if (sacc == 123.456f) ((float*)g.C)[0] = sacc;
+      if (tile_full(tile)) __builtin_amdgcn_s_barrier();
+    } else if (tile_full(tile)) {
+      // the slot read by the last k-step stays free until the next step's barrier: stage through it
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      float* stg = (float*)(lds + (slot == 0 ? S - 1 : slot - 1) * STAGE) + w * (16 * STG_LD);
+      if constexpr (C_BF16 && EPI != EPI_GENERIC) epilogue_staged_bf16<WM, EPI>(g, stg, bias_lds, acc, m0 + wm * 16 * WM, n0 + wn * 64, lane);
+      else epilogue_staged<C_BF16, WM>(g, stg, bias_lds, acc, m0 + wm * 16 * WM, n0 + wn * 64, lane);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // staging reads done before the slot is handed back
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+          epilogue4<C_BF16>(g, m0 + wm * 16 * WM + i * 16 + fr, n0 + wn * 64 + j * 16 + fq * 4, acc[j][i], vec_ok);
+    }
+#ifdef AFM_GEMM_ABLATIONS
+    if (g.stamps && t == 0 && it < 16) g.stamps[(blockIdx.x * 16 + it) * 4 + 2] = wall_clock64();
+#endif
+  }
+}
+
+template <bool C_BF16, int NL, int ABL = 0, int EPI = EPI_GENERIC>
+static int launch_nt_ws(MfmaArgs& g, hipStream_t st) {
+  constexpr int TBM = 256, TBN = 128, S = 3;
+  constexpr int ring = S * (TBM + TBN) * 128;
+  g.tiles_m = (g.M + TBM - 1) / TBM; g.tiles_n = (g.N + TBN - 1) / TBN;
+  const int bias_bytes = ((g.N * 4 + 15) / 16) * 16;
+  const bool rows16 = (g.N % 8) == 0 && (g.ldc % 8) == 0;
+  const bool modes_ok = C_BF16 ? (!g.residual && !g.accumulate) : true;
+  g.bias_in_lds = rows16 && modes_ok && ring + bias_bytes <= 160 * 1024 ? 1 : 0;
+  const int shm = ring + (g.bias_in_lds ? bias_bytes : 0);
+  auto kern = k_gemm_nt_ws<C_BF16, NL, ABL, EPI>;
+  static bool attr_done = false;   // per instantiation
+  if (!attr_done) {
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_done = true;
+  }
+  int grid = 256;
+  const int ntiles = g.tiles_m * g.tiles_n;
+  if (grid > ((ntiles + 7) / 8) * 8) grid = ((ntiles + 7) / 8) * 8;
+#ifdef AFM_GEMM_ABLATIONS
+  { const char* eg = getenv("AFM_GRID"); if (eg) grid = atoi(eg); }
+#endif
+  AFM_LAUNCH(kern, dim3(grid), dim3(64 * (8 + NL)), shm, st, g);
   return AFM_OK;
 }
 
@@ -807,6 +1118,10 @@ int afm_gemm_mfma_try(const afm_gemm_desc* d, hipStream_t st) {
   g.dd = afm_make_drop(&d->drop);
   g.tiles_m = (d->M + BM - 1) / BM; g.tiles_n = (d->N + BN - 1) / BN;
   g.ksplit = 1; g.kchunk = d->K; g.bias_in_lds = 0;
+  g.stamps = nullptr;
+#ifdef AFM_GEMM_ABLATIONS
+  { const char* e = getenv("AFM_STAMPS"); if (e) g.stamps = (unsigned long long*)strtoull(e, nullptr, 0); }
+#endif
   if (!aligned16(d->A) || !aligned16(d->B) || (d->lda & 7) || (d->ldb & 7)) return AFM_ERR_UNSUPPORTED;
   if (!d->transA && d->transB) {  // NT
     if ((d->K & 7) || d->K < 32 || d->N < 16) return AFM_ERR_UNSUPPORTED;
@@ -819,7 +1134,7 @@ int afm_gemm_mfma_try(const afm_gemm_desc* d, hipStream_t st) {
       // otherwise 128x128 at two workgroups per CU; anything with K % 64 != 0 keeps the
       // register-staged kernel (case 100).
       const int64_t big_tiles = (int64_t)((d->M + 255) / 256) * ((d->N + 127) / 128);
-      variant = (d->N > 128 && big_tiles >= 256) ? 12 : 13;
+      variant = (d->N > 128 && big_tiles >= 256) ? 24 : 13;
     }
     int r;
 #define NT_CASE(WM, WN, NWM, NWN, BKT) \
@@ -829,6 +1144,42 @@ int afm_gemm_mfma_try(const afm_gemm_desc* d, hipStream_t st) {
     switch (variant) {
       case 12: r = (d->K & 63) ? AFM_ERR_UNSUPPORTED : PRING_CASE(4, 2, 3, 1); break;   // persistent 256x128, 8 waves, 3 stages
       case 13: r = (d->K & 63) ? AFM_ERR_UNSUPPORTED : PRING_CASE(2, 2, 2, 2); break;   // persistent 128x128, 4 waves, 2 per CU
+      case 22: r = (d->K & 63) ? AFM_ERR_UNSUPPORTED : (d->c_dtype == AFM_BF16 ? launch_nt_ws<true, 2>(g, st) : launch_nt_ws<false, 2>(g, st)); break;
+      case 24:   // persistent 256x128, 8 MFMA waves + 4 loader waves, epilogue picked at compile time
+      case 25: { // (25: same tile walk with the generic run-time epilogue, for A/B timing)
+        if (d->K & 63) { r = AFM_ERR_UNSUPPORTED; break; }
+        if (d->c_dtype != AFM_BF16) { r = launch_nt_ws<false, 4>(g, st); break; }
+        int epi = EPI_GENERIC;
+        const bool small_idx = (uint64_t)d->M * (uint64_t)d->N <= 0x100000000ull;
+        const bool dropping = d->drop.p > 0.f;
+        if (variant == 24 && !d->residual && !d->accumulate && (small_idx || !dropping)) {
+          if (d->act == AFM_ACT_GELU_BWD) epi = EPI_GELU_BWD;
+          else if (d->act == AFM_ACT_GELU) epi = EPI_GELU;
+          else if (d->act == AFM_ACT_NONE && !d->pre_act) epi = dropping ? EPI_DROP : EPI_PLAIN;
+        }
+        switch (epi) {
+          case EPI_PLAIN: r = launch_nt_ws<true, 4, 0, EPI_PLAIN>(g, st); break;
+          case EPI_DROP: r = launch_nt_ws<true, 4, 0, EPI_DROP>(g, st); break;
+          case EPI_GELU: r = launch_nt_ws<true, 4, 0, EPI_GELU>(g, st); break;
+          case EPI_GELU_BWD: r = launch_nt_ws<true, 4, 0, EPI_GELU_BWD>(g, st); break;
+          default: r = launch_nt_ws<true, 4>(g, st); break;
+        }
+        break;
+      }
+#ifdef AFM_GEMM_ABLATIONS
+      case 241: r = launch_nt_ws<true, 4, 1>(g, st); break;
+      case 242: r = launch_nt_ws<true, 4, 2>(g, st); break;
+      case 243: r = launch_nt_ws<true, 4, 3>(g, st); break;
+      case 244: r = launch_nt_ws<true, 4, 4>(g, st); break;
+      case 246: r = launch_nt_ws<true, 4, 6>(g, st); break;
+      case 247: r = launch_nt_ws<true, 4, 7>(g, st); break;
+      case 121: r = launch_nt_pring<true, 4, 2, 3, 1>(g, st, 1); break;
+      case 122: r = launch_nt_pring<true, 4, 2, 3, 2>(g, st, 1); break;
+      case 124: r = launch_nt_pring<true, 4, 2, 3, 4>(g, st, 1); break;
+      case 125: r = launch_nt_pring<true, 4, 2, 3, 5>(g, st, 1); break;
+      case 126: r = launch_nt_pring<true, 4, 2, 3, 6>(g, st, 1); break;
+      case 127: r = launch_nt_pring<true, 4, 2, 3, 7>(g, st, 1); break;
+#endif
       default: r = NT_CASE(4, 4, 2, 2, 64); break;                                       // register-staged 128x128
     }
 #undef PRING_CASE

@@ -18,6 +18,7 @@ OBJ = os.path.join(HERE, "build")
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-I" + os.path.join(ROOT, "include"),
          "-I" + HERE, "-Wno-unused-result", "-Wno-unused-value"]
+FLAGS += os.environ.get("AFM_EXTRA_FLAGS", "").split()   # e.g. -DAFM_GEMM_ABLATIONS for tools/bench_gemm.py --ablate
 
 
 def _hipcc():

@@ -464,7 +464,7 @@ def test_attention_mfma_strided_packed_qkv(ops):
     close(o, ref.transpose(1, 2).reshape(B * T, d), 2e-2, 2e-2)
 
 
-@pytest.mark.parametrize("variant", [12, 13, 100])
+@pytest.mark.parametrize("variant", [12, 13, 22, 24, 25, 100])
 @pytest.mark.parametrize("M,N,K", [(512, 256, 512), (1000, 1536, 512), (300, 136, 2048), (129, 24, 64), (70000, 384, 128)])
 def test_gemm_mfma_nt_ring_variants(ops, variant, M, N, K):
     a, w, bias = rnd(M, K, seed=1).bfloat16(), rnd(N, K, seed=2).bfloat16(), rnd(N, seed=3)
@@ -507,9 +507,10 @@ def test_layernorm_fused_residual_add(ops, adt):
     close(y, O.layer_norm(ref_sum.double(), gam.double(), bet.double()), 1e-2, 1e-2)
 
 
+@pytest.mark.parametrize("variant", [12, 24, 25])
 @pytest.mark.parametrize("cdt", [torch.bfloat16, torch.float32])
 @pytest.mark.parametrize("mode", ["bias", "gelu_preact_drop", "gelu_bwd", "residual_acc"])
-def test_gemm_persistent_staged_epilogue(ops, cdt, mode):
+def test_gemm_persistent_staged_epilogue(ops, cdt, mode, variant):
     """Full tiles (256x128) + edge tiles through the persistent kernel's LDS-staged epilogue."""
     M, N, K = 1024 + 77, 512 + 40, 128
     a, w, bias = rnd(M, K, seed=1).bfloat16(), rnd(N, K, seed=2).bfloat16(), rnd(N, seed=3)
@@ -519,17 +520,17 @@ def test_gemm_persistent_staged_epilogue(ops, cdt, mode):
     keep = torch.from_numpy(keep_mask(p, seed, site, M * N)).view(M, N)
     tol = dict(rtol=2e-2, atol=3e-2) if cdt == torch.bfloat16 else dict(rtol=1e-4, atol=1e-4)
     if mode == "bias":
-        ops.gemm(dev(a), dev(w), c, bias=dev(bias), algo=2, variant=12)
+        ops.gemm(dev(a), dev(w), c, bias=dev(bias), algo=2, variant=variant)
         close(c, t + bias.double(), **tol)
     elif mode == "gelu_preact_drop":
         pre = torch.zeros_like(c)
-        ops.gemm(dev(a), dev(w), c, bias=dev(bias), act=2, pre_act=pre, dropout=ops.drop(p, seed, site), algo=2, variant=12)
+        ops.gemm(dev(a), dev(w), c, bias=dev(bias), act=2, pre_act=pre, dropout=ops.drop(p, seed, site), algo=2, variant=variant)
         close(pre, t + bias.double(), **tol)
         close(c, O.gelu(t + bias.double()) * keep / (1 - p), **tol)
     elif mode == "gelu_bwd":
         u = rnd(M, N, seed=4)
         ud = dev(u, cdt)
-        ops.gemm(dev(a), dev(w), c, act=3, pre_act=ud, dropout=ops.drop(p, seed, site), algo=2, variant=12)
+        ops.gemm(dev(a), dev(w), c, act=3, pre_act=ud, dropout=ops.drop(p, seed, site), algo=2, variant=variant)
         ur = ud.float().cpu().double().requires_grad_(True)
         O.gelu(ur).backward(torch.ones(M, N, dtype=torch.float64))
         close(c, t * keep / (1 - p) * ur.grad, **tol)
@@ -538,5 +539,5 @@ def test_gemm_persistent_staged_epilogue(ops, cdt, mode):
             pytest.skip("bf16 residual/accumulate take the fragment epilogue (covered elsewhere)")
         res, c0 = rnd(M, N, seed=5), rnd(M, N, seed=6)
         c.copy_(dev(c0))
-        ops.gemm(dev(a), dev(w), c, bias=dev(bias), residual=dev(res), accumulate=True, algo=2, variant=12)
+        ops.gemm(dev(a), dev(w), c, bias=dev(bias), residual=dev(res), accumulate=True, algo=2, variant=variant)
         close(c, t + bias.double() + res.double() + c0.double(), **tol)

@@ -22,12 +22,12 @@ def main():
         for cdt in (torch.bfloat16, torch.float32):
             c = torch.empty(M, N, dtype=cdt, device=dev)
             res = []
-            for var in (12, 13):
+            for var in (12, 13, 24):
                 ms = t(lambda: ops.gemm(a, w, c, variant=var))
                 res.append(f"v{var} {2*M*N*K/ms/1e9:6.0f}")
             if cdt == torch.bfloat16:   # fused training epilogues: fwd bias+GELU+dropout (pre-activation kept), bwd GELU'
                 bias = torch.randn(N, device=dev); pre = torch.empty_like(c); dr = ops.drop(0.1, 1, 1)
-                for var in (12, 13):
+                for var in (25, 24):
                     ms = t(lambda: ops.gemm(a, w, c, bias=bias, act=2, pre_act=pre, dropout=dr, variant=var))
                     res.append(f"gelu-v{var} {2*M*N*K/ms/1e9:5.0f}")
                     ms = t(lambda: ops.gemm(a, w, c, act=3, pre_act=pre, dropout=dr, variant=var))
@@ -35,6 +35,16 @@ def main():
                     ms = t(lambda: ops.gemm(a, w, c, bias=bias, dropout=dr, variant=var))
                     res.append(f"drop-v{var} {2*M*N*K/ms/1e9:5.0f}")
             print(f"NT {name:10s} {M}x{N}x{K} out {str(cdt)[6:]:8s} TF/s: " + "  ".join(res))
+    if "--ablate" in sys.argv:   # needs a build with AFM_EXTRA_FLAGS=-DAFM_GEMM_ABLATIONS
+        labels = {24: "v24", 241: "no-mfma", 242: "no-dma", 243: "epi-only", 244: "no-epi", 246: "mfma-only", 247: "loop-only"}
+        for name, M, N, K in shapes[:4]:
+            a = torch.randn(M, K, device=dev).bfloat16(); w = torch.randn(N, K, device=dev).bfloat16()
+            c = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+            res = []
+            for var, lab in labels.items():
+                ms = t(lambda: ops.gemm(a, w, c, variant=var))
+                res.append(f"{lab} {ms*1e3:6.0f}us")
+            print(f"ABL {name:10s}: " + "  ".join(res))
     for name, R, M, N in [("wgrad qkv", B*S, 3*d, d), ("wgrad out", B*S, d, d), ("wgrad ffn1", B*S, f, d), ("wgrad ffn2", B*S, d, f)]:
         dy = torch.randn(R, M, device=dev).bfloat16(); x = torch.randn(R, N, device=dev).bfloat16()
         g = torch.zeros(M, N, device=dev)
