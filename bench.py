@@ -58,39 +58,59 @@ def time_kernel(fn, iters=10, warm=3):
 
 
 def dominant_kernel_roofline(model, wl, B, dtype):
-    """The FFN up-projection GEMM (the largest single FLOP term of the step): one launch
-    = (B*S x d) @ (f x d)^T, algorithmic FLOPs 2*B*S*d*f, against the dense bf16 MFMA peak."""
+    """The kernel with the largest share of the step in the rocprofv3 summary
+    (profiles/r01_c2_kernel_stats.csv): k_gemm_tn_ring, the weight-gradient GEMM, timed here at its
+    largest shape -- the FFN up-projection wgrad dW1[f x d] += dU^T[f x B*S] X[B*S x d] with the bias
+    gradient fused (one launch = 2*B*S*d*f FLOPs).  Algorithmic bytes per launch: dU and X read once
+    (bf16) + dW1 written once (fp32) = 2*B*S*(f+d) + 4*f*d; at 8 TB/s that is less time than the
+    FLOPs take at the dense bf16 MFMA peak, so the MFMA roof is the binding one.
+    `secondary` is the same measurement for the forward launch of that layer (x W1^T with the
+    bias + GELU + dropout epilogue, pre-activation kept), whose 2 x 537 MB of output make HBM its roof."""
     from multimodalanalytical_amd import ops
+    from multimodalanalytical_amd.lib import ACT_GELU
     cfg = wl["cfg"]
     S = sum(v[0] if isinstance(v, tuple) else v for v in wl["lens"].values())
     d, f = cfg["d_model"], cfg["encoder_ffn_dim"] * (2 if cfg["gated_linear"] else 1)
     M = B * S
     eng = model.hf_model.engine
     x = torch.randn(M, d, device=eng.dev).to(eng.cd)
-    w = eng.W("encoder.layers.0.linear1.weight", f, d)
-    out = torch.empty(M, f, dtype=eng.cd, device=eng.dev)
-    if cfg["gated_linear"]:      # [u | v] projection, GLU applied by afm_glu_fwd
-        ms = time_kernel(lambda: ops.gemm(x, w, out, trans_b=True))
-    else:                        # exactly the training launch: bias + GELU + dropout epilogue, u kept
-        from multimodalanalytical_amd.lib import ACT_GELU
-        bias = eng.ps.p("encoder.layers.0.linear1.bias")
-        pre = torch.empty_like(out)
-        dr = ops.drop(cfg["dropout"], 1, 1)
-        ms = time_kernel(lambda: ops.gemm(x, w, out, trans_b=True, bias=bias, act=ACT_GELU, pre_act=pre, dropout=dr))
+    du = torch.randn(M, f, device=eng.dev).to(eng.cd)
+    gw = torch.zeros(f, d, device=eng.dev)
+    gb = torch.zeros(f, device=eng.dev)
+    ms = time_kernel(lambda: ops.gemm(du, x, gw, trans_a=True, trans_b=False, accumulate=True, a_colsum=gb))
     algo = ops.last_algo()
     flops = 2.0 * M * d * f
     ach = flops / (ms * 1e-3) / 1e12
     peak = PEAK_BF16_TFLOPS if dtype == "bf16" else 157.3
+    esz = 2 if dtype == "bf16" else 4
     # HBM bytes per launch of this very kernel/shape from the committed PMC passes (FETCH_SIZE x2 +
-    # WRITE_SIZE, profiles/r01_ffn1_gemm_pmc.json); null when the shape differs from the profiled one
+    # WRITE_SIZE, profiles/r01_wgrad_ffn1_pmc.json); null when the shape differs from the profiled one
     traffic = None
-    pmc = os.path.join(ROOT, "profiles", "r01_ffn1_gemm_pmc.json")
+    pmc = os.path.join(ROOT, "profiles", "r01_wgrad_ffn1_pmc.json")
     if os.path.exists(pmc) and (M, f, d) == (131072, 2048, 512) and dtype == "bf16":
         traffic = json.load(open(pmc)).get("traffic_bytes_per_launch")
-    return {"bound": "mfma", "kernel": f"afm_gemm[{algo}] {M}x{f}x{d} (FFN linear1, fused bias+GELU+dropout)",
-            "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
-            "traffic": traffic, "traffic_unit": "HBM bytes/launch (PMC)", "algorithmic_bytes": 2 * (M * d + f * d) + 2 * 2 * M * f,
-            "avg_launch_ms": round(ms, 4)}
+    out = {"bound": "mfma", "kernel": f"afm_gemm[{algo}] wgrad dW1 {f}x{d} over {M} tokens (FFN linear1, bias gradient fused)",
+           "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
+           "traffic": traffic, "traffic_unit": "HBM bytes/launch (PMC)",
+           "algorithmic_bytes": esz * M * (f + d) + 4 * f * d, "avg_launch_ms": round(ms, 4)}
+    if not cfg["gated_linear"]:
+        w = eng.W("encoder.layers.0.linear1.weight", f, d)
+        o = torch.empty(M, f, dtype=eng.cd, device=eng.dev)
+        bias = eng.ps.p("encoder.layers.0.linear1.bias")
+        pre = torch.empty_like(o)
+        dr = ops.drop(cfg["dropout"], 1, 1)
+        ms2 = time_kernel(lambda: ops.gemm(x, w, o, trans_b=True, bias=bias, act=ACT_GELU, pre_act=pre, dropout=dr))
+        by = esz * (M * d + f * d) + 2 * esz * M * f
+        tr2 = None
+        pmc2 = os.path.join(ROOT, "profiles", "r01_ffn1_gemm_pmc.json")
+        if os.path.exists(pmc2) and (M, f, d) == (131072, 2048, 512) and dtype == "bf16":
+            tr2 = json.load(open(pmc2)).get("traffic_bytes_per_launch")
+        out["secondary"] = {"bound": "hbm", "kernel": f"afm_gemm[{ops.last_algo()}] {M}x{f}x{d} (FFN linear1 forward, fused bias+GELU+dropout, pre-activation kept)",
+                            "achieved": round(by / (ms2 * 1e-3) / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
+                            "frac": round(by / (ms2 * 1e-3) / 1e9 / 8000.0, 4), "traffic": tr2,
+                            "algorithmic_bytes": by, "avg_launch_ms": round(ms2, 4),
+                            "tflops": round(flops / (ms2 * 1e-3) / 1e12, 1)}
+    return out
 
 
 def cpu_baseline(model, wl, name, cpu_batch, threads):
