@@ -203,6 +203,32 @@ int afm_batch_sum(const float* x, float* out, int32_t B, int64_t S, int32_t d, i
 int afm_cast_bf16(const float* src, void* dst, void* dst_t, int32_t rows, int32_t cols, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Input path: PatchPreprocessor.__call__ (data/preprocessing/patches.py:54-107)
+ * on the device.  spectra (B x L) fp32 rows, present[b] = 0 marks the reference's `None` spectrum
+ * (zeros BEFORE standardisation, patches.py:63-67).  Per row, in the reference's order:
+ *   interpolation (patches.py:47-52): scipy interp1d from the grid 400 + 2 i (L points) onto
+ *     650 + 2 i (1625 points), evaluated in fp64 as slope * (x_new - x_lo) + y_lo, rounded to fp32;
+ *   standardise in fp32: (x - (float)mean) / (float)std (patches.py:76);
+ *   trim to n = len / patch_size whole patches; patches = view (n, patch_size) or, for
+ *     step = patch_size / overlap < patch_size, unfold(patch_size, step) (patches.py:79-90);
+ *   derivative (patches.py:92-96): torch.gradient of the RAW spectrum (central differences, one-sided
+ *     ends), trimmed, n more patches appended;
+ *   mask (patches.py:99-105): masking -> (patch sum == 0), else 1 for every patch of an absent row.
+ * patches: (B, P, patch_size) fp32, or (P, B, patch_size) when seq_first (the layout the collator
+ * hands to the model, datamodules.py:201-218); mask: (B, P) or (P, B) bytes, 1 = pad.
+ * afm_patch_count returns P for the descriptor (<= 0: invalid descriptor).
+ * ---------------------------------------------------------------------------------------- */
+typedef struct afm_patch_desc {
+  int32_t B, L;
+  int32_t patch_size, step;      /* step = patch_size / overlap */
+  int32_t interpolation, derivative, masking, seq_first;
+  double mean, std;              /* PatchPreprocessor.initialise statistics (non-zero entries) */
+} afm_patch_desc;
+int32_t afm_patch_count(const afm_patch_desc* d);
+int afm_patch_preprocess(const afm_patch_desc* d, const float* spectra, const uint8_t* present,
+                         float* patches, uint8_t* mask, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * LM-head loss.  nn.CrossEntropyLoss() over logits.view(-1,V) with ignore_index -100
  * (custom_modeling.py:490-491) fused with the teacher-forced argmax of
  * HFWrapper._calc_token_acc (wrapper.py:641-655).

@@ -26,6 +26,12 @@ class Dropout(C.Structure):
     _fields_ = [("p", C.c_float), ("site", C.c_uint32), ("seed", C.c_uint64)]
 
 
+class PatchDesc(C.Structure):
+    _fields_ = [("B", C.c_int32), ("L", C.c_int32), ("patch_size", C.c_int32), ("step", C.c_int32),
+                ("interpolation", C.c_int32), ("derivative", C.c_int32), ("masking", C.c_int32),
+                ("seq_first", C.c_int32), ("mean", C.c_double), ("std", C.c_double)]
+
+
 class GemmDesc(C.Structure):
     _fields_ = [
         ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32),
@@ -82,6 +88,8 @@ _SIGS = {
     "afm_add_inplace": (C.c_int, [_P, _P, _I64, _P]),
     "afm_batch_sum": (C.c_int, [_P, _P, _I32, _I64, _I32, _I32, _P]),
     "afm_cast_bf16": (C.c_int, [_P, _P, _P, _I32, _I32, _P]),
+    "afm_patch_count": (C.c_int32, [C.POINTER(PatchDesc)]),
+    "afm_patch_preprocess": (C.c_int, [C.POINTER(PatchDesc), _P, _P, _P, _P, _P]),
     "afm_ce_fwd": (C.c_int, [_P, _P, _I64, _I32, _I32, _P, _P, _P, _P]),
     "afm_ce_bwd": (C.c_int, [_P, _P, _P, _P, _F, _P, _I32, _I32, _I64, _I32, _I32, _P]),
     "afm_sumsq": (C.c_int, [_P, _I64, _P, _P]),

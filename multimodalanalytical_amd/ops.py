@@ -225,6 +225,28 @@ def cast_bf16(src, dst=None, dst_t=None):
     L.check(L.load().afm_cast_bf16(_ptr(src), _ptr(dst), _ptr(dst_t), rows, cols, _stream()), "afm_cast_bf16")
 
 
+def patch_preprocess(spectra, present, mean, std, patch_size, masking=False, interpolation=False, overlap=1,
+                     derivative=False, seq_first=False):
+    """PatchPreprocessor.__call__ on the device: spectra (B, L) fp32, present (B,) bool/uint8 or None.
+    Returns (patches fp32 (B, P, ps) | (P, B, ps), mask bool, True = pad)."""
+    B, Ln = spectra.shape
+    assert spectra.dtype == torch.float32 and spectra.is_contiguous()
+    d = L.PatchDesc(B=B, L=Ln, patch_size=patch_size, step=patch_size // overlap, interpolation=int(interpolation),
+                    derivative=int(derivative), masking=int(masking), seq_first=int(seq_first),
+                    mean=float(mean), std=float(std))
+    lib = L.load()
+    P = lib.afm_patch_count(C.byref(d))
+    if P <= 0:
+        raise L.AfmError("afm_patch_preprocess: invalid descriptor")
+    pr = None if present is None else present.to(torch.uint8).contiguous()
+    shape = (P, B, patch_size) if seq_first else (B, P, patch_size)
+    patches = torch.empty(shape, dtype=torch.float32, device=spectra.device)
+    mask = torch.empty(shape[:2], dtype=torch.uint8, device=spectra.device)
+    L.check(lib.afm_patch_preprocess(C.byref(d), _ptr(spectra), _ptr(pr), _ptr(patches), _ptr(mask), _stream()),
+            "afm_patch_preprocess")
+    return patches, mask.bool()
+
+
 def ce_fwd(logits, labels, row_lse, argmax, stats):
     rows, V = logits.shape
     assert logits.dtype == torch.float32 and labels.dtype == torch.int64

@@ -403,3 +403,60 @@ def greedy_decode(sd, cfg, data_config, target_modality, enc_inputs, attention_m
             if bool(done.all()):
                 break
         return ids
+
+
+# ---------------------------------------------------------------- input path
+def patch_preprocess(spectra, present, mean: float, std: float, patch_size: int, masking: bool = False,
+                     interpolation: bool = False, overlap: int = 1, derivative: bool = False):
+    """CPU restatement of PatchPreprocessor.__call__ (data/preprocessing/patches.py:54-107), numpy, written
+    out element by element in the order the reference computes.
+
+    spectra (B, L) float32, present (B,) bool (False = the reference's `None` row: zeros before
+    standardisation, patches.py:63-67).  Returns (patches (B, P, ps) float32, mask (B, P) bool, True = pad).
+      * interpolation (patches.py:47-52): scipy interp1d (linear) from the grid 400, 402, .. (L points) to
+        650, 652, .. 3898: x_new = x_old[i + 125] exactly, interval (lo, hi) = (i + 124, i + 125), value
+        slope * (x_new - x_lo) + y_lo in float64 with slope = (y_hi - y_lo) / 2; the first point has
+        lo = 0.  torch.Tensor(...) then rounds to float32 (patches.py:73).
+      * standardise in float32: (x - float32(mean)) / float32(std) (patches.py:76).
+      * trim to whole patches, view (P, ps) or unfold with step ps // overlap (patches.py:79-90).
+      * derivative (patches.py:92-96): torch.gradient of the RAW float32 spectrum (central differences,
+        one-sided at the ends), trimmed and patched, appended after the spectrum's patches.
+      * mask (patches.py:99-105): masking -> patch sum == 0, else all-True rows for absent spectra.
+    """
+    import numpy as np
+    spectra = np.asarray(spectra, dtype=np.float32)
+    present = np.asarray(present, dtype=bool)
+    B, L = spectra.shape
+    raw = np.where(present[:, None], spectra, np.float32(0.0)).astype(np.float32)
+    if interpolation:
+        y = raw.astype(np.float64)
+        n_new = (3900 - 650 + 1) // 2                     # np.arange(650, 3900, 2): 1625 points
+        out = np.empty((B, n_new), dtype=np.float64)
+        for i in range(n_new):
+            hi = max(i + 125, 1)
+            lo = hi - 1
+            x_new = 650.0 + 2.0 * i
+            x_lo = 400.0 + 2.0 * lo
+            slope = (y[:, hi] - y[:, lo]) / 2.0
+            out[:, i] = slope * (x_new - x_lo) + y[:, lo]
+        raw = out.astype(np.float32)
+    stdz = ((raw - np.float32(mean)) / np.float32(std)).astype(np.float32)
+    n_patches = stdz.shape[1] // patch_size
+    trim = n_patches * patch_size
+    if overlap == 1:
+        patched = stdz[:, :trim].reshape(B, n_patches, patch_size)
+    else:
+        step = patch_size // overlap
+        n_unf = (trim - patch_size) // step + 1
+        patched = np.stack([stdz[:, k * step:k * step + patch_size] for k in range(n_unf)], axis=1)
+    if derivative:
+        g = np.empty_like(raw)
+        g[:, 1:-1] = (raw[:, 2:] - raw[:, :-2]) / np.float32(2.0)
+        g[:, 0] = raw[:, 1] - raw[:, 0]
+        g[:, -1] = raw[:, -1] - raw[:, -2]
+        patched = np.concatenate([patched, g[:, :trim].reshape(B, n_patches, patch_size)], axis=1)
+    if masking:
+        mask = patched.sum(-1, dtype=np.float32) == 0
+    else:
+        mask = np.repeat(~present[:, None], patched.shape[1], axis=1)
+    return patched.astype(np.float32), mask

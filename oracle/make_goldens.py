@@ -14,6 +14,8 @@ What is captured:
       torch.optim + torch.nn.utils.clip_grad_norm_ (what Lightning calls); greedy ids.
   embed_variants.npz   linear_2_layer / linear_3_layer / msms_number / xVal embedders.
   schedule.npz         OneCycleLR lr and beta1 for total_steps=100, sin-cos table rows.
+  patches.npz          PatchPreprocessor (data/preprocessing/patches.py) outputs on seeded synthetic
+                       spectra: plain, interpolated, overlapping, derivative, masking, None rows.
 """
 import json
 import os
@@ -238,6 +240,46 @@ def dump_embed_variants():
     np.savez_compressed(os.path.join(OUT, "embed_variants.npz"), **out)
 
 
+def dump_patches():
+    """G6 (data side): the reference's PatchPreprocessor on synthetic spectra."""
+    from analytical_fm.data.preprocessing.patches import PatchPreprocessor
+    rng = np.random.default_rng(SEED + 7)
+    out = {}
+    cases = [
+        ("ps125", dict(patch_size=125, masking=False, interpolation=False), 1800, 6),
+        ("ps75_interp", dict(patch_size=75, masking=False, interpolation=True), 1800, 5),
+        ("ps75_interp1791", dict(patch_size=75, masking=False, interpolation=True), 1791, 3),
+        ("ps2", dict(patch_size=2, masking=False, interpolation=False), 1984, 4),
+        ("ps50_overlap2", dict(patch_size=50, masking=False, interpolation=False, overlap=2), 1800, 4),
+        ("ps100_deriv", dict(patch_size=100, masking=False, interpolation=False, derivative=True), 1800, 4),
+        ("ps125_masking", dict(patch_size=125, masking=True, interpolation=False), 1800, 5),
+    ]
+    meta = {}
+    for name, kw, L, B in cases:
+        pp = PatchPreprocessor(**kw)
+        # fit statistics the way initialise() does (mean/std over non-zero entries, patches.py:37-39)
+        fit = np.abs(rng.standard_normal((16, L))).astype(np.float32).astype(np.float64)
+        fit[:, :7] = 0.0
+        pp.mean = fit[fit != 0].mean()
+        pp.std = fit[fit != 0].std()
+        spectra = np.abs(rng.standard_normal((B, L))).astype(np.float32)
+        present = np.ones(B, dtype=bool)
+        if B >= 4 and "interp" not in name:      # interpolate() cannot take the zero-filled None rows of another length
+            present[2] = False
+        if name == "ps125_masking":                # a patch that standardises to exact zeros is masked
+            spectra[0, 125:250] = np.float32(pp.mean)
+        rows = [spectra[i].astype(np.float64).tolist() if present[i] else None for i in range(B)]
+        patches, mask = pp(rows)
+        out[f"{name}/spectra"] = spectra
+        out[f"{name}/present"] = present
+        out[f"{name}/patches"] = patches.numpy()
+        out[f"{name}/mask"] = mask.numpy()
+        meta[name] = dict(kw, mean=float(pp.mean), std=float(pp.std), L=L)
+    out["meta"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+    np.savez_compressed(os.path.join(OUT, "patches.npz"), **out)
+    print("patches.npz", {k: v.shape for k, v in out.items() if k.endswith("patches")})
+
+
 def dump_schedule():
     from analytical_fm.modeling.utils import SincCosPositionalEncoding
     p = torch.nn.Parameter(torch.zeros(1))
@@ -257,6 +299,9 @@ def dump_schedule():
 
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
+    if "--only-patches" in sys.argv:
+        dump_patches()
+        sys.exit(0)
     dc_plain = {
         "Formula": {"type": "text", "vocab_size": 45, "pad_token_id": 0, "target": False},
         "IR": {"type": "1D_patches", "target": False,
@@ -281,3 +326,4 @@ if __name__ == "__main__":
                     full_mask=("Multiplets", 2))
     dump_embed_variants()
     dump_schedule()
+    dump_patches()

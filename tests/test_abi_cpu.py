@@ -33,6 +33,21 @@ def test_struct_layouts_match_the_header():
     assert L.GemmDesc.A.offset == 48 and L.GemmDesc.a_colsum.offset == 96 and L.GemmDesc.drop.offset == 120
     assert ctypes.sizeof(L.LnShape) == 48
     assert L.AttnShape.key_pad.offset == 56 and L.AttnShape.sqb.offset == 80 and ctypes.sizeof(L.AttnShape) == 112
+    assert L.PatchDesc.mean.offset == 32 and ctypes.sizeof(L.PatchDesc) == 48
+
+
+def test_patch_count_is_host_side():
+    """afm_patch_count is pure host arithmetic: usable here (sizes of PatchPreprocessor outputs, patches.py:79-96)."""
+    from multimodalanalytical_amd import lib as L
+    h = L.load()
+    def P(**kw):
+        base = dict(B=4, L=1800, patch_size=125, step=125, interpolation=0, derivative=0, masking=0, seq_first=0, mean=0.0, std=1.0)
+        base.update(kw)
+        d = L.PatchDesc(**base)
+        return h.afm_patch_count(ctypes.byref(d))
+    assert P() == 14 and P(patch_size=75, step=75, interpolation=1) == 21 and P(L=1984, patch_size=2, step=2) == 992
+    assert P(patch_size=50, step=25) == 71 and P(patch_size=100, step=100, derivative=1) == 36
+    assert P(std=0.0) == -1 and P(L=1000, interpolation=1) == -1 and P(patch_size=0) == -1
 
 
 def test_ops_refuse_cpu_tensors():

@@ -1,6 +1,7 @@
 """GPU: every C-ABI entry point against the CPU oracle's primitives (oracle/afm_oracle.py) on the
 same seeded inputs.  fp32 paths are held to ~1e-5; bf16 storage paths to bf16 rounding."""
 import math
+import os
 
 import numpy as np
 import pytest
@@ -541,3 +542,92 @@ def test_gemm_persistent_staged_epilogue(ops, cdt, mode, variant):
         c.copy_(dev(c0))
         ops.gemm(dev(a), dev(w), c, bias=dev(bias), residual=dev(res), accumulate=True, algo=2, variant=variant)
         close(c, t + bias.double() + res.double() + c0.double(), **tol)
+
+
+# ---------------------------------------------------------------- input path
+def _patch_golden():
+    import json
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "patches.npz"))
+    return g, json.loads(bytes(g["meta"]).decode())
+
+
+@pytest.mark.parametrize("seq_first", [False, True])
+def test_patch_preprocess_matches_reference_goldens(ops, seq_first):
+    """afm_patch_preprocess vs the reference's PatchPreprocessor outputs (tests/golden/patches.npz): bit-exact."""
+    g, meta = _patch_golden()
+    for name, kw in meta.items():
+        sp = torch.from_numpy(g[f"{name}/spectra"]).to(DEV)
+        pr = torch.from_numpy(g[f"{name}/present"]).to(DEV)
+        p, m = ops.patch_preprocess(sp, pr, kw["mean"], kw["std"], kw["patch_size"], masking=kw["masking"],
+                                    interpolation=kw["interpolation"], overlap=kw.get("overlap", 1),
+                                    derivative=kw.get("derivative", False), seq_first=seq_first)
+        if seq_first:
+            p, m = p.transpose(0, 1), m.transpose(0, 1)
+        assert torch.equal(p.cpu(), torch.from_numpy(g[f"{name}/patches"])), name
+        assert torch.equal(m.cpu(), torch.from_numpy(g[f"{name}/mask"])), name
+
+
+@pytest.mark.parametrize("B,Ln,ps,overlap,interp,deriv", [(128, 1984, 2, 1, False, False), (33, 1800, 75, 1, True, True),
+                                                          (7, 1791, 125, 1, True, False), (5, 1000, 64, 4, False, True),
+                                                          (1, 130, 130, 1, False, False)])
+def test_patch_preprocess_vs_oracle_shapes(ops, B, Ln, ps, overlap, interp, deriv):
+    from oracle import afm_oracle as Orc
+    rng = np.random.default_rng(B * 1000 + Ln)
+    sp = np.abs(rng.standard_normal((B, Ln))).astype(np.float32)
+    pr = rng.random(B) > 0.2
+    mean, std = 0.7312345678, 0.5923456789
+    ref_p, ref_m = Orc.patch_preprocess(sp, pr, mean, std, ps, False, interp, overlap, deriv)
+    p, m = ops.patch_preprocess(torch.from_numpy(sp).to(DEV), torch.from_numpy(pr).to(DEV), mean, std, ps,
+                                interpolation=interp, overlap=overlap, derivative=deriv)
+    assert torch.equal(p.cpu(), torch.from_numpy(ref_p)) and torch.equal(m.cpu(), torch.from_numpy(ref_m))
+
+
+def test_patch_preprocessor_class_mirrors_reference_interface(ops):
+    """Host mirror (multimodalanalytical_amd.preprocess.PatchPreprocessor): list-of-lists with None in, same outputs."""
+    from multimodalanalytical_amd.preprocess import PatchPreprocessor
+    g, meta = _patch_golden()
+    kw = meta["ps125"]
+    pp = PatchPreprocessor(patch_size=125, masking=False, interpolation=False)
+    pp.mean, pp.std = kw["mean"], kw["std"]
+    rows = [r.astype(np.float64).tolist() if ok else None for r, ok in zip(g["ps125/spectra"], g["ps125/present"])]
+    p, m = pp(rows)
+    assert torch.equal(p.cpu(), torch.from_numpy(g["ps125/patches"])) and torch.equal(m.cpu(), torch.from_numpy(g["ps125/mask"]))
+    fit = {"IR": [[0.0, 1.0, 3.0], [2.0, 0.0, 0.0]]}
+    pp.initialise(fit, "IR")
+    assert pp.mean == 2.0 and abs(pp.std - np.std([1.0, 3.0, 2.0])) < 1e-12      # non-zero entries only (patches.py:37-39)
+    with pytest.raises(Exception):
+        ops.patch_preprocess(torch.zeros(2, 100, device=DEV), None, 0.0, 0.0, 10)   # std == 0: refused, nothing launched
+
+
+def test_device_collator_batch_dict(ops):
+    """DeviceCollator emits the reference collator's sequence-first batch dict (datamodules.py:201-218)."""
+    from multimodalanalytical_amd.preprocess import DeviceCollator, PatchPreprocessor
+    from oracle import afm_oracle as Orc
+    rng = np.random.default_rng(11)
+    B, S, T, Ln = 5, 9, 12, 1800
+    dc = {"Formula": {"type": "text", "vocab_size": 45, "pad_token_id": 0, "target": False},
+          "IR": {"type": "1D_patches", "target": False},
+          "Smiles": {"type": "text", "vocab_size": 26, "pad_token_id": 0, "target": True}}
+    lens = rng.integers(3, S + 1, B); tl = rng.integers(4, T + 2, B)
+    f_ids = np.zeros((B, S), dtype=np.int64); f_att = np.zeros((B, S), dtype=np.int64)
+    t_ids = np.zeros((B, T + 1), dtype=np.int64); t_att = np.zeros((B, T + 1), dtype=np.int64)
+    for b in range(B):
+        f_ids[b, :lens[b]] = rng.integers(4, 45, lens[b]); f_att[b, :lens[b]] = 1
+        t_ids[b, :tl[b]] = rng.integers(4, 26, tl[b]); t_att[b, :tl[b]] = 1
+    sp = np.abs(rng.standard_normal((B, Ln))).astype(np.float32)
+    pr = np.array([True, True, False, True, True])
+    pp = PatchPreprocessor(patch_size=125, masking=False, interpolation=False)
+    pp.mean, pp.std = 0.81, 0.6
+    col = DeviceCollator(dc, {"IR": pp}, "Smiles")
+    d = lambda a: torch.from_numpy(a).to(DEV)
+    out = col({"Formula": {"input_ids": d(f_ids), "attention_mask": d(f_att)},
+               "IR": {"spectra": d(sp), "present": d(pr)},
+               "Smiles": {"input_ids": d(t_ids), "attention_mask": d(t_att)}})
+    ref_p, ref_m = Orc.patch_preprocess(sp, pr, pp.mean, pp.std, 125)
+    assert torch.equal(out["encoder_input"]["Formula"].cpu(), torch.from_numpy(f_ids.T))
+    assert torch.equal(out["encoder_input"]["IR"].cpu(), torch.from_numpy(ref_p).transpose(0, 1))
+    assert torch.equal(out["encoder_pad_mask"].cpu(), torch.from_numpy(np.concatenate([f_att.T == 0, ref_m.T], 0)))
+    assert torch.equal(out["decoder_input"]["Smiles"].cpu(), torch.from_numpy(t_ids.T[:-1]))
+    assert torch.equal(out["target"].cpu(), torch.from_numpy(t_ids.T[1:]))
+    assert torch.equal(out["decoder_pad_mask"].cpu(), torch.from_numpy(t_att.T[:-1] == 0))
+    assert torch.equal(out["target_mask"].cpu(), torch.from_numpy(t_att.T[1:] == 0))

@@ -1,5 +1,7 @@
 """CPU: the oracle (oracle/afm_oracle.py) against vectors produced by the reference itself
 (tests/golden/*.npz, generator oracle/make_goldens.py).  This is what pins the oracle."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -94,3 +96,20 @@ def test_schedule_and_sincos():
         np.testing.assert_allclose(b1, t[f"onecycle{total}"]["beta1"].numpy(), rtol=1e-12)
     for d in (64, 128, 30):
         torch.testing.assert_close(O.sincos_table(d, 40), t["sincos"][str(d)], rtol=0, atol=1e-6)
+
+
+def test_patch_preprocessor_oracle_matches_reference_bit_exact():
+    """oracle.patch_preprocess vs PatchPreprocessor.__call__ outputs captured from the reference
+    (tests/golden/patches.npz, oracle/make_goldens.py:dump_patches): plain, interpolated (both source
+    lengths), patch size 2, overlapping, derivative, masking, `None` rows.  Bit-exact fp32 + masks."""
+    import json
+    import numpy as np
+    from oracle import afm_oracle as O
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "patches.npz"))
+    meta = json.loads(bytes(g["meta"]).decode())
+    assert len(meta) == 7
+    for name, kw in meta.items():
+        p, m = O.patch_preprocess(g[f"{name}/spectra"], g[f"{name}/present"], kw["mean"], kw["std"], kw["patch_size"],
+                                  kw["masking"], kw["interpolation"], kw.get("overlap", 1), kw.get("derivative", False))
+        assert p.dtype == np.float32 and np.array_equal(p, g[f"{name}/patches"]), name
+        assert np.array_equal(m, g[f"{name}/mask"]), name
