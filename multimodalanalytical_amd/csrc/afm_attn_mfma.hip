@@ -37,6 +37,11 @@ __device__ __forceinline__ f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+__device__ __forceinline__ float max3_raw(float a, float b, float c) {
+  float r;
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
 
 // LDS images of a [64 rows][64 cols] bf16 tile (128-byte rows, 8 chunks of 16 bytes):
 //   "row image": read by rows with ds_read_b128 (lane = row, 32 rows x one chunk per half-wave)
@@ -163,6 +168,7 @@ __device__ __forceinline__ void build_mask_words(unsigned long long* maskw, cons
 }
 
 // ------------------------------------------------------------------------------------------ forward
+template <bool DROP>
 __global__ __launch_bounds__(256, 2) void k_attn_fwd_mfma(AttnM a, const bf16* __restrict__ Q,
                                                           const bf16* __restrict__ K,
                                                           const bf16* __restrict__ V, bf16* __restrict__ O,
@@ -205,13 +211,16 @@ __global__ __launch_bounds__(256, 2) void k_attn_fwd_mfma(AttnM a, const bf16* _
 #pragma unroll
   for (int s = 0; s < RS - 1; ++s)
     if (s < ntiles) issue(s);
+  // ntiles >= 1 always (Tk >= 1): without the guard the loop's exit block has one predecessor and the
+  // accumulators need no phi copies at the latch (they cost 32-64 v_mov per tile)
+  __builtin_assume(ntiles >= 1);
   for (int kt = 0; kt < ntiles; ++kt) {
     const int kb = kt * KT;
     if (ntiles - 1 - kt >= RS - 2) attn_wait_vmcnt<4 * (RS - 2)>(); else attn_wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
     if (kt + RS - 1 < ntiles) issue(kt + RS - 1);
-    if (a.causal && kb > q0 + 31) continue;  // wave-uniform: tile entirely above this wave's diagonal
-    if (maskw[kt] == ~0ull) continue;         // every key of the tile is padding: contributes nothing
+    // wave-uniform skips: tile entirely above this wave's diagonal / every key of the tile is padding
+    if ((a.causal && kb > q0 + 31) || maskw[kt] == ~0ull) continue;
     const unsigned char* Kimg = lds + (kt % RS) * STAGE;
     const unsigned char* Vimg = Kimg + KT * DH * 2;
     const unsigned long long mword = maskw[kt];
@@ -237,9 +246,11 @@ __global__ __launch_bounds__(256, 2) void k_attn_fwd_mfma(AttnM a, const bf16* _
           s[blk][r] = msk ? -INFINITY : s[blk][r];
         }
     }
+    // row maximum with v_max3_f32 from inline asm: fmaxf() makes hipcc canonicalise every MFMA output
+    // first (one extra `v_max_f32 x, x, x` per score); the scores are finite or -inf, never NaN
     float mt = fmaxf(s[0][0], s[1][0]);
 #pragma unroll
-    for (int r = 1; r < 16; ++r) mt = fmaxf(mt, fmaxf(s[0][r], s[1][r]));
+    for (int r = 1; r < 16; ++r) mt = max3_raw(mt, s[0][r], s[1][r]);
     mt = fmaxf(mt, __shfl_xor(mt, 32, 64)) * a.scale_log2;     // scale > 0: max commutes with it
     const float mn = fmaxf(m, mt);
     const float ms = mn == -INFINITY ? 0.f : mn;
@@ -256,11 +267,12 @@ __global__ __launch_bounds__(256, 2) void k_attn_fwd_mfma(AttnM a, const bf16* _
         ls += p;
       }
     l = l * alpha + ls;
-    if (__any(grew)) {   // the running maximum moved for some query of this wave: rescale O^T
+    // rescale O^T unconditionally: 16 packed multiplies; skipping them when no maximum moved made the
+    // register allocator copy all 32 accumulators at the branch join (32 v_mov per tile)
+    (void)grew;
 #pragma unroll
-      for (int i = 0; i < 16; ++i) { o[0][i] *= alpha; o[1][i] *= alpha; }
-    }
-    if (a.dd.thresh16) {
+    for (int i = 0; i < 16; ++i) { o[0][i] *= alpha; o[1][i] *= alpha; }
+    if (DROP) {   // compile-time: a run-time branch costs 32 register copies at its join
       drop_block(a.dd, rowbase, kb, h, s[0]);
       drop_block(a.dd, rowbase, kb + 32, h, s[1]);
     }
@@ -297,6 +309,7 @@ __global__ __launch_bounds__(256, 2) void k_attn_fwd_mfma(AttnM a, const bf16* _
 // ------------------------------------------------------------------------------------------ dQ
 // Per 64-key tile: S^T and dP^T (keys in registers, query on the lane), then
 // dQ^T[d][q] += sum_key K^T[d][key] dS^T[key][q].  Also writes delta = rowsum(dO * O).
+template <bool DROP>
 __global__ __launch_bounds__(256, 2) void k_attn_bwd_dq_mfma(AttnM a, const bf16* __restrict__ Q,
                                                           const bf16* __restrict__ K,
                                                           const bf16* __restrict__ V,
@@ -357,13 +370,15 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd_dq_mfma(AttnM a, const bf16
 #pragma unroll
   for (int s = 0; s < RS - 1; ++s)
     if (s < ntiles) issue(s);
+  // ntiles >= 1 always (Tk >= 1): without the guard the loop's exit block has one predecessor and the
+  // accumulators need no phi copies at the latch (they cost 32-64 v_mov per tile)
+  __builtin_assume(ntiles >= 1);
   for (int kt = 0; kt < ntiles; ++kt) {
     const int kb = kt * KT;
     if (ntiles - 1 - kt >= RS - 2) attn_wait_vmcnt<6 * (RS - 2)>(); else attn_wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
     if (kt + RS - 1 < ntiles) issue(kt + RS - 1);
-    if (a.causal && kb > q0 + 31) continue;
-    if (maskw[kt] == ~0ull) continue;         // all-padding key tile
+    if ((a.causal && kb > q0 + 31) || maskw[kt] == ~0ull) continue;   // above the diagonal / all-padding key tile
     const unsigned char* Krow = lds + (kt % RS) * STAGE;
     const unsigned char* Ktr = Krow + KT * DH * 2;
     const unsigned char* Vrow = Krow + 2 * KT * DH * 2;
@@ -381,7 +396,7 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd_dq_mfma(AttnM a, const bf16
         s = mfma32(frag_row(Krow, 32 * blk, ks, lane), qf[ks], s);
         dp = mfma32(frag_row(Vrow, 32 * blk, ks, lane), dof[ks], dp);
       }
-      if (a.dd.thresh16) {
+      if (DROP) {
         drop_block(a.dd, rowbase, kb + 32 * blk, h, dp);
 #pragma unroll
         for (int r = 0; r < 16; ++r) dp[r] *= a.dd.scale16;
@@ -429,6 +444,7 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd_dq_mfma(AttnM a, const bf16
 // Workgroup = 4 waves x 32 keys; loops over 64-query tiles.  S = Q K^T with the key on the lane
 // (queries in registers), P = exp2(S - lse[q]), dP = dO V^T, dS = P (D dP - delta[q]);
 // dV^T[d][key] += sum_q dO^T[d][q] (D P)[q][key],  dK^T[d][key] += sum_q Q^T[d][q] dS[q][key].
+template <bool DROP>
 __global__ __launch_bounds__(256, 2) void k_attn_bwd_dkv_mfma(AttnM a, const bf16* __restrict__ Q,
                                                            const bf16* __restrict__ K,
                                                            const bf16* __restrict__ V,
@@ -485,6 +501,7 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd_dkv_mfma(AttnM a, const bf1
     }
   };
   if (ntiles > 0) issue(0);
+  __builtin_assume(ntiles >= 1);   // see k_attn_fwd_mfma
   for (int qt = 0; qt < ntiles; ++qt) {
     const int qb = qbeg + qt * KT;
     attn_wait_vmcnt<0>();          // this tile's pieces (the only ones in flight)
@@ -497,8 +514,8 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd_dkv_mfma(AttnM a, const bf1
     const float* Ls = (const float*)(Qrow + 4 * KT * DH * 2);   // lse (natural log units)
     const float* Ds = Ls + KT;
     const bool ragged = qb + KT > a.Tq;   // wave-uniform: tile holds rows past Tq (clamped duplicates)
-    if (a.causal && qb + KT - 1 < k0) continue;   // wave-uniform: every query of the tile precedes this wave's keys
-    if (wave_all_masked) continue;                // this wave's 32 keys are all padding: dK = dV = 0
+    // wave-uniform skips: every query of the tile precedes this wave's keys / its 32 keys are all padding
+    if ((a.causal && qb + KT - 1 < k0) || wave_all_masked) continue;
     unsigned qa0, qa1, da0, da1;
     tr_lane_addr(Qtr, lane, qa0, qa1);
     tr_lane_addr(Dtr, lane, da0, da1);
@@ -528,7 +545,7 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd_dkv_mfma(AttnM a, const bf1
 #pragma unroll
         for (int j = 0; j < 4; ++j) pd[4 * g4 + j] = fast_exp2(fmaf(s[4 * g4 + j], a.scale_log2, -Lq[j]));
       }
-      if (a.dd.thresh16) {
+      if (DROP) {
         // Dropout keep bits.  Element (q, key) has index i = (lbase+q)*Tk + key; with Tk even the two
         // lanes of a key pair (lane, lane^1) share the hash of i>>1 = (lbase+q)*(Tk/2) + key/2 and take
         // its low / high 16 bits.  The even lane hashes the even register rows, the odd lane the odd
@@ -623,8 +640,8 @@ int afm_attn_fwd_mfma_try(const afm_attn_shape* s, const void* Q, const void* K,
   const dim3 grid((s->Tq + 127) / 128, s->H, s->B);
   const int shm = RS * 2 * KT * DH * 2 + ((s->Tk + KT - 1) / KT) * 8;
   if (shm > 64 * 1024) return AFM_ERR_UNSUPPORTED;
-  AFM_LAUNCH(k_attn_fwd_mfma, grid, dim3(256), shm, st, a, (const bf16*)Q, (const bf16*)K, (const bf16*)V,
-             (bf16*)O, lse);
+  if (a.dd.thresh16) AFM_LAUNCH(k_attn_fwd_mfma<true>, grid, dim3(256), shm, st, a, (const bf16*)Q, (const bf16*)K, (const bf16*)V, (bf16*)O, lse);
+  else AFM_LAUNCH(k_attn_fwd_mfma<false>, grid, dim3(256), shm, st, a, (const bf16*)Q, (const bf16*)K, (const bf16*)V, (bf16*)O, lse);
   afm_set_last_algo("attn_mfma");
   return AFM_OK;
 }
@@ -641,14 +658,22 @@ int afm_attn_bwd_mfma_try(const afm_attn_shape* s, const void* Q, const void* K,
   const int shm_q = RS * 3 * KT * DH * 2 + ((s->Tk + KT - 1) / KT) * 8;
   if (shm_q > 80 * 1024) return AFM_ERR_UNSUPPORTED;
   static bool attr_q = false;
-  if (!attr_q) { (void)hipFuncSetAttribute((const void*)k_attn_bwd_dq_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); attr_q = true; }
-  AFM_LAUNCH(k_attn_bwd_dq_mfma, gq, dim3(256), shm_q, st, a, (const bf16*)Q, (const bf16*)K, (const bf16*)V,
-             (const bf16*)O, (const bf16*)dO, lse, delta, (bf16*)dQ);
+  if (!attr_q) {
+    (void)hipFuncSetAttribute((const void*)k_attn_bwd_dq_mfma<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    (void)hipFuncSetAttribute((const void*)k_attn_bwd_dq_mfma<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    attr_q = true;
+  }
+  if (a.dd.thresh16) AFM_LAUNCH(k_attn_bwd_dq_mfma<true>, gq, dim3(256), shm_q, st, a, (const bf16*)Q, (const bf16*)K, (const bf16*)V, (const bf16*)O, (const bf16*)dO, lse, delta, (bf16*)dQ);
+  else AFM_LAUNCH(k_attn_bwd_dq_mfma<false>, gq, dim3(256), shm_q, st, a, (const bf16*)Q, (const bf16*)K, (const bf16*)V, (const bf16*)O, (const bf16*)dO, lse, delta, (bf16*)dQ);
   const int shm_k = 2 * (4 * KT * DH * 2 + 2 * KT * 4);
   static bool attr_k = false;
-  if (!attr_k) { (void)hipFuncSetAttribute((const void*)k_attn_bwd_dkv_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); attr_k = true; }
-  AFM_LAUNCH(k_attn_bwd_dkv_mfma, gk, dim3(256), shm_k, st, a, (const bf16*)Q, (const bf16*)K, (const bf16*)V,
-             (const bf16*)dO, lse, delta, (bf16*)dK, (bf16*)dV);
+  if (!attr_k) {
+    (void)hipFuncSetAttribute((const void*)k_attn_bwd_dkv_mfma<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    (void)hipFuncSetAttribute((const void*)k_attn_bwd_dkv_mfma<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    attr_k = true;
+  }
+  if (a.dd.thresh16) AFM_LAUNCH(k_attn_bwd_dkv_mfma<true>, gk, dim3(256), shm_k, st, a, (const bf16*)Q, (const bf16*)K, (const bf16*)V, (const bf16*)dO, lse, delta, (bf16*)dK, (bf16*)dV);
+  else AFM_LAUNCH(k_attn_bwd_dkv_mfma<false>, gk, dim3(256), shm_k, st, a, (const bf16*)Q, (const bf16*)K, (const bf16*)V, (const bf16*)dO, lse, delta, (bf16*)dK, (bf16*)dV);
   afm_set_last_algo("attn_mfma");
   return AFM_OK;
 }
