@@ -203,6 +203,38 @@ int afm_batch_sum(const float* x, float* out, int32_t B, int64_t S, int32_t d, i
 int afm_cast_bf16(const float* src, void* dst, void* dst_t, int32_t rows, int32_t cols, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Encoder alignment head (custom_modeling.py:363-396 network, 453-475 use).
+ * masked mean: out[b,:] = sum_s keep[b,s] x[b,s,:] / sum_s keep[b,s]   (keep = !key_pad;
+ *   `(last_hidden_state * mask).sum(1) / mask.sum(1)`, custom_modeling.py:469-470); x fp32 or bf16.
+ * bwd: dx[b,s,:] (+)= keep[b,s] dy[b,:] / n_b  (fp32; accumulate = 0 also writes the zeros of the
+ *   padded rows, so it can initialise the encoder-output gradient).
+ * loss: pred = sigmoid(z); kind 0 mse = mean (pred-t)^2, 1 mae = mean |pred-t| (nn.MSELoss / nn.L1Loss),
+ *   2 sid = the reference's own kl_div pair (modeling/utils.py:8-22): both clamped to >= 1e-16,
+ *   [sum p log(p/t) + sum t log(t/p)] / B.  stats[0] += loss; dz = grad_scale * dloss/dz.
+ * The Linear / ReLU / centre-tap Conv1d layers in between are afm_gemm calls.
+ * ---------------------------------------------------------------------------------------- */
+enum { AFM_ALIGN_MSE = 0, AFM_ALIGN_MAE = 1, AFM_ALIGN_SID = 2 };
+int afm_masked_mean_fwd(const void* x, int32_t x_dtype, const uint8_t* key_pad, int32_t B, int32_t S,
+                        int32_t d, float* out, void* stream);
+int afm_masked_mean_bwd(const float* dy, const uint8_t* key_pad, int32_t B, int32_t S, int32_t d,
+                        float* dx, int32_t accumulate, void* stream);
+int afm_align_loss(const float* z, const float* target, int32_t kind, int32_t B, int32_t n,
+                   float grad_scale, float* stats, float* dz, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Mixture generator (data/datasets.py:58-141 mix_spectra + normalize_spectrum
+ * :49-56).  For output row r: combined = np.average(table[idx[r, 0..c)], weights=ratio, axis=0)
+ * evaluated in fp64 in numpy's order (sum_c table[idx[r,c]] * ratio[c], then / sum(ratio));
+ * normalize != 0: min / max of the combined row, negatives clipped to 0, then
+ * (x - min) / (max - min) (all zeros when max == min); zero-padded to out_len (1800 in the reference)
+ * and rounded to fp32 (the collator's torch.Tensor(...)).  table (N x L) fp32, idx (n x c) int64.
+ * PARITY UNPINNED: data/datasets.py imports omegaconf, which this image lacks, so no reference outputs
+ * could be captured; the oracle restates the numpy arithmetic (oracle/afm_oracle.py:mix_spectra).
+ * ---------------------------------------------------------------------------------------- */
+int afm_mix_spectra(const float* table, int64_t N, int32_t L, const int64_t* idx, int32_t n, int32_t c,
+                    const double* ratio, int32_t normalize, int32_t out_len, float* out, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Input path: PatchPreprocessor.__call__ (data/preprocessing/patches.py:54-107)
  * on the device.  spectra (B x L) fp32 rows, present[b] = 0 marks the reference's `None` spectrum
  * (zeros BEFORE standardisation, patches.py:63-67).  Per row, in the reference's order:

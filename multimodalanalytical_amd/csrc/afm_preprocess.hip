@@ -100,3 +100,63 @@ extern "C" int afm_patch_preprocess(const afm_patch_desc* d, const float* spectr
   AFM_LAUNCH(k_patch_mask, dim3((a.B * a.P + 255) / 256), dim3(256), 0, st, a, present, patches, mask);
   return AFM_OK;
 }
+
+
+// ---------------------------------------------------------------- mixture generator (datasets.py:58-141)
+// One workgroup per mixed spectrum; a thread keeps its <= 8 fp64 points in registers between the
+// weighted average and the min-max normalisation (L <= 2048).
+__global__ __launch_bounds__(256) void k_mix_spectra(const float* __restrict__ table, int64_t N, int L,
+                                                     const int64_t* __restrict__ idx, int c, const double* __restrict__ ratio,
+                                                     int normalize, int out_len, float* __restrict__ out) {
+#pragma clang fp contract(off)   // numpy multiplies, then adds: no fused multiply-add in the weighted sum
+  const int r = blockIdx.x, t = threadIdx.x;
+  double wsum = 0.0;
+  for (int k = 0; k < c; ++k) wsum += ratio[k];
+  double v[8];
+  double mn = INFINITY, mx = -INFINITY;
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    const int j = t + 256 * u;
+    double acc = 0.0;
+    if (j < L) {
+      for (int k = 0; k < c; ++k) {
+        int64_t row = idx[(int64_t)r * c + k];
+        row = row < 0 ? 0 : (row >= N ? N - 1 : row);
+        const double term = (double)table[row * L + j] * ratio[k];
+        acc = k == 0 ? term : acc + term;
+      }
+      acc /= wsum;
+      mn = fmin(mn, acc); mx = fmax(mx, acc);
+    }
+    v[u] = acc;
+  }
+  __shared__ double smn[4], smx[4];
+  if (normalize) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { mn = fmin(mn, __shfl_xor(mn, o, 64)); mx = fmax(mx, __shfl_xor(mx, o, 64)); }
+    if ((t & 63) == 0) { smn[t >> 6] = mn; smx[t >> 6] = mx; }
+    __syncthreads();
+    mn = fmin(fmin(smn[0], smn[1]), fmin(smn[2], smn[3]));
+    mx = fmax(fmax(smx[0], smx[1]), fmax(smx[2], smx[3]));
+  }
+  const double range = mx - mn;
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    const int j = t + 256 * u;
+    if (j >= out_len) continue;
+    double x = j < L ? v[u] : 0.0;
+    if (normalize && j < L) {
+      x = x > 0.0 ? x : 0.0;                       // clipped AFTER min / max were taken (datasets.py:50-52)
+      x = range == 0.0 ? 0.0 : (x - mn) / range;
+    }
+    out[(int64_t)r * out_len + j] = (float)x;
+  }
+}
+
+extern "C" int afm_mix_spectra(const float* table, int64_t N, int32_t L, const int64_t* idx, int32_t n, int32_t c,
+                               const double* ratio, int32_t normalize, int32_t out_len, float* out, void* stream) {
+  if (!table || !idx || !ratio || !out || N <= 0 || L <= 0 || n <= 0 || c <= 0 || out_len < L) return AFM_ERR_ARG;
+  if (L > 2048 || out_len > 2048) return AFM_ERR_UNSUPPORTED;
+  AFM_LAUNCH(k_mix_spectra, dim3(n), dim3(256), 0, (hipStream_t)stream, table, N, L, idx, c, ratio, normalize, out_len, out);
+  return AFM_OK;
+}

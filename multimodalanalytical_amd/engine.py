@@ -19,7 +19,7 @@ import torch
 
 from . import ops
 from .lib import ACT_GELU, ACT_GELU_BWD, ACT_NONE, ACT_RELU, ALGO_AUTO
-from .params import PATCH_TYPES, TEXT_TYPES, ParamStore, build_specs, patch_layers
+from .params import align_dict, PATCH_TYPES, TEXT_TYPES, ParamStore, build_specs, patch_layers
 
 
 def sincos_table(d_model: int, max_len: int) -> torch.Tensor:
@@ -56,6 +56,8 @@ class Seq2SeqEngine:
         self.norm = bool(self.cfg["multimodal_norm"])
         if not self.norm:
             raise NotImplementedError("multimodal_norm=False is not on the reference's tested path")
+        self.align = align_dict(self.cfg.get("align_config"))
+        self.cfg["align_config"] = self.align
         self.ps = ParamStore(build_specs(self.cfg, data_config, self.V), self.dev,
                              with_bf16=compute_dtype == torch.bfloat16)
         self.ps.init_(seed)
@@ -551,8 +553,65 @@ class Seq2SeqEngine:
         st["t"] = t + 1
         return logits
 
+    def align_head(self, mem, mem_pad, B, S, target, backward: bool, loss_scale: float):
+        """Encoder alignment loss (custom_modeling.py:453-475): masked mean of the encoder output ->
+        Linear/ReLU stack (the two Conv1d layers act on a length-1 sequence: with padding k//2 only the
+        centre tap of the first one sees data) -> sigmoid -> mse / mae / sid.  With `backward` the head's
+        parameter gradients are accumulated (scaled by lambda * loss_scale) and the gradient w.r.t. the
+        encoder output is returned as the INITIAL value of the (B*S, d) fp32 memory gradient."""
+        ac, d = self.align, self.d
+        hid, n_out = int(ac["hidden_dimension"]), int(ac["output_dimension"])
+        conv = ac["align_network"] == "convolutional"
+        P, G = self.ps.p, self.ps.g
+        f32 = dict(dtype=torch.float32, device=self.dev)
+        pooled = torch.empty(B, d, **f32)
+        ops.masked_mean_fwd(mem, mem_pad, B, S, pooled)
+        a0 = torch.empty(B, hid, **f32)
+        ops.gemm(pooled, P("align_network.0.weight"), a0, trans_b=True, bias=P("align_network.0.bias"), act=ACT_RELU)
+        z = torch.empty(B, n_out, **f32)
+        if not conv:
+            ops.gemm(a0, P("align_network.2.weight"), z, trans_b=True, bias=P("align_network.2.bias"))
+        else:
+            C, k = int(ac["conv_channels"]), int(ac["kernel_size"])
+            a1 = torch.empty(B, hid, **f32)
+            ops.gemm(a0, P("align_network.2.weight"), a1, trans_b=True, bias=P("align_network.2.bias"))
+            wc = P("align_network.4.weight").view(C, hid, k)[:, :, k // 2].contiguous()     # centre tap (C, hid)
+            a2 = torch.empty(B, C, **f32)
+            ops.gemm(a1, wc, a2, trans_b=True, bias=P("align_network.4.bias"), act=ACT_RELU)
+            w6 = P("align_network.6.weight").view(n_out, C)
+            ops.gemm(a2, w6, z, trans_b=True, bias=P("align_network.6.bias"))
+        stats = torch.zeros(1, **f32)
+        dz = torch.empty_like(z) if backward else None
+        tgt = target.to(device=self.dev, dtype=torch.float32).contiguous()
+        ops.align_loss(z, tgt, ac["loss_function"], float(ac["loss_lambda"]) * loss_scale, stats, dz)
+        if not backward:
+            return stats[0], None
+
+        def layer_bwd(g, x_in, wname, w, gw_sink=None):
+            """g = dL/d(layer output): accumulates dW, db; returns dL/d(layer input)."""
+            gw = G(wname + "weight") if gw_sink is None else gw_sink
+            ops.gemm(g, x_in, gw.view(g.shape[1], x_in.shape[1]), trans_a=True, trans_b=False, accumulate=True)
+            ops.colsum(g, G(wname + "bias"), accumulate=True)
+            gi = torch.empty(g.shape[0], x_in.shape[1], **f32)
+            ops.gemm(g, w, gi, trans_b=False)
+            return gi
+
+        if not conv:
+            g = layer_bwd(dz, a0, "align_network.2.", P("align_network.2.weight"))
+        else:
+            g = layer_bwd(dz, a2, "align_network.6.", w6) * (a2 > 0)
+            gwc = torch.zeros(C, hid, **f32)
+            g = layer_bwd(g, a1, "align_network.4.", wc, gw_sink=gwc)
+            G("align_network.4.weight").view(C, hid, k)[:, :, k // 2] += gwc     # the other taps only ever see padding
+            g = layer_bwd(g, a0, "align_network.2.", P("align_network.2.weight"))
+        g = g * (a0 > 0)
+        dpooled = layer_bwd(g, pooled, "align_network.0.", P("align_network.0.weight"))
+        dmem = torch.empty(B * S, d, **f32)
+        ops.masked_mean_bwd(dpooled, mem_pad, B, S, dmem, accumulate=False)
+        return stats[0], dmem
+
     def forward(self, enc_inputs, attention_mask, dec_ids, dec_attention_mask=None, labels=None,
-                backward: bool = False, loss_scale: float = 1.0, memory=None):
+                backward: bool = False, loss_scale: float = 1.0, memory=None, encoder_align_target=None):
         """One pass.  With `backward` the parameter gradients are ACCUMULATED into the flat
         gradient buffer (scaled by loss_scale, e.g. 1/acc_batches).  Returns a dict with fp32
         `logits` (B,T,V), `loss` (0-dim device tensor, mean over labels != -100), `argmax`
@@ -566,6 +625,11 @@ class Seq2SeqEngine:
             mem = memory
             mem_pad = (attention_mask == 0).to(torch.uint8).contiguous()
         S = attention_mask.shape[1]
+        align_loss = None
+        if self.align and memory is None and encoder_align_target is not None and (labels is not None or backward):
+            align_loss, dmem0 = self.align_head(mem, mem_pad, B, S, encoder_align_target, backward, loss_scale)
+            if backward:
+                saved["dmem_init"] = dmem0
         logits = self.decode(dec_ids, mem, mem_pad, dec_attention_mask, S, saved)
         out = {"logits": logits.view(B, T, self.V), "encoder_hidden_states": mem.view(B, S, self.d)}
         rows = B * T
@@ -576,6 +640,9 @@ class Seq2SeqEngine:
             stats = torch.zeros(2, dtype=torch.float32, device=self.dev)
             ops.ce_fwd(logits, lab, row_lse, argmax, stats)
             out["loss"] = stats[0] / stats[1]
+            if align_loss is not None:     # total = lm + lambda * align (custom_modeling.py:492-497)
+                out["loss_dict"] = {"model_only_loss": out["loss"], "alignment_loss": align_loss}
+                out["loss"] = out["loss"] + float(self.align["loss_lambda"]) * align_loss
             out["argmax"] = argmax.view(B, T)
             out["loss_stats"] = stats
             if backward:
@@ -601,7 +668,9 @@ class Seq2SeqEngine:
         dhf = self._dgrad(dlog, "token_ff.weight", self.V, d)
         Ld, Le = self.cfg["decoder_layers"], self.cfg["encoder_layers"]
         dx, dy = self._ln_bwd(dhf, "decoder.norm.", saved, "dec_norm", dres=None, next_site=f"d{Ld - 1}res2")
-        dmem = torch.zeros(B * S, d, dtype=torch.float32, device=self.dev)
+        dmem = saved.pop("dmem_init", None)     # alignment head's gradient w.r.t. the encoder output, if any
+        if dmem is None:
+            dmem = torch.zeros(B * S, d, dtype=torch.float32, device=self.dev)
         for i in range(Ld - 1, -1, -1):
             p, sv = f"decoder.layers.{i}.", saved["dec_layers"][i]
             dx, dy = self._ffn_bwd(dx, dy, p, self.cfg["decoder_ffn_dim"], "norm3.", sv, f"d{i}xres")

@@ -88,6 +88,10 @@ _SIGS = {
     "afm_add_inplace": (C.c_int, [_P, _P, _I64, _P]),
     "afm_batch_sum": (C.c_int, [_P, _P, _I32, _I64, _I32, _I32, _P]),
     "afm_cast_bf16": (C.c_int, [_P, _P, _P, _I32, _I32, _P]),
+    "afm_masked_mean_fwd": (C.c_int, [_P, _I32, _P, _I32, _I32, _I32, _P, _P]),
+    "afm_masked_mean_bwd": (C.c_int, [_P, _P, _I32, _I32, _I32, _P, _I32, _P]),
+    "afm_align_loss": (C.c_int, [_P, _P, _I32, _I32, _I32, _F, _P, _P, _P]),
+    "afm_mix_spectra": (C.c_int, [_P, _I64, _I32, _P, _I32, _I32, _P, _I32, _I32, _P, _P]),
     "afm_patch_count": (C.c_int32, [C.POINTER(PatchDesc)]),
     "afm_patch_preprocess": (C.c_int, [C.POINTER(PatchDesc), _P, _P, _P, _P, _P]),
     "afm_ce_fwd": (C.c_int, [_P, _P, _I64, _I32, _I32, _P, _P, _P, _P]),

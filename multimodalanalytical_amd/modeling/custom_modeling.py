@@ -12,7 +12,7 @@ from .utils import CustomLMOutput, DeferredEmbedding, MultimodalEmbedding
 
 
 class AlignConfig:
-    """custom_modeling.py:18-37 (alignment head: SURVEY 8f 'next')."""
+    """custom_modeling.py:18-37."""
 
     def __init__(self, align_network, hidden_dimension, conv_channels, kernel_size, output_dimension,
                  loss_lambda, loss_function):
@@ -59,7 +59,10 @@ class CustomConfig:
         keys = ("d_model max_position_embeddings encoder_layers encoder_attention_heads encoder_ffn_dim "
                 "decoder_layers decoder_attention_heads decoder_ffn_dim dropout gated_linear "
                 "positional_encoding_type").split()
-        return {k: getattr(self, k) for k in keys}
+        out = {k: getattr(self, k) for k in keys}
+        if self.align_config is not None:
+            out["align_config"] = dict(vars(self.align_config))
+        return out
 
 
 class _EncoderHandle:
@@ -82,8 +85,6 @@ class CustomModel:
     def __init__(self, target_modality, target_tokenizer, config: CustomConfig,
                  multimodal_embedding_layer: MultimodalEmbedding, device="cuda:0",
                  compute_dtype=torch.bfloat16, seed: int = 3247):
-        if config.align_config is not None:
-            raise NotImplementedError("encoder alignment head: SURVEY 8f 'next', not built yet")
         self.config = config
         self.target_modality = target_modality
         self.decoder_vocab_size = target_tokenizer.vocab_size
@@ -131,9 +132,10 @@ class CustomModel:
             enc_inputs = inputs_embeds.token_ids
         out = eng.forward(enc_inputs, attention_mask, decoder_input_ids, decoder_attention_mask, labels,
                           backward=self._grad_enabled and labels is not None and not generating,
-                          loss_scale=self._loss_scale, memory=memory)
+                          loss_scale=self._loss_scale, memory=memory,
+                          encoder_align_target=None if generating else encoder_align_target)
         loss = out.get("loss")
-        loss_dict = None if loss is None else {"model_only_loss": loss, "alignment_loss": None}
+        loss_dict = None if loss is None else out.get("loss_dict", {"model_only_loss": loss, "alignment_loss": None})
         return CustomLMOutput(loss=loss, logits=out["logits"], decoder_hidden_states=None,
                               encoder_hidden_states=out["encoder_hidden_states"], loss_dict=loss_dict,
                               argmax=out.get("argmax"))

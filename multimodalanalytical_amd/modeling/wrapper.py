@@ -135,9 +135,12 @@ class HFWrapper:
             attention_mask = torch.concat(split, dim=-1)
         labels[labels == self.target_tokenizer.pad_token_id] = -100
         inputs_embeds = self.multimodal_embedding(input_ids)
+        kwargs = {}
+        if "encoder_alignment_input" in batch:       # wrapper.py:395-396
+            kwargs["encoder_align_target"] = batch["encoder_alignment_input"]
         return self.hf_model(inputs_embeds=inputs_embeds, attention_mask=attention_mask.contiguous(),
                              decoder_input_ids=decoder_input, decoder_attention_mask=decoder_attention_mask.contiguous(),
-                             labels=labels)
+                             labels=labels, **kwargs)
 
     __call__ = forward
 

@@ -225,6 +225,42 @@ def cast_bf16(src, dst=None, dst_t=None):
     L.check(L.load().afm_cast_bf16(_ptr(src), _ptr(dst), _ptr(dst_t), rows, cols, _stream()), "afm_cast_bf16")
 
 
+ALIGN_KINDS = {"mse": 0, "mae": 1, "sid": 2}
+
+
+def masked_mean_fwd(x, key_pad, B, S, out):
+    """out (B, d) fp32 = mean over the kept rows of x (B*S, d); key_pad (B, S) uint8, 1 = pad."""
+    d = x.shape[-1]
+    assert x.is_contiguous() and key_pad.dtype == torch.uint8 and out.dtype == torch.float32
+    L.check(L.load().afm_masked_mean_fwd(_ptr(x), _dt(x), _ptr(key_pad), B, S, d, _ptr(out), _stream()), "afm_masked_mean_fwd")
+
+
+def masked_mean_bwd(dy, key_pad, B, S, dx, accumulate=False):
+    d = dy.shape[-1]
+    assert dy.dtype == torch.float32 and dx.dtype == torch.float32 and dx.is_contiguous()
+    L.check(L.load().afm_masked_mean_bwd(_ptr(dy), _ptr(key_pad), B, S, d, _ptr(dx), int(accumulate), _stream()), "afm_masked_mean_bwd")
+
+
+def align_loss(z, target, kind: str, grad_scale, stats, dz=None):
+    B, n = z.shape
+    assert z.dtype == torch.float32 and target.dtype == torch.float32 and z.is_contiguous() and target.is_contiguous()
+    L.check(L.load().afm_align_loss(_ptr(z), _ptr(target), ALIGN_KINDS[kind], B, n, float(grad_scale), _ptr(stats),
+                                    _ptr(dz), _stream()), "afm_align_loss")
+
+
+def mix_spectra(table, idx, ratio, normalize=False, out_len=1800):
+    """Weighted mixtures of rows of `table` (N, L) fp32: idx (n, c) int64, ratio (c,) float64 -> (n, out_len) fp32."""
+    N, Ln = table.shape
+    n, c = idx.shape
+    assert table.dtype == torch.float32 and table.is_contiguous() and idx.dtype == torch.int64 and idx.is_contiguous()
+    ratio = torch.as_tensor(ratio, dtype=torch.float64, device=table.device).contiguous()
+    assert ratio.numel() == c
+    out = torch.empty(n, out_len, dtype=torch.float32, device=table.device)
+    L.check(L.load().afm_mix_spectra(_ptr(table), N, Ln, _ptr(idx), n, c, _ptr(ratio), int(normalize), out_len, _ptr(out),
+                                     _stream()), "afm_mix_spectra")
+    return out
+
+
 def patch_preprocess(spectra, present, mean, std, patch_size, masking=False, interpolation=False, overlap=1,
                      derivative=False, seq_first=False):
     """PatchPreprocessor.__call__ on the device: spectra (B, L) fp32, present (B,) bool/uint8 or None.

@@ -108,7 +108,31 @@ def build_specs(cfg: Dict[str, Any], data_config: Dict[str, Any], vocab_out: int
         ln(p + "norm1."); ln(p + "norm2."); ln(p + "norm3.")
     ln("decoder.norm.")
     lin("token_ff.", vocab_out, d)
+    # encoder alignment head (custom_modeling.py:363-396), LAST in the flat buffer: its backward runs
+    # first, so "gradients from offset X to the end are final" keeps holding for the DDP bucket hooks
+    ac = align_dict(cfg.get("align_config"))
+    if ac:
+        hid, n_out = int(ac["hidden_dimension"]), int(ac["output_dimension"])
+        lin("align_network.0.", hid, d)
+        if ac["align_network"] == "mlp":
+            lin("align_network.2.", n_out, hid)
+        elif ac["align_network"] == "convolutional":
+            C, k = int(ac["conv_channels"]), int(ac["kernel_size"])
+            lin("align_network.2.", hid, hid)
+            sp.append(Spec("align_network.4.weight", (C, hid, k), "matrix"))
+            sp.append(Spec("align_network.4.bias", (C,), "linear_bias", fan_in=hid * k))
+            sp.append(Spec("align_network.6.weight", (n_out, C, 1), "matrix"))
+            sp.append(Spec("align_network.6.bias", (n_out,), "linear_bias", fan_in=C))
+        else:
+            raise ValueError(f"unknown align_network {ac['align_network']}")
     return sp
+
+
+def align_dict(ac):
+    """AlignConfig object (custom_modeling.py:18-37) or yaml dict -> plain dict (None if absent)."""
+    if not ac:
+        return None
+    return dict(ac) if isinstance(ac, dict) else dict(vars(ac))
 
 
 class ParamStore:
@@ -157,7 +181,8 @@ class ParamStore:
         for s in self.specs.values():
             v = host[s.offset:s.offset + s.numel].view(s.shape)
             if s.kind == "matrix":        # xavier_uniform_ on every parameter with dim > 1
-                fan_out, fan_in = s.shape
+                rf = int(math.prod(s.shape[2:]))            # Conv1d weights: receptive field = kernel size
+                fan_out, fan_in = s.shape[0] * rf, s.shape[1] * rf
                 a = math.sqrt(6.0 / (fan_in + fan_out))
                 v.copy_((torch.rand(s.shape, generator=g) * 2 - 1) * a)
             elif s.kind == "linear_bias":  # nn.Linear default: U(+-1/sqrt(fan_in))

@@ -107,3 +107,59 @@ class DeviceCollator:
         return {"encoder_input": enc, "encoder_pad_mask": torch.cat(masks, 0),
                 "decoder_input": {self.target_modality: ids[:-1, :]}, "decoder_pad_mask": pad[:-1, :],
                 "target": ids.clone()[1:, :], "target_mask": pad.clone()[1:, :]}
+
+
+def mix_indices(n_rows: int, mix_config: dict, split: str, seed: int = 3247):
+    """Index stream of the reference's `mix_spectra` generator (data/datasets.py:59-116): numpy global RNG
+    seeded once, `np.random.choice(range(n_rows), (parallel_samples, n_compounds))` per round, duplicates
+    removed with `np.unique(axis=0)`, rows repeating a compound dropped, stop once
+    `n * parallel + parallel >= perm(n_rows, n_compounds)`."""
+    import math
+    np.random.seed(seed)
+    nc, par = mix_config["n_compounds"], mix_config["parallel_samples"]
+    max_n = mix_config[f"{split}_max_n_samples"]
+    if max_n // par < 1:
+        par = max_n
+    expected = math.perm(n_rows, nc)
+    a = list(range(n_rows))
+    for n in range(max_n // par):
+        ri = np.unique(np.random.choice(a, size=(par, nc)), axis=0)
+        ri = ri[np.array([len(set(row)) == len(row) for row in ri])]
+        if n * par + par >= expected:
+            break
+        yield ri
+
+
+class MixtureGenerator:
+    """Device-side counterpart of `mix_spectra` (data/datasets.py:58-141) over a spectra table resident in
+    HBM: the index stream stays on the host (numpy RNG, as the reference), the weighted average /
+    normalisation / padding of every round runs in one `afm_mix_spectra` launch.  Each round yields
+
+        indices      (n, n_compounds) int64   rows of the table that were mixed
+        IR           (n * k, 1800) fp32        the mixed spectrum, repeated for each compound with ratio > 0
+        compound     (n * k,) int64            table row whose Smiles / Formula is the target of that record
+        IR_target    (n * k, L) fp32           the pure spectrum of that compound (the alignment target)
+        Percentage   (n * k,) float64
+
+    in the reference's record order (for idx in indices: for i in compounds)."""
+
+    def __init__(self, table: torch.Tensor, mix_config: dict, split: str = "train", seed: int = 3247):
+        self.table, self.cfg, self.split, self.seed = table, dict(mix_config), split, seed
+        nc = self.cfg["n_compounds"]
+        ratio = self.cfg.get("compounds_ratio") or [1 / nc] * nc
+        if len(ratio) != nc or sum(ratio) != 1:
+            raise ValueError(f"Invalid compound ratios: expected {nc} compounds with ratios summing to 1.")
+        self.ratio = list(ratio)
+
+    def __iter__(self):
+        dev = self.table.device
+        keep = [i for i, r in enumerate(self.ratio) if r != 0]
+        for ri in mix_indices(self.table.shape[0], self.cfg, self.split, self.seed):
+            if len(ri) == 0:
+                continue
+            idx = torch.from_numpy(np.ascontiguousarray(ri)).to(dev)
+            mixed = ops.mix_spectra(self.table, idx, self.ratio, normalize=bool(self.cfg.get("normalize", False)))
+            comp = idx[:, keep].reshape(-1)
+            yield {"indices": ri, "IR": mixed.repeat_interleave(len(keep), dim=0), "compound": comp,
+                   "IR_target": self.table[comp],
+                   "Percentage": torch.tensor([self.ratio[i] for i in keep] * len(ri), dtype=torch.float64)}

@@ -237,11 +237,42 @@ def cross_entropy(logits: torch.Tensor, labels: torch.Tensor) -> torch.Tensor:
     return ((lse - picked) * keep).sum() / keep.sum()
 
 
+def align_head(sd: Dict[str, torch.Tensor], acfg: Dict[str, Any], memory: torch.Tensor,
+               attention_mask: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
+    """Encoder alignment loss (custom_modeling.py:363-396 network, 453-475 use): masked mean of the
+    encoder output over kept tokens -> MLP (or Linear-ReLU-Linear-Conv1d-ReLU-Conv1d on a length-1
+    sequence: with padding k//2 only the centre tap of the first convolution sees data) -> sigmoid ->
+    mse / mae / sid against the (B, output_dimension) target spectrum."""
+    mask = attention_mask.to(memory.dtype).unsqueeze(-1)
+    pooled = (memory * mask).sum(dim=1) / mask.sum(dim=1)
+    h = torch.relu(linear(pooled, sd["align_network.0.weight"], sd["align_network.0.bias"]))
+    if acfg["align_network"] == "mlp":
+        z = linear(h, sd["align_network.2.weight"], sd["align_network.2.bias"])
+    else:
+        h = linear(h, sd["align_network.2.weight"], sd["align_network.2.bias"])
+        k = acfg["kernel_size"]
+        h = torch.relu(linear(h, sd["align_network.4.weight"][:, :, k // 2], sd["align_network.4.bias"]))
+        z = linear(h, sd["align_network.6.weight"][:, :, 0], sd["align_network.6.bias"])
+    pred = torch.sigmoid(z)
+    fn = acfg["loss_function"]
+    if fn == "mse":
+        return ((pred - target) ** 2).mean()
+    if fn == "mae":
+        return (pred - target).abs().mean()
+    if fn == "sid":   # the reference's OWN kl_div (modeling/utils.py:8-22), not F.kl_div: both arguments are
+        # clamped to >= 1e-16, kl = p * log(p / q), "batchmean" = sum / B; sid = kl(pred, t) + kl(t, pred)
+        B = pred.shape[0]
+        p, q = pred.clamp(min=1e-16), target.clamp(min=1e-16)
+        return (p * (p / q).log()).sum() / B + (q * (q / p).log()).sum() / B
+    raise ValueError(f"Loss function {fn} not supported for alignment")
+
+
 def model_forward(
     sd: Dict[str, torch.Tensor], cfg: Dict[str, Any], data_config: Dict[str, Any],
     target_modality: str, enc_inputs: Dict[str, Any], attention_mask: torch.Tensor,
     dec_ids: torch.Tensor, dec_attention_mask: Optional[torch.Tensor],
     labels: Optional[torch.Tensor] = None, memory: Optional[torch.Tensor] = None,
+    encoder_align_target: Optional[torch.Tensor] = None,
 ) -> Dict[str, Any]:
     """HFWrapper.forward's model call (wrapper.py:392-405) -> CustomModel.forward
     (custom_modeling.py:420-508).  Batch-first inputs; labels already hold -100 on pads."""
@@ -255,6 +286,10 @@ def model_forward(
     out = {"logits": logits, "encoder_hidden_states": memory, "decoder_hidden_states": dec}
     if labels is not None:
         out["loss"] = cross_entropy(logits, labels)
+        if cfg.get("align_config") and encoder_align_target is not None:   # total = lm + lambda * align
+            al = align_head(sd, cfg["align_config"], memory, attention_mask, encoder_align_target)
+            out["loss_dict"] = {"model_only_loss": out["loss"], "alignment_loss": al}
+            out["loss"] = out["loss"] + cfg["align_config"]["loss_lambda"] * al
     return out
 
 
@@ -355,8 +390,9 @@ class OracleTrainer:
         self.step_count = 0
         self.micro = 0
 
-    def micro_batch(self, enc, am, dec_ids, dm, labels) -> Dict[str, Any]:
-        out = model_forward(self.sd, self.cfg, self.dc, self.tm, enc, am, dec_ids, dm, labels)
+    def micro_batch(self, enc, am, dec_ids, dm, labels, encoder_align_target=None) -> Dict[str, Any]:
+        out = model_forward(self.sd, self.cfg, self.dc, self.tm, enc, am, dec_ids, dm, labels,
+                            encoder_align_target=encoder_align_target)
         (out["loss"] / self.acc).backward()
         self.micro += 1
         if self.micro % self.acc == 0:
@@ -460,3 +496,51 @@ def patch_preprocess(spectra, present, mean: float, std: float, patch_size: int,
     else:
         mask = np.repeat(~present[:, None], patched.shape[1], axis=1)
     return patched.astype(np.float32), mask
+
+
+def normalize_spectrum(spectrum):
+    """data/datasets.py:49-56, list arithmetic in Python floats: min / max are taken BEFORE the negatives
+    are clipped, then (x - min) / (max - min); a flat spectrum becomes zeros."""
+    mn, mx = min(spectrum), max(spectrum)
+    spectrum = [max(0, x) for x in spectrum]
+    if mx - mn == 0:
+        return [0] * len(spectrum)
+    return [(x - mn) / (mx - mn) for x in spectrum]
+
+
+def mix_indices(n_rows: int, mix_config: Dict[str, Any], split: str, seed: int = 3247):
+    """The index stream of mix_spectra (data/datasets.py:59-116): np.random.seed(seed); per round
+    np.random.choice(range(n_rows), (parallel_samples, n_compounds)), np.unique(axis=0), rows with a
+    repeated compound dropped; stops when n * parallel + parallel >= perm(n_rows, n_compounds)."""
+    import math
+    import numpy as np
+    np.random.seed(seed)
+    nc, par = mix_config["n_compounds"], mix_config["parallel_samples"]
+    max_n = mix_config[f"{split}_max_n_samples"]
+    if max_n // par < 1:
+        par = max_n
+    expected = math.perm(n_rows, nc)
+    a = list(range(n_rows))
+    for n in range(max_n // par):
+        ri = np.unique(np.random.choice(a, size=(par, nc)), axis=0)
+        ri = ri[np.array([len(set(row)) == len(row) for row in ri])]
+        if n * par + par >= expected:
+            break
+        yield ri
+
+
+def mix_spectra(table, idx, ratio, normalize: bool, out_len: int = 1800):
+    """The spectrum arithmetic of mix_spectra (data/datasets.py:118-126): np.average(rows, weights=ratio,
+    axis=0) in float64, optional normalize_spectrum, zero padding to 1800; float32 at the end (the
+    collator's torch.Tensor).  PARITY UNPINNED (module not importable here: omegaconf missing)."""
+    import numpy as np
+    table = np.asarray(table)
+    out = np.zeros((len(idx), out_len), dtype=np.float32)
+    for r, row in enumerate(idx):
+        spectra = [table[s].astype(np.float64).tolist() for s in row]
+        comb = np.average(spectra, weights=ratio, axis=0).tolist()
+        if normalize:
+            comb = normalize_spectrum(comb)
+        comb = comb + [0] * (out_len - len(comb))
+        out[r] = np.asarray(comb, dtype=np.float64).astype(np.float32)
+    return out

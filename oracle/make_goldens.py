@@ -25,7 +25,7 @@ import numpy as np
 import torch
 
 sys.path.insert(0, "/root/reference/src")
-from analytical_fm.modeling.custom_modeling import CustomConfig, CustomModel  # noqa: E402
+from analytical_fm.modeling.custom_modeling import AlignConfig, CustomConfig, CustomModel  # noqa: E402
 from analytical_fm.modeling.utils import MultimodalEmbedding  # noqa: E402
 
 OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden")
@@ -40,7 +40,10 @@ class Tok:
 
 def build(cfg_kwargs, data_config, target="Smiles"):
     torch.manual_seed(SEED)
-    cfg = CustomConfig(**cfg_kwargs)
+    kw = dict(cfg_kwargs)
+    if kw.get("align_config"):   # load_custom_model converts the yaml dict (wrapper.py:164-165)
+        kw["align_config"] = AlignConfig(**kw["align_config"])
+    cfg = CustomConfig(**kw)
     emb = MultimodalEmbedding(data_config, cfg.d_model, True, do_positional_encodings=True,
                               positional_encodings_type=cfg.positional_encoding_type,
                               max_seq_len=cfg.max_position_embeddings)
@@ -110,8 +113,11 @@ def wrapper_forward(model, emb, batch, train=True):
     labels = batch["target"].T.contiguous().clone()
     labels[labels == 0] = -100
     model.train(train)
+    kwargs = {}
+    if "encoder_alignment_input" in batch:      # wrapper.py:395-396
+        kwargs["encoder_align_target"] = batch["encoder_alignment_input"]
     out = model(inputs_embeds=emb(input_ids), attention_mask=am, decoder_input_ids=dec_in,
-                decoder_attention_mask=dm, labels=labels)
+                decoder_attention_mask=dm, labels=labels, **kwargs)
     return out
 
 
@@ -158,6 +164,12 @@ def dump_model_case(name, cfg_kwargs, data_config, lens, T, B=4, full_mask=None,
         out[f"sd/{k}"] = v.numpy()
     batches = [make_batch(rng, data_config, B, lens, T, full_mask if i == 1 else None)
                for i in range(4)]
+    if cfg_kwargs.get("align_config"):
+        n_out = cfg_kwargs["align_config"]["output_dimension"]
+        for b in batches:            # min-max normalised target spectra: values in [0, 1] with exact zeros
+            t = rng.random((B, n_out)).astype(np.float32)
+            t[:, ::7] = 0.0
+            b["encoder_alignment_input"] = torch.from_numpy(t)
     for i, b in enumerate(batches):
         for m, v in b["encoder_input"].items():
             out[f"b{i}/encoder_input/{m}"] = v.numpy()
@@ -165,6 +177,8 @@ def dump_model_case(name, cfg_kwargs, data_config, lens, T, B=4, full_mask=None,
         out[f"b{i}/decoder_input/Smiles"] = b["decoder_input"]["Smiles"].numpy()
         out[f"b{i}/decoder_pad_mask"] = b["decoder_pad_mask"].numpy()
         out[f"b{i}/target"] = b["target"].numpy()
+        if "encoder_alignment_input" in b:
+            out[f"b{i}/encoder_alignment_input"] = b["encoder_alignment_input"].numpy()
     # forward / backward per micro-batch (train mode, dropout 0)
     for i, b in enumerate(batches):
         model.zero_grad()
@@ -175,6 +189,9 @@ def dump_model_case(name, cfg_kwargs, data_config, lens, T, B=4, full_mask=None,
         out[f"b{i}/argmax"] = o.logits.argmax(-1).numpy()
         out[f"b{i}/token_acc"] = token_acc(b, o.logits).numpy()
         out[f"b{i}/encoder_hidden_states"] = o.encoder_hidden_states.detach().numpy()
+        if cfg_kwargs.get("align_config"):
+            out[f"b{i}/model_only_loss"] = o.loss_dict["model_only_loss"].detach().numpy()
+            out[f"b{i}/alignment_loss"] = o.loss_dict["alignment_loss"].detach().numpy()
         if i == 0:
             for n, p in model.named_parameters():
                 if n.startswith("decoder.embedding."):
@@ -302,6 +319,7 @@ if __name__ == "__main__":
     if "--only-patches" in sys.argv:
         dump_patches()
         sys.exit(0)
+    ONLY_ALIGN = "--only-align" in sys.argv
     dc_plain = {
         "Formula": {"type": "text", "vocab_size": 45, "pad_token_id": 0, "target": False},
         "IR": {"type": "1D_patches", "target": False,
@@ -311,7 +329,8 @@ if __name__ == "__main__":
     base = dict(d_model=64, max_position_embeddings=128, encoder_layers=2, decoder_layers=2,
                 encoder_attention_heads=4, decoder_attention_heads=4, encoder_ffn_dim=128,
                 decoder_ffn_dim=128, dropout=0.0)
-    dump_model_case("model_plain", dict(base), dc_plain, {"Formula": 10, "IR": 14}, T=20)
+    if not ONLY_ALIGN:
+        dump_model_case("model_plain", dict(base), dc_plain, {"Formula": 10, "IR": 14}, T=20)
     dc_multi = {
         "Formula": {"type": "text", "vocab_size": 45, "pad_token_id": 0, "target": False},
         "IR": {"type": "1D_patches", "target": False,
@@ -320,10 +339,22 @@ if __name__ == "__main__":
         "Carbon": {"type": "carbon", "vocab_size": 50, "pad_token_id": 0, "target": False},
         "Smiles": {"type": "text", "vocab_size": 26, "pad_token_id": 0, "target": True},
     }
-    dump_model_case("model_gated_learned",
-                    dict(base, gated_linear=True, positional_encoding_type="learned"),
-                    dc_multi, {"Formula": 8, "IR": 6, "Multiplets": 17, "Carbon": 9}, T=16,
-                    full_mask=("Multiplets", 2))
+    if not ONLY_ALIGN:
+        dump_model_case("model_gated_learned",
+                        dict(base, gated_linear=True, positional_encoding_type="learned"),
+                        dc_multi, {"Formula": 8, "IR": 6, "Multiplets": 17, "Carbon": 9}, T=16,
+                        full_mask=("Multiplets", 2))
+    al = dict(hidden_dimension=32, conv_channels=8, kernel_size=3, output_dimension=40, loss_lambda=0.5)
+    dc_small = {k: dc_plain[k] for k in ("Formula", "IR", "Smiles")}
+    small = dict(base, encoder_layers=1, decoder_layers=1)
+    dump_model_case("model_align_mlp_mse", dict(small, align_config=dict(al, align_network="mlp", loss_function="mse")),
+                    dc_small, {"Formula": 10, "IR": 14}, T=12)
+    dump_model_case("model_align_conv_sid", dict(small, align_config=dict(al, align_network="convolutional", loss_function="sid")),
+                    dc_small, {"Formula": 10, "IR": 14}, T=12, full_mask=None)
+    dump_model_case("model_align_mlp_mae", dict(small, align_config=dict(al, align_network="mlp", loss_function="mae")),
+                    dc_small, {"Formula": 10, "IR": 14}, T=12)
+    if ONLY_ALIGN:
+        sys.exit(0)
     dump_embed_variants()
     dump_schedule()
     dump_patches()

@@ -38,6 +38,7 @@ def batch_of(tree, i):
         "decoder_input": dict(b["decoder_input"]),
         "decoder_pad_mask": b["decoder_pad_mask"],
         "target": b["target"],
+        **({"encoder_alignment_input": b["encoder_alignment_input"]} if "encoder_alignment_input" in b else {}),
     }
 
 

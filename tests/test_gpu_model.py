@@ -13,6 +13,7 @@ from tests import golden_io as G  # noqa: E402
 
 DEV = "cuda:0"
 CASES = ["model_plain", "model_gated_learned"]
+ALIGN_CASES = ["model_align_mlp_mse", "model_align_conv_sid", "model_align_mlp_mae"]
 
 
 def _engine(t, cfg, dtype, **kw):
@@ -33,18 +34,26 @@ def _inputs(t, i):
     return to(enc), am.to(DEV), dec.to(DEV), dm.to(DEV), labels.to(DEV)
 
 
+def _align_kw(t, i):
+    b = t[f"b{i}"]
+    return {"encoder_align_target": b["encoder_alignment_input"].to(DEV)} if "encoder_alignment_input" in b else {}
+
+
 def rel_err(got, ref):
     return float((got.double() - ref.double()).abs().max() / ref.double().abs().max())
 
 
-@pytest.mark.parametrize("name", CASES)
+@pytest.mark.parametrize("name", CASES + ALIGN_CASES)
 def test_fp32_forward_backward_vs_reference_golden(name):
     t = G.load(name); cfg = G.model_cfg(t["meta"])
     eng = _engine(t, cfg, torch.float32)
     for i in range(4):
         eng.ps.grad.zero_()
-        out = eng.forward(*_inputs(t, i), backward=(i == 0))
+        out = eng.forward(*_inputs(t, i), backward=(i == 0), **_align_kw(t, i))
         ref = t[f"b{i}"]
+        if "alignment_loss" in ref:   # CustomLMOutput.loss_dict (custom_modeling.py:494-497)
+            torch.testing.assert_close(out["loss_dict"]["alignment_loss"].cpu(), ref["alignment_loss"], rtol=2e-5, atol=1e-5)
+            torch.testing.assert_close(out["loss_dict"]["model_only_loss"].cpu(), ref["model_only_loss"], rtol=1e-5, atol=1e-5)
         assert rel_err(out["logits"].cpu(), ref["logits"]) < 1e-4          # north-star bar: 1e-3
         torch.testing.assert_close(out["loss"].cpu(), ref["loss"], rtol=1e-5, atol=1e-5)
         assert torch.equal(out["argmax"].cpu(), ref["argmax"])               # bit-exact token ids
@@ -55,7 +64,7 @@ def test_fp32_forward_backward_vs_reference_golden(name):
                 assert float((got - g).abs().max()) <= 2e-4 * float(g.abs().max()) + 2e-6, k
 
 
-@pytest.mark.parametrize("name", CASES)
+@pytest.mark.parametrize("name", CASES + ALIGN_CASES)
 def test_fp32_two_optimizer_steps_vs_reference_golden(name):
     from multimodalanalytical_amd.optim import FusedAdamOneCycle
     t = G.load(name); cfg = G.model_cfg(t["meta"]); m = t["meta"]
@@ -64,7 +73,7 @@ def test_fp32_two_optimizer_steps_vs_reference_golden(name):
                             clip_grad=m["clip"])
     for step in (1, 2):
         for i in range(4):
-            eng.forward(*_inputs(t, i), backward=True, loss_scale=1.0 / m["acc_batches"])
+            eng.forward(*_inputs(t, i), backward=True, loss_scale=1.0 / m["acc_batches"], **_align_kw(t, i))
         opt.step()
         torch.testing.assert_close(opt.grad_norm().cpu(), t[f"step{step}"]["grad_norm"], rtol=1e-4, atol=1e-6)
         for k, ref in t[f"step{step}"].items():
@@ -77,13 +86,13 @@ def test_fp32_two_optimizer_steps_vs_reference_golden(name):
             torch.testing.assert_close(got, ref, rtol=2e-4, atol=1e-5, msg=lambda s: f"step{step} {k}: {s}")
 
 
-@pytest.mark.parametrize("name", CASES)
+@pytest.mark.parametrize("name", CASES + ALIGN_CASES)
 def test_bf16_forward_backward_vs_reference_golden(name):
     t = G.load(name); cfg = G.model_cfg(t["meta"])
     eng = _engine(t, cfg, torch.bfloat16)
     for i in range(4):
         eng.ps.grad.zero_()
-        out = eng.forward(*_inputs(t, i), backward=(i == 0))
+        out = eng.forward(*_inputs(t, i), backward=(i == 0), **_align_kw(t, i))
         ref = t[f"b{i}"]
         err = (out["logits"].cpu().double() - ref["logits"].double()).abs().max()
         assert float(err / ref["logits"].abs().max()) < 3e-2
@@ -132,7 +141,7 @@ def _dev_batch(t, i):
     return to_device(G.batch_of(t, i), DEV)
 
 
-@pytest.mark.parametrize("name", CASES)
+@pytest.mark.parametrize("name", CASES + ALIGN_CASES[:2])
 def test_wrapper_batch_contract_token_acc_and_greedy_vs_reference_golden(name):
     """HFWrapper surface (seq-first batch dict in, CustomLMOutput out), `_calc_token_acc` incl. its quirk,
     and greedy generate against ids produced by looping the REFERENCE's forward."""
@@ -146,7 +155,10 @@ def test_wrapper_batch_contract_token_acc_and_greedy_vs_reference_golden(name):
         assert rel_err(out.logits.cpu(), ref["logits"]) < 1e-4
         torch.testing.assert_close(out.loss.cpu(), ref["loss"], rtol=1e-5, atol=1e-5)
         torch.testing.assert_close(w._calc_token_acc(b, out).cpu(), ref["token_acc"])
-        assert out.loss_dict["alignment_loss"] is None
+        if "alignment_loss" in ref:    # batch["encoder_alignment_input"] -> encoder_align_target (wrapper.py:395-396)
+            torch.testing.assert_close(out.loss_dict["alignment_loss"].cpu(), ref["alignment_loss"], rtol=2e-5, atol=1e-5)
+        else:
+            assert out.loss_dict["alignment_loss"] is None
     w.max_length = t["meta"]["greedy_max_length"]
     ids = w.generate(_dev_batch(t, 0), n_beams=1)
     assert torch.equal(ids.cpu(), t["greedy"]["ids"])

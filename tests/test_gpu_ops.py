@@ -631,3 +631,81 @@ def test_device_collator_batch_dict(ops):
     assert torch.equal(out["target"].cpu(), torch.from_numpy(t_ids.T[1:]))
     assert torch.equal(out["decoder_pad_mask"].cpu(), torch.from_numpy(t_att.T[:-1] == 0))
     assert torch.equal(out["target_mask"].cpu(), torch.from_numpy(t_att.T[1:] == 0))
+
+
+# ---------------------------------------------------------------- alignment head
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_masked_mean_fwd_bwd(ops, dt):
+    B, S, d = 5, 77, 96
+    x = rnd(B * S, d, seed=1)
+    if dt == torch.bfloat16:
+        x = x.bfloat16().float()
+    pad = torch.rand(B, S, generator=torch.Generator().manual_seed(2)) < 0.3
+    pad[:, 0] = False
+    keep = (~pad).double().unsqueeze(-1)
+    ref = (x.double().view(B, S, d) * keep).sum(1) / keep.sum(1)
+    out = torch.empty(B, d, device=DEV)
+    ops.masked_mean_fwd(dev(x, dt), pad.to(torch.uint8).to(DEV), B, S, out)
+    close(out, ref, 1e-5, 1e-6)
+    dy = rnd(B, d, seed=3)
+    dx = torch.full((B * S, d), 7.0, device=DEV)
+    ops.masked_mean_bwd(dev(dy), pad.to(torch.uint8).to(DEV), B, S, dx, accumulate=False)
+    refdx = (dy.double().unsqueeze(1) * keep / keep.sum(1, keepdim=True)).view(B * S, d)
+    close(dx, refdx, 1e-6, 1e-7)
+    ops.masked_mean_bwd(dev(dy), pad.to(torch.uint8).to(DEV), B, S, dx, accumulate=True)
+    close(dx, 2 * refdx, 1e-6, 1e-7)
+
+
+@pytest.mark.parametrize("kind", ["mse", "mae", "sid"])
+def test_align_loss_and_gradient(ops, kind):
+    """sigmoid + loss (nn.MSELoss / nn.L1Loss / the reference's own kl_div pair, modeling/utils.py:8-22) and d/dz."""
+    B, n = 6, 50
+    z = rnd(B, n, seed=1)
+    t = torch.rand(B, n, generator=torch.Generator().manual_seed(2))
+    t[:, ::7] = 0.0
+    zr = z.double().requires_grad_(True)
+    acfg = {"align_network": "mlp", "loss_function": kind}
+    p = torch.sigmoid(zr)
+    if kind == "mse": loss = ((p - t.double()) ** 2).mean()
+    elif kind == "mae": loss = (p - t.double()).abs().mean()
+    else:
+        pc, tc = p.clamp(min=1e-16), t.double().clamp(min=1e-16)
+        loss = (pc * (pc / tc).log()).sum() / B + (tc * (tc / pc).log()).sum() / B
+    loss.backward()
+    stats = torch.zeros(1, device=DEV); dz = torch.empty(B, n, device=DEV)
+    ops.align_loss(dev(z), dev(t), kind, 0.25, stats, dz)
+    close(stats[0], loss.detach(), 2e-5, 1e-6)
+    close(dz, 0.25 * zr.grad, 2e-4, 1e-7)
+
+
+@pytest.mark.parametrize("normalize", [False, True])
+@pytest.mark.parametrize("N,Ln,nc,ratio", [(40, 1800, 2, [0.5, 0.5]), (25, 1791, 3, [0.2, 0.5, 0.3]), (9, 300, 2, [0.9, 0.1])])
+def test_mix_spectra_vs_oracle(ops, normalize, N, Ln, nc, ratio):
+    """afm_mix_spectra vs the numpy restatement of data/datasets.py:49-56,118-126 (parity unpinned: see header)."""
+    from oracle import afm_oracle as Orc
+    rng = np.random.default_rng(N + Ln)
+    table = rng.standard_normal((N, Ln)).astype(np.float32)      # negatives exercise the clip-after-min/max quirk
+    table[3] = 0.25                                                # flat rows: mixture of two of them normalises to zeros
+    table[4] = 0.25
+    idx = rng.integers(0, N, (17, nc)).astype(np.int64)
+    idx[0, :] = [3, 4, 3][:nc]
+    ref = Orc.mix_spectra(table, idx, ratio, normalize)
+    out = ops.mix_spectra(torch.from_numpy(table).to(DEV), torch.from_numpy(idx).to(DEV), ratio, normalize=normalize)
+    assert torch.equal(out.cpu(), torch.from_numpy(ref))
+
+
+def test_mixture_generator_records(ops):
+    from multimodalanalytical_amd.preprocess import MixtureGenerator
+    from oracle import afm_oracle as Orc
+    rng = np.random.default_rng(5)
+    table = np.abs(rng.standard_normal((12, 1800))).astype(np.float32)
+    cfg = dict(n_compounds=2, compounds_ratio=[0.5, 0.5], parallel_samples=8, train_max_n_samples=16, normalize=True)
+    rounds = list(MixtureGenerator(torch.from_numpy(table).to(DEV), cfg, "train"))
+    ref_rounds = list(Orc.mix_indices(12, cfg, "train"))
+    assert len(rounds) == len(ref_rounds) > 0
+    for got, ri in zip(rounds, ref_rounds):
+        assert np.array_equal(got["indices"], ri)
+        ref = Orc.mix_spectra(table, ri, [0.5, 0.5], True)
+        assert torch.equal(got["IR"].cpu(), torch.from_numpy(ref).repeat_interleave(2, dim=0))
+        assert torch.equal(got["compound"].cpu(), torch.from_numpy(ri.reshape(-1)))
+        assert torch.equal(got["IR_target"].cpu(), torch.from_numpy(table[ri.reshape(-1)]))

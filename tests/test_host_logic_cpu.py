@@ -79,3 +79,18 @@ def test_dropmask_helpers_are_consistent():
     k16, scale = keep_mask16(0.1, 123, 4, 200000)
     assert abs(k16.mean() - 0.9) < 0.005 and abs(scale - 1 / 0.9) < 1e-3
     assert keep_mask(0.0, 1, 1, 10).all()
+
+
+def test_mixture_index_stream_matches_oracle_restatement():
+    """preprocess.mix_indices (host side of the mixture generator) == the oracle's restatement of
+    data/datasets.py:59-116 for the same seed; both follow numpy's global RNG as the reference does."""
+    import numpy as np
+    from multimodalanalytical_amd.preprocess import mix_indices
+    from oracle import afm_oracle as O
+    cfg = dict(n_compounds=2, compounds_ratio=None, parallel_samples=16, train_max_n_samples=64, normalize=True)
+    a = list(mix_indices(30, cfg, "train", seed=3247))
+    b = list(O.mix_indices(30, cfg, "train", seed=3247))
+    assert len(a) == len(b) == 4 and all(np.array_equal(x, y) for x, y in zip(a, b))
+    assert all((r[:, 0] != r[:, 1]).all() for r in a)
+    cfg3 = dict(n_compounds=3, parallel_samples=100, train_max_n_samples=10, normalize=False)
+    assert [len(x) for x in mix_indices(5, cfg3, "train")] == [len(x) for x in O.mix_indices(5, cfg3, "train")]

@@ -9,7 +9,7 @@ import torch
 from oracle import afm_oracle as O
 from tests import golden_io as G
 
-CASES = ["model_plain", "model_gated_learned"]
+CASES = ["model_plain", "model_gated_learned", "model_align_mlp_mse", "model_align_conv_sid", "model_align_mlp_mae"]
 
 
 @pytest.fixture(scope="module", params=CASES)
@@ -19,8 +19,10 @@ def case(request):
 
 
 def _fwd(t, cfg, i, sd=None):
-    enc, am, dec, dm, labels = O.batch_to_model_inputs(G.batch_of(t, i), "Smiles")
-    return O.model_forward(sd or t["sd"], cfg, t["meta"]["data_config"], "Smiles", enc, am, dec, dm, labels)
+    b = G.batch_of(t, i)
+    enc, am, dec, dm, labels = O.batch_to_model_inputs(b, "Smiles")
+    return O.model_forward(sd or t["sd"], cfg, t["meta"]["data_config"], "Smiles", enc, am, dec, dm, labels,
+                           encoder_align_target=b.get("encoder_alignment_input"))
 
 
 def test_forward_logits_loss_argmax(case):
@@ -34,6 +36,9 @@ def test_forward_logits_loss_argmax(case):
         torch.testing.assert_close(out["encoder_hidden_states"], ref["encoder_hidden_states"], rtol=1e-5, atol=2e-6)
         acc = O.token_accuracy(out["logits"], ref["target"].T)
         torch.testing.assert_close(acc, ref["token_acc"])
+        if cfg.get("align_config"):     # loss_dict of CustomLMOutput (custom_modeling.py:494-497)
+            torch.testing.assert_close(out["loss_dict"]["alignment_loss"], ref["alignment_loss"], rtol=1e-5, atol=1e-6)
+            torch.testing.assert_close(out["loss_dict"]["model_only_loss"], ref["model_only_loss"], rtol=1e-6, atol=1e-6)
 
 
 def test_backward_grads(case):
@@ -54,7 +59,8 @@ def test_two_optimizer_steps(case):
                          clip=m["clip"])
     for step in (1, 2):
         for i in range(4):
-            tr.micro_batch(*O.batch_to_model_inputs(G.batch_of(t, i), "Smiles"))
+            b = G.batch_of(t, i)
+            tr.micro_batch(*O.batch_to_model_inputs(b, "Smiles"), encoder_align_target=b.get("encoder_alignment_input"))
         torch.testing.assert_close(tr.last_norm, t[f"step{step}"]["grad_norm"], rtol=1e-5, atol=1e-6)
         for k, ref in t[f"step{step}"].items():
             if k == "grad_norm":
