@@ -106,6 +106,101 @@ __global__ __launch_bounds__(256) void k_gemm_generic(GemmArgs g) {
   }
 }
 
+// ---------------------------------------------------------------- skinny shapes of the patch embedders
+// The IR-only workload embeds 992 two-point patches per sample: the "GEMM" is (B*992 x 2) @ (2 x 512),
+// an HBM-bound outer product that writes 260 MB, and its weight gradient is a 512 x 2 reduction over
+// 127 k rows.  The 64 x 64 tile kernel above runs both at < 1 TB/s; these two stream them.
+//
+// forward:  C[m][n] = act(sum_{k < K <= 8} A[m][k] B(k, n) + bias[n]),  fp32, same FMA order as k_gemm_generic
+template <int KMAX>
+__global__ __launch_bounds__(256) void k_gemm_skinny_k(GemmArgs g, int rows_per_block) {
+  const int nq = g.N >> 2;                      // column quads
+  const int cq = threadIdx.x % nq, rsub = threadIdx.x / nq, rstep = 256 / nq;
+  float b[KMAX][4], bias4[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int k = 0; k < KMAX; ++k)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      b[k][j] = k < g.K ? ((const float*)g.B)[k * g.sbk + (int64_t)(cq * 4 + j) * g.sbn] : 0.f;
+  if (g.bias) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) bias4[j] = g.bias[cq * 4 + j];
+  }
+  const int m0 = blockIdx.x * rows_per_block;
+  for (int r = rsub; r < rows_per_block; r += rstep) {
+    const int m = m0 + r;
+    if (m >= g.M) break;
+    const float* arow = (const float*)g.A + (int64_t)m * g.sam;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
+      if (k < g.K) {
+        const float a = arow[k];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] += a * b[k][j];
+      }
+    }
+    f32x4 v;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float x = acc[j] + bias4[j];
+      if (g.act == AFM_ACT_RELU) x = fmaxf(x, 0.f);
+      v[j] = x;
+    }
+    *(f32x4*)((float*)g.C + (int64_t)m * g.ldc + cq * 4) = v;
+  }
+}
+
+// wgrad:  C[m][n] += sum_k A[k][m] B[k][n]  (N <= 8),  optional a_colsum[m] += sum_k A[k][m];  fp32 atomics
+template <int NMAX>
+__global__ __launch_bounds__(256) void k_gemm_skinny_n(GemmArgs g, float* a_colsum, int rows_per_block) {
+  __shared__ float bs[64][NMAX];
+  const int k0 = blockIdx.x * rows_per_block;
+  const int kend = min(g.K, k0 + rows_per_block);
+  for (int mbase = blockIdx.y * 256; mbase < g.M; mbase += gridDim.y * 256) {
+    const int m = mbase + threadIdx.x;
+    float acc[NMAX], cs = 0.f;
+#pragma unroll
+    for (int n = 0; n < NMAX; ++n) acc[n] = 0.f;
+    for (int kc = k0; kc < kend; kc += 64) {
+      __syncthreads();
+      for (int i = threadIdx.x; i < 64 * NMAX; i += 256) {
+        const int kk = i / NMAX, n = i % NMAX;
+        bs[kk][n] = (kc + kk < kend && n < g.N) ? ((const float*)g.B)[(int64_t)(kc + kk) * g.sbk + n * g.sbn] : 0.f;
+      }
+      __syncthreads();
+      if (m < g.M) {
+        const int lim = min(64, kend - kc);
+        const float* ap = (const float*)g.A + (int64_t)kc * g.sak + m;
+        int kk = 0;
+        for (; kk + 8 <= lim; kk += 8) {      // eight independent loads in flight per thread
+          float a[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) a[u] = ap[(int64_t)(kk + u) * g.sak];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            cs += a[u];
+#pragma unroll
+            for (int n = 0; n < NMAX; ++n) acc[n] += a[u] * bs[kk + u][n];
+          }
+        }
+        for (; kk < lim; ++kk) {
+          const float a = ap[(int64_t)kk * g.sak];
+          cs += a;
+#pragma unroll
+          for (int n = 0; n < NMAX; ++n) acc[n] += a * bs[kk][n];
+        }
+      }
+    }
+    if (m < g.M) {
+#pragma unroll
+      for (int n = 0; n < NMAX; ++n)
+        if (n < g.N) atomicAdd((float*)g.C + (int64_t)m * g.ldc + n, acc[n]);
+      if (a_colsum) atomicAdd(a_colsum + m, cs);
+    }
+  }
+}
+
 // defined in afm_gemm_mfma.hip; returns AFM_ERR_UNSUPPORTED when the shape is not eligible
 int afm_gemm_mfma_try(const afm_gemm_desc* d, hipStream_t st);
 
@@ -119,6 +214,26 @@ static int gemm_generic(const afm_gemm_desc* d, hipStream_t st) {
   g.A = d->A; g.B = d->B; g.C = d->C; g.bias = d->bias; g.residual = d->residual; g.pre_act = d->pre_act;
   g.act = d->act; g.accumulate = d->accumulate;
   g.dd = afm_make_drop(&d->drop);
+  const bool all_f32 = d->a_dtype == AFM_F32 && d->b_dtype == AFM_F32 && d->c_dtype == AFM_F32;
+  const bool plain = !d->residual && !d->pre_act && d->drop.p <= 0.f;
+  if (all_f32 && plain && !d->transA && !d->accumulate && d->K <= 8 && d->M >= 4096 && (d->N & 3) == 0 && d->N <= 1024 && 256 % (d->N >> 2) == 0 &&
+      (d->ldc & 3) == 0 && ((uintptr_t)d->C & 15) == 0 && (d->act == AFM_ACT_NONE || d->act == AFM_ACT_RELU)) {
+    const int rows_per_block = 32;
+    AFM_LAUNCH(k_gemm_skinny_k<8>, dim3((d->M + rows_per_block - 1) / rows_per_block), dim3(256), 0, st, g, rows_per_block);
+    afm_set_last_algo("skinny_k");
+    return AFM_OK;
+  }
+  if (all_f32 && plain && d->transA && !d->transB && d->N <= 8 && d->K >= 4096 && d->act == AFM_ACT_NONE && !d->bias) {
+    if (!d->accumulate &&
+        hipMemset2DAsync(d->C, sizeof(float) * d->ldc, 0, sizeof(float) * d->N, d->M, st) != hipSuccess)
+      return AFM_ERR_LAUNCH;
+    const int rows_per_block = 128;   // many small workgroups: the kernel streams A once and is latency-bound otherwise
+    const int gy = d->M <= 2048 ? (d->M + 255) / 256 : 8;
+    AFM_LAUNCH(k_gemm_skinny_n<8>, dim3((d->K + rows_per_block - 1) / rows_per_block, gy), dim3(256), 0, st, g, d->a_colsum,
+               rows_per_block);
+    afm_set_last_algo("skinny_n");
+    return AFM_OK;
+  }
   const int gx = (d->N + GT - 1) / GT, gy = (d->M + GT - 1) / GT;
   int splits = 1;
   const bool can_split = d->c_dtype == AFM_F32 && d->act == AFM_ACT_NONE && !d->pre_act && d->drop.p <= 0.f;

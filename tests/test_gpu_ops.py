@@ -709,3 +709,28 @@ def test_mixture_generator_records(ops):
         assert torch.equal(got["IR"].cpu(), torch.from_numpy(ref).repeat_interleave(2, dim=0))
         assert torch.equal(got["compound"].cpu(), torch.from_numpy(ri.reshape(-1)))
         assert torch.equal(got["IR_target"].cpu(), torch.from_numpy(table[ri.reshape(-1)]))
+
+
+@pytest.mark.parametrize("K,N,act", [(2, 512, 0), (5, 256, 1), (8, 64, 0)])
+def test_gemm_skinny_k_patch_embed_forward(ops, K, N, act):
+    """(rows x K<=8) @ (K x N): the two-point-patch embedder of the IR-only workload (modeling/utils.py:107-136)."""
+    M = 9000
+    x, w, b = rnd(M, K, seed=1), rnd(N, K, seed=2), rnd(N, seed=3)
+    y = torch.empty(M, N, device=DEV)
+    ops.gemm(dev(x), dev(w), y, trans_b=True, bias=dev(b), act=act)
+    assert ops.last_algo() == "skinny_k"
+    ref = x.double() @ w.double().T + b.double()
+    close(y, torch.relu(ref) if act else ref, 1e-5, 1e-6)
+
+
+@pytest.mark.parametrize("accumulate", [False, True])
+def test_gemm_skinny_n_patch_embed_wgrad(ops, accumulate):
+    R, M, N = 9001, 512, 2
+    dy, x = rnd(R, M, seed=1), rnd(R, N, seed=2)
+    g0 = rnd(M, N, seed=3)
+    g = dev(g0).clone(); gb = torch.zeros(M, device=DEV)
+    ops.gemm(dev(dy), dev(x), g, trans_a=True, trans_b=False, accumulate=accumulate, a_colsum=gb)
+    assert ops.last_algo() == "skinny_n"
+    ref = dy.double().T @ x.double() + (g0.double() if accumulate else 0)
+    close(g, ref, 1e-4, 1e-4)
+    close(gb, dy.double().sum(0), 1e-4, 1e-4)
