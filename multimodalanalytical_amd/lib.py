@@ -119,6 +119,10 @@ def load(build_if_missing: bool = True):
                 raise AfmError(f"{LIB_PATH} is missing; run `python -m multimodalanalytical_amd.csrc.build`")
             from .csrc import build as _b
             _b.build()
+        # torch ships its own libamdhip64: it must be the HIP runtime already resident when this library's
+        # dependency on that soname is resolved, or the process ends up with two runtimes (the system one
+        # bound here, torch's owning every stream and pointer) and every launch fails
+        import torch  # noqa: F401
         try:
             lib = C.CDLL(LIB_PATH)
         except OSError as e:  # no CPU fallback by design
