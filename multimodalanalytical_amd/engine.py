@@ -66,6 +66,7 @@ class Seq2SeqEngine:
         else:
             self.pos_enc = None
         self.wt: Dict[str, torch.Tensor] = {}  # transposed bf16 weights for dgrad
+        self.wt_kv_all = None                  # see _refresh_kv_concat
         self.training = True
         self.dropout_seed = int(seed)
         self.micro_step = 0
@@ -106,6 +107,7 @@ class Seq2SeqEngine:
             if name not in self.wt:
                 self.wt[name] = torch.empty(cols, rows, dtype=torch.bfloat16, device=self.dev)
             ops.cast_bf16(src, dst, self.wt[name])
+        self._refresh_kv_concat()
 
     def refresh_transposes(self) -> None:
         """After an optimiser step (which already wrote the flat bf16 shadow)."""
@@ -113,6 +115,17 @@ class Seq2SeqEngine:
             return
         for name, rows, cols in self._gemm_weight_groups():
             ops.cast_bf16(self.ps.span(self.ps.flat, name, rows, cols), None, self.wt[name])
+        self._refresh_kv_concat()
+
+    def _refresh_kv_concat(self) -> None:
+        """(d x Ld*2d) bf16: the transposed cross-attention K/V projection weights of every decoder layer side
+        by side, so the gradient w.r.t. the encoder output is ONE GEMM with K = Ld*2d over the concatenated
+        dK|dV of all layers instead of Ld fp32 read-modify-write passes over the (B*S x d) accumulator."""
+        Ld, d = self.cfg["decoder_layers"], self.d
+        if self.wt_kv_all is None:
+            self.wt_kv_all = torch.empty(d, Ld * 2 * d, dtype=torch.bfloat16, device=self.dev)
+        for i in range(Ld):
+            self.wt_kv_all[:, i * 2 * d:(i + 1) * 2 * d].copy_(self.wt[f"decoder.layers.{i}.multihead_attn.in_proj_weight"][:, d:3 * d])
 
     def W(self, name, rows, cols, r0=0, r1=None):
         """GEMM weight rows [r0:r1) of the (rows x cols) group at `name`, compute dtype."""
@@ -422,21 +435,25 @@ class Seq2SeqEngine:
             saved["ca"] = (h, q, kv, a, lse, shp)
         return x, br
 
-    def _cross_attn_bwd(self, dx1, dy, mem, dmem, p, saved, next_site):
+    def _cross_attn_bwd(self, dx1, dy, mem, dmem, p, saved, next_site, dkv_all=None, layer=0):
         d = self.d
         h, q, kv, a, lse, shp = saved["ca"]
         wo, bo = p + "multihead_attn.out_proj.weight", p + "multihead_attn.out_proj.bias"
         self._wgrad(dy, a, wo, d, d, bias_name=bo)
         da = self._dgrad(dy, wo, d, d)
         dq = self._empty(h.shape[0], d)
-        dkv = self._empty(mem.shape[0], 2 * d)
+        if dkv_all is not None:     # this layer's dK | dV columns of the all-layers buffer (one dgrad at the end)
+            dkv, ldkv = dkv_all[:, layer * 2 * d:(layer + 1) * 2 * d], dkv_all.shape[1]
+        else:
+            dkv, ldkv = self._empty(mem.shape[0], 2 * d), 2 * d
         delta = torch.empty_like(lse)
-        ops.attn_bwd(shp, q, kv[:, :d], kv[:, d:], a, da, lse, delta, dq, dkv[:, :d], dkv[:, d:], d, 2 * d, 2 * d)
+        ops.attn_bwd(shp, q, kv[:, :d], kv[:, d:], a, da, lse, delta, dq, dkv[:, :d], dkv[:, d:], d, ldkv, ldkv)
         w, bname = p + "multihead_attn.in_proj_weight", p + "multihead_attn.in_proj_bias"
         self._wgrad(dq, h, w, 3 * d, d, 0, d, bias_name=bname)
         self._wgrad(dkv, mem, w, 3 * d, d, d, 3 * d, bias_name=bname)
         dh = self._dgrad(dq, w, 3 * d, d, 0, d)
-        self._dgrad(dkv, w, 3 * d, d, d, 3 * d, out=dmem, accumulate=True)  # fp32 accumulator
+        if dkv_all is None:
+            self._dgrad(dkv, w, 3 * d, d, d, 3 * d, out=dmem, accumulate=True)  # fp32 accumulator
         return self._ln_bwd(dh, p + "norm2.", saved, "ln2", dres=dx1, next_site=next_site)
 
     # ------------------------------------------------------------------ whole model
@@ -669,14 +686,22 @@ class Seq2SeqEngine:
         Ld, Le = self.cfg["decoder_layers"], self.cfg["encoder_layers"]
         dx, dy = self._ln_bwd(dhf, "decoder.norm.", saved, "dec_norm", dres=None, next_site=f"d{Ld - 1}res2")
         dmem = saved.pop("dmem_init", None)     # alignment head's gradient w.r.t. the encoder output, if any
-        if dmem is None:
+        had_init = dmem is not None
+        if dmem is None and self.cd != torch.bfloat16:
             dmem = torch.zeros(B * S, d, dtype=torch.float32, device=self.dev)
+        dkv_all = None
+        if self.cd == torch.bfloat16 and Ld > 0:
+            dkv_all = torch.empty(B * S, Ld * 2 * d, dtype=torch.bfloat16, device=self.dev)
         for i in range(Ld - 1, -1, -1):
             p, sv = f"decoder.layers.{i}.", saved["dec_layers"][i]
             dx, dy = self._ffn_bwd(dx, dy, p, self.cfg["decoder_ffn_dim"], "norm3.", sv, f"d{i}xres")
-            dx, dy = self._cross_attn_bwd(dx, dy, mem, dmem, p, sv, f"d{i}res")
+            dx, dy = self._cross_attn_bwd(dx, dy, mem, dmem, p, sv, f"d{i}res", dkv_all, i)
             dx, dy = self._self_attn_bwd(dx, dy, p, sv, f"d{i - 1}res2" if i > 0 else None)
             self._grads_final_from(p + "self_attn.in_proj_weight")
+        if dkv_all is not None:      # d(encoder output) = [dK|dV of every layer] @ [their projection weights], K = Ld*2d
+            if dmem is None:
+                dmem = torch.empty(B * S, d, dtype=torch.float32, device=self.dev)
+            ops.gemm(dkv_all, self.wt_kv_all, dmem, trans_b=True, accumulate=had_init, algo=self.algo)
         self.embed_bwd(dx, saved["emb_dec"])
         dmem_c = dmem
         if self.cd != torch.float32:
