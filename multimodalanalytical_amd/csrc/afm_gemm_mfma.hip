@@ -369,10 +369,13 @@ __device__ __forceinline__ void epilogue_staged_bf16(const MfmaArgs& g, float* s
   bf16* const cbase = (bf16*)g.C + (int64_t)(mw + r8) * g.ldc + n;
   bf16* const pbase = (bf16*)g.pre_act + (int64_t)(mw + r8) * g.ldc + n;
   const uint32_t dbase = (uint32_t)(mw + r8) * (uint32_t)g.N + (uint32_t)n;
+  // pre-activations of the dropout * GELU' form: loaded PF row-groups ahead of their use (all 2*WM at once
+  // cost 8 VGPRs each: 64 at 128-row wave tiles, which spilled)
+  constexpr int PF = 4;
   bf16x8 uu[2 * WM];
-  if (EPI == EPI_GELU_BWD) {   // all pre-activation loads first: one wait, before any store
+  if (EPI == EPI_GELU_BWD) {
 #pragma unroll
-    for (int q = 0; q < 2 * WM; ++q) uu[q] = *(const bf16x8*)(pbase + (int64_t)(q * 8) * g.ldc);
+    for (int q = 0; q < (PF < 2 * WM ? PF : 2 * WM); ++q) uu[q] = *(const bf16x8*)(pbase + (int64_t)(q * 8) * g.ldc);
   }
 #pragma unroll
   for (int i = 0; i < WM; ++i) {
@@ -397,6 +400,7 @@ __device__ __forceinline__ void epilogue_staged_bf16(const MfmaArgs& g, float* s
       }
       if (EPI == EPI_GELU_BWD) {
         const bf16x8 u = uu[q];
+        if (q + PF < 2 * WM) uu[q + PF < 2 * WM ? q + PF : 0] = *(const bf16x8*)(pbase + (int64_t)((q + PF) * 8) * g.ldc);
         if (drop_on) {
 #pragma unroll
           for (int k = 0; k < 8; ++k) x[k] = afm_drop32(g.dd, di + k, x[k]) * afm_gelu_grad((float)u[k]);
@@ -421,7 +425,9 @@ __device__ __forceinline__ void epilogue_staged_bf16(const MfmaArgs& g, float* s
 // launch/teardown disappear from the critical path.
 // ABL (timing experiments only, bit mask): 1 = skip the LDS reads + MFMAs, 2 = skip the LDS-DMA loads,
 // 4 = skip the epilogue.
-template <bool C_BF16, int NWM, int NWN, int S, int ABL = 0, int WM = 4>
+// EPI: compile-time epilogue kind of full tiles (bf16 output); EDGE = false drops the fragment epilogue of
+// partial tiles (the dispatcher then only sends shapes made of whole tiles).
+template <bool C_BF16, int NWM, int NWN, int S, int ABL = 0, int WM = 4, int EPI = EPI_GENERIC, bool EDGE = true>
 __global__ __launch_bounds__(64 * NWM * NWN) void k_gemm_nt_pring(MfmaArgs g) {
   constexpr int NW = NWM * NWN;
   constexpr int TBM = 16 * WM * NWM, TBN = 64 * NWN;
@@ -558,8 +564,9 @@ __global__ __launch_bounds__(64 * NWM * NWN) void k_gemm_nt_pring(MfmaArgs g) {
       // the slot read by the last k-step is free until the next issue: stage through it
       __builtin_amdgcn_s_barrier();
       float* stg = (float*)(lds + (slot == 0 ? S - 1 : slot - 1) * STAGE) + w * (16 * STG_LD);
-      epilogue_staged<C_BF16, WM>(g, stg, bias_lds, acc, m0 + wm * 16 * WM, n0 + wn * 64, lane);
-    } else {
+      if constexpr (C_BF16 && EPI != EPI_GENERIC) epilogue_staged_bf16<WM, EPI>(g, stg, bias_lds, acc, m0 + wm * 16 * WM, n0 + wn * 64, lane);
+      else epilogue_staged<C_BF16, WM>(g, stg, bias_lds, acc, m0 + wm * 16 * WM, n0 + wn * 64, lane);
+    } else if constexpr (EDGE) {
 #pragma unroll
       for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -572,7 +579,7 @@ __global__ __launch_bounds__(64 * NWM * NWN) void k_gemm_nt_pring(MfmaArgs g) {
   }
 }
 
-template <bool C_BF16, int NWM, int NWN, int S, int ABL = 0, int WM = 4>
+template <bool C_BF16, int NWM, int NWN, int S, int ABL = 0, int WM = 4, int EPI = EPI_GENERIC, bool EDGE = true>
 static int launch_nt_pring(MfmaArgs& g, hipStream_t st, int blocks_per_cu) {
   constexpr int TBM = 16 * WM * NWM, TBN = 64 * NWN;
   constexpr int ring = S * (TBM + TBN) * 128;
@@ -584,7 +591,7 @@ static int launch_nt_pring(MfmaArgs& g, hipStream_t st, int blocks_per_cu) {
   const bool modes_ok = C_BF16 ? (!g.residual && !g.accumulate) : true;
   g.bias_in_lds = rows16 && modes_ok && ring * blocks_per_cu + bias_bytes * blocks_per_cu <= 160 * 1024 ? 1 : 0;
   const int shm = ring + (g.bias_in_lds ? bias_bytes : 0);
-  auto kern = k_gemm_nt_pring<C_BF16, NWM, NWN, S, ABL, WM>;
+  auto kern = k_gemm_nt_pring<C_BF16, NWM, NWN, S, ABL, WM, EPI, EDGE>;
   static int attr_shm = 0;   // per instantiation
   if (shm > attr_shm) {
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -1135,6 +1142,13 @@ int afm_gemm_mfma_try(const afm_gemm_desc* d, hipStream_t st) {
       // register-staged kernel (case 100).
       const int64_t big_tiles = (int64_t)((d->M + 255) / 256) * ((d->N + 127) / 128);
       variant = (d->N > 128 && big_tiles >= 256) ? 24 : 13;
+      // wide outputs of the long encoder sequence: 256x256 tiles (a quarter less L2->LDS fill and a quarter
+      // fewer LDS fragment reads per FLOP, 64 MFMAs per wave between barriers): +7..12 % at N >= 1024
+      const bool small_idx28 = (uint64_t)d->M * (uint64_t)d->N <= 0x100000000ull;
+      if (variant == 24 && d->N >= 1024 && !(d->M & 255) && !(d->N & 255) && (int64_t)(d->M >> 8) * (d->N >> 8) >= 1024 &&
+          d->c_dtype == AFM_BF16 && !d->residual && !d->accumulate && !(d->ldc % 8) && d->act != AFM_ACT_RELU &&
+          !(d->pre_act && d->act == AFM_ACT_NONE) && (d->drop.p <= 0.f || small_idx28))
+        variant = 28;
     }
     int r;
 #define NT_CASE(WM, WN, NWM, NWN, BKT) \
@@ -1144,6 +1158,17 @@ int afm_gemm_mfma_try(const afm_gemm_desc* d, hipStream_t st) {
     switch (variant) {
       case 12: r = (d->K & 63) ? AFM_ERR_UNSUPPORTED : PRING_CASE(4, 2, 3, 1); break;   // persistent 256x128, 8 waves, 3 stages
       case 13: r = (d->K & 63) ? AFM_ERR_UNSUPPORTED : PRING_CASE(2, 2, 2, 2); break;   // persistent 128x128, 4 waves, 2 per CU
+      case 28: {   // persistent 256x256 (8 waves of 128x64, 2 stages), whole tiles only, bf16 output
+        const bool small_idx = (uint64_t)d->M * (uint64_t)d->N <= 0x100000000ull;
+        if ((d->K & 63) || (d->M & 255) || (d->N & 255) || d->c_dtype != AFM_BF16 || d->residual || d->accumulate ||
+            (d->N % 8) || (d->ldc % 8) || d->act == AFM_ACT_RELU || (d->pre_act && d->act == AFM_ACT_NONE) ||
+            (d->drop.p > 0.f && !small_idx)) { r = AFM_ERR_UNSUPPORTED; break; }
+        if (d->act == AFM_ACT_GELU_BWD) r = launch_nt_pring<true, 2, 4, 2, 0, 8, EPI_GELU_BWD, false>(g, st, 1);
+        else if (d->act == AFM_ACT_GELU) r = launch_nt_pring<true, 2, 4, 2, 0, 8, EPI_GELU, false>(g, st, 1);
+        else if (d->drop.p > 0.f) r = launch_nt_pring<true, 2, 4, 2, 0, 8, EPI_DROP, false>(g, st, 1);
+        else r = launch_nt_pring<true, 2, 4, 2, 0, 8, EPI_PLAIN, false>(g, st, 1);
+        break;
+      }
       case 22: r = (d->K & 63) ? AFM_ERR_UNSUPPORTED : (d->c_dtype == AFM_BF16 ? launch_nt_ws<true, 2>(g, st) : launch_nt_ws<false, 2>(g, st)); break;
       case 24:   // persistent 256x128, 8 MFMA waves + 4 loader waves, epilogue picked at compile time
       case 25: { // (25: same tile walk with the generic run-time epilogue, for A/B timing)

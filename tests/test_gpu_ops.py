@@ -734,3 +734,35 @@ def test_gemm_skinny_n_patch_embed_wgrad(ops, accumulate):
     ref = dy.double().T @ x.double() + (g0.double() if accumulate else 0)
     close(g, ref, 1e-4, 1e-4)
     close(gb, dy.double().sum(0), 1e-4, 1e-4)
+
+
+@pytest.mark.parametrize("mode", ["bias", "drop", "gelu_preact_drop", "gelu_bwd"])
+def test_gemm_256x256_variant(ops, mode):
+    """Persistent 256x256-tile kernel (variant 28; picked automatically for N >= 1024 at M >= 32k): whole tiles only."""
+    M, N, K = 768, 512, 256
+    a, w, bias = rnd(M, K, seed=1).bfloat16(), rnd(N, K, seed=2).bfloat16(), rnd(N, seed=3)
+    t = a.double() @ w.double().T
+    c = torch.zeros(M, N, dtype=torch.bfloat16, device=DEV)
+    p, seed, site = 0.1, 31, 9
+    keep = torch.from_numpy(keep_mask(p, seed, site, M * N)).view(M, N)
+    tol = dict(rtol=2e-2, atol=4e-2)
+    if mode == "bias":
+        ops.gemm(dev(a), dev(w), c, bias=dev(bias), algo=2, variant=28)
+        close(c, t + bias.double(), **tol)
+    elif mode == "drop":
+        ops.gemm(dev(a), dev(w), c, bias=dev(bias), dropout=ops.drop(p, seed, site), algo=2, variant=28)
+        close(c, (t + bias.double()) * keep / (1 - p), **tol)
+    elif mode == "gelu_preact_drop":
+        pre = torch.zeros_like(c)
+        ops.gemm(dev(a), dev(w), c, bias=dev(bias), act=2, pre_act=pre, dropout=ops.drop(p, seed, site), algo=2, variant=28)
+        close(pre, t + bias.double(), **tol)
+        close(c, O.gelu(t + bias.double()) * keep / (1 - p), **tol)
+    else:
+        u = rnd(M, N, seed=4)
+        ud = dev(u, torch.bfloat16)
+        ops.gemm(dev(a), dev(w), c, act=3, pre_act=ud, dropout=ops.drop(p, seed, site), algo=2, variant=28)
+        ur = ud.float().cpu().double().requires_grad_(True)
+        O.gelu(ur).backward(torch.ones(M, N, dtype=torch.float64))
+        close(c, t * keep / (1 - p) * ur.grad, **tol)
+    with pytest.raises(Exception):
+        ops.gemm(dev(a[:700]), dev(w), c[:700], algo=2, variant=28)     # partial tiles are refused, not mishandled
