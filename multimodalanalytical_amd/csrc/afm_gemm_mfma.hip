@@ -1112,6 +1112,150 @@ __global__ __launch_bounds__(512, 2) void k_gemm_tn_ring(MfmaArgs g) {
     }
 }
 
+// Same kernel on 256 x 256 tiles: 8 waves of 128 x 64 (2 x 4), two 64-KiB ring slots.  Per FLOP a quarter
+// less L2->LDS fill and a quarter fewer transposed LDS reads than the 256 x 128 form, and 64 MFMAs per
+// wave between barriers; needs more split-K (fewer tiles), i.e. more fp32 atomics on the small dW.
+__global__ __launch_bounds__(512) void k_gemm_tn_ring256(MfmaArgs g) {
+  constexpr int S = 2, TBM = 256, TBN = 256, NW = 8, NIW = 8;
+  constexpr int ABYTES = 64 * TBM * 2, STAGE = 64 * (TBM + TBN) * 2;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  const int t = threadIdx.x, lane = t & 63;
+  const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wm = w >> 2, wn = w & 3;
+  const int ntile = g.tiles_m * g.tiles_n;
+  const int bid = xcd_remap(blockIdx.x, ntile * g.ksplit);
+  const int tile = bid % ntile, ks_id = bid / ntile;     // tile index fastest: an XCD's workgroups share a k-chunk
+  const int m0 = (tile / g.tiles_n) * TBM, n0 = (tile % g.tiles_n) * TBN;
+  const int kbeg = ks_id * g.kchunk, kend = min(g.K, kbeg + g.kchunk);
+  const int nk = (kend - kbeg) / 64;
+
+  // this wave's pieces: ii = w + 8 j; ii < 32 -> A rows {2 ii, 2 ii + 1}, else B rows {2 (ii-32), +1} (512 B rows)
+  const bf16* src[NIW];
+  int64_t pitch[NIW];
+#pragma unroll
+  for (int j = 0; j < NIW; ++j) {
+    const int ii = w + NW * j;
+    const int r = (ii & 31) * 2 + (lane >> 5);
+    const int c = (lane & 31) ^ tn_swz(r);
+    if (ii < 32) {
+      src[j] = g.A + (int64_t)(kbeg + r) * g.lda + min(m0 + c * 8, g.M - 8);
+      pitch[j] = (int64_t)64 * g.lda;
+    } else {
+      src[j] = g.B + (int64_t)(kbeg + r) * g.ldb + min(n0 + c * 8, g.N - 8);
+      pitch[j] = (int64_t)64 * g.ldb;
+    }
+  }
+  auto issue = [&](int kt) {
+    unsigned char* st = lds + (kt % S) * STAGE;
+#pragma unroll
+    for (int j = 0; j < NIW; ++j)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[j] + kt * pitch[j]),
+                                       (__attribute__((address_space(3))) void*)(st + (w + NW * j) * 1024), 16, 0, 0);
+  };
+
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const bool do_cs = g.a_colsum != nullptr && (tile % g.tiles_n) == 0 && wn == 0;
+  float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+
+  if (nk > 0) issue(0);
+  const int grp = lane >> 4, q = (lane >> 2) & 3, p = lane & 3;
+  int laneA[8], laneB[4];
+  {
+    const int lrow = grp * 8 + q, swz = tn_swz(lrow), sub = (p & 1) << 3;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) laneA[i] = lrow * 512 + (((((wm * 128 + i * 16) >> 3) + (p >> 1)) ^ swz) << 4) + sub;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) laneB[j] = ABYTES + lrow * 512 + (((((wn * 64 + j * 16) >> 3) + (p >> 1)) ^ swz) << 4) + sub;
+  }
+  for (int kt = 0; kt < nk; ++kt) {
+    wait_vmcnt<0>();                       // two slots: only this step's pieces are in flight
+    __builtin_amdgcn_s_barrier();
+    if (kt + 1 < nk) issue(kt + 1);
+    const unsigned sbase = (unsigned)(uintptr_t)(lds + (kt % S) * STAGE);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {       // two 32-deep k-slices; asm reads as in k_gemm_tn_ring
+      s16x4 a0[8], a1[8], b0[4], b1[4];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const unsigned va = sbase + (unsigned)laneA[i];
+        if (ks == 0) {
+          asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(a0[i]) : "v"(va));
+          asm volatile("ds_read_b64_tr_b16 %0, %1 offset:2048" : "=v"(a1[i]) : "v"(va));
+        } else {
+          asm volatile("ds_read_b64_tr_b16 %0, %1 offset:16384" : "=v"(a0[i]) : "v"(va));
+          asm volatile("ds_read_b64_tr_b16 %0, %1 offset:18432" : "=v"(a1[i]) : "v"(va));
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const unsigned vb = sbase + (unsigned)laneB[j];
+        if (ks == 0) {
+          asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(b0[j]) : "v"(vb));
+          asm volatile("ds_read_b64_tr_b16 %0, %1 offset:2048" : "=v"(b1[j]) : "v"(vb));
+        } else {
+          asm volatile("ds_read_b64_tr_b16 %0, %1 offset:16384" : "=v"(b0[j]) : "v"(vb));
+          asm volatile("ds_read_b64_tr_b16 %0, %1 offset:18432" : "=v"(b1[j]) : "v"(vb));
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      bf16x8 af[8], bfr[4];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const bf16x4 x0 = __builtin_bit_cast(bf16x4, a0[i]), x1 = __builtin_bit_cast(bf16x4, a1[i]);
+        af[i] = (bf16x8){x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const bf16x4 y0 = __builtin_bit_cast(bf16x4, b0[j]), y1 = __builtin_bit_cast(bf16x4, b1[j]);
+        bfr[j] = (bf16x8){y0[0], y0[1], y0[2], y0[3], y1[0], y1[1], y1[2], y1[3]};
+      }
+      if (do_cs) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+          for (int j = 0; j < 8; ++j) cs[i] += (float)af[i][j];
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+    }
+  }
+  const int fr = lane & 15, fq = lane >> 4;
+  if (do_cs) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      float s = cs[i];
+      s += __shfl_xor(s, 16, 64);
+      s += __shfl_xor(s, 32, 64);
+      const int mm = m0 + wm * 128 + i * 16 + fr;
+      if (fq == 0 && mm < g.M) atomicAdd(g.a_colsum + mm, s);
+    }
+  }
+  float* C = (float*)g.C;
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = n0 + wn * 64 + j * 16 + fr;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int mm = m0 + wm * 128 + i * 16 + fq * 4 + r;
+        if (mm < g.M && n < g.N) {
+          float* c = C + (int64_t)mm * g.ldc + n;
+          if (g.ksplit > 1) atomicAdd(c, acc[i][j][r]);
+          else *c = acc[i][j][r] + (g.accumulate ? *c : 0.f);
+        }
+      }
+    }
+}
+
 // ------------------------------------------------------------------------------------------ dispatch
 static inline bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
@@ -1218,6 +1362,35 @@ int afm_gemm_mfma_try(const afm_gemm_desc* d, hipStream_t st) {
         (d->a_colsum && ((uintptr_t)d->a_colsum & 3)))
       return AFM_ERR_UNSUPPORTED;
     if ((d->M & 7) || (d->N & 7) || d->K < 64 || d->M < 16 || d->N < 16) return AFM_ERR_UNSUPPORTED;
+    // 256 x 256 tiles when the gradient matrix has at least 8 of them and the token count is long enough for
+    // every workgroup to run >= 64 k-steps (measured at 131072 tokens: +4..18 % at 1536x512, 2048x512, 512x2048;
+    // -3 % at 512x512, which keeps the 256 x 128 form, as do the decoder's 16 k-token shapes); 105 / 106 force a form
+    const bool want256 = d->reserved == 105 ||
+                         (d->reserved == 0 && d->K >= 65536 && (int64_t)((d->M + 255) / 256) * ((d->N + 255) / 256) >= 8);
+    if (want256 && (d->K & 63) == 0 && d->K >= 4096 && d->M >= 256 && d->N >= 256) {
+      // 256 x 256 tiles
+      g.tiles_m = (d->M + 255) / 256; g.tiles_n = (d->N + 255) / 256;
+      const int tiles = g.tiles_m * g.tiles_n;
+      int ksplit = tiles >= 256 ? 1 : 256 / tiles;
+      const int maxs = d->K / 1024;
+      if (ksplit > maxs) ksplit = maxs;
+      if (ksplit < 1) ksplit = 1;
+      int kchunk = ((d->K / 64 + ksplit - 1) / ksplit) * 64;
+      ksplit = (d->K + kchunk - 1) / kchunk;
+      g.ksplit = ksplit; g.kchunk = kchunk;
+      if (ksplit > 1 && !d->accumulate) {
+        if (hipMemset2DAsync(d->C, sizeof(float) * d->ldc, 0, sizeof(float) * d->N, d->M, st) != hipSuccess)
+          return AFM_ERR_LAUNCH;
+      }
+      static bool attr256 = false;
+      if (!attr256) {
+        (void)hipFuncSetAttribute((const void*)k_gemm_tn_ring256, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 64 * 512 * 2);
+        attr256 = true;
+      }
+      AFM_LAUNCH(k_gemm_tn_ring256, dim3(tiles * ksplit), dim3(512), 2 * 64 * 512 * 2, st, g);
+      afm_set_last_algo(ksplit > 1 ? "mfma_tn_ring256_splitk" : "mfma_tn_ring256");
+      return AFM_OK;
+    }
     if (d->reserved != 100 && (d->K & 63) == 0 && d->K >= 4096 && d->M >= 64 && d->N >= 64) {
       // LDS-DMA ring kernel: 256 x 128 tiles, one 8-wave workgroup per CU, split-K to fill the chip
       g.tiles_m = (d->M + 255) / 256; g.tiles_n = (d->N + 127) / 128;

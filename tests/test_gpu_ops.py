@@ -766,3 +766,15 @@ def test_gemm_256x256_variant(ops, mode):
         close(c, t * keep / (1 - p) * ur.grad, **tol)
     with pytest.raises(Exception):
         ops.gemm(dev(a[:700]), dev(w), c[:700], algo=2, variant=28)     # partial tiles are refused, not mishandled
+
+
+@pytest.mark.parametrize("R,M,N", [(8192, 512, 512), (12288, 768, 256), (4096 + 64, 304, 520)])
+def test_gemm_tn_256x256_variant(ops, R, M, N):
+    """wgrad on 256 x 256 tiles (variant 105): full and ragged tiles, split-K atomics, fused bias gradient."""
+    dy, x = rnd(R, M, seed=1).bfloat16(), rnd(R, N, seed=2).bfloat16()
+    g0 = rnd(M, N, seed=3)
+    g = dev(g0).clone(); gb = torch.zeros(M, device=DEV)
+    ops.gemm(dev(dy), dev(x), g, trans_a=True, trans_b=False, accumulate=True, algo=2, a_colsum=gb, variant=105)
+    assert ops.last_algo().startswith("mfma_tn_ring256")
+    close(g, dy.double().T @ x.double() + g0.double(), 2e-3, 2e-2 * math.sqrt(R / 4096))
+    close(gb, dy.double().sum(0), 2e-3, 2e-2 * math.sqrt(R / 4096))
