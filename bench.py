@@ -58,8 +58,9 @@ def time_kernel(fn, iters=10, warm=3):
 
 
 def dominant_kernel_roofline(model, wl, B, dtype):
-    """The kernel with the largest share of the step in the rocprofv3 summary
-    (profiles/r01_c2_kernel_stats.csv): k_gemm_tn_ring, the weight-gradient GEMM, timed here at its
+    """The weight-gradient GEMM (k_gemm_tn_ring256): with the attention dK/dV kernel (VALU-bound, DESIGN.md
+    section 4) one of the two kernels with the largest share of the step in the rocprofv3 summary
+    (profiles/r01_c2_kernel_stats.csv, ~14 % each), and the one with a clean roofline; timed here at its
     largest shape -- the FFN up-projection wgrad dW1[f x d] += dU^T[f x B*S] X[B*S x d] with the bias
     gradient fused (one launch = 2*B*S*d*f FLOPs).  Algorithmic bytes per launch: dU and X read once
     (bf16) + dW1 written once (fp32) = 2*B*S*(f+d) + 4*f*d; at 8 TB/s that is less time than the
