@@ -171,7 +171,8 @@ class HFWrapper:
         enc = self.hf_model.encoder(attention_mask=attention_mask, inputs_embeds=self.multimodal_embedding(input_ids))
         return enc, attention_mask
 
-    def generate(self, batch: Dict[str, Any], n_beams: int = 1, logits_processor=None, use_cache: bool = True) -> torch.Tensor:
+    def generate(self, batch: Dict[str, Any], n_beams: int = 1, logits_processor=None, use_cache: bool = True,
+                 graph: bool = True) -> torch.Tensor:
         """wrapper.py:409-453.  Encoder once, then greedy (n_beams == 1) or beam search with
         num_return_sequences = n_beams, max_length 128, forced EOS; returns (B*n_beams, <=128) ids.
         use_cache=True decodes incrementally on a device-side KV cache (engine.decode_step);
@@ -195,6 +196,19 @@ class HFWrapper:
                     if bool(done.all()):
                         break
                 return ids
+            if n_beams == 1 and graph:
+                # one captured HIP graph per position (engine.decode_step_graphed); the all-finished test
+                # costs a host sync, so it runs every eighth token (finished rows emit pad meanwhile and the
+                # surplus all-pad columns are cut, so the ids equal the eager loop's)
+                st = eng.decode_init_graphed(enc["last_hidden_state"], attention_mask, max_len=self.max_length)
+                ids = torch.full((B, 1), tok.bos_token_id, dtype=torch.long, device=dev)
+                done = torch.zeros(B, dtype=torch.bool, device=dev)
+                while ids.shape[1] < self.max_length:
+                    ids, done = self._greedy_pick(eng.decode_step_graphed(st, ids[:, -1]), ids, done)
+                    if ids.shape[1] % 8 == 0 and bool(done.all()):
+                        break
+                keep = int((ids != tok.pad_token_id).any(0).nonzero().max()) + 1 if bool(done.all()) else ids.shape[1]
+                return ids[:, :max(keep, 2)]
             st = eng.decode_init(enc["last_hidden_state"], attention_mask, beams=n_beams, max_len=self.max_length)
             if n_beams == 1:
                 ids = torch.full((B, 1), tok.bos_token_id, dtype=torch.long, device=dev)

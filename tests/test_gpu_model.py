@@ -195,8 +195,12 @@ def test_kv_cached_decode_equals_full_recompute_and_beam_invariants(name, dtype)
     w = _wrapper(t, cfg, dtype)
     w.max_length = 14
     b = _dev_batch(t, 0)
-    greedy_cache = w.generate(b, n_beams=1)
+    greedy_cache = w.generate(b, n_beams=1)                      # one captured HIP graph per position
     greedy_full = w.generate(b, n_beams=1, use_cache=False)
+    assert torch.equal(w.generate(b, n_beams=1, graph=False), greedy_cache)      # eager launches, same kernels
+    assert torch.equal(w.generate(b, n_beams=1), greedy_cache)                   # replay of the captured graphs
+    b1 = _dev_batch(t, 1)                                                        # other inputs through the same graphs
+    assert torch.equal(w.generate(b1, n_beams=1), w.generate(b1, n_beams=1, graph=False))
     if dtype == torch.float32:
         assert torch.equal(greedy_cache, greedy_full)
         w.max_length = t["meta"]["greedy_max_length"]

@@ -15,7 +15,7 @@ def main():
                       **{k: v for k, v in wl["cfg"].items() if k != "multimodal_norm"})
     batch = synth.make_batch(name, B, seed=1, device=dev)[0]
     model.max_length = 128
-    for label, kw in (("greedy, KV cache", dict(n_beams=1)), ("beam 5, KV cache", dict(n_beams=5)),
+    for label, kw in (("greedy, KV cache, HIP graph per position", dict(n_beams=1)), ("greedy, KV cache, eager launches", dict(n_beams=1, graph=False)), ("beam 5, KV cache", dict(n_beams=5)),
                       ("greedy, full-prefix recompute (reference control flow)", dict(n_beams=1, use_cache=False))):
         model.generate(batch, **kw)            # warm-up
         torch.cuda.synchronize(); t0 = time.perf_counter()
