@@ -615,6 +615,7 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd_dkv_mfma(AttnM a, const bf1
 static bool eligible(const afm_attn_shape* s, const void* const* ptrs, int nptr, const int* lds, int nld) {
   if (s->dtype != AFM_BF16 || s->dh != DH) return false;
   if (s->sqb || s->skb || s->svb || s->sob) return false;   // KV-cache strides: generic kernel
+  if (s->causal && s->Tq != s->Tk) return false;            // the tile loops assume >= 1 tile per workgroup (self-attention)
   if (s->drop.p > 0.f && (s->Tk & 1)) return false;   // the pair hash needs even rows of the mask
   if (s->drop.p > 0.f && (uint64_t)s->B * s->H * s->Tq * (uint64_t)s->Tk > 0xFFFFFFFFull) return false;  // 32-bit mask index
   for (int i = 0; i < nptr; ++i) if ((uintptr_t)ptrs[i] & 15) return false;
