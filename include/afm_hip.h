@@ -30,7 +30,8 @@ extern "C" {
 
 enum { AFM_OK = 0, AFM_ERR_ARG = -1, AFM_ERR_UNSUPPORTED = -2, AFM_ERR_LAUNCH = -3 };
 enum { AFM_F32 = 0, AFM_BF16 = 1 };
-enum { AFM_ACT_NONE = 0, AFM_ACT_RELU = 1, AFM_ACT_GELU = 2, AFM_ACT_GELU_BWD = 3 };
+enum { AFM_ACT_NONE = 0, AFM_ACT_RELU = 1, AFM_ACT_GELU = 2, AFM_ACT_GELU_BWD = 3,
+       AFM_ACT_GELU_SAVE_GRAD = 4, AFM_ACT_MUL_SAVED = 5 };
 enum { AFM_ALGO_AUTO = 0, AFM_ALGO_GENERIC = 1, AFM_ALGO_MFMA = 2 };
 
 int afm_abi_version(void);
@@ -66,6 +67,10 @@ typedef struct {
  * `a_colsum` (wgrad form only) accumulates the column sums of A = dy: the bias gradient.
  * act == AFM_ACT_GELU_BWD fuses the GELU backward into a dgrad GEMM: T = dropout(T) * gelu'(U) with U read
  * from `pre_act` (the saved pre-activation, an INPUT in this mode): du = dropout'(dy W2) * gelu'(u).
+ * act == AFM_ACT_GELU_SAVE_GRAD is the forward of the same pair with the backward factor precomputed:
+ * C = dropout(gelu(T)) and pre_act <- keep * scale * gelu'(T) (same keep bits), so the dgrad needs neither
+ * erf nor the dropout hash: act == AFM_ACT_MUL_SAVED computes C = T * pre_act (pre_act an INPUT, no bias /
+ * dropout).  dropout'(dy W2) * gelu'(u) = (dy W2) * [keep * scale * gelu'(u)]: identical values.
  * bf16 operands take the MFMA path (v_mfma_f32_16x16x32_bf16 / 32x32x16, fp32 accumulate) when
  * shape/alignment allow; everything else takes the exact-fp32 FMA path.
  * ---------------------------------------------------------------------------------------- */

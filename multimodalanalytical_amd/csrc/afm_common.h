@@ -115,6 +115,19 @@ __device__ __forceinline__ float afm_erf(float x) {
 __device__ __forceinline__ float afm_gelu(float x) {
   return 0.5f * x * (1.0f + afm_erf(x * 0.70710678118654752440f));
 }
+// gelu(x) and gelu'(x) together: the exponential of the erf approximation IS exp(-x^2/2), the pdf term
+__device__ __forceinline__ void afm_gelu_both(float x, float& g, float& gp) {
+  const float z = x * 0.70710678118654752440f, az = fabsf(z);
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, az, 1.0f));
+  float p = fmaf(1.061405429f, t, -1.453152027f);
+  p = fmaf(p, t, 1.421413741f);
+  p = fmaf(p, t, -0.284496736f);
+  p = fmaf(p, t, 0.254829592f);
+  const float e = __builtin_amdgcn_exp2f(-1.4426950408889634f * az * az);
+  const float cdf = 0.5f * (1.0f + copysignf(fmaf(-p * t, e, 1.0f), z));
+  g = x * cdf;
+  gp = fmaf(x * 0.39894228040143267794f, e, cdf);
+}
 __device__ __forceinline__ float afm_gelu_grad(float x) {
   // d/dx [x Phi(x)] = Phi(x) + x phi(x)
   const float cdf = 0.5f * (1.0f + afm_erf(x * 0.70710678118654752440f));

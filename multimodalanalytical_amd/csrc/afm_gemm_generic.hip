@@ -93,6 +93,14 @@ __global__ __launch_bounds__(256) void k_gemm_generic(GemmArgs g) {
       if (g.bias) v += g.bias[n];
       if (g.act == AFM_ACT_GELU_BWD) {
         v = afm_drop(g.dd, (uint64_t)m * (uint64_t)g.N + (uint64_t)n, v) * afm_gelu_grad(ld_any(g.pre_act, g.c_bf16, ci));
+      } else if (g.act == AFM_ACT_GELU_SAVE_GRAD) {
+        float y, yp;
+        afm_gelu_both(v, y, yp);
+        const float k = afm_drop(g.dd, (uint64_t)m * (uint64_t)g.N + (uint64_t)n, 1.0f);   // scale or 0
+        st_any(g.pre_act, g.c_bf16, ci, yp * k);
+        v = y * k;
+      } else if (g.act == AFM_ACT_MUL_SAVED) {
+        v *= ld_any(g.pre_act, g.c_bf16, ci);
       } else {
         if (g.pre_act) st_any(g.pre_act, g.c_bf16, ci, v);
         if (g.act == AFM_ACT_RELU) v = fmaxf(v, 0.f);
@@ -269,8 +277,9 @@ extern "C" int afm_gemm(const afm_gemm_desc* d, void* stream) {
   if (!d || !d->A || !d->B || !d->C) return AFM_ERR_ARG;
   if (d->M < 0 || d->N < 0 || d->K < 0) return AFM_ERR_ARG;
   if ((d->a_dtype | d->b_dtype | d->c_dtype) & ~1) return AFM_ERR_ARG;
-  if (d->act < AFM_ACT_NONE || d->act > AFM_ACT_GELU_BWD) return AFM_ERR_ARG;
-  if (d->act == AFM_ACT_GELU_BWD && !d->pre_act) return AFM_ERR_ARG;
+  if (d->act < AFM_ACT_NONE || d->act > AFM_ACT_MUL_SAVED) return AFM_ERR_ARG;
+  if (d->act >= AFM_ACT_GELU_BWD && !d->pre_act) return AFM_ERR_ARG;
+  if (d->act == AFM_ACT_MUL_SAVED && (d->bias || d->drop.p > 0.f)) return AFM_ERR_ARG;
   if (d->ldc < d->N) return AFM_ERR_ARG;
   if (d->lda < (d->transA ? d->M : d->K) || d->ldb < (d->transB ? d->K : d->N)) return AFM_ERR_ARG;
   if (d->a_colsum && !d->transA) return AFM_ERR_ARG;

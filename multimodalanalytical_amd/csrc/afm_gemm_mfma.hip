@@ -351,9 +351,11 @@ __device__ __forceinline__ void epilogue_staged(const MfmaArgs& g, float* stg, c
 //   EPI_DROP      C = dropout(acc + bias)
 //   EPI_GELU      pre_act = acc + bias (if kept);  C = dropout(gelu(acc + bias))
 //   EPI_GELU_BWD  C = dropout(acc) * gelu'(pre_act)
+//   EPI_GELU_SG   C = dropout(gelu(acc + bias));  pre_act = keep * scale * gelu'(acc + bias)
+//   EPI_MUL       C = acc * pre_act                (the dgrad partner of EPI_GELU_SG: no erf, no hash)
 // Dropout indices are 32-bit here (the dispatcher requires M*N <= 2^32, where the stream's high-word
 // term is zero), which also removes a 64-bit multiply-add chain per element group.
-enum { EPI_GENERIC = 0, EPI_PLAIN = 1, EPI_DROP = 2, EPI_GELU = 3, EPI_GELU_BWD = 4 };
+enum { EPI_GENERIC = 0, EPI_PLAIN = 1, EPI_DROP = 2, EPI_GELU = 3, EPI_GELU_BWD = 4, EPI_GELU_SG = 5, EPI_MUL = 6 };
 __device__ __forceinline__ float afm_drop32(const DropDev& d, uint32_t idx, float x) {
   return afm_lowbias32(idx ^ d.key) >= d.thresh ? x * d.scale : 0.f;
 }
@@ -364,7 +366,7 @@ __device__ __forceinline__ void epilogue_staged_bf16(const MfmaArgs& g, float* s
   const int c8 = (lane & 7) * 8, r8 = lane >> 3;
   const int n = nw + c8;
   f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = {0.f, 0.f, 0.f, 0.f};
-  if (EPI != EPI_GELU_BWD && g.bias) { b0 = *(const f32x4*)(bias_lds + n); b1 = *(const f32x4*)(bias_lds + n + 4); }
+  if (EPI != EPI_GELU_BWD && EPI != EPI_MUL && g.bias) { b0 = *(const f32x4*)(bias_lds + n); b1 = *(const f32x4*)(bias_lds + n + 4); }
   const bool drop_on = g.dd.thresh != 0;   // wave-uniform
   bf16* const cbase = (bf16*)g.C + (int64_t)(mw + r8) * g.ldc + n;
   bf16* const pbase = (bf16*)g.pre_act + (int64_t)(mw + r8) * g.ldc + n;
@@ -373,7 +375,7 @@ __device__ __forceinline__ void epilogue_staged_bf16(const MfmaArgs& g, float* s
   // cost 8 VGPRs each: 64 at 128-row wave tiles, which spilled)
   constexpr int PF = 4;
   bf16x8 uu[2 * WM];
-  if (EPI == EPI_GELU_BWD) {
+  if (EPI == EPI_GELU_BWD || EPI == EPI_MUL) {
 #pragma unroll
     for (int q = 0; q < (PF < 2 * WM ? PF : 2 * WM); ++q) uu[q] = *(const bf16x8*)(pbase + (int64_t)(q * 8) * g.ldc);
   }
@@ -397,6 +399,24 @@ __device__ __forceinline__ void epilogue_staged_bf16(const MfmaArgs& g, float* s
         }
 #pragma unroll
         for (int k = 0; k < 8; ++k) x[k] = afm_gelu(x[k]);
+      }
+      if (EPI == EPI_GELU_SG) {
+        float gp[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          float y, yp;
+          afm_gelu_both(x[k], y, yp);
+          const float keep = drop_on ? afm_drop32(g.dd, di + k, 1.0f) : 1.0f;
+          x[k] = y * keep; gp[k] = yp * keep;
+        }
+        bf16x8 o = {(bf16)gp[0], (bf16)gp[1], (bf16)gp[2], (bf16)gp[3], (bf16)gp[4], (bf16)gp[5], (bf16)gp[6], (bf16)gp[7]};
+        *(bf16x8*)(pbase + ro) = o;
+      }
+      if (EPI == EPI_MUL) {
+        const bf16x8 u = uu[q];
+        if (q + PF < 2 * WM) uu[q + PF < 2 * WM ? q + PF : 0] = *(const bf16x8*)(pbase + (int64_t)((q + PF) * 8) * g.ldc);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) x[k] *= (float)u[k];
       }
       if (EPI == EPI_GELU_BWD) {
         const bf16x8 u = uu[q];
@@ -1286,6 +1306,7 @@ int afm_gemm_mfma_try(const afm_gemm_desc* d, hipStream_t st) {
       // register-staged kernel (case 100).
       const int64_t big_tiles = (int64_t)((d->M + 255) / 256) * ((d->N + 127) / 128);
       variant = (d->N > 128 && big_tiles >= 256) ? 24 : 13;
+      if (d->act >= AFM_ACT_GELU_SAVE_GRAD) variant = 24;   // only the loader-wave / 256x256 kernels know these epilogues
       // wide outputs of the long encoder sequence: 256x256 tiles (a quarter less L2->LDS fill and a quarter
       // fewer LDS fragment reads per FLOP, 64 MFMAs per wave between barriers): +7..12 % at N >= 1024
       const bool small_idx28 = (uint64_t)d->M * (uint64_t)d->N <= 0x100000000ull;
@@ -1294,6 +1315,7 @@ int afm_gemm_mfma_try(const afm_gemm_desc* d, hipStream_t st) {
           !(d->pre_act && d->act == AFM_ACT_NONE) && (d->drop.p <= 0.f || small_idx28))
         variant = 28;
     }
+    if (d->act >= AFM_ACT_GELU_SAVE_GRAD && variant != 24 && variant != 28) return AFM_ERR_UNSUPPORTED;
     int r;
 #define NT_CASE(WM, WN, NWM, NWN, BKT) \
     (d->c_dtype == AFM_BF16 ? launch_nt<true, WM, WN, NWM, NWN, BKT>(g, st) : launch_nt<false, WM, WN, NWM, NWN, BKT>(g, st))
@@ -1307,7 +1329,9 @@ int afm_gemm_mfma_try(const afm_gemm_desc* d, hipStream_t st) {
         if ((d->K & 63) || (d->M & 255) || (d->N & 255) || d->c_dtype != AFM_BF16 || d->residual || d->accumulate ||
             (d->N % 8) || (d->ldc % 8) || d->act == AFM_ACT_RELU || (d->pre_act && d->act == AFM_ACT_NONE) ||
             (d->drop.p > 0.f && !small_idx)) { r = AFM_ERR_UNSUPPORTED; break; }
-        if (d->act == AFM_ACT_GELU_BWD) r = launch_nt_pring<true, 2, 4, 2, 0, 8, EPI_GELU_BWD, false>(g, st, 1);
+        if (d->act == AFM_ACT_GELU_SAVE_GRAD) r = launch_nt_pring<true, 2, 4, 2, 0, 8, EPI_GELU_SG, false>(g, st, 1);
+        else if (d->act == AFM_ACT_MUL_SAVED) r = launch_nt_pring<true, 2, 4, 2, 0, 8, EPI_MUL, false>(g, st, 1);
+        else if (d->act == AFM_ACT_GELU_BWD) r = launch_nt_pring<true, 2, 4, 2, 0, 8, EPI_GELU_BWD, false>(g, st, 1);
         else if (d->act == AFM_ACT_GELU) r = launch_nt_pring<true, 2, 4, 2, 0, 8, EPI_GELU, false>(g, st, 1);
         else if (d->drop.p > 0.f) r = launch_nt_pring<true, 2, 4, 2, 0, 8, EPI_DROP, false>(g, st, 1);
         else r = launch_nt_pring<true, 2, 4, 2, 0, 8, EPI_PLAIN, false>(g, st, 1);
@@ -1317,20 +1341,29 @@ int afm_gemm_mfma_try(const afm_gemm_desc* d, hipStream_t st) {
       case 24:   // persistent 256x128, 8 MFMA waves + 4 loader waves, epilogue picked at compile time
       case 25: { // (25: same tile walk with the generic run-time epilogue, for A/B timing)
         if (d->K & 63) { r = AFM_ERR_UNSUPPORTED; break; }
-        if (d->c_dtype != AFM_BF16) { r = launch_nt_ws<false, 4>(g, st); break; }
+        if (d->c_dtype != AFM_BF16) { r = d->act >= AFM_ACT_GELU_SAVE_GRAD ? AFM_ERR_UNSUPPORTED : launch_nt_ws<false, 4>(g, st); break; }
         int epi = EPI_GENERIC;
         const bool small_idx = (uint64_t)d->M * (uint64_t)d->N <= 0x100000000ull;
         const bool dropping = d->drop.p > 0.f;
         if (variant == 24 && !d->residual && !d->accumulate && (small_idx || !dropping)) {
-          if (d->act == AFM_ACT_GELU_BWD) epi = EPI_GELU_BWD;
+          if (d->act == AFM_ACT_GELU_SAVE_GRAD) epi = EPI_GELU_SG;
+          else if (d->act == AFM_ACT_MUL_SAVED) epi = EPI_MUL;
+          else if (d->act == AFM_ACT_GELU_BWD) epi = EPI_GELU_BWD;
           else if (d->act == AFM_ACT_GELU) epi = EPI_GELU;
           else if (d->act == AFM_ACT_NONE && !d->pre_act) epi = dropping ? EPI_DROP : EPI_PLAIN;
+        }
+        // the save-grad pair exists only as whole-tile staged epilogues (the fragment epilogue of partial tiles
+        // is kept small: growing it demotes the accumulators of every kernel that inlines it to scratch)
+        if (d->act >= AFM_ACT_GELU_SAVE_GRAD && (epi == EPI_GENERIC || (d->M & 255) || (d->N & 127) || (d->ldc % 8))) {
+          r = AFM_ERR_UNSUPPORTED; break;   // FMA kernel
         }
         switch (epi) {
           case EPI_PLAIN: r = launch_nt_ws<true, 4, 0, EPI_PLAIN>(g, st); break;
           case EPI_DROP: r = launch_nt_ws<true, 4, 0, EPI_DROP>(g, st); break;
           case EPI_GELU: r = launch_nt_ws<true, 4, 0, EPI_GELU>(g, st); break;
           case EPI_GELU_BWD: r = launch_nt_ws<true, 4, 0, EPI_GELU_BWD>(g, st); break;
+          case EPI_GELU_SG: r = launch_nt_ws<true, 4, 0, EPI_GELU_SG>(g, st); break;
+          case EPI_MUL: r = launch_nt_ws<true, 4, 0, EPI_MUL>(g, st); break;
           default: r = launch_nt_ws<true, 4>(g, st); break;
         }
         break;

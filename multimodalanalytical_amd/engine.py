@@ -18,7 +18,7 @@ from typing import Any, Dict, List, Optional
 import torch
 
 from . import ops
-from .lib import ACT_GELU, ACT_GELU_BWD, ACT_NONE, ACT_RELU, ALGO_AUTO
+from .lib import ACT_GELU, ACT_GELU_BWD, ACT_GELU_SAVE_GRAD, ACT_MUL_SAVED, ACT_NONE, ACT_RELU, ALGO_AUTO
 from .params import align_dict, PATCH_TYPES, TEXT_TYPES, ParamStore, build_specs, patch_layers
 
 
@@ -396,10 +396,14 @@ class Seq2SeqEngine:
         if self.gated:
             uv = self._linear(h, p + "linear1.weight", k * f, d, bias_name=p + "linear1.bias")
             ops.glu_fwd(uv[:, :f], uv[:, f:], g, dr)
-        else:   # GELU + inner dropout fused into the up-projection's epilogue; u kept for backward
-            uv = self._empty(x.shape[0], f)
-            self._linear(h, p + "linear1.weight", f, d, out=g, bias_name=p + "linear1.bias", act=ACT_GELU,
-                         pre_act=uv, dropout=dr)
+        else:   # GELU + inner dropout fused into the up-projection's epilogue.  With backward pending the epilogue
+            # also stores keep * scale * gelu'(u) (same keep bits), so the dgrad epilogue is one multiply.
+            # (whole 256 x 256 tiles only: other shapes keep u and the GELU' epilogue)
+            sg = saved is not None and self.cd == torch.bfloat16 and x.shape[0] % 256 == 0 and f % 256 == 0
+            uv = self._empty(x.shape[0], f) if saved is not None else None
+            self._linear(h, p + "linear1.weight", f, d, out=g, bias_name=p + "linear1.bias",
+                         act=ACT_GELU_SAVE_GRAD if sg else ACT_GELU, pre_act=uv, dropout=dr)
+            dr = (dr, sg)
         br = self._linear(g, p + "linear2.weight", d, f, bias_name=p + "linear2.bias", dropout=self._drop(site + "res2"))
         if saved is not None:
             saved["ffn"] = (h, uv, g, dr)
@@ -414,8 +418,10 @@ class Seq2SeqEngine:
         if self.gated:
             dg = self._dgrad(dy, p + "linear2.weight", d, f)
             ops.glu_bwd(uv[:, :f], uv[:, f:], dg, duv[:, :f], duv[:, f:], dr)
-        else:   # du = dropout'(dy W2) * gelu'(u) in the dgrad epilogue: dg never reaches HBM
-            self._dgrad(dy, p + "linear2.weight", d, f, out=duv, act=ACT_GELU_BWD, pre_act=uv, dropout=dr)
+        elif dr[1]:   # du = (dy W2) * [keep * scale * gelu'(u)] in the dgrad epilogue: dg never reaches HBM
+            self._dgrad(dy, p + "linear2.weight", d, f, out=duv, act=ACT_MUL_SAVED, pre_act=uv)
+        else:       # du = dropout'(dy W2) * gelu'(u)
+            self._dgrad(dy, p + "linear2.weight", d, f, out=duv, act=ACT_GELU_BWD, pre_act=uv, dropout=dr[0])
         self._wgrad(duv, h, p + "linear1.weight", k * f, d, bias_name=p + "linear1.bias")
         dh = self._dgrad(duv, p + "linear1.weight", k * f, d)
         return self._ln_bwd(dh, p + norm, saved, "lnf", dres=dx1, next_site=next_site)

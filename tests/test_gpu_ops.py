@@ -510,7 +510,7 @@ def test_layernorm_fused_residual_add(ops, adt):
 
 @pytest.mark.parametrize("variant", [12, 24, 25])
 @pytest.mark.parametrize("cdt", [torch.bfloat16, torch.float32])
-@pytest.mark.parametrize("mode", ["bias", "gelu_preact_drop", "gelu_bwd", "residual_acc"])
+@pytest.mark.parametrize("mode", ["bias", "gelu_preact_drop", "gelu_bwd", "residual_acc", "gelu_save_grad_pair"])
 def test_gemm_persistent_staged_epilogue(ops, cdt, mode, variant):
     """Full tiles (256x128) + edge tiles through the persistent kernel's LDS-staged epilogue."""
     M, N, K = 1024 + 77, 512 + 40, 128
@@ -535,6 +535,29 @@ def test_gemm_persistent_staged_epilogue(ops, cdt, mode, variant):
         ur = ud.float().cpu().double().requires_grad_(True)
         O.gelu(ur).backward(torch.ones(M, N, dtype=torch.float64))
         close(c, t * keep / (1 - p) * ur.grad, **tol)
+    elif mode == "gelu_save_grad_pair":
+        # forward stores keep*scale*gelu'(T) (act 4); the dgrad multiplies by it (act 5): same values as act 2 / act 3
+        if variant != 24 and not (variant == 25 and cdt == torch.float32):
+            pytest.skip("only the loader-wave kernel (and the FMA kernel) know this epilogue pair")
+        alg = 2 if variant == 24 and cdt == torch.bfloat16 else 1
+        if alg == 2:     # the MFMA form exists for whole tiles only (partial tiles: FMA kernel, refused under algo=2)
+            with pytest.raises(Exception):
+                ops.gemm(dev(a), dev(w), c, bias=dev(bias), act=4, pre_act=torch.zeros_like(c), algo=2, variant=24)
+            M, N = 1024, 512
+            a, w, bias = a[:M], w[:N], bias[:N]
+            t = a.double() @ w.double().T
+            c = torch.zeros(M, N, dtype=cdt, device=DEV)
+            keep = torch.from_numpy(keep_mask(p, seed, site, M * N)).view(M, N)
+        aa, ww = (dev(a), dev(w)) if alg == 2 else (dev(a).float(), dev(w).float())
+        gp = torch.zeros_like(c)
+        ops.gemm(aa, ww, c, bias=dev(bias), act=4, pre_act=gp, dropout=ops.drop(p, seed, site), algo=alg, variant=variant if alg == 2 else 0)
+        tr = (t + bias.double()).requires_grad_(True)
+        O.gelu(tr).backward(torch.ones(M, N, dtype=torch.float64))
+        close(c, O.gelu(tr.detach()) * keep / (1 - p), **tol)
+        close(gp, tr.grad * keep / (1 - p), **tol)
+        c2 = torch.zeros_like(c)
+        ops.gemm(aa, ww, c2, act=5, pre_act=gp, algo=alg, variant=variant if alg == 2 else 0)
+        close(c2, t * gp.float().cpu().double(), **tol)
     else:
         if cdt == torch.bfloat16:
             pytest.skip("bf16 residual/accumulate take the fragment epilogue (covered elsewhere)")
@@ -736,7 +759,7 @@ def test_gemm_skinny_n_patch_embed_wgrad(ops, accumulate):
     close(gb, dy.double().sum(0), 1e-4, 1e-4)
 
 
-@pytest.mark.parametrize("mode", ["bias", "drop", "gelu_preact_drop", "gelu_bwd"])
+@pytest.mark.parametrize("mode", ["bias", "drop", "gelu_preact_drop", "gelu_bwd", "gelu_save_grad_pair"])
 def test_gemm_256x256_variant(ops, mode):
     """Persistent 256x256-tile kernel (variant 28; picked automatically for N >= 1024 at M >= 32k): whole tiles only."""
     M, N, K = 768, 512, 256
@@ -757,6 +780,16 @@ def test_gemm_256x256_variant(ops, mode):
         ops.gemm(dev(a), dev(w), c, bias=dev(bias), act=2, pre_act=pre, dropout=ops.drop(p, seed, site), algo=2, variant=28)
         close(pre, t + bias.double(), **tol)
         close(c, O.gelu(t + bias.double()) * keep / (1 - p), **tol)
+    elif mode == "gelu_save_grad_pair":
+        gp = torch.zeros_like(c)
+        ops.gemm(dev(a), dev(w), c, bias=dev(bias), act=4, pre_act=gp, dropout=ops.drop(p, seed, site), algo=2, variant=28)
+        tr = (t + bias.double()).requires_grad_(True)
+        O.gelu(tr).backward(torch.ones(M, N, dtype=torch.float64))
+        close(c, O.gelu(tr.detach()) * keep / (1 - p), **tol)
+        close(gp, tr.grad * keep / (1 - p), **tol)
+        c2 = torch.zeros_like(c)
+        ops.gemm(dev(a), dev(w), c2, act=5, pre_act=gp, algo=2, variant=28)
+        close(c2, t * gp.float().cpu().double(), **tol)
     else:
         u = rnd(M, N, seed=4)
         ud = dev(u, torch.bfloat16)
