@@ -32,6 +32,11 @@ def main():
                     res.append(f"gelu-v{var} {2*M*N*K/ms/1e9:5.0f}")
                     ms = t(lambda: ops.gemm(a, w, c, act=3, pre_act=pre, dropout=dr, variant=var))
                     res.append(f"gbwd-v{var} {2*M*N*K/ms/1e9:5.0f}")
+                    if M % 256 == 0 and N % 256 == 0:   # save-grad pair (whole tiles only)
+                        ms = t(lambda: ops.gemm(a, w, c, bias=bias, act=4, pre_act=pre, dropout=dr, variant=var))
+                        res.append(f"gsg-v{var} {2*M*N*K/ms/1e9:5.0f}")
+                        ms = t(lambda: ops.gemm(a, w, c, act=5, pre_act=pre, variant=var))
+                        res.append(f"mul-v{var} {2*M*N*K/ms/1e9:5.0f}")
                     ms = t(lambda: ops.gemm(a, w, c, bias=bias, dropout=dr, variant=var))
                     res.append(f"drop-v{var} {2*M*N*K/ms/1e9:5.0f}")
             print(f"NT {name:10s} {M}x{N}x{K} out {str(cdt)[6:]:8s} TF/s: " + "  ".join(res))
