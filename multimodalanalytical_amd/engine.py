@@ -547,6 +547,8 @@ class Seq2SeqEngine:
             st["pool"] = torch.cuda.graph_pool_handle()
             self.decode_step(st, st["ids_static"])      # eager warm-up: one-time function attributes, allocator
             torch.cuda.synchronize()
+            while len(self._graph_states) >= 2:          # at most two decode shapes stay resident (caches + graphs)
+                self._graph_states.pop(next(iter(self._graph_states)))
             self._graph_states[key] = st
         else:
             st["mem_pad"].copy_((attention_mask == 0).to(torch.uint8))
