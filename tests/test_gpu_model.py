@@ -292,3 +292,46 @@ def test_c2_shape_parity_vs_oracle():
             assert float(agree) > 0.97
             torch.testing.assert_close(out["loss"].cpu(), ref["loss"], rtol=2e-2, atol=2e-2)
         print(f"c2-shape parity {dtype}: logits rel err {err:.2e}")
+
+
+def test_c2_full_size_properties():
+    """BASELINE's full C2 size (B = 128, S = 1024, T = 128, bf16), through size-independent properties:
+    (1) batch permutation equivariance of the logits / argmax ids (dropout off); (2) the micro-batch of 128 equals
+    its two halves run separately (loss = label-weighted mean, logits row by row); (3) gradient accumulation is
+    linear: grads(batch, scale 1) == grads(batch, 1/2) accumulated twice; (4) every gradient is finite."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from multimodalanalytical_amd import synth
+    from multimodalanalytical_amd.engine import Seq2SeqEngine
+    wl = synth.WORKLOADS["c2"]
+    B = 128
+    batch, _ = synth.make_batch("c2", B, seed=21)
+    enc, am, dec, dm, labels = O.batch_to_model_inputs(batch, "Smiles")
+    to = lambda x: {k: to(v) for k, v in x.items()} if isinstance(x, dict) else x.to(DEV)
+    enc, am, dec, dm, labels = to(enc), am.to(DEV), dec.to(DEV), dm.to(DEV), labels.to(DEV)
+    eng = Seq2SeqEngine(dict(wl["cfg"], dropout=0.0), wl["data"], "Smiles", 128, device=DEV, compute_dtype=torch.bfloat16, seed=5)
+    sel = lambda x, idx: {k: sel(v, idx) for k, v in x.items()} if isinstance(x, dict) else x[idx]
+    full = eng.forward(enc, am, dec, dm, labels)
+    # (1) permutation
+    perm = torch.randperm(B, generator=torch.Generator().manual_seed(3)).to(DEV)
+    pm = eng.forward(sel(enc, perm), am[perm], dec[perm], dm[perm], labels[perm])
+    assert torch.equal(pm["argmax"], full["argmax"][perm])
+    assert float((pm["logits"] - full["logits"][perm]).abs().max()) <= 1e-3 * float(full["logits"].abs().max())
+    torch.testing.assert_close(pm["loss"], full["loss"], rtol=1e-5, atol=1e-5)
+    # (2) halves
+    h0, h1 = torch.arange(0, B // 2, device=DEV), torch.arange(B // 2, B, device=DEV)
+    o0 = eng.forward(sel(enc, h0), am[h0], dec[h0], dm[h0], labels[h0])
+    o1 = eng.forward(sel(enc, h1), am[h1], dec[h1], dm[h1], labels[h1])
+    assert torch.equal(torch.cat([o0["argmax"], o1["argmax"]]), full["argmax"])
+    n0, n1 = float((labels[h0] != -100).sum()), float((labels[h1] != -100).sum())
+    torch.testing.assert_close((o0["loss"] * n0 + o1["loss"] * n1) / (n0 + n1), full["loss"], rtol=1e-5, atol=1e-5)
+    # (3) accumulation linearity, (4) finiteness
+    eng.ps.grad.zero_()
+    eng.forward(enc, am, dec, dm, labels, backward=True, loss_scale=1.0)
+    g1 = eng.ps.grad.clone()
+    eng.ps.grad.zero_()
+    eng.forward(enc, am, dec, dm, labels, backward=True, loss_scale=0.5)
+    eng.forward(enc, am, dec, dm, labels, backward=True, loss_scale=0.5)
+    g2 = eng.ps.grad
+    assert torch.isfinite(g1).all() and float(g1.abs().max()) > 0
+    assert float((g1 - g2).norm() / g1.norm()) < 2e-3      # bf16 rounding of the scaled activation gradients
