@@ -169,7 +169,7 @@ __device__ __forceinline__ void build_mask_words(unsigned long long* maskw, cons
 
 // ------------------------------------------------------------------------------------------ forward
 template <bool DROP>
-__global__ __launch_bounds__(256, 2) void k_attn_fwd_mfma(AttnM a, const bf16* __restrict__ Q,
+__global__ __launch_bounds__(256, 3) void k_attn_fwd_mfma(AttnM a, const bf16* __restrict__ Q,
                                                           const bf16* __restrict__ K,
                                                           const bf16* __restrict__ V, bf16* __restrict__ O,
                                                           float* __restrict__ lse) {
