@@ -119,7 +119,9 @@ int afm_scatter_add_rows(const int64_t* ids, const float* scale, const float* do
  * Residual fusion: when `add` is given (rows x d, dtype add_dtype) the kernel first forms
  * x_sum = x + add, writes it to `x_sum` (fp32, may alias x) and normalises THAT: the residual add
  * `x + dropout(branch)` of the pre-LN blocks (torch:nn/modules/transformer.py:946-950) rides on
- * the LayerNorm that reads the stream next, so the projection GEMMs write plain bf16 branches.
+ * the LayerNorm that reads the stream next, so the projection GEMMs write plain bf16 branches; with
+ * `add_drop` the branch dropout is applied here too (this kernel is HBM-bound and has the VALU slack for
+ * the hash, the GEMM epilogue does not).
  * Backward: dx[r,:] = (dres ? dres[r,:] : 0) + LN'(dy[out_row(r),:]); dgamma/dbeta are
  * ACCUMULATED (+=) into fp32 buffers; `partial` is workspace of afm_layernorm_bwd_ws_floats().
  * `dx_drop` (optional, dtype y_dtype, rows x d): dropout(dx) with stream `drop`, i.e. the gradient
@@ -133,6 +135,9 @@ typedef struct {
   int64_t seg_len, out_seg_stride, out_off;
   float eps;
   int32_t add_dtype;      /* dtype of `add` (forward only) */
+  afm_dropout add_drop;   /* forward only: x_sum = x + dropout(add) with this stream (p = 0: plain add); the
+                             element index is row-major in `add`, the same index the GEMM epilogue and the
+                             backward's dx_drop use for that site */
 } afm_ln_shape;
 int afm_layernorm_fwd(const afm_ln_shape* s, const float* x, const float* gamma, const float* beta,
                       const float* pos, void* y, float* mean, float* rstd, const void* add,

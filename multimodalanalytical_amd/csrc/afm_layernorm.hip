@@ -20,7 +20,7 @@ __global__ void k_ln_fwd(const float* x, const float* __restrict__ gamma,
                          const float* __restrict__ beta, const float* __restrict__ pos,
                          TY* __restrict__ y, float* __restrict__ mean, float* __restrict__ rstd,
                          int64_t rows, int d, int64_t seg_len, int64_t seg_stride, int64_t off,
-                         float eps, const void* __restrict__ add, int add_bf16, float* x_sum) {
+                         float eps, const void* __restrict__ add, int add_bf16, float* x_sum, DropDev adrop) {
   const int lane = threadIdx.x & 63;
   const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
@@ -34,7 +34,8 @@ __global__ void k_ln_fwd(const float* x, const float* __restrict__ gamma,
       const int j = lane + 64 * i;
       v[i] = j < d ? xr[j] : 0.f;
       if (add && j < d) {   // fused residual add: the stream value is written back once
-        v[i] += add_bf16 ? (float)((const bf16*)add)[r * (int64_t)d + j] : ((const float*)add)[r * (int64_t)d + j];
+        const float a = add_bf16 ? (float)((const bf16*)add)[r * (int64_t)d + j] : ((const float*)add)[r * (int64_t)d + j];
+        v[i] += afm_drop(adrop, (uint64_t)r * (uint64_t)d + (uint64_t)j, a);   // branch dropout rides on the add
         x_sum[r * (int64_t)d + j] = v[i];
       }
       s += v[i];
@@ -91,7 +92,7 @@ __global__ __launch_bounds__(256) void k_ln_fwd_vec(const float* x, const float*
                                                     const float* __restrict__ beta, TY* __restrict__ y,
                                                     float* __restrict__ mean, float* __restrict__ rstd,
                                                     int64_t rows, int d, float eps, const TA* __restrict__ add,
-                                                    float* x_sum) {
+                                                    float* x_sum, DropDev adrop) {
   const int lane = threadIdx.x & 63;
   const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
@@ -111,7 +112,12 @@ __global__ __launch_bounds__(256) void k_ln_fwd_vec(const float* x, const float*
       if (c < d) {
         v[i] = ld8(x + r * (int64_t)d + c);
         if (add) {
-          const F8 a = ld8(add + r * (int64_t)d + c);
+          F8 a = ld8(add + r * (int64_t)d + c);
+          if (adrop.thresh) {   // wave-uniform: dropout of the residual branch, index row-major in `add`
+            const uint64_t base = (uint64_t)r * (uint64_t)d + (uint64_t)c;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { a.lo[k] = afm_drop(adrop, base + k, a.lo[k]); a.hi[k] = afm_drop(adrop, base + 4 + k, a.hi[k]); }
+          }
           v[i].lo += a.lo; v[i].hi += a.hi;
           st8(x_sum + r * (int64_t)d + c, v[i]);
         }
@@ -220,6 +226,7 @@ extern "C" int afm_layernorm_fwd(const afm_ln_shape* s, const float* x, const fl
   if (!s || !x || !gamma || !beta || !y || s->rows < 0 || s->d <= 0) return AFM_ERR_ARG;
   if (add && (!x_sum || (s->add_dtype != AFM_F32 && s->add_dtype != AFM_BF16) || s->seg_len != 0)) return AFM_ERR_ARG;
   const int add_bf16 = s->add_dtype == AFM_BF16;
+  const DropDev adrop = afm_make_drop(add ? &s->add_drop : nullptr);
   if (s->d > 64 * LN_MAXV) return AFM_ERR_UNSUPPORTED;
   if (s->rows == 0) return AFM_OK;
   int64_t g = (s->rows + 3) / 4;
@@ -228,7 +235,7 @@ extern "C" int afm_layernorm_fwd(const afm_ln_shape* s, const float* x, const fl
   if (s->y_dtype != AFM_F32 && s->y_dtype != AFM_BF16) return AFM_ERR_ARG;
   if (s->seg_len == 0 && !pos && (s->d % 8) == 0 && s->d <= 2048 && s->rows >= 64) {   // vectorised path
 #define LN_FV(TY, TA, NC) AFM_LAUNCH((k_ln_fwd_vec<TY, TA, NC>), dim3((int)g), dim3(256), 0, st, x, gamma, beta, (TY*)y, mean, \
-                                     rstd, s->rows, s->d, s->eps, (const TA*)add, x_sum)
+                                     rstd, s->rows, s->d, s->eps, (const TA*)add, x_sum, adrop)
 #define LN_FV2(TY, TA) do { if (s->d <= 512) LN_FV(TY, TA, 1); else if (s->d <= 1024) LN_FV(TY, TA, 2); else LN_FV(TY, TA, 4); } while (0)
     if (s->y_dtype == AFM_BF16) { if (add_bf16) LN_FV2(bf16, bf16); else LN_FV2(bf16, float); }
     else { if (add_bf16) LN_FV2(float, bf16); else LN_FV2(float, float); }
@@ -241,11 +248,11 @@ extern "C" int afm_layernorm_fwd(const afm_ln_shape* s, const float* x, const fl
     if (s->y_dtype == AFM_F32)                                                                      \
       AFM_LAUNCH((k_ln_fwd<float, NV>), dim3((int)g), dim3(256), 0, st, x, gamma, beta, pos, \
                          (float*)y, mean, rstd, s->rows, s->d, s->seg_len, s->out_seg_stride,       \
-                         s->out_off, s->eps, add, add_bf16, x_sum);                                   \
+                         s->out_off, s->eps, add, add_bf16, x_sum, adrop);                            \
     else                                                                                            \
       AFM_LAUNCH((k_ln_fwd<bf16, NV>), dim3((int)g), dim3(256), 0, st, x, gamma, beta, pos,  \
                          (bf16*)y, mean, rstd, s->rows, s->d, s->seg_len, s->out_seg_stride,        \
-                         s->out_off, s->eps, add, add_bf16, x_sum);                                   \
+                         s->out_off, s->eps, add, add_bf16, x_sum, adrop);                            \
   } while (0)
   const int nv = (s->d + 63) / 64;
   if (nv <= 1) LN_FWD(1); else if (nv <= 2) LN_FWD(2); else if (nv <= 4) LN_FWD(4);

@@ -331,9 +331,12 @@ class Seq2SeqEngine:
         mean = torch.empty(rows, dtype=torch.float32, device=self.dev)
         rstd = torch.empty(rows, dtype=torch.float32, device=self.dev)
         if pend is not None:
+            # `pend` = (branch, its dropout stream): the GEMM that produced the branch wrote it plain, the
+            # dropout is applied here on the way into the stream (this kernel is HBM-bound, the hash is free)
+            br, br_drop = pend if isinstance(pend, tuple) else (pend, ops.NO_DROP)
             xs = torch.empty_like(x)   # x itself is the saved input of an earlier LayerNorm: keep it
             ops.layernorm_fwd(x, self.ps.p(prefix + "weight"), self.ps.p(prefix + "bias"), y, mean, rstd,
-                              add=pend, x_sum=xs)
+                              add=br, x_sum=xs, add_dropout=br_drop)
             x = xs
         else:
             ops.layernorm_fwd(x, self.ps.p(prefix + "weight"), self.ps.p(prefix + "bias"), y, mean, rstd)
@@ -366,11 +369,10 @@ class Seq2SeqEngine:
         shp = ops.attn_shape(B, H, T, T, d // H, self.cd, 3 * d, 3 * d, 3 * d, d, key_pad, causal,
                              self._drop(site + "attn"), self.algo)
         ops.attn_fwd(shp, qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], a, lse)
-        br = self._linear(a, p + "self_attn.out_proj.weight", d, d, bias_name=p + "self_attn.out_proj.bias",
-                          dropout=self._drop(site + "res"))
+        br = self._linear(a, p + "self_attn.out_proj.weight", d, d, bias_name=p + "self_attn.out_proj.bias")
         if saved is not None:
             saved["sa"] = (h, qkv, a, lse, shp)
-        return x, br
+        return x, (br, self._drop(site + "res"))
 
     def _self_attn_bwd(self, dx1, dy, p, saved, next_site):
         """dx1: fp32 grad of the stream after this block; dy = dropout'(dx1) in the compute dtype.
@@ -404,10 +406,10 @@ class Seq2SeqEngine:
             self._linear(h, p + "linear1.weight", f, d, out=g, bias_name=p + "linear1.bias",
                          act=ACT_GELU_SAVE_GRAD if sg else ACT_GELU, pre_act=uv, dropout=dr)
             dr = (dr, sg)
-        br = self._linear(g, p + "linear2.weight", d, f, bias_name=p + "linear2.bias", dropout=self._drop(site + "res2"))
+        br = self._linear(g, p + "linear2.weight", d, f, bias_name=p + "linear2.bias")
         if saved is not None:
             saved["ffn"] = (h, uv, g, dr)
-        return x, br
+        return x, (br, self._drop(site + "res2"))
 
     def _ffn_bwd(self, dx1, dy, p, f, norm, saved, next_site):
         d, k = self.d, (2 if self.gated else 1)
@@ -438,10 +440,10 @@ class Seq2SeqEngine:
                              self._drop(site + "xattn"), self.algo)
         ops.attn_fwd(shp, q, kv[:, :d], kv[:, d:], a, lse)
         br = self._linear(a, p + "multihead_attn.out_proj.weight", d, d,
-                          bias_name=p + "multihead_attn.out_proj.bias", dropout=self._drop(site + "xres"))
+                          bias_name=p + "multihead_attn.out_proj.bias")
         if saved is not None:
             saved["ca"] = (h, q, kv, a, lse, shp)
-        return x, br
+        return x, (br, self._drop(site + "xres"))
 
     def _cross_attn_bwd(self, dx1, dy, mem, dmem, p, saved, next_site, dkv_all=None, layer=0):
         d = self.d

@@ -49,7 +49,7 @@ class LnShape(C.Structure):
     _fields_ = [
         ("rows", C.c_int64), ("d", C.c_int32), ("y_dtype", C.c_int32),
         ("seg_len", C.c_int64), ("out_seg_stride", C.c_int64), ("out_off", C.c_int64),
-        ("eps", C.c_float), ("add_dtype", C.c_int32),
+        ("eps", C.c_float), ("add_dtype", C.c_int32), ("add_drop", Dropout),
     ]
 
 

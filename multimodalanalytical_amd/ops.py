@@ -115,14 +115,15 @@ def ln_shape(rows, d, y_dtype, seg_len=0, out_seg_stride=0, out_off=0, eps=1e-5)
 
 
 def layernorm_fwd(x, gamma, beta, y, mean=None, rstd=None, pos=None, seg_len=0, out_seg_stride=0,
-                  out_off=0, eps=1e-5, add=None, x_sum=None):
-    """y = LN(x [+ add]); with `add` the summed stream is also written to x_sum (fp32, may be x)."""
+                  out_off=0, eps=1e-5, add=None, x_sum=None, add_dropout: Dropout = NO_DROP):
+    """y = LN(x [+ dropout(add)]); with `add` the summed stream is also written to x_sum (fp32, may be x)."""
     rows, d = x.shape
     assert x.dtype == torch.float32 and x.is_contiguous()
     s = ln_shape(rows, d, y.dtype, seg_len, out_seg_stride, out_off, eps)
     if add is not None:
         assert add.shape == x.shape and add.is_contiguous() and x_sum is not None and x_sum.dtype == torch.float32
         s.add_dtype = _dt(add)
+        s.add_drop = add_dropout
     L.check(L.load().afm_layernorm_fwd(C.byref(s), _ptr(x), _ptr(gamma), _ptr(beta), _ptr(pos), _ptr(y),
                                        _ptr(mean), _ptr(rstd), _ptr(add), _ptr(x_sum), _stream()),
             "afm_layernorm_fwd")

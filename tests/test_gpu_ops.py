@@ -811,3 +811,30 @@ def test_gemm_tn_256x256_variant(ops, R, M, N):
     assert ops.last_algo().startswith("mfma_tn_ring256")
     close(g, dy.double().T @ x.double() + g0.double(), 2e-3, 2e-2 * math.sqrt(R / 4096))
     close(gb, dy.double().sum(0), 2e-3, 2e-2 * math.sqrt(R / 4096))
+
+
+@pytest.mark.parametrize("adt,d", [(torch.bfloat16, 512), (torch.float32, 96)])
+def test_layernorm_residual_add_with_branch_dropout(ops, adt, d):
+    """x_sum = x + dropout(branch) inside the LayerNorm that reads the stream next (vectorised and scalar kernels);
+    the mask is the site's stream over the branch tensor, the same one the backward's dx_drop uses."""
+    rows = 130
+    x, br = rnd(rows, d, seed=1), rnd(rows, d, seed=2)
+    gam, bet = 1 + 0.1 * rnd(d, seed=3), 0.1 * rnd(d, seed=4)
+    brd = dev(br, adt)
+    p, seed, site = 0.1, 77, 5
+    keep = torch.from_numpy(keep_mask(p, seed, site, rows * d)).view(rows, d)
+    y = torch.empty(rows, d, dtype=torch.bfloat16, device=DEV); xs = torch.empty(rows, d, device=DEV)
+    ops.layernorm_fwd(dev(x), dev(gam), dev(bet), y, add=brd, x_sum=xs, add_dropout=ops.drop(p, seed, site))
+    ref_sum = x.double() + brd.float().cpu().double() * keep / (1 - p)
+    close(xs, ref_sum, 1e-6, 1e-6)
+    close(y, O.layer_norm(ref_sum, gam.double(), bet.double()), 1e-2, 1e-2)
+    # and the matching backward mask: dx_drop of layernorm_bwd keeps exactly the same elements
+    dy = dev(rnd(rows, d, seed=6))
+    mean = torch.empty(rows, device=DEV); rstd = torch.empty(rows, device=DEV)
+    y32 = torch.empty(rows, d, device=DEV)
+    ops.layernorm_fwd(xs, dev(gam), dev(bet), y32, mean, rstd)
+    dx = torch.empty(rows, d, device=DEV); dxd = torch.empty(rows, d, device=DEV)
+    gg, gb = torch.zeros(d, device=DEV), torch.zeros(d, device=DEV)
+    ws = torch.empty(ops.layernorm_bwd_ws(rows, d), device=DEV)
+    ops.layernorm_bwd(dy, xs, dev(gam), mean, rstd, dx, gg, gb, ws, dx_drop=dxd, dropout=ops.drop(p, seed, site))
+    close(dxd, dx.cpu().double() * keep / (1 - p), 1e-6, 1e-6)
