@@ -66,9 +66,9 @@ def dominant_kernel_roofline(model, wl, B, dtype):
     (bf16) + dW1 written once (fp32) = 2*B*S*(f+d) + 4*f*d; at 8 TB/s that is less time than the
     FLOPs take at the dense bf16 MFMA peak, so the MFMA roof is the binding one.
     `secondary` is the same measurement for the forward launch of that layer (x W1^T with the
-    bias + GELU + dropout epilogue, pre-activation kept), whose 2 x 537 MB of output make HBM its roof."""
+    bias + GELU + dropout epilogue, keep*scale*GELU' stored for backward), whose 2 x 537 MB of output make HBM its roof."""
     from multimodalanalytical_amd import ops
-    from multimodalanalytical_amd.lib import ACT_GELU
+    from multimodalanalytical_amd.lib import ACT_GELU_SAVE_GRAD
     cfg = wl["cfg"]
     S = sum(v[0] if isinstance(v, tuple) else v for v in wl["lens"].values())
     d, f = cfg["d_model"], cfg["encoder_ffn_dim"] * (2 if cfg["gated_linear"] else 1)
@@ -100,13 +100,13 @@ def dominant_kernel_roofline(model, wl, B, dtype):
         bias = eng.ps.p("encoder.layers.0.linear1.bias")
         pre = torch.empty_like(o)
         dr = ops.drop(cfg["dropout"], 1, 1)
-        ms2 = time_kernel(lambda: ops.gemm(x, w, o, trans_b=True, bias=bias, act=ACT_GELU, pre_act=pre, dropout=dr))
+        ms2 = time_kernel(lambda: ops.gemm(x, w, o, trans_b=True, bias=bias, act=ACT_GELU_SAVE_GRAD, pre_act=pre, dropout=dr))
         by = esz * (M * d + f * d) + 2 * esz * M * f
         tr2 = None
         pmc2 = os.path.join(ROOT, "profiles", "r01_ffn1_gemm_pmc.json")
         if os.path.exists(pmc2) and (M, f, d) == (131072, 2048, 512) and dtype == "bf16":
             tr2 = json.load(open(pmc2)).get("traffic_bytes_per_launch")
-        out["secondary"] = {"bound": "hbm", "kernel": f"afm_gemm[{ops.last_algo()}] {M}x{f}x{d} (FFN linear1 forward, fused bias+GELU+dropout, pre-activation kept)",
+        out["secondary"] = {"bound": "hbm", "kernel": f"afm_gemm[{ops.last_algo()}] {M}x{f}x{d} (FFN linear1 forward, fused bias+GELU+dropout, keep*scale*GELU' stored for backward)",
                             "achieved": round(by / (ms2 * 1e-3) / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
                             "frac": round(by / (ms2 * 1e-3) / 1e9 / 8000.0, 4), "traffic": tr2,
                             "algorithmic_bytes": by, "avg_launch_ms": round(ms2, 4),

@@ -20,10 +20,10 @@ def main():
         x = torch.randn(M, K, device=dev).bfloat16(); w = torch.randn(N, K, device=dev).bfloat16()
         c = torch.empty(M, N, dtype=torch.bfloat16 if a.out == "bf16" else torch.float32, device=dev)
         if a.op == "gemm_nt" and a.shape == "ffn1" and a.out == "bf16" and a.variant == 0:
-            # the training launch of the FFN up-projection: bias + GELU + dropout, pre-activation kept
+            # the training launch of the FFN up-projection: bias + GELU + dropout, keep*scale*GELU' stored for backward
             bias = torch.randn(N, device=dev); pre = torch.empty_like(c); dr = ops.drop(0.1, 1, 1)
             for _ in range(a.iters):
-                ops.gemm(x, w, c, bias=bias, act=2, pre_act=pre, dropout=dr)
+                ops.gemm(x, w, c, bias=bias, act=4, pre_act=pre, dropout=dr)
         else:
             for _ in range(a.iters):
                 ops.gemm(x, w, c, variant=a.variant)
