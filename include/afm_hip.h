@@ -15,7 +15,15 @@
  *     returns immediately (safe under hipGraph stream capture);
  *   - return value: AFM_OK (0) or a negative AFM_ERR_* code; nothing is launched on error;
  *   - matrices are row-major; `ld*` are row strides in ELEMENTS;
- *   - dtype codes: AFM_F32 = 0 (float), AFM_BF16 = 1 (bfloat16, round-to-nearest-even).
+ *   - dtype codes: AFM_F32 = 0 (float), AFM_BF16 = 1 (bfloat16, round-to-nearest-even),
+ *     AFM_BF16X2 = 2: a SPLIT bf16 pair per element, value = hi + lo with hi = bf16(v) and
+ *     lo = bf16(v - hi) (16 significant bits).  The two bf16 planes of a row sit side by side: a tensor
+ *     with row stride ld (elements) keeps hi(r, c) at base[r*ld + c] and lo(r, c) at base[r*ld + ld/2 + c],
+ *     so a contiguous (rows x n) tensor occupies rows x 2n bf16 and any column slice keeps the parent's
+ *     ld.  The hi plane alone is a valid AFM_BF16 tensor of the same ld.  GEMM / attention on split
+ *     operands run three bf16 MFMAs per product (hi*hi + hi*lo + lo*hi, fp32 accumulate): the
+ *     "bf16x3" precision mode, fp32-grade results (the <= 1e-3 logits / exact-argmax bar of the parity
+ *     tests) on the bf16 matrix cores.
  */
 #ifndef AFM_HIP_H
 #define AFM_HIP_H
@@ -26,15 +34,19 @@
 extern "C" {
 #endif
 
-#define AFM_ABI_VERSION 1
+#define AFM_ABI_VERSION 2
 
 enum { AFM_OK = 0, AFM_ERR_ARG = -1, AFM_ERR_UNSUPPORTED = -2, AFM_ERR_LAUNCH = -3 };
-enum { AFM_F32 = 0, AFM_BF16 = 1 };
+enum { AFM_F32 = 0, AFM_BF16 = 1, AFM_BF16X2 = 2 };
 enum { AFM_ACT_NONE = 0, AFM_ACT_RELU = 1, AFM_ACT_GELU = 2, AFM_ACT_GELU_BWD = 3,
        AFM_ACT_GELU_SAVE_GRAD = 4, AFM_ACT_MUL_SAVED = 5 };
 enum { AFM_ALGO_AUTO = 0, AFM_ALGO_GENERIC = 1, AFM_ALGO_MFMA = 2 };
 
 int afm_abi_version(void);
+/* sizeof() of the ABI structs as compiled into the library (0 afm_dropout, 1 afm_gemm_desc, 2 afm_ln_shape,
+ * 3 afm_attn_shape, 4 afm_patch_desc; -1 otherwise): a binding checks its own struct layouts against these,
+ * so a stale library cannot be driven with newer descriptors. */
+int afm_struct_size(int which);
 const char* afm_error_string(int code);
 /* Name of the kernel family the last afm_gemm / afm_attn_* call on this thread dispatched to
  * ("generic", "mfma_nt", "mfma_tn", ...): lets tests assert the fast path really ran. */
@@ -198,6 +210,14 @@ int afm_glu_bwd(const void* u, const void* v, const void* dg, void* du, void* dv
                 int32_t dtype, const afm_dropout* drop, void* stream);
 int afm_dropout_cast(const float* x, void* y, int64_t rows, int32_t n, int32_t ldx, int32_t ldy,
                      int32_t y_dtype, const afm_dropout* drop, void* stream);
+/* ReLU backward: dx[i] = act[i] > 0 ? dy[i] : 0 (fp32; dx may alias dy).  The hidden layers of the patch
+ * embedders (linear_2_layer / linear_3_layer, modeling/utils.py:107-136) and of the alignment head
+ * (custom_modeling.py:363-396). */
+int afm_relu_bwd(const float* dy, const float* act, float* dx, int64_t n, void* stream);
+/* dst = (dst_dtype) src, any pair of AFM_F32 / AFM_BF16 / AFM_BF16X2, rows x n with row strides lds / ldd
+ * (elements of the respective dtype's planes, see the AFM_BF16X2 convention above). */
+int afm_convert(const void* src, int32_t src_dtype, int32_t lds, void* dst, int32_t dst_dtype, int32_t ldd,
+                int64_t rows, int32_t n, void* stream);
 /* Column sums (bias gradients): out[j] (+)= sum_i x[i*ld + j].  Backward of the bias add of
  * every aten::linear above. */
 int afm_colsum(const void* x, float* out, int64_t rows, int32_t n, int32_t ld, int32_t dtype,
@@ -211,6 +231,9 @@ int afm_batch_sum(const float* x, float* out, int32_t B, int64_t S, int32_t d, i
 /* fp32 -> bf16 copies of the weights for the MFMA GEMMs: dst (rows x cols) and, when dst_t is
  * given, the transpose (cols x rows) used by dgrad. */
 int afm_cast_bf16(const float* src, void* dst, void* dst_t, int32_t rows, int32_t cols, void* stream);
+/* The same for the split-pair dtype: dst is (rows x cols) AFM_BF16X2 with row stride 2*cols, dst_t the
+ * transpose (cols x rows) with row stride 2*rows. */
+int afm_cast_x2(const float* src, void* dst, void* dst_t, int32_t rows, int32_t cols, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Encoder alignment head (custom_modeling.py:363-396 network, 453-475 use).

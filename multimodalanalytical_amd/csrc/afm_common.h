@@ -34,6 +34,42 @@ template <typename T> __device__ __forceinline__ void st_f32(T* p, int64_t i, fl
 template <> __device__ __forceinline__ void st_f32<float>(float* p, int64_t i, float v) { p[i] = v; }
 template <> __device__ __forceinline__ void st_f32<bf16>(bf16* p, int64_t i, float v) { p[i] = (bf16)v; }
 
+// ---------------------------------------------------------------- split bf16 pairs (AFM_BF16X2)
+// value = hi + lo; hi(r, c) at base[r*ld + c], lo(r, c) at base[r*ld + ld/2 + c] (include/afm_hip.h).
+// `x2` is a tag type: an x2* points at the hi plane.
+struct x2 { bf16 v; };
+__device__ __forceinline__ void afm_split(float v, bf16& hi, bf16& lo) { hi = (bf16)v; lo = (bf16)(v - (float)hi); }
+// element (r, c) of a matrix with row stride ld, any dtype
+template <typename T> __device__ __forceinline__ float ld_rc(const T* p, int64_t r, int c, int ld);
+template <> __device__ __forceinline__ float ld_rc<float>(const float* p, int64_t r, int c, int ld) { return p[r * ld + c]; }
+template <> __device__ __forceinline__ float ld_rc<bf16>(const bf16* p, int64_t r, int c, int ld) { return (float)p[r * ld + c]; }
+template <> __device__ __forceinline__ float ld_rc<x2>(const x2* p, int64_t r, int c, int ld) {
+  const bf16* q = (const bf16*)p + r * ld + c;
+  return (float)q[0] + (float)q[ld >> 1];
+}
+template <typename T> __device__ __forceinline__ void st_rc(T* p, int64_t r, int c, int ld, float v);
+template <> __device__ __forceinline__ void st_rc<float>(float* p, int64_t r, int c, int ld, float v) { p[r * ld + c] = v; }
+template <> __device__ __forceinline__ void st_rc<bf16>(bf16* p, int64_t r, int c, int ld, float v) { p[r * ld + c] = (bf16)v; }
+template <> __device__ __forceinline__ void st_rc<x2>(x2* p, int64_t r, int c, int ld, float v) {
+  bf16* q = (bf16*)p + r * ld + c;
+  bf16 hi, lo;
+  afm_split(v, hi, lo);
+  q[0] = hi; q[ld >> 1] = lo;
+}
+// 8 consecutive elements (16-byte accesses per plane)
+__device__ __forceinline__ void afm_split8(const float (&x)[8], bf16x8& hi, bf16x8& lo) {
+#pragma unroll
+  for (int k = 0; k < 8; ++k) { bf16 h, l; afm_split(x[k], h, l); hi[k] = h; lo[k] = l; }
+}
+// dtype dispatch of a templated launch: DT_SWITCH(code, T, stmt) runs stmt with T = float / bf16 / x2
+#define AFM_DT_SWITCH(code, T, ...)                                        \
+  do {                                                                     \
+    if ((code) == AFM_F32) { typedef float T; __VA_ARGS__; }               \
+    else if ((code) == AFM_BF16) { typedef bf16 T; __VA_ARGS__; }          \
+    else if ((code) == AFM_BF16X2) { typedef x2 T; __VA_ARGS__; }          \
+    else return AFM_ERR_ARG;                                               \
+  } while (0)
+
 // ---------------------------------------------------------------- dropout stream
 // keep(i) = mix32(lo(i) ^ key ^ hi(i)*phi) >= thresh ; documented in DESIGN.md and
 // re-implemented in tests (numpy) so parity tests run WITH dropout against the oracle.

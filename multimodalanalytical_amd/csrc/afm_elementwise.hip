@@ -6,6 +6,16 @@ static thread_local const char* g_last_algo = "none";
 extern "C" void afm_set_last_algo(const char* name) { g_last_algo = name; }
 extern "C" const char* afm_last_algo(void) { return g_last_algo; }
 extern "C" int afm_abi_version(void) { return AFM_ABI_VERSION; }
+extern "C" int afm_struct_size(int which) {
+  switch (which) {
+    case 0: return (int)sizeof(afm_dropout);
+    case 1: return (int)sizeof(afm_gemm_desc);
+    case 2: return (int)sizeof(afm_ln_shape);
+    case 3: return (int)sizeof(afm_attn_shape);
+    case 4: return (int)sizeof(afm_patch_desc);
+    default: return -1;
+  }
+}
 extern "C" const char* afm_error_string(int code) {
   switch (code) {
     case AFM_OK: return "ok";
@@ -83,9 +93,9 @@ __global__ void k_glu_fwd(const T* __restrict__ u, const T* __restrict__ v, T* _
        i += (int64_t)gridDim.x * blockDim.x) {
     const int64_t r = i / f;
     const int c = (int)(i - r * f);
-    float x = afm_gelu(ld_f32(u, r * ldu + c));
-    if (v) x *= ld_f32(v, r * ldv + c);
-    st_f32(g, r * ldg + c, afm_drop(dd, (uint64_t)i, x));
+    float x = afm_gelu(ld_rc(u, r, c, ldu));
+    if (v) x *= ld_rc(v, r, c, ldv);
+    st_rc(g, r, c, ldg, afm_drop(dd, (uint64_t)i, x));
   }
 }
 extern "C" int afm_glu_fwd(const void* u, const void* v, void* g, int64_t rows, int32_t f,
@@ -95,14 +105,8 @@ extern "C" int afm_glu_fwd(const void* u, const void* v, void* g, int64_t rows, 
   if (rows == 0) return AFM_OK;
   const DropDev dd = afm_make_drop(drop);
   const int grid = grid_for(rows * f, 256);
-  if (dtype == AFM_F32)
-    AFM_LAUNCH(k_glu_fwd<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream,
-                       (const float*)u, (const float*)v, (float*)g, rows, f, ldu, ldv, ldg, dd);
-  else if (dtype == AFM_BF16)
-    AFM_LAUNCH(k_glu_fwd<bf16>, dim3(grid), dim3(256), 0, (hipStream_t)stream,
-                       (const bf16*)u, (const bf16*)v, (bf16*)g, rows, f, ldu, ldv, ldg, dd);
-  else
-    return AFM_ERR_ARG;
+  AFM_DT_SWITCH(dtype, T, AFM_LAUNCH(k_glu_fwd<T>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const T*)u,
+                                     (const T*)v, (T*)g, rows, f, ldu, ldv, ldg, dd));
   return AFM_OK;
 }
 
@@ -115,14 +119,14 @@ __global__ void k_glu_bwd(const T* __restrict__ u, const T* __restrict__ v, cons
        i += (int64_t)gridDim.x * blockDim.x) {
     const int64_t r = i / f;
     const int c = (int)(i - r * f);
-    const float g = afm_drop(dd, (uint64_t)i, ld_f32(dg, r * lddg + c));
-    const float uu = ld_f32(u, r * ldu + c);
+    const float g = afm_drop(dd, (uint64_t)i, ld_rc(dg, r, c, lddg));
+    const float uu = ld_rc(u, r, c, ldu);
     float gu = g * afm_gelu_grad(uu);
     if (v) {
-      gu *= ld_f32(v, r * ldv + c);
-      st_f32(dv, r * lddv + c, g * afm_gelu(uu));
+      gu *= ld_rc(v, r, c, ldv);
+      st_rc(dv, r, c, lddv, g * afm_gelu(uu));
     }
-    st_f32(du, r * lddu + c, gu);
+    st_rc(du, r, c, lddu, gu);
   }
 }
 extern "C" int afm_glu_bwd(const void* u, const void* v, const void* dg, void* du, void* dv,
@@ -133,16 +137,8 @@ extern "C" int afm_glu_bwd(const void* u, const void* v, const void* dg, void* d
   if (rows == 0) return AFM_OK;
   const DropDev dd = afm_make_drop(drop);
   const int grid = grid_for(rows * f, 256);
-  if (dtype == AFM_F32)
-    AFM_LAUNCH(k_glu_bwd<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream,
-                       (const float*)u, (const float*)v, (const float*)dg, (float*)du, (float*)dv,
-                       rows, f, ldu, ldv, lddg, lddu, lddv, dd);
-  else if (dtype == AFM_BF16)
-    AFM_LAUNCH(k_glu_bwd<bf16>, dim3(grid), dim3(256), 0, (hipStream_t)stream,
-                       (const bf16*)u, (const bf16*)v, (const bf16*)dg, (bf16*)du, (bf16*)dv, rows,
-                       f, ldu, ldv, lddg, lddu, lddv, dd);
-  else
-    return AFM_ERR_ARG;
+  AFM_DT_SWITCH(dtype, T, AFM_LAUNCH(k_glu_bwd<T>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const T*)u,
+                                     (const T*)v, (const T*)dg, (T*)du, (T*)dv, rows, f, ldu, ldv, lddg, lddu, lddv, dd));
   return AFM_OK;
 }
 
@@ -155,7 +151,7 @@ __global__ void k_dropout_cast(const float* __restrict__ x, T* __restrict__ y, i
        i += (int64_t)gridDim.x * blockDim.x) {
     const int64_t r = i / n;
     const int c = (int)(i - r * n);
-    st_f32(y, r * ldy + c, afm_drop(dd, (uint64_t)i, x[r * ldx + c]));
+    st_rc(y, r, c, ldy, afm_drop(dd, (uint64_t)i, x[r * ldx + c]));
   }
 }
 extern "C" int afm_dropout_cast(const float* x, void* y, int64_t rows, int32_t n, int32_t ldx,
@@ -165,14 +161,41 @@ extern "C" int afm_dropout_cast(const float* x, void* y, int64_t rows, int32_t n
   if (rows == 0) return AFM_OK;
   const DropDev dd = afm_make_drop(drop);
   const int grid = grid_for(rows * n, 256);
-  if (y_dtype == AFM_F32)
-    AFM_LAUNCH(k_dropout_cast<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, x,
-                       (float*)y, rows, n, ldx, ldy, dd);
-  else if (y_dtype == AFM_BF16)
-    AFM_LAUNCH(k_dropout_cast<bf16>, dim3(grid), dim3(256), 0, (hipStream_t)stream, x,
-                       (bf16*)y, rows, n, ldx, ldy, dd);
-  else
-    return AFM_ERR_ARG;
+  AFM_DT_SWITCH(y_dtype, T, AFM_LAUNCH(k_dropout_cast<T>, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, (T*)y,
+                                       rows, n, ldx, ldy, dd));
+  return AFM_OK;
+}
+
+// ---------------------------------------------------------------- dtype conversion
+template <typename TS, typename TD>
+__global__ void k_convert(const TS* __restrict__ x, TD* __restrict__ y, int64_t rows, int n, int lds, int ldd) {
+  const int64_t total = rows * (int64_t)n;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / n;
+    const int c = (int)(i - r * n);
+    st_rc(y, r, c, ldd, ld_rc(x, r, c, lds));
+  }
+}
+extern "C" int afm_convert(const void* src, int32_t src_dtype, int32_t lds, void* dst, int32_t dst_dtype,
+                           int32_t ldd, int64_t rows, int32_t n, void* stream) {
+  if (!src || !dst || rows < 0 || n <= 0) return AFM_ERR_ARG;
+  if (rows == 0) return AFM_OK;
+  const int grid = grid_for(rows * n, 256);
+  AFM_DT_SWITCH(src_dtype, TS, AFM_DT_SWITCH(dst_dtype, TD,
+      AFM_LAUNCH((k_convert<TS, TD>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const TS*)src, (TD*)dst,
+                 rows, n, lds, ldd)));
+  return AFM_OK;
+}
+
+__global__ void k_relu_bwd(const float* __restrict__ dy, const float* __restrict__ act, float* __restrict__ dx, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    dx[i] = act[i] > 0.f ? dy[i] : 0.f;
+}
+extern "C" int afm_relu_bwd(const float* dy, const float* act, float* dx, int64_t n, void* stream) {
+  if (!dy || !act || !dx || n < 0) return AFM_ERR_ARG;
+  if (n == 0) return AFM_OK;
+  AFM_LAUNCH(k_relu_bwd, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, dy, act, dx, n);
   return AFM_OK;
 }
 
@@ -191,7 +214,7 @@ __global__ void k_colsum(const T* __restrict__ x, float* __restrict__ out, int64
   const int64_t r1 = r0 + chunk < rows ? r0 + chunk : rows;
   float acc = 0.f;
   if (c < n)
-    for (int64_t r = r0 + w; r < r1; r += 4) acc += ld_f32(x, r * ld + c);
+    for (int64_t r = r0 + w; r < r1; r += 4) acc += ld_rc(x, r, c, ld);
   part[w][lane] = acc;
   __syncthreads();
   if (w == 0 && c < n) atomicAdd(out + c, part[0][lane] + part[1][lane] + part[2][lane] + part[3][lane]);
@@ -208,12 +231,7 @@ extern "C" int afm_colsum(const void* x, float* out, int64_t rows, int32_t n, in
   const int cap = (2048 + gx - 1) / gx;
   if (gy > cap) gy = cap;
   if (gy < 1) gy = 1;
-  if (dtype == AFM_F32)
-    AFM_LAUNCH(k_colsum<float>, dim3(gx, gy), dim3(256), 0, st, (const float*)x, out, rows, n, ld);
-  else if (dtype == AFM_BF16)
-    AFM_LAUNCH(k_colsum<bf16>, dim3(gx, gy), dim3(256), 0, st, (const bf16*)x, out, rows, n, ld);
-  else
-    return AFM_ERR_ARG;
+  AFM_DT_SWITCH(dtype, T, AFM_LAUNCH(k_colsum<T>, dim3(gx, gy), dim3(256), 0, st, (const T*)x, out, rows, n, ld));
   return AFM_OK;
 }
 
@@ -276,6 +294,45 @@ extern "C" int afm_cast_bf16(const float* src, void* dst, void* dst_t, int32_t r
                              void* stream) {
   if (!src || (!dst && !dst_t) || rows <= 0 || cols <= 0) return AFM_ERR_ARG;
   AFM_LAUNCH(k_cast_bf16, dim3((cols + 63) / 64, (rows + 63) / 64), dim3(256), 0,
+                     (hipStream_t)stream, src, (bf16*)dst, (bf16*)dst_t, rows, cols);
+  return AFM_OK;
+}
+
+// fp32 -> split bf16 pair (+ transpose): dst rows are [hi(cols) | lo(cols)], dst_t rows [hi(rows) | lo(rows)]
+__global__ void k_cast_x2(const float* __restrict__ src, bf16* __restrict__ dst,
+                          bf16* __restrict__ dst_t, int rows, int cols) {
+  __shared__ float tile[64][65];
+  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  for (int i = ty; i < 64; i += 4) {
+    const int r = r0 + i, c = c0 + tx;
+    float v = 0.f;
+    if (r < rows && c < cols) {
+      v = src[(int64_t)r * cols + c];
+      if (dst) {
+        bf16 hi, lo;
+        afm_split(v, hi, lo);
+        dst[(int64_t)r * 2 * cols + c] = hi;
+        dst[(int64_t)r * 2 * cols + cols + c] = lo;
+      }
+    }
+    tile[i][tx] = v;
+  }
+  if (!dst_t) return;
+  __syncthreads();
+  for (int i = ty; i < 64; i += 4) {
+    const int c = c0 + i, r = r0 + tx;
+    if (r < rows && c < cols) {
+      bf16 hi, lo;
+      afm_split(tile[tx][i], hi, lo);
+      dst_t[(int64_t)c * 2 * rows + r] = hi;
+      dst_t[(int64_t)c * 2 * rows + rows + r] = lo;
+    }
+  }
+}
+extern "C" int afm_cast_x2(const float* src, void* dst, void* dst_t, int32_t rows, int32_t cols, void* stream) {
+  if (!src || (!dst && !dst_t) || rows <= 0 || cols <= 0) return AFM_ERR_ARG;
+  AFM_LAUNCH(k_cast_x2, dim3((cols + 63) / 64, (rows + 63) / 64), dim3(256), 0,
                      (hipStream_t)stream, src, (bf16*)dst, (bf16*)dst_t, rows, cols);
   return AFM_OK;
 }

@@ -28,6 +28,14 @@ def _hipcc():
     raise RuntimeError("hipcc not found: libafm_hip.so cannot be built")
 
 
+def have_hipcc() -> bool:
+    try:
+        _hipcc()
+        return True
+    except RuntimeError:
+        return False
+
+
 def _sources():
     return sorted(f for f in os.listdir(HERE) if f.endswith(".hip"))
 
@@ -49,7 +57,9 @@ def build(force=False, verbose=False):
         sp = os.path.join(HERE, src)
         op = os.path.join(OBJ, src[:-4] + ".o")
         stamp = op + ".sha1"
-        dig = _digest(sp, " ".join(FLAGS).encode())
+        # flags enter the digest with the checkout path normalised: the same tree at another path (the GPU box)
+        # must not look stale
+        dig = _digest(sp, " ".join(FLAGS).replace(ROOT, "$ROOT").encode())
         objs.append(op)
         if not force and os.path.exists(op) and os.path.exists(stamp) and open(stamp).read() == dig:
             continue

@@ -68,7 +68,6 @@ class Seq2SeqEngine:
         self.wt: Dict[str, torch.Tensor] = {}  # transposed bf16 weights for dgrad
         self.wt_kv_all = None                  # see _refresh_kv_concat
         self._graph_states: Dict[Any, dict] = {}   # decode_init_graphed
-        self._weights_version = 0
         self.training = True
         self.dropout_seed = int(seed)
         self.micro_step = 0
@@ -177,8 +176,7 @@ class Seq2SeqEngine:
             out = self._empty(x.shape[0], n, out_dtype)
         bias = None
         if bias_name is not None:
-            s = self.ps.specs[bias_name]
-            bias = self.ps.flat[s.offset + r0: s.offset + r0 + n]
+            bias = self.ps.vec_span(self.ps.flat, bias_name, r0, r0 + n)
         return ops.gemm(x, w, out, trans_b=True, bias=bias, residual=residual, dropout=dropout, act=act,
                         pre_act=pre_act, algo=self.algo)
 
@@ -200,8 +198,7 @@ class Seq2SeqEngine:
         gw = self.G(name, rows, cols, r0, r1)
         gb = None
         if bias_name is not None:
-            s = self.ps.specs[bias_name]
-            gb = self.ps.grad[s.offset + r0: s.offset + r0 + gw.shape[0]]
+            gb = self.ps.vec_span(self.ps.grad, bias_name, r0, r0 + gw.shape[0])
         if self.wgrad_stream is None:
             ops.gemm(dy, x, gw, trans_a=True, trans_b=False, accumulate=True, algo=self.algo, a_colsum=gb)
             return
@@ -313,7 +310,7 @@ class Seq2SeqEngine:
                 for li in range(len(layers) - 1, -1, -1):
                     suf = layers[li][0]
                     if li < len(layers) - 1:  # ReLU backward on the hidden activation
-                        g = g * (acts[li + 1] > 0)  # tiny fp32 embedder MLP: torch glue on device
+                        g = ops.relu_bwd(g, acts[li + 1])
                     ops.gemm(g, acts[li], self.ps.g(p + suf + "weight"), trans_a=True, trans_b=False,
                              accumulate=True)
                     ops.colsum(g, self.ps.g(p + suf + "bias"), accumulate=True)
@@ -554,11 +551,14 @@ class Seq2SeqEngine:
             self._graph_states[key] = st
         else:
             st["mem_pad"].copy_((attention_mask == 0).to(torch.uint8))
+            if self.pos_enc is None:   # learned positions are parameters: refresh the rows the graphs read, in place
+                tab = self.ps.p("embedding.positional_encodings.pos_encodings.weight")[:int(max_len)]
+                ops.layernorm_fwd(tab, self.ps.p("embedding.positional_encodings.norm.weight"),
+                                  self.ps.p("embedding.positional_encodings.norm.bias"), st["pe"])
             for i in range(Ld):
                 self._linear(mem2, f"decoder.layers.{i}.multihead_attn.in_proj_weight", 3 * d, d, d, 3 * d,
                              bias_name=f"decoder.layers.{i}.multihead_attn.in_proj_bias", out=st["xkv"][i])
         st["t"] = 0
-        st["weights_version"] = self._weights_version
         return st
 
     def decode_step_graphed(self, st, ids: torch.Tensor) -> torch.Tensor:
@@ -567,11 +567,11 @@ class Seq2SeqEngine:
         t = st["t"]
         st["ids_static"].copy_(ids.view(-1))
         ent = st["graphs"].get(t)
-        if ent is None or ent[2] != self._weights_version:
+        if ent is None:     # graphs read weights / positional rows / caches through fixed pointers that are updated in place
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, pool=st["pool"]):
                 out = self.decode_step(st, st["ids_static"])
-            ent = (g, out, self._weights_version)
+            ent = (g, out)
             st["graphs"][t] = ent
         ent[0].replay()
         st["t"] = t + 1
@@ -674,12 +674,12 @@ class Seq2SeqEngine:
         if not conv:
             g = layer_bwd(dz, a0, "align_network.2.", P("align_network.2.weight"))
         else:
-            g = layer_bwd(dz, a2, "align_network.6.", w6) * (a2 > 0)
+            g = ops.relu_bwd(layer_bwd(dz, a2, "align_network.6.", w6), a2)
             gwc = torch.zeros(C, hid, **f32)
             g = layer_bwd(g, a1, "align_network.4.", wc, gw_sink=gwc)
             G("align_network.4.weight").view(C, hid, k)[:, :, k // 2] += gwc     # the other taps only ever see padding
             g = layer_bwd(g, a0, "align_network.2.", P("align_network.2.weight"))
-        g = g * (a0 > 0)
+        g = ops.relu_bwd(g, a0)
         dpooled = layer_bwd(g, pooled, "align_network.0.", P("align_network.0.weight"))
         dmem = torch.empty(B * S, d, **f32)
         ops.masked_mean_bwd(dpooled, mem_pad, B, S, dmem, accumulate=False)

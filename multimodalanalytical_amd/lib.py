@@ -13,7 +13,8 @@ import threading
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libafm_hip.so")
 
-AFM_F32, AFM_BF16 = 0, 1
+AFM_F32, AFM_BF16, AFM_BF16X2 = 0, 1, 2
+ABI_VERSION = 2
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_GELU_BWD, ACT_GELU_SAVE_GRAD, ACT_MUL_SAVED = 0, 1, 2, 3, 4, 5
 ALGO_AUTO, ALGO_GENERIC, ALGO_MFMA = 0, 1, 2
 
@@ -69,6 +70,10 @@ _P = C.c_void_p
 _I32, _I64, _F = C.c_int32, C.c_int64, C.c_float
 _SIGS = {
     "afm_abi_version": (C.c_int, []),
+    "afm_struct_size": (C.c_int, [C.c_int]),
+    "afm_relu_bwd": (C.c_int, [_P, _P, _P, _I64, _P]),
+    "afm_convert": (C.c_int, [_P, _I32, _I32, _P, _I32, _I32, _I64, _I32, _P]),
+    "afm_cast_x2": (C.c_int, [_P, _P, _P, _I32, _I32, _P]),
     "afm_error_string": (C.c_char_p, [C.c_int]),
     "afm_last_algo": (C.c_char_p, []),
     "afm_gemm": (C.c_int, [C.POINTER(GemmDesc), _P]),
@@ -114,11 +119,14 @@ def load(build_if_missing: bool = True):
     with _lock:
         if _lib is not None:
             return _lib
-        if not os.path.exists(LIB_PATH):
-            if not build_if_missing:
-                raise AfmError(f"{LIB_PATH} is missing; run `python -m multimodalanalytical_amd.csrc.build`")
+        # (re)build whenever hipcc is here: csrc/build.py stamps every object with a digest of its sources, so
+        # this is a no-op for a fresh library and a stale git-ignored .so can never be loaded silently
+        if build_if_missing:
             from .csrc import build as _b
-            _b.build()
+            if _b.have_hipcc():
+                _b.build()
+        if not os.path.exists(LIB_PATH):
+            raise AfmError(f"{LIB_PATH} is missing; run `python -m multimodalanalytical_amd.csrc.build`")
         # torch ships its own libamdhip64: it must be the HIP runtime already resident when this library's
         # dependency on that soname is resolved, or the process ends up with two runtimes (the system one
         # bound here, torch's owning every stream and pointer) and every launch fails
@@ -133,8 +141,11 @@ def load(build_if_missing: bool = True):
             except AttributeError as e:
                 raise AfmError(f"{LIB_PATH} does not export {name}") from e
             fn.restype, fn.argtypes = res, args
-        if lib.afm_abi_version() != 1:
-            raise AfmError("libafm_hip.so ABI version mismatch")
+        if lib.afm_abi_version() != ABI_VERSION:
+            raise AfmError(f"libafm_hip.so ABI version {lib.afm_abi_version()} != binding {ABI_VERSION}: rebuild it")
+        for which, st in enumerate((Dropout, GemmDesc, LnShape, AttnShape, PatchDesc)):
+            if lib.afm_struct_size(which) != C.sizeof(st):
+                raise AfmError(f"libafm_hip.so was built with a different {st.__name__} layout: rebuild it")
         _lib = lib
         return lib
 

@@ -12,32 +12,51 @@ from typing import Optional
 import torch
 
 from . import lib as L
-from .lib import AFM_BF16, AFM_F32, ALGO_AUTO, ACT_NONE, AttnShape, Dropout, GemmDesc, LnShape
+from .lib import AFM_BF16, AFM_BF16X2, AFM_F32, ALGO_AUTO, ACT_NONE, AttnShape, Dropout, GemmDesc, LnShape
+from .x2 import X2
 
-_DT = {torch.float32: AFM_F32, torch.bfloat16: AFM_BF16}
+_DT = {torch.float32: AFM_F32, torch.bfloat16: AFM_BF16, X2.dtype: AFM_BF16X2}
 
 
-def _dt(t: torch.Tensor) -> int:
+def _dt(t) -> int:
     try:
         return _DT[t.dtype]
     except KeyError:
         raise L.AfmError(f"unsupported dtype {t.dtype}") from None
 
 
-def _ptr(t: Optional[torch.Tensor]):
+def _ptr(t):
     if t is None:
         return None
+    if isinstance(t, X2):
+        t = t.hi
     if not t.is_cuda:
         raise L.AfmError("libafm_hip operates on device memory only (got a CPU tensor)")
     return t.data_ptr()
+
+
+def empty(rows: int, cols: int, dtype, device):
+    """(rows x cols) activation buffer of a compute dtype (torch dtype or X2.dtype)."""
+    if dtype == X2.dtype:
+        return X2.empty(rows, cols, device)
+    return torch.empty(rows, cols, dtype=dtype, device=device)
+
+
+def is_contig(t) -> bool:
+    """Rows back to back (an X2 tensor: hi | lo planes of a row back to back, ld = 2 n)."""
+    if isinstance(t, X2):
+        return t.ld == 2 * t.shape[1]
+    return t.is_contiguous()
 
 
 def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
-def _ld(t: torch.Tensor) -> int:
+def _ld(t) -> int:
     """Row stride (elements) of a 2-D view whose last dim is contiguous."""
+    if isinstance(t, X2):
+        return t.ld
     if t.dim() != 2 or (t.shape[1] > 1 and t.stride(1) != 1):
         raise L.AfmError(f"expected a row-major 2-D view, got shape {tuple(t.shape)} stride {t.stride()}")
     return int(t.stride(0)) if t.shape[0] > 1 else max(int(t.stride(0)), int(t.shape[1]))
@@ -218,6 +237,32 @@ def add_inplace(y, x):
 
 def batch_sum(x, out, B, S, d, accumulate=True):
     L.check(L.load().afm_batch_sum(_ptr(x), _ptr(out), B, S, d, int(accumulate), _stream()), "afm_batch_sum")
+
+
+def relu_bwd(dy, act, dx=None):
+    """dx = dy * (act > 0), fp32, contiguous (dx defaults to dy: in place)."""
+    dx = dy if dx is None else dx
+    assert dy.dtype == torch.float32 and act.dtype == torch.float32 and dy.is_contiguous() and act.is_contiguous()
+    assert dx.is_contiguous() and dy.numel() == act.numel() == dx.numel()
+    L.check(L.load().afm_relu_bwd(_ptr(dy), _ptr(act), _ptr(dx), dy.numel(), _stream()), "afm_relu_bwd")
+    return dx
+
+
+def convert(src, dst):
+    """dst = cast(src) between fp32 / bf16 / split-pair 2-D views."""
+    rows, n = src.shape
+    assert tuple(dst.shape) == (rows, n)
+    L.check(L.load().afm_convert(_ptr(src), _dt(src), _ld(src), _ptr(dst), _dt(dst), _ld(dst), rows, n, _stream()),
+            "afm_convert")
+    return dst
+
+
+def cast_x2(src, dst=None, dst_t=None):
+    rows, cols = src.shape
+    assert src.dtype == torch.float32 and src.is_contiguous()
+    for t, (r, c) in ((dst, (rows, cols)), (dst_t, (cols, rows))):
+        assert t is None or (isinstance(t, X2) and tuple(t.shape) == (r, c) and t.ld == 2 * c)
+    L.check(L.load().afm_cast_x2(_ptr(src), _ptr(dst), _ptr(dst_t), rows, cols, _stream()), "afm_cast_x2")
 
 
 def cast_bf16(src, dst=None, dst_t=None):

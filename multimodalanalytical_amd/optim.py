@@ -62,6 +62,7 @@ class FusedAdamOneCycle:
         self._host = torch.zeros(32, 10, dtype=torch.float32)
         if dev.type == "cuda":
             self._host = self._host.pin_memory()
+        self._row_events = [None] * self._host.shape[0]   # H2D copy of each staging row: fence before its reuse
         self.last_lr, self.last_beta1 = 0.0, 0.0
 
     def step(self, grads_are_summed_over_ranks: bool = False) -> None:
@@ -75,9 +76,16 @@ class FusedAdamOneCycle:
         bc2 = 1.0 - self.beta2 ** t
         gmult = 1.0 / self.world_size if grads_are_summed_over_ranks else 1.0
         vals = [lr, beta1, self.beta2, self.eps, self.wd, bc1, bc2, self.clip, gmult, 1.0 if self.decoupled else 0.0]
-        row = self._host[self.step_count % self._host.shape[0]]
+        slot = self.step_count % self._host.shape[0]
+        row = self._host[slot]
+        if self._row_events[slot] is not None:
+            self._row_events[slot].synchronize()   # only ever waits when the host is a whole ring ahead of the stream
         row.copy_(torch.tensor(vals, dtype=torch.float32))
         self.hyper.copy_(row, non_blocking=True)
+        if self.hyper.is_cuda:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream())
+            self._row_events[slot] = ev
         self.sumsq.zero_()
         ops.sumsq(ps.grad, self.sumsq)
         ops.adam_step(ps.flat, ps.grad, ps.exp_avg, ps.exp_avg_sq, self.hyper, self.sumsq, ps.bf16, zero_grad=True)

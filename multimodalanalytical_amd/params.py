@@ -151,6 +151,7 @@ class ParamStore:
         self.exp_avg_sq = torch.zeros(off, dtype=torch.float32, device=device)
         self.bf16 = torch.zeros(off, dtype=torch.bfloat16, device=device) if with_bf16 else None
         self.num_params = sum(s.numel for s in specs)
+        self._span_ok = set()
 
     # ---- views
     def _view(self, buf, name):
@@ -169,7 +170,34 @@ class ParamStore:
     def span(self, buf, first: str, rows: int, cols: int):
         """(rows x cols) view starting at `first` that may cover several adjacent tensors."""
         s = self.specs[first]
+        self._check_span(first, rows * cols)
         return buf[s.offset:s.offset + rows * cols].view(rows, cols)
+
+    def vec_span(self, buf, first: str, i0: int, i1: int):
+        """Elements [i0, i1) of the vector starting at `first` (may run into adjacent tensors: packed biases)."""
+        s = self.specs[first]
+        if i1 > s.numel:
+            self._check_span(first, i1)
+        return buf[s.offset + i0:s.offset + i1]
+
+    def _check_span(self, first: str, numel: int) -> None:
+        """The covered tensors must tile [offset, offset + numel) exactly: every spec is padded to ALIGN
+        elements, so a tensor whose numel is not a multiple of ALIGN in the middle of a span (e.g. a gated FFN
+        with ffn_dim % 8 != 0) would shift its neighbours inside the view."""
+        key = (first, numel)
+        if key in self._span_ok:
+            return
+        names = list(self.specs)
+        i, covered, expect = names.index(first), 0, self.specs[first].offset
+        while covered < numel:
+            sp = self.specs[names[i]]
+            if sp.offset != expect or covered + sp.numel > numel and sp.numel != numel - covered:
+                raise ValueError(f"span({first}, {numel}): {sp.name} does not continue the view contiguously "
+                                 f"(dimensions must be multiples of {ALIGN})")
+            covered += sp.numel
+            expect = sp.offset + sp.numel     # the NEXT tensor must start right here, i.e. no padding in between
+            i += 1
+        self._span_ok.add(key)
 
     def names(self):
         return list(self.specs)

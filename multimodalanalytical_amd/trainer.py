@@ -106,10 +106,16 @@ class TrainLoop:
 def save_checkpoint(path: str, model, loop: "TrainLoop" = None, epoch: int = 0) -> None:
     """Lightning-shaped checkpoint (reference trainer/trainer.py:31-37, cli/training.py:152-183 read
     `checkpoint["state_dict"]` with `hf_model.*` / `multimodal_embedding.*` keys): the state dict uses the
-    reference's key names, so files written here load into the reference and vice versa."""
+    reference's key names, so `checkpoint["state_dict"]` written here loads into the reference model and vice
+    versa.  The interop is the state dict only: optimiser moments are stored flat (ParamStore order), not in
+    torch.optim's per-parameter layout, so Lightning's `fit(ckpt_path=)` cannot resume from these files."""
+    eng = model.hf_model.engine
     ckpt = {"state_dict": {k: v.detach().cpu() for k, v in model.state_dict().items()},
             "epoch": int(epoch), "global_step": 0 if loop is None else loop.optim.step_count,
-            "pytorch-lightning_version": "2.5.1 (multimodalanalytical_amd writer)"}
+            "pytorch-lightning_version": "2.5.1 (multimodalanalytical_amd writer)",
+            "dropout_stream": {"micro_step": int(eng.micro_step), "seed": int(eng.dropout_seed)}}
+    if loop is not None:
+        ckpt["micro"] = int(loop.micro)
     if loop is not None:
         opt = loop.optim.state_dict()
         ckpt["optimizer_states"] = [{"step": opt["step"], "exp_avg": opt["exp_avg"].cpu(), "exp_avg_sq": opt["exp_avg_sq"].cpu(),
@@ -121,8 +127,16 @@ def load_checkpoint(path: str, model, loop: "TrainLoop" = None, strict: bool = T
     """Counterpart of `model.load_state_dict(checkpoint["state_dict"])` in the reference CLIs
     (cli/predict.py:114-115, cli/training.py:152-163: `align_network.*` keys are dropped when unused)."""
     ckpt = torch.load(path, map_location="cpu", weights_only=False)
-    sd = {k: v for k, v in ckpt["state_dict"].items() if "align_network" not in k}
+    sd = ckpt["state_dict"]
+    eng = model.hf_model.engine
+    if eng.align is None:      # cli/training.py:152-161: only a model WITHOUT an alignment head drops the keys
+        sd = {k: v for k, v in sd.items() if "align_network" not in k}
     model.load_state_dict(sd, strict=strict)
+    if "dropout_stream" in ckpt:   # position of the counter-based dropout stream: a resumed run continues it
+        eng.micro_step = int(ckpt["dropout_stream"]["micro_step"])
+        eng.dropout_seed = int(ckpt["dropout_stream"]["seed"])
+    if loop is not None and "micro" in ckpt:
+        loop.micro = int(ckpt["micro"])
     if loop is not None and ckpt.get("optimizer_states") and "exp_avg" in ckpt["optimizer_states"][0]:
         st = ckpt["optimizer_states"][0]
         dev = model.hf_model.engine.dev

@@ -130,8 +130,9 @@ def _wrapper(t, cfg, dtype, **kw):
     m = t["meta"]
     mk = {k: v for k, v in cfg.items() if k != "multimodal_norm"}
     mk.update(kw)
+    lr = mk.pop("lr", m["lr"])
     w = HFWrapper(m["data_config"], "CustomModel", "facebook/bart-base", SimpleTokenizerInfo(26), optimiser=m["optimiser"],
-                  lr=m["lr"], weight_decay=m["weight_decay"], num_steps=m["total_steps"], device=DEV, compute_dtype=dtype, **mk)
+                  lr=lr, weight_decay=m["weight_decay"], num_steps=m["total_steps"], device=DEV, compute_dtype=dtype, **mk)
     w.hf_model.load_state_dict(t["sd"])
     return w
 
@@ -252,10 +253,53 @@ def test_lightning_shaped_checkpoint_roundtrip(tmp_path):
     w.eval(); w2.eval()
     b = _dev_batch(t, 0)
     assert torch.equal(w.forward(b).logits, w2.forward(b).logits)
+    assert w2.hf_model.engine.micro_step == w.hf_model.engine.micro_step   # dropout stream position restored
     for i in range(2):   # resumed training follows the same trajectory (same dropout stream position)
-        w2.hf_model.engine.micro_step = w.hf_model.engine.micro_step
         a, c = loop.micro_batch(_dev_batch(t, i)), loop2.micro_batch(_dev_batch(t, i))
         torch.testing.assert_close(a, c, rtol=1e-5, atol=1e-5)
+
+
+def test_align_head_checkpoint_roundtrip(tmp_path):
+    """A model WITH an alignment head keeps its `align_network.*` tensors through save -> load (the reference
+    drops those keys only when align_config is None, cli/training.py:152-161)."""
+    from multimodalanalytical_amd.trainer import TrainLoop, load_checkpoint, save_checkpoint
+    t = G.load("model_align_mlp_mse"); cfg = G.model_cfg(t["meta"])
+    w = _wrapper(t, cfg, torch.float32)
+    loop = TrainLoop(w, acc_batches=1)
+    loop.micro_batch(_dev_batch(t, 0))          # one optimiser step: the head moves away from the golden init
+    path = str(tmp_path / "align.ckpt")
+    save_checkpoint(path, w, loop)
+    w2 = _wrapper(t, cfg, torch.float32)
+    loop2 = TrainLoop(w2, acc_batches=1)
+    load_checkpoint(path, w2, loop2, strict=True)
+    k = "align_network.0.weight"
+    assert torch.equal(w2.hf_model.engine.ps.p(k), w.hf_model.engine.ps.p(k))
+    assert not torch.equal(w.hf_model.engine.ps.p(k).cpu(), t["sd"][k])
+    w.eval(); w2.eval()
+    b = _dev_batch(t, 0)
+    o1, o2 = w.forward(b), w2.forward(b)
+    assert torch.equal(o1.loss_dict["alignment_loss"], o2.loss_dict["alignment_loss"])
+    # a head-less model loading the same file drops the keys (reference behaviour)
+    t0 = G.load("model_plain")
+    w3 = _wrapper(t0, G.model_cfg(t0["meta"]), torch.float32)
+    raw = torch.load(path, map_location="cpu", weights_only=False)
+    assert any("align_network" in kk for kk in raw["state_dict"])
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_graphed_greedy_tracks_weight_updates_with_learned_positions(dtype):
+    """Learned positional encodings are parameters: after an optimiser step the captured decode graphs must
+    see the new LN(pos_encodings.weight) rows, i.e. graphed and eager greedy decoding keep agreeing."""
+    from multimodalanalytical_amd.trainer import TrainLoop
+    t = G.load("model_gated_learned"); cfg = G.model_cfg(t["meta"])
+    w = _wrapper(t, cfg, dtype, lr=5e-2)
+    w.max_length = 12
+    b = _dev_batch(t, 0)
+    assert torch.equal(w.generate(b, n_beams=1), w.generate(b, n_beams=1, graph=False))
+    loop = TrainLoop(w, acc_batches=1)
+    for i in range(3):
+        loop.micro_batch(_dev_batch(t, i))      # large lr: the positional table really changes
+    assert torch.equal(w.generate(b, n_beams=1), w.generate(b, n_beams=1, graph=False))
 
 
 def test_c2_shape_parity_vs_oracle():

@@ -94,3 +94,21 @@ def test_mixture_index_stream_matches_oracle_restatement():
     assert all((r[:, 0] != r[:, 1]).all() for r in a)
     cfg3 = dict(n_compounds=3, parallel_samples=100, train_max_n_samples=10, normalize=False)
     assert [len(x) for x in mix_indices(5, cfg3, "train")] == [len(x) for x in O.mix_indices(5, cfg3, "train")]
+
+
+def test_param_spans_must_be_contiguous():
+    """linear1|gate and the packed biases are read as ONE view: dimensions that leave alignment padding between
+    the tensors must be refused, not silently shifted (params.ParamStore.span / vec_span)."""
+    import pytest
+    from multimodalanalytical_amd import synth
+    from multimodalanalytical_amd.params import ParamStore, build_specs
+    wl = synth.WORKLOADS["c5"]
+    ps = ParamStore(build_specs(wl["cfg"], wl["data"], 128), "cpu", False)
+    f, d = wl["cfg"]["encoder_ffn_dim"], wl["cfg"]["d_model"]
+    assert ps.span(ps.flat, "encoder.layers.0.linear1.weight", 2 * f, d).shape == (2 * f, d)
+    assert ps.vec_span(ps.flat, "encoder.layers.0.linear1.bias", 0, 2 * f).numel() == 2 * f
+    bad = dict(wl["cfg"], d_model=36, encoder_ffn_dim=10, decoder_ffn_dim=10, encoder_attention_heads=4,
+               decoder_attention_heads=4)
+    ps = ParamStore(build_specs(bad, wl["data"], 128), "cpu", False)
+    with pytest.raises(ValueError):
+        ps.vec_span(ps.flat, "encoder.layers.0.linear1.bias", 0, 20)
