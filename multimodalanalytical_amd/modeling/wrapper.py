@@ -99,7 +99,12 @@ class HFWrapper:
         inner = {k[len("hf_model."):]: v for k, v in sd.items() if k.startswith("hf_model.")}
         self.hf_model.load_state_dict(inner or sd, strict)
 
-    def log(self, key, value, **_):
+    def log(self, key, value, sync_dist: bool = False, **_):
+        """LightningModule.log as the hot path uses it: sync_dist=True averages the scalar over the ranks
+        (one tiny all-reduce per logged value, reference wrapper.py:474,486,601)."""
+        if sync_dist:
+            from ..trainer import sync_mean
+            value = sync_mean(value)
         self.logged[key] = value
 
     def configure_optimizers(self):
@@ -154,7 +159,10 @@ class HFWrapper:
         finally:
             self.hf_model.backward_on_forward(False)
         if batch_idx % 10 == 0:
-            self.log("train_loss", out.loss)
+            self.log("train_loss", out.loss, sync_dist=True)
+            for key, val in (out.loss_dict or {}).items():        # wrapper.py:476-487
+                if val is not None:
+                    self.log(f"train_{key}", val, sync_dist=True)
         return out.loss
 
     def _calc_token_acc(self, batch_input, model_output):
@@ -240,8 +248,57 @@ class HFWrapper:
         self.eval()
         out = self.forward(batch)
         val = {"val_loss": out.loss, "val_token_acc": self._calc_token_acc(batch, out)}
+        # greedy decode of every validation batch (wrapper.py:507) scored Top-1.  The reference decodes to strings
+        # and compares them verbatim (`calc_sampling_metrics(..., molecules=False)`, no canonicalisation), which for
+        # an injective tokenizer is equality of the id sequences with the special tokens removed.
+        gen = self.generate(batch, n_beams=1)
+        top1 = self.sequence_accuracy(gen, batch["target"].T)
+        val["val_molecular_accuracy_tensorboard"] = top1
+        val["val_molecular_accuracy"] = top1
+        for key, v in (out.loss_dict or {}).items():
+            val[f"val_{key}"] = v
         self.validation_step_outputs.append(val)
         return val
+
+    def sequence_accuracy(self, generated: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
+        """Fraction of rows whose generated ids equal the target ids once bos / eos / pad are stripped
+        (score_val_sequences, wrapper.py:604-639, with n_beams = 1 and molecules=False)."""
+        tok = self.target_tokenizer
+        special = (tok.pad_token_id, tok.bos_token_id, tok.eos_token_id)
+
+        def strip(x):
+            keep = torch.ones_like(x, dtype=torch.bool)
+            for sp in special:
+                keep &= x != sp
+            keep &= x != -100
+            # stable compaction: position of each kept token among the kept ones
+            pos = keep.long().cumsum(1) - 1
+            out = torch.full((x.shape[0], x.shape[1] + 1), -1, dtype=torch.long, device=x.device)
+            out.scatter_(1, torch.where(keep, pos, torch.full_like(pos, x.shape[1])), torch.where(keep, x, torch.full_like(x, -1)))
+            return out[:, :x.shape[1]], keep.sum(1)
+
+        g, gn = strip(generated)
+        t, tn = strip(target.to(generated.device))
+        L = max(g.shape[1], t.shape[1])
+        g = torch.nn.functional.pad(g, (0, L - g.shape[1]), value=-1)
+        t = torch.nn.functional.pad(t, (0, L - t.shape[1]), value=-1)
+        return ((g == t).all(1) & (gn == tn)).float().mean().reshape(1)
+
+    def on_validation_epoch_end(self):
+        """wrapper.py:527-530,580-603: average every metric over the validation batches, log with sync_dist."""
+        if not self.validation_step_outputs:
+            return {}
+        keys = list(self.validation_step_outputs[0])
+        avg = {}
+        for k in keys:
+            vals = [o[k] for o in self.validation_step_outputs]
+            if any(v is None for v in vals):
+                continue
+            avg[k] = sum(vals) / len(vals)
+        for k, v in avg.items():
+            self.log(k, v, sync_dist=True)
+        self.validation_step_outputs = []
+        return avg
 
     def predict_step(self, batch, batch_idx):  # noqa: ARG002
         """wrapper.py:532-578 (greedy ids instead of decoded beam strings)."""

@@ -73,6 +73,25 @@ def last_algo() -> str:
     return L.load().afm_last_algo().decode()
 
 
+_ALGO_LOG = None   # tests: names of the kernel families dispatched by gemm / attention calls since reset_algo_log()
+
+
+def reset_algo_log() -> None:
+    global _ALGO_LOG
+    _ALGO_LOG = []
+
+
+def algo_log():
+    global _ALGO_LOG
+    out, _ALGO_LOG = _ALGO_LOG or [], None
+    return out
+
+
+def _log_algo() -> None:
+    if _ALGO_LOG is not None:
+        _ALGO_LOG.append(last_algo())
+
+
 def gemm(a: torch.Tensor, b: torch.Tensor, c: torch.Tensor, *, trans_a=False, trans_b=True,
          bias: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
          pre_act: Optional[torch.Tensor] = None, act: int = ACT_NONE, accumulate: bool = False,
@@ -108,6 +127,7 @@ def gemm(a: torch.Tensor, b: torch.Tensor, c: torch.Tensor, *, trans_a=False, tr
     d.reserved = int(variant)
     d.drop = dropout
     L.check(L.load().afm_gemm(C.byref(d), _stream()), "afm_gemm")
+    _log_algo()
     return c
 
 
@@ -190,6 +210,7 @@ def attn_shape(B, H, Tq, Tk, dh, dtype, ldq, ldk, ldv, ldo, key_pad=None, causal
 def attn_fwd(s: AttnShape, q, k, v, o, lse):
     L.check(L.load().afm_attn_fwd(C.byref(s), _ptr(q), _ptr(k), _ptr(v), _ptr(o), _ptr(lse), _stream()),
             "afm_attn_fwd")
+    _log_algo()
     return o
 
 
@@ -197,6 +218,7 @@ def attn_bwd(s: AttnShape, q, k, v, o, do, lse, delta, dq, dk, dv, lddq, lddk, l
     L.check(L.load().afm_attn_bwd(C.byref(s), _ptr(q), _ptr(k), _ptr(v), _ptr(o), _ptr(do), _ptr(lse),
                                   _ptr(delta), _ptr(dq), _ptr(dk), _ptr(dv), lddq, lddk, lddv, _stream()),
             "afm_attn_bwd")
+    _log_algo()
 
 
 def glu_fwd(u, v, g, dropout: Dropout = NO_DROP):

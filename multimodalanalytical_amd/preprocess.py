@@ -130,6 +130,17 @@ def mix_indices(n_rows: int, mix_config: dict, split: str, seed: int = 3247):
         yield ri
 
 
+def shard_rows(ri, rank: int, world_size: int):
+    """Rank-strided shard of one round of the index stream (the reference's iterable mixture dataset has no
+    DistributedSampler, so under DDP every rank would train on the SAME mixtures).  Every rank draws the identical
+    stream (same seed) and keeps rows rank, rank + world, ...; the tail that does not divide evenly is dropped so
+    all ranks run the same number of samples (and optimiser steps) per round."""
+    if world_size <= 1:
+        return ri
+    n = (len(ri) // world_size) * world_size
+    return ri[:n][rank::world_size]
+
+
 class MixtureGenerator:
     """Device-side counterpart of `mix_spectra` (data/datasets.py:58-141) over a spectra table resident in
     HBM: the index stream stays on the host (numpy RNG, as the reference), the weighted average /
@@ -143,8 +154,10 @@ class MixtureGenerator:
 
     in the reference's record order (for idx in indices: for i in compounds)."""
 
-    def __init__(self, table: torch.Tensor, mix_config: dict, split: str = "train", seed: int = 3247):
+    def __init__(self, table: torch.Tensor, mix_config: dict, split: str = "train", seed: int = 3247,
+                 rank: int = 0, world_size: int = 1):
         self.table, self.cfg, self.split, self.seed = table, dict(mix_config), split, seed
+        self.rank, self.world_size = int(rank), int(world_size)
         nc = self.cfg["n_compounds"]
         ratio = self.cfg.get("compounds_ratio") or [1 / nc] * nc
         if len(ratio) != nc or sum(ratio) != 1:
@@ -155,6 +168,7 @@ class MixtureGenerator:
         dev = self.table.device
         keep = [i for i, r in enumerate(self.ratio) if r != 0]
         for ri in mix_indices(self.table.shape[0], self.cfg, self.split, self.seed):
+            ri = shard_rows(ri, self.rank, self.world_size)
             if len(ri) == 0:
                 continue
             idx = torch.from_numpy(np.ascontiguousarray(ri)).to(dev)

@@ -24,6 +24,21 @@ def calculate_training_steps(len_train: int, batch_size: int, acc_batches: int, 
     return math.ceil(batches_per_gpu / acc_batches) * epochs
 
 
+def sync_mean(value, group=None):
+    """Lightning's `self.log(..., sync_dist=True)` (reference wrapper.py:474,486,601): the logged scalar is averaged
+    over the ranks.  Without an initialised process group (single GPU) the value is returned unchanged."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return value
+    world = dist.get_world_size(group)
+    if world == 1:
+        return value
+    t = value.detach().clone().float() if torch.is_tensor(value) else torch.tensor(float(value))
+    if t.device.type == "cpu" and dist.get_backend(group) == "nccl":
+        t = t.cuda()
+    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return t / world
+
+
 class BucketedReducer:
     """All-reduce a flat gradient buffer back to front in buckets, on a side stream.
 

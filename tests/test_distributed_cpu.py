@@ -46,3 +46,38 @@ def test_bucketed_reducer_world2_gloo():
 
 def test_bucketed_reducer_single_flush():
     mp.spawn(_worker, args=(2, _free_port(), [], 3000, 1 << 20), nprocs=2, join=True)
+
+
+def _sync_worker(rank, world, port):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from multimodalanalytical_amd.trainer import sync_mean
+    got = sync_mean(torch.tensor(float(rank + 1)))          # Lightning sync_dist=True: mean over ranks
+    assert abs(float(got) - sum(range(1, world + 1)) / world) < 1e-6
+    got = sync_mean(2.0 * (rank + 1))                       # plain floats are accepted too
+    assert abs(float(got) - 2.0 * sum(range(1, world + 1)) / world) < 1e-6
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sync_dist_scalar_mean_world2_gloo():
+    mp.spawn(_sync_worker, args=(2, _free_port()), nprocs=2, join=True)
+
+
+def test_mixture_stream_is_rank_sharded():
+    """the iterable mixture dataset needs rank-strided sharding (the reference has none): ranks draw the same
+    index stream and keep disjoint, equally long row sets whose union is the (evenly divisible part of the) round."""
+    import numpy as np
+    from multimodalanalytical_amd.preprocess import mix_indices, shard_rows
+    cfg = {"n_compounds": 2, "parallel_samples": 64, "train_max_n_samples": 256}
+    for world in (2, 4, 8):
+        rounds = list(mix_indices(50, cfg, "train", seed=3247))
+        assert len(rounds) >= 2
+        for ri in rounds:
+            parts = [shard_rows(ri, r, world) for r in range(world)]
+            assert len({len(p) for p in parts}) == 1
+            allrows = np.concatenate(parts)
+            assert len(allrows) == (len(ri) // world) * world
+            assert len(np.unique(allrows, axis=0)) == len(allrows)          # disjoint
+            assert set(map(tuple, allrows)) <= set(map(tuple, ri))
+    assert shard_rows(rounds[0], 0, 1) is rounds[0]

@@ -1,0 +1,158 @@
+"""GPU: engine branches the golden models do not reach: the patch-embedder
+variants (linear_2_layer / linear_3_layer / msms_number / xVal scaling, modeling/utils.py:107-160) forward
+against the reference's own outputs and backward against the oracle; HFWrapper.forward's modality dropout
+(wrapper.py:368-386); the RCCL gradient exchange of the data-parallel path on a 1-rank group."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import afm_oracle as O  # noqa: E402
+from tests import golden_io as G  # noqa: E402
+
+DEV = "cuda:0"
+
+
+def _need_gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+
+
+@pytest.mark.parametrize("pe", ["sin_cos", "learned"])
+def test_embedder_variants_forward_vs_reference_and_backward_vs_oracle(pe):
+    _need_gpu()
+    from multimodalanalytical_amd.engine import Seq2SeqEngine
+    t = G.load("embed_variants")
+    dc, d = t["meta"]["data_config"], t["meta"]["d_model"]
+    cfg = dict(d_model=d, encoder_layers=1, decoder_layers=1, encoder_attention_heads=4, decoder_attention_heads=4,
+               encoder_ffn_dim=64, decoder_ffn_dim=64, dropout=0.0, gated_linear=False, positional_encoding_type=pe,
+               max_position_embeddings=64, multimodal_norm=True)
+    eng = Seq2SeqEngine(cfg, dc, "Smiles", 26, device=DEV, compute_dtype=torch.float32, seed=1)
+    sd = t[pe]["sd"]
+    eng.load_state_dict(sd, strict=False)        # only the embedding tensors come from the reference
+    inp = {"A": t[pe]["in"]["A"], "B": t[pe]["in"]["B"], "C": t[pe]["in"]["C"], "D": dict(t[pe]["in"]["D"])}
+    dev_inp = {k: ({kk: vv.to(DEV) for kk, vv in v.items()} if isinstance(v, dict) else v.to(DEV)) for k, v in inp.items()}
+    saved = {}
+    y = eng.embed_fwd(dev_inp, saved)
+    B = inp["A"].shape[0]
+    ref = t[pe]["out"]                            # output of the reference's MultimodalEmbedding itself
+    torch.testing.assert_close(y.view(B, -1, d).cpu(), ref, rtol=1e-5, atol=3e-6)
+    # backward: a random upstream gradient through the engine vs autograd through the oracle's restatement
+    gen = torch.Generator().manual_seed(3)
+    dy = torch.randn(ref.shape, generator=gen)
+    leaf = {k: v.clone().requires_grad_(v.is_floating_point() and not k.endswith("pos_enc")) for k, v in sd.items()}
+    (O.embed(leaf, dc, inp, True, pe) * dy).sum().backward()
+    eng.ps.grad.zero_()
+    eng.embed_bwd(dy.reshape(-1, d).to(DEV).contiguous(), saved)
+    checked = 0
+    for k, v in leaf.items():
+        if v.grad is None:
+            continue
+        got = eng.ps.g(k).cpu()
+        assert float((got - v.grad).abs().max()) <= 2e-5 * float(v.grad.abs().max()) + 1e-6, k
+        checked += 1
+    assert checked >= 16      # 2 + 3 Linear layers (w, b), msms Linear, the xVal table, 4 LayerNorms (+ learned PE)
+
+
+def _wrapper(t, cfg, dtype, **kw):
+    from multimodalanalytical_amd.modeling.wrapper import HFWrapper, SimpleTokenizerInfo
+    m = t["meta"]
+    mk = {k: v for k, v in cfg.items() if k != "multimodal_norm"}
+    mk.update(kw)
+    w = HFWrapper(m["data_config"], "CustomModel", "facebook/bart-base", SimpleTokenizerInfo(26), optimiser=m["optimiser"],
+                  lr=m["lr"], weight_decay=m["weight_decay"], num_steps=m["total_steps"], device=DEV, compute_dtype=dtype, **mk)
+    w.hf_model.load_state_dict(t["sd"])
+    return w
+
+
+def test_modality_dropout_matches_oracle_on_surviving_modalities():
+    """wrapper.py:368-386: in training, k = np.random.randint(0, n) of the listed modalities are removed from the
+    encoder input together with their slice of the pad mask (numpy GLOBAL RNG).  Replaying the RNG gives the
+    surviving set; the oracle on exactly those modalities must give the same loss / logits."""
+    _need_gpu()
+    from multimodalanalytical_amd.synth import to_device
+    t = G.load("model_plain"); cfg = G.model_cfg(t["meta"])
+    mods = [m for m, c in t["meta"]["data_config"].items() if not c["target"]]
+    assert len(mods) >= 2
+    w = _wrapper(t, dict(cfg, dropout=0.0), torch.float32, modality_dropout=list(mods))
+    w.train()
+    dropped_any = False
+    for seed in range(6):
+        b = G.batch_of(t, seed % 4)
+        np.random.seed(seed)
+        out = w.forward(to_device(b, DEV))
+        np.random.seed(seed)
+        drop = set(np.random.choice(mods, np.random.randint(0, len(mods)), replace=False).tolist())
+        dropped_any |= bool(drop)
+        enc, am, dec, dm, labels = O.batch_to_model_inputs(b, "Smiles")
+        keep_cols, idx = [], 0
+        for m, v in enc.items():
+            n = (v["tokenized_input"] if isinstance(v, dict) else v).shape[1]
+            if m not in drop:
+                keep_cols.append(am[:, idx:idx + n])
+            idx += n
+        enc = {m: v for m, v in enc.items() if m not in drop}
+        ref = O.model_forward(t["sd"], dict(cfg, dropout=0.0), t["meta"]["data_config"], "Smiles", enc,
+                              torch.cat(keep_cols, -1), dec, dm, labels)
+        err = float((out.logits.cpu() - ref["logits"]).abs().max() / ref["logits"].abs().max())
+        assert err < 1e-4, (seed, drop, err)
+        torch.testing.assert_close(out.loss.cpu(), ref["loss"], rtol=1e-5, atol=1e-5)
+    assert dropped_any
+    # with backward: parameters of a dropped modality receive no gradient (the reason for
+    # find_unused_parameters=True, trainer/trainer.py:58)
+    for seed in range(6):
+        np.random.seed(seed)
+        drop = np.random.choice(mods, np.random.randint(0, len(mods)), replace=False).tolist()
+        if drop:
+            break
+    eng = w.hf_model.engine
+    eng.ps.grad.zero_()
+    np.random.seed(seed)
+    w.training_step(to_device(G.batch_of(t, 0), DEV), 0)
+    for m in mods:
+        gsum = sum(float(eng.ps.g(k).abs().sum()) for k in eng.ps.names() if f"embedding_layer_dict.{m}." in k)
+        assert (gsum == 0.0) == (m in drop), (m, drop, gsum)
+
+
+def test_rccl_reducer_on_a_one_rank_group_reproduces_the_plain_loop():
+    """The N > 1 code path (BucketedReducer: side HIP stream, events, async RCCL all-reduce per bucket, launched from
+    the engine's grad_ready_hook as backward retires layers; 1/world folded into Adam) on a 1-rank `nccl` group:
+    parameters after two optimiser steps must equal the non-DDP loop's (the exchange of a 1-rank group is the
+    identity; the only slack allowed is the summation order of the fp32 atomics in the embedding scatter-add, which
+    varies from run to run without DDP too), and every bucket must have gone through the exchange."""
+    _need_gpu()
+    import os
+    import socket
+    import torch.distributed as dist
+    from multimodalanalytical_amd.synth import to_device
+    from multimodalanalytical_amd.trainer import TrainLoop, sync_mean
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(DEV))
+    try:
+        t = G.load("model_gated_learned"); cfg = G.model_cfg(t["meta"])
+        outs = []
+        for force in (False, True):
+            w = _wrapper(t, cfg, torch.bfloat16)
+            loop = TrainLoop(w, acc_batches=2, bucket_elems=4096, force_reducer=force)
+            launched = []
+            for i in range(4):
+                loss = loop.micro_batch(to_device(G.batch_of(t, i), DEV))
+                if force and loop.reducer.launched:
+                    launched = list(loop.reducer.launched)
+            torch.cuda.synchronize()
+            outs.append((w.hf_model.engine.ps.flat.clone(), float(loss)))
+            if force:
+                n = w.hf_model.engine.ps.grad.numel()
+                spans = sorted(launched)
+                assert spans[0][0] == 0 and spans[-1][1] == n and len(spans) > 4
+                assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+                assert float(w.logged["train_loss"]) == float(w.logged["train_loss"])      # sync_dist path ran
+        torch.testing.assert_close(outs[0][0], outs[1][0], rtol=1e-6, atol=1e-8)
+        assert abs(outs[0][1] - outs[1][1]) <= 1e-6 * abs(outs[0][1])
+        x = torch.tensor([3.5], device=DEV)
+        assert float(sync_mean(x)) == 3.5
+    finally:
+        dist.destroy_process_group()

@@ -1,0 +1,113 @@
+"""GPU: BASELINE.json's workloads c2..c5 at their REAL layer shapes (d512/h8/f2048 and d768/h12/f3072 gated +
+learned positions, S = 1024 with the synthetic set's pad masks, T = 128 / 256), batch 2 so the CPU oracle
+finishes in seconds: forward AND backward of the HIP engine against the oracle, every precision mode.
+
+Bars (max |logit - ref| / max |ref|; gradients by relative norm per parameter tensor):
+  fp32    exact-fp32 FMA kernels                 logits 1e-4, ids bit-exact, grads 2e-3
+  bf16x3  split bf16 pairs, 3 MFMAs / product    logits 1e-3 (north star), ids bit-exact under the margin
+          policy below, grads 5e-3
+  bf16    single bf16 MFMA pass                  logits 3e-2, ids exact outside twice the measured error, grads 8e-2
+Margin policy for "bit-exact argmax": a position whose two largest REFERENCE logits are closer than
+2 * 1e-3 * max|logit| cannot be decided by any arithmetic that is only 1e-3-close; there the id must be one of
+those two.  Everywhere else ids must be equal.  (fp32 mode is held to plain equality.)
+"""
+import functools
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import afm_oracle as O  # noqa: E402
+
+DEV = "cuda:0"
+MODES = ["fp32", "bf16x3", "bf16"]
+
+
+def _dtype(mode):
+    from multimodalanalytical_amd.x2 import X2
+    return {"fp32": torch.float32, "bf16": torch.bfloat16, "bf16x3": X2.dtype}[mode]
+
+
+@functools.lru_cache(maxsize=None)
+def _case(name):
+    """(inputs, state dict, oracle logits / loss / gradients) of workload `name`, B = 2, dropout 0."""
+    from multimodalanalytical_amd import synth
+    from multimodalanalytical_amd.params import ParamStore, build_specs
+    wl = synth.WORKLOADS[name]
+    batch, _ = synth.make_batch(name, 2, seed=11)
+    inputs = O.batch_to_model_inputs(batch, "Smiles")
+    cfg = dict(wl["cfg"], dropout=0.0)
+    V = wl["data"]["Smiles"]["vocab_size"]
+    ps = ParamStore(build_specs(cfg, wl["data"], V), "cpu", False)
+    ps.init_(5)
+    # non-trivial biases / LayerNorm parameters so every gradient path carries signal
+    g = torch.Generator().manual_seed(7)
+    for s in ps.specs.values():
+        if s.kind in ("zeros", "ones"):
+            ps.p(s.name).add_(0.05 * torch.randn(s.shape, generator=g))
+    sd = {k: v.clone() for k, v in ps.state_dict().items()}
+    if cfg["positional_encoding_type"] == "sin_cos":
+        sd["embedding.positional_encodings.pos_enc"] = O.sincos_table(cfg["d_model"], cfg["max_position_embeddings"])
+    torch.set_num_threads(min(32, torch.get_num_threads()))
+    leaf = {k: v.clone().requires_grad_(not k.endswith("pos_enc")) for k, v in sd.items()}
+    ref = O.model_forward(leaf, cfg, wl["data"], "Smiles", *inputs)
+    ref["loss"].backward()
+    grads = {k: v.grad.detach() for k, v in leaf.items() if v.grad is not None}
+    return wl, cfg, inputs, sd, {"logits": ref["logits"].detach(), "loss": ref["loss"].detach()}, grads
+
+
+def _to(x):
+    return {k: _to(v) for k, v in x.items()} if isinstance(x, dict) else x.to(DEV)
+
+
+@pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("name", ["c2", "c3", "c4", "c5"])
+def test_shape_parity_forward_backward_vs_oracle(name, mode):
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from multimodalanalytical_amd import ops
+    from multimodalanalytical_amd.engine import Seq2SeqEngine
+    wl, cfg, inputs, sd, ref, grads = _case(name)
+    eng = Seq2SeqEngine(cfg, wl["data"], "Smiles", wl["data"]["Smiles"]["vocab_size"], device=DEV,
+                        compute_dtype=_dtype(mode), seed=5)
+    eng.load_state_dict(sd)
+    enc, am, dec, dm, labels = inputs
+    ops.reset_algo_log()
+    out = eng.forward(_to(enc), am.to(DEV), dec.to(DEV), dm.to(DEV), labels.to(DEV), backward=True)
+    algos = ops.algo_log()
+    if mode != "fp32":   # the MFMA kernels really ran (not the exact-fp32 FMA kernels)
+        assert any(a.startswith("attn_mfma") for a in algos), algos
+        assert any(a.startswith("mfma_nt") for a in algos) and any(a.startswith("mfma_tn") for a in algos), algos
+    logits, rl = out["logits"].cpu().double(), ref["logits"].double()
+    scale = float(rl.abs().max())
+    err = float((logits - rl).abs().max()) / scale
+    tol = {"fp32": 1e-4, "bf16x3": 1e-3, "bf16": 3e-2}[mode]
+    assert err < tol, (name, mode, err)
+    ids, rid = out["argmax"].cpu(), ref["logits"].argmax(-1)
+    top2 = ref["logits"].topk(2, -1)
+    margin = (top2.values[..., 0] - top2.values[..., 1]).double()
+    if mode == "fp32":
+        assert torch.equal(ids, rid)
+    else:
+        band = 2e-3 * scale if mode == "bf16x3" else 2 * err * scale
+        sure = margin > band
+        assert torch.equal(ids[sure], rid[sure]), (name, mode)
+        unsure = ~sure
+        assert bool(((ids == top2.indices[..., 0]) | (ids == top2.indices[..., 1]))[unsure].all())
+        assert float(sure.double().mean()) > (0.99 if mode == "bf16x3" else 0.5)
+    ltol = {"fp32": 1e-5, "bf16x3": 1e-4, "bf16": 2e-2}[mode]
+    torch.testing.assert_close(out["loss"].cpu(), ref["loss"], rtol=ltol, atol=ltol)
+    gtol = {"fp32": 2e-3, "bf16x3": 5e-3, "bf16": 8e-2}[mode]
+    gmax = max(float(g.norm()) for g in grads.values())
+    bad = []
+    for k, g in grads.items():
+        got = eng.ps.g(k).cpu()
+        if k.endswith("in_proj_bias"):     # the K-bias third is zero in exact arithmetic (softmax shift invariance)
+            d = got.numel() // 3
+            got, g = torch.cat([got[:d], got[2 * d:]]), torch.cat([g[:d], g[2 * d:]])
+        e = float((got - g).norm())
+        if e > gtol * float(g.norm()) + 1e-5 * gtol * gmax:
+            bad.append((k, e / (float(g.norm()) + 1e-30)))
+    assert not bad, (name, mode, bad[:8], len(bad))
+    print(f"{name} {mode}: logits rel err {err:.2e}, undecidable ids {int((margin <= 2e-3 * scale).sum())}")
