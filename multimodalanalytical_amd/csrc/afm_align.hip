@@ -3,7 +3,6 @@
 // the pooling reads B*S*d activations once (split over S with fp32 atomics so the chip is filled).
 #include "afm_common.h"
 
-template <typename T> __device__ __forceinline__ float ld_as_f32(const T* p, int64_t i) { return (float)p[i]; }
 
 // grid (d / 256, B, SPLIT): partial sums over an S-chunk, divided by the row's kept-token count
 template <typename T>
@@ -23,9 +22,8 @@ __global__ __launch_bounds__(256) void k_masked_mean_fwd(const T* __restrict__ x
   const int s0 = blockIdx.z * chunk, s1 = min(S, s0 + chunk);
   if (c >= d) return;
   float acc = 0.f;
-  const T* xb = x + ((int64_t)b * S) * d + c;
   for (int s = s0; s < s1; ++s)
-    if (kp[s] == 0) acc += ld_as_f32(xb, (int64_t)s * d);
+    if (kp[s] == 0) acc += ld_rc(x, (int64_t)b * S + s, c, d * RowMul<T>::v);
   atomicAdd(out + (int64_t)b * d + c, acc * inv);
 }
 
@@ -88,9 +86,7 @@ extern "C" int afm_masked_mean_fwd(const void* x, int32_t x_dtype, const uint8_t
   if (split < 1) split = 1;
   if (split > (S + 31) / 32) split = (S + 31) / 32;
   const dim3 grid((d + 255) / 256, B, split);
-  if (x_dtype == AFM_BF16) AFM_LAUNCH(k_masked_mean_fwd<bf16>, grid, dim3(256), 0, st, (const bf16*)x, key_pad, S, d, out);
-  else if (x_dtype == AFM_F32) AFM_LAUNCH(k_masked_mean_fwd<float>, grid, dim3(256), 0, st, (const float*)x, key_pad, S, d, out);
-  else return AFM_ERR_UNSUPPORTED;
+  AFM_DT_SWITCH(x_dtype, T, AFM_LAUNCH(k_masked_mean_fwd<T>, grid, dim3(256), 0, st, (const T*)x, key_pad, S, d, out));
   return AFM_OK;
 }
 

@@ -39,6 +39,8 @@ template <> __device__ __forceinline__ void st_f32<bf16>(bf16* p, int64_t i, flo
 // `x2` is a tag type: an x2* points at the hi plane.
 struct x2 { bf16 v; };
 __device__ __forceinline__ void afm_split(float v, bf16& hi, bf16& lo) { hi = (bf16)v; lo = (bf16)(v - (float)hi); }
+template <typename T> struct RowMul { static constexpr int v = 1; };
+template <> struct RowMul<x2> { static constexpr int v = 2; };   // a contiguous split-pair row is [hi(n) | lo(n)]
 // element (r, c) of a matrix with row stride ld, any dtype
 template <typename T> __device__ __forceinline__ float ld_rc(const T* p, int64_t r, int c, int ld);
 template <> __device__ __forceinline__ float ld_rc<float>(const float* p, int64_t r, int c, int ld) { return p[r * ld + c]; }

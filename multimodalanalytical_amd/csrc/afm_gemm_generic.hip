@@ -9,7 +9,8 @@ struct GemmArgs {
   int64_t sam, sak;  // element strides of op(A)[m][k]
   int64_t sbk, sbn;  // element strides of op(B)[k][n]
   int ldc;
-  int a_bf16, b_bf16, c_bf16;
+  int a_dt, b_dt, c_dt;      // AFM_F32 / AFM_BF16 / AFM_BF16X2
+  int a_lo, b_lo, c_lo;      // lo-plane offsets of split-pair operands (ld / 2)
   const void* A;
   const void* B;
   void* C;
@@ -21,11 +22,17 @@ struct GemmArgs {
   DropDev dd;
 };
 
-__device__ __forceinline__ float ld_any(const void* p, int is_bf16, int64_t i) {
-  return is_bf16 ? (float)((const bf16*)p)[i] : ((const float*)p)[i];
+__device__ __forceinline__ float ld_any(const void* p, int dt, int64_t i, int lo) {
+  if (dt == AFM_F32) return ((const float*)p)[i];
+  const float hi = (float)((const bf16*)p)[i];
+  return dt == AFM_BF16X2 ? hi + (float)((const bf16*)p)[i + lo] : hi;
 }
-__device__ __forceinline__ void st_any(void* p, int is_bf16, int64_t i, float v) {
-  if (is_bf16) ((bf16*)p)[i] = (bf16)v; else ((float*)p)[i] = v;
+__device__ __forceinline__ void st_any(void* p, int dt, int64_t i, float v, int lo) {
+  if (dt == AFM_F32) { ((float*)p)[i] = v; return; }
+  bf16 hi, l2;
+  afm_split(v, hi, l2);
+  ((bf16*)p)[i] = hi;
+  if (dt == AFM_BF16X2) ((bf16*)p)[i + lo] = l2;
 }
 
 #define GT 64
@@ -53,11 +60,11 @@ __global__ __launch_bounds__(256) void k_gemm_generic(GemmArgs g) {
       int m, k;
       if (a_kfast) { k = t & 15; m = (t >> 4) + 16 * i; } else { m = t & 63; k = (t >> 6) + 4 * i; }
       const int gm = m0 + m, gk = k0 + k;
-      As[k][m] = (gm < g.M && gk < kend) ? ld_any(g.A, g.a_bf16, gm * g.sam + gk * g.sak) : 0.f;
+      As[k][m] = (gm < g.M && gk < kend) ? ld_any(g.A, g.a_dt, gm * g.sam + gk * g.sak, g.a_lo) : 0.f;
       int n, kb;
       if (b_kfast) { kb = t & 15; n = (t >> 4) + 16 * i; } else { n = t & 63; kb = (t >> 6) + 4 * i; }
       const int gn = n0 + n, gkb = k0 + kb;
-      Bs[kb][n] = (gn < g.N && gkb < kend) ? ld_any(g.B, g.b_bf16, gkb * g.sbk + gn * g.sbn) : 0.f;
+      Bs[kb][n] = (gn < g.N && gkb < kend) ? ld_any(g.B, g.b_dt, gkb * g.sbk + gn * g.sbn, g.b_lo) : 0.f;
     }
     __syncthreads();
 #pragma unroll
@@ -92,24 +99,24 @@ __global__ __launch_bounds__(256) void k_gemm_generic(GemmArgs g) {
       }
       if (g.bias) v += g.bias[n];
       if (g.act == AFM_ACT_GELU_BWD) {
-        v = afm_drop(g.dd, (uint64_t)m * (uint64_t)g.N + (uint64_t)n, v) * afm_gelu_grad(ld_any(g.pre_act, g.c_bf16, ci));
+        v = afm_drop(g.dd, (uint64_t)m * (uint64_t)g.N + (uint64_t)n, v) * afm_gelu_grad(ld_any(g.pre_act, g.c_dt, ci, g.c_lo));
       } else if (g.act == AFM_ACT_GELU_SAVE_GRAD) {
         float y, yp;
         afm_gelu_both(v, y, yp);
         const float k = afm_drop(g.dd, (uint64_t)m * (uint64_t)g.N + (uint64_t)n, 1.0f);   // scale or 0
-        st_any(g.pre_act, g.c_bf16, ci, yp * k);
+        st_any(g.pre_act, g.c_dt, ci, yp * k, g.c_lo);
         v = y * k;
       } else if (g.act == AFM_ACT_MUL_SAVED) {
-        v *= ld_any(g.pre_act, g.c_bf16, ci);
+        v *= ld_any(g.pre_act, g.c_dt, ci, g.c_lo);
       } else {
-        if (g.pre_act) st_any(g.pre_act, g.c_bf16, ci, v);
+        if (g.pre_act) st_any(g.pre_act, g.c_dt, ci, v, g.c_lo);
         if (g.act == AFM_ACT_RELU) v = fmaxf(v, 0.f);
         else if (g.act == AFM_ACT_GELU) v = afm_gelu(v);
         v = afm_drop(g.dd, (uint64_t)m * (uint64_t)g.N + (uint64_t)n, v);
       }
-      if (g.residual) v += ld_any(g.residual, g.c_bf16, ci);
-      if (g.accumulate) v += ld_any(g.C, g.c_bf16, ci);
-      st_any(g.C, g.c_bf16, ci, v);
+      if (g.residual) v += ld_any(g.residual, g.c_dt, ci, g.c_lo);
+      if (g.accumulate) v += ld_any(g.C, g.c_dt, ci, g.c_lo);
+      st_any(g.C, g.c_dt, ci, v, g.c_lo);
     }
   }
 }
@@ -211,6 +218,8 @@ __global__ __launch_bounds__(256) void k_gemm_skinny_n(GemmArgs g, float* a_cols
 
 // defined in afm_gemm_mfma.hip; returns AFM_ERR_UNSUPPORTED when the shape is not eligible
 int afm_gemm_mfma_try(const afm_gemm_desc* d, hipStream_t st);
+// defined in afm_gemm_x3.hip: split-pair operands on three bf16 MFMAs per product
+int afm_gemm_x3_try(const afm_gemm_desc* d, hipStream_t st);
 
 static int gemm_generic(const afm_gemm_desc* d, hipStream_t st) {
   GemmArgs g;
@@ -218,7 +227,8 @@ static int gemm_generic(const afm_gemm_desc* d, hipStream_t st) {
   g.sam = d->transA ? 1 : d->lda; g.sak = d->transA ? d->lda : 1;
   g.sbk = d->transB ? 1 : d->ldb; g.sbn = d->transB ? d->ldb : 1;
   g.ldc = d->ldc;
-  g.a_bf16 = d->a_dtype == AFM_BF16; g.b_bf16 = d->b_dtype == AFM_BF16; g.c_bf16 = d->c_dtype == AFM_BF16;
+  g.a_dt = d->a_dtype; g.b_dt = d->b_dtype; g.c_dt = d->c_dtype;
+  g.a_lo = d->lda / 2; g.b_lo = d->ldb / 2; g.c_lo = d->ldc / 2;
   g.A = d->A; g.B = d->B; g.C = d->C; g.bias = d->bias; g.residual = d->residual; g.pre_act = d->pre_act;
   g.act = d->act; g.accumulate = d->accumulate;
   g.dd = afm_make_drop(&d->drop);
@@ -276,17 +286,22 @@ static int gemm_generic(const afm_gemm_desc* d, hipStream_t st) {
 extern "C" int afm_gemm(const afm_gemm_desc* d, void* stream) {
   if (!d || !d->A || !d->B || !d->C) return AFM_ERR_ARG;
   if (d->M < 0 || d->N < 0 || d->K < 0) return AFM_ERR_ARG;
-  if ((d->a_dtype | d->b_dtype | d->c_dtype) & ~1) return AFM_ERR_ARG;
+  if (d->a_dtype < AFM_F32 || d->a_dtype > AFM_BF16X2 || d->b_dtype < AFM_F32 || d->b_dtype > AFM_BF16X2 ||
+      d->c_dtype < AFM_F32 || d->c_dtype > AFM_BF16X2) return AFM_ERR_ARG;
   if (d->act < AFM_ACT_NONE || d->act > AFM_ACT_MUL_SAVED) return AFM_ERR_ARG;
   if (d->act >= AFM_ACT_GELU_BWD && !d->pre_act) return AFM_ERR_ARG;
   if (d->act == AFM_ACT_MUL_SAVED && (d->bias || d->drop.p > 0.f)) return AFM_ERR_ARG;
-  if (d->ldc < d->N) return AFM_ERR_ARG;
-  if (d->lda < (d->transA ? d->M : d->K) || d->ldb < (d->transB ? d->K : d->N)) return AFM_ERR_ARG;
+  {  // split-pair rows hold two planes: ld >= 2 * width, even
+    const int ca = d->a_dtype == AFM_BF16X2 ? 2 : 1, cb = d->b_dtype == AFM_BF16X2 ? 2 : 1, cc = d->c_dtype == AFM_BF16X2 ? 2 : 1;
+    if (d->ldc < cc * d->N || (cc == 2 && (d->ldc & 1))) return AFM_ERR_ARG;
+    if (d->lda < ca * (d->transA ? d->M : d->K) || d->ldb < cb * (d->transB ? d->K : d->N)) return AFM_ERR_ARG;
+    if ((ca == 2 && (d->lda & 1)) || (cb == 2 && (d->ldb & 1))) return AFM_ERR_ARG;
+  }
   if (d->a_colsum && !d->transA) return AFM_ERR_ARG;
   if (d->M == 0 || d->N == 0) return AFM_OK;
   hipStream_t st = (hipStream_t)stream;
   if (d->algo != AFM_ALGO_GENERIC) {
-    const int r = afm_gemm_mfma_try(d, st);
+    const int r = (d->a_dtype == AFM_BF16X2 && d->b_dtype == AFM_BF16X2) ? afm_gemm_x3_try(d, st) : afm_gemm_mfma_try(d, st);
     if (r != AFM_ERR_UNSUPPORTED) return r;
     if (d->algo == AFM_ALGO_MFMA) return AFM_ERR_UNSUPPORTED;
   }

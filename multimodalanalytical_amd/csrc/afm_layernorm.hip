@@ -20,7 +20,7 @@ __global__ void k_ln_fwd(const float* x, const float* __restrict__ gamma,
                          const float* __restrict__ beta, const float* __restrict__ pos,
                          TY* __restrict__ y, float* __restrict__ mean, float* __restrict__ rstd,
                          int64_t rows, int d, int64_t seg_len, int64_t seg_stride, int64_t off,
-                         float eps, const void* __restrict__ add, int add_bf16, float* x_sum, DropDev adrop) {
+                         float eps, const void* __restrict__ add, int add_dtype, float* x_sum, DropDev adrop) {
   const int lane = threadIdx.x & 63;
   const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
@@ -34,7 +34,8 @@ __global__ void k_ln_fwd(const float* x, const float* __restrict__ gamma,
       const int j = lane + 64 * i;
       v[i] = j < d ? xr[j] : 0.f;
       if (add && j < d) {   // fused residual add: the stream value is written back once
-        const float a = add_bf16 ? (float)((const bf16*)add)[r * (int64_t)d + j] : ((const float*)add)[r * (int64_t)d + j];
+        const float a = add_dtype == AFM_BF16 ? ld_rc((const bf16*)add, r, j, d)
+                        : add_dtype == AFM_BF16X2 ? ld_rc((const x2*)add, r, j, 2 * d) : ld_rc((const float*)add, r, j, d);
         v[i] += afm_drop(adrop, (uint64_t)r * (uint64_t)d + (uint64_t)j, a);   // branch dropout rides on the add
         x_sum[r * (int64_t)d + j] = v[i];
       }
@@ -55,7 +56,6 @@ __global__ void k_ln_fwd(const float* x, const float* __restrict__ gamma,
     }
     const int64_t orow = ln_out_row(r, seg_len, seg_stride, off);
     const int64_t prow = seg_len == 0 ? r : off + (r % seg_len);
-    TY* yr = y + orow * (int64_t)d;
     const float* pr = pos ? pos + prow * (int64_t)d : nullptr;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
@@ -63,7 +63,7 @@ __global__ void k_ln_fwd(const float* x, const float* __restrict__ gamma,
       if (j < d) {
         float o = (v[i] - mu) * rs * gamma[j] + beta[j];
         if (pr) o += pr[j];
-        st_f32(yr, j, o);
+        st_rc(y, orow, j, d * RowMul<TY>::v, o);
       }
     }
   }
@@ -84,6 +84,22 @@ __device__ __forceinline__ void st8(float* p, const F8& v) { *(f32x4*)p = v.lo; 
 __device__ __forceinline__ void st8(bf16* p, const F8& v) {
   bf16x8 o = {(bf16)v.lo[0], (bf16)v.lo[1], (bf16)v.lo[2], (bf16)v.lo[3], (bf16)v.hi[0], (bf16)v.hi[1], (bf16)v.hi[2], (bf16)v.hi[3]};
   *(bf16x8*)p = o;
+}
+// the same with the lo-plane offset of the split-pair dtype as second argument (ignored by plain dtypes)
+__device__ __forceinline__ F8 ld8(const float* p, int) { return ld8(p); }
+__device__ __forceinline__ F8 ld8(const bf16* p, int) { return ld8(p); }
+__device__ __forceinline__ F8 ld8(const x2* p, int lo) {
+  const F8 a = ld8((const bf16*)p), b = ld8((const bf16*)p + lo);
+  return {a.lo + b.lo, a.hi + b.hi};
+}
+__device__ __forceinline__ void st8(float* p, const F8& v, int) { st8(p, v); }
+__device__ __forceinline__ void st8(bf16* p, const F8& v, int) { st8(p, v); }
+__device__ __forceinline__ void st8(x2* p, const F8& v, int lo) {
+  const float x[8] = {v.lo[0], v.lo[1], v.lo[2], v.lo[3], v.hi[0], v.hi[1], v.hi[2], v.hi[3]};
+  bf16x8 h, l;
+  afm_split8(x, h, l);
+  *(bf16x8*)p = h;
+  *(bf16x8*)((bf16*)p + lo) = l;
 }
 __device__ __forceinline__ float hsum8(const F8& v) { return (v.lo[0] + v.lo[1]) + (v.lo[2] + v.lo[3]) + (v.hi[0] + v.hi[1]) + (v.hi[2] + v.hi[3]); }
 
@@ -112,7 +128,7 @@ __global__ __launch_bounds__(256) void k_ln_fwd_vec(const float* x, const float*
       if (c < d) {
         v[i] = ld8(x + r * (int64_t)d + c);
         if (add) {
-          F8 a = ld8(add + r * (int64_t)d + c);
+          F8 a = ld8(add + r * (int64_t)(d * RowMul<TA>::v) + c, d);
           if (adrop.thresh) {   // wave-uniform: dropout of the residual branch, index row-major in `add`
             const uint64_t base = (uint64_t)r * (uint64_t)d + (uint64_t)c;
 #pragma unroll
@@ -145,7 +161,7 @@ __global__ __launch_bounds__(256) void k_ln_fwd_vec(const float* x, const float*
       const int c = (lane + 64 * i) * 8;
       if (c < d) {
         F8 o = {v[i].lo * rs * gm[i].lo + bt[i].lo, v[i].hi * rs * gm[i].hi + bt[i].hi};
-        st8(y + r * (int64_t)d + c, o);
+        st8(y + r * (int64_t)(d * RowMul<TY>::v) + c, o, d);
       }
     }
   }
@@ -180,7 +196,7 @@ __global__ __launch_bounds__(256) void k_ln_bwd_vec(const TY* __restrict__ dy, c
     for (int i = 0; i < NC; ++i) {
       const int c = (lane + 64 * i) * 8;
       if (c < d) {
-        const F8 dyv = ld8(dy + r * (int64_t)d + c);
+        const F8 dyv = ld8(dy + r * (int64_t)(d * RowMul<TY>::v) + c, d);
         const F8 xv = ld8(x + r * (int64_t)d + c);
         xh[i] = {(xv.lo - mu) * rs, (xv.hi - mu) * rs};
         g[i] = {dyv.lo * gm[i].lo, dyv.hi * gm[i].hi};
@@ -204,7 +220,7 @@ __global__ __launch_bounds__(256) void k_ln_bwd_vec(const TY* __restrict__ dy, c
           F8 od;
 #pragma unroll
           for (int k = 0; k < 4; ++k) { od.lo[k] = afm_drop(dd, base + k, o.lo[k]); od.hi[k] = afm_drop(dd, base + 4 + k, o.hi[k]); }
-          st8(dx_drop + r * (int64_t)d + c, od);
+          st8(dx_drop + r * (int64_t)(d * RowMul<TY>::v) + c, od, d);
         }
       }
     }
@@ -224,35 +240,32 @@ extern "C" int afm_layernorm_fwd(const afm_ln_shape* s, const float* x, const fl
                                  const float* beta, const float* pos, void* y, float* mean,
                                  float* rstd, const void* add, float* x_sum, void* stream) {
   if (!s || !x || !gamma || !beta || !y || s->rows < 0 || s->d <= 0) return AFM_ERR_ARG;
-  if (add && (!x_sum || (s->add_dtype != AFM_F32 && s->add_dtype != AFM_BF16) || s->seg_len != 0)) return AFM_ERR_ARG;
-  const int add_bf16 = s->add_dtype == AFM_BF16;
+  if (add && (!x_sum || s->add_dtype < AFM_F32 || s->add_dtype > AFM_BF16X2 || s->seg_len != 0)) return AFM_ERR_ARG;
+  const int add_dtype = s->add_dtype;
   const DropDev adrop = afm_make_drop(add ? &s->add_drop : nullptr);
   if (s->d > 64 * LN_MAXV) return AFM_ERR_UNSUPPORTED;
   if (s->rows == 0) return AFM_OK;
   int64_t g = (s->rows + 3) / 4;
   if (g > 2048) g = 2048;
   hipStream_t st = (hipStream_t)stream;
-  if (s->y_dtype != AFM_F32 && s->y_dtype != AFM_BF16) return AFM_ERR_ARG;
+  if (s->y_dtype < AFM_F32 || s->y_dtype > AFM_BF16X2) return AFM_ERR_ARG;
   if (s->seg_len == 0 && !pos && (s->d % 8) == 0 && s->d <= 2048 && s->rows >= 64) {   // vectorised path
 #define LN_FV(TY, TA, NC) AFM_LAUNCH((k_ln_fwd_vec<TY, TA, NC>), dim3((int)g), dim3(256), 0, st, x, gamma, beta, (TY*)y, mean, \
                                      rstd, s->rows, s->d, s->eps, (const TA*)add, x_sum, adrop)
 #define LN_FV2(TY, TA) do { if (s->d <= 512) LN_FV(TY, TA, 1); else if (s->d <= 1024) LN_FV(TY, TA, 2); else LN_FV(TY, TA, 4); } while (0)
-    if (s->y_dtype == AFM_BF16) { if (add_bf16) LN_FV2(bf16, bf16); else LN_FV2(bf16, float); }
-    else { if (add_bf16) LN_FV2(float, bf16); else LN_FV2(float, float); }
+    // the branch added in front of the norm has the dtype of the mode's activations or fp32
+    if (s->y_dtype == AFM_BF16) { if (add_dtype == AFM_BF16) LN_FV2(bf16, bf16); else if (add_dtype == AFM_F32) LN_FV2(bf16, float); else return AFM_ERR_UNSUPPORTED; }
+    else if (s->y_dtype == AFM_BF16X2) { if (add_dtype == AFM_BF16X2) LN_FV2(x2, x2); else if (add_dtype == AFM_F32) LN_FV2(x2, float); else return AFM_ERR_UNSUPPORTED; }
+    else { if (add_dtype == AFM_BF16) LN_FV2(float, bf16); else if (add_dtype == AFM_F32) LN_FV2(float, float); else LN_FV2(float, x2); }
 #undef LN_FV2
 #undef LN_FV
     return AFM_OK;
   }
 #define LN_FWD(NV)                                                                                  \
   do {                                                                                              \
-    if (s->y_dtype == AFM_F32)                                                                      \
-      AFM_LAUNCH((k_ln_fwd<float, NV>), dim3((int)g), dim3(256), 0, st, x, gamma, beta, pos, \
-                         (float*)y, mean, rstd, s->rows, s->d, s->seg_len, s->out_seg_stride,       \
-                         s->out_off, s->eps, add, add_bf16, x_sum, adrop);                            \
-    else                                                                                            \
-      AFM_LAUNCH((k_ln_fwd<bf16, NV>), dim3((int)g), dim3(256), 0, st, x, gamma, beta, pos,  \
-                         (bf16*)y, mean, rstd, s->rows, s->d, s->seg_len, s->out_seg_stride,        \
-                         s->out_off, s->eps, add, add_bf16, x_sum, adrop);                            \
+    AFM_DT_SWITCH(s->y_dtype, TY, AFM_LAUNCH((k_ln_fwd<TY, NV>), dim3((int)g), dim3(256), 0, st, x, gamma, beta, pos, \
+                         (TY*)y, mean, rstd, s->rows, s->d, s->seg_len, s->out_seg_stride,       \
+                         s->out_off, s->eps, add, add_dtype, x_sum, adrop));                            \
   } while (0)
   const int nv = (s->d + 63) / 64;
   if (nv <= 1) LN_FWD(1); else if (nv <= 2) LN_FWD(2); else if (nv <= 4) LN_FWD(4);
@@ -295,14 +308,14 @@ __global__ void k_ln_bwd(const TY* __restrict__ dy, const float* __restrict__ x,
   for (int64_t r = wave; r < rows; r += nwaves) {
     const float mu = mean[r], rs = rstd[r];
     const float* xr = x + r * (int64_t)d;
-    const TY* dyr = dy + ln_out_row(r, seg_len, seg_stride, off) * (int64_t)d;
+    const int64_t dyrow = ln_out_row(r, seg_len, seg_stride, off);
     float xh[NV], g[NV];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       const int j = lane + 64 * i;
       if (j < d) {
-        const float dyv = ld_f32(dyr, j);
+        const float dyv = ld_rc(dy, dyrow, j, d * RowMul<TY>::v);
         xh[i] = (xr[j] - mu) * rs;
         g[i] = dyv * gm[i];
         ag[i] += dyv * xh[i];
@@ -323,7 +336,7 @@ __global__ void k_ln_bwd(const TY* __restrict__ dy, const float* __restrict__ x,
         float o = rs * (g[i] - m1 - xh[i] * m2);
         if (drr) o += drr[j];
         dxr[j] = o;
-        if (dx_drop) st_f32(dx_drop, r * (int64_t)d + j, afm_drop(dd, (uint64_t)r * (uint64_t)d + (uint64_t)j, o));
+        if (dx_drop) st_rc(dx_drop, r, j, d * RowMul<TY>::v, afm_drop(dd, (uint64_t)r * (uint64_t)d + (uint64_t)j, o));
       }
     }
   }
@@ -377,12 +390,12 @@ extern "C" int afm_layernorm_bwd(const afm_ln_shape* s, const void* dy, const fl
   const int g = ln_bwd_blocks(s->rows);
   hipStream_t st = (hipStream_t)stream;
   const size_t shm = sizeof(float) * 8 * s->d;
-  if (s->y_dtype != AFM_F32 && s->y_dtype != AFM_BF16) return AFM_ERR_ARG;
+  if (s->y_dtype < AFM_F32 || s->y_dtype > AFM_BF16X2) return AFM_ERR_ARG;
   if (s->seg_len == 0 && (s->d % 8) == 0 && s->d <= 2048 && s->rows >= 64) {   // vectorised path
 #define LN_BV(TY, NC) AFM_LAUNCH((k_ln_bwd_vec<TY, NC>), dim3(g), dim3(256), shm, st, (const TY*)dy, x, gamma, mean, rstd, dres, dx, \
                                  partial, s->rows, s->d, (TY*)dx_drop, dd)
 #define LN_BV2(TY) do { if (s->d <= 512) LN_BV(TY, 1); else if (s->d <= 1024) LN_BV(TY, 2); else LN_BV(TY, 4); } while (0)
-    if (s->y_dtype == AFM_BF16) LN_BV2(bf16); else LN_BV2(float);
+    if (s->y_dtype == AFM_BF16) LN_BV2(bf16); else if (s->y_dtype == AFM_BF16X2) LN_BV2(x2); else LN_BV2(float);
 #undef LN_BV2
 #undef LN_BV
     AFM_LAUNCH(k_ln_bwd_reduce, dim3((2 * s->d + 63) / 64, g >= 64 ? 16 : 1), dim3(256), 0, st, partial, dgamma, dbeta, g, s->d);
@@ -390,14 +403,9 @@ extern "C" int afm_layernorm_bwd(const afm_ln_shape* s, const void* dy, const fl
   }
 #define LN_BWD(NV)                                                                                   \
   do {                                                                                               \
-    if (s->y_dtype == AFM_F32)                                                                       \
-      AFM_LAUNCH((k_ln_bwd<float, NV>), dim3(g), dim3(256), shm, st, (const float*)dy, x,     \
+    AFM_DT_SWITCH(s->y_dtype, TY, AFM_LAUNCH((k_ln_bwd<TY, NV>), dim3(g), dim3(256), shm, st, (const TY*)dy, x,     \
                          gamma, mean, rstd, dres, dx, partial, s->rows, s->d, s->seg_len,            \
-                         s->out_seg_stride, s->out_off, (float*)dx_drop, dd);                                             \
-    else                                                                                             \
-      AFM_LAUNCH((k_ln_bwd<bf16, NV>), dim3(g), dim3(256), shm, st, (const bf16*)dy, x, gamma, \
-                         mean, rstd, dres, dx, partial, s->rows, s->d, s->seg_len,                   \
-                         s->out_seg_stride, s->out_off, (bf16*)dx_drop, dd);                                             \
+                         s->out_seg_stride, s->out_off, (TY*)dx_drop, dd));                                             \
   } while (0)
   const int nv = (s->d + 63) / 64;
   if (nv <= 1) LN_BWD(1); else if (nv <= 2) LN_BWD(2); else if (nv <= 4) LN_BWD(4);

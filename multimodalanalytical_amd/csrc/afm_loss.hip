@@ -64,11 +64,12 @@ __global__ void k_ce_bwd(const float* __restrict__ logits, const int64_t* __rest
                          float grad_scale, T* __restrict__ dl, int lddl, int64_t rows, int V, int ld) {
   const float cnt = stats[1];
   const float gs = cnt > 0.f ? grad_scale / cnt : 0.f;
-  const int64_t total = rows * (int64_t)lddl;
+  const int ncol = lddl / RowMul<T>::v;     // every column of the row (padding beyond V is zeroed), per plane
+  const int64_t total = rows * (int64_t)ncol;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
        i += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t r = i / lddl;
-    const int v = (int)(i - r * lddl);
+    const int64_t r = i / ncol;
+    const int v = (int)(i - r * ncol);
     float g = 0.f;
     const int64_t lb = labels[r];
     if (v < V && lb != -100 && lb >= 0 && lb < V) {
@@ -76,26 +77,21 @@ __global__ void k_ce_bwd(const float* __restrict__ logits, const int64_t* __rest
       if (v == lb) g -= 1.f;
       g *= gs;
     }
-    st_f32(dl, i, g);
+    st_rc(dl, r, v, lddl, g);
   }
 }
 
 extern "C" int afm_ce_bwd(const float* logits, const int64_t* labels, const float* row_lse,
                           const float* stats, float grad_scale, void* dlogits, int32_t dl_dtype,
                           int32_t lddl, int64_t rows, int32_t V, int32_t ld, void* stream) {
-  if (!logits || !labels || !row_lse || !stats || !dlogits || rows < 0 || V <= 0 || ld < V || lddl < V)
+  if (!logits || !labels || !row_lse || !stats || !dlogits || rows < 0 || V <= 0 || ld < V ||
+      lddl < V * (dl_dtype == AFM_BF16X2 ? 2 : 1))
     return AFM_ERR_ARG;
   if (rows == 0) return AFM_OK;
   int64_t g = (rows * lddl + 255) / 256;
   if (g > 2048) g = 2048;
   hipStream_t st = (hipStream_t)stream;
-  if (dl_dtype == AFM_F32)
-    AFM_LAUNCH(k_ce_bwd<float>, dim3((int)g), dim3(256), 0, st, logits, labels, row_lse, stats,
-                       grad_scale, (float*)dlogits, lddl, rows, V, ld);
-  else if (dl_dtype == AFM_BF16)
-    AFM_LAUNCH(k_ce_bwd<bf16>, dim3((int)g), dim3(256), 0, st, logits, labels, row_lse, stats,
-                       grad_scale, (bf16*)dlogits, lddl, rows, V, ld);
-  else
-    return AFM_ERR_ARG;
+  AFM_DT_SWITCH(dl_dtype, T, AFM_LAUNCH(k_ce_bwd<T>, dim3((int)g), dim3(256), 0, st, logits, labels, row_lse, stats,
+                                        grad_scale, (T*)dlogits, lddl, rows, V, ld));
   return AFM_OK;
 }
