@@ -14,6 +14,16 @@ struct AttnArgs {
   DropDev dd;
 };
 
+// row-pointer accessors: element j of a row; `lo` = offset of the lo plane of a split-pair tensor (ld / 2)
+template <typename T> __device__ __forceinline__ float ldp(const T* p, int j, int) { return (float)p[j]; }
+template <> __device__ __forceinline__ float ldp<x2>(const x2* p, int j, int lo) { return (float)((const bf16*)p)[j] + (float)((const bf16*)p)[j + lo]; }
+template <typename T> __device__ __forceinline__ void stp(T* p, int j, int, float v) { p[j] = (T)v; }
+template <> __device__ __forceinline__ void stp<x2>(x2* p, int j, int lo, float v) {
+  bf16 h, l;
+  afm_split(v, h, l);
+  ((bf16*)p)[j] = h; ((bf16*)p)[j + lo] = l;
+}
+
 __device__ __forceinline__ bool attn_masked(const AttnArgs& a, int b, int q, int k) {
   if (a.causal && k > q) return true;
   if (a.key_pad && a.key_pad[(int64_t)b * a.Tk + k]) return true;
@@ -36,7 +46,7 @@ __global__ __launch_bounds__(256) void k_attn_fwd_generic(AttnArgs a, const T* _
   const int h = (int)((row / a.Tq) % a.H);
   const int b = (int)(row / ((int64_t)a.Tq * a.H));
   const T* qp = Q + ((int64_t)b * a.sqb + (int64_t)q * a.ldq) + (int64_t)h * a.dh;
-  for (int j = lane; j < a.dh; j += 64) qv[j] = ld_f32(qp, j);
+  for (int j = lane; j < a.dh; j += 64) qv[j] = ldp(qp, j, a.ldq >> 1);
   // scores
   float mx = -INFINITY;
   for (int k = lane; k < a.Tk; k += 64) {
@@ -44,7 +54,7 @@ __global__ __launch_bounds__(256) void k_attn_fwd_generic(AttnArgs a, const T* _
     if (!attn_masked(a, b, q, k)) {
       const T* kp = K + ((int64_t)b * a.skb + (int64_t)k * a.ldk) + (int64_t)h * a.dh;
       float acc = 0.f;
-      for (int j = 0; j < a.dh; ++j) acc = fmaf(qv[j], ld_f32(kp, j), acc);
+      for (int j = 0; j < a.dh; ++j) acc = fmaf(qv[j], ldp(kp, j, a.ldk >> 1), acc);
       s = acc * a.scale;
     }
     sc[k] = s;
@@ -53,7 +63,7 @@ __global__ __launch_bounds__(256) void k_attn_fwd_generic(AttnArgs a, const T* _
   mx = wave_max(mx);
   T* op = O + ((int64_t)b * a.sob + (int64_t)q * a.ldo) + (int64_t)h * a.dh;
   if (mx == -INFINITY) {  // every key masked: zeros (torch _safe_softmax)
-    for (int j = lane; j < a.dh; j += 64) st_f32(op, j, 0.f);
+    for (int j = lane; j < a.dh; j += 64) stp(op, j, a.ldo >> 1, 0.f);
     if (lane == 0) lse[row] = INFINITY;
     return;
   }
@@ -71,9 +81,9 @@ __global__ __launch_bounds__(256) void k_attn_fwd_generic(AttnArgs a, const T* _
     float acc = 0.f;
     for (int k = 0; k < a.Tk; ++k) {
       const float p = afm_drop16(a.dd, didx + k, sc[k]);
-      acc = fmaf(p, ld_f32(V + ((int64_t)b * a.svb + (int64_t)k * a.ldv) + (int64_t)h * a.dh, j), acc);
+      acc = fmaf(p, ldp(V + ((int64_t)b * a.svb + (int64_t)k * a.ldv) + (int64_t)h * a.dh, j, a.ldv >> 1), acc);
     }
-    st_f32(op, j, acc * inv_l);
+    stp(op, j, a.ldo >> 1, acc * inv_l);
   }
 }
 
@@ -99,10 +109,10 @@ __global__ __launch_bounds__(256) void k_attn_bwd_q_generic(
   const T* dop = dO + ((int64_t)b * a.sob + (int64_t)q * a.ldo) + (int64_t)h * a.dh;
   float dl = 0.f;
   for (int j = lane; j < a.dh; j += 64) {
-    qv[j] = ld_f32(qp, j);
-    const float g = ld_f32(dop, j);
+    qv[j] = ldp(qp, j, a.ldq >> 1);
+    const float g = ldp(dop, j, a.ldo >> 1);
     dov[j] = g;
-    dl += g * ld_f32(op, j);
+    dl += g * ldp(op, j, a.ldo >> 1);
   }
   dl = wave_sum(dl);
   if (lane == 0) delta[row] = dl;
@@ -115,8 +125,8 @@ __global__ __launch_bounds__(256) void k_attn_bwd_q_generic(
       const T* vp = V + ((int64_t)b * a.svb + (int64_t)k * a.ldv) + (int64_t)h * a.dh;
       float s = 0.f, dp = 0.f;
       for (int j = 0; j < a.dh; ++j) {
-        s = fmaf(qv[j], ld_f32(kp, j), s);
-        dp = fmaf(dov[j], ld_f32(vp, j), dp);
+        s = fmaf(qv[j], ldp(kp, j, a.ldk >> 1), s);
+        dp = fmaf(dov[j], ldp(vp, j, a.ldv >> 1), dp);
       }
       const float p = expf(s * a.scale - L);
       dp = afm_drop16(a.dd, didx + k, dp);
@@ -128,8 +138,8 @@ __global__ __launch_bounds__(256) void k_attn_bwd_q_generic(
   for (int j = lane; j < a.dh; j += 64) {
     float acc = 0.f;
     for (int k = 0; k < a.Tk; ++k)
-      acc = fmaf(ds[k], ld_f32(K + ((int64_t)b * a.skb + (int64_t)k * a.ldk) + (int64_t)h * a.dh, j), acc);
-    st_f32(dqp, j, acc);
+      acc = fmaf(ds[k], ldp(K + ((int64_t)b * a.skb + (int64_t)k * a.ldk) + (int64_t)h * a.dh, j, a.ldk >> 1), acc);
+    stp(dqp, j, lddq >> 1, acc);
   }
 }
 
@@ -153,7 +163,7 @@ __global__ __launch_bounds__(256) void k_attn_bwd_kv_generic(
   const int b = (int)(row / ((int64_t)a.Tk * a.H));
   const T* kp = K + ((int64_t)b * a.skb + (int64_t)k * a.ldk) + (int64_t)h * a.dh;
   const T* vp = V + ((int64_t)b * a.svb + (int64_t)k * a.ldv) + (int64_t)h * a.dh;
-  for (int j = lane; j < a.dh; j += 64) { kv[j] = ld_f32(kp, j); vv[j] = ld_f32(vp, j); }
+  for (int j = lane; j < a.dh; j += 64) { kv[j] = ldp(kp, j, a.ldk >> 1); vv[j] = ldp(vp, j, a.ldv >> 1); }
   for (int q = lane; q < a.Tq; q += 64) {
     float pdv = 0.f, dsv = 0.f;
     const int64_t qrow = ((int64_t)b * a.H + h) * a.Tq + q;
@@ -163,8 +173,8 @@ __global__ __launch_bounds__(256) void k_attn_bwd_kv_generic(
       const T* dop = dO + ((int64_t)b * a.sob + (int64_t)q * a.ldo) + (int64_t)h * a.dh;
       float s = 0.f, dp = 0.f;
       for (int j = 0; j < a.dh; ++j) {
-        s = fmaf(ld_f32(qp, j), kv[j], s);
-        dp = fmaf(ld_f32(dop, j), vv[j], dp);
+        s = fmaf(ldp(qp, j, a.ldq >> 1), kv[j], s);
+        dp = fmaf(ldp(dop, j, a.ldo >> 1), vv[j], dp);
       }
       const float p = expf(s * a.scale - L);
       const uint64_t di = (uint64_t)qrow * (uint64_t)a.Tk + (uint64_t)k;
@@ -180,11 +190,11 @@ __global__ __launch_bounds__(256) void k_attn_bwd_kv_generic(
   for (int j = lane; j < a.dh; j += 64) {
     float ak = 0.f, av = 0.f;
     for (int q = 0; q < a.Tq; ++q) {
-      ak = fmaf(ds[q], ld_f32(Q + (int64_t)b * a.sqb + (int64_t)q * a.ldq + (int64_t)h * a.dh, j), ak);
-      av = fmaf(pd[q], ld_f32(dO + (int64_t)b * a.sob + (int64_t)q * a.ldo + (int64_t)h * a.dh, j), av);
+      ak = fmaf(ds[q], ldp(Q + (int64_t)b * a.sqb + (int64_t)q * a.ldq + (int64_t)h * a.dh, j, a.ldq >> 1), ak);
+      av = fmaf(pd[q], ldp(dO + (int64_t)b * a.sob + (int64_t)q * a.ldo + (int64_t)h * a.dh, j, a.ldo >> 1), av);
     }
-    st_f32(dkp, j, ak);
-    st_f32(dvp, j, av);
+    stp(dkp, j, lddk >> 1, ak);
+    stp(dvp, j, lddv >> 1, av);
   }
 }
 
@@ -201,13 +211,18 @@ static AttnArgs make_args(const afm_attn_shape* s) {
 
 static int check_shape(const afm_attn_shape* s) {
   if (!s || s->B <= 0 || s->H <= 0 || s->Tq <= 0 || s->Tk <= 0 || s->dh <= 0) return AFM_ERR_ARG;
-  if (s->dtype != AFM_F32 && s->dtype != AFM_BF16) return AFM_ERR_ARG;
-  const int w = s->H * s->dh;
+  if (s->dtype < AFM_F32 || s->dtype > AFM_BF16X2) return AFM_ERR_ARG;
+  const int w = s->H * s->dh * (s->dtype == AFM_BF16X2 ? 2 : 1);   // split-pair rows hold two planes
   if (s->ldq < w || s->ldk < w || s->ldv < w || s->ldo < w) return AFM_ERR_ARG;
   return AFM_OK;
 }
 
-// defined in afm_attn_mfma.hip
+// defined in afm_attn_x3.hip (split-pair operands) and afm_attn_mfma.hip
+int afm_attn_fwd_x3_try(const afm_attn_shape* s, const void* Q, const void* K, const void* V,
+                        void* O, float* lse, hipStream_t st);
+int afm_attn_bwd_x3_try(const afm_attn_shape* s, const void* Q, const void* K, const void* V,
+                        const void* O, const void* dO, const float* lse, float* delta, void* dQ,
+                        void* dK, void* dV, int lddq, int lddk, int lddv, hipStream_t st);
 int afm_attn_fwd_mfma_try(const afm_attn_shape* s, const void* Q, const void* K, const void* V,
                           void* O, float* lse, hipStream_t st);
 int afm_attn_bwd_mfma_try(const afm_attn_shape* s, const void* Q, const void* K, const void* V,
@@ -221,7 +236,7 @@ extern "C" int afm_attn_fwd(const afm_attn_shape* s, const void* Q, const void* 
   if (!Q || !K || !V || !O || !lse) return AFM_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
   if (s->algo != AFM_ALGO_GENERIC) {
-    r = afm_attn_fwd_mfma_try(s, Q, K, V, O, lse, st);
+    r = s->dtype == AFM_BF16X2 ? afm_attn_fwd_x3_try(s, Q, K, V, O, lse, st) : afm_attn_fwd_mfma_try(s, Q, K, V, O, lse, st);
     if (r != AFM_ERR_UNSUPPORTED) return r;
     if (s->algo == AFM_ALGO_MFMA) return r;
   }
@@ -230,15 +245,9 @@ extern "C" int afm_attn_fwd(const afm_attn_shape* s, const void* Q, const void* 
   if (shm > 160 * 1024) return AFM_ERR_UNSUPPORTED;
   const int64_t nrows = (int64_t)s->B * s->H * s->Tq;
   const dim3 grid((unsigned)((nrows + 3) / 4));
-  if (s->dtype == AFM_F32) {
-    if (shm > 64 * 1024) hipFuncSetAttribute((const void*)k_attn_fwd_generic<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
-    AFM_LAUNCH(k_attn_fwd_generic<float>, grid, dim3(256), shm, st, a, (const float*)Q,
-                       (const float*)K, (const float*)V, (float*)O, lse);
-  } else {
-    if (shm > 64 * 1024) hipFuncSetAttribute((const void*)k_attn_fwd_generic<bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
-    AFM_LAUNCH(k_attn_fwd_generic<bf16>, grid, dim3(256), shm, st, a, (const bf16*)Q,
-                       (const bf16*)K, (const bf16*)V, (bf16*)O, lse);
-  }
+  AFM_DT_SWITCH(s->dtype, T,
+    if (shm > 64 * 1024) hipFuncSetAttribute((const void*)k_attn_fwd_generic<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+    AFM_LAUNCH(k_attn_fwd_generic<T>, grid, dim3(256), shm, st, a, (const T*)Q, (const T*)K, (const T*)V, (T*)O, lse));
   afm_set_last_algo("attn_generic");
   return AFM_OK;
 }
@@ -250,12 +259,13 @@ extern "C" int afm_attn_bwd(const afm_attn_shape* s, const void* Q, const void* 
   int r = check_shape(s);
   if (r != AFM_OK) return r;
   if (!Q || !K || !V || !O || !dO || !lse || !delta || !dQ || !dK || !dV) return AFM_ERR_ARG;
-  const int w = s->H * s->dh;
+  const int w = s->H * s->dh * (s->dtype == AFM_BF16X2 ? 2 : 1);
   if (lddq < w || lddk < w || lddv < w) return AFM_ERR_ARG;
   if (s->sqb || s->skb || s->svb || s->sob) return AFM_ERR_UNSUPPORTED;   // strided batches: forward (decode) only
   hipStream_t st = (hipStream_t)stream;
   if (s->algo != AFM_ALGO_GENERIC) {
-    r = afm_attn_bwd_mfma_try(s, Q, K, V, O, dO, lse, delta, dQ, dK, dV, lddq, lddk, lddv, st);
+    r = s->dtype == AFM_BF16X2 ? afm_attn_bwd_x3_try(s, Q, K, V, O, dO, lse, delta, dQ, dK, dV, lddq, lddk, lddv, st)
+                               : afm_attn_bwd_mfma_try(s, Q, K, V, O, dO, lse, delta, dQ, dK, dV, lddq, lddk, lddv, st);
     if (r != AFM_ERR_UNSUPPORTED) return r;
     if (s->algo == AFM_ALGO_MFMA) return r;
   }
@@ -274,7 +284,7 @@ extern "C" int afm_attn_bwd(const afm_attn_shape* s, const void* Q, const void* 
     AFM_LAUNCH(k_attn_bwd_kv_generic<T>, gk, dim3(256), shm_k, st, a, (const T*)Q, (const T*)K, \
                        (const T*)V, (const T*)dO, lse, delta, (T*)dK, (T*)dV, lddk, lddv);             \
   } while (0)
-  if (s->dtype == AFM_F32) LAUNCH_BWD(float); else LAUNCH_BWD(bf16);
+  if (s->dtype == AFM_F32) LAUNCH_BWD(float); else if (s->dtype == AFM_BF16) LAUNCH_BWD(bf16); else LAUNCH_BWD(x2);
 #undef LAUNCH_BWD
   afm_set_last_algo("attn_generic");
   return AFM_OK;

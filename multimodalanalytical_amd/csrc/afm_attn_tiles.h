@@ -1,0 +1,155 @@
+// LDS tile images, transposed-read helpers, the LDS-DMA piece and the dropout block of the MFMA flash-attention
+// kernels (afm_attn_mfma.hip: single bf16 pass; afm_attn_x3.hip: split-pair operands, three passes per product).
+#pragma once
+#include "afm_common.h"
+
+#define DH 64
+#define KT 64   // keys (or queries, in the dK/dV kernel) per LDS tile
+
+struct AttnM {
+  int B, H, Tq, Tk;
+  int ldq, ldk, ldv, ldo;
+  int lddq, lddk, lddv;
+  int causal;
+  float scale_log2;  // scale * log2(e)
+  float scale;
+  const uint8_t* key_pad;
+  DropDev dd;
+};
+
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+
+__device__ __forceinline__ f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+__device__ __forceinline__ float max3_raw(float a, float b, float c) {
+  float r;
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+
+// LDS images of a [64 rows][64 cols] bf16 tile (128-byte rows, 8 chunks of 16 bytes):
+//   "row image": read by rows with ds_read_b128 (lane = row, 32 rows x one chunk per half-wave)
+//   "tr image" : read transposed with ds_read_b64_tr_b16 (4 rows x 16 columns per 16 lanes)
+__device__ __forceinline__ int img_row(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
+__device__ __forceinline__ int img_tr(int row, int chunk) { return row * 128 + ((chunk ^ (((row >> 1) & 1) << 2)) << 4); }
+
+// accumulator register r of a 32x32 tile <-> row (r&3) + 8*(r>>2) + 4*(lane>>5)
+#define ACC_ROW(r) (((r) & 3) + 8 * ((r) >> 2))
+
+// A-operand fragment "X^T slice": element j of lane-half h <-> tile row R0 + 4h + (j&3) + 8*(j>>2),
+// column C0 + (lane&31); two transposed reads.  R0 = first row of the 16-row k-slice.
+//
+// The reads are inline asm, not the ds_read_tr builtin: behind the builtin hipcc puts
+// `s_waitcnt vmcnt(0)` in front of the first transposed read of every tile, which drains the LDS-DMA
+// ring (the prefetch of the next tile) in the middle of the tile.  The asm reads are invisible to the
+// compiler's counters, so the consumer waits by hand: tr_wait<N>() = s_waitcnt lgkmcnt(N) + scheduling
+// fence (cdna_hip_programming.md 5.7 form iii).  LDS returns in order, so lgkmcnt(N) with N younger
+// reads outstanding is enough for the older ones (a compiler-issued LGKM op in between only makes the
+// wait stricter).  One quad = the two 32-column halves (db = 0, 1) of a 16-row slice.
+struct TrQuad { s16x4 lo0, hi0, lo1, hi1; };
+#define AFM_TR_RD(dst, addr, OFF) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:" #OFF : "=v"(dst) : "v"(addr))
+// per-lane byte addresses (db = 0 / 1) of slice R0 = 0 inside a tr image; slice R0 adds R0*128 (immediate)
+__device__ __forceinline__ void tr_lane_addr(const unsigned char* img, int lane, unsigned& a0, unsigned& a1) {
+  const int g = lane >> 4, qq = (lane >> 2) & 3, p = lane & 3;
+  const int row = 4 * (g >> 1) + qq, bsw = (qq >> 1) & 1;        // ((R0 + row) >> 1) & 1 for R0 % 16 == 0
+  const int c = 2 * (g & 1) + (p >> 1), sub = (p & 1) << 3;
+  const unsigned base = (unsigned)(uintptr_t)img + row * 128 + sub;
+  a0 = base + ((4 * bsw + c) << 4);
+  a1 = base + ((4 * (1 ^ bsw) + c) << 4);
+}
+__device__ __forceinline__ TrQuad tr_issue(unsigned a0, unsigned a1, int R0) {
+  TrQuad q;
+  switch (R0) {   // R0 is a constant after unrolling; the offsets must be literals for the asm
+    case 0:  AFM_TR_RD(q.lo0, a0, 0);    AFM_TR_RD(q.hi0, a0, 1024); AFM_TR_RD(q.lo1, a1, 0);    AFM_TR_RD(q.hi1, a1, 1024); break;
+    case 16: AFM_TR_RD(q.lo0, a0, 2048); AFM_TR_RD(q.hi0, a0, 3072); AFM_TR_RD(q.lo1, a1, 2048); AFM_TR_RD(q.hi1, a1, 3072); break;
+    case 32: AFM_TR_RD(q.lo0, a0, 4096); AFM_TR_RD(q.hi0, a0, 5120); AFM_TR_RD(q.lo1, a1, 4096); AFM_TR_RD(q.hi1, a1, 5120); break;
+    default: AFM_TR_RD(q.lo0, a0, 6144); AFM_TR_RD(q.hi0, a0, 7168); AFM_TR_RD(q.lo1, a1, 6144); AFM_TR_RD(q.hi1, a1, 7168); break;
+  }
+  return q;
+}
+template <int N> __device__ __forceinline__ void tr_wait() {
+  asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
+  __builtin_amdgcn_sched_barrier(0);
+}
+__device__ __forceinline__ bf16x8 tr_join(s16x4 lo, s16x4 hi) {
+  const bf16x4 l = __builtin_bit_cast(bf16x4, lo), h = __builtin_bit_cast(bf16x4, hi);
+  return (bf16x8){l[0], l[1], l[2], l[3], h[0], h[1], h[2], h[3]};
+}
+// A-operand fragment by rows: lane holds tile[R0 + (lane&31)][16*s + 8*(lane>>5) .. +7]
+__device__ __forceinline__ bf16x8 frag_row(const unsigned char* img, int R0, int s, int lane) {
+  return *(const bf16x8*)(img + img_row(R0 + (lane & 31), 2 * s + (lane >> 5)));
+}
+__device__ __forceinline__ bf16x8 cvt8(const f32x16& x, int s) {
+  return (bf16x8){(bf16)x[8 * s + 0], (bf16)x[8 * s + 1], (bf16)x[8 * s + 2], (bf16)x[8 * s + 3],
+                  (bf16)x[8 * s + 4], (bf16)x[8 * s + 5], (bf16)x[8 * s + 6], (bf16)x[8 * s + 7]};
+}
+
+// stage a [64][64] bf16 tile of a (rows x ld) matrix: thread t -> rows t>>3 and 32 + t>>3, chunk t&7
+struct Stage2 { uint4 v[2]; };
+__device__ __forceinline__ Stage2 stage_load(const bf16* base, int ld, int row0, int nrows, int t) {
+  Stage2 s;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    int r = row0 + (t >> 3) + 32 * i;
+    r = r < nrows ? r : nrows - 1;  // clamped rows are masked out by the caller
+    s.v[i] = *(const uint4*)(base + (int64_t)r * ld + (t & 7) * 8);
+  }
+  return s;
+}
+template <bool TR>
+__device__ __forceinline__ void stage_store(unsigned char* img, const Stage2& s, int t) {
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int r = (t >> 3) + 32 * i;
+    *(uint4*)(img + (TR ? img_tr(r, t & 7) : img_row(r, t & 7))) = s.v[i];
+  }
+}
+
+// dropout on a 32x32 score block held transposed (rows = keys in registers, query on the lane):
+// keep bits for key pairs (ACC_ROW(r), +1) come from one hash (afm_keep16).
+// The MFMA kernels only run when the whole probability tensor has <= 2^32 elements (eligible()), so
+// the element index fits 32 bits and the high-word term of the hash is zero.
+__device__ __forceinline__ uint32_t hash_pair32(const DropDev& dd, uint32_t half_idx) {
+  return afm_lowbias32(half_idx ^ dd.key);
+}
+__device__ __forceinline__ void drop_block(const DropDev& dd, uint32_t rowbase, int key0, int h, f32x16& x) {
+  const uint32_t base = (rowbase + (uint32_t)(key0 + 4 * h)) >> 1;       // even (Tk even, key0 even)
+#pragma unroll
+  for (int r = 0; r < 16; r += 2) {
+    const uint32_t hsh = hash_pair32(dd, base + (uint32_t)(ACC_ROW(r) >> 1));
+    x[r] = (hsh & 0xFFFFu) >= dd.thresh16 ? x[r] : 0.f;
+    x[r + 1] = (hsh >> 16) >= dd.thresh16 ? x[r + 1] : 0.f;
+  }
+}
+
+// ------------------------------------------------------------------------------------------ LDS-DMA tile ring
+// K / V / Q / dO tiles go HBM -> LDS with global_load_lds_dwordx4 (1-KiB pieces = 8 tile rows), the
+// image swizzles applied on the SOURCE chunk index, into a ring of RS stages with RS-1 tiles in
+// flight (counted vmcnt + raw s_barrier, as in the GEMM ring): the tile loads no longer sit on the
+// critical path of each iteration.
+template <int N> __device__ __forceinline__ void attn_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+#define RS 3
+// one piece: rows [8*pi, 8*pi+8) of the 64-row tile starting at global row `row0` of `base`
+template <bool TR>
+__device__ __forceinline__ void dma_piece(unsigned char* img, const bf16* base, int ld, int row0, int nrows,
+                                          int pi, int lane) {
+  const int r = 8 * pi + (lane >> 3), slot = lane & 7;
+  const int chunk = TR ? (slot ^ (((r >> 1) & 1) << 2)) : (slot ^ ((r >> 1) & 7));
+  int gr = row0 + r;
+  gr = gr < nrows ? gr : nrows - 1;   // clamped rows are masked out by the caller
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + (int64_t)gr * ld + chunk * 8),
+                                   (__attribute__((address_space(3))) void*)(img + pi * 1024), 16, 0, 0);
+}
+// key-mask words (bit i of word t = key 64 t + i is padded or past Tk) for one batch row, in LDS
+__device__ __forceinline__ void build_mask_words(unsigned long long* maskw, const uint8_t* key_pad, int b, int Tk,
+                                                 int nwords, int w, int lane) {
+  for (int wd = w; wd < nwords; wd += 4) {
+    const int kk = wd * 64 + lane;
+    const bool msk = kk >= Tk || (key_pad && key_pad[(int64_t)b * Tk + kk]);
+    const unsigned long long word = __ballot(msk);
+    if (lane == 0) maskw[wd] = word;
+  }
+}
+

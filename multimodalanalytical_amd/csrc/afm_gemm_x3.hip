@@ -1,0 +1,554 @@
+// "bf16x3" GEMMs for gfx950: operands are split bf16 pairs (AFM_BF16X2: value = hi + lo, include/afm_hip.h), every
+// product runs as three bf16 MFMAs  hi*hi + hi*lo + lo*hi  (v_mfma_f32_16x16x32_bf16, fp32 accumulate): results at
+// fp32-GEMM accuracy (the dropped lo*lo term is 2^-18 relative) on the bf16 matrix cores.
+//
+//   NT  C[m][n] = sum_k A[m][k] B[n][k]     forward / dgrad: persistent 256 x 128 tiles, 8 MFMA waves + 4 loader waves
+//   TN  C[m][n] += sum_k A[k][m] B[k][n]    wgrad: 256 x 128 tiles, split-K over the token rows, fp32 atomics
+//
+// Both reuse the LDS images of the single-pass kernels (afm_gemm_mfma.hip) with the k-step halved to 32: one LDS row
+// of the NT image holds [hi k0..31 | lo k0..31] (128 bytes, the XOR swizzle of the 64-deep single-pass row), the TN
+// stage holds 32 hi rows then 32 lo rows.  The fragment reads are therefore the single-pass reads, k-slice 0 returning
+// the hi fragments and k-slice 1 the lo fragments; the LDS-DMA pieces differ only in their per-lane SOURCE address.
+// Per byte staged the kernel issues 1.5x the MFMAs of the single-pass form, so it sits closer to the MFMA roof.
+#include "afm_common.h"
+
+struct X3Args {
+  int M, N, K;
+  int lda, ldb, ldc;
+  const bf16* A;
+  const bf16* B;
+  void* C;
+  const float* bias;
+  const void* residual;
+  void* pre_act;
+  float* a_colsum;
+  int act, accumulate;
+  int tiles_m, tiles_n;
+  int ksplit, kchunk;   // TN only
+  int bias_in_lds;
+  DropDev dd;
+};
+
+template <int N> __device__ __forceinline__ void x3_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+typedef __attribute__((ext_vector_type(4))) short x3_s16x4;
+
+enum { X3_F32 = 0, X3_X2 = 2 };
+enum { XE_GENERIC = 0, XE_PLAIN = 1, XE_GELU = 3, XE_GELU_BWD = 4, XE_GELU_SG = 5, XE_MUL = 6 };
+
+__device__ __forceinline__ float x3_drop32(const DropDev& d, uint32_t idx, float x) {
+  return afm_lowbias32(idx ^ d.key) >= d.thresh ? x * d.scale : 0.f;
+}
+
+// ------------------------------------------------------------------------------------------ fragment epilogue
+// Lane holds C[m][n0 .. n0+3] (edge tiles / shapes without whole tiles): every run-time option of afm_gemm.
+template <int CT>
+__device__ __forceinline__ float x3_ldc(const void* p, int64_t ci, int lo) {
+  if (CT == X3_F32) return ((const float*)p)[ci];
+  return (float)((const bf16*)p)[ci] + (float)((const bf16*)p)[ci + lo];
+}
+template <int CT>
+__device__ __forceinline__ void x3_stc(void* p, int64_t ci, int lo, float v) {
+  if (CT == X3_F32) { ((float*)p)[ci] = v; return; }
+  bf16 h, l;
+  afm_split(v, h, l);
+  ((bf16*)p)[ci] = h; ((bf16*)p)[ci + lo] = l;
+}
+template <int CT>
+__device__ __forceinline__ void x3_epilogue4(const X3Args& g, int m, int n0, f32x4 v) {
+  if (m >= g.M || n0 >= g.N) return;
+  const int lo = g.ldc >> 1;
+  const int nv = min(4, g.N - n0);
+  for (int r = 0; r < nv; ++r) {
+    float x = v[r];
+    const int n = n0 + r;
+    const int64_t ci = (int64_t)m * g.ldc + n;
+    const uint64_t di = (uint64_t)m * (uint64_t)g.N + (uint64_t)n;
+    if (g.bias) x += g.bias[n];
+    if (g.act == AFM_ACT_GELU_BWD) {
+      x = afm_drop(g.dd, di, x) * afm_gelu_grad(x3_ldc<CT>(g.pre_act, ci, lo));
+    } else if (g.act == AFM_ACT_GELU_SAVE_GRAD) {
+      float y, yp;
+      afm_gelu_both(x, y, yp);
+      const float k = afm_drop(g.dd, di, 1.0f);
+      x3_stc<CT>(g.pre_act, ci, lo, yp * k);
+      x = y * k;
+    } else if (g.act == AFM_ACT_MUL_SAVED) {
+      x *= x3_ldc<CT>(g.pre_act, ci, lo);
+    } else {
+      if (g.pre_act) x3_stc<CT>(g.pre_act, ci, lo, x);
+      if (g.act == AFM_ACT_RELU) x = fmaxf(x, 0.f);
+      else if (g.act == AFM_ACT_GELU) x = afm_gelu(x);
+      x = afm_drop(g.dd, di, x);
+    }
+    if (g.residual) x += x3_ldc<CT>(g.residual, ci, lo);
+    if (g.accumulate) x += x3_ldc<CT>(g.C, ci, lo);
+    x3_stc<CT>(g.C, ci, lo, x);
+  }
+}
+
+// ------------------------------------------------------------------------------------------ staged epilogue
+// Whole tiles: a wave's 64 x 64 accumulator block goes through a wave-private LDS patch 16 rows at a time so every
+// global access is 16 bytes per lane on whole 128-byte lines (as afm_gemm_mfma.hip's staged epilogue); the split-pair
+// output writes the hi and the lo plane of 8 rows x 64 columns with one store instruction each.
+#define X3_STG_LD 68
+template <int CT, int EPI, int WM>
+__device__ __forceinline__ void x3_epilogue_staged(const X3Args& g, float* stg, const float* bias_lds,
+                                                   f32x4 (&acc)[4][WM], int mw, int nw, int lane) {
+  const int fr = lane & 15, fq = lane >> 4;
+  if constexpr (CT == X3_X2) {
+    const int c8 = (lane & 7) * 8, r8 = lane >> 3;
+    const int n = nw + c8, lo = g.ldc >> 1;
+    f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = {0.f, 0.f, 0.f, 0.f};
+    if (EPI != XE_GELU_BWD && EPI != XE_MUL && g.bias) { b0 = *(const f32x4*)(bias_lds + n); b1 = *(const f32x4*)(bias_lds + n + 4); }
+    const bool drop_on = g.dd.thresh != 0;
+    bf16* const cbase = (bf16*)g.C + (int64_t)(mw + r8) * g.ldc + n;
+    bf16* const pbase = (bf16*)g.pre_act + (int64_t)(mw + r8) * g.ldc + n;
+    const uint32_t dbase = (uint32_t)(mw + r8) * (uint32_t)g.N + (uint32_t)n;
+#pragma unroll
+    for (int i = 0; i < WM; ++i) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) *(f32x4*)(stg + fr * X3_STG_LD + j * 16 + fq * 4) = acc[j][i];
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf) {
+        const int q = i * 2 + hf, row = hf * 8 + r8;
+        const f32x4 v0 = *(const f32x4*)(stg + row * X3_STG_LD + c8) + b0;
+        const f32x4 v1 = *(const f32x4*)(stg + row * X3_STG_LD + c8 + 4) + b1;
+        float x[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+        const int64_t ro = (int64_t)(q * 8) * g.ldc;
+        const uint32_t di = dbase + (uint32_t)(q * 8) * (uint32_t)g.N;
+        if (EPI == XE_GELU) {
+          if (g.pre_act) {
+            bf16x8 h, l;
+            afm_split8(x, h, l);
+            *(bf16x8*)(pbase + ro) = h; *(bf16x8*)(pbase + ro + lo) = l;
+          }
+#pragma unroll
+          for (int k = 0; k < 8; ++k) x[k] = afm_gelu(x[k]);
+          if (drop_on) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) x[k] = x3_drop32(g.dd, di + k, x[k]);
+          }
+        }
+        if (EPI == XE_GELU_SG) {
+          float gp[8];
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            float y, yp;
+            afm_gelu_both(x[k], y, yp);
+            const float keep = drop_on ? x3_drop32(g.dd, di + k, 1.0f) : 1.0f;
+            x[k] = y * keep; gp[k] = yp * keep;
+          }
+          bf16x8 h, l;
+          afm_split8(gp, h, l);
+          *(bf16x8*)(pbase + ro) = h; *(bf16x8*)(pbase + ro + lo) = l;
+        }
+        if (EPI == XE_MUL || EPI == XE_GELU_BWD) {
+          const bf16x8 uh = *(const bf16x8*)(pbase + ro), ul = *(const bf16x8*)(pbase + ro + lo);
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            const float u = (float)uh[k] + (float)ul[k];
+            if (EPI == XE_MUL) x[k] *= u;
+            else x[k] = (drop_on ? x3_drop32(g.dd, di + k, x[k]) : x[k]) * afm_gelu_grad(u);
+          }
+        }
+        bf16x8 h, l;
+        afm_split8(x, h, l);
+        *(bf16x8*)(cbase + ro) = h; *(bf16x8*)(cbase + ro + lo) = l;
+      }
+    }
+  } else {   // fp32 output: bias, residual, accumulate (logits, residual branches, encoder-output gradient)
+    const int c4 = (lane & 15) * 4, r4 = lane >> 4;
+    const int n = nw + c4;
+    f32x4 b0 = {0.f, 0.f, 0.f, 0.f};
+    if (g.bias) b0 = *(const f32x4*)(bias_lds + n);
+#pragma unroll
+    for (int i = 0; i < WM; ++i) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) *(f32x4*)(stg + fr * X3_STG_LD + j * 16 + fq * 4) = acc[j][i];
+#pragma unroll
+      for (int qq = 0; qq < 4; ++qq) {
+        const int row = qq * 4 + r4;
+        const int64_t ci = (int64_t)(mw + i * 16 + row) * g.ldc + n;
+        f32x4 v = *(const f32x4*)(stg + row * X3_STG_LD + c4) + b0;
+        if (g.residual) v += *(const f32x4*)((const float*)g.residual + ci);
+        if (g.accumulate) v += *(const f32x4*)((const float*)g.C + ci);
+        *(f32x4*)((float*)g.C + ci) = v;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------ NT
+template <int CT, int EPI>
+__global__ __launch_bounds__(768) void k_x3_nt(X3Args g) {
+  constexpr int NWN = 2, NW = 8, NL = 4, WM = 4, S = 3;
+  constexpr int TBM = 256, TBN = 128;
+  constexpr int NI = (TBM + TBN) / 8, NIL = NI / NL;
+  constexpr int STAGE = (TBM + TBN) * 128;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  float* bias_lds = (float*)(lds + S * STAGE);
+  const int t = threadIdx.x, lane = t & 63;
+  const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int ntiles = g.tiles_m * g.tiles_n;
+  if (g.bias_in_lds) {
+    for (int n = t; n < g.N; n += 64 * (NW + NL)) bias_lds[n] = g.bias ? g.bias[n] : 0.f;
+    __syncthreads();
+  }
+  const int xcd = blockIdx.x & 7, bx = blockIdx.x >> 3, nbx = gridDim.x >> 3;
+  const int tpx = (ntiles + 7) >> 3;
+  const int tlo = xcd * tpx, thi = min(ntiles, tlo + tpx);
+  auto tile_of = [&](int it) { const int tt = tlo + it * nbx + bx; return tt < thi ? tt : -1; };
+  auto tile_full = [&](int tile) {
+    const int m0 = (tile / g.tiles_n) * TBM, n0 = (tile % g.tiles_n) * TBN;
+    return g.bias_in_lds && m0 + TBM <= g.M && n0 + TBN <= g.N;
+  };
+  const int nk = g.K / 32;
+
+  if (w >= NW) {
+    // ---------------------------------------------------------------- loader wave
+    const int lw = w - NW;
+    const bf16* src[NIL];
+    auto set_src = [&](int tile) {
+      const int m0 = (tile / g.tiles_n) * TBM, n0 = (tile % g.tiles_n) * TBN;
+#pragma unroll
+      for (int j = 0; j < NIL; ++j) {
+        const int ii = lw + NL * j;
+        const int r8 = lane >> 3, ch = (lane & 7) ^ r8;          // data chunk landing in this lane's LDS slot
+        const int koff = (ch & 3) * 8;                            // chunks 0-3: hi plane, 4-7: lo plane
+        if (ii < TBM / 8) src[j] = g.A + (int64_t)min(m0 + ii * 8 + r8, g.M - 1) * g.lda + koff + (ch >> 2) * (g.lda >> 1);
+        else src[j] = g.B + (int64_t)min(n0 + (ii - TBM / 8) * 8 + r8, g.N - 1) * g.ldb + koff + (ch >> 2) * (g.ldb >> 1);
+      }
+    };
+    int is_it = 0, is_kt = 0, is_slot = 0;
+    int is_tile = tile_of(0);
+    if (is_tile >= 0) set_src(is_tile);
+    int ahead = 0;
+    auto issue_one = [&]() {
+      if (is_tile < 0) return;
+      unsigned char* st = lds + is_slot * STAGE;
+#pragma unroll
+      for (int j = 0; j < NIL; ++j)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[j] + is_kt * 32),
+                                         (__attribute__((address_space(3))) void*)(st + (lw + NL * j) * 1024), 16, 0, 0);
+      ++ahead;
+      is_slot = is_slot + 1 == S ? 0 : is_slot + 1;
+      if (++is_kt == nk) {
+        is_kt = 0;
+        is_tile = tile_of(++is_it);
+        if (is_tile >= 0) set_src(is_tile);
+      }
+    };
+#pragma unroll
+    for (int s = 0; s < S - 1; ++s) issue_one();
+    for (int it = 0;; ++it) {
+      const int tile = tile_of(it);
+      if (tile < 0) break;
+      for (int kt = 0; kt < nk; ++kt) {
+        if (ahead - 1 >= S - 2) x3_wait_vmcnt<NIL * (S - 2)>(); else x3_wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        --ahead;
+        issue_one();
+      }
+      if (tile_full(tile)) __builtin_amdgcn_s_barrier();
+    }
+    return;
+  }
+
+  // ------------------------------------------------------------------ compute wave
+  const int wm = w / NWN, wn = w % NWN;
+  auto off = [](int row, int chunk) { return row * 128 + ((chunk ^ (row & 7)) << 4); };
+  const int fr = lane & 15, fq = lane >> 4;
+  int slot = 0;
+  for (int it = 0;; ++it) {
+    const int tile = tile_of(it);
+    if (tile < 0) break;
+    const int m0 = (tile / g.tiles_n) * TBM, n0 = (tile % g.tiles_n) * TBN;
+    f32x4 acc[4][WM];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int i = 0; i < WM; ++i) acc[j][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int kt = 0; kt < nk; ++kt) {
+      __builtin_amdgcn_s_barrier();
+      const unsigned char* a = lds + slot * STAGE;
+      const unsigned char* b = a + TBM * 128;
+      slot = slot + 1 == S ? 0 : slot + 1;
+      bf16x8 ah[WM], bh[4], bl[4];
+#pragma unroll
+      for (int i = 0; i < WM; ++i) ah[i] = *(const bf16x8*)(a + off(wm * 16 * WM + i * 16 + fr, fq));
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bl[j] = *(const bf16x8*)(b + off(wn * 64 + j * 16 + fr, 4 + fq));
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bh[j] = *(const bf16x8*)(b + off(wn * 64 + j * 16 + fr, fq));
+      // small terms first: a_hi * b_lo, a_lo * b_hi, then a_hi * b_hi
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+          acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl[j], ah[i], acc[j][i], 0, 0, 0);
+      bf16x8 al[WM];
+#pragma unroll
+      for (int i = 0; i < WM; ++i) al[i] = *(const bf16x8*)(a + off(wm * 16 * WM + i * 16 + fr, 4 + fq));
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+          acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[j], al[i], acc[j][i], 0, 0, 0);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+          acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[j], ah[i], acc[j][i], 0, 0, 0);
+    }
+    if (tile_full(tile)) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      float* stg = (float*)(lds + (slot == 0 ? S - 1 : slot - 1) * STAGE) + w * (16 * X3_STG_LD);
+      x3_epilogue_staged<CT, EPI, WM>(g, stg, bias_lds, acc, m0 + wm * 16 * WM, n0 + wn * 64, lane);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+          x3_epilogue4<CT>(g, m0 + wm * 16 * WM + i * 16 + fr, n0 + wn * 64 + j * 16 + fq * 4, acc[j][i]);
+    }
+  }
+}
+
+template <int CT, int EPI>
+static int launch_x3_nt(X3Args& g, hipStream_t st, bool staged_ok) {
+  constexpr int TBM = 256, TBN = 128, S = 3;
+  constexpr int ring = S * (TBM + TBN) * 128;
+  g.tiles_m = (g.M + TBM - 1) / TBM; g.tiles_n = (g.N + TBN - 1) / TBN;
+  const int bias_bytes = ((g.N * 4 + 15) / 16) * 16;
+  g.bias_in_lds = staged_ok && ring + bias_bytes <= 160 * 1024 ? 1 : 0;
+  const int shm = ring + (g.bias_in_lds ? bias_bytes : 0);
+  auto kern = k_x3_nt<CT, EPI>;
+  static bool attr_done = false;   // per instantiation
+  if (!attr_done) {
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_done = true;
+  }
+  int grid = 256;
+  const int ntiles = g.tiles_m * g.tiles_n;
+  if (grid > ((ntiles + 7) / 8) * 8) grid = ((ntiles + 7) / 8) * 8;
+  AFM_LAUNCH(kern, dim3(grid), dim3(768), shm, st, g);
+  return AFM_OK;
+}
+
+// ------------------------------------------------------------------------------------------ TN (wgrad)
+// Stage = 64 LDS rows x (256 A columns + 128 B columns): rows 0-31 the hi plane of 32 token rows, rows 32-63 their lo
+// plane; 16-byte chunks XOR-swizzled as in k_gemm_tn_ring; fragments by ds_read_b64_tr_b16 (inline asm, hand-waited).
+__device__ __forceinline__ int x3_tn_swz(int row) { return ((row & 3) << 1) | (((row >> 3) & 1) << 3); }
+
+__global__ __launch_bounds__(512, 2) void k_x3_tn(X3Args g) {
+  constexpr int S = 3, TBM = 256, TBN = 128, NW = 8, NIW = 6;
+  constexpr int ABYTES = 64 * TBM * 2, STAGE = 64 * (TBM + TBN) * 2;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  const int t = threadIdx.x, lane = t & 63;
+  const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wm = w >> 1, wn = w & 1;
+  const int ntile = g.tiles_m * g.tiles_n;
+  // tile index fastest: the workgroups of one XCD share a k-chunk (dy / x rows served from that XCD's L2)
+  const int q8 = (ntile * g.ksplit) >> 3, r8 = (ntile * g.ksplit) & 7, xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+  const int bid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
+  const int tile = bid % ntile, ks_id = bid / ntile;
+  const int m0 = (tile / g.tiles_n) * TBM, n0 = (tile % g.tiles_n) * TBN;
+  const int kbeg = ks_id * g.kchunk, kend = min(g.K, kbeg + g.kchunk);
+  const int nk = (kend - kbeg) / 32;
+
+  const bf16* src[NIW];
+  int64_t pitch[NIW];
+#pragma unroll
+  for (int j = 0; j < NIW; ++j) {
+    const int ii = w + NW * j;
+    if (ii < 32) {
+      const int r = ii * 2 + (lane >> 5);                 // LDS row 0..63: plane r >> 5, token row r & 31
+      const int c = (lane & 31) ^ x3_tn_swz(r);
+      src[j] = g.A + (int64_t)(kbeg + (r & 31)) * g.lda + (r >> 5) * (g.lda >> 1) + min(m0 + c * 8, g.M - 8);
+      pitch[j] = (int64_t)32 * g.lda;
+    } else {
+      const int r = (ii - 32) * 4 + (lane >> 4);
+      const int c = (lane & 15) ^ x3_tn_swz(r);
+      src[j] = g.B + (int64_t)(kbeg + (r & 31)) * g.ldb + (r >> 5) * (g.ldb >> 1) + min(n0 + c * 8, g.N - 8);
+      pitch[j] = (int64_t)32 * g.ldb;
+    }
+  }
+  auto issue = [&](int kt) {
+    unsigned char* st = lds + (kt % S) * STAGE;
+#pragma unroll
+    for (int j = 0; j < NIW; ++j)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[j] + kt * pitch[j]),
+                                       (__attribute__((address_space(3))) void*)(st + (w + NW * j) * 1024), 16, 0, 0);
+  };
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const bool do_cs = g.a_colsum != nullptr && (tile % g.tiles_n) == 0 && wn == 0;
+  float cs[4] = {0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll
+  for (int s = 0; s < S - 1; ++s)
+    if (s < nk) issue(s);
+  const int grp = lane >> 4, q = (lane >> 2) & 3, p = lane & 3;
+  int laneA[4], laneB[4];
+  {
+    const int lrow = grp * 8 + q, swz = x3_tn_swz(lrow), sub = (p & 1) << 3;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int cha = ((wm * 64 + i * 16) >> 3) + (p >> 1), chb = ((wn * 64 + i * 16) >> 3) + (p >> 1);
+      laneA[i] = lrow * 512 + ((cha ^ swz) << 4) + sub;
+      laneB[i] = ABYTES + lrow * 256 + ((chb ^ swz) << 4) + sub;
+    }
+  }
+  for (int kt = 0; kt < nk; ++kt) {
+    const int later = min(S - 2, nk - 1 - kt);
+    if (later >= S - 2) x3_wait_vmcnt<NIW * (S - 2)>(); else x3_wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    if (kt + S - 1 < nk) issue(kt + S - 1);
+    const unsigned sbase = (unsigned)(uintptr_t)(lds + (kt % S) * STAGE);
+    unsigned va[4], vb[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { va[i] = sbase + (unsigned)laneA[i]; vb[i] = sbase + (unsigned)laneB[i]; }
+    x3_s16x4 a0[2][4], a1[2][4], b0[2][4], b1[2][4];      // [plane][fragment]
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(a0[0][i]) : "v"(va[i]));
+      asm volatile("ds_read_b64_tr_b16 %0, %1 offset:2048" : "=v"(a1[0][i]) : "v"(va[i]));
+      asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(b0[0][i]) : "v"(vb[i]));
+      asm volatile("ds_read_b64_tr_b16 %0, %1 offset:1024" : "=v"(b1[0][i]) : "v"(vb[i]));
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      asm volatile("ds_read_b64_tr_b16 %0, %1 offset:16384" : "=v"(a0[1][i]) : "v"(va[i]));
+      asm volatile("ds_read_b64_tr_b16 %0, %1 offset:18432" : "=v"(a1[1][i]) : "v"(va[i]));
+      asm volatile("ds_read_b64_tr_b16 %0, %1 offset:8192" : "=v"(b0[1][i]) : "v"(vb[i]));
+      asm volatile("ds_read_b64_tr_b16 %0, %1 offset:9216" : "=v"(b1[1][i]) : "v"(vb[i]));
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    bf16x8 af[2][4], bfr[2][4];
+#pragma unroll
+    for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const bf16x4 x0 = __builtin_bit_cast(bf16x4, a0[pl][i]), x1 = __builtin_bit_cast(bf16x4, a1[pl][i]);
+        const bf16x4 y0 = __builtin_bit_cast(bf16x4, b0[pl][i]), y1 = __builtin_bit_cast(bf16x4, b1[pl][i]);
+        af[pl][i] = (bf16x8){x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
+        bfr[pl][i] = (bf16x8){y0[0], y0[1], y0[2], y0[3], y1[0], y1[1], y1[2], y1[3]};
+      }
+    if (do_cs) {   // bias gradient: column sums of dy = hi + lo (lane: column fr, 8 token rows)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) cs[i] += (float)af[0][i][j] + (float)af[1][i][j];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0][i], bfr[1][j], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[1][i], bfr[0][j], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0][i], bfr[0][j], acc[i][j], 0, 0, 0);
+      }
+  }
+  const int fr = lane & 15, fq = lane >> 4;
+  if (do_cs) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float s = cs[i];
+      s += __shfl_xor(s, 16, 64);
+      s += __shfl_xor(s, 32, 64);
+      const int mm = m0 + wm * 64 + i * 16 + fr;
+      if (fq == 0 && mm < g.M) atomicAdd(g.a_colsum + mm, s);
+    }
+  }
+  float* C = (float*)g.C;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = n0 + wn * 64 + j * 16 + fr;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int mm = m0 + wm * 64 + i * 16 + fq * 4 + r;
+        if (mm < g.M && n < g.N) {
+          float* c = C + (int64_t)mm * g.ldc + n;
+          if (g.ksplit > 1) atomicAdd(c, acc[i][j][r]);
+          else *c = acc[i][j][r] + (g.accumulate ? *c : 0.f);
+        }
+      }
+    }
+}
+
+// ------------------------------------------------------------------------------------------ dispatch
+static inline bool x3_al16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+
+int afm_gemm_x3_try(const afm_gemm_desc* d, hipStream_t st) {
+  if (d->a_dtype != AFM_BF16X2 || d->b_dtype != AFM_BF16X2) return AFM_ERR_UNSUPPORTED;
+  X3Args g;
+  g.M = d->M; g.N = d->N; g.K = d->K; g.lda = d->lda; g.ldb = d->ldb; g.ldc = d->ldc;
+  g.A = (const bf16*)d->A; g.B = (const bf16*)d->B; g.C = d->C;
+  g.bias = d->bias; g.residual = d->residual; g.pre_act = d->pre_act; g.a_colsum = d->a_colsum;
+  g.act = d->act; g.accumulate = d->accumulate;
+  g.dd = afm_make_drop(&d->drop);
+  g.tiles_m = g.tiles_n = 0; g.ksplit = 1; g.kchunk = d->K; g.bias_in_lds = 0;
+  // 16-byte pieces of both planes: pointers 16-byte aligned, plane offsets (ld / 2) multiples of 8 elements
+  if (!x3_al16(d->A) || !x3_al16(d->B) || (d->lda & 15) || (d->ldb & 15)) return AFM_ERR_UNSUPPORTED;
+  if (!d->transA && d->transB) {   // NT
+    if ((d->K & 31) || d->K < 32 || d->N < 16) return AFM_ERR_UNSUPPORTED;
+    if (d->c_dtype == AFM_BF16) return AFM_ERR_UNSUPPORTED;
+    if (d->bias && !x3_al16(d->bias)) return AFM_ERR_UNSUPPORTED;
+    if (!x3_al16(d->C) || (d->residual && !x3_al16(d->residual)) || (d->pre_act && !x3_al16(d->pre_act))) return AFM_ERR_UNSUPPORTED;
+    const bool small_idx = (uint64_t)d->M * (uint64_t)d->N <= 0x100000000ull;
+    int r;
+    if (d->c_dtype == AFM_F32) {
+      if (d->act != AFM_ACT_NONE || d->pre_act || d->drop.p > 0.f) return AFM_ERR_UNSUPPORTED;   // exact-fp32 kernel
+      const bool staged = (d->N % 4) == 0 && (d->ldc % 4) == 0;
+      r = launch_x3_nt<X3_F32, XE_GENERIC>(g, st, staged);
+    } else {
+      if ((d->ldc & 15) || d->act == AFM_ACT_RELU) return AFM_ERR_UNSUPPORTED;
+      // compile-time staged epilogues for the training step's forms; anything else keeps the fragment epilogue
+      const bool plainish = !d->residual && !d->accumulate && (d->N % 8) == 0 && (small_idx || d->drop.p <= 0.f);
+      if (d->act == AFM_ACT_GELU_SAVE_GRAD) r = launch_x3_nt<X3_X2, XE_GELU_SG>(g, st, plainish);
+      else if (d->act == AFM_ACT_MUL_SAVED) r = launch_x3_nt<X3_X2, XE_MUL>(g, st, plainish);
+      else if (d->act == AFM_ACT_GELU_BWD) r = launch_x3_nt<X3_X2, XE_GELU_BWD>(g, st, plainish);
+      else if (d->act == AFM_ACT_GELU) r = launch_x3_nt<X3_X2, XE_GELU>(g, st, plainish);
+      else r = launch_x3_nt<X3_X2, XE_PLAIN>(g, st, plainish && !d->pre_act && d->drop.p <= 0.f);
+    }
+    if (r != AFM_OK) return r;
+    afm_set_last_algo("mfma_nt_x3");
+    return AFM_OK;
+  }
+  if (d->transA && !d->transB) {   // TN: the wgrad form
+    if (d->c_dtype != AFM_F32 || d->bias || d->residual || d->pre_act || d->act != AFM_ACT_NONE || d->drop.p > 0.f ||
+        (d->a_colsum && ((uintptr_t)d->a_colsum & 3)))
+      return AFM_ERR_UNSUPPORTED;
+    if ((d->M & 7) || (d->N & 7) || (d->K & 31) || d->K < 32 || d->M < 64 || d->N < 64) return AFM_ERR_UNSUPPORTED;
+    g.tiles_m = (d->M + 255) / 256; g.tiles_n = (d->N + 127) / 128;
+    const int tiles = g.tiles_m * g.tiles_n;
+    int ksplit = tiles >= 256 ? 1 : 256 / tiles;
+    const int maxs = d->K / 512;              // >= 16 k-steps per workgroup
+    if (ksplit > maxs) ksplit = maxs;
+    if (ksplit < 1) ksplit = 1;
+    int kchunk = ((d->K / 32 + ksplit - 1) / ksplit) * 32;
+    ksplit = (d->K + kchunk - 1) / kchunk;
+    g.ksplit = ksplit; g.kchunk = kchunk;
+    if (ksplit > 1 && !d->accumulate) {
+      if (hipMemset2DAsync(d->C, sizeof(float) * d->ldc, 0, sizeof(float) * d->N, d->M, st) != hipSuccess) return AFM_ERR_LAUNCH;
+    }
+    static bool attr_done = false;
+    if (!attr_done) {
+      (void)hipFuncSetAttribute((const void*)k_x3_tn, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 64 * 384 * 2);
+      attr_done = true;
+    }
+    AFM_LAUNCH(k_x3_tn, dim3(tiles * ksplit), dim3(512), 3 * 64 * 384 * 2, st, g);
+    afm_set_last_algo(ksplit > 1 ? "mfma_tn_x3_splitk" : "mfma_tn_x3");
+    return AFM_OK;
+  }
+  return AFM_ERR_UNSUPPORTED;
+}

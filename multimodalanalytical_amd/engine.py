@@ -20,6 +20,11 @@ import torch
 from . import ops
 from .lib import ACT_GELU, ACT_GELU_BWD, ACT_GELU_SAVE_GRAD, ACT_MUL_SAVED, ACT_NONE, ACT_RELU, ALGO_AUTO
 from .params import align_dict, PATCH_TYPES, TEXT_TYPES, ParamStore, build_specs, patch_layers
+from .x2 import X2
+
+# compute dtypes: torch.float32 (exact-fp32 FMA kernels), torch.bfloat16 (one bf16 MFMA pass per product),
+# X2.dtype = "bf16x2" (split bf16 pairs, three MFMA passes per product: fp32-grade results on the matrix cores)
+BF16X3 = X2.dtype
 
 
 def sincos_table(d_model: int, max_len: int) -> torch.Tensor:
@@ -58,8 +63,11 @@ class Seq2SeqEngine:
             raise NotImplementedError("multimodal_norm=False is not on the reference's tested path")
         self.align = align_dict(self.cfg.get("align_config"))
         self.cfg["align_config"] = self.align
+        self.x3 = compute_dtype == BF16X3
+        self.lowp = compute_dtype != torch.float32          # operands are not plain fp32: MFMA kernels, transposed weight copies
+        self.branch_dtype = torch.float32 if self.x3 else None   # residual branches: fp32 out of the x3 GEMMs (same bytes as a pair)
         self.ps = ParamStore(build_specs(self.cfg, data_config, self.V), self.dev,
-                             with_bf16=compute_dtype == torch.bfloat16)
+                             with_bf16=compute_dtype == torch.bfloat16, with_x2=self.x3)
         self.ps.init_(seed)
         if self.cfg["positional_encoding_type"] == "sin_cos":
             self.pos_enc = sincos_table(self.d, self.cfg["max_position_embeddings"]).to(self.dev)
@@ -100,20 +108,24 @@ class Seq2SeqEngine:
     def refresh_shadows(self) -> None:
         """bf16 copies (and transposes, for dgrad) of the GEMM weights; call after any change to
         the fp32 parameters that did not come from `afm_adam_step` (init, load_state_dict)."""
-        if self.cd != torch.bfloat16:
+        if not self.lowp:
             return
         for name, rows, cols in self._gemm_weight_groups():
             src = self.ps.span(self.ps.flat, name, rows, cols)
-            dst = self.ps.span(self.ps.bf16, name, rows, cols)
             if name not in self.wt:
-                self.wt[name] = torch.empty(cols, rows, dtype=torch.bfloat16, device=self.dev)
-            ops.cast_bf16(src, dst, self.wt[name])
+                self.wt[name] = ops.empty(cols, rows, self.cd, self.dev)
+            if self.x3:
+                ops.cast_x2(src, self.ps.span_x2(name, rows, cols), self.wt[name])
+            else:
+                ops.cast_bf16(src, self.ps.span(self.ps.bf16, name, rows, cols), self.wt[name])
         self._refresh_kv_concat()
 
     def refresh_transposes(self) -> None:
         """After an optimiser step (which already wrote the flat bf16 shadow)."""
-        if self.cd != torch.bfloat16:
+        if not self.lowp:
             return
+        if self.x3:     # the Adam kernel writes no split-pair shadow: both copies are made here
+            return self.refresh_shadows()
         for name, rows, cols in self._gemm_weight_groups():
             ops.cast_bf16(self.ps.span(self.ps.flat, name, rows, cols), None, self.wt[name])
         self._refresh_kv_concat()
@@ -124,12 +136,19 @@ class Seq2SeqEngine:
         dK|dV of all layers instead of Ld fp32 read-modify-write passes over the (B*S x d) accumulator."""
         Ld, d = self.cfg["decoder_layers"], self.d
         if self.wt_kv_all is None:
-            self.wt_kv_all = torch.empty(d, Ld * 2 * d, dtype=torch.bfloat16, device=self.dev)
+            self.wt_kv_all = ops.empty(d, Ld * 2 * d, self.cd, self.dev)
         for i in range(Ld):
-            self.wt_kv_all[:, i * 2 * d:(i + 1) * 2 * d].copy_(self.wt[f"decoder.layers.{i}.multihead_attn.in_proj_weight"][:, d:3 * d])
+            src = self.wt[f"decoder.layers.{i}.multihead_attn.in_proj_weight"][:, d:3 * d]
+            dst = self.wt_kv_all[:, i * 2 * d:(i + 1) * 2 * d]
+            if self.x3:
+                dst.hi.copy_(src.hi); dst.lo.copy_(src.lo)
+            else:
+                dst.copy_(src)
 
     def W(self, name, rows, cols, r0=0, r1=None):
         """GEMM weight rows [r0:r1) of the (rows x cols) group at `name`, compute dtype."""
+        if self.x3:
+            return self.ps.span_x2(name, rows, cols)[r0:r1]
         buf = self.ps.bf16 if self.cd == torch.bfloat16 else self.ps.flat
         return self.ps.span(buf, name, rows, cols)[r0:r1]
 
@@ -166,7 +185,7 @@ class Seq2SeqEngine:
         return ops.drop(p, self.dropout_seed + 7919 * self.micro_step, sid)
 
     def _empty(self, rows, cols, dtype=None):
-        return torch.empty(rows, cols, dtype=dtype or self.cd, device=self.dev)
+        return ops.empty(rows, cols, dtype or self.cd, self.dev)
 
     def _linear(self, x, name, rows, cols, r0=0, r1=None, out=None, out_dtype=None, bias_name=None,
                 residual=None, dropout=ops.NO_DROP, act=ACT_NONE, pre_act=None):
@@ -187,7 +206,7 @@ class Seq2SeqEngine:
         if out is None:
             out = self._empty(dy.shape[0], cols, out_dtype)
         kw = dict(accumulate=accumulate, algo=self.algo, act=act, pre_act=pre_act, dropout=dropout)
-        if self.cd == torch.bfloat16:
+        if self.lowp:
             wt = self.wt[name][:, r0:r1]  # (cols, n): NT form for the MFMA kernel
             return ops.gemm(dy, wt, out, trans_b=True, **kw)
         w = self.W(name, rows, cols, r0, r1)
@@ -363,10 +382,12 @@ class Seq2SeqEngine:
         qkv = self._linear(h, p + "self_attn.in_proj_weight", 3 * d, d, bias_name=p + "self_attn.in_proj_bias")
         a = self._empty(B * T, d)
         lse = torch.empty(B * H * T, dtype=torch.float32, device=self.dev)
-        shp = ops.attn_shape(B, H, T, T, d // H, self.cd, 3 * d, 3 * d, 3 * d, d, key_pad, causal,
+        lq, la = ops._ld(qkv), ops._ld(a)
+        shp = ops.attn_shape(B, H, T, T, d // H, self.cd, lq, lq, lq, la, key_pad, causal,
                              self._drop(site + "attn"), self.algo)
         ops.attn_fwd(shp, qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], a, lse)
-        br = self._linear(a, p + "self_attn.out_proj.weight", d, d, bias_name=p + "self_attn.out_proj.bias")
+        br = self._linear(a, p + "self_attn.out_proj.weight", d, d, bias_name=p + "self_attn.out_proj.bias",
+                          out_dtype=self.branch_dtype)
         if saved is not None:
             saved["sa"] = (h, qkv, a, lse, shp)
         return x, (br, self._drop(site + "res"))
@@ -381,8 +402,9 @@ class Seq2SeqEngine:
         da = self._dgrad(dy, p + "self_attn.out_proj.weight", d, d)
         dqkv = self._empty(rows, 3 * d)
         delta = torch.empty_like(lse)
+        ldg = ops._ld(dqkv)
         ops.attn_bwd(shp, qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], a, da, lse, delta,
-                     dqkv[:, :d], dqkv[:, d:2 * d], dqkv[:, 2 * d:], 3 * d, 3 * d, 3 * d)
+                     dqkv[:, :d], dqkv[:, d:2 * d], dqkv[:, 2 * d:], ldg, ldg, ldg)
         self._wgrad(dqkv, h, p + "self_attn.in_proj_weight", 3 * d, d, bias_name=p + "self_attn.in_proj_bias")
         dh = self._dgrad(dqkv, p + "self_attn.in_proj_weight", 3 * d, d)
         return self._ln_bwd(dh, p + "norm1.", saved, "ln1", dres=dx1, next_site=next_site)
@@ -398,12 +420,12 @@ class Seq2SeqEngine:
         else:   # GELU + inner dropout fused into the up-projection's epilogue.  With backward pending the epilogue
             # also stores keep * scale * gelu'(u) (same keep bits), so the dgrad epilogue is one multiply.
             # (whole 256 x 256 tiles only: other shapes keep u and the GELU' epilogue)
-            sg = saved is not None and self.cd == torch.bfloat16 and x.shape[0] % 256 == 0 and f % 256 == 0
+            sg = saved is not None and self.lowp and x.shape[0] % 256 == 0 and f % 256 == 0
             uv = self._empty(x.shape[0], f) if saved is not None else None
             self._linear(h, p + "linear1.weight", f, d, out=g, bias_name=p + "linear1.bias",
                          act=ACT_GELU_SAVE_GRAD if sg else ACT_GELU, pre_act=uv, dropout=dr)
             dr = (dr, sg)
-        br = self._linear(g, p + "linear2.weight", d, f, bias_name=p + "linear2.bias")
+        br = self._linear(g, p + "linear2.weight", d, f, bias_name=p + "linear2.bias", out_dtype=self.branch_dtype)
         if saved is not None:
             saved["ffn"] = (h, uv, g, dr)
         return x, (br, self._drop(site + "res2"))
@@ -433,11 +455,11 @@ class Seq2SeqEngine:
         kv = self._linear(mem, w, 3 * d, d, d, 3 * d, bias_name=bname)
         a = self._empty(B * T, d)
         lse = torch.empty(B * H * T, dtype=torch.float32, device=self.dev)
-        shp = ops.attn_shape(B, H, T, S, d // H, self.cd, d, 2 * d, 2 * d, d, mem_pad, False,
+        shp = ops.attn_shape(B, H, T, S, d // H, self.cd, ops._ld(q), ops._ld(kv), ops._ld(kv), ops._ld(a), mem_pad, False,
                              self._drop(site + "xattn"), self.algo)
         ops.attn_fwd(shp, q, kv[:, :d], kv[:, d:], a, lse)
         br = self._linear(a, p + "multihead_attn.out_proj.weight", d, d,
-                          bias_name=p + "multihead_attn.out_proj.bias")
+                          bias_name=p + "multihead_attn.out_proj.bias", out_dtype=self.branch_dtype)
         if saved is not None:
             saved["ca"] = (h, q, kv, a, lse, shp)
         return x, (br, self._drop(site + "xres"))
@@ -450,11 +472,12 @@ class Seq2SeqEngine:
         da = self._dgrad(dy, wo, d, d)
         dq = self._empty(h.shape[0], d)
         if dkv_all is not None:     # this layer's dK | dV columns of the all-layers buffer (one dgrad at the end)
-            dkv, ldkv = dkv_all[:, layer * 2 * d:(layer + 1) * 2 * d], dkv_all.shape[1]
+            dkv = dkv_all[:, layer * 2 * d:(layer + 1) * 2 * d]
         else:
-            dkv, ldkv = self._empty(mem.shape[0], 2 * d), 2 * d
+            dkv = self._empty(mem.shape[0], 2 * d)
+        ldkv = ops._ld(dkv)
         delta = torch.empty_like(lse)
-        ops.attn_bwd(shp, q, kv[:, :d], kv[:, d:], a, da, lse, delta, dq, dkv[:, :d], dkv[:, d:], d, ldkv, ldkv)
+        ops.attn_bwd(shp, q, kv[:, :d], kv[:, d:], a, da, lse, delta, dq, dkv[:, :d], dkv[:, d:], ops._ld(dq), ldkv, ldkv)
         w, bname = p + "multihead_attn.in_proj_weight", p + "multihead_attn.in_proj_bias"
         self._wgrad(dq, h, w, 3 * d, d, 0, d, bias_name=bname)
         self._wgrad(dkv, mem, w, 3 * d, d, d, 3 * d, bias_name=bname)
@@ -508,7 +531,15 @@ class Seq2SeqEngine:
 
 
     # ------------------------------------------------------------------ incremental decode (KV cache)
-    def decode_init(self, mem: torch.Tensor, attention_mask: torch.Tensor, beams: int = 1, max_len: int = 128):
+    def _mem_rows(self, mem, B, S):
+        """Encoder memory as a (B*S, d) operand of the compute dtype."""
+        mem2 = mem if isinstance(mem, X2) else mem.reshape(B * S, self.d)
+        if mem2.dtype != self.cd:
+            src = mem2 if isinstance(mem2, X2) else mem2.contiguous()
+            mem2 = ops.convert(src, self._empty(B * S, self.d))
+        return mem2
+
+    def decode_init(self, mem, attention_mask: torch.Tensor, beams: int = 1, max_len: int = 128):
         """State for token-by-token decoding against fixed encoder memory (eval semantics): the
         cross-attention K/V of every decoder layer are projected ONCE, self-attention K/V are
         appended to a (B*beams, max_len, 2d) cache per layer -- instead of the reference's
@@ -517,16 +548,16 @@ class Seq2SeqEngine:
         d, Ld = self.d, self.cfg["decoder_layers"]
         st = {"B": B, "S": S, "k": int(beams), "Tmax": int(max_len), "t": 0,
               "mem_pad": (attention_mask == 0).to(torch.uint8).contiguous()}
-        mem2 = mem.reshape(B * S, d)
-        if mem2.dtype != self.cd:
-            mem2 = mem2.to(self.cd)
+        mem2 = self._mem_rows(mem, B, S)
         st["xkv"] = [self._linear(mem2, f"decoder.layers.{i}.multihead_attn.in_proj_weight", 3 * d, d, d, 3 * d,
                                   bias_name=f"decoder.layers.{i}.multihead_attn.in_proj_bias") for i in range(Ld)]
-        st["cache"] = [torch.zeros(B * beams, max_len, 2 * d, dtype=self.cd, device=self.dev) for _ in range(Ld)]
+        # self-attention K|V cache, one (B*beams * max_len, 2d) matrix per layer: row (b, t) = b * max_len + t
+        st["cache"] = [X2.zeros(B * beams * max_len, 2 * d, self.dev) if self.x3 else
+                       torch.zeros(B * beams * max_len, 2 * d, dtype=self.cd, device=self.dev) for _ in range(Ld)]
         st["pe"] = self._pos_rows(max_len, None).contiguous()
         return st
 
-    def decode_init_graphed(self, mem: torch.Tensor, attention_mask: torch.Tensor, max_len: int = 128):
+    def decode_init_graphed(self, mem, attention_mask: torch.Tensor, max_len: int = 128):
         """Greedy decoding with one captured HIP graph per position: a decode step is ~70 launches of a few
         microseconds each, so eager stepping is bound by the host (1.4 ms per token at B = 128); the graph of
         position t (its cache slot, positional row and key count baked in) replays as ONE launch.  The state
@@ -536,9 +567,7 @@ class Seq2SeqEngine:
         key = (B, S, int(max_len))
         st = self._graph_states.get(key)
         d, Ld = self.d, self.cfg["decoder_layers"]
-        mem2 = mem.reshape(B * S, d)
-        if mem2.dtype != self.cd:
-            mem2 = mem2.to(self.cd)
+        mem2 = self._mem_rows(mem, B, S)
         if st is None:
             st = self.decode_init(mem, attention_mask, 1, max_len)
             st["ids_static"] = torch.zeros(B, dtype=torch.int64, device=self.dev)
@@ -579,7 +608,19 @@ class Seq2SeqEngine:
 
     def decode_reorder(self, st, beam_idx: torch.Tensor) -> None:
         """Beam search bookkeeping: row r of every cache continues beam beam_idx[r]."""
-        st["cache"] = [c.index_select(0, beam_idx) for c in st["cache"]]
+        Bk, Tmax = st["B"] * st["k"], st["Tmax"]
+
+        def pick(c):    # (Bk*Tmax, w) rows regrouped per beam
+            return c.view(Bk, Tmax, -1).index_select(0, beam_idx).view(Bk * Tmax, -1)
+        if self.x3:
+            new = []
+            for c in st["cache"]:
+                n = X2.empty(Bk * Tmax, c.shape[1], self.dev)
+                n.hi.copy_(pick(c.hi)); n.lo.copy_(pick(c.lo))
+                new.append(n)
+            st["cache"] = new
+        else:
+            st["cache"] = [pick(c) for c in st["cache"]]
 
     def decode_step(self, st, ids: torch.Tensor) -> torch.Tensor:
         """Feed token ids (B*beams,) at position st['t']; returns fp32 logits (B*beams, V)."""
@@ -602,15 +643,18 @@ class Seq2SeqEngine:
             # causal self-attention over the cache: the new token sees positions 0..t
             h, x = self._ln_fwd(x, p + "norm1.", None, None, pend=pend)
             qkv = self._linear(h, p + "self_attn.in_proj_weight", 3 * d, d, bias_name=p + "self_attn.in_proj_bias")
-            cache = st["cache"][i]
-            cache[:, t, :].copy_(qkv[:, d:])
+            c2 = st["cache"][i]                      # (Bk*Tmax, 2d): append this position's K|V
+            kv_new = qkv[:, d:]
+            for dst, src in (((c2.hi, kv_new.hi), (c2.lo, kv_new.lo)) if self.x3 else ((c2, kv_new),)):
+                dst.view(Bk, Tmax, 2 * d)[:, t, :].copy_(src)
             a = self._empty(Bk, d)
             lse = torch.empty(Bk * H, dtype=torch.float32, device=self.dev)
-            shp = ops.attn_shape(Bk, H, 1, t + 1, dh, self.cd, 3 * d, 2 * d, 2 * d, d, None, False, ops.NO_DROP,
-                                 self.algo, batch_strides=(3 * d, Tmax * 2 * d, Tmax * 2 * d, d))
-            c2 = cache.view(Bk * Tmax, 2 * d)
+            lq, lc, la = ops._ld(qkv), ops._ld(c2), ops._ld(a)
+            shp = ops.attn_shape(Bk, H, 1, t + 1, dh, self.cd, lq, lc, lc, la, None, False, ops.NO_DROP,
+                                 self.algo, batch_strides=(lq, Tmax * lc, Tmax * lc, la))
             ops.attn_fwd(shp, qkv[:, :d], c2[:, :d], c2[:, d:], a, lse)
-            pend = self._linear(a, p + "self_attn.out_proj.weight", d, d, bias_name=p + "self_attn.out_proj.bias")
+            pend = self._linear(a, p + "self_attn.out_proj.weight", d, d, bias_name=p + "self_attn.out_proj.bias",
+                                out_dtype=self.branch_dtype)
             # cross-attention: the k beams of a sample are k query rows against that sample's memory
             h, x = self._ln_fwd(x, p + "norm2.", None, None, pend=pend)
             w, bname = p + "multihead_attn.in_proj_weight", p + "multihead_attn.in_proj_bias"
@@ -618,10 +662,11 @@ class Seq2SeqEngine:
             kv = st["xkv"][i]
             a = self._empty(Bk, d)
             lse = torch.empty(Bk * H, dtype=torch.float32, device=self.dev)
-            shp = ops.attn_shape(B, H, k, S, dh, self.cd, d, 2 * d, 2 * d, d, st["mem_pad"], False, ops.NO_DROP, self.algo)
+            shp = ops.attn_shape(B, H, k, S, dh, self.cd, ops._ld(q), ops._ld(kv), ops._ld(kv), ops._ld(a), st["mem_pad"],
+                                 False, ops.NO_DROP, self.algo)
             ops.attn_fwd(shp, q, kv[:, :d], kv[:, d:], a, lse)
             pend = self._linear(a, p + "multihead_attn.out_proj.weight", d, d,
-                                bias_name=p + "multihead_attn.out_proj.bias")
+                                bias_name=p + "multihead_attn.out_proj.bias", out_dtype=self.branch_dtype)
             x, pend = self._ffn_fwd(x, pend, p, self.cfg["decoder_ffn_dim"], "norm3.", None, f"d{i}")
         hf, _ = self._ln_fwd(x, "decoder.norm.", None, None, pend=pend)
         logits = self._linear(hf, "token_ff.weight", self.V, d, out_dtype=torch.float32, bias_name="token_ff.bias")
@@ -706,7 +751,9 @@ class Seq2SeqEngine:
             if backward:
                 saved["dmem_init"] = dmem0
         logits = self.decode(dec_ids, mem, mem_pad, dec_attention_mask, S, saved)
-        out = {"logits": logits.view(B, T, self.V), "encoder_hidden_states": mem.view(B, S, self.d)}
+        # (split-pair memory stays a 2-D X2 object: .float() / .cpu() materialise it on demand)
+        out = {"logits": logits.view(B, T, self.V),
+               "encoder_hidden_states": mem if isinstance(mem, X2) else mem.view(B, S, self.d)}
         rows = B * T
         if labels is not None or backward:
             lab = labels.contiguous().view(-1)
@@ -745,11 +792,11 @@ class Seq2SeqEngine:
         dx, dy = self._ln_bwd(dhf, "decoder.norm.", saved, "dec_norm", dres=None, next_site=f"d{Ld - 1}res2")
         dmem = saved.pop("dmem_init", None)     # alignment head's gradient w.r.t. the encoder output, if any
         had_init = dmem is not None
-        if dmem is None and self.cd != torch.bfloat16:
+        if dmem is None and not self.lowp:
             dmem = torch.zeros(B * S, d, dtype=torch.float32, device=self.dev)
         dkv_all = None
-        if self.cd == torch.bfloat16 and Ld > 0:
-            dkv_all = torch.empty(B * S, Ld * 2 * d, dtype=torch.bfloat16, device=self.dev)
+        if self.lowp and Ld > 0:
+            dkv_all = self._empty(B * S, Ld * 2 * d)
         for i in range(Ld - 1, -1, -1):
             p, sv = f"decoder.layers.{i}.", saved["dec_layers"][i]
             dx, dy = self._ffn_bwd(dx, dy, p, self.cfg["decoder_ffn_dim"], "norm3.", sv, f"d{i}xres")
@@ -762,7 +809,7 @@ class Seq2SeqEngine:
             ops.gemm(dkv_all, self.wt_kv_all, dmem, trans_b=True, accumulate=had_init, algo=self.algo)
         self.embed_bwd(dx, saved["emb_dec"])
         dmem_c = dmem
-        if self.cd != torch.float32:
+        if self.lowp:
             dmem_c = self._empty(B * S, d)
             ops.dropout_cast(dmem, dmem_c)
         dx, dy = self._ln_bwd(dmem_c, "encoder.norm.", saved, "enc_norm", dres=None, next_site=f"e{Le - 1}res2")

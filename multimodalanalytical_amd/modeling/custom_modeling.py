@@ -76,7 +76,9 @@ class _EncoderHandle:
         assert isinstance(inputs_embeds, DeferredEmbedding)
         mem, _ = eng.encode(inputs_embeds.token_ids, attention_mask)
         B, S = attention_mask.shape
-        return {"last_hidden_state": mem.view(B, S, eng.d), "attention_mask": attention_mask}
+        from ..x2 import X2
+        hs = mem if isinstance(mem, X2) else mem.view(B, S, eng.d)   # split-pair memory stays the engine's 2-D object
+        return {"last_hidden_state": hs, "attention_mask": attention_mask}
 
 
 class CustomModel:
@@ -122,10 +124,8 @@ class CustomModel:
         generating = isinstance(encoder_outputs, dict)
         memory, enc_inputs = None, None
         if generating:
-            hs = encoder_outputs["last_hidden_state"]
-            memory = hs.reshape(-1, eng.d)
-            if memory.dtype != eng.cd:
-                memory = memory.to(eng.cd)
+            B_, S_ = attention_mask.shape
+            memory = eng._mem_rows(encoder_outputs["last_hidden_state"], B_, S_)
         else:
             if not isinstance(inputs_embeds, DeferredEmbedding):
                 raise TypeError("inputs_embeds must come from this model's MultimodalEmbedding")

@@ -157,10 +157,10 @@ def layernorm_fwd(x, gamma, beta, y, mean=None, rstd=None, pos=None, seg_len=0, 
                   out_off=0, eps=1e-5, add=None, x_sum=None, add_dropout: Dropout = NO_DROP):
     """y = LN(x [+ dropout(add)]); with `add` the summed stream is also written to x_sum (fp32, may be x)."""
     rows, d = x.shape
-    assert x.dtype == torch.float32 and x.is_contiguous()
+    assert x.dtype == torch.float32 and x.is_contiguous() and is_contig(y)
     s = ln_shape(rows, d, y.dtype, seg_len, out_seg_stride, out_off, eps)
     if add is not None:
-        assert add.shape == x.shape and add.is_contiguous() and x_sum is not None and x_sum.dtype == torch.float32
+        assert add.shape == x.shape and is_contig(add) and x_sum is not None and x_sum.dtype == torch.float32
         s.add_dtype = _dt(add)
         s.add_drop = add_dropout
     L.check(L.load().afm_layernorm_fwd(C.byref(s), _ptr(x), _ptr(gamma), _ptr(beta), _ptr(pos), _ptr(y),
@@ -180,7 +180,7 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, ws, dres=None, se
     s = ln_shape(rows, d, dy.dtype, seg_len, out_seg_stride, out_off)
     assert ws.numel() >= layernorm_bwd_ws(rows, d)
     if dx_drop is not None:
-        assert dx_drop.dtype == dy.dtype and dx_drop.shape == x.shape and dx_drop.is_contiguous()
+        assert dx_drop.dtype == dy.dtype and dx_drop.shape == x.shape and is_contig(dx_drop) and is_contig(dy)
     L.check(L.load().afm_layernorm_bwd(C.byref(s), _ptr(dy), _ptr(x), _ptr(gamma), _ptr(mean), _ptr(rstd),
                                        _ptr(dres), _ptr(dx), _ptr(dgamma), _ptr(dbeta), _ptr(ws),
                                        _ptr(dx_drop), C.byref(dropout), _stream()),
@@ -299,7 +299,7 @@ ALIGN_KINDS = {"mse": 0, "mae": 1, "sid": 2}
 def masked_mean_fwd(x, key_pad, B, S, out):
     """out (B, d) fp32 = mean over the kept rows of x (B*S, d); key_pad (B, S) uint8, 1 = pad."""
     d = x.shape[-1]
-    assert x.is_contiguous() and key_pad.dtype == torch.uint8 and out.dtype == torch.float32
+    assert is_contig(x) and key_pad.dtype == torch.uint8 and out.dtype == torch.float32
     L.check(L.load().afm_masked_mean_fwd(_ptr(x), _dt(x), _ptr(key_pad), B, S, d, _ptr(out), _stream()), "afm_masked_mean_fwd")
 
 

@@ -136,7 +136,7 @@ def align_dict(ac):
 
 
 class ParamStore:
-    def __init__(self, specs: List[Spec], device, with_bf16: bool):
+    def __init__(self, specs: List[Spec], device, with_bf16: bool, with_x2: bool = False):
         off = 0
         self.specs: "OrderedDict[str, Spec]" = OrderedDict()
         for s in specs:
@@ -150,6 +150,9 @@ class ParamStore:
         self.exp_avg = torch.zeros(off, dtype=torch.float32, device=device)
         self.exp_avg_sq = torch.zeros(off, dtype=torch.float32, device=device)
         self.bf16 = torch.zeros(off, dtype=torch.bfloat16, device=device) if with_bf16 else None
+        # split-pair shadow of the GEMM weights (bf16x3 mode): the (rows x cols) matrix at flat offset o lives at
+        # [2 o, 2 o + 2 rows cols) as rows of [hi(cols) | lo(cols)]
+        self.x2buf = torch.zeros(2 * off, dtype=torch.bfloat16, device=device) if with_x2 else None
         self.num_params = sum(s.numel for s in specs)
         self._span_ok = set()
 
@@ -172,6 +175,14 @@ class ParamStore:
         s = self.specs[first]
         self._check_span(first, rows * cols)
         return buf[s.offset:s.offset + rows * cols].view(rows, cols)
+
+    def span_x2(self, first: str, rows: int, cols: int):
+        """Split-pair (rows x cols) weight view starting at `first` (see x2buf)."""
+        from .x2 import X2
+        s = self.specs[first]
+        self._check_span(first, rows * cols)
+        phys = self.x2buf[2 * s.offset:2 * s.offset + 2 * rows * cols].view(rows, 2 * cols)
+        return X2(phys[:, :cols], 2 * cols)
 
     def vec_span(self, buf, first: str, i0: int, i1: int):
         """Elements [i0, i1) of the vector starting at `first` (may run into adjacent tensors: packed biases)."""

@@ -65,6 +65,16 @@ class X2:
     def float(self) -> torch.Tensor:
         return self.hi.float() + self.lo.float()
 
+    def cpu(self) -> torch.Tensor:
+        return self.float().cpu()
+
+    def view(self, *shape) -> torch.Tensor:
+        """fp32 materialisation viewed as `shape` (reporting / tests: e.g. (B, S, d) encoder states)."""
+        return self.float().view(*shape)
+
+    def reshape(self, *shape) -> torch.Tensor:
+        return self.float().reshape(*shape)
+
     def __getitem__(self, idx) -> "X2":
         """Row / column slices (step 1) keep the row stride, hence the lo-plane offset."""
         if not isinstance(idx, tuple):

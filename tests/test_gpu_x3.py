@@ -1,0 +1,182 @@
+"""GPU: the split-pair ("bf16x3") kernels through the C ABI against fp64 references: storage round trip,
+NT / TN GEMMs with every fused epilogue, flash attention forward / backward with masks and dropout.
+Bars are fp32-GEMM grade (1e-5 relative to the operand scale), two to three orders below the single-pass bf16
+kernels' 2e-2."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from tests.dropmask import keep_mask, keep_mask16  # noqa: E402
+from tests.test_gpu_ops import _attn_case, _attn_ref, dev, rnd  # noqa: E402
+
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def ops():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from multimodalanalytical_amd import ops as _ops
+    return _ops
+
+
+def x2(t):
+    from multimodalanalytical_amd.x2 import X2
+    return X2.from_float(t.to(DEV))
+
+
+def relnorm(got, ref):
+    return float((got.double().cpu() - ref.double()).norm() / (ref.double().norm() + 1e-300))
+
+
+def test_split_pair_storage_roundtrip(ops):
+    from multimodalanalytical_amd.x2 import X2
+    x = rnd(300, 72, seed=1) * torch.logspace(-6, 3, 72)
+    xd = x.to(DEV)
+    p = ops.convert(xd, X2.empty(300, 72, DEV))
+    assert relnorm(p.float(), x) < 2e-5 and float((p.float().cpu() - x).abs().max() / x.abs().max()) < 1e-5
+    assert torch.equal(p.hi, xd.to(torch.bfloat16))                       # hi plane = plain bf16 rounding
+    back = ops.convert(p, torch.empty(300, 72, device=DEV))
+    assert torch.equal(back, p.float())
+    host = X2.from_float(xd)                                                # host-side split = device split
+    assert torch.equal(host.hi, p.hi) and torch.equal(host.lo, p.lo)
+    sl = p[:, 8:40]                                                         # column slice keeps the lo offset
+    assert torch.equal(ops.convert(sl, torch.empty(300, 32, device=DEV)), p.float()[:, 8:40])
+    w = rnd(96, 40, seed=2).to(DEV)
+    d, dt = X2.empty(96, 40, DEV), X2.empty(40, 96, DEV)
+    ops.cast_x2(w, d, dt)
+    assert torch.equal(d.float(), X2.from_float(w).float()) and torch.equal(dt.float(), d.float().T)
+
+
+@pytest.mark.parametrize("M,N,K", [(512, 256, 512), (1000, 1536, 512), (300, 136, 2048), (129, 24, 64), (2048, 128, 96)])
+@pytest.mark.parametrize("out", ["x2", "f32"])
+def test_gemm_x3_nt_plain(ops, M, N, K, out):
+    from multimodalanalytical_amd.x2 import X2
+    a, w, bias = rnd(M, K, seed=1), rnd(N, K, seed=2), rnd(N, seed=3)
+    ref = a.double() @ w.double().T + bias.double()
+    c = X2.empty(M, N, DEV) if out == "x2" else torch.empty(M, N, device=DEV)
+    ops.gemm(x2(a), x2(w), c, bias=dev(bias), algo=2)
+    assert ops.last_algo() == "mfma_nt_x3"
+    got = c.float()
+    assert float((got.cpu().double() - ref).abs().max()) < 2e-5 * math.sqrt(K) * 4, (M, N, K)
+    assert relnorm(got, ref) < 1e-5
+    if out == "f32":   # residual + accumulate forms of the fp32 epilogue
+        res = rnd(M, N, seed=5)
+        c2 = dev(rnd(M, N, seed=6))
+        base = c2.clone().cpu()
+        ops.gemm(x2(a), x2(w), c2, bias=dev(bias), residual=dev(res), accumulate=True, algo=2)
+        assert relnorm(c2, ref + res.double() + base.double()) < 1e-5
+
+
+@pytest.mark.parametrize("M,N", [(512, 256), (300, 136)])
+def test_gemm_x3_nt_fused_epilogues(ops, M, N):
+    """GELU (+ pre-activation), GELU + dropout with the stored gradient factor, multiply-by-stored, dropout * GELU'."""
+    from multimodalanalytical_amd.x2 import X2
+    from oracle import afm_oracle as O
+    K = 256
+    a, w, bias = rnd(M, K, seed=1) * 0.2, rnd(N, K, seed=2) * 0.2, rnd(N, seed=3)
+    t = a.double() @ w.double().T + bias.double()
+    p, seed, site = 0.1, 99, 5
+    keep = torch.from_numpy(keep_mask(p, seed, site, M * N)).view(M, N).double() / (1 - p)
+    gelu = O.gelu(t)
+    gp = 0.5 * (1 + torch.erf(t / math.sqrt(2))) + t * torch.exp(-t * t / 2) / math.sqrt(2 * math.pi)
+    A, W = x2(a), x2(w)
+    # ACT_GELU with the pre-activation kept
+    c, pre = X2.empty(M, N, DEV), X2.empty(M, N, DEV)
+    ops.gemm(A, W, c, bias=dev(bias), act=2, pre_act=pre, dropout=ops.drop(p, seed, site), algo=2)
+    assert relnorm(pre.float(), t) < 1e-5 and relnorm(c.float(), gelu * keep) < 2e-5
+    # ACT_GELU_SAVE_GRAD: C = dropout(gelu), pre_act = keep * scale * gelu'
+    c2, sg = X2.empty(M, N, DEV), X2.empty(M, N, DEV)
+    ops.gemm(A, W, c2, bias=dev(bias), act=4, pre_act=sg, dropout=ops.drop(p, seed, site), algo=2)
+    assert relnorm(c2.float(), gelu * keep) < 2e-5 and relnorm(sg.float(), gp * keep) < 2e-5
+    # the dgrad partners on a second GEMM:  dy (M x K2) @ W2 (N x K2)^T
+    K2 = 128
+    dy, w2 = rnd(M, K2, seed=7), rnd(N, K2, seed=8) * 0.3
+    g = dy.double() @ w2.double().T
+    c3 = X2.empty(M, N, DEV)
+    ops.gemm(x2(dy), x2(w2), c3, act=5, pre_act=sg, algo=2)                     # ACT_MUL_SAVED
+    assert relnorm(c3.float(), g * gp * keep) < 3e-5
+    c4 = X2.empty(M, N, DEV)
+    ops.gemm(x2(dy), x2(w2), c4, act=3, pre_act=pre, dropout=ops.drop(p, seed, site), algo=2)   # ACT_GELU_BWD
+    assert relnorm(c4.float(), g * keep * gp) < 3e-5
+    assert ops.last_algo() == "mfma_nt_x3"
+
+
+@pytest.mark.parametrize("R,M,N", [(4096, 512, 512), (8192, 1536, 512), (2048, 64, 128), (256, 512, 2048), (1056, 200, 136)])
+def test_gemm_x3_tn_wgrad(ops, R, M, N):
+    dy, x = rnd(R, M, seed=1), rnd(R, N, seed=2)
+    gw = dev(rnd(M, N, seed=3))
+    gb = dev(rnd(M, seed=4))
+    ref = gw.cpu().double() + dy.double().T @ x.double()
+    refb = gb.cpu().double() + dy.double().sum(0)
+    ops.gemm(x2(dy), x2(x), gw, trans_a=True, trans_b=False, accumulate=True, a_colsum=gb, algo=2)
+    assert ops.last_algo().startswith("mfma_tn_x3")
+    assert relnorm(gw, ref) < 1e-5 and relnorm(gb, refb) < 1e-5
+    g2 = torch.empty(M, N, device=DEV)
+    ops.gemm(x2(dy), x2(x), g2, trans_a=True, trans_b=False, accumulate=False, algo=2)
+    assert relnorm(g2, dy.double().T @ x.double()) < 1e-5
+
+
+def test_gemm_x3_falls_back_to_exact_kernel_on_odd_shapes(ops):
+    from multimodalanalytical_amd.x2 import X2
+    a, w = rnd(37, 75, seed=1), rnd(26, 75, seed=2)
+    c = X2.empty(37, 26, DEV)
+    ops.gemm(x2(a), x2(w), c)
+    assert ops.last_algo().startswith("generic")
+    assert relnorm(c.float(), a.double() @ w.double().T) < 1e-5
+
+
+@pytest.mark.parametrize("B,H,Tq,Tk,causal,pad,pdrop", [
+    (2, 2, 128, 128, True, True, 0.0), (2, 3, 100, 200, False, True, 0.0), (1, 2, 300, 300, False, False, 0.0),
+    (1, 2, 192, 192, True, False, 0.0), (2, 2, 128, 256, False, True, 0.1), (1, 2, 160, 160, True, True, 0.1),
+    (2, 2, 130, 520, False, "blocks", 0.1)])
+def test_attention_x3(ops, B, H, Tq, Tk, causal, pad, pdrop):
+    from multimodalanalytical_amd.x2 import X2
+    dh = 64
+    q, k, v, key_pad = _attn_case(B, H, Tq, Tk, dh, causal, bool(pad), seed=10)
+    if pad == "blocks":
+        key_pad = torch.zeros(B, Tk, dtype=torch.bool)
+        key_pad[0, 64:192] = True; key_pad[0, 300:] = True
+        key_pad[1, 128:160] = True; key_pad[1, 448:512] = True
+    D = H * dh
+    # packed (rows, 3D) projection for self-attention shapes, separate tensors otherwise: both stride forms
+    if Tq == Tk:
+        qkv = x2(torch.cat([t.reshape(-1, D) for t in (q, k, v)], 1))
+        qd, kd, vd = qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:]
+    else:
+        qd, kd, vd = (x2(t.reshape(-1, D)) for t in (q, k, v))
+    q, k, v = (t.float().cpu().view(B, -1, H, dh) for t in (qd, kd, vd))       # what the kernel really sees
+    kp = None if key_pad is None else dev(key_pad.to(torch.uint8))
+    seed, site = 4242, 3
+    keep, dscale = None, 1.0
+    if pdrop > 0:
+        km, dscale = keep_mask16(pdrop, seed, site, B * H * Tq * Tk)
+        keep = torch.from_numpy(km).view(B, H, Tq, Tk)
+    o, lse = X2.empty(B * Tq, D, DEV), torch.empty(B * H * Tq, device=DEV)
+    shp = ops.attn_shape(B, H, Tq, Tk, dh, X2.dtype, ops._ld(qd), ops._ld(kd), ops._ld(vd), ops._ld(o), kp, causal,
+                         ops.drop(pdrop, seed, site), algo=2)
+    ops.attn_fwd(shp, qd, kd, vd, o, lse)
+    assert ops.last_algo() == "attn_mfma_x3"
+    qr, kr, vr, ref = _attn_ref(q, k, v, key_pad, causal, keep, dscale)
+    ref_o = ref.transpose(1, 2).reshape(B * Tq, D)
+    assert relnorm(o.float(), ref_o.detach()) < 2e-5
+    assert float((o.float().cpu().double() - ref_o.detach()).abs().max()) < 5e-5 * float(ref_o.abs().max())
+    # generic kernel on the same split operands: identical lse up to fp32 rounding
+    o1, lse1 = X2.empty(B * Tq, D, DEV), torch.empty_like(lse)
+    shp1 = ops.attn_shape(B, H, Tq, Tk, dh, X2.dtype, ops._ld(qd), ops._ld(kd), ops._ld(vd), ops._ld(o1), kp, causal,
+                          ops.drop(pdrop, seed, site), algo=1)
+    ops.attn_fwd(shp1, qd, kd, vd, o1, lse1)
+    assert ops.last_algo() == "attn_generic"
+    torch.testing.assert_close(lse, lse1, rtol=1e-5, atol=1e-5)
+    assert relnorm(o1.float(), ref_o.detach()) < 2e-5
+    do = x2(rnd(B * Tq, D, seed=9))
+    ref.backward(do.float().cpu().double().view(B, Tq, H, dh).transpose(1, 2))
+    dq, dk, dv = (X2.empty(n, D, DEV) for n in (B * Tq, B * Tk, B * Tk))
+    ops.attn_bwd(shp, qd, kd, vd, o, do, lse, torch.empty_like(lse), dq, dk, dv, ops._ld(dq), ops._ld(dk), ops._ld(dv))
+    assert ops.last_algo() == "attn_mfma_x3"
+    for name, got, r, T in (("dq", dq, qr, Tq), ("dk", dk, kr, Tk), ("dv", dv, vr, Tk)):
+        want = r.grad.transpose(1, 2).reshape(B * T, D)
+        assert relnorm(got.float(), want) < 5e-5, (name, relnorm(got.float(), want))
