@@ -7,9 +7,11 @@ Bars (max |logit - ref| / max |ref|; gradients by relative norm per parameter te
   bf16x3  split bf16 pairs, 3 MFMAs / product    logits 1e-3 (north star), ids bit-exact under the margin
           policy below, grads 5e-3
   bf16    single bf16 MFMA pass                  logits 3e-2, ids exact outside twice the measured error, grads 8e-2
-Margin policy for "bit-exact argmax": a position whose two largest REFERENCE logits are closer than
-2 * 1e-3 * max|logit| cannot be decided by any arithmetic that is only 1e-3-close; there the id must be one of
-those two.  Everywhere else ids must be equal.  (fp32 mode is held to plain equality.)
+Margin policy for "bit-exact argmax": a position whose two largest REFERENCE logits are closer than twice the
+MEASURED maximum logit error cannot be decided by the arithmetic under test (nor by the reference run on another
+BLAS); there the id must be one of those two.  Everywhere else ids must be equal.  bf16x3 measures ~1e-5, so
+at most a handful of exact near-ties are undecidable (>= 99.9 % of the positions must be decidable); fp32 mode
+is held to plain equality.
 """
 import functools
 
@@ -90,12 +92,12 @@ def test_shape_parity_forward_backward_vs_oracle(name, mode):
     if mode == "fp32":
         assert torch.equal(ids, rid)
     else:
-        band = 2e-3 * scale if mode == "bf16x3" else 2 * err * scale
+        band = 2 * err * scale
         sure = margin > band
         assert torch.equal(ids[sure], rid[sure]), (name, mode)
         unsure = ~sure
         assert bool(((ids == top2.indices[..., 0]) | (ids == top2.indices[..., 1]))[unsure].all())
-        assert float(sure.double().mean()) > (0.99 if mode == "bf16x3" else 0.5)
+        assert float(sure.double().mean()) > (0.999 if mode == "bf16x3" else 0.5)
     ltol = {"fp32": 1e-5, "bf16x3": 1e-4, "bf16": 2e-2}[mode]
     torch.testing.assert_close(out["loss"].cpu(), ref["loss"], rtol=ltol, atol=ltol)
     gtol = {"fp32": 2e-3, "bf16x3": 5e-3, "bf16": 8e-2}[mode]
@@ -110,4 +112,5 @@ def test_shape_parity_forward_backward_vs_oracle(name, mode):
         if e > gtol * float(g.norm()) + 1e-5 * gtol * gmax:
             bad.append((k, e / (float(g.norm()) + 1e-30)))
     assert not bad, (name, mode, bad[:8], len(bad))
-    print(f"{name} {mode}: logits rel err {err:.2e}, undecidable ids {int((margin <= 2e-3 * scale).sum())}")
+    print(f"{name} {mode}: logits rel err {err:.2e}, ids equal {bool(torch.equal(ids, rid))}, "
+          f"undecidable positions {int((margin <= 2 * err * scale).sum())} of {margin.numel()}")
