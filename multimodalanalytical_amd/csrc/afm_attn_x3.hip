@@ -528,9 +528,12 @@ int afm_attn_bwd_x3_try(const afm_attn_shape* s, const void* Q, const void* K, c
     (void)hipFuncSetAttribute((const void*)k_attn_bwd_dkv_x3<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
     attr = true;
   }
-  if (a.dd.thresh16) AFM_LAUNCH(k_attn_bwd_dq_x3<true>, gq, dim3(256), shm_q, st, a, (const bf16*)Q, (const bf16*)K, (const bf16*)V, (const bf16*)O, (const bf16*)dO, lse, delta, (bf16*)dQ);
+  const bool run_q = s->reserved != 2, run_k = s->reserved != 1;   // reserved = 1 / 2: only the dQ / only the dK-dV kernel (timing)
+  if (!run_q) {}
+  else if (a.dd.thresh16) AFM_LAUNCH(k_attn_bwd_dq_x3<true>, gq, dim3(256), shm_q, st, a, (const bf16*)Q, (const bf16*)K, (const bf16*)V, (const bf16*)O, (const bf16*)dO, lse, delta, (bf16*)dQ);
   else AFM_LAUNCH(k_attn_bwd_dq_x3<false>, gq, dim3(256), shm_q, st, a, (const bf16*)Q, (const bf16*)K, (const bf16*)V, (const bf16*)O, (const bf16*)dO, lse, delta, (bf16*)dQ);
-  if (a.dd.thresh16) AFM_LAUNCH(k_attn_bwd_dkv_x3<true>, gk, dim3(256), shm_k, st, a, (const bf16*)Q, (const bf16*)K, (const bf16*)V, (const bf16*)dO, lse, delta, (bf16*)dK, (bf16*)dV);
+  if (!run_k) {}
+  else if (a.dd.thresh16) AFM_LAUNCH(k_attn_bwd_dkv_x3<true>, gk, dim3(256), shm_k, st, a, (const bf16*)Q, (const bf16*)K, (const bf16*)V, (const bf16*)dO, lse, delta, (bf16*)dK, (bf16*)dV);
   else AFM_LAUNCH(k_attn_bwd_dkv_x3<false>, gk, dim3(256), shm_k, st, a, (const bf16*)Q, (const bf16*)K, (const bf16*)V, (const bf16*)dO, lse, delta, (bf16*)dK, (bf16*)dV);
   afm_set_last_algo("attn_mfma_x3");
   return AFM_OK;

@@ -119,3 +119,24 @@ def test_patch_preprocessor_oracle_matches_reference_bit_exact():
                                   kw["masking"], kw["interpolation"], kw.get("overlap", 1), kw.get("derivative", False))
         assert p.dtype == np.float32 and np.array_equal(p, g[f"{name}/patches"]), name
         assert np.array_equal(m, g[f"{name}/mask"]), name
+
+
+def test_stock_torch_wiring_equals_oracle_and_reference_golden():
+    """oracle/stock_torch.py (nn.TransformerEncoder / Decoder as the reference wires them, SURVEY 8c item 2: the
+    timed "reference PyTorch CPU path" of bench.py) reproduces the reference's own logits / loss / gradients."""
+    from oracle import stock_torch as ST
+    t = G.load("model_plain"); cfg = dict(G.model_cfg(t["meta"]), dropout=0.0)
+    dc = t["meta"]["data_config"]
+    m = ST.StockSeq2Seq(cfg, dc["Smiles"]["vocab_size"])
+    m.load_oracle_state(t["sd"])
+    m.train()
+    enc, am, dec, dm, labels = O.batch_to_model_inputs(G.batch_of(t, 0), "Smiles")
+    x_enc, x_dec = ST.embed_inputs(t["sd"], cfg, dc, "Smiles", enc, dec)
+    logits, loss = m(x_enc, am, x_dec, dm, labels)
+    ref = t["b0"]
+    torch.testing.assert_close(logits, ref["logits"], rtol=1e-4, atol=2e-5)
+    torch.testing.assert_close(loss, ref["loss"], rtol=1e-5, atol=1e-5)
+    loss.backward()
+    for k in ("encoder.layers.0.linear1.weight", "decoder.layers.1.multihead_attn.out_proj.weight", "token_ff.weight"):
+        g = dict(m.named_parameters())[k].grad
+        torch.testing.assert_close(g, t["grad0"][k], rtol=2e-4, atol=2e-6, msg=lambda s: f"{k}: {s}")
