@@ -1,0 +1,279 @@
+"""Config-driven training entry: the surface of the reference's `cli/training.py` (reference cli/training.py:44-254)
+on the HIP path.
+
+    python -m multimodalanalytical_amd.cli.training working_dir=runs job_name=train data=ir/patches \
+        data_path=<shard dir> model=custom_model trainer.epochs=1            # same key=value grammar as the reference
+
+    compose(configs/config_train.yaml + overrides)  ->  data_config / model_config / trainer settings
+    -> PatchPreprocessor statistics from the train shard, DeviceCollator            (reference: load_preprocessors,
+    -> calculate_training_steps -> HFWrapper(data_config, target_tokenizer, num_steps,     MultiModalDataModule)
+                                             modality_dropout, **model_config)
+    -> TrainLoop (accumulate / clip / AdamW + OneCycle, RCCL data parallel when launched with torch.distributed.run)
+    -> validation every epoch, last.ckpt + top-5 checkpoints by `trainer.checkpoint_monitor`, best.ckpt
+    -> reload best, predict the test shard with beam search, metrics_beam_{n}_{rank}.json (Top-k exact-sequence accuracy)
+
+What is NOT here (out of scope): parquet ETL, tokenizer training, RDKit canonicalisation.  `data_path`
+therefore points at PRE-TOKENISED shards, `{train,val,test}.pt`, each `{"meta": {modality: {"vocab_size", "pad_token_id"}},
+"data": {modality: {"input_ids", "attention_mask"} | {"spectra"[, "present"]}}}` (text-like modalities as padded id
+matrices, patch modalities as raw spectra; `multimodalanalytical_amd.synth.write_shards` writes synthetic ones), or
+`data_path=synthetic:<n_train>` to generate them on the fly from the composed data config.
+Like the reference the run is wrapped in one try/except that logs and returns 0 unless `strict=1` is passed.
+"""
+from __future__ import annotations
+
+import json
+import math
+import os
+import shutil
+import sys
+import traceback
+from typing import Any, Dict, List, Optional
+
+import torch
+
+from ..config import compose, wrapper_kwargs
+from ..params import PATCH_TYPES, TEXT_TYPES
+from ..trainer import calculate_training_steps
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+DEFAULT_CONFIG_DIR = os.path.join(os.path.dirname(os.path.dirname(HERE)), "configs")
+
+
+def split_cli(argv: List[str]):
+    """Pseudo-overrides consumed here (not part of the Hydra tree): config_dir=, config_name=, strict=, precision=, device=."""
+    own, rest = {}, []
+    for a in argv:
+        k, _, v = a.partition("=")
+        if k in ("config_dir", "config_name", "strict", "precision", "device", "max_steps"):
+            own[k] = v
+        else:
+            rest.append(a)
+    return own, rest
+
+
+def build_plan(cfg: Dict[str, Any], shard_meta: Dict[str, Dict[str, Any]], n_train: int, world_size: int = 1,
+               legacy_step_count: bool = False) -> Dict[str, Any]:
+    """Everything the run needs that does not touch the GPU: the model's data_config (config group `data` + the vocab
+    sizes / pad ids only the tokenised data knows), HFWrapper keywords, optimiser-step count, output paths."""
+    data_config: Dict[str, Any] = {}
+    target = None
+    for m, mc in cfg["data"].items():
+        mc = dict(mc)
+        if mc["type"] in TEXT_TYPES:
+            if m not in shard_meta:
+                raise KeyError(f"modality {m!r} of the data config is missing from the shards")
+            mc["vocab_size"] = int(shard_meta[m]["vocab_size"])
+            mc["pad_token_id"] = int(shard_meta[m].get("pad_token_id", 0))
+        elif mc["type"] not in PATCH_TYPES:
+            raise NotImplementedError(f"modality type {mc['type']!r}")
+        if mc.get("target"):
+            target = m
+        data_config[m] = mc
+    if target is None:
+        raise ValueError("no target modality in the data config")
+    model_cfg = wrapper_kwargs(cfg)
+    tr = cfg["trainer"]
+    steps = calculate_training_steps(n_train, model_cfg["batch_size"], tr["acc_batches"], tr["epochs"],
+                                     1 if legacy_step_count else world_size)   # reference utils.py:164-167 hard-codes 1 GPU
+    run_dir = os.path.join(str(cfg["working_dir"]), str(cfg["job_name"]))
+    return {"data_config": data_config, "target_modality": target, "model_config": model_cfg, "train_steps": steps,
+            "modality_dropout": cfg.get("modality_dropout"), "run_dir": run_dir,
+            "n_beams": model_cfg.get("n_beams", 10), "monitor": tr["checkpoint_monitor"],
+            "monitor_mode": "min" if "loss" in tr["checkpoint_monitor"] else "max",          # trainer/trainer.py:34
+            "acc_batches": tr["acc_batches"], "clip_grad": tr["clip_grad"], "epochs": tr["epochs"],
+            "limit_val_batches": tr.get("limit_val_batches", 1.0), "early_stopping_patience": tr.get("early_stopping_patience")}
+
+
+# ------------------------------------------------------------------------------------------------ shards
+def load_shards(data_path: str, cfg: Dict[str, Any], device: str):
+    if str(data_path).startswith("synthetic:"):
+        from ..synth import synth_shards
+        n = int(str(data_path).split(":", 1)[1])
+        return synth_shards(cfg["data"], n, max(8, n // 8), max(8, n // 8), seed=3247)
+    out = {}
+    for split in ("train", "val", "test"):
+        p = os.path.join(data_path, split + ".pt")
+        if os.path.exists(p):
+            out[split] = torch.load(p, map_location="cpu", weights_only=False)
+    if "train" not in out:
+        raise FileNotFoundError(f"{data_path}/train.pt not found (pre-tokenised shards, see the module docstring)")
+    return out
+
+
+def shard_len(shard) -> int:
+    first = next(iter(shard["data"].values()))
+    return int((first["input_ids"] if "input_ids" in first else first["spectra"]).shape[0])
+
+
+class ShardLoader:
+    """Rank-strided, seeded-permutation batches of one shard, collated on the device (DistributedSampler semantics:
+    every rank sees a disjoint 1/world of each epoch; the tail that does not fill a batch on every rank is dropped for
+    training so all ranks take the same number of optimiser steps)."""
+
+    def __init__(self, shard, collator, batch_size: int, device: str, rank: int = 0, world: int = 1, shuffle: bool = True,
+                 drop_last: bool = True):
+        self.shard, self.collator, self.bs, self.dev = shard, collator, int(batch_size), device
+        self.rank, self.world, self.shuffle, self.drop_last = rank, world, shuffle, drop_last
+        self.n = shard_len(shard)
+        self.dev_data = {m: {k: v.to(device) for k, v in d.items()} for m, d in shard["data"].items()}   # resident in HBM
+
+    def __len__(self):
+        per_rank = self.n // self.world
+        return per_rank // self.bs if self.drop_last else math.ceil(per_rank / self.bs)
+
+    def epoch(self, epoch: int):
+        g = torch.Generator().manual_seed(3247 + epoch)
+        order = torch.randperm(self.n, generator=g) if self.shuffle else torch.arange(self.n)
+        order = order[:(self.n // self.world) * self.world][self.rank::self.world].to(self.dev)
+        for i in range(len(self)):
+            idx = order[i * self.bs:(i + 1) * self.bs]
+            yield self.collator({m: {k: v.index_select(0, idx) for k, v in d.items()} for m, d in self.dev_data.items()})
+
+
+def build_preprocessors(train_shard, data_config, device):
+    """`load_preprocessors` for the patch modalities (reference data/data_utils.py -> PatchPreprocessor.initialise):
+    statistics over the non-zero entries of (a sample of) the training spectra."""
+    from ..preprocess import PatchPreprocessor
+    pre = {}
+    for m, mc in data_config.items():
+        if mc["type"] == "1D_patches":
+            a = mc.get("preprocessor_arguments") or {}
+            pp = PatchPreprocessor(patch_size=int(a["patch_size"]), masking=bool(a.get("masking", False)),
+                                   interpolation=bool(a.get("interpolation", False)), overlap=int(a.get("overlap", 1)),
+                                   derivative=bool(a.get("derivative", False)), device=device)
+            sample = train_shard["data"][m]["spectra"][:10000]
+            pp.initialise({m: sample.numpy()}, m)
+            pre[m] = pp
+    return pre
+
+
+# ------------------------------------------------------------------------------------------------ run
+def topk_sequence_accuracy(model, predictions: torch.Tensor, targets: torch.Tensor, n_beams: int) -> Dict[str, float]:
+    """`calc_sampling_metrics(..., molecules=False)` on token ids: Top-k = a target equals one of the first k beams."""
+    B = targets.shape[0]
+    hit_at = torch.full((B,), n_beams, dtype=torch.long)
+    for k in range(n_beams):
+        rows = predictions.view(B, n_beams, -1)[:, k]
+        same = torch.stack([model.sequence_accuracy(rows[i:i + 1], targets[i:i + 1])[0] for i in range(B)]).cpu() > 0.5
+        hit_at = torch.where(same & (hit_at == n_beams), torch.full_like(hit_at, k), hit_at)
+    return {f"Top-{k + 1}": float((hit_at <= k).float().mean()) for k in range(n_beams)}
+
+
+def run(cfg: Dict[str, Any], own: Dict[str, str]) -> Dict[str, Any]:
+    import torch.distributed as dist
+    from ..modeling.wrapper import HFWrapper, SimpleTokenizerInfo
+    from ..preprocess import DeviceCollator
+    from ..trainer import TrainLoop, load_checkpoint, save_checkpoint
+    from ..x2 import X2
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    device = own.get("device", f"cuda:{local}")
+    torch.cuda.set_device(device)
+    if world > 1 and not dist.is_initialized():
+        dist.init_process_group("nccl", device_id=torch.device(device))
+    shards = load_shards(cfg["data_path"], cfg, device)
+    meta = shards["train"]["meta"]
+    plan = build_plan(cfg, meta, shard_len(shards["train"]), world, bool(cfg["trainer"].get("legacy_step_count", False)))
+    os.makedirs(plan["run_dir"], exist_ok=True)
+    dc, tm = plan["data_config"], plan["target_modality"]
+    pre = build_preprocessors(shards["train"], dc, device)
+    collator = DeviceCollator(dc, pre, tm)
+    tok = SimpleTokenizerInfo(dc[tm]["vocab_size"], pad_token_id=dc[tm]["pad_token_id"])
+    precision = own.get("precision", "bf16x3")
+    cd = {"bf16x3": X2.dtype, "bf16": torch.bfloat16, "fp32": torch.float32}[precision]
+    mk = {k: v for k, v in plan["model_config"].items() if k != "multimodal_norm"}
+    bs = int(mk["batch_size"])
+
+    def new_model():
+        return HFWrapper(dc, target_tokenizer=tok, num_steps=plan["train_steps"], modality_dropout=plan["modality_dropout"],
+                         multimodal_norm=plan["model_config"].get("multimodal_norm", True), clip_grad=plan["clip_grad"],
+                         world_size=world, device=device, compute_dtype=cd, **mk)
+    model = new_model()
+    loop = TrainLoop(model, acc_batches=plan["acc_batches"], world_size=world)
+    if mk.get("model_checkpoint_path"):
+        load_checkpoint(mk["model_checkpoint_path"], model, None if cfg.get("finetuning") else loop)
+    train = ShardLoader(shards["train"], collator, bs, device, rank, world, shuffle=True)
+    val = ShardLoader(shards.get("val", shards["train"]), collator, bs, device, rank, world, shuffle=False, drop_last=False)
+    ckpt_dir = os.path.join(plan["run_dir"], "checkpoints")
+    os.makedirs(ckpt_dir, exist_ok=True)
+    top: List[tuple] = []        # (score, path), best first
+    sign = 1.0 if plan["monitor_mode"] == "max" else -1.0
+    max_steps = int(own.get("max_steps", 0))
+    history, stale = [], 0
+    for epoch in range(plan["epochs"]):
+        for i, batch in enumerate(train.epoch(epoch)):
+            if loop.optim.step_count >= plan["train_steps"] or (max_steps and loop.optim.step_count >= max_steps):
+                break
+            loop.micro_batch(batch, i)
+        nval = len(val)
+        lim = plan["limit_val_batches"]
+        nval = min(nval, int(lim) if isinstance(lim, int) or float(lim) > 1.0 else max(1, int(nval * float(lim))))
+        for i, batch in enumerate(val.epoch(0)):
+            if i >= nval:
+                break
+            model.validation_step(batch, i)
+        avg = {k: float(v) for k, v in model.on_validation_epoch_end().items()}
+        history.append({"epoch": epoch, "step": loop.optim.step_count, **avg})
+        if rank == 0:
+            score = avg.get(plan["monitor"], float("nan"))
+            path = os.path.join(ckpt_dir, f"epoch_{epoch}-step_{loop.optim.step_count}.ckpt")
+            save_checkpoint(path, model, loop, epoch)
+            shutil.copy(path, os.path.join(ckpt_dir, "last.ckpt"))                      # save_last=True
+            top.append((sign * score if score == score else -float("inf"), path))
+            top.sort(key=lambda t: -t[0])
+            for _, old in top[5:]:                                                      # save_top_k=5
+                if os.path.exists(old):
+                    os.remove(old)
+            top[:] = top[:5]
+            stale = 0 if top[0][1] == path else stale + 1
+        if plan["early_stopping_patience"] and stale >= plan["early_stopping_patience"]:
+            break
+    result = {"history": history, "run_dir": plan["run_dir"], "train_steps": plan["train_steps"], "precision": precision}
+    if rank == 0:
+        best = top[0][1]
+        shutil.copy(best, os.path.join(ckpt_dir, "best.ckpt"))
+        result["best_model_path"] = best
+    if world > 1:
+        dist.barrier()
+    # reload the best model and evaluate the test shard with beam search (cli/training.py:167-249)
+    best_model = new_model()
+    load_checkpoint(os.path.join(ckpt_dir, "best.ckpt"), best_model)
+    best_model.eval()
+    n_beams = int(plan["n_beams"])
+    test = ShardLoader(shards.get("test", shards.get("val", shards["train"])), collator, bs, device, rank, world,
+                       shuffle=False, drop_last=False)
+    losses, preds, tgts = [], [], []
+    for i, batch in enumerate(test.epoch(0)):
+        out = best_model.forward(batch)
+        losses.append(float(out.loss))
+        seqs = best_model.generate(batch, n_beams=n_beams)
+        width = best_model.max_length
+        preds.append(torch.nn.functional.pad(seqs, (0, width - seqs.shape[1]), value=tok.pad_token_id))
+        tgts.append(batch["target"].T)
+        if max_steps and i + 1 >= max_steps:
+            break
+    metrics = {"avg_loss": sum(losses) / max(1, len(losses))}
+    if preds:
+        metrics.update(topk_sequence_accuracy(best_model, torch.cat(preds), torch.cat(tgts), n_beams))
+    with open(os.path.join(plan["run_dir"], f"metrics_beam_{n_beams}_{rank}.json"), "w") as fh:
+        json.dump(metrics, fh)
+    result["metrics"] = metrics
+    return result
+
+
+def main(argv: Optional[List[str]] = None) -> int:
+    argv = list(sys.argv[1:] if argv is None else argv)
+    own, overrides = split_cli(argv)
+    cfg = compose(own.get("config_dir", os.environ.get("AFM_CONFIG_DIR", DEFAULT_CONFIG_DIR)), own.get("config_name", "config_train"),
+                  overrides)
+    try:
+        res = run(cfg, own)
+        print(json.dumps({"run_dir": res["run_dir"], "metrics": res["metrics"], "history": res["history"][-1:]}))
+    except Exception:       # cli/training.py:253-254: the reference logs the failure and still exits 0
+        traceback.print_exc()
+        return 1 if own.get("strict", "0") not in ("0", "false", "False") else 0
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -116,3 +116,41 @@ def to_device(b, device):
     if torch.is_tensor(b):
         return b.to(device, non_blocking=True)
     return b
+
+
+def synth_shards(data_config, n_train: int, n_val: int, n_test: int, seed: int = 3247, spectrum_len: int = 1800,
+                 text_len: int = 32, target_len: int = 64, vocab: int = 64):
+    """Pre-tokenised synthetic shards in the format `cli/training.py` reads, for ANY composed data config: text-like
+    modalities as padded id matrices (bos ... eos pad), patch modalities as raw positive spectra."""
+    rng = np.random.default_rng(seed)
+
+    def ids(n, L, V):
+        lens = rng.integers(max(3, L // 4), L - 1, size=n) + 1
+        x = rng.integers(4, V, size=(n, L)).astype(np.int64)
+        x[:, 0] = BOS
+        x[np.arange(n), lens - 1] = EOS
+        pad = np.arange(L)[None, :] >= lens[:, None]
+        x[pad] = PAD
+        return {"input_ids": torch.from_numpy(x), "attention_mask": torch.from_numpy(~pad)}
+
+    def shard(n):
+        data, meta = {}, {}
+        for m, mc in data_config.items():
+            if mc["type"] == "1D_patches":
+                x = np.abs(rng.standard_normal((n, spectrum_len))).astype(np.float32)
+                k = np.exp(-0.5 * (np.arange(-9, 10) / 3.0) ** 2); k /= k.sum()
+                x = np.apply_along_axis(lambda r: np.convolve(r, k, mode="same"), 1, x).astype(np.float32) + 0.05
+                data[m] = {"spectra": torch.from_numpy(x)}
+            else:
+                L = target_len + 1 if mc.get("target") else text_len
+                data[m] = ids(n, L, vocab)
+                meta[m] = {"vocab_size": vocab, "pad_token_id": PAD}
+        return {"meta": meta, "data": data}
+    return {"train": shard(n_train), "val": shard(n_val), "test": shard(n_test)}
+
+
+def write_shards(path: str, data_config, n_train: int, n_val: int, n_test: int, seed: int = 3247, **kw) -> None:
+    import os
+    os.makedirs(path, exist_ok=True)
+    for split, sh in synth_shards(data_config, n_train, n_val, n_test, seed, **kw).items():
+        torch.save(sh, os.path.join(path, split + ".pt"))

@@ -44,3 +44,25 @@ def test_compose_reference_tree_unchanged():
     assert ours["model"] == cfg["model"]
     assert ours["data"] == cfg["data"]
     assert ours["trainer"] == cfg["trainer"]
+
+
+def test_cli_plan_from_the_reference_tests_override_list():
+    """`python -m multimodalanalytical_amd.cli.training <the override list of reference tests/test_run.py:8-18>`:
+    everything up to the GPU (compose -> data_config with the tokenised data's vocab sizes -> HFWrapper keywords ->
+    optimiser-step count -> paths) resolves and is what the reference's CLI would hand to HFWrapper / build_trainer."""
+    from multimodalanalytical_amd.cli.training import build_plan, split_cli
+    from multimodalanalytical_amd.synth import synth_shards
+    own, ov = split_cli(OVERRIDES + ["precision=bf16", "strict=1"])
+    assert own == {"precision": "bf16", "strict": "1"} and ov == OVERRIDES
+    cfg = compose(os.path.join(ROOT, "configs"), "config_train", ov)
+    shards = synth_shards(cfg["data"], 1000, 16, 16)
+    plan = build_plan(cfg, shards["train"]["meta"], 1000)
+    assert plan["target_modality"] == "Smiles" and plan["run_dir"] == os.path.join("runs", "train")
+    assert plan["data_config"]["Smiles"]["vocab_size"] == 64 and plan["data_config"]["IR"]["preprocessor_arguments"]["patch_size"] == 125
+    assert plan["train_steps"] == 2          # ceil(ceil(1000/128)/4) * 1 epoch (utils.py:156-172)
+    assert build_plan(cfg, shards["train"]["meta"], 1000, world_size=8)["train_steps"] == 1
+    assert build_plan(cfg, shards["train"]["meta"], 1000, world_size=8, legacy_step_count=True)["train_steps"] == 2
+    assert plan["monitor"] == "val_molecular_accuracy" and plan["monitor_mode"] == "max" and plan["n_beams"] == 10
+    assert plan["model_config"]["model_type"] == "CustomModel" and plan["acc_batches"] == 4 and plan["clip_grad"] == 1.0
+    assert shards["train"]["data"]["IR"]["spectra"].shape == (1000, 1800)
+    assert shards["train"]["data"]["Smiles"]["input_ids"].shape == (1000, 65)
