@@ -9,9 +9,15 @@ is done when it holds k hypotheses and its worst kept score beats best_running /
 The arithmetic (decoder, logits) runs on the GPU; this module only moves 2k (score, token, beam)
 triples per sample per step to the host, as HF's Python loop does.
 
-Parity status: UNPINNED.  HF `generate()` cannot run in the build container (transformers 5.x rejects
-the reference's model), so there are no reference beam outputs to pin against; tests check
-invariants (k = 1 equals greedy, KV-cached equals full recompute, scores sorted, forced EOS).
+Parity status: PINNED to transformers' own `generate` on a table-lookup stub model (oracle/make_beam_goldens.py ->
+tests/golden/beam_cases.npz, tests/test_beam_cpu.py): sequences and sequence scores equal HF's on every case.
+Version skew, stated: the build container has transformers 5.x, the reference pins 4.48.3.  The two differ in ONE
+rule, the per-sample stop test with early_stopping=False: 4.48.3's BeamSearchScorer.process compares the worst kept
+hypothesis with the best of ALL 2k candidates of the step (`next_scores[batch_idx].max()`, EOS candidates included),
+5.x's vectorised `_check_early_stop_heuristic` with the best RUNNING beam (`running_beam_scores[:, :1]`); the 5.x rule
+can stop a sample one or more steps earlier when EOS candidates dominate.  `stop_rule="hf5"` is the rule the fixture
+pins (all cases equal); `stop_rule="hf4"`, the default, is the reference's pinned version (equal on every case where the
+two rules coincide, never worse in score where they do not).
 """
 from __future__ import annotations
 
@@ -47,7 +53,7 @@ class BeamHypotheses:
 
 
 def beam_search(step_fn, reorder_fn, B: int, k: int, V: int, max_length: int, bos: int, eos: int, pad: int,
-                device) -> Tuple[torch.Tensor, torch.Tensor]:
+                device, stop_rule: str = "hf4") -> Tuple[torch.Tensor, torch.Tensor]:
     """step_fn(ids_last (B*k,)) -> fp32 logits (B*k, V) for the next position; reorder_fn(beam_idx (B*k,)).
     Returns (sequences (B*k, L) int64 best-first per sample, scores (B*k,))."""
     ids = torch.full((B * k, 1), bos, dtype=torch.long, device=device)
@@ -90,7 +96,8 @@ def beam_search(step_fn, reorder_fn, B: int, k: int, V: int, max_length: int, bo
                     j += 1
                 if j == k:
                     break
-            done[b] = done[b] or hyps[b].is_done(float(top_s_h[b].max()), cur_len)
+            best = float(top_s_h[b].max()) if stop_rule == "hf4" else float(nxt_scores[b, 0])
+            done[b] = done[b] or hyps[b].is_done(best, cur_len)
         beam_scores = nxt_scores.view(-1).to(device)
         beam_idx = nxt_index.view(-1).to(device)
         ids = torch.cat([ids.index_select(0, beam_idx), nxt_tokens.view(-1, 1).to(device)], dim=1)
