@@ -44,7 +44,7 @@ enum { AFM_ALGO_AUTO = 0, AFM_ALGO_GENERIC = 1, AFM_ALGO_MFMA = 2 };
 
 int afm_abi_version(void);
 /* sizeof() of the ABI structs as compiled into the library (0 afm_dropout, 1 afm_gemm_desc, 2 afm_ln_shape,
- * 3 afm_attn_shape, 4 afm_patch_desc; -1 otherwise): a binding checks its own struct layouts against these,
+ * 3 afm_attn_shape, 4 afm_patch_desc, 5 afm_beam_desc; -1 otherwise): a binding checks its own struct layouts against these,
  * so a stale library cannot be driven with newer descriptors. */
 int afm_struct_size(int which);
 const char* afm_error_string(int code);
@@ -307,6 +307,43 @@ int afm_ce_fwd(const float* logits, const int64_t* labels, int64_t rows, int32_t
 int afm_ce_bwd(const float* logits, const int64_t* labels, const float* row_lse, const float* stats,
                float grad_scale, void* dlogits, int32_t dl_dtype, int32_t lddl, int64_t rows,
                int32_t V, int32_t ld, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Beam search bookkeeping on the device: what transformers' GenerationMixin beam search does on the
+ * host between two decoder steps when called as the reference calls it (modeling/wrapper.py:306-313,443-451:
+ * num_beams = num_return_sequences = k, length_penalty 1, early_stopping False, forced EOS at max_length).
+ * afm_beam_step, one launch per generated token: log-softmax of the (B*k x V) logits + running beam scores, the 2k best
+ * of the k*V candidates per sample in descending order, then per sample: an EOS candidate inside the top k closes a
+ * hypothesis (score = sum_logprobs / generated_len, the k best are kept), the first k other candidates continue;
+ * the sample is done when it holds k hypotheses and worst_kept >= best / generated_len, best = the step's best
+ * candidate (stop_rule 0, transformers 4.48.3: the reference's pin) or its best running beam (stop_rule 1, 5.x).
+ * Writes the new running sequences (seq_out rows = seq_in[source row] + token), beam scores, beam_idx (source row of
+ * every new row: the KV-cache reorder) and n_open = number of samples still open (the only word the host reads).
+ * afm_beam_finalize: open beams of unfinished samples become hypotheses; the k best per sample, best first, as
+ * `tokens, eos (if shorter than max_length), pad...` into out (B*k x max_length), their scores and lengths.
+ * afm_cache_reorder: dst block r = first used_bytes of src block beam_idx[r] (blocks of block_bytes: one row's KV cache).
+ * Pinned to transformers' own generate on a table-lookup model: tests/golden/beam_cases.npz.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct {
+  int32_t B, k, V, ldl;          /* logits (B*k x V) fp32, row stride ldl */
+  int32_t cur_len, max_length;   /* tokens in every running row before this step (>= 1: the start token) */
+  int32_t eos, pad, stop_rule, Lmax;   /* Lmax: row stride of seq_in / seq_out / hyp_seq (>= max_length) */
+  const float* logits;
+  const int64_t* seq_in;         /* (B*k x Lmax) running sequences */
+  int64_t* seq_out;
+  float* beam_scores;            /* (B*k) in/out: initialise to 0 for beam 0 of every sample, -1e9 for the others */
+  int32_t* beam_idx;             /* (B*k) out */
+  int64_t* hyp_seq;              /* (B x k x Lmax) closed hypotheses (without their eos) */
+  float* hyp_score;              /* (B x k) */
+  int32_t* hyp_len;              /* (B x k) */
+  int32_t* hyp_count;            /* (B) zero-initialised */
+  int32_t* done;                 /* (B) zero-initialised */
+  int32_t* n_open;               /* (1) out */
+} afm_beam_desc;
+int afm_beam_step(const afm_beam_desc* d, void* stream);
+int afm_beam_finalize(const afm_beam_desc* d, int64_t* out, float* out_scores, int32_t* out_len, void* stream);
+int afm_cache_reorder(const void* src, void* dst, const int32_t* beam_idx, int32_t rows, int64_t block_bytes,
+                      int64_t used_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Optimiser over ONE flat fp32 parameter buffer (all tensors of the model are views of it).

@@ -125,3 +125,43 @@ def beam_search(step_fn, reorder_fn, B: int, k: int, V: int, max_length: int, bo
         if len(h) < max_length:
             out[i, len(h)] = eos
     return out.to(device), torch.tensor(best_scores)
+
+
+def beam_search_device(step_fn, reorder_fn, B: int, k: int, V: int, max_length: int, bos: int, eos: int, pad: int,
+                       device, stop_rule: str = "hf4", sync_every: int = 8) -> Tuple[torch.Tensor, torch.Tensor]:
+    """The same search with the bookkeeping on the device (afm_beam_step / afm_beam_finalize): log-softmax, top-2k,
+    hypothesis pool, running sequences and beam reorder indices never leave HBM; the host reads one int32 (number of
+    open samples) every `sync_every` tokens to stop early.  step_fn(last ids (B*k,) int64) -> fp32 logits (B*k, V);
+    reorder_fn(beam_idx (B*k,) int32 device tensor)."""
+    from . import ops
+    i32 = dict(dtype=torch.int32, device=device)
+    seq = [torch.full((B * k, max_length), pad, dtype=torch.long, device=device) for _ in range(2)]
+    seq[0][:, 0] = bos
+    beam_scores = torch.zeros(B, k, dtype=torch.float32, device=device)
+    beam_scores[:, 1:] = -1e9
+    beam_scores = beam_scores.view(-1).contiguous()
+    beam_idx = torch.zeros(B * k, **i32)
+    hyp_seq = torch.zeros(B * k, max_length, dtype=torch.long, device=device)
+    hyp_score = torch.zeros(B * k, dtype=torch.float32, device=device)
+    hyp_len, hyp_count, done, n_open = torch.zeros(B * k, **i32), torch.zeros(B, **i32), torch.zeros(B, **i32), torch.zeros(1, **i32)
+    rule = {"hf4": 0, "hf5": 1}[stop_rule]
+    cur, cur_len = 0, 1
+
+    def desc(logits, length):
+        return ops.beam_desc(B, k, V, length, max_length, eos, pad, rule, logits, seq[cur], seq[cur ^ 1], beam_scores, beam_idx,
+                             hyp_seq, hyp_score, hyp_len, hyp_count, done, n_open)
+    while cur_len < max_length:
+        logits = step_fn(seq[cur][:, cur_len - 1])
+        ops.beam_step(desc(logits.float() if logits.dtype != torch.float32 else logits, cur_len))
+        cur ^= 1
+        cur_len += 1
+        if cur_len < max_length:
+            reorder_fn(beam_idx)
+        if cur_len % sync_every == 0 and int(n_open.item()) == 0:
+            break
+    out = torch.empty(B * k, max_length, dtype=torch.long, device=device)
+    out_scores = torch.empty(B * k, dtype=torch.float32, device=device)
+    out_len = torch.empty(B * k, **i32)
+    ops.beam_finalize(desc(None, cur_len), out, out_scores, out_len)
+    L = int(out_len.max().item())
+    return out[:, :L], out_scores

@@ -13,6 +13,7 @@ extern "C" int afm_struct_size(int which) {
     case 2: return (int)sizeof(afm_ln_shape);
     case 3: return (int)sizeof(afm_attn_shape);
     case 4: return (int)sizeof(afm_patch_desc);
+    case 5: return (int)sizeof(afm_beam_desc);
     default: return -1;
   }
 }

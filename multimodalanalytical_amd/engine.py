@@ -607,20 +607,16 @@ class Seq2SeqEngine:
         return ent[1]
 
     def decode_reorder(self, st, beam_idx: torch.Tensor) -> None:
-        """Beam search bookkeeping: row r of every cache continues beam beam_idx[r]."""
+        """Beam search bookkeeping: row r of every cache continues beam beam_idx[r].  One afm_cache_reorder launch per
+        layer copies the st['t'] filled positions of every beam row into the alternate buffer (the buffers swap)."""
         Bk, Tmax = st["B"] * st["k"], st["Tmax"]
-
-        def pick(c):    # (Bk*Tmax, w) rows regrouped per beam
-            return c.view(Bk, Tmax, -1).index_select(0, beam_idx).view(Bk * Tmax, -1)
-        if self.x3:
-            new = []
-            for c in st["cache"]:
-                n = X2.empty(Bk * Tmax, c.shape[1], self.dev)
-                n.hi.copy_(pick(c.hi)); n.lo.copy_(pick(c.lo))
-                new.append(n)
-            st["cache"] = new
-        else:
-            st["cache"] = [pick(c) for c in st["cache"]]
+        idx = beam_idx if beam_idx.dtype == torch.int32 else beam_idx.to(torch.int32)
+        if "cache_alt" not in st:
+            st["cache_alt"] = [(X2.empty(c.shape[0], c.shape[1], self.dev) if self.x3 else torch.empty_like(c)) for c in st["cache"]]
+        for i, (c, alt) in enumerate(zip(st["cache"], st["cache_alt"])):
+            row_bytes = ops._ld(c) * (2 if self.lowp else 4)          # physical bytes of one position (both planes of a pair)
+            ops.cache_reorder(c, alt, idx, Bk, Tmax * row_bytes, st["t"] * row_bytes)
+        st["cache"], st["cache_alt"] = st["cache_alt"], st["cache"]
 
     def decode_step(self, st, ids: torch.Tensor) -> torch.Tensor:
         """Feed token ids (B*beams,) at position st['t']; returns fp32 logits (B*beams, V)."""

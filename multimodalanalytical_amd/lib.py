@@ -54,6 +54,17 @@ class LnShape(C.Structure):
     ]
 
 
+class BeamDesc(C.Structure):
+    _fields_ = [
+        ("B", C.c_int32), ("k", C.c_int32), ("V", C.c_int32), ("ldl", C.c_int32),
+        ("cur_len", C.c_int32), ("max_length", C.c_int32),
+        ("eos", C.c_int32), ("pad", C.c_int32), ("stop_rule", C.c_int32), ("Lmax", C.c_int32),
+        ("logits", C.c_void_p), ("seq_in", C.c_void_p), ("seq_out", C.c_void_p), ("beam_scores", C.c_void_p),
+        ("beam_idx", C.c_void_p), ("hyp_seq", C.c_void_p), ("hyp_score", C.c_void_p), ("hyp_len", C.c_void_p),
+        ("hyp_count", C.c_void_p), ("done", C.c_void_p), ("n_open", C.c_void_p),
+    ]
+
+
 class AttnShape(C.Structure):
     _fields_ = [
         ("B", C.c_int32), ("H", C.c_int32), ("Tq", C.c_int32), ("Tk", C.c_int32), ("dh", C.c_int32),
@@ -101,6 +112,9 @@ _SIGS = {
     "afm_patch_preprocess": (C.c_int, [C.POINTER(PatchDesc), _P, _P, _P, _P, _P]),
     "afm_ce_fwd": (C.c_int, [_P, _P, _I64, _I32, _I32, _P, _P, _P, _P]),
     "afm_ce_bwd": (C.c_int, [_P, _P, _P, _P, _F, _P, _I32, _I32, _I64, _I32, _I32, _P]),
+    "afm_beam_step": (C.c_int, [C.POINTER(BeamDesc), _P]),
+    "afm_beam_finalize": (C.c_int, [C.POINTER(BeamDesc), _P, _P, _P, _P]),
+    "afm_cache_reorder": (C.c_int, [_P, _P, _P, _I32, _I64, _I64, _P]),
     "afm_sumsq": (C.c_int, [_P, _I64, _P, _P]),
     "afm_adam_step": (C.c_int, [_P, _P, _P, _P, _I64, _P, _P, _P, _I32, _P]),
 }
@@ -143,7 +157,7 @@ def load(build_if_missing: bool = True):
             fn.restype, fn.argtypes = res, args
         if lib.afm_abi_version() != ABI_VERSION:
             raise AfmError(f"libafm_hip.so ABI version {lib.afm_abi_version()} != binding {ABI_VERSION}: rebuild it")
-        for which, st in enumerate((Dropout, GemmDesc, LnShape, AttnShape, PatchDesc)):
+        for which, st in enumerate((Dropout, GemmDesc, LnShape, AttnShape, PatchDesc, BeamDesc)):
             if lib.afm_struct_size(which) != C.sizeof(st):
                 raise AfmError(f"libafm_hip.so was built with a different {st.__name__} layout: rebuild it")
         _lib = lib

@@ -76,6 +76,7 @@ class HFWrapper:
             model_name, target_tokenizer, self.target_modality, data_config, multimodal_norm, **kwargs)
         self.max_length = 128  # generation_config.max_length (wrapper.py:313)
         self.n_beams = kwargs.get("n_beams", 10)
+        self.beam_stop_rule = "hf4"     # transformers 4.48.3 (the reference's pin); "hf5": the 5.x rule (beam.py)
         self.training = True
         self.logged: Dict[str, Any] = {}
         # _init_params (wrapper.py:320-327) happens in the engine's ParamStore.init_
@@ -180,7 +181,7 @@ class HFWrapper:
         return enc, attention_mask
 
     def generate(self, batch: Dict[str, Any], n_beams: int = 1, logits_processor=None, use_cache: bool = True,
-                 graph: bool = True) -> torch.Tensor:
+                 graph: bool = True, device_beam: bool = True) -> torch.Tensor:
         """wrapper.py:409-453.  Encoder once, then greedy (n_beams == 1) or beam search with
         num_return_sequences = n_beams, max_length 128, forced EOS; returns (B*n_beams, <=128) ids.
         use_cache=True decodes incrementally on a device-side KV cache (engine.decode_step);
@@ -226,11 +227,14 @@ class HFWrapper:
                     if bool(done.all()):
                         break
                 return ids
-            from ..beam import beam_search
-            seqs, self.last_beam_scores = beam_search(lambda last: eng.decode_step(st, last),
-                                                      lambda idx: eng.decode_reorder(st, idx), B, n_beams, eng.V,
-                                                      self.max_length, tok.bos_token_id, tok.eos_token_id,
-                                                      tok.pad_token_id, dev)
+            # beam bookkeeping on the device (afm_beam_step): one small D2H every few tokens; `device_beam=False` keeps the
+            # host loop (the restatement of HF's Python code the kernels are tested against)
+            from ..beam import beam_search, beam_search_device
+            search = beam_search_device if device_beam else beam_search
+            seqs, self.last_beam_scores = search(lambda last: eng.decode_step(st, last),
+                                                 lambda idx: eng.decode_reorder(st, idx), B, n_beams, eng.V,
+                                                 self.max_length, tok.bos_token_id, tok.eos_token_id,
+                                                 tok.pad_token_id, dev, stop_rule=self.beam_stop_rule)
             return seqs
         finally:
             self.train(was)

@@ -351,6 +351,34 @@ def patch_preprocess(spectra, present, mean, std, patch_size, masking=False, int
     return patches, mask.bool()
 
 
+def beam_desc(B, k, V, cur_len, max_length, eos, pad, stop_rule, logits, seq_in, seq_out, beam_scores, beam_idx,
+              hyp_seq, hyp_score, hyp_len, hyp_count, done, n_open) -> "L.BeamDesc":
+    d = L.BeamDesc()
+    d.B, d.k, d.V, d.ldl = B, k, V, (_ld(logits) if logits is not None else V)
+    d.cur_len, d.max_length, d.eos, d.pad, d.stop_rule, d.Lmax = cur_len, max_length, eos, pad, stop_rule, int(seq_in.shape[1])
+    assert seq_in.dtype == torch.int64 and seq_in.is_contiguous() and hyp_seq.is_contiguous() and beam_scores.dtype == torch.float32
+    assert beam_idx is None or beam_idx.dtype == torch.int32
+    d.logits, d.seq_in, d.seq_out, d.beam_scores, d.beam_idx = _ptr(logits), _ptr(seq_in), _ptr(seq_out), _ptr(beam_scores), _ptr(beam_idx)
+    d.hyp_seq, d.hyp_score, d.hyp_len, d.hyp_count = _ptr(hyp_seq), _ptr(hyp_score), _ptr(hyp_len), _ptr(hyp_count)
+    d.done, d.n_open = _ptr(done), _ptr(n_open)
+    d._keep = (logits, seq_in, seq_out, beam_scores, beam_idx, hyp_seq, hyp_score, hyp_len, hyp_count, done, n_open)
+    return d
+
+
+def beam_step(d) -> None:
+    L.check(L.load().afm_beam_step(C.byref(d), _stream()), "afm_beam_step")
+
+
+def beam_finalize(d, out, out_scores, out_len) -> None:
+    L.check(L.load().afm_beam_finalize(C.byref(d), _ptr(out), _ptr(out_scores), _ptr(out_len), _stream()), "afm_beam_finalize")
+
+
+def cache_reorder(src, dst, beam_idx, rows: int, block_bytes: int, used_bytes: int) -> None:
+    assert beam_idx.dtype == torch.int32 and beam_idx.numel() == rows
+    L.check(L.load().afm_cache_reorder(_ptr(src), _ptr(dst), _ptr(beam_idx), rows, block_bytes, used_bytes, _stream()),
+            "afm_cache_reorder")
+
+
 def ce_fwd(logits, labels, row_lse, argmax, stats):
     rows, V = logits.shape
     assert logits.dtype == torch.float32 and labels.dtype == torch.int64
