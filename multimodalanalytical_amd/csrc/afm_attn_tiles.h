@@ -153,3 +153,52 @@ __device__ __forceinline__ void build_mask_words(unsigned long long* maskw, cons
   }
 }
 
+
+// ------------------------------------------------------------------------------------------ dual-use image
+// ONE LDS image of a [rows][64] bf16 tile that serves both the row reads (ds_read_b128: the 32x32x16 row operand) and
+// the transposed reads (ds_read_b64_tr_b16), conflict-free for both (tools/lds_swizzle_check.py): chunk c of row r sits
+// at chunk  c ^ f(r),  f(r) = ((r>>1)&1) << 2  |  ((r>>2)&3) ^ 3*((r>>4)&1).
+// Bit 2 separates rows r, r+2 of a transposed 4-row block into the two 64-byte halves; bits 1..0 spread the eight
+// same-parity rows of a ds_read_b128 lane group over eight chunk positions.  Backward kernels that used a row image AND
+// a transposed image of the same tile (K in the dQ kernel, Q and dO in the dK/dV kernel) stage it once: half the LDS
+// and half the LDS-DMA pieces.
+__device__ __forceinline__ int dual_f(int row) { return (((row >> 1) & 1) << 2) | (((row >> 2) & 3) ^ (3 * ((row >> 4) & 1))); }
+__device__ __forceinline__ void dma_piece_dual(unsigned char* img, const bf16* base, int ld, int row0, int nrows, int pi, int lane) {
+  const int r = 8 * pi + (lane >> 3), slot = lane & 7;
+  const int chunk = slot ^ dual_f(r);
+  int gr = row0 + r;
+  gr = gr < nrows ? gr : nrows - 1;
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + (int64_t)gr * ld + chunk * 8),
+                                   (__attribute__((address_space(3))) void*)(img + pi * 1024), 16, 0, 0);
+}
+// row fragment k-slice s of rows R0 .. R0+31 (R0 a multiple of 32): f(R0 + r) = f(r)
+__device__ __forceinline__ bf16x8 frag_row_dual(const unsigned char* img, int R0, int s, int lane) {
+  const int r = lane & 31;
+  return *(const bf16x8*)(img + (R0 + r) * 128 + (((2 * s + (lane >> 5)) ^ dual_f(r)) << 4));
+}
+// transposed reads: lane address of the 8-row block at row 0, 32-column half 0; the block at row R (multiple of 8), half
+// db is  R*128 + (T0 ^ (delta(R) << 4) ^ (db << 6))  with delta(R) = ((R>>2)&3) ^ 3*((R>>4)&1)  = 0, 2, 3, 1 for R = 0, 8, 16, 24
+__device__ __forceinline__ unsigned tr_dual_t0(int lane) {
+  const int g = lane >> 4, qq = (lane >> 2) & 3, p = lane & 3;
+  const int rl = 4 * (g >> 1) + qq;
+  const int c = 2 * (g & 1) + (p >> 1);
+  const int fl = (((rl >> 1) & 1) << 2) | ((rl >> 2) & 3);
+  return (unsigned)(rl * 128 + ((c ^ fl) << 4) + ((p & 1) << 3));
+}
+template <int OFF> __device__ __forceinline__ s16x4 tr_rd(unsigned addr) {
+  s16x4 r;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF));
+  return r;
+}
+// the A-operand quad (both 32-column halves) of the 16-row slice SL (0 / 1) of a 32-row dual-use image at byte offset IMG
+// from the address registers' base: xa[d] = base + (T0 ^ (d << 4)), xb[d] = base + (T0 ^ (d << 4) ^ 64), d = 0..3
+template <int IMG, int SL>
+__device__ __forceinline__ TrQuad tr_quad_dual(const unsigned (&xa)[4], const unsigned (&xb)[4]) {
+  TrQuad q;
+  constexpr int DLO = SL == 0 ? 0 : 3, DHI = SL == 0 ? 2 : 1;      // delta of rows 16 SL and 16 SL + 8
+  q.lo0 = tr_rd<IMG + (16 * SL) * 128>(xa[DLO]);
+  q.hi0 = tr_rd<IMG + (16 * SL + 8) * 128>(xa[DHI]);
+  q.lo1 = tr_rd<IMG + (16 * SL) * 128>(xb[DLO]);
+  q.hi1 = tr_rd<IMG + (16 * SL + 8) * 128>(xb[DHI]);
+  return q;
+}

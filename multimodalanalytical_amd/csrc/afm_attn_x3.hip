@@ -6,8 +6,9 @@
 // image exists twice (hi plane, lo plane).  Masks, the 16-bit dropout stream and lse / delta are identical.
 //
 //   forward   4 waves x 32 queries, 64-key tiles (K row + V tr images, hi and lo: 32 KiB per stage, 2 stages)
-//   dQ        4 waves x 32 queries, 32-key tiles (K row, K tr, V row, hi and lo: 24 KiB per stage)
-//   dK / dV   4 waves x 32 keys,    32-query tiles (Q row, Q tr, dO row, dO tr, hi and lo: 32 KiB per stage)
+//   dQ        4 waves x 32 queries, 32-key tiles (K dual-use image, V row image, hi and lo: 16 KiB per stage)
+//   dK / dV   4 waves x 32 keys,    32-query tiles (Q and dO dual-use images, hi and lo: 16 KiB per stage; the wave's
+//             K / V lo fragments parked in LDS)
 #include "afm_attn_tiles.h"
 
 #define IMG64 (64 * DH * 2)   // one 64-row image
@@ -184,7 +185,7 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd_dq_x3(AttnM a, const bf16* 
                                                            const float* __restrict__ lse,
                                                            float* __restrict__ delta, bf16* __restrict__ dQ) {
   constexpr int KT2 = 32, NS = 2;
-  constexpr int STAGE = 6 * IMG32;   // K row hi/lo, K tr hi/lo, V row hi/lo
+  constexpr int STAGE = 4 * IMG32;   // K hi / lo as dual-use images (row reads for S^T, transposed reads for dQ^T), V row hi / lo
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   unsigned long long* maskw = (unsigned long long*)(lds + NS * STAGE);
   const int t = threadIdx.x, lane = t & 63, h = lane >> 5;
@@ -226,15 +227,14 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd_dq_x3(AttnM a, const bf16* 
   const int ntiles = (kend + KT2 - 1) / KT2;
   build_mask_words(maskw, a.key_pad, b, a.Tk, (kend + 63) / 64, w, lane);
   __syncthreads();
-  auto issue = [&](int kt) {   // 6 images x 4 pieces: wave w moves piece w of every image
+  auto issue = [&](int kt) {   // 4 images x 4 pieces: wave w moves piece w of every image
     unsigned char* st = lds + (kt % NS) * STAGE;
-    dma_piece<false>(st, Kb, a.ldk, kt * KT2, a.Tk, w, lane);
-    dma_piece<false>(st + IMG32, Kb + lok, a.ldk, kt * KT2, a.Tk, w, lane);
-    dma_piece<true>(st + 2 * IMG32, Kb, a.ldk, kt * KT2, a.Tk, w, lane);
-    dma_piece<true>(st + 3 * IMG32, Kb + lok, a.ldk, kt * KT2, a.Tk, w, lane);
-    dma_piece<false>(st + 4 * IMG32, Vb, a.ldv, kt * KT2, a.Tk, w, lane);
-    dma_piece<false>(st + 5 * IMG32, Vb + lov, a.ldv, kt * KT2, a.Tk, w, lane);
+    dma_piece_dual(st, Kb, a.ldk, kt * KT2, a.Tk, w, lane);
+    dma_piece_dual(st + IMG32, Kb + lok, a.ldk, kt * KT2, a.Tk, w, lane);
+    dma_piece<false>(st + 2 * IMG32, Vb, a.ldv, kt * KT2, a.Tk, w, lane);
+    dma_piece<false>(st + 3 * IMG32, Vb + lov, a.ldv, kt * KT2, a.Tk, w, lane);
   };
+  const unsigned t0 = tr_dual_t0(lane);
   issue(0);
   __builtin_assume(ntiles >= 1);
   for (int kt = 0; kt < ntiles; ++kt) {
@@ -246,16 +246,15 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd_dq_x3(AttnM a, const bf16* 
     if ((a.causal && kb > q0 + 31) || mword == 0xFFFFFFFFu) continue;
     const unsigned char* Krh = lds + (kt % NS) * STAGE;
     const unsigned char* Krl = Krh + IMG32;
-    const unsigned char* Kth = Krh + 2 * IMG32;
-    const unsigned char* Vrh = Krh + 4 * IMG32;
-    const unsigned char* Vrl = Krh + 5 * IMG32;
+    const unsigned char* Vrh = Krh + 2 * IMG32;
+    const unsigned char* Vrl = Krh + 3 * IMG32;
     const uint32_t pad = mword >> (4 * h);
     f32x16 s, dp;
 #pragma unroll
     for (int i = 0; i < 16; ++i) { s[i] = 0.f; dp[i] = 0.f; }
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-      s = mfma3(frag_row(Krh, 0, ks, lane), frag_row(Krl, 0, ks, lane), qh[ks], ql[ks], s);
+      s = mfma3(frag_row_dual(Krh, 0, ks, lane), frag_row_dual(Krl, 0, ks, lane), qh[ks], ql[ks], s);
       dp = mfma3(frag_row(Vrh, 0, ks, lane), frag_row(Vrl, 0, ks, lane), dh_[ks], dl_[ks], dp);
     }
     if (DROP) {
@@ -277,11 +276,12 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd_dq_x3(AttnM a, const bf16* 
       const float p = fast_exp2(fmaf(s[r], a.scale_log2, -L2));
       s[r] = p * (dp[r] - dl);
     }
-    unsigned kh0, kh1;
-    tr_lane_addr(Kth, lane, kh0, kh1);
-    const unsigned kl0 = kh0 + IMG32, kl1 = kh1 + IMG32;
-    const TrQuad a0h = tr_issue(kh0, kh1, 0), a0l = tr_issue(kl0, kl1, 0);
-    const TrQuad a1h = tr_issue(kh0, kh1, 16), a1l = tr_issue(kl0, kl1, 16);
+    const unsigned sb = (unsigned)(uintptr_t)Krh;
+    unsigned xa[4], xb[4];
+#pragma unroll
+    for (int d = 0; d < 4; ++d) { xa[d] = sb + (t0 ^ (d << 4)); xb[d] = sb + (t0 ^ (d << 4) ^ 64); }
+    const TrQuad a0h = tr_quad_dual<0, 0>(xa, xb), a0l = tr_quad_dual<IMG32, 0>(xa, xb);
+    const TrQuad a1h = tr_quad_dual<0, 1>(xa, xb), a1l = tr_quad_dual<IMG32, 1>(xa, xb);
     bf16x8 d0h, d0l, d1h, d1l;
     split8(s, 0, d0h, d0l);
     split8(s, 1, d1h, d1l);
@@ -305,6 +305,10 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd_dq_x3(AttnM a, const bf16* 
 }
 
 // ------------------------------------------------------------------------------------------ dK, dV
+// Workgroup = 4 waves x 32 keys, 32-query tiles.  Stage = Q hi, Q lo, dO hi, dO lo as DUAL-USE images (row reads for
+// S = Q K^T / dP = dO V^T, transposed reads for dV^T += dO^T P / dK^T += Q^T dS) + lse / delta: 16.5 KiB, two stages.
+// The wave's K / V fragments: hi planes in registers, lo planes parked in LDS (8 KiB per wave, re-read per tile), so
+// the kernel holds dK, dV, K hi, V hi (96 registers) and stays clear of scratch at two waves per SIMD.
 template <bool DROP>
 __global__ __launch_bounds__(256, 2) void k_attn_bwd_dkv_x3(AttnM a, const bf16* __restrict__ Q,
                                                             const bf16* __restrict__ K,
@@ -314,8 +318,10 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd_dkv_x3(AttnM a, const bf16*
                                                             const float* __restrict__ delta,
                                                             bf16* __restrict__ dK, bf16* __restrict__ dV) {
   constexpr int QT = 32, NS = 2;
-  constexpr int STAGE = 8 * IMG32 + 2 * 64 * 4;   // Q row hi/lo, Q tr hi/lo, dO row hi/lo, dO tr hi/lo, lse[64], delta[64]
+  constexpr int STAGE = 4 * IMG32 + 2 * 64 * 4;
+  constexpr int KVL = 4 * 2 * 4096;             // parked lo fragments: [wave][K | V][slice][lane] x 16 B
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  unsigned char* ring = lds + KVL;
   const int t = threadIdx.x, lane = t & 63, h = lane >> 5;
   const int w = __builtin_amdgcn_readfirstlane(t >> 6);
   const int hd = blockIdx.y, b = blockIdx.z;
@@ -326,14 +332,17 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd_dkv_x3(AttnM a, const bf16*
   const int loq = a.ldq >> 1, loo = a.ldo >> 1;
   const bf16* Qb = Q + (int64_t)b * a.Tq * a.ldq + hd * DH;
   const bf16* Db = dO + (int64_t)b * a.Tq * a.ldo + hd * DH;
-  bf16x8 kh[4], kl[4], vh[4], vl[4];
+  bf16x8 kh[4], vh[4];
+  unsigned char* my_l = lds + w * 8192 + lane * 16;
   {
     const bf16* kp = K + ((int64_t)b * a.Tk + kc) * a.ldk + hd * DH + 8 * h;
     const bf16* vp = V + ((int64_t)b * a.Tk + kc) * a.ldv + hd * DH + 8 * h;
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-      kh[s] = *(const bf16x8*)(kp + 16 * s); kl[s] = *(const bf16x8*)(kp + (a.ldk >> 1) + 16 * s);
-      vh[s] = *(const bf16x8*)(vp + 16 * s); vl[s] = *(const bf16x8*)(vp + (a.ldv >> 1) + 16 * s);
+      kh[s] = *(const bf16x8*)(kp + 16 * s);
+      vh[s] = *(const bf16x8*)(vp + 16 * s);
+      *(bf16x8*)(my_l + s * 1024) = *(const bf16x8*)(kp + (a.ldk >> 1) + 16 * s);
+      *(bf16x8*)(my_l + 4096 + s * 1024) = *(const bf16x8*)(vp + (a.ldv >> 1) + 16 * s);
     }
   }
   f32x16 dk[2], dv[2];
@@ -345,26 +354,23 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd_dkv_x3(AttnM a, const bf16*
   if (a.causal) qbeg = (blockIdx.x * 128) / QT * QT;
   const int ntiles = (a.Tq - qbeg + QT - 1) / QT;
   const int64_t lbase = ((int64_t)b * a.H + hd) * a.Tq;
-  __syncthreads();
-  auto issue = [&](int qt) {   // 8 images x 4 pieces: wave w moves piece w of every image
-    unsigned char* st = lds + (qt % NS) * STAGE;
+  __syncthreads();   // plain loads retired / parked fragments visible before the LDS-DMA ring starts
+  auto issue = [&](int qt) {   // 4 images x 4 pieces: wave w moves piece w of every image
+    unsigned char* st = ring + (qt % NS) * STAGE;
     const int row0 = qbeg + qt * QT;
-    dma_piece<false>(st, Qb, a.ldq, row0, a.Tq, w, lane);
-    dma_piece<false>(st + IMG32, Qb + loq, a.ldq, row0, a.Tq, w, lane);
-    dma_piece<true>(st + 2 * IMG32, Qb, a.ldq, row0, a.Tq, w, lane);
-    dma_piece<true>(st + 3 * IMG32, Qb + loq, a.ldq, row0, a.Tq, w, lane);
-    dma_piece<false>(st + 4 * IMG32, Db, a.ldo, row0, a.Tq, w, lane);
-    dma_piece<false>(st + 5 * IMG32, Db + loo, a.ldo, row0, a.Tq, w, lane);
-    dma_piece<true>(st + 6 * IMG32, Db, a.ldo, row0, a.Tq, w, lane);
-    dma_piece<true>(st + 7 * IMG32, Db + loo, a.ldo, row0, a.Tq, w, lane);
-    if (w < 2) {   // lse / delta: lanes 0-31 carry the tile's queries (the upper lanes load clamped duplicates)
+    dma_piece_dual(st, Qb, a.ldq, row0, a.Tq, w, lane);
+    dma_piece_dual(st + IMG32, Qb + loq, a.ldq, row0, a.Tq, w, lane);
+    dma_piece_dual(st + 2 * IMG32, Db, a.ldo, row0, a.Tq, w, lane);
+    dma_piece_dual(st + 3 * IMG32, Db + loo, a.ldo, row0, a.Tq, w, lane);
+    if (w < 2) {
       int qq = row0 + lane;
       qq = qq < a.Tq ? qq : a.Tq - 1;
       const float* src = (w == 0 ? lse : delta) + lbase + qq;
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                       (__attribute__((address_space(3))) void*)(st + 8 * IMG32 + w * 64 * 4), 4, 0, 0);
+                                       (__attribute__((address_space(3))) void*)(st + 4 * IMG32 + w * 64 * 4), 4, 0, 0);
     }
   };
+  const unsigned t0 = tr_dual_t0(lane);
   if (ntiles > 0) issue(0);
   __builtin_assume(ntiles >= 1);
   for (int qt = 0; qt < ntiles; ++qt) {
@@ -372,23 +378,22 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd_dkv_x3(AttnM a, const bf16*
     attn_wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
     if (qt + 1 < ntiles) issue(qt + 1);
-    const unsigned char* Qrh = lds + (qt % NS) * STAGE;
-    const unsigned char* Qrl = Qrh + IMG32;
-    const unsigned char* Qth = Qrh + 2 * IMG32;
-    const unsigned char* Drh = Qrh + 4 * IMG32;
-    const unsigned char* Drl = Qrh + 5 * IMG32;
-    const unsigned char* Dth = Qrh + 6 * IMG32;
-    const float* Ls = (const float*)(Qrh + 8 * IMG32);
+    const unsigned char* Qh = ring + (qt % NS) * STAGE;
+    const unsigned char* Ql = Qh + IMG32;
+    const unsigned char* Dh = Qh + 2 * IMG32;
+    const unsigned char* Dl = Qh + 3 * IMG32;
+    const float* Ls = (const float*)(Qh + 4 * IMG32);
     const float* Ds = Ls + 64;
     const bool ragged = qb + QT > a.Tq;
     if ((a.causal && qb + QT - 1 < k0) || wave_all_masked) continue;
-    f32x16 s, dp, pd;
+    f32x16 s, dp;
 #pragma unroll
     for (int i = 0; i < 16; ++i) { s[i] = 0.f; dp[i] = 0.f; }
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-      s = mfma3(frag_row(Qrh, 0, ks, lane), frag_row(Qrl, 0, ks, lane), kh[ks], kl[ks], s);       // S[q][key]
-      dp = mfma3(frag_row(Drh, 0, ks, lane), frag_row(Drl, 0, ks, lane), vh[ks], vl[ks], dp);     // dP[q][key]
+      const bf16x8 kl = *(const bf16x8*)(my_l + ks * 1024), vl = *(const bf16x8*)(my_l + 4096 + ks * 1024);
+      s = mfma3(frag_row_dual(Qh, 0, ks, lane), frag_row_dual(Ql, 0, ks, lane), kh[ks], kl, s);       // S[q][key]
+      dp = mfma3(frag_row_dual(Dh, 0, ks, lane), frag_row_dual(Dl, 0, ks, lane), vh[ks], vl, dp);     // dP[q][key]
     }
     if (a.causal || ragged) {
 #pragma unroll
@@ -398,54 +403,68 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd_dkv_x3(AttnM a, const bf16*
         s[r] = msk ? -INFINITY : s[r];
       }
     }
+    // in place: s <- p = exp2(s * scale - lse[q]),  dp <- dS = p (keep dP - delta[q]),  s <- keep p
 #pragma unroll
     for (int g4 = 0; g4 < 4; ++g4) {
       const f32x4 Lq = *(const f32x4*)(Ls + 8 * g4 + 4 * h) * 1.4426950408889634f;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) pd[4 * g4 + j] = fast_exp2(fmaf(s[4 * g4 + j], a.scale_log2, -Lq[j]));
+      for (int j = 0; j < 4; ++j) s[4 * g4 + j] = fast_exp2(fmaf(s[4 * g4 + j], a.scale_log2, -Lq[j]));
     }
     if (DROP) {   // keep bits as in k_attn_bwd_dkv_mfma: the lanes of a key pair share one hash (DPP exchange)
       const uint32_t htk = (uint32_t)a.Tk >> 1;
       const uint32_t tb = (uint32_t)(lbase + qb + 4 * h + (lane & 1)) * htk + ((uint32_t)key >> 1);
       const uint32_t hshift = (lane & 1) << 4;
 #pragma unroll
-      for (int r = 0; r < 16; r += 2) {
-        const uint32_t own = hash_pair32(a.dd, tb + (uint32_t)ACC_ROW(r) * htk);
-        const uint32_t oth = (uint32_t)__builtin_amdgcn_mov_dpp((int)own, 0xB1, 0xF, 0xF, true);
-        const uint32_t h0 = (lane & 1) ? oth : own, h1 = (lane & 1) ? own : oth;
-        const float kp0 = ((h0 >> hshift) & 0xFFFFu) >= a.dd.thresh16 ? a.dd.scale16 : 0.f;
-        const float kp1 = ((h1 >> hshift) & 0xFFFFu) >= a.dd.thresh16 ? a.dd.scale16 : 0.f;
-        dp[r] *= kp0; dp[r + 1] *= kp1;
-        s[r] = pd[r]; s[r + 1] = pd[r + 1];
-        pd[r] *= kp0; pd[r + 1] *= kp1;
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const f32x4 Dq = *(const f32x4*)(Ds + 8 * g4 + 4 * h);
+#pragma unroll
+        for (int j = 0; j < 4; j += 2) {
+          const int r = 4 * g4 + j;
+          const uint32_t own = hash_pair32(a.dd, tb + (uint32_t)ACC_ROW(r) * htk);
+          const uint32_t oth = (uint32_t)__builtin_amdgcn_mov_dpp((int)own, 0xB1, 0xF, 0xF, true);
+          const uint32_t h0 = (lane & 1) ? oth : own, h1 = (lane & 1) ? own : oth;
+          const float kp0 = ((h0 >> hshift) & 0xFFFFu) >= a.dd.thresh16 ? a.dd.scale16 : 0.f;
+          const float kp1 = ((h1 >> hshift) & 0xFFFFu) >= a.dd.thresh16 ? a.dd.scale16 : 0.f;
+          dp[r] = (dp[r] * kp0 - Dq[j]) * s[r];
+          dp[r + 1] = (dp[r + 1] * kp1 - Dq[j + 1]) * s[r + 1];
+          s[r] *= kp0; s[r + 1] *= kp1;
+        }
       }
     } else {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) s[r] = pd[r];
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const f32x4 Dq = *(const f32x4*)(Ds + 8 * g4 + 4 * h);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dp[4 * g4 + j] = (dp[4 * g4 + j] - Dq[j]) * s[4 * g4 + j];
+      }
     }
+    // transposed-read address registers of this stage: base + (T0 ^ (delta << 4)) [^ 64 for the upper column half]
+    const unsigned sb = (unsigned)(uintptr_t)Qh;
+    unsigned xa[4], xb[4];
 #pragma unroll
-    for (int g4 = 0; g4 < 4; ++g4) {
-      const f32x4 Dq = *(const f32x4*)(Ds + 8 * g4 + 4 * h);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) s[4 * g4 + j] *= dp[4 * g4 + j] - Dq[j];
-    }
-    unsigned qa0, qa1, da0, da1;
-    tr_lane_addr(Qth, lane, qa0, qa1);
-    tr_lane_addr(Dth, lane, da0, da1);
-    const unsigned ql0 = qa0 + IMG32, ql1 = qa1 + IMG32, dl0 = da0 + IMG32, dl1 = da1 + IMG32;
-#pragma unroll
-    for (int sl = 0; sl < 2; ++sl) {   // 16-query slices
-      const TrQuad dh_ = tr_issue(da0, da1, 16 * sl), dl_ = tr_issue(dl0, dl1, 16 * sl);
-      const TrQuad qh_ = tr_issue(qa0, qa1, 16 * sl), ql_ = tr_issue(ql0, ql1, 16 * sl);
+    for (int d = 0; d < 4; ++d) { xa[d] = sb + (t0 ^ (d << 4)); xb[d] = sb + (t0 ^ (d << 4) ^ 64); }
+    {
+      const TrQuad dh0 = tr_quad_dual<2 * IMG32, 0>(xa, xb), dl0 = tr_quad_dual<3 * IMG32, 0>(xa, xb);
+      const TrQuad qh0 = tr_quad_dual<0, 0>(xa, xb), ql0 = tr_quad_dual<IMG32, 0>(xa, xb);
       bf16x8 ph, pl, sh, sl_;
-      split8(pd, sl, ph, pl);
-      split8(s, sl, sh, sl_);
+      split8(s, 0, ph, pl);
+      split8(dp, 0, sh, sl_);
       tr_wait<8>();
-      dv[0] = mfma3(tr_join(dh_.lo0, dh_.hi0), tr_join(dl_.lo0, dl_.hi0), ph, pl, dv[0]);
-      dv[1] = mfma3(tr_join(dh_.lo1, dh_.hi1), tr_join(dl_.lo1, dl_.hi1), ph, pl, dv[1]);
+      dv[0] = mfma3(tr_join(dh0.lo0, dh0.hi0), tr_join(dl0.lo0, dl0.hi0), ph, pl, dv[0]);
+      dv[1] = mfma3(tr_join(dh0.lo1, dh0.hi1), tr_join(dl0.lo1, dl0.hi1), ph, pl, dv[1]);
+      const TrQuad dh1 = tr_quad_dual<2 * IMG32, 1>(xa, xb), dl1 = tr_quad_dual<3 * IMG32, 1>(xa, xb);
+      tr_wait<8>();
+      dk[0] = mfma3(tr_join(qh0.lo0, qh0.hi0), tr_join(ql0.lo0, ql0.hi0), sh, sl_, dk[0]);
+      dk[1] = mfma3(tr_join(qh0.lo1, qh0.hi1), tr_join(ql0.lo1, ql0.hi1), sh, sl_, dk[1]);
+      const TrQuad qh1 = tr_quad_dual<0, 1>(xa, xb), ql1 = tr_quad_dual<IMG32, 1>(xa, xb);
+      split8(s, 1, ph, pl);
+      split8(dp, 1, sh, sl_);
+      tr_wait<8>();
+      dv[0] = mfma3(tr_join(dh1.lo0, dh1.hi0), tr_join(dl1.lo0, dl1.hi0), ph, pl, dv[0]);
+      dv[1] = mfma3(tr_join(dh1.lo1, dh1.hi1), tr_join(dl1.lo1, dl1.hi1), ph, pl, dv[1]);
       tr_wait<0>();
-      dk[0] = mfma3(tr_join(qh_.lo0, qh_.hi0), tr_join(ql_.lo0, ql_.hi0), sh, sl_, dk[0]);
-      dk[1] = mfma3(tr_join(qh_.lo1, qh_.hi1), tr_join(ql_.lo1, ql_.hi1), sh, sl_, dk[1]);
+      dk[0] = mfma3(tr_join(qh1.lo0, qh1.hi0), tr_join(ql1.lo0, ql1.hi0), sh, sl_, dk[0]);
+      dk[1] = mfma3(tr_join(qh1.lo1, qh1.hi1), tr_join(ql1.lo1, ql1.hi1), sh, sl_, dk[1]);
     }
   }
   if (kmasked) {
@@ -517,8 +536,8 @@ int afm_attn_bwd_x3_try(const afm_attn_shape* s, const void* Q, const void* K, c
   AttnM a = make_m_x3(s);
   a.lddq = lddq; a.lddk = lddk; a.lddv = lddv;
   const dim3 gq((s->Tq + 127) / 128, s->H, s->B), gk((s->Tk + 127) / 128, s->H, s->B);
-  const int shm_q = 2 * 6 * IMG32 + ((s->Tk + 63) / 64) * 8;
-  const int shm_k = 2 * (8 * IMG32 + 2 * 64 * 4);
+  const int shm_q = 2 * 4 * IMG32 + ((s->Tk + 63) / 64) * 8;
+  const int shm_k = 4 * 2 * 4096 + 2 * (4 * IMG32 + 2 * 64 * 4);
   if (shm_q > 80 * 1024) return AFM_ERR_UNSUPPORTED;
   static bool attr = false;
   if (!attr) {

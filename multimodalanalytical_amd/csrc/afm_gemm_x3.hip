@@ -337,6 +337,127 @@ static int launch_x3_nt(X3Args& g, hipStream_t st, bool staged_ok) {
   return AFM_OK;
 }
 
+// ------------------------------------------------------------------------------------------ NT, 256 x 256 tiles
+// Whole-tile problems with many tiles (the encoder's token count): 8 waves of 128 x 64 (2 x 4), no loader waves -- per
+// LDS-DMA piece the split-pair form issues three times the MFMAs of the single-pass kernel, so the waves can afford to
+// issue their own pieces -- two 64-KiB ring slots, 96 MFMAs per wave between barriers, a quarter less L2->LDS traffic
+// per FLOP than 256 x 128.  Whole tiles only (the dispatcher sends everything else to k_x3_nt).
+template <int CT, int EPI>
+__global__ __launch_bounds__(512) void k_x3_nt256(X3Args g) {
+  constexpr int NWN = 4, NW = 8, WM = 8, S = 2;
+  constexpr int TBM = 256, TBN = 256;
+  constexpr int NI = (TBM + TBN) / 8, NIW = NI / NW;
+  constexpr int STAGE = (TBM + TBN) * 128;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  float* bias_lds = (float*)(lds + S * STAGE);
+  const int t = threadIdx.x, lane = t & 63;
+  const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wm = w / NWN, wn = w % NWN;
+  const int ntiles = g.tiles_m * g.tiles_n;
+  for (int n = t; n < g.N; n += 64 * NW) bias_lds[n] = g.bias ? g.bias[n] : 0.f;
+  __syncthreads();
+  const int xcd = blockIdx.x & 7, bx = blockIdx.x >> 3, nbx = gridDim.x >> 3;
+  const int tpx = (ntiles + 7) >> 3;
+  const int tlo = xcd * tpx, thi = min(ntiles, tlo + tpx);
+  auto tile_of = [&](int it) { const int tt = tlo + it * nbx + bx; return tt < thi ? tt : -1; };
+  const int nk = g.K / 32;
+
+  const bf16* src[NIW];
+  auto set_src = [&](int tile) {
+    const int m0 = (tile / g.tiles_n) * TBM, n0 = (tile % g.tiles_n) * TBN;
+#pragma unroll
+    for (int j = 0; j < NIW; ++j) {
+      const int ii = w + NW * j;
+      const int r8 = lane >> 3, ch = (lane & 7) ^ r8;
+      const int koff = (ch & 3) * 8;
+      if (ii < TBM / 8) src[j] = g.A + (int64_t)(m0 + ii * 8 + r8) * g.lda + koff + (ch >> 2) * (g.lda >> 1);
+      else src[j] = g.B + (int64_t)(n0 + (ii - TBM / 8) * 8 + r8) * g.ldb + koff + (ch >> 2) * (g.ldb >> 1);
+    }
+  };
+  int is_it = 0, is_kt = 0, is_slot = 0;
+  int is_tile = tile_of(0);
+  if (is_tile >= 0) set_src(is_tile);
+  auto issue_one = [&]() {
+    if (is_tile < 0) return;
+    unsigned char* st = lds + is_slot * STAGE;
+#pragma unroll
+    for (int j = 0; j < NIW; ++j)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[j] + is_kt * 32),
+                                       (__attribute__((address_space(3))) void*)(st + (w + NW * j) * 1024), 16, 0, 0);
+    is_slot ^= 1;
+    if (++is_kt == nk) {
+      is_kt = 0;
+      is_tile = tile_of(++is_it);
+      if (is_tile >= 0) set_src(is_tile);
+    }
+  };
+  auto off = [](int row, int chunk) { return row * 128 + ((chunk ^ (row & 7)) << 4); };
+  issue_one();
+  const int fr = lane & 15, fq = lane >> 4;
+  int slot = 0;
+  for (int it = 0;; ++it) {
+    const int tile = tile_of(it);
+    if (tile < 0) break;
+    const int m0 = (tile / g.tiles_n) * TBM, n0 = (tile % g.tiles_n) * TBN;
+    f32x4 acc[4][WM];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int i = 0; i < WM; ++i) acc[j][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int kt = 0; kt < nk; ++kt) {
+      // only this step's pieces are in flight (two slots); behind them, at a tile boundary, sit the >= 32 stores of the
+      // previous tile's epilogue, which may stay outstanding under this tile's first MFMAs (in-order counter)
+      if (it > 0 && kt == 0) x3_wait_vmcnt<32>(); else x3_wait_vmcnt<0>();
+      __builtin_amdgcn_s_barrier();
+      issue_one();
+      const unsigned char* a = lds + slot * STAGE;
+      const unsigned char* b = a + TBM * 128;
+      slot ^= 1;
+      bf16x8 bh[4], bl[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        bh[j] = *(const bf16x8*)(b + off(wn * 64 + j * 16 + fr, fq));
+        bl[j] = *(const bf16x8*)(b + off(wn * 64 + j * 16 + fr, 4 + fq));
+      }
+#pragma unroll
+      for (int i = 0; i < WM; ++i) {
+        const bf16x8 ah = *(const bf16x8*)(a + off(wm * 16 * WM + i * 16 + fr, fq));
+        const bf16x8 al = *(const bf16x8*)(a + off(wm * 16 * WM + i * 16 + fr, 4 + fq));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl[j], ah, acc[j][i], 0, 0, 0);
+          acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[j], al, acc[j][i], 0, 0, 0);
+          acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[j], ah, acc[j][i], 0, 0, 0);
+        }
+      }
+    }
+    // stage through the slot read by the last k-step (the other one is receiving the next tile's first step)
+    __builtin_amdgcn_s_barrier();
+    float* stg = (float*)(lds + (slot ^ 1) * STAGE) + w * (16 * X3_STG_LD);
+    x3_epilogue_staged<CT, EPI, WM>(g, stg, bias_lds, acc, m0 + wm * 16 * WM, n0 + wn * 64, lane);
+  }
+}
+
+template <int CT, int EPI>
+static int launch_x3_nt256(X3Args& g, hipStream_t st) {
+  constexpr int ring = 2 * 512 * 128;
+  g.tiles_m = g.M / 256; g.tiles_n = g.N / 256;
+  const int bias_bytes = ((g.N * 4 + 15) / 16) * 16;
+  if (ring + bias_bytes > 160 * 1024) return AFM_ERR_UNSUPPORTED;
+  g.bias_in_lds = 1;
+  auto kern = k_x3_nt256<CT, EPI>;
+  static bool attr_done = false;   // per instantiation
+  if (!attr_done) {
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_done = true;
+  }
+  int grid = 256;
+  const int ntiles = g.tiles_m * g.tiles_n;
+  if (grid > ((ntiles + 7) / 8) * 8) grid = ((ntiles + 7) / 8) * 8;
+  AFM_LAUNCH(kern, dim3(grid), dim3(512), ring + bias_bytes, st, g);
+  return AFM_OK;
+}
+
 // ------------------------------------------------------------------------------------------ TN (wgrad)
 // Stage = 64 LDS rows x (256 A columns + 128 B columns): rows 0-31 the hi plane of 32 token rows, rows 32-63 their lo
 // plane; 16-byte chunks XOR-swizzled as in k_gemm_tn_ring; fragments by ds_read_b64_tr_b16 (inline asm, hand-waited).
@@ -485,6 +606,147 @@ __global__ __launch_bounds__(512, 2) void k_x3_tn(X3Args g) {
     }
 }
 
+// Same kernel on 256 x 256 tiles (8 waves of 128 x 64, two 64-KiB ring slots): a quarter less L2->LDS fill and a quarter
+// fewer transposed LDS reads per FLOP, 96 MFMAs per wave between barriers; needs more split-K (fewer tiles).
+__global__ __launch_bounds__(512) void k_x3_tn256(X3Args g) {
+  constexpr int S = 2, TBM = 256, TBN = 256, NW = 8, NIW = 8;
+  constexpr int ABYTES = 64 * TBM * 2, STAGE = 64 * (TBM + TBN) * 2;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  const int t = threadIdx.x, lane = t & 63;
+  const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wm = w >> 2, wn = w & 3;
+  const int ntile = g.tiles_m * g.tiles_n;
+  const int q8 = (ntile * g.ksplit) >> 3, r8 = (ntile * g.ksplit) & 7, xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+  const int bid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
+  const int tile = bid % ntile, ks_id = bid / ntile;
+  const int m0 = (tile / g.tiles_n) * TBM, n0 = (tile % g.tiles_n) * TBN;
+  const int kbeg = ks_id * g.kchunk, kend = min(g.K, kbeg + g.kchunk);
+  const int nk = (kend - kbeg) / 32;
+
+  const bf16* src[NIW];
+  int64_t pitch[NIW];
+#pragma unroll
+  for (int j = 0; j < NIW; ++j) {
+    const int ii = w + NW * j;
+    const int r = (ii & 31) * 2 + (lane >> 5);          // LDS row 0..63: plane r >> 5, token row r & 31
+    const int c = (lane & 31) ^ x3_tn_swz(r);
+    if (ii < 32) {
+      src[j] = g.A + (int64_t)(kbeg + (r & 31)) * g.lda + (r >> 5) * (g.lda >> 1) + min(m0 + c * 8, g.M - 8);
+      pitch[j] = (int64_t)32 * g.lda;
+    } else {
+      src[j] = g.B + (int64_t)(kbeg + (r & 31)) * g.ldb + (r >> 5) * (g.ldb >> 1) + min(n0 + c * 8, g.N - 8);
+      pitch[j] = (int64_t)32 * g.ldb;
+    }
+  }
+  auto issue = [&](int kt) {
+    unsigned char* st = lds + (kt % S) * STAGE;
+#pragma unroll
+    for (int j = 0; j < NIW; ++j)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[j] + kt * pitch[j]),
+                                       (__attribute__((address_space(3))) void*)(st + (w + NW * j) * 1024), 16, 0, 0);
+  };
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const bool do_cs = g.a_colsum != nullptr && (tile % g.tiles_n) == 0 && wn == 0;
+  float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (nk > 0) issue(0);
+  const int grp = lane >> 4, q = (lane >> 2) & 3, p = lane & 3;
+  int laneA[8], laneB[4];
+  {
+    const int lrow = grp * 8 + q, swz = x3_tn_swz(lrow), sub = (p & 1) << 3;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) laneA[i] = lrow * 512 + (((((wm * 128 + i * 16) >> 3) + (p >> 1)) ^ swz) << 4) + sub;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) laneB[j] = ABYTES + lrow * 512 + (((((wn * 64 + j * 16) >> 3) + (p >> 1)) ^ swz) << 4) + sub;
+  }
+  for (int kt = 0; kt < nk; ++kt) {
+    x3_wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    if (kt + 1 < nk) issue(kt + 1);
+    const unsigned sbase = (unsigned)(uintptr_t)(lds + (kt % S) * STAGE);
+    x3_s16x4 b0[2][4], b1[2][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const unsigned vb = sbase + (unsigned)laneB[j];
+      asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(b0[0][j]) : "v"(vb));
+      asm volatile("ds_read_b64_tr_b16 %0, %1 offset:2048" : "=v"(b1[0][j]) : "v"(vb));
+      asm volatile("ds_read_b64_tr_b16 %0, %1 offset:16384" : "=v"(b0[1][j]) : "v"(vb));
+      asm volatile("ds_read_b64_tr_b16 %0, %1 offset:18432" : "=v"(b1[1][j]) : "v"(vb));
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    bf16x8 bfr[2][4];
+#pragma unroll
+    for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const bf16x4 y0 = __builtin_bit_cast(bf16x4, b0[pl][j]), y1 = __builtin_bit_cast(bf16x4, b1[pl][j]);
+        bfr[pl][j] = (bf16x8){y0[0], y0[1], y0[2], y0[3], y1[0], y1[1], y1[2], y1[3]};
+      }
+#pragma unroll
+    for (int ih = 0; ih < 2; ++ih) {        // four A fragments at a time (register budget)
+      x3_s16x4 a0[2][4], a1[2][4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const unsigned va = sbase + (unsigned)laneA[ih * 4 + i];
+        asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(a0[0][i]) : "v"(va));
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:2048" : "=v"(a1[0][i]) : "v"(va));
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:16384" : "=v"(a0[1][i]) : "v"(va));
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:18432" : "=v"(a1[1][i]) : "v"(va));
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const bf16x4 h0 = __builtin_bit_cast(bf16x4, a0[0][i]), h1 = __builtin_bit_cast(bf16x4, a1[0][i]);
+        const bf16x4 l0 = __builtin_bit_cast(bf16x4, a0[1][i]), l1 = __builtin_bit_cast(bf16x4, a1[1][i]);
+        const bf16x8 ah = (bf16x8){h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
+        const bf16x8 al = (bf16x8){l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
+        if (do_cs) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) cs[ih * 4 + i] += (float)ah[e] + (float)al[e];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          acc[ih * 4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bfr[1][j], acc[ih * 4 + i][j], 0, 0, 0);
+          acc[ih * 4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bfr[0][j], acc[ih * 4 + i][j], 0, 0, 0);
+          acc[ih * 4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bfr[0][j], acc[ih * 4 + i][j], 0, 0, 0);
+        }
+      }
+    }
+  }
+  const int fr = lane & 15, fq = lane >> 4;
+  if (do_cs) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      float s = cs[i];
+      s += __shfl_xor(s, 16, 64);
+      s += __shfl_xor(s, 32, 64);
+      const int mm = m0 + wm * 128 + i * 16 + fr;
+      if (fq == 0 && mm < g.M) atomicAdd(g.a_colsum + mm, s);
+    }
+  }
+  float* C = (float*)g.C;
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = n0 + wn * 64 + j * 16 + fr;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int mm = m0 + wm * 128 + i * 16 + fq * 4 + r;
+        if (mm < g.M && n < g.N) {
+          float* c = C + (int64_t)mm * g.ldc + n;
+          if (g.ksplit > 1) atomicAdd(c, acc[i][j][r]);
+          else *c = acc[i][j][r] + (g.accumulate ? *c : 0.f);
+        }
+      }
+    }
+}
+
 // ------------------------------------------------------------------------------------------ dispatch
 static inline bool x3_al16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
@@ -505,11 +767,22 @@ int afm_gemm_x3_try(const afm_gemm_desc* d, hipStream_t st) {
     if (d->bias && !x3_al16(d->bias)) return AFM_ERR_UNSUPPORTED;
     if (!x3_al16(d->C) || (d->residual && !x3_al16(d->residual)) || (d->pre_act && !x3_al16(d->pre_act))) return AFM_ERR_UNSUPPORTED;
     const bool small_idx = (uint64_t)d->M * (uint64_t)d->N <= 0x100000000ull;
+    // 256 x 256 tiles: whole tiles, enough of them to fill the chip twice over; reserved = 31 / 32 force a form (tools)
+    const bool big = d->reserved != 31 && !(d->M & 255) && !(d->N & 255) && (d->ldc % 8) == 0 &&
+                     (d->reserved == 32 || (int64_t)(d->M >> 8) * (d->N >> 8) >= 512);
     int r;
     if (d->c_dtype == AFM_F32) {
       if (d->act != AFM_ACT_NONE || d->pre_act || d->drop.p > 0.f) return AFM_ERR_UNSUPPORTED;   // exact-fp32 kernel
       const bool staged = (d->N % 4) == 0 && (d->ldc % 4) == 0;
-      r = launch_x3_nt<X3_F32, XE_GENERIC>(g, st, staged);
+      if (big && staged) r = launch_x3_nt256<X3_F32, XE_GENERIC>(g, st);
+      else r = launch_x3_nt<X3_F32, XE_GENERIC>(g, st, staged);
+    } else if (big && !d->residual && !d->accumulate && (small_idx || d->drop.p <= 0.f) && (d->ldc & 15) == 0 &&
+               d->act != AFM_ACT_RELU && !(d->act == AFM_ACT_NONE && (d->pre_act || d->drop.p > 0.f))) {
+      if (d->act == AFM_ACT_GELU_SAVE_GRAD) r = launch_x3_nt256<X3_X2, XE_GELU_SG>(g, st);
+      else if (d->act == AFM_ACT_MUL_SAVED) r = launch_x3_nt256<X3_X2, XE_MUL>(g, st);
+      else if (d->act == AFM_ACT_GELU_BWD) r = launch_x3_nt256<X3_X2, XE_GELU_BWD>(g, st);
+      else if (d->act == AFM_ACT_GELU) r = launch_x3_nt256<X3_X2, XE_GELU>(g, st);
+      else r = launch_x3_nt256<X3_X2, XE_PLAIN>(g, st);
     } else {
       if ((d->ldc & 15) || d->act == AFM_ACT_RELU) return AFM_ERR_UNSUPPORTED;
       // compile-time staged epilogues for the training step's forms; anything else keeps the fragment epilogue
@@ -529,6 +802,32 @@ int afm_gemm_x3_try(const afm_gemm_desc* d, hipStream_t st) {
         (d->a_colsum && ((uintptr_t)d->a_colsum & 3)))
       return AFM_ERR_UNSUPPORTED;
     if ((d->M & 7) || (d->N & 7) || (d->K & 31) || d->K < 32 || d->M < 64 || d->N < 64) return AFM_ERR_UNSUPPORTED;
+    // 256 x 256 tiles for long token counts and gradient matrices with >= 8 such tiles (as the single-pass kernel);
+    // reserved = 105 / 106 force a form (tools)
+    const bool want256 = d->reserved == 105 || (d->reserved != 106 && d->K >= 65536 &&
+                                                 (int64_t)((d->M + 255) / 256) * ((d->N + 255) / 256) >= 8);
+    if (want256 && d->M >= 256 && d->N >= 256) {
+      g.tiles_m = (d->M + 255) / 256; g.tiles_n = (d->N + 255) / 256;
+      const int tiles = g.tiles_m * g.tiles_n;
+      int ksplit = tiles >= 256 ? 1 : 256 / tiles;
+      const int maxs = d->K / 512;
+      if (ksplit > maxs) ksplit = maxs;
+      if (ksplit < 1) ksplit = 1;
+      int kchunk = ((d->K / 32 + ksplit - 1) / ksplit) * 32;
+      ksplit = (d->K + kchunk - 1) / kchunk;
+      g.ksplit = ksplit; g.kchunk = kchunk;
+      if (ksplit > 1 && !d->accumulate) {
+        if (hipMemset2DAsync(d->C, sizeof(float) * d->ldc, 0, sizeof(float) * d->N, d->M, st) != hipSuccess) return AFM_ERR_LAUNCH;
+      }
+      static bool attr256 = false;
+      if (!attr256) {
+        (void)hipFuncSetAttribute((const void*)k_x3_tn256, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 64 * 512 * 2);
+        attr256 = true;
+      }
+      AFM_LAUNCH(k_x3_tn256, dim3(tiles * ksplit), dim3(512), 2 * 64 * 512 * 2, st, g);
+      afm_set_last_algo(ksplit > 1 ? "mfma_tn_x3_256_splitk" : "mfma_tn_x3_256");
+      return AFM_OK;
+    }
     g.tiles_m = (d->M + 255) / 256; g.tiles_n = (d->N + 127) / 128;
     const int tiles = g.tiles_m * g.tiles_n;
     int ksplit = tiles >= 256 ? 1 : 256 / tiles;

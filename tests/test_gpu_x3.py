@@ -180,3 +180,46 @@ def test_attention_x3(ops, B, H, Tq, Tk, causal, pad, pdrop):
     for name, got, r, T in (("dq", dq, qr, Tq), ("dk", dk, kr, Tk), ("dv", dv, vr, Tk)):
         want = r.grad.transpose(1, 2).reshape(B * T, D)
         assert relnorm(got.float(), want) < 5e-5, (name, relnorm(got.float(), want))
+
+
+@pytest.mark.parametrize("M,N,K", [(512, 256, 512), (1024, 768, 96), (768, 512, 2048)])
+def test_gemm_x3_nt_256_tiles(ops, M, N, K):
+    """The 256 x 256 whole-tile form (picked by itself for >= 512 tiles; forced here with variant 32) on every epilogue."""
+    from multimodalanalytical_amd.x2 import X2
+    a, w, bias = rnd(M, K, seed=1) * 0.3, rnd(N, K, seed=2) * 0.3, rnd(N, seed=3)
+    t = a.double() @ w.double().T + bias.double()
+    A, W = x2(a), x2(w)
+    c = X2.empty(M, N, DEV)
+    ops.gemm(A, W, c, bias=dev(bias), algo=2, variant=32)
+    assert ops.last_algo() == "mfma_nt_x3" and relnorm(c.float(), t) < 1e-5
+    cf = torch.empty(M, N, device=DEV)
+    ops.gemm(A, W, cf, bias=dev(bias), algo=2, variant=32)
+    assert relnorm(cf, t) < 1e-5
+    p, seed, site = 0.1, 99, 5
+    keep = torch.from_numpy(keep_mask(p, seed, site, M * N)).view(M, N).double() / (1 - p)
+    gp = 0.5 * (1 + torch.erf(t / math.sqrt(2))) + t * torch.exp(-t * t / 2) / math.sqrt(2 * math.pi)
+    gel = 0.5 * t * (1 + torch.erf(t / math.sqrt(2)))
+    c2, sg = X2.empty(M, N, DEV), X2.empty(M, N, DEV)
+    ops.gemm(A, W, c2, bias=dev(bias), act=4, pre_act=sg, dropout=ops.drop(p, seed, site), algo=2, variant=32)
+    assert relnorm(c2.float(), gel * keep) < 2e-5 and relnorm(sg.float(), gp * keep) < 2e-5
+    c3 = X2.empty(M, N, DEV)
+    ops.gemm(A, W, c3, act=5, pre_act=sg, algo=2, variant=32)
+    assert relnorm(c3.float(), (t - bias.double()) * gp * keep) < 3e-5
+    c4, pre = X2.empty(M, N, DEV), X2.empty(M, N, DEV)
+    ops.gemm(A, W, c4, bias=dev(bias), act=2, pre_act=pre, algo=2, variant=32)
+    assert relnorm(c4.float(), gel) < 2e-5 and relnorm(pre.float(), t) < 1e-5
+    # two back-to-back launches into the same output stay correct (ring / epilogue hand-over between tiles)
+    ops.gemm(A, W, c, bias=dev(bias), algo=2, variant=32)
+    ops.gemm(A, W, c, bias=dev(bias), algo=2, variant=32)
+    assert relnorm(c.float(), t) < 1e-5
+
+
+@pytest.mark.parametrize("R,M,N", [(4096, 512, 512), (8192, 768, 256), (1056, 256, 520)])
+def test_gemm_x3_tn_256_tiles(ops, R, M, N):
+    dy, x = rnd(R, M, seed=1), rnd(R, N, seed=2)
+    gw, gb = dev(rnd(M, N, seed=3)), dev(rnd(M, seed=4))
+    ref = gw.cpu().double() + dy.double().T @ x.double()
+    refb = gb.cpu().double() + dy.double().sum(0)
+    ops.gemm(x2(dy), x2(x), gw, trans_a=True, trans_b=False, accumulate=True, a_colsum=gb, algo=2, variant=105)
+    assert ops.last_algo().startswith("mfma_tn_x3_256")
+    assert relnorm(gw, ref) < 1e-5 and relnorm(gb, refb) < 1e-5
