@@ -39,7 +39,7 @@ extern "C" {
 enum { AFM_OK = 0, AFM_ERR_ARG = -1, AFM_ERR_UNSUPPORTED = -2, AFM_ERR_LAUNCH = -3 };
 enum { AFM_F32 = 0, AFM_BF16 = 1, AFM_BF16X2 = 2 };
 enum { AFM_ACT_NONE = 0, AFM_ACT_RELU = 1, AFM_ACT_GELU = 2, AFM_ACT_GELU_BWD = 3,
-       AFM_ACT_GELU_SAVE_GRAD = 4, AFM_ACT_MUL_SAVED = 5 };
+       AFM_ACT_GELU_SAVE_GRAD = 4, AFM_ACT_MUL_SAVED = 5, AFM_ACT_GLU = 6, AFM_ACT_GLU_SAVE = 7, AFM_ACT_GLU_BWD = 8 };
 enum { AFM_ALGO_AUTO = 0, AFM_ALGO_GENERIC = 1, AFM_ALGO_MFMA = 2 };
 
 int afm_abi_version(void);
@@ -83,6 +83,16 @@ typedef struct {
  * C = dropout(gelu(T)) and pre_act <- keep * scale * gelu'(T) (same keep bits), so the dgrad needs neither
  * erf nor the dropout hash: act == AFM_ACT_MUL_SAVED computes C = T * pre_act (pre_act an INPUT, no bias /
  * dropout).  dropout'(dy W2) * gelu'(u) = (dy W2) * [keep * scale * gelu'(u)]: identical values.
+ * Gated FFN (custom_modeling.py:137-152,184-199: W2 (gelu(W1 h) * (Wg h))), fused into the projections.  The up-projection
+ * runs as ONE GEMM over the (2f x d) matrix [W1 ; Wg] whose rows are INTERLEAVED in groups of four (rows 8i..8i+3 = W1 rows
+ * 4i..4i+3, rows 8i+4..8i+7 = Wg rows 4i..4i+3: afm_cast_weights with glu_rows = f), so one lane of the epilogue holds u and v of
+ * the same hidden units.  bias / a_colsum / the wgrad's C stay in the reference's [W1 ; Wg] order: glu_rows = f in the descriptor
+ * makes the kernels translate.   act == AFM_ACT_GLU:       N = 2f, C is M x f:  C = dropout(gelu(u) * v)
+ *                                 act == AFM_ACT_GLU_SAVE:  also pre_act (M x 2f, interleaved) <- keep*scale*[gelu'(u) v | gelu(u)]
+ *                                 act == AFM_ACT_GLU_BWD:   N = f (the dgrad dg = dy W2), C is M x 2f interleaved:
+ *                                                           C = [dg * saved_a | dg * saved_b] = [du | dv], pre_act an INPUT
+ * (dropout element index = row-major in the M x f tensor g, as afm_glu_fwd).  MFMA kernels, whole tiles only; other shapes
+ * return AFM_ERR_UNSUPPORTED and the caller keeps the unfused afm_glu_fwd / afm_glu_bwd path.
  * bf16 operands take the MFMA path (v_mfma_f32_16x16x32_bf16 / 32x32x16, fp32 accumulate) when
  * shape/alignment allow; everything else takes the exact-fp32 FMA path.
  * ---------------------------------------------------------------------------------------- */
@@ -104,6 +114,8 @@ typedef struct {
   int32_t algo;           /* AFM_ALGO_* */
   int32_t reserved;
   afm_dropout drop;
+  int32_t glu_rows;       /* f > 0: gated-FFN interleave (see above); wgrad form: rows of C / a_colsum are de-interleaved */
+  int32_t reserved2;
 } afm_gemm_desc;
 int afm_gemm(const afm_gemm_desc* d, void* stream);
 
@@ -235,6 +247,10 @@ int afm_cast_bf16(const float* src, void* dst, void* dst_t, int32_t rows, int32_
 /* The same for the split-pair dtype: dst is (rows x cols) AFM_BF16X2 with row stride 2*cols, dst_t the
  * transpose (cols x rows) with row stride 2*rows. */
 int afm_cast_x2(const float* src, void* dst, void* dst_t, int32_t rows, int32_t cols, void* stream);
+/* Both of the above with the gated-FFN row interleave: dtype AFM_BF16 or AFM_BF16X2; glu_rows = f > 0 (rows = 2f): source row
+ * r (r < f: W1, else Wg) lands in row ((j>>2)<<3) + (j&3) + 4*(r >= f), j = r mod f, of dst (column of dst_t). */
+int afm_cast_weights(const float* src, void* dst, void* dst_t, int32_t rows, int32_t cols, int32_t dtype, int32_t glu_rows,
+                     void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Encoder alignment head (custom_modeling.py:363-396 network, 453-475 use).

@@ -337,3 +337,54 @@ extern "C" int afm_cast_x2(const float* src, void* dst, void* dst_t, int32_t row
                      (hipStream_t)stream, src, (bf16*)dst, (bf16*)dst_t, rows, cols);
   return AFM_OK;
 }
+
+// ---------------------------------------------------------------- weight shadows with the gated-FFN interleave
+__device__ __forceinline__ int glu_interleave(int r, int f) {   // row r of [W1 ; Wg] -> row of the interleaved matrix
+  const int j = r < f ? r : r - f;
+  return ((j >> 2) << 3) + (j & 3) + (r < f ? 0 : 4);
+}
+template <bool X2T>
+__global__ void k_cast_weights(const float* __restrict__ src, bf16* __restrict__ dst, bf16* __restrict__ dst_t, int rows,
+                               int cols, int glu_f) {
+  __shared__ float tile[64][65];
+  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int ldd = X2T ? 2 * cols : cols, ldt = X2T ? 2 * rows : rows;
+  for (int i = ty; i < 64; i += 4) {
+    const int r = r0 + i, c = c0 + tx;
+    float v = 0.f;
+    if (r < rows && c < cols) {
+      v = src[(int64_t)r * cols + c];
+      if (dst) {
+        const int rd = glu_f ? glu_interleave(r, glu_f) : r;
+        bf16 hi, lo;
+        afm_split(v, hi, lo);
+        dst[(int64_t)rd * ldd + c] = hi;
+        if (X2T) dst[(int64_t)rd * ldd + cols + c] = lo;
+      }
+    }
+    tile[i][tx] = v;
+  }
+  if (!dst_t) return;
+  __syncthreads();
+  for (int i = ty; i < 64; i += 4) {
+    const int c = c0 + i, r = r0 + tx;
+    if (r < rows && c < cols) {
+      const int rd = glu_f ? glu_interleave(r, glu_f) : r;
+      bf16 hi, lo;
+      afm_split(tile[tx][i], hi, lo);
+      dst_t[(int64_t)c * ldt + rd] = hi;
+      if (X2T) dst_t[(int64_t)c * ldt + rows + rd] = lo;
+    }
+  }
+}
+extern "C" int afm_cast_weights(const float* src, void* dst, void* dst_t, int32_t rows, int32_t cols, int32_t dtype,
+                                int32_t glu_rows, void* stream) {
+  if (!src || (!dst && !dst_t) || rows <= 0 || cols <= 0 || glu_rows < 0) return AFM_ERR_ARG;
+  if (glu_rows && (rows != 2 * glu_rows || (glu_rows & 3))) return AFM_ERR_ARG;
+  const dim3 grid((cols + 63) / 64, (rows + 63) / 64);
+  if (dtype == AFM_BF16) AFM_LAUNCH(k_cast_weights<false>, grid, dim3(256), 0, (hipStream_t)stream, src, (bf16*)dst, (bf16*)dst_t, rows, cols, glu_rows);
+  else if (dtype == AFM_BF16X2) AFM_LAUNCH(k_cast_weights<true>, grid, dim3(256), 0, (hipStream_t)stream, src, (bf16*)dst, (bf16*)dst_t, rows, cols, glu_rows);
+  else return AFM_ERR_ARG;
+  return AFM_OK;
+}

@@ -288,12 +288,17 @@ extern "C" int afm_gemm(const afm_gemm_desc* d, void* stream) {
   if (d->M < 0 || d->N < 0 || d->K < 0) return AFM_ERR_ARG;
   if (d->a_dtype < AFM_F32 || d->a_dtype > AFM_BF16X2 || d->b_dtype < AFM_F32 || d->b_dtype > AFM_BF16X2 ||
       d->c_dtype < AFM_F32 || d->c_dtype > AFM_BF16X2) return AFM_ERR_ARG;
-  if (d->act < AFM_ACT_NONE || d->act > AFM_ACT_MUL_SAVED) return AFM_ERR_ARG;
-  if (d->act >= AFM_ACT_GELU_BWD && !d->pre_act) return AFM_ERR_ARG;
+  if (d->act < AFM_ACT_NONE || d->act > AFM_ACT_GLU_BWD) return AFM_ERR_ARG;
+  const bool glu = d->act >= AFM_ACT_GLU;
+  if (d->act >= AFM_ACT_GELU_BWD && d->act != AFM_ACT_GLU && !d->pre_act) return AFM_ERR_ARG;
+  if (glu && (d->glu_rows <= 0 || (d->glu_rows & 3) || d->transA || !d->transB ||
+              d->N != (d->act == AFM_ACT_GLU_BWD ? d->glu_rows : 2 * d->glu_rows)))
+    return AFM_ERR_ARG;
   if (d->act == AFM_ACT_MUL_SAVED && (d->bias || d->drop.p > 0.f)) return AFM_ERR_ARG;
   {  // split-pair rows hold two planes: ld >= 2 * width, even
     const int ca = d->a_dtype == AFM_BF16X2 ? 2 : 1, cb = d->b_dtype == AFM_BF16X2 ? 2 : 1, cc = d->c_dtype == AFM_BF16X2 ? 2 : 1;
-    if (d->ldc < cc * d->N || (cc == 2 && (d->ldc & 1))) return AFM_ERR_ARG;
+    const int ncol_c = d->act == AFM_ACT_GLU_BWD ? 2 * d->N : (d->act == AFM_ACT_GLU || d->act == AFM_ACT_GLU_SAVE) ? d->N / 2 : d->N;
+    if (d->ldc < cc * ncol_c || (cc == 2 && (d->ldc & 1))) return AFM_ERR_ARG;
     if (d->lda < ca * (d->transA ? d->M : d->K) || d->ldb < cb * (d->transB ? d->K : d->N)) return AFM_ERR_ARG;
     if ((ca == 2 && (d->lda & 1)) || (cb == 2 && (d->ldb & 1))) return AFM_ERR_ARG;
   }
@@ -305,5 +310,7 @@ extern "C" int afm_gemm(const afm_gemm_desc* d, void* stream) {
     if (r != AFM_ERR_UNSUPPORTED) return r;
     if (d->algo == AFM_ALGO_MFMA) return AFM_ERR_UNSUPPORTED;
   }
+  if (glu) return AFM_ERR_UNSUPPORTED;        // fused gated FFN: MFMA kernels only (the caller keeps afm_glu_fwd / afm_glu_bwd)
+  if (d->glu_rows && d->transA) return AFM_ERR_UNSUPPORTED;
   return gemm_generic(d, st);
 }

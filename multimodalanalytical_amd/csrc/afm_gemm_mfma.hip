@@ -29,6 +29,7 @@ struct MfmaArgs {
   int tiles_m, tiles_n;
   int ksplit, kchunk;  // TN only
   int bias_in_lds;     // persistent NT: staged epilogue enabled (bias vector cached in LDS)
+  int glu_f;           // gated-FFN interleave (include/afm_hip.h): bias / wgrad rows are translated to the [W1 ; Wg] order
   unsigned long long* stamps;   // ablation builds: per-workgroup phase time stamps (wall_clock64), else null
   DropDev dd;
 };
@@ -36,6 +37,9 @@ struct MfmaArgs {
 #define BM 128
 #define BN 128
 #define BK 64
+
+// interleaved row / column n of the gated up-projection -> its index in the reference's [W1 ; Wg] order
+__device__ __forceinline__ int glu_deint(int n, int f) { return ((n >> 3) << 2) + (n & 3) + ((n >> 2) & 1) * f; }
 
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
   // bijective "each XCD gets a contiguous chunk" renumbering (8 XCDs, round-robin dispatch)
@@ -355,7 +359,11 @@ __device__ __forceinline__ void epilogue_staged(const MfmaArgs& g, float* stg, c
 //   EPI_MUL       C = acc * pre_act                (the dgrad partner of EPI_GELU_SG: no erf, no hash)
 // Dropout indices are 32-bit here (the dispatcher requires M*N <= 2^32, where the stream's high-word
 // term is zero), which also removes a 64-bit multiply-add chain per element group.
-enum { EPI_GENERIC = 0, EPI_PLAIN = 1, EPI_DROP = 2, EPI_GELU = 3, EPI_GELU_BWD = 4, EPI_GELU_SG = 5, EPI_MUL = 6 };
+//   EPI_GLU / EPI_GLU_SG  gated FFN forward on the interleaved (2f-wide) accumulators: C (f wide) = dropout(gelu(u) * v)
+//                         [SG: pre_act (2f wide) = keep*scale*[gelu'(u) v | gelu(u)]]
+//   EPI_GLU_BWD           accumulators = dg (f wide): C (2f wide, interleaved) = [dg * saved_a | dg * saved_b]
+enum { EPI_GENERIC = 0, EPI_PLAIN = 1, EPI_DROP = 2, EPI_GELU = 3, EPI_GELU_BWD = 4, EPI_GELU_SG = 5, EPI_MUL = 6,
+       EPI_GLU = 7, EPI_GLU_SG = 8, EPI_GLU_BWD = 9 };
 __device__ __forceinline__ float afm_drop32(const DropDev& d, uint32_t idx, float x) {
   return afm_lowbias32(idx ^ d.key) >= d.thresh ? x * d.scale : 0.f;
 }
@@ -366,7 +374,9 @@ __device__ __forceinline__ void epilogue_staged_bf16(const MfmaArgs& g, float* s
   const int c8 = (lane & 7) * 8, r8 = lane >> 3;
   const int n = nw + c8;
   f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = {0.f, 0.f, 0.f, 0.f};
-  if (EPI != EPI_GELU_BWD && EPI != EPI_MUL && g.bias) { b0 = *(const f32x4*)(bias_lds + n); b1 = *(const f32x4*)(bias_lds + n + 4); }
+  if constexpr (EPI == EPI_GLU || EPI == EPI_GLU_SG) {   // u / v biases of hidden units (n >> 1) .. +3, reference order [b1 ; bg]
+    if (g.bias) { b0 = *(const f32x4*)(g.bias + (n >> 1)); b1 = *(const f32x4*)(g.bias + g.glu_f + (n >> 1)); }
+  } else if (EPI != EPI_GELU_BWD && EPI != EPI_MUL && EPI != EPI_GLU_BWD && g.bias) { b0 = *(const f32x4*)(bias_lds + n); b1 = *(const f32x4*)(bias_lds + n + 4); }
   const bool drop_on = g.dd.thresh != 0;   // wave-uniform
   bf16* const cbase = (bf16*)g.C + (int64_t)(mw + r8) * g.ldc + n;
   bf16* const pbase = (bf16*)g.pre_act + (int64_t)(mw + r8) * g.ldc + n;
@@ -392,6 +402,42 @@ __device__ __forceinline__ void epilogue_staged_bf16(const MfmaArgs& g, float* s
       float x[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
       const int64_t ro = (int64_t)(q * 8) * g.ldc;
       const uint32_t di = dbase + (uint32_t)(q * 8) * (uint32_t)g.N;
+      if constexpr (EPI == EPI_GLU || EPI == EPI_GLU_SG) {
+        // x[0..3] = u, x[4..7] = v of hidden units (n >> 1) .. +3; C and the dropout stream are f = N/2 wide
+        const int64_t rowi = mw + r8 + q * 8;
+        const int hcol = n >> 1;
+        const uint32_t dg0 = (uint32_t)rowi * (uint32_t)(g.N >> 1) + (uint32_t)hcol;
+        float gv[4], sa[4], sb[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          float y, yp;
+          afm_gelu_both(x[k], y, yp);
+          const float keep = drop_on ? afm_drop32(g.dd, dg0 + k, 1.0f) : 1.0f;
+          gv[k] = y * x[4 + k] * keep; sa[k] = yp * x[4 + k] * keep; sb[k] = y * keep;
+        }
+        bf16x4 o = {(bf16)gv[0], (bf16)gv[1], (bf16)gv[2], (bf16)gv[3]};
+        *(bf16x4*)((bf16*)g.C + rowi * g.ldc + hcol) = o;
+        if (EPI == EPI_GLU_SG) {
+          bf16x8 sv = {(bf16)sa[0], (bf16)sa[1], (bf16)sa[2], (bf16)sa[3], (bf16)sb[0], (bf16)sb[1], (bf16)sb[2], (bf16)sb[3]};
+          *(bf16x8*)((bf16*)g.pre_act + rowi * g.N + n) = sv;
+        }
+        continue;
+      }
+      if constexpr (EPI == EPI_GLU_BWD) {
+        // x[0..7] = dg of hidden units n .. n+7; saved / output columns 2n .. 2n+15 (two interleave groups), 2f = ldc wide
+        const int64_t rowi = mw + r8 + q * 8;
+        const bf16* sp = (const bf16*)g.pre_act + rowi * g.ldc + 2 * n;
+        bf16* cp = (bf16*)g.C + rowi * g.ldc + 2 * n;
+        const bf16x8 s0 = *(const bf16x8*)sp, s1 = *(const bf16x8*)(sp + 8);
+        bf16x8 o0, o1;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          o0[k] = (bf16)(x[k] * (float)s0[k]); o0[4 + k] = (bf16)(x[k] * (float)s0[4 + k]);
+          o1[k] = (bf16)(x[4 + k] * (float)s1[k]); o1[4 + k] = (bf16)(x[4 + k] * (float)s1[4 + k]);
+        }
+        *(bf16x8*)cp = o0; *(bf16x8*)(cp + 8) = o1;
+        continue;
+      }
       if (EPI == EPI_GELU) {
         if (g.pre_act) {
           bf16x8 o = {(bf16)x[0], (bf16)x[1], (bf16)x[2], (bf16)x[3], (bf16)x[4], (bf16)x[5], (bf16)x[6], (bf16)x[7]};
@@ -647,7 +693,8 @@ __global__ __launch_bounds__(64 * (8 + NL)) void k_gemm_nt_ws(MfmaArgs g) {
   const int t = threadIdx.x, lane = t & 63;
   const int w = __builtin_amdgcn_readfirstlane(t >> 6);
   const int ntiles = g.tiles_m * g.tiles_n;
-  if (g.bias_in_lds) {   // plain loads, retired (barrier) before the first LDS-DMA piece is issued
+  constexpr bool GLU_EPI = EPI == EPI_GLU || EPI == EPI_GLU_SG || EPI == EPI_GLU_BWD;   // these read the bias from global memory
+  if (g.bias_in_lds && !GLU_EPI) {   // plain loads, retired (barrier) before the first LDS-DMA piece is issued
     for (int n = t; n < g.N; n += 64 * (NW + NL)) bias_lds[n] = g.bias ? g.bias[n] : 0.f;
     __syncthreads();
   }
@@ -816,8 +863,9 @@ static int launch_nt_ws(MfmaArgs& g, hipStream_t st) {
   const int bias_bytes = ((g.N * 4 + 15) / 16) * 16;
   const bool rows16 = (g.N % 8) == 0 && (g.ldc % 8) == 0;
   const bool modes_ok = C_BF16 ? (!g.residual && !g.accumulate) : true;
-  g.bias_in_lds = rows16 && modes_ok && ring + bias_bytes <= 160 * 1024 ? 1 : 0;
-  const int shm = ring + (g.bias_in_lds ? bias_bytes : 0);
+  constexpr bool GLU_EPI = EPI == EPI_GLU || EPI == EPI_GLU_SG || EPI == EPI_GLU_BWD;
+  g.bias_in_lds = rows16 && modes_ok && (GLU_EPI || ring + bias_bytes <= 160 * 1024) ? 1 : 0;
+  const int shm = ring + (g.bias_in_lds && !GLU_EPI ? bias_bytes : 0);
   auto kern = k_gemm_nt_ws<C_BF16, NL, ABL, EPI>;
   static bool attr_done = false;   // per instantiation
   if (!attr_done) {
@@ -947,7 +995,7 @@ __global__ __launch_bounds__(256) void k_gemm_tn(MfmaArgs g) {
       float s = 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) s += red[r * 128 + t];
-      atomicAdd(g.a_colsum + m0 + t, s);
+      atomicAdd(g.a_colsum + (g.glu_f ? glu_deint(m0 + t, g.glu_f) : m0 + t), s);
     }
   }
   // D[row = fq*4 + r][col = fr] -> C[m = .. + fq*4 + r][n = .. + fr]; fp32 atomics when the
@@ -963,7 +1011,7 @@ __global__ __launch_bounds__(256) void k_gemm_tn(MfmaArgs g) {
       for (int r = 0; r < 4; ++r) {
         const int m = m0 + wm * 64 + i * 16 + fq * 4 + r;
         if (m < g.M && n < g.N) {
-          float* c = C + (int64_t)m * g.ldc + n;
+          float* c = C + (int64_t)(g.glu_f ? glu_deint(m, g.glu_f) : m) * g.ldc + n;
           if (g.ksplit > 1) atomicAdd(c, acc[i][j][r]);
           else *c = acc[i][j][r] + (g.accumulate ? *c : 0.f);
         }
@@ -1111,7 +1159,7 @@ __global__ __launch_bounds__(512, 2) void k_gemm_tn_ring(MfmaArgs g) {
       s += __shfl_xor(s, 16, 64);
       s += __shfl_xor(s, 32, 64);
       const int mm = m0 + wm * 64 + i * 16 + fr;
-      if (fq == 0 && mm < g.M) atomicAdd(g.a_colsum + mm, s);
+      if (fq == 0 && mm < g.M) atomicAdd(g.a_colsum + (g.glu_f ? glu_deint(mm, g.glu_f) : mm), s);
     }
   }
   float* C = (float*)g.C;
@@ -1124,7 +1172,7 @@ __global__ __launch_bounds__(512, 2) void k_gemm_tn_ring(MfmaArgs g) {
       for (int r = 0; r < 4; ++r) {
         const int mm = m0 + wm * 64 + i * 16 + fq * 4 + r;
         if (mm < g.M && n < g.N) {
-          float* c = C + (int64_t)mm * g.ldc + n;
+          float* c = C + (int64_t)(g.glu_f ? glu_deint(mm, g.glu_f) : mm) * g.ldc + n;
           if (g.ksplit > 1) atomicAdd(c, acc[i][j][r]);
           else *c = acc[i][j][r] + (g.accumulate ? *c : 0.f);
         }
@@ -1255,7 +1303,7 @@ __global__ __launch_bounds__(512) void k_gemm_tn_ring256(MfmaArgs g) {
       s += __shfl_xor(s, 16, 64);
       s += __shfl_xor(s, 32, 64);
       const int mm = m0 + wm * 128 + i * 16 + fr;
-      if (fq == 0 && mm < g.M) atomicAdd(g.a_colsum + mm, s);
+      if (fq == 0 && mm < g.M) atomicAdd(g.a_colsum + (g.glu_f ? glu_deint(mm, g.glu_f) : mm), s);
     }
   }
   float* C = (float*)g.C;
@@ -1268,7 +1316,7 @@ __global__ __launch_bounds__(512) void k_gemm_tn_ring256(MfmaArgs g) {
       for (int r = 0; r < 4; ++r) {
         const int mm = m0 + wm * 128 + i * 16 + fq * 4 + r;
         if (mm < g.M && n < g.N) {
-          float* c = C + (int64_t)mm * g.ldc + n;
+          float* c = C + (int64_t)(g.glu_f ? glu_deint(mm, g.glu_f) : mm) * g.ldc + n;
           if (g.ksplit > 1) atomicAdd(c, acc[i][j][r]);
           else *c = acc[i][j][r] + (g.accumulate ? *c : 0.f);
         }
@@ -1289,6 +1337,7 @@ int afm_gemm_mfma_try(const afm_gemm_desc* d, hipStream_t st) {
   g.dd = afm_make_drop(&d->drop);
   g.tiles_m = (d->M + BM - 1) / BM; g.tiles_n = (d->N + BN - 1) / BN;
   g.ksplit = 1; g.kchunk = d->K; g.bias_in_lds = 0;
+  g.glu_f = d->glu_rows;
   g.stamps = nullptr;
 #ifdef AFM_GEMM_ABLATIONS
   { const char* e = getenv("AFM_STAMPS"); if (e) g.stamps = (unsigned long long*)strtoull(e, nullptr, 0); }
@@ -1300,6 +1349,21 @@ int afm_gemm_mfma_try(const afm_gemm_desc* d, hipStream_t st) {
     if (!aligned16(d->C) || (d->residual && !aligned16(d->residual)) || (d->pre_act && !aligned16(d->pre_act)))
       return AFM_ERR_UNSUPPORTED;
     int variant = d->reserved;  // tile-shape experiments (tools/bench_gemm.py); 0 = pick by shape
+    if (d->act >= AFM_ACT_GLU) {
+      // fused gated FFN: whole 256 x 128 tiles through the loader-wave kernel, bf16 in / out, contiguous C and pre_act
+      const int ncol_c = d->act == AFM_ACT_GLU_BWD ? 2 * d->N : d->N / 2;
+      if ((d->K & 63) || (d->M & 255) || (d->N & 127) || d->c_dtype != AFM_BF16 || d->residual || d->accumulate ||
+          d->ldc != ncol_c || (d->drop.p > 0.f && (uint64_t)d->M * (uint64_t)d->N > 0x100000000ull) ||
+          (d->act == AFM_ACT_GLU_BWD && (d->bias || d->drop.p > 0.f)))
+        return AFM_ERR_UNSUPPORTED;
+      int r;
+      if (d->act == AFM_ACT_GLU) r = launch_nt_ws<true, 4, 0, EPI_GLU>(g, st);
+      else if (d->act == AFM_ACT_GLU_SAVE) r = launch_nt_ws<true, 4, 0, EPI_GLU_SG>(g, st);
+      else r = launch_nt_ws<true, 4, 0, EPI_GLU_BWD>(g, st);
+      if (r != AFM_OK) return r;
+      afm_set_last_algo("mfma_nt_glu");
+      return AFM_OK;
+    }
     if (variant == 0 && (d->K & 63) == 0) {
       // persistent LDS-DMA ring: 256x128 tiles when there are enough of them to fill the chip,
       // otherwise 128x128 at two workgroups per CU; anything with K % 64 != 0 keeps the

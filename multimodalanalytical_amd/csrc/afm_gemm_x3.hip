@@ -26,6 +26,8 @@ struct X3Args {
   int tiles_m, tiles_n;
   int ksplit, kchunk;   // TN only
   int bias_in_lds;
+  int glu_f;            // gated-FFN interleave (include/afm_hip.h)
+  int abl;              // timing experiments (tools/bench_gemm_x3.py): 1 skip LDS reads + MFMAs, 2 skip LDS-DMA, 4 skip epilogue
   DropDev dd;
 };
 
@@ -33,7 +35,8 @@ template <int N> __device__ __forceinline__ void x3_wait_vmcnt() { asm volatile(
 typedef __attribute__((ext_vector_type(4))) short x3_s16x4;
 
 enum { X3_F32 = 0, X3_X2 = 2 };
-enum { XE_GENERIC = 0, XE_PLAIN = 1, XE_GELU = 3, XE_GELU_BWD = 4, XE_GELU_SG = 5, XE_MUL = 6 };
+enum { XE_GENERIC = 0, XE_PLAIN = 1, XE_GELU = 3, XE_GELU_BWD = 4, XE_GELU_SG = 5, XE_MUL = 6, XE_GLU = 7, XE_GLU_SG = 8, XE_GLU_BWD = 9 };
+__device__ __forceinline__ int x3_glu_deint(int n, int f) { return ((n >> 3) << 2) + (n & 3) + ((n >> 2) & 1) * f; }
 
 __device__ __forceinline__ float x3_drop32(const DropDev& d, uint32_t idx, float x) {
   return afm_lowbias32(idx ^ d.key) >= d.thresh ? x * d.scale : 0.f;
@@ -99,7 +102,9 @@ __device__ __forceinline__ void x3_epilogue_staged(const X3Args& g, float* stg, 
     const int c8 = (lane & 7) * 8, r8 = lane >> 3;
     const int n = nw + c8, lo = g.ldc >> 1;
     f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = {0.f, 0.f, 0.f, 0.f};
-    if (EPI != XE_GELU_BWD && EPI != XE_MUL && g.bias) { b0 = *(const f32x4*)(bias_lds + n); b1 = *(const f32x4*)(bias_lds + n + 4); }
+    if constexpr (EPI == XE_GLU || EPI == XE_GLU_SG) {   // u / v biases of hidden units (n >> 1) .. +3, reference order [b1 ; bg]
+      if (g.bias) { b0 = *(const f32x4*)(g.bias + (n >> 1)); b1 = *(const f32x4*)(g.bias + g.glu_f + (n >> 1)); }
+    } else if (EPI != XE_GELU_BWD && EPI != XE_MUL && EPI != XE_GLU_BWD && g.bias) { b0 = *(const f32x4*)(bias_lds + n); b1 = *(const f32x4*)(bias_lds + n + 4); }
     const bool drop_on = g.dd.thresh != 0;
     bf16* const cbase = (bf16*)g.C + (int64_t)(mw + r8) * g.ldc + n;
     bf16* const pbase = (bf16*)g.pre_act + (int64_t)(mw + r8) * g.ldc + n;
@@ -116,6 +121,56 @@ __device__ __forceinline__ void x3_epilogue_staged(const X3Args& g, float* stg, 
         float x[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
         const int64_t ro = (int64_t)(q * 8) * g.ldc;
         const uint32_t di = dbase + (uint32_t)(q * 8) * (uint32_t)g.N;
+        if constexpr (EPI == XE_GLU || EPI == XE_GLU_SG) {
+          // x[0..3] = u, x[4..7] = v of hidden units (n >> 1) .. +3; C / the dropout stream are f = N/2 wide (ldc = 2 f: two planes)
+          const int64_t rowi = mw + r8 + q * 8;
+          const int hcol = n >> 1;
+          const uint32_t dg0 = (uint32_t)rowi * (uint32_t)(g.N >> 1) + (uint32_t)hcol;
+          float gv[4], sv[8];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            float y, yp;
+            afm_gelu_both(x[k], y, yp);
+            const float keep = drop_on ? x3_drop32(g.dd, dg0 + k, 1.0f) : 1.0f;
+            gv[k] = y * x[4 + k] * keep; sv[k] = yp * x[4 + k] * keep; sv[4 + k] = y * keep;
+          }
+          bf16 h0, l0, h1, l1, h2, l2, h3, l3;
+          afm_split(gv[0], h0, l0); afm_split(gv[1], h1, l1); afm_split(gv[2], h2, l2); afm_split(gv[3], h3, l3);
+          bf16* cp = (bf16*)g.C + rowi * g.ldc + hcol;
+          *(bf16x4*)cp = (bf16x4){h0, h1, h2, h3};
+          *(bf16x4*)(cp + lo) = (bf16x4){l0, l1, l2, l3};
+          if (EPI == XE_GLU_SG) {
+            bf16x8 sh, sl;
+            afm_split8(sv, sh, sl);
+            bf16* pp = (bf16*)g.pre_act + rowi * (2 * g.N) + n;        // saved tensor: M x N pairs, row stride 2 N
+            *(bf16x8*)pp = sh; *(bf16x8*)(pp + g.N) = sl;
+          }
+          continue;
+        }
+        if constexpr (EPI == XE_GLU_BWD) {
+          // x[0..7] = dg of hidden units n .. n+7; saved / output columns 2n .. 2n+15 of the 2f-wide pair tensors (ldc = 4 f)
+          const int64_t rowi = mw + r8 + q * 8;
+          const bf16* sp = (const bf16*)g.pre_act + rowi * g.ldc + 2 * n;
+          bf16* cp = (bf16*)g.C + rowi * g.ldc + 2 * n;
+          float o[16];
+#pragma unroll
+          for (int hh = 0; hh < 2; ++hh) {
+            const bf16x8 sh = *(const bf16x8*)(sp + 8 * hh), sl = *(const bf16x8*)(sp + 8 * hh + lo);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              o[8 * hh + k] = x[4 * hh + k] * ((float)sh[k] + (float)sl[k]);
+              o[8 * hh + 4 + k] = x[4 * hh + k] * ((float)sh[4 + k] + (float)sl[4 + k]);
+            }
+          }
+#pragma unroll
+          for (int hh = 0; hh < 2; ++hh) {
+            const float oo[8] = {o[8 * hh], o[8 * hh + 1], o[8 * hh + 2], o[8 * hh + 3], o[8 * hh + 4], o[8 * hh + 5], o[8 * hh + 6], o[8 * hh + 7]};
+            bf16x8 oh, ol;
+            afm_split8(oo, oh, ol);
+            *(bf16x8*)(cp + 8 * hh) = oh; *(bf16x8*)(cp + 8 * hh + lo) = ol;
+          }
+          continue;
+        }
         if (EPI == XE_GELU) {
           if (g.pre_act) {
             bf16x8 h, l;
@@ -190,7 +245,8 @@ __global__ __launch_bounds__(768) void k_x3_nt(X3Args g) {
   const int t = threadIdx.x, lane = t & 63;
   const int w = __builtin_amdgcn_readfirstlane(t >> 6);
   const int ntiles = g.tiles_m * g.tiles_n;
-  if (g.bias_in_lds) {
+  constexpr bool GLU_EPI = EPI == XE_GLU || EPI == XE_GLU_SG || EPI == XE_GLU_BWD;   // these read the bias from global memory
+  if (g.bias_in_lds && !GLU_EPI) {
     for (int n = t; n < g.N; n += 64 * (NW + NL)) bias_lds[n] = g.bias ? g.bias[n] : 0.f;
     __syncthreads();
   }
@@ -322,8 +378,9 @@ static int launch_x3_nt(X3Args& g, hipStream_t st, bool staged_ok) {
   constexpr int ring = S * (TBM + TBN) * 128;
   g.tiles_m = (g.M + TBM - 1) / TBM; g.tiles_n = (g.N + TBN - 1) / TBN;
   const int bias_bytes = ((g.N * 4 + 15) / 16) * 16;
-  g.bias_in_lds = staged_ok && ring + bias_bytes <= 160 * 1024 ? 1 : 0;
-  const int shm = ring + (g.bias_in_lds ? bias_bytes : 0);
+  constexpr bool GLU_EPI = EPI == XE_GLU || EPI == XE_GLU_SG || EPI == XE_GLU_BWD;
+  g.bias_in_lds = staged_ok && (GLU_EPI || ring + bias_bytes <= 160 * 1024) ? 1 : 0;
+  const int shm = ring + (g.bias_in_lds && !GLU_EPI ? bias_bytes : 0);
   auto kern = k_x3_nt<CT, EPI>;
   static bool attr_done = false;   // per instantiation
   if (!attr_done) {
@@ -380,10 +437,12 @@ __global__ __launch_bounds__(512) void k_x3_nt256(X3Args g) {
   auto issue_one = [&]() {
     if (is_tile < 0) return;
     unsigned char* st = lds + is_slot * STAGE;
+    if (!(g.abl & 2)) {
 #pragma unroll
-    for (int j = 0; j < NIW; ++j)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[j] + is_kt * 32),
-                                       (__attribute__((address_space(3))) void*)(st + (w + NW * j) * 1024), 16, 0, 0);
+      for (int j = 0; j < NIW; ++j)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[j] + is_kt * 32),
+                                         (__attribute__((address_space(3))) void*)(st + (w + NW * j) * 1024), 16, 0, 0);
+    }
     is_slot ^= 1;
     if (++is_kt == nk) {
       is_kt = 0;
@@ -413,6 +472,7 @@ __global__ __launch_bounds__(512) void k_x3_nt256(X3Args g) {
       const unsigned char* a = lds + slot * STAGE;
       const unsigned char* b = a + TBM * 128;
       slot ^= 1;
+      if (g.abl & 1) continue;
       bf16x8 bh[4], bl[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -434,7 +494,12 @@ __global__ __launch_bounds__(512) void k_x3_nt256(X3Args g) {
     // stage through the slot read by the last k-step (the other one is receiving the next tile's first step)
     __builtin_amdgcn_s_barrier();
     float* stg = (float*)(lds + (slot ^ 1) * STAGE) + w * (16 * X3_STG_LD);
-    x3_epilogue_staged<CT, EPI, WM>(g, stg, bias_lds, acc, m0 + wm * 16 * WM, n0 + wn * 64, lane);
+    if (g.abl & 4) {   // keep the accumulators alive, store nothing (the next tile's counted wait assumes >= 32 stores: drain)
+      if (acc[0][0][0] == 123.456f) ((float*)g.C)[0] = 1.f;
+      x3_wait_vmcnt<0>();
+    } else {
+      x3_epilogue_staged<CT, EPI, WM>(g, stg, bias_lds, acc, m0 + wm * 16 * WM, n0 + wn * 64, lane);
+    }
   }
 }
 
@@ -585,7 +650,7 @@ __global__ __launch_bounds__(512, 2) void k_x3_tn(X3Args g) {
       s += __shfl_xor(s, 16, 64);
       s += __shfl_xor(s, 32, 64);
       const int mm = m0 + wm * 64 + i * 16 + fr;
-      if (fq == 0 && mm < g.M) atomicAdd(g.a_colsum + mm, s);
+      if (fq == 0 && mm < g.M) atomicAdd(g.a_colsum + (g.glu_f ? x3_glu_deint(mm, g.glu_f) : mm), s);
     }
   }
   float* C = (float*)g.C;
@@ -598,7 +663,7 @@ __global__ __launch_bounds__(512, 2) void k_x3_tn(X3Args g) {
       for (int r = 0; r < 4; ++r) {
         const int mm = m0 + wm * 64 + i * 16 + fq * 4 + r;
         if (mm < g.M && n < g.N) {
-          float* c = C + (int64_t)mm * g.ldc + n;
+          float* c = C + (int64_t)(g.glu_f ? x3_glu_deint(mm, g.glu_f) : mm) * g.ldc + n;
           if (g.ksplit > 1) atomicAdd(c, acc[i][j][r]);
           else *c = acc[i][j][r] + (g.accumulate ? *c : 0.f);
         }
@@ -726,7 +791,7 @@ __global__ __launch_bounds__(512) void k_x3_tn256(X3Args g) {
       s += __shfl_xor(s, 16, 64);
       s += __shfl_xor(s, 32, 64);
       const int mm = m0 + wm * 128 + i * 16 + fr;
-      if (fq == 0 && mm < g.M) atomicAdd(g.a_colsum + mm, s);
+      if (fq == 0 && mm < g.M) atomicAdd(g.a_colsum + (g.glu_f ? x3_glu_deint(mm, g.glu_f) : mm), s);
     }
   }
   float* C = (float*)g.C;
@@ -739,7 +804,7 @@ __global__ __launch_bounds__(512) void k_x3_tn256(X3Args g) {
       for (int r = 0; r < 4; ++r) {
         const int mm = m0 + wm * 128 + i * 16 + fq * 4 + r;
         if (mm < g.M && n < g.N) {
-          float* c = C + (int64_t)mm * g.ldc + n;
+          float* c = C + (int64_t)(g.glu_f ? x3_glu_deint(mm, g.glu_f) : mm) * g.ldc + n;
           if (g.ksplit > 1) atomicAdd(c, acc[i][j][r]);
           else *c = acc[i][j][r] + (g.accumulate ? *c : 0.f);
         }
@@ -759,6 +824,8 @@ int afm_gemm_x3_try(const afm_gemm_desc* d, hipStream_t st) {
   g.act = d->act; g.accumulate = d->accumulate;
   g.dd = afm_make_drop(&d->drop);
   g.tiles_m = g.tiles_n = 0; g.ksplit = 1; g.kchunk = d->K; g.bias_in_lds = 0;
+  g.abl = (d->reserved >= 320 && d->reserved < 328) ? d->reserved - 320 : 0;
+  g.glu_f = d->glu_rows;
   // 16-byte pieces of both planes: pointers 16-byte aligned, plane offsets (ld / 2) multiples of 8 elements
   if (!x3_al16(d->A) || !x3_al16(d->B) || (d->lda & 15) || (d->ldb & 15)) return AFM_ERR_UNSUPPORTED;
   if (!d->transA && d->transB) {   // NT
@@ -767,9 +834,23 @@ int afm_gemm_x3_try(const afm_gemm_desc* d, hipStream_t st) {
     if (d->bias && !x3_al16(d->bias)) return AFM_ERR_UNSUPPORTED;
     if (!x3_al16(d->C) || (d->residual && !x3_al16(d->residual)) || (d->pre_act && !x3_al16(d->pre_act))) return AFM_ERR_UNSUPPORTED;
     const bool small_idx = (uint64_t)d->M * (uint64_t)d->N <= 0x100000000ull;
+    if (d->act >= AFM_ACT_GLU) {
+      // fused gated FFN: whole 256 x 128 tiles, split-pair in / out, contiguous C and saved tensor
+      const int ncol_c = d->act == AFM_ACT_GLU_BWD ? 2 * d->N : d->N / 2;
+      if ((d->M & 255) || (d->N & 127) || d->c_dtype != AFM_BF16X2 || d->residual || d->accumulate || d->ldc != 2 * ncol_c ||
+          (d->drop.p > 0.f && !small_idx) || (d->act == AFM_ACT_GLU_BWD && (d->bias || d->drop.p > 0.f)))
+        return AFM_ERR_UNSUPPORTED;
+      int r;
+      if (d->act == AFM_ACT_GLU) r = launch_x3_nt<X3_X2, XE_GLU>(g, st, true);
+      else if (d->act == AFM_ACT_GLU_SAVE) r = launch_x3_nt<X3_X2, XE_GLU_SG>(g, st, true);
+      else r = launch_x3_nt<X3_X2, XE_GLU_BWD>(g, st, true);
+      if (r != AFM_OK) return r;
+      afm_set_last_algo("mfma_nt_x3_glu");
+      return AFM_OK;
+    }
     // 256 x 256 tiles: whole tiles, enough of them to fill the chip twice over; reserved = 31 / 32 force a form (tools)
     const bool big = d->reserved != 31 && !(d->M & 255) && !(d->N & 255) && (d->ldc % 8) == 0 &&
-                     (d->reserved == 32 || (int64_t)(d->M >> 8) * (d->N >> 8) >= 512);
+                     (d->reserved == 32 || g.abl || (int64_t)(d->M >> 8) * (d->N >> 8) >= 512);
     int r;
     if (d->c_dtype == AFM_F32) {
       if (d->act != AFM_ACT_NONE || d->pre_act || d->drop.p > 0.f) return AFM_ERR_UNSUPPORTED;   // exact-fp32 kernel

@@ -18,7 +18,8 @@ from typing import Any, Dict, List, Optional
 import torch
 
 from . import ops
-from .lib import ACT_GELU, ACT_GELU_BWD, ACT_GELU_SAVE_GRAD, ACT_MUL_SAVED, ACT_NONE, ACT_RELU, ALGO_AUTO
+from .lib import (ACT_GELU, ACT_GELU_BWD, ACT_GELU_SAVE_GRAD, ACT_GLU, ACT_GLU_BWD, ACT_GLU_SAVE, ACT_MUL_SAVED, ACT_NONE, ACT_RELU,
+                  ALGO_AUTO)
 from .params import align_dict, PATCH_TYPES, TEXT_TYPES, ParamStore, build_specs, patch_layers
 from .x2 import X2
 
@@ -74,6 +75,8 @@ class Seq2SeqEngine:
         else:
             self.pos_enc = None
         self.wt: Dict[str, torch.Tensor] = {}  # transposed bf16 weights for dgrad
+        self.w_glu: Dict[str, Any] = {}        # gated FFN: [W1 ; Wg] with rows interleaved in fours (fused GLU epilogues), and
+        self.wt_glu: Dict[str, Any] = {}       # its transpose (d x 2f, columns interleaved) for the data gradient
         self.wt_kv_all = None                  # see _refresh_kv_concat
         self._graph_states: Dict[Any, dict] = {}   # decode_init_graphed
         self.training = True
@@ -118,6 +121,7 @@ class Seq2SeqEngine:
                 ops.cast_x2(src, self.ps.span_x2(name, rows, cols), self.wt[name])
             else:
                 ops.cast_bf16(src, self.ps.span(self.ps.bf16, name, rows, cols), self.wt[name])
+        self._refresh_glu()
         self._refresh_kv_concat()
 
     def refresh_transposes(self) -> None:
@@ -128,7 +132,25 @@ class Seq2SeqEngine:
             return self.refresh_shadows()
         for name, rows, cols in self._gemm_weight_groups():
             ops.cast_bf16(self.ps.span(self.ps.flat, name, rows, cols), None, self.wt[name])
+        self._refresh_glu()
         self._refresh_kv_concat()
+
+    def _refresh_glu(self) -> None:
+        """Interleaved shadows of the gated up-projections [linear1 ; gate] (include/afm_hip.h, AFM_ACT_GLU*)."""
+        if not (self.gated and self.lowp):
+            return
+        for name, rows, cols in self._gemm_weight_groups():
+            if not name.endswith("linear1.weight"):
+                continue
+            if name not in self.w_glu:
+                self.w_glu[name] = ops.empty(rows, cols, self.cd, self.dev)
+                self.wt_glu[name] = ops.empty(cols, rows, self.cd, self.dev)
+            ops.cast_weights(self.ps.span(self.ps.flat, name, rows, cols), self.w_glu[name], self.wt_glu[name], glu_rows=rows // 2)
+
+    def _glu_fusable(self, rows: int, f: int) -> bool:
+        """Whole 256 x 128 tiles of the (rows x 2f) up-projection and MFMA-sized K: the fused kernels' domain."""
+        return (self.gated and self.lowp and rows % 256 == 0 and (2 * f) % 128 == 0 and f % 128 == 0 and self.d % 64 == 0
+                and rows * 2 * f <= 0xFFFFFFFF)
 
     def _refresh_kv_concat(self) -> None:
         """(d x Ld*2d) bf16: the transposed cross-attention K/V projection weights of every decoder layer side
@@ -414,7 +436,16 @@ class Seq2SeqEngine:
         h, x = self._ln_fwd(x, p + norm, saved, "lnf", pend=pend)
         dr = self._drop(site + "ffn")
         g = self._empty(x.shape[0], f)
-        if self.gated:
+        if self.gated and self._glu_fusable(x.shape[0], f):
+            # gelu(u) * v (+ dropout) in the epilogue of ONE GEMM over the interleaved [W1 ; Wg]; with backward pending the
+            # epilogue stores keep*scale*[gelu'(u) v | gelu(u)] instead of u and v, so the data-gradient epilogue of the
+            # down-projection is two multiplies and afm_glu_fwd / afm_glu_bwd drop out of the step
+            uv = self._empty(x.shape[0], 2 * f) if saved is not None else None
+            ops.gemm(h, self.w_glu[p + "linear1.weight"], g, trans_b=True,
+                     bias=self.ps.vec_span(self.ps.flat, p + "linear1.bias", 0, 2 * f),
+                     act=ACT_GLU_SAVE if saved is not None else ACT_GLU, pre_act=uv, dropout=dr, algo=self.algo, glu_rows=f)
+            dr = (dr, "glu")
+        elif self.gated:
             uv = self._linear(h, p + "linear1.weight", k * f, d, bias_name=p + "linear1.bias")
             ops.glu_fwd(uv[:, :f], uv[:, f:], g, dr)
         else:   # GELU + inner dropout fused into the up-projection's epilogue.  With backward pending the epilogue
@@ -436,6 +467,16 @@ class Seq2SeqEngine:
         rows = h.shape[0]
         self._wgrad(dy, g, p + "linear2.weight", d, f, bias_name=p + "linear2.bias")
         duv = self._empty(rows, k * f)
+        if self.gated and isinstance(dr, tuple) and dr[1] == "glu":
+            # [du | dv] (interleaved) = (dy W2) * saved factors in the dgrad epilogue; weight gradient rows de-interleaved by
+            # the wgrad kernel into the reference's [linear1 ; gate] layout; dh through the interleaved transpose
+            ops.gemm(dy, self.wt[p + "linear2.weight"], duv, trans_b=True, act=ACT_GLU_BWD, pre_act=uv, algo=self.algo, glu_rows=f)
+            gw = self.G(p + "linear1.weight", 2 * f, d)
+            gb = self.ps.vec_span(self.ps.grad, p + "linear1.bias", 0, 2 * f)
+            ops.gemm(duv, h, gw, trans_a=True, trans_b=False, accumulate=True, algo=self.algo, a_colsum=gb, glu_rows=f)
+            dh = self._empty(rows, d)
+            ops.gemm(duv, self.wt_glu[p + "linear1.weight"], dh, trans_b=True, algo=self.algo)
+            return self._ln_bwd(dh, p + norm, saved, "lnf", dres=dx1, next_site=next_site)
         if self.gated:
             dg = self._dgrad(dy, p + "linear2.weight", d, f)
             ops.glu_bwd(uv[:, :f], uv[:, f:], dg, duv[:, :f], duv[:, f:], dr)

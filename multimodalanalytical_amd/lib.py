@@ -16,6 +16,7 @@ LIB_PATH = os.path.join(_HERE, "libafm_hip.so")
 AFM_F32, AFM_BF16, AFM_BF16X2 = 0, 1, 2
 ABI_VERSION = 2
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_GELU_BWD, ACT_GELU_SAVE_GRAD, ACT_MUL_SAVED = 0, 1, 2, 3, 4, 5
+ACT_GLU, ACT_GLU_SAVE, ACT_GLU_BWD = 6, 7, 8
 ALGO_AUTO, ALGO_GENERIC, ALGO_MFMA = 0, 1, 2
 
 
@@ -43,6 +44,7 @@ class GemmDesc(C.Structure):
         ("bias", C.c_void_p), ("residual", C.c_void_p), ("pre_act", C.c_void_p), ("a_colsum", C.c_void_p),
         ("act", C.c_int32), ("accumulate", C.c_int32), ("algo", C.c_int32), ("reserved", C.c_int32),
         ("drop", Dropout),
+        ("glu_rows", C.c_int32), ("reserved2", C.c_int32),
     ]
 
 
@@ -85,6 +87,7 @@ _SIGS = {
     "afm_relu_bwd": (C.c_int, [_P, _P, _P, _I64, _P]),
     "afm_convert": (C.c_int, [_P, _I32, _I32, _P, _I32, _I32, _I64, _I32, _P]),
     "afm_cast_x2": (C.c_int, [_P, _P, _P, _I32, _I32, _P]),
+    "afm_cast_weights": (C.c_int, [_P, _P, _P, _I32, _I32, _I32, _I32, _P]),
     "afm_error_string": (C.c_char_p, [C.c_int]),
     "afm_last_algo": (C.c_char_p, []),
     "afm_gemm": (C.c_int, [C.POINTER(GemmDesc), _P]),

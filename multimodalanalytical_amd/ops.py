@@ -96,10 +96,15 @@ def gemm(a: torch.Tensor, b: torch.Tensor, c: torch.Tensor, *, trans_a=False, tr
          bias: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
          pre_act: Optional[torch.Tensor] = None, act: int = ACT_NONE, accumulate: bool = False,
          dropout: Dropout = NO_DROP, algo: int = ALGO_AUTO, a_colsum: Optional[torch.Tensor] = None,
-         variant: int = 0) -> torch.Tensor:
+         variant: int = 0, glu_rows: int = 0) -> torch.Tensor:
     """c = epilogue(op(a) @ op(b)); default is the nn.Linear form c = a @ b^T + bias.
-    a_colsum (trans_a only): a_colsum[m] += sum_k a[k, m], the bias gradient of the wgrad form."""
+    a_colsum (trans_a only): a_colsum[m] += sum_k a[k, m], the bias gradient of the wgrad form.
+    Gated-FFN forms (act 6 / 7 / 8, include/afm_hip.h): c is (M, N/2) resp. (M, 2N); glu_rows = f."""
     M, N = c.shape
+    if act in (L.ACT_GLU, L.ACT_GLU_SAVE):
+        N *= 2
+    elif act == L.ACT_GLU_BWD:
+        N //= 2
     K = a.shape[0] if trans_a else a.shape[1]
     d = GemmDesc()
     d.M, d.N, d.K = M, N, K
@@ -117,7 +122,9 @@ def gemm(a: torch.Tensor, b: torch.Tensor, c: torch.Tensor, *, trans_a=False, tr
     if residual is not None:
         assert residual.dtype == c.dtype and _ld(residual) == d.ldc and residual.shape == c.shape
     d.residual = _ptr(residual)
-    if pre_act is not None:
+    if pre_act is not None and act in (L.ACT_GLU_SAVE, L.ACT_GLU_BWD):
+        assert pre_act.dtype == c.dtype and tuple(pre_act.shape) == (M, max(N, c.shape[1])) and is_contig(pre_act) and is_contig(c)
+    elif pre_act is not None:
         assert pre_act.dtype == c.dtype and _ld(pre_act) == d.ldc and pre_act.shape == c.shape
     d.pre_act = _ptr(pre_act)
     if a_colsum is not None:
@@ -125,6 +132,7 @@ def gemm(a: torch.Tensor, b: torch.Tensor, c: torch.Tensor, *, trans_a=False, tr
     d.a_colsum = _ptr(a_colsum)
     d.act, d.accumulate, d.algo = int(act), int(accumulate), int(algo)
     d.reserved = int(variant)
+    d.glu_rows = int(glu_rows)
     d.drop = dropout
     L.check(L.load().afm_gemm(C.byref(d), _stream()), "afm_gemm")
     _log_algo()
@@ -285,6 +293,17 @@ def cast_x2(src, dst=None, dst_t=None):
     for t, (r, c) in ((dst, (rows, cols)), (dst_t, (cols, rows))):
         assert t is None or (isinstance(t, X2) and tuple(t.shape) == (r, c) and t.ld == 2 * c)
     L.check(L.load().afm_cast_x2(_ptr(src), _ptr(dst), _ptr(dst_t), rows, cols, _stream()), "afm_cast_x2")
+
+
+def cast_weights(src, dst=None, dst_t=None, glu_rows: int = 0):
+    """fp32 (rows x cols) -> bf16 / split-pair shadow `dst` and its transpose `dst_t`, optionally with the gated-FFN row
+    interleave (glu_rows = f, rows = 2f)."""
+    rows, cols = src.shape
+    assert src.dtype == torch.float32 and src.is_contiguous()
+    t = dst if dst is not None else dst_t
+    assert (dst is None or is_contig(dst)) and (dst_t is None or is_contig(dst_t))
+    L.check(L.load().afm_cast_weights(_ptr(src), _ptr(dst), _ptr(dst_t), rows, cols, _dt(t), int(glu_rows), _stream()),
+            "afm_cast_weights")
 
 
 def cast_bf16(src, dst=None, dst_t=None):

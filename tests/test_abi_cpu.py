@@ -29,9 +29,9 @@ def test_header_symbols_are_exported_and_bound():
 
 def test_struct_layouts_match_the_header():
     from multimodalanalytical_amd import lib as L
-    # 11 int32 (+pad) + 7 pointers + 4 int32 + dropout{float,u32,u64}
+    # 11 int32 (+pad) + 7 pointers + 4 int32 + dropout{float,u32,u64} + glu_rows, reserved2
     assert ctypes.sizeof(L.Dropout) == 16
-    assert ctypes.sizeof(L.GemmDesc) == 48 + 7 * 8 + 16 + 16
+    assert ctypes.sizeof(L.GemmDesc) == 48 + 7 * 8 + 16 + 16 + 8 and L.GemmDesc.glu_rows.offset == 136
     assert L.GemmDesc.A.offset == 48 and L.GemmDesc.a_colsum.offset == 96 and L.GemmDesc.drop.offset == 120
     assert ctypes.sizeof(L.LnShape) == 64 and L.LnShape.add_drop.offset == 48
     assert L.AttnShape.key_pad.offset == 56 and L.AttnShape.sqb.offset == 80 and ctypes.sizeof(L.AttnShape) == 112

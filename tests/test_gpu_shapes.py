@@ -9,7 +9,8 @@ Bars (max |logit - ref| / max |ref|; gradients by relative norm per parameter te
   bf16    single bf16 MFMA pass                  logits 3e-2, ids exact outside twice the measured error, grads 8e-2
 Margin policy for "bit-exact argmax": a position whose two largest REFERENCE logits are closer than twice the
 MEASURED maximum logit error cannot be decided by the arithmetic under test (nor by the reference run on another
-BLAS); there the id must be one of those two.  Everywhere else ids must be equal.  bf16x3 measures ~1e-5, so
+BLAS); there the id must be a candidate whose reference logit lies within that band of the maximum.  Everywhere else ids
+must be equal.  bf16x3 measures ~1e-5, so
 at most a handful of exact near-ties are undecidable (>= 99.9 % of the positions must be decidable); fp32 mode
 is held to plain equality.
 """
@@ -81,6 +82,8 @@ def test_shape_parity_forward_backward_vs_oracle(name, mode):
     if mode != "fp32":   # the MFMA kernels really ran (not the exact-fp32 FMA kernels)
         assert any(a.startswith("attn_mfma") for a in algos), algos
         assert any(a.startswith("mfma_nt") for a in algos) and any(a.startswith("mfma_tn") for a in algos), algos
+        if cfg["gated_linear"]:   # c4 / c5: the gated FFN runs through the fused GLU epilogues
+            assert any("glu" in a for a in algos), algos
     logits, rl = out["logits"].cpu().double(), ref["logits"].double()
     scale = float(rl.abs().max())
     err = float((logits - rl).abs().max()) / scale
@@ -95,8 +98,9 @@ def test_shape_parity_forward_backward_vs_oracle(name, mode):
         band = 2 * err * scale
         sure = margin > band
         assert torch.equal(ids[sure], rid[sure]), (name, mode)
-        unsure = ~sure
-        assert bool(((ids == top2.indices[..., 0]) | (ids == top2.indices[..., 1]))[unsure].all())
+        # inside the band any candidate whose REFERENCE logit is within the band of the maximum may win (near-ties of 2+ ids)
+        chosen = ref["logits"].double().gather(-1, ids.unsqueeze(-1)).squeeze(-1)
+        assert bool((chosen >= top2.values[..., 0].double() - band).all())
         assert float(sure.double().mean()) > (0.999 if mode == "bf16x3" else 0.5)
     ltol = {"fp32": 1e-5, "bf16x3": 1e-4, "bf16": 2e-2}[mode]
     torch.testing.assert_close(out["loss"].cpu(), ref["loss"], rtol=ltol, atol=ltol)

@@ -223,3 +223,74 @@ def test_gemm_x3_tn_256_tiles(ops, R, M, N):
     ops.gemm(x2(dy), x2(x), gw, trans_a=True, trans_b=False, accumulate=True, a_colsum=gb, algo=2, variant=105)
     assert ops.last_algo().startswith("mfma_tn_x3_256")
     assert relnorm(gw, ref) < 1e-5 and relnorm(gb, refb) < 1e-5
+
+
+def _glu_interleave_rows(w1, wg):
+    """[W1 ; Wg] -> rows interleaved in fours (include/afm_hip.h)."""
+    f = w1.shape[0]
+    out = torch.empty(2 * f, w1.shape[1], dtype=w1.dtype)
+    idx = torch.arange(f)
+    pos = (idx // 4) * 8 + (idx % 4)
+    out[pos] = w1
+    out[pos + 4] = wg
+    return out
+
+
+@pytest.mark.parametrize("mode", ["bf16", "bf16x3"])
+@pytest.mark.parametrize("M,f,d", [(512, 128, 128), (256, 384, 64), (1024, 256, 512)])
+def test_fused_gated_ffn_epilogues(ops, mode, M, f, d):
+    """AFM_ACT_GLU / GLU_SAVE / GLU_BWD + the de-interleaving wgrad against the unfused definition
+    (custom_modeling.py:137-152: gelu(W1 h + b1) * (Wg h + bg), dropout; its gradients w.r.t. u, v, W, b)."""
+    from multimodalanalytical_amd.x2 import X2
+    from multimodalanalytical_amd.lib import ACT_GLU, ACT_GLU_BWD, ACT_GLU_SAVE
+    cd = torch.bfloat16 if mode == "bf16" else X2.dtype
+    tol = 2e-2 if mode == "bf16" else 3e-5
+    h, w1, wg = rnd(M, d, seed=1) * 0.5, rnd(f, d, seed=2) * 0.2, rnd(f, d, seed=3) * 0.2
+    b = rnd(2 * f, seed=4) * 0.1
+    w12 = torch.cat([w1, wg]).to(DEV).contiguous()
+    w_glu, wt_glu = ops.empty(2 * f, d, cd, DEV), ops.empty(d, 2 * f, cd, DEV)
+    ops.cast_weights(w12, w_glu, wt_glu, glu_rows=f)
+    got_w = w_glu.float().cpu()
+    want_w = _glu_interleave_rows(w1, wg)
+    assert relnorm(got_w, want_w) < (4e-3 if mode == "bf16" else 1e-5)
+    assert torch.equal(wt_glu.float().cpu(), got_w.T)
+    hd = ops.convert(h.to(DEV), ops.empty(M, d, cd, DEV))
+    hq, w1q, wgq = hd.float().cpu().double(), got_w[(torch.arange(f) // 4) * 8 + torch.arange(f) % 4].double(), None
+    wgq = got_w[(torch.arange(f) // 4) * 8 + torch.arange(f) % 4 + 4].double()
+    u = hq @ w1q.T + b[:f].double()
+    v = hq @ wgq.T + b[f:].double()
+    gel = 0.5 * u * (1 + torch.erf(u / math.sqrt(2)))
+    gp = 0.5 * (1 + torch.erf(u / math.sqrt(2))) + u * torch.exp(-u * u / 2) / math.sqrt(2 * math.pi)
+    p, seed, site = 0.1, 77, 9
+    keep = torch.from_numpy(keep_mask(p, seed, site, M * f)).view(M, f).double() / (1 - p)
+    # forward without / with the saved factors
+    g0 = ops.empty(M, f, cd, DEV)
+    ops.gemm(hd, w_glu, g0, bias=dev(b), act=ACT_GLU, algo=2, glu_rows=f)
+    assert ops.last_algo() in ("mfma_nt_glu", "mfma_nt_x3_glu")
+    assert relnorm(g0.float(), gel * v) < tol
+    g1, sv = ops.empty(M, f, cd, DEV), ops.empty(M, 2 * f, cd, DEV)
+    ops.gemm(hd, w_glu, g1, bias=dev(b), act=ACT_GLU_SAVE, pre_act=sv, dropout=ops.drop(p, seed, site), algo=2, glu_rows=f)
+    assert relnorm(g1.float(), gel * v * keep) < tol
+    svf = sv.float().cpu().double()
+    pos = (torch.arange(f) // 4) * 8 + torch.arange(f) % 4
+    assert relnorm(svf[:, pos], gp * v * keep) < tol and relnorm(svf[:, pos + 4], gel * keep) < tol
+    # backward: dg = dy W2 (N = f) -> [du | dv] interleaved
+    d2 = 128
+    dy, w2t = rnd(M, d2, seed=6), rnd(f, d2, seed=7) * 0.2       # W2^T (f x d2): the NT operand of the data gradient
+    dyd, w2d = ops.convert(dy.to(DEV), ops.empty(M, d2, cd, DEV)), ops.convert(w2t.to(DEV), ops.empty(f, d2, cd, DEV))
+    dg = dyd.float().cpu().double() @ w2d.float().cpu().double().T
+    duv = ops.empty(M, 2 * f, cd, DEV)
+    ops.gemm(dyd, w2d, duv, act=ACT_GLU_BWD, pre_act=sv, algo=2, glu_rows=f)
+    duvf = duv.float().cpu().double()
+    assert relnorm(duvf[:, pos], dg * svf[:, pos]) < tol and relnorm(duvf[:, pos + 4], dg * svf[:, pos + 4]) < tol
+    # weight / bias gradient of [W1 ; Wg] in the reference's row order from the interleaved duv
+    gw, gb = torch.zeros(2 * f, d, device=DEV), torch.zeros(2 * f, device=DEV)
+    ops.gemm(duv, hd, gw, trans_a=True, trans_b=False, accumulate=True, a_colsum=gb, algo=2, glu_rows=f)
+    du_ref, dv_ref = duvf[:, pos], duvf[:, pos + 4]
+    want_gw = torch.cat([du_ref.T @ hq, dv_ref.T @ hq])
+    want_gb = torch.cat([du_ref.sum(0), dv_ref.sum(0)])
+    assert relnorm(gw, want_gw) < tol and relnorm(gb, want_gb) < tol
+    # data gradient through the interleaved transpose
+    dh = ops.empty(M, d, cd, DEV)
+    ops.gemm(duv, wt_glu, dh, algo=2)
+    assert relnorm(dh.float(), du_ref @ w1q + dv_ref @ wgq) < tol
