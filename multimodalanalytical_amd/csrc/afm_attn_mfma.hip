@@ -28,14 +28,15 @@ __global__ __launch_bounds__(256, 3) void k_attn_fwd_mfma(AttnM a, const bf16* _
   unsigned long long* maskw = (unsigned long long*)(lds + RS * STAGE);
   const int t = threadIdx.x, lane = t & 63, h = lane >> 5;
   const int w = __builtin_amdgcn_readfirstlane(t >> 6);
-  const int hd = blockIdx.y, b = blockIdx.z;
-  const int q0 = blockIdx.x * 128 + w * 32;          // this wave's first query
+  const AttnBlock blk_ = attn_block(a.H, a.B, (a.Tq + 127) / 128);
+  const int hd = blk_.hd, b = blk_.b;
+  const int q0 = blk_.xb * 128 + w * 32;          // this wave's first query
   const int q = q0 + (lane & 31);
   const int qc = q < a.Tq ? q : a.Tq - 1;
   const bf16* Kb = K + (int64_t)b * a.Tk * a.ldk + hd * DH;
   const bf16* Vb = V + (int64_t)b * a.Tk * a.ldv + hd * DH;
   int kend = a.Tk;
-  if (a.causal) kend = min(a.Tk, blockIdx.x * 128 + 128);  // keys beyond the block's last query are masked
+  if (a.causal) kend = min(a.Tk, blk_.xb * 128 + 128);  // keys beyond the block's last query are masked
   const int ntiles = (kend + KT - 1) / KT;
   // Q fragments (B operand of S^T = K Q^T): Q[q][16 s + 8 h ..]
   bf16x8 qf[4];
@@ -172,8 +173,9 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd_dq_mfma(AttnM a, const bf16
   unsigned long long* maskw = (unsigned long long*)(lds + RS * STAGE);
   const int t = threadIdx.x, lane = t & 63, h = lane >> 5;
   const int w = __builtin_amdgcn_readfirstlane(t >> 6);
-  const int hd = blockIdx.y, b = blockIdx.z;
-  const int q0 = blockIdx.x * 128 + w * 32;
+  const AttnBlock blk_ = attn_block(a.H, a.B, (a.Tq + 127) / 128);
+  const int hd = blk_.hd, b = blk_.b;
+  const int q0 = blk_.xb * 128 + w * 32;
   const int q = q0 + (lane & 31);
   const int qc = q < a.Tq ? q : a.Tq - 1;
   const bf16* Kb = K + (int64_t)b * a.Tk * a.ldk + hd * DH;
@@ -204,7 +206,7 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd_dq_mfma(AttnM a, const bf16
   const uint32_t rowbase = (uint32_t)((uint64_t)lrow * (uint64_t)a.Tk);
 
   int kend = a.Tk;
-  if (a.causal) kend = min(a.Tk, blockIdx.x * 128 + 128);
+  if (a.causal) kend = min(a.Tk, blk_.xb * 128 + 128);
   const int ntiles = (kend + KT - 1) / KT;
   build_mask_words(maskw, a.key_pad, b, a.Tk, ntiles, w, lane);
   __syncthreads();   // retires the plain loads / the delta store before the LDS-DMA ring starts
@@ -308,8 +310,9 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd_dkv_mfma(AttnM a, const bf1
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   const int t = threadIdx.x, lane = t & 63, h = lane >> 5;
   const int w = __builtin_amdgcn_readfirstlane(t >> 6);
-  const int hd = blockIdx.y, b = blockIdx.z;
-  const int k0 = blockIdx.x * 128 + w * 32;
+  const AttnBlock blk_ = attn_block(a.H, a.B, (a.Tk + 127) / 128);
+  const int hd = blk_.hd, b = blk_.b;
+  const int k0 = blk_.xb * 128 + w * 32;
   const int key = k0 + (lane & 31);
   const int kc = key < a.Tk ? key : a.Tk - 1;
   const bool kmasked = key >= a.Tk || (a.key_pad && a.key_pad[(int64_t)b * a.Tk + kc]);
@@ -328,7 +331,7 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd_dkv_mfma(AttnM a, const bf1
   const bool wave_all_masked = __all(kmasked);
 
   int qbeg = 0;
-  if (a.causal) qbeg = (blockIdx.x * 128) / KT * KT;   // queries before the block's first key see none of it
+  if (a.causal) qbeg = (blk_.xb * 128) / KT * KT;   // queries before the block's first key see none of it
   const int ntiles = (a.Tq - qbeg + KT - 1) / KT;
   const int64_t lbase = ((int64_t)b * a.H + hd) * a.Tq;
   __syncthreads();   // K / V fragment loads retired before the LDS-DMA ring starts
@@ -488,7 +491,7 @@ int afm_attn_fwd_mfma_try(const afm_attn_shape* s, const void* Q, const void* K,
   const int lds[] = {s->ldq, s->ldk, s->ldv, s->ldo};
   if (!eligible(s, ptrs, 4, lds, 4)) return AFM_ERR_UNSUPPORTED;
   const AttnM a = make_m(s);
-  const dim3 grid((s->Tq + 127) / 128, s->H, s->B);
+  const dim3 grid(((s->Tq + 127) / 128) * s->H * s->B);
   const int shm = RS * 2 * KT * DH * 2 + ((s->Tk + KT - 1) / KT) * 8;
   if (shm > 64 * 1024) return AFM_ERR_UNSUPPORTED;
   if (a.dd.thresh16) AFM_LAUNCH(k_attn_fwd_mfma<true>, grid, dim3(256), shm, st, a, (const bf16*)Q, (const bf16*)K, (const bf16*)V, (bf16*)O, lse);
@@ -505,7 +508,7 @@ int afm_attn_bwd_mfma_try(const afm_attn_shape* s, const void* Q, const void* K,
   if (!eligible(s, ptrs, 8, lds, 7)) return AFM_ERR_UNSUPPORTED;
   AttnM a = make_m(s);
   a.lddq = lddq; a.lddk = lddk; a.lddv = lddv;
-  const dim3 gq((s->Tq + 127) / 128, s->H, s->B), gk((s->Tk + 127) / 128, s->H, s->B);
+  const dim3 gq(((s->Tq + 127) / 128) * s->H * s->B), gk(((s->Tk + 127) / 128) * s->H * s->B);
   const int shm_q = RS * 3 * KT * DH * 2 + ((s->Tk + KT - 1) / KT) * 8;
   if (shm_q > 80 * 1024) return AFM_ERR_UNSUPPORTED;
   static bool attr_q = false;

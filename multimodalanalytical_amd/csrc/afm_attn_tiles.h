@@ -154,6 +154,27 @@ __device__ __forceinline__ void build_mask_words(unsigned long long* maskw, cons
 }
 
 
+// ------------------------------------------------------------------------------------------ XCD-aware block map
+// 1-D grid of nblk * B * H workgroups (nblk = 128-row blocks of one (batch, head)).  Workgroups are dealt round-robin
+// over the 8 XCDs (block L -> XCD L % 8), so with the natural order the blocks of one (batch, head) land on 8 different
+// L2s and each of them streams that head's K / V (or Q / dO) from HBM: measured 4.8 GB of L2 fills for 1.1 GB of
+// tensors, L2 hit rate 0.28 (profiles/r02_attn_*).  Here the blocks of one (batch, head) share an XCD: they run side by
+// side on its 32 CUs and the second to eighth block find the tiles in that XCD's L2.  Speed only, never correctness.
+struct AttnBlock { int xb, hd, b; };
+__device__ __forceinline__ AttnBlock attn_block(int H, int B, int nblk) {
+  const int L = blockIdx.x, nbh = H * B;
+  int bh, xb;
+  if ((nbh & 7) == 0) {
+    const int xcd = L & 7, idx = L >> 3;
+    bh = (idx / nblk) * 8 + xcd;
+    xb = idx % nblk;
+  } else {
+    xb = L % nblk;
+    bh = L / nblk;
+  }
+  return {xb, bh % H, bh / H};
+}
+
 // ------------------------------------------------------------------------------------------ dual-use image
 // ONE LDS image of a [rows][64] bf16 tile that serves both the row reads (ds_read_b128: the 32x32x16 row operand) and
 // the transposed reads (ds_read_b64_tr_b16), conflict-free for both (tools/lds_swizzle_check.py): chunk c of row r sits

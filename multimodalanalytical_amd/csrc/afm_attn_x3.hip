@@ -52,15 +52,16 @@ __global__ __launch_bounds__(256, 2) void k_attn_fwd_x3(AttnM a, const bf16* __r
   unsigned long long* maskw = (unsigned long long*)(lds + NS * STAGE);
   const int t = threadIdx.x, lane = t & 63, h = lane >> 5;
   const int w = __builtin_amdgcn_readfirstlane(t >> 6);
-  const int hd = blockIdx.y, b = blockIdx.z;
-  const int q0 = blockIdx.x * 128 + w * 32;
+  const AttnBlock blk_ = attn_block(a.H, a.B, (a.Tq + 127) / 128);
+  const int hd = blk_.hd, b = blk_.b;
+  const int q0 = blk_.xb * 128 + w * 32;
   const int q = q0 + (lane & 31);
   const int qc = q < a.Tq ? q : a.Tq - 1;
   const int lok = a.ldk >> 1, lov = a.ldv >> 1;
   const bf16* Kb = K + (int64_t)b * a.Tk * a.ldk + hd * DH;
   const bf16* Vb = V + (int64_t)b * a.Tk * a.ldv + hd * DH;
   int kend = a.Tk;
-  if (a.causal) kend = min(a.Tk, blockIdx.x * 128 + 128);
+  if (a.causal) kend = min(a.Tk, blk_.xb * 128 + 128);
   const int ntiles = (kend + KT - 1) / KT;
   bf16x8 qh[4], ql[4];
   {
@@ -190,8 +191,9 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd_dq_x3(AttnM a, const bf16* 
   unsigned long long* maskw = (unsigned long long*)(lds + NS * STAGE);
   const int t = threadIdx.x, lane = t & 63, h = lane >> 5;
   const int w = __builtin_amdgcn_readfirstlane(t >> 6);
-  const int hd = blockIdx.y, b = blockIdx.z;
-  const int q0 = blockIdx.x * 128 + w * 32;
+  const AttnBlock blk_ = attn_block(a.H, a.B, (a.Tq + 127) / 128);
+  const int hd = blk_.hd, b = blk_.b;
+  const int q0 = blk_.xb * 128 + w * 32;
   const int q = q0 + (lane & 31);
   const int qc = q < a.Tq ? q : a.Tq - 1;
   const int lok = a.ldk >> 1, lov = a.ldv >> 1, loq = a.ldq >> 1, loo = a.ldo >> 1;
@@ -223,7 +225,7 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd_dq_x3(AttnM a, const bf16* 
   const uint32_t rowbase = (uint32_t)((uint64_t)lrow * (uint64_t)a.Tk);
 
   int kend = a.Tk;
-  if (a.causal) kend = min(a.Tk, blockIdx.x * 128 + 128);
+  if (a.causal) kend = min(a.Tk, blk_.xb * 128 + 128);
   const int ntiles = (kend + KT2 - 1) / KT2;
   build_mask_words(maskw, a.key_pad, b, a.Tk, (kend + 63) / 64, w, lane);
   __syncthreads();
@@ -324,8 +326,9 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd_dkv_x3(AttnM a, const bf16*
   unsigned char* ring = lds + KVL;
   const int t = threadIdx.x, lane = t & 63, h = lane >> 5;
   const int w = __builtin_amdgcn_readfirstlane(t >> 6);
-  const int hd = blockIdx.y, b = blockIdx.z;
-  const int k0 = blockIdx.x * 128 + w * 32;
+  const AttnBlock blk_ = attn_block(a.H, a.B, (a.Tk + 127) / 128);
+  const int hd = blk_.hd, b = blk_.b;
+  const int k0 = blk_.xb * 128 + w * 32;
   const int key = k0 + (lane & 31);
   const int kc = key < a.Tk ? key : a.Tk - 1;
   const bool kmasked = key >= a.Tk || (a.key_pad && a.key_pad[(int64_t)b * a.Tk + kc]);
@@ -351,7 +354,7 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd_dkv_x3(AttnM a, const bf16*
   const bool wave_all_masked = __all(kmasked);
 
   int qbeg = 0;
-  if (a.causal) qbeg = (blockIdx.x * 128) / QT * QT;
+  if (a.causal) qbeg = (blk_.xb * 128) / QT * QT;
   const int ntiles = (a.Tq - qbeg + QT - 1) / QT;
   const int64_t lbase = ((int64_t)b * a.H + hd) * a.Tq;
   __syncthreads();   // plain loads retired / parked fragments visible before the LDS-DMA ring starts
@@ -512,7 +515,7 @@ int afm_attn_fwd_x3_try(const afm_attn_shape* s, const void* Q, const void* K, c
   const int lds[] = {s->ldq, s->ldk, s->ldv, s->ldo};
   if (!eligible_x3(s, ptrs, 4, lds, 4)) return AFM_ERR_UNSUPPORTED;
   const AttnM a = make_m_x3(s);
-  const dim3 grid((s->Tq + 127) / 128, s->H, s->B);
+  const dim3 grid(((s->Tq + 127) / 128) * s->H * s->B);
   const int shm = 2 * 4 * IMG64 + ((s->Tk + KT - 1) / KT) * 8;
   if (shm > 80 * 1024) return AFM_ERR_UNSUPPORTED;
   static bool attr = false;
@@ -535,7 +538,7 @@ int afm_attn_bwd_x3_try(const afm_attn_shape* s, const void* Q, const void* K, c
   if (!eligible_x3(s, ptrs, 8, lds, 7)) return AFM_ERR_UNSUPPORTED;
   AttnM a = make_m_x3(s);
   a.lddq = lddq; a.lddk = lddk; a.lddv = lddv;
-  const dim3 gq((s->Tq + 127) / 128, s->H, s->B), gk((s->Tk + 127) / 128, s->H, s->B);
+  const dim3 gq(((s->Tq + 127) / 128) * s->H * s->B), gk(((s->Tk + 127) / 128) * s->H * s->B);
   const int shm_q = 2 * 4 * IMG32 + ((s->Tk + 63) / 64) * 8;
   const int shm_k = 4 * 2 * 4096 + 2 * (4 * IMG32 + 2 * 64 * 4);
   if (shm_q > 80 * 1024) return AFM_ERR_UNSUPPORTED;
