@@ -200,6 +200,13 @@ typedef struct {
   /* batch strides in ELEMENTS of Q, K, V, O (0 = dense: Tq*ldq, Tk*ldk, Tk*ldv, Tq*ldo).  Non-dense
    * strides address a KV cache laid out (batch, Tmax, 2d) during incremental decode; forward only. */
   int64_t sqb, skb, svb, sob;
+  /* Optional keep-bit tensor of the attention-probability dropout (nullable; only read / written when drop.p > 0):
+   * B*H * ceil(Tq/32) * ceil(Tk/32) blocks of 16 uint64.  Block (bh, qb, kb), word r, bit l = keep of query 32 qb + (l & 31),
+   * key 32 kb + (r & 3) + 8 (r >> 2) + 4 (l >> 5): the 64-lane masks of the kernels' score registers.  afm_attn_fwd writes it
+   * (the MFMA kernels as a by-product of their own dropout, through the scalar store path), afm_attn_bwd's MFMA kernels read it
+   * instead of re-evaluating the hash per score: the dQ kernel as SGPR lane masks (one v_cndmask per score), the dK/dV kernel as one
+   * word per lane.  The bits ARE the counter-based stream above, so results do not depend on whether the tensor is used. */
+  uint64_t* drop_bits;
 } afm_attn_shape;
 int afm_attn_fwd(const afm_attn_shape* s, const void* Q, const void* K, const void* V, void* O,
                  float* lse, void* stream);

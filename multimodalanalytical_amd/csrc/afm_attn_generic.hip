@@ -198,6 +198,26 @@ __global__ __launch_bounds__(256) void k_attn_bwd_kv_generic(
   }
 }
 
+// Keep-bit tensor (afm_attn_shape.drop_bits) from the dropout stream, for forwards that run the generic kernel: the layout the
+// MFMA forward kernels emit, so a backward that takes the MFMA path finds valid bits whatever the forward dispatched to.
+__global__ __launch_bounds__(256) void k_drop_bits(DropDev dd, int B, int H, int Tq, int Tk, int nq32, int nk32,
+                                                   unsigned long long* __restrict__ bits) {
+  const int lane = threadIdx.x & 63;
+  const int64_t blk = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int64_t nblk = (int64_t)B * H * nq32 * nk32;
+  if (blk >= nblk) return;
+  const int kb = (int)(blk % nk32), qb = (int)((blk / nk32) % nq32);
+  const int64_t bh = blk / ((int64_t)nk32 * nq32);
+  const int q = qb * 32 + (lane & 31);
+  for (int r = 0; r < 16; ++r) {
+    const int key = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+    const bool in = q < Tq && key < Tk;
+    const bool keep = in && afm_keep16(dd, ((uint64_t)bh * Tq + q) * (uint64_t)Tk + key);
+    const unsigned long long m = __ballot(keep);
+    if (lane == 0) bits[blk * 16 + r] = m;
+  }
+}
+
 static AttnArgs make_args(const afm_attn_shape* s) {
   AttnArgs a;
   a.B = s->B; a.H = s->H; a.Tq = s->Tq; a.Tk = s->Tk; a.dh = s->dh;
@@ -248,6 +268,12 @@ extern "C" int afm_attn_fwd(const afm_attn_shape* s, const void* Q, const void* 
   AFM_DT_SWITCH(s->dtype, T,
     if (shm > 64 * 1024) hipFuncSetAttribute((const void*)k_attn_fwd_generic<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
     AFM_LAUNCH(k_attn_fwd_generic<T>, grid, dim3(256), shm, st, a, (const T*)Q, (const T*)K, (const T*)V, (T*)O, lse));
+  if (s->drop_bits && a.dd.thresh16) {
+    const int nq32 = ((s->Tq + 127) / 128) * 4, nk32 = ((s->Tk + 63) / 64) * 2;
+    const int64_t nblk = (int64_t)s->B * s->H * nq32 * nk32;
+    AFM_LAUNCH(k_drop_bits, dim3((unsigned)((nblk + 3) / 4)), dim3(256), 0, st, a.dd, s->B, s->H, s->Tq, s->Tk, nq32, nk32,
+               (unsigned long long*)s->drop_bits);
+  }
   afm_set_last_algo("attn_generic");
   return AFM_OK;
 }

@@ -18,7 +18,7 @@
 #include "afm_attn_tiles.h"
 
 // ------------------------------------------------------------------------------------------ forward
-template <bool DROP>
+template <int DROP>
 __global__ __launch_bounds__(256, 3) void k_attn_fwd_mfma(AttnM a, const bf16* __restrict__ Q,
                                                           const bf16* __restrict__ K,
                                                           const bf16* __restrict__ V, bf16* __restrict__ O,
@@ -123,9 +123,14 @@ __global__ __launch_bounds__(256, 3) void k_attn_fwd_mfma(AttnM a, const bf16* _
     (void)grew;
 #pragma unroll
     for (int i = 0; i < 16; ++i) { o[0][i] *= alpha; o[1][i] *= alpha; }
-    if (DROP) {   // compile-time: a run-time branch costs 32 register copies at its join
+    if (DROP == DROP_HASH) {   // compile-time: a run-time branch costs 32 register copies at its join
       drop_block(a.dd, rowbase, kb, h, s[0]);
       drop_block(a.dd, rowbase, kb + 32, h, s[1]);
+    }
+    if (DROP == DROP_BITS) {   // the same dropout, and the keep bits of both 32-key blocks go to the keep-bit tensor
+      unsigned long long* bb = bits_block(a, b * a.H + hd, q0 >> 5, kb >> 5);
+      drop_block_emit(a.dd, rowbase, kb, h, s[0], bb);
+      drop_block_emit(a.dd, rowbase, kb + 32, h, s[1], bb + 16);
     }
     // O^T += V^T P^T over the four 16-key slices, the V^T reads one slice ahead of the MFMAs
     unsigned va0, va1;
@@ -141,6 +146,7 @@ __global__ __launch_bounds__(256, 3) void k_attn_fwd_mfma(AttnM a, const bf16* _
       o[1] = mfma32(tr_join(vq[i & 1].lo1, vq[i & 1].hi1), pf, o[1]);
     }
   }
+  if (DROP == DROP_BITS) bits_flush();
   l += __shfl_xor(l, 32, 64);
   const float inv = l > 0.f ? a.dd.scale16 / l : 0.f;
   if (q < a.Tq) {
@@ -160,7 +166,7 @@ __global__ __launch_bounds__(256, 3) void k_attn_fwd_mfma(AttnM a, const bf16* _
 // ------------------------------------------------------------------------------------------ dQ
 // Per 64-key tile: S^T and dP^T (keys in registers, query on the lane), then
 // dQ^T[d][q] += sum_key K^T[d][key] dS^T[key][q].  Also writes delta = rowsum(dO * O).
-template <bool DROP>
+template <int DROP>
 __global__ __launch_bounds__(256, 2) void k_attn_bwd_dq_mfma(AttnM a, const bf16* __restrict__ Q,
                                                           const bf16* __restrict__ K,
                                                           const bf16* __restrict__ V,
@@ -238,6 +244,12 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd_dq_mfma(AttnM a, const bf16
     const unsigned long long pad = mword >> (4 * h);
     unsigned ka0, ka1;
     tr_lane_addr(Ktr, lane, ka0, ka1);
+    KeepMasks km[2];
+    if (DROP == DROP_BITS) {   // both 32-key blocks of the tile now; used after the S / dP products
+      const unsigned long long* kbp = bits_block(a, b * a.H + hd, q0 >> 5, 2 * kt);
+      keep_masks_issue(km[0], kbp);
+      keep_masks_issue(km[1], kbp + 16);
+    }
 #pragma unroll
     for (int blk = 0; blk < 2; ++blk) {
       f32x16 s, dp;
@@ -248,11 +260,12 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd_dq_mfma(AttnM a, const bf16
         s = mfma32(frag_row(Krow, 32 * blk, ks, lane), qf[ks], s);
         dp = mfma32(frag_row(Vrow, 32 * blk, ks, lane), dof[ks], dp);
       }
-      if (DROP) {
+      if (DROP == DROP_HASH) {
         drop_block(a.dd, rowbase, kb + 32 * blk, h, dp);
 #pragma unroll
         for (int r = 0; r < 16; ++r) dp[r] *= a.dd.scale16;
       }
+      if (DROP == DROP_BITS) drop_apply_masks(dp, km[blk], a.dd.scale16);
       if (mword != 0ull || (a.causal && (kb + KT - 1 > q0))) {   // wave-uniform: tile has masked keys
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -296,7 +309,7 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd_dq_mfma(AttnM a, const bf16
 // Workgroup = 4 waves x 32 keys; loops over 64-query tiles.  S = Q K^T with the key on the lane
 // (queries in registers), P = exp2(S - lse[q]), dP = dO V^T, dS = P (D dP - delta[q]);
 // dV^T[d][key] += sum_q dO^T[d][q] (D P)[q][key],  dK^T[d][key] += sum_q Q^T[d][q] dS[q][key].
-template <bool DROP>
+template <int DROP>
 __global__ __launch_bounds__(256, 2) void k_attn_bwd_dkv_mfma(AttnM a, const bf16* __restrict__ Q,
                                                            const bf16* __restrict__ K,
                                                            const bf16* __restrict__ V,
@@ -305,7 +318,7 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd_dkv_mfma(AttnM a, const bf1
                                                            const float* __restrict__ delta,
                                                            bf16* __restrict__ dK, bf16* __restrict__ dV) {
   // stage: Q row image, Q tr image, dO row image, dO tr image, lse[64], delta[64]; 2-stage LDS-DMA ring
-  constexpr int STAGE = 4 * KT * DH * 2 + 2 * KT * 4;
+  constexpr int STAGE = 4 * KT * DH * 2 + 2 * KT * 4 + 4 * 256;   // + two 128-byte keep-bit blocks (the tile's two 32-query blocks) per wave
   constexpr int DS = 2;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   const int t = threadIdx.x, lane = t & 63, h = lane >> 5;
@@ -351,6 +364,12 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd_dkv_mfma(AttnM a, const bf1
       const float* src = (w == 0 ? lse : delta) + lbase + qq;
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                        (__attribute__((address_space(3))) void*)(st + 4 * KT * DH * 2 + w * KT * 4), 4, 0, 0);
+    }
+    if (DROP == DROP_BITS) {   // keep-bit blocks (query block of lanes 0-31 / 32-63, this wave's key block): 2 x 32 dwords
+      // (bits_block returns a wave-uniform pointer: the second query block of lanes 32-63 is a per-lane offset on top of it)
+      const uint32_t* src = (const uint32_t*)bits_block(a, b * a.H + hd, row0 >> 5, k0 >> 5) + (lane >> 5) * (a.nk32 * 32) + (lane & 31);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(st + 4 * KT * DH * 2 + 2 * KT * 4 + w * 256), 4, 0, 0);
     }
   };
   if (ntiles > 0) issue(0);
@@ -398,7 +417,17 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd_dkv_mfma(AttnM a, const bf1
 #pragma unroll
         for (int j = 0; j < 4; ++j) pd[4 * g4 + j] = fast_exp2(fmaf(s[4 * g4 + j], a.scale_log2, -Lq[j]));
       }
-      if (DROP) {
+      if (DROP == DROP_BITS) {   // one dword per lane and 32-query block: bit q = keep(query q, this lane's key)
+        const uint32_t word = ((const uint32_t*)(Qrow + 4 * KT * DH * 2 + 2 * KT * 4 + w * 256))[32 * blk + bits_word_of_key(lane & 31)] >> (4 * h);
+        const int sbits = __builtin_bit_cast(int, a.dd.scale16);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float kp = __builtin_bit_cast(float, __builtin_amdgcn_sbfe((int)word, ACC_ROW(r), 1) & sbits);   // scale or 0
+          dp[r] *= kp;
+          s[r] = pd[r];
+          pd[r] *= kp;
+        }
+      } else if (DROP == DROP_HASH) {
         // Dropout keep bits.  Element (q, key) has index i = (lbase+q)*Tk + key; with Tk even the two
         // lanes of a key pair (lane, lane^1) share the hash of i>>1 = (lbase+q)*(Tk/2) + key/2 and take
         // its low / high 16 bits.  The even lane hashes the even register rows, the odd lane the odd
@@ -482,6 +511,8 @@ static AttnM make_m(const afm_attn_shape* s) {
   a.lddq = a.lddk = a.lddv = 0;
   a.causal = s->causal; a.scale = s->scale; a.scale_log2 = s->scale * 1.4426950408889634f;
   a.key_pad = s->key_pad; a.dd = afm_make_drop(&s->drop);
+  a.bits = a.dd.thresh16 ? (unsigned long long*)s->drop_bits : nullptr;
+  a.nq32 = ((s->Tq + 127) / 128) * 4; a.nk32 = ((s->Tk + 63) / 64) * 2;      // whole workgroups / whole 64-key tiles
   return a;
 }
 
@@ -494,8 +525,9 @@ int afm_attn_fwd_mfma_try(const afm_attn_shape* s, const void* Q, const void* K,
   const dim3 grid(((s->Tq + 127) / 128) * s->H * s->B);
   const int shm = RS * 2 * KT * DH * 2 + ((s->Tk + KT - 1) / KT) * 8;
   if (shm > 64 * 1024) return AFM_ERR_UNSUPPORTED;
-  if (a.dd.thresh16) AFM_LAUNCH(k_attn_fwd_mfma<true>, grid, dim3(256), shm, st, a, (const bf16*)Q, (const bf16*)K, (const bf16*)V, (bf16*)O, lse);
-  else AFM_LAUNCH(k_attn_fwd_mfma<false>, grid, dim3(256), shm, st, a, (const bf16*)Q, (const bf16*)K, (const bf16*)V, (bf16*)O, lse);
+  if (a.dd.thresh16 && a.bits) AFM_LAUNCH(k_attn_fwd_mfma<DROP_BITS>, grid, dim3(256), shm, st, a, (const bf16*)Q, (const bf16*)K, (const bf16*)V, (bf16*)O, lse);
+  else if (a.dd.thresh16) AFM_LAUNCH(k_attn_fwd_mfma<DROP_HASH>, grid, dim3(256), shm, st, a, (const bf16*)Q, (const bf16*)K, (const bf16*)V, (bf16*)O, lse);
+  else AFM_LAUNCH(k_attn_fwd_mfma<DROP_NONE>, grid, dim3(256), shm, st, a, (const bf16*)Q, (const bf16*)K, (const bf16*)V, (bf16*)O, lse);
   afm_set_last_algo("attn_mfma");
   return AFM_OK;
 }
@@ -513,24 +545,28 @@ int afm_attn_bwd_mfma_try(const afm_attn_shape* s, const void* Q, const void* K,
   if (shm_q > 80 * 1024) return AFM_ERR_UNSUPPORTED;
   static bool attr_q = false;
   if (!attr_q) {
-    (void)hipFuncSetAttribute((const void*)k_attn_bwd_dq_mfma<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-    (void)hipFuncSetAttribute((const void*)k_attn_bwd_dq_mfma<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    (void)hipFuncSetAttribute((const void*)k_attn_bwd_dq_mfma<DROP_HASH>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    (void)hipFuncSetAttribute((const void*)k_attn_bwd_dq_mfma<DROP_BITS>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    (void)hipFuncSetAttribute((const void*)k_attn_bwd_dq_mfma<DROP_NONE>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
     attr_q = true;
   }
   const bool run_q = s->reserved != 2, run_k = s->reserved != 1;   // reserved = 1 / 2: only the dQ / only the dK-dV kernel (timing)
   if (!run_q) {}
-  else if (a.dd.thresh16) AFM_LAUNCH(k_attn_bwd_dq_mfma<true>, gq, dim3(256), shm_q, st, a, (const bf16*)Q, (const bf16*)K, (const bf16*)V, (const bf16*)O, (const bf16*)dO, lse, delta, (bf16*)dQ);
-  else AFM_LAUNCH(k_attn_bwd_dq_mfma<false>, gq, dim3(256), shm_q, st, a, (const bf16*)Q, (const bf16*)K, (const bf16*)V, (const bf16*)O, (const bf16*)dO, lse, delta, (bf16*)dQ);
-  const int shm_k = 2 * (4 * KT * DH * 2 + 2 * KT * 4);
+  else if (a.dd.thresh16 && a.bits) AFM_LAUNCH(k_attn_bwd_dq_mfma<DROP_BITS>, gq, dim3(256), shm_q, st, a, (const bf16*)Q, (const bf16*)K, (const bf16*)V, (const bf16*)O, (const bf16*)dO, lse, delta, (bf16*)dQ);
+  else if (a.dd.thresh16) AFM_LAUNCH(k_attn_bwd_dq_mfma<DROP_HASH>, gq, dim3(256), shm_q, st, a, (const bf16*)Q, (const bf16*)K, (const bf16*)V, (const bf16*)O, (const bf16*)dO, lse, delta, (bf16*)dQ);
+  else AFM_LAUNCH(k_attn_bwd_dq_mfma<DROP_NONE>, gq, dim3(256), shm_q, st, a, (const bf16*)Q, (const bf16*)K, (const bf16*)V, (const bf16*)O, (const bf16*)dO, lse, delta, (bf16*)dQ);
+  const int shm_k = 2 * (4 * KT * DH * 2 + 2 * KT * 4 + 4 * 256);
   static bool attr_k = false;
   if (!attr_k) {
-    (void)hipFuncSetAttribute((const void*)k_attn_bwd_dkv_mfma<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-    (void)hipFuncSetAttribute((const void*)k_attn_bwd_dkv_mfma<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    (void)hipFuncSetAttribute((const void*)k_attn_bwd_dkv_mfma<DROP_HASH>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    (void)hipFuncSetAttribute((const void*)k_attn_bwd_dkv_mfma<DROP_BITS>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    (void)hipFuncSetAttribute((const void*)k_attn_bwd_dkv_mfma<DROP_NONE>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
     attr_k = true;
   }
   if (!run_k) {}
-  else if (a.dd.thresh16) AFM_LAUNCH(k_attn_bwd_dkv_mfma<true>, gk, dim3(256), shm_k, st, a, (const bf16*)Q, (const bf16*)K, (const bf16*)V, (const bf16*)dO, lse, delta, (bf16*)dK, (bf16*)dV);
-  else AFM_LAUNCH(k_attn_bwd_dkv_mfma<false>, gk, dim3(256), shm_k, st, a, (const bf16*)Q, (const bf16*)K, (const bf16*)V, (const bf16*)dO, lse, delta, (bf16*)dK, (bf16*)dV);
+  else if (a.dd.thresh16 && a.bits) AFM_LAUNCH(k_attn_bwd_dkv_mfma<DROP_BITS>, gk, dim3(256), shm_k, st, a, (const bf16*)Q, (const bf16*)K, (const bf16*)V, (const bf16*)dO, lse, delta, (bf16*)dK, (bf16*)dV);
+  else if (a.dd.thresh16) AFM_LAUNCH(k_attn_bwd_dkv_mfma<DROP_HASH>, gk, dim3(256), shm_k, st, a, (const bf16*)Q, (const bf16*)K, (const bf16*)V, (const bf16*)dO, lse, delta, (bf16*)dK, (bf16*)dV);
+  else AFM_LAUNCH(k_attn_bwd_dkv_mfma<DROP_NONE>, gk, dim3(256), shm_k, st, a, (const bf16*)Q, (const bf16*)K, (const bf16*)V, (const bf16*)dO, lse, delta, (bf16*)dK, (bf16*)dV);
   afm_set_last_algo("attn_mfma");
   return AFM_OK;
 }

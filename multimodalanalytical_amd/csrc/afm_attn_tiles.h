@@ -15,6 +15,8 @@ struct AttnM {
   float scale;
   const uint8_t* key_pad;
   DropDev dd;
+  unsigned long long* bits;   // keep-bit tensor (include/afm_hip.h: afm_attn_shape.drop_bits), null = re-hash
+  int nq32, nk32;
 };
 
 typedef __attribute__((ext_vector_type(4))) short s16x4;
@@ -223,3 +225,70 @@ __device__ __forceinline__ TrQuad tr_quad_dual(const unsigned (&xa)[4], const un
   q.hi1 = tr_rd<IMG + (16 * SL + 8) * 128>(xb[DHI]);
   return q;
 }
+
+// ------------------------------------------------------------------------------------------ keep-bit tensor
+// DROP template values of the MFMA attention kernels: 0 no dropout, 1 hash per score pair, 2 keep-bit tensor (forward:
+// hash + emit the lane masks; backward: read them).
+enum { DROP_NONE = 0, DROP_HASH = 1, DROP_BITS = 2 };
+__device__ __forceinline__ unsigned long long* bits_block(const AttnM& a, int bh, int qb32, int kb32) {
+  // every index is wave-uniform; readfirstlane tells the compiler so (the masks then travel through SGPRs: s_load / s_store)
+  unsigned long long* p = a.bits + (((int64_t)bh * a.nq32 + qb32) * a.nk32 + kb32) * 16;
+  const uint64_t u = (uint64_t)p;
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)u), hi = __builtin_amdgcn_readfirstlane((uint32_t)(u >> 32));
+  return (unsigned long long*)(((uint64_t)hi << 32) | lo);
+}
+// forward: dropout of a 32x32 transposed score block (as drop_block) + the 16 lane masks to `blk` (wave-uniform pointer)
+// through the scalar store path: no vector instruction, no VGPR
+template <int R>
+__device__ __forceinline__ void drop_emit_rows(const DropDev& dd, uint32_t base, f32x16& x, unsigned long long* blk) {
+  if constexpr (R < 16) {
+    const uint32_t hsh = hash_pair32(dd, base + (uint32_t)(ACC_ROW(R) >> 1));
+    const bool k0 = (hsh & 0xFFFFu) >= dd.thresh16, k1 = (hsh >> 16) >= dd.thresh16;
+    const unsigned long long m0 = __ballot(k0), m1 = __ballot(k1);
+    x[R] = k0 ? x[R] : 0.f;
+    x[R + 1] = k1 ? x[R + 1] : 0.f;
+    asm volatile("s_store_dwordx2 %0, %1, %2" ::"s"(m0), "s"(blk), "n"(R * 8) : "memory");
+    asm volatile("s_store_dwordx2 %0, %1, %2" ::"s"(m1), "s"(blk), "n"(R * 8 + 8) : "memory");
+    drop_emit_rows<R + 2>(dd, base, x, blk);
+  }
+}
+__device__ __forceinline__ void drop_block_emit(const DropDev& dd, uint32_t rowbase, int key0, int h, f32x16& x,
+                                                unsigned long long* blk) {
+  drop_emit_rows<0>(dd, (rowbase + (uint32_t)(key0 + 4 * h)) >> 1, x, blk);
+}
+__device__ __forceinline__ void bits_flush() {   // before the kernel ends: write the scalar cache back
+  asm volatile("s_dcache_wb\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+}
+// backward, query-on-lane layout (dQ kernel): x[r] = keep ? x[r] * scale : 0 with the block's 16 masks as SGPR pairs.
+// The loads are explicit (the compiler only picks the scalar path when it can prove nobody writes the memory): two
+// s_load_dwordx16 issued at the top of the key tile (keep_masks_issue), waited for by hand right before use
+// (keep_masks_wait, which ties the 32 SGPRs through "+s" so nothing consumes them earlier), ~1 us of MFMA work in between.
+typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));
+struct KeepMasks { u32x16 a, b; };
+__device__ __forceinline__ void keep_masks_issue(KeepMasks& m, const unsigned long long* blk) {
+  asm volatile("s_load_dwordx16 %0, %2, 0x0\n\ts_load_dwordx16 %1, %2, 0x40" : "=&s"(m.a), "=&s"(m.b) : "s"(blk) : "memory");
+}
+__device__ __forceinline__ void keep_masks_wait(KeepMasks& m) {
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(m.a), "+s"(m.b));
+}
+template <int R>
+__device__ __forceinline__ void keep_apply_rows(f32x16& x, const KeepMasks& m, float scale) {
+  // The multiply is ordinary C++ ON PURPOSE: x comes straight out of an MFMA chain and hipcc inserts the MFMA -> VALU wait
+  // states only for instructions it emits itself; an asm v_cndmask reading the accumulator directly executed too early and
+  // saw stale registers (found by bit-comparing against the re-hash path).
+  if constexpr (R < 16) {
+    const u32x16& v = R < 8 ? m.a : m.b;
+    const unsigned long long mk = ((unsigned long long)v[2 * (R & 7) + 1] << 32) | v[2 * (R & 7)];
+    const float t = x[R] * scale;
+    float y;
+    asm volatile("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(y) : "v"(t), "s"(mk));
+    x[R] = y;
+    keep_apply_rows<R + 1>(x, m, scale);
+  }
+}
+__device__ __forceinline__ void drop_apply_masks(f32x16& x, KeepMasks& m, float scale) {
+  keep_masks_wait(m);
+  keep_apply_rows<0>(x, m, scale);
+}
+// backward, key-on-lane layout (dK/dV kernel): dword of the block that holds this lane's key (bit q = keep of the tile's query q)
+__device__ __forceinline__ int bits_word_of_key(int j) { return 2 * ((j & 3) + 4 * (j >> 3)) + ((j >> 2) & 1); }

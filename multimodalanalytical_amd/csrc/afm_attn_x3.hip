@@ -41,7 +41,7 @@ __device__ __forceinline__ uint32_t mask32_of(const unsigned long long* maskw, i
 }
 
 // ------------------------------------------------------------------------------------------ forward
-template <bool DROP>
+template <int DROP>
 __global__ __launch_bounds__(256, 2) void k_attn_fwd_x3(AttnM a, const bf16* __restrict__ Q,
                                                         const bf16* __restrict__ K,
                                                         const bf16* __restrict__ V, bf16* __restrict__ O,
@@ -140,9 +140,14 @@ __global__ __launch_bounds__(256, 2) void k_attn_fwd_x3(AttnM a, const bf16* __r
     l = l * alpha + ls;
 #pragma unroll
     for (int i = 0; i < 16; ++i) { o[0][i] *= alpha; o[1][i] *= alpha; }
-    if (DROP) {
+    if (DROP == DROP_HASH) {
       drop_block(a.dd, rowbase, kb, h, s[0]);
       drop_block(a.dd, rowbase, kb + 32, h, s[1]);
+    }
+    if (DROP == DROP_BITS) {   // the same dropout, and the keep bits of both 32-key blocks go to the keep-bit tensor
+      unsigned long long* bb = bits_block(a, b * a.H + hd, q0 >> 5, kb >> 5);
+      drop_block_emit(a.dd, rowbase, kb, h, s[0], bb);
+      drop_block_emit(a.dd, rowbase, kb + 32, h, s[1], bb + 16);
     }
     unsigned vh0, vh1;
     tr_lane_addr(Vh, lane, vh0, vh1);
@@ -161,6 +166,7 @@ __global__ __launch_bounds__(256, 2) void k_attn_fwd_x3(AttnM a, const bf16* __r
       o[1] = mfma3(tr_join(vh.lo1, vh.hi1), tr_join(vl.lo1, vl.hi1), ph, pl, o[1]);
     }
   }
+  if (DROP == DROP_BITS) bits_flush();
   l += __shfl_xor(l, 32, 64);
   const float inv = l > 0.f ? a.dd.scale16 / l : 0.f;
   if (q < a.Tq) {
@@ -177,7 +183,7 @@ __global__ __launch_bounds__(256, 2) void k_attn_fwd_x3(AttnM a, const bf16* __r
 }
 
 // ------------------------------------------------------------------------------------------ dQ
-template <bool DROP>
+template <int DROP>
 __global__ __launch_bounds__(256, 2) void k_attn_bwd_dq_x3(AttnM a, const bf16* __restrict__ Q,
                                                            const bf16* __restrict__ K,
                                                            const bf16* __restrict__ V,
@@ -251,6 +257,8 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd_dq_x3(AttnM a, const bf16* 
     const unsigned char* Vrh = Krh + 2 * IMG32;
     const unsigned char* Vrl = Krh + 3 * IMG32;
     const uint32_t pad = mword >> (4 * h);
+    KeepMasks km;
+    if (DROP == DROP_BITS) keep_masks_issue(km, bits_block(a, b * a.H + hd, q0 >> 5, kt));
     f32x16 s, dp;
 #pragma unroll
     for (int i = 0; i < 16; ++i) { s[i] = 0.f; dp[i] = 0.f; }
@@ -259,11 +267,12 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd_dq_x3(AttnM a, const bf16* 
       s = mfma3(frag_row_dual(Krh, 0, ks, lane), frag_row_dual(Krl, 0, ks, lane), qh[ks], ql[ks], s);
       dp = mfma3(frag_row(Vrh, 0, ks, lane), frag_row(Vrl, 0, ks, lane), dh_[ks], dl_[ks], dp);
     }
-    if (DROP) {
+    if (DROP == DROP_HASH) {
       drop_block(a.dd, rowbase, kb, h, dp);
 #pragma unroll
       for (int r = 0; r < 16; ++r) dp[r] *= a.dd.scale16;
     }
+    if (DROP == DROP_BITS) drop_apply_masks(dp, km, a.dd.scale16);
     if (mword != 0u || (a.causal && (kb + KT2 - 1 > q0))) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
@@ -311,7 +320,7 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd_dq_x3(AttnM a, const bf16* 
 // S = Q K^T / dP = dO V^T, transposed reads for dV^T += dO^T P / dK^T += Q^T dS) + lse / delta: 16.5 KiB, two stages.
 // The wave's K / V fragments: hi planes in registers, lo planes parked in LDS (8 KiB per wave, re-read per tile), so
 // the kernel holds dK, dV, K hi, V hi (96 registers) and stays clear of scratch at two waves per SIMD.
-template <bool DROP>
+template <int DROP>
 __global__ __launch_bounds__(256, 2) void k_attn_bwd_dkv_x3(AttnM a, const bf16* __restrict__ Q,
                                                             const bf16* __restrict__ K,
                                                             const bf16* __restrict__ V,
@@ -320,7 +329,7 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd_dkv_x3(AttnM a, const bf16*
                                                             const float* __restrict__ delta,
                                                             bf16* __restrict__ dK, bf16* __restrict__ dV) {
   constexpr int QT = 32, NS = 2;
-  constexpr int STAGE = 4 * IMG32 + 2 * 64 * 4;
+  constexpr int STAGE = 4 * IMG32 + 2 * 64 * 4 + 4 * 256;   // + one 256-byte keep-bit block per wave
   constexpr int KVL = 4 * 2 * 4096;             // parked lo fragments: [wave][K | V][slice][lane] x 16 B
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   unsigned char* ring = lds + KVL;
@@ -372,6 +381,11 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd_dkv_x3(AttnM a, const bf16*
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                        (__attribute__((address_space(3))) void*)(st + 4 * IMG32 + w * 64 * 4), 4, 0, 0);
     }
+    if (DROP == DROP_BITS) {   // this wave's (query block, key block) of the keep-bit tensor: 32 dwords (upper lanes: duplicates)
+      const uint32_t* src = (const uint32_t*)bits_block(a, b * a.H + hd, row0 >> 5, k0 >> 5) + (lane & 31);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(st + 4 * IMG32 + 2 * 64 * 4 + w * 256), 4, 0, 0);
+    }
   };
   const unsigned t0 = tr_dual_t0(lane);
   if (ntiles > 0) issue(0);
@@ -413,7 +427,21 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd_dkv_x3(AttnM a, const bf16*
 #pragma unroll
       for (int j = 0; j < 4; ++j) s[4 * g4 + j] = fast_exp2(fmaf(s[4 * g4 + j], a.scale_log2, -Lq[j]));
     }
-    if (DROP) {   // keep bits as in k_attn_bwd_dkv_mfma: the lanes of a key pair share one hash (DPP exchange)
+    if (DROP == DROP_BITS) {   // one dword per lane: bit q = keep(query q of the tile, this lane's key)
+      const uint32_t word = ((const uint32_t*)(Qh + 4 * IMG32 + 2 * 64 * 4 + w * 256))[bits_word_of_key(lane & 31)] >> (4 * h);
+      const int sbits = __builtin_bit_cast(int, a.dd.scale16);
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const f32x4 Dq = *(const f32x4*)(Ds + 8 * g4 + 4 * h);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int r = 4 * g4 + j;
+          const float kp = __builtin_bit_cast(float, __builtin_amdgcn_sbfe((int)word, ACC_ROW(r), 1) & sbits);   // scale or 0
+          dp[r] = (dp[r] * kp - Dq[j]) * s[r];
+          s[r] *= kp;
+        }
+      }
+    } else if (DROP == DROP_HASH) {   // keep bits as in k_attn_bwd_dkv_mfma: the lanes of a key pair share one hash (DPP exchange)
       const uint32_t htk = (uint32_t)a.Tk >> 1;
       const uint32_t tb = (uint32_t)(lbase + qb + 4 * h + (lane & 1)) * htk + ((uint32_t)key >> 1);
       const uint32_t hshift = (lane & 1) << 4;
@@ -506,6 +534,8 @@ static AttnM make_m_x3(const afm_attn_shape* s) {
   a.lddq = a.lddk = a.lddv = 0;
   a.causal = s->causal; a.scale = s->scale; a.scale_log2 = s->scale * 1.4426950408889634f;
   a.key_pad = s->key_pad; a.dd = afm_make_drop(&s->drop);
+  a.bits = a.dd.thresh16 ? (unsigned long long*)s->drop_bits : nullptr;
+  a.nq32 = ((s->Tq + 127) / 128) * 4; a.nk32 = ((s->Tk + 63) / 64) * 2;      // whole workgroups / whole 64-key tiles
   return a;
 }
 
@@ -520,12 +550,14 @@ int afm_attn_fwd_x3_try(const afm_attn_shape* s, const void* Q, const void* K, c
   if (shm > 80 * 1024) return AFM_ERR_UNSUPPORTED;
   static bool attr = false;
   if (!attr) {
-    (void)hipFuncSetAttribute((const void*)k_attn_fwd_x3<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-    (void)hipFuncSetAttribute((const void*)k_attn_fwd_x3<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    (void)hipFuncSetAttribute((const void*)k_attn_fwd_x3<DROP_HASH>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    (void)hipFuncSetAttribute((const void*)k_attn_fwd_x3<DROP_BITS>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    (void)hipFuncSetAttribute((const void*)k_attn_fwd_x3<DROP_NONE>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
     attr = true;
   }
-  if (a.dd.thresh16) AFM_LAUNCH(k_attn_fwd_x3<true>, grid, dim3(256), shm, st, a, (const bf16*)Q, (const bf16*)K, (const bf16*)V, (bf16*)O, lse);
-  else AFM_LAUNCH(k_attn_fwd_x3<false>, grid, dim3(256), shm, st, a, (const bf16*)Q, (const bf16*)K, (const bf16*)V, (bf16*)O, lse);
+  if (a.dd.thresh16 && a.bits) AFM_LAUNCH(k_attn_fwd_x3<DROP_BITS>, grid, dim3(256), shm, st, a, (const bf16*)Q, (const bf16*)K, (const bf16*)V, (bf16*)O, lse);
+  else if (a.dd.thresh16) AFM_LAUNCH(k_attn_fwd_x3<DROP_HASH>, grid, dim3(256), shm, st, a, (const bf16*)Q, (const bf16*)K, (const bf16*)V, (bf16*)O, lse);
+  else AFM_LAUNCH(k_attn_fwd_x3<DROP_NONE>, grid, dim3(256), shm, st, a, (const bf16*)Q, (const bf16*)K, (const bf16*)V, (bf16*)O, lse);
   afm_set_last_algo("attn_mfma_x3");
   return AFM_OK;
 }
@@ -540,23 +572,27 @@ int afm_attn_bwd_x3_try(const afm_attn_shape* s, const void* Q, const void* K, c
   a.lddq = lddq; a.lddk = lddk; a.lddv = lddv;
   const dim3 gq(((s->Tq + 127) / 128) * s->H * s->B), gk(((s->Tk + 127) / 128) * s->H * s->B);
   const int shm_q = 2 * 4 * IMG32 + ((s->Tk + 63) / 64) * 8;
-  const int shm_k = 4 * 2 * 4096 + 2 * (4 * IMG32 + 2 * 64 * 4);
+  const int shm_k = 4 * 2 * 4096 + 2 * (4 * IMG32 + 2 * 64 * 4 + 4 * 256);
   if (shm_q > 80 * 1024) return AFM_ERR_UNSUPPORTED;
   static bool attr = false;
   if (!attr) {
-    (void)hipFuncSetAttribute((const void*)k_attn_bwd_dq_x3<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-    (void)hipFuncSetAttribute((const void*)k_attn_bwd_dq_x3<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-    (void)hipFuncSetAttribute((const void*)k_attn_bwd_dkv_x3<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-    (void)hipFuncSetAttribute((const void*)k_attn_bwd_dkv_x3<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    (void)hipFuncSetAttribute((const void*)k_attn_bwd_dq_x3<DROP_HASH>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    (void)hipFuncSetAttribute((const void*)k_attn_bwd_dq_x3<DROP_BITS>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    (void)hipFuncSetAttribute((const void*)k_attn_bwd_dq_x3<DROP_NONE>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    (void)hipFuncSetAttribute((const void*)k_attn_bwd_dkv_x3<DROP_HASH>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    (void)hipFuncSetAttribute((const void*)k_attn_bwd_dkv_x3<DROP_BITS>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    (void)hipFuncSetAttribute((const void*)k_attn_bwd_dkv_x3<DROP_NONE>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
     attr = true;
   }
   const bool run_q = s->reserved != 2, run_k = s->reserved != 1;   // reserved = 1 / 2: only the dQ / only the dK-dV kernel (timing)
   if (!run_q) {}
-  else if (a.dd.thresh16) AFM_LAUNCH(k_attn_bwd_dq_x3<true>, gq, dim3(256), shm_q, st, a, (const bf16*)Q, (const bf16*)K, (const bf16*)V, (const bf16*)O, (const bf16*)dO, lse, delta, (bf16*)dQ);
-  else AFM_LAUNCH(k_attn_bwd_dq_x3<false>, gq, dim3(256), shm_q, st, a, (const bf16*)Q, (const bf16*)K, (const bf16*)V, (const bf16*)O, (const bf16*)dO, lse, delta, (bf16*)dQ);
+  else if (a.dd.thresh16 && a.bits) AFM_LAUNCH(k_attn_bwd_dq_x3<DROP_BITS>, gq, dim3(256), shm_q, st, a, (const bf16*)Q, (const bf16*)K, (const bf16*)V, (const bf16*)O, (const bf16*)dO, lse, delta, (bf16*)dQ);
+  else if (a.dd.thresh16) AFM_LAUNCH(k_attn_bwd_dq_x3<DROP_HASH>, gq, dim3(256), shm_q, st, a, (const bf16*)Q, (const bf16*)K, (const bf16*)V, (const bf16*)O, (const bf16*)dO, lse, delta, (bf16*)dQ);
+  else AFM_LAUNCH(k_attn_bwd_dq_x3<DROP_NONE>, gq, dim3(256), shm_q, st, a, (const bf16*)Q, (const bf16*)K, (const bf16*)V, (const bf16*)O, (const bf16*)dO, lse, delta, (bf16*)dQ);
   if (!run_k) {}
-  else if (a.dd.thresh16) AFM_LAUNCH(k_attn_bwd_dkv_x3<true>, gk, dim3(256), shm_k, st, a, (const bf16*)Q, (const bf16*)K, (const bf16*)V, (const bf16*)dO, lse, delta, (bf16*)dK, (bf16*)dV);
-  else AFM_LAUNCH(k_attn_bwd_dkv_x3<false>, gk, dim3(256), shm_k, st, a, (const bf16*)Q, (const bf16*)K, (const bf16*)V, (const bf16*)dO, lse, delta, (bf16*)dK, (bf16*)dV);
+  else if (a.dd.thresh16 && a.bits) AFM_LAUNCH(k_attn_bwd_dkv_x3<DROP_BITS>, gk, dim3(256), shm_k, st, a, (const bf16*)Q, (const bf16*)K, (const bf16*)V, (const bf16*)dO, lse, delta, (bf16*)dK, (bf16*)dV);
+  else if (a.dd.thresh16) AFM_LAUNCH(k_attn_bwd_dkv_x3<DROP_HASH>, gk, dim3(256), shm_k, st, a, (const bf16*)Q, (const bf16*)K, (const bf16*)V, (const bf16*)dO, lse, delta, (bf16*)dK, (bf16*)dV);
+  else AFM_LAUNCH(k_attn_bwd_dkv_x3<DROP_NONE>, gk, dim3(256), shm_k, st, a, (const bf16*)Q, (const bf16*)K, (const bf16*)V, (const bf16*)dO, lse, delta, (bf16*)dK, (bf16*)dV);
   afm_set_last_algo("attn_mfma_x3");
   return AFM_OK;
 }

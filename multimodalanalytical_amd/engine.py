@@ -15,6 +15,8 @@ from __future__ import annotations
 
 from typing import Any, Dict, List, Optional
 
+import os
+
 import torch
 
 from . import ops
@@ -66,6 +68,8 @@ class Seq2SeqEngine:
         self.cfg["align_config"] = self.align
         self.x3 = compute_dtype == BF16X3
         self.lowp = compute_dtype != torch.float32          # operands are not plain fp32: MFMA kernels, transposed weight copies
+        # attention-probability dropout: forward stores 1 keep bit per score, backward reads it (AFM_ATTN_KEEP_BITS=0: re-hash)
+        self.keep_bits = os.environ.get("AFM_ATTN_KEEP_BITS", "1") != "0"
         self.branch_dtype = torch.float32 if self.x3 else None   # residual branches: fp32 out of the x3 GEMMs (same bytes as a pair)
         self.ps = ParamStore(build_specs(self.cfg, data_config, self.V), self.dev,
                              with_bf16=compute_dtype == torch.bfloat16, with_x2=self.x3)
@@ -397,6 +401,13 @@ class Seq2SeqEngine:
                           self.ps.g(prefix + "bias"), ws, dres=dres, dx_drop=dxd, dropout=dr)
         return dx, dxd
 
+    def _attach_drop_bits(self, shp, saved) -> None:
+        """With backward pending and dropout on, the forward attention kernel also writes the keep bits of its dropout
+        (1 bit per score, B*H*Tq*Tk/8 bytes) and the backward kernels read them instead of re-hashing every score."""
+        if saved is not None and self.lowp and shp.drop.p > 0.0 and self.keep_bits:
+            n = ops.attn_drop_bits_words(shp.B, shp.H, shp.Tq, shp.Tk)
+            ops.attn_set_drop_bits(shp, torch.empty(n, dtype=torch.int64, device=self.dev))
+
     def _self_attn_fwd(self, x, pend, p, B, T, H, key_pad, causal, saved, site):
         """x + pend is the incoming stream; returns (stream, this block's branch to be added)."""
         d = self.d
@@ -407,6 +418,7 @@ class Seq2SeqEngine:
         lq, la = ops._ld(qkv), ops._ld(a)
         shp = ops.attn_shape(B, H, T, T, d // H, self.cd, lq, lq, lq, la, key_pad, causal,
                              self._drop(site + "attn"), self.algo)
+        self._attach_drop_bits(shp, saved)
         ops.attn_fwd(shp, qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], a, lse)
         br = self._linear(a, p + "self_attn.out_proj.weight", d, d, bias_name=p + "self_attn.out_proj.bias",
                           out_dtype=self.branch_dtype)
@@ -498,6 +510,7 @@ class Seq2SeqEngine:
         lse = torch.empty(B * H * T, dtype=torch.float32, device=self.dev)
         shp = ops.attn_shape(B, H, T, S, d // H, self.cd, ops._ld(q), ops._ld(kv), ops._ld(kv), ops._ld(a), mem_pad, False,
                              self._drop(site + "xattn"), self.algo)
+        self._attach_drop_bits(shp, saved)
         ops.attn_fwd(shp, q, kv[:, :d], kv[:, d:], a, lse)
         br = self._linear(a, p + "multihead_attn.out_proj.weight", d, d,
                           bias_name=p + "multihead_attn.out_proj.bias", out_dtype=self.branch_dtype)

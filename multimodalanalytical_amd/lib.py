@@ -76,6 +76,7 @@ class AttnShape(C.Structure):
         ("key_pad", C.c_void_p),
         ("drop", Dropout),
         ("sqb", C.c_int64), ("skb", C.c_int64), ("svb", C.c_int64), ("sob", C.c_int64),
+        ("drop_bits", C.c_void_p),
     ]
 
 

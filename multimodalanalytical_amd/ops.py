@@ -215,6 +215,19 @@ def attn_shape(B, H, Tq, Tk, dh, dtype, ldq, ldk, ldv, ldo, key_pad=None, causal
     return s
 
 
+def attn_drop_bits_words(B, H, Tq, Tk) -> int:
+    """uint64 words of the keep-bit tensor of one attention call (afm_attn_shape.drop_bits)."""
+    return B * H * (((Tq + 127) // 128) * 4) * (((Tk + 63) // 64) * 2) * 16
+
+
+def attn_set_drop_bits(s: AttnShape, bits) -> AttnShape:
+    if bits is not None:
+        assert bits.dtype == torch.int64 and bits.is_contiguous() and bits.numel() >= attn_drop_bits_words(s.B, s.H, s.Tq, s.Tk)
+    s.drop_bits = _ptr(bits)
+    s._bits_keepalive = bits
+    return s
+
+
 def attn_fwd(s: AttnShape, q, k, v, o, lse):
     L.check(L.load().afm_attn_fwd(C.byref(s), _ptr(q), _ptr(k), _ptr(v), _ptr(o), _ptr(lse), _stream()),
             "afm_attn_fwd")

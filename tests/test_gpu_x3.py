@@ -129,6 +129,34 @@ def test_gemm_x3_falls_back_to_exact_kernel_on_odd_shapes(ops):
     assert relnorm(c.float(), a.double() @ w.double().T) < 1e-5
 
 
+def _check_keep_bits(bits, keep, B, H, Tq, Tk, key_pad, causal):
+    """Every block the kernels can read (not skipped as fully masked / above the diagonal) must hold the stream's bits."""
+    import numpy as np
+    nq32, nk32 = ((Tq + 127) // 128) * 4, ((Tk + 63) // 64) * 2
+    w = bits.cpu().numpy().view(np.uint64).reshape(B, H, nq32, nk32, 16)
+    l = np.arange(64)
+    lu = l.astype(np.uint64)
+    kp = None if key_pad is None else key_pad.numpy()
+    checked = 0
+    for b in range(B):
+        for qb in range((Tq + 31) // 32):
+            for kb in range((Tk + 31) // 32):
+                t64 = slice(64 * (kb // 2), min(Tk, 64 * (kb // 2) + 64))
+                if kp is not None and kp[b, t64].all():
+                    continue                       # whole 64-key tile is padding: skipped by the forward kernel
+                if causal and 64 * (kb // 2) > qb * 32 + 31:
+                    continue                       # tile above the wave's diagonal
+                for r in range(16):
+                    q = qb * 32 + (l & 31)
+                    key = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5)
+                    ok = (q < Tq) & (key < Tk)
+                    got = (np.uint64(w[b, 0, qb, kb, r]) >> lu) & np.uint64(1)
+                    want = keep[b, 0].numpy()[np.minimum(q, Tq - 1), np.minimum(key, Tk - 1)]
+                    assert np.array_equal(got[ok].astype(bool), want[ok]), (b, qb, kb, r)
+                    checked += 1
+    assert checked > 0
+
+
 @pytest.mark.parametrize("B,H,Tq,Tk,causal,pad,pdrop", [
     (2, 2, 128, 128, True, True, 0.0), (2, 3, 100, 200, False, True, 0.0), (1, 2, 300, 300, False, False, 0.0),
     (1, 2, 192, 192, True, False, 0.0), (2, 2, 128, 256, False, True, 0.1), (1, 2, 160, 160, True, True, 0.1),
@@ -158,8 +186,14 @@ def test_attention_x3(ops, B, H, Tq, Tk, causal, pad, pdrop):
     o, lse = X2.empty(B * Tq, D, DEV), torch.empty(B * H * Tq, device=DEV)
     shp = ops.attn_shape(B, H, Tq, Tk, dh, X2.dtype, ops._ld(qd), ops._ld(kd), ops._ld(vd), ops._ld(o), kp, causal,
                          ops.drop(pdrop, seed, site), algo=2)
+    bits = None
+    if pdrop > 0:   # keep-bit tensor: written by the forward kernel, read by both backward kernels
+        bits = torch.zeros(ops.attn_drop_bits_words(B, H, Tq, Tk), dtype=torch.int64, device=DEV)
+        ops.attn_set_drop_bits(shp, bits)
     ops.attn_fwd(shp, qd, kd, vd, o, lse)
     assert ops.last_algo() == "attn_mfma_x3"
+    if bits is not None:
+        _check_keep_bits(bits, keep, B, H, Tq, Tk, key_pad, causal)
     qr, kr, vr, ref = _attn_ref(q, k, v, key_pad, causal, keep, dscale)
     ref_o = ref.transpose(1, 2).reshape(B * Tq, D)
     assert relnorm(o.float(), ref_o.detach()) < 2e-5

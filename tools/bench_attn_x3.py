@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--B", type=int, default=128); ap.add_argument("--H", type=int, default=8)
     ap.add_argument("--S", type=int, default=1024); ap.add_argument("--Tq", type=int, default=0)
     ap.add_argument("--p", type=float, default=0.1); ap.add_argument("--causal", type=int, default=0)
+    ap.add_argument("--bits", type=int, default=1, help="1: forward stores the keep-bit tensor, backward reads it; 0: re-hash")
     a = ap.parse_args()
     dev = "cuda:0"
     cd = {"bf16": torch.bfloat16, "bf16x3": X2.dtype, "fp32": torch.float32}[a.mode]
@@ -45,7 +46,8 @@ def main():
     def shp(res):
         s = ops.attn_shape(B, H, Tq, S, dh, cd, ops._ld(q), ops._ld(k), ops._ld(v), ops._ld(o), None, bool(a.causal), dr)
         s.reserved = res
-        return s
+        return ops.attn_set_drop_bits(s, bits)
+    bits = torch.zeros(ops.attn_drop_bits_words(B, H, Tq, S), dtype=torch.int64, device=dev) if a.bits and a.p > 0 else None
     s0, s1, s2 = shp(0), shp(1), shp(2)
     passes = 3 if a.mode == "bf16x3" else 1
     for name, fn, np_ in (("fwd", lambda: ops.attn_fwd(s0, q, k, v, o, lse), 2),
