@@ -451,6 +451,10 @@ __global__ __launch_bounds__(512) void k_x3_nt256(X3Args g) {
     }
   };
   auto off = [](int row, int chunk) { return row * 128 + ((chunk ^ (row & 7)) << 4); };
+  if (g.abl >> 4) {
+    const int ph = bx & 3;
+    for (int i = 0; i < ph * (g.abl >> 4); ++i) __builtin_amdgcn_s_sleep(127);
+  }
   issue_one();
   const int fr = lane & 15, fq = lane >> 4;
   int slot = 0;
@@ -825,6 +829,7 @@ int afm_gemm_x3_try(const afm_gemm_desc* d, hipStream_t st) {
   g.dd = afm_make_drop(&d->drop);
   g.tiles_m = g.tiles_n = 0; g.ksplit = 1; g.kchunk = d->K; g.bias_in_lds = 0;
   g.abl = (d->reserved >= 320 && d->reserved < 328) ? d->reserved - 320 : 0;
+  if (d->reserved >= 400 && d->reserved < 464) g.abl = (d->reserved - 400) << 4;   // stagger experiment: sleeps per phase
   g.glu_f = d->glu_rows;
   // 16-byte pieces of both planes: pointers 16-byte aligned, plane offsets (ld / 2) multiples of 8 elements
   if (!x3_al16(d->A) || !x3_al16(d->B) || (d->lda & 15) || (d->ldb & 15)) return AFM_ERR_UNSUPPORTED;

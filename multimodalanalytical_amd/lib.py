@@ -139,20 +139,24 @@ def load(build_if_missing: bool = True):
             return _lib
         # (re)build whenever hipcc is here: csrc/build.py stamps every object with a digest of its sources, so
         # this is a no-op for a fresh library and a stale git-ignored .so can never be loaded silently
+        override = os.environ.get("AFM_LIB_OVERRIDE")   # timing experiments: an ablation build of the same sources (tools/)
+        if override:
+            build_if_missing = False
         if build_if_missing:
             from .csrc import build as _b
             if _b.have_hipcc():
                 _b.build()
-        if not os.path.exists(LIB_PATH):
-            raise AfmError(f"{LIB_PATH} is missing; run `python -m multimodalanalytical_amd.csrc.build`")
+        lib_path = override or LIB_PATH
+        if not os.path.exists(lib_path):
+            raise AfmError(f"{lib_path} is missing; run `python -m multimodalanalytical_amd.csrc.build`")
         # torch ships its own libamdhip64: it must be the HIP runtime already resident when this library's
         # dependency on that soname is resolved, or the process ends up with two runtimes (the system one
         # bound here, torch's owning every stream and pointer) and every launch fails
         import torch  # noqa: F401
         try:
-            lib = C.CDLL(LIB_PATH)
+            lib = C.CDLL(lib_path)
         except OSError as e:  # no CPU fallback by design
-            raise AfmError(f"cannot load {LIB_PATH}: {e}") from e
+            raise AfmError(f"cannot load {lib_path}: {e}") from e
         for name, (res, args) in _SIGS.items():
             try:
                 fn = getattr(lib, name)

@@ -9,7 +9,7 @@ from multimodalanalytical_amd.x2 import X2
 SHAPES = {"qkv": (131072, 1536, 512), "out": (131072, 512, 512), "ffn1": (131072, 2048, 512), "ffn2": (131072, 512, 2048)}
 
 
-def t(fn, iters=10, warm=3):
+def t(fn, iters=30, warm=5):
     for _ in range(warm): fn()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize(); a.record()

@@ -1,0 +1,102 @@
+// Micro-benchmark: do the MFMA phase of one wave and the VALU phase of ANOTHER wave on the same SIMD overlap?
+// Each wave loops { NM dependent-free MFMAs ; NV plain VALU (optionally NE v_exp among them) }.  Launched with
+// 1 wave per SIMD (256 threads, 1 WG/CU via LDS) and 2 waves per SIMD (two WGs per CU), same total work per wave.
+// hipcc --offload-arch=gfx950 -O3 -o coissue coissue.hip && ./coissue
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+template <int NM, int NV, int NE>
+__global__ __launch_bounds__(256) void k(float* out, int iters, int lds_touch) {
+  extern __shared__ float sh[];
+  if (lds_touch) sh[threadIdx.x] = 0.f;
+  bf16x8 a, b;
+  for (int i = 0; i < 8; ++i) { a[i] = (__bf16)(0.001f * (threadIdx.x + i)); b[i] = (__bf16)(0.002f * i); }
+  f32x16 acc[4];
+  for (int j = 0; j < 4; ++j) for (int i = 0; i < 16; ++i) acc[j][i] = 0.f;
+  float v[8];
+  for (int i = 0; i < 8; ++i) v[i] = 0.5f + 0.01f * i + 0.001f * threadIdx.x;
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int m = 0; m < NM; ++m) acc[m & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[m & 3], 0, 0, 0);
+#pragma unroll
+    for (int n = 0; n < NV; ++n) {
+      if (n < NE) asm volatile("v_exp_f32 %0, %0" : "+v"(v[n & 7]));
+      else asm volatile("v_fma_f32 %0, %0, %1, %0" : "+v"(v[n & 7]) : "v"(v[(n + 1) & 7]));
+    }
+  }
+  float s = 0.f;
+  for (int j = 0; j < 4; ++j) for (int i = 0; i < 16; ++i) s += acc[j][i];
+  for (int i = 0; i < 8; ++i) s += v[i];
+  out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+
+// dependent form: the VALU block reads the accumulators (waits for the MFMA chain) and the next iteration's MFMA operand
+// is produced by the VALU block -- the S -> softmax -> P.V dependency chain of an attention tile
+template <int NM, int NV, int NE>
+__global__ __launch_bounds__(256) void kd(float* out, int iters, int lds_touch) {
+  extern __shared__ float sh[];
+  if (lds_touch) sh[threadIdx.x] = 0.f;
+  bf16x8 a, b;
+  for (int i = 0; i < 8; ++i) { a[i] = (__bf16)(0.001f * (threadIdx.x + i)); b[i] = (__bf16)(0.002f * i); }
+  f32x16 acc[4];
+  for (int j = 0; j < 4; ++j) for (int i = 0; i < 16; ++i) acc[j][i] = 0.f;
+  float v[8];
+  for (int i = 0; i < 8; ++i) v[i] = 0.5f + 0.01f * i + 0.001f * threadIdx.x;
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int m = 0; m < NM; ++m) acc[m & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[m & 3], 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] += acc[i & 3][i];            // waits for the chain
+#pragma unroll
+    for (int n = 0; n < NV; ++n) {
+      if (n < NE) asm volatile("v_exp_f32 %0, %0" : "+v"(v[n & 7]));
+      else asm volatile("v_fma_f32 %0, %0, %1, %0" : "+v"(v[n & 7]) : "v"(v[(n + 1) & 7]));
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) a[i] = (__bf16)v[i];               // next chain's operand
+  }
+  float s = 0.f;
+  for (int j = 0; j < 4; ++j) for (int i = 0; i < 16; ++i) s += acc[j][i];
+  for (int i = 0; i < 8; ++i) s += v[i];
+  out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+
+template <int NM, int NV, int NE, bool DEP = false>
+static void run(const char* name) {
+  float* out; hipMalloc(&out, 4096 * 256 * 4);
+  const int iters = 2000;
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  auto kern = DEP ? kd<NM, NV, NE> : k<NM, NV, NE>;
+  hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  for (int occ = 1; occ <= 4; ++occ) {
+    const int shm = occ == 1 ? 100 * 1024 : occ == 2 ? 60 * 1024 : occ == 3 ? 50 * 1024 : 36 * 1024;   // workgroups per CU
+    const int grid = 256 * occ;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), shm, 0, out, 10, 1);
+    hipDeviceSynchronize();
+    hipEventRecord(e0);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), shm, 0, out, iters, 1);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    // cycles per wave-iteration at a nominal 2.4 GHz (the clock may be lower under load: compare rows, not absolutes)
+    printf("%-28s NM=%2d NV=%3d NE=%2d  waves/SIMD=%d  %.3f ms  %.0f ns per iteration per SIMD (%.0f per wave-iteration)\n", name, NM, NV, NE, occ,
+           ms, ms * 1e6 / iters / occ, ms * 1e6 / iters);
+  }
+  hipFree(out);
+}
+
+int main() {
+  run<24, 0, 0>("mfma only");
+  run<0, 200, 0>("valu only");
+  run<0, 200, 16>("valu+exp only");
+  run<24, 200, 0>("mfma then valu");
+  run<24, 200, 16>("mfma then valu+exp");
+  run<36, 170, 16>("x3 dq-like");
+  run<16, 400, 32>("bf16 fwd-like");
+  run<24, 200, 16, true>("dependent mfma->valu->mfma");
+  run<36, 170, 16, true>("dependent x3 dq-like");
+  run<16, 400, 32, true>("dependent bf16 fwd-like");
+  return 0;
+}
