@@ -64,6 +64,75 @@ __global__ __launch_bounds__(256) void kd(float* out, int iters, int lds_touch) 
   out[blockIdx.x * 256 + threadIdx.x] = s;
 }
 
+// the real arithmetic of the bf16x3 dQ tile between its MFMA segments (no LDS, no loads): S^T and dP^T chains (24 MFMAs),
+// p = exp2(s*c - L), dS = p*(dp*keep - delta), split into hi / lo bf16, 12 MFMAs with the split operands
+__device__ __forceinline__ void split8(const f32x16& x, int s, bf16x8& hi, bf16x8& lo) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { const float v = x[8 * s + j]; const __bf16 h = (__bf16)v; hi[j] = h; lo[j] = (__bf16)(v - (float)h); }
+}
+template <int MODE>   // 0 full, 1 no split (plain cvt), 2 no exp
+__global__ __launch_bounds__(256) void kreal(float* out, int iters, int lds_touch) {
+  extern __shared__ float sh[];
+  if (lds_touch) sh[threadIdx.x] = 0.f;
+  bf16x8 a, b, d0h, d0l, d1h, d1l;
+  for (int i = 0; i < 8; ++i) { a[i] = (__bf16)(0.001f * (threadIdx.x + i)); b[i] = (__bf16)(0.002f * i); d0h[i] = a[i]; d0l[i] = b[i]; d1h[i] = a[i]; d1l[i] = b[i]; }
+  f32x16 dq0, dq1;
+  for (int i = 0; i < 16; ++i) { dq0[i] = 0.f; dq1[i] = 0.f; }
+  const float c = 0.18f, L = 3.f, dl = 0.01f;
+  f32x16 sp, dpp;
+  for (int i = 0; i < 16; ++i) { sp[i] = 0.1f * i; dpp[i] = 0.2f * i; }
+  for (int it = 0; it < iters; ++it) {
+    f32x16 s, dp;
+    for (int i = 0; i < 16; ++i) { s[i] = 0.f; dp[i] = 0.f; }
+#pragma unroll
+    for (int m = 0; m < 12; ++m) { s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, MODE >= 3 ? b : d0h, s, 0, 0, 0); dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b, MODE >= 3 ? a : d1h, dp, 0, 0, 0); }
+    if (MODE >= 3) { const f32x16 ts = s, td = dp; s = sp; dp = dpp; sp = ts; dpp = td; }   // arithmetic on the previous tile's scores
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float p = MODE == 2 ? fmaf(s[r], c, -L) : __builtin_amdgcn_exp2f(fmaf(s[r], c, -L));
+      s[r] = p * (dp[r] * 1.1f - dl);
+    }
+    if (MODE == 1) {
+      for (int j = 0; j < 8; ++j) { d0h[j] = (__bf16)s[j]; d1h[j] = (__bf16)s[8 + j]; }
+    } else {
+      split8(s, 0, d0h, d0l);
+      split8(s, 1, d1h, d1l);
+    }
+    if (MODE == 4) {
+#pragma unroll
+      for (int i = 0; i < 24; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 7, 0); }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int m = 0; m < 3; ++m) {
+      dq0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, d0h, dq0, 0, 0, 0); dq1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b, d0l, dq1, 0, 0, 0);
+      dq0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, d1h, dq0, 0, 0, 0); dq1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b, d1l, dq1, 0, 0, 0);
+    }
+  }
+  float r = 0.f;
+  for (int i = 0; i < 16; ++i) r += dq0[i] + dq1[i];
+  out[blockIdx.x * 256 + threadIdx.x] = r;
+}
+template <int MODE>
+static void run_real(const char* name) {
+  float* out; hipMalloc(&out, 4096 * 256 * 4);
+  const int iters = 2000;
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  auto kern = kreal<MODE>;
+  hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  for (int occ = 1; occ <= 2; ++occ) {
+    const int shm = occ == 1 ? 100 * 1024 : 60 * 1024;
+    hipLaunchKernelGGL(kern, dim3(256 * occ), dim3(256), shm, 0, out, 10, 1);
+    hipDeviceSynchronize();
+    hipEventRecord(e0);
+    hipLaunchKernelGGL(kern, dim3(256 * occ), dim3(256), shm, 0, out, iters, 1);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    printf("%-28s 36 MFMA + real dQ arithmetic  waves/SIMD=%d  %.3f ms  %.0f ns per iteration per SIMD\n", name, occ, ms, ms * 1e6 / iters / occ);
+  }
+  hipFree(out);
+}
+
 template <int NM, int NV, int NE, bool DEP = false>
 static void run(const char* name) {
   float* out; hipMalloc(&out, 4096 * 256 * 4);
@@ -88,7 +157,12 @@ static void run(const char* name) {
 }
 
 int main() {
-  run<24, 0, 0>("mfma only");
+  run_real<0>("real dq tile");
+  run_real<1>("real dq tile, no split");
+  run_real<2>("real dq tile, no exp");
+  run_real<3>("real dq tile, skewed");
+  run_real<4>("real dq tile, skewed+sgb");
+  run<36, 0, 0>("mfma only");
   run<0, 200, 0>("valu only");
   run<0, 200, 16>("valu+exp only");
   run<24, 200, 0>("mfma then valu");
