@@ -124,21 +124,27 @@ def kernel_rooflines(model, wl, B, mode):
     prod = 2.0 * B * H * S * S * dh                      # one S x S x dh product over the batch
     lq, lo, lg = ops._ld(qkv), ops._ld(o), ops._ld(dqkv)
 
+    # the keep-bit tensor of the attention-probability dropout, as the engine attaches it in a training step
+    bits = None
+    if eng.keep_bits and mode != "fp32" and cfg["dropout"] > 0:
+        bits = torch.zeros(ops.attn_drop_bits_words(B, H, S, S), dtype=torch.int64, device=dev)
+    bits_bytes = 0 if bits is None else bits.numel() * 8
+
     def shape(res):
         s = ops.attn_shape(B, H, S, S, dh, cd, lq, lq, lq, lo, None, False, dr)
         s.reserved = res
-        return s
+        return ops.attn_set_drop_bits(s, bits)
     s0, s1, s2 = shape(0), shape(1), shape(2)
     ms = time_kernel(lambda: ops.attn_fwd(s0, q, k, v, o, lse))
     algo = ops.last_algo()
     add("attention forward (encoder self-attention)", f"afm_attn_fwd[{algo}]", ms, 2 * prod,
-        esz * 4 * M * d, Le, "2 products: Q K^T, P V")
+        esz * 4 * M * d + bits_bytes, Le, "2 products: Q K^T, P V" + ("; writes the dropout keep bits" if bits is not None else ""))
     ms = time_kernel(lambda: ops.attn_bwd(s1, q, k, v, o, do, lse, delta, dqkv[:, :d], dqkv[:, d:2 * d], dqkv[:, 2 * d:], lg, lg, lg))
-    add("attention backward, dQ kernel", f"afm_attn_bwd[{algo}] dQ", ms, 3 * prod, esz * 6 * M * d, Le,
-        "3 products: Q K^T and dO V^T recomputed, dS K")
+    add("attention backward, dQ kernel", f"afm_attn_bwd[{algo}] dQ", ms, 3 * prod, esz * 6 * M * d + bits_bytes, Le,
+        "3 products: Q K^T and dO V^T recomputed, dS K" + ("; reads the dropout keep bits" if bits is not None else ""))
     ms = time_kernel(lambda: ops.attn_bwd(s2, q, k, v, o, do, lse, delta, dqkv[:, :d], dqkv[:, d:2 * d], dqkv[:, 2 * d:], lg, lg, lg))
-    add("attention backward, dK/dV kernel", f"afm_attn_bwd[{algo}] dK/dV", ms, 4 * prod, esz * 6 * M * d, Le,
-        "4 products: Q K^T and dO V^T recomputed, P^T dO, dS^T Q")
+    add("attention backward, dK/dV kernel", f"afm_attn_bwd[{algo}] dK/dV", ms, 4 * prod, esz * 6 * M * d + bits_bytes, Le,
+        "4 products: Q K^T and dO V^T recomputed, P^T dO, dS^T Q" + ("; reads the dropout keep bits" if bits is not None else ""))
 
     # --- GEMMs of one encoder layer at their training epilogues
     x = _rand(M, d, cd, dev)

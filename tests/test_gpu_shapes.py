@@ -118,3 +118,36 @@ def test_shape_parity_forward_backward_vs_oracle(name, mode):
     assert not bad, (name, mode, bad[:8], len(bad))
     print(f"{name} {mode}: logits rel err {err:.2e}, ids equal {bool(torch.equal(ids, rid))}, "
           f"undecidable positions {int((margin <= 2 * err * scale).sum())} of {margin.numel()}")
+
+
+@pytest.mark.parametrize("mode", ["bf16x3", "bf16"])
+def test_dropout_keep_bits_equal_rehash(mode):
+    """Training step with dropout 0.1 at the c2 shape: the backward kernels reading the forward's keep-bit tensor give the
+    logits, the loss and (to the rounding of the gradient storage format) the gradients of the kernels that re-hash every
+    score: same dropout stream, so the two are the same function."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from multimodalanalytical_amd import ops
+    from multimodalanalytical_amd.engine import Seq2SeqEngine
+    wl, cfg, inputs, sd, _ref, _ = _case("c2")    # _ : the oracle's gradient dict = the names of the trained parameters
+    cfg = dict(cfg, dropout=0.1)
+    enc, am, dec, dm, labels = inputs
+    res = []
+    for keep_bits in (True, False):
+        eng = Seq2SeqEngine(cfg, wl["data"], "Smiles", wl["data"]["Smiles"]["vocab_size"], device=DEV,
+                            compute_dtype=_dtype(mode), seed=5)
+        eng.keep_bits = keep_bits
+        eng.load_state_dict(sd)
+        eng.train()
+        out = eng.forward(_to(enc), am.to(DEV), dec.to(DEV), dm.to(DEV), labels.to(DEV), backward=True)
+        res.append((float(out["loss"]), {k: eng.ps.g(k).cpu().clone() for k in _.keys()}, out["logits"].float().cpu().clone()))
+    (l1, g1, y1), (l0, g0, y0) = res
+    assert torch.equal(y1, y0)                      # the forward kernels differ only in what they store
+    assert abs(l1 - l0) <= 1e-6 * abs(l0), (l1, l0)  # (the mean over tokens is an atomic sum: last-bit run-to-run noise)
+    # gradients: same function, same keep decisions (dK / dV are bit-equal kernel by kernel, tools/experiments/check_bits.py);
+    # the dQ kernels round `keep * scale * dP - delta` in a different order (fma contraction), which flips last bits of the
+    # stored gradients: 1 ulp of the storage format = 2e-5-level in pair mode, bf16-level (4e-3) in single-pass mode
+    tol = 1e-2 if mode == "bf16" else 2e-5
+    for k in g1:
+        d, n = float((g1[k] - g0[k]).norm()), float(g0[k].norm())
+        assert d <= tol * n + 1e-12, (k, d, n)

@@ -51,7 +51,8 @@ def merge(prefix):
         if "TCC_HIT_sum" in e:
             e["l2_hit_rate"] = e["TCC_HIT_sum"] / (e["TCC_HIT_sum"] + e["TCC_MISS_sum"])
         e["what"] = NAMES.get(pretty(k), pretty(k))
-        res[pretty(k) + ("<dropout>" if "ILb1E" in k else "")] = e
+        tag = "<dropout, re-hash>" if "ILi1E" in k else "<dropout, keep bits>" if "ILi2E" in k else ""
+        res[pretty(k) + tag] = e
     return res
 
 
@@ -66,6 +67,9 @@ def main():
     for m in ("bf16x3", "bf16"):
         a = merge(f"attn_{m}")
         json.dump(a, open(os.path.join(DST, f"r02_attn_{m}_pmc.json"), "w"), indent=1)
+        hsh = merge(f"attn_{m}_hash")
+        if hsh:
+            json.dump(hsh, open(os.path.join(DST, f"r02_attn_{m}_rehash_pmc.json"), "w"), indent=1)
         table[m] = {e["what"]: {"hbm_bytes_per_launch": e.get("hbm_bytes_per_launch"), "kernel": k} for k, e in a.items()}
     g = merge("gemm_bf16x3")
     json.dump(g, open(os.path.join(DST, "r02_gemm_bf16x3_pmc.json"), "w"), indent=1)

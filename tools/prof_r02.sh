@@ -23,6 +23,12 @@ for m in bf16x3 bf16; do
     rm -rf $O/attn_${m}_$i
   done
 done
+# the same attention kernels re-hashing the dropout (no keep-bit tensor): instruction counters only, to show what the bits save
+for m in bf16x3 bf16; do
+  rocprofv3 --kernel-trace --pmc $G1 -d $O/attn_${m}_hash_1 -o pmc -- python3 $R/tools/bench_attn_x3.py --mode $m --bits 0 > $O/attn_${m}_hash_1.log 2>&1
+  python3 $R/tools/rocpd_pmc.py $(find $O/attn_${m}_hash_1 -name "*.db" | head -1) k_attn > $O/attn_${m}_hash_pmc_1.json
+  rm -rf $O/attn_${m}_hash_1
+done
 i=0
 for g in "$G1" "$G2" "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum"; do
   i=$((i+1))
