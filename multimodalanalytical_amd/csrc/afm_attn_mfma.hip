@@ -367,7 +367,7 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd_dkv_mfma(AttnM a, const bf1
     }
     if (DROP == DROP_BITS) {   // keep-bit blocks (query block of lanes 0-31 / 32-63, this wave's key block): 2 x 32 dwords
       // (bits_block returns a wave-uniform pointer: the second query block of lanes 32-63 is a per-lane offset on top of it)
-      const uint32_t* src = (const uint32_t*)bits_block(a, b * a.H + hd, row0 >> 5, k0 >> 5) + (lane >> 5) * (a.nk32 * 32) + (lane & 31);
+      const uint32_t* src = (const uint32_t*)bits_block(a, b * a.H + hd, row0 >> 5, min(k0 >> 5, a.nk32 - 1)) + (lane >> 5) * (a.nk32 * 32) + (lane & 31);
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                        (__attribute__((address_space(3))) void*)(st + 4 * KT * DH * 2 + 2 * KT * 4 + w * 256), 4, 0, 0);
     }

@@ -382,7 +382,8 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd_dkv_x3(AttnM a, const bf16*
                                        (__attribute__((address_space(3))) void*)(st + 4 * IMG32 + w * 64 * 4), 4, 0, 0);
     }
     if (DROP == DROP_BITS) {   // this wave's (query block, key block) of the keep-bit tensor: 32 dwords (upper lanes: duplicates)
-      const uint32_t* src = (const uint32_t*)bits_block(a, b * a.H + hd, row0 >> 5, k0 >> 5) + (lane & 31);
+      // key block clamped: with Tk < 128 the waves past Tk skip all work but still issue their pieces (read past the tensor)
+      const uint32_t* src = (const uint32_t*)bits_block(a, b * a.H + hd, row0 >> 5, min(k0 >> 5, a.nk32 - 1)) + (lane & 31);
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                        (__attribute__((address_space(3))) void*)(st + 4 * IMG32 + 2 * 64 * 4 + w * 256), 4, 0, 0);
     }

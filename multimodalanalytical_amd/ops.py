@@ -7,6 +7,7 @@ all-reduce.  Nothing here computes on the CPU or through torch ops.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Optional
 
 import torch
@@ -228,10 +229,22 @@ def attn_set_drop_bits(s: AttnShape, bits) -> AttnShape:
     return s
 
 
+_DEBUG_SYNC = bool(os.environ.get("AFM_DEBUG_SYNC"))   # debugging aid: synchronise and name the attention call that faulted
+
+
+def _debug_sync(what, s):
+    if _DEBUG_SYNC:
+        print(f"[afm] {what} B={s.B} H={s.H} Tq={s.Tq} Tk={s.Tk} causal={s.causal} bits={bool(s.drop_bits)} ld=({s.ldq},{s.ldk},{s.ldv},{s.ldo})",
+              flush=True)
+        torch.cuda.synchronize()
+
+
 def attn_fwd(s: AttnShape, q, k, v, o, lse):
+    _debug_sync("attn_fwd ->", s)
     L.check(L.load().afm_attn_fwd(C.byref(s), _ptr(q), _ptr(k), _ptr(v), _ptr(o), _ptr(lse), _stream()),
             "afm_attn_fwd")
     _log_algo()
+    _debug_sync("attn_fwd ok " + last_algo(), s)
     return o
 
 
@@ -240,6 +253,7 @@ def attn_bwd(s: AttnShape, q, k, v, o, do, lse, delta, dq, dk, dv, lddq, lddk, l
                                   _ptr(delta), _ptr(dq), _ptr(dk), _ptr(dv), lddq, lddk, lddv, _stream()),
             "afm_attn_bwd")
     _log_algo()
+    _debug_sync("attn_bwd ok " + last_algo(), s)
 
 
 def glu_fwd(u, v, g, dropout: Dropout = NO_DROP):

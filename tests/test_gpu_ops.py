@@ -410,7 +410,7 @@ def _attn_ref(q, k, v, key_pad, causal, keep=None, dscale=1.0):
 @pytest.mark.parametrize("B,H,Tq,Tk,causal,pad,pdrop", [
     (2, 2, 128, 128, True, True, 0.0), (2, 3, 100, 200, False, True, 0.0), (1, 2, 300, 300, False, False, 0.0),
     (1, 2, 192, 192, True, False, 0.0), (2, 2, 128, 256, False, True, 0.1), (1, 2, 160, 160, True, True, 0.1),
-    (2, 2, 130, 520, False, "blocks", 0.1)])
+    (2, 2, 130, 520, False, "blocks", 0.1), (2, 2, 256, 56, False, True, 0.1), (2, 2, 56, 56, False, True, 0.1)])
 def test_attention_mfma(ops, B, H, Tq, Tk, causal, pad, pdrop):
     dh, dt = 64, torch.bfloat16
     q, k, v, key_pad = _attn_case(B, H, Tq, Tk, dh, causal, bool(pad), seed=10)
@@ -431,10 +431,16 @@ def test_attention_mfma(ops, B, H, Tq, Tk, causal, pad, pdrop):
     for algo in (1, 2):
         o = torch.empty(B * Tq, D, dtype=dt, device=DEV); lse = torch.empty(B * H * Tq, device=DEV)
         shp = ops.attn_shape(B, H, Tq, Tk, dh, dt, D, D, D, D, kp, causal, ops.drop(pdrop, seed, site), algo=algo)
+        guard = None
         if pdrop > 0 and algo == 2 and Tq % 2 == 0:   # half of the dropout cases run with the keep-bit tensor, half re-hash
-            ops.attn_set_drop_bits(shp, torch.zeros(ops.attn_drop_bits_words(B, H, Tq, Tk), dtype=torch.int64, device=DEV))
+            nb = ops.attn_drop_bits_words(B, H, Tq, Tk)
+            guard = torch.full((nb + 256,), 0x5A5A5A5A5A5A5A5A, dtype=torch.int64, device=DEV)   # guard words behind the tensor
+            guard[:nb] = 0
+            ops.attn_set_drop_bits(shp, guard)
         ops.attn_fwd(shp, qd, kd, vd, o, lse)
         assert ops.last_algo() == ("attn_generic" if algo == 1 else "attn_mfma")
+        if guard is not None:
+            assert bool((guard[nb:] == 0x5A5A5A5A5A5A5A5A).all())          # the scalar stores stay inside the tensor
         res[algo] = (o, lse, shp)
     qr, kr, vr, ref = _attn_ref(q, k, v, key_pad, causal, keep, dscale)
     ref_o = ref.transpose(1, 2).reshape(B * Tq, D)

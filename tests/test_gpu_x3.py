@@ -160,7 +160,7 @@ def _check_keep_bits(bits, keep, B, H, Tq, Tk, key_pad, causal):
 @pytest.mark.parametrize("B,H,Tq,Tk,causal,pad,pdrop", [
     (2, 2, 128, 128, True, True, 0.0), (2, 3, 100, 200, False, True, 0.0), (1, 2, 300, 300, False, False, 0.0),
     (1, 2, 192, 192, True, False, 0.0), (2, 2, 128, 256, False, True, 0.1), (1, 2, 160, 160, True, True, 0.1),
-    (2, 2, 130, 520, False, "blocks", 0.1)])
+    (2, 2, 130, 520, False, "blocks", 0.1), (2, 2, 256, 56, False, True, 0.1), (2, 2, 56, 56, False, True, 0.1)])
 def test_attention_x3(ops, B, H, Tq, Tk, causal, pad, pdrop):
     from multimodalanalytical_amd.x2 import X2
     dh = 64
@@ -188,12 +188,15 @@ def test_attention_x3(ops, B, H, Tq, Tk, causal, pad, pdrop):
                          ops.drop(pdrop, seed, site), algo=2)
     bits = None
     if pdrop > 0:   # keep-bit tensor: written by the forward kernel, read by both backward kernels
-        bits = torch.zeros(ops.attn_drop_bits_words(B, H, Tq, Tk), dtype=torch.int64, device=DEV)
+        nb = ops.attn_drop_bits_words(B, H, Tq, Tk)
+        bits = torch.full((nb + 256,), 0x5A5A5A5A5A5A5A5A, dtype=torch.int64, device=DEV)   # guard words behind the tensor
+        bits[:nb] = 0
         ops.attn_set_drop_bits(shp, bits)
     ops.attn_fwd(shp, qd, kd, vd, o, lse)
     assert ops.last_algo() == "attn_mfma_x3"
     if bits is not None:
-        _check_keep_bits(bits, keep, B, H, Tq, Tk, key_pad, causal)
+        assert bool((bits[nb:] == 0x5A5A5A5A5A5A5A5A).all())          # the scalar stores stay inside the tensor
+        _check_keep_bits(bits[:nb], keep, B, H, Tq, Tk, key_pad, causal)
     qr, kr, vr, ref = _attn_ref(q, k, v, key_pad, causal, keep, dscale)
     ref_o = ref.transpose(1, 2).reshape(B * Tq, D)
     assert relnorm(o.float(), ref_o.detach()) < 2e-5
