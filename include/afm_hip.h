@@ -201,7 +201,8 @@ typedef struct {
    * strides address a KV cache laid out (batch, Tmax, 2d) during incremental decode; forward only. */
   int64_t sqb, skb, svb, sob;
   /* Optional keep-bit tensor of the attention-probability dropout (nullable; only read / written when drop.p > 0):
-   * B*H * ceil(Tq/32) * ceil(Tk/32) blocks of 16 uint64.  Block (bh, qb, kb), word r, bit l = keep of query 32 qb + (l & 31),
+   * B*H * NQ * NK blocks of 16 uint64 with NQ = 4 ceil(Tq/128) query blocks and NK = 2 ceil(Tk/64) key blocks of 32 (whole kernel
+ * tiles: blocks past Tq / Tk exist and are never meaningful).  Block (bh, qb, kb), word r, bit l = keep of query 32 qb + (l & 31),
    * key 32 kb + (r & 3) + 8 (r >> 2) + 4 (l >> 5): the 64-lane masks of the kernels' score registers.  afm_attn_fwd writes it
    * (the MFMA kernels as a by-product of their own dropout, through the scalar store path), afm_attn_bwd's MFMA kernels read it
    * instead of re-evaluating the hash per score: the dQ kernel as SGPR lane masks (one v_cndmask per score), the dK/dV kernel as one
