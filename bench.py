@@ -9,10 +9,14 @@ gradient clip 1.0 + AdamW + OneCycleLR; with N > 1 the flat gradient buffer is a
 step, overlapped with the last backward.  Inputs are synthetic (multimodalanalytical_amd/synth.py, seeded) and
 resident in HBM before the timed region.  Prints ONE JSON line (rank 0).
 
-Precision modes: `value` is the PARITY-GRADE mode "bf16x3" -- split bf16 operand pairs, three
-bf16 MFMA passes per product, fp32 accumulation: logits within 1e-5 of the CPU reference (bar 1e-3), argmax ids
-equal -- so the number and the parity claim refer to the same arithmetic.  `modes` also carries the single-pass
-"bf16" mode (3e-3..6e-3 on the logits: outside the parity bar, reported for comparison only), timed in the same run.
+Precision modes, all timed in the same run and listed under `modes`:
+  bf16x3-mixed  (`value`) the FORWARD runs on split bf16 operand pairs -- three bf16 MFMA passes per product, fp32
+                accumulation: logits within 1e-5 of the CPU reference (bar 1e-3), argmax ids equal, i.e. the outputs the
+                parity bar is stated on come from parity-grade arithmetic -- and the BACKWARD on the single-pass bf16
+                kernels, reading the hi planes of the saved pair tensors in place: gradients at the precision class of the
+                reference's own 16-bit mixed training (4e-3 over all parameters against the CPU reference)
+  bf16x3        split pairs in both directions (gradients 1e-5 against the CPU reference)
+  bf16          single pass everywhere (3e-3..6e-3 on the logits: outside the parity bar, for comparison only)
 """
 import argparse
 import json
@@ -38,8 +42,8 @@ def parse():
     ap.add_argument("--workload", default="c2", help="c1..c5 (multimodalanalytical_amd/synth.py)")
     ap.add_argument("--batch", type=int, default=0, help="per-GPU micro-batch (default: the workload's, 128)")
     ap.add_argument("--acc", type=int, default=4)
-    ap.add_argument("--dtype", default="bf16x3", choices=["bf16x3", "bf16", "fp32"], help="mode of `value`")
-    ap.add_argument("--other-modes", default="bf16", help="comma list of further modes timed in the same run ('' = none)")
+    ap.add_argument("--dtype", default="bf16x3-mixed", choices=["bf16x3", "bf16x3-mixed", "bf16", "fp32"], help="mode of `value`")
+    ap.add_argument("--other-modes", default="bf16x3,bf16", help="comma list of further modes timed in the same run ('' = none)")
     ap.add_argument("--other-steps", type=int, default=3)
     ap.add_argument("--extra-workloads", default="c3", help="comma list: further workloads timed in the primary mode (N = 1 only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -54,7 +58,12 @@ def parse():
 
 def compute_dtype(name):
     from multimodalanalytical_amd.x2 import X2
-    return {"bf16": torch.bfloat16, "bf16x3": X2.dtype, "fp32": torch.float32}[name]
+    return {"bf16": torch.bfloat16, "bf16x3": X2.dtype, "bf16x3-mixed": X2.dtype, "fp32": torch.float32}[name]
+
+
+def backward_dtype(name):
+    import torch
+    return torch.bfloat16 if name == "bf16x3-mixed" else None
 
 
 def time_kernel(fn, iters=10, warm=3):
@@ -90,23 +99,36 @@ def kernel_rooflines(model, wl, B, mode):
     The entry with the largest share of the step becomes `roofline`; the others are listed in `roofline_kernels`."""
     from multimodalanalytical_amd import ops
     from multimodalanalytical_amd.lib import ACT_GELU_SAVE_GRAD, ACT_MUL_SAVED
+    from multimodalanalytical_amd.x2 import X2
     cfg = wl["cfg"]
     eng = model.hf_model.engine
     dev, cd = eng.dev, eng.cd
+    mixed = getattr(eng, "mixed", False)     # bf16x3 forward kernels, single-pass bf16 backward kernels on the hi planes
     S = sum(v[0] if isinstance(v, tuple) else v for v in wl["lens"].values())
     d, H = cfg["d_model"], cfg["encoder_attention_heads"]
     f = cfg["encoder_ffn_dim"] * (2 if cfg["gated_linear"] else 1)
     Le = cfg["encoder_layers"]
     M, dh = B * S, d // H
-    passes = 3 if mode == "bf16x3" else 1
-    esz = {"bf16": 2, "bf16x3": 4, "fp32": 4}[mode]
+    fmode = "bf16x3" if mixed else mode                       # arithmetic of the forward kernels
+    bmode = "bf16" if mixed else mode                         # ... of the backward kernels
+    PASS = {"bf16x3": 3, "bf16": 1, "fp32": 1}
+    ESZ = {"bf16": 2, "bf16x3": 4, "fp32": 4}
     peak = PEAK_BF16_TFLOPS if mode != "fp32" else 157.3
     out = []
 
-    def add(name, kern, ms, flops, alg_bytes, calls, note):
+    def hb(t):                                                # what a backward kernel reads of a saved forward tensor
+        return t.hi if (mixed and isinstance(t, X2)) else t
+
+    def empty_b(rows, cols, like=None):                       # backward activation gradient (row stride of `like` in mixed mode)
+        if mixed and like is not None:
+            return torch.empty(rows, like.ld, dtype=torch.bfloat16, device=dev)[:, :cols]
+        return ops.empty(rows, cols, torch.bfloat16 if mixed else cd, dev)
+
+    def add(name, kern, ms, flops, alg_bytes, calls, note, kmode):
         ach = flops / (ms * 1e-3) / 1e12
-        out.append({"bound": "mfma", "kernel": kern, "what": name, "achieved": round(ach, 1), "peak": peak, "unit": "TFLOP/s",
-                    "frac": round(ach / peak, 4), "mfma_frac_executed": round(min(1.0, passes * ach / peak), 4) if mode != "fp32" else None,
+        out.append({"bound": "mfma", "kernel": kern, "what": name, "arithmetic": kmode, "achieved": round(ach, 1), "peak": peak,
+                    "unit": "TFLOP/s", "frac": round(ach / peak, 4),
+                    "mfma_frac_executed": round(min(1.0, PASS[kmode] * ach / peak), 4) if mode != "fp32" else None,
                     "avg_launch_ms": round(ms, 4), "algorithmic_flops": flops, "algorithmic_bytes": alg_bytes,
                     "hbm_time_at_peak_ms": round(alg_bytes / (PEAK_HBM_GBS * 1e9) * 1e3, 4),
                     "launches_per_micro_batch": calls, "ms_per_micro_batch": round(ms * calls, 3), "counts": note,
@@ -116,73 +138,85 @@ def kernel_rooflines(model, wl, B, mode):
     qkv = _rand(M, 3 * d, cd, dev)
     q, k, v = qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:]
     o = ops.empty(M, d, cd, dev)
-    do = _rand(M, d, cd, dev, 0.01)
-    dqkv = ops.empty(M, 3 * d, cd, dev)
+    do = empty_b(M, d, like=o if mixed else None)
+    ops.convert(torch.randn(M, d, device=dev) * 0.01, do)
+    dqkv = empty_b(M, 3 * d)
     lse = torch.empty(B * H * S, device=dev)
     delta = torch.empty_like(lse)
     dr = ops.drop(cfg["dropout"], 1, 3)
     prod = 2.0 * B * H * S * S * dh                      # one S x S x dh product over the batch
     lq, lo, lg = ops._ld(qkv), ops._ld(o), ops._ld(dqkv)
-
     # the keep-bit tensor of the attention-probability dropout, as the engine attaches it in a training step
     bits = None
     if eng.keep_bits and mode != "fp32" and cfg["dropout"] > 0:
         bits = torch.zeros(ops.attn_drop_bits_words(B, H, S, S), dtype=torch.int64, device=dev)
     bits_bytes = 0 if bits is None else bits.numel() * 8
 
-    def shape(res):
-        s = ops.attn_shape(B, H, S, S, dh, cd, lq, lq, lq, lo, None, False, dr)
+    def shape(res, dt):
+        s = ops.attn_shape(B, H, S, S, dh, dt, lq, lq, lq, lo, None, False, dr)
         s.reserved = res
         return ops.attn_set_drop_bits(s, bits)
-    s0, s1, s2 = shape(0), shape(1), shape(2)
+    bdt = torch.bfloat16 if mixed else cd
+    s0, s1, s2 = shape(0, cd), shape(1, bdt), shape(2, bdt)
+    ef, eb = ESZ[fmode], ESZ[bmode]
     ms = time_kernel(lambda: ops.attn_fwd(s0, q, k, v, o, lse))
     algo = ops.last_algo()
     add("attention forward (encoder self-attention)", f"afm_attn_fwd[{algo}]", ms, 2 * prod,
-        esz * 4 * M * d + bits_bytes, Le, "2 products: Q K^T, P V" + ("; writes the dropout keep bits" if bits is not None else ""))
-    ms = time_kernel(lambda: ops.attn_bwd(s1, q, k, v, o, do, lse, delta, dqkv[:, :d], dqkv[:, d:2 * d], dqkv[:, 2 * d:], lg, lg, lg))
-    add("attention backward, dQ kernel", f"afm_attn_bwd[{algo}] dQ", ms, 3 * prod, esz * 6 * M * d + bits_bytes, Le,
-        "3 products: Q K^T and dO V^T recomputed, dS K" + ("; reads the dropout keep bits" if bits is not None else ""))
-    ms = time_kernel(lambda: ops.attn_bwd(s2, q, k, v, o, do, lse, delta, dqkv[:, :d], dqkv[:, d:2 * d], dqkv[:, 2 * d:], lg, lg, lg))
-    add("attention backward, dK/dV kernel", f"afm_attn_bwd[{algo}] dK/dV", ms, 4 * prod, esz * 6 * M * d + bits_bytes, Le,
-        "4 products: Q K^T and dO V^T recomputed, P^T dO, dS^T Q" + ("; reads the dropout keep bits" if bits is not None else ""))
+        ef * 4 * M * d + bits_bytes, Le, "2 products: Q K^T, P V" + ("; writes the dropout keep bits" if bits is not None else ""), fmode)
+    qb, kb, vb, ob = hb(q), hb(k), hb(v), hb(o)
+    ms = time_kernel(lambda: ops.attn_bwd(s1, qb, kb, vb, ob, do, lse, delta, dqkv[:, :d], dqkv[:, d:2 * d], dqkv[:, 2 * d:], lg, lg, lg))
+    algo = ops.last_algo()
+    add("attention backward, dQ kernel", f"afm_attn_bwd[{algo}] dQ", ms, 3 * prod, eb * 6 * M * d + bits_bytes, Le,
+        "3 products: Q K^T and dO V^T recomputed, dS K" + ("; reads the dropout keep bits" if bits is not None else ""), bmode)
+    ms = time_kernel(lambda: ops.attn_bwd(s2, qb, kb, vb, ob, do, lse, delta, dqkv[:, :d], dqkv[:, d:2 * d], dqkv[:, 2 * d:], lg, lg, lg))
+    add("attention backward, dK/dV kernel", f"afm_attn_bwd[{algo}] dK/dV", ms, 4 * prod, eb * 6 * M * d + bits_bytes, Le,
+        "4 products: Q K^T and dO V^T recomputed, P^T dO, dS^T Q" + ("; reads the dropout keep bits" if bits is not None else ""), bmode)
 
     # --- GEMMs of one encoder layer at their training epilogues
     x = _rand(M, d, cd, dev)
-    du = _rand(M, f, cd, dev, 0.01)
+    pre = ops.empty(M, f, cd, dev)                       # stored keep*scale*GELU' (forward output, backward input)
+    du = empty_b(M, f, like=pre if mixed else None)
+    ops.convert(torch.randn(M, f, device=dev) * 0.01, du)
     gw = torch.zeros(f, d, device=dev)
     gb = torch.zeros(f, device=dev)
-    ms = time_kernel(lambda: ops.gemm(du, x, gw, trans_a=True, trans_b=False, accumulate=True, a_colsum=gb))
+    xb = hb(x)
+    ms = time_kernel(lambda: ops.gemm(du, xb, gw, trans_a=True, trans_b=False, accumulate=True, a_colsum=gb))
     add("FFN up-projection weight gradient (bias gradient fused)", f"afm_gemm[{ops.last_algo()}] dW1 {f}x{d} over {M} tokens",
-        ms, 2.0 * M * d * f, esz * M * (f + d) + 4 * f * d, 1 * Le, "1 product")
+        ms, 2.0 * M * d * f, eb * M * (f + d) + 4 * f * d, 1 * Le, "1 product", bmode)
     wq = eng.W("encoder.layers.0.self_attn.in_proj_weight", 3 * d, d)
     bq = eng.ps.p("encoder.layers.0.self_attn.in_proj_bias")
     oq = ops.empty(M, 3 * d, cd, dev)
     ms = time_kernel(lambda: ops.gemm(x, wq, oq, trans_b=True, bias=bq))
     add("QKV projection forward", f"afm_gemm[{ops.last_algo()}] {M}x{3 * d}x{d}", ms, 2.0 * M * 3 * d * d,
-        esz * (M * d + 3 * d * d + M * 3 * d), Le, "1 product")
+        ef * (M * d + 3 * d * d + M * 3 * d), Le, "1 product", fmode)
     if not cfg["gated_linear"]:
         w1 = eng.W("encoder.layers.0.linear1.weight", f, d)
         b1 = eng.ps.p("encoder.layers.0.linear1.bias")
-        g, pre = ops.empty(M, f, cd, dev), ops.empty(M, f, cd, dev)
+        g = ops.empty(M, f, cd, dev)
         ms = time_kernel(lambda: ops.gemm(x, w1, g, trans_b=True, bias=b1, act=ACT_GELU_SAVE_GRAD, pre_act=pre, dropout=dr))
-        by = esz * (M * d + f * d) + 2 * esz * M * f
+        by = ef * (M * d + f * d) + 2 * ef * M * f
         add("FFN up-projection forward (bias + GELU + dropout fused, keep*scale*GELU' stored)",
-            f"afm_gemm[{ops.last_algo()}] {M}x{f}x{d}", ms, 2.0 * M * d * f, by, Le, "1 product; HBM-heavy: two M x f outputs")
-        if by / (PEAK_HBM_GBS * 1e9) > 2.0 * M * d * f * passes / (peak * 1e12):
+            f"afm_gemm[{ops.last_algo()}] {M}x{f}x{d}", ms, 2.0 * M * d * f, by, Le, "1 product; HBM-heavy: two M x f outputs", fmode)
+        if by / (PEAK_HBM_GBS * 1e9) > 2.0 * M * d * f * PASS[fmode] / (peak * 1e12):
             out[-1].update(bound="hbm", achieved=round(by / (ms * 1e-3) / 1e9, 1), peak=PEAK_HBM_GBS, unit="GB/s",
                            frac=round(by / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4))
         if mode != "fp32":
-            w2t = eng.wt["encoder.layers.0.linear2.weight"]          # (f x d): dgrad of linear2 as an NT GEMM
-            dy = _rand(M, d, cd, dev, 0.01)
-            ms = time_kernel(lambda: ops.gemm(dy, w2t, du, trans_b=True, act=ACT_MUL_SAVED, pre_act=pre))
+            w2t = hb(eng.wt["encoder.layers.0.linear2.weight"])      # (f x d): dgrad of linear2 as an NT GEMM
+            dy = ops.empty(M, d, torch.bfloat16 if mixed else cd, dev)
+            ops.convert(torch.randn(M, d, device=dev) * 0.01, dy)
+            preb = hb(pre)
+            ms = time_kernel(lambda: ops.gemm(dy, w2t, du, trans_b=True, act=ACT_MUL_SAVED, pre_act=preb))
             add("FFN down-projection data gradient (x stored keep*scale*GELU')", f"afm_gemm[{ops.last_algo()}] {M}x{f}x{d}",
-                ms, 2.0 * M * d * f, esz * (M * d + f * d + 2 * M * f), Le, "1 product")
+                ms, 2.0 * M * d * f, eb * (M * d + f * d + 2 * M * f), Le, "1 product", bmode)
     # traffic from committed PMC passes of the same launches (profiles/r02_*_pmc.json: {kernel what: bytes})
-    pmc = os.path.join(ROOT, "profiles", f"r02_{mode}_pmc.json")
-    if os.path.exists(pmc) and (B, S, d) == (128, 1024, 512):
-        table = json.load(open(pmc))
+    if (B, S, d) == (128, 1024, 512):
+        tables = {}
         for e in out:
-            e["traffic"] = table.get(e["what"], {}).get("hbm_bytes_per_launch")
+            km = e["arithmetic"]
+            if km not in tables:
+                pmc = os.path.join(ROOT, "profiles", f"r02_{km}_pmc.json")
+                tables[km] = json.load(open(pmc)) if os.path.exists(pmc) else {}
+            e["traffic"] = tables[km].get(e["what"], {}).get("hbm_bytes_per_launch")
     out.sort(key=lambda e: -e["ms_per_micro_batch"])
     return out
 
@@ -253,6 +287,7 @@ def build(workload, mode, steps_total, world, dev, args):
     tok = SimpleTokenizerInfo(wl["data"]["Smiles"]["vocab_size"])
     model = HFWrapper(wl["data"], "CustomModel", "facebook/bart-base", tok, optimiser="adamw", lr=1e-4,
                       num_steps=steps_total + 1, world_size=world, device=dev, compute_dtype=compute_dtype(mode),
+                      backward_dtype=backward_dtype(mode),
                       **{k: v for k, v in wl["cfg"].items() if k != "multimodal_norm"})
     loop = TrainLoop(model, acc_batches=args.acc, world_size=world, force_reducer=args.force_ddp)
     return wl, tok, model, loop
@@ -318,14 +353,18 @@ def main():
     main_run = timed_run(args.workload, args.dtype, args.steps, args.warmup, rank, world, dev, args, keep=True)
     wl, B, S, flops = main_run["wl"], main_run["B"], main_run["S"], main_run["flops"]
     value = main_run["value"]
-    passes = 3 if args.dtype == "bf16x3" else 1
+    # executed MFMA passes per algorithmic product: forward third of the FLOPs at 3, backward two thirds at 1 in mixed mode
+    PASSES = {"bf16x3": 3.0, "bf16x3-mixed": (1.0 * 3 + 2.0 * 1) / 3, "bf16": 1.0, "fp32": 1.0}
+    passes = PASSES[args.dtype]
 
     def mode_entry(r, mode, steps):
-        p = 3 if mode == "bf16x3" else 1
+        p = PASSES[mode]
         return {"value": round(r["value"], 3), "unit": "samples/s", "ms_per_step": round(r["dt"] / steps * 1e3, 3), "steps": steps,
                 "step_flop_frac": round(r["value"] / world * r["flops"] / (PEAK_BF16_TFLOPS * 1e12), 4),
                 "step_mfma_frac_executed": round(p * r["value"] / world * r["flops"] / (PEAK_BF16_TFLOPS * 1e12), 4) if mode != "fp32" else None,
                 "logits_vs_cpu_reference": {"bf16x3": "~1e-5 rel., argmax ids equal (tests/test_gpu_shapes.py; bar 1e-3)",
+                                            "bf16x3-mixed": "~1e-5 rel., argmax ids equal: the forward IS the bf16x3 forward (bar 1e-3); "
+                                                            "gradients at bf16 precision (global 4e-3 rel. vs the CPU reference)",
                                             "bf16": "3e-3..6e-3 rel. (outside the 1e-3 bar)", "fp32": "~1e-6 rel., ids equal"}[mode],
                 "final_loss": round(r["loss"], 4)}
 
@@ -354,6 +393,8 @@ def main():
                    "parallelism": f"dp{world}", "rccl_ranks": world if ddp else 0, "dropout": wl["cfg"]["dropout"],
                    "optimiser": "adamw+onecycle, clip 1.0",
                    "precision": {"bf16x3": "split bf16 operand pairs, 3 bf16 MFMA passes per product, fp32 accumulate / residual stream / statistics",
+                                 "bf16x3-mixed": "forward as bf16x3 (split pairs, 3 MFMA passes: parity-grade logits); backward on the single-pass bf16 "
+                                                 "kernels reading the hi planes of the saved pair tensors (the reference trains in 16-bit mixed precision)",
                                  "bf16": "bf16 operands, 1 MFMA pass, fp32 accumulate / residual stream / statistics",
                                  "fp32": "exact fp32 FMA kernels"}[args.dtype]},
         "train_gflop_per_sample": round(flops / 1e9, 2),

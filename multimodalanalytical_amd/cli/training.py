@@ -179,15 +179,18 @@ def run(cfg: Dict[str, Any], own: Dict[str, str]) -> Dict[str, Any]:
     pre = build_preprocessors(shards["train"], dc, device)
     collator = DeviceCollator(dc, pre, tm)
     tok = SimpleTokenizerInfo(dc[tm]["vocab_size"], pad_token_id=dc[tm]["pad_token_id"])
-    precision = own.get("precision", "bf16x3")
-    cd = {"bf16x3": X2.dtype, "bf16": torch.bfloat16, "fp32": torch.float32}[precision]
+    # precision=: bf16x3-mixed (default: split-pair forward = parity-grade outputs, single-pass bf16 backward, the analogue of
+    # the reference's 16-bit mixed training) | bf16x3 (split pairs in both directions) | bf16 | fp32
+    precision = own.get("precision", "bf16x3-mixed")
+    cd = {"bf16x3-mixed": X2.dtype, "bf16x3": X2.dtype, "bf16": torch.bfloat16, "fp32": torch.float32}[precision]
+    bd = torch.bfloat16 if precision == "bf16x3-mixed" else None
     mk = {k: v for k, v in plan["model_config"].items() if k != "multimodal_norm"}
     bs = int(mk["batch_size"])
 
     def new_model():
         return HFWrapper(dc, target_tokenizer=tok, num_steps=plan["train_steps"], modality_dropout=plan["modality_dropout"],
                          multimodal_norm=plan["model_config"].get("multimodal_norm", True), clip_grad=plan["clip_grad"],
-                         world_size=world, device=device, compute_dtype=cd, **mk)
+                         world_size=world, device=device, compute_dtype=cd, backward_dtype=bd, **mk)
     model = new_model()
     loop = TrainLoop(model, acc_batches=plan["acc_batches"], world_size=world)
     if mk.get("model_checkpoint_path"):

@@ -1350,10 +1350,12 @@ int afm_gemm_mfma_try(const afm_gemm_desc* d, hipStream_t st) {
       return AFM_ERR_UNSUPPORTED;
     int variant = d->reserved;  // tile-shape experiments (tools/bench_gemm.py); 0 = pick by shape
     if (d->act >= AFM_ACT_GLU) {
-      // fused gated FFN: whole 256 x 128 tiles through the loader-wave kernel, bf16 in / out, contiguous C and pre_act
+      // fused gated FFN: whole 256 x 128 tiles through the loader-wave kernel, bf16 in / out, contiguous C and pre_act (the
+      // backward form reads pre_act with C's row stride, which may exceed the row: hi planes of pair tensors in mixed mode)
       const int ncol_c = d->act == AFM_ACT_GLU_BWD ? 2 * d->N : d->N / 2;
       if ((d->K & 63) || (d->M & 255) || (d->N & 127) || d->c_dtype != AFM_BF16 || d->residual || d->accumulate ||
-          d->ldc != ncol_c || (d->drop.p > 0.f && (uint64_t)d->M * (uint64_t)d->N > 0x100000000ull) ||
+          (d->act == AFM_ACT_GLU_BWD ? (d->ldc < ncol_c || (d->ldc & 7)) : d->ldc != ncol_c) ||   // GLU_BWD: C and pre_act share ldc
+          (d->drop.p > 0.f && (uint64_t)d->M * (uint64_t)d->N > 0x100000000ull) ||
           (d->act == AFM_ACT_GLU_BWD && (d->bias || d->drop.p > 0.f)))
         return AFM_ERR_UNSUPPORTED;
       int r;

@@ -21,7 +21,7 @@ import torch
 
 from . import ops
 from .lib import (ACT_GELU, ACT_GELU_BWD, ACT_GELU_SAVE_GRAD, ACT_GLU, ACT_GLU_BWD, ACT_GLU_SAVE, ACT_MUL_SAVED, ACT_NONE, ACT_RELU,
-                  ALGO_AUTO)
+                  AFM_BF16, ALGO_AUTO)
 from .params import align_dict, PATCH_TYPES, TEXT_TYPES, ParamStore, build_specs, patch_layers
 from .x2 import X2
 
@@ -46,7 +46,7 @@ class Seq2SeqEngine:
 
     def __init__(self, cfg: Dict[str, Any], data_config: Dict[str, Any], target_modality: str,
                  vocab_out: int, device="cuda:0", compute_dtype=torch.bfloat16, seed: int = 3247,
-                 algo: int = ALGO_AUTO, side_wgrad: bool = False):
+                 algo: int = ALGO_AUTO, side_wgrad: bool = False, backward_dtype=None):
         self.cfg = dict(cfg)
         self.cfg.setdefault("multimodal_norm", True)
         self.cfg.setdefault("gated_linear", False)
@@ -68,6 +68,14 @@ class Seq2SeqEngine:
         self.cfg["align_config"] = self.align
         self.x3 = compute_dtype == BF16X3
         self.lowp = compute_dtype != torch.float32          # operands are not plain fp32: MFMA kernels, transposed weight copies
+        # "bf16x3 forward / bf16 backward": the forward (what the parity bar is stated on: logits, token ids) runs on split
+        # pairs, the backward on the single-pass bf16 kernels reading the HI planes of the saved pair tensors and of the pair
+        # weight copies in place (a hi plane is an ordinary bf16 view) -- gradients at the precision class of the reference's
+        # own 16-bit mixed training (trainer/trainer.py:69), two thirds of the step's products at one MFMA pass instead of three
+        self.bd = backward_dtype if backward_dtype is not None else compute_dtype
+        self.mixed = self.x3 and self.bd == torch.bfloat16
+        if self.bd != compute_dtype and not self.mixed:
+            raise ValueError("backward_dtype: only bfloat16 under the bf16x3 forward is supported")
         # attention-probability dropout: forward stores 1 keep bit per score, backward reads it (AFM_ATTN_KEEP_BITS=0: re-hash)
         self.keep_bits = os.environ.get("AFM_ATTN_KEEP_BITS", "1") != "0"
         self.branch_dtype = torch.float32 if self.x3 else None   # residual branches: fp32 out of the x3 GEMMs (same bytes as a pair)
@@ -213,6 +221,18 @@ class Seq2SeqEngine:
     def _empty(self, rows, cols, dtype=None):
         return ops.empty(rows, cols, dtype or self.cd, self.dev)
 
+    def _empty_b(self, rows, cols, dtype=None, like=None):
+        """Backward-pass activation gradient.  `like`: a saved tensor read by the same GEMM epilogue as `pre_act` (which
+        shares C's row stride): in mixed mode that is the hi plane of a pair tensor, so C gets the pair's row stride."""
+        dt = dtype or self.bd
+        if self.mixed and like is not None and isinstance(like, X2) and dt == torch.bfloat16:
+            return torch.empty(rows, like.ld, dtype=dt, device=self.dev)[:, :cols]
+        return ops.empty(rows, cols, dt, self.dev)
+
+    def _hb(self, t):
+        """Operand of a backward kernel: in mixed mode the hi plane of a pair tensor."""
+        return t.hi if (self.mixed and isinstance(t, X2)) else t
+
     def _linear(self, x, name, rows, cols, r0=0, r1=None, out=None, out_dtype=None, bias_name=None,
                 residual=None, dropout=ops.NO_DROP, act=ACT_NONE, pre_act=None):
         w = self.W(name, rows, cols, r0, r1)
@@ -230,10 +250,10 @@ class Seq2SeqEngine:
         """dx = dy @ W[r0:r1]  (W rows = output features)."""
         r1 = rows if r1 is None else r1
         if out is None:
-            out = self._empty(dy.shape[0], cols, out_dtype)
-        kw = dict(accumulate=accumulate, algo=self.algo, act=act, pre_act=pre_act, dropout=dropout)
+            out = self._empty_b(dy.shape[0], cols, out_dtype)
+        kw = dict(accumulate=accumulate, algo=self.algo, act=act, pre_act=self._hb(pre_act), dropout=dropout)
         if self.lowp:
-            wt = self.wt[name][:, r0:r1]  # (cols, n): NT form for the MFMA kernel
+            wt = self._hb(self.wt[name][:, r0:r1])  # (cols, n): NT form for the MFMA kernel
             return ops.gemm(dy, wt, out, trans_b=True, **kw)
         w = self.W(name, rows, cols, r0, r1)
         return ops.gemm(dy, w, out, trans_b=False, **kw)
@@ -241,6 +261,7 @@ class Seq2SeqEngine:
     def _wgrad(self, dy, x, name, rows, cols, r0=0, r1=None, bias_name=None):
         """dW[r0:r1] += dy^T x ; db[r0:r1] += colsum(dy)."""
         gw = self.G(name, rows, cols, r0, r1)
+        x = self._hb(x)
         gb = None
         if bias_name is not None:
             gb = self.ps.vec_span(self.ps.grad, bias_name, r0, r0 + gw.shape[0])
@@ -408,6 +429,18 @@ class Seq2SeqEngine:
             n = ops.attn_drop_bits_words(shp.B, shp.H, shp.Tq, shp.Tk)
             ops.attn_set_drop_bits(shp, torch.empty(n, dtype=torch.int64, device=self.dev))
 
+    def _shape_b(self, shp):
+        """The forward's attention descriptor for the backward kernels: in mixed mode the same strides (a hi plane keeps the
+        pair tensor's row stride), keep-bit tensor and dropout stream with the single-pass dtype."""
+        if not self.mixed:
+            return shp
+        sb = type(shp).from_buffer_copy(shp)
+        sb.dtype = AFM_BF16
+        for k in ("_bits_keepalive", "_keepalive"):
+            if hasattr(shp, k):
+                setattr(sb, k, getattr(shp, k))
+        return sb
+
     def _self_attn_fwd(self, x, pend, p, B, T, H, key_pad, causal, saved, site):
         """x + pend is the incoming stream; returns (stream, this block's branch to be added)."""
         d = self.d
@@ -433,11 +466,13 @@ class Seq2SeqEngine:
         h, qkv, a, lse, shp = saved["sa"]
         rows = h.shape[0]
         self._wgrad(dy, a, p + "self_attn.out_proj.weight", d, d, bias_name=p + "self_attn.out_proj.bias")
-        da = self._dgrad(dy, p + "self_attn.out_proj.weight", d, d)
-        dqkv = self._empty(rows, 3 * d)
+        # (the attention ABI has ONE row stride for O and dO: in mixed mode dO takes the stride of O's hi plane)
+        da = self._dgrad(dy, p + "self_attn.out_proj.weight", d, d, out=self._empty_b(rows, d, like=a))
+        dqkv = self._empty_b(rows, 3 * d)
         delta = torch.empty_like(lse)
         ldg = ops._ld(dqkv)
-        ops.attn_bwd(shp, qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], a, da, lse, delta,
+        qkv_b, shp = self._hb(qkv), self._shape_b(shp)
+        ops.attn_bwd(shp, qkv_b[:, :d], qkv_b[:, d:2 * d], qkv_b[:, 2 * d:], self._hb(a), da, lse, delta,
                      dqkv[:, :d], dqkv[:, d:2 * d], dqkv[:, 2 * d:], ldg, ldg, ldg)
         self._wgrad(dqkv, h, p + "self_attn.in_proj_weight", 3 * d, d, bias_name=p + "self_attn.in_proj_bias")
         dh = self._dgrad(dqkv, p + "self_attn.in_proj_weight", 3 * d, d)
@@ -478,20 +513,22 @@ class Seq2SeqEngine:
         h, uv, g, dr = saved["ffn"]
         rows = h.shape[0]
         self._wgrad(dy, g, p + "linear2.weight", d, f, bias_name=p + "linear2.bias")
-        duv = self._empty(rows, k * f)
+        duv = self._empty_b(rows, k * f, like=uv)
         if self.gated and isinstance(dr, tuple) and dr[1] == "glu":
             # [du | dv] (interleaved) = (dy W2) * saved factors in the dgrad epilogue; weight gradient rows de-interleaved by
             # the wgrad kernel into the reference's [linear1 ; gate] layout; dh through the interleaved transpose
-            ops.gemm(dy, self.wt[p + "linear2.weight"], duv, trans_b=True, act=ACT_GLU_BWD, pre_act=uv, algo=self.algo, glu_rows=f)
+            ops.gemm(dy, self._hb(self.wt[p + "linear2.weight"]), duv, trans_b=True, act=ACT_GLU_BWD, pre_act=self._hb(uv),
+                     algo=self.algo, glu_rows=f)
             gw = self.G(p + "linear1.weight", 2 * f, d)
             gb = self.ps.vec_span(self.ps.grad, p + "linear1.bias", 0, 2 * f)
-            ops.gemm(duv, h, gw, trans_a=True, trans_b=False, accumulate=True, algo=self.algo, a_colsum=gb, glu_rows=f)
-            dh = self._empty(rows, d)
-            ops.gemm(duv, self.wt_glu[p + "linear1.weight"], dh, trans_b=True, algo=self.algo)
+            ops.gemm(duv, self._hb(h), gw, trans_a=True, trans_b=False, accumulate=True, algo=self.algo, a_colsum=gb, glu_rows=f)
+            dh = self._empty_b(rows, d)
+            ops.gemm(duv, self._hb(self.wt_glu[p + "linear1.weight"]), dh, trans_b=True, algo=self.algo)
             return self._ln_bwd(dh, p + norm, saved, "lnf", dres=dx1, next_site=next_site)
         if self.gated:
             dg = self._dgrad(dy, p + "linear2.weight", d, f)
-            ops.glu_bwd(uv[:, :f], uv[:, f:], dg, duv[:, :f], duv[:, f:], dr)
+            uv_b = self._hb(uv)
+            ops.glu_bwd(uv_b[:, :f], uv_b[:, f:], dg, duv[:, :f], duv[:, f:], dr)
         elif dr[1]:   # du = (dy W2) * [keep * scale * gelu'(u)] in the dgrad epilogue: dg never reaches HBM
             self._dgrad(dy, p + "linear2.weight", d, f, out=duv, act=ACT_MUL_SAVED, pre_act=uv)
         else:       # du = dropout'(dy W2) * gelu'(u)
@@ -523,15 +560,17 @@ class Seq2SeqEngine:
         h, q, kv, a, lse, shp = saved["ca"]
         wo, bo = p + "multihead_attn.out_proj.weight", p + "multihead_attn.out_proj.bias"
         self._wgrad(dy, a, wo, d, d, bias_name=bo)
-        da = self._dgrad(dy, wo, d, d)
-        dq = self._empty(h.shape[0], d)
+        da = self._dgrad(dy, wo, d, d, out=self._empty_b(h.shape[0], d, like=a))
+        dq = self._empty_b(h.shape[0], d)
         if dkv_all is not None:     # this layer's dK | dV columns of the all-layers buffer (one dgrad at the end)
             dkv = dkv_all[:, layer * 2 * d:(layer + 1) * 2 * d]
         else:
-            dkv = self._empty(mem.shape[0], 2 * d)
+            dkv = self._empty_b(mem.shape[0], 2 * d)
         ldkv = ops._ld(dkv)
         delta = torch.empty_like(lse)
-        ops.attn_bwd(shp, q, kv[:, :d], kv[:, d:], a, da, lse, delta, dq, dkv[:, :d], dkv[:, d:], ops._ld(dq), ldkv, ldkv)
+        kv_b = self._hb(kv)
+        ops.attn_bwd(self._shape_b(shp), self._hb(q), kv_b[:, :d], kv_b[:, d:], self._hb(a), da, lse, delta, dq, dkv[:, :d], dkv[:, d:],
+                     ops._ld(dq), ldkv, ldkv)
         w, bname = p + "multihead_attn.in_proj_weight", p + "multihead_attn.in_proj_bias"
         self._wgrad(dq, h, w, 3 * d, d, 0, d, bias_name=bname)
         self._wgrad(dkv, mem, w, 3 * d, d, d, 3 * d, bias_name=bname)
@@ -833,7 +872,7 @@ class Seq2SeqEngine:
     def _backward(self, saved, logits, lab, row_lse, stats, loss_scale, mem):
         d = self.d
         B, S, T = saved["B"], saved["S"], saved["T"]
-        dlog = self._empty(B * T, self.V)
+        dlog = self._empty_b(B * T, self.V)
         ops.ce_bwd(logits, lab, row_lse, stats, loss_scale, dlog)
         hf = saved["hf"]
         self._wgrad(dlog, hf, "token_ff.weight", self.V, d, bias_name="token_ff.bias")
@@ -846,7 +885,7 @@ class Seq2SeqEngine:
             dmem = torch.zeros(B * S, d, dtype=torch.float32, device=self.dev)
         dkv_all = None
         if self.lowp and Ld > 0:
-            dkv_all = self._empty(B * S, Ld * 2 * d)
+            dkv_all = self._empty_b(B * S, Ld * 2 * d)
         for i in range(Ld - 1, -1, -1):
             p, sv = f"decoder.layers.{i}.", saved["dec_layers"][i]
             dx, dy = self._ffn_bwd(dx, dy, p, self.cfg["decoder_ffn_dim"], "norm3.", sv, f"d{i}xres")
@@ -856,11 +895,11 @@ class Seq2SeqEngine:
         if dkv_all is not None:      # d(encoder output) = [dK|dV of every layer] @ [their projection weights], K = Ld*2d
             if dmem is None:
                 dmem = torch.empty(B * S, d, dtype=torch.float32, device=self.dev)
-            ops.gemm(dkv_all, self.wt_kv_all, dmem, trans_b=True, accumulate=had_init, algo=self.algo)
+            ops.gemm(dkv_all, self._hb(self.wt_kv_all), dmem, trans_b=True, accumulate=had_init, algo=self.algo)
         self.embed_bwd(dx, saved["emb_dec"])
         dmem_c = dmem
         if self.lowp:
-            dmem_c = self._empty(B * S, d)
+            dmem_c = self._empty_b(B * S, d)
             ops.dropout_cast(dmem, dmem_c)
         dx, dy = self._ln_bwd(dmem_c, "encoder.norm.", saved, "enc_norm", dres=None, next_site=f"e{Le - 1}res2")
         for i in range(Le - 1, -1, -1):

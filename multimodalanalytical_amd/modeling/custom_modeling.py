@@ -86,7 +86,7 @@ class CustomModel:
 
     def __init__(self, target_modality, target_tokenizer, config: CustomConfig,
                  multimodal_embedding_layer: MultimodalEmbedding, device="cuda:0",
-                 compute_dtype=torch.bfloat16, seed: int = 3247):
+                 compute_dtype=torch.bfloat16, seed: int = 3247, backward_dtype=None):
         self.config = config
         self.target_modality = target_modality
         self.decoder_vocab_size = target_tokenizer.vocab_size
@@ -94,7 +94,8 @@ class CustomModel:
         cfg = config.to_dict()
         cfg["multimodal_norm"] = multimodal_embedding_layer.embedding_norm
         self.engine = Seq2SeqEngine(cfg, multimodal_embedding_layer.data_config, target_modality,
-                                    self.decoder_vocab_size, device=device, compute_dtype=compute_dtype, seed=seed)
+                                    self.decoder_vocab_size, device=device, compute_dtype=compute_dtype, seed=seed,
+                                    backward_dtype=backward_dtype)
         multimodal_embedding_layer.engine = self.engine
         self.encoder = _EncoderHandle(self)
         self._grad_enabled, self._loss_scale = False, 1.0

@@ -22,7 +22,7 @@ OPTIMISER_REGISTRY = {"adam": "adam", "adamw": "adamw"}  # wrapper.py:29
 def load_custom_model(model_name: str, target_tokenizer, target_modality: str, data_config: Dict[str, Any],
                       multimodal_norm: bool, **kwargs) -> Tuple[CustomModel, MultimodalEmbedding]:
     """wrapper.py:144-180."""
-    engine_kw = {k: kwargs.pop(k) for k in ("device", "compute_dtype", "seed") if k in kwargs}
+    engine_kw = {k: kwargs.pop(k) for k in ("device", "compute_dtype", "seed", "backward_dtype") if k in kwargs}
     known = CustomConfig.__init__.__code__.co_varnames
     cfg_kw = {k: v for k, v in kwargs.items() if k in known}
     model_config = CustomConfig.from_pretrained(

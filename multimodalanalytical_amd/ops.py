@@ -93,6 +93,10 @@ def _log_algo() -> None:
         _ALGO_LOG.append(last_algo())
 
 
+_DEBUG_SYNC = bool(os.environ.get("AFM_DEBUG_SYNC"))   # debugging aid: synchronise and name the attention call that faulted
+
+
+
 def gemm(a: torch.Tensor, b: torch.Tensor, c: torch.Tensor, *, trans_a=False, trans_b=True,
          bias: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
          pre_act: Optional[torch.Tensor] = None, act: int = ACT_NONE, accumulate: bool = False,
@@ -124,7 +128,11 @@ def gemm(a: torch.Tensor, b: torch.Tensor, c: torch.Tensor, *, trans_a=False, tr
         assert residual.dtype == c.dtype and _ld(residual) == d.ldc and residual.shape == c.shape
     d.residual = _ptr(residual)
     if pre_act is not None and act in (L.ACT_GLU_SAVE, L.ACT_GLU_BWD):
-        assert pre_act.dtype == c.dtype and tuple(pre_act.shape) == (M, max(N, c.shape[1])) and is_contig(pre_act) and is_contig(c)
+        assert pre_act.dtype == c.dtype and tuple(pre_act.shape) == (M, max(N, c.shape[1]))
+        if act == L.ACT_GLU_SAVE:     # the saved factors are written with their own dense row stride
+            assert is_contig(pre_act) and is_contig(c)
+        else:                         # read back with C's row stride (hi-plane views in mixed mode: equal strides, not dense)
+            assert _ld(pre_act) == _ld(c)
     elif pre_act is not None:
         assert pre_act.dtype == c.dtype and _ld(pre_act) == d.ldc and pre_act.shape == c.shape
     d.pre_act = _ptr(pre_act)
@@ -137,6 +145,10 @@ def gemm(a: torch.Tensor, b: torch.Tensor, c: torch.Tensor, *, trans_a=False, tr
     d.drop = dropout
     L.check(L.load().afm_gemm(C.byref(d), _stream()), "afm_gemm")
     _log_algo()
+    if _DEBUG_SYNC:
+        print(f"[afm] gemm {last_algo()} M={d.M} N={d.N} K={d.K} ta={d.transA} tb={d.transB} ld=({d.lda},{d.ldb},{d.ldc}) dt=({d.a_dtype},{d.b_dtype},{d.c_dtype}) "
+              f"act={d.act} glu={d.glu_rows}", flush=True)
+        torch.cuda.synchronize()
     return c
 
 
@@ -227,9 +239,6 @@ def attn_set_drop_bits(s: AttnShape, bits) -> AttnShape:
     s.drop_bits = _ptr(bits)
     s._bits_keepalive = bits
     return s
-
-
-_DEBUG_SYNC = bool(os.environ.get("AFM_DEBUG_SYNC"))   # debugging aid: synchronise and name the attention call that faulted
 
 
 def _debug_sync(what, s):

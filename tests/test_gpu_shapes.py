@@ -6,6 +6,8 @@ Bars (max |logit - ref| / max |ref|; gradients by relative norm per parameter te
   fp32    exact-fp32 FMA kernels                 logits 1e-4, ids bit-exact, grads 2e-3
   bf16x3  split bf16 pairs, 3 MFMAs / product    logits 1e-3 (north star), ids bit-exact under the margin
           policy below, grads 5e-3
+  bf16x3-mixed  bf16x3 forward, single-pass bf16 backward on the hi planes of the saved pair tensors: logits and ids
+          exactly as bf16x3 (same kernels), grads at the bf16 bar 8e-2 per tensor and 1e-2 over all parameters
   bf16    single bf16 MFMA pass                  logits 3e-2, ids exact outside twice the measured error, grads 8e-2
 Margin policy for "bit-exact argmax": a position whose two largest REFERENCE logits are closer than twice the
 MEASURED maximum logit error cannot be decided by the arithmetic under test (nor by the reference run on another
@@ -24,12 +26,16 @@ pytestmark = pytest.mark.gpu
 from oracle import afm_oracle as O  # noqa: E402
 
 DEV = "cuda:0"
-MODES = ["fp32", "bf16x3", "bf16"]
+MODES = ["fp32", "bf16x3", "bf16x3-mixed", "bf16"]
 
 
 def _dtype(mode):
     from multimodalanalytical_amd.x2 import X2
-    return {"fp32": torch.float32, "bf16": torch.bfloat16, "bf16x3": X2.dtype}[mode]
+    return {"fp32": torch.float32, "bf16": torch.bfloat16, "bf16x3": X2.dtype, "bf16x3-mixed": X2.dtype}[mode]
+
+
+def _bdtype(mode):
+    return torch.bfloat16 if mode == "bf16x3-mixed" else None
 
 
 @functools.lru_cache(maxsize=None)
@@ -73,7 +79,7 @@ def test_shape_parity_forward_backward_vs_oracle(name, mode):
     from multimodalanalytical_amd.engine import Seq2SeqEngine
     wl, cfg, inputs, sd, ref, grads = _case(name)
     eng = Seq2SeqEngine(cfg, wl["data"], "Smiles", wl["data"]["Smiles"]["vocab_size"], device=DEV,
-                        compute_dtype=_dtype(mode), seed=5)
+                        compute_dtype=_dtype(mode), seed=5, backward_dtype=_bdtype(mode))
     eng.load_state_dict(sd)
     enc, am, dec, dm, labels = inputs
     ops.reset_algo_log()
@@ -87,7 +93,7 @@ def test_shape_parity_forward_backward_vs_oracle(name, mode):
     logits, rl = out["logits"].cpu().double(), ref["logits"].double()
     scale = float(rl.abs().max())
     err = float((logits - rl).abs().max()) / scale
-    tol = {"fp32": 1e-4, "bf16x3": 1e-3, "bf16": 3e-2}[mode]
+    tol = {"fp32": 1e-4, "bf16x3": 1e-3, "bf16x3-mixed": 1e-3, "bf16": 3e-2}[mode]
     assert err < tol, (name, mode, err)
     ids, rid = out["argmax"].cpu(), ref["logits"].argmax(-1)
     top2 = ref["logits"].topk(2, -1)
@@ -101,11 +107,15 @@ def test_shape_parity_forward_backward_vs_oracle(name, mode):
         # inside the band any candidate whose REFERENCE logit is within the band of the maximum may win (near-ties of 2+ ids)
         chosen = ref["logits"].double().gather(-1, ids.unsqueeze(-1)).squeeze(-1)
         assert bool((chosen >= top2.values[..., 0].double() - band).all())
-        assert float(sure.double().mean()) > (0.999 if mode == "bf16x3" else 0.5)
-    ltol = {"fp32": 1e-5, "bf16x3": 1e-4, "bf16": 2e-2}[mode]
+        assert float(sure.double().mean()) > (0.999 if mode.startswith("bf16x3") else 0.5)
+    ltol = {"fp32": 1e-5, "bf16x3": 1e-4, "bf16x3-mixed": 1e-4, "bf16": 2e-2}[mode]
     torch.testing.assert_close(out["loss"].cpu(), ref["loss"], rtol=ltol, atol=ltol)
-    gtol = {"fp32": 2e-3, "bf16x3": 5e-3, "bf16": 8e-2}[mode]
+    gtol = {"fp32": 2e-3, "bf16x3": 5e-3, "bf16x3-mixed": 8e-2, "bf16": 8e-2}[mode]
     gmax = max(float(g.norm()) for g in grads.values())
+    if mode == "bf16x3-mixed":   # all parameters together: bf16-grade backward on parity-grade activations
+        num = sum(float((eng.ps.g(k).cpu() - g).norm()) ** 2 for k, g in grads.items() if not k.endswith("in_proj_bias"))
+        den = sum(float(g.norm()) ** 2 for k, g in grads.items() if not k.endswith("in_proj_bias"))
+        assert (num / den) ** 0.5 < 1e-2, (name, (num / den) ** 0.5)
     bad = []
     for k, g in grads.items():
         got = eng.ps.g(k).cpu()
@@ -120,7 +130,7 @@ def test_shape_parity_forward_backward_vs_oracle(name, mode):
           f"undecidable positions {int((margin <= 2 * err * scale).sum())} of {margin.numel()}")
 
 
-@pytest.mark.parametrize("mode", ["bf16x3", "bf16"])
+@pytest.mark.parametrize("mode", ["bf16x3", "bf16x3-mixed", "bf16"])
 def test_dropout_keep_bits_equal_rehash(mode):
     """Training step with dropout 0.1 at the c2 shape: the backward kernels reading the forward's keep-bit tensor give the
     logits, the loss and (to the rounding of the gradient storage format) the gradients of the kernels that re-hash every
@@ -135,7 +145,7 @@ def test_dropout_keep_bits_equal_rehash(mode):
     res = []
     for keep_bits in (True, False):
         eng = Seq2SeqEngine(cfg, wl["data"], "Smiles", wl["data"]["Smiles"]["vocab_size"], device=DEV,
-                            compute_dtype=_dtype(mode), seed=5)
+                            compute_dtype=_dtype(mode), seed=5, backward_dtype=_bdtype(mode))
         eng.keep_bits = keep_bits
         eng.load_state_dict(sd)
         eng.train()
@@ -147,7 +157,7 @@ def test_dropout_keep_bits_equal_rehash(mode):
     # gradients: same function, same keep decisions (dK / dV are bit-equal kernel by kernel, tools/experiments/check_bits.py);
     # the dQ kernels round `keep * scale * dP - delta` in a different order (fma contraction), which flips last bits of the
     # stored gradients: 1 ulp of the storage format = 2e-5-level in pair mode, bf16-level (4e-3) in single-pass mode
-    tol = 1e-2 if mode == "bf16" else 2e-5
+    tol = 2e-5 if mode == "bf16x3" else 1e-2       # (mixed: bf16 backward kernels, the forward's bits)
     for k in g1:
         d, n = float((g1[k] - g0[k]).norm()), float(g0[k].norm())
         assert d <= tol * n + 1e-12, (k, d, n)

@@ -58,7 +58,9 @@ def merge(prefix):
 
 def main():
     os.makedirs(DST, exist_ok=True)
-    for m in ("bf16x3", "bf16"):
+    for m in ("bf16x3-mixed", "bf16x3", "bf16"):
+        if not os.path.exists(os.path.join(SRC, f"step_{m}_kernel_stats.csv")):
+            continue
         shutil.copy(os.path.join(SRC, f"step_{m}_kernel_stats.csv"), os.path.join(DST, f"r02_c2_{m}_kernel_stats.csv"))
         tot = open(os.path.join(SRC, f"step_{m}_total.txt")).read().strip()
         with open(os.path.join(DST, f"r02_c2_{m}_kernel_stats.csv"), "a") as fh:
