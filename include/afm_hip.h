@@ -115,7 +115,8 @@ typedef struct {
   int32_t reserved;
   afm_dropout drop;
   int32_t glu_rows;       /* f > 0: gated-FFN interleave (see above); wgrad form: rows of C / a_colsum are de-interleaved */
-  int32_t reserved2;
+  int32_t reserved2;      /* bit 0 (pair dtype, act GELU_SAVE_GRAD / GLU_SAVE): the stored factors get their hi plane only -- the
+                             consumer is the single-pass bf16 backward of the mixed precision mode, which never reads the lo plane */
 } afm_gemm_desc;
 int afm_gemm(const afm_gemm_desc* d, void* stream);
 

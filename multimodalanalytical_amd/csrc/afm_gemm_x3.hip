@@ -27,6 +27,7 @@ struct X3Args {
   int ksplit, kchunk;   // TN only
   int bias_in_lds;
   int glu_f;            // gated-FFN interleave (include/afm_hip.h)
+  int sg_hi_only;       // stored gradient factors (GELU_SG / GLU_SG): hi plane only (the bf16 backward of mixed mode reads nothing else)
   int abl;              // timing experiments (tools/bench_gemm_x3.py): 1 skip LDS reads + MFMAs, 2 skip LDS-DMA, 4 skip epilogue
   DropDev dd;
 };
@@ -140,10 +141,14 @@ __device__ __forceinline__ void x3_epilogue_staged(const X3Args& g, float* stg, 
           *(bf16x4*)cp = (bf16x4){h0, h1, h2, h3};
           *(bf16x4*)(cp + lo) = (bf16x4){l0, l1, l2, l3};
           if (EPI == XE_GLU_SG) {
-            bf16x8 sh, sl;
-            afm_split8(sv, sh, sl);
             bf16* pp = (bf16*)g.pre_act + rowi * (2 * g.N) + n;        // saved tensor: M x N pairs, row stride 2 N
-            *(bf16x8*)pp = sh; *(bf16x8*)(pp + g.N) = sl;
+            if (g.sg_hi_only) {
+              *(bf16x8*)pp = (bf16x8){(bf16)sv[0], (bf16)sv[1], (bf16)sv[2], (bf16)sv[3], (bf16)sv[4], (bf16)sv[5], (bf16)sv[6], (bf16)sv[7]};
+            } else {
+              bf16x8 sh, sl;
+              afm_split8(sv, sh, sl);
+              *(bf16x8*)pp = sh; *(bf16x8*)(pp + g.N) = sl;
+            }
           }
           continue;
         }
@@ -193,9 +198,13 @@ __device__ __forceinline__ void x3_epilogue_staged(const X3Args& g, float* stg, 
             const float keep = drop_on ? x3_drop32(g.dd, di + k, 1.0f) : 1.0f;
             x[k] = y * keep; gp[k] = yp * keep;
           }
-          bf16x8 h, l;
-          afm_split8(gp, h, l);
-          *(bf16x8*)(pbase + ro) = h; *(bf16x8*)(pbase + ro + lo) = l;
+          if (g.sg_hi_only) {
+            *(bf16x8*)(pbase + ro) = (bf16x8){(bf16)gp[0], (bf16)gp[1], (bf16)gp[2], (bf16)gp[3], (bf16)gp[4], (bf16)gp[5], (bf16)gp[6], (bf16)gp[7]};
+          } else {
+            bf16x8 h, l;
+            afm_split8(gp, h, l);
+            *(bf16x8*)(pbase + ro) = h; *(bf16x8*)(pbase + ro + lo) = l;
+          }
         }
         if (EPI == XE_MUL || EPI == XE_GELU_BWD) {
           const bf16x8 uh = *(const bf16x8*)(pbase + ro), ul = *(const bf16x8*)(pbase + ro + lo);
@@ -831,6 +840,7 @@ int afm_gemm_x3_try(const afm_gemm_desc* d, hipStream_t st) {
   g.abl = (d->reserved >= 320 && d->reserved < 328) ? d->reserved - 320 : 0;
   if (d->reserved >= 400 && d->reserved < 464) g.abl = (d->reserved - 400) << 4;   // stagger experiment: sleeps per phase
   g.glu_f = d->glu_rows;
+  g.sg_hi_only = d->reserved2 & 1;
   // 16-byte pieces of both planes: pointers 16-byte aligned, plane offsets (ld / 2) multiples of 8 elements
   if (!x3_al16(d->A) || !x3_al16(d->B) || (d->lda & 15) || (d->ldb & 15)) return AFM_ERR_UNSUPPORTED;
   if (!d->transA && d->transB) {   // NT

@@ -234,7 +234,7 @@ class Seq2SeqEngine:
         return t.hi if (self.mixed and isinstance(t, X2)) else t
 
     def _linear(self, x, name, rows, cols, r0=0, r1=None, out=None, out_dtype=None, bias_name=None,
-                residual=None, dropout=ops.NO_DROP, act=ACT_NONE, pre_act=None):
+                residual=None, dropout=ops.NO_DROP, act=ACT_NONE, pre_act=None, sg_hi_only=False):
         w = self.W(name, rows, cols, r0, r1)
         n = w.shape[0]
         if out is None:
@@ -243,7 +243,7 @@ class Seq2SeqEngine:
         if bias_name is not None:
             bias = self.ps.vec_span(self.ps.flat, bias_name, r0, r0 + n)
         return ops.gemm(x, w, out, trans_b=True, bias=bias, residual=residual, dropout=dropout, act=act,
-                        pre_act=pre_act, algo=self.algo)
+                        pre_act=pre_act, algo=self.algo, sg_hi_only=sg_hi_only)
 
     def _dgrad(self, dy, name, rows, cols, r0=0, r1=None, out=None, out_dtype=None, accumulate=False,
                act=ACT_NONE, pre_act=None, dropout=ops.NO_DROP):
@@ -490,7 +490,8 @@ class Seq2SeqEngine:
             uv = self._empty(x.shape[0], 2 * f) if saved is not None else None
             ops.gemm(h, self.w_glu[p + "linear1.weight"], g, trans_b=True,
                      bias=self.ps.vec_span(self.ps.flat, p + "linear1.bias", 0, 2 * f),
-                     act=ACT_GLU_SAVE if saved is not None else ACT_GLU, pre_act=uv, dropout=dr, algo=self.algo, glu_rows=f)
+                     act=ACT_GLU_SAVE if saved is not None else ACT_GLU, pre_act=uv, dropout=dr, algo=self.algo, glu_rows=f,
+                     sg_hi_only=self.mixed)
             dr = (dr, "glu")
         elif self.gated:
             uv = self._linear(h, p + "linear1.weight", k * f, d, bias_name=p + "linear1.bias")
@@ -501,7 +502,7 @@ class Seq2SeqEngine:
             sg = saved is not None and self.lowp and x.shape[0] % 256 == 0 and f % 256 == 0
             uv = self._empty(x.shape[0], f) if saved is not None else None
             self._linear(h, p + "linear1.weight", f, d, out=g, bias_name=p + "linear1.bias",
-                         act=ACT_GELU_SAVE_GRAD if sg else ACT_GELU, pre_act=uv, dropout=dr)
+                         act=ACT_GELU_SAVE_GRAD if sg else ACT_GELU, pre_act=uv, dropout=dr, sg_hi_only=self.mixed and sg)
             dr = (dr, sg)
         br = self._linear(g, p + "linear2.weight", d, f, bias_name=p + "linear2.bias", out_dtype=self.branch_dtype)
         if saved is not None:

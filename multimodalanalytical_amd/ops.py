@@ -101,7 +101,7 @@ def gemm(a: torch.Tensor, b: torch.Tensor, c: torch.Tensor, *, trans_a=False, tr
          bias: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
          pre_act: Optional[torch.Tensor] = None, act: int = ACT_NONE, accumulate: bool = False,
          dropout: Dropout = NO_DROP, algo: int = ALGO_AUTO, a_colsum: Optional[torch.Tensor] = None,
-         variant: int = 0, glu_rows: int = 0) -> torch.Tensor:
+         variant: int = 0, glu_rows: int = 0, sg_hi_only: bool = False) -> torch.Tensor:
     """c = epilogue(op(a) @ op(b)); default is the nn.Linear form c = a @ b^T + bias.
     a_colsum (trans_a only): a_colsum[m] += sum_k a[k, m], the bias gradient of the wgrad form.
     Gated-FFN forms (act 6 / 7 / 8, include/afm_hip.h): c is (M, N/2) resp. (M, 2N); glu_rows = f."""
@@ -142,6 +142,7 @@ def gemm(a: torch.Tensor, b: torch.Tensor, c: torch.Tensor, *, trans_a=False, tr
     d.act, d.accumulate, d.algo = int(act), int(accumulate), int(algo)
     d.reserved = int(variant)
     d.glu_rows = int(glu_rows)
+    d.reserved2 = 1 if sg_hi_only else 0
     d.drop = dropout
     L.check(L.load().afm_gemm(C.byref(d), _stream()), "afm_gemm")
     _log_algo()
