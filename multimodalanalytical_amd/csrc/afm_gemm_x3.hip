@@ -403,6 +403,89 @@ static int launch_x3_nt(X3Args& g, hipStream_t st, bool staged_ok) {
   return AFM_OK;
 }
 
+// ------------------------------------------------------------------------------------------ NT, few rows (decode)
+// Incremental decode multiplies 128-640 rows: on 256 x 128 tiles that is 4-16 workgroups on the chip, each grinding through a
+// tile that is half padding (48 us per GEMM whatever the shape).  Here: 64 x 64 tiles, four waves of 32 x 32, every wave moves
+// its own four LDS-DMA pieces per k-step, ring of four 16-KiB stages (three steps in flight), one workgroup per tile, so the
+// grid is (M/64) x (N/64) workgroups and a GEMM is a handful of microseconds of LDS-DMA latency.  Fragment epilogue (bias,
+// GELU / ReLU, dropout, residual, accumulate, saved pre-activation; pair or fp32 output).
+template <int CT>
+__global__ __launch_bounds__(256) void k_x3_nt_small(X3Args g) {
+  constexpr int TB = 64, S = 4, STAGE = 2 * TB * 128, NP = 2 * TB / 8 / 4;   // pieces per wave and stage = 4
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  const int t = threadIdx.x, lane = t & 63;
+  const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int tile = blockIdx.x;
+  const int m0 = (tile / g.tiles_n) * TB, n0 = (tile % g.tiles_n) * TB;
+  const int nk = g.K / 32;
+  const bf16* src[NP];
+#pragma unroll
+  for (int j = 0; j < NP; ++j) {
+    const int ii = w + 4 * j;                                   // piece 0..15: 0..7 rows of A, 8..15 rows of B
+    const int r8 = lane >> 3, ch = (lane & 7) ^ r8;
+    const int koff = (ch & 3) * 8;
+    if (ii < TB / 8) src[j] = g.A + (int64_t)min(m0 + ii * 8 + r8, g.M - 1) * g.lda + koff + (ch >> 2) * (g.lda >> 1);
+    else src[j] = g.B + (int64_t)min(n0 + (ii - TB / 8) * 8 + r8, g.N - 1) * g.ldb + koff + (ch >> 2) * (g.ldb >> 1);
+  }
+  auto issue = [&](int kt) {
+    unsigned char* st = lds + (kt % S) * STAGE;
+#pragma unroll
+    for (int j = 0; j < NP; ++j)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[j] + kt * 32),
+                                       (__attribute__((address_space(3))) void*)(st + (w + 4 * j) * 1024), 16, 0, 0);
+  };
+  auto off = [](int row, int chunk) { return row * 128 + ((chunk ^ (row & 7)) << 4); };
+  const int wm = w >> 1, wn = w & 1, fr = lane & 15, fq = lane >> 4;
+  f32x4 acc[2][2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) acc[j][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int s = 0; s < S - 1; ++s)
+    if (s < nk) issue(s);
+  for (int kt = 0; kt < nk; ++kt) {
+    const int later = min(S - 2, nk - 1 - kt);                  // younger steps already issued behind step kt
+    if (later >= 2) x3_wait_vmcnt<2 * NP>(); else if (later == 1) x3_wait_vmcnt<NP>(); else x3_wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    if (kt + S - 1 < nk) issue(kt + S - 1);
+    const unsigned char* a = lds + (kt % S) * STAGE;
+    const unsigned char* b = a + TB * 128;
+    bf16x8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      ah[i] = *(const bf16x8*)(a + off(wm * 32 + i * 16 + fr, fq)); al[i] = *(const bf16x8*)(a + off(wm * 32 + i * 16 + fr, 4 + fq));
+      bh[i] = *(const bf16x8*)(b + off(wn * 32 + i * 16 + fr, fq)); bl[i] = *(const bf16x8*)(b + off(wn * 32 + i * 16 + fr, 4 + fq));
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl[j], ah[i], acc[j][i], 0, 0, 0);
+        acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[j], al[i], acc[j][i], 0, 0, 0);
+        acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[j], ah[i], acc[j][i], 0, 0, 0);
+      }
+  }
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+      x3_epilogue4<CT>(g, m0 + wm * 32 + i * 16 + fr, n0 + wn * 32 + j * 16 + fq * 4, acc[j][i]);
+}
+
+template <int CT>
+static int launch_x3_nt_small(X3Args& g, hipStream_t st) {
+  g.tiles_m = (g.M + 63) / 64; g.tiles_n = (g.N + 63) / 64;
+  auto kern = k_x3_nt_small<CT>;
+  static bool attr_done = false;   // per instantiation
+  if (!attr_done) {
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+    attr_done = true;
+  }
+  AFM_LAUNCH(kern, dim3(g.tiles_m * g.tiles_n), dim3(256), 4 * 2 * 64 * 128, st, g);
+  return AFM_OK;
+}
+
 // ------------------------------------------------------------------------------------------ NT, 256 x 256 tiles
 // Whole-tile problems with many tiles (the encoder's token count): 8 waves of 128 x 64 (2 x 4), no loader waves -- per
 // LDS-DMA piece the split-pair form issues three times the MFMAs of the single-pass kernel, so the waves can afford to
@@ -861,6 +944,16 @@ int afm_gemm_x3_try(const afm_gemm_desc* d, hipStream_t st) {
       else r = launch_x3_nt<X3_X2, XE_GLU_BWD>(g, st, true);
       if (r != AFM_OK) return r;
       afm_set_last_algo("mfma_nt_x3_glu");
+      return AFM_OK;
+    }
+    // few rows (incremental decode): 64 x 64 tiles over the whole chip instead of a handful of 256 x 128 tiles; reserved = 33 forces it
+    const int64_t tiles_256x128 = (int64_t)((d->M + 255) / 256) * ((d->N + 127) / 128);
+    if ((d->reserved == 33 || (d->reserved == 0 && tiles_256x128 < 64 && d->M <= 1024)) && d->act <= AFM_ACT_GELU && (d->ldc & 1) == 0 &&
+        !(d->c_dtype == AFM_F32 && (d->act != AFM_ACT_NONE || d->pre_act || d->drop.p > 0.f)) &&
+        (uint64_t)d->M * (uint64_t)d->N <= 0x100000000ull) {
+      const int r = d->c_dtype == AFM_F32 ? launch_x3_nt_small<X3_F32>(g, st) : launch_x3_nt_small<X3_X2>(g, st);
+      if (r != AFM_OK) return r;
+      afm_set_last_algo("mfma_nt_x3_small");
       return AFM_OK;
     }
     // 256 x 256 tiles: whole tiles, enough of them to fill the chip twice over; reserved = 31 / 32 force a form (tools)

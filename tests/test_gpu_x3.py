@@ -59,7 +59,8 @@ def test_gemm_x3_nt_plain(ops, M, N, K, out):
     ref = a.double() @ w.double().T + bias.double()
     c = X2.empty(M, N, DEV) if out == "x2" else torch.empty(M, N, device=DEV)
     ops.gemm(x2(a), x2(w), c, bias=dev(bias), algo=2)
-    assert ops.last_algo() == "mfma_nt_x3"
+    few = M <= 1024 and ((M + 255) // 256) * ((N + 127) // 128) < 64      # decode-sized: the 64 x 64 tile kernel
+    assert ops.last_algo() == ("mfma_nt_x3_small" if few else "mfma_nt_x3")
     got = c.float()
     assert float((got.cpu().double() - ref).abs().max()) < 2e-5 * math.sqrt(K) * 4, (M, N, K)
     assert relnorm(got, ref) < 1e-5
@@ -69,6 +70,14 @@ def test_gemm_x3_nt_plain(ops, M, N, K, out):
         base = c2.clone().cpu()
         ops.gemm(x2(a), x2(w), c2, bias=dev(bias), residual=dev(res), accumulate=True, algo=2)
         assert relnorm(c2, ref + res.double() + base.double()) < 1e-5
+    if few:            # the same problem on the big-tile kernel (variant 31) and, for big ones, on the small-tile kernel (33)
+        c3 = X2.empty(M, N, DEV) if out == "x2" else torch.empty(M, N, device=DEV)
+        ops.gemm(x2(a), x2(w), c3, bias=dev(bias), algo=2, variant=31)
+        assert ops.last_algo() == "mfma_nt_x3" and relnorm(c3.float(), ref) < 1e-5
+    else:
+        c3 = X2.empty(M, N, DEV) if out == "x2" else torch.empty(M, N, device=DEV)
+        ops.gemm(x2(a), x2(w), c3, bias=dev(bias), algo=2, variant=33)
+        assert ops.last_algo() == "mfma_nt_x3_small" and relnorm(c3.float(), ref) < 1e-5
 
 
 @pytest.mark.parametrize("M,N", [(512, 256), (300, 136)])
@@ -103,6 +112,13 @@ def test_gemm_x3_nt_fused_epilogues(ops, M, N):
     ops.gemm(x2(dy), x2(w2), c4, act=3, pre_act=pre, dropout=ops.drop(p, seed, site), algo=2)   # ACT_GELU_BWD
     assert relnorm(c4.float(), g * keep * gp) < 3e-5
     assert ops.last_algo() == "mfma_nt_x3"
+    # ACT_GELU / ReLU on the decode-sized kernel (fragment epilogue)
+    c5, pre5 = X2.empty(M, N, DEV), X2.empty(M, N, DEV)
+    ops.gemm(A, W, c5, bias=dev(bias), act=2, pre_act=pre5, dropout=ops.drop(p, seed, site), algo=2, variant=33)
+    assert ops.last_algo() == "mfma_nt_x3_small"
+    assert relnorm(pre5.float(), t) < 1e-5 and relnorm(c5.float(), gelu * keep) < 2e-5
+    ops.gemm(A, W, c5, bias=dev(bias), act=1, algo=2, variant=33)
+    assert relnorm(c5.float(), t.clamp_min(0)) < 1e-5
 
 
 @pytest.mark.parametrize("R,M,N", [(4096, 512, 512), (8192, 1536, 512), (2048, 64, 128), (256, 512, 2048), (1056, 200, 136)])

@@ -11,7 +11,10 @@ def main():
     wl = synth.WORKLOADS[name]
     B = int(sys.argv[2]) if len(sys.argv) > 2 else 128
     tok = SimpleTokenizerInfo(wl["data"]["Smiles"]["vocab_size"])
-    model = HFWrapper(wl["data"], "CustomModel", "facebook/bart-base", tok, device=dev, compute_dtype=torch.bfloat16,
+    from multimodalanalytical_amd.x2 import X2
+    mode = sys.argv[3] if len(sys.argv) > 3 else "bf16x3"
+    cd = {"bf16x3": X2.dtype, "bf16": torch.bfloat16, "fp32": torch.float32}[mode]
+    model = HFWrapper(wl["data"], "CustomModel", "facebook/bart-base", tok, device=dev, compute_dtype=cd,
                       **{k: v for k, v in wl["cfg"].items() if k != "multimodal_norm"})
     batch = synth.make_batch(name, B, seed=1, device=dev)[0]
     model.max_length = 128
@@ -21,7 +24,7 @@ def main():
         torch.cuda.synchronize(); t0 = time.perf_counter()
         ids = model.generate(batch, **kw)
         torch.cuda.synchronize(); dt = time.perf_counter() - t0
-        print(f"{name} B={B} {label:55s}: {dt*1e3:8.1f} ms  {B/dt:8.1f} samples/s  ({ids.shape[1]} tokens, {dt/ids.shape[1]*1e3:.2f} ms/token)")
+        print(f"{name} {mode} B={B} {label:55s}: {dt*1e3:8.1f} ms  {B/dt:8.1f} samples/s  ({ids.shape[1]} tokens, {dt/ids.shape[1]*1e3:.2f} ms/token)")
 
 if __name__ == "__main__":
     main()
