@@ -14,14 +14,11 @@
 #define IMG64 (64 * DH * 2)   // one 64-row image
 #define IMG32 (32 * DH * 2)   // one 32-row image
 
-__device__ __forceinline__ void split8(const f32x16& x, int s, bf16x8& hi, bf16x8& lo) {
+__device__ __forceinline__ void split8(const f32x16& x, int s, bf16x8& hi, bf16x8& lo) {   // x: VALU results (see afm_split2)
+  afm_u32x4 h, l;
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const float v = x[8 * s + j];
-    const bf16 h = (bf16)v;
-    hi[j] = h;
-    lo[j] = (bf16)(v - (float)h);
-  }
+  for (int j = 0; j < 4; ++j) { uint32_t a, b; afm_split2(x[8 * s + 2 * j], x[8 * s + 2 * j + 1], a, b); h[j] = a; l[j] = b; }
+  hi = __builtin_bit_cast(bf16x8, h); lo = __builtin_bit_cast(bf16x8, l);
 }
 // the three passes of one split product: acc += A * B with A = (ah, al), B = (bh, bl)
 __device__ __forceinline__ f32x16 mfma3(bf16x8 ah, bf16x8 al, bf16x8 bh, bf16x8 bl, f32x16 c) {

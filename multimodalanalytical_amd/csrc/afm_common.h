@@ -58,10 +58,25 @@ template <> __device__ __forceinline__ void st_rc<x2>(x2* p, int64_t r, int c, i
   afm_split(v, hi, lo);
   q[0] = hi; q[ld >> 1] = lo;
 }
+// two values -> packed hi pair and packed lo pair (element 0 in the low half): 6 vector instructions for 2 elements (the compiler's
+// per-element form converts and packs each bf16 by itself: 8+).  Same rounding as afm_split (v_cvt_pk_bf16_f32 is RNE).  The inputs
+// must be VALU results, not MFMA accumulators read in place (no hazard wait states around inline asm).
+typedef uint32_t afm_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void afm_split2(float v0, float v1, uint32_t& hi2, uint32_t& lo2) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(hi2) : "v"(v0), "v"(v1));
+  const float l0 = v0 - __uint_as_float(hi2 << 16), l1 = v1 - __uint_as_float(hi2 & 0xffff0000u);
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(lo2) : "v"(l0), "v"(l1));
+#else
+  hi2 = lo2 = 0; (void)v0; (void)v1;
+#endif
+}
 // 8 consecutive elements (16-byte accesses per plane)
 __device__ __forceinline__ void afm_split8(const float (&x)[8], bf16x8& hi, bf16x8& lo) {
+  afm_u32x4 h, l;
 #pragma unroll
-  for (int k = 0; k < 8; ++k) { bf16 h, l; afm_split(x[k], h, l); hi[k] = h; lo[k] = l; }
+  for (int k = 0; k < 4; ++k) { uint32_t a, b; afm_split2(x[2 * k], x[2 * k + 1], a, b); h[k] = a; l[k] = b; }
+  hi = __builtin_bit_cast(bf16x8, h); lo = __builtin_bit_cast(bf16x8, l);
 }
 // dtype dispatch of a templated launch: DT_SWITCH(code, T, stmt) runs stmt with T = float / bf16 / x2
 #define AFM_DT_SWITCH(code, T, ...)                                        \
