@@ -28,7 +28,8 @@ struct X3Args {
   int bias_in_lds;
   int glu_f;            // gated-FFN interleave (include/afm_hip.h)
   int sg_hi_only;       // stored gradient factors (GELU_SG / GLU_SG): hi plane only (the bf16 backward of mixed mode reads nothing else)
-  int abl;              // timing experiments (tools/bench_gemm_x3.py): 1 skip LDS reads + MFMAs, 2 skip LDS-DMA, 4 skip epilogue
+  int abl;              // timing experiments (tools/bench_gemm_x3.py): 1 skip LDS reads + MFMAs, 2 skip LDS-DMA, 4 skip epilogue,
+                        // 8 skip the LDS-DMA of the B rows, 16 read the B fragments once per tile
   DropDev dd;
 };
 
@@ -532,8 +533,9 @@ __global__ __launch_bounds__(512) void k_x3_nt256(X3Args g) {
     if (!(g.abl & 2)) {
 #pragma unroll
       for (int j = 0; j < NIW; ++j)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[j] + is_kt * 32),
-                                         (__attribute__((address_space(3))) void*)(st + (w + NW * j) * 1024), 16, 0, 0);
+        if (!((g.abl & 8) && w + NW * j >= TBM / 8))
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[j] + is_kt * 32),
+                                           (__attribute__((address_space(3))) void*)(st + (w + NW * j) * 1024), 16, 0, 0);
     }
     is_slot ^= 1;
     if (++is_kt == nk) {
@@ -559,6 +561,7 @@ __global__ __launch_bounds__(512) void k_x3_nt256(X3Args g) {
     for (int j = 0; j < 4; ++j)
 #pragma unroll
       for (int i = 0; i < WM; ++i) acc[j][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    bf16x8 bh[4], bl[4];
     for (int kt = 0; kt < nk; ++kt) {
       // only this step's pieces are in flight (two slots); behind them, at a tile boundary, sit the >= 32 stores of the
       // previous tile's epilogue, which may stay outstanding under this tile's first MFMAs (in-order counter)
@@ -569,11 +572,12 @@ __global__ __launch_bounds__(512) void k_x3_nt256(X3Args g) {
       const unsigned char* b = a + TBM * 128;
       slot ^= 1;
       if (g.abl & 1) continue;
-      bf16x8 bh[4], bl[4];
+      if (!(g.abl & 16) || kt == 0) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        bh[j] = *(const bf16x8*)(b + off(wn * 64 + j * 16 + fr, fq));
-        bl[j] = *(const bf16x8*)(b + off(wn * 64 + j * 16 + fr, 4 + fq));
+        for (int j = 0; j < 4; ++j) {
+          bh[j] = *(const bf16x8*)(b + off(wn * 64 + j * 16 + fr, fq));
+          bl[j] = *(const bf16x8*)(b + off(wn * 64 + j * 16 + fr, 4 + fq));
+        }
       }
 #pragma unroll
       for (int i = 0; i < WM; ++i) {
@@ -920,7 +924,7 @@ int afm_gemm_x3_try(const afm_gemm_desc* d, hipStream_t st) {
   g.act = d->act; g.accumulate = d->accumulate;
   g.dd = afm_make_drop(&d->drop);
   g.tiles_m = g.tiles_n = 0; g.ksplit = 1; g.kchunk = d->K; g.bias_in_lds = 0;
-  g.abl = (d->reserved >= 320 && d->reserved < 328) ? d->reserved - 320 : 0;
+  g.abl = (d->reserved >= 320 && d->reserved < 352) ? d->reserved - 320 : 0;   // + 8: no LDS-DMA of the B rows, + 16: B fragments read once per tile
   if (d->reserved >= 400 && d->reserved < 464) g.abl = (d->reserved - 400) << 4;   // stagger experiment: sleeps per phase
   g.glu_f = d->glu_rows;
   g.sg_hi_only = d->reserved2 & 1;
