@@ -42,7 +42,7 @@ def parse():
     ap.add_argument("--workload", default="c2", help="c1..c5 (multimodalanalytical_amd/synth.py)")
     ap.add_argument("--batch", type=int, default=0, help="per-GPU micro-batch (default: the workload's, 128)")
     ap.add_argument("--acc", type=int, default=4)
-    ap.add_argument("--dtype", default="bf16x3-mixed", choices=["bf16x3", "bf16x3-mixed", "bf16", "fp32"], help="mode of `value`")
+    ap.add_argument("--dtype", default="bf16x3-mixed", choices=["fp16", "bf16x3", "bf16x3-mixed", "bf16", "fp32"], help="mode of `value`")
     ap.add_argument("--other-modes", default="bf16x3,bf16", help="comma list of further modes timed in the same run ('' = none)")
     ap.add_argument("--other-steps", type=int, default=3)
     ap.add_argument("--extra-workloads", default="c3", help="comma list: further workloads timed in the primary mode (N = 1 only)")
@@ -58,7 +58,7 @@ def parse():
 
 def compute_dtype(name):
     from multimodalanalytical_amd.x2 import X2
-    return {"bf16": torch.bfloat16, "bf16x3": X2.dtype, "bf16x3-mixed": X2.dtype, "fp32": torch.float32}[name]
+    return {"fp16": torch.float16, "bf16": torch.bfloat16, "bf16x3": X2.dtype, "bf16x3-mixed": X2.dtype, "fp32": torch.float32}[name]
 
 
 def backward_dtype(name):
@@ -111,8 +111,8 @@ def kernel_rooflines(model, wl, B, mode):
     M, dh = B * S, d // H
     fmode = "bf16x3" if mixed else mode                       # arithmetic of the forward kernels
     bmode = "bf16" if mixed else mode                         # ... of the backward kernels
-    PASS = {"bf16x3": 3, "bf16": 1, "fp32": 1}
-    ESZ = {"bf16": 2, "bf16x3": 4, "fp32": 4}
+    PASS = {"bf16x3": 3, "bf16": 1, "fp16": 1, "fp32": 1}
+    ESZ = {"bf16": 2, "fp16": 2, "bf16x3": 4, "fp32": 4}
     peak = PEAK_BF16_TFLOPS if mode != "fp32" else 157.3
     out = []
 
@@ -214,7 +214,7 @@ def kernel_rooflines(model, wl, B, mode):
         for e in out:
             km = e["arithmetic"]
             if km not in tables:
-                pmc = os.path.join(ROOT, "profiles", f"r02_{km}_pmc.json")
+                pmc = os.path.join(ROOT, "profiles", f"r02_{'bf16' if km == 'fp16' else km}_pmc.json")
                 tables[km] = json.load(open(pmc)) if os.path.exists(pmc) else {}
             e["traffic"] = tables[km].get(e["what"], {}).get("hbm_bytes_per_launch")
     out.sort(key=lambda e: -e["ms_per_micro_batch"])
@@ -354,7 +354,7 @@ def main():
     wl, B, S, flops = main_run["wl"], main_run["B"], main_run["S"], main_run["flops"]
     value = main_run["value"]
     # executed MFMA passes per algorithmic product: forward third of the FLOPs at 3, backward two thirds at 1 in mixed mode
-    PASSES = {"bf16x3": 3.0, "bf16x3-mixed": (1.0 * 3 + 2.0 * 1) / 3, "bf16": 1.0, "fp32": 1.0}
+    PASSES = {"fp16": 1.0, "bf16x3": 3.0, "bf16x3-mixed": (1.0 * 3 + 2.0 * 1) / 3, "bf16": 1.0, "fp32": 1.0}
     passes = PASSES[args.dtype]
 
     def mode_entry(r, mode, steps):
@@ -365,6 +365,8 @@ def main():
                 "logits_vs_cpu_reference": {"bf16x3": "~1e-5 rel., argmax ids equal (tests/test_gpu_shapes.py; bar 1e-3)",
                                             "bf16x3-mixed": "~1e-5 rel., argmax ids equal: the forward IS the bf16x3 forward (bar 1e-3); "
                                                             "gradients at bf16 precision (global 4e-3 rel. vs the CPU reference)",
+                                            "fp16": "4e-4..7e-4 rel. at c1..c5 (bar 1e-3), ids equal wherever the reference's top-2 margin exceeds "
+                                                    "twice that (tests/test_gpu_shapes.py, tests/test_gpu_model.py at the timed size)",
                                             "bf16": "3e-3..6e-3 rel. (outside the 1e-3 bar)", "fp32": "~1e-6 rel., ids equal"}[mode],
                 "final_loss": round(r["loss"], 4)}
 
@@ -395,6 +397,8 @@ def main():
                    "precision": {"bf16x3": "split bf16 operand pairs, 3 bf16 MFMA passes per product, fp32 accumulate / residual stream / statistics",
                                  "bf16x3-mixed": "forward as bf16x3 (split pairs, 3 MFMA passes: parity-grade logits); backward on the single-pass bf16 "
                                                  "kernels reading the hi planes of the saved pair tensors (the reference trains in 16-bit mixed precision)",
+                                 "fp16": "fp16 operands forward and backward, 1 MFMA pass per product, fp32 accumulate / residual stream / statistics / "
+                                         "master weights, dynamic loss scaling on the device: the reference's own GPU precision (Lightning 16-mixed)",
                                  "bf16": "bf16 operands, 1 MFMA pass, fp32 accumulate / residual stream / statistics",
                                  "fp32": "exact fp32 FMA kernels"}[args.dtype]},
         "train_gflop_per_sample": round(flops / 1e9, 2),

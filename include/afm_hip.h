@@ -24,6 +24,10 @@
  *     operands run three bf16 MFMAs per product (hi*hi + hi*lo + lo*hi, fp32 accumulate): the
  *     "bf16x3" precision mode, fp32-grade results (the <= 1e-3 logits / exact-argmax bar of the parity
  *     tests) on the bf16 matrix cores.
+ *     AFM_F16 = 3 (IEEE half, round-to-nearest-even): the operand format of the "fp16" precision mode, the reference's own
+ *     GPU arithmetic (trainer/trainer.py:69, Lightning "16-mixed": fp16 autocast + GradScaler).  One v_mfma_*_f16 pass per
+ *     product, fp32 accumulate; 11 significant bits keep the logits within the 1e-3 bar (measured 4e-4 .. 7e-4 at the BASELINE
+ *     shapes), the 5-bit exponent is what the loss scaler of afm_adam_step / afm_scaler_update exists for.
  */
 #ifndef AFM_HIP_H
 #define AFM_HIP_H
@@ -34,10 +38,10 @@
 extern "C" {
 #endif
 
-#define AFM_ABI_VERSION 2
+#define AFM_ABI_VERSION 3
 
 enum { AFM_OK = 0, AFM_ERR_ARG = -1, AFM_ERR_UNSUPPORTED = -2, AFM_ERR_LAUNCH = -3 };
-enum { AFM_F32 = 0, AFM_BF16 = 1, AFM_BF16X2 = 2 };
+enum { AFM_F32 = 0, AFM_BF16 = 1, AFM_BF16X2 = 2, AFM_F16 = 3 };
 enum { AFM_ACT_NONE = 0, AFM_ACT_RELU = 1, AFM_ACT_GELU = 2, AFM_ACT_GELU_BWD = 3,
        AFM_ACT_GELU_SAVE_GRAD = 4, AFM_ACT_MUL_SAVED = 5, AFM_ACT_GLU = 6, AFM_ACT_GLU_SAVE = 7, AFM_ACT_GLU_BWD = 8 };
 enum { AFM_ALGO_AUTO = 0, AFM_ALGO_GENERIC = 1, AFM_ALGO_MFMA = 2 };
@@ -93,7 +97,7 @@ typedef struct {
  *                                                           C = [dg * saved_a | dg * saved_b] = [du | dv], pre_act an INPUT
  * (dropout element index = row-major in the M x f tensor g, as afm_glu_fwd).  MFMA kernels, whole tiles only; other shapes
  * return AFM_ERR_UNSUPPORTED and the caller keeps the unfused afm_glu_fwd / afm_glu_bwd path.
- * bf16 operands take the MFMA path (v_mfma_f32_16x16x32_bf16 / 32x32x16, fp32 accumulate) when
+ * bf16 / fp16 operands take the MFMA path (v_mfma_f32_16x16x32_bf16 | _f16 / 32x32x16, fp32 accumulate) when
  * shape/alignment allow; everything else takes the exact-fp32 FMA path.
  * ---------------------------------------------------------------------------------------- */
 typedef struct {
@@ -236,7 +240,7 @@ int afm_dropout_cast(const float* x, void* y, int64_t rows, int32_t n, int32_t l
  * embedders (linear_2_layer / linear_3_layer, modeling/utils.py:107-136) and of the alignment head
  * (custom_modeling.py:363-396). */
 int afm_relu_bwd(const float* dy, const float* act, float* dx, int64_t n, void* stream);
-/* dst = (dst_dtype) src, any pair of AFM_F32 / AFM_BF16 / AFM_BF16X2, rows x n with row strides lds / ldd
+/* dst = (dst_dtype) src, any pair of AFM_F32 / AFM_BF16 / AFM_BF16X2 / AFM_F16, rows x n with row strides lds / ldd
  * (elements of the respective dtype's planes, see the AFM_BF16X2 convention above). */
 int afm_convert(const void* src, int32_t src_dtype, int32_t lds, void* dst, int32_t dst_dtype, int32_t ldd,
                 int64_t rows, int32_t n, void* stream);
@@ -256,7 +260,8 @@ int afm_cast_bf16(const float* src, void* dst, void* dst_t, int32_t rows, int32_
 /* The same for the split-pair dtype: dst is (rows x cols) AFM_BF16X2 with row stride 2*cols, dst_t the
  * transpose (cols x rows) with row stride 2*rows. */
 int afm_cast_x2(const float* src, void* dst, void* dst_t, int32_t rows, int32_t cols, void* stream);
-/* Both of the above with the gated-FFN row interleave: dtype AFM_BF16 or AFM_BF16X2; glu_rows = f > 0 (rows = 2f): source row
+/* Both of the above for dtype AFM_BF16, AFM_BF16X2 or AFM_F16 (glu_rows = 0: plain copies), and with the gated-FFN row
+ * interleave: glu_rows = f > 0 (rows = 2f): source row
  * r (r < f: W1, else Wg) lands in row ((j>>2)<<3) + (j&3) + 4*(r >= f), j = r mod f, of dst (column of dst_t). */
 int afm_cast_weights(const float* src, void* dst, void* dst_t, int32_t rows, int32_t cols, int32_t dtype, int32_t glu_rows,
                      void* stream);
@@ -269,7 +274,7 @@ int afm_cast_weights(const float* src, void* dst, void* dst_t, int32_t rows, int
  *   padded rows, so it can initialise the encoder-output gradient).
  * loss: pred = sigmoid(z); kind 0 mse = mean (pred-t)^2, 1 mae = mean |pred-t| (nn.MSELoss / nn.L1Loss),
  *   2 sid = the reference's own kl_div pair (modeling/utils.py:8-22): both clamped to >= 1e-16,
- *   [sum p log(p/t) + sum t log(t/p)] / B.  stats[0] += loss; dz = grad_scale * dloss/dz.
+ *   [sum p log(p/t) + sum t log(t/p)] / B.  stats[0] += loss; dz = grad_scale * (scale_dev ? scale_dev[0] : 1) * dloss/dz.
  * The Linear / ReLU / centre-tap Conv1d layers in between are afm_gemm calls.
  * ---------------------------------------------------------------------------------------- */
 enum { AFM_ALIGN_MSE = 0, AFM_ALIGN_MAE = 1, AFM_ALIGN_SID = 2 };
@@ -278,7 +283,7 @@ int afm_masked_mean_fwd(const void* x, int32_t x_dtype, const uint8_t* key_pad, 
 int afm_masked_mean_bwd(const float* dy, const uint8_t* key_pad, int32_t B, int32_t S, int32_t d,
                         float* dx, int32_t accumulate, void* stream);
 int afm_align_loss(const float* z, const float* target, int32_t kind, int32_t B, int32_t n,
-                   float grad_scale, float* stats, float* dz, void* stream);
+                   float grad_scale, const float* scale_dev, float* stats, float* dz, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Mixture generator (data/datasets.py:58-141 mix_spectra + normalize_spectrum
@@ -325,12 +330,13 @@ int afm_patch_preprocess(const afm_patch_desc* d, const float* spectra, const ui
  * HFWrapper._calc_token_acc (wrapper.py:641-655).
  * fwd: per row log-sum-exp and argmax (first maximal index, as torch.argmax); stats[0] += sum of
  *      -log_softmax[label] over labels != -100, stats[1] += number of such labels.
- * bwd: dlogits = (softmax - onehot(label)) * grad_scale / stats[1] for kept rows, 0 otherwise.
+ * bwd: dlogits = (softmax - onehot(label)) * grad_scale * (scale_dev ? scale_dev[0] : 1) / stats[1] for kept rows, 0 otherwise;
+ *      scale_dev (DEVICE, nullable) is the dynamic loss scale of the fp16 mode (word 0 of the scaler state, below).
  * ---------------------------------------------------------------------------------------- */
 int afm_ce_fwd(const float* logits, const int64_t* labels, int64_t rows, int32_t V, int32_t ld,
                float* row_lse, int64_t* argmax, float* stats, void* stream);
 int afm_ce_bwd(const float* logits, const int64_t* labels, const float* row_lse, const float* stats,
-               float grad_scale, void* dlogits, int32_t dl_dtype, int32_t lddl, int64_t rows,
+               float grad_scale, const float* scale_dev, void* dlogits, int32_t dl_dtype, int32_t lddl, int64_t rows,
                int32_t V, int32_t ld, void* stream);
 
 /* ------------------------------------------------------------------------------------------
@@ -375,17 +381,25 @@ int afm_cache_reorder(const void* src, void* dst, const int32_t* beam_idx, int32
  * afm_sumsq:  out[0] += sum g[i]^2   (torch.nn.utils.clip_grad_norm_, Lightning
  *             gradient_clip_val, trainer/trainer.py:65)
  * afm_adam_step: torch.optim.Adam / AdamW (wrapper.py:29,333-338) with the clip folded in:
- *     coef = min(1, max_norm / (sqrt(sumsq[0]) + 1e-6)) * grad_mult ; g = g * coef
+ *     coef = grad_mult * min(1, max_norm / (sqrt(sumsq[0]) * grad_mult + 1e-6)) ; g = g * coef
+ *     (grad_mult = 1/world under data parallelism: sumsq is taken over the SUMMED gradients, the clip acts on their mean)
  *     Adam  (decoupled == 0): g += wd * p        AdamW (decoupled == 1): p *= 1 - lr*wd
  *     m = b1 m + (1-b1) g ; v = b2 v + (1-b2) g^2
  *     p -= lr / (1 - b1^t) * m / (sqrt(v) / sqrt(1 - b2^t) + eps)
  * hyper (DEVICE, 10 floats) = { lr, beta1, beta2, eps, weight_decay, 1-beta1^t, 1-beta2^t,
  *     max_norm (<=0: no clip), grad_mult, decoupled } so a captured graph replays with new
- * values.  g is zeroed when zero_grad != 0.  p_bf16 (nullable) receives the bf16 copy of p.
+ * values.  g is zeroed when zero_grad != 0.  p_lowp (nullable) receives the 16-bit copy of p (lowp_dtype AFM_BF16 / AFM_F16).
+ * Dynamic loss scaling of the fp16 mode (torch.amp.GradScaler as Lightning's "16-mixed" drives it, trainer/trainer.py:69):
+ * `scaler` (DEVICE, 4 floats, nullable) = { loss scale S, growth tracker, optimiser steps taken, steps skipped }.  With it the
+ * gradients in g are S times the true ones (afm_ce_bwd / afm_align_loss multiplied by scaler[0]): grad_mult is divided by S,
+ * a non-finite sumsq[0] SKIPS the step (p, m, v untouched, g zeroed) and the bias corrections use t = scaler[2] + 1, the
+ * number of steps actually taken (torch's per-parameter `step`), instead of hyper[5..6].  afm_scaler_update then applies
+ * GradScaler.update(): skipped -> S *= backoff, tracker = 0; else tracker += 1 and after `interval` good steps S *= growth.
  * ---------------------------------------------------------------------------------------- */
 int afm_sumsq(const float* g, int64_t n, float* out, void* stream);
 int afm_adam_step(float* p, float* g, float* m, float* v, int64_t n, const float* hyper,
-                  const float* sumsq, void* p_bf16, int32_t zero_grad, void* stream);
+                  const float* sumsq, void* p_lowp, int32_t lowp_dtype, int32_t zero_grad, const float* scaler, void* stream);
+int afm_scaler_update(float* scaler, const float* sumsq, float growth, float backoff, int32_t interval, void* stream);
 
 #ifdef __cplusplus
 }

@@ -179,10 +179,12 @@ def run(cfg: Dict[str, Any], own: Dict[str, str]) -> Dict[str, Any]:
     pre = build_preprocessors(shards["train"], dc, device)
     collator = DeviceCollator(dc, pre, tm)
     tok = SimpleTokenizerInfo(dc[tm]["vocab_size"], pad_token_id=dc[tm]["pad_token_id"])
-    # precision=: bf16x3-mixed (default: split-pair forward = parity-grade outputs, single-pass bf16 backward, the analogue of
-    # the reference's 16-bit mixed training) | bf16x3 (split pairs in both directions) | bf16 | fp32
-    precision = own.get("precision", "bf16x3-mixed")
-    cd = {"bf16x3-mixed": X2.dtype, "bf16x3": X2.dtype, "bf16": torch.bfloat16, "fp32": torch.float32}[precision]
+    # precision=: fp16 (= Lightning's "16-mixed", what the reference trains with on a GPU, trainer/trainer.py:69: single-pass fp16
+    # MFMA forward and backward, dynamic loss scaling; logits within the 1e-3 bar) | bf16x3-mixed (split-pair forward = fp32-grade
+    # outputs, single-pass bf16 backward) | bf16x3 (split pairs in both directions) | bf16 (= "bf16-mixed") | fp32 (= "32-true")
+    precision = {"16-mixed": "fp16", "bf16-mixed": "bf16", "32-true": "fp32", "32": "fp32"}.get(str(own.get("precision", "fp16")),
+                                                                                                 str(own.get("precision", "fp16")))
+    cd = {"fp16": torch.float16, "bf16x3-mixed": X2.dtype, "bf16x3": X2.dtype, "bf16": torch.bfloat16, "fp32": torch.float32}[precision]
     bd = torch.bfloat16 if precision == "bf16x3-mixed" else None
     mk = {k: v for k, v in plan["model_config"].items() if k != "multimodal_norm"}
     bs = int(mk["batch_size"])

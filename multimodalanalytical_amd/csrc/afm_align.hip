@@ -52,7 +52,7 @@ __global__ __launch_bounds__(256) void k_masked_mean_bwd(const float* __restrict
 }
 
 __global__ __launch_bounds__(256) void k_align_loss(const float* __restrict__ z, const float* __restrict__ target, int kind,
-                                                    int B, int64_t total, float grad_scale, float* __restrict__ stats,
+                                                    int B, int64_t total, float grad_scale, const float* __restrict__ scale_dev, float* __restrict__ stats,
                                                     float* __restrict__ dz) {
   const float inv_all = 1.0f / (float)total, inv_b = 1.0f / (float)B;
   float acc = 0.f;
@@ -68,7 +68,7 @@ __global__ __launch_bounds__(256) void k_align_loss(const float* __restrict__ z,
       g = p > 1e-16f ? (lr + 1.f - tc / pc) * inv_b : 0.f;      // clamp passes the gradient only above eps
     }
     acc += l;
-    if (dz) dz[i] = grad_scale * g * p * (1.f - p);
+    if (dz) dz[i] = grad_scale * (scale_dev ? scale_dev[0] : 1.f) * g * p * (1.f - p);
   }
   acc = wave_sum(acc);
   __shared__ float part[4];
@@ -101,11 +101,11 @@ extern "C" int afm_masked_mean_bwd(const float* dy, const uint8_t* key_pad, int3
 }
 
 extern "C" int afm_align_loss(const float* z, const float* target, int32_t kind, int32_t B, int32_t n,
-                              float grad_scale, float* stats, float* dz, void* stream) {
+                              float grad_scale, const float* scale_dev, float* stats, float* dz, void* stream) {
   if (!z || !target || !stats || B <= 0 || n <= 0 || kind < 0 || kind > 2) return AFM_ERR_ARG;
   const int64_t total = (int64_t)B * n;
   int64_t blocks = (total + 255) / 256;
   if (blocks > 1024) blocks = 1024;
-  AFM_LAUNCH(k_align_loss, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, z, target, kind, B, total, grad_scale, stats, dz);
+  AFM_LAUNCH(k_align_loss, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, z, target, kind, B, total, grad_scale, scale_dev, stats, dz);
   return AFM_OK;
 }

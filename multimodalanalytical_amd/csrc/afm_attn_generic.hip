@@ -231,7 +231,7 @@ static AttnArgs make_args(const afm_attn_shape* s) {
 
 static int check_shape(const afm_attn_shape* s) {
   if (!s || s->B <= 0 || s->H <= 0 || s->Tq <= 0 || s->Tk <= 0 || s->dh <= 0) return AFM_ERR_ARG;
-  if (s->dtype < AFM_F32 || s->dtype > AFM_BF16X2) return AFM_ERR_ARG;
+  if (s->dtype < AFM_F32 || s->dtype > AFM_F16) return AFM_ERR_ARG;
   const int w = s->H * s->dh * (s->dtype == AFM_BF16X2 ? 2 : 1);   // split-pair rows hold two planes
   if (s->ldq < w || s->ldk < w || s->ldv < w || s->ldo < w) return AFM_ERR_ARG;
   return AFM_OK;
@@ -248,6 +248,12 @@ int afm_attn_fwd_mfma_try(const afm_attn_shape* s, const void* Q, const void* K,
 int afm_attn_bwd_mfma_try(const afm_attn_shape* s, const void* Q, const void* K, const void* V,
                           const void* O, const void* dO, const float* lse, float* delta, void* dQ,
                           void* dK, void* dV, int lddq, int lddk, int lddv, hipStream_t st);
+// the same kernels compiled for fp16 operands (afm_attn_mfma_f16.hip)
+int afm_attn_fwd_mfma_try_f16(const afm_attn_shape* s, const void* Q, const void* K, const void* V,
+                              void* O, float* lse, hipStream_t st);
+int afm_attn_bwd_mfma_try_f16(const afm_attn_shape* s, const void* Q, const void* K, const void* V,
+                              const void* O, const void* dO, const float* lse, float* delta, void* dQ,
+                              void* dK, void* dV, int lddq, int lddk, int lddv, hipStream_t st);
 
 extern "C" int afm_attn_fwd(const afm_attn_shape* s, const void* Q, const void* K, const void* V,
                             void* O, float* lse, void* stream) {
@@ -256,7 +262,8 @@ extern "C" int afm_attn_fwd(const afm_attn_shape* s, const void* Q, const void* 
   if (!Q || !K || !V || !O || !lse) return AFM_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
   if (s->algo != AFM_ALGO_GENERIC) {
-    r = s->dtype == AFM_BF16X2 ? afm_attn_fwd_x3_try(s, Q, K, V, O, lse, st) : afm_attn_fwd_mfma_try(s, Q, K, V, O, lse, st);
+    r = s->dtype == AFM_BF16X2 ? afm_attn_fwd_x3_try(s, Q, K, V, O, lse, st)
+        : s->dtype == AFM_F16 ? afm_attn_fwd_mfma_try_f16(s, Q, K, V, O, lse, st) : afm_attn_fwd_mfma_try(s, Q, K, V, O, lse, st);
     if (r != AFM_ERR_UNSUPPORTED) return r;
     if (s->algo == AFM_ALGO_MFMA) return r;
   }
@@ -291,7 +298,8 @@ extern "C" int afm_attn_bwd(const afm_attn_shape* s, const void* Q, const void* 
   hipStream_t st = (hipStream_t)stream;
   if (s->algo != AFM_ALGO_GENERIC) {
     r = s->dtype == AFM_BF16X2 ? afm_attn_bwd_x3_try(s, Q, K, V, O, dO, lse, delta, dQ, dK, dV, lddq, lddk, lddv, st)
-                               : afm_attn_bwd_mfma_try(s, Q, K, V, O, dO, lse, delta, dQ, dK, dV, lddq, lddk, lddv, st);
+        : s->dtype == AFM_F16 ? afm_attn_bwd_mfma_try_f16(s, Q, K, V, O, dO, lse, delta, dQ, dK, dV, lddq, lddk, lddv, st)
+                              : afm_attn_bwd_mfma_try(s, Q, K, V, O, dO, lse, delta, dQ, dK, dV, lddq, lddk, lddv, st);
     if (r != AFM_ERR_UNSUPPORTED) return r;
     if (s->algo == AFM_ALGO_MFMA) return r;
   }
@@ -310,7 +318,7 @@ extern "C" int afm_attn_bwd(const afm_attn_shape* s, const void* Q, const void* 
     AFM_LAUNCH(k_attn_bwd_kv_generic<T>, gk, dim3(256), shm_k, st, a, (const T*)Q, (const T*)K, \
                        (const T*)V, (const T*)dO, lse, delta, (T*)dK, (T*)dV, lddk, lddv);             \
   } while (0)
-  if (s->dtype == AFM_F32) LAUNCH_BWD(float); else if (s->dtype == AFM_BF16) LAUNCH_BWD(bf16); else LAUNCH_BWD(x2);
+  if (s->dtype == AFM_F32) LAUNCH_BWD(float); else if (s->dtype == AFM_BF16) LAUNCH_BWD(bf16); else if (s->dtype == AFM_F16) LAUNCH_BWD(f16); else LAUNCH_BWD(x2);
 #undef LAUNCH_BWD
   afm_set_last_algo("attn_generic");
   return AFM_OK;

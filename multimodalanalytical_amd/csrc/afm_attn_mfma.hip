@@ -1,572 +1,2 @@
-// bf16 MFMA flash attention for gfx950, head size 64 (d_model 512/8 and 768/12 of the reference's
-// model yamls), forward and backward, with key-padding / causal masks and attention-probability
-// dropout fused; scores never leave the chip.
-//
-// All products use v_mfma_f32_32x32x16_bf16 in the "swapped" orientation: the score tile is
-// computed TRANSPOSED (S^T = K Q^T), so the softmax axis (keys) runs over a lane's registers and
-// the query sits on the lane.  The row maximum / sum are then register loops plus one exchange
-// with lane^32, the probability tile (an accumulator) is directly the B operand of the next MFMA
-// (O^T = V^T P^T: cdna_hip_programming.md section 3, "an accumulator tile as the next MFMA's
-// operand"), and the per-query rescale of O^T is a per-lane multiply.  V^T fragments come from the
-// row-major V tile in LDS through ds_read_b64_tr_b16.
-//
-// forward:   workgroup = 4 waves x 32 queries = 128 queries of one (batch, head); 64-key tiles.
-// backward:  two kernels, no atomics, deterministic:
-//   dQ   : same geometry as forward; per tile S^T, dP^T = V dO^T, dS^T, dQ^T += K^T dS^T.
-//   dK/dV: workgroup = 4 waves x 32 keys; 64-query tiles; S = Q K^T with the KEY on the lane,
-//          dV^T += dO^T P, dK^T += Q^T dS.
-#include "afm_attn_tiles.h"
-
-// ------------------------------------------------------------------------------------------ forward
-template <int DROP>
-__global__ __launch_bounds__(256, 3) void k_attn_fwd_mfma(AttnM a, const bf16* __restrict__ Q,
-                                                          const bf16* __restrict__ K,
-                                                          const bf16* __restrict__ V, bf16* __restrict__ O,
-                                                          float* __restrict__ lse) {
-  constexpr int STAGE = 2 * KT * DH * 2;   // K row image + V tr image
-  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-  unsigned long long* maskw = (unsigned long long*)(lds + RS * STAGE);
-  const int t = threadIdx.x, lane = t & 63, h = lane >> 5;
-  const int w = __builtin_amdgcn_readfirstlane(t >> 6);
-  const AttnBlock blk_ = attn_block(a.H, a.B, (a.Tq + 127) / 128);
-  const int hd = blk_.hd, b = blk_.b;
-  const int q0 = blk_.xb * 128 + w * 32;          // this wave's first query
-  const int q = q0 + (lane & 31);
-  const int qc = q < a.Tq ? q : a.Tq - 1;
-  const bf16* Kb = K + (int64_t)b * a.Tk * a.ldk + hd * DH;
-  const bf16* Vb = V + (int64_t)b * a.Tk * a.ldv + hd * DH;
-  int kend = a.Tk;
-  if (a.causal) kend = min(a.Tk, blk_.xb * 128 + 128);  // keys beyond the block's last query are masked
-  const int ntiles = (kend + KT - 1) / KT;
-  // Q fragments (B operand of S^T = K Q^T): Q[q][16 s + 8 h ..]
-  bf16x8 qf[4];
-  {
-    const bf16* qp = Q + ((int64_t)b * a.Tq + qc) * a.ldq + hd * DH + 8 * h;
-#pragma unroll
-    for (int s = 0; s < 4; ++s) qf[s] = *(const bf16x8*)(qp + 16 * s);
-  }
-  build_mask_words(maskw, a.key_pad, b, a.Tk, ntiles, w, lane);
-  __syncthreads();   // plain loads above are retired here (vmcnt(0)), before any LDS-DMA is in flight
-  auto issue = [&](int kt) {
-    unsigned char* st = lds + (kt % RS) * STAGE;
-    dma_piece<false>(st, Kb, a.ldk, kt * KT, a.Tk, w, lane);
-    dma_piece<false>(st, Kb, a.ldk, kt * KT, a.Tk, w + 4, lane);
-    dma_piece<true>(st + KT * DH * 2, Vb, a.ldv, kt * KT, a.Tk, w, lane);
-    dma_piece<true>(st + KT * DH * 2, Vb, a.ldv, kt * KT, a.Tk, w + 4, lane);
-  };
-  f32x16 o[2];
-#pragma unroll
-  for (int i = 0; i < 16; ++i) { o[0][i] = 0.f; o[1][i] = 0.f; }
-  float m = -INFINITY, l = 0.f;
-  const uint32_t rowbase = (uint32_t)(((uint64_t)(b * a.H + hd) * a.Tq + qc) * (uint64_t)a.Tk);
-#pragma unroll
-  for (int s = 0; s < RS - 1; ++s)
-    if (s < ntiles) issue(s);
-  // ntiles >= 1 always (Tk >= 1): without the guard the loop's exit block has one predecessor and the
-  // accumulators need no phi copies at the latch (they cost 32-64 v_mov per tile)
-  __builtin_assume(ntiles >= 1);
-  for (int kt = 0; kt < ntiles; ++kt) {
-    const int kb = kt * KT;
-    if (ntiles - 1 - kt >= RS - 2) attn_wait_vmcnt<4 * (RS - 2)>(); else attn_wait_vmcnt<0>();
-    __builtin_amdgcn_s_barrier();
-    if (kt + RS - 1 < ntiles) issue(kt + RS - 1);
-    // wave-uniform skips: tile entirely above this wave's diagonal / every key of the tile is padding
-    if ((a.causal && kb > q0 + 31) || maskw[kt] == ~0ull) continue;
-    const unsigned char* Kimg = lds + (kt % RS) * STAGE;
-    const unsigned char* Vimg = Kimg + KT * DH * 2;
-    const unsigned long long mword = maskw[kt];
-    const unsigned long long pad = mword >> (4 * h);
-    f32x16 s[2];
-#pragma unroll
-    for (int blk = 0; blk < 2; ++blk) {
-#pragma unroll
-      for (int i = 0; i < 16; ++i) s[blk][i] = 0.f;
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) s[blk] = mfma32(frag_row(Kimg, 32 * blk, ks, lane), qf[ks], s[blk]);
-    }
-    // masks only where the tile has any (wave-uniform test): most tiles of a padded batch have none
-    const bool diag = a.causal && (kb + KT - 1 > q0);
-    if (mword != 0ull || diag) {
-#pragma unroll
-      for (int blk = 0; blk < 2; ++blk)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int ko = 32 * blk + ACC_ROW(r);
-          bool msk = (pad >> ko) & 1ull;
-          if (a.causal) msk = msk || (kb + ko + 4 * h > q);
-          s[blk][r] = msk ? -INFINITY : s[blk][r];
-        }
-    }
-    // row maximum with v_max3_f32 from inline asm: fmaxf() makes hipcc canonicalise every MFMA output
-    // first (one extra `v_max_f32 x, x, x` per score); the scores are finite or -inf, never NaN
-    float mt = fmaxf(s[0][0], s[1][0]);
-#pragma unroll
-    for (int r = 1; r < 16; ++r) mt = max3_raw(mt, s[0][r], s[1][r]);
-    mt = fmaxf(mt, __shfl_xor(mt, 32, 64)) * a.scale_log2;     // scale > 0: max commutes with it
-    const float mn = fmaxf(m, mt);
-    const float ms = mn == -INFINITY ? 0.f : mn;
-    const float alpha = fast_exp2(m - ms);
-    const bool grew = mn > m;
-    m = mn;
-    float ls = 0.f;
-#pragma unroll
-    for (int blk = 0; blk < 2; ++blk)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float p = fast_exp2(fmaf(s[blk][r], a.scale_log2, -ms));   // exp2(-inf) = 0 for masked keys
-        s[blk][r] = p;
-        ls += p;
-      }
-    l = l * alpha + ls;
-    // rescale O^T unconditionally: 16 packed multiplies; skipping them when no maximum moved made the
-    // register allocator copy all 32 accumulators at the branch join (32 v_mov per tile)
-    (void)grew;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) { o[0][i] *= alpha; o[1][i] *= alpha; }
-    if (DROP == DROP_HASH) {   // compile-time: a run-time branch costs 32 register copies at its join
-      drop_block(a.dd, rowbase, kb, h, s[0]);
-      drop_block(a.dd, rowbase, kb + 32, h, s[1]);
-    }
-    if (DROP == DROP_BITS) {   // the same dropout, and the keep bits of both 32-key blocks go to the keep-bit tensor
-      unsigned long long* bb = bits_block(a, b * a.H + hd, q0 >> 5, kb >> 5);
-      drop_block_emit(a.dd, rowbase, kb, h, s[0], bb);
-      drop_block_emit(a.dd, rowbase, kb + 32, h, s[1], bb + 16);
-    }
-    // O^T += V^T P^T over the four 16-key slices, the V^T reads one slice ahead of the MFMAs
-    unsigned va0, va1;
-    tr_lane_addr(Vimg, lane, va0, va1);
-    TrQuad vq[2];
-    vq[0] = tr_issue(va0, va1, 0);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {   // slice i = 2 blk + ks
-      if (i < 3) vq[(i + 1) & 1] = tr_issue(va0, va1, 16 * (i + 1));
-      const bf16x8 pf = cvt8(s[i >> 1], i & 1);
-      if (i < 3) tr_wait<4>(); else tr_wait<0>();
-      o[0] = mfma32(tr_join(vq[i & 1].lo0, vq[i & 1].hi0), pf, o[0]);
-      o[1] = mfma32(tr_join(vq[i & 1].lo1, vq[i & 1].hi1), pf, o[1]);
-    }
-  }
-  if (DROP == DROP_BITS) bits_flush();
-  l += __shfl_xor(l, 32, 64);
-  const float inv = l > 0.f ? a.dd.scale16 / l : 0.f;
-  if (q < a.Tq) {
-    bf16* op = O + ((int64_t)b * a.Tq + q) * a.ldo + hd * DH + 4 * h;
-#pragma unroll
-    for (int db = 0; db < 2; ++db)
-#pragma unroll
-      for (int g4 = 0; g4 < 4; ++g4) {
-        bf16x4 v = {(bf16)(o[db][4 * g4 + 0] * inv), (bf16)(o[db][4 * g4 + 1] * inv),
-                    (bf16)(o[db][4 * g4 + 2] * inv), (bf16)(o[db][4 * g4 + 3] * inv)};
-        *(bf16x4*)(op + 32 * db + 8 * g4) = v;
-      }
-    if (h == 0) lse[((int64_t)b * a.H + hd) * a.Tq + q] = l > 0.f ? (m + __log2f(l)) * 0.69314718055994531f : INFINITY;
-  }
-}
-
-// ------------------------------------------------------------------------------------------ dQ
-// Per 64-key tile: S^T and dP^T (keys in registers, query on the lane), then
-// dQ^T[d][q] += sum_key K^T[d][key] dS^T[key][q].  Also writes delta = rowsum(dO * O).
-template <int DROP>
-__global__ __launch_bounds__(256, 2) void k_attn_bwd_dq_mfma(AttnM a, const bf16* __restrict__ Q,
-                                                          const bf16* __restrict__ K,
-                                                          const bf16* __restrict__ V,
-                                                          const bf16* __restrict__ O,
-                                                          const bf16* __restrict__ dO,
-                                                          const float* __restrict__ lse,
-                                                          float* __restrict__ delta, bf16* __restrict__ dQ) {
-  constexpr int STAGE = 3 * KT * DH * 2;   // K row image, K tr image, V row image
-  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-  unsigned long long* maskw = (unsigned long long*)(lds + RS * STAGE);
-  const int t = threadIdx.x, lane = t & 63, h = lane >> 5;
-  const int w = __builtin_amdgcn_readfirstlane(t >> 6);
-  const AttnBlock blk_ = attn_block(a.H, a.B, (a.Tq + 127) / 128);
-  const int hd = blk_.hd, b = blk_.b;
-  const int q0 = blk_.xb * 128 + w * 32;
-  const int q = q0 + (lane & 31);
-  const int qc = q < a.Tq ? q : a.Tq - 1;
-  const bf16* Kb = K + (int64_t)b * a.Tk * a.ldk + hd * DH;
-  const bf16* Vb = V + (int64_t)b * a.Tk * a.ldv + hd * DH;
-  bf16x8 qf[4], dof[4];
-  float dl = 0.f;
-  {
-    const bf16* qp = Q + ((int64_t)b * a.Tq + qc) * a.ldq + hd * DH + 8 * h;
-    const bf16* dop = dO + ((int64_t)b * a.Tq + qc) * a.ldo + hd * DH + 8 * h;
-    const bf16* op = O + ((int64_t)b * a.Tq + qc) * a.ldo + hd * DH + 8 * h;
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      qf[s] = *(const bf16x8*)(qp + 16 * s);
-      dof[s] = *(const bf16x8*)(dop + 16 * s);
-      const bf16x8 ov = *(const bf16x8*)(op + 16 * s);
-#pragma unroll
-      for (int j = 0; j < 8; ++j) dl += (float)dof[s][j] * (float)ov[j];
-    }
-  }
-  dl += __shfl_xor(dl, 32, 64);
-  const int64_t lrow = ((int64_t)b * a.H + hd) * a.Tq + qc;
-  if (q < a.Tq && h == 0) delta[lrow] = dl;
-  const float L = lse[lrow];
-  const float L2 = L == INFINITY ? INFINITY : L * 1.4426950408889634f;  // log2 units
-  f32x16 dq[2];
-#pragma unroll
-  for (int i = 0; i < 16; ++i) { dq[0][i] = 0.f; dq[1][i] = 0.f; }
-  const uint32_t rowbase = (uint32_t)((uint64_t)lrow * (uint64_t)a.Tk);
-
-  int kend = a.Tk;
-  if (a.causal) kend = min(a.Tk, blk_.xb * 128 + 128);
-  const int ntiles = (kend + KT - 1) / KT;
-  build_mask_words(maskw, a.key_pad, b, a.Tk, ntiles, w, lane);
-  __syncthreads();   // retires the plain loads / the delta store before the LDS-DMA ring starts
-  auto issue = [&](int kt) {
-    unsigned char* st = lds + (kt % RS) * STAGE;
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      dma_piece<false>(st, Kb, a.ldk, kt * KT, a.Tk, w + 4 * u, lane);
-      dma_piece<true>(st + KT * DH * 2, Kb, a.ldk, kt * KT, a.Tk, w + 4 * u, lane);
-      dma_piece<false>(st + 2 * KT * DH * 2, Vb, a.ldv, kt * KT, a.Tk, w + 4 * u, lane);
-    }
-  };
-#pragma unroll
-  for (int s = 0; s < RS - 1; ++s)
-    if (s < ntiles) issue(s);
-  // ntiles >= 1 always (Tk >= 1): without the guard the loop's exit block has one predecessor and the
-  // accumulators need no phi copies at the latch (they cost 32-64 v_mov per tile)
-  __builtin_assume(ntiles >= 1);
-  for (int kt = 0; kt < ntiles; ++kt) {
-    const int kb = kt * KT;
-    if (ntiles - 1 - kt >= RS - 2) attn_wait_vmcnt<6 * (RS - 2)>(); else attn_wait_vmcnt<0>();
-    __builtin_amdgcn_s_barrier();
-    if (kt + RS - 1 < ntiles) issue(kt + RS - 1);
-    if ((a.causal && kb > q0 + 31) || maskw[kt] == ~0ull) continue;   // above the diagonal / all-padding key tile
-    const unsigned char* Krow = lds + (kt % RS) * STAGE;
-    const unsigned char* Ktr = Krow + KT * DH * 2;
-    const unsigned char* Vrow = Krow + 2 * KT * DH * 2;
-    const unsigned long long mword = maskw[kt];
-    const unsigned long long pad = mword >> (4 * h);
-    unsigned ka0, ka1;
-    tr_lane_addr(Ktr, lane, ka0, ka1);
-    KeepMasks km[2];
-    if (DROP == DROP_BITS) {   // both 32-key blocks of the tile now; used after the S / dP products
-      const unsigned long long* kbp = bits_block(a, b * a.H + hd, q0 >> 5, 2 * kt);
-      keep_masks_issue(km[0], kbp);
-      keep_masks_issue(km[1], kbp + 16);
-    }
-#pragma unroll
-    for (int blk = 0; blk < 2; ++blk) {
-      f32x16 s, dp;
-#pragma unroll
-      for (int i = 0; i < 16; ++i) { s[i] = 0.f; dp[i] = 0.f; }
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        s = mfma32(frag_row(Krow, 32 * blk, ks, lane), qf[ks], s);
-        dp = mfma32(frag_row(Vrow, 32 * blk, ks, lane), dof[ks], dp);
-      }
-      if (DROP == DROP_HASH) {
-        drop_block(a.dd, rowbase, kb + 32 * blk, h, dp);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) dp[r] *= a.dd.scale16;
-      }
-      if (DROP == DROP_BITS) drop_apply_masks(dp, km[blk], a.dd.scale16);
-      if (mword != 0ull || (a.causal && (kb + KT - 1 > q0))) {   // wave-uniform: tile has masked keys
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int ko = 32 * blk + ACC_ROW(r);
-          bool msk = (pad >> ko) & 1ull;
-          if (a.causal) msk = msk || (kb + ko + 4 * h > q);
-          s[r] = msk ? -INFINITY : s[r];
-        }
-      }
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float p = fast_exp2(fmaf(s[r], a.scale_log2, -L2));   // masked: exp2(-inf) = 0
-        s[r] = p * (dp[r] - dl);   // dS^T (the 1/sqrt(dh) factor is applied once at the end)
-      }
-      {
-        const TrQuad k0q = tr_issue(ka0, ka1, 32 * blk), k1q = tr_issue(ka0, ka1, 32 * blk + 16);
-        const bf16x8 ds0 = cvt8(s, 0), ds1 = cvt8(s, 1);
-        tr_wait<4>();
-        dq[0] = mfma32(tr_join(k0q.lo0, k0q.hi0), ds0, dq[0]);
-        dq[1] = mfma32(tr_join(k0q.lo1, k0q.hi1), ds0, dq[1]);
-        tr_wait<0>();
-        dq[0] = mfma32(tr_join(k1q.lo0, k1q.hi0), ds1, dq[0]);
-        dq[1] = mfma32(tr_join(k1q.lo1, k1q.hi1), ds1, dq[1]);
-      }
-    }
-  }
-  if (q < a.Tq) {
-    bf16* dqp = dQ + ((int64_t)b * a.Tq + q) * a.lddq + hd * DH + 4 * h;
-#pragma unroll
-    for (int db = 0; db < 2; ++db)
-#pragma unroll
-      for (int g4 = 0; g4 < 4; ++g4) {
-        bf16x4 v = {(bf16)(dq[db][4 * g4 + 0] * a.scale), (bf16)(dq[db][4 * g4 + 1] * a.scale),
-                    (bf16)(dq[db][4 * g4 + 2] * a.scale), (bf16)(dq[db][4 * g4 + 3] * a.scale)};
-        *(bf16x4*)(dqp + 32 * db + 8 * g4) = v;
-      }
-  }
-}
-
-// ------------------------------------------------------------------------------------------ dK, dV
-// Workgroup = 4 waves x 32 keys; loops over 64-query tiles.  S = Q K^T with the key on the lane
-// (queries in registers), P = exp2(S - lse[q]), dP = dO V^T, dS = P (D dP - delta[q]);
-// dV^T[d][key] += sum_q dO^T[d][q] (D P)[q][key],  dK^T[d][key] += sum_q Q^T[d][q] dS[q][key].
-template <int DROP>
-__global__ __launch_bounds__(256, 2) void k_attn_bwd_dkv_mfma(AttnM a, const bf16* __restrict__ Q,
-                                                           const bf16* __restrict__ K,
-                                                           const bf16* __restrict__ V,
-                                                           const bf16* __restrict__ dO,
-                                                           const float* __restrict__ lse,
-                                                           const float* __restrict__ delta,
-                                                           bf16* __restrict__ dK, bf16* __restrict__ dV) {
-  // stage: Q row image, Q tr image, dO row image, dO tr image, lse[64], delta[64]; 2-stage LDS-DMA ring
-  constexpr int STAGE = 4 * KT * DH * 2 + 2 * KT * 4 + 4 * 256;   // + two 128-byte keep-bit blocks (the tile's two 32-query blocks) per wave
-  constexpr int DS = 2;
-  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-  const int t = threadIdx.x, lane = t & 63, h = lane >> 5;
-  const int w = __builtin_amdgcn_readfirstlane(t >> 6);
-  const AttnBlock blk_ = attn_block(a.H, a.B, (a.Tk + 127) / 128);
-  const int hd = blk_.hd, b = blk_.b;
-  const int k0 = blk_.xb * 128 + w * 32;
-  const int key = k0 + (lane & 31);
-  const int kc = key < a.Tk ? key : a.Tk - 1;
-  const bool kmasked = key >= a.Tk || (a.key_pad && a.key_pad[(int64_t)b * a.Tk + kc]);
-  const bf16* Qb = Q + (int64_t)b * a.Tq * a.ldq + hd * DH;
-  const bf16* Db = dO + (int64_t)b * a.Tq * a.ldo + hd * DH;
-  bf16x8 kf[4], vf[4];
-  {
-    const bf16* kp = K + ((int64_t)b * a.Tk + kc) * a.ldk + hd * DH + 8 * h;
-    const bf16* vp = V + ((int64_t)b * a.Tk + kc) * a.ldv + hd * DH + 8 * h;
-#pragma unroll
-    for (int s = 0; s < 4; ++s) { kf[s] = *(const bf16x8*)(kp + 16 * s); vf[s] = *(const bf16x8*)(vp + 16 * s); }
-  }
-  f32x16 dk[2], dv[2];
-#pragma unroll
-  for (int i = 0; i < 16; ++i) { dk[0][i] = 0.f; dk[1][i] = 0.f; dv[0][i] = 0.f; dv[1][i] = 0.f; }
-  const bool wave_all_masked = __all(kmasked);
-
-  int qbeg = 0;
-  if (a.causal) qbeg = (blk_.xb * 128) / KT * KT;   // queries before the block's first key see none of it
-  const int ntiles = (a.Tq - qbeg + KT - 1) / KT;
-  const int64_t lbase = ((int64_t)b * a.H + hd) * a.Tq;
-  __syncthreads();   // K / V fragment loads retired before the LDS-DMA ring starts
-  auto issue = [&](int qt) {
-    unsigned char* st = lds + (qt % DS) * STAGE;
-    const int row0 = qbeg + qt * KT;
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      dma_piece<false>(st, Qb, a.ldq, row0, a.Tq, w + 4 * u, lane);
-      dma_piece<true>(st + KT * DH * 2, Qb, a.ldq, row0, a.Tq, w + 4 * u, lane);
-      dma_piece<false>(st + 2 * KT * DH * 2, Db, a.ldo, row0, a.Tq, w + 4 * u, lane);
-      dma_piece<true>(st + 3 * KT * DH * 2, Db, a.ldo, row0, a.Tq, w + 4 * u, lane);
-    }
-    if (w < 2) {   // lse / delta of the tile's 64 queries: one 4-byte piece each
-      int qq = row0 + lane;
-      qq = qq < a.Tq ? qq : a.Tq - 1;
-      const float* src = (w == 0 ? lse : delta) + lbase + qq;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                       (__attribute__((address_space(3))) void*)(st + 4 * KT * DH * 2 + w * KT * 4), 4, 0, 0);
-    }
-    if (DROP == DROP_BITS) {   // keep-bit blocks (query block of lanes 0-31 / 32-63, this wave's key block): 2 x 32 dwords
-      // (bits_block returns a wave-uniform pointer: the second query block of lanes 32-63 is a per-lane offset on top of it)
-      const uint32_t* src = (const uint32_t*)bits_block(a, b * a.H + hd, row0 >> 5, min(k0 >> 5, a.nk32 - 1)) + (lane >> 5) * (a.nk32 * 32) + (lane & 31);
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                       (__attribute__((address_space(3))) void*)(st + 4 * KT * DH * 2 + 2 * KT * 4 + w * 256), 4, 0, 0);
-    }
-  };
-  if (ntiles > 0) issue(0);
-  __builtin_assume(ntiles >= 1);   // see k_attn_fwd_mfma
-  for (int qt = 0; qt < ntiles; ++qt) {
-    const int qb = qbeg + qt * KT;
-    attn_wait_vmcnt<0>();          // this tile's pieces (the only ones in flight)
-    __builtin_amdgcn_s_barrier();
-    if (qt + 1 < ntiles) issue(qt + 1);
-    const unsigned char* Qrow = lds + (qt % DS) * STAGE;
-    const unsigned char* Qtr = Qrow + KT * DH * 2;
-    const unsigned char* Drow = Qrow + 2 * KT * DH * 2;
-    const unsigned char* Dtr = Qrow + 3 * KT * DH * 2;
-    const float* Ls = (const float*)(Qrow + 4 * KT * DH * 2);   // lse (natural log units)
-    const float* Ds = Ls + KT;
-    const bool ragged = qb + KT > a.Tq;   // wave-uniform: tile holds rows past Tq (clamped duplicates)
-    // wave-uniform skips: every query of the tile precedes this wave's keys / its 32 keys are all padding
-    if ((a.causal && qb + KT - 1 < k0) || wave_all_masked) continue;
-    unsigned qa0, qa1, da0, da1;
-    tr_lane_addr(Qtr, lane, qa0, qa1);
-    tr_lane_addr(Dtr, lane, da0, da1);
-#pragma unroll
-    for (int blk = 0; blk < 2; ++blk) {
-      f32x16 s, dp;
-#pragma unroll
-      for (int i = 0; i < 16; ++i) { s[i] = 0.f; dp[i] = 0.f; }
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        s = mfma32(frag_row(Qrow, 32 * blk, ks, lane), kf[ks], s);     // S[q][key]
-        dp = mfma32(frag_row(Drow, 32 * blk, ks, lane), vf[ks], dp);   // dP[q][key]
-      }
-      f32x16 pd;
-      // Uniform conditions select whole loops (a branch per score would sit inside the unrolled body).
-      if (a.causal || ragged) {   // rare: diagonal tiles of the decoder / the last, partly filled tile
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int qq = qb + 32 * blk + ACC_ROW(r) + 4 * h;
-          const bool msk = (a.causal && key > qq) || qq >= a.Tq;
-          s[r] = msk ? -INFINITY : s[r];
-        }
-      }
-#pragma unroll
-      for (int g4 = 0; g4 < 4; ++g4) {   // p = exp2(s*scale - lse[q]); masked keys: outputs zeroed at the end
-        const f32x4 Lq = *(const f32x4*)(Ls + 32 * blk + 8 * g4 + 4 * h) * 1.4426950408889634f;   // log2 units; +inf stays
-#pragma unroll
-        for (int j = 0; j < 4; ++j) pd[4 * g4 + j] = fast_exp2(fmaf(s[4 * g4 + j], a.scale_log2, -Lq[j]));
-      }
-      if (DROP == DROP_BITS) {   // one dword per lane and 32-query block: bit q = keep(query q, this lane's key)
-        const uint32_t word = ((const uint32_t*)(Qrow + 4 * KT * DH * 2 + 2 * KT * 4 + w * 256))[32 * blk + bits_word_of_key(lane & 31)] >> (4 * h);
-        const int sbits = __builtin_bit_cast(int, a.dd.scale16);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const float kp = __builtin_bit_cast(float, __builtin_amdgcn_sbfe((int)word, ACC_ROW(r), 1) & sbits);   // scale or 0
-          dp[r] *= kp;
-          s[r] = pd[r];
-          pd[r] *= kp;
-        }
-      } else if (DROP == DROP_HASH) {
-        // Dropout keep bits.  Element (q, key) has index i = (lbase+q)*Tk + key; with Tk even the two
-        // lanes of a key pair (lane, lane^1) share the hash of i>>1 = (lbase+q)*(Tk/2) + key/2 and take
-        // its low / high 16 bits.  The even lane hashes the even register rows, the odd lane the odd
-        // rows, and a quad-permute DPP move hands each lane its partner's hash.
-        const uint32_t htk = (uint32_t)a.Tk >> 1;
-        const uint32_t tb = (uint32_t)(lbase + qb + 32 * blk + 4 * h + (lane & 1)) * htk + ((uint32_t)key >> 1);
-        const uint32_t hshift = (lane & 1) << 4;
-#pragma unroll
-        for (int r = 0; r < 16; r += 2) {
-          const uint32_t own = hash_pair32(a.dd, tb + (uint32_t)ACC_ROW(r) * htk);   // row r + (lane&1)
-          const uint32_t oth = (uint32_t)__builtin_amdgcn_mov_dpp((int)own, 0xB1, 0xF, 0xF, true);  // lane^1
-          const uint32_t h0 = (lane & 1) ? oth : own, h1 = (lane & 1) ? own : oth;
-          const float k0 = ((h0 >> hshift) & 0xFFFFu) >= a.dd.thresh16 ? a.dd.scale16 : 0.f;
-          const float k1 = ((h1 >> hshift) & 0xFFFFu) >= a.dd.thresh16 ? a.dd.scale16 : 0.f;
-          dp[r] *= k0; dp[r + 1] *= k1;
-          s[r] = pd[r]; s[r + 1] = pd[r + 1];            // undropped p for dS
-          pd[r] *= k0; pd[r + 1] *= k1;                  // dropped p for dV
-        }
-      } else {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) s[r] = pd[r];
-      }
-#pragma unroll
-      for (int g4 = 0; g4 < 4; ++g4) {   // dS = p (D dP - delta[q])
-        const f32x4 Dq = *(const f32x4*)(Ds + 32 * blk + 8 * g4 + 4 * h);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) s[4 * g4 + j] *= dp[4 * g4 + j] - Dq[j];
-      }
-      {
-        const TrQuad d0 = tr_issue(da0, da1, 32 * blk), q0f = tr_issue(qa0, qa1, 32 * blk);
-        const TrQuad d1 = tr_issue(da0, da1, 32 * blk + 16), q1f = tr_issue(qa0, qa1, 32 * blk + 16);
-        const bf16x8 pf0 = cvt8(pd, 0), dsf0 = cvt8(s, 0), pf1 = cvt8(pd, 1), dsf1 = cvt8(s, 1);
-        tr_wait<8>();
-        dv[0] = mfma32(tr_join(d0.lo0, d0.hi0), pf0, dv[0]);
-        dv[1] = mfma32(tr_join(d0.lo1, d0.hi1), pf0, dv[1]);
-        dk[0] = mfma32(tr_join(q0f.lo0, q0f.hi0), dsf0, dk[0]);
-        dk[1] = mfma32(tr_join(q0f.lo1, q0f.hi1), dsf0, dk[1]);
-        tr_wait<0>();
-        dv[0] = mfma32(tr_join(d1.lo0, d1.hi0), pf1, dv[0]);
-        dv[1] = mfma32(tr_join(d1.lo1, d1.hi1), pf1, dv[1]);
-        dk[0] = mfma32(tr_join(q1f.lo0, q1f.hi0), dsf1, dk[0]);
-        dk[1] = mfma32(tr_join(q1f.lo1, q1f.hi1), dsf1, dk[1]);
-      }
-    }
-  }
-  if (kmasked) {   // a padded key took no part in any softmax: its dK / dV rows are zero
-#pragma unroll
-    for (int i = 0; i < 16; ++i) { dk[0][i] = 0.f; dk[1][i] = 0.f; dv[0][i] = 0.f; dv[1][i] = 0.f; }
-  }
-  if (key < a.Tk) {
-    bf16* dkp = dK + ((int64_t)b * a.Tk + key) * a.lddk + hd * DH + 4 * h;
-    bf16* dvp = dV + ((int64_t)b * a.Tk + key) * a.lddv + hd * DH + 4 * h;
-#pragma unroll
-    for (int db = 0; db < 2; ++db)
-#pragma unroll
-      for (int g4 = 0; g4 < 4; ++g4) {
-        bf16x4 x = {(bf16)(dk[db][4 * g4 + 0] * a.scale), (bf16)(dk[db][4 * g4 + 1] * a.scale),
-                    (bf16)(dk[db][4 * g4 + 2] * a.scale), (bf16)(dk[db][4 * g4 + 3] * a.scale)};
-        bf16x4 y = {(bf16)dv[db][4 * g4 + 0], (bf16)dv[db][4 * g4 + 1], (bf16)dv[db][4 * g4 + 2], (bf16)dv[db][4 * g4 + 3]};
-        *(bf16x4*)(dkp + 32 * db + 8 * g4) = x;
-        *(bf16x4*)(dvp + 32 * db + 8 * g4) = y;
-      }
-  }
-}
-
-// ------------------------------------------------------------------------------------------ dispatch
-static bool eligible(const afm_attn_shape* s, const void* const* ptrs, int nptr, const int* lds, int nld) {
-  if (s->dtype != AFM_BF16 || s->dh != DH) return false;
-  if (s->sqb || s->skb || s->svb || s->sob) return false;   // KV-cache strides: generic kernel
-  if (s->causal && s->Tq != s->Tk) return false;            // the tile loops assume >= 1 tile per workgroup (self-attention)
-  if (s->drop.p > 0.f && (s->Tk & 1)) return false;   // the pair hash needs even rows of the mask
-  if (s->drop.p > 0.f && (uint64_t)s->B * s->H * s->Tq * (uint64_t)s->Tk > 0xFFFFFFFFull) return false;  // 32-bit mask index
-  for (int i = 0; i < nptr; ++i) if ((uintptr_t)ptrs[i] & 15) return false;
-  for (int i = 0; i < nld; ++i) if (lds[i] & 7) return false;
-  return true;
-}
-static AttnM make_m(const afm_attn_shape* s) {
-  AttnM a;
-  a.B = s->B; a.H = s->H; a.Tq = s->Tq; a.Tk = s->Tk;
-  a.ldq = s->ldq; a.ldk = s->ldk; a.ldv = s->ldv; a.ldo = s->ldo;
-  a.lddq = a.lddk = a.lddv = 0;
-  a.causal = s->causal; a.scale = s->scale; a.scale_log2 = s->scale * 1.4426950408889634f;
-  a.key_pad = s->key_pad; a.dd = afm_make_drop(&s->drop);
-  a.bits = a.dd.thresh16 ? (unsigned long long*)s->drop_bits : nullptr;
-  a.nq32 = ((s->Tq + 127) / 128) * 4; a.nk32 = ((s->Tk + 63) / 64) * 2;      // whole workgroups / whole 64-key tiles
-  return a;
-}
-
-int afm_attn_fwd_mfma_try(const afm_attn_shape* s, const void* Q, const void* K, const void* V, void* O,
-                          float* lse, hipStream_t st) {
-  const void* ptrs[] = {Q, K, V, O};
-  const int lds[] = {s->ldq, s->ldk, s->ldv, s->ldo};
-  if (!eligible(s, ptrs, 4, lds, 4)) return AFM_ERR_UNSUPPORTED;
-  const AttnM a = make_m(s);
-  const dim3 grid(((s->Tq + 127) / 128) * s->H * s->B);
-  const int shm = RS * 2 * KT * DH * 2 + ((s->Tk + KT - 1) / KT) * 8;
-  if (shm > 64 * 1024) return AFM_ERR_UNSUPPORTED;
-  if (a.dd.thresh16 && a.bits) AFM_LAUNCH(k_attn_fwd_mfma<DROP_BITS>, grid, dim3(256), shm, st, a, (const bf16*)Q, (const bf16*)K, (const bf16*)V, (bf16*)O, lse);
-  else if (a.dd.thresh16) AFM_LAUNCH(k_attn_fwd_mfma<DROP_HASH>, grid, dim3(256), shm, st, a, (const bf16*)Q, (const bf16*)K, (const bf16*)V, (bf16*)O, lse);
-  else AFM_LAUNCH(k_attn_fwd_mfma<DROP_NONE>, grid, dim3(256), shm, st, a, (const bf16*)Q, (const bf16*)K, (const bf16*)V, (bf16*)O, lse);
-  afm_set_last_algo("attn_mfma");
-  return AFM_OK;
-}
-
-int afm_attn_bwd_mfma_try(const afm_attn_shape* s, const void* Q, const void* K, const void* V, const void* O,
-                          const void* dO, const float* lse, float* delta, void* dQ, void* dK, void* dV,
-                          int lddq, int lddk, int lddv, hipStream_t st) {
-  const void* ptrs[] = {Q, K, V, O, dO, dQ, dK, dV};
-  const int lds[] = {s->ldq, s->ldk, s->ldv, s->ldo, lddq, lddk, lddv};
-  if (!eligible(s, ptrs, 8, lds, 7)) return AFM_ERR_UNSUPPORTED;
-  AttnM a = make_m(s);
-  a.lddq = lddq; a.lddk = lddk; a.lddv = lddv;
-  const dim3 gq(((s->Tq + 127) / 128) * s->H * s->B), gk(((s->Tk + 127) / 128) * s->H * s->B);
-  const int shm_q = RS * 3 * KT * DH * 2 + ((s->Tk + KT - 1) / KT) * 8;
-  if (shm_q > 80 * 1024) return AFM_ERR_UNSUPPORTED;
-  static bool attr_q = false;
-  if (!attr_q) {
-    (void)hipFuncSetAttribute((const void*)k_attn_bwd_dq_mfma<DROP_HASH>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-    (void)hipFuncSetAttribute((const void*)k_attn_bwd_dq_mfma<DROP_BITS>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-    (void)hipFuncSetAttribute((const void*)k_attn_bwd_dq_mfma<DROP_NONE>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-    attr_q = true;
-  }
-  const bool run_q = s->reserved != 2, run_k = s->reserved != 1;   // reserved = 1 / 2: only the dQ / only the dK-dV kernel (timing)
-  if (!run_q) {}
-  else if (a.dd.thresh16 && a.bits) AFM_LAUNCH(k_attn_bwd_dq_mfma<DROP_BITS>, gq, dim3(256), shm_q, st, a, (const bf16*)Q, (const bf16*)K, (const bf16*)V, (const bf16*)O, (const bf16*)dO, lse, delta, (bf16*)dQ);
-  else if (a.dd.thresh16) AFM_LAUNCH(k_attn_bwd_dq_mfma<DROP_HASH>, gq, dim3(256), shm_q, st, a, (const bf16*)Q, (const bf16*)K, (const bf16*)V, (const bf16*)O, (const bf16*)dO, lse, delta, (bf16*)dQ);
-  else AFM_LAUNCH(k_attn_bwd_dq_mfma<DROP_NONE>, gq, dim3(256), shm_q, st, a, (const bf16*)Q, (const bf16*)K, (const bf16*)V, (const bf16*)O, (const bf16*)dO, lse, delta, (bf16*)dQ);
-  const int shm_k = 2 * (4 * KT * DH * 2 + 2 * KT * 4 + 4 * 256);
-  static bool attr_k = false;
-  if (!attr_k) {
-    (void)hipFuncSetAttribute((const void*)k_attn_bwd_dkv_mfma<DROP_HASH>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-    (void)hipFuncSetAttribute((const void*)k_attn_bwd_dkv_mfma<DROP_BITS>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-    (void)hipFuncSetAttribute((const void*)k_attn_bwd_dkv_mfma<DROP_NONE>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-    attr_k = true;
-  }
-  if (!run_k) {}
-  else if (a.dd.thresh16 && a.bits) AFM_LAUNCH(k_attn_bwd_dkv_mfma<DROP_BITS>, gk, dim3(256), shm_k, st, a, (const bf16*)Q, (const bf16*)K, (const bf16*)V, (const bf16*)dO, lse, delta, (bf16*)dK, (bf16*)dV);
-  else if (a.dd.thresh16) AFM_LAUNCH(k_attn_bwd_dkv_mfma<DROP_HASH>, gk, dim3(256), shm_k, st, a, (const bf16*)Q, (const bf16*)K, (const bf16*)V, (const bf16*)dO, lse, delta, (bf16*)dK, (bf16*)dV);
-  else AFM_LAUNCH(k_attn_bwd_dkv_mfma<DROP_NONE>, gk, dim3(256), shm_k, st, a, (const bf16*)Q, (const bf16*)K, (const bf16*)V, (const bf16*)dO, lse, delta, (bf16*)dK, (bf16*)dV);
-  afm_set_last_algo("attn_mfma");
-  return AFM_OK;
-}
+// bf16 instantiation of the single-pass MFMA attention kernels
+#include "afm_attn_mfma_impl.h"

@@ -1,5 +1,5 @@
 // LDS tile images, transposed-read helpers, the LDS-DMA piece and the dropout block of the MFMA flash-attention
-// kernels (afm_attn_mfma.hip: single bf16 pass; afm_attn_x3.hip: split-pair operands, three passes per product).
+// kernels (afm_attn_mfma.hip: single e16 pass; afm_attn_x3.hip: split-pair operands, three passes per product).
 #pragma once
 #include "afm_common.h"
 
@@ -21,8 +21,8 @@ struct AttnM {
 
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 
-__device__ __forceinline__ f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) {
-  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+__device__ __forceinline__ f32x16 mfma32(e16x8 a, e16x8 b, f32x16 c) {
+  return mfma32_raw(a, b, c);
 }
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 __device__ __forceinline__ float max3_raw(float a, float b, float c) {
@@ -31,7 +31,7 @@ __device__ __forceinline__ float max3_raw(float a, float b, float c) {
   return r;
 }
 
-// LDS images of a [64 rows][64 cols] bf16 tile (128-byte rows, 8 chunks of 16 bytes):
+// LDS images of a [64 rows][64 cols] e16 tile (128-byte rows, 8 chunks of 16 bytes):
 //   "row image": read by rows with ds_read_b128 (lane = row, 32 rows x one chunk per half-wave)
 //   "tr image" : read transposed with ds_read_b64_tr_b16 (4 rows x 16 columns per 16 lanes)
 __device__ __forceinline__ int img_row(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
@@ -75,22 +75,22 @@ template <int N> __device__ __forceinline__ void tr_wait() {
   asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
   __builtin_amdgcn_sched_barrier(0);
 }
-__device__ __forceinline__ bf16x8 tr_join(s16x4 lo, s16x4 hi) {
-  const bf16x4 l = __builtin_bit_cast(bf16x4, lo), h = __builtin_bit_cast(bf16x4, hi);
-  return (bf16x8){l[0], l[1], l[2], l[3], h[0], h[1], h[2], h[3]};
+__device__ __forceinline__ e16x8 tr_join(s16x4 lo, s16x4 hi) {
+  const e16x4 l = __builtin_bit_cast(e16x4, lo), h = __builtin_bit_cast(e16x4, hi);
+  return (e16x8){l[0], l[1], l[2], l[3], h[0], h[1], h[2], h[3]};
 }
 // A-operand fragment by rows: lane holds tile[R0 + (lane&31)][16*s + 8*(lane>>5) .. +7]
-__device__ __forceinline__ bf16x8 frag_row(const unsigned char* img, int R0, int s, int lane) {
-  return *(const bf16x8*)(img + img_row(R0 + (lane & 31), 2 * s + (lane >> 5)));
+__device__ __forceinline__ e16x8 frag_row(const unsigned char* img, int R0, int s, int lane) {
+  return *(const e16x8*)(img + img_row(R0 + (lane & 31), 2 * s + (lane >> 5)));
 }
-__device__ __forceinline__ bf16x8 cvt8(const f32x16& x, int s) {
-  return (bf16x8){(bf16)x[8 * s + 0], (bf16)x[8 * s + 1], (bf16)x[8 * s + 2], (bf16)x[8 * s + 3],
-                  (bf16)x[8 * s + 4], (bf16)x[8 * s + 5], (bf16)x[8 * s + 6], (bf16)x[8 * s + 7]};
+__device__ __forceinline__ e16x8 cvt8(const f32x16& x, int s) {
+  return (e16x8){(e16)x[8 * s + 0], (e16)x[8 * s + 1], (e16)x[8 * s + 2], (e16)x[8 * s + 3],
+                  (e16)x[8 * s + 4], (e16)x[8 * s + 5], (e16)x[8 * s + 6], (e16)x[8 * s + 7]};
 }
 
-// stage a [64][64] bf16 tile of a (rows x ld) matrix: thread t -> rows t>>3 and 32 + t>>3, chunk t&7
+// stage a [64][64] e16 tile of a (rows x ld) matrix: thread t -> rows t>>3 and 32 + t>>3, chunk t&7
 struct Stage2 { uint4 v[2]; };
-__device__ __forceinline__ Stage2 stage_load(const bf16* base, int ld, int row0, int nrows, int t) {
+__device__ __forceinline__ Stage2 stage_load(const e16* base, int ld, int row0, int nrows, int t) {
   Stage2 s;
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
@@ -135,7 +135,7 @@ template <int N> __device__ __forceinline__ void attn_wait_vmcnt() { asm volatil
 #define RS 3
 // one piece: rows [8*pi, 8*pi+8) of the 64-row tile starting at global row `row0` of `base`
 template <bool TR>
-__device__ __forceinline__ void dma_piece(unsigned char* img, const bf16* base, int ld, int row0, int nrows,
+__device__ __forceinline__ void dma_piece(unsigned char* img, const e16* base, int ld, int row0, int nrows,
                                           int pi, int lane) {
   const int r = 8 * pi + (lane >> 3), slot = lane & 7;
   const int chunk = TR ? (slot ^ (((r >> 1) & 1) << 2)) : (slot ^ ((r >> 1) & 7));
@@ -178,7 +178,7 @@ __device__ __forceinline__ AttnBlock attn_block(int H, int B, int nblk) {
 }
 
 // ------------------------------------------------------------------------------------------ dual-use image
-// ONE LDS image of a [rows][64] bf16 tile that serves both the row reads (ds_read_b128: the 32x32x16 row operand) and
+// ONE LDS image of a [rows][64] e16 tile that serves both the row reads (ds_read_b128: the 32x32x16 row operand) and
 // the transposed reads (ds_read_b64_tr_b16), conflict-free for both (tools/lds_swizzle_check.py): chunk c of row r sits
 // at chunk  c ^ f(r),  f(r) = ((r>>1)&1) << 2  |  ((r>>2)&3) ^ 3*((r>>4)&1).
 // Bit 2 separates rows r, r+2 of a transposed 4-row block into the two 64-byte halves; bits 1..0 spread the eight
@@ -186,7 +186,7 @@ __device__ __forceinline__ AttnBlock attn_block(int H, int B, int nblk) {
 // a transposed image of the same tile (K in the dQ kernel, Q and dO in the dK/dV kernel) stage it once: half the LDS
 // and half the LDS-DMA pieces.
 __device__ __forceinline__ int dual_f(int row) { return (((row >> 1) & 1) << 2) | (((row >> 2) & 3) ^ (3 * ((row >> 4) & 1))); }
-__device__ __forceinline__ void dma_piece_dual(unsigned char* img, const bf16* base, int ld, int row0, int nrows, int pi, int lane) {
+__device__ __forceinline__ void dma_piece_dual(unsigned char* img, const e16* base, int ld, int row0, int nrows, int pi, int lane) {
   const int r = 8 * pi + (lane >> 3), slot = lane & 7;
   const int chunk = slot ^ dual_f(r);
   int gr = row0 + r;
@@ -195,9 +195,9 @@ __device__ __forceinline__ void dma_piece_dual(unsigned char* img, const bf16* b
                                    (__attribute__((address_space(3))) void*)(img + pi * 1024), 16, 0, 0);
 }
 // row fragment k-slice s of rows R0 .. R0+31 (R0 a multiple of 32): f(R0 + r) = f(r)
-__device__ __forceinline__ bf16x8 frag_row_dual(const unsigned char* img, int R0, int s, int lane) {
+__device__ __forceinline__ e16x8 frag_row_dual(const unsigned char* img, int R0, int s, int lane) {
   const int r = lane & 31;
-  return *(const bf16x8*)(img + (R0 + r) * 128 + (((2 * s + (lane >> 5)) ^ dual_f(r)) << 4));
+  return *(const e16x8*)(img + (R0 + r) * 128 + (((2 * s + (lane >> 5)) ^ dual_f(r)) << 4));
 }
 // transposed reads: lane address of the 8-row block at row 0, 32-column half 0; the block at row R (multiple of 8), half
 // db is  R*128 + (T0 ^ (delta(R) << 4) ^ (db << 6))  with delta(R) = ((R>>2)&3) ^ 3*((R>>4)&1)  = 0, 2, 3, 1 for R = 0, 8, 16, 24

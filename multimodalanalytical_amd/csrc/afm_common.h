@@ -8,8 +8,43 @@ typedef __bf16 bf16;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef _Float16 f16;                                       // AFM_F16: IEEE half, conversions round to nearest even (v_cvt_pk_f16_f32)
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
+// The single-pass MFMA kernels (afm_gemm_mfma_impl.h, afm_attn_mfma_impl.h) are written once against `e16`, a 16-bit floating
+// element, and compiled twice: bf16 (v_mfma_*_bf16) and, with AFM_E16_F16 defined, fp16 (v_mfma_*_f16).  Same tiles, same LDS
+// images, same instruction counts: the two formats differ only in the MFMA opcode and the conversion instructions.
+#ifdef AFM_E16_F16
+typedef f16 e16;
+typedef f16x8 e16x8;
+typedef f16x4 e16x4;
+#define AFM_E16 AFM_F16
+#define AFM_E16_NS afm_f16
+#define AFM_E16_FN(name) name##_f16
+#define AFM_E16_NAME "f16"
+#else
+typedef bf16 e16;
+typedef bf16x8 e16x8;
+typedef bf16x4 e16x4;
+#define AFM_E16 AFM_BF16
+#define AFM_E16_NS afm_bf16
+#define AFM_E16_FN(name) name
+#define AFM_E16_NAME "bf16"
+#endif
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef f32x16 afm_f32x16_;
+typedef f32x4 afm_f32x4_;
+// (host pass: the builtins do not exist there, the bodies are never run)
+#if defined(__HIP_DEVICE_COMPILE__)
+#define AFM_MFMA_BODY(expr) return expr
+#else
+#define AFM_MFMA_BODY(expr) return c
+#endif
+__device__ __forceinline__ afm_f32x4_ mfma16(bf16x8 a, bf16x8 b, afm_f32x4_ c) { AFM_MFMA_BODY(__builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0)); }
+__device__ __forceinline__ afm_f32x4_ mfma16(f16x8 a, f16x8 b, afm_f32x4_ c) { AFM_MFMA_BODY(__builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0)); }
+__device__ __forceinline__ afm_f32x16_ mfma32_raw(bf16x8 a, bf16x8 b, afm_f32x16_ c) { AFM_MFMA_BODY(__builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0)); }
+__device__ __forceinline__ afm_f32x16_ mfma32_raw(f16x8 a, f16x8 b, afm_f32x16_ c) { AFM_MFMA_BODY(__builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0)); }
 
 #define AFM_WAVE 64
 
@@ -30,9 +65,11 @@ extern "C" void afm_set_last_algo(const char* name);
 template <typename T> __device__ __forceinline__ float ld_f32(const T* p, int64_t i);
 template <> __device__ __forceinline__ float ld_f32<float>(const float* p, int64_t i) { return p[i]; }
 template <> __device__ __forceinline__ float ld_f32<bf16>(const bf16* p, int64_t i) { return (float)p[i]; }
+template <> __device__ __forceinline__ float ld_f32<f16>(const f16* p, int64_t i) { return (float)p[i]; }
 template <typename T> __device__ __forceinline__ void st_f32(T* p, int64_t i, float v);
 template <> __device__ __forceinline__ void st_f32<float>(float* p, int64_t i, float v) { p[i] = v; }
 template <> __device__ __forceinline__ void st_f32<bf16>(bf16* p, int64_t i, float v) { p[i] = (bf16)v; }
+template <> __device__ __forceinline__ void st_f32<f16>(f16* p, int64_t i, float v) { p[i] = (f16)v; }
 
 // ---------------------------------------------------------------- split bf16 pairs (AFM_BF16X2)
 // value = hi + lo; hi(r, c) at base[r*ld + c], lo(r, c) at base[r*ld + ld/2 + c] (include/afm_hip.h).
@@ -45,6 +82,7 @@ template <> struct RowMul<x2> { static constexpr int v = 2; };   // a contiguous
 template <typename T> __device__ __forceinline__ float ld_rc(const T* p, int64_t r, int c, int ld);
 template <> __device__ __forceinline__ float ld_rc<float>(const float* p, int64_t r, int c, int ld) { return p[r * ld + c]; }
 template <> __device__ __forceinline__ float ld_rc<bf16>(const bf16* p, int64_t r, int c, int ld) { return (float)p[r * ld + c]; }
+template <> __device__ __forceinline__ float ld_rc<f16>(const f16* p, int64_t r, int c, int ld) { return (float)p[r * ld + c]; }
 template <> __device__ __forceinline__ float ld_rc<x2>(const x2* p, int64_t r, int c, int ld) {
   const bf16* q = (const bf16*)p + r * ld + c;
   return (float)q[0] + (float)q[ld >> 1];
@@ -52,6 +90,7 @@ template <> __device__ __forceinline__ float ld_rc<x2>(const x2* p, int64_t r, i
 template <typename T> __device__ __forceinline__ void st_rc(T* p, int64_t r, int c, int ld, float v);
 template <> __device__ __forceinline__ void st_rc<float>(float* p, int64_t r, int c, int ld, float v) { p[r * ld + c] = v; }
 template <> __device__ __forceinline__ void st_rc<bf16>(bf16* p, int64_t r, int c, int ld, float v) { p[r * ld + c] = (bf16)v; }
+template <> __device__ __forceinline__ void st_rc<f16>(f16* p, int64_t r, int c, int ld, float v) { p[r * ld + c] = (f16)v; }
 template <> __device__ __forceinline__ void st_rc<x2>(x2* p, int64_t r, int c, int ld, float v) {
   bf16* q = (bf16*)p + r * ld + c;
   bf16 hi, lo;
@@ -78,12 +117,13 @@ __device__ __forceinline__ void afm_split8(const float (&x)[8], bf16x8& hi, bf16
   for (int k = 0; k < 4; ++k) { uint32_t a, b; afm_split2(x[2 * k], x[2 * k + 1], a, b); h[k] = a; l[k] = b; }
   hi = __builtin_bit_cast(bf16x8, h); lo = __builtin_bit_cast(bf16x8, l);
 }
-// dtype dispatch of a templated launch: DT_SWITCH(code, T, stmt) runs stmt with T = float / bf16 / x2
+// dtype dispatch of a templated launch: DT_SWITCH(code, T, stmt) runs stmt with T = float / bf16 / x2 / f16
 #define AFM_DT_SWITCH(code, T, ...)                                        \
   do {                                                                     \
     if ((code) == AFM_F32) { typedef float T; __VA_ARGS__; }               \
     else if ((code) == AFM_BF16) { typedef bf16 T; __VA_ARGS__; }          \
     else if ((code) == AFM_BF16X2) { typedef x2 T; __VA_ARGS__; }          \
+    else if ((code) == AFM_F16) { typedef f16 T; __VA_ARGS__; }            \
     else return AFM_ERR_ARG;                                               \
   } while (0)
 

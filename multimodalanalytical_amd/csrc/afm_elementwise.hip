@@ -343,9 +343,11 @@ __device__ __forceinline__ int glu_interleave(int r, int f) {   // row r of [W1 
   const int j = r < f ? r : r - f;
   return ((j >> 2) << 3) + (j & 3) + (r < f ? 0 : 4);
 }
-template <bool X2T>
+// MODE 0: bf16, 1: split bf16 pair, 2: fp16 (one plane)
+template <int MODE>
 __global__ void k_cast_weights(const float* __restrict__ src, bf16* __restrict__ dst, bf16* __restrict__ dst_t, int rows,
                                int cols, int glu_f) {
+  constexpr bool X2T = MODE == 1;
   __shared__ float tile[64][65];
   const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
@@ -357,10 +359,13 @@ __global__ void k_cast_weights(const float* __restrict__ src, bf16* __restrict__
       v = src[(int64_t)r * cols + c];
       if (dst) {
         const int rd = glu_f ? glu_interleave(r, glu_f) : r;
-        bf16 hi, lo;
-        afm_split(v, hi, lo);
-        dst[(int64_t)rd * ldd + c] = hi;
-        if (X2T) dst[(int64_t)rd * ldd + cols + c] = lo;
+        if (MODE == 2) ((f16*)dst)[(int64_t)rd * ldd + c] = (f16)v;
+        else {
+          bf16 hi, lo;
+          afm_split(v, hi, lo);
+          dst[(int64_t)rd * ldd + c] = hi;
+          if (X2T) dst[(int64_t)rd * ldd + cols + c] = lo;
+        }
       }
     }
     tile[i][tx] = v;
@@ -371,10 +376,13 @@ __global__ void k_cast_weights(const float* __restrict__ src, bf16* __restrict__
     const int c = c0 + i, r = r0 + tx;
     if (r < rows && c < cols) {
       const int rd = glu_f ? glu_interleave(r, glu_f) : r;
-      bf16 hi, lo;
-      afm_split(tile[tx][i], hi, lo);
-      dst_t[(int64_t)c * ldt + rd] = hi;
-      if (X2T) dst_t[(int64_t)c * ldt + rows + rd] = lo;
+      if (MODE == 2) ((f16*)dst_t)[(int64_t)c * ldt + rd] = (f16)tile[tx][i];
+      else {
+        bf16 hi, lo;
+        afm_split(tile[tx][i], hi, lo);
+        dst_t[(int64_t)c * ldt + rd] = hi;
+        if (X2T) dst_t[(int64_t)c * ldt + rows + rd] = lo;
+      }
     }
   }
 }
@@ -383,8 +391,9 @@ extern "C" int afm_cast_weights(const float* src, void* dst, void* dst_t, int32_
   if (!src || (!dst && !dst_t) || rows <= 0 || cols <= 0 || glu_rows < 0) return AFM_ERR_ARG;
   if (glu_rows && (rows != 2 * glu_rows || (glu_rows & 3))) return AFM_ERR_ARG;
   const dim3 grid((cols + 63) / 64, (rows + 63) / 64);
-  if (dtype == AFM_BF16) AFM_LAUNCH(k_cast_weights<false>, grid, dim3(256), 0, (hipStream_t)stream, src, (bf16*)dst, (bf16*)dst_t, rows, cols, glu_rows);
-  else if (dtype == AFM_BF16X2) AFM_LAUNCH(k_cast_weights<true>, grid, dim3(256), 0, (hipStream_t)stream, src, (bf16*)dst, (bf16*)dst_t, rows, cols, glu_rows);
+  if (dtype == AFM_BF16) AFM_LAUNCH(k_cast_weights<0>, grid, dim3(256), 0, (hipStream_t)stream, src, (bf16*)dst, (bf16*)dst_t, rows, cols, glu_rows);
+  else if (dtype == AFM_BF16X2) AFM_LAUNCH(k_cast_weights<1>, grid, dim3(256), 0, (hipStream_t)stream, src, (bf16*)dst, (bf16*)dst_t, rows, cols, glu_rows);
+  else if (dtype == AFM_F16) AFM_LAUNCH(k_cast_weights<2>, grid, dim3(256), 0, (hipStream_t)stream, src, (bf16*)dst, (bf16*)dst_t, rows, cols, glu_rows);
   else return AFM_ERR_ARG;
   return AFM_OK;
 }

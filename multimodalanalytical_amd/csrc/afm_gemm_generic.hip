@@ -9,7 +9,7 @@ struct GemmArgs {
   int64_t sam, sak;  // element strides of op(A)[m][k]
   int64_t sbk, sbn;  // element strides of op(B)[k][n]
   int ldc;
-  int a_dt, b_dt, c_dt;      // AFM_F32 / AFM_BF16 / AFM_BF16X2
+  int a_dt, b_dt, c_dt;      // AFM_F32 / AFM_BF16 / AFM_BF16X2 / AFM_F16
   int a_lo, b_lo, c_lo;      // lo-plane offsets of split-pair operands (ld / 2)
   const void* A;
   const void* B;
@@ -24,11 +24,13 @@ struct GemmArgs {
 
 __device__ __forceinline__ float ld_any(const void* p, int dt, int64_t i, int lo) {
   if (dt == AFM_F32) return ((const float*)p)[i];
+  if (dt == AFM_F16) return (float)((const f16*)p)[i];
   const float hi = (float)((const bf16*)p)[i];
   return dt == AFM_BF16X2 ? hi + (float)((const bf16*)p)[i + lo] : hi;
 }
 __device__ __forceinline__ void st_any(void* p, int dt, int64_t i, float v, int lo) {
   if (dt == AFM_F32) { ((float*)p)[i] = v; return; }
+  if (dt == AFM_F16) { ((f16*)p)[i] = (f16)v; return; }
   bf16 hi, l2;
   afm_split(v, hi, l2);
   ((bf16*)p)[i] = hi;
@@ -216,8 +218,9 @@ __global__ __launch_bounds__(256) void k_gemm_skinny_n(GemmArgs g, float* a_cols
   }
 }
 
-// defined in afm_gemm_mfma.hip; returns AFM_ERR_UNSUPPORTED when the shape is not eligible
+// defined in afm_gemm_mfma.hip / afm_gemm_mfma_f16.hip (bf16 / fp16 operands); return AFM_ERR_UNSUPPORTED when the shape is not eligible
 int afm_gemm_mfma_try(const afm_gemm_desc* d, hipStream_t st);
+int afm_gemm_mfma_try_f16(const afm_gemm_desc* d, hipStream_t st);
 // defined in afm_gemm_x3.hip: split-pair operands on three bf16 MFMAs per product
 int afm_gemm_x3_try(const afm_gemm_desc* d, hipStream_t st);
 
@@ -286,8 +289,8 @@ static int gemm_generic(const afm_gemm_desc* d, hipStream_t st) {
 extern "C" int afm_gemm(const afm_gemm_desc* d, void* stream) {
   if (!d || !d->A || !d->B || !d->C) return AFM_ERR_ARG;
   if (d->M < 0 || d->N < 0 || d->K < 0) return AFM_ERR_ARG;
-  if (d->a_dtype < AFM_F32 || d->a_dtype > AFM_BF16X2 || d->b_dtype < AFM_F32 || d->b_dtype > AFM_BF16X2 ||
-      d->c_dtype < AFM_F32 || d->c_dtype > AFM_BF16X2) return AFM_ERR_ARG;
+  if (d->a_dtype < AFM_F32 || d->a_dtype > AFM_F16 || d->b_dtype < AFM_F32 || d->b_dtype > AFM_F16 ||
+      d->c_dtype < AFM_F32 || d->c_dtype > AFM_F16) return AFM_ERR_ARG;
   if (d->act < AFM_ACT_NONE || d->act > AFM_ACT_GLU_BWD) return AFM_ERR_ARG;
   const bool glu = d->act >= AFM_ACT_GLU;
   if (d->act >= AFM_ACT_GELU_BWD && d->act != AFM_ACT_GLU && !d->pre_act) return AFM_ERR_ARG;
@@ -306,7 +309,8 @@ extern "C" int afm_gemm(const afm_gemm_desc* d, void* stream) {
   if (d->M == 0 || d->N == 0) return AFM_OK;
   hipStream_t st = (hipStream_t)stream;
   if (d->algo != AFM_ALGO_GENERIC) {
-    const int r = (d->a_dtype == AFM_BF16X2 && d->b_dtype == AFM_BF16X2) ? afm_gemm_x3_try(d, st) : afm_gemm_mfma_try(d, st);
+    const int r = (d->a_dtype == AFM_BF16X2 && d->b_dtype == AFM_BF16X2) ? afm_gemm_x3_try(d, st)
+                  : (d->a_dtype == AFM_F16 && d->b_dtype == AFM_F16) ? afm_gemm_mfma_try_f16(d, st) : afm_gemm_mfma_try(d, st);
     if (r != AFM_ERR_UNSUPPORTED) return r;
     if (d->algo == AFM_ALGO_MFMA) return AFM_ERR_UNSUPPORTED;
   }

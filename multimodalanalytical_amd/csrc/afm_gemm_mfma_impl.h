@@ -1,0 +1,1549 @@
+// Single-pass 16-bit MFMA GEMMs for gfx950 (v_mfma_f32_16x16x32_bf16 / _f16, fp32 accumulate) with the afm_gemm epilogue.
+// Written against `e16` (afm_common.h) and compiled twice: afm_gemm_mfma.hip (bf16) and afm_gemm_mfma_f16.hip (fp16, the
+// reference's own GPU precision: trainer/trainer.py:69 "16-mixed").
+//
+//   NT  C[m][n] = sum_k A[m][k] * B[n][k]      forward (x W^T) and dgrad (dy (W^T)^T, W^T kept as a
+//                                              second e16 copy): both operands K-contiguous.
+//   TN  C[m][n] += sum_k A[k][m] * B[k][n]     wgrad (dy^T x): the reduction index is the ROW of both
+//                                              operands; tiles are staged row-major and read back
+//                                              transposed with ds_read_b64_tr_b16.
+//
+// Block = 256 threads = 4 waves (2 x 2), block tile 128 x 128, wave tile 64 x 64 = 4 x 4 MFMA
+// fragments, k-step 64 (two MFMA k-slices), LDS double-buffered (64 KiB) with an XOR swizzle so
+// the fragment reads are bank-conflict free, next tile prefetched into registers while the
+// current one is multiplied (one barrier per k-step).  The MFMA is issued with the WEIGHT tile as
+// the first operand so a lane ends up with 4 consecutive output columns of one row: 8-/16-byte
+// epilogue accesses.  Blocks are renumbered so the 8 XCDs each walk a contiguous range of tiles
+// (all column tiles of a row panel share one L2).
+#include "afm_common.h"
+
+namespace AFM_E16_NS {
+
+struct MfmaArgs {
+  int M, N, K;
+  int lda, ldb, ldc;
+  const e16* A;
+  const e16* B;
+  void* C;
+  const float* bias;
+  const void* residual;
+  void* pre_act;
+  float* a_colsum;
+  int act, accumulate;
+  int tiles_m, tiles_n;
+  int ksplit, kchunk;  // TN only
+  int bias_in_lds;     // persistent NT: staged epilogue enabled (bias vector cached in LDS)
+  int glu_f;           // gated-FFN interleave (include/afm_hip.h): bias / wgrad rows are translated to the [W1 ; Wg] order
+  unsigned long long* stamps;   // ablation builds: per-workgroup phase time stamps (wall_clock64), else null
+  DropDev dd;
+};
+
+#define BM 128
+#define BN 128
+#define BK 64
+
+// interleaved row / column n of the gated up-projection -> its index in the reference's [W1 ; Wg] order
+__device__ __forceinline__ int glu_deint(int n, int f) { return ((n >> 3) << 2) + (n & 3) + ((n >> 2) & 1) * f; }
+
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+  // bijective "each XCD gets a contiguous chunk" renumbering (8 XCDs, round-robin dispatch)
+  const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
+// ------------------------------------------------------------------------------------------ epilogue
+// Lane holds, for fragment (jn, im): C[m][n0 .. n0+3], m = m_base + im*16 + (lane&15),
+// n0 = n_base + jn*16 + (lane>>4)*4.
+template <bool C_BF16>
+__device__ __forceinline__ void epilogue4(const MfmaArgs& g, int m, int n0, f32x4 v, bool vec_ok) {
+  if (m >= g.M || n0 >= g.N) return;
+  const int64_t ci = (int64_t)m * g.ldc + n0;
+  const int nv = min(4, g.N - n0);
+  if (vec_ok && nv == 4) {
+    if (g.bias) v += *(const f32x4*)(g.bias + n0);
+    if (g.act == AFM_ACT_GELU_BWD) {
+      f32x4 u;
+      if (C_BF16) { const e16x4 uu = *(const e16x4*)((const e16*)g.pre_act + ci); u = (f32x4){(float)uu[0], (float)uu[1], (float)uu[2], (float)uu[3]}; }
+      else u = *(const f32x4*)((const float*)g.pre_act + ci);
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        v[r] = afm_drop(g.dd, (uint64_t)m * (uint64_t)g.N + (uint64_t)(n0 + r), v[r]) * afm_gelu_grad(u[r]);
+    } else {
+      if (g.pre_act) {
+        if (C_BF16) { e16x4 o = {(e16)v[0], (e16)v[1], (e16)v[2], (e16)v[3]}; *(e16x4*)((e16*)g.pre_act + ci) = o; }
+        else *(f32x4*)((float*)g.pre_act + ci) = v;
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float x = v[r];
+        if (g.act == AFM_ACT_RELU) x = fmaxf(x, 0.f);
+        else if (g.act == AFM_ACT_GELU) x = afm_gelu(x);
+        v[r] = afm_drop(g.dd, (uint64_t)m * (uint64_t)g.N + (uint64_t)(n0 + r), x);
+      }
+    }
+    if (g.residual) {
+      if (C_BF16) { const e16x4 rr = *(const e16x4*)((const e16*)g.residual + ci); v[0] += (float)rr[0]; v[1] += (float)rr[1]; v[2] += (float)rr[2]; v[3] += (float)rr[3]; }
+      else v += *(const f32x4*)((const float*)g.residual + ci);
+    }
+    if (g.accumulate) {
+      if (C_BF16) { const e16x4 rr = *(const e16x4*)((const e16*)g.C + ci); v[0] += (float)rr[0]; v[1] += (float)rr[1]; v[2] += (float)rr[2]; v[3] += (float)rr[3]; }
+      else v += *(const f32x4*)((const float*)g.C + ci);
+    }
+    if (C_BF16) { e16x4 o = {(e16)v[0], (e16)v[1], (e16)v[2], (e16)v[3]}; *(e16x4*)((e16*)g.C + ci) = o; }
+    else *(f32x4*)((float*)g.C + ci) = v;
+    return;
+  }
+  for (int r = 0; r < nv; ++r) {
+    float x = v[r];
+    const int n = n0 + r;
+    if (g.bias) x += g.bias[n];
+    if (g.act == AFM_ACT_GELU_BWD) {
+      const float u = C_BF16 ? (float)((const e16*)g.pre_act)[ci + r] : ((const float*)g.pre_act)[ci + r];
+      x = afm_drop(g.dd, (uint64_t)m * (uint64_t)g.N + (uint64_t)n, x) * afm_gelu_grad(u);
+    } else {
+      if (g.pre_act) { if (C_BF16) ((e16*)g.pre_act)[ci + r] = (e16)x; else ((float*)g.pre_act)[ci + r] = x; }
+      if (g.act == AFM_ACT_RELU) x = fmaxf(x, 0.f);
+      else if (g.act == AFM_ACT_GELU) x = afm_gelu(x);
+      x = afm_drop(g.dd, (uint64_t)m * (uint64_t)g.N + (uint64_t)n, x);
+    }
+    if (g.residual) x += C_BF16 ? (float)((const e16*)g.residual)[ci + r] : ((const float*)g.residual)[ci + r];
+    if (g.accumulate) x += C_BF16 ? (float)((const e16*)g.C)[ci + r] : ((const float*)g.C)[ci + r];
+    if (C_BF16) ((e16*)g.C)[ci + r] = (e16)x; else ((float*)g.C)[ci + r] = x;
+  }
+}
+
+// Same, for a tile known to be entirely inside C with 16-byte aligned rows: no per-lane exits, so
+// every wave issues exactly one store instruction per fragment (the persistent kernel counts on it).
+template <bool C_BF16>
+__device__ __forceinline__ void epilogue4_full(const MfmaArgs& g, int m, int n0, f32x4 v) {
+  const int64_t ci = (int64_t)m * g.ldc + n0;
+  if (g.bias) v += *(const f32x4*)(g.bias + n0);
+  if (g.act == AFM_ACT_GELU_BWD) {
+    f32x4 u;
+    if (C_BF16) { const e16x4 uu = *(const e16x4*)((const e16*)g.pre_act + ci); u = (f32x4){(float)uu[0], (float)uu[1], (float)uu[2], (float)uu[3]}; }
+    else u = *(const f32x4*)((const float*)g.pre_act + ci);
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      v[r] = afm_drop(g.dd, (uint64_t)m * (uint64_t)g.N + (uint64_t)(n0 + r), v[r]) * afm_gelu_grad(u[r]);
+  } else if (g.pre_act) {
+    if (C_BF16) { e16x4 o = {(e16)v[0], (e16)v[1], (e16)v[2], (e16)v[3]}; *(e16x4*)((e16*)g.pre_act + ci) = o; }
+    else *(f32x4*)((float*)g.pre_act + ci) = v;
+  }
+  if (g.act != AFM_ACT_GELU_BWD && (g.act != AFM_ACT_NONE || g.dd.thresh)) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float x = v[r];
+      if (g.act == AFM_ACT_RELU) x = fmaxf(x, 0.f);
+      else if (g.act == AFM_ACT_GELU) x = afm_gelu(x);
+      v[r] = afm_drop(g.dd, (uint64_t)m * (uint64_t)g.N + (uint64_t)(n0 + r), x);
+    }
+  }
+  if (g.residual) {
+    if (C_BF16) { const e16x4 rr = *(const e16x4*)((const e16*)g.residual + ci); v[0] += (float)rr[0]; v[1] += (float)rr[1]; v[2] += (float)rr[2]; v[3] += (float)rr[3]; }
+    else v += *(const f32x4*)((const float*)g.residual + ci);
+  }
+  if (g.accumulate) {
+    if (C_BF16) { const e16x4 rr = *(const e16x4*)((const e16*)g.C + ci); v[0] += (float)rr[0]; v[1] += (float)rr[1]; v[2] += (float)rr[2]; v[3] += (float)rr[3]; }
+    else v += *(const f32x4*)((const float*)g.C + ci);
+  }
+  if (C_BF16) { e16x4 o = {(e16)v[0], (e16)v[1], (e16)v[2], (e16)v[3]}; *(e16x4*)((e16*)g.C + ci) = o; }
+  else *(f32x4*)((float*)g.C + ci) = v;
+}
+
+// ------------------------------------------------------------------------------------------ NT
+// LDS tile [128 rows][64 k] e16 = 128-byte rows of 8 16-byte chunks; chunk c of row r is stored at
+// chunk (c ^ (r & 7)): the 16 lanes of a ds_read_b128 group then hit 16 distinct 16-byte slots.
+__device__ __forceinline__ int nt_off(int row, int chunk) { return row * 128 + ((chunk ^ (row & 7)) << 4); }
+
+// WM x WN MFMA fragments (16x16) per wave, NWM x NWN waves per block, BKT-deep k-steps.
+template <bool C_BF16, int WM, int WN, int NWM, int NWN, int BKT>
+__global__ __launch_bounds__(64 * NWM * NWN) void k_gemm_nt(MfmaArgs g) {
+  constexpr int NT = 64 * NWM * NWN;             // threads
+  constexpr int TBM = 16 * WM * NWM, TBN = 16 * WN * NWN;
+  constexpr int CH = BKT / 8;                    // 16-byte chunks per tile row
+  constexpr int ROWB = BKT * 2;                  // bytes per tile row
+  constexpr int RPP = NT / CH;                   // rows staged per pass
+  constexpr int PA = TBM / RPP, PB = TBN / RPP;  // passes
+  static_assert(TBM % RPP == 0 && TBN % RPP == 0, "tile/thread mismatch");
+  constexpr int ABYTES = TBM * ROWB, BBYTES = TBN * ROWB;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];  // [2][A | B]
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  const int wm = w / NWN, wn = w % NWN;
+  const int tile = xcd_remap(blockIdx.x, g.tiles_m * g.tiles_n);
+  const int m0 = (tile / g.tiles_n) * TBM, n0 = (tile % g.tiles_n) * TBN;
+  auto off = [](int row, int chunk) { return row * ROWB + ((chunk ^ (row & (CH - 1))) << 4); };
+
+  const int srow = t / CH, sch = t % CH;
+  const e16* ap[PA];
+  const e16* bp[PB];
+#pragma unroll
+  for (int i = 0; i < PA; ++i) ap[i] = g.A + (int64_t)min(m0 + srow + RPP * i, g.M - 1) * g.lda + sch * 8;
+#pragma unroll
+  for (int i = 0; i < PB; ++i) bp[i] = g.B + (int64_t)min(n0 + srow + RPP * i, g.N - 1) * g.ldb + sch * 8;
+  uint4 ra_[PA], rb_[PB];
+  auto gload = [&](int k0) {
+    const bool in = k0 + sch * 8 < g.K;  // K % 8 == 0: a chunk is entirely inside or outside
+#pragma unroll
+    for (int i = 0; i < PA; ++i) ra_[i] = in ? *(const uint4*)(ap[i] + k0) : make_uint4(0, 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < PB; ++i) rb_[i] = in ? *(const uint4*)(bp[i] + k0) : make_uint4(0, 0, 0, 0);
+  };
+  auto sstore = [&](int buf) {
+    unsigned char* a = lds + buf * (ABYTES + BBYTES);
+    unsigned char* b = a + ABYTES;
+#pragma unroll
+    for (int i = 0; i < PA; ++i) *(uint4*)(a + off(srow + RPP * i, sch)) = ra_[i];
+#pragma unroll
+    for (int i = 0; i < PB; ++i) *(uint4*)(b + off(srow + RPP * i, sch)) = rb_[i];
+  };
+
+  f32x4 acc[WN][WM];
+#pragma unroll
+  for (int j = 0; j < WN; ++j)
+#pragma unroll
+    for (int i = 0; i < WM; ++i) acc[j][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int nk = (g.K + BKT - 1) / BKT;
+  gload(0);
+  sstore(0);
+  __syncthreads();
+  const int fr = lane & 15, fq = lane >> 4;
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nk) gload((kt + 1) * BKT);
+    const unsigned char* a = lds + buf * (ABYTES + BBYTES);
+    const unsigned char* b = a + ABYTES;
+#pragma unroll
+    for (int ks = 0; ks < BKT / 32; ++ks) {
+      e16x8 af[WM], bfr[WN];
+#pragma unroll
+      for (int i = 0; i < WM; ++i) af[i] = *(const e16x8*)(a + off(wm * 16 * WM + i * 16 + fr, ks * 4 + fq));
+#pragma unroll
+      for (int j = 0; j < WN; ++j) bfr[j] = *(const e16x8*)(b + off(wn * 16 * WN + j * 16 + fr, ks * 4 + fq));
+#pragma unroll
+      for (int j = 0; j < WN; ++j)
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+          acc[j][i] = mfma16(bfr[j], af[i], acc[j][i]);
+    }
+    if (kt + 1 < nk) sstore(buf ^ 1);
+    __syncthreads();
+  }
+
+  const bool vec_ok = (g.ldc & 3) == 0 && (g.N & 3) == 0;
+#pragma unroll
+  for (int j = 0; j < WN; ++j)
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+      epilogue4<C_BF16>(g, m0 + wm * 16 * WM + i * 16 + fr, n0 + wn * 16 * WN + j * 16 + fq * 4, acc[j][i], vec_ok);
+}
+
+template <bool C_BF16, int WM, int WN, int NWM, int NWN, int BKT>
+static int launch_nt(MfmaArgs& g, hipStream_t st) {
+  constexpr int TBM = 16 * WM * NWM, TBN = 16 * WN * NWN;
+  constexpr int shm = 2 * (TBM + TBN) * BKT * 2;
+  g.tiles_m = (g.M + TBM - 1) / TBM; g.tiles_n = (g.N + TBN - 1) / TBN;
+  auto kern = k_gemm_nt<C_BF16, WM, WN, NWM, NWN, BKT>;
+  if (shm > 64 * 1024) {
+    static bool done = false;  // per instantiation
+    if (!done) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, shm); done = true; }
+  }
+  AFM_LAUNCH(kern, dim3(g.tiles_m * g.tiles_n), dim3(64 * NWM * NWN), shm, st, g);
+  return AFM_OK;
+}
+
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+// ------------------------------------------------------------------------------------------ staged epilogue
+// Full-tile epilogue of the persistent kernel.  A wave's 64 x 64 accumulator block is transposed
+// through a wave-private LDS patch (16 rows x 64 fp32 at a time, 272-byte rows) so that every global
+// access of the epilogue is 16 bytes per lane on whole 128-byte lines: a store instruction covers
+// 8 complete rows of the tile instead of 16 scattered 32-byte segments (the fragment layout gives
+// a lane 4 columns of one row), which is what bounded the K = 512 GEMMs of this model.
+#define STG_LD 68   // floats per staged row (64 + 4: conflict-free 16-byte writes, 16-byte aligned reads)
+template <bool C_BF16, int WM>
+__device__ __forceinline__ void epilogue_staged(const MfmaArgs& g, float* stg, const float* bias_lds,
+                                                f32x4 (&acc)[4][WM], int mw, int nw, int lane) {
+  const int fr = lane & 15, fq = lane >> 4;
+  if (C_BF16) {
+    const int c8 = (lane & 7) * 8, r8 = lane >> 3;
+    const int n = nw + c8;
+    f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = {0.f, 0.f, 0.f, 0.f};
+    if (g.bias) { b0 = *(const f32x4*)(bias_lds + n); b1 = *(const f32x4*)(bias_lds + n + 4); }
+    e16x8 uu[2 * WM];
+    if (g.act == AFM_ACT_GELU_BWD) {   // all pre-activation loads first: one wait, before any store
+#pragma unroll
+      for (int q = 0; q < 2 * WM; ++q)
+        uu[q] = *(const e16x8*)((const e16*)g.pre_act + (int64_t)(mw + (q >> 1) * 16 + (q & 1) * 8 + r8) * g.ldc + n);
+    }
+#pragma unroll
+    for (int i = 0; i < WM; ++i) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) *(f32x4*)(stg + fr * STG_LD + j * 16 + fq * 4) = acc[j][i];
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf) {
+        const int row = hf * 8 + r8;
+        const int mrow = mw + i * 16 + row;
+        const f32x4 v0 = *(const f32x4*)(stg + row * STG_LD + c8) + b0;
+        const f32x4 v1 = *(const f32x4*)(stg + row * STG_LD + c8 + 4) + b1;
+        float x[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+        const int64_t ci = (int64_t)mrow * g.ldc + n;
+        const uint64_t di = (uint64_t)mrow * (uint64_t)g.N + (uint64_t)n;
+        if (g.act == AFM_ACT_GELU_BWD) {
+          const e16x8 u = uu[i * 2 + hf];
+#pragma unroll
+          for (int k = 0; k < 8; ++k) x[k] = afm_drop(g.dd, di + k, x[k]) * afm_gelu_grad((float)u[k]);
+        } else {
+          if (g.pre_act) {
+            e16x8 o = {(e16)x[0], (e16)x[1], (e16)x[2], (e16)x[3], (e16)x[4], (e16)x[5], (e16)x[6], (e16)x[7]};
+            *(e16x8*)((e16*)g.pre_act + ci) = o;
+          }
+          if (g.act != AFM_ACT_NONE || g.dd.thresh) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+              float y = x[k];
+              if (g.act == AFM_ACT_RELU) y = fmaxf(y, 0.f);
+              else if (g.act == AFM_ACT_GELU) y = afm_gelu(y);
+              x[k] = afm_drop(g.dd, di + k, y);
+            }
+          }
+        }
+        e16x8 o = {(e16)x[0], (e16)x[1], (e16)x[2], (e16)x[3], (e16)x[4], (e16)x[5], (e16)x[6], (e16)x[7]};
+        *(e16x8*)((e16*)g.C + ci) = o;
+      }
+    }
+  } else {
+    const int c4 = (lane & 15) * 4, r4 = lane >> 4;
+    const int n = nw + c4;
+    f32x4 b0 = {0.f, 0.f, 0.f, 0.f};
+    if (g.bias) b0 = *(const f32x4*)(bias_lds + n);
+#pragma unroll
+    for (int i = 0; i < WM; ++i) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) *(f32x4*)(stg + fr * STG_LD + j * 16 + fq * 4) = acc[j][i];
+#pragma unroll
+      for (int qq = 0; qq < 4; ++qq) {
+        const int row = qq * 4 + r4;
+        const int mrow = mw + i * 16 + row;
+        f32x4 v = *(const f32x4*)(stg + row * STG_LD + c4) + b0;
+        const int64_t ci = (int64_t)mrow * g.ldc + n;
+        const uint64_t di = (uint64_t)mrow * (uint64_t)g.N + (uint64_t)n;
+        if (g.act == AFM_ACT_GELU_BWD) {
+          const f32x4 u = *(const f32x4*)((const float*)g.pre_act + ci);
+#pragma unroll
+          for (int k = 0; k < 4; ++k) v[k] = afm_drop(g.dd, di + k, v[k]) * afm_gelu_grad(u[k]);
+        } else {
+          if (g.pre_act) *(f32x4*)((float*)g.pre_act + ci) = v;
+          if (g.act != AFM_ACT_NONE || g.dd.thresh) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              float y = v[k];
+              if (g.act == AFM_ACT_RELU) y = fmaxf(y, 0.f);
+              else if (g.act == AFM_ACT_GELU) y = afm_gelu(y);
+              v[k] = afm_drop(g.dd, di + k, y);
+            }
+          }
+        }
+        if (g.residual) v += *(const f32x4*)((const float*)g.residual + ci);
+        if (g.accumulate) v += *(const f32x4*)((const float*)g.C + ci);
+        *(f32x4*)((float*)g.C + ci) = v;
+      }
+    }
+  }
+}
+
+// Compile-time epilogue kinds of the e16 staged epilogue (the training step's four fused forms): the
+// generic one above tests act / dropout / pre_act per element group at run time, which costs scalar
+// branches between every eight elements and keeps the compiler from scheduling across them.
+//   EPI_PLAIN     C = acc + bias
+//   EPI_DROP      C = dropout(acc + bias)
+//   EPI_GELU      pre_act = acc + bias (if kept);  C = dropout(gelu(acc + bias))
+//   EPI_GELU_BWD  C = dropout(acc) * gelu'(pre_act)
+//   EPI_GELU_SG   C = dropout(gelu(acc + bias));  pre_act = keep * scale * gelu'(acc + bias)
+//   EPI_MUL       C = acc * pre_act                (the dgrad partner of EPI_GELU_SG: no erf, no hash)
+// Dropout indices are 32-bit here (the dispatcher requires M*N <= 2^32, where the stream's high-word
+// term is zero), which also removes a 64-bit multiply-add chain per element group.
+//   EPI_GLU / EPI_GLU_SG  gated FFN forward on the interleaved (2f-wide) accumulators: C (f wide) = dropout(gelu(u) * v)
+//                         [SG: pre_act (2f wide) = keep*scale*[gelu'(u) v | gelu(u)]]
+//   EPI_GLU_BWD           accumulators = dg (f wide): C (2f wide, interleaved) = [dg * saved_a | dg * saved_b]
+enum { EPI_GENERIC = 0, EPI_PLAIN = 1, EPI_DROP = 2, EPI_GELU = 3, EPI_GELU_BWD = 4, EPI_GELU_SG = 5, EPI_MUL = 6,
+       EPI_GLU = 7, EPI_GLU_SG = 8, EPI_GLU_BWD = 9 };
+__device__ __forceinline__ float afm_drop32(const DropDev& d, uint32_t idx, float x) {
+  return afm_lowbias32(idx ^ d.key) >= d.thresh ? x * d.scale : 0.f;
+}
+template <int WM, int EPI>
+__device__ __forceinline__ void epilogue_staged_bf16(const MfmaArgs& g, float* stg, const float* bias_lds,
+                                                     f32x4 (&acc)[4][WM], int mw, int nw, int lane) {
+  const int fr = lane & 15, fq = lane >> 4;
+  const int c8 = (lane & 7) * 8, r8 = lane >> 3;
+  const int n = nw + c8;
+  f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = {0.f, 0.f, 0.f, 0.f};
+  if constexpr (EPI == EPI_GLU || EPI == EPI_GLU_SG) {   // u / v biases of hidden units (n >> 1) .. +3, reference order [b1 ; bg]
+    if (g.bias) { b0 = *(const f32x4*)(g.bias + (n >> 1)); b1 = *(const f32x4*)(g.bias + g.glu_f + (n >> 1)); }
+  } else if (EPI != EPI_GELU_BWD && EPI != EPI_MUL && EPI != EPI_GLU_BWD && g.bias) { b0 = *(const f32x4*)(bias_lds + n); b1 = *(const f32x4*)(bias_lds + n + 4); }
+  const bool drop_on = g.dd.thresh != 0;   // wave-uniform
+  e16* const cbase = (e16*)g.C + (int64_t)(mw + r8) * g.ldc + n;
+  e16* const pbase = (e16*)g.pre_act + (int64_t)(mw + r8) * g.ldc + n;
+  const uint32_t dbase = (uint32_t)(mw + r8) * (uint32_t)g.N + (uint32_t)n;
+  // pre-activations of the dropout * GELU' form: loaded PF row-groups ahead of their use (all 2*WM at once
+  // cost 8 VGPRs each: 64 at 128-row wave tiles, which spilled)
+  constexpr int PF = 4;
+  e16x8 uu[2 * WM];
+  if (EPI == EPI_GELU_BWD || EPI == EPI_MUL) {
+#pragma unroll
+    for (int q = 0; q < (PF < 2 * WM ? PF : 2 * WM); ++q) uu[q] = *(const e16x8*)(pbase + (int64_t)(q * 8) * g.ldc);
+  }
+#pragma unroll
+  for (int i = 0; i < WM; ++i) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) *(f32x4*)(stg + fr * STG_LD + j * 16 + fq * 4) = acc[j][i];
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {
+      const int q = i * 2 + hf;                       // 8-row group of the wave's 16*WM rows
+      const int row = hf * 8 + r8;
+      const f32x4 v0 = *(const f32x4*)(stg + row * STG_LD + c8) + b0;
+      const f32x4 v1 = *(const f32x4*)(stg + row * STG_LD + c8 + 4) + b1;
+      float x[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+      const int64_t ro = (int64_t)(q * 8) * g.ldc;
+      const uint32_t di = dbase + (uint32_t)(q * 8) * (uint32_t)g.N;
+      if constexpr (EPI == EPI_GLU || EPI == EPI_GLU_SG) {
+        // x[0..3] = u, x[4..7] = v of hidden units (n >> 1) .. +3; C and the dropout stream are f = N/2 wide
+        const int64_t rowi = mw + r8 + q * 8;
+        const int hcol = n >> 1;
+        const uint32_t dg0 = (uint32_t)rowi * (uint32_t)(g.N >> 1) + (uint32_t)hcol;
+        float gv[4], sa[4], sb[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          float y, yp;
+          afm_gelu_both(x[k], y, yp);
+          const float keep = drop_on ? afm_drop32(g.dd, dg0 + k, 1.0f) : 1.0f;
+          gv[k] = y * x[4 + k] * keep; sa[k] = yp * x[4 + k] * keep; sb[k] = y * keep;
+        }
+        e16x4 o = {(e16)gv[0], (e16)gv[1], (e16)gv[2], (e16)gv[3]};
+        *(e16x4*)((e16*)g.C + rowi * g.ldc + hcol) = o;
+        if (EPI == EPI_GLU_SG) {
+          e16x8 sv = {(e16)sa[0], (e16)sa[1], (e16)sa[2], (e16)sa[3], (e16)sb[0], (e16)sb[1], (e16)sb[2], (e16)sb[3]};
+          *(e16x8*)((e16*)g.pre_act + rowi * g.N + n) = sv;
+        }
+        continue;
+      }
+      if constexpr (EPI == EPI_GLU_BWD) {
+        // x[0..7] = dg of hidden units n .. n+7; saved / output columns 2n .. 2n+15 (two interleave groups), 2f = ldc wide
+        const int64_t rowi = mw + r8 + q * 8;
+        const e16* sp = (const e16*)g.pre_act + rowi * g.ldc + 2 * n;
+        e16* cp = (e16*)g.C + rowi * g.ldc + 2 * n;
+        const e16x8 s0 = *(const e16x8*)sp, s1 = *(const e16x8*)(sp + 8);
+        e16x8 o0, o1;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          o0[k] = (e16)(x[k] * (float)s0[k]); o0[4 + k] = (e16)(x[k] * (float)s0[4 + k]);
+          o1[k] = (e16)(x[4 + k] * (float)s1[k]); o1[4 + k] = (e16)(x[4 + k] * (float)s1[4 + k]);
+        }
+        *(e16x8*)cp = o0; *(e16x8*)(cp + 8) = o1;
+        continue;
+      }
+      if (EPI == EPI_GELU) {
+        if (g.pre_act) {
+          e16x8 o = {(e16)x[0], (e16)x[1], (e16)x[2], (e16)x[3], (e16)x[4], (e16)x[5], (e16)x[6], (e16)x[7]};
+          *(e16x8*)(pbase + ro) = o;
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) x[k] = afm_gelu(x[k]);
+      }
+      if (EPI == EPI_GELU_SG) {
+        float gp[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          float y, yp;
+          afm_gelu_both(x[k], y, yp);
+          const float keep = drop_on ? afm_drop32(g.dd, di + k, 1.0f) : 1.0f;
+          x[k] = y * keep; gp[k] = yp * keep;
+        }
+        e16x8 o = {(e16)gp[0], (e16)gp[1], (e16)gp[2], (e16)gp[3], (e16)gp[4], (e16)gp[5], (e16)gp[6], (e16)gp[7]};
+        *(e16x8*)(pbase + ro) = o;
+      }
+      if (EPI == EPI_MUL) {
+        const e16x8 u = uu[q];
+        if (q + PF < 2 * WM) uu[q + PF < 2 * WM ? q + PF : 0] = *(const e16x8*)(pbase + (int64_t)((q + PF) * 8) * g.ldc);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) x[k] *= (float)u[k];
+      }
+      if (EPI == EPI_GELU_BWD) {
+        const e16x8 u = uu[q];
+        if (q + PF < 2 * WM) uu[q + PF < 2 * WM ? q + PF : 0] = *(const e16x8*)(pbase + (int64_t)((q + PF) * 8) * g.ldc);
+        if (drop_on) {
+#pragma unroll
+          for (int k = 0; k < 8; ++k) x[k] = afm_drop32(g.dd, di + k, x[k]) * afm_gelu_grad((float)u[k]);
+        } else {
+#pragma unroll
+          for (int k = 0; k < 8; ++k) x[k] *= afm_gelu_grad((float)u[k]);
+        }
+      } else if (EPI == EPI_DROP || (EPI == EPI_GELU && drop_on)) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) x[k] = afm_drop32(g.dd, di + k, x[k]);
+      }
+      e16x8 o = {(e16)x[0], (e16)x[1], (e16)x[2], (e16)x[3], (e16)x[4], (e16)x[5], (e16)x[6], (e16)x[7]};
+      *(e16x8*)(cbase + ro) = o;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------ NT, persistent ring
+// One workgroup per CU walks a contiguous range of output tiles of its XCD; the LDS-DMA ring keeps
+// running ACROSS tiles (the first k-steps of the next tile are in flight while the current tile
+// finishes and its epilogue stores drain), so the per-tile prologue bubble and the workgroup
+// launch/teardown disappear from the critical path.
+// ABL (timing experiments only, bit mask): 1 = skip the LDS reads + MFMAs, 2 = skip the LDS-DMA loads,
+// 4 = skip the epilogue.
+// EPI: compile-time epilogue kind of full tiles (e16 output); EDGE = false drops the fragment epilogue of
+// partial tiles (the dispatcher then only sends shapes made of whole tiles).
+template <bool C_BF16, int NWM, int NWN, int S, int ABL = 0, int WM = 4, int EPI = EPI_GENERIC, bool EDGE = true>
+__global__ __launch_bounds__(64 * NWM * NWN) void k_gemm_nt_pring(MfmaArgs g) {
+  constexpr int NW = NWM * NWN;
+  constexpr int TBM = 16 * WM * NWM, TBN = 64 * NWN;
+  constexpr int NI = (TBM + TBN) / 8, NIW = NI / NW;
+  static_assert(NI % NW == 0, "pieces must divide over the waves");
+  constexpr int STAGE = (TBM + TBN) * 128;
+  static_assert(NW * 16 * STG_LD * 4 <= STAGE, "wave-private staging patches must fit one ring slot");
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  float* bias_lds = (float*)(lds + S * STAGE);   // whole bias vector, loaded once (g.bias_in_lds)
+  const int t = threadIdx.x, lane = t & 63;
+  const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wm = w / NWN, wn = w % NWN;
+  const int ntiles = g.tiles_m * g.tiles_n;
+  if (g.bias_in_lds) {   // plain loads, retired (barrier) before the first LDS-DMA piece is issued
+    for (int n = t; n < g.N; n += 64 * NW) bias_lds[n] = g.bias ? g.bias[n] : 0.f;
+    __syncthreads();
+  }
+  // XCD x owns tiles [x*tpx, (x+1)*tpx); its blocks (blockIdx % 8 == x) stride through them together
+  const int xcd = blockIdx.x & 7, bx = blockIdx.x >> 3, nbx = gridDim.x >> 3;
+  const int tpx = (ntiles + 7) >> 3;
+  const int tlo = xcd * tpx, thi = min(ntiles, tlo + tpx);
+  auto tile_of = [&](int it) { const int tt = tlo + it * nbx + bx; return tt < thi ? tt : -1; };
+  const int nk = g.K / 64;
+
+  const e16* src[NIW];
+  auto set_src = [&](int tile) {
+    const int m0 = (tile / g.tiles_n) * TBM, n0 = (tile % g.tiles_n) * TBN;
+#pragma unroll
+    for (int j = 0; j < NIW; ++j) {
+      const int ii = w + NW * j;
+      const int r8 = lane >> 3, ch = (lane & 7) ^ r8;
+      if (ii < TBM / 8) src[j] = g.A + (int64_t)min(m0 + ii * 8 + r8, g.M - 1) * g.lda + ch * 8;
+      else src[j] = g.B + (int64_t)min(n0 + (ii - TBM / 8) * 8 + r8, g.N - 1) * g.ldb + ch * 8;
+    }
+  };
+  int is_it = 0, is_kt = 0, is_slot = 0;       // next step to issue: tile iteration, k-step, ring slot
+  int is_tile = tile_of(0);
+  if (is_tile >= 0) set_src(is_tile);
+  int ahead = 0;                                // steps issued but not yet consumed
+  auto issue_one = [&]() {
+    if (is_tile < 0) return;
+    unsigned char* st = lds + is_slot * STAGE;
+    if (!(ABL & 2)) {
+#pragma unroll
+      for (int j = 0; j < NIW; ++j)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[j] + is_kt * 64),
+                                         (__attribute__((address_space(3))) void*)(st + (w + NW * j) * 1024), 16, 0, 0);
+    }
+    ++ahead;
+    is_slot = is_slot + 1 == S ? 0 : is_slot + 1;
+    if (++is_kt == nk) {
+      is_kt = 0;
+      is_tile = tile_of(++is_it);
+      if (is_tile >= 0) set_src(is_tile);
+    }
+  };
+  auto off = [](int row, int chunk) { return row * 128 + ((chunk ^ (row & 7)) << 4); };
+#pragma unroll
+  for (int s = 0; s < S - 1; ++s) issue_one();
+
+  const int fr = lane & 15, fq = lane >> 4;
+  const bool vec_ok = (g.ldc & 3) == 0 && (g.N & 3) == 0;
+  int slot = 0;
+  bool prev_full = false;
+  for (int it = 0;; ++it) {
+    const int tile = tile_of(it);
+    if (tile < 0) break;
+    const int m0 = (tile / g.tiles_n) * TBM, n0 = (tile % g.tiles_n) * TBN;
+#ifdef AFM_GEMM_ABLATIONS
+    if (g.stamps && t == 0 && it < 16) g.stamps[(blockIdx.x * 16 + it) * 4 + 0] = wall_clock64();
+#endif
+    f32x4 acc[4][WM];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int i = 0; i < WM; ++i) acc[j][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int kt = 0; kt < nk; ++kt) {
+      // `ahead` counts the current step too; (ahead-1)*NIW younger pieces may stay in flight.  The
+      // previous tile's epilogue sits in the same in-order counter BEHIND the pieces of this tile's
+      // first S-1 steps: after a full-tile epilogue (exactly 8 / 16 stores per wave for e16 / fp32
+      // output, plus loads) those younger operations may stay outstanding too, so the stores drain under the next tile's
+      // MFMAs; after an edge-tile epilogue (store count unknown) drain everything.
+#ifdef AFM_GEMM_ABLATIONS
+      const bool stampk = g.stamps && lane == 0 && it == 5 && blockIdx.x < 64;
+      unsigned long long* sk = g.stamps + 512 * 64 + ((blockIdx.x * 12 + w) * 8 + kt) * 5;
+      if (stampk) sk[0] = clock64();
+#endif
+      if (it > 0 && kt < S - 1 && !prev_full) wait_vmcnt<0>();
+      else if (it > 0 && kt < S - 1 && ahead - 1 >= S - 2) wait_vmcnt<NIW * (S - 2) + (C_BF16 ? 2 * WM : 4 * WM)>();
+      else if (ahead - 1 >= S - 2) wait_vmcnt<NIW * (S - 2)>();
+      else if (S > 3 && ahead - 1 == S - 3) wait_vmcnt<NIW * (S > 3 ? S - 3 : 0)>();
+      else wait_vmcnt<0>();
+#ifdef AFM_GEMM_ABLATIONS
+      if (stampk) sk[1] = clock64();
+#endif
+      __builtin_amdgcn_s_barrier();
+#ifdef AFM_GEMM_ABLATIONS
+      if (stampk) sk[2] = clock64();
+#endif
+      --ahead;
+      issue_one();
+#ifdef AFM_GEMM_ABLATIONS
+      if (stampk) sk[3] = clock64();
+#endif
+      const unsigned char* a = lds + slot * STAGE;
+      const unsigned char* b = a + TBM * 128;
+      slot = slot + 1 == S ? 0 : slot + 1;
+      if (ABL & 1) continue;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        e16x8 af[WM], bfr[4];
+#pragma unroll
+        for (int i = 0; i < WM; ++i) af[i] = *(const e16x8*)(a + off(wm * 16 * WM + i * 16 + fr, ks * 4 + fq));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bfr[j] = *(const e16x8*)(b + off(wn * 64 + j * 16 + fr, ks * 4 + fq));
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int i = 0; i < WM; ++i)
+            acc[j][i] = mfma16(bfr[j], af[i], acc[j][i]);
+      }
+#ifdef AFM_GEMM_ABLATIONS
+      if (stampk) sk[4] = clock64();
+#endif
+    }
+#ifdef AFM_GEMM_ABLATIONS
+    if (g.stamps && t == 0 && it < 16) g.stamps[(blockIdx.x * 16 + it) * 4 + 1] = wall_clock64();
+#endif
+    prev_full = g.bias_in_lds && m0 + TBM <= g.M && n0 + TBN <= g.N;
+    if (ABL & 4) {
+      if (acc[0][0][0] == 123.456f) ((float*)g.C)[0] = 1.f;   // keep the accumulators alive
+      prev_full = false;
+    } else if (prev_full) {
+      // the slot read by the last k-step is free until the next issue: stage through it
+      __builtin_amdgcn_s_barrier();
+      float* stg = (float*)(lds + (slot == 0 ? S - 1 : slot - 1) * STAGE) + w * (16 * STG_LD);
+      if constexpr (C_BF16 && EPI != EPI_GENERIC) epilogue_staged_bf16<WM, EPI>(g, stg, bias_lds, acc, m0 + wm * 16 * WM, n0 + wn * 64, lane);
+      else epilogue_staged<C_BF16, WM>(g, stg, bias_lds, acc, m0 + wm * 16 * WM, n0 + wn * 64, lane);
+    } else if constexpr (EDGE) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+          epilogue4<C_BF16>(g, m0 + wm * 16 * WM + i * 16 + fr, n0 + wn * 64 + j * 16 + fq * 4, acc[j][i], vec_ok);
+    }
+#ifdef AFM_GEMM_ABLATIONS
+    if (g.stamps && t == 0 && it < 16) g.stamps[(blockIdx.x * 16 + it) * 4 + 2] = wall_clock64();
+#endif
+  }
+}
+
+template <bool C_BF16, int NWM, int NWN, int S, int ABL = 0, int WM = 4, int EPI = EPI_GENERIC, bool EDGE = true>
+static int launch_nt_pring(MfmaArgs& g, hipStream_t st, int blocks_per_cu) {
+  constexpr int TBM = 16 * WM * NWM, TBN = 64 * NWN;
+  constexpr int ring = S * (TBM + TBN) * 128;
+  static_assert(ring <= 160 * 1024, "ring does not fit the 160 KiB LDS");
+  g.tiles_m = (g.M + TBM - 1) / TBM; g.tiles_n = (g.N + TBN - 1) / TBN;
+  // staged epilogue: needs 16-byte rows everywhere and room for the bias vector behind the ring
+  const int bias_bytes = ((g.N * 4 + 15) / 16) * 16;
+  const bool rows16 = (g.N % 8) == 0 && (g.ldc % 8) == 0;
+  const bool modes_ok = C_BF16 ? (!g.residual && !g.accumulate) : true;
+  g.bias_in_lds = rows16 && modes_ok && ring * blocks_per_cu + bias_bytes * blocks_per_cu <= 160 * 1024 ? 1 : 0;
+  const int shm = ring + (g.bias_in_lds ? bias_bytes : 0);
+  auto kern = k_gemm_nt_pring<C_BF16, NWM, NWN, S, ABL, WM, EPI, EDGE>;
+  static int attr_shm = 0;   // per instantiation
+  if (shm > attr_shm) {
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_shm = 160 * 1024;
+  }
+  int grid = 256 * blocks_per_cu;                      // 256 CUs; multiple of 8 (XCD ranges)
+  const int ntiles = g.tiles_m * g.tiles_n;
+  if (grid > ((ntiles + 7) / 8) * 8) grid = ((ntiles + 7) / 8) * 8;
+  AFM_LAUNCH(kern, dim3(grid), dim3(64 * NWM * NWN), shm, st, g);
+  return AFM_OK;
+}
+
+// ------------------------------------------------------------------------------------------ NT, loader waves
+// Same tile walk and LDS ring as k_gemm_nt_pring, but the LDS-DMA pieces are issued by NL extra
+// "loader" waves.  Measured on the all-waves-issue kernel (in-kernel stamps, tools/stamp_gemm.py): a
+// global_load_lds wave-instruction holds its wave for ~20 ns (the CU takes in ~50 GB/s, one 1-KiB
+// piece at a time), so the 48 pieces of a k-step cost every compute wave 0.5-1 us of issue time in
+// front of 0.95 us of LDS reads + MFMAs, and the per-step barrier makes all of them wait for the
+// last issuer: fill and compute ran strictly one after the other (2.5 us per k-step).  Loader waves
+// take the issue time (and the counted vmcnt waits) off the MFMA waves; the workgroup barrier of each
+// k-step publishes a landed slot and frees the one read a step earlier.  The compute waves issue no
+// LDS-DMA at all, so their epilogue stores need no counted waits.
+template <bool C_BF16, int NL, int ABL = 0, int EPI = EPI_GENERIC>
+__global__ __launch_bounds__(64 * (8 + NL)) void k_gemm_nt_ws(MfmaArgs g) {
+  constexpr int NWN = 2, NW = 8, WM = 4, S = 3;
+  constexpr int TBM = 256, TBN = 128;
+  constexpr int NI = (TBM + TBN) / 8, NIL = NI / NL;   // 1-KiB pieces per k-step, per loader wave
+  static_assert(NI % NL == 0, "pieces must divide over the loader waves");
+  constexpr int STAGE = (TBM + TBN) * 128;
+  static_assert(NW * 16 * STG_LD * 4 <= STAGE, "wave-private staging patches must fit one ring slot");
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  float* bias_lds = (float*)(lds + S * STAGE);
+  const int t = threadIdx.x, lane = t & 63;
+  const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int ntiles = g.tiles_m * g.tiles_n;
+  constexpr bool GLU_EPI = EPI == EPI_GLU || EPI == EPI_GLU_SG || EPI == EPI_GLU_BWD;   // these read the bias from global memory
+  if (g.bias_in_lds && !GLU_EPI) {   // plain loads, retired (barrier) before the first LDS-DMA piece is issued
+    for (int n = t; n < g.N; n += 64 * (NW + NL)) bias_lds[n] = g.bias ? g.bias[n] : 0.f;
+    __syncthreads();
+  }
+  const int xcd = blockIdx.x & 7, bx = blockIdx.x >> 3, nbx = gridDim.x >> 3;
+  const int tpx = (ntiles + 7) >> 3;
+  const int tlo = xcd * tpx, thi = min(ntiles, tlo + tpx);
+  auto tile_of = [&](int it) { const int tt = tlo + it * nbx + bx; return tt < thi ? tt : -1; };
+  auto tile_full = [&](int tile) {
+    const int m0 = (tile / g.tiles_n) * TBM, n0 = (tile % g.tiles_n) * TBN;
+    return g.bias_in_lds && m0 + TBM <= g.M && n0 + TBN <= g.N;
+  };
+  const int nk = g.K / 64;
+
+  if (w >= NW) {
+    // ---------------------------------------------------------------- loader wave
+    const int lw = w - NW;
+    const e16* src[NIL];
+    auto set_src = [&](int tile) {
+      const int m0 = (tile / g.tiles_n) * TBM, n0 = (tile % g.tiles_n) * TBN;
+#pragma unroll
+      for (int j = 0; j < NIL; ++j) {
+        const int ii = lw + NL * j;
+        const int r8 = lane >> 3, ch = (lane & 7) ^ r8;
+        if (ii < TBM / 8) src[j] = g.A + (int64_t)min(m0 + ii * 8 + r8, g.M - 1) * g.lda + ch * 8;
+        else src[j] = g.B + (int64_t)min(n0 + (ii - TBM / 8) * 8 + r8, g.N - 1) * g.ldb + ch * 8;
+      }
+    };
+    int is_it = 0, is_kt = 0, is_slot = 0;
+    int is_tile = tile_of(0);
+    if (is_tile >= 0) set_src(is_tile);
+    int ahead = 0;   // steps issued and not yet published
+    auto issue_one = [&]() {
+      if (is_tile < 0) return;
+      unsigned char* st = lds + is_slot * STAGE;
+      if (!(ABL & 2)) {
+#pragma unroll
+        for (int j = 0; j < NIL; ++j)
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[j] + is_kt * 64),
+                                           (__attribute__((address_space(3))) void*)(st + (lw + NL * j) * 1024), 16, 0, 0);
+      }
+      ++ahead;
+      is_slot = is_slot + 1 == S ? 0 : is_slot + 1;
+      if (++is_kt == nk) {
+        is_kt = 0;
+        is_tile = tile_of(++is_it);
+        if (is_tile >= 0) set_src(is_tile);
+      }
+    };
+#pragma unroll
+    for (int s = 0; s < S - 1; ++s) issue_one();
+    for (int it = 0;; ++it) {
+      const int tile = tile_of(it);
+      if (tile < 0) break;
+      for (int kt = 0; kt < nk; ++kt) {
+        // publish this step: its pieces must have landed; the step issued after it may stay in flight
+#ifdef AFM_GEMM_ABLATIONS
+        const bool stampk = g.stamps && lane == 0 && it == 5 && blockIdx.x < 64 && w < 12;
+        unsigned long long* sk = g.stamps + 512 * 64 + ((blockIdx.x * 12 + w) * 8 + kt) * 5;
+        if (stampk) sk[0] = clock64();
+#endif
+        if (ahead - 1 >= S - 2) wait_vmcnt<NIL*(S - 2)>(); else wait_vmcnt<0>();
+#ifdef AFM_GEMM_ABLATIONS
+        if (stampk) sk[1] = clock64();
+#endif
+        __builtin_amdgcn_s_barrier();
+#ifdef AFM_GEMM_ABLATIONS
+        if (stampk) sk[2] = clock64();
+#endif
+        --ahead;
+        issue_one();   // into the slot every compute wave finished reading before this barrier
+#ifdef AFM_GEMM_ABLATIONS
+        if (stampk) { sk[3] = clock64(); sk[4] = sk[3]; }
+#endif
+      }
+      if (tile_full(tile)) __builtin_amdgcn_s_barrier();   // the compute waves' pre-epilogue barrier
+    }
+    return;
+  }
+
+  // ------------------------------------------------------------------ compute wave
+  const int wm = w / NWN, wn = w % NWN;
+  auto off = [](int row, int chunk) { return row * 128 + ((chunk ^ (row & 7)) << 4); };
+  const int fr = lane & 15, fq = lane >> 4;
+  const bool vec_ok = (g.ldc & 3) == 0 && (g.N & 3) == 0;
+  int slot = 0;
+  for (int it = 0;; ++it) {
+    const int tile = tile_of(it);
+    if (tile < 0) break;
+    const int m0 = (tile / g.tiles_n) * TBM, n0 = (tile % g.tiles_n) * TBN;
+    f32x4 acc[4][WM];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int i = 0; i < WM; ++i) acc[j][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#ifdef AFM_GEMM_ABLATIONS
+    if (g.stamps && t == 0 && it < 16) g.stamps[(blockIdx.x * 16 + it) * 4 + 0] = wall_clock64();
+#endif
+    for (int kt = 0; kt < nk; ++kt) {
+#ifdef AFM_GEMM_ABLATIONS
+      const bool stampk = g.stamps && lane == 0 && it == 5 && blockIdx.x < 64;
+      unsigned long long* sk = g.stamps + 512 * 64 + ((blockIdx.x * 12 + w) * 8 + kt) * 5;
+      if (stampk) { sk[0] = clock64(); sk[1] = sk[0]; }
+#endif
+      __builtin_amdgcn_s_barrier();
+#ifdef AFM_GEMM_ABLATIONS
+      if (stampk) { sk[2] = clock64(); sk[3] = sk[2]; }
+#endif
+      const unsigned char* a = lds + slot * STAGE;
+      const unsigned char* b = a + TBM * 128;
+      slot = slot + 1 == S ? 0 : slot + 1;
+      if (ABL & 1) continue;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        e16x8 af[WM], bfr[4];
+#pragma unroll
+        for (int i = 0; i < WM; ++i) af[i] = *(const e16x8*)(a + off(wm * 16 * WM + i * 16 + fr, ks * 4 + fq));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bfr[j] = *(const e16x8*)(b + off(wn * 64 + j * 16 + fr, ks * 4 + fq));
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int i = 0; i < WM; ++i)
+            acc[j][i] = mfma16(bfr[j], af[i], acc[j][i]);
+      }
+#ifdef AFM_GEMM_ABLATIONS
+      if (stampk) sk[4] = clock64();
+#endif
+    }
+#ifdef AFM_GEMM_ABLATIONS
+    if (g.stamps && t == 0 && it < 16) g.stamps[(blockIdx.x * 16 + it) * 4 + 1] = wall_clock64();
+#endif
+    if (ABL & 4) {   // timing only: keep every accumulator alive, store nothing
+      float sacc = 0.f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < WM; ++i) sacc += acc[j][i][0] + acc[j][i][1] + acc[j][i][2] + acc[j][i][3];
+      if (sacc == 123.456f) ((float*)g.C)[0] = sacc;
+      if (tile_full(tile)) __builtin_amdgcn_s_barrier();
+    } else if (tile_full(tile)) {
+      // the slot read by the last k-step stays free until the next step's barrier: stage through it
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      float* stg = (float*)(lds + (slot == 0 ? S - 1 : slot - 1) * STAGE) + w * (16 * STG_LD);
+      if constexpr (C_BF16 && EPI != EPI_GENERIC) epilogue_staged_bf16<WM, EPI>(g, stg, bias_lds, acc, m0 + wm * 16 * WM, n0 + wn * 64, lane);
+      else epilogue_staged<C_BF16, WM>(g, stg, bias_lds, acc, m0 + wm * 16 * WM, n0 + wn * 64, lane);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // staging reads done before the slot is handed back
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+          epilogue4<C_BF16>(g, m0 + wm * 16 * WM + i * 16 + fr, n0 + wn * 64 + j * 16 + fq * 4, acc[j][i], vec_ok);
+    }
+#ifdef AFM_GEMM_ABLATIONS
+    if (g.stamps && t == 0 && it < 16) g.stamps[(blockIdx.x * 16 + it) * 4 + 2] = wall_clock64();
+#endif
+  }
+}
+
+template <bool C_BF16, int NL, int ABL = 0, int EPI = EPI_GENERIC>
+static int launch_nt_ws(MfmaArgs& g, hipStream_t st) {
+  constexpr int TBM = 256, TBN = 128, S = 3;
+  constexpr int ring = S * (TBM + TBN) * 128;
+  g.tiles_m = (g.M + TBM - 1) / TBM; g.tiles_n = (g.N + TBN - 1) / TBN;
+  const int bias_bytes = ((g.N * 4 + 15) / 16) * 16;
+  const bool rows16 = (g.N % 8) == 0 && (g.ldc % 8) == 0;
+  const bool modes_ok = C_BF16 ? (!g.residual && !g.accumulate) : true;
+  constexpr bool GLU_EPI = EPI == EPI_GLU || EPI == EPI_GLU_SG || EPI == EPI_GLU_BWD;
+  g.bias_in_lds = rows16 && modes_ok && (GLU_EPI || ring + bias_bytes <= 160 * 1024) ? 1 : 0;
+  const int shm = ring + (g.bias_in_lds && !GLU_EPI ? bias_bytes : 0);
+  auto kern = k_gemm_nt_ws<C_BF16, NL, ABL, EPI>;
+  static bool attr_done = false;   // per instantiation
+  if (!attr_done) {
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_done = true;
+  }
+  int grid = 256;
+  const int ntiles = g.tiles_m * g.tiles_n;
+  if (grid > ((ntiles + 7) / 8) * 8) grid = ((ntiles + 7) / 8) * 8;
+#ifdef AFM_GEMM_ABLATIONS
+  { const char* eg = getenv("AFM_GRID"); if (eg) grid = atoi(eg); }
+#endif
+  AFM_LAUNCH(kern, dim3(grid), dim3(64 * (8 + NL)), shm, st, g);
+  return AFM_OK;
+}
+
+// ------------------------------------------------------------------------------------------ TN (wgrad)
+// C[m][n] += sum_k A[k][m] B[k][n]: A is dy (rows = tokens, cols = output features m), B is x
+// (rows = tokens, cols = input features n).  LDS tile [64 k-rows][128 cols] e16 = 256-byte rows of
+// 16 chunks; chunk c of row r is stored at chunk c ^ s(r), s(r) = 2*(r&3) + 8*((r>>3)&1): a
+// ds_read_b64_tr_b16 half-wave (2 groups x 4 rows x 4 column quads) then covers all 64 banks once.
+__device__ __forceinline__ int tn_swz(int row) { return ((row & 3) << 1) | (((row >> 3) & 1) << 3); }
+__device__ __forceinline__ int tn_off(int row, int chunk) { return row * 256 + ((chunk ^ tn_swz(row)) << 4); }
+
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+__device__ __forceinline__ e16x4 ds_read_tr(const unsigned char* p) {
+  // ds_read_b64_tr_b16 through the compiler builtin, so hipcc schedules and counts it (lgkmcnt)
+  const s16x4 r = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p);
+  return __builtin_bit_cast(e16x4, r);
+}
+
+__global__ __launch_bounds__(256) void k_gemm_tn(MfmaArgs g) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * 2 * BK * BM * 2];  // [buf][A|B][64][128]
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  const int wm = w >> 1, wn = w & 1;
+  const int ntile = g.tiles_m * g.tiles_n;
+  const int bid = xcd_remap(blockIdx.x, ntile * g.ksplit);
+  // tile index fastest: the workgroups of one XCD share a k-chunk, so the dy / x rows they stream are
+  // fetched from HBM once and served to the other tiles from that XCD's L2
+  const int tile = bid % ntile, ks_id = bid / ntile;
+  const int m0 = (tile / g.tiles_n) * BM, n0 = (tile % g.tiles_n) * BN;
+  const int kbeg = ks_id * g.kchunk, kend = min(g.K, kbeg + g.kchunk);
+
+  // staging: thread -> 4 k-rows x one 16-byte chunk (8 columns) per operand
+  const int srow = t >> 4, sch = t & 15;
+  const bool a_in = m0 + sch * 8 < g.M, b_in = n0 + sch * 8 < g.N;  // M, N % 8 == 0
+  uint4 ra_[4], rb_[4];
+  auto gload = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int k = k0 + srow + 16 * i;
+      const bool kin = k < kend;
+      ra_[i] = (kin && a_in) ? *(const uint4*)(g.A + (int64_t)k * g.lda + m0 + sch * 8) : make_uint4(0, 0, 0, 0);
+      rb_[i] = (kin && b_in) ? *(const uint4*)(g.B + (int64_t)k * g.ldb + n0 + sch * 8) : make_uint4(0, 0, 0, 0);
+    }
+  };
+  // bias gradient: the blocks of the first column tile also sum the dy rows they stage
+  const bool do_cs = g.a_colsum != nullptr && (tile % g.tiles_n) == 0;
+  float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  auto sstore = [&](int buf) {
+    unsigned char* a = lds + buf * (2 * BK * BM * 2);
+    unsigned char* b = a + BK * BM * 2;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r = srow + 16 * i;
+      *(uint4*)(a + tn_off(r, sch)) = ra_[i];
+      *(uint4*)(b + tn_off(r, sch)) = rb_[i];
+      if (do_cs) {
+        const e16x8 v = __builtin_bit_cast(e16x8, ra_[i]);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) cs[j] += (float)v[j];
+      }
+    }
+  };
+
+  f32x4 acc[4][4];  // [im][jn]: D rows = m (A operand), cols = n (B operand)
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int nk = (kend - kbeg + BK - 1) / BK;
+  if (nk > 0) {
+    gload(kbeg);
+    sstore(0);
+  }
+  __syncthreads();
+  // transposed fragment read: lane = 16*grp + 4*q + p supplies row (kb + 8*grp + 4*half + q), the 4
+  // columns (cbase + 4*p ..); it receives, for column cbase + (lane&15), the 4 rows of the block.
+  const int grp = lane >> 4, q = (lane >> 2) & 3, p = lane & 3;
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nk) gload(kbeg + (kt + 1) * BK);
+    const unsigned char* a = lds + buf * (2 * BK * BM * 2);
+    const unsigned char* b = a + BK * BM * 2;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {  // two 32-deep k-slices
+      e16x8 af[4], bfr[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int ca = wm * 64 + i * 16, cb = wn * 64 + i * 16;  // first column of the 16-wide fragment
+        const int r0 = ks * 32 + grp * 8 + q, r1 = r0 + 4;
+        const int cha = (ca >> 3) + (p >> 1), chb = (cb >> 3) + (p >> 1);
+        const e16x4 a0 = ds_read_tr(a + tn_off(r0, cha) + ((p & 1) << 3));
+        const e16x4 a1 = ds_read_tr(a + tn_off(r1, cha) + ((p & 1) << 3));
+        const e16x4 b0 = ds_read_tr(b + tn_off(r0, chb) + ((p & 1) << 3));
+        const e16x4 b1 = ds_read_tr(b + tn_off(r1, chb) + ((p & 1) << 3));
+        af[i] = (e16x8){a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+        bfr[i] = (e16x8){b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = mfma16(af[i], bfr[j], acc[i][j]);
+    }
+    if (kt + 1 < nk) sstore(buf ^ 1);
+    __syncthreads();
+  }
+
+  if (do_cs) {  // 16 row phases x 128 columns of partial sums -> LDS -> one atomic per column
+    float* red = (float*)lds;               // the k-loop ended with a barrier: tiles are dead
+#pragma unroll
+    for (int j = 0; j < 8; ++j) red[srow * 128 + sch * 8 + j] = cs[j];
+    __syncthreads();
+    if (t < 128 && m0 + t < g.M) {
+      float s = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s += red[r * 128 + t];
+      atomicAdd(g.a_colsum + (g.glu_f ? glu_deint(m0 + t, g.glu_f) : m0 + t), s);
+    }
+  }
+  // D[row = fq*4 + r][col = fr] -> C[m = .. + fq*4 + r][n = .. + fr]; fp32 atomics when the
+  // reduction is split over blocks (the gradient buffer accumulates anyway), plain += otherwise.
+  const int fr = lane & 15, fq = lane >> 4;
+  float* C = (float*)g.C;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = n0 + wn * 64 + j * 16 + fr;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = m0 + wm * 64 + i * 16 + fq * 4 + r;
+        if (m < g.M && n < g.N) {
+          float* c = C + (int64_t)(g.glu_f ? glu_deint(m, g.glu_f) : m) * g.ldc + n;
+          if (g.ksplit > 1) atomicAdd(c, acc[i][j][r]);
+          else *c = acc[i][j][r] + (g.accumulate ? *c : 0.f);
+        }
+      }
+    }
+}
+
+// ------------------------------------------------------------------------------------------ TN, LDS-DMA ring
+// wgrad with the operands streamed HBM -> LDS by LDS-DMA into a 3-stage ring (two 64-row k-steps in
+// flight), 8 waves, 256 x 128 output tile (dy columns x input features), split-K over the token rows
+// with fp32 atomics into the gradient buffer.  Stage image: A rows of 256 columns (512 B) and B rows of
+// 128 columns (256 B), 16-byte chunks XOR-swizzled with tn_swz(row) on the source side; fragments by
+// ds_read_b64_tr_b16 exactly as in k_gemm_tn.  Needs K % 64 == 0 (no zero fill with LDS-DMA).
+template <int ABL>
+__global__ __launch_bounds__(512, 2) void k_gemm_tn_ring(MfmaArgs g) {
+  constexpr int S = 3, TBM = 256, TBN = 128, NW = 8, NIW = 6;
+  constexpr int ABYTES = 64 * TBM * 2, STAGE = 64 * (TBM + TBN) * 2;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  const int t = threadIdx.x, lane = t & 63;
+  const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wm = w >> 1, wn = w & 1;
+  const int ntile = g.tiles_m * g.tiles_n;
+  const int bid = xcd_remap(blockIdx.x, ntile * g.ksplit);
+  // tile index fastest: the workgroups of one XCD share a k-chunk, so the dy / x rows they stream are
+  // fetched from HBM once and served to the other tiles from that XCD's L2
+  const int tile = bid % ntile, ks_id = bid / ntile;
+  const int m0 = (tile / g.tiles_n) * TBM, n0 = (tile % g.tiles_n) * TBN;
+  const int kbeg = ks_id * g.kchunk, kend = min(g.K, kbeg + g.kchunk);
+  const int nk = (kend - kbeg) / 64;
+
+  // this wave's pieces: ii = w + 8 j; ii < 32 -> A rows {2 ii, 2 ii + 1} (512 B each), else B rows 4 (ii-32) ..
+  const e16* src[NIW];
+  int64_t pitch[NIW];
+#pragma unroll
+  for (int j = 0; j < NIW; ++j) {
+    const int ii = w + NW * j;
+    if (ii < 32) {
+      const int r = ii * 2 + (lane >> 5);
+      const int c = (lane & 31) ^ tn_swz(r);
+      src[j] = g.A + (int64_t)(kbeg + r) * g.lda + min(m0 + c * 8, g.M - 8);
+      pitch[j] = (int64_t)64 * g.lda;
+    } else {
+      const int r = (ii - 32) * 4 + (lane >> 4);
+      const int c = (lane & 15) ^ tn_swz(r);
+      src[j] = g.B + (int64_t)(kbeg + r) * g.ldb + min(n0 + c * 8, g.N - 8);
+      pitch[j] = (int64_t)64 * g.ldb;
+    }
+  }
+  auto issue = [&](int kt) {
+    unsigned char* st = lds + (kt % S) * STAGE;
+    if (ABL == 2) return;
+#pragma unroll
+    for (int j = 0; j < NIW; ++j)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[j] + kt * pitch[j]),
+                                       (__attribute__((address_space(3))) void*)(st + (w + NW * j) * 1024), 16, 0, 0);
+  };
+  auto offA = [](int row, int chunk) { return row * 512 + ((chunk ^ tn_swz(row)) << 4); };
+  auto offB = [](int row, int chunk) { return row * 256 + ((chunk ^ tn_swz(row)) << 4); };
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const bool do_cs = g.a_colsum != nullptr && (tile % g.tiles_n) == 0 && wn == 0;
+  float cs[4] = {0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll
+  for (int s = 0; s < S - 1; ++s)
+    if (s < nk) issue(s);
+  // Transposed-fragment addresses, hoisted: a read is  stage + lane_off[i] + (ks*32 + 4*half) * pitch.
+  // The swizzle of row r = ks*32 + grp*8 + q (+4) is tn_swz(r) = 2q | 8(grp&1): lane-constant, so only
+  // the fragment index i needs its own per-lane offset (8 VGPRs) and the loop issues reads with
+  // immediate offsets instead of recomputing the XOR address (2 VALU ops per read before).
+  const int grp = lane >> 4, q = (lane >> 2) & 3, p = lane & 3;
+  int laneA[4], laneB[4];
+  {
+    const int lrow = grp * 8 + q, swz = tn_swz(lrow), sub = (p & 1) << 3;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int cha = ((wm * 64 + i * 16) >> 3) + (p >> 1), chb = ((wn * 64 + i * 16) >> 3) + (p >> 1);
+      laneA[i] = lrow * 512 + ((cha ^ swz) << 4) + sub;
+      laneB[i] = ABYTES + lrow * 256 + ((chb ^ swz) << 4) + sub;
+    }
+  }
+  for (int kt = 0; kt < nk; ++kt) {
+    const int later = min(S - 2, nk - 1 - kt);
+    if (later >= S - 2) wait_vmcnt<NIW * (S - 2)>(); else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    if (kt + S - 1 < nk) issue(kt + S - 1);
+    const unsigned char* a = lds + (kt % S) * STAGE;
+    if (ABL == 1) continue;
+    // fragment reads in inline asm: the ds_read_tr builtin makes hipcc drain the whole LDS-DMA ring
+    // (s_waitcnt vmcnt(0)) in front of every k-step; asm reads carry immediate offsets and are waited
+    // for by hand (lgkmcnt(0) + sched_barrier, cdna_hip_programming.md 5.7 form iii)
+    unsigned va[4], vb[4];
+    const unsigned sbase = (unsigned)(uintptr_t)a;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { va[i] = sbase + (unsigned)laneA[i]; vb[i] = sbase + (unsigned)laneB[i]; }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {  // two 32-deep k-slices
+      s16x4 a0[4], a1[4], b0[4], b1[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        if (ks == 0) {
+          asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(a0[i]) : "v"(va[i]));
+          asm volatile("ds_read_b64_tr_b16 %0, %1 offset:2048" : "=v"(a1[i]) : "v"(va[i]));
+          asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(b0[i]) : "v"(vb[i]));
+          asm volatile("ds_read_b64_tr_b16 %0, %1 offset:1024" : "=v"(b1[i]) : "v"(vb[i]));
+        } else {
+          asm volatile("ds_read_b64_tr_b16 %0, %1 offset:16384" : "=v"(a0[i]) : "v"(va[i]));
+          asm volatile("ds_read_b64_tr_b16 %0, %1 offset:18432" : "=v"(a1[i]) : "v"(va[i]));
+          asm volatile("ds_read_b64_tr_b16 %0, %1 offset:8192" : "=v"(b0[i]) : "v"(vb[i]));
+          asm volatile("ds_read_b64_tr_b16 %0, %1 offset:9216" : "=v"(b1[i]) : "v"(vb[i]));
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      e16x8 af[4], bfr[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const e16x4 x0 = __builtin_bit_cast(e16x4, a0[i]), x1 = __builtin_bit_cast(e16x4, a1[i]);
+        const e16x4 y0 = __builtin_bit_cast(e16x4, b0[i]), y1 = __builtin_bit_cast(e16x4, b1[i]);
+        af[i] = (e16x8){x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
+        bfr[i] = (e16x8){y0[0], y0[1], y0[2], y0[3], y1[0], y1[1], y1[2], y1[3]};
+      }
+      if (do_cs) {   // bias gradient: column sums of dy from the A fragments (lane: column fr, 8 rows)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 8; ++j) cs[i] += (float)af[i][j];
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = mfma16(af[i], bfr[j], acc[i][j]);
+    }
+  }
+  const int fr = lane & 15, fq = lane >> 4;
+  if (do_cs) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float s = cs[i];
+      s += __shfl_xor(s, 16, 64);
+      s += __shfl_xor(s, 32, 64);
+      const int mm = m0 + wm * 64 + i * 16 + fr;
+      if (fq == 0 && mm < g.M) atomicAdd(g.a_colsum + (g.glu_f ? glu_deint(mm, g.glu_f) : mm), s);
+    }
+  }
+  float* C = (float*)g.C;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = n0 + wn * 64 + j * 16 + fr;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int mm = m0 + wm * 64 + i * 16 + fq * 4 + r;
+        if (mm < g.M && n < g.N) {
+          float* c = C + (int64_t)(g.glu_f ? glu_deint(mm, g.glu_f) : mm) * g.ldc + n;
+          if (g.ksplit > 1) atomicAdd(c, acc[i][j][r]);
+          else *c = acc[i][j][r] + (g.accumulate ? *c : 0.f);
+        }
+      }
+    }
+}
+
+// Same kernel on 256 x 256 tiles: 8 waves of 128 x 64 (2 x 4), two 64-KiB ring slots.  Per FLOP a quarter
+// less L2->LDS fill and a quarter fewer transposed LDS reads than the 256 x 128 form, and 64 MFMAs per
+// wave between barriers; needs more split-K (fewer tiles), i.e. more fp32 atomics on the small dW.
+__global__ __launch_bounds__(512) void k_gemm_tn_ring256(MfmaArgs g) {
+  constexpr int S = 2, TBM = 256, TBN = 256, NW = 8, NIW = 8;
+  constexpr int ABYTES = 64 * TBM * 2, STAGE = 64 * (TBM + TBN) * 2;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  const int t = threadIdx.x, lane = t & 63;
+  const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wm = w >> 2, wn = w & 3;
+  const int ntile = g.tiles_m * g.tiles_n;
+  const int bid = xcd_remap(blockIdx.x, ntile * g.ksplit);
+  const int tile = bid % ntile, ks_id = bid / ntile;     // tile index fastest: an XCD's workgroups share a k-chunk
+  const int m0 = (tile / g.tiles_n) * TBM, n0 = (tile % g.tiles_n) * TBN;
+  const int kbeg = ks_id * g.kchunk, kend = min(g.K, kbeg + g.kchunk);
+  const int nk = (kend - kbeg) / 64;
+
+  // this wave's pieces: ii = w + 8 j; ii < 32 -> A rows {2 ii, 2 ii + 1}, else B rows {2 (ii-32), +1} (512 B rows)
+  const e16* src[NIW];
+  int64_t pitch[NIW];
+#pragma unroll
+  for (int j = 0; j < NIW; ++j) {
+    const int ii = w + NW * j;
+    const int r = (ii & 31) * 2 + (lane >> 5);
+    const int c = (lane & 31) ^ tn_swz(r);
+    if (ii < 32) {
+      src[j] = g.A + (int64_t)(kbeg + r) * g.lda + min(m0 + c * 8, g.M - 8);
+      pitch[j] = (int64_t)64 * g.lda;
+    } else {
+      src[j] = g.B + (int64_t)(kbeg + r) * g.ldb + min(n0 + c * 8, g.N - 8);
+      pitch[j] = (int64_t)64 * g.ldb;
+    }
+  }
+  auto issue = [&](int kt) {
+    unsigned char* st = lds + (kt % S) * STAGE;
+#pragma unroll
+    for (int j = 0; j < NIW; ++j)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[j] + kt * pitch[j]),
+                                       (__attribute__((address_space(3))) void*)(st + (w + NW * j) * 1024), 16, 0, 0);
+  };
+
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const bool do_cs = g.a_colsum != nullptr && (tile % g.tiles_n) == 0 && wn == 0;
+  float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+
+  if (nk > 0) issue(0);
+  const int grp = lane >> 4, q = (lane >> 2) & 3, p = lane & 3;
+  int laneA[8], laneB[4];
+  {
+    const int lrow = grp * 8 + q, swz = tn_swz(lrow), sub = (p & 1) << 3;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) laneA[i] = lrow * 512 + (((((wm * 128 + i * 16) >> 3) + (p >> 1)) ^ swz) << 4) + sub;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) laneB[j] = ABYTES + lrow * 512 + (((((wn * 64 + j * 16) >> 3) + (p >> 1)) ^ swz) << 4) + sub;
+  }
+  for (int kt = 0; kt < nk; ++kt) {
+    wait_vmcnt<0>();                       // two slots: only this step's pieces are in flight
+    __builtin_amdgcn_s_barrier();
+    if (kt + 1 < nk) issue(kt + 1);
+    const unsigned sbase = (unsigned)(uintptr_t)(lds + (kt % S) * STAGE);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {       // two 32-deep k-slices; asm reads as in k_gemm_tn_ring
+      s16x4 a0[8], a1[8], b0[4], b1[4];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const unsigned va = sbase + (unsigned)laneA[i];
+        if (ks == 0) {
+          asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(a0[i]) : "v"(va));
+          asm volatile("ds_read_b64_tr_b16 %0, %1 offset:2048" : "=v"(a1[i]) : "v"(va));
+        } else {
+          asm volatile("ds_read_b64_tr_b16 %0, %1 offset:16384" : "=v"(a0[i]) : "v"(va));
+          asm volatile("ds_read_b64_tr_b16 %0, %1 offset:18432" : "=v"(a1[i]) : "v"(va));
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const unsigned vb = sbase + (unsigned)laneB[j];
+        if (ks == 0) {
+          asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(b0[j]) : "v"(vb));
+          asm volatile("ds_read_b64_tr_b16 %0, %1 offset:2048" : "=v"(b1[j]) : "v"(vb));
+        } else {
+          asm volatile("ds_read_b64_tr_b16 %0, %1 offset:16384" : "=v"(b0[j]) : "v"(vb));
+          asm volatile("ds_read_b64_tr_b16 %0, %1 offset:18432" : "=v"(b1[j]) : "v"(vb));
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      e16x8 af[8], bfr[4];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const e16x4 x0 = __builtin_bit_cast(e16x4, a0[i]), x1 = __builtin_bit_cast(e16x4, a1[i]);
+        af[i] = (e16x8){x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const e16x4 y0 = __builtin_bit_cast(e16x4, b0[j]), y1 = __builtin_bit_cast(e16x4, b1[j]);
+        bfr[j] = (e16x8){y0[0], y0[1], y0[2], y0[3], y1[0], y1[1], y1[2], y1[3]};
+      }
+      if (do_cs) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+          for (int j = 0; j < 8; ++j) cs[i] += (float)af[i][j];
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = mfma16(af[i], bfr[j], acc[i][j]);
+    }
+  }
+  const int fr = lane & 15, fq = lane >> 4;
+  if (do_cs) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      float s = cs[i];
+      s += __shfl_xor(s, 16, 64);
+      s += __shfl_xor(s, 32, 64);
+      const int mm = m0 + wm * 128 + i * 16 + fr;
+      if (fq == 0 && mm < g.M) atomicAdd(g.a_colsum + (g.glu_f ? glu_deint(mm, g.glu_f) : mm), s);
+    }
+  }
+  float* C = (float*)g.C;
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = n0 + wn * 64 + j * 16 + fr;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int mm = m0 + wm * 128 + i * 16 + fq * 4 + r;
+        if (mm < g.M && n < g.N) {
+          float* c = C + (int64_t)(g.glu_f ? glu_deint(mm, g.glu_f) : mm) * g.ldc + n;
+          if (g.ksplit > 1) atomicAdd(c, acc[i][j][r]);
+          else *c = acc[i][j][r] + (g.accumulate ? *c : 0.f);
+        }
+      }
+    }
+}
+
+}  // namespace AFM_E16_NS
+using namespace AFM_E16_NS;
+
+// ------------------------------------------------------------------------------------------ dispatch
+static inline bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+
+int AFM_E16_FN(afm_gemm_mfma_try)(const afm_gemm_desc* d, hipStream_t st) {
+  if (d->a_dtype != AFM_E16 || d->b_dtype != AFM_E16) return AFM_ERR_UNSUPPORTED;
+  MfmaArgs g;
+  g.M = d->M; g.N = d->N; g.K = d->K; g.lda = d->lda; g.ldb = d->ldb; g.ldc = d->ldc;
+  g.A = (const e16*)d->A; g.B = (const e16*)d->B; g.C = d->C;
+  g.bias = d->bias; g.residual = d->residual; g.pre_act = d->pre_act; g.a_colsum = d->a_colsum;
+  g.act = d->act; g.accumulate = d->accumulate;
+  g.dd = afm_make_drop(&d->drop);
+  g.tiles_m = (d->M + BM - 1) / BM; g.tiles_n = (d->N + BN - 1) / BN;
+  g.ksplit = 1; g.kchunk = d->K; g.bias_in_lds = 0;
+  g.glu_f = d->glu_rows;
+  g.stamps = nullptr;
+#ifdef AFM_GEMM_ABLATIONS
+  { const char* e = getenv("AFM_STAMPS"); if (e) g.stamps = (unsigned long long*)strtoull(e, nullptr, 0); }
+#endif
+  if (!aligned16(d->A) || !aligned16(d->B) || (d->lda & 7) || (d->ldb & 7)) return AFM_ERR_UNSUPPORTED;
+  if (!d->transA && d->transB) {  // NT
+    if ((d->K & 7) || d->K < 32 || d->N < 16) return AFM_ERR_UNSUPPORTED;
+    if (d->bias && !aligned16(d->bias)) return AFM_ERR_UNSUPPORTED;
+    if (!aligned16(d->C) || (d->residual && !aligned16(d->residual)) || (d->pre_act && !aligned16(d->pre_act)))
+      return AFM_ERR_UNSUPPORTED;
+    int variant = d->reserved;  // tile-shape experiments (tools/bench_gemm.py); 0 = pick by shape
+    if (d->act >= AFM_ACT_GLU) {
+      // fused gated FFN: whole 256 x 128 tiles through the loader-wave kernel, e16 in / out, contiguous C and pre_act (the
+      // backward form reads pre_act with C's row stride, which may exceed the row: hi planes of pair tensors in mixed mode)
+      const int ncol_c = d->act == AFM_ACT_GLU_BWD ? 2 * d->N : d->N / 2;
+      if ((d->K & 63) || (d->M & 255) || (d->N & 127) || d->c_dtype != AFM_E16 || d->residual || d->accumulate ||
+          (d->act == AFM_ACT_GLU_BWD ? (d->ldc < ncol_c || (d->ldc & 7)) : d->ldc != ncol_c) ||   // GLU_BWD: C and pre_act share ldc
+          (d->drop.p > 0.f && (uint64_t)d->M * (uint64_t)d->N > 0x100000000ull) ||
+          (d->act == AFM_ACT_GLU_BWD && (d->bias || d->drop.p > 0.f)))
+        return AFM_ERR_UNSUPPORTED;
+      int r;
+      if (d->act == AFM_ACT_GLU) r = launch_nt_ws<true, 4, 0, EPI_GLU>(g, st);
+      else if (d->act == AFM_ACT_GLU_SAVE) r = launch_nt_ws<true, 4, 0, EPI_GLU_SG>(g, st);
+      else r = launch_nt_ws<true, 4, 0, EPI_GLU_BWD>(g, st);
+      if (r != AFM_OK) return r;
+      afm_set_last_algo("mfma_nt_glu");
+      return AFM_OK;
+    }
+    if (variant == 0 && (d->K & 63) == 0) {
+      // persistent LDS-DMA ring: 256x128 tiles when there are enough of them to fill the chip,
+      // otherwise 128x128 at two workgroups per CU; anything with K % 64 != 0 keeps the
+      // register-staged kernel (case 100).
+      const int64_t big_tiles = (int64_t)((d->M + 255) / 256) * ((d->N + 127) / 128);
+      variant = (d->N > 128 && big_tiles >= 256) ? 24 : 13;
+      if (d->act >= AFM_ACT_GELU_SAVE_GRAD) variant = 24;   // only the loader-wave / 256x256 kernels know these epilogues
+      // wide outputs of the long encoder sequence: 256x256 tiles (a quarter less L2->LDS fill and a quarter
+      // fewer LDS fragment reads per FLOP, 64 MFMAs per wave between barriers): +7..12 % at N >= 1024
+      const bool small_idx28 = (uint64_t)d->M * (uint64_t)d->N <= 0x100000000ull;
+      if (variant == 24 && d->N >= 1024 && !(d->M & 255) && !(d->N & 255) && (int64_t)(d->M >> 8) * (d->N >> 8) >= 1024 &&
+          d->c_dtype == AFM_E16 && !d->residual && !d->accumulate && !(d->ldc % 8) && d->act != AFM_ACT_RELU &&
+          !(d->pre_act && d->act == AFM_ACT_NONE) && (d->drop.p <= 0.f || small_idx28))
+        variant = 28;
+    }
+    if (d->act >= AFM_ACT_GELU_SAVE_GRAD && variant != 24 && variant != 28) return AFM_ERR_UNSUPPORTED;
+    int r;
+#define NT_CASE(WM, WN, NWM, NWN, BKT) \
+    (d->c_dtype == AFM_E16 ? launch_nt<true, WM, WN, NWM, NWN, BKT>(g, st) : launch_nt<false, WM, WN, NWM, NWN, BKT>(g, st))
+#define PRING_CASE(NWM, NWN, S, BPC) \
+    (d->c_dtype == AFM_E16 ? launch_nt_pring<true, NWM, NWN, S>(g, st, BPC) : launch_nt_pring<false, NWM, NWN, S>(g, st, BPC))
+    switch (variant) {
+      case 12: r = (d->K & 63) ? AFM_ERR_UNSUPPORTED : PRING_CASE(4, 2, 3, 1); break;   // persistent 256x128, 8 waves, 3 stages
+      case 13: r = (d->K & 63) ? AFM_ERR_UNSUPPORTED : PRING_CASE(2, 2, 2, 2); break;   // persistent 128x128, 4 waves, 2 per CU
+      case 28: {   // persistent 256x256 (8 waves of 128x64, 2 stages), whole tiles only, e16 output
+        const bool small_idx = (uint64_t)d->M * (uint64_t)d->N <= 0x100000000ull;
+        if ((d->K & 63) || (d->M & 255) || (d->N & 255) || d->c_dtype != AFM_E16 || d->residual || d->accumulate ||
+            (d->N % 8) || (d->ldc % 8) || d->act == AFM_ACT_RELU || (d->pre_act && d->act == AFM_ACT_NONE) ||
+            (d->drop.p > 0.f && !small_idx)) { r = AFM_ERR_UNSUPPORTED; break; }
+        if (d->act == AFM_ACT_GELU_SAVE_GRAD) r = launch_nt_pring<true, 2, 4, 2, 0, 8, EPI_GELU_SG, false>(g, st, 1);
+        else if (d->act == AFM_ACT_MUL_SAVED) r = launch_nt_pring<true, 2, 4, 2, 0, 8, EPI_MUL, false>(g, st, 1);
+        else if (d->act == AFM_ACT_GELU_BWD) r = launch_nt_pring<true, 2, 4, 2, 0, 8, EPI_GELU_BWD, false>(g, st, 1);
+        else if (d->act == AFM_ACT_GELU) r = launch_nt_pring<true, 2, 4, 2, 0, 8, EPI_GELU, false>(g, st, 1);
+        else if (d->drop.p > 0.f) r = launch_nt_pring<true, 2, 4, 2, 0, 8, EPI_DROP, false>(g, st, 1);
+        else r = launch_nt_pring<true, 2, 4, 2, 0, 8, EPI_PLAIN, false>(g, st, 1);
+        break;
+      }
+      case 22: r = (d->K & 63) ? AFM_ERR_UNSUPPORTED : (d->c_dtype == AFM_E16 ? launch_nt_ws<true, 2>(g, st) : launch_nt_ws<false, 2>(g, st)); break;
+      case 24:   // persistent 256x128, 8 MFMA waves + 4 loader waves, epilogue picked at compile time
+      case 25: { // (25: same tile walk with the generic run-time epilogue, for A/B timing)
+        if (d->K & 63) { r = AFM_ERR_UNSUPPORTED; break; }
+        if (d->c_dtype != AFM_E16) { r = d->act >= AFM_ACT_GELU_SAVE_GRAD ? AFM_ERR_UNSUPPORTED : launch_nt_ws<false, 4>(g, st); break; }
+        int epi = EPI_GENERIC;
+        const bool small_idx = (uint64_t)d->M * (uint64_t)d->N <= 0x100000000ull;
+        const bool dropping = d->drop.p > 0.f;
+        if (variant == 24 && !d->residual && !d->accumulate && (small_idx || !dropping)) {
+          if (d->act == AFM_ACT_GELU_SAVE_GRAD) epi = EPI_GELU_SG;
+          else if (d->act == AFM_ACT_MUL_SAVED) epi = EPI_MUL;
+          else if (d->act == AFM_ACT_GELU_BWD) epi = EPI_GELU_BWD;
+          else if (d->act == AFM_ACT_GELU) epi = EPI_GELU;
+          else if (d->act == AFM_ACT_NONE && !d->pre_act) epi = dropping ? EPI_DROP : EPI_PLAIN;
+        }
+        // the save-grad pair exists only as whole-tile staged epilogues (the fragment epilogue of partial tiles
+        // is kept small: growing it demotes the accumulators of every kernel that inlines it to scratch)
+        if (d->act >= AFM_ACT_GELU_SAVE_GRAD && (epi == EPI_GENERIC || (d->M & 255) || (d->N & 127) || (d->ldc % 8))) {
+          r = AFM_ERR_UNSUPPORTED; break;   // FMA kernel
+        }
+        switch (epi) {
+          case EPI_PLAIN: r = launch_nt_ws<true, 4, 0, EPI_PLAIN>(g, st); break;
+          case EPI_DROP: r = launch_nt_ws<true, 4, 0, EPI_DROP>(g, st); break;
+          case EPI_GELU: r = launch_nt_ws<true, 4, 0, EPI_GELU>(g, st); break;
+          case EPI_GELU_BWD: r = launch_nt_ws<true, 4, 0, EPI_GELU_BWD>(g, st); break;
+          case EPI_GELU_SG: r = launch_nt_ws<true, 4, 0, EPI_GELU_SG>(g, st); break;
+          case EPI_MUL: r = launch_nt_ws<true, 4, 0, EPI_MUL>(g, st); break;
+          default: r = launch_nt_ws<true, 4>(g, st); break;
+        }
+        break;
+      }
+#ifdef AFM_GEMM_ABLATIONS
+      case 241: r = launch_nt_ws<true, 4, 1>(g, st); break;
+      case 242: r = launch_nt_ws<true, 4, 2>(g, st); break;
+      case 243: r = launch_nt_ws<true, 4, 3>(g, st); break;
+      case 244: r = launch_nt_ws<true, 4, 4>(g, st); break;
+      case 246: r = launch_nt_ws<true, 4, 6>(g, st); break;
+      case 247: r = launch_nt_ws<true, 4, 7>(g, st); break;
+      case 121: r = launch_nt_pring<true, 4, 2, 3, 1>(g, st, 1); break;
+      case 122: r = launch_nt_pring<true, 4, 2, 3, 2>(g, st, 1); break;
+      case 124: r = launch_nt_pring<true, 4, 2, 3, 4>(g, st, 1); break;
+      case 125: r = launch_nt_pring<true, 4, 2, 3, 5>(g, st, 1); break;
+      case 126: r = launch_nt_pring<true, 4, 2, 3, 6>(g, st, 1); break;
+      case 127: r = launch_nt_pring<true, 4, 2, 3, 7>(g, st, 1); break;
+#endif
+      default: r = NT_CASE(4, 4, 2, 2, 64); break;                                       // register-staged 128x128
+    }
+#undef PRING_CASE
+#undef NT_CASE
+    if (r != AFM_OK) return r;
+    afm_set_last_algo("mfma_nt");
+    return AFM_OK;
+  }
+  if (d->transA && !d->transB) {  // TN: the wgrad form only
+    if (d->c_dtype != AFM_F32 || d->bias || d->residual || d->pre_act || d->act != AFM_ACT_NONE || d->drop.p > 0.f ||
+        (d->a_colsum && ((uintptr_t)d->a_colsum & 3)))
+      return AFM_ERR_UNSUPPORTED;
+    if ((d->M & 7) || (d->N & 7) || d->K < 64 || d->M < 16 || d->N < 16) return AFM_ERR_UNSUPPORTED;
+    // 256 x 256 tiles when the gradient matrix has at least 8 of them and the token count is long enough for
+    // every workgroup to run >= 64 k-steps (measured at 131072 tokens: +4..18 % at 1536x512, 2048x512, 512x2048;
+    // -3 % at 512x512, which keeps the 256 x 128 form, as do the decoder's 16 k-token shapes); 105 / 106 force a form
+    const bool want256 = d->reserved == 105 ||
+                         (d->reserved == 0 && d->K >= 65536 && (int64_t)((d->M + 255) / 256) * ((d->N + 255) / 256) >= 8);
+    if (want256 && (d->K & 63) == 0 && d->K >= 4096 && d->M >= 256 && d->N >= 256) {
+      // 256 x 256 tiles
+      g.tiles_m = (d->M + 255) / 256; g.tiles_n = (d->N + 255) / 256;
+      const int tiles = g.tiles_m * g.tiles_n;
+      int ksplit = tiles >= 256 ? 1 : 256 / tiles;
+      const int maxs = d->K / 1024;
+      if (ksplit > maxs) ksplit = maxs;
+      if (ksplit < 1) ksplit = 1;
+      int kchunk = ((d->K / 64 + ksplit - 1) / ksplit) * 64;
+      ksplit = (d->K + kchunk - 1) / kchunk;
+      g.ksplit = ksplit; g.kchunk = kchunk;
+      if (ksplit > 1 && !d->accumulate) {
+        if (hipMemset2DAsync(d->C, sizeof(float) * d->ldc, 0, sizeof(float) * d->N, d->M, st) != hipSuccess)
+          return AFM_ERR_LAUNCH;
+      }
+      static bool attr256 = false;
+      if (!attr256) {
+        (void)hipFuncSetAttribute((const void*)k_gemm_tn_ring256, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 64 * 512 * 2);
+        attr256 = true;
+      }
+      AFM_LAUNCH(k_gemm_tn_ring256, dim3(tiles * ksplit), dim3(512), 2 * 64 * 512 * 2, st, g);
+      afm_set_last_algo(ksplit > 1 ? "mfma_tn_ring256_splitk" : "mfma_tn_ring256");
+      return AFM_OK;
+    }
+    if (d->reserved != 100 && (d->K & 63) == 0 && d->K >= 4096 && d->M >= 64 && d->N >= 64) {
+      // LDS-DMA ring kernel: 256 x 128 tiles, one 8-wave workgroup per CU, split-K to fill the chip
+      g.tiles_m = (d->M + 255) / 256; g.tiles_n = (d->N + 127) / 128;
+      const int tiles = g.tiles_m * g.tiles_n;
+      int ksplit = tiles >= 256 ? 1 : 256 / tiles;   // at most one workgroup per CU, no ragged second wave
+      const int maxs = d->K / 1024;            // >= 16 k-steps per workgroup
+      if (ksplit > maxs) ksplit = maxs;
+      if (ksplit < 1) ksplit = 1;
+      int kchunk = ((d->K / 64 + ksplit - 1) / ksplit) * 64;
+      ksplit = (d->K + kchunk - 1) / kchunk;
+      g.ksplit = ksplit; g.kchunk = kchunk;
+      if (ksplit > 1 && !d->accumulate) {
+        if (hipMemset2DAsync(d->C, sizeof(float) * d->ldc, 0, sizeof(float) * d->N, d->M, st) != hipSuccess)
+          return AFM_ERR_LAUNCH;
+      }
+      static bool attr_done = false;
+      if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)k_gemm_tn_ring<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 64 * 384 * 2);
+        (void)hipFuncSetAttribute((const void*)k_gemm_tn_ring<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 64 * 384 * 2);
+        (void)hipFuncSetAttribute((const void*)k_gemm_tn_ring<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 64 * 384 * 2);
+        attr_done = true;
+      }
+      if (d->reserved == 101) AFM_LAUNCH(k_gemm_tn_ring<1>, dim3(tiles * ksplit), dim3(512), 3 * 64 * 384 * 2, st, g);
+      else if (d->reserved == 102) AFM_LAUNCH(k_gemm_tn_ring<2>, dim3(tiles * ksplit), dim3(512), 3 * 64 * 384 * 2, st, g);
+      else AFM_LAUNCH(k_gemm_tn_ring<0>, dim3(tiles * ksplit), dim3(512), 3 * 64 * 384 * 2, st, g);
+      afm_set_last_algo(ksplit > 1 ? "mfma_tn_ring_splitk" : "mfma_tn_ring");
+      return AFM_OK;
+    }
+    const int tiles = g.tiles_m * g.tiles_n;
+    int ksplit = 1;
+    if (tiles < 512) {
+      ksplit = (768 + tiles - 1) / tiles;
+      const int maxs = (d->K + 511) / 512;  // at least 8 k-steps per block
+      if (ksplit > maxs) ksplit = maxs;
+      if (ksplit < 1) ksplit = 1;
+    }
+    int kchunk = (d->K + ksplit - 1) / ksplit;
+    kchunk = (kchunk + BK - 1) / BK * BK;
+    ksplit = (d->K + kchunk - 1) / kchunk;
+    g.ksplit = ksplit; g.kchunk = kchunk;
+    if (ksplit > 1 && !d->accumulate) {
+      if (hipMemset2DAsync(d->C, sizeof(float) * d->ldc, 0, sizeof(float) * d->N, d->M, st) != hipSuccess)
+        return AFM_ERR_LAUNCH;
+    }
+    AFM_LAUNCH(k_gemm_tn, dim3(tiles * ksplit), dim3(256), 0, st, g);
+    afm_set_last_algo(ksplit > 1 ? "mfma_tn_splitk" : "mfma_tn");
+    return AFM_OK;
+  }
+  return AFM_ERR_UNSUPPORTED;
+}

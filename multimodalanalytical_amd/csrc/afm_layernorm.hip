@@ -35,6 +35,7 @@ __global__ void k_ln_fwd(const float* x, const float* __restrict__ gamma,
       v[i] = j < d ? xr[j] : 0.f;
       if (add && j < d) {   // fused residual add: the stream value is written back once
         const float a = add_dtype == AFM_BF16 ? ld_rc((const bf16*)add, r, j, d)
+                        : add_dtype == AFM_F16 ? ld_rc((const f16*)add, r, j, d)
                         : add_dtype == AFM_BF16X2 ? ld_rc((const x2*)add, r, j, 2 * d) : ld_rc((const float*)add, r, j, d);
         v[i] += afm_drop(adrop, (uint64_t)r * (uint64_t)d + (uint64_t)j, a);   // branch dropout rides on the add
         x_sum[r * (int64_t)d + j] = v[i];
@@ -80,7 +81,15 @@ __device__ __forceinline__ F8 ld8(const bf16* p) {
   const bf16x8 v = *(const bf16x8*)p;
   return {(f32x4){(float)v[0], (float)v[1], (float)v[2], (float)v[3]}, (f32x4){(float)v[4], (float)v[5], (float)v[6], (float)v[7]}};
 }
+__device__ __forceinline__ F8 ld8(const f16* p) {
+  const f16x8 v = *(const f16x8*)p;
+  return {(f32x4){(float)v[0], (float)v[1], (float)v[2], (float)v[3]}, (f32x4){(float)v[4], (float)v[5], (float)v[6], (float)v[7]}};
+}
 __device__ __forceinline__ void st8(float* p, const F8& v) { *(f32x4*)p = v.lo; *(f32x4*)(p + 4) = v.hi; }
+__device__ __forceinline__ void st8(f16* p, const F8& v) {
+  f16x8 o = {(f16)v.lo[0], (f16)v.lo[1], (f16)v.lo[2], (f16)v.lo[3], (f16)v.hi[0], (f16)v.hi[1], (f16)v.hi[2], (f16)v.hi[3]};
+  *(f16x8*)p = o;
+}
 __device__ __forceinline__ void st8(bf16* p, const F8& v) {
   bf16x8 o = {(bf16)v.lo[0], (bf16)v.lo[1], (bf16)v.lo[2], (bf16)v.lo[3], (bf16)v.hi[0], (bf16)v.hi[1], (bf16)v.hi[2], (bf16)v.hi[3]};
   *(bf16x8*)p = o;
@@ -88,12 +97,14 @@ __device__ __forceinline__ void st8(bf16* p, const F8& v) {
 // the same with the lo-plane offset of the split-pair dtype as second argument (ignored by plain dtypes)
 __device__ __forceinline__ F8 ld8(const float* p, int) { return ld8(p); }
 __device__ __forceinline__ F8 ld8(const bf16* p, int) { return ld8(p); }
+__device__ __forceinline__ F8 ld8(const f16* p, int) { return ld8(p); }
 __device__ __forceinline__ F8 ld8(const x2* p, int lo) {
   const F8 a = ld8((const bf16*)p), b = ld8((const bf16*)p + lo);
   return {a.lo + b.lo, a.hi + b.hi};
 }
 __device__ __forceinline__ void st8(float* p, const F8& v, int) { st8(p, v); }
 __device__ __forceinline__ void st8(bf16* p, const F8& v, int) { st8(p, v); }
+__device__ __forceinline__ void st8(f16* p, const F8& v, int) { st8(p, v); }
 __device__ __forceinline__ void st8(x2* p, const F8& v, int lo) {
   const float x[8] = {v.lo[0], v.lo[1], v.lo[2], v.lo[3], v.hi[0], v.hi[1], v.hi[2], v.hi[3]};
   bf16x8 h, l;
@@ -240,7 +251,7 @@ extern "C" int afm_layernorm_fwd(const afm_ln_shape* s, const float* x, const fl
                                  const float* beta, const float* pos, void* y, float* mean,
                                  float* rstd, const void* add, float* x_sum, void* stream) {
   if (!s || !x || !gamma || !beta || !y || s->rows < 0 || s->d <= 0) return AFM_ERR_ARG;
-  if (add && (!x_sum || s->add_dtype < AFM_F32 || s->add_dtype > AFM_BF16X2 || s->seg_len != 0)) return AFM_ERR_ARG;
+  if (add && (!x_sum || s->add_dtype < AFM_F32 || s->add_dtype > AFM_F16 || s->seg_len != 0)) return AFM_ERR_ARG;
   const int add_dtype = s->add_dtype;
   const DropDev adrop = afm_make_drop(add ? &s->add_drop : nullptr);
   if (s->d > 64 * LN_MAXV) return AFM_ERR_UNSUPPORTED;
@@ -248,7 +259,7 @@ extern "C" int afm_layernorm_fwd(const afm_ln_shape* s, const float* x, const fl
   int64_t g = (s->rows + 3) / 4;
   if (g > 2048) g = 2048;
   hipStream_t st = (hipStream_t)stream;
-  if (s->y_dtype < AFM_F32 || s->y_dtype > AFM_BF16X2) return AFM_ERR_ARG;
+  if (s->y_dtype < AFM_F32 || s->y_dtype > AFM_F16) return AFM_ERR_ARG;
   if (s->seg_len == 0 && !pos && (s->d % 8) == 0 && s->d <= 2048 && s->rows >= 64) {   // vectorised path
 #define LN_FV(TY, TA, NC) AFM_LAUNCH((k_ln_fwd_vec<TY, TA, NC>), dim3((int)g), dim3(256), 0, st, x, gamma, beta, (TY*)y, mean, \
                                      rstd, s->rows, s->d, s->eps, (const TA*)add, x_sum, adrop)
@@ -256,7 +267,8 @@ extern "C" int afm_layernorm_fwd(const afm_ln_shape* s, const float* x, const fl
     // the branch added in front of the norm has the dtype of the mode's activations or fp32
     if (s->y_dtype == AFM_BF16) { if (add_dtype == AFM_BF16) LN_FV2(bf16, bf16); else if (add_dtype == AFM_F32) LN_FV2(bf16, float); else return AFM_ERR_UNSUPPORTED; }
     else if (s->y_dtype == AFM_BF16X2) { if (add_dtype == AFM_BF16X2) LN_FV2(x2, x2); else if (add_dtype == AFM_F32) LN_FV2(x2, float); else return AFM_ERR_UNSUPPORTED; }
-    else { if (add_dtype == AFM_BF16) LN_FV2(float, bf16); else if (add_dtype == AFM_F32) LN_FV2(float, float); else LN_FV2(float, x2); }
+    else if (s->y_dtype == AFM_F16) { if (add_dtype == AFM_F16) LN_FV2(f16, f16); else if (add_dtype == AFM_F32) LN_FV2(f16, float); else return AFM_ERR_UNSUPPORTED; }
+    else { if (add_dtype == AFM_BF16) LN_FV2(float, bf16); else if (add_dtype == AFM_F32) LN_FV2(float, float); else if (add_dtype == AFM_F16) LN_FV2(float, f16); else LN_FV2(float, x2); }
 #undef LN_FV2
 #undef LN_FV
     return AFM_OK;
@@ -390,12 +402,12 @@ extern "C" int afm_layernorm_bwd(const afm_ln_shape* s, const void* dy, const fl
   const int g = ln_bwd_blocks(s->rows);
   hipStream_t st = (hipStream_t)stream;
   const size_t shm = sizeof(float) * 8 * s->d;
-  if (s->y_dtype < AFM_F32 || s->y_dtype > AFM_BF16X2) return AFM_ERR_ARG;
+  if (s->y_dtype < AFM_F32 || s->y_dtype > AFM_F16) return AFM_ERR_ARG;
   if (s->seg_len == 0 && (s->d % 8) == 0 && s->d <= 2048 && s->rows >= 64) {   // vectorised path
 #define LN_BV(TY, NC) AFM_LAUNCH((k_ln_bwd_vec<TY, NC>), dim3(g), dim3(256), shm, st, (const TY*)dy, x, gamma, mean, rstd, dres, dx, \
                                  partial, s->rows, s->d, (TY*)dx_drop, dd)
 #define LN_BV2(TY) do { if (s->d <= 512) LN_BV(TY, 1); else if (s->d <= 1024) LN_BV(TY, 2); else LN_BV(TY, 4); } while (0)
-    if (s->y_dtype == AFM_BF16) LN_BV2(bf16); else if (s->y_dtype == AFM_BF16X2) LN_BV2(x2); else LN_BV2(float);
+    if (s->y_dtype == AFM_BF16) LN_BV2(bf16); else if (s->y_dtype == AFM_BF16X2) LN_BV2(x2); else if (s->y_dtype == AFM_F16) LN_BV2(f16); else LN_BV2(float);
 #undef LN_BV2
 #undef LN_BV
     AFM_LAUNCH(k_ln_bwd_reduce, dim3((2 * s->d + 63) / 64, g >= 64 ? 16 : 1), dim3(256), 0, st, partial, dgamma, dbeta, g, s->d);

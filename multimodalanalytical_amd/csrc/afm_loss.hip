@@ -61,9 +61,10 @@ extern "C" int afm_ce_fwd(const float* logits, const int64_t* labels, int64_t ro
 template <typename T>
 __global__ void k_ce_bwd(const float* __restrict__ logits, const int64_t* __restrict__ labels,
                          const float* __restrict__ row_lse, const float* __restrict__ stats,
-                         float grad_scale, T* __restrict__ dl, int lddl, int64_t rows, int V, int ld) {
+                         float grad_scale, const float* __restrict__ scale_dev, T* __restrict__ dl, int lddl, int64_t rows, int V,
+                         int ld) {
   const float cnt = stats[1];
-  const float gs = cnt > 0.f ? grad_scale / cnt : 0.f;
+  const float gs = cnt > 0.f ? grad_scale * (scale_dev ? scale_dev[0] : 1.f) / cnt : 0.f;
   const int ncol = lddl / RowMul<T>::v;     // every column of the row (padding beyond V is zeroed), per plane
   const int64_t total = rows * (int64_t)ncol;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
@@ -82,7 +83,7 @@ __global__ void k_ce_bwd(const float* __restrict__ logits, const int64_t* __rest
 }
 
 extern "C" int afm_ce_bwd(const float* logits, const int64_t* labels, const float* row_lse,
-                          const float* stats, float grad_scale, void* dlogits, int32_t dl_dtype,
+                          const float* stats, float grad_scale, const float* scale_dev, void* dlogits, int32_t dl_dtype,
                           int32_t lddl, int64_t rows, int32_t V, int32_t ld, void* stream) {
   if (!logits || !labels || !row_lse || !stats || !dlogits || rows < 0 || V <= 0 || ld < V ||
       lddl < V * (dl_dtype == AFM_BF16X2 ? 2 : 1))
@@ -92,6 +93,6 @@ extern "C" int afm_ce_bwd(const float* logits, const int64_t* labels, const floa
   if (g > 2048) g = 2048;
   hipStream_t st = (hipStream_t)stream;
   AFM_DT_SWITCH(dl_dtype, T, AFM_LAUNCH(k_ce_bwd<T>, dim3((int)g), dim3(256), 0, st, logits, labels, row_lse, stats,
-                                        grad_scale, (T*)dlogits, lddl, rows, V, ld));
+                                        grad_scale, scale_dev, (T*)dlogits, lddl, rows, V, ld));
   return AFM_OK;
 }

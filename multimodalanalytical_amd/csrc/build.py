@@ -4,8 +4,10 @@ The library is the product's compute path; there is no CPU fallback.  hipcc cros
 without a GPU, so this runs in the build container and the .so travels to the GPU box.
 """
 import concurrent.futures as cf
+import fcntl
 import hashlib
 import os
+import re
 import shutil
 import subprocess
 import sys
@@ -40,19 +42,52 @@ def _sources():
     return sorted(f for f in os.listdir(HERE) if f.endswith(".hip"))
 
 
+_INC = re.compile(r'^\s*#\s*include\s+"([^"]+)"', re.M)
+
+
+def _closure(path, seen=None):
+    """`path` and every header it includes with quotes, transitively (csrc/ and include/ only)."""
+    seen = [] if seen is None else seen
+    if path in seen:
+        return seen
+    seen.append(path)
+    with open(path, "r") as fh:
+        text = fh.read()
+    for name in _INC.findall(text):
+        for d in (HERE, os.path.join(ROOT, "include")):
+            cand = os.path.join(d, name)
+            if os.path.exists(cand):
+                _closure(cand, seen)
+                break
+    return seen
+
+
 def _digest(path, extra=b""):
+    """sha1 of a source, the headers it (transitively) includes and the flags: an object is stale exactly when one of
+    them changed (the single-pass MFMA kernels live in *_impl.h files that two .hip files instantiate)."""
     h = hashlib.sha1(extra)
-    for f in [path] + [os.path.join(HERE, x) for x in sorted(os.listdir(HERE)) if x.endswith(".h")] + \
-            [os.path.join(ROOT, "include", "afm_hip.h")]:
+    for f in _closure(path):
         with open(f, "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()
 
 
 def build(force=False, verbose=False):
+    """Compile what is stale and link.  Safe under `torch.distributed.run`: an exclusive lock file serialises the ranks (the
+    first one builds, the others find everything fresh), the library is linked to a temporary name and renamed into place,
+    and a link stamp (digest of all object digests) forces a relink when an earlier run died between compile and link."""
     os.makedirs(OBJ, exist_ok=True)
+    with open(os.path.join(OBJ, ".lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            return _build_locked(force, verbose)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+
+
+def _build_locked(force, verbose):
     hipcc = _hipcc()
-    jobs, objs = [], []
+    jobs, objs, digs = [], [], []
     for src in _sources():
         sp = os.path.join(HERE, src)
         op = os.path.join(OBJ, src[:-4] + ".o")
@@ -61,6 +96,7 @@ def build(force=False, verbose=False):
         # must not look stale
         dig = _digest(sp, " ".join(FLAGS).replace(ROOT, "$ROOT").encode())
         objs.append(op)
+        digs.append(dig)
         if not force and os.path.exists(op) and os.path.exists(stamp) and open(stamp).read() == dig:
             continue
         jobs.append((sp, op, stamp, dig))
@@ -78,15 +114,22 @@ def build(force=False, verbose=False):
         return sp
 
     if jobs:
-        with cf.ThreadPoolExecutor(max_workers=min(4, len(jobs))) as ex:
+        with cf.ThreadPoolExecutor(max_workers=min(int(os.environ.get("AFM_BUILD_JOBS", "6")), len(jobs))) as ex:
             for done in ex.map(run, jobs):
                 if verbose:
                     print("compiled", os.path.basename(done))
-    if jobs or not os.path.exists(LIB):
-        cmd = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB] + objs
+    link_dig = hashlib.sha1("\n".join(digs).encode()).hexdigest()
+    link_stamp = os.path.join(OBJ, "libafm_hip.so.sha1")
+    stale = not os.path.exists(LIB) or not os.path.exists(link_stamp) or open(link_stamp).read() != link_dig
+    if jobs or stale:
+        tmp = LIB + f".tmp{os.getpid()}"
+        cmd = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", tmp] + objs
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+        os.replace(tmp, LIB)
+        with open(link_stamp, "w") as fh:
+            fh.write(link_dig)
     return LIB
 
 

@@ -26,8 +26,10 @@ from .params import align_dict, PATCH_TYPES, TEXT_TYPES, ParamStore, build_specs
 from .x2 import X2
 
 # compute dtypes: torch.float32 (exact-fp32 FMA kernels), torch.bfloat16 (one bf16 MFMA pass per product),
-# X2.dtype = "bf16x2" (split bf16 pairs, three MFMA passes per product: fp32-grade results on the matrix cores)
+# torch.float16 (one fp16 MFMA pass per product + dynamic loss scaling: the reference's own GPU precision, Lightning "16-mixed",
+# trainer/trainer.py:69), X2.dtype = "bf16x2" (split bf16 pairs, three MFMA passes per product: fp32-grade results)
 BF16X3 = X2.dtype
+LOSS_SCALE_INIT = 65536.0      # torch.amp.GradScaler defaults (init_scale, growth_factor, backoff_factor, growth_interval)
 
 
 def sincos_table(d_model: int, max_len: int) -> torch.Tensor:
@@ -79,8 +81,14 @@ class Seq2SeqEngine:
         # attention-probability dropout: forward stores 1 keep bit per score, backward reads it (AFM_ATTN_KEEP_BITS=0: re-hash)
         self.keep_bits = os.environ.get("AFM_ATTN_KEEP_BITS", "1") != "0"
         self.branch_dtype = torch.float32 if self.x3 else None   # residual branches: fp32 out of the x3 GEMMs (same bytes as a pair)
+        self.single16 = compute_dtype in (torch.bfloat16, torch.float16)      # one 16-bit MFMA pass per product
         self.ps = ParamStore(build_specs(self.cfg, data_config, self.V), self.dev,
-                             with_bf16=compute_dtype == torch.bfloat16, with_x2=self.x3)
+                             with_bf16=self.single16, with_x2=self.x3, lowp_dtype=compute_dtype if self.single16 else torch.bfloat16)
+        # fp16: gradients leave the loss S times too large (S = scaler[0], device-resident) and the optimiser divides it out;
+        # state = {S, growth tracker, steps taken, steps skipped} (include/afm_hip.h, afm_adam_step)
+        self.scaler = None
+        if compute_dtype == torch.float16:
+            self.scaler = torch.tensor([LOSS_SCALE_INIT, 0.0, 0.0, 0.0], dtype=torch.float32, device=self.dev)
         self.ps.init_(seed)
         if self.cfg["positional_encoding_type"] == "sin_cos":
             self.pos_enc = sincos_table(self.d, self.cfg["max_position_embeddings"]).to(self.dev)
@@ -131,6 +139,8 @@ class Seq2SeqEngine:
                 self.wt[name] = ops.empty(cols, rows, self.cd, self.dev)
             if self.x3:
                 ops.cast_x2(src, self.ps.span_x2(name, rows, cols), self.wt[name])
+            elif self.cd == torch.float16:
+                ops.cast_weights(src, self.ps.span(self.ps.bf16, name, rows, cols), self.wt[name])
             else:
                 ops.cast_bf16(src, self.ps.span(self.ps.bf16, name, rows, cols), self.wt[name])
         self._refresh_glu()
@@ -143,7 +153,10 @@ class Seq2SeqEngine:
         if self.x3:     # the Adam kernel writes no split-pair shadow: both copies are made here
             return self.refresh_shadows()
         for name, rows, cols in self._gemm_weight_groups():
-            ops.cast_bf16(self.ps.span(self.ps.flat, name, rows, cols), None, self.wt[name])
+            if self.cd == torch.float16:
+                ops.cast_weights(self.ps.span(self.ps.flat, name, rows, cols), None, self.wt[name])
+            else:
+                ops.cast_bf16(self.ps.span(self.ps.flat, name, rows, cols), None, self.wt[name])
         self._refresh_glu()
         self._refresh_kv_concat()
 
@@ -183,7 +196,7 @@ class Seq2SeqEngine:
         """GEMM weight rows [r0:r1) of the (rows x cols) group at `name`, compute dtype."""
         if self.x3:
             return self.ps.span_x2(name, rows, cols)[r0:r1]
-        buf = self.ps.bf16 if self.cd == torch.bfloat16 else self.ps.flat
+        buf = self.ps.bf16 if self.single16 else self.ps.flat
         return self.ps.span(buf, name, rows, cols)[r0:r1]
 
     def G(self, name, rows, cols, r0=0, r1=None):
@@ -793,7 +806,8 @@ class Seq2SeqEngine:
         stats = torch.zeros(1, **f32)
         dz = torch.empty_like(z) if backward else None
         tgt = target.to(device=self.dev, dtype=torch.float32).contiguous()
-        ops.align_loss(z, tgt, ac["loss_function"], float(ac["loss_lambda"]) * loss_scale, stats, dz)
+        ops.align_loss(z, tgt, ac["loss_function"], float(ac["loss_lambda"]) * loss_scale, stats, dz,
+                       scale_dev=self.scaler if backward else None)
         if not backward:
             return stats[0], None
 
@@ -874,7 +888,7 @@ class Seq2SeqEngine:
         d = self.d
         B, S, T = saved["B"], saved["S"], saved["T"]
         dlog = self._empty_b(B * T, self.V)
-        ops.ce_bwd(logits, lab, row_lse, stats, loss_scale, dlog)
+        ops.ce_bwd(logits, lab, row_lse, stats, loss_scale, dlog, scale_dev=self.scaler)
         hf = saved["hf"]
         self._wgrad(dlog, hf, "token_ff.weight", self.V, d, bias_name="token_ff.bias")
         dhf = self._dgrad(dlog, "token_ff.weight", self.V, d)

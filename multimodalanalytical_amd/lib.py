@@ -13,8 +13,8 @@ import threading
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libafm_hip.so")
 
-AFM_F32, AFM_BF16, AFM_BF16X2 = 0, 1, 2
-ABI_VERSION = 2
+AFM_F32, AFM_BF16, AFM_BF16X2, AFM_F16 = 0, 1, 2, 3
+ABI_VERSION = 3
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_GELU_BWD, ACT_GELU_SAVE_GRAD, ACT_MUL_SAVED = 0, 1, 2, 3, 4, 5
 ACT_GLU, ACT_GLU_SAVE, ACT_GLU_BWD = 6, 7, 8
 ALGO_AUTO, ALGO_GENERIC, ALGO_MFMA = 0, 1, 2
@@ -110,17 +110,18 @@ _SIGS = {
     "afm_cast_bf16": (C.c_int, [_P, _P, _P, _I32, _I32, _P]),
     "afm_masked_mean_fwd": (C.c_int, [_P, _I32, _P, _I32, _I32, _I32, _P, _P]),
     "afm_masked_mean_bwd": (C.c_int, [_P, _P, _I32, _I32, _I32, _P, _I32, _P]),
-    "afm_align_loss": (C.c_int, [_P, _P, _I32, _I32, _I32, _F, _P, _P, _P]),
+    "afm_align_loss": (C.c_int, [_P, _P, _I32, _I32, _I32, _F, _P, _P, _P, _P]),
     "afm_mix_spectra": (C.c_int, [_P, _I64, _I32, _P, _I32, _I32, _P, _I32, _I32, _P, _P]),
     "afm_patch_count": (C.c_int32, [C.POINTER(PatchDesc)]),
     "afm_patch_preprocess": (C.c_int, [C.POINTER(PatchDesc), _P, _P, _P, _P, _P]),
     "afm_ce_fwd": (C.c_int, [_P, _P, _I64, _I32, _I32, _P, _P, _P, _P]),
-    "afm_ce_bwd": (C.c_int, [_P, _P, _P, _P, _F, _P, _I32, _I32, _I64, _I32, _I32, _P]),
+    "afm_ce_bwd": (C.c_int, [_P, _P, _P, _P, _F, _P, _P, _I32, _I32, _I64, _I32, _I32, _P]),
     "afm_beam_step": (C.c_int, [C.POINTER(BeamDesc), _P]),
     "afm_beam_finalize": (C.c_int, [C.POINTER(BeamDesc), _P, _P, _P, _P]),
     "afm_cache_reorder": (C.c_int, [_P, _P, _P, _I32, _I64, _I64, _P]),
     "afm_sumsq": (C.c_int, [_P, _I64, _P, _P]),
-    "afm_adam_step": (C.c_int, [_P, _P, _P, _P, _I64, _P, _P, _P, _I32, _P]),
+    "afm_adam_step": (C.c_int, [_P, _P, _P, _P, _I64, _P, _P, _P, _I32, _I32, _P, _P]),
+    "afm_scaler_update": (C.c_int, [_P, _P, _F, _F, _I32, _P]),
 }
 
 _lock = threading.Lock()

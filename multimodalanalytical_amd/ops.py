@@ -13,10 +13,10 @@ from typing import Optional
 import torch
 
 from . import lib as L
-from .lib import AFM_BF16, AFM_BF16X2, AFM_F32, ALGO_AUTO, ACT_NONE, AttnShape, Dropout, GemmDesc, LnShape
+from .lib import AFM_BF16, AFM_BF16X2, AFM_F16, AFM_F32, ALGO_AUTO, ACT_NONE, AttnShape, Dropout, GemmDesc, LnShape
 from .x2 import X2
 
-_DT = {torch.float32: AFM_F32, torch.bfloat16: AFM_BF16, X2.dtype: AFM_BF16X2}
+_DT = {torch.float32: AFM_F32, torch.bfloat16: AFM_BF16, X2.dtype: AFM_BF16X2, torch.float16: AFM_F16}
 
 
 def _dt(t) -> int:
@@ -333,7 +333,7 @@ def cast_x2(src, dst=None, dst_t=None):
 
 
 def cast_weights(src, dst=None, dst_t=None, glu_rows: int = 0):
-    """fp32 (rows x cols) -> bf16 / split-pair shadow `dst` and its transpose `dst_t`, optionally with the gated-FFN row
+    """fp32 (rows x cols) -> bf16 / fp16 / split-pair shadow `dst` and its transpose `dst_t`, optionally with the gated-FFN row
     interleave (glu_rows = f, rows = 2f)."""
     rows, cols = src.shape
     assert src.dtype == torch.float32 and src.is_contiguous()
@@ -365,11 +365,11 @@ def masked_mean_bwd(dy, key_pad, B, S, dx, accumulate=False):
     L.check(L.load().afm_masked_mean_bwd(_ptr(dy), _ptr(key_pad), B, S, d, _ptr(dx), int(accumulate), _stream()), "afm_masked_mean_bwd")
 
 
-def align_loss(z, target, kind: str, grad_scale, stats, dz=None):
+def align_loss(z, target, kind: str, grad_scale, stats, dz=None, scale_dev=None):
     B, n = z.shape
     assert z.dtype == torch.float32 and target.dtype == torch.float32 and z.is_contiguous() and target.is_contiguous()
-    L.check(L.load().afm_align_loss(_ptr(z), _ptr(target), ALIGN_KINDS[kind], B, n, float(grad_scale), _ptr(stats),
-                                    _ptr(dz), _stream()), "afm_align_loss")
+    L.check(L.load().afm_align_loss(_ptr(z), _ptr(target), ALIGN_KINDS[kind], B, n, float(grad_scale), _ptr(scale_dev),
+                                    _ptr(stats), _ptr(dz), _stream()), "afm_align_loss")
 
 
 def mix_spectra(table, idx, ratio, normalize=False, out_len=1800):
@@ -442,9 +442,10 @@ def ce_fwd(logits, labels, row_lse, argmax, stats):
                                 _ptr(stats), _stream()), "afm_ce_fwd")
 
 
-def ce_bwd(logits, labels, row_lse, stats, grad_scale, dlogits):
+def ce_bwd(logits, labels, row_lse, stats, grad_scale, dlogits, scale_dev=None):
+    """scale_dev: device float (word 0 of the loss-scaler state) multiplied into the gradient (fp16 mode)."""
     rows, V = logits.shape
-    L.check(L.load().afm_ce_bwd(_ptr(logits), _ptr(labels), _ptr(row_lse), _ptr(stats), float(grad_scale),
+    L.check(L.load().afm_ce_bwd(_ptr(logits), _ptr(labels), _ptr(row_lse), _ptr(stats), float(grad_scale), _ptr(scale_dev),
                                 _ptr(dlogits), _dt(dlogits), _ld(dlogits), rows, V, _ld(logits), _stream()),
             "afm_ce_bwd")
 
@@ -453,6 +454,15 @@ def sumsq(g, out):
     L.check(L.load().afm_sumsq(_ptr(g), g.numel(), _ptr(out), _stream()), "afm_sumsq")
 
 
-def adam_step(p, g, m, v, hyper, sumsq_buf, p_bf16=None, zero_grad=True):
+def adam_step(p, g, m, v, hyper, sumsq_buf, p_lowp=None, zero_grad=True, scaler=None):
+    """p_lowp: flat bf16 / fp16 shadow of p written by the same kernel; scaler: the 4-float loss-scaler state (fp16 mode)."""
     L.check(L.load().afm_adam_step(_ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), _ptr(hyper), _ptr(sumsq_buf),
-                                   _ptr(p_bf16), int(zero_grad), _stream()), "afm_adam_step")
+                                   _ptr(p_lowp), _dt(p_lowp) if p_lowp is not None else AFM_BF16, int(zero_grad),
+                                   _ptr(scaler), _stream()), "afm_adam_step")
+
+
+def scaler_update(state, sumsq_buf, growth=2.0, backoff=0.5, interval=2000):
+    """torch.amp.GradScaler.update() on the device (include/afm_hip.h, afm_scaler_update)."""
+    assert state.dtype == torch.float32 and state.numel() >= 4
+    L.check(L.load().afm_scaler_update(_ptr(state), _ptr(sumsq_buf), float(growth), float(backoff), int(interval), _stream()),
+            "afm_scaler_update")

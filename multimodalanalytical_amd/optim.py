@@ -54,6 +54,7 @@ class FusedAdamOneCycle:
         self.num_steps, self.clip = int(num_steps), float(clip_grad or 0.0)
         self.world_size = int(world_size)
         self.step_count = 0
+        self.growth, self.backoff, self.growth_interval = 2.0, 0.5, 2000      # torch.amp.GradScaler defaults (fp16 mode only)
         self.beta1_pow = 1.0  # product of the (cycled) beta1 is NOT what torch uses: see step()
         dev = engine.dev
         self.hyper = torch.zeros(10, dtype=torch.float32, device=dev)
@@ -88,20 +89,32 @@ class FusedAdamOneCycle:
             self._row_events[slot] = ev
         self.sumsq.zero_()
         ops.sumsq(ps.grad, self.sumsq)
-        ops.adam_step(ps.flat, ps.grad, ps.exp_avg, ps.exp_avg_sq, self.hyper, self.sumsq, ps.bf16, zero_grad=True)
+        scaler = getattr(self.engine, "scaler", None)
+        ops.adam_step(ps.flat, ps.grad, ps.exp_avg, ps.exp_avg_sq, self.hyper, self.sumsq, ps.bf16, zero_grad=True, scaler=scaler)
+        if scaler is not None:   # fp16: GradScaler.update() on the device (a skipped step halves S, 2000 good ones double it)
+            ops.scaler_update(scaler, self.sumsq, self.growth, self.backoff, self.growth_interval)
         self.engine.refresh_transposes()
         self.last_lr, self.last_beta1 = lr, beta1
 
     def grad_norm(self) -> torch.Tensor:
-        """Global L2 norm measured by the last step (device tensor; before clipping)."""
+        """Global L2 norm measured by the last step (device tensor; before clipping).  fp16 mode: the buffer held S x the
+        gradients when it was measured; the scaler may have moved since, so this is exact only between scale changes."""
         g = 1.0 / self.world_size if self.world_size > 1 else 1.0
+        scaler = getattr(self.engine, "scaler", None)
+        if scaler is not None:
+            return torch.sqrt(self.sumsq[0]) * g / scaler[0]
         return torch.sqrt(self.sumsq[0]) * g
 
     def state_dict(self):
         ps = self.engine.ps
-        return {"step": self.step_count, "exp_avg": ps.exp_avg.clone(), "exp_avg_sq": ps.exp_avg_sq.clone()}
+        sd = {"step": self.step_count, "exp_avg": ps.exp_avg.clone(), "exp_avg_sq": ps.exp_avg_sq.clone()}
+        if getattr(self.engine, "scaler", None) is not None:
+            sd["loss_scaler"] = self.engine.scaler.clone()
+        return sd
 
     def load_state_dict(self, sd):
         ps = self.engine.ps
         self.step_count = int(sd["step"])
         ps.exp_avg.copy_(sd["exp_avg"]); ps.exp_avg_sq.copy_(sd["exp_avg_sq"])
+        if sd.get("loss_scaler") is not None and getattr(self.engine, "scaler", None) is not None:
+            self.engine.scaler.copy_(sd["loss_scaler"].to(self.engine.scaler.device))

@@ -136,7 +136,7 @@ def align_dict(ac):
 
 
 class ParamStore:
-    def __init__(self, specs: List[Spec], device, with_bf16: bool, with_x2: bool = False):
+    def __init__(self, specs: List[Spec], device, with_bf16: bool, with_x2: bool = False, lowp_dtype=torch.bfloat16):
         off = 0
         self.specs: "OrderedDict[str, Spec]" = OrderedDict()
         for s in specs:
@@ -149,7 +149,8 @@ class ParamStore:
         self.grad = torch.zeros(off, dtype=torch.float32, device=device)
         self.exp_avg = torch.zeros(off, dtype=torch.float32, device=device)
         self.exp_avg_sq = torch.zeros(off, dtype=torch.float32, device=device)
-        self.bf16 = torch.zeros(off, dtype=torch.bfloat16, device=device) if with_bf16 else None
+        # flat 16-bit shadow of every parameter (single-pass modes: bf16 or fp16), written by the Adam kernel
+        self.bf16 = torch.zeros(off, dtype=lowp_dtype, device=device) if with_bf16 else None
         # split-pair shadow of the GEMM weights (bf16x3 mode): the (rows x cols) matrix at flat offset o lives at
         # [2 o, 2 o + 2 rows cols) as rows of [hi(cols) | lo(cols)]
         self.x2buf = torch.zeros(2 * off, dtype=torch.bfloat16, device=device) if with_x2 else None

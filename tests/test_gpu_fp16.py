@@ -1,0 +1,289 @@
+"""GPU: the fp16 precision mode (AFM_F16 operands, one v_mfma_*_f16 pass per product, fp32 accumulate, dynamic loss scaling):
+the reference's own GPU arithmetic (trainer/trainer.py:69, Lightning "16-mixed" = fp16 autocast + GradScaler).  Every kernel
+family that takes the dtype against an fp64 reference on fp16-rounded inputs, the loss scaler against torch.amp.GradScaler's
+rules, and the training loop against the reference goldens (parameters after two optimiser steps)."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import afm_oracle as O  # noqa: E402
+from tests import golden_io as G  # noqa: E402
+from tests.dropmask import keep_mask, keep_mask16  # noqa: E402
+from tests.test_gpu_ops import _attn_case, _attn_ref, close, dev, rnd  # noqa: E402
+
+DEV = "cuda:0"
+H16 = torch.float16
+
+
+@pytest.fixture(scope="module")
+def ops():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from multimodalanalytical_amd import ops as _ops
+    return _ops
+
+
+# ------------------------------------------------------------------ GEMMs
+@pytest.mark.parametrize("M,N,K", [(256, 256, 128), (100, 200, 72), (1000, 1536, 512), (129, 24, 64), (4096, 2048, 512), (70000, 384, 128)])
+@pytest.mark.parametrize("cdt", [H16, torch.float32])
+def test_gemm_f16_nt(ops, M, N, K, cdt):
+    a, w, bias = rnd(M, K, seed=1).half(), rnd(N, K, seed=2).half(), rnd(N, seed=3)
+    c = torch.empty(M, N, dtype=cdt, device=DEV)
+    ops.gemm(dev(a), dev(w), c, bias=dev(bias), algo=2)
+    assert ops.last_algo() == "mfma_nt"
+    ref = a.double() @ w.double().T + bias.double()
+    tol = dict(rtol=2e-3, atol=2e-3 * math.sqrt(K) / 4) if cdt == H16 else dict(rtol=1e-4, atol=2e-4 * math.sqrt(K) / 8)
+    close(c, ref, **tol)
+
+
+def test_gemm_f16_nt_identity_asymmetric(ops):
+    n = 128
+    a = torch.eye(n).half()
+    w = (torch.arange(n * n).view(n, n) % 251 - 125).float().half()
+    c = torch.empty(n, n, device=DEV)
+    ops.gemm(dev(a), dev(w), c, algo=2)
+    close(c, w.float().T, 0, 0)
+
+
+@pytest.mark.parametrize("variant", [12, 13, 22, 24, 25, 28, 100])
+def test_gemm_f16_nt_variants(ops, variant):
+    M, N, K = 1024, 1024, 256
+    a, w, bias = rnd(M, K, seed=1).half(), rnd(N, K, seed=2).half(), rnd(N, seed=3)
+    c = torch.empty(M, N, dtype=H16 if variant == 28 else torch.float32, device=DEV)
+    ops.gemm(dev(a), dev(w), c, bias=dev(bias), algo=2, variant=variant)
+    tol = dict(rtol=2e-3, atol=1e-2) if variant == 28 else dict(rtol=1e-4, atol=2e-4 * math.sqrt(K) / 8)
+    close(c, a.double() @ w.double().T + bias.double(), **tol)
+
+
+@pytest.mark.parametrize("M,N", [(1024, 512), (4096, 2048)])     # 256x128 loader-wave form / 256x256 form (auto-selected)
+def test_gemm_f16_gelu_save_grad_pair(ops, M, N):
+    """FFN up-projection forward with the stored backward factor (act 4) and the dgrad that multiplies by it (act 5)."""
+    K = 128
+    a, w, bias = rnd(M, K, seed=1).half(), rnd(N, K, seed=2).half(), rnd(N, seed=3)
+    t = a.double() @ w.double().T
+    p, seed, site = 0.1, 31, 9
+    keep = torch.from_numpy(keep_mask(p, seed, site, M * N)).view(M, N)
+    c, gp = torch.zeros(M, N, dtype=H16, device=DEV), torch.zeros(M, N, dtype=H16, device=DEV)
+    ops.gemm(dev(a), dev(w), c, bias=dev(bias), act=4, pre_act=gp, dropout=ops.drop(p, seed, site), algo=2)
+    tr = (t + bias.double()).requires_grad_(True)
+    O.gelu(tr).backward(torch.ones(M, N, dtype=torch.float64))
+    close(c, O.gelu(tr.detach()) * keep / (1 - p), rtol=3e-3, atol=4e-3)
+    close(gp, tr.grad * keep / (1 - p), rtol=3e-3, atol=4e-3)
+    c2 = torch.zeros_like(c)
+    ops.gemm(dev(a), dev(w), c2, act=5, pre_act=gp, algo=2)
+    close(c2, t * gp.float().cpu().double(), rtol=3e-3, atol=1e-2)
+
+
+def test_gemm_f16_glu_fused(ops):
+    """Gated FFN through the fused epilogues (act 6 / 7 / 8) on fp16 operands, against the unfused formulas."""
+    M, f, d = 512, 256, 128
+    h = rnd(M, d, seed=1).half()
+    w1, wg = rnd(f, d, seed=2) * 0.2, rnd(f, d, seed=3) * 0.2
+    bias = rnd(2 * f, seed=4) * 0.1
+    wcat = torch.cat([w1, wg], 0)
+    w_il, wt_il = torch.empty(2 * f, d, dtype=H16, device=DEV), torch.empty(d, 2 * f, dtype=H16, device=DEV)
+    ops.cast_weights(dev(wcat), w_il, wt_il, glu_rows=f)
+    g = torch.empty(M, f, dtype=H16, device=DEV); uv = torch.empty(M, 2 * f, dtype=H16, device=DEV)
+    ops.gemm(dev(h), w_il, g, bias=dev(bias), act=7, pre_act=uv, glu_rows=f, algo=2)
+    assert "glu" in ops.last_algo()
+    u = h.double() @ w1.half().double().T + bias[:f].double()
+    v = h.double() @ wg.half().double().T + bias[f:].double()
+    close(g, O.gelu(u) * v, rtol=3e-3, atol=4e-3)
+
+
+@pytest.mark.parametrize("R,M,N", [(512, 128, 128), (4096, 1536, 512), (777, 24, 64), (16384, 520, 200), (131072, 512, 256)])
+def test_gemm_f16_tn_wgrad(ops, R, M, N):
+    dy, x = (rnd(R, M, seed=1) * 0.5).half(), rnd(R, N, seed=2).half()
+    g0 = rnd(M, N, seed=3)
+    g = dev(g0).clone()
+    b0 = rnd(M, seed=4); gb = dev(b0).clone()
+    ops.gemm(dev(dy), dev(x), g, trans_a=True, trans_b=False, accumulate=True, algo=2, a_colsum=gb)
+    assert ops.last_algo().startswith("mfma_tn")
+    close(g, g0.double() + dy.double().T @ x.double(), 1e-4, 2e-4 * math.sqrt(R) / 4)
+    close(gb, b0.double() + dy.double().sum(0), 1e-4, 2e-4 * math.sqrt(R) / 4, "fused bias gradient")
+
+
+def test_gemm_f16_generic_odd_shapes(ops):
+    """Shapes outside the MFMA kernels (the SMILES vocabulary, patch sizes) run on the exact-fp32 FMA kernel with fp16 I/O."""
+    M, N, K = 37, 26, 75
+    a, w = rnd(M, K, seed=1).half(), rnd(N, K, seed=2).half()
+    c = torch.empty(M, N, dtype=H16, device=DEV)
+    ops.gemm(dev(a), dev(w), c)
+    assert ops.last_algo().startswith("generic")
+    close(c, a.double() @ w.double().T, 2e-3, 2e-3 * math.sqrt(K))
+
+
+# ------------------------------------------------------------------ attention
+@pytest.mark.parametrize("B,H,Tq,Tk,causal,pad,pdrop", [
+    (2, 2, 128, 128, True, True, 0.0), (2, 3, 100, 200, False, True, 0.0), (1, 2, 192, 192, True, False, 0.0),
+    (2, 2, 128, 256, False, True, 0.1), (1, 2, 160, 160, True, True, 0.1), (2, 2, 130, 520, False, True, 0.1), (2, 2, 256, 56, False, True, 0.1)])
+def test_attention_f16(ops, B, H, Tq, Tk, causal, pad, pdrop):
+    dh, dt = 64, H16
+    q, k, v, key_pad = _attn_case(B, H, Tq, Tk, dh, causal, bool(pad), seed=10)
+    q, k, v = q.half().float(), k.half().float(), v.half().float()
+    D = H * dh
+    qd, kd, vd = (dev(t.reshape(-1, D), dt) for t in (q, k, v))
+    kp = None if key_pad is None else dev(key_pad.to(torch.uint8))
+    seed, site = 4242, 3
+    keep, dscale = None, 1.0
+    if pdrop > 0:
+        km, dscale = keep_mask16(pdrop, seed, site, B * H * Tq * Tk)
+        keep = torch.from_numpy(km).view(B, H, Tq, Tk)
+    res = {}
+    for algo in (1, 2):
+        o = torch.empty(B * Tq, D, dtype=dt, device=DEV); lse = torch.empty(B * H * Tq, device=DEV)
+        shp = ops.attn_shape(B, H, Tq, Tk, dh, dt, D, D, D, D, kp, causal, ops.drop(pdrop, seed, site), algo=algo)
+        if pdrop > 0 and algo == 2 and Tq % 2 == 0:
+            ops.attn_set_drop_bits(shp, torch.zeros(ops.attn_drop_bits_words(B, H, Tq, Tk), dtype=torch.int64, device=DEV))
+        ops.attn_fwd(shp, qd, kd, vd, o, lse)
+        assert ops.last_algo() == ("attn_generic" if algo == 1 else "attn_mfma")
+        res[algo] = (o, lse, shp)
+    qr, kr, vr, ref = _attn_ref(q, k, v, key_pad, causal, keep, dscale)
+    ref_o = ref.transpose(1, 2).reshape(B * Tq, D)
+    close(res[2][0], ref_o, 3e-3, 3e-3, "mfma fwd vs oracle")
+    close(res[1][0], ref_o, 3e-3, 3e-3, "generic fwd vs oracle")
+    close(res[2][1], res[1][1].cpu(), 1e-3, 1e-3, "lse mfma vs generic")
+    do = rnd(B * Tq, D, seed=9).half().float()
+    ref.backward(do.double().view(B, Tq, H, dh).transpose(1, 2))
+    o, lse, shp = res[2]
+    dq, dk, dv = (torch.empty(n, D, dtype=dt, device=DEV) for n in (B * Tq, B * Tk, B * Tk))
+    ops.attn_bwd(shp, qd, kd, vd, o, dev(do, dt), lse, torch.empty_like(lse), dq, dk, dv, D, D, D)
+    assert ops.last_algo() == "attn_mfma"
+    for name, got, r, T in (("dq", dq, qr, Tq), ("dk", dk, kr, Tk), ("dv", dv, vr, Tk)):
+        want = r.grad.transpose(1, 2).reshape(B * T, D)
+        err = float((got.float().cpu().double() - want).norm() / want.norm())
+        assert err < 4e-3, (name, err)
+
+
+# ------------------------------------------------------------------ LayerNorm, elementwise, loss
+@pytest.mark.parametrize("d", [64, 512, 768])
+def test_layernorm_f16(ops, d):
+    rows = 300
+    x, br = rnd(rows, d, seed=1) * 2 + 0.5, rnd(rows, d, seed=2)
+    gam, bet = 1 + 0.1 * rnd(d, seed=3), 0.1 * rnd(d, seed=4)
+    brd = dev(br, H16)
+    y = torch.empty(rows, d, dtype=H16, device=DEV); xs = torch.empty(rows, d, device=DEV)
+    mean = torch.empty(rows, device=DEV); rstd = torch.empty(rows, device=DEV)
+    p, seed, site = 0.1, 3, 8
+    ops.layernorm_fwd(dev(x), dev(gam), dev(bet), y, mean, rstd, add=brd, x_sum=xs, add_dropout=ops.drop(p, seed, site))
+    keep = torch.from_numpy(keep_mask(p, seed, site, rows * d)).view(rows, d)
+    ref_sum = x.double() + brd.float().cpu().double() * keep / (1 - p)
+    close(xs, ref_sum, 1e-6, 1e-6)
+    close(y, O.layer_norm(ref_sum, gam.double(), bet.double()), 2e-3, 2e-3)
+    # backward with the dropped copy of dx in fp16
+    dy = (rnd(rows, d, seed=5) * 0.1).half()
+    dx = torch.empty(rows, d, device=DEV); dxd = torch.empty(rows, d, dtype=H16, device=DEV)
+    dg, db = torch.zeros(d, device=DEV), torch.zeros(d, device=DEV)
+    ws = torch.empty(ops.layernorm_bwd_ws(rows, d), device=DEV)
+    ops.layernorm_bwd(dev(dy), xs, dev(gam), mean, rstd, dx, dg, db, ws, dx_drop=dxd, dropout=ops.drop(p, seed + 1, site))
+    xr = ref_sum.clone().requires_grad_(True); gr = gam.double().requires_grad_(True); brr = bet.double().requires_grad_(True)
+    O.layer_norm(xr, gr, brr).backward(dy.double())
+    close(dx, xr.grad, 1e-4, 1e-5)
+    close(dg, gr.grad, 1e-4, 1e-4); close(db, brr.grad, 1e-4, 1e-4)
+    keep2 = torch.from_numpy(keep_mask(p, seed + 1, site, rows * d)).view(rows, d)
+    close(dxd, xr.grad * keep2 / (1 - p), 2e-3, 1e-5)
+
+
+def test_convert_cast_and_ce_scale(ops):
+    x = rnd(70, 96, seed=1)
+    h = ops.convert(dev(x), torch.empty(70, 96, dtype=H16, device=DEV))
+    assert torch.equal(h.cpu(), x.half())                                   # round to nearest even, as torch
+    back = ops.convert(h, torch.empty(70, 96, device=DEV))
+    assert torch.equal(back.cpu(), x.half().float())
+    w = rnd(64, 96, seed=2)
+    wd, wt = torch.empty(64, 96, dtype=H16, device=DEV), torch.empty(96, 64, dtype=H16, device=DEV)
+    ops.cast_weights(dev(w), wd, wt)
+    assert torch.equal(wd.cpu(), w.half()) and torch.equal(wt.cpu(), w.half().T)
+    # CE backward multiplies by the device-resident loss scale
+    rows, V = 50, 26
+    logits, labels = rnd(rows, V, seed=3), torch.randint(0, V, (rows,), generator=torch.Generator().manual_seed(4))
+    labels[::7] = -100
+    lse = torch.empty(rows, device=DEV); am = torch.empty(rows, dtype=torch.int64, device=DEV); stats = torch.zeros(2, device=DEV)
+    ops.ce_fwd(dev(logits), dev(labels), lse, am, stats)
+    scale = torch.tensor([1024.0, 0, 0, 0], device=DEV)
+    d1, d2 = torch.empty(rows, V, dtype=H16, device=DEV), torch.empty(rows, V, device=DEV)
+    ops.ce_bwd(dev(logits), dev(labels), lse, stats, 0.25, d1, scale_dev=scale)
+    ops.ce_bwd(dev(logits), dev(labels), lse, stats, 0.25, d2)
+    close(d1, d2.cpu().double() * 1024.0, 2e-3, 1e-6)
+
+
+# ------------------------------------------------------------------ loss scaler
+def test_adam_with_loss_scaler_skips_and_rescales(ops):
+    """GradScaler semantics on the device: gradients arrive S times too large; a non-finite norm skips the step (parameters and
+    moments untouched, gradients zeroed) and halves S; `interval` good steps in a row double it; bias corrections count the
+    steps TAKEN."""
+    n = 4096 + 3
+    p0, g0 = rnd(n, seed=1), rnd(n, seed=2) * 0.01
+    S = 1024.0
+    pd = dev(p0).clone(); m = torch.zeros(n, device=DEV); v = torch.zeros(n, device=DEV)
+    shadow = torch.empty(n, dtype=H16, device=DEV)
+    st = torch.tensor([S, 0.0, 0.0, 0.0], device=DEV)
+    pr, mr, vr = p0.clone().double(), torch.zeros(n, dtype=torch.float64), torch.zeros(n, dtype=torch.float64)
+    ss = torch.zeros(1, device=DEV)
+    taken = 0
+    for it in range(6):
+        lr, b1 = O.onecycle(it, 10, 1e-2)
+        scale_now = float(st[0])
+        gd = dev(g0) * scale_now * (it + 1)
+        if it in (1, 4):
+            gd[17] = float("inf")                                           # fp16 overflow somewhere in the backward pass
+        hyper = torch.tensor([lr, b1, 0.999, 1e-8, 0.01, -1.0, -1.0, 1.0, 1.0, 1.0], device=DEV)   # bc fields unused with a scaler
+        ss.zero_(); ops.sumsq(gd, ss)
+        before = pd.clone()
+        ops.adam_step(pd, gd, m, v, hyper, ss, shadow, zero_grad=True, scaler=st)
+        ops.scaler_update(st, ss, growth=2.0, backoff=0.5, interval=2)
+        assert float(gd.abs().max()) == 0.0
+        if it in (1, 4):
+            assert torch.equal(pd, before)                                  # skipped
+        else:
+            taken += 1
+            gt = g0.double() * (it + 1)
+            coef = min(1.0, 1.0 / (float(gt.norm()) + 1e-6))
+            O.adam_step(pr, gt * coef, mr, vr, taken, lr, b1, 0.999, 1e-8, 0.01, True)
+            close(pd, pr, 2e-5, 2e-6, f"step {it}")
+            close(shadow, pd.float().cpu().half(), 0, 0)
+    # scale history: 1024 -(good)-> tracker 1 -(inf)-> 512 -(good, good)-> 1024 -(inf)-> 512 -(good)-> 512
+    assert st.cpu().tolist() == [512.0, 1.0, 4.0, 2.0]
+
+
+# ------------------------------------------------------------------ training loop vs the reference goldens
+@pytest.mark.parametrize("name", ["model_plain", "model_gated_learned"])
+def test_f16_two_optimizer_steps_vs_reference_golden(name):
+    """fp16 forward / backward with the dynamic loss scale against the reference's fp32 run: logits inside the north star's 1e-3,
+    parameters after two optimiser steps (accumulate 4, clip, AdamW + OneCycle) at fp16-gradient tolerance."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from multimodalanalytical_amd.engine import Seq2SeqEngine
+    from multimodalanalytical_amd.optim import FusedAdamOneCycle
+    t = G.load(name); cfg = G.model_cfg(t["meta"]); m = t["meta"]
+    eng = Seq2SeqEngine(dict(cfg), m["data_config"], "Smiles", m["data_config"]["Smiles"]["vocab_size"], device=DEV, compute_dtype=H16)
+    eng.load_state_dict(t["sd"])
+    opt = FusedAdamOneCycle(eng, m["optimiser"], lr=m["lr"], weight_decay=m["weight_decay"], num_steps=m["total_steps"], clip_grad=m["clip"])
+
+    def inputs(i):
+        enc, am, dec, dm, labels = O.batch_to_model_inputs(G.batch_of(t, i), "Smiles")
+        to = lambda x: {k: to(v) for k, v in x.items()} if isinstance(x, dict) else x.to(DEV)
+        return to(enc), am.to(DEV), dec.to(DEV), dm.to(DEV), labels.to(DEV)
+    for step in (1, 2):
+        for i in range(4):
+            out = eng.forward(*inputs(i), backward=True, loss_scale=1.0 / m["acc_batches"])
+            if step == 1:
+                ref = t[f"b{i}"]
+                err = float((out["logits"].cpu().double() - ref["logits"].double()).abs().max() / ref["logits"].double().abs().max())
+                assert err < 1e-3, (i, err)
+        opt.step()
+        torch.testing.assert_close(opt.grad_norm().cpu(), t[f"step{step}"]["grad_norm"], rtol=5e-3, atol=1e-6)
+        # Adam normalises the step (after step 1 every element has moved by ~lr whatever its gradient's size), so the measure
+        # is the error of the MOVEMENT over all parameters; elements whose gradient is at the fp16 noise floor may go the other way
+        num = den = 0.0
+        for k, ref in t[f"step{step}"].items():
+            if k == "grad_norm" or k.endswith("in_proj_bias"):
+                continue
+            got = eng.ps.p(k).cpu().double()
+            num += float((got - ref.double()).norm()) ** 2
+            den += float((ref.double() - t["sd"][k].double()).norm()) ** 2
+        assert (num / den) ** 0.5 < 0.15, (step, (num / den) ** 0.5)
+    assert eng.scaler.cpu().tolist() == [65536.0, 2.0, 2.0, 0.0]
