@@ -10,13 +10,14 @@ step, overlapped with the last backward.  Inputs are synthetic (multimodalanalyt
 resident in HBM before the timed region.  Prints ONE JSON line (rank 0).
 
 Precision modes, all timed in the same run and listed under `modes`:
-  bf16x3-mixed  (`value`) the FORWARD runs on split bf16 operand pairs -- three bf16 MFMA passes per product, fp32
-                accumulation: logits within 1e-5 of the CPU reference (bar 1e-3), argmax ids equal, i.e. the outputs the
-                parity bar is stated on come from parity-grade arithmetic -- and the BACKWARD on the single-pass bf16
-                kernels, reading the hi planes of the saved pair tensors in place: gradients at the precision class of the
-                reference's own 16-bit mixed training (4e-3 over all parameters against the CPU reference)
+  fp16          (`value`) fp16 operands, ONE MFMA pass per product forward and backward, fp32 accumulation / residual stream /
+                statistics / master weights, dynamic loss scaling on the device: the reference's own GPU arithmetic
+                (trainer/trainer.py:69, Lightning "16-mixed").  Logits 4e-4 .. 7e-4 of the CPU reference at c1..c5 and at the
+                timed size (bar 1e-3; tests/test_gpu_shapes.py, tests/test_gpu_model.py), gradients 6e-4 .. 9e-4
+  bf16x3-mixed  the forward on split bf16 operand pairs (three bf16 MFMA passes per product: logits within 1e-5), the backward
+                on the single-pass bf16 kernels reading the hi planes of the saved pair tensors (gradients 4e-3)
   bf16x3        split pairs in both directions (gradients 1e-5 against the CPU reference)
-  bf16          single pass everywhere (3e-3..6e-3 on the logits: outside the parity bar, for comparison only)
+  bf16          single bf16 pass everywhere (3e-3..6e-3 on the logits: outside the parity bar, for comparison only)
 """
 import argparse
 import json
@@ -42,15 +43,16 @@ def parse():
     ap.add_argument("--workload", default="c2", help="c1..c5 (multimodalanalytical_amd/synth.py)")
     ap.add_argument("--batch", type=int, default=0, help="per-GPU micro-batch (default: the workload's, 128)")
     ap.add_argument("--acc", type=int, default=4)
-    ap.add_argument("--dtype", default="bf16x3-mixed", choices=["fp16", "bf16x3", "bf16x3-mixed", "bf16", "fp32"], help="mode of `value`")
-    ap.add_argument("--other-modes", default="bf16x3,bf16", help="comma list of further modes timed in the same run ('' = none)")
-    ap.add_argument("--other-steps", type=int, default=3)
+    ap.add_argument("--dtype", default="fp16", choices=["fp16", "bf16x3", "bf16x3-mixed", "bf16", "fp32"], help="mode of `value`")
+    ap.add_argument("--other-modes", default="bf16x3-mixed,bf16x3,bf16", help="comma list of further modes timed in the same run ('' = none)")
+    ap.add_argument("--other-steps", type=int, default=5)
+    ap.add_argument("--extra-steps", type=int, default=10, help="timed steps of each --extra-workloads entry")
     ap.add_argument("--extra-workloads", default="c3", help="comma list: further workloads timed in the primary mode (N = 1 only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--cpu-batch", type=int, default=4)
-    ap.add_argument("--cpu-steps", type=int, default=3)
-    ap.add_argument("--cpu-threads", type=int, default=32)
+    ap.add_argument("--cpu-batch", type=int, default=8)
+    ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--cpu-threads", type=int, default=32, help="torch CPU threads of the baseline (more than 32 ran SLOWER on the GPU box; the host's core count is printed beside it)")
     ap.add_argument("--force-ddp", action="store_true",
                     help="run the RCCL gradient exchange even with one rank (exercises the N>1 code path on a 1-GPU box)")
     return ap.parse_args()
@@ -214,8 +216,12 @@ def kernel_rooflines(model, wl, B, mode):
         for e in out:
             km = e["arithmetic"]
             if km not in tables:
-                pmc = os.path.join(ROOT, "profiles", f"r02_{'bf16' if km == 'fp16' else km}_pmc.json")
-                tables[km] = json.load(open(pmc)) if os.path.exists(pmc) else {}
+                tables[km] = {}
+                for cand in (f"r03_{km}_pmc.json", f"r02_{km}_pmc.json"):      # PMC passes of the same launches, newest round first
+                    pmc = os.path.join(ROOT, "profiles", cand)
+                    if os.path.exists(pmc):
+                        tables[km] = json.load(open(pmc))
+                        break
             e["traffic"] = tables[km].get(e["what"], {}).get("hbm_bytes_per_launch")
     out.sort(key=lambda e: -e["ms_per_micro_batch"])
     return out
@@ -231,7 +237,8 @@ def cpu_baseline(model, wl, name, cpu_batch, steps, threads):
     from multimodalanalytical_amd import synth
     from oracle import afm_oracle as O
     from oracle import stock_torch as ST
-    cores = max(1, min(threads, os.cpu_count() or 1))
+    host_cores = os.cpu_count() or 1
+    cores = max(1, min(threads or host_cores, host_cores))
     torch.set_num_threads(cores)
     eng = model.hf_model.engine
     sd = {k: v.detach().float().cpu() for k, v in eng.state_dict().items() if not k.startswith("decoder.embedding.")}
@@ -244,7 +251,7 @@ def cpu_baseline(model, wl, name, cpu_batch, steps, threads):
     for _ in range(steps):
         tr.micro_batch(enc, am, dec, dm, labels)
     dt = (time.perf_counter() - t0) / steps
-    port = {"value": round(cpu_batch / dt, 4), "unit": "samples/s", "cores": cores,
+    port = {"value": round(cpu_batch / dt, 4), "unit": "samples/s", "cores": cores, "host_cores": host_cores,
             "sample": f"op-by-op oracle (oracle/afm_oracle.py, the parity checker; it materialises the S x S scores), {steps} timed "
                       f"steps after 1 warm-up, {dt:.2f} s/step"}
     res = dict(port, kind="port", sample=f"{steps} timed optimiser steps (after 1 warm-up) on a micro-batch of {cpu_batch} samples of "
@@ -270,7 +277,7 @@ def cpu_baseline(model, wl, name, cpu_batch, steps, threads):
         dt2 = (time.perf_counter() - t0) / steps
         # the stock-torch wiring IS the reference's arithmetic (its layers subclass these modules) and the faster of the two:
         # it is the baseline proper; the op-by-op oracle's time is kept beside it
-        res = {"value": round(cpu_batch / dt2, 4), "unit": "samples/s", "cores": cores, "kind": "port",
+        res = {"value": round(cpu_batch / dt2, 4), "unit": "samples/s", "cores": cores, "host_cores": host_cores, "kind": "port",
                "sample": f"{steps} timed optimiser steps (after 1 warm-up) on a micro-batch of {cpu_batch} samples of workload {name}: "
                          f"fwd+bwd+clip+AdamW, fp32, through torch.nn.TransformerEncoder/Decoder wired as the reference wires them "
                          f"(oracle/stock_torch.py), {dt2:.2f} s/step",
@@ -377,9 +384,10 @@ def main():
     workloads = {}
     if world == 1:
         for w in [x for x in args.extra_workloads.split(",") if x and x != args.workload]:
-            r = timed_run(w, args.dtype, 2, 1, rank, world, dev, args)
+            r = timed_run(w, args.dtype, args.extra_steps, 1, rank, world, dev, args)
             workloads[w] = {"workload": f"{w}: modalities {'+'.join(k for k in r['wl']['data'] if k != 'Smiles')}, enc_len {r['S']}, dec_len {r['wl']['T']}",
-                            "value": round(r["value"], 3), "unit": "samples/s", "ms_per_step": round(r["dt"] / 2 * 1e3, 3), "steps": 2,
+                            "value": round(r["value"], 3), "unit": "samples/s", "ms_per_step": round(r["dt"] / args.extra_steps * 1e3, 3),
+                            "steps": args.extra_steps,
                             "train_gflop_per_sample": round(r["flops"] / 1e9, 2), "dtype": args.dtype}
 
     out = {

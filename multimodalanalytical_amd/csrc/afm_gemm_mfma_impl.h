@@ -1460,7 +1460,7 @@ int AFM_E16_FN(afm_gemm_mfma_try)(const afm_gemm_desc* d, hipStream_t st) {
 #undef PRING_CASE
 #undef NT_CASE
     if (r != AFM_OK) return r;
-    afm_set_last_algo("mfma_nt");
+    afm_set_last_algo(variant == 28 ? "mfma_nt_256" : "mfma_nt");     // (_256: the 256 x 256-tile form)
     return AFM_OK;
   }
   if (d->transA && !d->transB) {  // TN: the wgrad form only

@@ -987,7 +987,10 @@ int afm_gemm_x3_try(const afm_gemm_desc* d, hipStream_t st) {
       else r = launch_x3_nt<X3_X2, XE_PLAIN>(g, st, plainish && !d->pre_act && d->drop.p <= 0.f);
     }
     if (r != AFM_OK) return r;
-    afm_set_last_algo("mfma_nt_x3");
+    const bool ran256 = big && (d->c_dtype == AFM_F32 ? (d->N % 4) == 0 && (d->ldc % 4) == 0
+                                : (!d->residual && !d->accumulate && (small_idx || d->drop.p <= 0.f) && (d->ldc & 15) == 0 &&
+                                   d->act != AFM_ACT_RELU && !(d->act == AFM_ACT_NONE && (d->pre_act || d->drop.p > 0.f))));
+    afm_set_last_algo(ran256 ? "mfma_nt_x3_256" : "mfma_nt_x3");     // (_256: the 256 x 256-tile form)
     return AFM_OK;
   }
   if (d->transA && !d->transB) {   // TN: the wgrad form

@@ -379,3 +379,82 @@ def test_c2_full_size_properties():
     g2 = eng.ps.grad
     assert torch.isfinite(g1).all() and float(g1.abs().max()) > 0
     assert float((g1 - g2).norm() / g1.norm()) < 2e-3      # bf16 rounding of the scaled activation gradients
+
+
+@pytest.mark.parametrize("mode", ["fp16", "bf16x3-mixed"])
+def test_c2_full_size_forward_vs_oracle_in_the_timed_modes(mode):
+    """What `bench.py` times, at the size it times it: workload c2 at B = 128 (131 072 encoder rows), forward in the headline
+    precision modes against the CPU oracle on the same batch (the oracle materialises S x S scores: run in chunks of 8 samples).
+    Logits inside the north star's 1e-3, argmax ids equal wherever the reference's top-2 margin exceeds twice the measured
+    error, and the kernels dispatched are the large-size forms the benchmark runs (256 x 256 tiles, MFMA attention)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from multimodalanalytical_amd import ops, synth
+    from multimodalanalytical_amd.engine import Seq2SeqEngine
+    from multimodalanalytical_amd.x2 import X2
+    wl = synth.WORKLOADS["c2"]
+    B = 128
+    batch, _ = synth.make_batch("c2", B, seed=33)
+    enc, am, dec, dm, labels = O.batch_to_model_inputs(batch, "Smiles")
+    cfg = dict(wl["cfg"], dropout=0.0)
+    cd, bd = (torch.float16, None) if mode == "fp16" else (X2.dtype, torch.bfloat16)
+    eng = Seq2SeqEngine(cfg, wl["data"], "Smiles", 128, device=DEV, compute_dtype=cd, backward_dtype=bd, seed=5)
+    to = lambda x: {k: to(v) for k, v in x.items()} if isinstance(x, dict) else x.to(DEV)
+    ops.reset_algo_log()
+    out = eng.forward(to(enc), am.to(DEV), dec.to(DEV), dm.to(DEV), labels.to(DEV))
+    algos = set(ops.algo_log())
+    assert any(a.startswith("attn_mfma") for a in algos), algos
+    assert ("mfma_nt_x3_256" if mode != "fp16" else "mfma_nt_256") in algos, algos        # the 256 x 256-tile GEMM forms
+    sd = {k: v.float().cpu() for k, v in eng.state_dict().items()}
+    sel = lambda x, s: {k: sel(v, s) for k, v in x.items()} if isinstance(x, dict) else x[s]
+    torch.set_num_threads(min(64, torch.get_num_threads()))
+    refs = []
+    with torch.no_grad():
+        for i in range(0, B, 8):
+            s = slice(i, i + 8)
+            refs.append(O.model_forward(sd, cfg, wl["data"], "Smiles", sel(enc, s), am[s], dec[s], dm[s])["logits"])
+    ref = torch.cat(refs).double()
+    got = out["logits"].cpu().double()
+    scale = float(ref.abs().max())
+    err = float((got - ref).abs().max()) / scale
+    assert err < 1e-3, (mode, err)
+    ids, rid = out["logits"].argmax(-1).cpu(), ref.argmax(-1)
+    top2 = ref.topk(2, -1).values
+    sure = (top2[..., 0] - top2[..., 1]) > 2 * err * scale
+    assert torch.equal(ids[sure], rid[sure])
+    chosen = ref.gather(-1, ids.unsqueeze(-1)).squeeze(-1)
+    assert bool((chosen >= top2[..., 0] - 2 * err * scale).all())
+    assert float(sure.double().mean()) > (0.999 if mode != "fp16" else 0.98)
+    print(f"c2 B=128 {mode}: logits rel err {err:.2e}, ids equal {float((ids == rid).double().mean()):.5f}, "
+          f"decidable {float(sure.double().mean()):.5f}")
+
+
+def test_training_losses_agree_across_modes():
+    """16 optimiser steps (accumulate 2, dropout 0.1, clip, AdamW + OneCycle) at the c2 layer shape, B = 4: the loss curves of
+    fp16 (loss-scaled), bf16x3-mixed and bf16x3 agree to 3 decimals -- the 16-bit backward passes train like the pair-mode one."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from multimodalanalytical_amd import synth
+    from multimodalanalytical_amd.modeling.wrapper import HFWrapper, SimpleTokenizerInfo
+    from multimodalanalytical_amd.trainer import TrainLoop
+    from multimodalanalytical_amd.x2 import X2
+    wl = synth.WORKLOADS["c2"]
+    batches = [synth.make_batch("c2", 4, seed=100 + i, device=DEV)[0] for i in range(4)]
+    curves = {}
+    for mode, (cd, bd) in {"bf16x3": (X2.dtype, None), "bf16x3-mixed": (X2.dtype, torch.bfloat16), "fp16": (torch.float16, None)}.items():
+        model = HFWrapper(wl["data"], "CustomModel", "facebook/bart-base", SimpleTokenizerInfo(128), optimiser="adamw", lr=3e-4,
+                          num_steps=17, device=DEV, compute_dtype=cd, backward_dtype=bd, seed=11,
+                          **{k: v for k, v in wl["cfg"].items() if k != "multimodal_norm"})
+        loop = TrainLoop(model, acc_batches=2)
+        losses = []
+        for step in range(16):
+            for j in range(2):
+                losses.append(float(loop.micro_batch(batches[(2 * step + j) % 4])))
+        curves[mode] = torch.tensor(losses)
+        if mode == "fp16":
+            st = model.hf_model.engine.scaler.cpu().tolist()
+            assert st[2] == 16.0 and st[3] == 0.0, st          # every step taken, none skipped
+    assert float(curves["bf16x3"][-1]) < float(curves["bf16x3"][0]) - 0.3       # it trains
+    for mode in ("bf16x3-mixed", "fp16"):
+        d = float((curves[mode] - curves["bf16x3"]).abs().max())
+        assert d < 5e-3, (mode, d, curves[mode][-4:], curves["bf16x3"][-4:])

@@ -244,7 +244,7 @@ def test_gemm_x3_nt_256_tiles(ops, M, N, K):
     A, W = x2(a), x2(w)
     c = X2.empty(M, N, DEV)
     ops.gemm(A, W, c, bias=dev(bias), algo=2, variant=32)
-    assert ops.last_algo() == "mfma_nt_x3" and relnorm(c.float(), t) < 1e-5
+    assert ops.last_algo() == "mfma_nt_x3_256" and relnorm(c.float(), t) < 1e-5
     cf = torch.empty(M, N, device=DEV)
     ops.gemm(A, W, cf, bias=dev(bias), algo=2, variant=32)
     assert relnorm(cf, t) < 1e-5
@@ -347,3 +347,70 @@ def test_fused_gated_ffn_epilogues(ops, mode, M, f, d):
     dh = ops.empty(M, d, cd, DEV)
     ops.gemm(duv, wt_glu, dh, algo=2)
     assert relnorm(dh.float(), du_ref @ w1q + dv_ref @ wgq) < tol
+
+
+def test_gemm_x3_nt256_auto_selected_gelu_save_grad_hi_only(ops):
+    """The FFN up-projection exactly as the mixed-mode training step launches it at the benchmark size: M = 131 072 token rows,
+    the 256 x 256-tile pair kernel picked BY THE DISPATCHER (no forced variant), GELU + dropout + stored backward factor, the
+    factor's hi plane only (sg_hi_only: its consumer is the single-pass backward).  Checked on a row sample against fp64."""
+    from multimodalanalytical_amd.x2 import X2
+    M, N, K = 131072, 2048, 512
+    g = torch.Generator(device=DEV).manual_seed(3)
+    a = torch.randn(M, K, device=DEV, generator=g) * 0.3
+    w, bias = rnd(N, K, seed=2) * 0.3, rnd(N, seed=3)
+    A, W = ops.convert(a, X2.empty(M, K, DEV)), x2(w)
+    p, seed, site = 0.1, 99, 5
+    c, sg = X2.empty(M, N, DEV), X2.empty(M, N, DEV)
+    sg.hi.fill_(0); sg.lo.fill_(7.0)                                 # the lo plane must stay untouched
+    ops.gemm(A, W, c, bias=dev(bias), act=4, pre_act=sg, dropout=ops.drop(p, seed, site), algo=2, sg_hi_only=True)
+    assert ops.last_algo() == "mfma_nt_x3_256"
+    rows = torch.cat([torch.arange(0, 300), torch.arange(65536 - 150, 65536 + 150), torch.arange(M - 300, M)])
+    t = A.float()[rows.to(DEV)].cpu().double() @ W.float().cpu().double().T + bias.double()
+    keep = torch.cat([torch.from_numpy(keep_mask(p, seed, site, n * N, start=r0 * N)).view(n, N)
+                      for r0, n in ((0, 300), (65536 - 150, 300), (M - 300, 300))]).double() / (1 - p)
+    gp = 0.5 * (1 + torch.erf(t / math.sqrt(2))) + t * torch.exp(-t * t / 2) / math.sqrt(2 * math.pi)
+    gel = 0.5 * t * (1 + torch.erf(t / math.sqrt(2)))
+    assert relnorm(c.float()[rows.to(DEV)].cpu(), gel * keep) < 2e-5
+    assert relnorm(sg.hi[rows.to(DEV)].float().cpu(), gp * keep) < 4e-3           # hi plane = bf16(factor)
+    assert float((sg.lo != 7.0).sum()) == 0
+    # the dgrad that consumes the hi plane in place (single-pass bf16 kernel, ACT_MUL_SAVED)
+    d2 = 512
+    dy = (torch.randn(M, d2, device=DEV, generator=g) * 0.01).bfloat16()
+    w2t = rnd(N, d2, seed=7).bfloat16()
+    du = torch.empty(M, sg.ld, dtype=torch.bfloat16, device=DEV)[:, :N]
+    ops.gemm(dy, dev(w2t), du, act=5, pre_act=sg.hi, algo=2)
+    assert ops.last_algo().startswith("mfma_nt")
+    want = (dy[rows.to(DEV)].float().cpu().double() @ w2t.double().T) * sg.hi[rows.to(DEV)].float().cpu().double()
+    assert relnorm(du[rows.to(DEV)].float().cpu(), want) < 5e-3
+
+
+def test_gemm_x3_glu_save_hi_only_at_benchmark_rows(ops):
+    """The gated twin (c4 / c5): fused gelu(u) * v + dropout with the stored factor pair's hi planes only, 131 072 token rows."""
+    from multimodalanalytical_amd.x2 import X2
+    from multimodalanalytical_amd.lib import ACT_GLU_SAVE
+    M, f, d = 131072, 512, 256
+    g = torch.Generator(device=DEV).manual_seed(5)
+    h = torch.randn(M, d, device=DEV, generator=g) * 0.5
+    w1, wg, b = rnd(f, d, seed=2) * 0.2, rnd(f, d, seed=3) * 0.2, rnd(2 * f, seed=4) * 0.1
+    w_glu, wt_glu = X2.empty(2 * f, d, DEV), X2.empty(d, 2 * f, DEV)
+    ops.cast_weights(torch.cat([w1, wg]).to(DEV).contiguous(), w_glu, wt_glu, glu_rows=f)
+    hd = ops.convert(h, X2.empty(M, d, DEV))
+    p, seed, site = 0.1, 77, 9
+    g1, sv = X2.empty(M, f, DEV), X2.empty(M, 2 * f, DEV)
+    sv.lo.fill_(7.0)
+    ops.gemm(hd, w_glu, g1, bias=dev(b), act=ACT_GLU_SAVE, pre_act=sv, dropout=ops.drop(p, seed, site), algo=2, glu_rows=f,
+             sg_hi_only=True)
+    assert ops.last_algo() == "mfma_nt_x3_glu"
+    rows = torch.cat([torch.arange(0, 256), torch.arange(M - 256, M)])
+    hq = hd.float()[rows.to(DEV)].cpu().double()
+    got_w = w_glu.float().cpu().double()
+    pos = (torch.arange(f) // 4) * 8 + torch.arange(f) % 4
+    u = hq @ got_w[pos].T + b[:f].double()
+    v = hq @ got_w[pos + 4].T + b[f:].double()
+    gel = 0.5 * u * (1 + torch.erf(u / math.sqrt(2)))
+    gp = 0.5 * (1 + torch.erf(u / math.sqrt(2))) + u * torch.exp(-u * u / 2) / math.sqrt(2 * math.pi)
+    keep = torch.cat([torch.from_numpy(keep_mask(p, seed, site, 256 * f, start=r0 * f)).view(256, f) for r0 in (0, M - 256)]).double() / (1 - p)
+    assert relnorm(g1.float()[rows.to(DEV)].cpu(), gel * v * keep) < 3e-5
+    svh = sv.hi[rows.to(DEV)].float().cpu().double()
+    assert relnorm(svh[:, pos], gp * v * keep) < 4e-3 and relnorm(svh[:, pos + 4], gel * keep) < 4e-3
+    assert float((sv.lo != 7.0).sum()) == 0
