@@ -165,6 +165,215 @@ __global__ __launch_bounds__(256, 3) void k_attn_fwd_mfma(AttnM a, const e16* __
   }
 }
 
+// ------------------------------------------------------------------------------------------ forward, 8 staggered waves
+// Round-3 form for long query sequences (Tq >= 256).  Measurements behind it (tools/experiments/pingpong.hip):
+// ONE wave issues at most one vector instruction per ~5 cycles, whereas the SIMD's vector pipe takes two to three waves' worth;
+// the matrix pipe is shared by the SIMD's waves.  Two waves that run the same tile loop half a tile apart -- one in its MFMA
+// segment (S = K Q^T, O += V^T P) while the other is in its softmax -- overlap almost completely, two waves in lockstep do not.
+//   workgroup = 8 waves x 32 queries = 256 queries of one (batch, head); waves w and w + 4 share a SIMD
+//   waves 4-7 run HALF A TILE LATE: the tile loop has ONE barrier per tile, which the early waves meet at the top of tile t and
+//   the late waves between the softmax and the P V product of tile t, so the offset is kept for the whole kernel
+//   K / V tiles (64 keys) arrive by LDS-DMA in a 3-stage ring shared by all 8 waves (half the L2 -> LDS traffic per query)
+// Vector work per score is cut as well: Q is multiplied by scale * log2(e) once per kernel, and the running maximum enters
+// the S^T accumulators as their initial value (S' = S - m), so a probability is one v_exp_f32; O and l are rescaled only when a
+// row maximum grew by more than 2^8 (wave-uniform branch; P <= 2^8 is exact in either 16-bit format and fp32 sums do not care).
+template <int DROP>
+__global__ __launch_bounds__(512, 2) void k_attn_fwd_st(AttnM a, const e16* __restrict__ Q,
+                                                        const e16* __restrict__ K,
+                                                        const e16* __restrict__ V, e16* __restrict__ O,
+                                                        float* __restrict__ lse) {
+  constexpr int STAGE = 2 * KT * DH * 2;   // K row image + V tr image
+  constexpr int NST = 4;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  unsigned long long* maskw = (unsigned long long*)(lds + NST * STAGE);
+  const int t = threadIdx.x, lane = t & 63, h = lane >> 5;
+  const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+  const bool late = w >= 4;
+  const AttnBlock blk_ = attn_block(a.H, a.B, (a.Tq + 255) / 256);
+  const int hd = blk_.hd, b = blk_.b;
+  const int q0 = blk_.xb * 256 + w * 32;
+  const int q = q0 + (lane & 31);
+  const int qc = q < a.Tq ? q : a.Tq - 1;
+  const bool wave_on = q0 < a.Tq;           // waves past the last query only keep the ring and the barriers going
+  const e16* Kb = K + (int64_t)b * a.Tk * a.ldk + hd * DH;
+  const e16* Vb = V + (int64_t)b * a.Tk * a.ldv + hd * DH;
+  int kend = a.Tk;
+  if (a.causal) kend = min(a.Tk, blk_.xb * 256 + 256);
+  const int ntiles = (kend + KT - 1) / KT;
+  // Q fragments, pre-multiplied by scale * log2(e): S comes out of the MFMA chain in log2 units
+  e16x8 qf[4];
+  {
+    const e16* qp = Q + ((int64_t)b * a.Tq + qc) * a.ldq + hd * DH + 8 * h;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const e16x8 x = *(const e16x8*)(qp + 16 * s);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) qf[s][j] = (e16)((float)x[j] * a.scale_log2);
+    }
+  }
+  build_mask_words(maskw, a.key_pad, b, a.Tk, ntiles, w & 3, lane);   // (both halves write the same words)
+  __syncthreads();   // plain loads retired before any LDS-DMA is in flight
+  auto issue = [&](int kt) {      // 16 pieces per tile: wave w moves piece w of the K image and of the V image
+    unsigned char* st = lds + (kt % NST) * STAGE;
+    dma_piece<false>(st, Kb, a.ldk, kt * KT, a.Tk, w, lane);
+    dma_piece<true>(st + KT * DH * 2, Vb, a.ldv, kt * KT, a.Tk, w, lane);
+  };
+  f32x16 o[2], s[2];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { o[0][i] = 0.f; o[1][i] = 0.f; }
+  float m = -INFINITY, l = 0.f;   // running maximum (log2 units; -inf until the row has seen an unmasked key) and row sum
+  e16x8 pf[4];                    // the tile's probabilities as MFMA operands (written by the vector segment)
+  const uint32_t rowbase = (uint32_t)(((uint64_t)(b * a.H + hd) * a.Tq + qc) * (uint64_t)a.Tk);
+  issue(0);
+  if (ntiles > 1) issue(1);
+  attn_wait_vmcnt<0>();
+  __builtin_amdgcn_s_barrier();
+
+  // one barrier per tile.  At barrier kt the early waves are about to run { O += V^T P (kt - 1) ; S (kt) } -- their MFMA segment --
+  // and the late waves softmax (kt), then their MFMA segment { O += V^T P (kt) ; S (kt + 1) }: tile kt + 1 has landed for
+  // everybody, tiles kt - 1 .. kt + 1 stay, stage (kt + 2) % 4 (tile kt - 2) is free for the next DMA
+  auto sync = [&](int kt) {
+#if !defined(AFM_ABL) || (AFM_ABL != 2 && AFM_ABL != 4)
+    attn_wait_vmcnt<0>();
+#endif
+#if !defined(AFM_ABL) || (AFM_ABL != 1 && AFM_ABL != 4)
+    __builtin_amdgcn_s_barrier();
+#endif
+#if !defined(AFM_ABL) || (AFM_ABL != 2 && AFM_ABL != 4)
+    if (kt + 2 < ntiles) issue(kt + 2);
+#endif
+  };
+  auto live = [&](int kt) {   // wave-uniform: the tile has unmasked keys for this wave
+    return wave_on && !(a.causal && kt * KT > q0 + 31) && maskw[kt] != ~0ull;
+  };
+  auto scores = [&](int kt) {
+    const unsigned char* Kimg = lds + (kt % NST) * STAGE;
+    const float init = m == -INFINITY ? 0.f : -m;
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) s[blk][i] = init;
+#pragma unroll
+#if defined(AFM_ABL) && AFM_ABL >= 3
+      for (int ks = 0; ks < 4; ++ks) s[blk] = mfma32(qf[(ks + blk) & 3], qf[ks], s[blk]);
+#else
+      for (int ks = 0; ks < 4; ++ks) s[blk] = mfma32(frag_row(Kimg, 32 * blk, ks, lane), qf[ks], s[blk]);
+      asm volatile("" ::: "memory");    // keep the second block's four fragment reads behind the first block's (16 fewer live registers)
+#endif
+    }
+  };
+  auto softmax = [&](int kt) {
+    const int kb = kt * KT;
+    const unsigned long long mword = maskw[kt];
+    const bool diag = a.causal && (kb + KT - 1 > q0);
+    if (mword != 0ull || diag) {
+      const unsigned long long pad = mword >> (4 * h);
+#pragma unroll
+      for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int ko = 32 * blk + ACC_ROW(r);
+          bool msk = (pad >> ko) & 1ull;
+          if (a.causal) msk = msk || (kb + ko + 4 * h > q);
+          s[blk][r] = msk ? -INFINITY : s[blk][r];
+        }
+    }
+    float mt = fmaxf(s[0][0], s[1][0]);
+#pragma unroll
+    for (int r = 1; r < 16; ++r) mt = max3_raw(mt, s[0][r], s[1][r]);
+    mt = fmaxf(mt, __shfl_xor(mt, 32, 64));        // maximum of S' = S - m over the tile's keys
+    // a row's first unmasked key sets m to the true maximum; afterwards m moves only when the row grew by more than 2^8
+    const bool unset = m == -INFINITY;
+    if (__any((unset && mt != -INFINITY) || mt > 8.f)) {
+      const float dlt = unset ? (mt == -INFINITY ? 0.f : mt) : fmaxf(mt, 0.f);
+      const float alpha = unset ? 1.f : fast_exp2(-dlt);     // (an unset row has accumulated nothing yet)
+      m = (unset && mt == -INFINITY) ? m : (unset ? dlt : m + dlt);
+      l *= alpha;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { o[0][i] *= alpha; o[1][i] *= alpha; s[0][i] -= dlt; s[1][i] -= dlt; }
+    }
+    float ls = 0.f;
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float p = fast_exp2(s[blk][r]);       // exp2(-inf) = 0 for masked keys
+        s[blk][r] = p;
+        ls += p;
+      }
+    l += ls;
+    if (DROP == DROP_HASH) {
+      drop_block(a.dd, rowbase, kb, h, s[0]);
+      drop_block(a.dd, rowbase, kb + 32, h, s[1]);
+    }
+    if (DROP == DROP_BITS) {
+      unsigned long long* bb = bits_block(a, b * a.H + hd, q0 >> 5, kb >> 5);
+      drop_block_emit(a.dd, rowbase, kb, h, s[0], bb);
+      drop_block_emit(a.dd, rowbase, kb + 32, h, s[1], bb + 16);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) pf[i] = cvt8(s[i >> 1], i & 1);
+  };
+  auto pv = [&](int kt) {
+    const unsigned char* Vimg = lds + (kt % NST) * STAGE + KT * DH * 2;
+#if defined(AFM_ABL) && AFM_ABL >= 3
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { o[0] = mfma32(qf[i], pf[i], o[0]); o[1] = mfma32(qf[(i + 1) & 3], pf[i], o[1]); }
+#else
+    unsigned va0, va1;
+    tr_lane_addr(Vimg, lane, va0, va1);
+    TrQuad vq[2];
+    vq[0] = tr_issue(va0, va1, 0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if (i < 3) vq[(i + 1) & 1] = tr_issue(va0, va1, 16 * (i + 1));
+      if (i < 3) tr_wait<4>(); else tr_wait<0>();
+      o[0] = mfma32(tr_join(vq[i & 1].lo0, vq[i & 1].hi0), pf[i], o[0]);
+      o[1] = mfma32(tr_join(vq[i & 1].lo1, vq[i & 1].hi1), pf[i], o[1]);
+    }
+#endif
+  };
+  __builtin_assume(ntiles >= 1);
+  // Each wave alternates an MFMA segment { P V of the previous tile ; S of the next } with a vector segment (softmax); the
+  // barrier sits at the START of the early waves' MFMA segment and at the START of the late waves' vector segment, so the
+  // two waves of a SIMD are held in opposite segments (two MFMA segments side by side would serialise on the matrix pipe).
+  bool pl = false;      // the previous tile was live: its P V product is pending
+  if (!late) {
+    for (int kt = 0; kt < ntiles; ++kt) {
+      sync(kt);
+      if (pl) pv(kt - 1);
+      pl = live(kt);
+      if (pl) { scores(kt); softmax(kt); }
+    }
+    if (pl) pv(ntiles - 1);
+  } else {
+    __builtin_amdgcn_s_setprio(1);      // the younger half loses issue arbitration otherwise (MI355X_MICROARCH.md, two waves per SIMD)
+    bool lv = live(0);
+    if (lv) scores(0);
+    for (int kt = 0; kt < ntiles; ++kt) {
+      sync(kt);
+      if (lv) { softmax(kt); pv(kt); }
+      lv = kt + 1 < ntiles && live(kt + 1);
+      if (lv) scores(kt + 1);
+    }
+  }
+  if (DROP == DROP_BITS) bits_flush();
+  l += __shfl_xor(l, 32, 64);
+  const float inv = l > 0.f ? a.dd.scale16 / l : 0.f;
+  if (q < a.Tq) {
+    e16* op = O + ((int64_t)b * a.Tq + q) * a.ldo + hd * DH + 4 * h;
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        e16x4 v = {(e16)(o[db][4 * g4 + 0] * inv), (e16)(o[db][4 * g4 + 1] * inv),
+                    (e16)(o[db][4 * g4 + 2] * inv), (e16)(o[db][4 * g4 + 3] * inv)};
+        *(e16x4*)(op + 32 * db + 8 * g4) = v;
+      }
+    if (h == 0) lse[((int64_t)b * a.H + hd) * a.Tq + q] = l > 0.f ? (m + __log2f(l)) * 0.69314718055994531f : INFINITY;
+  }
+}
+
 // ------------------------------------------------------------------------------------------ dQ
 // Per 64-key tile: S^T and dP^T (keys in registers, query on the lane), then
 // dQ^T[d][q] += sum_key K^T[d][key] dS^T[key][q].  Also writes delta = rowsum(dO * O).
@@ -207,7 +416,18 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd_dq_mfma(AttnM a, const e16*
   const int64_t lrow = ((int64_t)b * a.H + hd) * a.Tq + qc;
   if (q < a.Tq && h == 0) delta[lrow] = dl;
   const float L = lse[lrow];
-  const float L2 = L == INFINITY ? INFINITY : L * 1.4426950408889634f;  // log2 units
+  // Row constants as the initial accumulators (round 3): Q is pre-multiplied by scale * log2(e) and S^T starts at -lse (log2
+  // units), so p = exp2(S') is one instruction; dO is pre-multiplied by the dropout scale and dP^T starts at -delta, so
+  // dS = p * (keep ? acc : -delta) is a select and a multiply.
+  const float nL2 = L == INFINITY ? -INFINITY : -L * 1.4426950408889634f;
+  const float ndl = -dl;
+#pragma unroll
+  for (int s = 0; s < 4; ++s)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      qf[s][j] = (e16)((float)qf[s][j] * a.scale_log2);
+      if (DROP != DROP_NONE) dof[s][j] = (e16)((float)dof[s][j] * a.dd.scale16);
+    }
   f32x16 dq[2];
 #pragma unroll
   for (int i = 0; i < 16; ++i) { dq[0][i] = 0.f; dq[1][i] = 0.f; }
@@ -256,18 +476,14 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd_dq_mfma(AttnM a, const e16*
     for (int blk = 0; blk < 2; ++blk) {
       f32x16 s, dp;
 #pragma unroll
-      for (int i = 0; i < 16; ++i) { s[i] = 0.f; dp[i] = 0.f; }
+      for (int i = 0; i < 16; ++i) { s[i] = nL2; dp[i] = ndl; }
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
         s = mfma32(frag_row(Krow, 32 * blk, ks, lane), qf[ks], s);
         dp = mfma32(frag_row(Vrow, 32 * blk, ks, lane), dof[ks], dp);
       }
-      if (DROP == DROP_HASH) {
-        drop_block(a.dd, rowbase, kb + 32 * blk, h, dp);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) dp[r] *= a.dd.scale16;
-      }
-      if (DROP == DROP_BITS) drop_apply_masks(dp, km[blk], a.dd.scale16);
+      if (DROP == DROP_HASH) drop_block_select(a.dd, rowbase, kb + 32 * blk, h, dp, ndl);
+      if (DROP == DROP_BITS) drop_select_masks(dp, km[blk], ndl);
       if (mword != 0ull || (a.causal && (kb + KT - 1 > q0))) {   // wave-uniform: tile has masked keys
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -279,8 +495,8 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd_dq_mfma(AttnM a, const e16*
       }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float p = fast_exp2(fmaf(s[r], a.scale_log2, -L2));   // masked: exp2(-inf) = 0
-        s[r] = p * (dp[r] - dl);   // dS^T (the 1/sqrt(dh) factor is applied once at the end)
+        const float p = fast_exp2(s[r]);   // masked: exp2(-inf) = 0
+        s[r] = p * dp[r];   // dS^T = P (D dP - delta) (the 1/sqrt(dh) factor is applied once at the end)
       }
       {
         const TrQuad k0q = tr_issue(ka0, ka1, 32 * blk), k1q = tr_issue(ka0, ka1, 32 * blk + 16);
@@ -339,6 +555,16 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd_dkv_mfma(AttnM a, const e16
     const e16* vp = V + ((int64_t)b * a.Tk + kc) * a.ldv + hd * DH + 8 * h;
 #pragma unroll
     for (int s = 0; s < 4; ++s) { kf[s] = *(const e16x8*)(kp + 16 * s); vf[s] = *(const e16x8*)(vp + 16 * s); }
+    // round 3: K pre-multiplied by scale * log2(e) (S comes out in log2 units, -lse[q] is the chain's initial value: p = exp2(S')
+    // is one instruction), V by the dropout scale (dP' = scale * dP with -delta[q] as initial value: dS = p * (keep ? acc : -delta));
+    // dV accumulates the UNSCALED dropped probabilities and takes the dropout scale once at the end
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        kf[s][j] = (e16)((float)kf[s][j] * a.scale_log2);
+        if (DROP != DROP_NONE) vf[s][j] = (e16)((float)vf[s][j] * a.dd.scale16);
+      }
   }
   f32x16 dk[2], dv[2];
 #pragma unroll
@@ -396,12 +622,18 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd_dkv_mfma(AttnM a, const e16
 #pragma unroll
     for (int blk = 0; blk < 2; ++blk) {
       f32x16 s, dp;
+      float nd[16];                       // -delta of the register's query row
 #pragma unroll
-      for (int i = 0; i < 16; ++i) { s[i] = 0.f; dp[i] = 0.f; }
+      for (int g4 = 0; g4 < 4; ++g4) {    // initial accumulators: -lse[q] (log2 units; lse = +inf for an all-masked row) and -delta[q]
+        const f32x4 Lq = *(const f32x4*)(Ls + 32 * blk + 8 * g4 + 4 * h) * -1.4426950408889634f;
+        const f32x4 Dq = *(const f32x4*)(Ds + 32 * blk + 8 * g4 + 4 * h);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { s[4 * g4 + j] = Lq[j]; nd[4 * g4 + j] = -Dq[j]; dp[4 * g4 + j] = -Dq[j]; }
+      }
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
-        s = mfma32(frag_row(Qrow, 32 * blk, ks, lane), kf[ks], s);     // S[q][key]
-        dp = mfma32(frag_row(Drow, 32 * blk, ks, lane), vf[ks], dp);   // dP[q][key]
+        s = mfma32(frag_row(Qrow, 32 * blk, ks, lane), kf[ks], s);     // S'[q][key] = S log2(e) / sqrt(dh) - lse[q]
+        dp = mfma32(frag_row(Drow, 32 * blk, ks, lane), vf[ks], dp);   // scale dP[q][key] - delta[q]
       }
       f32x16 pd;
       // Uniform conditions select whole loops (a branch per score would sit inside the unrolled body).
@@ -414,20 +646,14 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd_dkv_mfma(AttnM a, const e16
         }
       }
 #pragma unroll
-      for (int g4 = 0; g4 < 4; ++g4) {   // p = exp2(s*scale - lse[q]); masked keys: outputs zeroed at the end
-        const f32x4 Lq = *(const f32x4*)(Ls + 32 * blk + 8 * g4 + 4 * h) * 1.4426950408889634f;   // log2 units; +inf stays
-#pragma unroll
-        for (int j = 0; j < 4; ++j) pd[4 * g4 + j] = fast_exp2(fmaf(s[4 * g4 + j], a.scale_log2, -Lq[j]));
-      }
+      for (int r = 0; r < 16; ++r) pd[r] = fast_exp2(s[r]);     // masked keys: outputs zeroed at the end
       if (DROP == DROP_BITS) {   // one dword per lane and 32-query block: bit q = keep(query q, this lane's key)
         const uint32_t word = ((const uint32_t*)(Qrow + 4 * KT * DH * 2 + 2 * KT * 4 + w * 256))[32 * blk + bits_word_of_key(lane & 31)] >> (4 * h);
-        const int sbits = __builtin_bit_cast(int, a.dd.scale16);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const float kp = __builtin_bit_cast(float, __builtin_amdgcn_sbfe((int)word, ACC_ROW(r), 1) & sbits);   // scale or 0
-          dp[r] *= kp;
-          s[r] = pd[r];
-          pd[r] *= kp;
+          const bool kp = (int)(word << (31 - ACC_ROW(r))) < 0;      // shift the row's bit into the sign: one shift, one compare
+          s[r] = pd[r] * (kp ? dp[r] : nd[r]);                       // dS = P (D dP - delta)
+          pd[r] = kp ? pd[r] : 0.f;                                  // dropped P for dV
         }
       } else if (DROP == DROP_HASH) {
         // Dropout keep bits.  Element (q, key) has index i = (lbase+q)*Tk + key; with Tk even the two
@@ -442,21 +668,13 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd_dkv_mfma(AttnM a, const e16
           const uint32_t own = hash_pair32(a.dd, tb + (uint32_t)ACC_ROW(r) * htk);   // row r + (lane&1)
           const uint32_t oth = (uint32_t)__builtin_amdgcn_mov_dpp((int)own, 0xB1, 0xF, 0xF, true);  // lane^1
           const uint32_t h0 = (lane & 1) ? oth : own, h1 = (lane & 1) ? own : oth;
-          const float k0 = ((h0 >> hshift) & 0xFFFFu) >= a.dd.thresh16 ? a.dd.scale16 : 0.f;
-          const float k1 = ((h1 >> hshift) & 0xFFFFu) >= a.dd.thresh16 ? a.dd.scale16 : 0.f;
-          dp[r] *= k0; dp[r + 1] *= k1;
-          s[r] = pd[r]; s[r + 1] = pd[r + 1];            // undropped p for dS
-          pd[r] *= k0; pd[r + 1] *= k1;                  // dropped p for dV
+          const bool k0 = ((h0 >> hshift) & 0xFFFFu) >= a.dd.thresh16, k1 = ((h1 >> hshift) & 0xFFFFu) >= a.dd.thresh16;
+          s[r] = pd[r] * (k0 ? dp[r] : nd[r]); s[r + 1] = pd[r + 1] * (k1 ? dp[r + 1] : nd[r + 1]);
+          pd[r] = k0 ? pd[r] : 0.f; pd[r + 1] = k1 ? pd[r + 1] : 0.f;
         }
       } else {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) s[r] = pd[r];
-      }
-#pragma unroll
-      for (int g4 = 0; g4 < 4; ++g4) {   // dS = p (D dP - delta[q])
-        const f32x4 Dq = *(const f32x4*)(Ds + 32 * blk + 8 * g4 + 4 * h);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) s[4 * g4 + j] *= dp[4 * g4 + j] - Dq[j];
+        for (int r = 0; r < 16; ++r) s[r] = pd[r] * dp[r];
       }
       {
         const TrQuad d0 = tr_issue(da0, da1, 32 * blk), q0f = tr_issue(qa0, qa1, 32 * blk);
@@ -478,6 +696,10 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd_dkv_mfma(AttnM a, const e16
   if (kmasked) {   // a padded key took no part in any softmax: its dK / dV rows are zero
 #pragma unroll
     for (int i = 0; i < 16; ++i) { dk[0][i] = 0.f; dk[1][i] = 0.f; dv[0][i] = 0.f; dv[1][i] = 0.f; }
+  }
+  if (DROP != DROP_NONE) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { dv[0][i] *= a.dd.scale16; dv[1][i] *= a.dd.scale16; }
   }
   if (key < a.Tk) {
     e16* dkp = dK + ((int64_t)b * a.Tk + key) * a.lddk + hd * DH + 4 * h;
@@ -527,6 +749,24 @@ int AFM_E16_FN(afm_attn_fwd_mfma_try)(const afm_attn_shape* s, const void* Q, co
   const int lds[] = {s->ldq, s->ldk, s->ldv, s->ldo};
   if (!eligible(s, ptrs, 4, lds, 4)) return AFM_ERR_UNSUPPORTED;
   const AttnM a = make_m(s);
+  // long query sequences: 8 staggered waves per workgroup (256 queries); reserved = 8 keeps the 4-wave kernel (A/B timing)
+  if (s->Tq >= 256 && s->reserved != 8) {
+    const dim3 grid8(((s->Tq + 255) / 256) * s->H * s->B);
+    const int shm8 = 4 * 2 * KT * DH * 2 + ((s->Tk + KT - 1) / KT) * 8;
+    if (shm8 > 80 * 1024) return AFM_ERR_UNSUPPORTED;
+    static bool attr8 = false;
+    if (!attr8) {
+      (void)hipFuncSetAttribute((const void*)k_attn_fwd_st<DROP_HASH>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+      (void)hipFuncSetAttribute((const void*)k_attn_fwd_st<DROP_BITS>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+      (void)hipFuncSetAttribute((const void*)k_attn_fwd_st<DROP_NONE>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+      attr8 = true;
+    }
+    if (a.dd.thresh16 && a.bits) AFM_LAUNCH(k_attn_fwd_st<DROP_BITS>, grid8, dim3(512), shm8, st, a, (const e16*)Q, (const e16*)K, (const e16*)V, (e16*)O, lse);
+    else if (a.dd.thresh16) AFM_LAUNCH(k_attn_fwd_st<DROP_HASH>, grid8, dim3(512), shm8, st, a, (const e16*)Q, (const e16*)K, (const e16*)V, (e16*)O, lse);
+    else AFM_LAUNCH(k_attn_fwd_st<DROP_NONE>, grid8, dim3(512), shm8, st, a, (const e16*)Q, (const e16*)K, (const e16*)V, (e16*)O, lse);
+    afm_set_last_algo("attn_mfma");
+    return AFM_OK;
+  }
   const dim3 grid(((s->Tq + 127) / 128) * s->H * s->B);
   const int shm = RS * 2 * KT * DH * 2 + ((s->Tk + KT - 1) / KT) * 8;
   if (shm > 64 * 1024) return AFM_ERR_UNSUPPORTED;

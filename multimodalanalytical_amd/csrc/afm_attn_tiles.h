@@ -290,5 +290,31 @@ __device__ __forceinline__ void drop_apply_masks(f32x16& x, KeepMasks& m, float 
   keep_masks_wait(m);
   keep_apply_rows<0>(x, m, scale);
 }
+// Select forms for the single-pass backward kernels (round 3): the accumulator already holds  scale * dP - delta  (V / dO
+// fragments pre-multiplied by the dropout scale, -delta as the chain's initial value), so dropout is ONE select per score,
+// x = keep ? x : alt.  __builtin_amdgcn_inverse_ballot_w64 turns the 64-bit SGPR mask into the select's condition without an
+// instruction, and the v_cndmask is compiler-emitted (it gets the MFMA -> VALU wait states an asm statement would not).
+template <int R>
+__device__ __forceinline__ void keep_select_rows(f32x16& x, const KeepMasks& m, float alt) {
+  if constexpr (R < 16) {
+    const u32x16& v = R < 8 ? m.a : m.b;
+    const unsigned long long mk = ((unsigned long long)v[2 * (R & 7) + 1] << 32) | v[2 * (R & 7)];
+    x[R] = __builtin_amdgcn_inverse_ballot_w64(mk) ? x[R] : alt;
+    keep_select_rows<R + 1>(x, m, alt);
+  }
+}
+__device__ __forceinline__ void drop_select_masks(f32x16& x, KeepMasks& m, float alt) {
+  keep_masks_wait(m);
+  keep_select_rows<0>(x, m, alt);
+}
+__device__ __forceinline__ void drop_block_select(const DropDev& dd, uint32_t rowbase, int key0, int h, f32x16& x, float alt) {
+  const uint32_t base = (rowbase + (uint32_t)(key0 + 4 * h)) >> 1;
+#pragma unroll
+  for (int r = 0; r < 16; r += 2) {
+    const uint32_t hsh = hash_pair32(dd, base + (uint32_t)(ACC_ROW(r) >> 1));
+    x[r] = (hsh & 0xFFFFu) >= dd.thresh16 ? x[r] : alt;
+    x[r + 1] = (hsh >> 16) >= dd.thresh16 ? x[r + 1] : alt;
+  }
+}
 // backward, key-on-lane layout (dK/dV kernel): dword of the block that holds this lane's key (bit q = keep of the tile's query q)
 __device__ __forceinline__ int bits_word_of_key(int j) { return 2 * ((j & 3) + 4 * (j >> 3)) + ((j >> 2) & 1); }

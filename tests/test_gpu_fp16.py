@@ -119,10 +119,18 @@ def test_gemm_f16_generic_odd_shapes(ops):
 # ------------------------------------------------------------------ attention
 @pytest.mark.parametrize("B,H,Tq,Tk,causal,pad,pdrop", [
     (2, 2, 128, 128, True, True, 0.0), (2, 3, 100, 200, False, True, 0.0), (1, 2, 192, 192, True, False, 0.0),
-    (2, 2, 128, 256, False, True, 0.1), (1, 2, 160, 160, True, True, 0.1), (2, 2, 130, 520, False, True, 0.1), (2, 2, 256, 56, False, True, 0.1)])
+    (2, 2, 128, 256, False, True, 0.1), (1, 2, 160, 160, True, True, 0.1), (2, 2, 130, 520, False, True, 0.1), (2, 2, 256, 56, False, True, 0.1),
+    (1, 2, 320, 320, True, True, 0.1), (2, 2, 512, 1024, False, "blocks", 0.1), (1, 1, 1024, 1024, False, False, 0.0), (1, 2, 300, 300, False, False, 0.0)])
 def test_attention_f16(ops, B, H, Tq, Tk, causal, pad, pdrop):
     dh, dt = 64, H16
     q, k, v, key_pad = _attn_case(B, H, Tq, Tk, dh, causal, bool(pad), seed=10)
+    if pad == "blocks":   # whole 64-key tiles of padding, as in multimodal batches
+        key_pad = torch.zeros(B, Tk, dtype=torch.bool)
+        key_pad[0, 64:192] = True; key_pad[0, 300:] = True
+        key_pad[1, 128:160] = True; key_pad[1, 448:512] = True
+    if Tq == 1024:        # a score spike far above the running maximum in a LATE tile: the deferred-rescale branch must fire
+        k[0, 700, 0] = q[0, 5, 0] * 6.0
+        k[0, 900, 0] = q[0, 37, 0] * 9.0
     q, k, v = q.half().float(), k.half().float(), v.half().float()
     D = H * dh
     qd, kd, vd = (dev(t.reshape(-1, D), dt) for t in (q, k, v))

@@ -410,7 +410,8 @@ def _attn_ref(q, k, v, key_pad, causal, keep=None, dscale=1.0):
 @pytest.mark.parametrize("B,H,Tq,Tk,causal,pad,pdrop", [
     (2, 2, 128, 128, True, True, 0.0), (2, 3, 100, 200, False, True, 0.0), (1, 2, 300, 300, False, False, 0.0),
     (1, 2, 192, 192, True, False, 0.0), (2, 2, 128, 256, False, True, 0.1), (1, 2, 160, 160, True, True, 0.1),
-    (2, 2, 130, 520, False, "blocks", 0.1), (2, 2, 256, 56, False, True, 0.1), (2, 2, 56, 56, False, True, 0.1)])
+    (2, 2, 130, 520, False, "blocks", 0.1), (2, 2, 256, 56, False, True, 0.1), (2, 2, 56, 56, False, True, 0.1),
+    (1, 2, 320, 320, True, True, 0.1), (2, 2, 512, 1024, False, "blocks", 0.1)])
 def test_attention_mfma(ops, B, H, Tq, Tk, causal, pad, pdrop):
     dh, dt = 64, torch.bfloat16
     q, k, v, key_pad = _attn_case(B, H, Tq, Tk, dh, causal, bool(pad), seed=10)
@@ -445,7 +446,7 @@ def test_attention_mfma(ops, B, H, Tq, Tk, causal, pad, pdrop):
     qr, kr, vr, ref = _attn_ref(q, k, v, key_pad, causal, keep, dscale)
     ref_o = ref.transpose(1, 2).reshape(B * Tq, D)
     close(res[2][0], ref_o, 2e-2, 2e-2, "mfma fwd vs oracle")
-    close(res[2][1], res[1][1].cpu(), 1e-3, 1e-3, "lse mfma vs generic")
+    close(res[2][1], res[1][1].cpu(), 4e-3, 4e-3, "lse mfma vs generic")      # (Q * scale * log2e is rounded to bf16 once more in the 8-wave kernel)
     do = rnd(B * Tq, D, seed=9).bfloat16().float()
     ref.backward(do.double().view(B, Tq, H, dh).transpose(1, 2))
     o, lse, shp = res[2]

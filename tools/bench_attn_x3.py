@@ -22,9 +22,10 @@ def main():
     ap.add_argument("--S", type=int, default=1024); ap.add_argument("--Tq", type=int, default=0)
     ap.add_argument("--p", type=float, default=0.1); ap.add_argument("--causal", type=int, default=0)
     ap.add_argument("--bits", type=int, default=1, help="1: forward stores the keep-bit tensor, backward reads it; 0: re-hash")
+    ap.add_argument("--old", type=int, default=0, help="1: also time the 4-wave kernels (afm_attn_shape.reserved = 8 / 9 / 10)")
     a = ap.parse_args()
     dev = "cuda:0"
-    cd = {"bf16": torch.bfloat16, "bf16x3": X2.dtype, "fp32": torch.float32}[a.mode]
+    cd = {"bf16": torch.bfloat16, "fp16": torch.float16, "bf16x3": X2.dtype, "fp32": torch.float32}[a.mode]
     B, H, S, dh = a.B, a.H, a.S, 64
     Tq = a.Tq or S
     d = H * dh
@@ -50,9 +51,13 @@ def main():
     bits = torch.zeros(ops.attn_drop_bits_words(B, H, Tq, S), dtype=torch.int64, device=dev) if a.bits and a.p > 0 else None
     s0, s1, s2 = shp(0), shp(1), shp(2)
     passes = 3 if a.mode == "bf16x3" else 1
-    for name, fn, np_ in (("fwd", lambda: ops.attn_fwd(s0, q, k, v, o, lse), 2),
+    cases = []
+    if a.old:
+        s8 = shp(8)
+        cases.append(("fwd4", lambda: ops.attn_fwd(s8, q, k, v, o, lse), 2))
+    for name, fn, np_ in cases + [("fwd", lambda: ops.attn_fwd(s0, q, k, v, o, lse), 2),
                           ("dq", lambda: ops.attn_bwd(s1, q, k, v, o, do, lse, delta, dq, dk, dv, ops._ld(dq), ops._ld(dk), ops._ld(dv)), 3),
-                          ("dkv", lambda: ops.attn_bwd(s2, q, k, v, o, do, lse, delta, dq, dk, dv, ops._ld(dq), ops._ld(dk), ops._ld(dv)), 4)):
+                          ("dkv", lambda: ops.attn_bwd(s2, q, k, v, o, do, lse, delta, dq, dk, dv, ops._ld(dq), ops._ld(dk), ops._ld(dv)), 4)]:
         ms = t(fn)
         print(f"{a.mode} {name:4s} [{ops.last_algo()}] {ms:.3f} ms  {np_ * prod / ms / 1e9:.0f} TF/s algorithmic, "
               f"{passes * np_ * prod / ms / 1e9 / 2500:.3f} of MFMA peak executed")
