@@ -401,6 +401,21 @@ int afm_adam_step(float* p, float* g, float* m, float* v, int64_t n, const float
                   const float* sumsq, void* p_lowp, int32_t lowp_dtype, int32_t zero_grad, const float* scaler, void* stream);
 int afm_scaler_update(float* scaler, const float* sumsq, float growth, float backoff, int32_t interval, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Data-parallel gradient exchange (reference: Lightning DDP, trainer/trainer.py:58 + cli/training.py:49-59: one
+ * all-reduce of the gradients per optimiser step).  One process per GPU; the flat fp32 gradient buffer is summed over the ranks
+ * in buckets, back to front while the backward pass still runs, each bucket as ONE RCCL all-reduce (xGMI rings inside a node)
+ * enqueued on `stream` (the caller's side stream; events order it against the compute stream).  The mean (1/world) is folded
+ * into afm_adam_step's grad_mult.  librccl.so is resolved at run time (dlopen; AFM_RCCL_PATH overrides): AFM_ERR_UNSUPPORTED
+ * when it cannot be found.  Bootstrap: rank 0 calls afm_comm_unique_id, the 128 bytes travel to the other ranks by any means
+ * (the host side uses its torch.distributed store), every rank calls afm_comm_create with the current device selected.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct afm_comm afm_comm;
+int afm_comm_unique_id(void* out128);
+int afm_comm_create(afm_comm** out, const void* id128, int32_t rank, int32_t world);
+int afm_allreduce_bucket(afm_comm* comm, float* buf, int64_t n, void* stream);      /* buf[0..n) = sum over ranks, in place */
+int afm_comm_destroy(afm_comm* comm);
+
 #ifdef __cplusplus
 }
 #endif

@@ -33,7 +33,7 @@ import torch
 
 from ..config import compose, wrapper_kwargs
 from ..params import PATCH_TYPES, TEXT_TYPES
-from ..trainer import calculate_training_steps
+from ..trainer import sync_flag, calculate_training_steps
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 DEFAULT_CONFIG_DIR = os.path.join(os.path.dirname(os.path.dirname(HERE)), "configs")
@@ -210,6 +210,7 @@ def run(cfg: Dict[str, Any], own: Dict[str, str]) -> Dict[str, Any]:
             if loop.optim.step_count >= plan["train_steps"] or (max_steps and loop.optim.step_count >= max_steps):
                 break
             loop.micro_batch(batch, i)
+        loop.flush()      # Lightning steps the optimiser on the last batch of an epoch even when the accumulation window is not full
         nval = len(val)
         lim = plan["limit_val_batches"]
         nval = min(nval, int(lim) if isinstance(lim, int) or float(lim) > 1.0 else max(1, int(nval * float(lim))))
@@ -231,7 +232,8 @@ def run(cfg: Dict[str, Any], own: Dict[str, str]) -> Dict[str, Any]:
                     os.remove(old)
             top[:] = top[:5]
             stale = 0 if top[0][1] == path else stale + 1
-        if plan["early_stopping_patience"] and stale >= plan["early_stopping_patience"]:
+        # EarlyStopping stops every rank in the same epoch: rank 0 owns the checkpoint ranking, its decision is broadcast
+        if sync_flag(bool(plan["early_stopping_patience"] and stale >= plan["early_stopping_patience"]), 0, device):
             break
     result = {"history": history, "run_dir": plan["run_dir"], "train_steps": plan["train_steps"], "precision": precision}
     if rank == 0:

@@ -754,12 +754,11 @@ int AFM_E16_FN(afm_attn_fwd_mfma_try)(const afm_attn_shape* s, const void* Q, co
     const dim3 grid8(((s->Tq + 255) / 256) * s->H * s->B);
     const int shm8 = 4 * 2 * KT * DH * 2 + ((s->Tk + KT - 1) / KT) * 8;
     if (shm8 > 80 * 1024) return AFM_ERR_UNSUPPORTED;
-    static bool attr8 = false;
-    if (!attr8) {
+    static AfmOncePerDevice attr8;
+    if (attr8.need()) {
       (void)hipFuncSetAttribute((const void*)k_attn_fwd_st<DROP_HASH>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
       (void)hipFuncSetAttribute((const void*)k_attn_fwd_st<DROP_BITS>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
       (void)hipFuncSetAttribute((const void*)k_attn_fwd_st<DROP_NONE>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-      attr8 = true;
     }
     if (a.dd.thresh16 && a.bits) AFM_LAUNCH(k_attn_fwd_st<DROP_BITS>, grid8, dim3(512), shm8, st, a, (const e16*)Q, (const e16*)K, (const e16*)V, (e16*)O, lse);
     else if (a.dd.thresh16) AFM_LAUNCH(k_attn_fwd_st<DROP_HASH>, grid8, dim3(512), shm8, st, a, (const e16*)Q, (const e16*)K, (const e16*)V, (e16*)O, lse);
@@ -788,12 +787,11 @@ int AFM_E16_FN(afm_attn_bwd_mfma_try)(const afm_attn_shape* s, const void* Q, co
   const dim3 gq(((s->Tq + 127) / 128) * s->H * s->B), gk(((s->Tk + 127) / 128) * s->H * s->B);
   const int shm_q = RS * 3 * KT * DH * 2 + ((s->Tk + KT - 1) / KT) * 8;
   if (shm_q > 80 * 1024) return AFM_ERR_UNSUPPORTED;
-  static bool attr_q = false;
-  if (!attr_q) {
+  static AfmOncePerDevice attr_q;
+  if (attr_q.need()) {
     (void)hipFuncSetAttribute((const void*)k_attn_bwd_dq_mfma<DROP_HASH>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
     (void)hipFuncSetAttribute((const void*)k_attn_bwd_dq_mfma<DROP_BITS>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
     (void)hipFuncSetAttribute((const void*)k_attn_bwd_dq_mfma<DROP_NONE>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-    attr_q = true;
   }
   const bool run_q = s->reserved != 2, run_k = s->reserved != 1;   // reserved = 1 / 2: only the dQ / only the dK-dV kernel (timing)
   if (!run_q) {}
@@ -801,12 +799,11 @@ int AFM_E16_FN(afm_attn_bwd_mfma_try)(const afm_attn_shape* s, const void* Q, co
   else if (a.dd.thresh16) AFM_LAUNCH(k_attn_bwd_dq_mfma<DROP_HASH>, gq, dim3(256), shm_q, st, a, (const e16*)Q, (const e16*)K, (const e16*)V, (const e16*)O, (const e16*)dO, lse, delta, (e16*)dQ);
   else AFM_LAUNCH(k_attn_bwd_dq_mfma<DROP_NONE>, gq, dim3(256), shm_q, st, a, (const e16*)Q, (const e16*)K, (const e16*)V, (const e16*)O, (const e16*)dO, lse, delta, (e16*)dQ);
   const int shm_k = 2 * (4 * KT * DH * 2 + 2 * KT * 4 + 4 * 256);
-  static bool attr_k = false;
-  if (!attr_k) {
+  static AfmOncePerDevice attr_k;
+  if (attr_k.need()) {
     (void)hipFuncSetAttribute((const void*)k_attn_bwd_dkv_mfma<DROP_HASH>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
     (void)hipFuncSetAttribute((const void*)k_attn_bwd_dkv_mfma<DROP_BITS>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
     (void)hipFuncSetAttribute((const void*)k_attn_bwd_dkv_mfma<DROP_NONE>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-    attr_k = true;
   }
   if (!run_k) {}
   else if (a.dd.thresh16 && a.bits) AFM_LAUNCH(k_attn_bwd_dkv_mfma<DROP_BITS>, gk, dim3(256), shm_k, st, a, (const e16*)Q, (const e16*)K, (const e16*)V, (const e16*)dO, lse, delta, (e16*)dK, (e16*)dV);

@@ -546,12 +546,11 @@ int afm_attn_fwd_x3_try(const afm_attn_shape* s, const void* Q, const void* K, c
   const dim3 grid(((s->Tq + 127) / 128) * s->H * s->B);
   const int shm = 2 * 4 * IMG64 + ((s->Tk + KT - 1) / KT) * 8;
   if (shm > 80 * 1024) return AFM_ERR_UNSUPPORTED;
-  static bool attr = false;
-  if (!attr) {
+  static AfmOncePerDevice attr;
+  if (attr.need()) {
     (void)hipFuncSetAttribute((const void*)k_attn_fwd_x3<DROP_HASH>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
     (void)hipFuncSetAttribute((const void*)k_attn_fwd_x3<DROP_BITS>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
     (void)hipFuncSetAttribute((const void*)k_attn_fwd_x3<DROP_NONE>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-    attr = true;
   }
   if (a.dd.thresh16 && a.bits) AFM_LAUNCH(k_attn_fwd_x3<DROP_BITS>, grid, dim3(256), shm, st, a, (const bf16*)Q, (const bf16*)K, (const bf16*)V, (bf16*)O, lse);
   else if (a.dd.thresh16) AFM_LAUNCH(k_attn_fwd_x3<DROP_HASH>, grid, dim3(256), shm, st, a, (const bf16*)Q, (const bf16*)K, (const bf16*)V, (bf16*)O, lse);
@@ -572,15 +571,14 @@ int afm_attn_bwd_x3_try(const afm_attn_shape* s, const void* Q, const void* K, c
   const int shm_q = 2 * 4 * IMG32 + ((s->Tk + 63) / 64) * 8;
   const int shm_k = 4 * 2 * 4096 + 2 * (4 * IMG32 + 2 * 64 * 4 + 4 * 256);
   if (shm_q > 80 * 1024) return AFM_ERR_UNSUPPORTED;
-  static bool attr = false;
-  if (!attr) {
+  static AfmOncePerDevice attr;
+  if (attr.need()) {
     (void)hipFuncSetAttribute((const void*)k_attn_bwd_dq_x3<DROP_HASH>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
     (void)hipFuncSetAttribute((const void*)k_attn_bwd_dq_x3<DROP_BITS>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
     (void)hipFuncSetAttribute((const void*)k_attn_bwd_dq_x3<DROP_NONE>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
     (void)hipFuncSetAttribute((const void*)k_attn_bwd_dkv_x3<DROP_HASH>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
     (void)hipFuncSetAttribute((const void*)k_attn_bwd_dkv_x3<DROP_BITS>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
     (void)hipFuncSetAttribute((const void*)k_attn_bwd_dkv_x3<DROP_NONE>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-    attr = true;
   }
   const bool run_q = s->reserved != 2, run_k = s->reserved != 1;   // reserved = 1 / 2: only the dQ / only the dK-dV kernel (timing)
   if (!run_q) {}

@@ -58,6 +58,21 @@ __device__ __forceinline__ afm_f32x16_ mfma32_raw(f16x8 a, f16x8 b, afm_f32x16_ 
     if (hipGetLastError() != hipSuccess) return AFM_ERR_LAUNCH;            \
   } while (0)
 
+// hipFuncSetAttribute (the > 64 KiB dynamic LDS opt-in) is PER DEVICE: a process-wide `static bool` would leave the kernels of a
+// second GPU driven by the same process at the default limit.  need() is true the first time it is called on each device.
+#include <atomic>
+struct AfmOncePerDevice {
+  std::atomic<unsigned long long> mask{0};
+  bool need() {
+    int d = 0;
+    (void)hipGetDevice(&d);
+    const unsigned long long b = 1ull << (d & 63);
+    if (mask.load(std::memory_order_relaxed) & b) return false;
+    mask.fetch_or(b, std::memory_order_relaxed);
+    return true;
+  }
+};
+
 // thread-local name of the kernel family last dispatched (afm_last_algo)
 extern "C" void afm_set_last_algo(const char* name);
 

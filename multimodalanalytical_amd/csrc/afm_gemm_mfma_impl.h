@@ -245,8 +245,8 @@ static int launch_nt(MfmaArgs& g, hipStream_t st) {
   g.tiles_m = (g.M + TBM - 1) / TBM; g.tiles_n = (g.N + TBN - 1) / TBN;
   auto kern = k_gemm_nt<C_BF16, WM, WN, NWM, NWN, BKT>;
   if (shm > 64 * 1024) {
-    static bool done = false;  // per instantiation
-    if (!done) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, shm); done = true; }
+    static AfmOncePerDevice done;  // per instantiation
+    if (done.need()) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, shm);
   }
   AFM_LAUNCH(kern, dim3(g.tiles_m * g.tiles_n), dim3(64 * NWM * NWN), shm, st, g);
   return AFM_OK;
@@ -871,10 +871,9 @@ static int launch_nt_ws(MfmaArgs& g, hipStream_t st) {
   g.bias_in_lds = rows16 && modes_ok && (GLU_EPI || ring + bias_bytes <= 160 * 1024) ? 1 : 0;
   const int shm = ring + (g.bias_in_lds && !GLU_EPI ? bias_bytes : 0);
   auto kern = k_gemm_nt_ws<C_BF16, NL, ABL, EPI>;
-  static bool attr_done = false;   // per instantiation
-  if (!attr_done) {
+  static AfmOncePerDevice attr_done;   // per instantiation
+  if (attr_done.need()) {
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_done = true;
   }
   int grid = 256;
   const int ntiles = g.tiles_m * g.tiles_n;
@@ -1488,10 +1487,9 @@ int AFM_E16_FN(afm_gemm_mfma_try)(const afm_gemm_desc* d, hipStream_t st) {
         if (hipMemset2DAsync(d->C, sizeof(float) * d->ldc, 0, sizeof(float) * d->N, d->M, st) != hipSuccess)
           return AFM_ERR_LAUNCH;
       }
-      static bool attr256 = false;
-      if (!attr256) {
+      static AfmOncePerDevice attr256;
+      if (attr256.need()) {
         (void)hipFuncSetAttribute((const void*)k_gemm_tn_ring256, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 64 * 512 * 2);
-        attr256 = true;
       }
       AFM_LAUNCH(k_gemm_tn_ring256, dim3(tiles * ksplit), dim3(512), 2 * 64 * 512 * 2, st, g);
       afm_set_last_algo(ksplit > 1 ? "mfma_tn_ring256_splitk" : "mfma_tn_ring256");
@@ -1512,12 +1510,11 @@ int AFM_E16_FN(afm_gemm_mfma_try)(const afm_gemm_desc* d, hipStream_t st) {
         if (hipMemset2DAsync(d->C, sizeof(float) * d->ldc, 0, sizeof(float) * d->N, d->M, st) != hipSuccess)
           return AFM_ERR_LAUNCH;
       }
-      static bool attr_done = false;
-      if (!attr_done) {
+      static AfmOncePerDevice attr_done;
+      if (attr_done.need()) {
         (void)hipFuncSetAttribute((const void*)k_gemm_tn_ring<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 64 * 384 * 2);
         (void)hipFuncSetAttribute((const void*)k_gemm_tn_ring<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 64 * 384 * 2);
         (void)hipFuncSetAttribute((const void*)k_gemm_tn_ring<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 64 * 384 * 2);
-        attr_done = true;
       }
       if (d->reserved == 101) AFM_LAUNCH(k_gemm_tn_ring<1>, dim3(tiles * ksplit), dim3(512), 3 * 64 * 384 * 2, st, g);
       else if (d->reserved == 102) AFM_LAUNCH(k_gemm_tn_ring<2>, dim3(tiles * ksplit), dim3(512), 3 * 64 * 384 * 2, st, g);

@@ -392,10 +392,9 @@ static int launch_x3_nt(X3Args& g, hipStream_t st, bool staged_ok) {
   g.bias_in_lds = staged_ok && (GLU_EPI || ring + bias_bytes <= 160 * 1024) ? 1 : 0;
   const int shm = ring + (g.bias_in_lds && !GLU_EPI ? bias_bytes : 0);
   auto kern = k_x3_nt<CT, EPI>;
-  static bool attr_done = false;   // per instantiation
-  if (!attr_done) {
+  static AfmOncePerDevice attr_done;   // per instantiation
+  if (attr_done.need()) {
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_done = true;
   }
   int grid = 256;
   const int ntiles = g.tiles_m * g.tiles_n;
@@ -478,10 +477,9 @@ template <int CT>
 static int launch_x3_nt_small(X3Args& g, hipStream_t st) {
   g.tiles_m = (g.M + 63) / 64; g.tiles_n = (g.N + 63) / 64;
   auto kern = k_x3_nt_small<CT>;
-  static bool attr_done = false;   // per instantiation
-  if (!attr_done) {
+  static AfmOncePerDevice attr_done;   // per instantiation
+  if (attr_done.need()) {
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
-    attr_done = true;
   }
   AFM_LAUNCH(kern, dim3(g.tiles_m * g.tiles_n), dim3(256), 4 * 2 * 64 * 128, st, g);
   return AFM_OK;
@@ -611,10 +609,9 @@ static int launch_x3_nt256(X3Args& g, hipStream_t st) {
   if (ring + bias_bytes > 160 * 1024) return AFM_ERR_UNSUPPORTED;
   g.bias_in_lds = 1;
   auto kern = k_x3_nt256<CT, EPI>;
-  static bool attr_done = false;   // per instantiation
-  if (!attr_done) {
+  static AfmOncePerDevice attr_done;   // per instantiation
+  if (attr_done.need()) {
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_done = true;
   }
   int grid = 256;
   const int ntiles = g.tiles_m * g.tiles_n;
@@ -1015,10 +1012,9 @@ int afm_gemm_x3_try(const afm_gemm_desc* d, hipStream_t st) {
       if (ksplit > 1 && !d->accumulate) {
         if (hipMemset2DAsync(d->C, sizeof(float) * d->ldc, 0, sizeof(float) * d->N, d->M, st) != hipSuccess) return AFM_ERR_LAUNCH;
       }
-      static bool attr256 = false;
-      if (!attr256) {
+      static AfmOncePerDevice attr256;
+      if (attr256.need()) {
         (void)hipFuncSetAttribute((const void*)k_x3_tn256, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 64 * 512 * 2);
-        attr256 = true;
       }
       AFM_LAUNCH(k_x3_tn256, dim3(tiles * ksplit), dim3(512), 2 * 64 * 512 * 2, st, g);
       afm_set_last_algo(ksplit > 1 ? "mfma_tn_x3_256_splitk" : "mfma_tn_x3_256");
@@ -1036,10 +1032,9 @@ int afm_gemm_x3_try(const afm_gemm_desc* d, hipStream_t st) {
     if (ksplit > 1 && !d->accumulate) {
       if (hipMemset2DAsync(d->C, sizeof(float) * d->ldc, 0, sizeof(float) * d->N, d->M, st) != hipSuccess) return AFM_ERR_LAUNCH;
     }
-    static bool attr_done = false;
-    if (!attr_done) {
+    static AfmOncePerDevice attr_done;
+    if (attr_done.need()) {
       (void)hipFuncSetAttribute((const void*)k_x3_tn, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 64 * 384 * 2);
-      attr_done = true;
     }
     AFM_LAUNCH(k_x3_tn, dim3(tiles * ksplit), dim3(512), 3 * 64 * 384 * 2, st, g);
     afm_set_last_algo(ksplit > 1 ? "mfma_tn_x3_splitk" : "mfma_tn_x3");

@@ -174,8 +174,9 @@ class Seq2SeqEngine:
 
     def _glu_fusable(self, rows: int, f: int) -> bool:
         """Whole 256 x 128 tiles of the (rows x 2f) up-projection and MFMA-sized K: the fused kernels' domain."""
-        return (self.gated and self.lowp and rows % 256 == 0 and (2 * f) % 128 == 0 and f % 128 == 0 and self.d % 64 == 0
-                and rows * 2 * f <= 0xFFFFFFFF)
+        from .lib import ALGO_GENERIC
+        return (self.gated and self.lowp and self.algo != ALGO_GENERIC and rows % 256 == 0 and (2 * f) % 128 == 0 and f % 128 == 0
+                and self.d % 64 == 0 and rows * 2 * f <= 0xFFFFFFFF)
 
     def _refresh_kv_concat(self) -> None:
         """(d x Ld*2d) bf16: the transposed cross-attention K/V projection weights of every decoder layer side

@@ -302,7 +302,8 @@ class HFWrapper:
         for k, v in avg.items():
             self.log(k, v, sync_dist=True)
         self.validation_step_outputs = []
-        return avg
+        # what ModelCheckpoint / EarlyStopping monitor in the reference is the LOGGED (rank-averaged) value, the same on every rank
+        return {k: self.logged[k] for k in avg}
 
     def predict_step(self, batch, batch_idx):  # noqa: ARG002
         """wrapper.py:532-578 (greedy ids instead of decoded beam strings)."""

@@ -39,21 +39,75 @@ def sync_mean(value, group=None):
     return t / world
 
 
+def sync_flag(flag: bool, src: int = 0, device=None, group=None) -> bool:
+    """Rank `src`'s boolean, on every rank (loop control that only one rank can decide: early stopping follows the checkpoint
+    ranking kept on rank 0; every rank must leave the epoch loop in the same epoch or the others hang in the next collective)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return bool(flag)
+    dev = device if (device is not None and dist.get_backend(group) == "nccl") else "cpu"
+    t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=dev)
+    dist.broadcast(t, src=src, group=group)
+    return bool(int(t.item()))
+
+
+class NativeComm:
+    """RCCL communicator behind the C ABI (include/afm_hip.h: afm_comm_create / afm_allreduce_bucket).  torch.distributed is
+    only the bootstrap: rank 0's 128-byte unique id is broadcast over the existing process group."""
+
+    def __init__(self, group=None):
+        import ctypes as C
+        from . import lib as L
+        self._L, self._C = L, C
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        buf = (C.c_ubyte * 128)()
+        if rank == 0:
+            L.check(L.load().afm_comm_unique_id(buf), "afm_comm_unique_id")
+        ids = [bytes(buf)]
+        dist.broadcast_object_list(ids, src=0, group=group)
+        raw = (C.c_ubyte * 128).from_buffer_copy(ids[0])
+        self.handle = C.c_void_p()
+        L.check(L.load().afm_comm_create(C.byref(self.handle), raw, rank, world), "afm_comm_create")
+        self.rank, self.world = rank, world
+
+    def all_reduce(self, view: torch.Tensor, stream) -> None:
+        assert view.is_cuda and view.dtype == torch.float32 and view.is_contiguous()
+        self._L.check(self._L.load().afm_allreduce_bucket(self.handle, view.data_ptr(), view.numel(), stream.cuda_stream),
+                      "afm_allreduce_bucket")
+
+    def close(self) -> None:
+        if self.handle:
+            self._L.load().afm_comm_destroy(self.handle)
+            self.handle = None
+
+
+def bucket_elems_for(numel: int, target_buckets: int = 8, floor: int = 1 << 20) -> int:
+    """About eight buckets per exchange whatever the model size (c2: 47 M gradients -> 6 M floats = 24 MB per bucket, c4: 256 M ->
+    32 M floats): the last bucket (embeddings + first encoder layer) is the only one that cannot overlap the backward pass,
+    and xGMI ring all-reduce is bandwidth-bound from a few MB upwards."""
+    return max(floor, -(-int(numel) // target_buckets))
+
+
 class BucketedReducer:
     """All-reduce a flat gradient buffer back to front in buckets, on a side stream.
 
     `ready(lo)` declares that every gradient at flat offset >= lo is final; whole buckets below the
     previous mark are launched immediately.  `finish()` flushes the remainder and makes the compute
-    stream wait for the exchange.  Works on CPU tensors with gloo (tests) and on HIP with RCCL."""
+    stream wait for the exchange.  On HIP the buckets go through the C ABI's afm_allreduce_bucket (RCCL; `native`, the
+    default; AFM_NATIVE_RCCL=0 keeps torch.distributed's nccl backend); CPU tensors use gloo (tests)."""
 
-    def __init__(self, flat: torch.Tensor, bucket_elems: int = 16 << 20, group=None):
+    def __init__(self, flat: torch.Tensor, bucket_elems: int = 0, group=None, native: Optional[bool] = None):
         self.flat, self.group = flat, group
-        self.bucket = int(bucket_elems)
+        self.bucket = int(bucket_elems) or bucket_elems_for(flat.numel())
         self.hi = flat.numel()
         self.is_cuda = flat.is_cuda
         self.stream = torch.cuda.Stream() if self.is_cuda else None
         self.handles: List = []
         self.launched: List[Tuple[int, int]] = []
+        if native is None:
+            import os
+            native = self.is_cuda and os.environ.get("AFM_NATIVE_RCCL", "1") != "0" and dist.is_initialized() and \
+                dist.get_backend(group) == "nccl"
+        self.comm = NativeComm(group) if native else None
 
     def reset(self):
         self.hi = self.flat.numel()
@@ -69,8 +123,11 @@ class BucketedReducer:
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream())
             self.stream.wait_event(ev)                 # gradients in [lo, hi) are produced before this point
-            with torch.cuda.stream(self.stream):
-                self.handles.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            if self.comm is not None:
+                self.comm.all_reduce(view, self.stream)    # enqueued on the side stream; finish() orders the compute stream behind it
+            else:
+                with torch.cuda.stream(self.stream):
+                    self.handles.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
         else:
             self.handles.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
@@ -93,7 +150,7 @@ class BucketedReducer:
 class TrainLoop:
     """accumulate -> (all-reduce) -> clip + Adam + OneCycle, driving an HFWrapper."""
 
-    def __init__(self, model, acc_batches: int = 4, world_size: int = 1, bucket_elems: int = 16 << 20,
+    def __init__(self, model, acc_batches: int = 4, world_size: int = 1, bucket_elems: int = 0,
                  force_reducer: bool = False):
         self.model, self.acc, self.world = model, int(acc_batches), int(world_size)
         (self.optim,), _ = model.configure_optimizers()
@@ -116,6 +173,18 @@ class TrainLoop:
                 self.reducer.finish()
             self.optim.step(grads_are_summed_over_ranks=self.reducer is not None)
         return loss
+
+    def flush(self) -> None:
+        """End of an epoch with a partly filled accumulation window: step on what has been accumulated (Lightning steps on the
+        last batch of every epoch; `calculate_training_steps` counts ceil(batches / acc) steps per epoch accordingly).  The
+        micro-batches were scaled by 1/acc like any others, as Lightning scales them."""
+        if self.micro % self.acc == 0:
+            return
+        if self.reducer is not None:       # no bucket was launched during these backward passes: one exchange of the whole buffer
+            self.reducer.reset()
+            self.reducer.finish()
+        self.optim.step(grads_are_summed_over_ranks=self.reducer is not None)
+        self.micro += self.acc - self.micro % self.acc
 
 
 def save_checkpoint(path: str, model, loop: "TrainLoop" = None, epoch: int = 0) -> None:

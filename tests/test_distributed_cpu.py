@@ -81,3 +81,31 @@ def test_mixture_stream_is_rank_sharded():
             assert len(np.unique(allrows, axis=0)) == len(allrows)          # disjoint
             assert set(map(tuple, allrows)) <= set(map(tuple, ri))
     assert shard_rows(rounds[0], 0, 1) is rounds[0]
+
+
+def _flag_worker(rank, world, port):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from multimodalanalytical_amd.trainer import sync_flag
+    # only rank 0 knows the decision (it ranks the checkpoints): every rank must leave the epoch loop in the same epoch
+    stale, left_at = 0, None
+    for epoch in range(6):
+        if rank == 0:
+            stale = stale + 1 if epoch >= 2 else 0
+        if sync_flag(rank == 0 and stale >= 2):
+            left_at = epoch
+            break
+        dist.barrier()          # stands for the next epoch's collectives: a rank that stayed behind would hang here
+    assert left_at == 3, (rank, left_at)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_early_stopping_flag_reaches_every_rank_world2_gloo():
+    mp.spawn(_flag_worker, args=(2, _free_port()), nprocs=2, join=True)
+
+
+def test_bucket_size_follows_the_gradient_buffer():
+    from multimodalanalytical_amd.trainer import bucket_elems_for
+    assert bucket_elems_for(47_000_000) * 8 >= 47_000_000 > bucket_elems_for(47_000_000) * 7      # c2: about eight buckets
+    assert bucket_elems_for(100) == 1 << 20                                                        # tiny models: one bucket

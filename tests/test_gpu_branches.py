@@ -137,6 +137,8 @@ def test_rccl_reducer_on_a_one_rank_group_reproduces_the_plain_loop():
         for force in (False, True):
             w = _wrapper(t, cfg, torch.bfloat16)
             loop = TrainLoop(w, acc_batches=2, bucket_elems=4096, force_reducer=force)
+            if force:     # nccl group: the buckets go through the C ABI's afm_allreduce_bucket (RCCL communicator of its own)
+                assert loop.reducer.comm is not None and loop.reducer.comm.world == 1
             launched = []
             for i in range(4):
                 loss = loop.micro_batch(to_device(G.batch_of(t, i), DEV))
@@ -184,3 +186,59 @@ def test_config_driven_training_entry(tmp_path):
     # an unknown data path: the reference's CLI swallows the exception and exits 0; strict=1 surfaces it
     assert main(argv[:3] + ["data_path=/nonexistent"] + argv[4:]) == 1
     assert main([a for a in argv[:3] + ["data_path=/nonexistent"] + argv[4:] if a != "strict=1"]) == 0
+
+
+def _dp2_worker(rank, world, port, name, q):
+    """One of two data-parallel ranks, both on cuda:0, exchanging over gloo (device tensors): the N > 1 code path without a
+    second GPU -- bucket hooks from the backward pass, summed gradients, 1/world in the fused clip + Adam."""
+    import os
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from multimodalanalytical_amd.synth import to_device
+    from multimodalanalytical_amd.trainer import TrainLoop
+    t = G.load(name); cfg = G.model_cfg(t["meta"])
+    w = _wrapper(t, cfg, torch.float32, dropout=0.0, world_size=world)
+    loop = TrainLoop(w, acc_batches=1, world_size=world, bucket_elems=4096)
+    assert loop.reducer is not None and loop.reducer.comm is None        # gloo group: torch.distributed carries the buckets
+    loss = loop.micro_batch(to_device(G.batch_of(t, rank), DEV))          # rank r trains on batch r
+    torch.cuda.synchronize()
+    q.put((rank, w.hf_model.engine.ps.flat.cpu().clone(), float(loss), len(loop.reducer.launched)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_on_one_gpu_equal_the_averaged_single_process_step():
+    """Data-parallel equivalence (trainer/trainer.py:58,61 of the reference: DDP averages the ranks' gradients): two processes,
+    one batch each, one optimiser step == one process that averages the two batches' gradients itself."""
+    _need_gpu()
+    import socket
+    import torch.multiprocessing as mp
+    from multimodalanalytical_amd.optim import FusedAdamOneCycle
+    from multimodalanalytical_amd.synth import to_device
+    name = "model_plain"
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_dp2_worker, args=(r, 2, port, name, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted([q.get(timeout=300) for _ in procs], key=lambda x: x[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    # single process: accumulate batch 0 and batch 1 at weight 1/2 each, one step (no reducer)
+    t = G.load(name); cfg = G.model_cfg(t["meta"])
+    w = _wrapper(t, cfg, torch.float32, dropout=0.0)
+    eng = w.hf_model.engine
+    (opt,), _ = w.configure_optimizers()
+    for i in range(2):
+        w.training_step(to_device(G.batch_of(t, i), DEV), i, 0.5)
+    opt.step()
+    torch.cuda.synchronize()
+    ref = eng.ps.flat.cpu()
+    for rank, flat, loss, nbuckets in got:
+        assert nbuckets > 4
+        torch.testing.assert_close(flat, ref, rtol=2e-5, atol=2e-7, msg=lambda m: f"rank {rank}: {m}")
+    assert torch.equal(got[0][1], got[1][1])          # the replicas stay bit-identical
