@@ -333,6 +333,9 @@ def timed_run(workload, mode, steps, warmup, rank, world, dev, args, keep=False)
     S = batches[0]["encoder_pad_mask"].shape[0]
     flops = synth.train_flops_per_sample(wl["cfg"], S, wl["T"], tok.vocab_size)
     res = {"value": steps * args.acc * B * world / dt, "dt": dt, "loss": float(loss), "S": S, "B": B, "flops": flops, "wl": wl}
+    if loop.reducer is not None and loop.reducer.comm is not None:      # the C-ABI RCCL communicator of this run
+        torch.cuda.synchronize()
+        loop.reducer.comm.close()
     if keep:
         res["model"] = model
     else:
@@ -378,7 +381,7 @@ def main():
                 "final_loss": round(r["loss"], 4)}
 
     modes = {args.dtype: mode_entry(main_run, args.dtype, args.steps)}
-    for m in [x for x in args.other_modes.split(",") if x and x != args.dtype]:
+    for m in [x for x in args.other_modes.split(",") if x and x != args.dtype and world == 1]:      # (N > 1: the headline mode only)
         r = timed_run(args.workload, m, args.other_steps, 1, rank, world, dev, args)
         modes[m] = mode_entry(r, m, args.other_steps)
     workloads = {}

@@ -177,6 +177,12 @@ int afm_layernorm_bwd(const afm_ln_shape* s, const void* dy, const float* x, con
                       float* dgamma, float* dbeta, float* partial, void* dx_drop,
                       const afm_dropout* drop, void* stream);
 
+/* Embedding rows WITHOUT the per-modality LayerNorm (`multimodal_norm: false`, modeling/utils.py:165-168 skipped), same layout
+ * fusion as above:  gather == 0: y[out_row(r), :] = x[r, :] + (pos ? pos[out_off + r % seg_len, :] : 0);
+ *                   gather == 1: y[r, :] = x[out_row(r), :]  (backward: the modality's slice of the stream gradient). */
+int afm_place_rows(const float* x, const float* pos, float* y, int64_t rows, int32_t d, int64_t seg_len,
+                   int64_t out_seg_stride, int64_t out_off, int32_t gather, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Masked multi-head attention, flash style (no T_q x T_k tensor in HBM).
  * F.scaled_dot_product_attention as reached from nn.MultiheadAttention

@@ -85,6 +85,31 @@ extern "C" int afm_scatter_add_rows(const int64_t* ids, const float* scale, cons
   return AFM_OK;
 }
 
+// ---------------------------------------------------------------- embedding rows without the per-modality LayerNorm
+// multimodal_norm = False (modeling/utils.py:165-168 skipped): the modality's rows go straight into their slice of the
+// concatenated sequence, positional rows added: the LayerNorm kernel's layout fusion without the normalisation.
+//   gather == 0:  y[out_row(r), :] = x[r, :] + (pos ? pos[out_off + r % seg_len, :] : 0)
+//   gather == 1:  y[r, :] = x[out_row(r), :]                         (its backward: the slice of the stream gradient)
+__global__ void k_place_rows(const float* __restrict__ x, const float* __restrict__ pos, float* __restrict__ y, int64_t rows, int d,
+                             int64_t seg_len, int64_t seg_stride, int64_t off, int gather) {
+  const int64_t total = rows * (int64_t)d;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / d;
+    const int c = (int)(i - r * d);
+    const int64_t orow = seg_len ? (r / seg_len) * seg_stride + off + (r % seg_len) : r;
+    if (gather) y[i] = x[orow * d + c];
+    else y[orow * d + c] = x[i] + (pos ? pos[(off + (seg_len ? r % seg_len : r)) * d + c] : 0.f);
+  }
+}
+extern "C" int afm_place_rows(const float* x, const float* pos, float* y, int64_t rows, int32_t d, int64_t seg_len,
+                              int64_t out_seg_stride, int64_t out_off, int32_t gather, void* stream) {
+  if (!x || !y || rows < 0 || d <= 0 || seg_len < 0) return AFM_ERR_ARG;
+  if (rows == 0) return AFM_OK;
+  AFM_LAUNCH(k_place_rows, dim3(grid_for(rows * d, 256)), dim3(256), 0, (hipStream_t)stream, x, pos, y, rows, d, seg_len,
+             out_seg_stride, out_off, gather);
+  return AFM_OK;
+}
+
 // ---------------------------------------------------------------- GLU / GELU
 template <typename T>
 __global__ void k_glu_fwd(const T* __restrict__ u, const T* __restrict__ v, T* __restrict__ g,

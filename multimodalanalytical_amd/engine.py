@@ -63,9 +63,7 @@ class Seq2SeqEngine:
         self.algo = algo
         self.d = int(cfg["d_model"])
         self.gated = bool(self.cfg["gated_linear"])
-        self.norm = bool(self.cfg["multimodal_norm"])
-        if not self.norm:
-            raise NotImplementedError("multimodal_norm=False is not on the reference's tested path")
+        self.norm = bool(self.cfg["multimodal_norm"])      # False: no per-modality LayerNorm (modeling/utils.py:165-168)
         self.align = align_dict(self.cfg.get("align_config"))
         self.cfg["align_config"] = self.align
         self.x3 = compute_dtype == BF16X3
@@ -345,12 +343,15 @@ class Seq2SeqEngine:
                 rec.update(acts=acts, layers=layers)
             else:
                 raise NotImplementedError(mc["type"])
-            mean = torch.empty(B * Sm, dtype=torch.float32, device=self.dev)
-            rstd = torch.empty(B * Sm, dtype=torch.float32, device=self.dev)
-            ops.layernorm_fwd(e, self.ps.p(f"embedding.embedding_norm_dict.{m}.weight"),
-                              self.ps.p(f"embedding.embedding_norm_dict.{m}.bias"), x_out, mean, rstd,
-                              pos=pe, seg_len=Sm, out_seg_stride=S, out_off=off)
-            rec.update(e=e, mean=mean, rstd=rstd)
+            if self.norm:
+                mean = torch.empty(B * Sm, dtype=torch.float32, device=self.dev)
+                rstd = torch.empty(B * Sm, dtype=torch.float32, device=self.dev)
+                ops.layernorm_fwd(e, self.ps.p(f"embedding.embedding_norm_dict.{m}.weight"),
+                                  self.ps.p(f"embedding.embedding_norm_dict.{m}.bias"), x_out, mean, rstd,
+                                  pos=pe, seg_len=Sm, out_seg_stride=S, out_off=off)
+                rec.update(e=e, mean=mean, rstd=rstd)
+            else:
+                ops.place_rows(e, x_out, pos=pe, seg_len=Sm, out_seg_stride=S, out_off=off)
             mods.append(rec)
             off += Sm
         if saved is not None:
@@ -375,12 +376,15 @@ class Seq2SeqEngine:
             m, Sm, off = rec["name"], rec["S"], rec["off"]
             rows = B * Sm
             de = torch.empty(rows, d, dtype=torch.float32, device=self.dev)
-            ws = torch.empty(ops.layernorm_bwd_ws(rows, d), dtype=torch.float32, device=self.dev)
-            ops.layernorm_bwd(dx, rec["e"], self.ps.p(f"embedding.embedding_norm_dict.{m}.weight"),
-                              rec["mean"], rec["rstd"], de,
-                              self.ps.g(f"embedding.embedding_norm_dict.{m}.weight"),
-                              self.ps.g(f"embedding.embedding_norm_dict.{m}.bias"), ws,
-                              seg_len=Sm, out_seg_stride=S, out_off=off)
+            if self.norm:
+                ws = torch.empty(ops.layernorm_bwd_ws(rows, d), dtype=torch.float32, device=self.dev)
+                ops.layernorm_bwd(dx, rec["e"], self.ps.p(f"embedding.embedding_norm_dict.{m}.weight"),
+                                  rec["mean"], rec["rstd"], de,
+                                  self.ps.g(f"embedding.embedding_norm_dict.{m}.weight"),
+                                  self.ps.g(f"embedding.embedding_norm_dict.{m}.bias"), ws,
+                                  seg_len=Sm, out_seg_stride=S, out_off=off)
+            else:
+                ops.place_rows(dx, de, seg_len=Sm, out_seg_stride=S, out_off=off, gather=True)
             p = f"embedding.embedding_layer_dict.{m}."
             if "ids" in rec:
                 ops.scatter_add_rows(rec["ids"], de, self.ps.g(p + "weight"), rec["scale"], rec["pad"])
@@ -596,9 +600,18 @@ class Seq2SeqEngine:
 
     # ------------------------------------------------------------------ whole model
     def encode(self, enc_inputs, attention_mask, saved: Optional[dict] = None):
-        """embed + CustomEncoder.forward (custom_modeling.py:220-243) -> memory (B*S, d)."""
-        x = self.embed_fwd(enc_inputs, None if saved is None else saved.setdefault("emb_enc", {}))
+        """embed + CustomEncoder.forward (custom_modeling.py:220-243) -> memory (B*S, d).  `enc_inputs` is the modality dict
+        (embedded here, on the engine's schedule) or an already embedded (B, S, d) tensor, as the reference's
+        `inputs_embeds` (custom_modeling.py:420-445): forward / generate only, its producer is outside this engine."""
         B, S = attention_mask.shape
+        if torch.is_tensor(enc_inputs):
+            if saved is not None:
+                raise ValueError("a backward pass through externally embedded inputs is not available: pass the modality dict")
+            if tuple(enc_inputs.shape) != (B, S, self.d):
+                raise ValueError(f"inputs_embeds must be (B, S, d) = {(B, S, self.d)}, got {tuple(enc_inputs.shape)}")
+            x = enc_inputs.to(device=self.dev, dtype=torch.float32).reshape(B * S, self.d).contiguous()
+        else:
+            x = self.embed_fwd(enc_inputs, None if saved is None else saved.setdefault("emb_enc", {}))
         assert x.shape[0] == B * S, "attention_mask does not match the concatenated modalities"
         key_pad = (attention_mask == 0).to(torch.uint8).contiguous()
         H = self.cfg["encoder_attention_heads"]
@@ -738,9 +751,12 @@ class Seq2SeqEngine:
         e = torch.empty(Bk, d, dtype=torch.float32, device=self.dev)
         ops.gather_rows(ids.contiguous().view(-1), self.ps.p(f"embedding.embedding_layer_dict.{m}.weight"), e)
         x = torch.empty(Bk, d, dtype=torch.float32, device=self.dev)
-        ops.layernorm_fwd(e, self.ps.p(f"embedding.embedding_norm_dict.{m}.weight"),
-                          self.ps.p(f"embedding.embedding_norm_dict.{m}.bias"), x, pos=st["pe"][t:t + 1],
-                          seg_len=1, out_seg_stride=1, out_off=0)
+        if self.norm:
+            ops.layernorm_fwd(e, self.ps.p(f"embedding.embedding_norm_dict.{m}.weight"),
+                              self.ps.p(f"embedding.embedding_norm_dict.{m}.bias"), x, pos=st["pe"][t:t + 1],
+                              seg_len=1, out_seg_stride=1, out_off=0)
+        else:
+            ops.place_rows(e, x, pos=st["pe"][t:t + 1], seg_len=1, out_seg_stride=1, out_off=0)
         pend = None
         for i in range(self.cfg["decoder_layers"]):
             p = f"decoder.layers.{i}."

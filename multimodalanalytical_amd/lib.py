@@ -122,6 +122,7 @@ _SIGS = {
     "afm_sumsq": (C.c_int, [_P, _I64, _P, _P]),
     "afm_adam_step": (C.c_int, [_P, _P, _P, _P, _I64, _P, _P, _P, _I32, _I32, _P, _P]),
     "afm_scaler_update": (C.c_int, [_P, _P, _F, _F, _I32, _P]),
+    "afm_place_rows": (C.c_int, [_P, _P, _P, _I64, _I32, _I64, _I64, _I64, _I32, _P]),
     "afm_comm_unique_id": (C.c_int, [_P]),
     "afm_comm_create": (C.c_int, [C.POINTER(_P), _P, _I32, _I32]),
     "afm_allreduce_bucket": (C.c_int, [_P, _P, _I64, _P]),

@@ -73,8 +73,8 @@ class _EncoderHandle:
 
     def __call__(self, inputs_embeds=None, attention_mask=None):
         eng = self.model.engine
-        assert isinstance(inputs_embeds, DeferredEmbedding)
-        mem, _ = eng.encode(inputs_embeds.token_ids, attention_mask)
+        enc = inputs_embeds.token_ids if isinstance(inputs_embeds, DeferredEmbedding) else inputs_embeds    # dict or (B, S, d) tensor
+        mem, _ = eng.encode(enc, attention_mask)
         B, S = attention_mask.shape
         from ..x2 import X2
         hs = mem if isinstance(mem, X2) else mem.view(B, S, eng.d)   # split-pair memory stays the engine's 2-D object
@@ -128,9 +128,14 @@ class CustomModel:
             B_, S_ = attention_mask.shape
             memory = eng._mem_rows(encoder_outputs["last_hidden_state"], B_, S_)
         else:
-            if not isinstance(inputs_embeds, DeferredEmbedding):
-                raise TypeError("inputs_embeds must come from this model's MultimodalEmbedding")
-            enc_inputs = inputs_embeds.token_ids
+            # this model's MultimodalEmbedding output (embedded inside the engine, trainable) or, as in the reference
+            # (custom_modeling.py:420-445), any (B, S, d) tensor of embeddings: forward / generate only
+            if isinstance(inputs_embeds, DeferredEmbedding):
+                enc_inputs = inputs_embeds.token_ids
+            elif torch.is_tensor(inputs_embeds):
+                enc_inputs = inputs_embeds
+            else:
+                raise TypeError("inputs_embeds: MultimodalEmbedding output or a (B, S, d) tensor")
         out = eng.forward(enc_inputs, attention_mask, decoder_input_ids, decoder_attention_mask, labels,
                           backward=self._grad_enabled and labels is not None and not generating,
                           loss_scale=self._loss_scale, memory=memory,

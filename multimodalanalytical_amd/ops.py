@@ -210,6 +210,15 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, ws, dres=None, se
     return dx
 
 
+def place_rows(x, y, pos=None, seg_len=0, out_seg_stride=0, out_off=0, gather=False):
+    """multimodal_norm = False: rows of x into their slice of the concatenated sequence (+ positional rows), or back (gather)."""
+    assert x.dtype == torch.float32 and y.dtype == torch.float32 and x.is_contiguous() and y.is_contiguous()
+    rows, d = (y.shape if gather else x.shape)
+    L.check(L.load().afm_place_rows(_ptr(x), _ptr(pos), _ptr(y), rows, d, int(seg_len), int(out_seg_stride), int(out_off),
+                                    int(gather), _stream()), "afm_place_rows")
+    return y
+
+
 def attn_shape(B, H, Tq, Tk, dh, dtype, ldq, ldk, ldv, ldo, key_pad=None, causal=False,
                dropout: Dropout = NO_DROP, algo=ALGO_AUTO, scale=None, batch_strides=None) -> AttnShape:
     s = AttnShape()

@@ -242,3 +242,40 @@ def test_two_ranks_on_one_gpu_equal_the_averaged_single_process_step():
         assert nbuckets > 4
         torch.testing.assert_close(flat, ref, rtol=2e-5, atol=2e-7, msg=lambda m: f"rank {rank}: {m}")
     assert torch.equal(got[0][1], got[1][1])          # the replicas stay bit-identical
+
+
+def test_multimodal_norm_false_forward_backward_vs_oracle():
+    """`multimodal_norm: false` (configs/model/*.yaml surface; modeling/utils.py:165-168 skips the per-modality LayerNorm): the
+    state dict has no embedding_norm_dict entries, embeddings go straight into the concatenated sequence (+ positions)."""
+    _need_gpu()
+    from multimodalanalytical_amd import synth
+    from multimodalanalytical_amd.engine import Seq2SeqEngine
+    wl = synth.WORKLOADS["c1"]
+    cfg = dict(wl["cfg"], dropout=0.0, multimodal_norm=False)
+    eng = Seq2SeqEngine(cfg, wl["data"], "Smiles", 128, device=DEV, compute_dtype=torch.float32, seed=9)
+    assert not any("embedding_norm_dict" in k for k in eng.ps.names())
+    batch, _ = synth.make_batch("c1", 4, seed=3)
+    enc, am, dec, dm, labels = O.batch_to_model_inputs(batch, "Smiles")
+    sd = {k: v.float().cpu() for k, v in eng.state_dict().items()}
+    leaf = {k: v.clone().requires_grad_(not k.endswith("pos_enc")) for k, v in sd.items() if not k.startswith("decoder.embedding.")}
+    ref = O.model_forward(leaf, cfg, wl["data"], "Smiles", enc, am, dec, dm, labels)
+    ref["loss"].backward()
+    to = lambda x: {k: to(v) for k, v in x.items()} if isinstance(x, dict) else x.to(DEV)
+    out = eng.forward(to(enc), am.to(DEV), dec.to(DEV), dm.to(DEV), labels.to(DEV), backward=True)
+    assert float((out["logits"].cpu() - ref["logits"].detach()).abs().max()) < 1e-4 * float(ref["logits"].detach().abs().max())
+    torch.testing.assert_close(out["loss"].cpu(), ref["loss"].detach(), rtol=1e-5, atol=1e-5)
+    for k, v in leaf.items():
+        if v.grad is None:
+            continue
+        got, g = eng.ps.g(k).cpu(), v.grad
+        if k.endswith("in_proj_bias"):
+            d3 = got.numel() // 3
+            got, g = torch.cat([got[:d3], got[2 * d3:]]), torch.cat([g[:d3], g[2 * d3:]])
+        assert float((got - g).norm()) <= 2e-3 * float(g.norm()) + 1e-7, k
+    # eval + greedy decode run through the same branch (single-token embedding without the norm)
+    eng.eval()
+    mem, _ = eng.encode(to(enc), am.to(DEV))
+    st = eng.decode_init(mem, am.to(DEV), 1, 8)
+    lg = eng.decode_step(st, dec[:, 0].to(DEV))
+    full = eng.forward(to(enc), am.to(DEV), dec.to(DEV), dm.to(DEV))["logits"][:, 0]
+    assert float((lg - full).abs().max()) < 1e-4 * float(full.abs().max())

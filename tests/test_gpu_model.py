@@ -458,3 +458,24 @@ def test_training_losses_agree_across_modes():
     for mode in ("bf16x3-mixed", "fp16"):
         d = float((curves[mode] - curves["bf16x3"]).abs().max())
         assert d < 5e-3, (mode, d, curves[mode][-4:], curves["bf16x3"][-4:])
+
+
+def test_plain_tensor_inputs_embeds_forward_and_generate_prefix():
+    """The reference's inner model takes any (B, S, d) tensor as `inputs_embeds` (custom_modeling.py:420-445): the materialised
+    embeddings give the logits of the modality-dict call; a backward pass through them is refused."""
+    t = G.load("model_plain"); cfg = G.model_cfg(t["meta"])
+    w = _wrapper(t, cfg, torch.float32, dropout=0.0)
+    w.eval()
+    batch = _dev_batch(t, 0)
+    ref = w.forward(batch)
+    enc, am, dec, dm, labels = _inputs(t, 0)
+    emb = w.multimodal_embedding(enc).materialize()
+    assert emb.dim() == 3 and emb.shape[-1] == w.hf_model.engine.d
+    out = w.hf_model(inputs_embeds=emb, attention_mask=am, decoder_input_ids=dec, decoder_attention_mask=dm, labels=labels)
+    assert rel_err(out.logits.cpu(), ref.logits.cpu()) < 1e-6
+    mem = w.hf_model.encoder(inputs_embeds=emb, attention_mask=am)["last_hidden_state"]
+    assert rel_err(mem.cpu(), ref.encoder_hidden_states.cpu()) < 1e-6
+    w.hf_model.backward_on_forward(True, 1.0)
+    with pytest.raises(ValueError):
+        w.hf_model(inputs_embeds=emb, attention_mask=am, decoder_input_ids=dec, decoder_attention_mask=dm, labels=labels)
+    w.hf_model.backward_on_forward(False)
