@@ -204,8 +204,9 @@ typedef struct {
   int32_t causal;
   int32_t algo;
   float scale;
-  int32_t reserved;       /* afm_attn_bwd: 0 = dQ and dK/dV kernels; 1 = dQ (+ delta) only; 2 = dK/dV only (delta from an
-                             earlier call): lets bench.py / the profiler time the two backward kernels separately */
+  int32_t reserved;       /* afm_attn_bwd, bits 0-1: 0 = dQ and dK/dV kernels; 1 = dQ (+ delta) only; 2 = dK/dV only (delta from an
+                             earlier call): lets bench.py / the profiler time the two backward kernels separately.
+                             bit 4 (16): the 8-wave staggered forms of the single-pass forward / dQ kernels (Tq >= 256), see DESIGN.md 4 */
   const uint8_t* key_pad;
   afm_dropout drop;
   /* batch strides in ELEMENTS of Q, K, V, O (0 = dense: Tq*ldq, Tk*ldk, Tk*ldv, Tq*ldo).  Non-dense

@@ -45,7 +45,11 @@ __global__ __launch_bounds__(256, 3) void k_attn_fwd_mfma(AttnM a, const e16* __
   {
     const e16* qp = Q + ((int64_t)b * a.Tq + qc) * a.ldq + hd * DH + 8 * h;
 #pragma unroll
-    for (int s = 0; s < 4; ++s) qf[s] = *(const e16x8*)(qp + 16 * s);
+    for (int s = 0; s < 4; ++s) {     // pre-multiplied by scale * log2(e): S^T comes out of the MFMA chain in log2 units (round 3)
+      const e16x8 x = *(const e16x8*)(qp + 16 * s);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) qf[s][j] = (e16)((float)x[j] * a.scale_log2);
+    }
   }
   build_mask_words(maskw, a.key_pad, b, a.Tk, ntiles, w, lane);
   __syncthreads();   // plain loads above are retired here (vmcnt(0)), before any LDS-DMA is in flight
@@ -59,7 +63,7 @@ __global__ __launch_bounds__(256, 3) void k_attn_fwd_mfma(AttnM a, const e16* __
   f32x16 o[2];
 #pragma unroll
   for (int i = 0; i < 16; ++i) { o[0][i] = 0.f; o[1][i] = 0.f; }
-  float m = -INFINITY, l = 0.f;
+  float m = -INFINITY, l = 0.f;   // running maximum (log2 units; -inf until the row has seen an unmasked key) and row sum
   const uint32_t rowbase = (uint32_t)(((uint64_t)(b * a.H + hd) * a.Tq + qc) * (uint64_t)a.Tk);
 #pragma unroll
   for (int s = 0; s < RS - 1; ++s)
@@ -79,10 +83,11 @@ __global__ __launch_bounds__(256, 3) void k_attn_fwd_mfma(AttnM a, const e16* __
     const unsigned long long mword = maskw[kt];
     const unsigned long long pad = mword >> (4 * h);
     f32x16 s[2];
+    const float init = m == -INFINITY ? 0.f : -m;      // S' = S - m: the running maximum is the chain's initial value
 #pragma unroll
     for (int blk = 0; blk < 2; ++blk) {
 #pragma unroll
-      for (int i = 0; i < 16; ++i) s[blk][i] = 0.f;
+      for (int i = 0; i < 16; ++i) s[blk][i] = init;
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) s[blk] = mfma32(frag_row(Kimg, 32 * blk, ks, lane), qf[ks], s[blk]);
     }
@@ -104,27 +109,28 @@ __global__ __launch_bounds__(256, 3) void k_attn_fwd_mfma(AttnM a, const e16* __
     float mt = fmaxf(s[0][0], s[1][0]);
 #pragma unroll
     for (int r = 1; r < 16; ++r) mt = max3_raw(mt, s[0][r], s[1][r]);
-    mt = fmaxf(mt, __shfl_xor(mt, 32, 64)) * a.scale_log2;     // scale > 0: max commutes with it
-    const float mn = fmaxf(m, mt);
-    const float ms = mn == -INFINITY ? 0.f : mn;
-    const float alpha = fast_exp2(m - ms);
-    const bool grew = mn > m;
-    m = mn;
+    mt = fmaxf(mt, __shfl_xor(mt, 32, 64));        // maximum of S' over the tile's keys
+    // a row's first unmasked key sets m to the true maximum; afterwards m moves only when the row grew by more than 2^8
+    // (P <= 2^8 is exact in either 16-bit format and the fp32 sums do not care): O and l are rescaled in that rare tile only
+    const bool unset = m == -INFINITY;
+    if (__any((unset && mt != -INFINITY) || mt > 8.f)) {
+      const float dlt = unset ? (mt == -INFINITY ? 0.f : mt) : fmaxf(mt, 0.f);
+      const float alpha = unset ? 1.f : fast_exp2(-dlt);     // (an unset row has accumulated nothing yet)
+      m = (unset && mt == -INFINITY) ? m : (unset ? dlt : m + dlt);
+      l *= alpha;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { o[0][i] *= alpha; o[1][i] *= alpha; s[0][i] -= dlt; s[1][i] -= dlt; }
+    }
     float ls = 0.f;
 #pragma unroll
     for (int blk = 0; blk < 2; ++blk)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float p = fast_exp2(fmaf(s[blk][r], a.scale_log2, -ms));   // exp2(-inf) = 0 for masked keys
+        const float p = fast_exp2(s[blk][r]);   // exp2(-inf) = 0 for masked keys
         s[blk][r] = p;
         ls += p;
       }
-    l = l * alpha + ls;
-    // rescale O^T unconditionally: 16 packed multiplies; skipping them when no maximum moved made the
-    // register allocator copy all 32 accumulators at the branch join (32 v_mov per tile)
-    (void)grew;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) { o[0][i] *= alpha; o[1][i] *= alpha; }
+    l += ls;
     if (DROP == DROP_HASH) {   // compile-time: a run-time branch costs 32 register copies at its join
       drop_block(a.dd, rowbase, kb, h, s[0]);
       drop_block(a.dd, rowbase, kb + 32, h, s[1]);
@@ -523,6 +529,204 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd_dq_mfma(AttnM a, const e16*
   }
 }
 
+// ------------------------------------------------------------------------------------------ dQ, 8 staggered waves
+// The forward's round-3 structure (k_attn_fwd_st) for the dQ kernel: 8 waves x 32 queries, waves 4-7 half a tile late, one
+// barrier per 64-key tile.  A wave alternates an MFMA segment { dQ^T += K^T dS^T of the previous tile (8 MFMAs) ; S^T and dP^T of
+// the next (16) } with a vector segment { p = exp2(S'), dropout select, dS = p * dP' , conversion to MFMA operands }: 768 matrix
+// cycles against ~1000 vector-issue cycles, so the two waves of a SIMD keep both pipes busy.  4-stage ring of K row / K tr / V row
+// images shared by the 8 waves.
+template <int DROP>
+__global__ __launch_bounds__(512, 2) void k_attn_bwd_dq_st(AttnM a, const e16* __restrict__ Q,
+                                                           const e16* __restrict__ K,
+                                                           const e16* __restrict__ V,
+                                                           const e16* __restrict__ O,
+                                                           const e16* __restrict__ dO,
+                                                           const float* __restrict__ lse,
+                                                           float* __restrict__ delta, e16* __restrict__ dQ) {
+  constexpr int STAGE = 3 * KT * DH * 2;   // K row image, K tr image, V row image
+  constexpr int NST = 4;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  unsigned long long* maskw = (unsigned long long*)(lds + NST * STAGE);
+  const int t = threadIdx.x, lane = t & 63, h = lane >> 5;
+  const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+  const bool late = w >= 4;    // waves w and w + 4 share a SIMD (measured: pairing by parity or by w & 2 is 15 % slower)
+  const AttnBlock blk_ = attn_block(a.H, a.B, (a.Tq + 255) / 256);
+  const int hd = blk_.hd, b = blk_.b;
+  const int q0 = blk_.xb * 256 + w * 32;
+  const int q = q0 + (lane & 31);
+  const int qc = q < a.Tq ? q : a.Tq - 1;
+  const bool wave_on = q0 < a.Tq;
+  const e16* Kb = K + (int64_t)b * a.Tk * a.ldk + hd * DH;
+  const e16* Vb = V + (int64_t)b * a.Tk * a.ldv + hd * DH;
+  e16x8 qf[4], dof[4];
+  float dl = 0.f;
+  {
+    const e16* qp = Q + ((int64_t)b * a.Tq + qc) * a.ldq + hd * DH + 8 * h;
+    const e16* dop = dO + ((int64_t)b * a.Tq + qc) * a.ldo + hd * DH + 8 * h;
+    const e16* op = O + ((int64_t)b * a.Tq + qc) * a.ldo + hd * DH + 8 * h;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      qf[s] = *(const e16x8*)(qp + 16 * s);
+      dof[s] = *(const e16x8*)(dop + 16 * s);
+      const e16x8 ov = *(const e16x8*)(op + 16 * s);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) dl += (float)dof[s][j] * (float)ov[j];
+    }
+  }
+  dl += __shfl_xor(dl, 32, 64);
+  const int64_t lrow = ((int64_t)b * a.H + hd) * a.Tq + qc;
+  if (q < a.Tq && h == 0) delta[lrow] = dl;
+  const float L = lse[lrow];
+  const float nL2 = L == INFINITY ? -INFINITY : -L * 1.4426950408889634f;    // row constants as initial accumulators
+  const float ndl = -dl;
+#pragma unroll
+  for (int s = 0; s < 4; ++s)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      qf[s][j] = (e16)((float)qf[s][j] * a.scale_log2);
+      if (DROP != DROP_NONE) dof[s][j] = (e16)((float)dof[s][j] * a.dd.scale16);
+    }
+  f32x16 dq[2], sc[2], dp[2];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { dq[0][i] = 0.f; dq[1][i] = 0.f; }
+  e16x8 ds[4];                       // dS^T of the tile as MFMA operands (written by the vector segment)
+  const uint32_t rowbase = (uint32_t)((uint64_t)lrow * (uint64_t)a.Tk);
+  int kend = a.Tk;
+  if (a.causal) kend = min(a.Tk, blk_.xb * 256 + 256);
+  const int ntiles = (kend + KT - 1) / KT;
+  build_mask_words(maskw, a.key_pad, b, a.Tk, ntiles, w & 3, lane);
+  __syncthreads();   // retires the plain loads / the delta store before the LDS-DMA ring starts
+  auto issue = [&](int kt) {      // 24 pieces per tile: wave w moves piece w of each of the three images
+    unsigned char* st = lds + (kt % NST) * STAGE;
+    dma_piece<false>(st, Kb, a.ldk, kt * KT, a.Tk, w, lane);
+    dma_piece<true>(st + KT * DH * 2, Kb, a.ldk, kt * KT, a.Tk, w, lane);
+    dma_piece<false>(st + 2 * KT * DH * 2, Vb, a.ldv, kt * KT, a.Tk, w, lane);
+  };
+  issue(0);
+  if (ntiles > 1) issue(1);
+  attn_wait_vmcnt<0>();
+  __builtin_amdgcn_s_barrier();
+  auto sync = [&](int kt) {         // see k_attn_fwd_st: tile kt + 1 landed for everybody, stage (kt + 2) % 4 is free
+#if defined(AFM_ABL) && AFM_ABL == 8      // timing only: no barrier, no DMA
+    return;
+#endif
+    attn_wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    if (kt + 2 < ntiles) issue(kt + 2);
+  };
+  auto live = [&](int kt) { return wave_on && !(a.causal && kt * KT > q0 + 31) && maskw[kt] != ~0ull; };
+  KeepMasks km[2];
+  auto products = [&](int kt) {     // MFMA segment, second half: S^T = K Q^T - lse, dP'^T = scale V dO^T - delta
+    const unsigned char* Krow = lds + (kt % NST) * STAGE;
+    const unsigned char* Vrow = Krow + 2 * KT * DH * 2;
+    if (DROP == DROP_BITS) {        // the tile's keep masks: scalar loads in flight during the MFMAs
+      const unsigned long long* kbp = bits_block(a, b * a.H + hd, q0 >> 5, 2 * kt);
+      keep_masks_issue(km[0], kbp);
+      keep_masks_issue(km[1], kbp + 16);
+    }
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { sc[blk][i] = nL2; dp[blk][i] = ndl; }
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+#if defined(AFM_ABL) && AFM_ABL == 6      // timing only: fragment reads without the MFMAs
+        const e16x8 fk = frag_row(Krow, 32 * blk, ks, lane), fv = frag_row(Vrow, 32 * blk, ks, lane);
+        asm volatile("" :: "v"(fk), "v"(fv));
+#elif defined(AFM_ABL) && AFM_ABL == 7    // timing only: MFMAs on register operands, no fragment reads
+        sc[blk] = mfma32(qf[(ks + 1) & 3], qf[ks], sc[blk]);
+        dp[blk] = mfma32(dof[(ks + 1) & 3], dof[ks], dp[blk]);
+#else
+        sc[blk] = mfma32(frag_row(Krow, 32 * blk, ks, lane), qf[ks], sc[blk]);
+        dp[blk] = mfma32(frag_row(Vrow, 32 * blk, ks, lane), dof[ks], dp[blk]);
+#endif
+      }
+      asm volatile("" ::: "memory");     // fragment reads of the second block stay behind the first block's
+    }
+  };
+  auto vector_seg = [&](int kt) {
+#if defined(AFM_ABL) && AFM_ABL == 5      // timing only: no vector segment
+    if (DROP == DROP_BITS) { keep_masks_wait(km[0]); keep_masks_wait(km[1]); }
+    return;
+#endif
+    const int kb = kt * KT;
+    const unsigned long long mword = maskw[kt];
+    const unsigned long long pad = mword >> (4 * h);
+    const bool masked = mword != 0ull || (a.causal && (kb + KT - 1 > q0));
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk) {
+      if (DROP == DROP_HASH) drop_block_select(a.dd, rowbase, kb + 32 * blk, h, dp[blk], ndl);
+      if (DROP == DROP_BITS) drop_select_masks(dp[blk], km[blk], ndl);
+      if (masked) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int ko = 32 * blk + ACC_ROW(r);
+          bool msk = (pad >> ko) & 1ull;
+          if (a.causal) msk = msk || (kb + ko + 4 * h > q);
+          sc[blk][r] = msk ? -INFINITY : sc[blk][r];
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sc[blk][r] = fast_exp2(sc[blk][r]) * dp[blk][r];     // dS^T = P (D dP - delta)
+      ds[2 * blk] = cvt8(sc[blk], 0);
+      ds[2 * blk + 1] = cvt8(sc[blk], 1);
+    }
+  };
+  auto dq_mm = [&](int kt) {        // MFMA segment, first half: dQ^T += K^T dS^T
+    const unsigned char* Ktr = lds + (kt % NST) * STAGE + KT * DH * 2;
+    unsigned ka0, ka1;
+    tr_lane_addr(Ktr, lane, ka0, ka1);
+    TrQuad kq[2];
+    kq[0] = tr_issue(ka0, ka1, 0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if (i < 3) kq[(i + 1) & 1] = tr_issue(ka0, ka1, 16 * (i + 1));
+      if (i < 3) tr_wait<4>(); else tr_wait<0>();
+#if defined(AFM_ABL) && AFM_ABL == 6
+      asm volatile("" :: "v"(kq[i & 1].lo0), "v"(kq[i & 1].hi0), "v"(kq[i & 1].lo1), "v"(kq[i & 1].hi1));
+#elif defined(AFM_ABL) && AFM_ABL == 7
+      dq[0] = mfma32(qf[i], ds[i], dq[0]);
+      dq[1] = mfma32(dof[i], ds[i], dq[1]);
+#else
+      dq[0] = mfma32(tr_join(kq[i & 1].lo0, kq[i & 1].hi0), ds[i], dq[0]);
+      dq[1] = mfma32(tr_join(kq[i & 1].lo1, kq[i & 1].hi1), ds[i], dq[1]);
+#endif
+    }
+  };
+  __builtin_assume(ntiles >= 1);
+  bool pl = false;
+  if (!late) {
+    for (int kt = 0; kt < ntiles; ++kt) {
+      sync(kt);
+      if (pl) dq_mm(kt - 1);
+      pl = live(kt);
+      if (pl) { products(kt); vector_seg(kt); }
+    }
+    if (pl) dq_mm(ntiles - 1);
+  } else {
+    __builtin_amdgcn_s_setprio(1);     // (measured: 0.571 -> 0.621 ms without it)
+    bool lv = live(0);
+    if (lv) products(0);
+    for (int kt = 0; kt < ntiles; ++kt) {
+      sync(kt);
+      if (lv) { vector_seg(kt); dq_mm(kt); }
+      lv = kt + 1 < ntiles && live(kt + 1);
+      if (lv) products(kt + 1);
+    }
+  }
+  if (q < a.Tq) {
+    e16* dqp = dQ + ((int64_t)b * a.Tq + q) * a.lddq + hd * DH + 4 * h;
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        e16x4 v = {(e16)(dq[db][4 * g4 + 0] * a.scale), (e16)(dq[db][4 * g4 + 1] * a.scale),
+                    (e16)(dq[db][4 * g4 + 2] * a.scale), (e16)(dq[db][4 * g4 + 3] * a.scale)};
+        *(e16x4*)(dqp + 32 * db + 8 * g4) = v;
+      }
+  }
+}
+
 // ------------------------------------------------------------------------------------------ dK, dV
 // Workgroup = 4 waves x 32 keys; loops over 64-query tiles.  S = Q K^T with the key on the lane
 // (queries in registers), P = exp2(S - lse[q]), dP = dO V^T, dS = P (D dP - delta[q]);
@@ -749,8 +953,11 @@ int AFM_E16_FN(afm_attn_fwd_mfma_try)(const afm_attn_shape* s, const void* Q, co
   const int lds[] = {s->ldq, s->ldk, s->ldv, s->ldo};
   if (!eligible(s, ptrs, 4, lds, 4)) return AFM_ERR_UNSUPPORTED;
   const AttnM a = make_m(s);
-  // long query sequences: 8 staggered waves per workgroup (256 queries); reserved = 8 keeps the 4-wave kernel (A/B timing)
-  if (s->Tq >= 256 && s->reserved != 8) {
+  // 8 staggered waves per workgroup (256 queries): built and verified in round 3, 10 % faster than the 4-wave kernel on random
+  // operands in isolation (0.61 vs 0.68 ms at the c2 shape) but SLOWER inside the training step (0.67 vs 0.58 ms per launch in the
+  // same rocprofv3 run, same box): not the default.  afm_attn_shape.reserved & 16 or AFM_ATTN_8WAVE=1 selects it.
+  static const bool eight_wave = getenv("AFM_ATTN_8WAVE") != nullptr;
+  if (s->Tq >= 256 && ((s->reserved & 16) || eight_wave)) {
     const dim3 grid8(((s->Tq + 255) / 256) * s->H * s->B);
     const int shm8 = 4 * 2 * KT * DH * 2 + ((s->Tk + KT - 1) / KT) * 8;
     if (shm8 > 80 * 1024) return AFM_ERR_UNSUPPORTED;
@@ -793,8 +1000,24 @@ int AFM_E16_FN(afm_attn_bwd_mfma_try)(const afm_attn_shape* s, const void* Q, co
     (void)hipFuncSetAttribute((const void*)k_attn_bwd_dq_mfma<DROP_BITS>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
     (void)hipFuncSetAttribute((const void*)k_attn_bwd_dq_mfma<DROP_NONE>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
   }
-  const bool run_q = s->reserved != 2, run_k = s->reserved != 1;   // reserved = 1 / 2: only the dQ / only the dK-dV kernel (timing)
-  if (!run_q) {}
+  const bool run_q = (s->reserved & 3) != 2, run_k = (s->reserved & 3) != 1;   // reserved & 3 = 1 / 2: only the dQ / only the dK-dV kernel (timing)
+  static const bool eight_wave = getenv("AFM_ATTN_8WAVE") != nullptr;
+  const bool q8 = s->Tq >= 256 && ((s->reserved & 16) || eight_wave);   // the 8-wave staggered dQ kernel (see afm_attn_fwd_mfma_try: not the default)
+  const int shm_q8 = 4 * 3 * KT * DH * 2 + ((s->Tk + KT - 1) / KT) * 8;
+  if (run_q && q8) {
+    static AfmOncePerDevice attr_q8;
+    if (attr_q8.need()) {
+      (void)hipFuncSetAttribute((const void*)k_attn_bwd_dq_st<DROP_HASH>, hipFuncAttributeMaxDynamicSharedMemorySize, 112 * 1024);
+      (void)hipFuncSetAttribute((const void*)k_attn_bwd_dq_st<DROP_BITS>, hipFuncAttributeMaxDynamicSharedMemorySize, 112 * 1024);
+      (void)hipFuncSetAttribute((const void*)k_attn_bwd_dq_st<DROP_NONE>, hipFuncAttributeMaxDynamicSharedMemorySize, 112 * 1024);
+    }
+    if (shm_q8 > 112 * 1024) return AFM_ERR_UNSUPPORTED;
+    const dim3 gq8(((s->Tq + 255) / 256) * s->H * s->B);
+    if (a.dd.thresh16 && a.bits) AFM_LAUNCH(k_attn_bwd_dq_st<DROP_BITS>, gq8, dim3(512), shm_q8, st, a, (const e16*)Q, (const e16*)K, (const e16*)V, (const e16*)O, (const e16*)dO, lse, delta, (e16*)dQ);
+    else if (a.dd.thresh16) AFM_LAUNCH(k_attn_bwd_dq_st<DROP_HASH>, gq8, dim3(512), shm_q8, st, a, (const e16*)Q, (const e16*)K, (const e16*)V, (const e16*)O, (const e16*)dO, lse, delta, (e16*)dQ);
+    else AFM_LAUNCH(k_attn_bwd_dq_st<DROP_NONE>, gq8, dim3(512), shm_q8, st, a, (const e16*)Q, (const e16*)K, (const e16*)V, (const e16*)O, (const e16*)dO, lse, delta, (e16*)dQ);
+  }
+  else if (!run_q) {}
   else if (a.dd.thresh16 && a.bits) AFM_LAUNCH(k_attn_bwd_dq_mfma<DROP_BITS>, gq, dim3(256), shm_q, st, a, (const e16*)Q, (const e16*)K, (const e16*)V, (const e16*)O, (const e16*)dO, lse, delta, (e16*)dQ);
   else if (a.dd.thresh16) AFM_LAUNCH(k_attn_bwd_dq_mfma<DROP_HASH>, gq, dim3(256), shm_q, st, a, (const e16*)Q, (const e16*)K, (const e16*)V, (const e16*)O, (const e16*)dO, lse, delta, (e16*)dQ);
   else AFM_LAUNCH(k_attn_bwd_dq_mfma<DROP_NONE>, gq, dim3(256), shm_q, st, a, (const e16*)Q, (const e16*)K, (const e16*)V, (const e16*)O, (const e16*)dO, lse, delta, (e16*)dQ);

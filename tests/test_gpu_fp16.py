@@ -144,6 +144,8 @@ def test_attention_f16(ops, B, H, Tq, Tk, causal, pad, pdrop):
     for algo in (1, 2):
         o = torch.empty(B * Tq, D, dtype=dt, device=DEV); lse = torch.empty(B * H * Tq, device=DEV)
         shp = ops.attn_shape(B, H, Tq, Tk, dh, dt, D, D, D, D, kp, causal, ops.drop(pdrop, seed, site), algo=algo)
+        if Tq in (256, 320, 512, 1024):      # these cases run the 8-wave staggered forward / dQ kernels (opt-in forms), Tq = 300 the default ones
+            shp.reserved = 16
         if pdrop > 0 and algo == 2 and Tq % 2 == 0:
             ops.attn_set_drop_bits(shp, torch.zeros(ops.attn_drop_bits_words(B, H, Tq, Tk), dtype=torch.int64, device=DEV))
         ops.attn_fwd(shp, qd, kd, vd, o, lse)

@@ -6,7 +6,7 @@ from multimodalanalytical_amd import ops
 from multimodalanalytical_amd.x2 import X2
 
 
-def t(fn, iters=10, warm=3):
+def t(fn, iters=20, warm=30):      # (a kernel timed right after process start reads ~15 % slow: warm the clocks up)
     for _ in range(warm): fn()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize(); a.record()
@@ -22,7 +22,7 @@ def main():
     ap.add_argument("--S", type=int, default=1024); ap.add_argument("--Tq", type=int, default=0)
     ap.add_argument("--p", type=float, default=0.1); ap.add_argument("--causal", type=int, default=0)
     ap.add_argument("--bits", type=int, default=1, help="1: forward stores the keep-bit tensor, backward reads it; 0: re-hash")
-    ap.add_argument("--old", type=int, default=0, help="1: also time the 4-wave kernels (afm_attn_shape.reserved = 8 / 9 / 10)")
+    ap.add_argument("--old", type=int, default=0, help="1: also time the 8-wave staggered forms (afm_attn_shape.reserved | 16)")
     a = ap.parse_args()
     dev = "cuda:0"
     cd = {"bf16": torch.bfloat16, "fp16": torch.float16, "bf16x3": X2.dtype, "fp32": torch.float32}[a.mode]
@@ -53,8 +53,9 @@ def main():
     passes = 3 if a.mode == "bf16x3" else 1
     cases = []
     if a.old:
-        s8 = shp(8)
-        cases.append(("fwd4", lambda: ops.attn_fwd(s8, q, k, v, o, lse), 2))
+        s8, s9 = shp(16), shp(17)
+        cases.append(("fwd8", lambda: ops.attn_fwd(s8, q, k, v, o, lse), 2))
+        cases.append(("dq8", lambda: ops.attn_bwd(s9, q, k, v, o, do, lse, delta, dq, dk, dv, ops._ld(dq), ops._ld(dk), ops._ld(dv)), 3))
     for name, fn, np_ in cases + [("fwd", lambda: ops.attn_fwd(s0, q, k, v, o, lse), 2),
                           ("dq", lambda: ops.attn_bwd(s1, q, k, v, o, do, lse, delta, dq, dk, dv, ops._ld(dq), ops._ld(dk), ops._ld(dv)), 3),
                           ("dkv", lambda: ops.attn_bwd(s2, q, k, v, o, do, lse, delta, dq, dk, dv, ops._ld(dq), ops._ld(dk), ops._ld(dv)), 4)]:
