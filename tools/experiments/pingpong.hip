@@ -245,6 +245,8 @@ __global__ __launch_bounds__(512) void k_split(u64* cyc, float* out, int iters, 
   Tile t;
   for (int i = 0; i < 16; ++i) { t.s0[i] = 0.1f * i; t.s1[i] = 0.05f * i; }
   float m = 0.f, l = 0.f;
+  if ((mode & 4) && w < 4) __builtin_amdgcn_s_setprio(3);
+  if ((mode & 8) && w >= 4) __builtin_amdgcn_s_setprio(3);
   const u64 t0 = __builtin_amdgcn_s_memtime();
   if (w < 4) {
     if (mode & 1)
@@ -307,14 +309,23 @@ int main() {
   for (int i = 0; i < 128; ++i) hm[i] = 0xFFFFFFFFFFFFFFFFull ^ (0x0123456789ABCDEFull * (i + 1));
   hipMemcpy(d_masks, hm, sizeof hm, hipMemcpyHostToDevice);
   const char* opn[] = {"v_fma_f32", "v_exp_f32", "v_cvt_pk_bf16_f32", "v_max3_f32", "v_mad_u32_u24", "lshr+xor (2)", "cmp+cndmask (2)", "v_add_f32", "v_pk_mul_f32", "v_cvt_pk_f16_f32"};
+  const bool split_only = getenv("PP_SPLIT_ONLY") != nullptr;
   printf("== 1. VALU issue: SIMD-cycles per instruction (64 instructions per iteration)\n");
-#define VAL(OP, MULT) for (int occ = 1; occ <= 3; ++occ) run(opn[OP], k_valu<OP>, 256, occ, 2000, 64.0 * MULT, "instr");
+#define VAL(OP, MULT) for (int occ = 1; occ <= 3 && !split_only; ++occ) run(opn[OP], k_valu<OP>, 256, occ, 2000, 64.0 * MULT, "instr");
   VAL(0, 1) VAL(1, 1) VAL(2, 1) VAL(3, 1) VAL(4, 1) VAL(5, 2) VAL(6, 2) VAL(7, 1) VAL(8, 1) VAL(9, 1)
   printf("== 2. wave-specialised: waves 0-3 16 MFMA per iteration, waves 4-7 one softmax tile per iteration (median wave cycles: of all 8 waves)\n");
   for (int mode = 1; mode <= 3; ++mode) {
     run(mode == 1 ? "split A0: MFMA waves only" : mode == 2 ? "split A0: VALU waves only" : "split A0: both", k_split<0>, 512, 1, 1000, 1.0, "iter", mode, (const u64*)d_masks);
   }
   for (int mode = 2; mode <= 3; ++mode) run(mode == 2 ? "split A1: VALU waves only" : "split A1: both", k_split<1>, 512, 1, 1000, 1.0, "iter", mode, (const u64*)d_masks);
+  run("split A0: both, MFMA waves prio 3", k_split<0>, 512, 1, 1000, 1.0, "iter", 3 | 4, (const u64*)d_masks);
+  run("split A0: both, VALU waves prio 3", k_split<0>, 512, 1, 1000, 1.0, "iter", 3 | 8, (const u64*)d_masks);
+  run("split A1: both, MFMA waves prio 3", k_split<1>, 512, 1, 1000, 1.0, "iter", 3 | 4, (const u64*)d_masks);
+  run("split A1: both, VALU waves prio 3", k_split<1>, 512, 1, 1000, 1.0, "iter", 3 | 8, (const u64*)d_masks);
+  run("split A2: VALU waves only", k_split<2>, 512, 1, 1000, 1.0, "iter", 2, (const u64*)d_masks);
+  run("split A2: both", k_split<2>, 512, 1, 1000, 1.0, "iter", 3, (const u64*)d_masks);
+  run("split A2: both, MFMA waves prio 3", k_split<2>, 512, 1, 1000, 1.0, "iter", 3 | 4, (const u64*)d_masks);
+  if (getenv("PP_SPLIT_ONLY")) return 0;
   printf("== 3. forward tile (16 MFMA + softmax of 32 scores / lane): SIMD-cycles per tile; MFMA floor = 512\n");
 #define FWD(S, A, T, NAME) run(NAME, k_fwd<S, A, T>, T, occ, 1000, 1.0, "tile", (const u64*)d_masks)
   for (int occ = 1; occ <= 3; ++occ) FWD(SEQ, 0, 256, "SEQ  current arithmetic");
