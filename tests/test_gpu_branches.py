@@ -188,7 +188,7 @@ def test_config_driven_training_entry(tmp_path):
     assert main([a for a in argv[:3] + ["data_path=/nonexistent"] + argv[4:] if a != "strict=1"]) == 0
 
 
-def _dp2_worker(rank, world, port, name, q):
+def _dp2_worker(rank, world, port, name, outdir):
     """One of two data-parallel ranks, both on cuda:0, exchanging over gloo (device tensors): the N > 1 code path without a
     second GPU -- bucket hooks from the backward pass, summed gradients, 1/world in the fused clip + Adam."""
     import os
@@ -204,12 +204,14 @@ def _dp2_worker(rank, world, port, name, q):
     assert loop.reducer is not None and loop.reducer.comm is None        # gloo group: torch.distributed carries the buckets
     loss = loop.micro_batch(to_device(G.batch_of(t, rank), DEV))          # rank r trains on batch r
     torch.cuda.synchronize()
-    q.put((rank, w.hf_model.engine.ps.flat.cpu().clone(), float(loss), len(loop.reducer.launched)))
+    import os as _os
+    torch.save({"rank": rank, "flat": w.hf_model.engine.ps.flat.cpu().clone(), "loss": float(loss), "buckets": len(loop.reducer.launched)},
+               _os.path.join(outdir, f"rank{rank}.pt"))       # (a file, not a Queue: tensors in a Queue need the sender alive)
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_two_ranks_on_one_gpu_equal_the_averaged_single_process_step():
+def test_two_ranks_on_one_gpu_equal_the_averaged_single_process_step(tmp_path):
     """Data-parallel equivalence (trainer/trainer.py:58,61 of the reference: DDP averages the ranks' gradients): two processes,
     one batch each, one optimiser step == one process that averages the two batches' gradients itself."""
     _need_gpu()
@@ -220,14 +222,17 @@ def test_two_ranks_on_one_gpu_equal_the_averaged_single_process_step():
     name = "model_plain"
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    procs = [ctx.Process(target=_dp2_worker, args=(r, 2, port, name, q)) for r in range(2)]
+    procs = [ctx.Process(target=_dp2_worker, args=(r, 2, port, name, str(tmp_path))) for r in range(2)]
     for p in procs:
         p.start()
-    got = sorted([q.get(timeout=300) for _ in procs], key=lambda x: x[0])
     for p in procs:
-        p.join(60)
+        p.join(600)
         assert p.exitcode == 0
+    import os
+    got = []
+    for r in range(2):
+        d = torch.load(os.path.join(str(tmp_path), f"rank{r}.pt"))
+        got.append((d["rank"], d["flat"], d["loss"], d["buckets"]))
     # single process: accumulate batch 0 and batch 1 at weight 1/2 each, one step (no reducer)
     t = G.load(name); cfg = G.model_cfg(t["meta"])
     w = _wrapper(t, cfg, torch.float32, dropout=0.0)
