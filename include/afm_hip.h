@@ -386,7 +386,9 @@ int afm_cache_reorder(const void* src, void* dst, const int32_t* beam_idx, int32
 /* ------------------------------------------------------------------------------------------
  * Optimiser over ONE flat fp32 parameter buffer (all tensors of the model are views of it).
  * afm_sumsq:  out[0] += sum g[i]^2   (torch.nn.utils.clip_grad_norm_, Lightning
- *             gradient_clip_val, trainer/trainer.py:65)
+ *             gradient_clip_val, trainer/trainer.py:65).  Two stages through `partial` (workspace of AFM_SUMSQ_PARTIALS
+ *             floats), no atomics: the sum is bit-reproducible, so data-parallel replicas derive identical clip coefficients
+ *             from the all-reduced buffer and stay bit-identical
  * afm_adam_step: torch.optim.Adam / AdamW (wrapper.py:29,333-338) with the clip folded in:
  *     coef = grad_mult * min(1, max_norm / (sqrt(sumsq[0]) * grad_mult + 1e-6)) ; g = g * coef
  *     (grad_mult = 1/world under data parallelism: sumsq is taken over the SUMMED gradients, the clip acts on their mean)
@@ -403,7 +405,8 @@ int afm_cache_reorder(const void* src, void* dst, const int32_t* beam_idx, int32
  * number of steps actually taken (torch's per-parameter `step`), instead of hyper[5..6].  afm_scaler_update then applies
  * GradScaler.update(): skipped -> S *= backoff, tracker = 0; else tracker += 1 and after `interval` good steps S *= growth.
  * ---------------------------------------------------------------------------------------- */
-int afm_sumsq(const float* g, int64_t n, float* out, void* stream);
+#define AFM_SUMSQ_PARTIALS 2048
+int afm_sumsq(const float* g, int64_t n, float* out, float* partial, void* stream);
 int afm_adam_step(float* p, float* g, float* m, float* v, int64_t n, const float* hyper,
                   const float* sumsq, void* p_lowp, int32_t lowp_dtype, int32_t zero_grad, const float* scaler, void* stream);
 int afm_scaler_update(float* scaler, const float* sumsq, float growth, float backoff, int32_t interval, void* stream);

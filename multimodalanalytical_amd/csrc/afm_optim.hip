@@ -3,9 +3,10 @@
 // + 16-bit shadow) = 28-34 B/param.
 #include "afm_common.h"
 
-__global__ __launch_bounds__(256) void k_sumsq(const float* __restrict__ g, int64_t n,
-                                               float* __restrict__ out) {
-  __shared__ float part[4];
+// Two stages, no atomics: every rank of a data-parallel job must derive the SAME clip coefficient from the same (all-reduced)
+// gradient buffer, bit for bit, or the replicas drift apart by an ulp per step -- an atomic sum's order changes from run to run.
+__global__ __launch_bounds__(256) void k_sumsq(const float* __restrict__ g, int64_t n, float* __restrict__ part) {
+  __shared__ float sh[4];
   float acc = 0.f;
   const int64_t n4 = n >> 2;
   const f32x4* g4 = (const f32x4*)g;
@@ -19,18 +20,28 @@ __global__ __launch_bounds__(256) void k_sumsq(const float* __restrict__ g, int6
     acc += v * v;
   }
   acc = wave_sum(acc);
-  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
   __syncthreads();
-  if (threadIdx.x == 0) atomicAdd(out, part[0] + part[1] + part[2] + part[3]);
+  if (threadIdx.x == 0) part[blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+__global__ __launch_bounds__(256) void k_sumsq_final(const float* __restrict__ part, int nblocks, float* __restrict__ out) {
+  __shared__ float sh[4];
+  float acc = 0.f;
+  for (int i = threadIdx.x; i < nblocks; i += 256) acc += part[i];      // fixed order per thread, fixed tree below
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) out[0] += (sh[0] + sh[1]) + (sh[2] + sh[3]);
 }
 
-extern "C" int afm_sumsq(const float* g, int64_t n, float* out, void* stream) {
-  if (!g || !out || n < 0 || ((uintptr_t)g & 15)) return AFM_ERR_ARG;
+extern "C" int afm_sumsq(const float* g, int64_t n, float* out, float* partial, void* stream) {
+  if (!g || !out || !partial || n < 0 || ((uintptr_t)g & 15)) return AFM_ERR_ARG;
   if (n == 0) return AFM_OK;
   int64_t blocks = (n / 4 + 255) / 256;
-  if (blocks > 2048) blocks = 2048;
+  if (blocks > AFM_SUMSQ_PARTIALS) blocks = AFM_SUMSQ_PARTIALS;
   if (blocks < 1) blocks = 1;
-  AFM_LAUNCH(k_sumsq, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, g, n, out);
+  AFM_LAUNCH(k_sumsq, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, g, n, partial);
+  AFM_LAUNCH(k_sumsq_final, dim3(1), dim3(256), 0, (hipStream_t)stream, partial, (int)blocks, out);
   return AFM_OK;
 }
 

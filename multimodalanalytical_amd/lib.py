@@ -119,7 +119,7 @@ _SIGS = {
     "afm_beam_step": (C.c_int, [C.POINTER(BeamDesc), _P]),
     "afm_beam_finalize": (C.c_int, [C.POINTER(BeamDesc), _P, _P, _P, _P]),
     "afm_cache_reorder": (C.c_int, [_P, _P, _P, _I32, _I64, _I64, _P]),
-    "afm_sumsq": (C.c_int, [_P, _I64, _P, _P]),
+    "afm_sumsq": (C.c_int, [_P, _I64, _P, _P, _P]),
     "afm_adam_step": (C.c_int, [_P, _P, _P, _P, _I64, _P, _P, _P, _I32, _I32, _P, _P]),
     "afm_scaler_update": (C.c_int, [_P, _P, _F, _F, _I32, _P]),
     "afm_place_rows": (C.c_int, [_P, _P, _P, _I64, _I32, _I64, _I64, _I64, _I32, _P]),

@@ -459,8 +459,16 @@ def ce_bwd(logits, labels, row_lse, stats, grad_scale, dlogits, scale_dev=None):
             "afm_ce_bwd")
 
 
-def sumsq(g, out):
-    L.check(L.load().afm_sumsq(_ptr(g), g.numel(), _ptr(out), _stream()), "afm_sumsq")
+_SUMSQ_WS = {}
+
+
+def sumsq(g, out, partial=None):
+    """out[0] += sum g^2, bit-reproducible (two stages through a 2048-float workspace, kept per device when not given)."""
+    if partial is None:
+        partial = _SUMSQ_WS.get(g.device)
+        if partial is None:
+            partial = _SUMSQ_WS[g.device] = torch.empty(2048, dtype=torch.float32, device=g.device)
+    L.check(L.load().afm_sumsq(_ptr(g), g.numel(), _ptr(out), _ptr(partial), _stream()), "afm_sumsq")
 
 
 def adam_step(p, g, m, v, hyper, sumsq_buf, p_lowp=None, zero_grad=True, scaler=None):

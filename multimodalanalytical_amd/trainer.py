@@ -24,14 +24,22 @@ def calculate_training_steps(len_train: int, batch_size: int, acc_batches: int, 
     return math.ceil(batches_per_gpu / acc_batches) * epochs
 
 
+_NATIVE = None      # (NativeComm, side stream) of the live BucketedReducer, if any
+
+
 def sync_mean(value, group=None):
     """Lightning's `self.log(..., sync_dist=True)` (reference wrapper.py:474,486,601): the logged scalar is averaged
-    over the ranks.  Without an initialised process group (single GPU) the value is returned unchanged."""
+    over the ranks.  Without an initialised process group (single GPU) the value is returned unchanged.  While a reducer with
+    the C-ABI RCCL communicator is live, device scalars travel through THAT communicator on its side stream: the logged loss is
+    reduced while gradient buckets are in flight, and collectives of two communicators issued from two streams have no defined
+    relative order across ranks (one communicator, one stream: issue order = execution order everywhere)."""
     if not (dist.is_available() and dist.is_initialized()):
         return value
     world = dist.get_world_size(group)
     if world == 1:
         return value
+    if _NATIVE is not None and torch.is_tensor(value) and value.is_cuda and group is None:
+        return _native_mean(value, *_NATIVE)
     t = value.detach().clone().float() if torch.is_tensor(value) else torch.tensor(float(value))
     if t.device.type == "cpu" and dist.get_backend(group) == "nccl":
         t = t.cuda()
@@ -48,6 +56,18 @@ def sync_flag(flag: bool, src: int = 0, device=None, group=None) -> bool:
     t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=dev)
     dist.broadcast(t, src=src, group=group)
     return bool(int(t.item()))
+
+
+def _native_mean(value: torch.Tensor, comm, side) -> torch.Tensor:
+    """Mean over the ranks of a device scalar through the C-ABI communicator, on its side stream."""
+    t = value.detach().float().reshape(-1).clone()
+    ev = torch.cuda.Event()
+    ev.record(torch.cuda.current_stream())
+    side.wait_event(ev)
+    comm.all_reduce(t, side)
+    t.record_stream(side)
+    torch.cuda.current_stream().wait_stream(side)
+    return (t / comm.world).reshape(value.shape)
 
 
 class NativeComm:
@@ -75,6 +95,9 @@ class NativeComm:
                       "afm_allreduce_bucket")
 
     def close(self) -> None:
+        global _NATIVE
+        if _NATIVE is not None and _NATIVE[0] is self:
+            _NATIVE = None
         if self.handle:
             self._L.load().afm_comm_destroy(self.handle)
             self.handle = None
@@ -108,6 +131,9 @@ class BucketedReducer:
             native = self.is_cuda and os.environ.get("AFM_NATIVE_RCCL", "1") != "0" and dist.is_initialized() and \
                 dist.get_backend(group) == "nccl"
         self.comm = NativeComm(group) if native else None
+        if self.comm is not None and group is None:
+            global _NATIVE
+            _NATIVE = (self.comm, self.stream)
 
     def reset(self):
         self.hi = self.flat.numel()

@@ -156,6 +156,12 @@ def test_rccl_reducer_on_a_one_rank_group_reproduces_the_plain_loop():
         assert abs(outs[0][1] - outs[1][1]) <= 1e-6 * abs(outs[0][1])
         x = torch.tensor([3.5], device=DEV)
         assert float(sync_mean(x)) == 3.5
+        # the route logged scalars take at world > 1 while the C-ABI communicator is live (same communicator, same side stream)
+        from multimodalanalytical_amd import trainer as T
+        assert T._NATIVE is not None and T._NATIVE[0] is loop.reducer.comm
+        y = T._native_mean(torch.tensor(2.25, device=DEV), *T._NATIVE)
+        torch.cuda.synchronize()
+        assert y.shape == () and float(y) == 2.25
     finally:
         dist.destroy_process_group()
 

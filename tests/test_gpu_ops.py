@@ -319,6 +319,22 @@ def test_adam_against_oracle(ops):
             close(shadow, pd.float().cpu().bfloat16(), 0, 0)
 
 
+@pytest.mark.parametrize("n", [3, 1000 + 3, 45_000_000 + 1])
+def test_sumsq_is_bit_reproducible(ops, n):
+    # data-parallel replicas derive their clip coefficient from this number: it has to be the same bits on every rank and every run
+    g = torch.randn(n, device=DEV) * 0.3
+    got = []
+    for _ in range(6):
+        ss = torch.zeros(1, device=DEV)
+        ops.sumsq(g, ss)
+        got.append(ss.clone())
+    assert all(torch.equal(got[0], x) for x in got[1:])
+    close(got[0][0], g.double().pow(2).sum().float().cpu(), 2e-6, 0)
+    ss = torch.full((1,), 2.0, device=DEV)          # accumulates into out[0]
+    ops.sumsq(g, ss)
+    close(ss[0] - 2.0, got[0][0].cpu(), 1e-5, 1e-5 * n)
+
+
 # ------------------------------------------------------------------ MFMA GEMMs (bf16 operands, fp32 accumulate)
 @pytest.mark.parametrize("M,N,K", [(256, 256, 128), (100, 200, 72), (1000, 1536, 512), (384, 64, 2048), (129, 24, 64)])
 @pytest.mark.parametrize("cdt", [torch.bfloat16, torch.float32])
