@@ -124,6 +124,15 @@ typedef struct {
 } afm_gemm_desc;
 int afm_gemm(const afm_gemm_desc* d, void* stream);
 
+/* afm_gemm_group: `count` independent GEMMs, with the result of calling afm_gemm on each (C matrices must not alias).
+ *   What it is for: the weight gradients of one transformer layer -- in the reference one `addmm` each inside
+ *   torch.autograd's Linear backward (custom_modeling.py:117-160 layers under Lightning's backward, trainer/trainer.py:60-75).
+ *   Each is a small matrix (dW: 512 x 512 .. 2048 x 512) over a long token axis; alone, each needs split-K 16 .. 64 to fill the
+ *   chip, and every split adds dW once more through fp32 atomics.  Weight-gradient problems (transA, !transB, both operands
+ *   AFM_BF16 or both AFM_F16, AFM_F32 C with accumulate = 1, no epilogue, M, N >= 256, K % 64 == 0) are fused, up to 8 per
+ *   launch, into ONE grid sharing one split-K budget; any other problem runs through afm_gemm, in order. */
+int afm_gemm_group(const afm_gemm_desc* descs, int32_t count, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Embedding rows.  nn.Embedding forward / embedding_dense_backward (modeling/utils.py:102-106,
  * 155-162): out[i,:] = table[ids[i],:] * (scale ? scale[i] : 1).  Backward adds

@@ -221,6 +221,10 @@ __global__ __launch_bounds__(256) void k_gemm_skinny_n(GemmArgs g, float* a_cols
 // defined in afm_gemm_mfma.hip / afm_gemm_mfma_f16.hip (bf16 / fp16 operands); return AFM_ERR_UNSUPPORTED when the shape is not eligible
 int afm_gemm_mfma_try(const afm_gemm_desc* d, hipStream_t st);
 int afm_gemm_mfma_try_f16(const afm_gemm_desc* d, hipStream_t st);
+bool afm_gemm_tn_group_eligible(const afm_gemm_desc* d);
+bool afm_gemm_tn_group_eligible_f16(const afm_gemm_desc* d);
+int afm_gemm_tn_group_launch(const afm_gemm_desc* const* ds, int count, hipStream_t st);
+int afm_gemm_tn_group_launch_f16(const afm_gemm_desc* const* ds, int count, hipStream_t st);
 // defined in afm_gemm_x3.hip: split-pair operands on three bf16 MFMAs per product
 int afm_gemm_x3_try(const afm_gemm_desc* d, hipStream_t st);
 
@@ -317,4 +321,31 @@ extern "C" int afm_gemm(const afm_gemm_desc* d, void* stream) {
   if (glu) return AFM_ERR_UNSUPPORTED;        // fused gated FFN: MFMA kernels only (the caller keeps afm_glu_fwd / afm_glu_bwd)
   if (d->glu_rows && d->transA) return AFM_ERR_UNSUPPORTED;
   return gemm_generic(d, st);
+}
+
+// count independent GEMMs with the result of calling afm_gemm on each.  Weight-gradient problems (TN, 16-bit operands of one
+// type, fp32 accumulate into C, M, N >= 256, K a multiple of 64) are fused, up to 8 per launch, into one grid that shares ONE
+// split-K budget; everything else goes through afm_gemm one by one, in order.  The problems must not alias each other's C.
+extern "C" int afm_gemm_group(const afm_gemm_desc* descs, int32_t count, void* stream) {
+  if (count < 0 || (count > 0 && !descs)) return AFM_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  const afm_gemm_desc* grp[2][8];
+  int ng[2] = {0, 0};
+  auto flush = [&](int t) -> int {
+    int r = AFM_OK;
+    if (ng[t] == 1) r = afm_gemm(grp[t][0], stream);          // alone it keeps its own tile / split-K choice
+    else if (ng[t] > 1) r = t ? afm_gemm_tn_group_launch_f16(grp[t], ng[t], st) : afm_gemm_tn_group_launch(grp[t], ng[t], st);
+    ng[t] = 0;
+    return r;
+  };
+  for (int i = 0; i < count; ++i) {
+    const afm_gemm_desc* d = descs + i;
+    if (!d->A || !d->B || !d->C || d->M <= 0 || d->N <= 0 || d->K < 0) { const int r = afm_gemm(d, stream); if (r != AFM_OK) return r; continue; }
+    const int t = afm_gemm_tn_group_eligible_f16(d) ? 1 : afm_gemm_tn_group_eligible(d) ? 0 : -1;
+    if (t < 0) { const int r = afm_gemm(d, stream); if (r != AFM_OK) return r; continue; }
+    grp[t][ng[t]++] = d;
+    if (ng[t] == 8) { const int r = flush(t); if (r != AFM_OK) return r; }
+  }
+  for (int t = 0; t < 2; ++t) { const int r = flush(t); if (r != AFM_OK) return r; }
+  return AFM_OK;
 }

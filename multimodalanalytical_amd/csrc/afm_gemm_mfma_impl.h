@@ -1079,7 +1079,12 @@ __global__ __launch_bounds__(512, 2) void k_gemm_tn_ring(MfmaArgs g) {
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  const bool do_cs = g.a_colsum != nullptr && (tile % g.tiles_n) == 0 && wn == 0;
+  // bias gradient = column sums of dy, from the A fragments.  Every wave of the tile row holds them (the fragment depends on wm
+  // only), so the k-slices are dealt round-robin over the 2 x tiles_n waves that share them: a few instructions per wave instead of
+  // 128 per k-step on one wave of every tile row, which made those workgroups the tail of the launch (-11 .. 19 %).
+  const bool do_cs = g.a_colsum != nullptr;
+  const int cs_slots = 2 * g.tiles_n;
+  int cs_next = (tile % g.tiles_n) * 2 + wn;
   float cs[4] = {0.f, 0.f, 0.f, 0.f};
 
 #pragma unroll
@@ -1141,7 +1146,8 @@ __global__ __launch_bounds__(512, 2) void k_gemm_tn_ring(MfmaArgs g) {
         af[i] = (e16x8){x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
         bfr[i] = (e16x8){y0[0], y0[1], y0[2], y0[3], y1[0], y1[1], y1[2], y1[3]};
       }
-      if (do_cs) {   // bias gradient: column sums of dy from the A fragments (lane: column fr, 8 rows)
+      if (do_cs && kt * 2 + ks == cs_next) {   // this wave's turn (lane: column fr, 8 rows)
+        cs_next += cs_slots;
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -1186,16 +1192,18 @@ __global__ __launch_bounds__(512, 2) void k_gemm_tn_ring(MfmaArgs g) {
 // Same kernel on 256 x 256 tiles: 8 waves of 128 x 64 (2 x 4), two 64-KiB ring slots.  Per FLOP a quarter
 // less L2->LDS fill and a quarter fewer transposed LDS reads than the 256 x 128 form, and 64 MFMAs per
 // wave between barriers; needs more split-K (fewer tiles), i.e. more fp32 atomics on the small dW.
-__global__ __launch_bounds__(512) void k_gemm_tn_ring256(MfmaArgs g) {
+// One (tile, k-chunk) unit of the wgrad form; shared by the single-problem kernel and the grouped one.
+struct TnProb {
+  const e16* A; const e16* B; float* C; float* a_colsum;
+  int M, N, K, lda, ldb, ldc, tiles_n, ntile, ksplit, kchunk, glu_f, accumulate;
+  int unit0;       // grouped launch: index of this problem's first (tile, k-chunk) unit
+};
+__device__ __forceinline__ void tn256_unit(const TnProb& g, int tile, int ks_id, unsigned char* lds) {
   constexpr int S = 2, TBM = 256, TBN = 256, NW = 8, NIW = 8;
   constexpr int ABYTES = 64 * TBM * 2, STAGE = 64 * (TBM + TBN) * 2;
-  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   const int t = threadIdx.x, lane = t & 63;
   const int w = __builtin_amdgcn_readfirstlane(t >> 6);
   const int wm = w >> 2, wn = w & 3;
-  const int ntile = g.tiles_m * g.tiles_n;
-  const int bid = xcd_remap(blockIdx.x, ntile * g.ksplit);
-  const int tile = bid % ntile, ks_id = bid / ntile;     // tile index fastest: an XCD's workgroups share a k-chunk
   const int m0 = (tile / g.tiles_n) * TBM, n0 = (tile % g.tiles_n) * TBN;
   const int kbeg = ks_id * g.kchunk, kend = min(g.K, kbeg + g.kchunk);
   const int nk = (kend - kbeg) / 64;
@@ -1229,7 +1237,9 @@ __global__ __launch_bounds__(512) void k_gemm_tn_ring256(MfmaArgs g) {
   for (int i = 0; i < 8; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  const bool do_cs = g.a_colsum != nullptr && (tile % g.tiles_n) == 0 && wn == 0;
+  const bool do_cs = g.a_colsum != nullptr;     // k-slices dealt over the 4 x tiles_n waves holding the same A fragments (k_gemm_tn_ring)
+  const int cs_slots = 4 * g.tiles_n;
+  int cs_next = (tile % g.tiles_n) * 4 + wn;
   float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
   if (nk > 0) issue(0);
@@ -1285,7 +1295,8 @@ __global__ __launch_bounds__(512) void k_gemm_tn_ring256(MfmaArgs g) {
         const e16x4 y0 = __builtin_bit_cast(e16x4, b0[j]), y1 = __builtin_bit_cast(e16x4, b1[j]);
         bfr[j] = (e16x8){y0[0], y0[1], y0[2], y0[3], y1[0], y1[1], y1[2], y1[3]};
       }
-      if (do_cs) {
+      if (do_cs && kt * 2 + ks == cs_next) {
+        cs_next += cs_slots;
 #pragma unroll
         for (int i = 0; i < 8; ++i)
 #pragma unroll
@@ -1309,7 +1320,7 @@ __global__ __launch_bounds__(512) void k_gemm_tn_ring256(MfmaArgs g) {
       if (fq == 0 && mm < g.M) atomicAdd(g.a_colsum + (g.glu_f ? glu_deint(mm, g.glu_f) : mm), s);
     }
   }
-  float* C = (float*)g.C;
+  float* C = g.C;
 #pragma unroll
   for (int i = 0; i < 8; ++i)
 #pragma unroll
@@ -1325,6 +1336,36 @@ __global__ __launch_bounds__(512) void k_gemm_tn_ring256(MfmaArgs g) {
         }
       }
     }
+}
+
+
+__global__ __launch_bounds__(512) void k_gemm_tn_ring256(MfmaArgs g) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  TnProb pr;
+  pr.A = g.A; pr.B = g.B; pr.C = (float*)g.C; pr.a_colsum = g.a_colsum;
+  pr.M = g.M; pr.N = g.N; pr.K = g.K; pr.lda = g.lda; pr.ldb = g.ldb; pr.ldc = g.ldc;
+  pr.tiles_n = g.tiles_n; pr.ntile = g.tiles_m * g.tiles_n; pr.ksplit = g.ksplit; pr.kchunk = g.kchunk;
+  pr.glu_f = g.glu_f; pr.accumulate = g.accumulate; pr.unit0 = 0;
+  const int bid = xcd_remap(blockIdx.x, pr.ntile * pr.ksplit);
+  tn256_unit(pr, bid % pr.ntile, bid / pr.ntile, lds);     // tile index fastest: an XCD's workgroups share a k-chunk
+}
+
+// Grouped wgrad: the (tile, k-chunk) units of up to AFM_TN_GROUP_MAX weight gradients in ONE launch.  A layer's weight
+// gradients are small matrices (4 .. 16 tiles of 256 x 256) over a long token axis: launched one by one each needs split-K 16 .. 64
+// to fill 256 CUs, and every split adds the whole dW once more through memory-side fp32 atomics (1.3 TB/s chip-wide: 51 us of a
+// 300-us launch at 131 072 tokens, 25 of 33 us at 16 384).  Together they fill the chip at split-K 4 .. 5.
+#define AFM_TN_GROUP_MAX 8
+struct TnGroup { int n, units; TnProb p[AFM_TN_GROUP_MAX]; };
+__global__ __launch_bounds__(512) void k_gemm_tn_group256(TnGroup gr) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  const int bid = xcd_remap(blockIdx.x, gr.units);
+  int pi = 0;
+#pragma unroll
+  for (int i = 1; i < AFM_TN_GROUP_MAX; ++i)
+    if (i < gr.n && bid >= gr.p[i].unit0) pi = i;
+  const TnProb pr = gr.p[pi];
+  const int local = bid - pr.unit0;
+  tn256_unit(pr, local % pr.ntile, local / pr.ntile, lds);
 }
 
 }  // namespace AFM_E16_NS
@@ -1543,4 +1584,67 @@ int AFM_E16_FN(afm_gemm_mfma_try)(const afm_gemm_desc* d, hipStream_t st) {
     return AFM_OK;
   }
   return AFM_ERR_UNSUPPORTED;
+}
+
+// ------------------------------------------------------------------------------------------ grouped wgrad
+// A problem the grouped wgrad launch takes: the TN form with 16-bit operands of this translation unit's type, fp32 accumulate
+// INTO C (the gradient buffer), whole 64-token k-steps, at least one 256 x 256 tile's worth of rows and columns.
+bool AFM_E16_FN(afm_gemm_tn_group_eligible)(const afm_gemm_desc* d) {
+  if (!d->transA || d->transB || d->a_dtype != AFM_E16 || d->b_dtype != AFM_E16 || d->c_dtype != AFM_F32) return false;
+  if (!d->accumulate || d->bias || d->residual || d->pre_act || d->act != AFM_ACT_NONE || d->drop.p > 0.f) return false;
+  if (d->a_colsum && ((uintptr_t)d->a_colsum & 3)) return false;
+  if ((d->M & 7) || (d->N & 7) || d->M < 256 || d->N < 256 || (d->K & 63) || d->K < 1024) return false;
+  if (d->lda < d->M || d->ldb < d->N || d->ldc < d->N) return false;     // (afm_gemm reports it)
+  if (!aligned16(d->A) || !aligned16(d->B) || (d->lda & 7) || (d->ldb & 7)) return false;
+  if (d->algo == AFM_ALGO_GENERIC || (d->reserved != 0 && d->reserved != 105)) return false;
+  return true;
+}
+// count <= AFM_TN_GROUP_MAX eligible problems.  One chunk length (in 64-token k-steps) for all of them: the smallest for which the
+// units fit one wave of workgroups (256), so every problem is split only as far as filling the chip TOGETHER needs.
+int AFM_E16_FN(afm_gemm_tn_group_launch)(const afm_gemm_desc* const* ds, int count, hipStream_t st) {
+  if (count < 1 || count > AFM_TN_GROUP_MAX) return AFM_ERR_ARG;
+  TnGroup gr;
+  gr.n = count;
+  int steps[AFM_TN_GROUP_MAX], tiles = 0;
+  int64_t work = 0;
+  int max_steps = 0;
+  for (int i = 0; i < count; ++i) {
+    const afm_gemm_desc* d = ds[i];
+    TnProb& pr = gr.p[i];
+    pr.A = (const e16*)d->A; pr.B = (const e16*)d->B; pr.C = (float*)d->C; pr.a_colsum = d->a_colsum;
+    pr.M = d->M; pr.N = d->N; pr.K = d->K; pr.lda = d->lda; pr.ldb = d->ldb; pr.ldc = d->ldc;
+    pr.tiles_n = (d->N + 255) / 256; pr.ntile = ((d->M + 255) / 256) * pr.tiles_n;
+    pr.glu_f = d->glu_rows; pr.accumulate = 1;
+    steps[i] = d->K / 64;
+    tiles += pr.ntile;
+    work += (int64_t)pr.ntile * steps[i];
+    if (steps[i] > max_steps) max_steps = steps[i];
+  }
+  int chunk = max_steps;                                   // >= 256 tiles: no split-K at all
+  if (tiles < 256) {
+    chunk = (int)((work + 255) / 256);
+    if (chunk < 16) chunk = 16;                            // >= 1024 tokens per unit
+    for (;; ++chunk) {
+      int units = 0;
+      for (int i = 0; i < count; ++i) units += gr.p[i].ntile * ((steps[i] + chunk - 1) / chunk);
+      if (units <= 256 || chunk >= max_steps) break;
+    }
+  }
+  int units = 0;
+  for (int i = 0; i < count; ++i) {
+    TnProb& pr = gr.p[i];
+    int ks = (steps[i] + chunk - 1) / chunk;
+    const int per = (steps[i] + ks - 1) / ks;              // equal chunks inside a problem
+    ks = (steps[i] + per - 1) / per;
+    pr.ksplit = ks; pr.kchunk = per * 64; pr.unit0 = units;
+    units += pr.ntile * ks;
+  }
+  gr.units = units;
+  for (int i = count; i < AFM_TN_GROUP_MAX; ++i) { gr.p[i] = gr.p[0]; gr.p[i].unit0 = 0x7fffffff; }
+  static AfmOncePerDevice attr;
+  if (attr.need())
+    (void)hipFuncSetAttribute((const void*)k_gemm_tn_group256, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 64 * 512 * 2);
+  AFM_LAUNCH(k_gemm_tn_group256, dim3(units), dim3(512), 2 * 64 * 512 * 2, st, gr);
+  afm_set_last_algo("mfma_tn_group256");
+  return AFM_OK;
 }

@@ -671,7 +671,11 @@ __global__ __launch_bounds__(512, 2) void k_x3_tn(X3Args g) {
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  const bool do_cs = g.a_colsum != nullptr && (tile % g.tiles_n) == 0 && wn == 0;
+  // bias gradient: the k-steps are dealt round-robin over the 2 x tiles_n waves of the tile row that hold the same A fragments
+  // (afm_gemm_mfma_impl.h, k_gemm_tn_ring), instead of one wave per tile row summing all of them
+  const bool do_cs = g.a_colsum != nullptr;
+  const int cs_slots = 2 * g.tiles_n;
+  int cs_next = (tile % g.tiles_n) * 2 + wn;
   float cs[4] = {0.f, 0.f, 0.f, 0.f};
 
 #pragma unroll
@@ -724,7 +728,8 @@ __global__ __launch_bounds__(512, 2) void k_x3_tn(X3Args g) {
         af[pl][i] = (bf16x8){x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
         bfr[pl][i] = (bf16x8){y0[0], y0[1], y0[2], y0[3], y1[0], y1[1], y1[2], y1[3]};
       }
-    if (do_cs) {   // bias gradient: column sums of dy = hi + lo (lane: column fr, 8 token rows)
+    if (do_cs && kt == cs_next) {   // column sums of dy = hi + lo (lane: column fr, 8 token rows)
+      cs_next += cs_slots;
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -812,7 +817,9 @@ __global__ __launch_bounds__(512) void k_x3_tn256(X3Args g) {
   for (int i = 0; i < 8; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  const bool do_cs = g.a_colsum != nullptr && (tile % g.tiles_n) == 0 && wn == 0;
+  const bool do_cs = g.a_colsum != nullptr;     // k-steps dealt over the 4 x tiles_n waves holding the same A fragments (see k_x3_tn)
+  const int cs_slots = 4 * g.tiles_n;
+  int cs_next = (tile % g.tiles_n) * 4 + wn;
   float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   if (nk > 0) issue(0);
   const int grp = lane >> 4, q = (lane >> 2) & 3, p = lane & 3;
@@ -848,6 +855,8 @@ __global__ __launch_bounds__(512) void k_x3_tn256(X3Args g) {
         const bf16x4 y0 = __builtin_bit_cast(bf16x4, b0[pl][j]), y1 = __builtin_bit_cast(bf16x4, b1[pl][j]);
         bfr[pl][j] = (bf16x8){y0[0], y0[1], y0[2], y0[3], y1[0], y1[1], y1[2], y1[3]};
       }
+    const bool cs_now = do_cs && kt == cs_next;
+    if (cs_now) cs_next += cs_slots;
 #pragma unroll
     for (int ih = 0; ih < 2; ++ih) {        // four A fragments at a time (register budget)
       x3_s16x4 a0[2][4], a1[2][4];
@@ -867,7 +876,7 @@ __global__ __launch_bounds__(512) void k_x3_tn256(X3Args g) {
         const bf16x4 l0 = __builtin_bit_cast(bf16x4, a0[1][i]), l1 = __builtin_bit_cast(bf16x4, a1[1][i]);
         const bf16x8 ah = (bf16x8){h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
         const bf16x8 al = (bf16x8){l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
-        if (do_cs) {
+        if (cs_now) {
 #pragma unroll
           for (int e = 0; e < 8; ++e) cs[ih * 4 + i] += (float)ah[e] + (float)al[e];
         }

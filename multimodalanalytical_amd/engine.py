@@ -106,6 +106,8 @@ class Seq2SeqEngine:
         # optimiser / all-reduce): they run on a side HIP stream and overlap the LDS-free kernels
         # (LayerNorm backward, casts) of the main stream on the same CUs
         self.wgrad_stream = torch.cuda.Stream(device=self.dev) if (self.dev.type == "cuda" and side_wgrad) else None
+        self.group_wgrad = os.environ.get("AFM_GROUP_WGRAD", "1") != "0"    # (0: one launch per weight gradient, for A/B timing)
+        self._wg_pending = []
         self.refresh_shadows()
 
     # ------------------------------------------------------------------ parameters
@@ -273,18 +275,42 @@ class Seq2SeqEngine:
     def _wgrad(self, dy, x, name, rows, cols, r0=0, r1=None, bias_name=None):
         """dW[r0:r1] += dy^T x ; db[r0:r1] += colsum(dy)."""
         gw = self.G(name, rows, cols, r0, r1)
-        x = self._hb(x)
         gb = None
         if bias_name is not None:
             gb = self.ps.vec_span(self.ps.grad, bias_name, r0, r0 + gw.shape[0])
+        self._wgrad_raw(dy, self._hb(x), gw, gb)
+
+    def _wgrad_raw(self, dy, x, gw, gb, glu_rows=0):
+        kw = dict(trans_a=True, trans_b=False, accumulate=True, algo=self.algo, a_colsum=gb, glu_rows=glu_rows)
+        if self.group_wgrad and torch.is_tensor(dy) and torch.is_tensor(x) and dy.dtype == x.dtype and dy.dtype != torch.float32:
+            # 16-bit operands: the layer's weight gradients go out together at the end of its backward (afm_gemm_group: one
+            # launch, one split-K budget); the list keeps dy / x alive until then
+            self._wg_pending.append((ops.gemm_desc(dy, x, gw, **kw), dy, x))
+            return
         if self.wgrad_stream is None:
-            ops.gemm(dy, x, gw, trans_a=True, trans_b=False, accumulate=True, algo=self.algo, a_colsum=gb)
+            ops.gemm(dy, x, gw, **kw)
             return
         side = self.wgrad_stream
         side.wait_stream(torch.cuda.current_stream())          # dy / x are produced on the main stream
         with torch.cuda.stream(side):
-            ops.gemm(dy, x, gw, trans_a=True, trans_b=False, accumulate=True, algo=self.algo, a_colsum=gb)
+            ops.gemm(dy, x, gw, **kw)
         dy.record_stream(side); x.record_stream(side)          # keep their memory until the side stream is done
+
+    def _wgrad_flush(self) -> None:
+        """Launch the weight gradients collected since the last flush (afm_gemm_group)."""
+        pending, self._wg_pending = self._wg_pending, []
+        if not pending:
+            return
+        descs = [p[0] for p in pending]
+        if self.wgrad_stream is None:
+            ops.gemm_group(descs)
+            return
+        side = self.wgrad_stream
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            ops.gemm_group(descs)
+        for _, dy, x in pending:
+            dy.record_stream(side); x.record_stream(side)
 
     # ------------------------------------------------------------------ embedding
     def _pos_rows(self, S: int, saved: Optional[dict]):
@@ -540,7 +566,7 @@ class Seq2SeqEngine:
                      algo=self.algo, glu_rows=f)
             gw = self.G(p + "linear1.weight", 2 * f, d)
             gb = self.ps.vec_span(self.ps.grad, p + "linear1.bias", 0, 2 * f)
-            ops.gemm(duv, self._hb(h), gw, trans_a=True, trans_b=False, accumulate=True, algo=self.algo, a_colsum=gb, glu_rows=f)
+            self._wgrad_raw(duv, self._hb(h), gw, gb, glu_rows=f)
             dh = self._empty_b(rows, d)
             ops.gemm(duv, self._hb(self.wt_glu[p + "linear1.weight"]), dh, trans_b=True, algo=self.algo)
             return self._ln_bwd(dh, p + norm, saved, "lnf", dres=dx1, next_site=next_site)
@@ -896,6 +922,7 @@ class Seq2SeqEngine:
     def _grads_final_from(self, first_name: str) -> None:
         """Parameters are laid out in forward order, so once a layer's backward is done every
         gradient from its first tensor to the end of the flat buffer is final."""
+        self._wgrad_flush()
         if self.grad_ready_hook is not None:
             if self.wgrad_stream is not None:
                 torch.cuda.current_stream().wait_stream(self.wgrad_stream)
@@ -904,6 +931,7 @@ class Seq2SeqEngine:
     def _backward(self, saved, logits, lab, row_lse, stats, loss_scale, mem):
         d = self.d
         B, S, T = saved["B"], saved["S"], saved["T"]
+        self._wg_pending = []          # (a backward pass that raised may have left entries behind)
         dlog = self._empty_b(B * T, self.V)
         ops.ce_bwd(logits, lab, row_lse, stats, loss_scale, dlog, scale_dev=self.scaler)
         hf = saved["hf"]
@@ -940,5 +968,6 @@ class Seq2SeqEngine:
             dx, dy = self._self_attn_bwd(dx, dy, p, sv, f"e{i - 1}res2" if i > 0 else None)
             self._grads_final_from(p + "self_attn.in_proj_weight")
         self.embed_bwd(dx, saved["emb_enc"])
+        self._wgrad_flush()
         if self.wgrad_stream is not None:   # every weight gradient is in before the caller reads the buffer
             torch.cuda.current_stream().wait_stream(self.wgrad_stream)

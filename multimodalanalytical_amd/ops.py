@@ -97,14 +97,12 @@ _DEBUG_SYNC = bool(os.environ.get("AFM_DEBUG_SYNC"))   # debugging aid: synchron
 
 
 
-def gemm(a: torch.Tensor, b: torch.Tensor, c: torch.Tensor, *, trans_a=False, trans_b=True,
-         bias: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
-         pre_act: Optional[torch.Tensor] = None, act: int = ACT_NONE, accumulate: bool = False,
-         dropout: Dropout = NO_DROP, algo: int = ALGO_AUTO, a_colsum: Optional[torch.Tensor] = None,
-         variant: int = 0, glu_rows: int = 0, sg_hi_only: bool = False) -> torch.Tensor:
-    """c = epilogue(op(a) @ op(b)); default is the nn.Linear form c = a @ b^T + bias.
-    a_colsum (trans_a only): a_colsum[m] += sum_k a[k, m], the bias gradient of the wgrad form.
-    Gated-FFN forms (act 6 / 7 / 8, include/afm_hip.h): c is (M, N/2) resp. (M, 2N); glu_rows = f."""
+def gemm_desc(a: torch.Tensor, b: torch.Tensor, c: torch.Tensor, *, trans_a=False, trans_b=True,
+              bias: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
+              pre_act: Optional[torch.Tensor] = None, act: int = ACT_NONE, accumulate: bool = False,
+              dropout: Dropout = NO_DROP, algo: int = ALGO_AUTO, a_colsum: Optional[torch.Tensor] = None,
+              variant: int = 0, glu_rows: int = 0, sg_hi_only: bool = False) -> GemmDesc:
+    """The afm_gemm_desc of c = epilogue(op(a) @ op(b)) (arguments as `gemm`); the caller keeps the tensors alive until launch."""
     M, N = c.shape
     if act in (L.ACT_GLU, L.ACT_GLU_SAVE):
         N *= 2
@@ -144,6 +142,14 @@ def gemm(a: torch.Tensor, b: torch.Tensor, c: torch.Tensor, *, trans_a=False, tr
     d.glu_rows = int(glu_rows)
     d.reserved2 = 1 if sg_hi_only else 0
     d.drop = dropout
+    return d
+
+
+def gemm(a: torch.Tensor, b: torch.Tensor, c: torch.Tensor, **kw) -> torch.Tensor:
+    """c = epilogue(op(a) @ op(b)); default is the nn.Linear form c = a @ b^T + bias.
+    a_colsum (trans_a only): a_colsum[m] += sum_k a[k, m], the bias gradient of the wgrad form.
+    Gated-FFN forms (act 6 / 7 / 8, include/afm_hip.h): c is (M, N/2) resp. (M, 2N); glu_rows = f."""
+    d = gemm_desc(a, b, c, **kw)
     L.check(L.load().afm_gemm(C.byref(d), _stream()), "afm_gemm")
     _log_algo()
     if _DEBUG_SYNC:
@@ -151,6 +157,15 @@ def gemm(a: torch.Tensor, b: torch.Tensor, c: torch.Tensor, *, trans_a=False, tr
               f"act={d.act} glu={d.glu_rows}", flush=True)
         torch.cuda.synchronize()
     return c
+
+
+def gemm_group(descs) -> None:
+    """afm_gemm_group: the GEMMs of `descs` (gemm_desc objects), weight-gradient problems fused into shared launches."""
+    if not descs:
+        return
+    arr = (GemmDesc * len(descs))(*descs)
+    L.check(L.load().afm_gemm_group(C.cast(arr, C.c_void_p), len(descs), _stream()), "afm_gemm_group")
+    _log_algo()
 
 
 def gather_rows(ids, table, out, scale=None):

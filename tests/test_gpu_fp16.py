@@ -106,6 +106,76 @@ def test_gemm_f16_tn_wgrad(ops, R, M, N):
     close(gb, b0.double() + dy.double().sum(0), 1e-4, 2e-4 * math.sqrt(R) / 4, "fused bias gradient")
 
 
+@pytest.mark.parametrize("dt", [H16, torch.bfloat16])
+@pytest.mark.parametrize("R", [4096, 16384 + 64])
+def test_gemm_group_wgrads_share_one_launch(ops, dt, R):
+    """afm_gemm_group: a layer's weight gradients in one grid (one split-K budget) equal the one-by-one launches; problems it does
+    not fuse (small, NT, fp32) run through afm_gemm in order; more than 8 eligible problems take a second launch."""
+    shapes = [(512, 512), (1536, 512), (512, 2048), (264, 520), (2048, 512), (256, 256), (512, 264), (768, 256), (512, 512), (256, 1024)]
+    probs, keep = [], []
+    for i, (M, N) in enumerate(shapes):
+        dy, x = (rnd(R, M, seed=10 + i) * 0.5).to(dt), rnd(R, N, seed=40 + i).to(dt)
+        g0, b0 = rnd(M, N, seed=70 + i), rnd(M, seed=90 + i)
+        glu = M // 2 if i == 4 else 0              # one gated problem: rows de-interleaved into the [W1 ; Wg] order
+        probs.append((dy, x, g0, b0 if i % 3 else None, glu))
+    # not fused: a small weight gradient, an NT product, an fp32 weight gradient
+    sm_dy, sm_x, sm_g0 = (rnd(R, 64, seed=5) * 0.5).to(dt), rnd(R, 128, seed=6).to(dt), rnd(64, 128, seed=7)
+    nt_a, nt_w = rnd(300, 128, seed=8).to(dt), rnd(200, 128, seed=9).to(dt)
+    descs, outs = [], []
+    for dy, x, g0, b0, glu in probs[:5]:
+        g = dev(g0).clone(); gb = None if b0 is None else dev(b0).clone()
+        a, b = dev(dy), dev(x); keep += [a, b]
+        descs.append(ops.gemm_desc(a, b, g, trans_a=True, trans_b=False, accumulate=True, a_colsum=gb, glu_rows=glu)); outs.append((g, gb))
+    sm_g = dev(sm_g0).clone(); a, b = dev(sm_dy), dev(sm_x); keep += [a, b]
+    descs.append(ops.gemm_desc(a, b, sm_g, trans_a=True, trans_b=False, accumulate=True))
+    nt_c = torch.empty(300, 200, dtype=dt, device=DEV); a, b = dev(nt_a), dev(nt_w); keep += [a, b]
+    descs.append(ops.gemm_desc(a, b, nt_c))
+    for dy, x, g0, b0, glu in probs[5:]:
+        g = dev(g0).clone(); gb = None if b0 is None else dev(b0).clone()
+        a, b = dev(dy), dev(x); keep += [a, b]
+        descs.append(ops.gemm_desc(a, b, g, trans_a=True, trans_b=False, accumulate=True, a_colsum=gb, glu_rows=glu)); outs.append((g, gb))
+    ops.reset_algo_log()
+    ops.gemm_group(descs)
+    assert ops.last_algo() == "mfma_tn_group256"
+    tol = (1e-4, 2e-4 * math.sqrt(R) / 4)
+    for (dy, x, g0, b0, glu), (g, gb) in zip(probs, outs):
+        ref = dy.double().T @ x.double()
+        refb = dy.double().sum(0)
+        if glu:      # row m of the interleaved product (4 rows of W1, 4 gate rows, ...) lands in the [W1 ; Wg] layout (include/afm_hip.h)
+            m = torch.arange(ref.shape[0])
+            dest = ((m >> 3) << 2) + (m & 3) + ((m >> 2) & 1) * glu
+            r2, b2 = torch.empty_like(ref), torch.empty_like(refb)
+            r2[dest], b2[dest] = ref, refb
+            ref, refb = r2, b2
+        close(g, g0.double() + ref, *tol)
+        if gb is not None:
+            close(gb, b0.double() + refb, *tol, "fused bias gradient")
+    close(sm_g, sm_g0.double() + sm_dy.double().T @ sm_x.double(), *tol)
+    close(nt_c, nt_a.double() @ nt_w.double().T, 1e-2 if dt == torch.bfloat16 else 2e-3, 0.2 if dt == torch.bfloat16 else 0.03)
+
+
+def test_gemm_group_matches_single_launches_at_the_step_size(ops):
+    """The c2 encoder layer's four weight gradients (131 072 tokens): grouped == one by one (fp32 atomics in another order)."""
+    R = 131072
+    shapes = [(512, 512), (1536, 512), (512, 2048), (2048, 512)]
+    gen = torch.Generator(device=DEV).manual_seed(3)
+    descs, outs, singles = [], [], []
+    for M, N in shapes:
+        dy = (torch.randn(R, M, device=DEV, generator=gen) * 0.05).half(); x = torch.randn(R, N, device=DEV, generator=gen).half()
+        g, gb = torch.zeros(M, N, device=DEV), torch.zeros(M, device=DEV)
+        g1, gb1 = torch.zeros(M, N, device=DEV), torch.zeros(M, device=DEV)
+        ops.gemm(dy, x, g1, trans_a=True, trans_b=False, accumulate=True, a_colsum=gb1)
+        descs.append(ops.gemm_desc(dy, x, g, trans_a=True, trans_b=False, accumulate=True, a_colsum=gb))
+        outs.append((g, gb, dy, x)); singles.append((g1, gb1))
+    ops.gemm_group(descs)
+    assert ops.last_algo() == "mfma_tn_group256"
+    for (g, gb, dy, x), (g1, gb1) in zip(outs, singles):
+        torch.testing.assert_close(g, g1, rtol=1e-4, atol=2e-3)
+        torch.testing.assert_close(gb, gb1, rtol=1e-4, atol=2e-3)
+    g, _, dy, x = outs[0]
+    close(g, dy.double().T.cpu() @ x.double().cpu(), 1e-4, 2e-4 * math.sqrt(R) / 4)
+
+
 def test_gemm_f16_generic_odd_shapes(ops):
     """Shapes outside the MFMA kernels (the SMILES vocabulary, patch sizes) run on the exact-fp32 FMA kernel with fp16 I/O."""
     M, N, K = 37, 26, 75
