@@ -420,7 +420,7 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd_dq_mfma(AttnM a, const e16*
   }
   dl += __shfl_xor(dl, 32, 64);
   const int64_t lrow = ((int64_t)b * a.H + hd) * a.Tq + qc;
-  if (q < a.Tq && h == 0) delta[lrow] = dl;
+  if (q < a.Tq && h == 0) delta[lrow] = -dl;      // the workspace holds -delta: the dK/dV kernel starts its dP accumulators from it as is
   const float L = lse[lrow];
   // Row constants as the initial accumulators (round 3): Q is pre-multiplied by scale * log2(e) and S^T starts at -lse (log2
   // units), so p = exp2(S') is one instruction; dO is pre-multiplied by the dropout scale and dP^T starts at -delta, so
@@ -575,7 +575,7 @@ __global__ __launch_bounds__(512, 2) void k_attn_bwd_dq_st(AttnM a, const e16* _
   }
   dl += __shfl_xor(dl, 32, 64);
   const int64_t lrow = ((int64_t)b * a.H + hd) * a.Tq + qc;
-  if (q < a.Tq && h == 0) delta[lrow] = dl;
+  if (q < a.Tq && h == 0) delta[lrow] = -dl;      // the workspace holds -delta: the dK/dV kernel starts its dP accumulators from it as is
   const float L = lse[lrow];
   const float nL2 = L == INFINITY ? -INFINITY : -L * 1.4426950408889634f;    // row constants as initial accumulators
   const float ndl = -dl;
@@ -739,8 +739,10 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd_dkv_mfma(AttnM a, const e16
                                                            const float* __restrict__ lse,
                                                            const float* __restrict__ delta,
                                                            e16* __restrict__ dK, e16* __restrict__ dV) {
-  // stage: Q row image, Q tr image, dO row image, dO tr image, lse[64], delta[64]; 2-stage LDS-DMA ring
-  constexpr int STAGE = 4 * KT * DH * 2 + 2 * KT * 4 + 4 * 256;   // + two 128-byte keep-bit blocks (the tile's two 32-query blocks) per wave
+  // stage: Q and dO as dual-use images (afm_attn_tiles.h: one image serves the row reads of S / dP and the transposed reads of
+  // dK / dV; round 3: half the LDS and half the LDS-DMA pieces of the row + transposed pair), lse[64], delta[64]; 2-stage ring
+  constexpr int IMG = KT * DH * 2;
+  constexpr int STAGE = 2 * IMG + 2 * KT * 4 + 4 * 256;   // + two 128-byte keep-bit blocks (the tile's two 32-query blocks) per wave
   constexpr int DS = 2;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   const int t = threadIdx.x, lane = t & 63, h = lane >> 5;
@@ -785,25 +787,24 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd_dkv_mfma(AttnM a, const e16
     const int row0 = qbeg + qt * KT;
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
-      dma_piece<false>(st, Qb, a.ldq, row0, a.Tq, w + 4 * u, lane);
-      dma_piece<true>(st + KT * DH * 2, Qb, a.ldq, row0, a.Tq, w + 4 * u, lane);
-      dma_piece<false>(st + 2 * KT * DH * 2, Db, a.ldo, row0, a.Tq, w + 4 * u, lane);
-      dma_piece<true>(st + 3 * KT * DH * 2, Db, a.ldo, row0, a.Tq, w + 4 * u, lane);
+      dma_piece_dual(st, Qb, a.ldq, row0, a.Tq, w + 4 * u, lane);
+      dma_piece_dual(st + IMG, Db, a.ldo, row0, a.Tq, w + 4 * u, lane);
     }
     if (w < 2) {   // lse / delta of the tile's 64 queries: one 4-byte piece each
       int qq = row0 + lane;
       qq = qq < a.Tq ? qq : a.Tq - 1;
       const float* src = (w == 0 ? lse : delta) + lbase + qq;
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                       (__attribute__((address_space(3))) void*)(st + 4 * KT * DH * 2 + w * KT * 4), 4, 0, 0);
+                                       (__attribute__((address_space(3))) void*)(st + 2 * IMG + w * KT * 4), 4, 0, 0);
     }
     if (DROP == DROP_BITS) {   // keep-bit blocks (query block of lanes 0-31 / 32-63, this wave's key block): 2 x 32 dwords
       // (bits_block returns a wave-uniform pointer: the second query block of lanes 32-63 is a per-lane offset on top of it)
       const uint32_t* src = (const uint32_t*)bits_block(a, b * a.H + hd, row0 >> 5, min(k0 >> 5, a.nk32 - 1)) + (lane >> 5) * (a.nk32 * 32) + (lane & 31);
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                       (__attribute__((address_space(3))) void*)(st + 4 * KT * DH * 2 + 2 * KT * 4 + w * 256), 4, 0, 0);
+                                       (__attribute__((address_space(3))) void*)(st + 2 * IMG + 2 * KT * 4 + w * 256), 4, 0, 0);
     }
   };
+  const unsigned t0 = tr_dual_t0(lane);
   if (ntiles > 0) issue(0);
   __builtin_assume(ntiles >= 1);   // see k_attn_fwd_mfma
   for (int qt = 0; qt < ntiles; ++qt) {
@@ -812,32 +813,31 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd_dkv_mfma(AttnM a, const e16
     __builtin_amdgcn_s_barrier();
     if (qt + 1 < ntiles) issue(qt + 1);
     const unsigned char* Qrow = lds + (qt % DS) * STAGE;
-    const unsigned char* Qtr = Qrow + KT * DH * 2;
-    const unsigned char* Drow = Qrow + 2 * KT * DH * 2;
-    const unsigned char* Dtr = Qrow + 3 * KT * DH * 2;
-    const float* Ls = (const float*)(Qrow + 4 * KT * DH * 2);   // lse (natural log units)
+    const unsigned char* Drow = Qrow + IMG;
+    const float* Ls = (const float*)(Qrow + 2 * IMG);   // lse (natural log units)
     const float* Ds = Ls + KT;
     const bool ragged = qb + KT > a.Tq;   // wave-uniform: tile holds rows past Tq (clamped duplicates)
     // wave-uniform skips: every query of the tile precedes this wave's keys / its 32 keys are all padding
     if ((a.causal && qb + KT - 1 < k0) || wave_all_masked) continue;
-    unsigned qa0, qa1, da0, da1;
-    tr_lane_addr(Qtr, lane, qa0, qa1);
-    tr_lane_addr(Dtr, lane, da0, da1);
+    // transposed-read address registers of this stage: base + (T0 ^ (delta << 4)) [^ 64 for the upper column half]
+    const unsigned sb = (unsigned)(uintptr_t)Qrow;
+    unsigned xa[4], xb[4];
+#pragma unroll
+    for (int dd_ = 0; dd_ < 4; ++dd_) { xa[dd_] = sb + (t0 ^ (dd_ << 4)); xb[dd_] = sb + (t0 ^ (dd_ << 4) ^ 64); }
 #pragma unroll
     for (int blk = 0; blk < 2; ++blk) {
       f32x16 s, dp;
-      float nd[16];                       // -delta of the register's query row
 #pragma unroll
       for (int g4 = 0; g4 < 4; ++g4) {    // initial accumulators: -lse[q] (log2 units; lse = +inf for an all-masked row) and -delta[q]
         const f32x4 Lq = *(const f32x4*)(Ls + 32 * blk + 8 * g4 + 4 * h) * -1.4426950408889634f;
-        const f32x4 Dq = *(const f32x4*)(Ds + 32 * blk + 8 * g4 + 4 * h);
+        const f32x4 Dq = *(const f32x4*)(Ds + 32 * blk + 8 * g4 + 4 * h);      // -delta (the dQ kernel stores it negated)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { s[4 * g4 + j] = Lq[j]; nd[4 * g4 + j] = -Dq[j]; dp[4 * g4 + j] = -Dq[j]; }
+        for (int j = 0; j < 4; ++j) { s[4 * g4 + j] = Lq[j]; dp[4 * g4 + j] = Dq[j]; }
       }
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
-        s = mfma32(frag_row(Qrow, 32 * blk, ks, lane), kf[ks], s);     // S'[q][key] = S log2(e) / sqrt(dh) - lse[q]
-        dp = mfma32(frag_row(Drow, 32 * blk, ks, lane), vf[ks], dp);   // scale dP[q][key] - delta[q]
+        s = mfma32(frag_row_dual(Qrow, 32 * blk, ks, lane), kf[ks], s);     // S'[q][key] = S log2(e) / sqrt(dh) - lse[q]
+        dp = mfma32(frag_row_dual(Drow, 32 * blk, ks, lane), vf[ks], dp);   // scale dP[q][key] - delta[q]
       }
       f32x16 pd;
       // Uniform conditions select whole loops (a branch per score would sit inside the unrolled body).
@@ -852,12 +852,17 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd_dkv_mfma(AttnM a, const e16
 #pragma unroll
       for (int r = 0; r < 16; ++r) pd[r] = fast_exp2(s[r]);     // masked keys: outputs zeroed at the end
       if (DROP == DROP_BITS) {   // one dword per lane and 32-query block: bit q = keep(query q, this lane's key)
-        const uint32_t word = ((const uint32_t*)(Qrow + 4 * KT * DH * 2 + 2 * KT * 4 + w * 256))[32 * blk + bits_word_of_key(lane & 31)] >> (4 * h);
+        const uint32_t word = ((const uint32_t*)(Qrow + 2 * IMG + 2 * KT * 4 + w * 256))[32 * blk + bits_word_of_key(lane & 31)] >> (4 * h);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const bool kp = (int)(word << (31 - ACC_ROW(r))) < 0;      // shift the row's bit into the sign: one shift, one compare
-          s[r] = pd[r] * (kp ? dp[r] : nd[r]);                       // dS = P (D dP - delta)
-          pd[r] = kp ? pd[r] : 0.f;                                  // dropped P for dV
+        for (int g4 = 0; g4 < 4; ++g4) {
+          const f32x4 nd = *(const f32x4*)(Ds + 32 * blk + 8 * g4 + 4 * h);   // -delta again, from LDS: 16 registers less to hold
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int r = 4 * g4 + j;
+            const bool kp = (int)(word << (31 - ACC_ROW(r))) < 0;      // shift the row's bit into the sign: one shift, one compare
+            s[r] = pd[r] * (kp ? dp[r] : nd[j]);                       // dS = P (D dP - delta)
+            pd[r] = kp ? pd[r] : 0.f;                                  // dropped P for dV
+          }
         }
       } else if (DROP == DROP_HASH) {
         // Dropout keep bits.  Element (q, key) has index i = (lbase+q)*Tk + key; with Tk even the two
@@ -873,7 +878,8 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd_dkv_mfma(AttnM a, const e16
           const uint32_t oth = (uint32_t)__builtin_amdgcn_mov_dpp((int)own, 0xB1, 0xF, 0xF, true);  // lane^1
           const uint32_t h0 = (lane & 1) ? oth : own, h1 = (lane & 1) ? own : oth;
           const bool k0 = ((h0 >> hshift) & 0xFFFFu) >= a.dd.thresh16, k1 = ((h1 >> hshift) & 0xFFFFu) >= a.dd.thresh16;
-          s[r] = pd[r] * (k0 ? dp[r] : nd[r]); s[r + 1] = pd[r + 1] * (k1 ? dp[r + 1] : nd[r + 1]);
+          const float nd0 = Ds[32 * blk + 8 * (r >> 2) + 4 * h + (r & 3)], nd1 = Ds[32 * blk + 8 * ((r + 1) >> 2) + 4 * h + ((r + 1) & 3)];
+          s[r] = pd[r] * (k0 ? dp[r] : nd0); s[r + 1] = pd[r + 1] * (k1 ? dp[r + 1] : nd1);
           pd[r] = k0 ? pd[r] : 0.f; pd[r + 1] = k1 ? pd[r + 1] : 0.f;
         }
       } else {
@@ -881,19 +887,31 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd_dkv_mfma(AttnM a, const e16
         for (int r = 0; r < 16; ++r) s[r] = pd[r] * dp[r];
       }
       {
-        const TrQuad d0 = tr_issue(da0, da1, 32 * blk), q0f = tr_issue(qa0, qa1, 32 * blk);
-        const TrQuad d1 = tr_issue(da0, da1, 32 * blk + 16), q1f = tr_issue(qa0, qa1, 32 * blk + 16);
+        // 16-bit operands first (the fp32 P / dS registers die here), then the transposed reads two quads at a time.
+        // (Forcing three workgroups per CU -- 168 registers, with or without the V fragments parked in LDS -- was measured:
+        // 1.02 .. 1.24 ms against 0.78 at two per CU; per product this kernel already runs at the dQ kernel's rate.)
         const e16x8 pf0 = cvt8(pd, 0), dsf0 = cvt8(s, 0), pf1 = cvt8(pd, 1), dsf1 = cvt8(s, 1);
-        tr_wait<8>();
-        dv[0] = mfma32(tr_join(d0.lo0, d0.hi0), pf0, dv[0]);
-        dv[1] = mfma32(tr_join(d0.lo1, d0.hi1), pf0, dv[1]);
-        dk[0] = mfma32(tr_join(q0f.lo0, q0f.hi0), dsf0, dk[0]);
-        dk[1] = mfma32(tr_join(q0f.lo1, q0f.hi1), dsf0, dk[1]);
-        tr_wait<0>();
-        dv[0] = mfma32(tr_join(d1.lo0, d1.hi0), pf1, dv[0]);
-        dv[1] = mfma32(tr_join(d1.lo1, d1.hi1), pf1, dv[1]);
-        dk[0] = mfma32(tr_join(q1f.lo0, q1f.hi0), dsf1, dk[0]);
-        dk[1] = mfma32(tr_join(q1f.lo1, q1f.hi1), dsf1, dk[1]);
+        constexpr int QO = 0, DO_ = IMG;
+#define AFM_DKV_QUADS(B32)                                                                                        \
+        {                                                                                                         \
+          const TrQuad d0 = tr_quad_dual<DO_ + B32, 0>(xa, xb), q0f = tr_quad_dual<QO + B32, 0>(xa, xb);          \
+          tr_wait<4>();                                                                                           \
+          dv[0] = mfma32(tr_join(d0.lo0, d0.hi0), pf0, dv[0]);                                                    \
+          dv[1] = mfma32(tr_join(d0.lo1, d0.hi1), pf0, dv[1]);                                                    \
+          const TrQuad d1 = tr_quad_dual<DO_ + B32, 1>(xa, xb);                                                   \
+          tr_wait<4>();                                                                                           \
+          dk[0] = mfma32(tr_join(q0f.lo0, q0f.hi0), dsf0, dk[0]);                                                 \
+          dk[1] = mfma32(tr_join(q0f.lo1, q0f.hi1), dsf0, dk[1]);                                                 \
+          const TrQuad q1f = tr_quad_dual<QO + B32, 1>(xa, xb);                                                   \
+          tr_wait<4>();                                                                                           \
+          dv[0] = mfma32(tr_join(d1.lo0, d1.hi0), pf1, dv[0]);                                                    \
+          dv[1] = mfma32(tr_join(d1.lo1, d1.hi1), pf1, dv[1]);                                                    \
+          tr_wait<0>();                                                                                           \
+          dk[0] = mfma32(tr_join(q1f.lo0, q1f.hi0), dsf1, dk[0]);                                                 \
+          dk[1] = mfma32(tr_join(q1f.lo1, q1f.hi1), dsf1, dk[1]);                                                 \
+        }
+        if (blk == 0) AFM_DKV_QUADS(0) else AFM_DKV_QUADS(32 * 128)
+#undef AFM_DKV_QUADS
       }
     }
   }
@@ -1021,7 +1039,7 @@ int AFM_E16_FN(afm_attn_bwd_mfma_try)(const afm_attn_shape* s, const void* Q, co
   else if (a.dd.thresh16 && a.bits) AFM_LAUNCH(k_attn_bwd_dq_mfma<DROP_BITS>, gq, dim3(256), shm_q, st, a, (const e16*)Q, (const e16*)K, (const e16*)V, (const e16*)O, (const e16*)dO, lse, delta, (e16*)dQ);
   else if (a.dd.thresh16) AFM_LAUNCH(k_attn_bwd_dq_mfma<DROP_HASH>, gq, dim3(256), shm_q, st, a, (const e16*)Q, (const e16*)K, (const e16*)V, (const e16*)O, (const e16*)dO, lse, delta, (e16*)dQ);
   else AFM_LAUNCH(k_attn_bwd_dq_mfma<DROP_NONE>, gq, dim3(256), shm_q, st, a, (const e16*)Q, (const e16*)K, (const e16*)V, (const e16*)O, (const e16*)dO, lse, delta, (e16*)dQ);
-  const int shm_k = 2 * (4 * KT * DH * 2 + 2 * KT * 4 + 4 * 256);
+  const int shm_k = 2 * (2 * KT * DH * 2 + 2 * KT * 4 + 4 * 256);     // two stages of {Q, dO dual-use images, lse, delta, keep bits}
   static AfmOncePerDevice attr_k;
   if (attr_k.need()) {
     (void)hipFuncSetAttribute((const void*)k_attn_bwd_dkv_mfma<DROP_HASH>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);

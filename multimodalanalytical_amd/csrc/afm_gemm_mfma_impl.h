@@ -371,9 +371,11 @@ enum { EPI_GENERIC = 0, EPI_PLAIN = 1, EPI_DROP = 2, EPI_GELU = 3, EPI_GELU_BWD 
 __device__ __forceinline__ float afm_drop32(const DropDev& d, uint32_t idx, float x) {
   return afm_lowbias32(idx ^ d.key) >= d.thresh ? x * d.scale : 0.f;
 }
-template <int WM, int EPI>
-__device__ __forceinline__ void epilogue_staged_bf16(const MfmaArgs& g, float* stg, const float* bias_lds,
-                                                     f32x4 (&acc)[4][WM], int mw, int nw, int lane) {
+// DROP_ON is the wave-uniform "this site drops" bit as a template argument: tested per element (`drop_on ? hash : 1`) it compiled
+// to a scalar branch around every element's hash chain, 128 basic blocks per wave tile that nothing could be scheduled across.
+template <int WM, int EPI, bool DROP_ON>
+__device__ __forceinline__ void epilogue_staged_e16(const MfmaArgs& g, float* stg, const float* bias_lds,
+                                                    f32x4 (&acc)[4][WM], int mw, int nw, int lane) {
   const int fr = lane & 15, fq = lane >> 4;
   const int c8 = (lane & 7) * 8, r8 = lane >> 3;
   const int n = nw + c8;
@@ -381,7 +383,7 @@ __device__ __forceinline__ void epilogue_staged_bf16(const MfmaArgs& g, float* s
   if constexpr (EPI == EPI_GLU || EPI == EPI_GLU_SG) {   // u / v biases of hidden units (n >> 1) .. +3, reference order [b1 ; bg]
     if (g.bias) { b0 = *(const f32x4*)(g.bias + (n >> 1)); b1 = *(const f32x4*)(g.bias + g.glu_f + (n >> 1)); }
   } else if (EPI != EPI_GELU_BWD && EPI != EPI_MUL && EPI != EPI_GLU_BWD && g.bias) { b0 = *(const f32x4*)(bias_lds + n); b1 = *(const f32x4*)(bias_lds + n + 4); }
-  const bool drop_on = g.dd.thresh != 0;   // wave-uniform
+  constexpr bool drop_on = DROP_ON;
   e16* const cbase = (e16*)g.C + (int64_t)(mw + r8) * g.ldc + n;
   e16* const pbase = (e16*)g.pre_act + (int64_t)(mw + r8) * g.ldc + n;
   const uint32_t dbase = (uint32_t)(mw + r8) * (uint32_t)g.N + (uint32_t)n;
@@ -478,7 +480,7 @@ __device__ __forceinline__ void epilogue_staged_bf16(const MfmaArgs& g, float* s
 #pragma unroll
           for (int k = 0; k < 8; ++k) x[k] *= afm_gelu_grad((float)u[k]);
         }
-      } else if (EPI == EPI_DROP || (EPI == EPI_GELU && drop_on)) {
+      } else if ((EPI == EPI_DROP || EPI == EPI_GELU) && drop_on) {
 #pragma unroll
         for (int k = 0; k < 8; ++k) x[k] = afm_drop32(g.dd, di + k, x[k]);
       }
@@ -486,6 +488,14 @@ __device__ __forceinline__ void epilogue_staged_bf16(const MfmaArgs& g, float* s
       *(e16x8*)(cbase + ro) = o;
     }
   }
+}
+
+template <int WM, int EPI>
+__device__ __forceinline__ void epilogue_staged_bf16(const MfmaArgs& g, float* stg, const float* bias_lds,
+                                                     f32x4 (&acc)[4][WM], int mw, int nw, int lane) {
+  constexpr bool drops = EPI == EPI_DROP || EPI == EPI_GELU || EPI == EPI_GELU_BWD || EPI == EPI_GELU_SG || EPI == EPI_GLU || EPI == EPI_GLU_SG;
+  if (drops && g.dd.thresh != 0) epilogue_staged_e16<WM, EPI, true>(g, stg, bias_lds, acc, mw, nw, lane);
+  else epilogue_staged_e16<WM, EPI, false>(g, stg, bias_lds, acc, mw, nw, lane);
 }
 
 // ------------------------------------------------------------------------------------------ NT, persistent ring

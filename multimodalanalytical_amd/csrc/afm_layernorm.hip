@@ -94,6 +94,19 @@ __device__ __forceinline__ void st8(bf16* p, const F8& v) {
   bf16x8 o = {(bf16)v.lo[0], (bf16)v.lo[1], (bf16)v.lo[2], (bf16)v.lo[3], (bf16)v.hi[0], (bf16)v.hi[1], (bf16)v.hi[2], (bf16)v.hi[3]};
   *(bf16x8*)p = o;
 }
+// streaming (write-once) forms: nontemporal stores keep the written lines from displacing the read streams in L2
+__device__ __forceinline__ void st8s(float* p, const F8& v) {
+  __builtin_nontemporal_store(v.lo, (f32x4*)p); __builtin_nontemporal_store(v.hi, (f32x4*)(p + 4));
+}
+__device__ __forceinline__ void st8s(f16* p, const F8& v, int) {
+  f16x8 o = {(f16)v.lo[0], (f16)v.lo[1], (f16)v.lo[2], (f16)v.lo[3], (f16)v.hi[0], (f16)v.hi[1], (f16)v.hi[2], (f16)v.hi[3]};
+  __builtin_nontemporal_store(o, (f16x8*)p);
+}
+__device__ __forceinline__ void st8s(bf16* p, const F8& v, int) {
+  bf16x8 o = {(bf16)v.lo[0], (bf16)v.lo[1], (bf16)v.lo[2], (bf16)v.lo[3], (bf16)v.hi[0], (bf16)v.hi[1], (bf16)v.hi[2], (bf16)v.hi[3]};
+  __builtin_nontemporal_store(o, (bf16x8*)p);
+}
+__device__ __forceinline__ void st8s(float* p, const F8& v, int) { st8s(p, v); }
 // the same with the lo-plane offset of the split-pair dtype as second argument (ignored by plain dtypes)
 __device__ __forceinline__ F8 ld8(const float* p, int) { return ld8(p); }
 __device__ __forceinline__ F8 ld8(const bf16* p, int) { return ld8(p); }
@@ -112,6 +125,7 @@ __device__ __forceinline__ void st8(x2* p, const F8& v, int lo) {
   *(bf16x8*)p = h;
   *(bf16x8*)((bf16*)p + lo) = l;
 }
+__device__ __forceinline__ void st8s(x2* p, const F8& v, int lo) { st8(p, v, lo); }
 __device__ __forceinline__ float hsum8(const F8& v) { return (v.lo[0] + v.lo[1]) + (v.lo[2] + v.lo[3]) + (v.hi[0] + v.hi[1]) + (v.hi[2] + v.hi[3]); }
 
 template <typename TY, typename TA, int NC>
@@ -130,23 +144,38 @@ __global__ __launch_bounds__(256) void k_ln_fwd_vec(const float* x, const float*
     const int c = (lane + 64 * i) * 8;
     if (c < d) { gm[i] = ld8(gamma + c); bt[i] = ld8(beta + c); }
   }
+  // software-pipelined over the wave's rows: the loads of row r + nwaves are issued before row r's two reductions, so a wave
+  // keeps two rows of reads in flight instead of one
+  F8 nx[NC], na[NC];
+  auto fetch = [&](int64_t r) {
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+      const int c = (lane + 64 * i) * 8;
+      if (c < d) {
+        nx[i] = ld8(x + r * (int64_t)d + c);
+        if (add) na[i] = ld8(add + r * (int64_t)(d * RowMul<TA>::v) + c, d);
+      }
+    }
+  };
+  if (wave < rows) fetch(wave);
   for (int64_t r = wave; r < rows; r += nwaves) {
-    F8 v[NC];
+    F8 v[NC], a[NC];
+#pragma unroll
+    for (int i = 0; i < NC; ++i) { v[i] = nx[i]; a[i] = na[i]; }
+    if (r + nwaves < rows) fetch(r + nwaves);
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < NC; ++i) {
       const int c = (lane + 64 * i) * 8;
       if (c < d) {
-        v[i] = ld8(x + r * (int64_t)d + c);
         if (add) {
-          F8 a = ld8(add + r * (int64_t)(d * RowMul<TA>::v) + c, d);
           if (adrop.thresh) {   // wave-uniform: dropout of the residual branch, index row-major in `add`
             const uint64_t base = (uint64_t)r * (uint64_t)d + (uint64_t)c;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) { a.lo[k] = afm_drop(adrop, base + k, a.lo[k]); a.hi[k] = afm_drop(adrop, base + 4 + k, a.hi[k]); }
+            for (int k = 0; k < 4; ++k) { a[i].lo[k] = afm_drop(adrop, base + k, a[i].lo[k]); a[i].hi[k] = afm_drop(adrop, base + 4 + k, a[i].hi[k]); }
           }
-          v[i].lo += a.lo; v[i].hi += a.hi;
-          st8(x_sum + r * (int64_t)d + c, v[i]);
+          v[i].lo += a[i].lo; v[i].hi += a[i].hi;
+          st8s(x_sum + r * (int64_t)d + c, v[i]);
         }
         s += hsum8(v[i]);
       }
@@ -172,7 +201,7 @@ __global__ __launch_bounds__(256) void k_ln_fwd_vec(const float* x, const float*
       const int c = (lane + 64 * i) * 8;
       if (c < d) {
         F8 o = {v[i].lo * rs * gm[i].lo + bt[i].lo, v[i].hi * rs * gm[i].hi + bt[i].hi};
-        st8(y + r * (int64_t)(d * RowMul<TY>::v) + c, o, d);
+        st8s(y + r * (int64_t)(d * RowMul<TY>::v) + c, o, d);
       }
     }
   }
