@@ -215,7 +215,7 @@ typedef struct {
   float scale;
   int32_t reserved;       /* afm_attn_bwd, bits 0-1: 0 = dQ and dK/dV kernels; 1 = dQ (+ delta) only; 2 = dK/dV only (delta from an
                              earlier call): lets bench.py / the profiler time the two backward kernels separately.
-                             bit 4 (16): the 8-wave staggered forms of the single-pass forward / dQ kernels (Tq >= 256), see DESIGN.md 4 */
+                             bit 5 (32): forward reads drop_bits (afm_attn_drop_bits_fill ran before); bit 4 (16): the 8-wave staggered forms of the single-pass forward / dQ kernels (Tq >= 256), see DESIGN.md 4 */
   const uint8_t* key_pad;
   afm_dropout drop;
   /* batch strides in ELEMENTS of Q, K, V, O (0 = dense: Tq*ldq, Tk*ldk, Tk*ldv, Tq*ldo).  Non-dense
@@ -232,6 +232,13 @@ typedef struct {
 } afm_attn_shape;
 int afm_attn_fwd(const afm_attn_shape* s, const void* Q, const void* K, const void* V, void* O,
                  float* lse, void* stream);
+/* afm_attn_drop_bits_fill: write s->drop_bits ahead of the forward -- the bits depend on (drop.seed, drop.site, B, H, Tq, Tk) only,
+ * so the caller can run this on another stream, under an HBM-bound kernel that precedes the attention block (the hash is pure
+ * vector work).  A forward whose shape carries reserved |= 32 then READS the tensor (one select per score) instead of hashing and
+ * writing it; results are bit-identical either way.  AFM_ERR_UNSUPPORTED where the single-pass MFMA kernels would not run the
+ * shape (the caller then leaves the flag off).  Reference: the dropout inside F.scaled_dot_product_attention / nn.MultiheadAttention
+ * (custom_modeling.py:117-160), whose mask torch also draws ahead of the product. */
+int afm_attn_drop_bits_fill(const afm_attn_shape* s, void* stream);
 int afm_attn_bwd(const afm_attn_shape* s, const void* Q, const void* K, const void* V, const void* O,
                  const void* dO, const float* lse, float* delta, void* dQ, void* dK, void* dV,
                  int32_t lddq, int32_t lddk, int32_t lddv, void* stream);

@@ -255,6 +255,19 @@ int afm_attn_bwd_mfma_try_f16(const afm_attn_shape* s, const void* Q, const void
                               const void* O, const void* dO, const float* lse, float* delta, void* dQ,
                               void* dK, void* dV, int lddq, int lddk, int lddv, hipStream_t st);
 
+int afm_attn_bits_fill_try(const afm_attn_shape* s, hipStream_t st);
+int afm_attn_bits_fill_try_f16(const afm_attn_shape* s, hipStream_t st);
+
+extern "C" int afm_attn_drop_bits_fill(const afm_attn_shape* s, void* stream) {
+  int r = check_shape(s);
+  if (r != AFM_OK) return r;
+  if (!s->drop_bits) return AFM_ERR_ARG;
+  if (s->algo == AFM_ALGO_GENERIC) return AFM_ERR_UNSUPPORTED;
+  if (s->dtype == AFM_F16) return afm_attn_bits_fill_try_f16(s, (hipStream_t)stream);
+  if (s->dtype == AFM_BF16) return afm_attn_bits_fill_try(s, (hipStream_t)stream);
+  return AFM_ERR_UNSUPPORTED;
+}
+
 extern "C" int afm_attn_fwd(const afm_attn_shape* s, const void* Q, const void* K, const void* V,
                             void* O, float* lse, void* stream) {
   int r = check_shape(s);

@@ -82,6 +82,12 @@ __global__ __launch_bounds__(256, 3) void k_attn_fwd_mfma(AttnM a, const e16* __
     const unsigned char* Vimg = Kimg + KT * DH * 2;
     const unsigned long long mword = maskw[kt];
     const unsigned long long pad = mword >> (4 * h);
+    KeepMasks km[2];
+    if (DROP == DROP_READ) {   // the tensor was filled beforehand (afm_attn_drop_bits_fill): 2 x 16 lane masks as SGPR pairs
+      const unsigned long long* bb = bits_block(a, b * a.H + hd, q0 >> 5, kb >> 5);
+      keep_masks_issue(km[0], bb);
+      keep_masks_issue(km[1], bb + 16);
+    }
     f32x16 s[2];
     const float init = m == -INFINITY ? 0.f : -m;      // S' = S - m: the running maximum is the chain's initial value
 #pragma unroll
@@ -139,6 +145,10 @@ __global__ __launch_bounds__(256, 3) void k_attn_fwd_mfma(AttnM a, const e16* __
       unsigned long long* bb = bits_block(a, b * a.H + hd, q0 >> 5, kb >> 5);
       drop_block_emit(a.dd, rowbase, kb, h, s[0], bb);
       drop_block_emit(a.dd, rowbase, kb + 32, h, s[1], bb + 16);
+    }
+    if (DROP == DROP_READ) {   // one select per score
+      drop_select_masks(s[0], km[0], 0.f);
+      drop_select_masks(s[1], km[1], 0.f);
     }
     // O^T += V^T P^T over the four 16-key slices, the V^T reads one slice ahead of the MFMAs
     unsigned va0, va1;
@@ -939,6 +949,25 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd_dkv_mfma(AttnM a, const e16
   }
 }
 
+// ------------------------------------------------------------------------------------------ keep-bit tensor, filled ahead
+// The forward's own dropout bits cost it a hash per score pair (0.53 vs 0.40 ms at the c2 shape).  The bits depend on nothing but
+// (seed, site, shape): this kernel writes the whole tensor -- one wave per (batch*head, 32-query block), all its 32-key blocks,
+// the forward kernel's indexing to the letter -- so it can run on another stream under the HBM-bound LayerNorm that precedes the
+// attention block, and the forward reads lane masks like the dQ kernel does (DROP_READ).
+__global__ __launch_bounds__(256) void k_attn_bits_fill(AttnM a) {
+  const int lane = threadIdx.x & 63, h = lane >> 5;
+  const int64_t wave = __builtin_amdgcn_readfirstlane((int)(((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6));
+  const int64_t nrows = (int64_t)a.B * a.H * a.nq32;
+  if (wave >= nrows) return;
+  const int bh = (int)(wave / a.nq32), qb32 = (int)(wave % a.nq32);
+  const int q = qb32 * 32 + (lane & 31);
+  const int qc = q < a.Tq ? q : a.Tq - 1;
+  const uint32_t rowbase = (uint32_t)(((uint64_t)bh * a.Tq + qc) * (uint64_t)a.Tk);
+  for (int kb32 = 0; kb32 < a.nk32; ++kb32)
+    bits_emit_rows<0>(a.dd, (rowbase + (uint32_t)(kb32 * 32 + 4 * h)) >> 1, bits_block(a, bh, qb32, kb32));
+  bits_flush();
+}
+
 }  // namespace AFM_E16_NS
 using namespace AFM_E16_NS;
 
@@ -994,10 +1023,22 @@ int AFM_E16_FN(afm_attn_fwd_mfma_try)(const afm_attn_shape* s, const void* Q, co
   const dim3 grid(((s->Tq + 127) / 128) * s->H * s->B);
   const int shm = RS * 2 * KT * DH * 2 + ((s->Tk + KT - 1) / KT) * 8;
   if (shm > 64 * 1024) return AFM_ERR_UNSUPPORTED;
-  if (a.dd.thresh16 && a.bits) AFM_LAUNCH(k_attn_fwd_mfma<DROP_BITS>, grid, dim3(256), shm, st, a, (const e16*)Q, (const e16*)K, (const e16*)V, (e16*)O, lse);
+  if (a.dd.thresh16 && a.bits && (s->reserved & 32)) AFM_LAUNCH(k_attn_fwd_mfma<DROP_READ>, grid, dim3(256), shm, st, a, (const e16*)Q, (const e16*)K, (const e16*)V, (e16*)O, lse);
+  else if (a.dd.thresh16 && a.bits) AFM_LAUNCH(k_attn_fwd_mfma<DROP_BITS>, grid, dim3(256), shm, st, a, (const e16*)Q, (const e16*)K, (const e16*)V, (e16*)O, lse);
   else if (a.dd.thresh16) AFM_LAUNCH(k_attn_fwd_mfma<DROP_HASH>, grid, dim3(256), shm, st, a, (const e16*)Q, (const e16*)K, (const e16*)V, (e16*)O, lse);
   else AFM_LAUNCH(k_attn_fwd_mfma<DROP_NONE>, grid, dim3(256), shm, st, a, (const e16*)Q, (const e16*)K, (const e16*)V, (e16*)O, lse);
   afm_set_last_algo("attn_mfma");
+  return AFM_OK;
+}
+
+// Fill the keep-bit tensor of `s` (the bits the forward kernel would have written).  Only the shape and the dropout stream matter.
+int AFM_E16_FN(afm_attn_bits_fill_try)(const afm_attn_shape* s, hipStream_t st) {
+  if (s->dtype != AFM_E16 || s->dh != DH || s->drop.p <= 0.f || !s->drop_bits) return AFM_ERR_UNSUPPORTED;
+  if (s->sqb || s->skb || s->svb || s->sob || (s->causal && s->Tq != s->Tk) || (s->Tk & 1)) return AFM_ERR_UNSUPPORTED;
+  if ((uint64_t)s->B * s->H * s->Tq * (uint64_t)s->Tk > 0xFFFFFFFFull) return AFM_ERR_UNSUPPORTED;
+  const AttnM a = make_m(s);
+  const int64_t nrows = (int64_t)a.B * a.H * a.nq32;
+  AFM_LAUNCH(k_attn_bits_fill, dim3((int)((nrows + 3) / 4)), dim3(256), 0, st, a);
   return AFM_OK;
 }
 

@@ -229,7 +229,7 @@ __device__ __forceinline__ TrQuad tr_quad_dual(const unsigned (&xa)[4], const un
 // ------------------------------------------------------------------------------------------ keep-bit tensor
 // DROP template values of the MFMA attention kernels: 0 no dropout, 1 hash per score pair, 2 keep-bit tensor (forward:
 // hash + emit the lane masks; backward: read them).
-enum { DROP_NONE = 0, DROP_HASH = 1, DROP_BITS = 2 };
+enum { DROP_NONE = 0, DROP_HASH = 1, DROP_BITS = 2, DROP_READ = 3 };   // (READ: forward only -- the tensor was filled beforehand, afm_attn_drop_bits_fill)
 __device__ __forceinline__ unsigned long long* bits_block(const AttnM& a, int bh, int qb32, int kb32) {
   // every index is wave-uniform; readfirstlane tells the compiler so (the masks then travel through SGPRs: s_load / s_store)
   unsigned long long* p = a.bits + (((int64_t)bh * a.nq32 + qb32) * a.nk32 + kb32) * 16;
@@ -255,6 +255,17 @@ __device__ __forceinline__ void drop_emit_rows(const DropDev& dd, uint32_t base,
 __device__ __forceinline__ void drop_block_emit(const DropDev& dd, uint32_t rowbase, int key0, int h, f32x16& x,
                                                 unsigned long long* blk) {
   drop_emit_rows<0>(dd, (rowbase + (uint32_t)(key0 + 4 * h)) >> 1, x, blk);
+}
+// the same 16 lane masks without a score block to apply them to (k_attn_bits_fill)
+template <int R>
+__device__ __forceinline__ void bits_emit_rows(const DropDev& dd, uint32_t base, unsigned long long* blk) {
+  if constexpr (R < 16) {
+    const uint32_t hsh = hash_pair32(dd, base + (uint32_t)(ACC_ROW(R) >> 1));
+    const unsigned long long m0 = __ballot((hsh & 0xFFFFu) >= dd.thresh16), m1 = __ballot((hsh >> 16) >= dd.thresh16);
+    asm volatile("s_store_dwordx2 %0, %1, %2" ::"s"(m0), "s"(blk), "n"(R * 8) : "memory");
+    asm volatile("s_store_dwordx2 %0, %1, %2" ::"s"(m1), "s"(blk), "n"(R * 8 + 8) : "memory");
+    bits_emit_rows<R + 2>(dd, base, blk);
+  }
 }
 __device__ __forceinline__ void bits_flush() {   // before the kernel ends: write the scalar cache back
   asm volatile("s_dcache_wb\n\ts_waitcnt lgkmcnt(0)" ::: "memory");

@@ -672,11 +672,8 @@ static int launch_nt_pring(MfmaArgs& g, hipStream_t st, int blocks_per_cu) {
   g.bias_in_lds = rows16 && modes_ok && ring * blocks_per_cu + bias_bytes * blocks_per_cu <= 160 * 1024 ? 1 : 0;
   const int shm = ring + (g.bias_in_lds ? bias_bytes : 0);
   auto kern = k_gemm_nt_pring<C_BF16, NWM, NWN, S, ABL, WM, EPI, EDGE>;
-  static int attr_shm = 0;   // per instantiation
-  if (shm > attr_shm) {
-    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_shm = 160 * 1024;
-  }
+  static AfmOncePerDevice attr_shm;   // per instantiation and per device (function attributes are per device)
+  if (attr_shm.need()) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   int grid = 256 * blocks_per_cu;                      // 256 CUs; multiple of 8 (XCD ranges)
   const int ntiles = g.tiles_m * g.tiles_n;
   if (grid > ((ntiles + 7) / 8) * 8) grid = ((ntiles + 7) / 8) * 8;

@@ -18,6 +18,7 @@ ABI_VERSION = 3
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_GELU_BWD, ACT_GELU_SAVE_GRAD, ACT_MUL_SAVED = 0, 1, 2, 3, 4, 5
 ACT_GLU, ACT_GLU_SAVE, ACT_GLU_BWD = 6, 7, 8
 ALGO_AUTO, ALGO_GENERIC, ALGO_MFMA = 0, 1, 2
+ERR_ARG, ERR_UNSUPPORTED, ERR_LAUNCH = -1, -2, -3
 
 
 class AfmError(RuntimeError):
@@ -99,6 +100,7 @@ _SIGS = {
     "afm_layernorm_bwd_ws_floats": (C.c_int64, [C.POINTER(LnShape)]),
     "afm_layernorm_bwd": (C.c_int, [C.POINTER(LnShape), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.POINTER(Dropout), _P]),
     "afm_attn_fwd": (C.c_int, [C.POINTER(AttnShape), _P, _P, _P, _P, _P, _P]),
+    "afm_attn_drop_bits_fill": (C.c_int, [C.POINTER(AttnShape), _P]),
     "afm_attn_bwd": (C.c_int, [C.POINTER(AttnShape), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
                                _I32, _I32, _I32, _P]),
     "afm_glu_fwd": (C.c_int, [_P, _P, _P, _I64, _I32, _I32, _I32, _I32, _I32, C.POINTER(Dropout), _P]),

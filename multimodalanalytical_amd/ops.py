@@ -266,6 +266,17 @@ def attn_set_drop_bits(s: AttnShape, bits) -> AttnShape:
     return s
 
 
+def attn_fill_drop_bits(s: AttnShape) -> bool:
+    """afm_attn_drop_bits_fill on the current stream; True (and the shape's "forward reads the bits" flag set) when the kernels
+    of this shape take the tensor, False otherwise (the forward then hashes and writes it as before)."""
+    r = L.load().afm_attn_drop_bits_fill(C.byref(s), _stream())
+    if r == L.ERR_UNSUPPORTED:
+        return False
+    L.check(r, "afm_attn_drop_bits_fill")
+    s.reserved |= 32
+    return True
+
+
 def _debug_sync(what, s):
     if _DEBUG_SYNC:
         print(f"[afm] {what} B={s.B} H={s.H} Tq={s.Tq} Tk={s.Tk} causal={s.causal} bits={bool(s.drop_bits)} ld=({s.ldq},{s.ldk},{s.ldv},{s.ldo})",

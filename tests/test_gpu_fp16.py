@@ -238,6 +238,62 @@ def test_attention_f16(ops, B, H, Tq, Tk, causal, pad, pdrop):
         assert err < 4e-3, (name, err)
 
 
+@pytest.mark.parametrize("dt", [H16, torch.bfloat16])
+@pytest.mark.parametrize("B,H,Tq,Tk,causal,pad", [(2, 2, 128, 256, False, True), (1, 2, 160, 160, True, True), (2, 2, 130, 520, False, True),
+                                                  (2, 2, 256, 56, False, False), (2, 8, 1024, 1024, False, False)])
+def test_attention_keep_bits_filled_ahead(ops, dt, B, H, Tq, Tk, causal, pad):
+    """afm_attn_drop_bits_fill + a forward that READS the keep-bit tensor == the forward that hashes and writes it, bit for bit
+    (output, lse, and the bits of every score inside the tensors); the backward takes either tensor."""
+    dh, D = 64, H * 64
+    q, k, v, key_pad = _attn_case(B, H, Tq, Tk, dh, causal, pad, seed=21)
+    qd, kd, vd = (dev(t.reshape(-1, D), dt) for t in (q, k, v))
+    kp = None if key_pad is None else dev(key_pad.to(torch.uint8))
+    dr = ops.drop(0.1, 777, 5)
+    nw = ops.attn_drop_bits_words(B, H, Tq, Tk)
+    outs = []
+    for ahead in (False, True):
+        o = torch.empty(B * Tq, D, dtype=dt, device=DEV); lse = torch.empty(B * H * Tq, device=DEV)
+        bits = torch.zeros(nw, dtype=torch.int64, device=DEV)
+        shp = ops.attn_shape(B, H, Tq, Tk, dh, dt, D, D, D, D, kp, causal, dr, algo=2)
+        ops.attn_set_drop_bits(shp, bits)
+        if ahead:
+            assert ops.attn_fill_drop_bits(shp) and shp.reserved & 32
+        ops.attn_fwd(shp, qd, kd, vd, o, lse)
+        assert ops.last_algo() == "attn_mfma"
+        outs.append((o, lse, bits, shp))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    # bits: 16 lane masks per (batch*head, 32-query block, 32-key block); compare the scores that exist (q < Tq, key < Tk), in the
+    # tiles the forward visits (it skips tiles above the causal diagonal and tiles of nothing but padding)
+    nq32, nk32 = ((Tq + 127) // 128) * 4, ((Tk + 63) // 64) * 2
+    b0 = outs[0][2].view(B * H, nq32, nk32, 16).cpu().numpy().view("uint64")
+    b1 = outs[1][2].view(B * H, nq32, nk32, 16).cpu().numpy().view("uint64")
+    import numpy as np
+    lane = np.arange(64)
+    checked = 0
+    for qb in range(nq32):
+        for kb in range(nk32):
+            if causal and (kb // 2) * 64 > qb * 32 + 31:      # the wave's first query block row ends before the tile's first key
+                continue
+            for r in range(16):
+                key = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+                qq = qb * 32 + (lane & 31)
+                valid = (qq < Tq) & (key < Tk)
+                m = np.uint64(sum(1 << int(i) for i in lane[valid]))
+                assert np.array_equal(b0[:, qb, kb, r] & m, b1[:, qb, kb, r] & m), (qb, kb, r)
+                checked += 1
+    assert checked > 0      # (no case here pads a whole 64-key tile: the emitting forward would have skipped it)
+    # the backward is indifferent to who wrote the tensor
+    do = dev(rnd(B * Tq, D, seed=9), dt)
+    grads = []
+    for o, lse, bits, shp in outs:
+        dq, dk, dv = (torch.empty(n, D, dtype=dt, device=DEV) for n in (B * Tq, B * Tk, B * Tk))
+        delta = torch.empty_like(lse)
+        ops.attn_bwd(shp, qd, kd, vd, o, do, lse, delta, dq, dk, dv, D, D, D)
+        grads.append((dq, dk, dv))
+    for a, b in zip(*grads):
+        assert torch.equal(a, b)
+
+
 # ------------------------------------------------------------------ LayerNorm, elementwise, loss
 @pytest.mark.parametrize("d", [64, 512, 768])
 def test_layernorm_f16(ops, d):

@@ -52,6 +52,10 @@ def main():
     s0, s1, s2 = shp(0), shp(1), shp(2)
     passes = 3 if a.mode == "bf16x3" else 1
     cases = []
+    if bits is not None and a.mode in ("fp16", "bf16"):     # keep bits filled ahead + the forward that reads them
+        sr = shp(0)
+        cases.append(("fill", lambda: ops.attn_fill_drop_bits(sr), 0))
+        cases.append(("fwdR", lambda: ops.attn_fwd(sr, q, k, v, o, lse), 2))
     if a.old:
         s8, s9 = shp(16), shp(17)
         cases.append(("fwd8", lambda: ops.attn_fwd(s8, q, k, v, o, lse), 2))
