@@ -20,8 +20,12 @@
 namespace AFM_E16_NS {
 
 // ------------------------------------------------------------------------------------------ forward
+#ifndef AFM_FWD_OCC
+#define AFM_FWD_OCC 4     // waves per SIMD the forward is compiled for: 4 = 128 registers (125 used, no scratch with the keep-bit tensor) and, with
+                          // RS = 2, four workgroups' LDS per CU: 0.50 -> 0.48 ms against 3 at RS = 3
+#endif
 template <int DROP>
-__global__ __launch_bounds__(256, 3) void k_attn_fwd_mfma(AttnM a, const e16* __restrict__ Q,
+__global__ __launch_bounds__(256, AFM_FWD_OCC) void k_attn_fwd_mfma(AttnM a, const e16* __restrict__ Q,
                                                           const e16* __restrict__ K,
                                                           const e16* __restrict__ V, e16* __restrict__ O,
                                                           float* __restrict__ lse) {

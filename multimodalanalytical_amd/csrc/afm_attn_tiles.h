@@ -132,7 +132,11 @@ __device__ __forceinline__ void drop_block(const DropDev& dd, uint32_t rowbase, 
 // flight (counted vmcnt + raw s_barrier, as in the GEMM ring): the tile loads no longer sit on the
 // critical path of each iteration.
 template <int N> __device__ __forceinline__ void attn_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
-#define RS 3
+// Two stages since round 3 (three before): with three, the dQ kernel's ring (3 images x 8 KB x RS) left room for only two
+// workgroups per CU although its registers allow three (0.59 -> 0.51 ms at the c2 shape), and the forward can run four (below).
+#ifndef RS
+#define RS 2
+#endif
 // one piece: rows [8*pi, 8*pi+8) of the 64-row tile starting at global row `row0` of `base`
 template <bool TR>
 __device__ __forceinline__ void dma_piece(unsigned char* img, const e16* base, int ld, int row0, int nrows,
