@@ -133,7 +133,8 @@ __global__ __launch_bounds__(256) void k_ln_fwd_vec(const float* x, const float*
                                                     const float* __restrict__ beta, TY* __restrict__ y,
                                                     float* __restrict__ mean, float* __restrict__ rstd,
                                                     int64_t rows, int d, float eps, const TA* __restrict__ add,
-                                                    float* x_sum, DropDev adrop) {
+                                                    float* x_sum, DropDev adrop, const float* __restrict__ pos,
+                                                    int64_t seg_len, int64_t seg_stride, int64_t off) {
   const int lane = threadIdx.x & 63;
   const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
@@ -144,37 +145,22 @@ __global__ __launch_bounds__(256) void k_ln_fwd_vec(const float* x, const float*
     const int c = (lane + 64 * i) * 8;
     if (c < d) { gm[i] = ld8(gamma + c); bt[i] = ld8(beta + c); }
   }
-  // software-pipelined over the wave's rows: the loads of row r + nwaves are issued before row r's two reductions, so a wave
-  // keeps two rows of reads in flight instead of one
-  F8 nx[NC], na[NC];
-  auto fetch = [&](int64_t r) {
-#pragma unroll
-    for (int i = 0; i < NC; ++i) {
-      const int c = (lane + 64 * i) * 8;
-      if (c < d) {
-        nx[i] = ld8(x + r * (int64_t)d + c);
-        if (add) na[i] = ld8(add + r * (int64_t)(d * RowMul<TA>::v) + c, d);
-      }
-    }
-  };
-  if (wave < rows) fetch(wave);
   for (int64_t r = wave; r < rows; r += nwaves) {
-    F8 v[NC], a[NC];
-#pragma unroll
-    for (int i = 0; i < NC; ++i) { v[i] = nx[i]; a[i] = na[i]; }
-    if (r + nwaves < rows) fetch(r + nwaves);
+    F8 v[NC];
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < NC; ++i) {
       const int c = (lane + 64 * i) * 8;
       if (c < d) {
+        v[i] = ld8(x + r * (int64_t)d + c);
         if (add) {
+          F8 a = ld8(add + r * (int64_t)(d * RowMul<TA>::v) + c, d);
           if (adrop.thresh) {   // wave-uniform: dropout of the residual branch, index row-major in `add`
             const uint64_t base = (uint64_t)r * (uint64_t)d + (uint64_t)c;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) { a[i].lo[k] = afm_drop(adrop, base + k, a[i].lo[k]); a[i].hi[k] = afm_drop(adrop, base + 4 + k, a[i].hi[k]); }
+            for (int k = 0; k < 4; ++k) { a.lo[k] = afm_drop(adrop, base + k, a.lo[k]); a.hi[k] = afm_drop(adrop, base + 4 + k, a.hi[k]); }
           }
-          v[i].lo += a[i].lo; v[i].hi += a[i].hi;
+          v[i].lo += a.lo; v[i].hi += a.hi;
           st8s(x_sum + r * (int64_t)d + c, v[i]);
         }
         s += hsum8(v[i]);
@@ -196,12 +182,16 @@ __global__ __launch_bounds__(256) void k_ln_fwd_vec(const float* x, const float*
       if (mean) mean[r] = mu;
       if (rstd) rstd[r] = rs;
     }
+    // the embedder's form: row r of modality rows lands in row orow of the concatenated sequence, plus its positional row
+    const int64_t orow = ln_out_row(r, seg_len, seg_stride, off);
+    const float* pr = pos ? pos + (seg_len == 0 ? r : off + (r % seg_len)) * (int64_t)d : nullptr;
 #pragma unroll
     for (int i = 0; i < NC; ++i) {
       const int c = (lane + 64 * i) * 8;
       if (c < d) {
         F8 o = {v[i].lo * rs * gm[i].lo + bt[i].lo, v[i].hi * rs * gm[i].hi + bt[i].hi};
-        st8s(y + r * (int64_t)(d * RowMul<TY>::v) + c, o, d);
+        if (pr) { const F8 pv = ld8(pr + c); o.lo += pv.lo; o.hi += pv.hi; }
+        st8s(y + orow * (int64_t)(d * RowMul<TY>::v) + c, o, d);
       }
     }
   }
@@ -214,7 +204,8 @@ __global__ __launch_bounds__(256) void k_ln_bwd_vec(const TY* __restrict__ dy, c
                                                     const float* __restrict__ rstd,
                                                     const float* __restrict__ dres, float* __restrict__ dx,
                                                     float* __restrict__ partial, int64_t rows, int d,
-                                                    TY* __restrict__ dx_drop, DropDev dd) {
+                                                    TY* __restrict__ dx_drop, DropDev dd, int64_t seg_len, int64_t seg_stride,
+                                                    int64_t off) {
   extern __shared__ __attribute__((aligned(16))) float sm[];  // [4 waves][2][d]
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -236,7 +227,7 @@ __global__ __launch_bounds__(256) void k_ln_bwd_vec(const TY* __restrict__ dy, c
     for (int i = 0; i < NC; ++i) {
       const int c = (lane + 64 * i) * 8;
       if (c < d) {
-        const F8 dyv = ld8(dy + r * (int64_t)(d * RowMul<TY>::v) + c, d);
+        const F8 dyv = ld8(dy + ln_out_row(r, seg_len, seg_stride, off) * (int64_t)(d * RowMul<TY>::v) + c, d);
         const F8 xv = ld8(x + r * (int64_t)d + c);
         xh[i] = {(xv.lo - mu) * rs, (xv.hi - mu) * rs};
         g[i] = {dyv.lo * gm[i].lo, dyv.hi * gm[i].hi};
@@ -289,9 +280,10 @@ extern "C" int afm_layernorm_fwd(const afm_ln_shape* s, const float* x, const fl
   if (g > 2048) g = 2048;
   hipStream_t st = (hipStream_t)stream;
   if (s->y_dtype < AFM_F32 || s->y_dtype > AFM_F16) return AFM_ERR_ARG;
-  if (s->seg_len == 0 && !pos && (s->d % 8) == 0 && s->d <= 2048 && s->rows >= 64) {   // vectorised path
+  if ((s->d % 8) == 0 && s->d <= 2048 && s->rows >= 64 && (!pos || ((uintptr_t)pos & 15) == 0)) {   // vectorised path
 #define LN_FV(TY, TA, NC) AFM_LAUNCH((k_ln_fwd_vec<TY, TA, NC>), dim3((int)g), dim3(256), 0, st, x, gamma, beta, (TY*)y, mean, \
-                                     rstd, s->rows, s->d, s->eps, (const TA*)add, x_sum, adrop)
+                                     rstd, s->rows, s->d, s->eps, (const TA*)add, x_sum, adrop, pos, s->seg_len,   \
+                                     s->out_seg_stride, s->out_off)
 #define LN_FV2(TY, TA) do { if (s->d <= 512) LN_FV(TY, TA, 1); else if (s->d <= 1024) LN_FV(TY, TA, 2); else LN_FV(TY, TA, 4); } while (0)
     // the branch added in front of the norm has the dtype of the mode's activations or fp32
     if (s->y_dtype == AFM_BF16) { if (add_dtype == AFM_BF16) LN_FV2(bf16, bf16); else if (add_dtype == AFM_F32) LN_FV2(bf16, float); else return AFM_ERR_UNSUPPORTED; }
@@ -432,9 +424,9 @@ extern "C" int afm_layernorm_bwd(const afm_ln_shape* s, const void* dy, const fl
   hipStream_t st = (hipStream_t)stream;
   const size_t shm = sizeof(float) * 8 * s->d;
   if (s->y_dtype < AFM_F32 || s->y_dtype > AFM_F16) return AFM_ERR_ARG;
-  if (s->seg_len == 0 && (s->d % 8) == 0 && s->d <= 2048 && s->rows >= 64) {   // vectorised path
+  if ((s->d % 8) == 0 && s->d <= 2048 && s->rows >= 64) {   // vectorised path (dy rows follow the embedder's placement, if any)
 #define LN_BV(TY, NC) AFM_LAUNCH((k_ln_bwd_vec<TY, NC>), dim3(g), dim3(256), shm, st, (const TY*)dy, x, gamma, mean, rstd, dres, dx, \
-                                 partial, s->rows, s->d, (TY*)dx_drop, dd)
+                                 partial, s->rows, s->d, (TY*)dx_drop, dd, s->seg_len, s->out_seg_stride, s->out_off)
 #define LN_BV2(TY) do { if (s->d <= 512) LN_BV(TY, 1); else if (s->d <= 1024) LN_BV(TY, 2); else LN_BV(TY, 4); } while (0)
     if (s->y_dtype == AFM_BF16) LN_BV2(bf16); else if (s->y_dtype == AFM_BF16X2) LN_BV2(x2); else if (s->y_dtype == AFM_F16) LN_BV2(f16); else LN_BV2(float);
 #undef LN_BV2

@@ -106,8 +106,8 @@ def test_gather_scatter(ops):
 # ------------------------------------------------------------------ LayerNorm
 @pytest.mark.parametrize("d", [48, 64, 512, 768])
 @pytest.mark.parametrize("ydt", [torch.float32, torch.bfloat16])
-def test_layernorm_fwd_bwd(ops, d, ydt):
-    B, Sm, S, off = 3, 5, 12, 4
+@pytest.mark.parametrize("B,Sm,S,off", [(3, 5, 12, 4), (8, 12, 20, 7)])     # 15 rows: row-per-wave scalar kernels; 96 rows: the vectorised ones
+def test_layernorm_fwd_bwd(ops, d, ydt, B, Sm, S, off):
     rows = B * Sm
     x = rnd(rows, d, seed=1) * 2 + 0.5
     gam, bet = 1 + 0.1 * rnd(d, seed=2), 0.1 * rnd(d, seed=3)
