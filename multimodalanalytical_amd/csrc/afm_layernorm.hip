@@ -2,8 +2,8 @@
 // wave owns a row, keeps it in registers (two-pass mean / centred variance like torch), and
 // writes the normalised row once.  The forward fuses the embedding's positional add and the
 // per-modality placement into the concatenated sequence; the backward fuses the residual
-// gradient add.  dgamma/dbeta: per-block register partials -> workspace -> one reduce kernel
-// (no atomics, deterministic).
+// gradient add.  dgamma/dbeta: per-block register partials -> LDS -> fp32 atomics (vectorised kernels) or a workspace and a
+// reduce kernel (row-per-wave scalar kernels).
 #include "afm_common.h"
 
 #define LN_MAXV 32  // up to d = 2048 held in registers (template NV = ceil(d/64) rounded up)
@@ -203,7 +203,7 @@ __global__ __launch_bounds__(256) void k_ln_bwd_vec(const TY* __restrict__ dy, c
                                                     const float* __restrict__ mean,
                                                     const float* __restrict__ rstd,
                                                     const float* __restrict__ dres, float* __restrict__ dx,
-                                                    float* __restrict__ partial, int64_t rows, int d,
+                                                    float* __restrict__ dgamma, float* __restrict__ dbeta, int64_t rows, int d,
                                                     TY* __restrict__ dx_drop, DropDev dd, int64_t seg_len, int64_t seg_stride,
                                                     int64_t off) {
   extern __shared__ __attribute__((aligned(16))) float sm[];  // [4 waves][2][d]
@@ -262,9 +262,13 @@ __global__ __launch_bounds__(256) void k_ln_bwd_vec(const TY* __restrict__ dy, c
     if (c < d) { st8(sm + (w * 2 + 0) * d + c, ag[i]); st8(sm + (w * 2 + 1) * d + c, ab[i]); }
   }
   __syncthreads();
-  float* pb = partial + (int64_t)blockIdx.x * 2 * d;
-  for (int j = threadIdx.x; j < 2 * d; j += blockDim.x)
-    pb[j] = sm[0 * 2 * d + j] + sm[1 * 2 * d + j] + sm[2 * 2 * d + j] + sm[3 * 2 * d + j];
+  // block sums straight into dgamma / dbeta: 2d fp32 atomics per block (4 MB over the launch, a few microseconds at the memory
+  // side's rate) instead of a workspace pass and a reduce kernel behind every LayerNorm backward
+  for (int j = threadIdx.x; j < 2 * d; j += blockDim.x) {
+    const float t = sm[0 * 2 * d + j] + sm[1 * 2 * d + j] + sm[2 * 2 * d + j] + sm[3 * 2 * d + j];
+    if (j < d) { if (dgamma) atomicAdd(dgamma + j, t); }
+    else if (dbeta) atomicAdd(dbeta + j - d, t);
+  }
 }
 
 extern "C" int afm_layernorm_fwd(const afm_ln_shape* s, const float* x, const float* gamma,
@@ -426,12 +430,11 @@ extern "C" int afm_layernorm_bwd(const afm_ln_shape* s, const void* dy, const fl
   if (s->y_dtype < AFM_F32 || s->y_dtype > AFM_F16) return AFM_ERR_ARG;
   if ((s->d % 8) == 0 && s->d <= 2048 && s->rows >= 64) {   // vectorised path (dy rows follow the embedder's placement, if any)
 #define LN_BV(TY, NC) AFM_LAUNCH((k_ln_bwd_vec<TY, NC>), dim3(g), dim3(256), shm, st, (const TY*)dy, x, gamma, mean, rstd, dres, dx, \
-                                 partial, s->rows, s->d, (TY*)dx_drop, dd, s->seg_len, s->out_seg_stride, s->out_off)
+                                 dgamma, dbeta, s->rows, s->d, (TY*)dx_drop, dd, s->seg_len, s->out_seg_stride, s->out_off)
 #define LN_BV2(TY) do { if (s->d <= 512) LN_BV(TY, 1); else if (s->d <= 1024) LN_BV(TY, 2); else LN_BV(TY, 4); } while (0)
     if (s->y_dtype == AFM_BF16) LN_BV2(bf16); else if (s->y_dtype == AFM_BF16X2) LN_BV2(x2); else if (s->y_dtype == AFM_F16) LN_BV2(f16); else LN_BV2(float);
 #undef LN_BV2
 #undef LN_BV
-    AFM_LAUNCH(k_ln_bwd_reduce, dim3((2 * s->d + 63) / 64, g >= 64 ? 16 : 1), dim3(256), 0, st, partial, dgamma, dbeta, g, s->d);
     return AFM_OK;
   }
 #define LN_BWD(NV)                                                                                   \

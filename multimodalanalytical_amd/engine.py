@@ -984,15 +984,23 @@ class Seq2SeqEngine:
             dx, dy = self._cross_attn_bwd(dx, dy, mem, dmem, p, sv, f"d{i}res", dkv_all, i)
             dx, dy = self._self_attn_bwd(dx, dy, p, sv, f"d{i - 1}res2" if i > 0 else None)
             self._grads_final_from(p + "self_attn.in_proj_weight")
+        dmem_c = None
         if dkv_all is not None:      # d(encoder output) = [dK|dV of every layer] @ [their projection weights], K = Ld*2d
-            if dmem is None:
-                dmem = torch.empty(B * S, d, dtype=torch.float32, device=self.dev)
-            ops.gemm(dkv_all, self._hb(self.wt_kv_all), dmem, trans_b=True, accumulate=had_init, algo=self.algo)
+            if dmem is None and self.single16:
+                # nothing to add to (no alignment head): the GEMM writes the 16-bit operand of the encoder's final LayerNorm
+                # backward itself, instead of an fp32 matrix and a cast kernel behind it (the same rounding, once)
+                dmem_c = self._empty_b(B * S, d)
+                ops.gemm(dkv_all, self._hb(self.wt_kv_all), dmem_c, trans_b=True, algo=self.algo)
+            else:
+                if dmem is None:
+                    dmem = torch.empty(B * S, d, dtype=torch.float32, device=self.dev)
+                ops.gemm(dkv_all, self._hb(self.wt_kv_all), dmem, trans_b=True, accumulate=had_init, algo=self.algo)
         self.embed_bwd(dx, saved["emb_dec"])
-        dmem_c = dmem
-        if self.lowp:
-            dmem_c = self._empty_b(B * S, d)
-            ops.dropout_cast(dmem, dmem_c)
+        if dmem_c is None:
+            dmem_c = dmem
+            if self.lowp:
+                dmem_c = self._empty_b(B * S, d)
+                ops.dropout_cast(dmem, dmem_c)
         dx, dy = self._ln_bwd(dmem_c, "encoder.norm.", saved, "enc_norm", dres=None, next_site=f"e{Le - 1}res2")
         for i in range(Le - 1, -1, -1):
             p, sv = f"encoder.layers.{i}.", saved["enc_layers"][i]
