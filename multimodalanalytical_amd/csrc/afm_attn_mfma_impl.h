@@ -904,7 +904,7 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd_dkv_mfma(AttnM a, const e16
         // 16-bit operands first (the fp32 P / dS registers die here), then the transposed reads two quads at a time.
         // (Forcing three workgroups per CU -- 168 registers, with or without the V fragments parked in LDS -- was measured:
         // 1.02 .. 1.24 ms against 0.78 at two per CU; per product this kernel already runs at the dQ kernel's rate.)
-        const e16x8 pf0 = cvt8(pd, 0), dsf0 = cvt8(s, 0), pf1 = cvt8(pd, 1), dsf1 = cvt8(s, 1);
+        const e16x8 pf0 = cvt8_pk(pd, 0), dsf0 = cvt8_pk(s, 0), pf1 = cvt8_pk(pd, 1), dsf1 = cvt8_pk(s, 1);
         constexpr int QO = 0, DO_ = IMG;
 #define AFM_DKV_QUADS(B32)                                                                                        \
         {                                                                                                         \
