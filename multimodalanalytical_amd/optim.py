@@ -59,6 +59,7 @@ class FusedAdamOneCycle:
         dev = engine.dev
         self.hyper = torch.zeros(10, dtype=torch.float32, device=dev)
         self.sumsq = torch.zeros(1, dtype=torch.float32, device=dev)
+        self.sumsq_ws = torch.empty(2048, dtype=torch.float32, device=dev)    # afm_sumsq's partial sums (AFM_SUMSQ_PARTIALS)
         # ring of pinned staging rows: the host may run several steps ahead of the stream
         self._host = torch.zeros(32, 10, dtype=torch.float32)
         if dev.type == "cuda":
@@ -88,7 +89,7 @@ class FusedAdamOneCycle:
             ev.record(torch.cuda.current_stream())
             self._row_events[slot] = ev
         self.sumsq.zero_()
-        ops.sumsq(ps.grad, self.sumsq)
+        ops.sumsq(ps.grad, self.sumsq, self.sumsq_ws)
         scaler = getattr(self.engine, "scaler", None)
         ops.adam_step(ps.flat, ps.grad, ps.exp_avg, ps.exp_avg_sq, self.hyper, self.sumsq, ps.bf16, zero_grad=True, scaler=scaler)
         if scaler is not None:   # fp16: GradScaler.update() on the device (a skipped step halves S, 2000 good ones double it)
