@@ -130,7 +130,26 @@ class BucketedReducer:
             import os
             native = self.is_cuda and os.environ.get("AFM_NATIVE_RCCL", "1") != "0" and dist.is_initialized() and \
                 dist.get_backend(group) == "nccl"
-        self.comm = NativeComm(group) if native else None
+        self.comm = None
+        if native:
+            # every rank tries; the ranks then agree (MIN over the process group) so that one rank's failure -- librccl not
+            # found, a communicator the fabric refuses -- moves ALL of them to torch.distributed's all-reduce instead of
+            # leaving the job with two exchange paths that never meet
+            comm, err = None, None
+            try:
+                comm = NativeComm(group)
+            except Exception as e:      # noqa: BLE001
+                err = e
+            ok = torch.tensor([1 if comm is not None else 0], dtype=torch.int32, device=flat.device)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
+            if int(ok.item()) == 1:
+                self.comm = comm
+            else:
+                if comm is not None:
+                    comm.close()
+                import warnings
+                warnings.warn(f"native RCCL communicator unavailable on at least one rank ({err!r} here): "
+                              "gradient buckets go through torch.distributed.all_reduce")
         if self.comm is not None and group is None:
             global _NATIVE
             _NATIVE = (self.comm, self.stream)

@@ -162,6 +162,23 @@ def test_rccl_reducer_on_a_one_rank_group_reproduces_the_plain_loop():
         y = T._native_mean(torch.tensor(2.25, device=DEV), *T._NATIVE)
         torch.cuda.synchronize()
         assert y.shape == () and float(y) == 2.25
+        # a communicator that cannot be built on some rank: the ranks agree and all take torch.distributed's all-reduce
+        loop.reducer.comm.close()
+        real = T.NativeComm
+
+        class Broken:
+            def __init__(self, group=None):
+                raise RuntimeError("no librccl here")
+        T.NativeComm = Broken
+        try:
+            with pytest.warns(UserWarning, match="native RCCL communicator unavailable"):
+                red = T.BucketedReducer(torch.ones(10000, device=DEV), bucket_elems=4096)
+        finally:
+            T.NativeComm = real
+        assert red.comm is None
+        red.ready(0); red.finish()
+        torch.cuda.synchronize()
+        assert float(red.flat.sum()) == 10000.0 and len(red.launched) == 3
     finally:
         dist.destroy_process_group()
 
