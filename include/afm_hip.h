@@ -315,8 +315,9 @@ int afm_align_loss(const float* z, const float* target, int32_t kind, int32_t B,
  * normalize != 0: min / max of the combined row, negatives clipped to 0, then
  * (x - min) / (max - min) (all zeros when max == min); zero-padded to out_len (1800 in the reference)
  * and rounded to fp32 (the collator's torch.Tensor(...)).  table (N x L) fp32, idx (n x c) int64.
- * PARITY UNPINNED: data/datasets.py imports omegaconf, which this image lacks, so no reference outputs
- * could be captured; the oracle restates the numpy arithmetic (oracle/afm_oracle.py:mix_spectra).
+ * Pinned: tests/golden/mixture.npz holds the records the reference's own two functions yield on a seeded table
+ * (oracle/make_mixture_goldens.py runs them out of the reference's source file; the module itself cannot be imported
+ * here: omegaconf is missing); the oracle's restatement and this kernel reproduce them bit for bit.
  * ---------------------------------------------------------------------------------------- */
 int afm_mix_spectra(const float* table, int64_t N, int32_t L, const int64_t* idx, int32_t n, int32_t c,
                     const double* ratio, int32_t normalize, int32_t out_len, float* out, void* stream);

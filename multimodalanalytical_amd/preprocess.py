@@ -167,6 +167,20 @@ class MixtureGenerator:
     def __iter__(self):
         dev = self.table.device
         keep = [i for i, r in enumerate(self.ratio) if r != 0]
+        if self.cfg.get("mixed", False):
+            # data/datasets.py:92-105: the table already holds mixtures; every row goes out once, normalised if asked, with a
+            # mock target (equal ratios only, as the reference insists)
+            nc = self.cfg["n_compounds"]
+            if self.ratio != [1 / nc] * nc:
+                raise ValueError("Mixed mode is only supported with equal compound ratios at the moment.")
+            rows = shard_rows(np.arange(self.table.shape[0], dtype=np.int64)[:, None], self.rank, self.world_size)
+            idx = torch.from_numpy(np.ascontiguousarray(rows)).to(dev)
+            L = self.table.shape[1]
+            ir = (ops.mix_spectra(self.table, idx, [1.0], normalize=True, out_len=L) if self.cfg.get("normalize", False)
+                  else self.table[idx[:, 0]])
+            yield {"indices": rows, "IR": ir, "compound": idx[:, 0], "IR_target": torch.zeros_like(ir),
+                   "Percentage": torch.full((len(rows),), 1 / nc, dtype=torch.float64)}
+            return
         for ri in mix_indices(self.table.shape[0], self.cfg, self.split, self.seed):
             ri = shard_rows(ri, self.rank, self.world_size)
             if len(ri) == 0:

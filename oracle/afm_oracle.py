@@ -532,7 +532,7 @@ def mix_indices(n_rows: int, mix_config: Dict[str, Any], split: str, seed: int =
 def mix_spectra(table, idx, ratio, normalize: bool, out_len: int = 1800):
     """The spectrum arithmetic of mix_spectra (data/datasets.py:118-126): np.average(rows, weights=ratio,
     axis=0) in float64, optional normalize_spectrum, zero padding to 1800; float32 at the end (the
-    collator's torch.Tensor).  PARITY UNPINNED (module not importable here: omegaconf missing)."""
+    collator's torch.Tensor).  Pinned to the reference's own records: tests/golden/mixture.npz (oracle/make_mixture_goldens.py)."""
     import numpy as np
     table = np.asarray(table)
     out = np.zeros((len(idx), out_len), dtype=np.float32)

@@ -731,7 +731,8 @@ def test_align_loss_and_gradient(ops, kind):
 @pytest.mark.parametrize("normalize", [False, True])
 @pytest.mark.parametrize("N,Ln,nc,ratio", [(40, 1800, 2, [0.5, 0.5]), (25, 1791, 3, [0.2, 0.5, 0.3]), (9, 300, 2, [0.9, 0.1])])
 def test_mix_spectra_vs_oracle(ops, normalize, N, Ln, nc, ratio):
-    """afm_mix_spectra vs the numpy restatement of data/datasets.py:49-56,118-126 (parity unpinned: see header)."""
+    """afm_mix_spectra vs the numpy restatement of data/datasets.py:49-56,118-126 (itself pinned to the reference's records:
+    tests/test_oracle_golden.py; the device generator against the same records: test_mixture_generator_vs_reference_records)."""
     from oracle import afm_oracle as Orc
     rng = np.random.default_rng(N + Ln)
     table = rng.standard_normal((N, Ln)).astype(np.float32)      # negatives exercise the clip-after-min/max quirk
@@ -759,6 +760,27 @@ def test_mixture_generator_records(ops):
         assert torch.equal(got["IR"].cpu(), torch.from_numpy(ref).repeat_interleave(2, dim=0))
         assert torch.equal(got["compound"].cpu(), torch.from_numpy(ri.reshape(-1)))
         assert torch.equal(got["IR_target"].cpu(), torch.from_numpy(table[ri.reshape(-1)]))
+
+
+def test_mixture_generator_vs_reference_records(ops):
+    """preprocess.MixtureGenerator (host index stream + afm_mix_spectra on the device) against the records the reference's own
+    mix_spectra produced on the same table (tests/golden/mixture.npz): order, mixed spectra bit for bit, targets, percentages;
+    incl. zero-weight compounds, spectra shorter than 1800 points and the `mixed` pass-through mode."""
+    from multimodalanalytical_amd.preprocess import MixtureGenerator
+    from tests.test_oracle_golden import _mixture_cases
+    seen = 0
+    for tag, cfg, g in _mixture_cases():
+        table = torch.from_numpy(g["table"]).to(DEV)
+        ir, comp, tgt, pct = [], [], [], []
+        for rnd_ in MixtureGenerator(table, cfg, "train", seed=3247):
+            ir.append(rnd_["IR"].cpu()); comp.append(rnd_["compound"].cpu()); tgt.append(rnd_["IR_target"].cpu()); pct.append(rnd_["Percentage"])
+        ir, comp, tgt, pct = torch.cat(ir), torch.cat(comp), torch.cat(tgt), torch.cat(pct)
+        assert torch.equal(comp, torch.from_numpy(g["smiles"])), tag
+        assert torch.equal(ir, torch.from_numpy(g["ir"].astype(np.float32))), tag
+        assert torch.equal(tgt.double(), torch.from_numpy(g["ir_target"])), tag
+        assert [float(x) for x in g["percentage"]] == pct.tolist(), tag
+        seen += 1
+    assert seen == 6
 
 
 @pytest.mark.parametrize("K,N,act", [(2, 512, 0), (5, 256, 1), (8, 64, 0)])

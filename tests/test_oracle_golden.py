@@ -140,3 +140,60 @@ def test_stock_torch_wiring_equals_oracle_and_reference_golden():
     for k in ("encoder.layers.0.linear1.weight", "decoder.layers.1.multihead_attn.out_proj.weight", "token_ff.weight"):
         g = dict(m.named_parameters())[k].grad
         torch.testing.assert_close(g, t["grad0"][k], rtol=2e-4, atol=2e-6, msg=lambda s: f"{k}: {s}")
+
+
+# ------------------------------------------------------------------ mixture generator (data/datasets.py:49-141)
+def _mixture_cases():
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "mixture.npz"))
+    for tag in z["cases"]:
+        tag = str(tag)
+        ratio = z[f"{tag}/cfg_ratio"].tolist() or None
+        cfg = dict(n_compounds=int(z[f"{tag}/cfg_n_compounds"]), compounds_ratio=ratio, parallel_samples=int(z[f"{tag}/cfg_parallel"]),
+                   train_max_n_samples=int(z[f"{tag}/cfg_max_n"]), normalize=bool(z[f"{tag}/cfg_normalize"]), mixed=bool(z[f"{tag}/cfg_mixed"]))
+        yield tag, cfg, {k.split("/", 1)[1]: z[k] for k in z.files if k.startswith(tag + "/")}
+    return
+
+
+def mixture_records_from(index_rounds, mix_fn, table, cfg):
+    """The reference's record stream rebuilt from an index stream and a mixing function: for every index row, one record per
+    compound with a non-zero ratio (data/datasets.py:107-141)."""
+    nc = cfg["n_compounds"]
+    ratio = cfg["compounds_ratio"] or [1 / nc] * nc
+    ir, tgt, smi, add, pct = [], [], [], [], []
+    for ri in index_rounds:
+        mixed = mix_fn(table, ri, ratio, cfg["normalize"])
+        for r, row in enumerate(ri):
+            for i in range(nc):
+                if ratio[i] == 0:
+                    continue
+                ir.append(mixed[r]); tgt.append(table[row[i]]); smi.append(int(row[i]))
+                add.append(",".join(f"S{row[j]}" for j in range(nc) if j != i)); pct.append(f"{ratio[i]}")
+    return np.asarray(ir), np.asarray(tgt), np.asarray(smi), np.asarray(add), np.asarray(pct)
+
+
+def test_mixture_generator_restatement_reproduces_the_reference_records():
+    """oracle.mix_indices + oracle.mix_spectra (and the package's host-side index stream) against the records the reference's own
+    mix_spectra / normalize_spectrum produced (tests/golden/mixture.npz, oracle/make_mixture_goldens.py): which rows are mixed, in
+    which order, the mixed spectrum to the bit (as the float32 the collator makes of it), targets, partner names, percentages."""
+    from multimodalanalytical_amd.preprocess import mix_indices
+    seen = 0
+    for tag, cfg, g in _mixture_cases():
+        table = g["table"]
+        if cfg["mixed"]:
+            want = np.asarray([O.normalize_spectrum(r.astype(np.float64).tolist()) if cfg["normalize"] else r for r in table])
+            assert np.array_equal(want, g["ir"]) and np.array_equal(g["smiles"], np.arange(len(table)))
+            assert not g["ir_target"].any() and set(g["percentage"]) == {f"{1 / cfg['n_compounds']}"}
+            continue
+        for stream in (O.mix_indices, mix_indices):
+            rounds = list(stream(len(table), cfg, "train", seed=3247))
+            ir, tgt, smi, add, pct = mixture_records_from(rounds, O.mix_spectra, table, cfg)
+            assert len(smi) == len(g["smiles"]) > 0, tag
+            assert np.array_equal(smi, g["smiles"]), tag
+            assert np.array_equal(ir, g["ir"].astype(np.float32)), tag
+            assert np.array_equal(tgt.astype(np.float64), g["ir_target"]), tag
+            assert list(add) == list(g["additional"]) and list(pct) == list(g["percentage"]), tag
+        seen += 1
+    assert seen >= 5
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "mixture.npz"))
+    for i in range(3):
+        assert O.normalize_spectrum(z[f"normalize/{i}/in"].tolist()) == z[f"normalize/{i}/out"].tolist()
