@@ -245,18 +245,19 @@ int afm_attn_bwd(const afm_attn_shape* s, const void* Q, const void* K, const vo
 
 /* ------------------------------------------------------------------------------------------
  * Elementwise pieces of the FFN and the residual branches.
- * afm_glu_fwd:  g = gelu(u) * (v ? v : 1), then dropout      (torch:nn/modules/transformer.py:980-982,
- *               custom_modeling.py:145-148,192-195; exact erf GELU)
- * afm_glu_bwd:  du = dg' * (v ? v : 1) * gelu'(u), dv = dg' * gelu(u), dg' = dropout'(dg)
+ * afm_glu_fwd:  g = act(u) * (v ? v : 1), then dropout       (torch:nn/modules/transformer.py:980-982,
+ *               custom_modeling.py:145-148,192-195); act = AFM_ACT_GELU (exact erf form, the reference default) or
+ *               AFM_ACT_RELU: config.activation_function goes straight to the torch layers (custom_modeling.py:127,174)
+ * afm_glu_bwd:  du = dg' * (v ? v : 1) * act'(u), dv = dg' * act(u), dg' = dropout'(dg)
  * afm_dropout_cast: y = dropout(x) cast to y_dtype  (backward of the dropout1/2/3 residual branches:
  *               the fp32 residual gradient masked and handed to the GEMMs in their operand dtype)
  * u, v, g are rows x f with row strides ld*, dtype `dtype`.
  * ---------------------------------------------------------------------------------------- */
 int afm_glu_fwd(const void* u, const void* v, void* g, int64_t rows, int32_t f, int32_t ldu,
-                int32_t ldv, int32_t ldg, int32_t dtype, const afm_dropout* drop, void* stream);
+                int32_t ldv, int32_t ldg, int32_t dtype, int32_t act, const afm_dropout* drop, void* stream);
 int afm_glu_bwd(const void* u, const void* v, const void* dg, void* du, void* dv, int64_t rows,
                 int32_t f, int32_t ldu, int32_t ldv, int32_t lddg, int32_t lddu, int32_t lddv,
-                int32_t dtype, const afm_dropout* drop, void* stream);
+                int32_t dtype, int32_t act, const afm_dropout* drop, void* stream);
 int afm_dropout_cast(const float* x, void* y, int64_t rows, int32_t n, int32_t ldx, int32_t ldy,
                      int32_t y_dtype, const afm_dropout* drop, void* stream);
 /* ReLU backward: dx[i] = act[i] > 0 ? dy[i] : 0 (fp32; dx may alias dy).  The hidden layers of the patch

@@ -111,7 +111,7 @@ extern "C" int afm_place_rows(const float* x, const float* pos, float* y, int64_
 }
 
 // ---------------------------------------------------------------- GLU / GELU
-template <typename T>
+template <typename T, bool RELU>
 __global__ void k_glu_fwd(const T* __restrict__ u, const T* __restrict__ v, T* __restrict__ g,
                           int64_t rows, int f, int ldu, int ldv, int ldg, DropDev dd) {
   const int64_t total = rows * (int64_t)f;
@@ -119,24 +119,30 @@ __global__ void k_glu_fwd(const T* __restrict__ u, const T* __restrict__ v, T* _
        i += (int64_t)gridDim.x * blockDim.x) {
     const int64_t r = i / f;
     const int c = (int)(i - r * f);
-    float x = afm_gelu(ld_rc(u, r, c, ldu));
+    const float uu = ld_rc(u, r, c, ldu);
+    float x = RELU ? fmaxf(uu, 0.f) : afm_gelu(uu);
     if (v) x *= ld_rc(v, r, c, ldv);
     st_rc(g, r, c, ldg, afm_drop(dd, (uint64_t)i, x));
   }
 }
 extern "C" int afm_glu_fwd(const void* u, const void* v, void* g, int64_t rows, int32_t f,
-                           int32_t ldu, int32_t ldv, int32_t ldg, int32_t dtype,
+                           int32_t ldu, int32_t ldv, int32_t ldg, int32_t dtype, int32_t act,
                            const afm_dropout* drop, void* stream) {
-  if (!u || !g || rows < 0 || f <= 0) return AFM_ERR_ARG;
+  if (!u || !g || rows < 0 || f <= 0 || (act != AFM_ACT_GELU && act != AFM_ACT_RELU)) return AFM_ERR_ARG;
   if (rows == 0) return AFM_OK;
   const DropDev dd = afm_make_drop(drop);
   const int grid = grid_for(rows * f, 256);
-  AFM_DT_SWITCH(dtype, T, AFM_LAUNCH(k_glu_fwd<T>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const T*)u,
-                                     (const T*)v, (T*)g, rows, f, ldu, ldv, ldg, dd));
+  if (act == AFM_ACT_RELU) {
+    AFM_DT_SWITCH(dtype, T, AFM_LAUNCH((k_glu_fwd<T, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const T*)u,
+                                       (const T*)v, (T*)g, rows, f, ldu, ldv, ldg, dd));
+  } else {
+    AFM_DT_SWITCH(dtype, T, AFM_LAUNCH((k_glu_fwd<T, false>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const T*)u,
+                                       (const T*)v, (T*)g, rows, f, ldu, ldv, ldg, dd));
+  }
   return AFM_OK;
 }
 
-template <typename T>
+template <typename T, bool RELU>
 __global__ void k_glu_bwd(const T* __restrict__ u, const T* __restrict__ v, const T* __restrict__ dg,
                           T* __restrict__ du, T* __restrict__ dv, int64_t rows, int f, int ldu,
                           int ldv, int lddg, int lddu, int lddv, DropDev dd) {
@@ -147,24 +153,29 @@ __global__ void k_glu_bwd(const T* __restrict__ u, const T* __restrict__ v, cons
     const int c = (int)(i - r * f);
     const float g = afm_drop(dd, (uint64_t)i, ld_rc(dg, r, c, lddg));
     const float uu = ld_rc(u, r, c, ldu);
-    float gu = g * afm_gelu_grad(uu);
+    float gu = RELU ? (uu > 0.f ? g : 0.f) : g * afm_gelu_grad(uu);      // (torch: relu'(0) = 0)
     if (v) {
       gu *= ld_rc(v, r, c, ldv);
-      st_rc(dv, r, c, lddv, g * afm_gelu(uu));
+      st_rc(dv, r, c, lddv, g * (RELU ? fmaxf(uu, 0.f) : afm_gelu(uu)));
     }
     st_rc(du, r, c, lddu, gu);
   }
 }
 extern "C" int afm_glu_bwd(const void* u, const void* v, const void* dg, void* du, void* dv,
                            int64_t rows, int32_t f, int32_t ldu, int32_t ldv, int32_t lddg,
-                           int32_t lddu, int32_t lddv, int32_t dtype, const afm_dropout* drop,
+                           int32_t lddu, int32_t lddv, int32_t dtype, int32_t act, const afm_dropout* drop,
                            void* stream) {
-  if (!u || !dg || !du || rows < 0 || f <= 0 || (v && !dv)) return AFM_ERR_ARG;
+  if (!u || !dg || !du || rows < 0 || f <= 0 || (v && !dv) || (act != AFM_ACT_GELU && act != AFM_ACT_RELU)) return AFM_ERR_ARG;
   if (rows == 0) return AFM_OK;
   const DropDev dd = afm_make_drop(drop);
   const int grid = grid_for(rows * f, 256);
-  AFM_DT_SWITCH(dtype, T, AFM_LAUNCH(k_glu_bwd<T>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const T*)u,
-                                     (const T*)v, (const T*)dg, (T*)du, (T*)dv, rows, f, ldu, ldv, lddg, lddu, lddv, dd));
+  if (act == AFM_ACT_RELU) {
+    AFM_DT_SWITCH(dtype, T, AFM_LAUNCH((k_glu_bwd<T, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const T*)u,
+                                       (const T*)v, (const T*)dg, (T*)du, (T*)dv, rows, f, ldu, ldv, lddg, lddu, lddv, dd));
+  } else {
+    AFM_DT_SWITCH(dtype, T, AFM_LAUNCH((k_glu_bwd<T, false>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const T*)u,
+                                       (const T*)v, (const T*)dg, (T*)du, (T*)dv, rows, f, ldu, ldv, lddg, lddu, lddv, dd));
+  }
   return AFM_OK;
 }
 

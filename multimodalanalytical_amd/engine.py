@@ -107,6 +107,12 @@ class Seq2SeqEngine:
         # (LayerNorm backward, casts) of the main stream on the same CUs
         self.wgrad_stream = torch.cuda.Stream(device=self.dev) if (self.dev.type == "cuda" and side_wgrad) else None
         self.group_wgrad = os.environ.get("AFM_GROUP_WGRAD", "1") != "0"    # (0: one launch per weight gradient, for A/B timing)
+        # layer options of configs/model/*.yaml beside the defaults: the reference's `post_layer_normalisation` IS torch's norm_first
+        # (custom_modeling.py:129,176: True = pre-LN, the shipped setting); `activation_function` goes to the torch layers as is
+        self.pre_ln = bool(cfg.get("post_layer_normalisation", True))
+        self.act = str(cfg.get("activation_function", "gelu"))
+        if self.act not in ("gelu", "relu"):
+            raise NotImplementedError(f"activation_function {self.act!r}: 'gelu' and 'relu' are built")
         # AFM_BITS_AHEAD=1: keep-bit tensors filled ahead of the attention forward on a side stream (_bits_ahead).  Built, verified
         # bit-identical and measured in round 3: the forward drops from 0.52 to 0.44 ms but the fill takes 0.195 ms and does not
         # hide under the LayerNorm (whose grid already holds every wave slot): step -1.1 %.  Off by default.
@@ -515,11 +521,13 @@ class Seq2SeqEngine:
                 setattr(sb, k, getattr(shp, k))
         return sb
 
-    def _self_attn_fwd(self, x, pend, p, B, T, H, key_pad, causal, saved, site):
-        """x + pend is the incoming stream; returns (stream, this block's branch to be added)."""
+    def _self_attn_fwd(self, x, pend, p, B, T, H, key_pad, causal, saved, site, h=None):
+        """x + pend is the incoming stream; returns (stream, this block's branch to be added).  Post-LN layers pass the block's
+        input operand `h` themselves (x, pend unused) and normalise AFTER the branch is added (_post_norm)."""
         d = self.d
         ahead = self._bits_ahead(B, H, T, T, site + "attn", saved)
-        h, x = self._ln_fwd(x, p + "norm1.", saved, "ln1", pend=pend)
+        if h is None:
+            h, x = self._ln_fwd(x, p + "norm1.", saved, "ln1", pend=pend)
         qkv = self._linear(h, p + "self_attn.in_proj_weight", 3 * d, d, bias_name=p + "self_attn.in_proj_bias")
         a = self._empty(B * T, d)
         lse = torch.empty(B * H * T, dtype=torch.float32, device=self.dev)
@@ -534,9 +542,10 @@ class Seq2SeqEngine:
             saved["sa"] = (h, qkv, a, lse, shp)
         return x, (br, self._drop(site + "res"))
 
-    def _self_attn_bwd(self, dx1, dy, p, saved, next_site):
+    def _self_attn_bwd(self, dx1, dy, p, saved, next_site, acc=None):
         """dx1: fp32 grad of the stream after this block; dy = dropout'(dx1) in the compute dtype.
-        Returns (grad of the stream before the block, its dropped copy for `next_site`)."""
+        Returns (grad of the stream before the block, its dropped copy for `next_site`).  Post-LN: `acc` is the fp32 gradient of
+        the block's input so far; the gradient through the block is accumulated into it by the last dgrad (nothing returned)."""
         d = self.d
         h, qkv, a, lse, shp = saved["sa"]
         rows = h.shape[0]
@@ -550,19 +559,29 @@ class Seq2SeqEngine:
         ops.attn_bwd(shp, qkv_b[:, :d], qkv_b[:, d:2 * d], qkv_b[:, 2 * d:], self._hb(a), da, lse, delta,
                      dqkv[:, :d], dqkv[:, d:2 * d], dqkv[:, 2 * d:], ldg, ldg, ldg)
         self._wgrad(dqkv, h, p + "self_attn.in_proj_weight", 3 * d, d, bias_name=p + "self_attn.in_proj_bias")
+        if acc is not None:
+            self._dgrad(dqkv, p + "self_attn.in_proj_weight", 3 * d, d, out=acc, accumulate=True)
+            return None
         dh = self._dgrad(dqkv, p + "self_attn.in_proj_weight", 3 * d, d)
         return self._ln_bwd(dh, p + "norm1.", saved, "ln1", dres=dx1, next_site=next_site)
 
-    def _ffn_fwd(self, x, pend, p, f, norm, saved, site):
+    def _ffn_fwd(self, x, pend, p, f, norm, saved, site, h=None):
         d, k = self.d, (2 if self.gated else 1)
-        h, x = self._ln_fwd(x, p + norm, saved, "lnf", pend=pend)
+        if h is None:
+            h, x = self._ln_fwd(x, p + norm, saved, "lnf", pend=pend)
+        rows = h.shape[0]
         dr = self._drop(site + "ffn")
-        g = self._empty(x.shape[0], f)
-        if self.gated and self._glu_fusable(x.shape[0], f):
+        g = self._empty(rows, f)
+        if self.act != "gelu":
+            # activation "relu": the projection, then act(u) [* v] + dropout in one elementwise kernel (afm_glu_fwd with its
+            # activation selector); the fused epilogues below are GELU's
+            uv = self._linear(h, p + "linear1.weight", k * f, d, bias_name=p + "linear1.bias")
+            ops.glu_fwd(uv[:, :f], uv[:, f:] if self.gated else None, g, dr, act=ACT_RELU)
+        elif self.gated and self._glu_fusable(rows, f):
             # gelu(u) * v (+ dropout) in the epilogue of ONE GEMM over the interleaved [W1 ; Wg]; with backward pending the
             # epilogue stores keep*scale*[gelu'(u) v | gelu(u)] instead of u and v, so the data-gradient epilogue of the
             # down-projection is two multiplies and afm_glu_fwd / afm_glu_bwd drop out of the step
-            uv = self._empty(x.shape[0], 2 * f) if saved is not None else None
+            uv = self._empty(rows, 2 * f) if saved is not None else None
             ops.gemm(h, self.w_glu[p + "linear1.weight"], g, trans_b=True,
                      bias=self.ps.vec_span(self.ps.flat, p + "linear1.bias", 0, 2 * f),
                      act=ACT_GLU_SAVE if saved is not None else ACT_GLU, pre_act=uv, dropout=dr, algo=self.algo, glu_rows=f,
@@ -574,8 +593,8 @@ class Seq2SeqEngine:
         else:   # GELU + inner dropout fused into the up-projection's epilogue.  With backward pending the epilogue
             # also stores keep * scale * gelu'(u) (same keep bits), so the dgrad epilogue is one multiply.
             # (whole 256 x 256 tiles only: other shapes keep u and the GELU' epilogue)
-            sg = saved is not None and self.lowp and x.shape[0] % 256 == 0 and f % 256 == 0
-            uv = self._empty(x.shape[0], f) if saved is not None else None
+            sg = saved is not None and self.lowp and rows % 256 == 0 and f % 256 == 0
+            uv = self._empty(rows, f) if saved is not None else None
             self._linear(h, p + "linear1.weight", f, d, out=g, bias_name=p + "linear1.bias",
                          act=ACT_GELU_SAVE_GRAD if sg else ACT_GELU, pre_act=uv, dropout=dr, sg_hi_only=self.mixed and sg)
             dr = (dr, sg)
@@ -584,12 +603,28 @@ class Seq2SeqEngine:
             saved["ffn"] = (h, uv, g, dr)
         return x, (br, self._drop(site + "res2"))
 
-    def _ffn_bwd(self, dx1, dy, p, f, norm, saved, next_site):
+    def _ffn_bwd(self, dx1, dy, p, f, norm, saved, next_site, acc=None):
         d, k = self.d, (2 if self.gated else 1)
         h, uv, g, dr = saved["ffn"]
         rows = h.shape[0]
         self._wgrad(dy, g, p + "linear2.weight", d, f, bias_name=p + "linear2.bias")
         duv = self._empty_b(rows, k * f, like=uv)
+
+        def tail(dh_from, weight_t=None):
+            """dh = duv W1 (or its interleaved transpose), then the block's LayerNorm backward -- or, post-LN, accumulated."""
+            if acc is not None:
+                if weight_t is not None:
+                    ops.gemm(dh_from, weight_t, acc, trans_b=True, accumulate=True, algo=self.algo)
+                else:
+                    self._dgrad(dh_from, p + "linear1.weight", k * f, d, out=acc, accumulate=True)
+                return None
+            if weight_t is not None:
+                dh = self._empty_b(rows, d)
+                ops.gemm(dh_from, weight_t, dh, trans_b=True, algo=self.algo)
+            else:
+                dh = self._dgrad(dh_from, p + "linear1.weight", k * f, d)
+            return self._ln_bwd(dh, p + norm, saved, "lnf", dres=dx1, next_site=next_site)
+
         if self.gated and isinstance(dr, tuple) and dr[1] == "glu":
             # [du | dv] (interleaved) = (dy W2) * saved factors in the dgrad epilogue; weight gradient rows de-interleaved by
             # the wgrad kernel into the reference's [linear1 ; gate] layout; dh through the interleaved transpose
@@ -598,25 +633,24 @@ class Seq2SeqEngine:
             gw = self.G(p + "linear1.weight", 2 * f, d)
             gb = self.ps.vec_span(self.ps.grad, p + "linear1.bias", 0, 2 * f)
             self._wgrad_raw(duv, self._hb(h), gw, gb, glu_rows=f)
-            dh = self._empty_b(rows, d)
-            ops.gemm(duv, self._hb(self.wt_glu[p + "linear1.weight"]), dh, trans_b=True, algo=self.algo)
-            return self._ln_bwd(dh, p + norm, saved, "lnf", dres=dx1, next_site=next_site)
-        if self.gated:
+            return tail(duv, self._hb(self.wt_glu[p + "linear1.weight"]))
+        if not isinstance(dr, tuple):     # unfused forms (gated shapes outside the fused kernels' domain; activation "relu")
             dg = self._dgrad(dy, p + "linear2.weight", d, f)
             uv_b = self._hb(uv)
-            ops.glu_bwd(uv_b[:, :f], uv_b[:, f:], dg, duv[:, :f], duv[:, f:], dr)
+            ops.glu_bwd(uv_b[:, :f], uv_b[:, f:] if self.gated else None, dg, duv[:, :f], duv[:, f:] if self.gated else None, dr,
+                        act=ACT_GELU if self.act == "gelu" else ACT_RELU)
         elif dr[1]:   # du = (dy W2) * [keep * scale * gelu'(u)] in the dgrad epilogue: dg never reaches HBM
             self._dgrad(dy, p + "linear2.weight", d, f, out=duv, act=ACT_MUL_SAVED, pre_act=uv)
         else:       # du = dropout'(dy W2) * gelu'(u)
             self._dgrad(dy, p + "linear2.weight", d, f, out=duv, act=ACT_GELU_BWD, pre_act=uv, dropout=dr[0])
         self._wgrad(duv, h, p + "linear1.weight", k * f, d, bias_name=p + "linear1.bias")
-        dh = self._dgrad(duv, p + "linear1.weight", k * f, d)
-        return self._ln_bwd(dh, p + norm, saved, "lnf", dres=dx1, next_site=next_site)
+        return tail(duv)
 
-    def _cross_attn_fwd(self, x, pend, mem, p, B, T, S, H, mem_pad, saved, site):
+    def _cross_attn_fwd(self, x, pend, mem, p, B, T, S, H, mem_pad, saved, site, h=None):
         d = self.d
         ahead = self._bits_ahead(B, H, T, S, site + "xattn", saved)
-        h, x = self._ln_fwd(x, p + "norm2.", saved, "ln2", pend=pend)
+        if h is None:
+            h, x = self._ln_fwd(x, p + "norm2.", saved, "ln2", pend=pend)
         w, bname = p + "multihead_attn.in_proj_weight", p + "multihead_attn.in_proj_bias"
         q = self._linear(h, w, 3 * d, d, 0, d, bias_name=bname)
         kv = self._linear(mem, w, 3 * d, d, d, 3 * d, bias_name=bname)
@@ -632,7 +666,7 @@ class Seq2SeqEngine:
             saved["ca"] = (h, q, kv, a, lse, shp)
         return x, (br, self._drop(site + "xres"))
 
-    def _cross_attn_bwd(self, dx1, dy, mem, dmem, p, saved, next_site, dkv_all=None, layer=0):
+    def _cross_attn_bwd(self, dx1, dy, mem, dmem, p, saved, next_site, dkv_all=None, layer=0, acc=None):
         d = self.d
         h, q, kv, a, lse, shp = saved["ca"]
         wo, bo = p + "multihead_attn.out_proj.weight", p + "multihead_attn.out_proj.bias"
@@ -651,10 +685,34 @@ class Seq2SeqEngine:
         w, bname = p + "multihead_attn.in_proj_weight", p + "multihead_attn.in_proj_bias"
         self._wgrad(dq, h, w, 3 * d, d, 0, d, bias_name=bname)
         self._wgrad(dkv, mem, w, 3 * d, d, d, 3 * d, bias_name=bname)
-        dh = self._dgrad(dq, w, 3 * d, d, 0, d)
         if dkv_all is None:
             self._dgrad(dkv, w, 3 * d, d, d, 3 * d, out=dmem, accumulate=True)  # fp32 accumulator
+        if acc is not None:
+            self._dgrad(dq, w, 3 * d, d, 0, d, out=acc, accumulate=True)
+            return None
+        dh = self._dgrad(dq, w, 3 * d, d, 0, d)
         return self._ln_bwd(dh, p + "norm2.", saved, "ln2", dres=dx1, next_site=next_site)
+
+    # ------------------------------------------------------------------ post-LN sublayers (post_layer_normalisation=False)
+    def _operand(self, x32, backward=False):
+        """The fp32 stream as a GEMM operand of the (forward / backward) compute dtype."""
+        if not self.lowp:
+            return x32
+        dst = self._empty_b(x32.shape[0], x32.shape[1]) if backward else self._empty(x32.shape[0], x32.shape[1])
+        return ops.convert(x32, dst)
+
+    def _post_norm(self, x, pend, prefix, saved, key):
+        """torch's norm_first=False sublayer tail (torch:nn/modules/transformer.py, `x = norm(x + dropout(block(x)))`): the new
+        stream in fp32 (one fused add + dropout + LayerNorm launch) and its operand copy for the next block."""
+        y, _ = self._ln_fwd(x, prefix, saved, key, out_dtype=torch.float32, pend=pend)
+        return y, self._operand(y)
+
+    def _post_sub_bwd(self, dY, prefix, saved, key, site, core):
+        """Backward of one post-LN sublayer y = LN(x + dropout(block(x))): dY (fp32) -> d(x + branch) through the LayerNorm,
+        its dropped copy drives the block's backward, which accumulates the gradient through the block onto the same buffer."""
+        dxs, ddrop = self._ln_bwd(dY, prefix, saved, key, dres=None, next_site=site)
+        core(self._operand(ddrop, backward=True), dxs)
+        return dxs
 
     # ------------------------------------------------------------------ whole model
     def encode(self, enc_inputs, attention_mask, saved: Optional[dict] = None):
@@ -674,11 +732,18 @@ class Seq2SeqEngine:
         key_pad = (attention_mask == 0).to(torch.uint8).contiguous()
         H = self.cfg["encoder_attention_heads"]
         layers, pend = [], None
+        h = None if self.pre_ln else self._operand(x)
         for i in range(self.cfg["encoder_layers"]):
             p = f"encoder.layers.{i}."
             sv = {} if saved is not None else None
-            x, pend = self._self_attn_fwd(x, pend, p, B, S, H, key_pad, False, sv, f"e{i}")
-            x, pend = self._ffn_fwd(x, pend, p, self.cfg["encoder_ffn_dim"], "norm2.", sv, f"e{i}")
+            if self.pre_ln:
+                x, pend = self._self_attn_fwd(x, pend, p, B, S, H, key_pad, False, sv, f"e{i}")
+                x, pend = self._ffn_fwd(x, pend, p, self.cfg["encoder_ffn_dim"], "norm2.", sv, f"e{i}")
+            else:   # x = norm1(x + sa(x)); x = norm2(x + ff(x))
+                _, br = self._self_attn_fwd(None, None, p, B, S, H, key_pad, False, sv, f"e{i}", h=h)
+                x, h = self._post_norm(x, br, p + "norm1.", sv, "ln1")
+                _, br = self._ffn_fwd(None, None, p, self.cfg["encoder_ffn_dim"], "norm2.", sv, f"e{i}", h=h)
+                x, h = self._post_norm(x, br, p + "norm2.", sv, "lnf")
             layers.append(sv)
         mem, _ = self._ln_fwd(x, "encoder.norm.", saved, "enc_norm", pend=pend)
         if saved is not None:
@@ -694,12 +759,21 @@ class Seq2SeqEngine:
             tgt_pad = (dec_attention_mask == 0).to(torch.uint8).contiguous()
         H = self.cfg["decoder_attention_heads"]
         layers, pend = [], None
+        h = None if self.pre_ln else self._operand(x)
         for i in range(self.cfg["decoder_layers"]):
             p = f"decoder.layers.{i}."
             sv = {} if saved is not None else None
-            x, pend = self._self_attn_fwd(x, pend, p, B, T, H, tgt_pad, True, sv, f"d{i}")
-            x, pend = self._cross_attn_fwd(x, pend, mem, p, B, T, S, H, mem_pad, sv, f"d{i}")
-            x, pend = self._ffn_fwd(x, pend, p, self.cfg["decoder_ffn_dim"], "norm3.", sv, f"d{i}")
+            if self.pre_ln:
+                x, pend = self._self_attn_fwd(x, pend, p, B, T, H, tgt_pad, True, sv, f"d{i}")
+                x, pend = self._cross_attn_fwd(x, pend, mem, p, B, T, S, H, mem_pad, sv, f"d{i}")
+                x, pend = self._ffn_fwd(x, pend, p, self.cfg["decoder_ffn_dim"], "norm3.", sv, f"d{i}")
+            else:
+                _, br = self._self_attn_fwd(None, None, p, B, T, H, tgt_pad, True, sv, f"d{i}", h=h)
+                x, h = self._post_norm(x, br, p + "norm1.", sv, "ln1")
+                _, br = self._cross_attn_fwd(None, None, mem, p, B, T, S, H, mem_pad, sv, f"d{i}", h=h)
+                x, h = self._post_norm(x, br, p + "norm2.", sv, "ln2")
+                _, br = self._ffn_fwd(None, None, p, self.cfg["decoder_ffn_dim"], "norm3.", sv, f"d{i}", h=h)
+                x, h = self._post_norm(x, br, p + "norm3.", sv, "lnf")
             layers.append(sv)
         hf, _ = self._ln_fwd(x, "decoder.norm.", saved, "dec_norm", pend=pend)
         logits = self._linear(hf, "token_ff.weight", self.V, self.d, out_dtype=torch.float32,
@@ -816,10 +890,13 @@ class Seq2SeqEngine:
         else:
             ops.place_rows(e, x, pos=st["pe"][t:t + 1], seg_len=1, out_seg_stride=1, out_off=0)
         pend = None
+        pre = self.pre_ln
+        h = None if pre else self._operand(x)
         for i in range(self.cfg["decoder_layers"]):
             p = f"decoder.layers.{i}."
             # causal self-attention over the cache: the new token sees positions 0..t
-            h, x = self._ln_fwd(x, p + "norm1.", None, None, pend=pend)
+            if pre:
+                h, x = self._ln_fwd(x, p + "norm1.", None, None, pend=pend)
             qkv = self._linear(h, p + "self_attn.in_proj_weight", 3 * d, d, bias_name=p + "self_attn.in_proj_bias")
             c2 = st["cache"][i]                      # (Bk*Tmax, 2d): append this position's K|V
             kv_new = qkv[:, d:]
@@ -834,7 +911,10 @@ class Seq2SeqEngine:
             pend = self._linear(a, p + "self_attn.out_proj.weight", d, d, bias_name=p + "self_attn.out_proj.bias",
                                 out_dtype=self.branch_dtype)
             # cross-attention: the k beams of a sample are k query rows against that sample's memory
-            h, x = self._ln_fwd(x, p + "norm2.", None, None, pend=pend)
+            if pre:
+                h, x = self._ln_fwd(x, p + "norm2.", None, None, pend=pend)
+            else:
+                x, h = self._post_norm(x, pend, p + "norm1.", None, None)
             w, bname = p + "multihead_attn.in_proj_weight", p + "multihead_attn.in_proj_bias"
             q = self._linear(h, w, 3 * d, d, 0, d, bias_name=bname)
             kv = st["xkv"][i]
@@ -845,7 +925,13 @@ class Seq2SeqEngine:
             ops.attn_fwd(shp, q, kv[:, :d], kv[:, d:], a, lse)
             pend = self._linear(a, p + "multihead_attn.out_proj.weight", d, d,
                                 bias_name=p + "multihead_attn.out_proj.bias", out_dtype=self.branch_dtype)
-            x, pend = self._ffn_fwd(x, pend, p, self.cfg["decoder_ffn_dim"], "norm3.", None, f"d{i}")
+            if pre:
+                x, pend = self._ffn_fwd(x, pend, p, self.cfg["decoder_ffn_dim"], "norm3.", None, f"d{i}")
+            else:
+                x, h = self._post_norm(x, pend, p + "norm2.", None, None)
+                _, pend = self._ffn_fwd(None, None, p, self.cfg["decoder_ffn_dim"], "norm3.", None, f"d{i}", h=h)
+                x, h = self._post_norm(x, pend, p + "norm3.", None, None)
+                pend = None
         hf, _ = self._ln_fwd(x, "decoder.norm.", None, None, pend=pend)
         logits = self._linear(hf, "token_ff.weight", self.V, d, out_dtype=torch.float32, bias_name="token_ff.bias")
         st["t"] = t + 1
@@ -951,6 +1037,46 @@ class Seq2SeqEngine:
                 self.micro_step += 1
         return out
 
+    def _backward_post(self, saved, dhf, mem):
+        """_backward for post-LN layers (post_layer_normalisation=False): every sublayer is y = LN(x + dropout(block(x))), so the
+        stream gradient passes THROUGH each LayerNorm (no bypass) and the block's input gradient is added behind it."""
+        d = self.d
+        B, S = saved["B"], saved["S"]
+        Ld, Le = self.cfg["decoder_layers"], self.cfg["encoder_layers"]
+        fd, fe = self.cfg["decoder_ffn_dim"], self.cfg["encoder_ffn_dim"]
+        dx, _ = self._ln_bwd(dhf, "decoder.norm.", saved, "dec_norm", dres=None, next_site=None)
+        dmem = saved.pop("dmem_init", None)
+        had_init = dmem is not None
+        if dmem is None and not self.lowp:
+            dmem = torch.zeros(B * S, d, dtype=torch.float32, device=self.dev)
+        dkv_all = self._empty_b(B * S, Ld * 2 * d) if self.lowp and Ld > 0 else None
+        for i in range(Ld - 1, -1, -1):
+            p, sv = f"decoder.layers.{i}.", saved["dec_layers"][i]
+            dx = self._post_sub_bwd(dx, p + "norm3.", sv, "lnf", f"d{i}res2",
+                                    lambda dy, acc: self._ffn_bwd(None, dy, p, fd, "norm3.", sv, None, acc=acc))
+            dx = self._post_sub_bwd(dx, p + "norm2.", sv, "ln2", f"d{i}xres",
+                                    lambda dy, acc: self._cross_attn_bwd(None, dy, mem, dmem, p, sv, None, dkv_all, i, acc=acc))
+            dx = self._post_sub_bwd(dx, p + "norm1.", sv, "ln1", f"d{i}res",
+                                    lambda dy, acc: self._self_attn_bwd(None, dy, p, sv, None, acc=acc))
+            self._grads_final_from(p + "self_attn.in_proj_weight")
+        if dkv_all is not None:
+            if dmem is None:
+                dmem = torch.empty(B * S, d, dtype=torch.float32, device=self.dev)
+            ops.gemm(dkv_all, self._hb(self.wt_kv_all), dmem, trans_b=True, accumulate=had_init, algo=self.algo)
+        self.embed_bwd(dx, saved["emb_dec"])
+        dx, _ = self._ln_bwd(self._operand(dmem, backward=True), "encoder.norm.", saved, "enc_norm", dres=None, next_site=None)
+        for i in range(Le - 1, -1, -1):
+            p, sv = f"encoder.layers.{i}.", saved["enc_layers"][i]
+            dx = self._post_sub_bwd(dx, p + "norm2.", sv, "lnf", f"e{i}res2",
+                                    lambda dy, acc: self._ffn_bwd(None, dy, p, fe, "norm2.", sv, None, acc=acc))
+            dx = self._post_sub_bwd(dx, p + "norm1.", sv, "ln1", f"e{i}res",
+                                    lambda dy, acc: self._self_attn_bwd(None, dy, p, sv, None, acc=acc))
+            self._grads_final_from(p + "self_attn.in_proj_weight")
+        self.embed_bwd(dx, saved["emb_enc"])
+        self._wgrad_flush()
+        if self.wgrad_stream is not None:
+            torch.cuda.current_stream().wait_stream(self.wgrad_stream)
+
     def _grads_final_from(self, first_name: str) -> None:
         """Parameters are laid out in forward order, so once a layer's backward is done every
         gradient from its first tensor to the end of the flat buffer is final."""
@@ -970,6 +1096,8 @@ class Seq2SeqEngine:
         self._wgrad(dlog, hf, "token_ff.weight", self.V, d, bias_name="token_ff.bias")
         dhf = self._dgrad(dlog, "token_ff.weight", self.V, d)
         Ld, Le = self.cfg["decoder_layers"], self.cfg["encoder_layers"]
+        if not self.pre_ln:
+            return self._backward_post(saved, dhf, mem)
         dx, dy = self._ln_bwd(dhf, "decoder.norm.", saved, "dec_norm", dres=None, next_site=f"d{Ld - 1}res2")
         dmem = saved.pop("dmem_init", None)     # alignment head's gradient w.r.t. the encoder output, if any
         had_init = dmem is not None

@@ -103,8 +103,8 @@ _SIGS = {
     "afm_attn_drop_bits_fill": (C.c_int, [C.POINTER(AttnShape), _P]),
     "afm_attn_bwd": (C.c_int, [C.POINTER(AttnShape), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
                                _I32, _I32, _I32, _P]),
-    "afm_glu_fwd": (C.c_int, [_P, _P, _P, _I64, _I32, _I32, _I32, _I32, _I32, C.POINTER(Dropout), _P]),
-    "afm_glu_bwd": (C.c_int, [_P, _P, _P, _P, _P, _I64, _I32, _I32, _I32, _I32, _I32, _I32, _I32,
+    "afm_glu_fwd": (C.c_int, [_P, _P, _P, _I64, _I32, _I32, _I32, _I32, _I32, _I32, C.POINTER(Dropout), _P]),
+    "afm_glu_bwd": (C.c_int, [_P, _P, _P, _P, _P, _I64, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32,
                               C.POINTER(Dropout), _P]),
     "afm_dropout_cast": (C.c_int, [_P, _P, _I64, _I32, _I32, _I32, _I32, C.POINTER(Dropout), _P]),
     "afm_colsum": (C.c_int, [_P, _P, _I64, _I32, _I32, _I32, _I32, _P]),

@@ -46,10 +46,8 @@ class CustomConfig:
         self.align_config = align_config
         self.is_encoder_decoder = True
         self.extra = kwargs
-        if activation_function != "gelu":
-            raise NotImplementedError("only the reference default activation 'gelu' is built")
-        if not post_layer_normalisation:
-            raise NotImplementedError("post-LN (post_layer_normalisation=False) is not on the reference's path")
+        if activation_function not in ("gelu", "relu"):     # torch's string options for the layers (custom_modeling.py:127,174)
+            raise NotImplementedError(f"activation_function {activation_function!r}: 'gelu' (reference default) and 'relu' are built")
 
     @classmethod
     def from_pretrained(cls, model_name: str, **kwargs):  # noqa: ARG003 - name kept, no hub lookup
@@ -58,7 +56,7 @@ class CustomConfig:
     def to_dict(self) -> Dict[str, Any]:
         keys = ("d_model max_position_embeddings encoder_layers encoder_attention_heads encoder_ffn_dim "
                 "decoder_layers decoder_attention_heads decoder_ffn_dim dropout gated_linear "
-                "positional_encoding_type").split()
+                "positional_encoding_type post_layer_normalisation activation_function").split()
         out = {k: getattr(self, k) for k in keys}
         if self.align_config is not None:
             out["align_config"] = dict(vars(self.align_config))

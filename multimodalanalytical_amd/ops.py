@@ -13,7 +13,7 @@ from typing import Optional
 import torch
 
 from . import lib as L
-from .lib import AFM_BF16, AFM_BF16X2, AFM_F16, AFM_F32, ALGO_AUTO, ACT_NONE, AttnShape, Dropout, GemmDesc, LnShape
+from .lib import AFM_BF16, AFM_BF16X2, AFM_F16, AFM_F32, ALGO_AUTO, ACT_GELU, ACT_NONE, ACT_RELU, AttnShape, Dropout, GemmDesc, LnShape
 from .x2 import X2
 
 _DT = {torch.float32: AFM_F32, torch.bfloat16: AFM_BF16, X2.dtype: AFM_BF16X2, torch.float16: AFM_F16}
@@ -301,18 +301,19 @@ def attn_bwd(s: AttnShape, q, k, v, o, do, lse, delta, dq, dk, dv, lddq, lddk, l
     _debug_sync("attn_bwd ok " + last_algo(), s)
 
 
-def glu_fwd(u, v, g, dropout: Dropout = NO_DROP):
+def glu_fwd(u, v, g, dropout: Dropout = NO_DROP, act: int = ACT_GELU):
+    """g = dropout(act(u) * (v if v is not None else 1)); act = ACT_GELU or ACT_RELU."""
     rows, f = g.shape
     L.check(L.load().afm_glu_fwd(_ptr(u), _ptr(v), _ptr(g), rows, f, _ld(u), _ld(v) if v is not None else 0,
-                                 _ld(g), _dt(g), C.byref(dropout), _stream()), "afm_glu_fwd")
+                                 _ld(g), _dt(g), int(act), C.byref(dropout), _stream()), "afm_glu_fwd")
     return g
 
 
-def glu_bwd(u, v, dg, du, dv, dropout: Dropout = NO_DROP):
+def glu_bwd(u, v, dg, du, dv, dropout: Dropout = NO_DROP, act: int = ACT_GELU):
     rows, f = dg.shape
     L.check(L.load().afm_glu_bwd(_ptr(u), _ptr(v), _ptr(dg), _ptr(du), _ptr(dv), rows, f, _ld(u),
                                  _ld(v) if v is not None else 0, _ld(dg), _ld(du),
-                                 _ld(dv) if dv is not None else 0, _dt(dg), C.byref(dropout), _stream()),
+                                 _ld(dv) if dv is not None else 0, _dt(dg), int(act), C.byref(dropout), _stream()),
             "afm_glu_bwd")
 
 

@@ -123,9 +123,13 @@ def mha(
     return linear(o, sd[prefix + "out_proj.weight"], sd[prefix + "out_proj.bias"])
 
 
-def ffn(x: torch.Tensor, sd: Dict[str, torch.Tensor], prefix: str, gated: bool) -> torch.Tensor:
-    """W2 gelu(W1 x) or W2 (gelu(W1 x) * (Wg x)) (custom_modeling.py:137-152,184-199)."""
-    h = gelu(linear(x, sd[prefix + "linear1.weight"], sd[prefix + "linear1.bias"]))
+def ffn(x: torch.Tensor, sd: Dict[str, torch.Tensor], prefix: str, gated: bool, act: str = "gelu") -> torch.Tensor:
+    """W2 act(W1 x) or W2 (act(W1 x) * (Wg x)) (custom_modeling.py:137-152,184-199); act = config.activation_function, which the
+    layers hand to torch (custom_modeling.py:127,174): "gelu" (exact erf form) or "relu"."""
+    u = linear(x, sd[prefix + "linear1.weight"], sd[prefix + "linear1.bias"])
+    if act not in ("gelu", "relu"):
+        raise ValueError(f"activation {act!r}")
+    h = gelu(u) if act == "gelu" else torch.clamp(u, min=0)
     if gated:
         h = h * linear(x, sd[prefix + "gate.weight"], sd[prefix + "gate.bias"])
     return linear(h, sd[prefix + "linear2.weight"], sd[prefix + "linear2.bias"])
@@ -196,12 +200,19 @@ def encoder(sd, cfg: Dict[str, Any], x: torch.Tensor, attention_mask: torch.Tens
     """CustomEncoder.forward (custom_modeling.py:220-243): N pre-LN layers + final LN.
     attention_mask (B,S) 1 = keep; gate is always applied (training semantics, A.1)."""
     key_pad = ~attention_mask.bool()
+    act = cfg.get("activation_function", "gelu")
+    pre = cfg.get("post_layer_normalisation", True)      # the reference's flag IS torch's norm_first (custom_modeling.py:129, A.2)
     for i in range(cfg["encoder_layers"]):
         p = f"encoder.layers.{i}."
-        h = layer_norm(x, sd[p + "norm1.weight"], sd[p + "norm1.bias"])
-        x = x + mha(h, h, sd, p + "self_attn.", cfg["encoder_attention_heads"], key_pad, False)
-        h = layer_norm(x, sd[p + "norm2.weight"], sd[p + "norm2.bias"])
-        x = x + ffn(h, sd, p, cfg["gated_linear"])
+        if pre:
+            h = layer_norm(x, sd[p + "norm1.weight"], sd[p + "norm1.bias"])
+            x = x + mha(h, h, sd, p + "self_attn.", cfg["encoder_attention_heads"], key_pad, False)
+            h = layer_norm(x, sd[p + "norm2.weight"], sd[p + "norm2.bias"])
+            x = x + ffn(h, sd, p, cfg["gated_linear"], act)
+        else:   # torch:nn/modules/transformer.py norm_first=False: x = norm1(x + sa(x)); x = norm2(x + ff(x))
+            x = layer_norm(x + mha(x, x, sd, p + "self_attn.", cfg["encoder_attention_heads"], key_pad, False),
+                           sd[p + "norm1.weight"], sd[p + "norm1.bias"])
+            x = layer_norm(x + ffn(x, sd, p, cfg["gated_linear"], act), sd[p + "norm2.weight"], sd[p + "norm2.bias"])
     return layer_norm(x, sd["encoder.norm.weight"], sd["encoder.norm.bias"])
 
 
@@ -214,14 +225,22 @@ def decoder(sd, cfg, data_config, target_modality: str, dec_ids: torch.Tensor,
               cfg["positional_encoding_type"])
     tgt_pad = None if dec_attention_mask is None else ~dec_attention_mask.bool()
     mem_pad = ~enc_attention_mask.bool()
+    act = cfg.get("activation_function", "gelu")
+    pre = cfg.get("post_layer_normalisation", True)
+    H = cfg["decoder_attention_heads"]
     for i in range(cfg["decoder_layers"]):
         p = f"decoder.layers.{i}."
-        h = layer_norm(x, sd[p + "norm1.weight"], sd[p + "norm1.bias"])
-        x = x + mha(h, h, sd, p + "self_attn.", cfg["decoder_attention_heads"], tgt_pad, True)
-        h = layer_norm(x, sd[p + "norm2.weight"], sd[p + "norm2.bias"])
-        x = x + mha(h, memory, sd, p + "multihead_attn.", cfg["decoder_attention_heads"], mem_pad, False)
-        h = layer_norm(x, sd[p + "norm3.weight"], sd[p + "norm3.bias"])
-        x = x + ffn(h, sd, p, cfg["gated_linear"])
+        if pre:
+            h = layer_norm(x, sd[p + "norm1.weight"], sd[p + "norm1.bias"])
+            x = x + mha(h, h, sd, p + "self_attn.", H, tgt_pad, True)
+            h = layer_norm(x, sd[p + "norm2.weight"], sd[p + "norm2.bias"])
+            x = x + mha(h, memory, sd, p + "multihead_attn.", H, mem_pad, False)
+            h = layer_norm(x, sd[p + "norm3.weight"], sd[p + "norm3.bias"])
+            x = x + ffn(h, sd, p, cfg["gated_linear"], act)
+        else:
+            x = layer_norm(x + mha(x, x, sd, p + "self_attn.", H, tgt_pad, True), sd[p + "norm1.weight"], sd[p + "norm1.bias"])
+            x = layer_norm(x + mha(x, memory, sd, p + "multihead_attn.", H, mem_pad, False), sd[p + "norm2.weight"], sd[p + "norm2.bias"])
+            x = layer_norm(x + ffn(x, sd, p, cfg["gated_linear"], act), sd[p + "norm3.weight"], sd[p + "norm3.bias"])
     return layer_norm(x, sd["decoder.norm.weight"], sd["decoder.norm.bias"])
 
 

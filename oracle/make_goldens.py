@@ -320,6 +320,7 @@ if __name__ == "__main__":
         dump_patches()
         sys.exit(0)
     ONLY_ALIGN = "--only-align" in sys.argv
+    ONLY_OPTIONS = "--only-options" in sys.argv     # round 3: post-LN / ReLU layer options (configs/model/*.yaml surface)
     dc_plain = {
         "Formula": {"type": "text", "vocab_size": 45, "pad_token_id": 0, "target": False},
         "IR": {"type": "1D_patches", "target": False,
@@ -329,6 +330,15 @@ if __name__ == "__main__":
     base = dict(d_model=64, max_position_embeddings=128, encoder_layers=2, decoder_layers=2,
                 encoder_attention_heads=4, decoder_attention_heads=4, encoder_ffn_dim=128,
                 decoder_ffn_dim=128, dropout=0.0)
+    if ONLY_OPTIONS:
+        # post_layer_normalisation=False is torch's norm_first=False (custom_modeling.py:129,176); activation_function goes straight to
+        # nn.TransformerEncoderLayer / DecoderLayer (custom_modeling.py:127,174)
+        dump_model_case("model_postln_relu", dict(base, post_layer_normalisation=False, activation_function="relu"), dc_plain,
+                        {"Formula": 10, "IR": 14}, T=20)
+        dump_model_case("model_postln_gated", dict(base, post_layer_normalisation=False, gated_linear=True,
+                                                   positional_encoding_type="learned"), dc_plain, {"Formula": 10, "IR": 14}, T=20,
+                        full_mask=None)
+        sys.exit(0)
     if not ONLY_ALIGN:
         dump_model_case("model_plain", dict(base), dc_plain, {"Formula": 10, "IR": 14}, T=20)
     dc_multi = {

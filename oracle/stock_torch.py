@@ -29,8 +29,8 @@ class StockSeq2Seq(nn.Module):
         if cfg.get("gated_linear"):
             raise NotImplementedError("the gated FFN is the reference's own block, not a stock torch layer")
         d = cfg["d_model"]
-        kw = dict(dropout=float(cfg.get("dropout", 0.0)), activation="gelu", batch_first=True, norm_first=True,
-                  layer_norm_eps=O.LN_EPS)
+        kw = dict(dropout=float(cfg.get("dropout", 0.0)), activation=cfg.get("activation_function", "gelu"), batch_first=True,
+                  norm_first=bool(cfg.get("post_layer_normalisation", True)), layer_norm_eps=O.LN_EPS)    # (custom_modeling.py:122-130)
         enc = nn.TransformerEncoderLayer(d, cfg["encoder_attention_heads"], cfg["encoder_ffn_dim"], **kw)
         dec = nn.TransformerDecoderLayer(d, cfg["decoder_attention_heads"], cfg["decoder_ffn_dim"], **kw)
         self.encoder = nn.TransformerEncoder(enc, cfg["encoder_layers"], norm=nn.LayerNorm(d, eps=O.LN_EPS),

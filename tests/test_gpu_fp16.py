@@ -386,7 +386,7 @@ def test_adam_with_loss_scaler_skips_and_rescales(ops):
 
 
 # ------------------------------------------------------------------ training loop vs the reference goldens
-@pytest.mark.parametrize("name", ["model_plain", "model_gated_learned"])
+@pytest.mark.parametrize("name", ["model_plain", "model_gated_learned", "model_postln_relu", "model_postln_gated"])
 def test_f16_two_optimizer_steps_vs_reference_golden(name):
     """fp16 forward / backward with the dynamic loss scale against the reference's fp32 run: logits inside the north star's 1e-3,
     parameters after two optimiser steps (accumulate 4, clip, AdamW + OneCycle) at fp16-gradient tolerance."""

@@ -12,7 +12,7 @@ from oracle import afm_oracle as O  # noqa: E402
 from tests import golden_io as G  # noqa: E402
 
 DEV = "cuda:0"
-CASES = ["model_plain", "model_gated_learned"]
+CASES = ["model_plain", "model_gated_learned", "model_postln_relu", "model_postln_gated"]      # (last two: post-LN layers, ReLU / gated GELU)
 ALIGN_CASES = ["model_align_mlp_mse", "model_align_conv_sid", "model_align_mlp_mae"]
 
 
@@ -109,6 +109,39 @@ def test_bf16_forward_backward_vs_reference_golden(name):
                 if e > 6e-2 and float(g.norm()) > 1e-4:
                     bad.append((k, e))
             assert not bad, bad
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+@pytest.mark.parametrize("name,opts", [("model_plain", dict(activation_function="relu")),
+                                       ("model_gated_learned", dict(activation_function="relu")),
+                                       ("model_gated_learned", dict(activation_function="relu", post_layer_normalisation=False)),
+                                       ("model_plain", dict(post_layer_normalisation=False))])
+def test_layer_option_combinations_vs_oracle_autograd(name, opts, dtype):
+    """The layer options the reference hands to torch (activation_function, post_layer_normalisation = norm_first) in the
+    combinations no reference golden covers: logits, loss and every parameter gradient against the oracle's autograd on the
+    golden's weights and batch (the oracle itself is pinned to the reference with both options: model_postln_relu / _gated)."""
+    t = G.load(name); cfg = dict(G.model_cfg(t["meta"]), **opts)
+    eng = _engine(t, cfg, dtype)
+    sd = {k: v.clone().double().requires_grad_(True) for k, v in t["sd"].items()}
+    enc, am, dec, dm, labels = O.batch_to_model_inputs(G.batch_of(t, 0), "Smiles")
+    ref = O.model_forward(sd, cfg, t["meta"]["data_config"], "Smiles", enc, am, dec, dm, labels)
+    ref["loss"].backward()
+    eng.ps.grad.zero_()
+    out = eng.forward(*_inputs(t, 0), backward=True)
+    tol = 1e-4 if dtype == torch.float32 else 2e-3
+    assert rel_err(out["logits"].cpu(), ref["logits"].detach()) < tol
+    assert abs(float(out["loss"]) - float(ref["loss"].detach())) < 10 * tol
+    scale = float(eng.scaler[0]) if getattr(eng, "scaler", None) is not None else 1.0
+    num = den = 0.0
+    for k, v in sd.items():
+        if v.grad is None or k.startswith("embedding.positional_encodings.pos_enc"):
+            continue
+        got = eng.ps.g(k).cpu().double() / scale
+        num += float((got - v.grad).pow(2).sum()); den += float(v.grad.pow(2).sum())
+        if dtype == torch.float32:
+            assert float((got - v.grad).abs().max()) <= 2e-4 * float(v.grad.abs().max()) + 2e-6, k
+    # (fp16: a ReLU whose pre-activation rounds across zero flips a whole gradient term; the real-shape bars are in test_gpu_shapes.py)
+    assert (num / den) ** 0.5 < (1e-4 if dtype == torch.float32 else 1.5e-2)
 
 
 def test_eval_forward_matches_train_forward_without_dropout():

@@ -224,22 +224,25 @@ def test_attention_all_masked_row_and_dropout(ops):
 
 # ------------------------------------------------------------------ GLU, dropout-cast, colsum, casts
 @pytest.mark.parametrize("gated", [False, True])
-def test_glu(ops, gated):
+@pytest.mark.parametrize("act", ["gelu", "relu"])
+def test_glu(ops, gated, act):
+    from multimodalanalytical_amd.lib import ACT_GELU, ACT_RELU
     rows, f = 37, 72
     uv = rnd(rows, 2 * f, seed=1)
     p, seed, site = 0.2, 42, 3
     g = torch.empty(rows, f, device=DEV)
     uvd = dev(uv)
-    ops.glu_fwd(uvd[:, :f], uvd[:, f:] if gated else None, g, ops.drop(p, seed, site))
+    code = ACT_GELU if act == "gelu" else ACT_RELU
+    ops.glu_fwd(uvd[:, :f], uvd[:, f:] if gated else None, g, ops.drop(p, seed, site), act=code)
     ur = uv[:, :f].double().requires_grad_(True); vr = uv[:, f:].double().requires_grad_(True)
     keep = torch.from_numpy(keep_mask(p, seed, site, rows * f)).view(rows, f)
-    ref = O.gelu(ur) * (vr if gated else 1.0) * keep / (1 - p)
+    ref = (O.gelu(ur) if act == "gelu" else torch.relu(ur)) * (vr if gated else 1.0) * keep / (1 - p)
     close(g, ref, 1e-5, 1e-6)
     dg = rnd(rows, f, seed=2)
     ref.backward(dg.double())
     duv = torch.zeros(rows, 2 * f, device=DEV)
     ops.glu_bwd(uvd[:, :f], uvd[:, f:] if gated else None, dev(dg), duv[:, :f], duv[:, f:] if gated else None,
-                ops.drop(p, seed, site))
+                ops.drop(p, seed, site), act=code)
     close(duv[:, :f], ur.grad, 1e-4, 1e-6)
     if gated:
         close(duv[:, f:], vr.grad, 1e-4, 1e-6)

@@ -9,7 +9,8 @@ import torch
 from oracle import afm_oracle as O
 from tests import golden_io as G
 
-CASES = ["model_plain", "model_gated_learned", "model_align_mlp_mse", "model_align_conv_sid", "model_align_mlp_mae"]
+CASES = ["model_plain", "model_gated_learned", "model_align_mlp_mse", "model_align_conv_sid", "model_align_mlp_mae",
+         "model_postln_relu", "model_postln_gated"]      # (the last two: post_layer_normalisation=False, activation "relu")
 
 
 @pytest.fixture(scope="module", params=CASES)
@@ -121,11 +122,13 @@ def test_patch_preprocessor_oracle_matches_reference_bit_exact():
         assert np.array_equal(m, g[f"{name}/mask"]), name
 
 
-def test_stock_torch_wiring_equals_oracle_and_reference_golden():
+@pytest.mark.parametrize("name", ["model_plain", "model_postln_relu"])
+def test_stock_torch_wiring_equals_oracle_and_reference_golden(name):
     """oracle/stock_torch.py (nn.TransformerEncoder / Decoder as the reference wires them, SURVEY 8c item 2: the
-    timed "reference PyTorch CPU path" of bench.py) reproduces the reference's own logits / loss / gradients."""
+    timed "reference PyTorch CPU path" of bench.py) reproduces the reference's own logits / loss / gradients
+    (also with the post-LN / ReLU layer options)."""
     from oracle import stock_torch as ST
-    t = G.load("model_plain"); cfg = dict(G.model_cfg(t["meta"]), dropout=0.0)
+    t = G.load(name); cfg = dict(G.model_cfg(t["meta"]), dropout=0.0)
     dc = t["meta"]["data_config"]
     m = ST.StockSeq2Seq(cfg, dc["Smiles"]["vocab_size"])
     m.load_oracle_state(t["sd"])
