@@ -215,7 +215,9 @@ typedef struct {
   float scale;
   int32_t reserved;       /* afm_attn_bwd, bits 0-1: 0 = dQ and dK/dV kernels; 1 = dQ (+ delta) only; 2 = dK/dV only (delta from an
                              earlier call): lets bench.py / the profiler time the two backward kernels separately.
-                             bit 5 (32): forward reads drop_bits (afm_attn_drop_bits_fill ran before); bit 4 (16): the 8-wave staggered forms of the single-pass forward / dQ kernels (Tq >= 256), see DESIGN.md 4 */
+                             bit 6 (64): afm_attn_bwd, self-attention (Tq == Tk, key_pad given): the caller vouches that dO is zero in the query rows
+                             key_pad marks (a training step's padded positions); the single-pass kernels then skip them -- dQ rows stay
+                             zero, dK / dV lose exact zeros.  bit 5 (32): forward reads drop_bits (afm_attn_drop_bits_fill ran before); bit 4 (16): the 8-wave staggered forms of the single-pass forward / dQ kernels (Tq >= 256), see DESIGN.md 4 */
   const uint8_t* key_pad;
   afm_dropout drop;
   /* batch strides in ELEMENTS of Q, K, V, O (0 = dense: Tq*ldq, Tk*ldk, Tk*ldv, Tq*ldo).  Non-dense

@@ -56,9 +56,14 @@ __global__ __launch_bounds__(256, AFM_FWD_OCC) void k_attn_fwd_mfma(AttnM a, con
     }
   }
   build_mask_words(maskw, a.key_pad, b, a.Tk, ntiles, w, lane);
+  int* const tl = (int*)(maskw + (a.Tk + KT - 1) / KT) + 1;      // key tiles with at least one real key (build_tile_list)
+  __syncthreads();
+  build_tile_list(tl, a.key_pad ? maskw : nullptr, 0, ntiles, w, lane);
   __syncthreads();   // plain loads above are retired here (vmcnt(0)), before any LDS-DMA is in flight
-  auto issue = [&](int kt) {
-    unsigned char* st = lds + (kt % RS) * STAGE;
+  const int nlive = __builtin_amdgcn_readfirstlane(tl[-1]);
+  auto issue = [&](int j) {
+    unsigned char* st = lds + (j % RS) * STAGE;
+    const int kt = tl[j];
     dma_piece<false>(st, Kb, a.ldk, kt * KT, a.Tk, w, lane);
     dma_piece<false>(st, Kb, a.ldk, kt * KT, a.Tk, w + 4, lane);
     dma_piece<true>(st + KT * DH * 2, Vb, a.ldv, kt * KT, a.Tk, w, lane);
@@ -71,18 +76,19 @@ __global__ __launch_bounds__(256, AFM_FWD_OCC) void k_attn_fwd_mfma(AttnM a, con
   const uint32_t rowbase = (uint32_t)(((uint64_t)(b * a.H + hd) * a.Tq + qc) * (uint64_t)a.Tk);
 #pragma unroll
   for (int s = 0; s < RS - 1; ++s)
-    if (s < ntiles) issue(s);
-  // ntiles >= 1 always (Tk >= 1): without the guard the loop's exit block has one predecessor and the
+    if (s < nlive) issue(s);
+  // nlive >= 1 always (build_tile_list): without the guard the loop's exit block has one predecessor and the
   // accumulators need no phi copies at the latch (they cost 32-64 v_mov per tile)
-  __builtin_assume(ntiles >= 1);
-  for (int kt = 0; kt < ntiles; ++kt) {
+  __builtin_assume(nlive >= 1);
+  for (int j = 0; j < nlive; ++j) {
+    const int kt = __builtin_amdgcn_readfirstlane(tl[j]);
     const int kb = kt * KT;
-    if (ntiles - 1 - kt >= RS - 2) attn_wait_vmcnt<4 * (RS - 2)>(); else attn_wait_vmcnt<0>();
+    if (nlive - 1 - j >= RS - 2) attn_wait_vmcnt<4 * (RS - 2)>(); else attn_wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
-    if (kt + RS - 1 < ntiles) issue(kt + RS - 1);
-    // wave-uniform skips: tile entirely above this wave's diagonal / every key of the tile is padding
+    if (j + RS - 1 < nlive) issue(j + RS - 1);
+    // wave-uniform skips: tile entirely above this wave's diagonal / every key of the tile is padding (the list's fallback tile)
     if ((a.causal && kb > q0 + 31) || maskw[kt] == ~0ull) continue;
-    const unsigned char* Kimg = lds + (kt % RS) * STAGE;
+    const unsigned char* Kimg = lds + (j % RS) * STAGE;
     const unsigned char* Vimg = Kimg + KT * DH * 2;
     const unsigned long long mword = maskw[kt];
     const unsigned long long pad = mword >> (4 * h);
@@ -457,9 +463,27 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd_dq_mfma(AttnM a, const e16*
   if (a.causal) kend = min(a.Tk, blk_.xb * 128 + 128);
   const int ntiles = (kend + KT - 1) / KT;
   build_mask_words(maskw, a.key_pad, b, a.Tk, ntiles, w, lane);
+  // self-attention over a padded batch: the caller vouches (qskip) that padded query rows carry zero dO -- their dQ rows are exact
+  // zeros whatever the keys, so a wave whose 32 queries are all padding only keeps the ring and the barriers going
+  const bool wave_qskip = a.qskip && __all(q >= a.Tq || a.key_pad[(int64_t)b * a.Tk + qc] != 0);
+  int* const tl = (int*)(maskw + (a.Tk + KT - 1) / KT) + 1;      // key tiles with at least one real key
+  if (__syncthreads_and(wave_qskip)) {   // all 128 queries of the workgroup are padding: their dQ rows are zeros, nothing to load
+    if (q < a.Tq) {
+      e16* dqp = dQ + ((int64_t)b * a.Tq + q) * a.lddq + hd * DH + 4 * h;
+      const e16x4 z = {(e16)0.f, (e16)0.f, (e16)0.f, (e16)0.f};
+#pragma unroll
+      for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) *(e16x4*)(dqp + 32 * db + 8 * g4) = z;
+    }
+    return;
+  }
+  build_tile_list(tl, a.key_pad ? maskw : nullptr, 0, ntiles, w, lane);
   __syncthreads();   // retires the plain loads / the delta store before the LDS-DMA ring starts
-  auto issue = [&](int kt) {
-    unsigned char* st = lds + (kt % RS) * STAGE;
+  const int nlive = __builtin_amdgcn_readfirstlane(tl[-1]);
+  auto issue = [&](int j) {
+    unsigned char* st = lds + (j % RS) * STAGE;
+    const int kt = tl[j];
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       dma_piece<false>(st, Kb, a.ldk, kt * KT, a.Tk, w + 4 * u, lane);
@@ -469,17 +493,18 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd_dq_mfma(AttnM a, const e16*
   };
 #pragma unroll
   for (int s = 0; s < RS - 1; ++s)
-    if (s < ntiles) issue(s);
-  // ntiles >= 1 always (Tk >= 1): without the guard the loop's exit block has one predecessor and the
+    if (s < nlive) issue(s);
+  // nlive >= 1 always (build_tile_list): without the guard the loop's exit block has one predecessor and the
   // accumulators need no phi copies at the latch (they cost 32-64 v_mov per tile)
-  __builtin_assume(ntiles >= 1);
-  for (int kt = 0; kt < ntiles; ++kt) {
+  __builtin_assume(nlive >= 1);
+  for (int j = 0; j < nlive; ++j) {
+    const int kt = __builtin_amdgcn_readfirstlane(tl[j]);
     const int kb = kt * KT;
-    if (ntiles - 1 - kt >= RS - 2) attn_wait_vmcnt<6 * (RS - 2)>(); else attn_wait_vmcnt<0>();
+    if (nlive - 1 - j >= RS - 2) attn_wait_vmcnt<6 * (RS - 2)>(); else attn_wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
-    if (kt + RS - 1 < ntiles) issue(kt + RS - 1);
-    if ((a.causal && kb > q0 + 31) || maskw[kt] == ~0ull) continue;   // above the diagonal / all-padding key tile
-    const unsigned char* Krow = lds + (kt % RS) * STAGE;
+    if (j + RS - 1 < nlive) issue(j + RS - 1);
+    if ((a.causal && kb > q0 + 31) || maskw[kt] == ~0ull || wave_qskip) continue;   // above the diagonal / all-padding key tile / all-padding queries
+    const unsigned char* Krow = lds + (j % RS) * STAGE;
     const unsigned char* Ktr = Krow + KT * DH * 2;
     const unsigned char* Vrow = Krow + 2 * KT * DH * 2;
     const unsigned long long mword = maskw[kt];
@@ -795,10 +820,29 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd_dkv_mfma(AttnM a, const e16
   if (a.causal) qbeg = (blk_.xb * 128) / KT * KT;   // queries before the block's first key see none of it
   const int ntiles = (a.Tq - qbeg + KT - 1) / KT;
   const int64_t lbase = ((int64_t)b * a.H + hd) * a.Tq;
+  // qskip (self-attention, Tq == Tk): 64-query tiles of nothing but padding carry dO = 0 and delta = 0, i.e. they add exact zeros
+  // to dK and dV: skipped.  One mask word per query tile, behind the ring.
+  unsigned long long* qmaskw = (unsigned long long*)(lds + DS * STAGE);
+  int* const tl = (int*)(qmaskw + (a.Tq + KT - 1) / KT) + 1;      // the query tiles to visit (build_tile_list): all, or the ones with a real query
+  if (a.qskip) build_mask_words(qmaskw, a.key_pad, b, a.Tq, (a.Tq + KT - 1) / KT, w, lane);
+  if (__syncthreads_and(wave_all_masked)) {   // 128 padded keys: their dK / dV rows are zeros (see the end of the kernel), nothing to load
+    if (key < a.Tk) {
+      e16* dkp = dK + ((int64_t)b * a.Tk + key) * a.lddk + hd * DH + 4 * h;
+      e16* dvp = dV + ((int64_t)b * a.Tk + key) * a.lddv + hd * DH + 4 * h;
+      const e16x4 z = {(e16)0.f, (e16)0.f, (e16)0.f, (e16)0.f};
+#pragma unroll
+      for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) { *(e16x4*)(dkp + 32 * db + 8 * g4) = z; *(e16x4*)(dvp + 32 * db + 8 * g4) = z; }
+    }
+    return;
+  }
+  build_tile_list(tl, a.qskip ? qmaskw : nullptr, qbeg / KT, qbeg / KT + ntiles, w, lane);
   __syncthreads();   // K / V fragment loads retired before the LDS-DMA ring starts
-  auto issue = [&](int qt) {
-    unsigned char* st = lds + (qt % DS) * STAGE;
-    const int row0 = qbeg + qt * KT;
+  const int nlive = __builtin_amdgcn_readfirstlane(tl[-1]);
+  auto issue = [&](int j) {
+    unsigned char* st = lds + (j % DS) * STAGE;
+    const int row0 = tl[j] * KT;
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       dma_piece_dual(st, Qb, a.ldq, row0, a.Tq, w + 4 * u, lane);
@@ -819,20 +863,20 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd_dkv_mfma(AttnM a, const e16
     }
   };
   const unsigned t0 = tr_dual_t0(lane);
-  if (ntiles > 0) issue(0);
-  __builtin_assume(ntiles >= 1);   // see k_attn_fwd_mfma
-  for (int qt = 0; qt < ntiles; ++qt) {
-    const int qb = qbeg + qt * KT;
+  issue(0);
+  __builtin_assume(nlive >= 1);   // see k_attn_fwd_mfma
+  for (int j = 0; j < nlive; ++j) {
+    const int qb = __builtin_amdgcn_readfirstlane(tl[j]) * KT;
     attn_wait_vmcnt<0>();          // this tile's pieces (the only ones in flight)
     __builtin_amdgcn_s_barrier();
-    if (qt + 1 < ntiles) issue(qt + 1);
-    const unsigned char* Qrow = lds + (qt % DS) * STAGE;
+    if (j + 1 < nlive) issue(j + 1);
+    const unsigned char* Qrow = lds + (j % DS) * STAGE;
     const unsigned char* Drow = Qrow + IMG;
     const float* Ls = (const float*)(Qrow + 2 * IMG);   // lse (natural log units)
     const float* Ds = Ls + KT;
     const bool ragged = qb + KT > a.Tq;   // wave-uniform: tile holds rows past Tq (clamped duplicates)
     // wave-uniform skips: every query of the tile precedes this wave's keys / its 32 keys are all padding
-    if ((a.causal && qb + KT - 1 < k0) || wave_all_masked) continue;
+    if ((a.causal && qb + KT - 1 < k0) || wave_all_masked || (a.qskip && qmaskw[qb / KT] == ~0ull)) continue;
     // transposed-read address registers of this stage: base + (T0 ^ (delta << 4)) [^ 64 for the upper column half]
     const unsigned sb = (unsigned)(uintptr_t)Qrow;
     unsigned xa[4], xb[4];
@@ -995,6 +1039,7 @@ static AttnM make_m(const afm_attn_shape* s) {
   a.key_pad = s->key_pad; a.dd = afm_make_drop(&s->drop);
   a.bits = a.dd.thresh16 ? (unsigned long long*)s->drop_bits : nullptr;
   a.nq32 = ((s->Tq + 127) / 128) * 4; a.nk32 = ((s->Tk + 63) / 64) * 2;      // whole workgroups / whole 64-key tiles
+  a.qskip = (s->reserved & 64) && s->key_pad && s->Tq == s->Tk;
   return a;
 }
 
@@ -1025,7 +1070,7 @@ int AFM_E16_FN(afm_attn_fwd_mfma_try)(const afm_attn_shape* s, const void* Q, co
     return AFM_OK;
   }
   const dim3 grid(((s->Tq + 127) / 128) * s->H * s->B);
-  const int shm = RS * 2 * KT * DH * 2 + ((s->Tk + KT - 1) / KT) * 8;
+  const int shm = RS * 2 * KT * DH * 2 + ((s->Tk + KT - 1) / KT) * 12 + 8;      // ring, key-mask words, tile list
   if (shm > 64 * 1024) return AFM_ERR_UNSUPPORTED;
   if (a.dd.thresh16 && a.bits && (s->reserved & 32)) AFM_LAUNCH(k_attn_fwd_mfma<DROP_READ>, grid, dim3(256), shm, st, a, (const e16*)Q, (const e16*)K, (const e16*)V, (e16*)O, lse);
   else if (a.dd.thresh16 && a.bits) AFM_LAUNCH(k_attn_fwd_mfma<DROP_BITS>, grid, dim3(256), shm, st, a, (const e16*)Q, (const e16*)K, (const e16*)V, (e16*)O, lse);
@@ -1055,7 +1100,7 @@ int AFM_E16_FN(afm_attn_bwd_mfma_try)(const afm_attn_shape* s, const void* Q, co
   AttnM a = make_m(s);
   a.lddq = lddq; a.lddk = lddk; a.lddv = lddv;
   const dim3 gq(((s->Tq + 127) / 128) * s->H * s->B), gk(((s->Tk + 127) / 128) * s->H * s->B);
-  const int shm_q = RS * 3 * KT * DH * 2 + ((s->Tk + KT - 1) / KT) * 8;
+  const int shm_q = RS * 3 * KT * DH * 2 + ((s->Tk + KT - 1) / KT) * 12 + 8;
   if (shm_q > 80 * 1024) return AFM_ERR_UNSUPPORTED;
   static AfmOncePerDevice attr_q;
   if (attr_q.need()) {
@@ -1084,7 +1129,7 @@ int AFM_E16_FN(afm_attn_bwd_mfma_try)(const afm_attn_shape* s, const void* Q, co
   else if (a.dd.thresh16 && a.bits) AFM_LAUNCH(k_attn_bwd_dq_mfma<DROP_BITS>, gq, dim3(256), shm_q, st, a, (const e16*)Q, (const e16*)K, (const e16*)V, (const e16*)O, (const e16*)dO, lse, delta, (e16*)dQ);
   else if (a.dd.thresh16) AFM_LAUNCH(k_attn_bwd_dq_mfma<DROP_HASH>, gq, dim3(256), shm_q, st, a, (const e16*)Q, (const e16*)K, (const e16*)V, (const e16*)O, (const e16*)dO, lse, delta, (e16*)dQ);
   else AFM_LAUNCH(k_attn_bwd_dq_mfma<DROP_NONE>, gq, dim3(256), shm_q, st, a, (const e16*)Q, (const e16*)K, (const e16*)V, (const e16*)O, (const e16*)dO, lse, delta, (e16*)dQ);
-  const int shm_k = 2 * (2 * KT * DH * 2 + 2 * KT * 4 + 4 * 256);     // two stages of {Q, dO dual-use images, lse, delta, keep bits}
+  const int shm_k = 2 * (2 * KT * DH * 2 + 2 * KT * 4 + 4 * 256) + ((s->Tq + KT - 1) / KT) * 12 + 8;     // two stages of {Q, dO dual-use images, lse, delta, keep bits} + the query-tile mask words and list
   static AfmOncePerDevice attr_k;
   if (attr_k.need()) {
     (void)hipFuncSetAttribute((const void*)k_attn_bwd_dkv_mfma<DROP_HASH>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);

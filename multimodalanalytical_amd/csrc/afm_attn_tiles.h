@@ -17,6 +17,7 @@ struct AttnM {
   DropDev dd;
   unsigned long long* bits;   // keep-bit tensor (include/afm_hip.h: afm_attn_shape.drop_bits), null = re-hash
   int nq32, nk32;
+  int qskip;   // backward, self-attention: query rows at padded positions carry zero dO (afm_attn_shape.reserved & 64): skipped, exactly
 };
 
 typedef __attribute__((ext_vector_type(4))) short s16x4;
@@ -176,6 +177,25 @@ __device__ __forceinline__ void build_mask_words(unsigned long long* maskw, cons
   }
 }
 
+// Compacted list of the tiles [t_lo, t_hi) a workgroup really has to visit: those whose mask word is not all ones (`maskw` null:
+// all of them).  Skipping a padded tile inside the loop still paid its LDS-DMA and its barrier; walking the list does not load it
+// at all.  Wave 0 writes list[0 .. n) and the count to list[-1]; never empty (an all-padded range keeps its first tile, which the
+// kernels' own masks then turn into zeros).  The caller puts a workgroup barrier before (masks built) and after.
+__device__ __forceinline__ void build_tile_list(int* list, const unsigned long long* maskw, int t_lo, int t_hi, int w, int lane) {
+  if (w != 0) return;
+  int n = 0;
+  for (int t0 = t_lo; t0 < t_hi; t0 += 64) {
+    const int tt = t0 + lane;
+    const bool live = tt < t_hi && (!maskw || maskw[tt] != ~0ull);
+    const unsigned long long bal = __ballot(live);
+    if (live) list[n + __popcll(bal & ((1ull << lane) - 1ull))] = tt;
+    n += __popcll(bal);
+  }
+  if (lane == 0) {
+    if (n == 0) { list[0] = t_lo; n = 1; }
+    list[-1] = n;
+  }
+}
 
 // ------------------------------------------------------------------------------------------ XCD-aware block map
 // 1-D grid of nblk * B * H workgroups (nblk = 128-row blocks of one (batch, head)).  Workgroups are dealt round-robin

@@ -556,6 +556,9 @@ class Seq2SeqEngine:
         delta = torch.empty_like(lse)
         ldg = ops._ld(dqkv)
         qkv_b, shp = self._hb(qkv), self._shape_b(shp)
+        # padded positions are masked as keys everywhere and take no part in the loss: their rows of every activation gradient
+        # are exact zeros, so the self-attention backward may skip them as queries (include/afm_hip.h, reserved bit 6)
+        shp.reserved |= 64
         ops.attn_bwd(shp, qkv_b[:, :d], qkv_b[:, d:2 * d], qkv_b[:, 2 * d:], self._hb(a), da, lse, delta,
                      dqkv[:, :d], dqkv[:, d:2 * d], dqkv[:, 2 * d:], ldg, ldg, ldg)
         self._wgrad(dqkv, h, p + "self_attn.in_proj_weight", 3 * d, d, bias_name=p + "self_attn.in_proj_bias")

@@ -294,6 +294,38 @@ def test_attention_keep_bits_filled_ahead(ops, dt, B, H, Tq, Tk, causal, pad):
         assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("dt", [H16, torch.bfloat16])
+@pytest.mark.parametrize("causal", [False, True])
+def test_attention_backward_skips_padded_query_rows_exactly(ops, dt, causal):
+    """afm_attn_shape.reserved bit 6: self-attention over a padded batch whose padded rows carry zero dO (a training step's
+    padded positions).  With the flag the single-pass kernels skip those rows as queries: dQ, dK, dV equal the unflagged run."""
+    B, H, T, dh = 3, 2, 512, 64
+    D = H * dh
+    q, k, v, _ = _attn_case(B, H, T, T, dh, causal, False, seed=31)
+    key_pad = torch.zeros(B, T, dtype=torch.bool)
+    key_pad[0, 100:] = True; key_pad[1, 333:] = True          # whole 32-query waves / 64-query tiles of padding, and ragged edges
+    qd, kd, vd = (dev(t.reshape(-1, D), dt) for t in (q, k, v))
+    kp = dev(key_pad.to(torch.uint8))
+    dr = ops.drop(0.1, 99, 4)
+    do = rnd(B * T, D, seed=9)
+    do[key_pad.reshape(-1)] = 0.0                              # what the engine's backward hands over at padded positions
+    dod = dev(do, dt)
+    res = []
+    for flag in (0, 64):
+        o = torch.empty(B * T, D, dtype=dt, device=DEV); lse = torch.empty(B * H * T, device=DEV)
+        shp = ops.attn_shape(B, H, T, T, dh, dt, D, D, D, D, kp, causal, dr, algo=2)
+        ops.attn_set_drop_bits(shp, torch.zeros(ops.attn_drop_bits_words(B, H, T, T), dtype=torch.int64, device=DEV))
+        ops.attn_fwd(shp, qd, kd, vd, o, lse)
+        shp.reserved |= flag
+        dq, dk, dv = (torch.full((B * T, D), 7.0, dtype=dt, device=DEV) for _ in range(3))
+        ops.attn_bwd(shp, qd, kd, vd, o, dod, lse, torch.empty_like(lse), dq, dk, dv, D, D, D)
+        assert ops.last_algo() == "attn_mfma"
+        res.append((dq, dk, dv))
+    for a, b in zip(*res):
+        assert torch.equal(a, b)                               # (-0 == +0: the skipped rows are written as zeros either way)
+    assert float(res[1][0].view(B, T, D)[0, 100:].abs().max()) == 0.0
+
+
 # ------------------------------------------------------------------ LayerNorm, elementwise, loss
 @pytest.mark.parametrize("d", [64, 512, 768])
 def test_layernorm_f16(ops, d):
