@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define AFM_ABI_VERSION 3
+#define AFM_ABI_VERSION 4
 
 enum { AFM_OK = 0, AFM_ERR_ARG = -1, AFM_ERR_UNSUPPORTED = -2, AFM_ERR_LAUNCH = -3 };
 enum { AFM_F32 = 0, AFM_BF16 = 1, AFM_BF16X2 = 2, AFM_F16 = 3 };
@@ -121,6 +121,10 @@ typedef struct {
   int32_t glu_rows;       /* f > 0: gated-FFN interleave (see above); wgrad form: rows of C / a_colsum are de-interleaved */
   int32_t reserved2;      /* bit 0 (pair dtype, act GELU_SAVE_GRAD / GLU_SAVE): the stored factors get their hi plane only -- the
                              consumer is the single-pass bf16 backward of the mixed precision mode, which never reads the lo plane */
+  const uint8_t* k_live;  /* wgrad form (transA), nullable: k_live[i] == 0 says rows 64 i .. 64 i + 63 of A (64 token positions) are all
+                             zero -- the padded positions of a training step's backward, whose activation gradients are exact
+                             zeros -- and the MFMA kernels leave those k-steps out (K % 64 == 0; same result).  Device memory,
+                             K / 64 bytes. */
 } afm_gemm_desc;
 int afm_gemm(const afm_gemm_desc* d, void* stream);
 
@@ -176,6 +180,9 @@ typedef struct {
   afm_dropout add_drop;   /* forward only: x_sum = x + dropout(add) with this stream (p = 0: plain add); the
                              element index is row-major in `add`, the same index the GEMM epilogue and the
                              backward's dx_drop use for that site */
+  const uint8_t* row_live; /* backward only, nullable: row_live[i] == 0 says rows 64 i .. 64 i + 63 of dy (and of dres) are all zero
+                             (padded positions): their dx / dx_drop rows are written as zeros without reading anything and they
+                             add nothing to dgamma / dbeta.  rows / 64 bytes (rows % 64 == 0), identity row mapping only. */
 } afm_ln_shape;
 int afm_layernorm_fwd(const afm_ln_shape* s, const float* x, const float* gamma, const float* beta,
                       const float* pos, void* y, float* mean, float* rstd, const void* add,

@@ -29,6 +29,7 @@ struct MfmaArgs {
   const void* residual;
   void* pre_act;
   float* a_colsum;
+  const uint8_t* k_live;   // TN only (afm_gemm_desc.k_live)
   int act, accumulate;
   int tiles_m, tiles_n;
   int ksplit, kchunk;  // TN only
@@ -1199,9 +1200,11 @@ __global__ __launch_bounds__(512, 2) void k_gemm_tn_ring(MfmaArgs g) {
 // Same kernel on 256 x 256 tiles: 8 waves of 128 x 64 (2 x 4), two 64-KiB ring slots.  Per FLOP a quarter
 // less L2->LDS fill and a quarter fewer transposed LDS reads than the 256 x 128 form, and 64 MFMAs per
 // wave between barriers; needs more split-K (fewer tiles), i.e. more fp32 atomics on the small dW.
+#define TN_LIST_MAX 4096     // live-k-step list entries behind the 128-KiB ring (16 KiB)
 // One (tile, k-chunk) unit of the wgrad form; shared by the single-problem kernel and the grouped one.
 struct TnProb {
   const e16* A; const e16* B; float* C; float* a_colsum;
+  const uint8_t* k_live;   // one byte per 64-token k-step, 0 = all of A's rows there are zero (padding): left out; null = all live
   int M, N, K, lda, ldb, ldc, tiles_n, ntile, ksplit, kchunk, glu_f, accumulate;
   int unit0;       // grouped launch: index of this problem's first (tile, k-chunk) unit
 };
@@ -1213,7 +1216,27 @@ __device__ __forceinline__ void tn256_unit(const TnProb& g, int tile, int ks_id,
   const int wm = w >> 2, wn = w & 3;
   const int m0 = (tile / g.tiles_n) * TBM, n0 = (tile % g.tiles_n) * TBN;
   const int kbeg = ks_id * g.kchunk, kend = min(g.K, kbeg + g.kchunk);
-  const int nk = (kend - kbeg) / 64;
+  int nk = (kend - kbeg) / 64;
+  // k-steps whose 64 token rows are all padding (A rows exact zeros: afm_gemm_desc.k_live) are left out: the list of the live ones
+  // sits behind the ring (wave 0 compacts it with one ballot per 64 steps); without the hint it is the identity
+  int* const kl = (int*)(lds + S * STAGE);
+  const bool listed = g.k_live != nullptr && nk <= TN_LIST_MAX;
+  if (listed) {
+    if (w == 0) {
+      int n = 0;
+      for (int t0 = 0; t0 < nk; t0 += 64) {
+        const int tt = t0 + lane;
+        const bool live = tt < nk && g.k_live[kbeg / 64 + tt] != 0;
+        const unsigned long long bal = __ballot(live);
+        if (live) kl[1 + n + __popcll(bal & ((1ull << lane) - 1ull))] = tt;
+        n += __popcll(bal);
+      }
+      if (lane == 0) kl[0] = n;
+    }
+    __syncthreads();
+    nk = __builtin_amdgcn_readfirstlane(kl[0]);
+  }
+  auto step_of = [&](int j) { return listed ? kl[1 + j] : j; };
 
   // this wave's pieces: ii = w + 8 j; ii < 32 -> A rows {2 ii, 2 ii + 1}, else B rows {2 (ii-32), +1} (512 B rows)
   const e16* src[NIW];
@@ -1233,9 +1256,10 @@ __device__ __forceinline__ void tn256_unit(const TnProb& g, int tile, int ks_id,
   }
   auto issue = [&](int kt) {
     unsigned char* st = lds + (kt % S) * STAGE;
+    const int64_t step = step_of(kt);
 #pragma unroll
     for (int j = 0; j < NIW; ++j)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[j] + kt * pitch[j]),
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[j] + step * pitch[j]),
                                        (__attribute__((address_space(3))) void*)(st + (w + NW * j) * 1024), 16, 0, 0);
   };
 
@@ -1349,7 +1373,7 @@ __device__ __forceinline__ void tn256_unit(const TnProb& g, int tile, int ks_id,
 __global__ __launch_bounds__(512) void k_gemm_tn_ring256(MfmaArgs g) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   TnProb pr;
-  pr.A = g.A; pr.B = g.B; pr.C = (float*)g.C; pr.a_colsum = g.a_colsum;
+  pr.A = g.A; pr.B = g.B; pr.C = (float*)g.C; pr.a_colsum = g.a_colsum; pr.k_live = g.k_live;
   pr.M = g.M; pr.N = g.N; pr.K = g.K; pr.lda = g.lda; pr.ldb = g.ldb; pr.ldc = g.ldc;
   pr.tiles_n = g.tiles_n; pr.ntile = g.tiles_m * g.tiles_n; pr.ksplit = g.ksplit; pr.kchunk = g.kchunk;
   pr.glu_f = g.glu_f; pr.accumulate = g.accumulate; pr.unit0 = 0;
@@ -1362,6 +1386,7 @@ __global__ __launch_bounds__(512) void k_gemm_tn_ring256(MfmaArgs g) {
 // to fill 256 CUs, and every split adds the whole dW once more through memory-side fp32 atomics (1.3 TB/s chip-wide: 51 us of a
 // 300-us launch at 131 072 tokens, 25 of 33 us at 16 384).  Together they fill the chip at split-K 4 .. 5.
 #define AFM_TN_GROUP_MAX 8
+#define TN_LIST_MAX_BYTES (4 * (TN_LIST_MAX + 1))
 struct TnGroup { int n, units; TnProb p[AFM_TN_GROUP_MAX]; };
 __global__ __launch_bounds__(512) void k_gemm_tn_group256(TnGroup gr) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -1386,7 +1411,7 @@ int AFM_E16_FN(afm_gemm_mfma_try)(const afm_gemm_desc* d, hipStream_t st) {
   MfmaArgs g;
   g.M = d->M; g.N = d->N; g.K = d->K; g.lda = d->lda; g.ldb = d->ldb; g.ldc = d->ldc;
   g.A = (const e16*)d->A; g.B = (const e16*)d->B; g.C = d->C;
-  g.bias = d->bias; g.residual = d->residual; g.pre_act = d->pre_act; g.a_colsum = d->a_colsum;
+  g.bias = d->bias; g.residual = d->residual; g.pre_act = d->pre_act; g.a_colsum = d->a_colsum; g.k_live = d->k_live;
   g.act = d->act; g.accumulate = d->accumulate;
   g.dd = afm_make_drop(&d->drop);
   g.tiles_m = (d->M + BM - 1) / BM; g.tiles_n = (d->N + BN - 1) / BN;
@@ -1537,9 +1562,9 @@ int AFM_E16_FN(afm_gemm_mfma_try)(const afm_gemm_desc* d, hipStream_t st) {
       }
       static AfmOncePerDevice attr256;
       if (attr256.need()) {
-        (void)hipFuncSetAttribute((const void*)k_gemm_tn_ring256, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 64 * 512 * 2);
+        (void)hipFuncSetAttribute((const void*)k_gemm_tn_ring256, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 64 * 512 * 2 + TN_LIST_MAX_BYTES);
       }
-      AFM_LAUNCH(k_gemm_tn_ring256, dim3(tiles * ksplit), dim3(512), 2 * 64 * 512 * 2, st, g);
+      AFM_LAUNCH(k_gemm_tn_ring256, dim3(tiles * ksplit), dim3(512), 2 * 64 * 512 * 2 + TN_LIST_MAX_BYTES, st, g);
       afm_set_last_algo(ksplit > 1 ? "mfma_tn_ring256_splitk" : "mfma_tn_ring256");
       return AFM_OK;
     }
@@ -1618,7 +1643,7 @@ int AFM_E16_FN(afm_gemm_tn_group_launch)(const afm_gemm_desc* const* ds, int cou
   for (int i = 0; i < count; ++i) {
     const afm_gemm_desc* d = ds[i];
     TnProb& pr = gr.p[i];
-    pr.A = (const e16*)d->A; pr.B = (const e16*)d->B; pr.C = (float*)d->C; pr.a_colsum = d->a_colsum;
+    pr.A = (const e16*)d->A; pr.B = (const e16*)d->B; pr.C = (float*)d->C; pr.a_colsum = d->a_colsum; pr.k_live = d->k_live;
     pr.M = d->M; pr.N = d->N; pr.K = d->K; pr.lda = d->lda; pr.ldb = d->ldb; pr.ldc = d->ldc;
     pr.tiles_n = (d->N + 255) / 256; pr.ntile = ((d->M + 255) / 256) * pr.tiles_n;
     pr.glu_f = d->glu_rows; pr.accumulate = 1;
@@ -1650,8 +1675,8 @@ int AFM_E16_FN(afm_gemm_tn_group_launch)(const afm_gemm_desc* const* ds, int cou
   for (int i = count; i < AFM_TN_GROUP_MAX; ++i) { gr.p[i] = gr.p[0]; gr.p[i].unit0 = 0x7fffffff; }
   static AfmOncePerDevice attr;
   if (attr.need())
-    (void)hipFuncSetAttribute((const void*)k_gemm_tn_group256, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 64 * 512 * 2);
-  AFM_LAUNCH(k_gemm_tn_group256, dim3(units), dim3(512), 2 * 64 * 512 * 2, st, gr);
+    (void)hipFuncSetAttribute((const void*)k_gemm_tn_group256, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 64 * 512 * 2 + TN_LIST_MAX_BYTES);
+  AFM_LAUNCH(k_gemm_tn_group256, dim3(units), dim3(512), 2 * 64 * 512 * 2 + TN_LIST_MAX_BYTES, st, gr);
   afm_set_last_algo("mfma_tn_group256");
   return AFM_OK;
 }

@@ -205,7 +205,7 @@ __global__ __launch_bounds__(256) void k_ln_bwd_vec(const TY* __restrict__ dy, c
                                                     const float* __restrict__ dres, float* __restrict__ dx,
                                                     float* __restrict__ dgamma, float* __restrict__ dbeta, int64_t rows, int d,
                                                     TY* __restrict__ dx_drop, DropDev dd, int64_t seg_len, int64_t seg_stride,
-                                                    int64_t off) {
+                                                    int64_t off, const uint8_t* __restrict__ row_live) {
   extern __shared__ __attribute__((aligned(16))) float sm[];  // [4 waves][2][d]
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -220,6 +220,19 @@ __global__ __launch_bounds__(256) void k_ln_bwd_vec(const TY* __restrict__ dy, c
     if (c < d) gm[i] = ld8(gamma + c);
   }
   for (int64_t r = wave; r < rows; r += nwaves) {
+    if (row_live && !row_live[r >> 6]) {     // a block of padded positions: dy = dres = 0 there, so dx = 0 and nothing is added to dgamma / dbeta
+      const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+      const F8 z = {z4, z4};
+#pragma unroll
+      for (int i = 0; i < NC; ++i) {
+        const int c = (lane + 64 * i) * 8;
+        if (c < d) {
+          st8(dx + r * (int64_t)d + c, z);
+          if (dx_drop) st8(dx_drop + r * (int64_t)(d * RowMul<TY>::v) + c, z, d);
+        }
+      }
+      continue;
+    }
     const float mu = mean[r], rs = rstd[r];
     F8 xh[NC], g[NC];
     float s1 = 0.f, s2 = 0.f;
@@ -430,7 +443,8 @@ extern "C" int afm_layernorm_bwd(const afm_ln_shape* s, const void* dy, const fl
   if (s->y_dtype < AFM_F32 || s->y_dtype > AFM_F16) return AFM_ERR_ARG;
   if ((s->d % 8) == 0 && s->d <= 2048 && s->rows >= 64) {   // vectorised path (dy rows follow the embedder's placement, if any)
 #define LN_BV(TY, NC) AFM_LAUNCH((k_ln_bwd_vec<TY, NC>), dim3(g), dim3(256), shm, st, (const TY*)dy, x, gamma, mean, rstd, dres, dx, \
-                                 dgamma, dbeta, s->rows, s->d, (TY*)dx_drop, dd, s->seg_len, s->out_seg_stride, s->out_off)
+                                 dgamma, dbeta, s->rows, s->d, (TY*)dx_drop, dd, s->seg_len, s->out_seg_stride, s->out_off,   \
+                                 (s->seg_len == 0 && (s->rows & 63) == 0) ? s->row_live : nullptr)
 #define LN_BV2(TY) do { if (s->d <= 512) LN_BV(TY, 1); else if (s->d <= 1024) LN_BV(TY, 2); else LN_BV(TY, 4); } while (0)
     if (s->y_dtype == AFM_BF16) LN_BV2(bf16); else if (s->y_dtype == AFM_BF16X2) LN_BV2(x2); else if (s->y_dtype == AFM_F16) LN_BV2(f16); else LN_BV2(float);
 #undef LN_BV2

@@ -107,6 +107,7 @@ class Seq2SeqEngine:
         # (LayerNorm backward, casts) of the main stream on the same CUs
         self.wgrad_stream = torch.cuda.Stream(device=self.dev) if (self.dev.type == "cuda" and side_wgrad) else None
         self.group_wgrad = os.environ.get("AFM_GROUP_WGRAD", "1") != "0"    # (0: one launch per weight gradient, for A/B timing)
+        self.row_skip = os.environ.get("AFM_ROW_SKIP", "1") != "0"          # (0: the backward computes padded rows like any other)
         # layer options of configs/model/*.yaml beside the defaults: the reference's `post_layer_normalisation` IS torch's norm_first
         # (custom_modeling.py:129,176: True = pre-LN, the shipped setting); `activation_function` goes to the torch layers as is
         self.pre_ln = bool(cfg.get("post_layer_normalisation", True))
@@ -119,6 +120,7 @@ class Seq2SeqEngine:
         self.bits_stream = (torch.cuda.Stream(device=self.dev)
                             if self.dev.type == "cuda" and os.environ.get("AFM_BITS_AHEAD", "0") == "1" else None)
         self._wg_pending = []
+        self._live = {}       # backward only: rows -> uint8 per 64-row block, 0 = nothing but padded positions (_backward)
         self.refresh_shadows()
 
     # ------------------------------------------------------------------ parameters
@@ -293,6 +295,8 @@ class Seq2SeqEngine:
 
     def _wgrad_raw(self, dy, x, gw, gb, glu_rows=0):
         kw = dict(trans_a=True, trans_b=False, accumulate=True, algo=self.algo, a_colsum=gb, glu_rows=glu_rows)
+        if torch.is_tensor(dy) and dy.dtype != torch.float32:
+            kw["k_live"] = self._live.get(dy.shape[0])      # padded 64-token blocks carry exact zeros: left out of the token axis
         if self.group_wgrad and torch.is_tensor(dy) and torch.is_tensor(x) and dy.dtype == x.dtype and dy.dtype != torch.float32:
             # 16-bit operands: the layer's weight gradients go out together at the end of its backward (afm_gemm_group: one
             # launch, one split-K budget); the list keeps dy / x alive until then
@@ -474,7 +478,7 @@ class Seq2SeqEngine:
             dxd = self._empty(x.shape[0], self.d, dy.dtype)
             dr = self._drop(next_site)
         ops.layernorm_bwd(dy, x, self.ps.p(prefix + "weight"), mean, rstd, dx, self.ps.g(prefix + "weight"),
-                          self.ps.g(prefix + "bias"), ws, dres=dres, dx_drop=dxd, dropout=dr)
+                          self.ps.g(prefix + "bias"), ws, dres=dres, dx_drop=dxd, dropout=dr, row_live=self._live.get(x.shape[0]))
         return dx, dxd
 
     def _bits_ahead(self, B, H, Tq, Tk, site, saved):
@@ -782,7 +786,7 @@ class Seq2SeqEngine:
         logits = self._linear(hf, "token_ff.weight", self.V, self.d, out_dtype=torch.float32,
                               bias_name="token_ff.bias")
         if saved is not None:
-            saved.update(dec_layers=layers, hf=hf, T=T)
+            saved.update(dec_layers=layers, hf=hf, T=T, tgt_pad=tgt_pad)
         return logits
 
 
@@ -1077,6 +1081,7 @@ class Seq2SeqEngine:
             self._grads_final_from(p + "self_attn.in_proj_weight")
         self.embed_bwd(dx, saved["emb_enc"])
         self._wgrad_flush()
+        self._live = {}
         if self.wgrad_stream is not None:
             torch.cuda.current_stream().wait_stream(self.wgrad_stream)
 
@@ -1093,6 +1098,14 @@ class Seq2SeqEngine:
         d = self.d
         B, S, T = saved["B"], saved["S"], saved["T"]
         self._wg_pending = []          # (a backward pass that raised may have left entries behind)
+        # Padded positions are masked as keys everywhere and take no part in the loss: their rows of every activation gradient are
+        # exact zeros.  One byte per 64-row block tells the weight-gradient kernels (token axis) and the LayerNorm backward which
+        # blocks hold nothing else (include/afm_hip.h: afm_gemm_desc.k_live, afm_ln_shape.row_live).
+        self._live = {}
+        if self.row_skip and B * S != B * T:
+            for L, pad in ((S, saved.get("key_pad")), (T, saved.get("tgt_pad"))):
+                if pad is not None and L % 64 == 0:
+                    self._live[B * L] = (pad.view(B, L // 64, 64) == 0).any(-1).to(torch.uint8).reshape(-1).contiguous()
         dlog = self._empty_b(B * T, self.V)
         ops.ce_bwd(logits, lab, row_lse, stats, loss_scale, dlog, scale_dev=self.scaler)
         hf = saved["hf"]
@@ -1140,5 +1153,6 @@ class Seq2SeqEngine:
             self._grads_final_from(p + "self_attn.in_proj_weight")
         self.embed_bwd(dx, saved["emb_enc"])
         self._wgrad_flush()
+        self._live = {}
         if self.wgrad_stream is not None:   # every weight gradient is in before the caller reads the buffer
             torch.cuda.current_stream().wait_stream(self.wgrad_stream)

@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libafm_hip.so")
 
 AFM_F32, AFM_BF16, AFM_BF16X2, AFM_F16 = 0, 1, 2, 3
-ABI_VERSION = 3
+ABI_VERSION = 4
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_GELU_BWD, ACT_GELU_SAVE_GRAD, ACT_MUL_SAVED = 0, 1, 2, 3, 4, 5
 ACT_GLU, ACT_GLU_SAVE, ACT_GLU_BWD = 6, 7, 8
 ALGO_AUTO, ALGO_GENERIC, ALGO_MFMA = 0, 1, 2
@@ -46,6 +46,7 @@ class GemmDesc(C.Structure):
         ("act", C.c_int32), ("accumulate", C.c_int32), ("algo", C.c_int32), ("reserved", C.c_int32),
         ("drop", Dropout),
         ("glu_rows", C.c_int32), ("reserved2", C.c_int32),
+        ("k_live", C.c_void_p),
     ]
 
 
@@ -54,6 +55,7 @@ class LnShape(C.Structure):
         ("rows", C.c_int64), ("d", C.c_int32), ("y_dtype", C.c_int32),
         ("seg_len", C.c_int64), ("out_seg_stride", C.c_int64), ("out_off", C.c_int64),
         ("eps", C.c_float), ("add_dtype", C.c_int32), ("add_drop", Dropout),
+        ("row_live", C.c_void_p),
     ]
 
 

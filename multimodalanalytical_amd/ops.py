@@ -101,7 +101,7 @@ def gemm_desc(a: torch.Tensor, b: torch.Tensor, c: torch.Tensor, *, trans_a=Fals
               bias: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
               pre_act: Optional[torch.Tensor] = None, act: int = ACT_NONE, accumulate: bool = False,
               dropout: Dropout = NO_DROP, algo: int = ALGO_AUTO, a_colsum: Optional[torch.Tensor] = None,
-              variant: int = 0, glu_rows: int = 0, sg_hi_only: bool = False) -> GemmDesc:
+              variant: int = 0, glu_rows: int = 0, sg_hi_only: bool = False, k_live: Optional[torch.Tensor] = None) -> GemmDesc:
     """The afm_gemm_desc of c = epilogue(op(a) @ op(b)) (arguments as `gemm`); the caller keeps the tensors alive until launch."""
     M, N = c.shape
     if act in (L.ACT_GLU, L.ACT_GLU_SAVE):
@@ -142,6 +142,9 @@ def gemm_desc(a: torch.Tensor, b: torch.Tensor, c: torch.Tensor, *, trans_a=Fals
     d.glu_rows = int(glu_rows)
     d.reserved2 = 1 if sg_hi_only else 0
     d.drop = dropout
+    if k_live is not None:      # wgrad form: one byte per 64 token rows of `a`, 0 = all of them zero (padding)
+        assert trans_a and k_live.dtype == torch.uint8 and k_live.is_contiguous() and K % 64 == 0 and k_live.numel() == K // 64
+    d.k_live = _ptr(k_live)
     return d
 
 
@@ -212,9 +215,13 @@ def layernorm_bwd_ws(rows, d) -> int:
 
 
 def layernorm_bwd(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, ws, dres=None, seg_len=0,
-                  out_seg_stride=0, out_off=0, dx_drop=None, dropout: Dropout = NO_DROP):
+                  out_seg_stride=0, out_off=0, dx_drop=None, dropout: Dropout = NO_DROP, row_live=None):
     rows, d = x.shape
     s = ln_shape(rows, d, dy.dtype, seg_len, out_seg_stride, out_off)
+    if row_live is not None:     # one byte per 64 rows, 0 = dy (and dres) are zero there: skipped, zeros written
+        assert row_live.dtype == torch.uint8 and row_live.is_contiguous() and rows % 64 == 0 and row_live.numel() == rows // 64
+        assert seg_len == 0
+        s.row_live = _ptr(row_live)
     assert ws.numel() >= layernorm_bwd_ws(rows, d)
     if dx_drop is not None:
         assert dx_drop.dtype == dy.dtype and dx_drop.shape == x.shape and is_contig(dx_drop) and is_contig(dy)

@@ -378,6 +378,62 @@ def test_convert_cast_and_ce_scale(ops):
     close(d1, d2.cpu().double() * 1024.0, 2e-3, 1e-6)
 
 
+@pytest.mark.parametrize("dt", [H16, torch.bfloat16])
+def test_wgrad_leaves_out_padded_token_blocks(ops, dt):
+    """afm_gemm_desc.k_live: 64-token blocks whose dy rows are exact zeros (padded positions of a training step) are left out of
+    the token axis -- same weight and bias gradients as the full sweep, one by one and grouped."""
+    R = 8192
+    live = torch.ones(R // 64, dtype=torch.uint8)
+    live[5:40] = 0; live[77] = 0; live[100:] = 0                 # long dead runs, a single dead block, a dead tail
+    rows_live = live.repeat_interleave(64).bool()
+    shapes = [(512, 512), (1536, 512), (512, 2048)]
+    ten, descs_a, descs_b, outs_a, outs_b = [], [], [], [], []
+    for i, (M, N) in enumerate(shapes):
+        dy = (rnd(R, M, seed=3 + i) * 0.5); dy[~rows_live] = 0.0
+        a, b = dev(dy, dt), dev(rnd(R, N, seed=13 + i), dt)
+        ten += [a, b]
+        for descs, outs, kl in ((descs_a, outs_a, None), (descs_b, outs_b, dev(live))):
+            g, gb = torch.zeros(M, N, device=DEV), torch.zeros(M, device=DEV)
+            descs.append(ops.gemm_desc(a, b, g, trans_a=True, trans_b=False, accumulate=True, a_colsum=gb, k_live=kl)); outs.append((g, gb))
+            ten.append(kl)
+        g1, gb1 = torch.zeros(M, N, device=DEV), torch.zeros(M, device=DEV)
+        ops.gemm(a, b, g1, trans_a=True, trans_b=False, accumulate=True, a_colsum=gb1, k_live=dev(live), variant=105)   # alone, 256 x 256 form
+        ref = a.double().T @ b.double()
+        close(g1, ref.cpu(), 1e-4, 2e-4 * math.sqrt(R) / 4)
+        close(gb1, a.double().sum(0).cpu(), 1e-4, 2e-4 * math.sqrt(R) / 4)
+    ops.gemm_group(descs_a); ops.gemm_group(descs_b)
+    assert ops.last_algo() == "mfma_tn_group256"
+    for (g0, b0), (g1, b1) in zip(outs_a, outs_b):
+        torch.testing.assert_close(g0, g1, rtol=1e-5, atol=2e-4)
+        torch.testing.assert_close(b0, b1, rtol=1e-5, atol=2e-4)
+
+
+@pytest.mark.parametrize("dt", [H16, torch.float32])
+def test_layernorm_backward_skips_padded_row_blocks(ops, dt):
+    """afm_ln_shape.row_live: blocks of 64 rows with zero dy / dres are written as zeros without being read: same dx, dropped copy,
+    dgamma and dbeta as the full pass."""
+    rows, d = 1024, 512
+    live = torch.ones(rows // 64, dtype=torch.uint8); live[3:9] = 0; live[12:] = 0
+    rl = live.repeat_interleave(64).bool()
+    x = rnd(rows, d, seed=1) * 2 + 0.3
+    gam = 1 + 0.1 * rnd(d, seed=2)
+    dy = rnd(rows, d, seed=3); dy[~rl] = 0.0
+    dres = rnd(rows, d, seed=4); dres[~rl] = 0.0
+    mean = dev(x.mean(1)); rstd = dev(1.0 / (x.var(1, unbiased=False) + 1e-5).sqrt())
+    res = []
+    for hint in (None, dev(live)):
+        dx = torch.full((rows, d), 9.0, device=DEV); dxd = torch.full((rows, d), 9.0, dtype=dt, device=DEV)
+        dg, db = torch.zeros(d, device=DEV), torch.zeros(d, device=DEV)
+        ws = torch.empty(ops.layernorm_bwd_ws(rows, d), device=DEV)
+        ops.layernorm_bwd(dev(dy, dt), dev(x), dev(gam), mean, rstd, dx, dg, db, ws, dres=dev(dres), dx_drop=dxd,
+                          dropout=ops.drop(0.1, 5, 6), row_live=hint)
+        res.append((dx, dxd, dg, db))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    torch.testing.assert_close(res[0][2], res[1][2], rtol=1e-5, atol=1e-4)
+    torch.testing.assert_close(res[0][3], res[1][3], rtol=1e-5, atol=1e-4)
+    assert float(res[1][0][~rl.to(DEV)].abs().max()) == 0.0
+
+
 # ------------------------------------------------------------------ loss scaler
 def test_adam_with_loss_scaler_skips_and_rescales(ops):
     """GradScaler semantics on the device: gradients arrive S times too large; a non-finite norm skips the step (parameters and
