@@ -121,10 +121,11 @@ typedef struct {
   int32_t glu_rows;       /* f > 0: gated-FFN interleave (see above); wgrad form: rows of C / a_colsum are de-interleaved */
   int32_t reserved2;      /* bit 0 (pair dtype, act GELU_SAVE_GRAD / GLU_SAVE): the stored factors get their hi plane only -- the
                              consumer is the single-pass bf16 backward of the mixed precision mode, which never reads the lo plane */
-  const uint8_t* k_live;  /* wgrad form (transA), nullable: k_live[i] == 0 says rows 64 i .. 64 i + 63 of A (64 token positions) are all
-                             zero -- the padded positions of a training step's backward, whose activation gradients are exact
-                             zeros -- and the MFMA kernels leave those k-steps out (K % 64 == 0; same result).  Device memory,
-                             K / 64 bytes. */
+  const uint8_t* k_live;  /* nullable: k_live[i] == 0 says the STORED rows 64 i .. 64 i + 63 of A (64 token positions) are all zero --
+                             the padded positions of a training step's backward, whose activation gradients are exact zeros.
+                             wgrad form (transA): the MFMA kernels leave those k-steps out (K / 64 bytes).  NT form without bias /
+                             residual / accumulate, act NONE or MUL_SAVED: 256-row tiles of nothing but such blocks are written as
+                             zeros without being computed (M / 64 bytes).  Same results either way; a hint, ignored elsewhere. */
 } afm_gemm_desc;
 int afm_gemm(const afm_gemm_desc* d, void* stream);
 

@@ -29,7 +29,8 @@ struct MfmaArgs {
   const void* residual;
   void* pre_act;
   float* a_colsum;
-  const uint8_t* k_live;   // TN only (afm_gemm_desc.k_live)
+  const uint8_t* k_live;   // afm_gemm_desc.k_live: 64-row blocks of A's stored rows (TN: k-steps; NT: row blocks of A and C)
+  int live_off;            // NT, persistent kernels: LDS byte offset of the live / dead tile lists (0: no hint in use)
   int act, accumulate;
   int tiles_m, tiles_n;
   int ksplit, kchunk;  // TN only
@@ -499,6 +500,53 @@ __device__ __forceinline__ void epilogue_staged_bf16(const MfmaArgs& g, float* s
   else epilogue_staged_e16<WM, EPI, false>(g, stg, bias_lds, acc, mw, nw, lane);
 }
 
+// ------------------------------------------------------------------------------------------ NT: padded row tiles
+// afm_gemm_desc.k_live for the NT form (A's rows are token positions; no bias / residual / accumulate, act NONE or x saved): a tile
+// whose TBM rows of A are all padding has a zero product.  Each workgroup splits the tiles of its strided walk into a live list (the
+// ring and the main loop only ever see those) and a dead list, whose C tiles it writes as zeros before the ring starts.
+#define NT_LIVE_MAX 120
+#define NT_LIVE_BYTES (4 * (2 * NT_LIVE_MAX + 2))
+template <int TBM, int TBN, bool C16, int NTHREADS>
+__device__ __forceinline__ void nt_tile_lists(const MfmaArgs& g, int* list, int tlo, int thi, int nbx, int bx) {
+  const int t = threadIdx.x, lane = t & 63;
+  int* dead = list + 1 + NT_LIVE_MAX;        // list[0] / dead[0] = counts
+  if (t < 64) {
+    // every workgroup of the XCD scans the XCD's whole tile range and keeps every nbx-th LIVE tile (and every nbx-th dead one):
+    // with the plain strided walk the workgroups that own the tails of the sequences would get nothing but dead tiles
+    int nl = 0, nd = 0, il = 0, id = 0;      // kept so far; live / dead tiles seen so far
+    for (int t0 = tlo; t0 < thi; t0 += 64) {
+      const int tt = t0 + lane;
+      const bool valid = tt < thi;
+      bool live = false;
+      if (valid) {
+        const int mb = (tt / g.tiles_n) * (TBM / 64);
+#pragma unroll
+        for (int i = 0; i < TBM / 64; ++i) live |= g.k_live[mb + i] != 0;
+      }
+      const unsigned long long bl = __ballot(valid && live), bd = __ballot(valid && !live), lt = (1ull << lane) - 1ull;
+      const int li = il + __popcll(bl & lt), di = id + __popcll(bd & lt);        // this tile's index among the live / dead ones
+      const bool mine_l = valid && live && (li % nbx) == bx, mine_d = valid && !live && (di % nbx) == bx;
+      const unsigned long long ml = __ballot(mine_l), md = __ballot(mine_d);
+      if (mine_l) list[1 + nl + __popcll(ml & lt)] = tt;
+      if (mine_d) dead[1 + nd + __popcll(md & lt)] = tt;
+      nl += __popcll(ml); nd += __popcll(md);
+      il += __popcll(bl); id += __popcll(bd);
+    }
+    if (lane == 0) { list[0] = nl; dead[0] = nd; }
+  }
+  __syncthreads();
+  const int nd = dead[0];
+  constexpr int EB = C16 ? 2 : 4, PER = 16 / EB, CPR = TBN / PER;   // 16-byte chunks per tile row
+  for (int i = 0; i < nd; ++i) {
+    const int tt = dead[1 + i];
+    const int m0 = (tt / g.tiles_n) * TBM, n0 = (tt % g.tiles_n) * TBN;
+    for (int c = t; c < TBM * CPR; c += NTHREADS) {
+      const int r = c / CPR, cc = (c % CPR) * PER;
+      if (n0 + cc < g.N) *(uint4*)((char*)g.C + ((int64_t)(m0 + r) * g.ldc + n0 + cc) * EB) = make_uint4(0u, 0u, 0u, 0u);
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------ NT, persistent ring
 // One workgroup per CU walks a contiguous range of output tiles of its XCD; the LDS-DMA ring keeps
 // running ACROSS tiles (the first k-steps of the next tile are in flight while the current tile
@@ -530,7 +578,13 @@ __global__ __launch_bounds__(64 * NWM * NWN) void k_gemm_nt_pring(MfmaArgs g) {
   const int xcd = blockIdx.x & 7, bx = blockIdx.x >> 3, nbx = gridDim.x >> 3;
   const int tpx = (ntiles + 7) >> 3;
   const int tlo = xcd * tpx, thi = min(ntiles, tlo + tpx);
-  auto tile_of = [&](int it) { const int tt = tlo + it * nbx + bx; return tt < thi ? tt : -1; };
+  int* const tlist = (int*)(lds + g.live_off);
+  if (g.live_off) nt_tile_lists<TBM, TBN, C_BF16, 64 * NW>(g, tlist, tlo, thi, nbx, bx);
+  auto tile_of = [&](int it) {
+    if (g.live_off) return it < tlist[0] ? tlist[1 + it] : -1;
+    const int tt = tlo + it * nbx + bx;
+    return tt < thi ? tt : -1;
+  };
   const int nk = g.K / 64;
 
   const e16* src[NIW];
@@ -671,7 +725,15 @@ static int launch_nt_pring(MfmaArgs& g, hipStream_t st, int blocks_per_cu) {
   const bool rows16 = (g.N % 8) == 0 && (g.ldc % 8) == 0;
   const bool modes_ok = C_BF16 ? (!g.residual && !g.accumulate) : true;
   g.bias_in_lds = rows16 && modes_ok && ring * blocks_per_cu + bias_bytes * blocks_per_cu <= 160 * 1024 ? 1 : 0;
-  const int shm = ring + (g.bias_in_lds ? bias_bytes : 0);
+  int shm = ring + (g.bias_in_lds ? bias_bytes : 0);
+  g.live_off = 0;
+  if (g.k_live && TBM % 64 == 0 && (g.M % TBM) == 0 && blocks_per_cu == 1 && shm + NT_LIVE_BYTES <= 160 * 1024) {
+    int grid0 = 256;
+    const int nt0 = g.tiles_m * g.tiles_n;
+    if (grid0 > ((nt0 + 7) / 8) * 8) grid0 = ((nt0 + 7) / 8) * 8;
+    const int tpx0 = (nt0 + 7) / 8, nbx0 = grid0 / 8;
+    if ((tpx0 + nbx0 - 1) / nbx0 <= NT_LIVE_MAX) { g.live_off = shm; shm += NT_LIVE_BYTES; }
+  }
   auto kern = k_gemm_nt_pring<C_BF16, NWM, NWN, S, ABL, WM, EPI, EDGE>;
   static AfmOncePerDevice attr_shm;   // per instantiation and per device (function attributes are per device)
   if (attr_shm.need()) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -713,7 +775,13 @@ __global__ __launch_bounds__(64 * (8 + NL)) void k_gemm_nt_ws(MfmaArgs g) {
   const int xcd = blockIdx.x & 7, bx = blockIdx.x >> 3, nbx = gridDim.x >> 3;
   const int tpx = (ntiles + 7) >> 3;
   const int tlo = xcd * tpx, thi = min(ntiles, tlo + tpx);
-  auto tile_of = [&](int it) { const int tt = tlo + it * nbx + bx; return tt < thi ? tt : -1; };
+  int* const tlist = (int*)(lds + g.live_off);
+  if (g.live_off) nt_tile_lists<TBM, TBN, C_BF16, 64 * (NW + NL)>(g, tlist, tlo, thi, nbx, bx);
+  auto tile_of = [&](int it) {
+    if (g.live_off) return it < tlist[0] ? tlist[1 + it] : -1;
+    const int tt = tlo + it * nbx + bx;
+    return tt < thi ? tt : -1;
+  };
   auto tile_full = [&](int tile) {
     const int m0 = (tile / g.tiles_n) * TBM, n0 = (tile % g.tiles_n) * TBN;
     return g.bias_in_lds && m0 + TBM <= g.M && n0 + TBN <= g.N;
@@ -877,7 +945,15 @@ static int launch_nt_ws(MfmaArgs& g, hipStream_t st) {
   const bool modes_ok = C_BF16 ? (!g.residual && !g.accumulate) : true;
   constexpr bool GLU_EPI = EPI == EPI_GLU || EPI == EPI_GLU_SG || EPI == EPI_GLU_BWD;
   g.bias_in_lds = rows16 && modes_ok && (GLU_EPI || ring + bias_bytes <= 160 * 1024) ? 1 : 0;
-  const int shm = ring + (g.bias_in_lds && !GLU_EPI ? bias_bytes : 0);
+  int shm = ring + (g.bias_in_lds && !GLU_EPI ? bias_bytes : 0);
+  g.live_off = 0;
+  if (g.k_live && (g.M % TBM) == 0 && shm + NT_LIVE_BYTES <= 160 * 1024) {
+    int grid0 = 256;
+    const int nt0 = g.tiles_m * g.tiles_n;
+    if (grid0 > ((nt0 + 7) / 8) * 8) grid0 = ((nt0 + 7) / 8) * 8;
+    const int tpx0 = (nt0 + 7) / 8, nbx0 = grid0 / 8;
+    if ((tpx0 + nbx0 - 1) / nbx0 <= NT_LIVE_MAX) { g.live_off = shm; shm += NT_LIVE_BYTES; }
+  }
   auto kern = k_gemm_nt_ws<C_BF16, NL, ABL, EPI>;
   static AfmOncePerDevice attr_done;   // per instantiation
   if (attr_done.need()) {
@@ -1415,7 +1491,7 @@ int AFM_E16_FN(afm_gemm_mfma_try)(const afm_gemm_desc* d, hipStream_t st) {
   g.act = d->act; g.accumulate = d->accumulate;
   g.dd = afm_make_drop(&d->drop);
   g.tiles_m = (d->M + BM - 1) / BM; g.tiles_n = (d->N + BN - 1) / BN;
-  g.ksplit = 1; g.kchunk = d->K; g.bias_in_lds = 0;
+  g.ksplit = 1; g.kchunk = d->K; g.bias_in_lds = 0; g.live_off = 0;
   g.glu_f = d->glu_rows;
   g.stamps = nullptr;
 #ifdef AFM_GEMM_ABLATIONS
@@ -1424,6 +1500,10 @@ int AFM_E16_FN(afm_gemm_mfma_try)(const afm_gemm_desc* d, hipStream_t st) {
   if (!aligned16(d->A) || !aligned16(d->B) || (d->lda & 7) || (d->ldb & 7)) return AFM_ERR_UNSUPPORTED;
   if (!d->transA && d->transB) {  // NT
     if ((d->K & 7) || d->K < 32 || d->N < 16) return AFM_ERR_UNSUPPORTED;
+    // row hint (k_live): only where a zero row of A means a zero row of C, and C can be zero-filled in 16-byte pieces
+    if (d->bias || d->residual || d->accumulate || (d->act != AFM_ACT_NONE && d->act != AFM_ACT_MUL_SAVED) ||
+        (d->pre_act && d->act == AFM_ACT_NONE) || d->drop.p > 0.f || (d->N & 7) || (d->ldc & 7) || !aligned16(d->C) || (d->M & 63))
+      g.k_live = nullptr;
     if (d->bias && !aligned16(d->bias)) return AFM_ERR_UNSUPPORTED;
     if (!aligned16(d->C) || (d->residual && !aligned16(d->residual)) || (d->pre_act && !aligned16(d->pre_act)))
       return AFM_ERR_UNSUPPORTED;

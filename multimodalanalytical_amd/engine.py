@@ -279,6 +279,8 @@ class Seq2SeqEngine:
         if out is None:
             out = self._empty_b(dy.shape[0], cols, out_dtype)
         kw = dict(accumulate=accumulate, algo=self.algo, act=act, pre_act=self._hb(pre_act), dropout=dropout)
+        if self.lowp and torch.is_tensor(dy):
+            kw["k_live"] = self._live.get(dy.shape[0])      # row tiles of nothing but padded positions: zeros in, zeros out
         if self.lowp:
             wt = self._hb(self.wt[name][:, r0:r1])  # (cols, n): NT form for the MFMA kernel
             return ops.gemm(dy, wt, out, trans_b=True, **kw)
@@ -627,7 +629,7 @@ class Seq2SeqEngine:
                 return None
             if weight_t is not None:
                 dh = self._empty_b(rows, d)
-                ops.gemm(dh_from, weight_t, dh, trans_b=True, algo=self.algo)
+                ops.gemm(dh_from, weight_t, dh, trans_b=True, algo=self.algo, k_live=self._live.get(rows))
             else:
                 dh = self._dgrad(dh_from, p + "linear1.weight", k * f, d)
             return self._ln_bwd(dh, p + norm, saved, "lnf", dres=dx1, next_site=next_site)
@@ -1134,7 +1136,7 @@ class Seq2SeqEngine:
                 # nothing to add to (no alignment head): the GEMM writes the 16-bit operand of the encoder's final LayerNorm
                 # backward itself, instead of an fp32 matrix and a cast kernel behind it (the same rounding, once)
                 dmem_c = self._empty_b(B * S, d)
-                ops.gemm(dkv_all, self._hb(self.wt_kv_all), dmem_c, trans_b=True, algo=self.algo)
+                ops.gemm(dkv_all, self._hb(self.wt_kv_all), dmem_c, trans_b=True, algo=self.algo, k_live=self._live.get(B * S))
             else:
                 if dmem is None:
                     dmem = torch.empty(B * S, d, dtype=torch.float32, device=self.dev)

@@ -142,8 +142,10 @@ def gemm_desc(a: torch.Tensor, b: torch.Tensor, c: torch.Tensor, *, trans_a=Fals
     d.glu_rows = int(glu_rows)
     d.reserved2 = 1 if sg_hi_only else 0
     d.drop = dropout
-    if k_live is not None:      # wgrad form: one byte per 64 token rows of `a`, 0 = all of them zero (padding)
-        assert trans_a and k_live.dtype == torch.uint8 and k_live.is_contiguous() and K % 64 == 0 and k_live.numel() == K // 64
+    if k_live is not None:      # one byte per 64 stored rows of `a` (token positions), 0 = all of them zero (padding)
+        nrows = K if trans_a else M
+        assert (trans_a or trans_b) and k_live.dtype == torch.uint8 and k_live.is_contiguous()
+        assert nrows % 64 == 0 and k_live.numel() == nrows // 64
     d.k_live = _ptr(k_live)
     return d
 

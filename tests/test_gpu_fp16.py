@@ -408,6 +408,27 @@ def test_wgrad_leaves_out_padded_token_blocks(ops, dt):
         torch.testing.assert_close(b0, b1, rtol=1e-5, atol=2e-4)
 
 
+@pytest.mark.parametrize("N,K,act", [(512, 512, 0), (512, 2048, 0), (2048, 512, 5), (1536, 512, 0)])
+def test_nt_gemm_writes_padded_row_tiles_as_zeros(ops, N, K, act):
+    """afm_gemm_desc.k_live on the NT form (dgrad): row tiles of A that are nothing but padded positions (zero rows) come out as
+    zero rows without being computed -- the same C as the full product, through the loader-wave and the 256 x 256 kernels."""
+    M = 4096
+    live = torch.ones(M // 64, dtype=torch.uint8)
+    live[4:12] = 0; live[13] = 0; live[20:44] = 0; live[60:] = 0       # whole dead 256-row tiles, a tile with one dead block, a dead tail
+    rl = live.repeat_interleave(64).bool()
+    a = rnd(M, K, seed=1) * 0.5; a[~rl] = 0.0
+    ad, wd = dev(a, H16), dev(rnd(N, K, seed=2) * 0.1, H16)
+    pre = dev(rnd(M, N, seed=3), H16) if act == 5 else None
+    outs = []
+    for hint in (None, dev(live)):
+        c = torch.full((M, N), 3.0, dtype=H16, device=DEV)
+        ops.gemm(ad, wd, c, act=act, pre_act=pre, k_live=hint)
+        assert ops.last_algo() in ("mfma_nt", "mfma_nt_256")
+        outs.append(c)
+    assert torch.equal(outs[0], outs[1])
+    assert float(outs[1][~rl.to(DEV)].abs().max()) == 0.0
+
+
 @pytest.mark.parametrize("dt", [H16, torch.float32])
 def test_layernorm_backward_skips_padded_row_blocks(ops, dt):
     """afm_ln_shape.row_live: blocks of 64 rows with zero dy / dres are written as zeros without being read: same dx, dropped copy,
