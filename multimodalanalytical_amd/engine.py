@@ -562,9 +562,11 @@ class Seq2SeqEngine:
         delta = torch.empty_like(lse)
         ldg = ops._ld(dqkv)
         qkv_b, shp = self._hb(qkv), self._shape_b(shp)
-        # padded positions are masked as keys everywhere and take no part in the loss: their rows of every activation gradient
-        # are exact zeros, so the self-attention backward may skip them as queries (include/afm_hip.h, reserved bit 6)
-        shp.reserved |= 64
+        # encoder: padded positions are masked as keys everywhere and take no part in the loss: their rows of every activation
+        # gradient are exact zeros, so the self-attention backward may skip them as queries (include/afm_hip.h, reserved bit 6).
+        # (Not the decoder's: whether its padded rows carry a gradient depends on the labels the caller passes.)
+        if self.row_skip and not shp.causal:
+            shp.reserved |= 64
         ops.attn_bwd(shp, qkv_b[:, :d], qkv_b[:, d:2 * d], qkv_b[:, 2 * d:], self._hb(a), da, lse, delta,
                      dqkv[:, :d], dqkv[:, d:2 * d], dqkv[:, 2 * d:], ldg, ldg, ldg)
         self._wgrad(dqkv, h, p + "self_attn.in_proj_weight", 3 * d, d, bias_name=p + "self_attn.in_proj_bias")
@@ -1105,7 +1107,10 @@ class Seq2SeqEngine:
         # blocks hold nothing else (include/afm_hip.h: afm_gemm_desc.k_live, afm_ln_shape.row_live).
         self._live = {}
         if self.row_skip and B * S != B * T:
-            for L, pad in ((S, saved.get("key_pad")), (T, saved.get("tgt_pad"))):
+            tgt_pad = saved.get("tgt_pad")
+            if tgt_pad is not None:      # a padded decoder row is dead only if it has no label either (the caller's labels are its own)
+                tgt_pad = tgt_pad.view(B, T).bool() & (lab.view(B, T) == -100)
+            for L, pad in ((S, saved.get("key_pad")), (T, tgt_pad)):
                 if pad is not None and L % 64 == 0:
                     self._live[B * L] = (pad.view(B, L // 64, 64) == 0).any(-1).to(torch.uint8).reshape(-1).contiguous()
         dlog = self._empty_b(B * T, self.V)
