@@ -404,7 +404,7 @@ __global__ __launch_bounds__(512, 2) void k_attn_fwd_st(AttnM a, const e16* __re
 // Per 64-key tile: S^T and dP^T (keys in registers, query on the lane), then
 // dQ^T[d][q] += sum_key K^T[d][key] dS^T[key][q].  Also writes delta = rowsum(dO * O).
 template <int DROP>
-__global__ __launch_bounds__(256, 2) void k_attn_bwd_dq_mfma(AttnM a, const e16* __restrict__ Q,
+__global__ __launch_bounds__(256, 3) void k_attn_bwd_dq_mfma(AttnM a, const e16* __restrict__ Q,
                                                           const e16* __restrict__ K,
                                                           const e16* __restrict__ V,
                                                           const e16* __restrict__ O,
