@@ -124,7 +124,7 @@ typedef struct {
   const uint8_t* k_live;  /* nullable: k_live[i] == 0 says the STORED rows 64 i .. 64 i + 63 of A (64 token positions) are all zero --
                              the padded positions of a training step's backward, whose activation gradients are exact zeros.
                              wgrad form (transA): the MFMA kernels leave those k-steps out (K / 64 bytes).  NT form without bias /
-                             residual / accumulate, act NONE or MUL_SAVED: 256-row tiles of nothing but such blocks are written as
+                             residual / accumulate, act NONE, MUL_SAVED or GLU_BWD: 256-row tiles of nothing but such blocks are written as
                              zeros without being computed (M / 64 bytes).  Same results either way; a hint, ignored elsewhere. */
 } afm_gemm_desc;
 int afm_gemm(const afm_gemm_desc* d, void* stream);

@@ -506,7 +506,7 @@ __device__ __forceinline__ void epilogue_staged_bf16(const MfmaArgs& g, float* s
 // ring and the main loop only ever see those) and a dead list, whose C tiles it writes as zeros before the ring starts.
 #define NT_LIVE_MAX 120
 #define NT_LIVE_BYTES (4 * (2 * NT_LIVE_MAX + 2))
-template <int TBM, int TBN, bool C16, int NTHREADS>
+template <int TBM, int TBN, bool C16, int NTHREADS, int CM = 1>      // CM = 2: the gated dgrad form, whose C tile is 2 x TBN columns wide
 __device__ __forceinline__ void nt_tile_lists(const MfmaArgs& g, int* list, int tlo, int thi, int nbx, int bx) {
   const int t = threadIdx.x, lane = t & 63;
   int* dead = list + 1 + NT_LIVE_MAX;        // list[0] / dead[0] = counts
@@ -536,13 +536,13 @@ __device__ __forceinline__ void nt_tile_lists(const MfmaArgs& g, int* list, int 
   }
   __syncthreads();
   const int nd = dead[0];
-  constexpr int EB = C16 ? 2 : 4, PER = 16 / EB, CPR = TBN / PER;   // 16-byte chunks per tile row
+  constexpr int EB = C16 ? 2 : 4, PER = 16 / EB, CPR = CM * TBN / PER;   // 16-byte chunks per tile row
   for (int i = 0; i < nd; ++i) {
     const int tt = dead[1 + i];
-    const int m0 = (tt / g.tiles_n) * TBM, n0 = (tt % g.tiles_n) * TBN;
+    const int m0 = (tt / g.tiles_n) * TBM, n0 = (tt % g.tiles_n) * TBN * CM;
     for (int c = t; c < TBM * CPR; c += NTHREADS) {
       const int r = c / CPR, cc = (c % CPR) * PER;
-      if (n0 + cc < g.N) *(uint4*)((char*)g.C + ((int64_t)(m0 + r) * g.ldc + n0 + cc) * EB) = make_uint4(0u, 0u, 0u, 0u);
+      if (n0 + cc < CM * g.N) *(uint4*)((char*)g.C + ((int64_t)(m0 + r) * g.ldc + n0 + cc) * EB) = make_uint4(0u, 0u, 0u, 0u);
     }
   }
 }
@@ -776,7 +776,7 @@ __global__ __launch_bounds__(64 * (8 + NL)) void k_gemm_nt_ws(MfmaArgs g) {
   const int tpx = (ntiles + 7) >> 3;
   const int tlo = xcd * tpx, thi = min(ntiles, tlo + tpx);
   int* const tlist = (int*)(lds + g.live_off);
-  if (g.live_off) nt_tile_lists<TBM, TBN, C_BF16, 64 * (NW + NL)>(g, tlist, tlo, thi, nbx, bx);
+  if (g.live_off) nt_tile_lists<TBM, TBN, C_BF16, 64 * (NW + NL), (EPI == EPI_GLU_BWD ? 2 : 1)>(g, tlist, tlo, thi, nbx, bx);
   auto tile_of = [&](int it) {
     if (g.live_off) return it < tlist[0] ? tlist[1 + it] : -1;
     const int tt = tlo + it * nbx + bx;
@@ -1501,7 +1501,7 @@ int AFM_E16_FN(afm_gemm_mfma_try)(const afm_gemm_desc* d, hipStream_t st) {
   if (!d->transA && d->transB) {  // NT
     if ((d->K & 7) || d->K < 32 || d->N < 16) return AFM_ERR_UNSUPPORTED;
     // row hint (k_live): only where a zero row of A means a zero row of C, and C can be zero-filled in 16-byte pieces
-    if (d->bias || d->residual || d->accumulate || (d->act != AFM_ACT_NONE && d->act != AFM_ACT_MUL_SAVED) ||
+    if (d->bias || d->residual || d->accumulate || (d->act != AFM_ACT_NONE && d->act != AFM_ACT_MUL_SAVED && d->act != AFM_ACT_GLU_BWD) ||
         (d->pre_act && d->act == AFM_ACT_NONE) || d->drop.p > 0.f || (d->N & 7) || (d->ldc & 7) || !aligned16(d->C) || (d->M & 63))
       g.k_live = nullptr;
     if (d->bias && !aligned16(d->bias)) return AFM_ERR_UNSUPPORTED;

@@ -640,7 +640,7 @@ class Seq2SeqEngine:
             # [du | dv] (interleaved) = (dy W2) * saved factors in the dgrad epilogue; weight gradient rows de-interleaved by
             # the wgrad kernel into the reference's [linear1 ; gate] layout; dh through the interleaved transpose
             ops.gemm(dy, self._hb(self.wt[p + "linear2.weight"]), duv, trans_b=True, act=ACT_GLU_BWD, pre_act=self._hb(uv),
-                     algo=self.algo, glu_rows=f)
+                     algo=self.algo, glu_rows=f, k_live=self._live.get(rows))
             gw = self.G(p + "linear1.weight", 2 * f, d)
             gb = self.ps.vec_span(self.ps.grad, p + "linear1.bias", 0, 2 * f)
             self._wgrad_raw(duv, self._hb(h), gw, gb, glu_rows=f)

@@ -429,6 +429,24 @@ def test_nt_gemm_writes_padded_row_tiles_as_zeros(ops, N, K, act):
     assert float(outs[1][~rl.to(DEV)].abs().max()) == 0.0
 
 
+def test_gated_dgrad_writes_padded_row_tiles_as_zeros(ops):
+    """The same hint on the gated FFN's dgrad form (act GLU_BWD: C is M x 2f, [dg * saved_a | dg * saved_b] interleaved)."""
+    M, f, d = 2048, 256, 512
+    live = torch.ones(M // 64, dtype=torch.uint8); live[4:8] = 0; live[9] = 0; live[16:] = 0
+    rl = live.repeat_interleave(64).bool()
+    dy = rnd(M, d, seed=1) * 0.5; dy[~rl] = 0.0
+    dyd, w2t = dev(dy, H16), dev(rnd(f, d, seed=2) * 0.1, H16)          # (f x d): the NT operand of dg = dy W2
+    saved = dev(rnd(M, 2 * f, seed=3), H16)
+    outs = []
+    for hint in (None, dev(live)):
+        c = torch.full((M, 2 * f), 3.0, dtype=H16, device=DEV)
+        ops.gemm(dyd, w2t, c, act=8, pre_act=saved, glu_rows=f, algo=2, k_live=hint)
+        assert "glu" in ops.last_algo()
+        outs.append(c)
+    assert torch.equal(outs[0], outs[1])
+    assert float(outs[1][~rl.to(DEV)].abs().max()) == 0.0
+
+
 @pytest.mark.parametrize("dt", [H16, torch.float32])
 def test_layernorm_backward_skips_padded_row_blocks(ops, dt):
     """afm_ln_shape.row_live: blocks of 64 rows with zero dy / dres are written as zeros without being read: same dx, dropped copy,
