@@ -375,7 +375,31 @@ __device__ __forceinline__ float afm_drop32(const DropDev& d, uint32_t idx, floa
 }
 // DROP_ON is the wave-uniform "this site drops" bit as a template argument: tested per element (`drop_on ? hash : 1`) it compiled
 // to a scalar branch around every element's hash chain, 128 basic blocks per wave tile that nothing could be scheduled across.
-template <int WM, int EPI, bool DROP_ON>
+// Output stores of the persistent NT kernels are nontemporal.  Measured (tools/experiments/nt_epi_burst.py, round 4, QKV 131072 x
+// 1536 x 512 on the loader-wave kernel): main loop alone 183 us; + epilogue with its stores aimed at one L2-resident tile 208 us;
+// + the real stores, default policy 252 us, sc1 243 us, nt 226 us (FFN-up shape: 354 / 333 / 299 us).  Holding the stores back and
+// issuing them one per eighth of the next tile's k-steps changed nothing (260 us plain, 228 us nt): the cost is not the burst but the
+// output lines themselves, which the write-back L2 keeps at the expense of the A panel and the weight tile.
+#ifndef AFM_C_STORE_AUX
+#define AFM_C_STORE_AUX 2
+#endif
+// 16-byte store of an output piece with a cache policy (aux: 0 plain, 2 nt, 16 sc1 = written through and dropped from the XCD's L2,
+// MI355X_MICROARCH.md "stores of each flavour"): the output stream of a GEMM is never read again by this kernel, and left in the
+// write-back L2 it evicts the weight tile and the A panels the other column tiles of the row are about to re-read.
+typedef unsigned int uint2_t __attribute__((ext_vector_type(2)));
+template <int AUX>
+__device__ __forceinline__ void store16_policy(void* base, uint64_t byte_off, uint4 v) {
+  typedef unsigned int u32x4_nt __attribute__((ext_vector_type(4)));
+  if constexpr (AUX == 0) *(uint4*)((char*)base + byte_off) = v;
+  else if constexpr (AUX == 2) __builtin_nontemporal_store(__builtin_bit_cast(u32x4_nt, v), (u32x4_nt*)((char*)base + byte_off));
+  else {   // (timing experiments only: 32-bit buffer offsets)
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(base, 0, -1, 0x00020000);
+    typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), rs, (int)(uint32_t)byte_off, 0, AUX);
+  }
+}
+
+template <int WM, int EPI, bool DROP_ON, int CAUX = 0>
 __device__ __forceinline__ void epilogue_staged_e16(const MfmaArgs& g, float* stg, const float* bias_lds,
                                                     f32x4 (&acc)[4][WM], int mw, int nw, int lane) {
   const int fr = lane & 15, fq = lane >> 4;
@@ -424,10 +448,11 @@ __device__ __forceinline__ void epilogue_staged_e16(const MfmaArgs& g, float* st
           gv[k] = y * x[4 + k] * keep; sa[k] = yp * x[4 + k] * keep; sb[k] = y * keep;
         }
         e16x4 o = {(e16)gv[0], (e16)gv[1], (e16)gv[2], (e16)gv[3]};
-        *(e16x4*)((e16*)g.C + rowi * g.ldc + hcol) = o;
+        if constexpr (CAUX != 0) __builtin_nontemporal_store(__builtin_bit_cast(uint2_t, o), (uint2_t*)((e16*)g.C + rowi * g.ldc + hcol));
+        else *(e16x4*)((e16*)g.C + rowi * g.ldc + hcol) = o;
         if (EPI == EPI_GLU_SG) {
           e16x8 sv = {(e16)sa[0], (e16)sa[1], (e16)sa[2], (e16)sa[3], (e16)sb[0], (e16)sb[1], (e16)sb[2], (e16)sb[3]};
-          *(e16x8*)((e16*)g.pre_act + rowi * g.N + n) = sv;
+          store16_policy<CAUX>(g.pre_act, (uint64_t)((rowi * g.N + n) * 2), __builtin_bit_cast(uint4, sv));
         }
         continue;
       }
@@ -443,13 +468,14 @@ __device__ __forceinline__ void epilogue_staged_e16(const MfmaArgs& g, float* st
           o0[k] = (e16)(x[k] * (float)s0[k]); o0[4 + k] = (e16)(x[k] * (float)s0[4 + k]);
           o1[k] = (e16)(x[4 + k] * (float)s1[k]); o1[4 + k] = (e16)(x[4 + k] * (float)s1[4 + k]);
         }
-        *(e16x8*)cp = o0; *(e16x8*)(cp + 8) = o1;
+        store16_policy<CAUX>(g.C, (uint64_t)((cp - (e16*)g.C) * 2), __builtin_bit_cast(uint4, o0));
+        store16_policy<CAUX>(g.C, (uint64_t)((cp + 8 - (e16*)g.C) * 2), __builtin_bit_cast(uint4, o1));
         continue;
       }
       if (EPI == EPI_GELU) {
         if (g.pre_act) {
           e16x8 o = {(e16)x[0], (e16)x[1], (e16)x[2], (e16)x[3], (e16)x[4], (e16)x[5], (e16)x[6], (e16)x[7]};
-          *(e16x8*)(pbase + ro) = o;
+          store16_policy<CAUX>(g.pre_act, (uint64_t)((pbase + ro - (e16*)g.pre_act) * 2), __builtin_bit_cast(uint4, o));
         }
 #pragma unroll
         for (int k = 0; k < 8; ++k) x[k] = afm_gelu(x[k]);
@@ -464,7 +490,7 @@ __device__ __forceinline__ void epilogue_staged_e16(const MfmaArgs& g, float* st
           x[k] = y * keep; gp[k] = yp * keep;
         }
         e16x8 o = {(e16)gp[0], (e16)gp[1], (e16)gp[2], (e16)gp[3], (e16)gp[4], (e16)gp[5], (e16)gp[6], (e16)gp[7]};
-        *(e16x8*)(pbase + ro) = o;
+        store16_policy<CAUX>(g.pre_act, (uint64_t)((pbase + ro - (e16*)g.pre_act) * 2), __builtin_bit_cast(uint4, o));
       }
       if (EPI == EPI_MUL) {
         const e16x8 u = uu[q];
@@ -487,17 +513,17 @@ __device__ __forceinline__ void epilogue_staged_e16(const MfmaArgs& g, float* st
         for (int k = 0; k < 8; ++k) x[k] = afm_drop32(g.dd, di + k, x[k]);
       }
       e16x8 o = {(e16)x[0], (e16)x[1], (e16)x[2], (e16)x[3], (e16)x[4], (e16)x[5], (e16)x[6], (e16)x[7]};
-      *(e16x8*)(cbase + ro) = o;
+      store16_policy<CAUX>(g.C, (uint64_t)((cbase + ro - (e16*)g.C) * 2), __builtin_bit_cast(uint4, o));
     }
   }
 }
 
-template <int WM, int EPI>
+template <int WM, int EPI, int CAUX = 0>
 __device__ __forceinline__ void epilogue_staged_bf16(const MfmaArgs& g, float* stg, const float* bias_lds,
                                                      f32x4 (&acc)[4][WM], int mw, int nw, int lane) {
   constexpr bool drops = EPI == EPI_DROP || EPI == EPI_GELU || EPI == EPI_GELU_BWD || EPI == EPI_GELU_SG || EPI == EPI_GLU || EPI == EPI_GLU_SG;
-  if (drops && g.dd.thresh != 0) epilogue_staged_e16<WM, EPI, true>(g, stg, bias_lds, acc, mw, nw, lane);
-  else epilogue_staged_e16<WM, EPI, false>(g, stg, bias_lds, acc, mw, nw, lane);
+  if (drops && g.dd.thresh != 0) epilogue_staged_e16<WM, EPI, true, CAUX>(g, stg, bias_lds, acc, mw, nw, lane);
+  else epilogue_staged_e16<WM, EPI, false, CAUX>(g, stg, bias_lds, acc, mw, nw, lane);
 }
 
 // ------------------------------------------------------------------------------------------ NT: padded row tiles
@@ -699,7 +725,7 @@ __global__ __launch_bounds__(64 * NWM * NWN) void k_gemm_nt_pring(MfmaArgs g) {
       // the slot read by the last k-step is free until the next issue: stage through it
       __builtin_amdgcn_s_barrier();
       float* stg = (float*)(lds + (slot == 0 ? S - 1 : slot - 1) * STAGE) + w * (16 * STG_LD);
-      if constexpr (C_BF16 && EPI != EPI_GENERIC) epilogue_staged_bf16<WM, EPI>(g, stg, bias_lds, acc, m0 + wm * 16 * WM, n0 + wn * 64, lane);
+      if constexpr (C_BF16 && EPI != EPI_GENERIC) epilogue_staged_bf16<WM, EPI, AFM_C_STORE_AUX>(g, stg, bias_lds, acc, m0 + wm * 16 * WM, n0 + wn * 64, lane);
       else epilogue_staged<C_BF16, WM>(g, stg, bias_lds, acc, m0 + wm * 16 * WM, n0 + wn * 64, lane);
     } else if constexpr (EDGE) {
 #pragma unroll
@@ -754,7 +780,7 @@ static int launch_nt_pring(MfmaArgs& g, hipStream_t st, int blocks_per_cu) {
 // take the issue time (and the counted vmcnt waits) off the MFMA waves; the workgroup barrier of each
 // k-step publishes a landed slot and frees the one read a step earlier.  The compute waves issue no
 // LDS-DMA at all, so their epilogue stores need no counted waits.
-template <bool C_BF16, int NL, int ABL = 0, int EPI = EPI_GENERIC>
+template <bool C_BF16, int NL, int ABL = 0, int EPI = EPI_GENERIC, int CAUX = AFM_C_STORE_AUX>
 __global__ __launch_bounds__(64 * (8 + NL)) void k_gemm_nt_ws(MfmaArgs g) {
   constexpr int NWN = 2, NW = 8, WM = 4, S = 3;
   constexpr int TBM = 256, TBN = 128;
@@ -919,8 +945,10 @@ __global__ __launch_bounds__(64 * (8 + NL)) void k_gemm_nt_ws(MfmaArgs g) {
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       float* stg = (float*)(lds + (slot == 0 ? S - 1 : slot - 1) * STAGE) + w * (16 * STG_LD);
-      if constexpr (C_BF16 && EPI != EPI_GENERIC) epilogue_staged_bf16<WM, EPI>(g, stg, bias_lds, acc, m0 + wm * 16 * WM, n0 + wn * 64, lane);
-      else epilogue_staged<C_BF16, WM>(g, stg, bias_lds, acc, m0 + wm * 16 * WM, n0 + wn * 64, lane);
+      // ABL & 8 (timing only): every tile's epilogue writes tile 0 (L2-resident): the epilogue's arithmetic without its HBM stores
+      const int em0 = (ABL & 8) ? 0 : m0, en0 = (ABL & 8) ? 0 : n0;
+      if constexpr (C_BF16 && EPI != EPI_GENERIC) epilogue_staged_bf16<WM, EPI, CAUX>(g, stg, bias_lds, acc, em0 + wm * 16 * WM, en0 + wn * 64, lane);
+      else epilogue_staged<C_BF16, WM>(g, stg, bias_lds, acc, em0 + wm * 16 * WM, en0 + wn * 64, lane);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // staging reads done before the slot is handed back
     } else {
 #pragma unroll
@@ -935,7 +963,7 @@ __global__ __launch_bounds__(64 * (8 + NL)) void k_gemm_nt_ws(MfmaArgs g) {
   }
 }
 
-template <bool C_BF16, int NL, int ABL = 0, int EPI = EPI_GENERIC>
+template <bool C_BF16, int NL, int ABL = 0, int EPI = EPI_GENERIC, int CAUX = AFM_C_STORE_AUX>
 static int launch_nt_ws(MfmaArgs& g, hipStream_t st) {
   constexpr int TBM = 256, TBN = 128, S = 3;
   constexpr int ring = S * (TBM + TBN) * 128;
@@ -954,7 +982,7 @@ static int launch_nt_ws(MfmaArgs& g, hipStream_t st) {
     const int tpx0 = (nt0 + 7) / 8, nbx0 = grid0 / 8;
     if ((tpx0 + nbx0 - 1) / nbx0 <= NT_LIVE_MAX) { g.live_off = shm; shm += NT_LIVE_BYTES; }
   }
-  auto kern = k_gemm_nt_ws<C_BF16, NL, ABL, EPI>;
+  auto kern = k_gemm_nt_ws<C_BF16, NL, ABL, EPI, CAUX>;
   static AfmOncePerDevice attr_done;   // per instantiation
   if (attr_done.need()) {
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -1600,6 +1628,12 @@ int AFM_E16_FN(afm_gemm_mfma_try)(const afm_gemm_desc* d, hipStream_t st) {
       case 244: r = launch_nt_ws<true, 4, 4>(g, st); break;
       case 246: r = launch_nt_ws<true, 4, 6>(g, st); break;
       case 247: r = launch_nt_ws<true, 4, 7>(g, st); break;
+      case 248: r = launch_nt_ws<true, 4, 8, EPI_PLAIN, 0>(g, st); break;    // epilogue without HBM stores (every tile writes tile 0)
+      case 249: r = launch_nt_ws<true, 4, 0, EPI_PLAIN, 0>(g, st); break;    // plain compile-time epilogue, default store policy
+      case 250: r = launch_nt_ws<true, 4, 4, EPI_PLAIN, 0>(g, st); break;    // no epilogue
+      case 252: r = launch_nt_ws<true, 4, 0, EPI_PLAIN, 16>(g, st); break;   // sc1 stores (written through, dropped from L2)
+      case 256: r = launch_nt_ws<true, 4, 0, EPI_PLAIN, 2>(g, st); break;    // nt stores (the shipped policy)
+      case 257: r = launch_nt_ws<true, 4, 0, EPI_PLAIN, 18>(g, st); break;   // sc1 nt
       case 121: r = launch_nt_pring<true, 4, 2, 3, 1>(g, st, 1); break;
       case 122: r = launch_nt_pring<true, 4, 2, 3, 2>(g, st, 1); break;
       case 124: r = launch_nt_pring<true, 4, 2, 3, 4>(g, st, 1); break;

@@ -15,8 +15,11 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 PKG = os.path.dirname(HERE)
 ROOT = os.path.dirname(PKG)
-LIB = os.path.join(PKG, "libafm_hip.so")
-OBJ = os.path.join(HERE, "build")
+# AFM_BUILD_VARIANT=name: an experiment build (usually with AFM_EXTRA_FLAGS) beside the product library, with its own object
+# directory; load it with AFM_LIB_OVERRIDE=<printed path>.  Never set in product runs.
+_VARIANT = os.environ.get("AFM_BUILD_VARIANT", "")
+LIB = os.path.join(PKG, "libafm_hip.so") if not _VARIANT else os.path.join(ROOT, "tools", "experiments", "_abl", f"libafm_{_VARIANT}.so")
+OBJ = os.path.join(HERE, "build" if not _VARIANT else f"build/{_VARIANT}")
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-I" + os.path.join(ROOT, "include"),
          "-I" + HERE, "-Wno-unused-result", "-Wno-unused-value"]
@@ -77,6 +80,7 @@ def build(force=False, verbose=False):
     first one builds, the others find everything fresh), the library is linked to a temporary name and renamed into place,
     and a link stamp (digest of all object digests) forces a relink when an earlier run died between compile and link."""
     os.makedirs(OBJ, exist_ok=True)
+    os.makedirs(os.path.dirname(LIB), exist_ok=True)
     with open(os.path.join(OBJ, ".lock"), "w") as lock:
         fcntl.flock(lock, fcntl.LOCK_EX)
         try:

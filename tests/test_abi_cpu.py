@@ -38,6 +38,25 @@ def test_struct_layouts_match_the_header():
     assert L.PatchDesc.mean.offset == 32 and ctypes.sizeof(L.PatchDesc) == 48
 
 
+def test_integration_md_struct_example_matches_the_library():
+    """The ctypes structs INTEGRATION.md shows a maintainer are executed as written and held to the library's own sizes
+    (the example had lost `k_live`, 8 bytes short of the ABI-4 descriptor)."""
+    from multimodalanalytical_amd import lib as L
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    blocks = re.findall(r"```python\n(.*?)```", text, flags=re.S)
+    block = next(b for b in blocks if "class AfmGemmDesc" in b)
+    classes = block[block.index("class AfmDropout"):block.index("lib = ctypes.CDLL")]
+    ns = {"ctypes": ctypes}
+    exec(compile(classes, "INTEGRATION.md", "exec"), ns)
+    handle = L.load()
+    assert ctypes.sizeof(ns["AfmDropout"]) == handle.afm_struct_size(0)
+    assert ctypes.sizeof(ns["AfmGemmDesc"]) == handle.afm_struct_size(1)
+    assert [f[0] for f in ns["AfmGemmDesc"]._fields_] == [f[0] for f in L.GemmDesc._fields_]
+    for name, _ in L.GemmDesc._fields_:
+        assert getattr(ns["AfmGemmDesc"], name).offset == getattr(L.GemmDesc, name).offset, name
+    assert "afm_abi_version() == %d" % L.ABI_VERSION in text
+
+
 def test_patch_count_is_host_side():
     """afm_patch_count is pure host arithmetic: usable here (sizes of PatchPreprocessor outputs, patches.py:79-96)."""
     from multimodalanalytical_amd import lib as L
