@@ -452,6 +452,7 @@ typedef struct afm_comm afm_comm;
 int afm_comm_unique_id(void* out128);
 int afm_comm_create(afm_comm** out, const void* id128, int32_t rank, int32_t world);
 int afm_allreduce_bucket(afm_comm* comm, float* buf, int64_t n, void* stream);      /* buf[0..n) = sum over ranks, in place */
+int afm_comm_count(afm_comm* comm, int32_t* rank, int32_t* world);                 /* what RCCL itself reports: ncclCommUserRank / ncclCommCount */
 int afm_comm_destroy(afm_comm* comm);
 
 #ifdef __cplusplus

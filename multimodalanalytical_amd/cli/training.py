@@ -33,7 +33,7 @@ import torch
 
 from ..config import compose, wrapper_kwargs
 from ..params import PATCH_TYPES, TEXT_TYPES
-from ..trainer import sync_flag, calculate_training_steps
+from ..trainer import barrier, sync_flag, calculate_training_steps
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 DEFAULT_CONFIG_DIR = os.path.join(os.path.dirname(os.path.dirname(HERE)), "configs")
@@ -241,7 +241,7 @@ def run(cfg: Dict[str, Any], own: Dict[str, str]) -> Dict[str, Any]:
         shutil.copy(best, os.path.join(ckpt_dir, "best.ckpt"))
         result["best_model_path"] = best
     if world > 1:
-        dist.barrier()
+        barrier()
     # reload the best model and evaluate the test shard with beam search (cli/training.py:167-249)
     best_model = new_model()
     load_checkpoint(os.path.join(ckpt_dir, "best.ckpt"), best_model)

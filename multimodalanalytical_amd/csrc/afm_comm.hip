@@ -15,6 +15,8 @@ struct Rccl {
   ncclResult_t (*comm_init_rank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
   ncclResult_t (*all_reduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*comm_destroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*comm_count)(const ncclComm_t, int*) = nullptr;
+  ncclResult_t (*comm_user_rank)(const ncclComm_t, int*) = nullptr;
   bool ok = false;
 };
 Rccl g_rccl;
@@ -33,7 +35,10 @@ void load_rccl() {
   g_rccl.comm_init_rank = (decltype(g_rccl.comm_init_rank))dlsym(g_rccl.h, "ncclCommInitRank");
   g_rccl.all_reduce = (decltype(g_rccl.all_reduce))dlsym(g_rccl.h, "ncclAllReduce");
   g_rccl.comm_destroy = (decltype(g_rccl.comm_destroy))dlsym(g_rccl.h, "ncclCommDestroy");
-  g_rccl.ok = g_rccl.get_unique_id && g_rccl.comm_init_rank && g_rccl.all_reduce && g_rccl.comm_destroy;
+  g_rccl.comm_count = (decltype(g_rccl.comm_count))dlsym(g_rccl.h, "ncclCommCount");
+  g_rccl.comm_user_rank = (decltype(g_rccl.comm_user_rank))dlsym(g_rccl.h, "ncclCommUserRank");
+  g_rccl.ok = g_rccl.get_unique_id && g_rccl.comm_init_rank && g_rccl.all_reduce && g_rccl.comm_destroy && g_rccl.comm_count &&
+              g_rccl.comm_user_rank;
 }
 bool rccl() {
   std::call_once(g_once, load_rccl);
@@ -70,6 +75,14 @@ extern "C" int afm_allreduce_bucket(afm_comm* c, float* buf, int64_t n, void* st
   if (!c || !buf || n < 0) return AFM_ERR_ARG;
   if (n == 0) return AFM_OK;
   if (g_rccl.all_reduce(buf, buf, (size_t)n, ncclFloat32, ncclSum, c->comm, (hipStream_t)stream) != ncclSuccess) return AFM_ERR_LAUNCH;
+  return AFM_OK;
+}
+
+extern "C" int afm_comm_count(afm_comm* c, int32_t* rank, int32_t* world) {
+  if (!c || !rank || !world) return AFM_ERR_ARG;
+  int r = -1, w = -1;
+  if (g_rccl.comm_user_rank(c->comm, &r) != ncclSuccess || g_rccl.comm_count(c->comm, &w) != ncclSuccess) return AFM_ERR_LAUNCH;
+  *rank = r; *world = w;
   return AFM_OK;
 }
 

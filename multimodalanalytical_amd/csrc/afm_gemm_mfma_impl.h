@@ -997,6 +997,8 @@ static int launch_nt_ws(MfmaArgs& g, hipStream_t st) {
   return AFM_OK;
 }
 
+#include "afm_gemm_pp_impl.h"
+
 // ------------------------------------------------------------------------------------------ TN (wgrad)
 // C[m][n] += sum_k A[k][m] B[k][n]: A is dy (rows = tokens, cols = output features m), B is x
 // (rows = tokens, cols = input features n).  LDS tile [64 k-rows][128 cols] e16 = 256-byte rows of
@@ -1568,6 +1570,14 @@ int AFM_E16_FN(afm_gemm_mfma_try)(const afm_gemm_desc* d, hipStream_t st) {
           !(d->pre_act && d->act == AFM_ACT_NONE) && (d->drop.p <= 0.f || small_idx28))
         variant = 28;
     }
+    // plain (bias-only) products over many whole 256 x 256 tiles: the ping-pong kernel (afm_gemm_pp_impl.h).  Measured against the
+    // 256 x 128 loader-wave form at the c2 step's shapes, same box: N = 512 / K = 2048  +5 %, N = 512 / K = 1536  +9 %,
+    // N = 1024 / K = 512  +6 %, N = 2048 / K = 512  +4 %, N = 1536 / K = 512 and N = 512 / K = 512  equal (left where they were);
+    // 64-row-tile problems (the decoder's 16 384 rows) lose: too few tiles for a 256-CU chip.
+    if (d->reserved == 0 && (variant == 24 || variant == 28) && d->act == AFM_ACT_NONE && !d->pre_act && d->drop.p <= 0.f &&
+        !d->residual && !d->accumulate && d->c_dtype == AFM_E16 && !(d->M & 255) && !(d->N & 255) && !(d->K & 63) && d->K >= 128 &&
+        !(d->ldc % 8) && d->N <= PP_BIAS_MAX && (int64_t)(d->M >> 8) * (d->N >> 8) >= 512 && (d->K >= 1024 || d->N >= 1024))
+      variant = 30;
     if (d->act >= AFM_ACT_GELU_SAVE_GRAD && variant != 24 && variant != 28) return AFM_ERR_UNSUPPORTED;
     int r;
 #define NT_CASE(WM, WN, NWM, NWN, BKT) \
@@ -1590,6 +1600,19 @@ int AFM_E16_FN(afm_gemm_mfma_try)(const afm_gemm_desc* d, hipStream_t st) {
         else r = launch_nt_pring<true, 2, 4, 2, 0, 8, EPI_PLAIN, false>(g, st, 1);
         break;
       }
+      case 30:   // ping-pong 256 x 256 (afm_gemm_pp_impl.h): whole tiles, e16 output, plain (+ bias) epilogue
+        if ((d->K & 63) || d->K < 128 || (d->M & 255) || (d->N & 255) || d->N > PP_BIAS_MAX || d->c_dtype != AFM_E16 || d->residual ||
+            d->accumulate || d->act != AFM_ACT_NONE || d->pre_act || d->drop.p > 0.f || (d->ldc % 8)) { r = AFM_ERR_UNSUPPORTED; break; }
+        r = launch_nt_pp<EPI_PLAIN>(g, st);
+        break;
+#ifdef AFM_GEMM_ABLATIONS
+      case 301: r = launch_nt_pp<EPI_PLAIN, 1>(g, st); break;
+      case 302: r = launch_nt_pp<EPI_PLAIN, 2>(g, st); break;
+      case 304: r = launch_nt_pp<EPI_PLAIN, 4>(g, st); break;
+      case 306: r = launch_nt_pp<EPI_PLAIN, 6>(g, st); break;
+      case 310: g.accumulate = 7; r = launch_nt_pp<EPI_PLAIN, 0>(g, st); break;   // tile stamps only (in-kernel clock)
+      case 316: g.accumulate = 7; r = launch_nt_pp<EPI_PLAIN, 6>(g, st); break;
+#endif
       case 22: r = (d->K & 63) ? AFM_ERR_UNSUPPORTED : (d->c_dtype == AFM_E16 ? launch_nt_ws<true, 2>(g, st) : launch_nt_ws<false, 2>(g, st)); break;
       case 24:   // persistent 256x128, 8 MFMA waves + 4 loader waves, epilogue picked at compile time
       case 25: { // (25: same tile walk with the generic run-time epilogue, for A/B timing)
@@ -1646,7 +1669,7 @@ int AFM_E16_FN(afm_gemm_mfma_try)(const afm_gemm_desc* d, hipStream_t st) {
 #undef PRING_CASE
 #undef NT_CASE
     if (r != AFM_OK) return r;
-    afm_set_last_algo(variant == 28 ? "mfma_nt_256" : "mfma_nt");     // (_256: the 256 x 256-tile form)
+    afm_set_last_algo(variant == 28 ? "mfma_nt_256" : variant == 30 ? "mfma_nt_pp" : "mfma_nt");     // (_256: the 256 x 256-tile form)
     return AFM_OK;
   }
   if (d->transA && !d->transB) {  // TN: the wgrad form only

@@ -1,0 +1,348 @@
+// Ping-pong NT GEMM for gfx950 (included by afm_gemm_mfma_impl.h inside namespace AFM_E16_NS): C[m][n] = sum_k A[m][k] B[n][k],
+// 16-bit operands, fp32 accumulate, e16 output, whole 256 x 256 tiles, persistent over the tiles of an XCD.
+//
+// Why (round 4, tools/experiments/nt_epi_burst.py on the loader-wave kernel): LDS reads + MFMAs alone run at 1 340 TF/s (64 % of
+// what the clock under load allows) because every wave of a SIMD reads its fragments right after the k-step's barrier and multiplies
+// afterwards -- the matrix pipe waits for LDS, then LDS waits for the matrix pipe -- and the LDS-DMA of 256 x 128 tiles (48 KB per
+// 4.2 MFLOP: 24 TB/s of L2 -> LDS traffic at full MFMA rate) costs another 20 %.  Here:
+//   * 8 waves = 2 groups (waves 0-3 / 4-7: one wave of each on every SIMD), a wave owns 128 x 64 of the tile (group = row half,
+//     wave = column quarter).  The groups run ONE BARRIER APART: between two barriers one group issues its LDS reads and LDS-DMA
+//     pieces and waits for them, the other issues 16 MFMAs (a 64 x 32 quadrant of its tile over a 64-deep K-tile); at the next barrier
+//     they swap.  The matrix pipe of every SIMD always has a wave in its MFMA section (cdna_hip_programming.md 5, the 8-phase
+//     template's stagger; MI355X_MICROARCH.md "Two waves per SIMD" item 9).
+//   * 256 x 256 tiles: 64 KB of L2 -> LDS traffic per 8.4 MFLOP (two thirds of the 256 x 128 form's) and 3/4 of its LDS reads.
+//   * The K-tile (A 256 x 64, B 256 x 64) is staged as FOUR 16-KB sub-blocks in the order the phases consume them:
+//       X0 = a0 rows of both groups (tile rows 0-63, 128-191)      read in phase 0
+//       X1 = b0 columns of every wave (cols 64c + 0..31)           read in phase 0
+//       X2 = b1 columns of every wave (cols 64c + 32..63)          read in phase 1
+//       X3 = a1 rows of both groups (tile rows 64-127, 192-255)    read in phase 2        (phase 3 reads nothing)
+//     so a sub-block is read in exactly one phase (by both groups, one barrier apart) and is free right after it.  The ring holds 8
+//     sub-blocks (two K-tiles, 128 KB); phase p issues sub-block p + 7 of the stream (2 LDS-DMA pieces per wave) into the slot
+//     sub-block p - 1 left: 5 .. 6 phases (10 .. 12 barrier intervals, ~1.5 us) of flight time for every piece, across tile boundaries.
+//     Proof of the hazards (p = phase index, interval 2p = group 0's read section of phase p, 2p + 1 = group 1's; sub-block g =
+//     4t + j of K-tile t is read in phase 4t + s_j, s = {0, 0, 1, 2}):
+//       WAR  slot of g = p + 7 held g - 8 = p - 1 = (t0, j0), last read in interval 2 (4 t0 + s_j0) + 1 and complete at its end (every
+//            read section ends with lgkmcnt(0) BEFORE the barrier); the first piece of g is issued in interval 2p = 2 (4 t0 + j0 + 1)
+//            > 2 (4 t0 + s_j0) + 1 because j0 >= s_j0.
+//       RAW  every wave ends the read section of phase q with vmcnt(10): its pieces of phases <= q - 5, i.e. of sub-blocks <= q + 2, have
+//            landed; after group 1's section (interval 2q + 1) the barrier publishes them.  g = (t, j) is first read in interval
+//            2 (4t + s_j) >= 2 (q + 1) with q = 4t + j - 2 because s_j >= j - 1.
+//     The 16 stores of a wave's epilogue enter the same in-order counter: for the 5 phases after an epilogue the wait allows them too.
+//   * Epilogue per wave, no barrier: accumulators (bias is their initial value) -> e16 -> wave-private LDS patch (16 rows x 64 columns)
+//     -> 16-byte nontemporal stores of whole 128-byte lines.
+//
+// ABL (timing builds): 1 no MFMAs, 2 no LDS-DMA, 4 no epilogue.
+
+#define PP_SUB 16384              // bytes of one sub-block: 128 rows x 128 B
+#define PP_RING (8 * PP_SUB)
+#define PP_PATCH_LD 144           // bytes per staged row (128 + 16: 16-byte aligned rows, 2-way instead of 8-way write conflicts)
+#define PP_PATCH (16 * PP_PATCH_LD)
+#define PP_BIAS_OFF (PP_RING + 8 * PP_PATCH)
+#define PP_BIAS_MAX 3072          // floats of bias behind the patches
+#define PP_LIST_OFF (PP_BIAS_OFF + 4 * PP_BIAS_MAX)
+
+// timing builds: clock64 stamps of tile 3 of the first 32 workgroups, waves 0 and 4 (tools/experiments/pp_stamps.py)
+#ifdef AFM_GEMM_ABLATIONS
+#define PP_STAMP(kt_, ph_, i_) do { if (stamp_on) g.stamps[(((blockIdx.x * 2 + wr) * 8 + (kt_)) * 4 + (ph_)) * 8 + (i_)] = clock64(); } while (0)
+#define PP_TSTAMP(i_) do { if (tstamp_on) g.stamps[32 * 2 * 8 * 4 * 8 + ((blockIdx.x * 2 + wr) * 16 + it) * 4 + (i_)] = clock64(); } while (0)
+#else
+#define PP_STAMP(kt_, ph_, i_) do {} while (0)
+#define PP_TSTAMP(i_) do {} while (0)
+#endif
+#ifdef AFM_GEMM_ABLATIONS
+__device__ __forceinline__ bool getenv_no_phase_stamps(const MfmaArgs& g) { return g.accumulate == 7; }   // (timing builds: accumulate = 7 switches the per-phase stamps off)
+#endif
+template <int N> __device__ __forceinline__ void pp_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <int EPI, int ABL = 0>
+__global__ __launch_bounds__(512) void k_gemm_nt_pp(MfmaArgs g) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  const int t = threadIdx.x, lane = t & 63;
+  const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wr = w >> 2, wc = w & 3;
+  const int fr = lane & 15, fq = lane >> 4;
+  float* const bias_lds = (float*)(lds + PP_BIAS_OFF);
+  for (int n = t; n < g.N; n += 512) bias_lds[n] = g.bias ? g.bias[n] : 0.f;   // plain loads, retired before the first LDS-DMA piece
+  __syncthreads();
+
+  // tiles of this workgroup: XCD x owns [x * tpx, (x+1) * tpx), its workgroups stride through them together (k_gemm_nt_pring)
+  const int ntiles = g.tiles_m * g.tiles_n;
+  const int xcd = blockIdx.x & 7, bx = blockIdx.x >> 3, nbx = gridDim.x >> 3;
+  const int tpx = (ntiles + 7) >> 3;
+  const int tlo = xcd * tpx, thi = min(ntiles, tlo + tpx);
+  int* const tlist = (int*)(lds + PP_LIST_OFF);
+  if (g.live_off) nt_tile_lists<256, 256, true, 512>(g, tlist, tlo, thi, nbx, bx);
+  auto tile_of = [&](int it) -> int {
+    if (g.live_off) return it < __builtin_amdgcn_readfirstlane(tlist[0]) ? __builtin_amdgcn_readfirstlane(tlist[1 + it]) : -1;
+    const int tt = tlo + it * nbx + bx;
+    return tt < thi ? tt : -1;
+  };
+  const int nk = g.K >> 6;
+
+  // ---- LDS-DMA side: this wave's two pieces (8 rows x 128 B each) of every sub-block kind, as byte offsets from the tile's first
+  // A row / B row at the K-tile's first column.  LDS position (lane & 7) of row r8 holds the row's chunk (lane & 7) ^ r8.
+  uint32_t voff[4][2];
+  {
+    const int r8 = lane >> 3, ch = (lane & 7) ^ r8;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int lrow = 8 * (w + 8 * h) + r8;                       // row inside the 128-row sub-block
+      const int arow = lrow < 64 ? lrow : lrow + 64;               // X0: tile rows 0-63 | 128-191      (X3: + 64)
+      const int bcol = (lrow >> 5) * 64 + (lrow & 31);             // X1: tile cols 64c + 0..31         (X2: + 32)
+      voff[0][h] = (uint32_t)arow * (uint32_t)g.lda * 2u + ch * 16;
+      voff[3][h] = (uint32_t)(arow + 64) * (uint32_t)g.lda * 2u + ch * 16;
+      voff[1][h] = (uint32_t)bcol * (uint32_t)g.ldb * 2u + ch * 16;
+      voff[2][h] = (uint32_t)(bcol + 32) * (uint32_t)g.ldb * 2u + ch * 16;
+    }
+  }
+  int is_it = 0, is_kt = 0, is_par = 0;
+  int is_tile = tile_of(0);
+  const char* is_a = nullptr;
+  const char* is_b = nullptr;
+  auto is_set = [&]() {
+    if (is_tile < 0) return;
+    const int m0 = (is_tile / g.tiles_n) * 256, n0 = (is_tile % g.tiles_n) * 256;
+    is_a = (const char*)(g.A + (int64_t)m0 * g.lda + is_kt * 64);
+    is_b = (const char*)(g.B + (int64_t)n0 * g.ldb + is_kt * 64);
+  };
+  is_set();
+  auto is_advance = [&]() {           // next K-tile of the stream
+    if (is_tile < 0) return;
+    is_par ^= 1;
+    if (++is_kt == nk) { is_kt = 0; is_tile = tile_of(++is_it); is_set(); }
+    else { is_a += 128; is_b += 128; }
+  };
+  auto issue_h = [&](int j, int h) {  // piece h of this wave's two pieces of sub-block kind j of the issue K-tile (no-op past the end)
+    if (is_tile < 0 || (ABL & 2)) return;
+    const char* base = (j == 0 || j == 3) ? is_a : is_b;
+    unsigned char* dst = lds + (is_par * 4 + j) * PP_SUB + w * 1024;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + voff[j][h]),
+                                     (__attribute__((address_space(3))) void*)(dst + h * 8192), 16, 0, 0);
+  };
+  auto issue = [&](int j) { issue_h(j, 0); issue_h(j, 1); };
+
+  // ---- fragment reads (bytes inside a sub-block): row * 128 + ((chunk ^ (row & 7)) << 4), chunk = ks * 4 + fq; the rows of a fragment
+  // are 16-aligned, so row & 7 = fr & 7 and the two k-slices differ by an XOR of 64 on a lane-constant term.  Every LDS access of this
+  // kernel behind the first LDS-DMA piece is inline asm: hipcc answers a compiler-visible LDS access that may alias an LDS-DMA in flight
+  // with s_waitcnt vmcnt(0) (seen before the epilogue's patch reads), which would drain the ring; the waits are counted by hand.
+  const unsigned lds0 = (unsigned)(uintptr_t)lds;
+  const unsigned swz0 = ((fq ^ (fr & 7)) << 4), swz1 = swz0 ^ 64;
+  const unsigned a_lane = lds0 + (wr * 64 + fr) * 128, b_lane = lds0 + (wc * 32 + fr) * 128;
+#define PP_RD(dst, base, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(base), "n"(off) : "memory")
+
+  f32x4 acc[4][4][2];                 // [quadrant 2 * a + b][i][j]
+  e16x8 fa[4][2], fb0[2][2], fb1[2][2];
+
+  // ---- prologue: sub-blocks 0 .. 6 of the stream
+  issue(0); issue(1); issue(2); issue(3);
+  is_advance();
+  issue(0); issue(1); issue(2);
+  pp_wait_vm<10>();                    // (fewer were issued if the stream is shorter: the wait is then stricter, never weaker)
+  __builtin_amdgcn_s_barrier();
+  if (wr == 1) __builtin_amdgcn_s_barrier();   // group 1 runs one barrier behind group 0
+
+  // A read section ends with the counted wait: in steady state vmcnt(10).  `slow` > 0 marks the sections where the count differs: the 5
+  // after an epilogue (its 16 stores sit in the same in-order queue behind the older pieces) and everything after the stream's end.
+  int since_epi = 1000;               // read sections since this wave's last epilogue
+  int par = 0;
+  int tail = 0;                       // read sections since the stream's last sub-block was issued
+#ifdef AFM_GEMM_ABLATIONS
+  bool stamp_on = false, tstamp_on = false;
+#endif
+  auto read_end = [&](int skt, int sph) {   // DMA pieces of 5 phases ago have landed, own LDS reads are complete
+    PP_STAMP(skt, sph, 1);
+    if (__builtin_expect(is_tile >= 0 && since_epi >= 5, 1)) pp_wait_vm<10>();
+    else {
+      const int young = (is_tile < 0 ? (tail >= 5 ? 0 : 10 - 2 * tail) : 10) + (since_epi < 5 ? 16 : 0);
+      if (is_tile < 0) ++tail;
+      if (young >= 26) pp_wait_vm<26>(); else if (young >= 24) pp_wait_vm<24>(); else if (young >= 22) pp_wait_vm<22>();
+      else if (young >= 20) pp_wait_vm<20>(); else if (young >= 18) pp_wait_vm<18>(); else if (young >= 16) pp_wait_vm<16>();
+      else if (young >= 10) pp_wait_vm<10>(); else if (young >= 8) pp_wait_vm<8>(); else if (young >= 6) pp_wait_vm<6>();
+      else if (young >= 4) pp_wait_vm<4>(); else if (young >= 2) pp_wait_vm<2>(); else pp_wait_vm<0>();
+    }
+    ++since_epi;
+    PP_STAMP(skt, sph, 2);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    PP_STAMP(skt, sph, 3);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    PP_STAMP(skt, sph, 4);
+  };
+  auto mfma_end = [&](int skt, int sph) {
+    PP_STAMP(skt, sph, 5);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    PP_STAMP(skt, sph, 6);
+  };
+
+  for (int it = 0;; ++it) {
+    const int tile = tile_of(it);
+    if (tile < 0) break;
+    const int m0 = (tile / g.tiles_n) * 256, n0 = (tile % g.tiles_n) * 256;
+#ifdef AFM_GEMM_ABLATIONS
+    tstamp_on = g.stamps && blockIdx.x < 32 && (w & 3) == 0 && lane == 0 && it < 16;
+    stamp_on = tstamp_on && it == 3 && nk <= 8;
+#endif
+    PP_TSTAMP(0);
+#ifdef AFM_GEMM_ABLATIONS
+    if (tstamp_on) g.stamps[32 * 2 * 8 * 4 * 8 + ((blockIdx.x * 2 + wr) * 16 + it) * 4 + 3] = wall_clock64();
+    if (getenv_no_phase_stamps(g)) stamp_on = false;
+#endif
+    {  // accumulators start from the bias of their columns
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          f32x4 bv;
+          const unsigned ba = lds0 + PP_BIAS_OFF + (n0 + wc * 64 + b * 32 + j * 16 + fq * 4) * 4;
+          asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(bv) : "v"(ba) : "memory");
+#pragma unroll
+          for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[a * 2 + b][i][j] = bv;
+        }
+    }
+    for (int kt = 0; kt < nk; ++kt) {
+      const unsigned s0 = par * 4 * PP_SUB;
+      par ^= 1;
+      const unsigned a0 = a_lane + s0 + swz0, a1 = a_lane + s0 + swz1, b0 = b_lane + s0 + swz0, b1 = b_lane + s0 + swz1;
+      // ---------------- phase 0: a0, b0 -> quadrant (0, 0)
+      PP_STAMP(kt, 0, 0);
+      issue_h(3, 0);
+      PP_RD(fb0[0][0], b0, 1 * PP_SUB); PP_RD(fb0[0][1], b1, 1 * PP_SUB);
+      PP_RD(fb0[1][0], b0, 1 * PP_SUB + 2048); PP_RD(fb0[1][1], b1, 1 * PP_SUB + 2048);
+      PP_RD(fa[0][0], a0, 0); PP_RD(fa[0][1], a1, 0);
+      PP_RD(fa[1][0], a0, 2048); PP_RD(fa[1][1], a1, 2048);
+      PP_RD(fa[2][0], a0, 4096); PP_RD(fa[2][1], a1, 4096);
+      PP_RD(fa[3][0], a0, 6144); PP_RD(fa[3][1], a1, 6144);
+      issue_h(3, 1);
+      is_advance();
+      read_end(kt, 0);
+      if (!(ABL & 1)) {
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[0][i][j] = mfma16(fb0[j][ks], fa[i][ks], acc[0][i][j]);
+        __builtin_amdgcn_s_setprio(0);
+      }
+      mfma_end(kt, 0);
+      // ---------------- phase 1: b1 -> quadrant (0, 1)
+      PP_STAMP(kt, 1, 0);
+      issue_h(0, 0);
+      PP_RD(fb1[0][0], b0, 2 * PP_SUB); PP_RD(fb1[0][1], b1, 2 * PP_SUB);
+      PP_RD(fb1[1][0], b0, 2 * PP_SUB + 2048); PP_RD(fb1[1][1], b1, 2 * PP_SUB + 2048);
+      issue_h(0, 1);
+      read_end(kt, 1);
+      if (!(ABL & 1)) {
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[1][i][j] = mfma16(fb1[j][ks], fa[i][ks], acc[1][i][j]);
+        __builtin_amdgcn_s_setprio(0);
+      }
+      mfma_end(kt, 1);
+      // ---------------- phase 2: a1 -> quadrant (1, 1)
+      PP_STAMP(kt, 2, 0);
+      issue_h(1, 0);
+      PP_RD(fa[0][0], a0, 3 * PP_SUB); PP_RD(fa[0][1], a1, 3 * PP_SUB);
+      PP_RD(fa[1][0], a0, 3 * PP_SUB + 2048); PP_RD(fa[1][1], a1, 3 * PP_SUB + 2048);
+      PP_RD(fa[2][0], a0, 3 * PP_SUB + 4096); PP_RD(fa[2][1], a1, 3 * PP_SUB + 4096);
+      PP_RD(fa[3][0], a0, 3 * PP_SUB + 6144); PP_RD(fa[3][1], a1, 3 * PP_SUB + 6144);
+      issue_h(1, 1);
+      read_end(kt, 2);
+      if (!(ABL & 1)) {
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[3][i][j] = mfma16(fb1[j][ks], fa[i][ks], acc[3][i][j]);
+        __builtin_amdgcn_s_setprio(0);
+      }
+      mfma_end(kt, 2);
+      // ---------------- phase 3: quadrant (1, 0) from registers
+      PP_STAMP(kt, 3, 0);
+      issue(2);
+      read_end(kt, 3);
+      if (!(ABL & 1)) {
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[2][i][j] = mfma16(fb0[j][ks], fa[i][ks], acc[2][i][j]);
+        __builtin_amdgcn_s_setprio(0);
+      }
+      mfma_end(kt, 3);
+    }
+
+    // ---------------- epilogue (wave-private; the other group keeps computing)
+    PP_TSTAMP(1);
+    if (ABL & 4) {
+      float sacc = 0.f;
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) sacc += acc[q][i][j][0] + acc[q][i][j][1] + acc[q][i][j][2] + acc[q][i][j][3];
+      if (sacc == 123.456f) ((float*)g.C)[0] = sacc;
+    } else {
+      unsigned char* const patch = lds + PP_RING + w * PP_PATCH;
+      const int r8 = lane >> 3, c8 = (lane & 7) * 8;
+      const unsigned patch_w = (unsigned)(uintptr_t)patch + fr * PP_PATCH_LD + fq * 8;      // this lane's 4 columns of a fragment
+      const unsigned patch_r = (unsigned)(uintptr_t)patch + r8 * PP_PATCH_LD + c8 * 2;     // this lane's 16 bytes of rows r8, r8 + 8
+      typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+      e16* const cw = (e16*)g.C + (int64_t)(m0 + wr * 128 + r8) * g.ldc + n0 + wc * 64 + c8;
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+#pragma unroll
+          for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+              const f32x4 v = acc[a * 2 + b][i][j];
+              const e16x4 o = {(e16)v[0], (e16)v[1], (e16)v[2], (e16)v[3]};
+              // asm: a compiler-visible LDS store makes hipcc drain the LDS-DMA ring first (s_waitcnt vmcnt(0) before the patch access)
+              asm volatile("ds_write_b64 %0, %1 offset:%2" ::"v"(patch_w), "v"(__builtin_bit_cast(uint2_t, o)), "n"((b * 32 + j * 16) * 2) : "memory");
+            }
+          u32x4_t o0, o1;
+          asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:%3\n\ts_waitcnt lgkmcnt(0)"
+                       : "=&v"(o0), "=&v"(o1) : "v"(patch_r), "n"(8 * PP_PATCH_LD) : "memory");
+          store16_policy<AFM_C_STORE_AUX>(cw, (uint64_t)((int64_t)(a * 64 + i * 16) * g.ldc * 2), __builtin_bit_cast(uint4, o0));
+          store16_policy<AFM_C_STORE_AUX>(cw, (uint64_t)((int64_t)(a * 64 + i * 16 + 8) * g.ldc * 2), __builtin_bit_cast(uint4, o1));
+        }
+      since_epi = 0;
+    }
+    PP_TSTAMP(2);
+  }
+  if (wr == 0) __builtin_amdgcn_s_barrier();   // group 0's extra barrier: both groups execute the same number
+}
+
+template <int EPI, int ABL = 0>
+static int launch_nt_pp(MfmaArgs& g, hipStream_t st) {
+  g.tiles_m = g.M / 256; g.tiles_n = g.N / 256;
+  int shm = PP_LIST_OFF;
+  g.live_off = 0;
+  const int ntiles = g.tiles_m * g.tiles_n;
+  int grid = 256;
+  if (grid > ((ntiles + 7) / 8) * 8) grid = ((ntiles + 7) / 8) * 8;
+  if (g.k_live) {
+    const int tpx0 = (ntiles + 7) / 8, nbx0 = grid / 8;
+    if ((tpx0 + nbx0 - 1) / nbx0 <= NT_LIVE_MAX) { g.live_off = PP_LIST_OFF; shm += NT_LIVE_BYTES; }
+  }
+  auto kern = k_gemm_nt_pp<EPI, ABL>;
+  static AfmOncePerDevice attr;
+  if (attr.need()) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  AFM_LAUNCH(kern, dim3(grid), dim3(512), shm, st, g);
+  return AFM_OK;
+}

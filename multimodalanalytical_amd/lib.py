@@ -131,6 +131,7 @@ _SIGS = {
     "afm_comm_unique_id": (C.c_int, [_P]),
     "afm_comm_create": (C.c_int, [C.POINTER(_P), _P, _I32, _I32]),
     "afm_allreduce_bucket": (C.c_int, [_P, _P, _I64, _P]),
+    "afm_comm_count": (C.c_int, [_P, C.POINTER(_I32), C.POINTER(_I32)]),
     "afm_comm_destroy": (C.c_int, [_P]),
 }
 

@@ -52,10 +52,32 @@ def sync_flag(flag: bool, src: int = 0, device=None, group=None) -> bool:
     ranking kept on rank 0; every rank must leave the epoch loop in the same epoch or the others hang in the next collective)."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return bool(flag)
+    if _NATIVE is not None and group is None:
+        # ONE communicator, ONE stream while the C-ABI exchange is live (see sync_mean): the flag is a sum to which only `src` contributes
+        comm, side = _NATIVE
+        t = torch.tensor([1.0 if (flag and comm.rank == src) else 0.0], device=device or torch.device("cuda", torch.cuda.current_device()))
+        return bool(float(_native_mean(t, comm, side).item()) > 0.0)
     dev = device if (device is not None and dist.get_backend(group) == "nccl") else "cpu"
     t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=dev)
     dist.broadcast(t, src=src, group=group)
     return bool(int(t.item()))
+
+
+def barrier(group=None) -> None:
+    """All ranks have reached this point.  While the C-ABI communicator is live it carries the barrier too (a one-float all-reduce on
+    the side stream, then a host wait): a torch-communicator collective enqueued while a native bucket is still in flight has no
+    defined order against it across ranks.  Otherwise torch.distributed.barrier."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return
+    if _NATIVE is not None and group is None:
+        comm, side = _NATIVE
+        t = torch.zeros(1, device=torch.device("cuda", torch.cuda.current_device()))
+        _native_mean(t, comm, side)
+        torch.cuda.current_stream().synchronize()
+        return
+    if torch.cuda.is_available() and dist.get_backend(group) == "nccl":
+        torch.cuda.synchronize()        # nothing of this process is still in flight on another stream when the collective is enqueued
+    dist.barrier(group=group)
 
 
 def _native_mean(value: torch.Tensor, comm, side) -> torch.Tensor:
@@ -80,14 +102,25 @@ class NativeComm:
         self._L, self._C = L, C
         rank, world = dist.get_rank(group), dist.get_world_size(group)
         buf = (C.c_ubyte * 128)()
-        if rank == 0:
-            L.check(L.load().afm_comm_unique_id(buf), "afm_comm_unique_id")
-        ids = [bytes(buf)]
+        status = 0
+        if rank == 0:       # rank 0 ALWAYS reaches the broadcast, with a failure marker if it has no id (raising here
+            try:            # left the other ranks in the broadcast while rank 0 went on to the MIN agreement)
+                status = int(L.load().afm_comm_unique_id(buf))
+            except Exception:      # noqa: BLE001
+                status = -100
+        ids = [(status, bytes(buf))]
         dist.broadcast_object_list(ids, src=0, group=group)
-        raw = (C.c_ubyte * 128).from_buffer_copy(ids[0])
+        status, payload = ids[0]
         self.handle = C.c_void_p()
+        if status != 0:
+            raise L.AfmError(f"afm_comm_unique_id failed on rank 0 ({status})")
+        raw = (C.c_ubyte * 128).from_buffer_copy(payload)
         L.check(L.load().afm_comm_create(C.byref(self.handle), raw, rank, world), "afm_comm_create")
-        self.rank, self.world = rank, world
+        r, w = C.c_int32(-1), C.c_int32(-1)
+        L.check(L.load().afm_comm_count(self.handle, C.byref(r), C.byref(w)), "afm_comm_count")
+        self.rank, self.world = int(r.value), int(w.value)      # what the communicator itself reports (ncclCommUserRank / ncclCommCount)
+        if (self.rank, self.world) != (rank, world):
+            raise L.AfmError(f"communicator reports rank {self.rank} of {self.world}, process group {rank} of {world}")
 
     def all_reduce(self, view: torch.Tensor, stream) -> None:
         assert view.is_cuda and view.dtype == torch.float32 and view.is_contiguous()
@@ -249,6 +282,10 @@ def save_checkpoint(path: str, model, loop: "TrainLoop" = None, epoch: int = 0) 
         opt = loop.optim.state_dict()
         ckpt["optimizer_states"] = [{"step": opt["step"], "exp_avg": opt["exp_avg"].cpu(), "exp_avg_sq": opt["exp_avg_sq"].cpu(),
                                      "layout": "flat (params.ParamStore offsets)"}]
+        if opt.get("loss_scaler") is not None:
+            # fp16 mode: {S, growth tracker, steps taken, steps skipped}.  k_adam takes its bias corrections from "steps taken", so a
+            # resume without it would restart them at t = 1 on warm moments
+            ckpt["optimizer_states"][0]["loss_scaler"] = opt["loss_scaler"].cpu()
     torch.save(ckpt, path)
 
 
@@ -269,5 +306,11 @@ def load_checkpoint(path: str, model, loop: "TrainLoop" = None, strict: bool = T
     if loop is not None and ckpt.get("optimizer_states") and "exp_avg" in ckpt["optimizer_states"][0]:
         st = ckpt["optimizer_states"][0]
         dev = model.hf_model.engine.dev
-        loop.optim.load_state_dict({"step": st["step"], "exp_avg": st["exp_avg"].to(dev), "exp_avg_sq": st["exp_avg_sq"].to(dev)})
+        scaler = st.get("loss_scaler")
+        if scaler is None and getattr(model.hf_model.engine, "scaler", None) is not None:
+            # a checkpoint written before the scaler was stored (or by a non-fp16 run): every optimiser step counted as taken, fresh scale
+            scaler = model.hf_model.engine.scaler.detach().cpu().clone()
+            scaler[1], scaler[2], scaler[3] = 0.0, float(st["step"]), 0.0
+        loop.optim.load_state_dict({"step": st["step"], "exp_avg": st["exp_avg"].to(dev), "exp_avg_sq": st["exp_avg_sq"].to(dev),
+                                    "loss_scaler": scaler})
     return ckpt

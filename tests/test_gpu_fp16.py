@@ -58,6 +58,48 @@ def test_gemm_f16_nt_variants(ops, variant):
     close(c, a.double() @ w.double().T + bias.double(), **tol)
 
 
+@pytest.mark.parametrize("M,N,K,bias", [(256, 256, 128, True), (512, 768, 192, True), (256 * 37, 256 * 3, 320, True), (4096, 1024, 512, False),
+                                        (16384, 512, 2048, True), (16384, 1536, 512, True)])
+def test_gemm_f16_nt_pingpong(ops, M, N, K, bias):
+    """The ping-pong 256 x 256 kernel (variant 30, csrc/afm_gemm_pp_impl.h): stream starts, tile boundaries, tails shorter than the
+    ring, uneven tile counts per workgroup -- against fp64, and bit-equal to the loader-wave kernel when no bias is added (with a bias
+    the accumulators START from it there: same sum, other rounding order)."""
+    a, w = rnd(M, K, seed=1).half(), (rnd(N, K, seed=2) * 0.1).half()
+    b = rnd(N, seed=3) if bias else None
+    c = torch.full((M, N), float("nan"), dtype=H16, device=DEV)
+    ops.gemm(dev(a), dev(w), c, bias=None if b is None else dev(b), variant=30)
+    assert ops.last_algo() == "mfma_nt_pp"
+    ref = a.double() @ w.double().T + (b.double() if bias else 0.0)
+    close(c, ref, rtol=2e-3, atol=2e-3 * math.sqrt(K) / 4)
+    c2 = torch.empty_like(c)
+    ops.gemm(dev(a), dev(w), c2, bias=None if b is None else dev(b), variant=24)
+    if not bias:
+        assert torch.equal(c, c2)
+    c3 = torch.full_like(c, float("nan"))
+    ops.gemm(dev(a), dev(w), c3, bias=None if b is None else dev(b), variant=30)       # same bits run to run (no race on the ring)
+    assert torch.equal(c, c3)
+
+
+def test_gemm_f16_nt_pingpong_is_selected_and_takes_the_row_hint(ops):
+    """Automatic dispatch at a step-sized shape, and afm_gemm_desc.k_live through the kernel's tile lists (dead tiles written as zeros)."""
+    M, N, K = 65536, 512, 1536
+    live = torch.ones(M // 64, dtype=torch.uint8)
+    live[8:24] = 0; live[29] = 0; live[400:700] = 0; live[1000:] = 0
+    rl = live.repeat_interleave(64).bool()
+    a = rnd(M, K, seed=1) * 0.5; a[~rl] = 0.0
+    ad, wd = dev(a, H16), dev(rnd(N, K, seed=2) * 0.1, H16)
+    outs = []
+    for hint in (None, dev(live)):
+        c = torch.full((M, N), 3.0, dtype=H16, device=DEV)
+        ops.gemm(ad, wd, c, k_live=hint)
+        assert ops.last_algo() == "mfma_nt_pp"
+        outs.append(c)
+    assert torch.equal(outs[0], outs[1])
+    assert float(outs[1][~rl.to(DEV)].abs().max()) == 0.0
+    ref = torch.empty_like(outs[0]); ops.gemm(ad, wd, ref, variant=24)
+    assert torch.equal(outs[0], ref)
+
+
 @pytest.mark.parametrize("M,N", [(1024, 512), (4096, 2048)])     # 256x128 loader-wave form / 256x256 form (auto-selected)
 def test_gemm_f16_gelu_save_grad_pair(ops, M, N):
     """FFN up-projection forward with the stored backward factor (act 4) and the dgrad that multiplies by it (act 5)."""
@@ -423,7 +465,7 @@ def test_nt_gemm_writes_padded_row_tiles_as_zeros(ops, N, K, act):
     for hint in (None, dev(live)):
         c = torch.full((M, N), 3.0, dtype=H16, device=DEV)
         ops.gemm(ad, wd, c, act=act, pre_act=pre, k_live=hint)
-        assert ops.last_algo() in ("mfma_nt", "mfma_nt_256")
+        assert ops.last_algo() in ("mfma_nt", "mfma_nt_256", "mfma_nt_pp")
         outs.append(c)
     assert torch.equal(outs[0], outs[1])
     assert float(outs[1][~rl.to(DEV)].abs().max()) == 0.0

@@ -292,6 +292,50 @@ def test_lightning_shaped_checkpoint_roundtrip(tmp_path):
         torch.testing.assert_close(a, c, rtol=1e-5, atol=1e-5)
 
 
+def test_fp16_checkpoint_resume_continues_the_run(tmp_path):
+    """fp16 (the default precision): the loss scaler's state {S, growth tracker, steps taken, steps skipped} travels with the checkpoint.
+    k_adam takes its bias corrections from "steps taken": without it a resumed run restarts them at t = 1 on warm moments (ADVICE r03:
+    bc1 ~ 0.1, bc2 ~ 0.001, i.e. updates several times too large).  A run resumed after 3 optimiser steps follows the uninterrupted one
+    (to the run-to-run noise of the atomic sums: 1e-5), the same resume WITHOUT the scaler state does not; a checkpoint that lacks the
+    state (older writer) gets "steps taken" from its step count."""
+    from multimodalanalytical_amd.trainer import TrainLoop, load_checkpoint, save_checkpoint
+    t = G.load("model_plain"); cfg = G.model_cfg(t["meta"])
+
+    def fresh():
+        w = _wrapper(t, cfg, torch.float16)
+        return w, TrainLoop(w, acc_batches=2)
+    w, loop = fresh()
+    for i in range(6):
+        loop.micro_batch(_dev_batch(t, i % 4))
+    path = str(tmp_path / "fp16.ckpt")
+    save_checkpoint(path, w, loop, epoch=1)
+    raw = torch.load(path, map_location="cpu", weights_only=False)
+    assert raw["optimizer_states"][0]["loss_scaler"].tolist()[2] == 3.0       # three steps taken, none skipped
+    w2, loop2 = fresh()
+    load_checkpoint(path, w2, loop2)
+    assert torch.equal(w2.hf_model.engine.scaler, w.hf_model.engine.scaler)
+    w_bad, loop_bad = fresh()                                                  # what the old loader did: moments restored, scaler fresh
+    load_checkpoint(path, w_bad, loop_bad)
+    w_bad.hf_model.engine.scaler[1:].zero_()
+    for i in range(6, 10):
+        a, c = loop.micro_batch(_dev_batch(t, i % 4)), loop2.micro_batch(_dev_batch(t, i % 4))
+        loop_bad.micro_batch(_dev_batch(t, i % 4))
+        torch.testing.assert_close(a, c, rtol=2e-5, atol=2e-5)
+    e1, e2, e3 = w.hf_model.engine, w2.hf_model.engine, w_bad.hf_model.engine
+    d_good = float((e1.ps.flat - e2.ps.flat).abs().max())
+    d_bad = float((e1.ps.flat - e3.ps.flat).abs().max())
+    assert d_good < 2e-5 and d_bad > 50 * max(d_good, 1e-6), (d_good, d_bad)
+    torch.testing.assert_close(e1.ps.exp_avg_sq, e2.ps.exp_avg_sq, rtol=1e-3, atol=1e-12)
+    assert torch.equal(e1.scaler, e2.scaler) and loop.optim.step_count == loop2.optim.step_count == 5
+    # a checkpoint from before the scaler was stored
+    del raw["optimizer_states"][0]["loss_scaler"]
+    old = str(tmp_path / "fp16_old.ckpt")
+    torch.save(raw, old)
+    w3, loop3 = fresh()
+    load_checkpoint(old, w3, loop3)
+    assert w3.hf_model.engine.scaler.tolist()[2] == 3.0 and w3.hf_model.engine.scaler.tolist()[0] == 65536.0
+
+
 def test_align_head_checkpoint_roundtrip(tmp_path):
     """A model WITH an alignment head keeps its `align_network.*` tensors through save -> load (the reference
     drops those keys only when align_config is None, cli/training.py:152-161)."""
