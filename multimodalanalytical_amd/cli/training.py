@@ -66,7 +66,7 @@ def build_plan(cfg: Dict[str, Any], shard_meta: Dict[str, Dict[str, Any]], n_tra
             mc["pad_token_id"] = int(shard_meta[m].get("pad_token_id", 0))
         elif mc["type"] not in PATCH_TYPES:
             raise NotImplementedError(f"modality type {mc['type']!r}")
-        if mc.get("target"):
+        if mc.get("target") and not mc.get("alignment"):      # (an alignment modality is a target too, datamodules.py:45-56)
             target = m
         data_config[m] = mc
     if target is None:
@@ -130,7 +130,67 @@ class ShardLoader:
             yield self.collator({m: {k: v.index_select(0, idx) for k, v in d.items()} for m, d in self.dev_data.items()})
 
 
-def build_preprocessors(train_shard, data_config, device):
+class MixtureLoader:
+    """The reference's mixture datasets (data/datasets.py:395-412: with a `mixture` config group every split becomes an iterable of
+    mixtures, `multi_config_mix` over the named configurations) on the device: the shard holds the PURE compounds (ids of the text
+    modalities, IR spectra) resident in HBM, every configuration is a `MixtureGenerator` (index stream on the host with the
+    reference's numpy RNG, the weighted average in `afm_mix_spectra`, rank-strided under data parallelism), the configurations
+    alternate record by record, and the records are cut into batches and collated:
+
+        IR          the mixed spectrum                      (input modality)
+        IR_target   the pure spectrum of the record's compound -> `encoder_alignment_input` (the alignment head's target)
+        text ids    gathered from the compound's row
+
+    Like the reference's generator it restarts with the same seed every epoch, and its nominal length is the configured
+    sum of `<split>_max_n_samples` (what `calculate_training_steps` is given), not the number of records that survive the
+    duplicate / permutation checks."""
+
+    SPLIT_KEY = {"train": "train", "val": "validation", "test": "test"}
+
+    def __init__(self, shard, mixture_cfg, split, collator, batch_size: int, device: str, rank: int = 0, world: int = 1,
+                 spectrum_modality: str = "IR", seed: int = 3247):
+        from ..preprocess import MixtureGenerator
+        self.collator, self.bs, self.dev, self.rank, self.world = collator, int(batch_size), device, rank, world
+        self.key = self.SPLIT_KEY[split]
+        self.spec = spectrum_modality
+        self.dev_data = {m: {k: v.to(device) for k, v in d.items()} for m, d in shard["data"].items()}
+        table = self.dev_data[spectrum_modality]["spectra"]
+        self.configs = {name: dict(c) for name, c in mixture_cfg.items() if c.get(f"{self.key}_max_n_samples", 0) > 0 or c.get("mixed")}
+        self.gens = [MixtureGenerator(table, c, self.key, seed, rank, world) for c in self.configs.values()]
+        self.nominal = sum(int(c.get(f"{self.key}_max_n_samples", 0)) for c in mixture_cfg.values())
+        self.align = collator.alignment_modality[0] if collator.alignment_modality else None
+
+    def __len__(self):
+        return (self.nominal // self.world) // self.bs
+
+    def records(self):
+        from ..preprocess import interleave_rounds
+        yield from interleave_rounds(self.gens)
+
+    def epoch(self, epoch: int):     # noqa: ARG002 (the reference's generator reseeds: every epoch is the same stream)
+        pend = None
+        for r in self.records():
+            r = {k: v for k, v in r.items() if k in ("IR", "compound", "IR_target")}
+            pend = r if pend is None else {k: torch.cat([pend[k], r[k]]) for k in r}
+            while pend["compound"].shape[0] >= self.bs:
+                cut = {k: v[:self.bs] for k, v in pend.items()}
+                pend = {k: v[self.bs:] for k, v in pend.items()}
+                yield self._collate(cut)
+
+    def _collate(self, rec):
+        comp = rec["compound"]
+        inputs = {}
+        for m, d in self.dev_data.items():
+            if m == self.spec:
+                inputs[m] = {"spectra": rec["IR"]}
+            else:
+                inputs[m] = {k: v.index_select(0, comp) for k, v in d.items()}
+        if self.align is not None:
+            inputs[self.align] = {"spectra": rec["IR_target"]}
+        return self.collator(inputs)
+
+
+def build_preprocessors(train_shard, data_config, device, mixture_sample=None):
     """`load_preprocessors` for the patch modalities (reference data/data_utils.py -> PatchPreprocessor.initialise):
     statistics over the non-zero entries of (a sample of) the training spectra."""
     from ..preprocess import PatchPreprocessor
@@ -141,10 +201,45 @@ def build_preprocessors(train_shard, data_config, device):
             pp = PatchPreprocessor(patch_size=int(a["patch_size"]), masking=bool(a.get("masking", False)),
                                    interpolation=bool(a.get("interpolation", False)), overlap=int(a.get("overlap", 1)),
                                    derivative=bool(a.get("derivative", False)), device=device)
-            sample = train_shard["data"][m]["spectra"][:10000]
-            pp.initialise({m: sample.numpy()}, m)
+            # data_utils.py:49-59: statistics from (up to) the first 10 000 records -- of the mixture stream when there is one
+            # (`data_set.take(num_samples)`), else a sample of the training shard
+            if mixture_sample is not None and m in mixture_sample:
+                sample = mixture_sample[m]
+            elif m in train_shard["data"]:
+                sample = train_shard["data"][m]["spectra"][:10000]
+            else:
+                sample = None       # (an alignment modality the shards do not carry: only its `interpolation` flag is consulted)
+            if sample is not None:
+                pp.initialise({m: sample.cpu().numpy()}, m)
             pre[m] = pp
     return pre
+
+
+def setup_data(cfg: Dict[str, Any], device: str, world: int = 1):
+    """Shards, run plan, collator and the mixture group of a composed config (the reference's build_dataset_multimodal +
+    load_preprocessors + MultiModalDataModule, cli/training.py:80-131)."""
+    from ..preprocess import DeviceCollator
+    shards = load_shards(cfg["data_path"], cfg, device)
+    meta = shards["train"]["meta"]
+    mixture = cfg.get("mixture")            # cli/training.py:86-94 hands it to the dataset builder (datasets.py:395-412)
+    n_train = shard_len(shards["train"])
+    if isinstance(mixture, dict):
+        n_train = sum(int(c.get("train_max_n_samples", 0)) for c in mixture.values())      # the iterable's nominal length
+    plan = build_plan(cfg, meta, n_train, world, bool(cfg["trainer"].get("legacy_step_count", False)))
+    dc, tm = plan["data_config"], plan["target_modality"]
+    mix_sample = None
+    if isinstance(mixture, dict):           # preprocessor statistics from the head of the mixture stream (data_utils.py:49-54)
+        probe = MixtureLoader(shards["train"], mixture, "train", DeviceCollator(dc, {}, tm), 1, device, 0, 1)
+        got, rows = [], 0
+        for r in probe.records():
+            got.append(r["IR"]); rows += int(r["IR"].shape[0])
+            if rows >= 10000:
+                break
+        if got:
+            mix_sample = {probe.spec: torch.cat(got)[:10000]}
+        del probe
+    pre = build_preprocessors(shards["train"], dc, device, mix_sample)
+    return shards, plan, DeviceCollator(dc, pre, tm), (mixture if isinstance(mixture, dict) else None)
 
 
 # ------------------------------------------------------------------------------------------------ run
@@ -171,13 +266,9 @@ def run(cfg: Dict[str, Any], own: Dict[str, str]) -> Dict[str, Any]:
     torch.cuda.set_device(device)
     if world > 1 and not dist.is_initialized():
         dist.init_process_group("nccl", device_id=torch.device(device))
-    shards = load_shards(cfg["data_path"], cfg, device)
-    meta = shards["train"]["meta"]
-    plan = build_plan(cfg, meta, shard_len(shards["train"]), world, bool(cfg["trainer"].get("legacy_step_count", False)))
+    shards, plan, collator, mixture = setup_data(cfg, device, world)
     os.makedirs(plan["run_dir"], exist_ok=True)
     dc, tm = plan["data_config"], plan["target_modality"]
-    pre = build_preprocessors(shards["train"], dc, device)
-    collator = DeviceCollator(dc, pre, tm)
     tok = SimpleTokenizerInfo(dc[tm]["vocab_size"], pad_token_id=dc[tm]["pad_token_id"])
     # precision=: fp16 (= Lightning's "16-mixed", what the reference trains with on a GPU, trainer/trainer.py:69: single-pass fp16
     # MFMA forward and backward, dynamic loss scaling; logits within the 1e-3 bar) | bf16x3-mixed (split-pair forward = fp32-grade
@@ -197,19 +288,26 @@ def run(cfg: Dict[str, Any], own: Dict[str, str]) -> Dict[str, Any]:
     loop = TrainLoop(model, acc_batches=plan["acc_batches"], world_size=world)
     if mk.get("model_checkpoint_path"):
         load_checkpoint(mk["model_checkpoint_path"], model, None if cfg.get("finetuning") else loop)
-    train = ShardLoader(shards["train"], collator, bs, device, rank, world, shuffle=True)
-    val = ShardLoader(shards.get("val", shards["train"]), collator, bs, device, rank, world, shuffle=False, drop_last=False)
+    if isinstance(mixture, dict):
+        train = MixtureLoader(shards["train"], mixture, "train", collator, bs, device, rank, world)
+        val = MixtureLoader(shards.get("val", shards["train"]), mixture, "val", collator, bs, device, rank, world)
+    else:
+        train = ShardLoader(shards["train"], collator, bs, device, rank, world, shuffle=True)
+        val = ShardLoader(shards.get("val", shards["train"]), collator, bs, device, rank, world, shuffle=False, drop_last=False)
     ckpt_dir = os.path.join(plan["run_dir"], "checkpoints")
     os.makedirs(ckpt_dir, exist_ok=True)
     top: List[tuple] = []        # (score, path), best first
     sign = 1.0 if plan["monitor_mode"] == "max" else -1.0
     max_steps = int(own.get("max_steps", 0))
     history, stale = [], 0
+    first_logged = None
     for epoch in range(plan["epochs"]):
         for i, batch in enumerate(train.epoch(epoch)):
             if loop.optim.step_count >= plan["train_steps"] or (max_steps and loop.optim.step_count >= max_steps):
                 break
             loop.micro_batch(batch, i)
+            if first_logged is None:      # what Lightning would log at step 0: train_loss (+ model_only / alignment loss with the head)
+                first_logged = {k: float(v) for k, v in model.logged.items() if k.startswith("train_")}
         loop.flush()      # Lightning steps the optimiser on the last batch of an epoch even when the accumulation window is not full
         nval = len(val)
         lim = plan["limit_val_batches"]
@@ -235,7 +333,8 @@ def run(cfg: Dict[str, Any], own: Dict[str, str]) -> Dict[str, Any]:
         # EarlyStopping stops every rank in the same epoch: rank 0 owns the checkpoint ranking, its decision is broadcast
         if sync_flag(bool(plan["early_stopping_patience"] and stale >= plan["early_stopping_patience"]), 0, device):
             break
-    result = {"history": history, "run_dir": plan["run_dir"], "train_steps": plan["train_steps"], "precision": precision}
+    result = {"history": history, "run_dir": plan["run_dir"], "train_steps": plan["train_steps"], "precision": precision,
+              "first_train_step": first_logged, "optimizer_steps": loop.optim.step_count}
     if rank == 0:
         best = top[0][1]
         shutil.copy(best, os.path.join(ckpt_dir, "best.ckpt"))
@@ -247,8 +346,9 @@ def run(cfg: Dict[str, Any], own: Dict[str, str]) -> Dict[str, Any]:
     load_checkpoint(os.path.join(ckpt_dir, "best.ckpt"), best_model)
     best_model.eval()
     n_beams = int(plan["n_beams"])
-    test = ShardLoader(shards.get("test", shards.get("val", shards["train"])), collator, bs, device, rank, world,
-                       shuffle=False, drop_last=False)
+    tshard = shards.get("test", shards.get("val", shards["train"]))
+    test = (MixtureLoader(tshard, mixture, "test", collator, bs, device, rank, world) if isinstance(mixture, dict) else
+            ShardLoader(tshard, collator, bs, device, rank, world, shuffle=False, drop_last=False))
     losses, preds, tgts = [], [], []
     for i, batch in enumerate(test.epoch(0)):
         out = best_model.forward(batch)
@@ -275,7 +375,8 @@ def main(argv: Optional[List[str]] = None) -> int:
                   overrides)
     try:
         res = run(cfg, own)
-        print(json.dumps({"run_dir": res["run_dir"], "metrics": res["metrics"], "history": res["history"][-1:]}))
+        print(json.dumps({"run_dir": res["run_dir"], "metrics": res["metrics"], "history": res["history"][-1:],
+                          "first_train_step": res["first_train_step"], "optimizer_steps": res["optimizer_steps"]}))
     except Exception:       # cli/training.py:253-254: the reference logs the failure and still exits 0
         traceback.print_exc()
         return 1 if own.get("strict", "0") not in ("0", "false", "False") else 0

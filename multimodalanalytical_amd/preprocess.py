@@ -78,11 +78,23 @@ class DeviceCollator:
     the spectrum work runs in `afm_patch_preprocess` and lands sequence-first without a transpose pass.
     """
 
-    def __init__(self, data_config: dict, preprocessors: dict, target_modality: str):
+    ALIGN_LEN = 1800     # datamodules.py:151-160: the alignment target is zero-padded to 1800 points
+
+    def __init__(self, data_config: dict, preprocessors: dict, target_modality: str = None):
         self.data_config = data_config
         self.preprocessors = preprocessors          # {modality: PatchPreprocessor} for 1D_patches modalities
-        self.target_modality = target_modality
+        # datamodules.py:39-66: inputs = not target; target = target and not alignment (exactly one); alignment = target and
+        # alignment (at most one): its raw spectrum becomes `encoder_alignment_input`, the alignment head's regression target
         self.input_modalities = [m for m, c in data_config.items() if not c.get("target", False)]
+        targets = [m for m, c in data_config.items() if c.get("target", False) and not c.get("alignment", False)]
+        self.alignment_modality = [m for m, c in data_config.items() if c.get("target", False) and c.get("alignment", False)]
+        if len(self.alignment_modality) > 1:
+            raise ValueError("At most 1 target alignment modality can be specified.")
+        if len(targets) != 1:
+            raise ValueError("Only 1 target modality can be specified.")
+        if target_modality is not None and target_modality != targets[0]:
+            raise ValueError(f"target modality {target_modality!r} is not the data config's ({targets[0]!r})")
+        self.target_modality = targets[0]
 
     def __call__(self, inputs: dict) -> dict:
         enc, masks = {}, []
@@ -104,9 +116,26 @@ class DeviceCollator:
         tgt = inputs[self.target_modality]
         ids = tgt["input_ids"].transpose(0, 1)
         pad = ~tgt["attention_mask"].transpose(0, 1).bool()
-        return {"encoder_input": enc, "encoder_pad_mask": torch.cat(masks, 0),
-                "decoder_input": {self.target_modality: ids[:-1, :]}, "decoder_pad_mask": pad[:-1, :],
-                "target": ids.clone()[1:, :], "target_mask": pad.clone()[1:, :]}
+        out = {"encoder_input": enc, "encoder_pad_mask": torch.cat(masks, 0),
+               "decoder_input": {self.target_modality: ids[:-1, :]}, "decoder_pad_mask": pad[:-1, :],
+               "target": ids.clone()[1:, :], "target_mask": pad.clone()[1:, :]}
+        if len(self.alignment_modality) == 1:       # datamodules.py:148-169, 211-212
+            am = self.alignment_modality[0]
+            B = ids.shape[1]
+            if am not in inputs or inputs[am] is None:
+                a = torch.zeros(B, self.ALIGN_LEN, dtype=torch.float32, device=ids.device)
+            else:
+                x = inputs[am]
+                a = (x["spectra"] if isinstance(x, dict) else x).to(torch.float32)
+            if a.shape[1] < self.ALIGN_LEN:
+                a = torch.nn.functional.pad(a, (0, self.ALIGN_LEN - a.shape[1]), "constant", 0)
+            pp = self.preprocessors.get(am)
+            if self.data_config[am]["type"] == "1D_patches" and pp is not None and pp.interpolation:
+                # the reference CALLS the boolean field here (`self.preprocessors[m].interpolation(alignment_input)`): it cannot run
+                raise TypeError("'bool' object is not callable (reference datamodules.py:161-168: alignment targets with "
+                                "preprocessor_arguments.interpolation = True fail there too)")
+            out["encoder_alignment_input"] = a.contiguous()
+        return out
 
 
 def mix_indices(n_rows: int, mix_config: dict, split: str, seed: int = 3247):
@@ -191,3 +220,44 @@ class MixtureGenerator:
             yield {"indices": ri, "IR": mixed.repeat_interleave(len(keep), dim=0), "compound": comp,
                    "IR_target": self.table[comp],
                    "Percentage": torch.tensor([self.ratio[i] for i in keep] * len(ri), dtype=torch.float64)}
+
+
+def interleave_rounds(streams):
+    """`multi_config_mix` (data/datasets.py:24-46): the record streams of several mixture configurations alternate record by record
+    (zip_longest: an exhausted stream drops out, the others go on).  `streams`: iterables of dicts of equally long tensors (the rounds
+    of a MixtureGenerator); yields dicts in the interleaved order, at most one round's worth per yield."""
+    its = [iter(s) for s in streams]
+    if len(its) == 1:
+        for r in its[0]:
+            yield {k: v for k, v in r.items() if k != "indices"}
+        return
+    buf = [None] * len(its)          # unread tail of each stream's current round
+    live = [True] * len(its)
+
+    def n_rows(d):
+        return int(next(iter(d.values())).shape[0])
+
+    def refill(i):
+        while live[i] and (buf[i] is None or n_rows(buf[i]) == 0):
+            try:
+                r = next(its[i])
+                buf[i] = {k: v for k, v in r.items() if k != "indices"}
+            except StopIteration:
+                live[i], buf[i] = False, None
+    while True:
+        for i in range(len(its)):
+            refill(i)
+        act = [i for i in range(len(its)) if live[i]]
+        if not act:
+            return
+        n = min(n_rows(buf[i]) for i in act)                       # records every live stream can contribute right now
+        out = {}
+        for k in buf[act[0]]:
+            parts = [buf[i][k][:n] for i in act]
+            if torch.is_tensor(parts[0]):
+                out[k] = torch.stack(parts, 1).reshape((n * len(act),) + tuple(parts[0].shape[1:]))
+            else:
+                out[k] = np.stack(parts, 1).reshape((n * len(act),) + tuple(parts[0].shape[1:]))
+        for i in act:
+            buf[i] = {k: v[n:] for k, v in buf[i].items()}
+        yield out

@@ -50,7 +50,13 @@ WORKLOADS: Dict[str, Dict[str, Any]] = {
                      "Carbon": {**_text(2304), "type": "carbon"}, "Smiles": _text(128, True)},
                lens={"Formula": (32, 6, 20), "IR": 24, "Multiplets": (768, 100, 760), "Carbon": (200, 20, 190)},
                T=128, batch=128),
-    "c5": dict(cfg=dict(BASE, gated_linear=True), data={"Formula": _text(64), "IR": _patch(75), "Smiles": _text(128, True)},
+    # mixture IR -> SMILES with the alignment head of the reference's mixture runs (configs/model/custom_model_align.yaml:29-36,
+    # data/ir/patches_mixture_text_align.yaml): IR = the mean of two pure spectra, IR_target = the pure spectrum of the target compound
+    "c5": dict(cfg=dict(BASE, gated_linear=True,
+                        align_config=dict(align_network="convolutional", hidden_dimension=256, conv_channels=512, kernel_size=5,
+                                          output_dimension=1800, loss_lambda=50, loss_function="mae")),
+               data={"Formula": _text(64), "IR": _patch(75),
+                     "IR_target": {**_patch(75), "target": True, "alignment": True}, "Smiles": _text(128, True)},
                lens={"Formula": (32, 6, 20), "IR": 24}, T=256, batch=128),
 }
 
@@ -92,6 +98,7 @@ def make_batch(name: str, batch: int, seed: int, device="cpu") -> Tuple[Dict[str
     w = WORKLOADS[name]
     rng = np.random.default_rng(seed)
     enc, masks = {}, []
+    align = None
     for m, spec in w["lens"].items():
         mc = w["data"][m]
         if isinstance(spec, tuple):
@@ -108,9 +115,14 @@ def make_batch(name: str, batch: int, seed: int, device="cpu") -> Tuple[Dict[str
             masks.append(torch.from_numpy(pad))
         else:
             P, ps = spec, mc["preprocessor_arguments"]["patch_size"]
-            x = np.abs(rng.standard_normal((batch, P * ps))).astype(np.float32)
             k = np.exp(-0.5 * (np.arange(-9, 10) / 3.0) ** 2); k /= k.sum()       # sigma=3 smoothing
-            x = np.apply_along_axis(lambda r: np.convolve(r, k, mode="same"), 1, x)
+            smooth = lambda a: np.apply_along_axis(lambda r: np.convolve(r, k, mode="same"), 1, a)
+            x = smooth(np.abs(rng.standard_normal((batch, P * ps))).astype(np.float32))
+            if any(c.get("alignment") for c in w["data"].values()):
+                # a mixture workload: the input is the mean of this compound's spectrum and a second one (mix_spectra, equal
+                # ratios); the compound's own raw spectrum is the alignment head's target (datamodules.py:148-160)
+                align = x.astype(np.float32)
+                x = 0.5 * (x + smooth(np.abs(rng.standard_normal((batch, P * ps))).astype(np.float32)))
             x = (x - x.mean()) / (x.std() + 1e-8)                                  # PatchPreprocessor standardise
             enc[m] = torch.from_numpy(np.ascontiguousarray(x.reshape(batch, P, ps).transpose(1, 0, 2)).astype(np.float32))
             masks.append(torch.zeros(P, batch, dtype=torch.bool))
@@ -128,6 +140,9 @@ def make_batch(name: str, batch: int, seed: int, device="cpu") -> Tuple[Dict[str
         "decoder_pad_mask": ids[:-1] == PAD,
         "target": ids[1:].contiguous(),
     }
+    if align is not None:
+        a = torch.from_numpy(align)
+        b["encoder_alignment_input"] = torch.nn.functional.pad(a, (0, max(0, 1800 - a.shape[1])))
     if device != "cpu":
         b = to_device(b, device)
     return b, w
@@ -159,6 +174,8 @@ def synth_shards(data_config, n_train: int, n_val: int, n_test: int, seed: int =
     def shard(n):
         data, meta = {}, {}
         for m, mc in data_config.items():
+            if mc.get("alignment"):
+                continue            # the alignment target is made by the mixture generator (or absent: the collator fills zeros)
             if mc["type"] == "1D_patches":
                 x = np.abs(rng.standard_normal((n, spectrum_len))).astype(np.float32)
                 k = np.exp(-0.5 * (np.arange(-9, 10) / 3.0) ** 2); k /= k.sum()

@@ -66,3 +66,28 @@ def test_cli_plan_from_the_reference_tests_override_list():
     assert plan["model_config"]["model_type"] == "CustomModel" and plan["acc_batches"] == 4 and plan["clip_grad"] == 1.0
     assert shards["train"]["data"]["IR"]["spectra"].shape == (1000, 1800)
     assert shards["train"]["data"]["Smiles"]["input_ids"].shape == (1000, 65)
+
+
+C5 = ["data=ir/patches_mixture_text_align", "mixture=ir/binary", "model=custom_model_align"]
+
+
+def test_compose_mixture_run_groups():
+    """The groups of the reference's mixture runs (paper_replication/mixture scripts: data=ir/patches_mixture_text_align,
+    mixture=ir/binary, model=custom_model_align) exist in this repo's tree with the reference's keys."""
+    cfg = compose(os.path.join(ROOT, "configs"), "config_train", C5 + ["mixture.balanced.train_max_n_samples=4096"])
+    assert cfg["mixture"]["balanced"]["n_compounds"] == 2 and cfg["mixture"]["balanced"]["train_max_n_samples"] == 4096
+    assert cfg["data"]["IR_target"]["alignment"] is True and cfg["data"]["IR_target"]["target"] is True
+    assert cfg["model"]["align_config"]["loss_lambda"] == 50 and cfg["model"]["align_config"]["align_network"] == "convolutional"
+    from multimodalanalytical_amd.cli.training import build_plan
+    from multimodalanalytical_amd.synth import synth_shards
+    shards = synth_shards(cfg["data"], 64, 8, 8)
+    assert "IR_target" not in shards["train"]["data"]                       # made by the mixture generator, not stored
+    plan = build_plan(cfg, shards["train"]["meta"], 4096)
+    assert plan["target_modality"] == "Smiles" and plan["model_config"]["align_config"]["output_dimension"] == 1800
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/configs"), reason="reference tree only exists in the build container")
+def test_mixture_run_groups_equal_the_reference_tree():
+    ours = compose(os.path.join(ROOT, "configs"), "config_train", C5)
+    ref = compose("/root/reference/configs", "config_train", C5)
+    assert ours["data"] == ref["data"] and ours["mixture"] == ref["mixture"] and ours["model"] == ref["model"]

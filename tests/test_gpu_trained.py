@@ -1,0 +1,71 @@
+"""GPU: the argmax-id claim on TRAINED weights (north star: "bit-exact on argmax SMILES token ids").
+
+Freshly initialised weights give near-flat logits: the top-2 margins are tiny and a 1e-3 arithmetic cannot decide every position,
+which is why the other parity tests use a margin policy.  A trained model is what the claim is about: here a model of the workload's
+layer shapes is trained for a few hundred optimiser steps on a small fixed synthetic set in the parity-grade mode (bf16x3), then the
+SAME weights are run forward in the timed mode (fp16) and on the CPU oracle: logits within 1e-3, ids EXACTLY equal, and at least
+99.9 % of the positions decidable (top-2 margin above twice the measured error).  The counts go to gpurun_out/parity_records.jsonl."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import afm_oracle as O  # noqa: E402
+from tests.conftest import record_parity  # noqa: E402
+
+DEV = "cuda:0"
+
+
+@pytest.mark.parametrize("name,B,steps,lr", [("c2", 8, 200, 5e-4), ("c4", 2, 160, 2e-4)])
+def test_trained_weights_fp16_ids_equal_the_cpu_oracle(name, B, steps, lr):
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from multimodalanalytical_amd import synth
+    from multimodalanalytical_amd.engine import Seq2SeqEngine
+    from multimodalanalytical_amd.modeling.wrapper import HFWrapper, SimpleTokenizerInfo
+    from multimodalanalytical_amd.trainer import TrainLoop
+    from multimodalanalytical_amd.x2 import X2
+    wl = synth.WORKLOADS[name]
+    V = wl["data"]["Smiles"]["vocab_size"]
+    cfg = dict(wl["cfg"], dropout=0.0)                 # a fixed set, memorised: margins grow fastest without noise
+    batch_cpu, _ = synth.make_batch(name, B, seed=77)
+    batch = synth.to_device(batch_cpu, DEV)
+    model = HFWrapper(wl["data"], "CustomModel", "facebook/bart-base", SimpleTokenizerInfo(V), optimiser="adamw", lr=lr,
+                      num_steps=steps + 1, device=DEV, compute_dtype=X2.dtype, backward_dtype=torch.bfloat16, seed=3,
+                      **{k: v for k, v in cfg.items() if k != "multimodal_norm"})
+    loop = TrainLoop(model, acc_batches=1)
+    first = last = None
+    for i in range(steps):
+        loss = loop.micro_batch(batch)
+        if i == 0:
+            first = float(loss)
+    last = float(loss)
+    assert last < 0.25 * first, (first, last)          # it learned the set: the logits have margins now
+    sd = {k: v.detach().float().cpu() for k, v in model.hf_model.engine.state_dict().items()}
+    del model, loop
+    torch.cuda.empty_cache()
+    enc, am, dec, dm, labels = O.batch_to_model_inputs(batch_cpu, "Smiles")
+    to = lambda x: {k: to(v) for k, v in x.items()} if isinstance(x, dict) else x.to(DEV)
+    eng = Seq2SeqEngine(cfg, wl["data"], "Smiles", V, device=DEV, compute_dtype=torch.float16, seed=5)
+    eng.load_state_dict(sd)
+    out = eng.forward(to(enc), am.to(DEV), dec.to(DEV), dm.to(DEV), labels.to(DEV))
+    torch.set_num_threads(min(64, torch.get_num_threads()))
+    with torch.no_grad():
+        ref = O.model_forward(sd, cfg, wl["data"], "Smiles", enc, am, dec, dm)["logits"].double()
+    got = out["logits"].cpu().double()
+    scale = float(ref.abs().max())
+    err = float((got - ref).abs().max()) / scale
+    ids, rid = out["argmax"].cpu(), ref.argmax(-1)
+    keep = dm.bool()                                   # real decoder positions (padded ones carry no label and no loss)
+    top2 = ref.topk(2, -1).values
+    sure = (top2[..., 0] - top2[..., 1]) > 2 * err * scale
+    rec = dict(workload=name, mode="fp16", batch=B, weights=f"trained {steps} steps in bf16x3-mixed (loss {first:.3f} -> {last:.3f})",
+               logits_rel_err=err, logits_abs_max=scale, positions=int(ids.numel()), ids_differ=int((ids != rid).sum()),
+               ids_differ_at_real_positions=int((ids != rid)[keep].sum()), undecidable=int((~sure).sum()),
+               undecidable_at_real_positions=int((~sure)[keep].sum()))
+    record_parity("test_trained_weights_fp16_ids_equal_the_cpu_oracle", **rec)
+    print(rec)
+    assert err < 1e-3, rec
+    assert torch.equal(ids[keep], rid[keep]), rec      # the ids the accuracy and the decode are made of: exactly equal
+    assert float(sure[keep].double().mean()) >= 0.999, rec
+    assert torch.equal(ids[sure], rid[sure]), rec

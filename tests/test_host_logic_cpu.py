@@ -96,6 +96,28 @@ def test_mixture_index_stream_matches_oracle_restatement():
     assert [len(x) for x in mix_indices(5, cfg3, "train")] == [len(x) for x in O.mix_indices(5, cfg3, "train")]
 
 
+def test_interleave_rounds_is_zip_longest_over_the_record_streams():
+    """preprocess.interleave_rounds == `multi_config_mix` (data/datasets.py:24-46): the record streams of several mixture
+    configurations alternate record by record, an exhausted stream drops out."""
+    from itertools import zip_longest
+    from multimodalanalytical_amd.preprocess import interleave_rounds
+
+    def stream(tag, sizes):
+        base = 0
+        for n in sizes:
+            yield {"indices": None, "IR": torch.arange(base, base + n).float()[:, None] + 1000.0 * tag,
+                   "compound": torch.arange(base, base + n) + 1000 * tag}
+            base += n
+    layouts = [[(0, [5, 3, 4])], [(0, [5, 3]), (1, [2, 9, 1])], [(0, [4]), (1, [4, 4]), (2, [1, 1, 1, 7])]]
+    for lay in layouts:
+        got = torch.cat([r["compound"] for r in interleave_rounds([stream(t, sz) for t, sz in lay])]).tolist()
+        flat = [[1000 * t + i for i in range(sum(sz))] for t, sz in lay]
+        want = [x for row in zip_longest(*flat, fillvalue=None) for x in row if x is not None]
+        assert got == want, lay
+        ir = torch.cat([r["IR"] for r in interleave_rounds([stream(t, sz) for t, sz in lay])])[:, 0].long().tolist()
+        assert ir == want
+
+
 def test_param_spans_must_be_contiguous():
     """linear1|gate and the packed biases are read as ONE view: dimensions that leave alignment padding between
     the tensors must be refused, not silently shifted (params.ParamStore.span / vec_span)."""
