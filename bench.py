@@ -6,8 +6,10 @@
 A "step" is one optimiser step of the reference's training configuration: acc_batches (4) micro-batches of
 `batch` (128) samples each through HFWrapper.training_step (forward + backward, dropout 0.1 active), then
 gradient clip 1.0 + AdamW + OneCycleLR; with N > 1 the flat gradient buffer is all-reduced over RCCL once per
-step, overlapped with the last backward.  Inputs are synthetic (multimodalanalytical_amd/synth.py, seeded) and
-resident in HBM before the timed region.  Prints ONE JSON line (rank 0).
+step, overlapped with the last backward.  Inputs are synthetic (multimodalanalytical_amd/synth.py, seeded): the 177 000-sample
+set of SURVEY 8(d) is resident in HBM before the timed region as RAW pre-tokenised data, and every micro-batch is drawn, standardised,
+patchified and collated on the device inside it (--input-path fixed: the pre-collated batches of rounds 1-3).  Prints ONE JSON line
+(rank 0).
 
 Precision modes, all timed in the same run and listed under `modes`:
   fp16          (`value`) fp16 operands, ONE MFMA pass per product forward and backward, fp32 accumulation / residual stream /
@@ -49,6 +51,11 @@ def parse():
     ap.add_argument("--extra-steps", type=int, default=10, help="timed steps of each --extra-workloads entry (5 for c4 / c5)")
     ap.add_argument("--extra-workloads", default="c3,c4,c5", help="comma list: further workloads timed in the primary mode (N = 1 only)")
     ap.add_argument("--no-parity", action="store_true", help="skip the in-run logits / ids check against the CPU oracle")
+    ap.add_argument("--input-path", default="loader", choices=["loader", "fixed"],
+                    help="loader: every micro-batch is drawn inside the timed region from the resident 177 000-sample synthetic shard "
+                         "(ShardLoader -> DeviceCollator -> afm_patch_preprocess; mixture workloads: MixtureLoader -> afm_mix_spectra); "
+                         "fixed: 4 pre-collated batches per rank, cycled (the loop of rounds 1-3)")
+    ap.add_argument("--set-size", type=int, default=177000, help="samples of the resident synthetic set (SURVEY 8d: synth-177K)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=8)
@@ -334,19 +341,61 @@ def build(workload, mode, steps_total, world, dev, args):
     return wl, tok, model, loop
 
 
-def timed_run(workload, mode, steps, warmup, rank, world, dev, args, keep=False):
+def make_loader(workload, B, rank, world, dev, n):
+    """The input path of the training loop over the resident synthetic set (reference data/datamodules.py:140-228 +
+    preprocessing/patches.py:54-107 + datasets.py:58-141 for the mixture workload): rank-strided, shuffled, collated on the device."""
+    from multimodalanalytical_amd import synth
+    from multimodalanalytical_amd.cli.training import MixtureLoader, ShardLoader
+    from multimodalanalytical_amd.preprocess import DeviceCollator, PatchPreprocessor
+    wl = synth.WORKLOADS[workload]
+    shard = synth.make_shard(workload, n, seed=3247, device=dev)
+    if any(c.get("alignment") for c in wl["data"].values()):       # c5: mixtures of two compounds + the alignment target
+        base = synth.shard_collator(workload, shard, dev)
+        pre = dict(base.preprocessors)
+        for m, c in wl["data"].items():
+            if c.get("alignment"):
+                pre[m] = PatchPreprocessor(int(c["preprocessor_arguments"]["patch_size"]), False, False, device=str(dev))
+        mix = {"balanced": dict(n_compounds=2, compounds_ratio=None, train_max_n_samples=320000000, validation_max_n_samples=10000,
+                                test_max_n_samples=10000, parallel_samples=16384, normalize=False)}    # configs/mixture/ir/binary.yaml
+        return MixtureLoader(shard, mix, "train", DeviceCollator(wl["data"], pre), B, dev, rank, world)
+    return ShardLoader(shard, synth.shard_collator(workload, shard, dev), B, dev, rank, world, shuffle=True)
+
+
+def timed_run(workload, mode, steps, warmup, rank, world, dev, args, keep=False, input_path=None):
     """W untimed + K timed optimiser steps; returns (samples/s over all ranks, seconds, final loss, extras)."""
     import torch.distributed as dist
     from multimodalanalytical_amd import synth
     wl, tok, model, loop = build(workload, mode, steps + warmup, world, dev, args)
     B = args.batch or wl["batch"]
-    batches = [synth.make_batch(workload, B, seed=3247 + 1000 * rank + i, device=dev)[0] for i in range(args.acc)]
-    torch.cuda.synchronize()
+    input_path = input_path or args.input_path
+    if input_path == "loader":
+        loader = make_loader(workload, B, rank, world, dev, args.set_size)
 
-    def step():
-        for i in range(args.acc):
-            loss = loop.micro_batch(batches[i])
-        return loss
+        def stream():
+            e = 0
+            while True:
+                got = False
+                for b in loader.epoch(e):
+                    got = True
+                    yield b
+                if not got:
+                    raise RuntimeError("the loader produced no batch")
+                e += 1
+        it = stream()
+        batches = [next(it) for _ in range(args.acc)]          # (shape / mask statistics only; the timed loop keeps drawing)
+
+        def step():
+            for _ in range(args.acc):
+                loss = loop.micro_batch(next(it))
+            return loss
+    else:
+        batches = [synth.make_batch(workload, B, seed=3247 + 1000 * rank + i, device=dev)[0] for i in range(args.acc)]
+
+        def step():
+            for i in range(args.acc):
+                loss = loop.micro_batch(batches[i])
+            return loss
+    torch.cuda.synchronize()
 
     from multimodalanalytical_amd.trainer import barrier
     for _ in range(warmup):
@@ -372,7 +421,7 @@ def timed_run(workload, mode, steps, warmup, rank, world, dev, args, keep=False)
     live = torch.cat([(~b["encoder_pad_mask"]).sum(0).double() for b in batches])          # live encoder positions per sample
     ex = synth.executed_flops_per_sample(wl["cfg"], S, wl["T"], tok.vocab_size, float(live.mean()), float((live * live).mean()))
     res = {"value": steps * args.acc * B * world / dt, "dt": dt, "loss": float(loss), "S": S, "B": B, "flops": flops, "wl": wl,
-           "executed": ex, "live_frac": float(live.mean()) / S}
+           "executed": ex, "live_frac": float(live.mean()) / S, "input_path": input_path}
     if rank == 0 and world == 1 and not args.no_parity and not args.no_cpu_baseline:
         res["parity"] = measured_parity(model, wl, workload)
     if loop.reducer is not None:
@@ -384,7 +433,9 @@ def timed_run(workload, mode, steps, warmup, rank, world, dev, args, keep=False)
         res["model"] = model
     else:
         del model, loop, batches
-        torch.cuda.empty_cache()
+    if input_path == "loader":
+        del it, loader
+    torch.cuda.empty_cache()
     return res
 
 
@@ -446,6 +497,14 @@ def main():
             if "parity" in r:
                 workloads[w]["logits_vs_cpu_reference"] = r["parity"]
 
+    # the same loop over 4 fixed pre-collated batches (rounds 1-3): what the input path costs inside the timed region
+    input_cmp = None
+    if world == 1 and args.input_path == "loader":
+        r = timed_run(args.workload, args.dtype, 4, 1, rank, world, dev, args, input_path="fixed")
+        input_cmp = {"timed": "loader: ShardLoader -> DeviceCollator -> afm_patch_preprocess over the resident synthetic set, inside the timed region",
+                     "set_size": args.set_size, "fixed_batch_value": round(r["value"], 3), "fixed_batch_ms_per_step": round(r["dt"] / 4 * 1e3, 3),
+                     "loader_over_fixed": round(value / r["value"], 4)}
+
     # step-level counters (committed rocprofv3 PMC passes of this command, tools/prof_step_pmc.sh): MFMA-busy share and HBM rate of a step
     step_pmc = None
     sp = os.path.join(ROOT, "profiles", f"r04_{args.workload}_{args.dtype}_step_pmc.json")
@@ -461,6 +520,9 @@ def main():
                                f"modalities {'+'.join(k for k in wl['data'] if k != 'Smiles')}",
                    "workload_note": "BASELINE.json configs[1], the designated 1-GPU configuration (IR-only, S = 1024); the IR+NMR "
                                     "configuration configs[2] (c3, same 196 GFLOP/sample) is timed under `workloads`",
+                   "input_path": (f"synth-{args.set_size // 1000}K ({args.set_size} samples, seed 3247) resident in HBM; every micro-batch drawn, "
+                                  "standardised, patchified and collated on the device INSIDE the timed region") if args.input_path == "loader"
+                   else "4 pre-collated batches per rank, cycled",
                    "micro_batch_per_gpu": B, "acc_batches": args.acc, "global_batch": B * args.acc * world,
                    "parallelism": f"dp{world}", "rccl_ranks": main_run.get("rccl_ranks", 0), "dropout": wl["cfg"]["dropout"],
                    "optimiser": "adamw+onecycle, clip 1.0",
@@ -482,6 +544,8 @@ def main():
         "final_loss": round(main_run["loss"], 4),
         "modes": modes,
     }
+    if input_cmp is not None:
+        out["input_path"] = input_cmp
     if workloads:
         out["workloads"] = workloads
     if rank == 0:

@@ -156,6 +156,63 @@ def to_device(b, device):
     return b
 
 
+def make_shard(name: str, n: int = 177000, seed: int = 3247, device="cpu") -> Dict[str, Any]:
+    """The synthetic set of SURVEY 8(d) ("synth-177K": 177 000 samples, seed 3247) for workload `name`, as ONE shard in the format
+    `cli/training.py` reads (pre-tokenised ids + RAW spectra): what `bench.py` keeps resident in HBM and draws every micro-batch
+    from through ShardLoader -> DeviceCollator -> afm_patch_preprocess inside the timed region.  Same layout and length
+    distributions as `make_batch`; the spectra are raw (positive, smoothed), standardisation happens in the collator's
+    PatchPreprocessor (statistics over the non-zero entries of the first 10 000 rows, patches.py:35-39)."""
+    w = WORKLOADS[name]
+    g = torch.Generator(device=device).manual_seed(seed)
+    data, meta = {}, {}
+
+    def ids(L, lo, hi, V, first_real=4):
+        nn = torch.randint(lo, hi + 1, (n,), generator=g, device=device) + 2          # + bos / eos
+        x = torch.randint(first_real, V, (n, L), generator=g, device=device)
+        pos = torch.arange(L, device=device)[None, :]
+        x[:, 0] = BOS
+        x.scatter_(1, torch.clamp(nn - 1, max=L - 1)[:, None], EOS)
+        pad = pos >= nn[:, None]
+        x[pad] = PAD
+        return {"input_ids": x, "attention_mask": ~pad}
+
+    for m, spec in w["lens"].items():
+        mc = w["data"][m]
+        if isinstance(spec, tuple):
+            L, lo, hi = spec
+            data[m] = ids(L, lo, hi, mc["vocab_size"])
+            meta[m] = {"vocab_size": mc["vocab_size"], "pad_token_id": PAD}
+        else:
+            P, ps = spec, mc["preprocessor_arguments"]["patch_size"]
+            k = torch.exp(-0.5 * (torch.arange(-9, 10, device=device, dtype=torch.float32) / 3.0) ** 2)
+            k = (k / k.sum())[None, None, :]
+            out = torch.empty(n, P * ps, dtype=torch.float32, device=device)
+            for i in range(0, n, 16384):                                               # sigma = 3 smoothing, in slabs
+                x = torch.randn(min(16384, n - i), 1, P * ps, generator=g, device=device).abs()
+                out[i:i + x.shape[0]] = torch.nn.functional.conv1d(x, k, padding=9)[:, 0] + 0.05
+            data[m] = {"spectra": out}
+    T, V = w["T"], w["data"]["Smiles"]["vocab_size"]
+    data["Smiles"] = ids(T + 1, 20, min(120, T - 8), V)
+    meta["Smiles"] = {"vocab_size": V, "pad_token_id": PAD}
+    return {"meta": meta, "data": data}
+
+
+def shard_collator(name: str, shard, device):
+    """DeviceCollator of workload `name` over `shard` (PatchPreprocessor statistics from its first 10 000 spectra)."""
+    from .preprocess import DeviceCollator, PatchPreprocessor
+    w = WORKLOADS[name]
+    dc = {m: c for m, c in w["data"].items() if not c.get("alignment")}
+    pre = {}
+    for m, mc in dc.items():
+        if mc["type"] == "1D_patches":
+            a = mc["preprocessor_arguments"]
+            pp = PatchPreprocessor(patch_size=int(a["patch_size"]), masking=bool(a.get("masking", False)),
+                                   interpolation=bool(a.get("interpolation", False)), device=str(device))
+            pp.initialise({m: shard["data"][m]["spectra"][:10000].cpu().numpy()}, m)
+            pre[m] = pp
+    return DeviceCollator(dc, pre)
+
+
 def synth_shards(data_config, n_train: int, n_val: int, n_test: int, seed: int = 3247, spectrum_len: int = 1800,
                  text_len: int = 32, target_len: int = 64, vocab: int = 64):
     """Pre-tokenised synthetic shards in the format `cli/training.py` reads, for ANY composed data config: text-like
