@@ -1605,6 +1605,11 @@ int AFM_E16_FN(afm_gemm_mfma_try)(const afm_gemm_desc* d, hipStream_t st) {
             d->accumulate || d->act != AFM_ACT_NONE || d->pre_act || d->drop.p > 0.f || (d->ldc % 8)) { r = AFM_ERR_UNSUPPORTED; break; }
         r = launch_nt_pp<EPI_PLAIN>(g, st);
         break;
+      case 31:   // (A/B partner of 30: the second DMA piece of a phase issued in the wave's MFMA section)
+        if ((d->K & 63) || d->K < 128 || (d->M & 255) || (d->N & 255) || d->N > PP_BIAS_MAX || d->c_dtype != AFM_E16 || d->residual ||
+            d->accumulate || d->act != AFM_ACT_NONE || d->pre_act || d->drop.p > 0.f || (d->ldc % 8)) { r = AFM_ERR_UNSUPPORTED; break; }
+        r = launch_nt_pp<EPI_PLAIN, 0, true>(g, st);
+        break;
 #ifdef AFM_GEMM_ABLATIONS
       case 301: r = launch_nt_pp<EPI_PLAIN, 1>(g, st); break;
       case 302: r = launch_nt_pp<EPI_PLAIN, 2>(g, st); break;

@@ -31,6 +31,9 @@
 //   * Epilogue per wave, no barrier: accumulators (bias is their initial value) -> e16 -> wave-private LDS patch (16 rows x 64 columns)
 //     -> 16-byte nontemporal stores of whole 128-byte lines.
 //
+// SPLIT (measured, not adopted): the second DMA piece of a phase issued by the wave in its MFMA section instead of its read section
+// (the idea: shorter read sections).  Same box, same run: QKV 215 vs 210 us, N 512 / K 2048 256 vs 247, N 512 / K 1536 199 vs 192:
+// slower; a piece issued behind the MFMAs delays the wave's arrival at the barrier by its ~60-cycle issue cost just the same.
 // ABL (timing builds): 1 no MFMAs, 2 no LDS-DMA, 4 no epilogue.
 
 #define PP_SUB 16384              // bytes of one sub-block: 128 rows x 128 B
@@ -54,7 +57,7 @@ __device__ __forceinline__ bool getenv_no_phase_stamps(const MfmaArgs& g) { retu
 #endif
 template <int N> __device__ __forceinline__ void pp_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <int EPI, int ABL = 0>
+template <int EPI, int ABL = 0, bool SPLIT = false>
 __global__ __launch_bounds__(512) void k_gemm_nt_pp(MfmaArgs g) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   const int t = threadIdx.x, lane = t & 63;
@@ -151,14 +154,18 @@ __global__ __launch_bounds__(512) void k_gemm_nt_pp(MfmaArgs g) {
 #endif
   auto read_end = [&](int skt, int sph) {   // DMA pieces of 5 phases ago have landed, own LDS reads are complete
     PP_STAMP(skt, sph, 1);
-    if (__builtin_expect(is_tile >= 0 && since_epi >= 5, 1)) pp_wait_vm<10>();
+    // pieces that may still be in flight: those of the last 5 phases (SPLIT: the MFMA-section piece of this phase is not issued yet:
+    // 9), fewer once the stream has ended, plus a recent epilogue's 16 stores
+    constexpr int BASE = SPLIT ? 9 : 10;
+    if (__builtin_expect(is_tile >= 0 && since_epi >= 5, 1)) pp_wait_vm<BASE>();
     else {
-      const int young = (is_tile < 0 ? (tail >= 5 ? 0 : 10 - 2 * tail) : 10) + (since_epi < 5 ? 16 : 0);
+      const int young = (is_tile < 0 ? (tail >= 4 ? 0 : 8 - 2 * tail) : BASE) + (since_epi < 5 ? 16 : 0);
       if (is_tile < 0) ++tail;
-      if (young >= 26) pp_wait_vm<26>(); else if (young >= 24) pp_wait_vm<24>(); else if (young >= 22) pp_wait_vm<22>();
-      else if (young >= 20) pp_wait_vm<20>(); else if (young >= 18) pp_wait_vm<18>(); else if (young >= 16) pp_wait_vm<16>();
-      else if (young >= 10) pp_wait_vm<10>(); else if (young >= 8) pp_wait_vm<8>(); else if (young >= 6) pp_wait_vm<6>();
-      else if (young >= 4) pp_wait_vm<4>(); else if (young >= 2) pp_wait_vm<2>(); else pp_wait_vm<0>();
+      if (young >= 26) pp_wait_vm<26>(); else if (young >= 25) pp_wait_vm<25>(); else if (young >= 24) pp_wait_vm<24>();
+      else if (young >= 22) pp_wait_vm<22>(); else if (young >= 20) pp_wait_vm<20>(); else if (young >= 18) pp_wait_vm<18>();
+      else if (young >= 16) pp_wait_vm<16>(); else if (young >= 10) pp_wait_vm<10>(); else if (young >= 9) pp_wait_vm<9>();
+      else if (young >= 8) pp_wait_vm<8>(); else if (young >= 6) pp_wait_vm<6>(); else if (young >= 4) pp_wait_vm<4>();
+      else if (young >= 2) pp_wait_vm<2>(); else pp_wait_vm<0>();
     }
     ++since_epi;
     PP_STAMP(skt, sph, 2);
@@ -215,8 +222,7 @@ __global__ __launch_bounds__(512) void k_gemm_nt_pp(MfmaArgs g) {
       PP_RD(fa[1][0], a0, 2048); PP_RD(fa[1][1], a1, 2048);
       PP_RD(fa[2][0], a0, 4096); PP_RD(fa[2][1], a1, 4096);
       PP_RD(fa[3][0], a0, 6144); PP_RD(fa[3][1], a1, 6144);
-      issue_h(3, 1);
-      is_advance();
+      if (!SPLIT) { issue_h(3, 1); is_advance(); }
       read_end(kt, 0);
       if (!(ABL & 1)) {
         __builtin_amdgcn_s_setprio(1);
@@ -228,13 +234,14 @@ __global__ __launch_bounds__(512) void k_gemm_nt_pp(MfmaArgs g) {
             for (int j = 0; j < 2; ++j) acc[0][i][j] = mfma16(fb0[j][ks], fa[i][ks], acc[0][i][j]);
         __builtin_amdgcn_s_setprio(0);
       }
+      if (SPLIT) { issue_h(3, 1); is_advance(); }
       mfma_end(kt, 0);
       // ---------------- phase 1: b1 -> quadrant (0, 1)
       PP_STAMP(kt, 1, 0);
       issue_h(0, 0);
       PP_RD(fb1[0][0], b0, 2 * PP_SUB); PP_RD(fb1[0][1], b1, 2 * PP_SUB);
       PP_RD(fb1[1][0], b0, 2 * PP_SUB + 2048); PP_RD(fb1[1][1], b1, 2 * PP_SUB + 2048);
-      issue_h(0, 1);
+      if (!SPLIT) issue_h(0, 1);
       read_end(kt, 1);
       if (!(ABL & 1)) {
         __builtin_amdgcn_s_setprio(1);
@@ -246,6 +253,7 @@ __global__ __launch_bounds__(512) void k_gemm_nt_pp(MfmaArgs g) {
             for (int j = 0; j < 2; ++j) acc[1][i][j] = mfma16(fb1[j][ks], fa[i][ks], acc[1][i][j]);
         __builtin_amdgcn_s_setprio(0);
       }
+      if (SPLIT) issue_h(0, 1);
       mfma_end(kt, 1);
       // ---------------- phase 2: a1 -> quadrant (1, 1)
       PP_STAMP(kt, 2, 0);
@@ -254,7 +262,7 @@ __global__ __launch_bounds__(512) void k_gemm_nt_pp(MfmaArgs g) {
       PP_RD(fa[1][0], a0, 3 * PP_SUB + 2048); PP_RD(fa[1][1], a1, 3 * PP_SUB + 2048);
       PP_RD(fa[2][0], a0, 3 * PP_SUB + 4096); PP_RD(fa[2][1], a1, 3 * PP_SUB + 4096);
       PP_RD(fa[3][0], a0, 3 * PP_SUB + 6144); PP_RD(fa[3][1], a1, 3 * PP_SUB + 6144);
-      issue_h(1, 1);
+      if (!SPLIT) issue_h(1, 1);
       read_end(kt, 2);
       if (!(ABL & 1)) {
         __builtin_amdgcn_s_setprio(1);
@@ -266,10 +274,12 @@ __global__ __launch_bounds__(512) void k_gemm_nt_pp(MfmaArgs g) {
             for (int j = 0; j < 2; ++j) acc[3][i][j] = mfma16(fb1[j][ks], fa[i][ks], acc[3][i][j]);
         __builtin_amdgcn_s_setprio(0);
       }
+      if (SPLIT) issue_h(1, 1);
       mfma_end(kt, 2);
       // ---------------- phase 3: quadrant (1, 0) from registers
       PP_STAMP(kt, 3, 0);
-      issue(2);
+      issue_h(2, 0);
+      if (!SPLIT) issue_h(2, 1);
       read_end(kt, 3);
       if (!(ABL & 1)) {
         __builtin_amdgcn_s_setprio(1);
@@ -281,6 +291,7 @@ __global__ __launch_bounds__(512) void k_gemm_nt_pp(MfmaArgs g) {
             for (int j = 0; j < 2; ++j) acc[2][i][j] = mfma16(fb0[j][ks], fa[i][ks], acc[2][i][j]);
         __builtin_amdgcn_s_setprio(0);
       }
+      if (SPLIT) issue_h(2, 1);
       mfma_end(kt, 3);
     }
 
@@ -328,7 +339,7 @@ __global__ __launch_bounds__(512) void k_gemm_nt_pp(MfmaArgs g) {
   if (wr == 0) __builtin_amdgcn_s_barrier();   // group 0's extra barrier: both groups execute the same number
 }
 
-template <int EPI, int ABL = 0>
+template <int EPI, int ABL = 0, bool SPLIT = false>
 static int launch_nt_pp(MfmaArgs& g, hipStream_t st) {
   g.tiles_m = g.M / 256; g.tiles_n = g.N / 256;
   int shm = PP_LIST_OFF;
@@ -340,7 +351,7 @@ static int launch_nt_pp(MfmaArgs& g, hipStream_t st) {
     const int tpx0 = (ntiles + 7) / 8, nbx0 = grid / 8;
     if ((tpx0 + nbx0 - 1) / nbx0 <= NT_LIVE_MAX) { g.live_off = PP_LIST_OFF; shm += NT_LIVE_BYTES; }
   }
-  auto kern = k_gemm_nt_pp<EPI, ABL>;
+  auto kern = k_gemm_nt_pp<EPI, ABL, SPLIT>;
   static AfmOncePerDevice attr;
   if (attr.need()) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   AFM_LAUNCH(kern, dim3(grid), dim3(512), shm, st, g);

@@ -45,7 +45,7 @@ def main():
     M = B * S
     shapes = [("qkv fwd", M, 3 * d, d), ("out fwd", M, d, d), ("ffn1 plain", M, f, d), ("ffn2 fwd", M, d, f), ("qkv dgrad", M, d, 3 * d),
               ("mem kv", M, 2 * d, d), ("dec qkv", 16384, 3 * d, d), ("dec ffn2", 16384, d, f)]
-    variants = {30: "pp", 24: "ws 256x128", 28: "256x256"}
+    variants = {30: "pp", 31: "pp split-dma", 24: "ws 256x128", 28: "256x256"}
     if "--abl" in sys.argv:
         variants.update({304: "pp no-epilogue", 302: "pp no-dma", 306: "pp lds+mfma", 301: "pp no-mfma", 250: "ws no-epilogue", 246: "ws lds+mfma"})
     for rnd in range(2):
