@@ -55,6 +55,7 @@ def parse():
                     help="loader: every micro-batch is drawn inside the timed region from the resident 177 000-sample synthetic shard "
                          "(ShardLoader -> DeviceCollator -> afm_patch_preprocess; mixture workloads: MixtureLoader -> afm_mix_spectra); "
                          "fixed: 4 pre-collated batches per rank, cycled (the loop of rounds 1-3)")
+    ap.add_argument("--no-input-compare", action="store_true", help="skip the fixed-batch comparison run (profiling: keeps the trace to the timed loop)")
     ap.add_argument("--set-size", type=int, default=177000, help="samples of the resident synthetic set (SURVEY 8d: synth-177K)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -499,7 +500,7 @@ def main():
 
     # the same loop over 4 fixed pre-collated batches (rounds 1-3): what the input path costs inside the timed region
     input_cmp = None
-    if world == 1 and args.input_path == "loader":
+    if world == 1 and args.input_path == "loader" and not args.no_input_compare:
         r = timed_run(args.workload, args.dtype, 4, 1, rank, world, dev, args, input_path="fixed")
         input_cmp = {"timed": "loader: ShardLoader -> DeviceCollator -> afm_patch_preprocess over the resident synthetic set, inside the timed region",
                      "set_size": args.set_size, "fixed_batch_value": round(r["value"], 3), "fixed_batch_ms_per_step": round(r["dt"] / 4 * 1e3, 3),

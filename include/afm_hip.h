@@ -166,7 +166,8 @@ int afm_scatter_add_rows(const int64_t* ids, const float* scale, const float* do
  * `add_drop` the branch dropout is applied here too (this kernel is HBM-bound and has the VALU slack for
  * the hash, the GEMM epilogue does not).
  * Backward: dx[r,:] = (dres ? dres[r,:] : 0) + LN'(dy[out_row(r),:]); dgamma/dbeta are
- * ACCUMULATED (+=) into fp32 buffers; `partial` is workspace of afm_layernorm_bwd_ws_floats().
+ * ACCUMULATED (+=) into fp32 buffers; `partial` is workspace of afm_layernorm_bwd_ws_floats() floats (0 for the shapes the
+ * vectorised kernel takes -- d % 8 == 0, d <= 2048, rows >= 64 --, which adds its block sums with atomics: `partial` may then be null).
  * `dx_drop` (optional, dtype y_dtype, rows x d): dropout(dx) with stream `drop`, i.e. the gradient
  * of the dropped-out residual branch that was added in front of this LayerNorm, handed to the
  * branch's GEMMs in their operand dtype without another pass over dx.

@@ -331,8 +331,11 @@ static inline int ln_bwd_blocks(int64_t rows) {
   if (g < 1) g = 1;
   return (int)g;
 }
+// the vectorised backward adds its block sums to dgamma / dbeta with atomics and touches no workspace
+static inline bool ln_bwd_vectorised(const afm_ln_shape* s) { return (s->d % 8) == 0 && s->d <= 2048 && s->rows >= 64; }
 extern "C" int64_t afm_layernorm_bwd_ws_floats(const afm_ln_shape* s) {
   if (!s) return 0;
+  if (ln_bwd_vectorised(s)) return 0;
   return (int64_t)ln_bwd_blocks(s->rows) * 2 * s->d;
 }
 
@@ -433,15 +436,16 @@ extern "C" int afm_layernorm_bwd(const afm_ln_shape* s, const void* dy, const fl
                                  const float* dres, float* dx, float* dgamma, float* dbeta,
                                  float* partial, void* dx_drop, const afm_dropout* drop, void* stream) {
   const DropDev dd = afm_make_drop(drop);
-  if (!s || !dy || !x || !gamma || !mean || !rstd || !dx || !partial || s->rows < 0 || s->d <= 0)
+  if (!s || !dy || !x || !gamma || !mean || !rstd || !dx || s->rows < 0 || s->d <= 0)
     return AFM_ERR_ARG;
+  if (!partial && !ln_bwd_vectorised(s)) return AFM_ERR_ARG;      // (afm_layernorm_bwd_ws_floats says which shapes need it)
   if (s->d > 64 * LN_MAXV) return AFM_ERR_UNSUPPORTED;
   if (s->rows == 0) return AFM_OK;
   const int g = ln_bwd_blocks(s->rows);
   hipStream_t st = (hipStream_t)stream;
   const size_t shm = sizeof(float) * 8 * s->d;
   if (s->y_dtype < AFM_F32 || s->y_dtype > AFM_F16) return AFM_ERR_ARG;
-  if ((s->d % 8) == 0 && s->d <= 2048 && s->rows >= 64) {   // vectorised path (dy rows follow the embedder's placement, if any)
+  if (ln_bwd_vectorised(s)) {   // vectorised path (dy rows follow the embedder's placement, if any)
 #define LN_BV(TY, NC) AFM_LAUNCH((k_ln_bwd_vec<TY, NC>), dim3(g), dim3(256), shm, st, (const TY*)dy, x, gamma, mean, rstd, dres, dx, \
                                  dgamma, dbeta, s->rows, s->d, (TY*)dx_drop, dd, s->seg_len, s->out_seg_stride, s->out_off,   \
                                  (s->seg_len == 0 && (s->rows & 63) == 0) ? s->row_live : nullptr)

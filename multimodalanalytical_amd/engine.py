@@ -19,6 +19,8 @@ import os
 
 import torch
 
+_DEBUG_LIVE = os.environ.get("AFM_DEBUG_LIVE", "0") == "1"      # verify the padded-row hints against the data (host sync)
+
 from . import ops
 from .lib import (ACT_GELU, ACT_GELU_BWD, ACT_GELU_SAVE_GRAD, ACT_GLU, ACT_GLU_BWD, ACT_GLU_SAVE, ACT_MUL_SAVED, ACT_NONE, ACT_RELU,
                   AFM_BF16, ALGO_AUTO)
@@ -280,7 +282,7 @@ class Seq2SeqEngine:
             out = self._empty_b(dy.shape[0], cols, out_dtype)
         kw = dict(accumulate=accumulate, algo=self.algo, act=act, pre_act=self._hb(pre_act), dropout=dropout)
         if self.lowp and torch.is_tensor(dy):
-            kw["k_live"] = self._live.get(dy.shape[0])      # row tiles of nothing but padded positions: zeros in, zeros out
+            kw["k_live"] = self._live_hint(dy)      # row tiles of nothing but padded positions: zeros in, zeros out
         if self.lowp:
             wt = self._hb(self.wt[name][:, r0:r1])  # (cols, n): NT form for the MFMA kernel
             return ops.gemm(dy, wt, out, trans_b=True, **kw)
@@ -298,7 +300,7 @@ class Seq2SeqEngine:
     def _wgrad_raw(self, dy, x, gw, gb, glu_rows=0):
         kw = dict(trans_a=True, trans_b=False, accumulate=True, algo=self.algo, a_colsum=gb, glu_rows=glu_rows)
         if torch.is_tensor(dy) and dy.dtype != torch.float32:
-            kw["k_live"] = self._live.get(dy.shape[0])      # padded 64-token blocks carry exact zeros: left out of the token axis
+            kw["k_live"] = self._live_hint(dy)      # padded 64-token blocks carry exact zeros: left out of the token axis
         if self.group_wgrad and torch.is_tensor(dy) and torch.is_tensor(x) and dy.dtype == x.dtype and dy.dtype != torch.float32:
             # 16-bit operands: the layer's weight gradients go out together at the end of its backward (afm_gemm_group: one
             # launch, one split-K budget); the list keeps dy / x alive until then
@@ -1083,7 +1085,7 @@ class Seq2SeqEngine:
             dx = self._post_sub_bwd(dx, p + "norm1.", sv, "ln1", f"e{i}res",
                                     lambda dy, acc: self._self_attn_bwd(None, dy, p, sv, None, acc=acc))
             self._grads_final_from(p + "self_attn.in_proj_weight")
-        self.embed_bwd(dx, saved["emb_enc"])
+        self._embed_bwd_unhinted(dx, saved["emb_enc"])
         self._wgrad_flush()
         self._live = {}
         if self.wgrad_stream is not None:
@@ -1097,6 +1099,26 @@ class Seq2SeqEngine:
             if self.wgrad_stream is not None:
                 torch.cuda.current_stream().wait_stream(self.wgrad_stream)
             self.grad_ready_hook(self.ps.specs[first_name].offset)
+
+    def _embed_bwd_unhinted(self, dx, saved_emb):
+        """The padded-row hints (`_live`) are keyed by row count and belong to the layer stacks (B * S encoder rows, B * T decoder rows).
+        A modality's own row count may coincide with one of them (a modality as long as the decoder sequence) while its padding
+        differs: the embedder backward therefore runs without hints."""
+        keep, self._live = self._live, {}
+        try:
+            self.embed_bwd(dx, saved_emb)
+        finally:
+            self._live = keep
+
+    def _live_hint(self, t):
+        """Padded-row hint for a backward operand `t` (one byte per 64-row block; None: no hint).  AFM_DEBUG_LIVE=1 checks, with a
+        host synchronisation, that every row the hint calls dead really is zero."""
+        h = self._live.get(t.shape[0]) if torch.is_tensor(t) else None
+        if h is not None and _DEBUG_LIVE:
+            rows = t.hi if hasattr(t, "hi") else t
+            dead = (h == 0).repeat_interleave(64)
+            assert float(rows[dead].float().abs().max() if bool(dead.any()) else 0.0) == 0.0, "a row marked dead by the padded-row hint is not zero"
+        return h
 
     def _backward(self, saved, logits, lab, row_lse, stats, loss_scale, mem):
         d = self.d
@@ -1146,7 +1168,7 @@ class Seq2SeqEngine:
                 if dmem is None:
                     dmem = torch.empty(B * S, d, dtype=torch.float32, device=self.dev)
                 ops.gemm(dkv_all, self._hb(self.wt_kv_all), dmem, trans_b=True, accumulate=had_init, algo=self.algo)
-        self.embed_bwd(dx, saved["emb_dec"])
+        self._embed_bwd_unhinted(dx, saved["emb_dec"])
         if dmem_c is None:
             dmem_c = dmem
             if self.lowp:
@@ -1158,7 +1180,7 @@ class Seq2SeqEngine:
             dx, dy = self._ffn_bwd(dx, dy, p, self.cfg["encoder_ffn_dim"], "norm2.", sv, f"e{i}res")
             dx, dy = self._self_attn_bwd(dx, dy, p, sv, f"e{i - 1}res2" if i > 0 else None)
             self._grads_final_from(p + "self_attn.in_proj_weight")
-        self.embed_bwd(dx, saved["emb_enc"])
+        self._embed_bwd_unhinted(dx, saved["emb_enc"])
         self._wgrad_flush()
         self._live = {}
         if self.wgrad_stream is not None:   # every weight gradient is in before the caller reads the buffer

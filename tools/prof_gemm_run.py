@@ -16,6 +16,8 @@ CONFIGS = [
     ("ffn2_dgrad_xsaved_default", f, d, dict(act=5, pre=1), 0),
     ("ffn1_plain_default", f, d, dict(bias=1), 0),
     ("ffn1_plain_pingpong", f, d, dict(bias=1), 30),
+    ("qkv_dgrad_default", d, 3 * d, dict(), 0),
+    ("ffn1_wgrad_default", f, d, dict(tn=1), 0),          # dW1 (f x d) over M tokens, bias gradient fused
 ]
 
 
@@ -30,6 +32,14 @@ def main():
     dev = "cuda:0"
     dr = ops.drop(0.1, 1, 1)
     for name, N, K, kw, var in CONFIGS:
+        if kw.get("tn"):
+            dy = (torch.randn(M, N, device=dev) * 0.01).half(); xx = torch.randn(M, K, device=dev).half()
+            gw = torch.zeros(N, K, device=dev); gb = torch.zeros(N, device=dev)
+            torch.cuda.synchronize()
+            for _ in range(a.reps): ops.gemm(dy, xx, gw, trans_a=True, trans_b=False, accumulate=True, a_colsum=gb)
+            torch.cuda.synchronize()
+            print(name, ops.last_algo(), flush=True)
+            continue
         x = torch.randn(M, K, device=dev).half(); w = (torch.randn(N, K, device=dev) * 0.05).half()
         c = torch.empty(M, N, dtype=torch.float16, device=dev)
         args = dict(variant=var)

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Step-level counters of the benchmark command: three rocprofv3 PMC passes (--kernel-trace --pmc only) over
-#   python3 bench.py --steps 2 --warmup 1 --other-modes "" --extra-workloads "" --no-roofline --no-cpu-baseline   (3 optimiser steps)
+#   python3 bench.py --steps 2 --warmup 1 --other-modes "" --extra-workloads "" --no-roofline --no-cpu-baseline --no-input-compare   (3 optimiser steps)
 #   bash tools/prof_step_pmc.sh <tag> [workload] [dtype]  -> gpurun_out/prof/<tag>_<workload>_<dtype>_step_pmc.json
 set -u
 R=$GRAFT_REPO_ROOT
@@ -14,7 +14,7 @@ G3="WRITE_SIZE"
 i=0
 for g in "$G1" "$G2" "$G3"; do
   i=$((i+1))
-  timeout 600 rocprofv3 --kernel-trace --pmc $g -d $O/spmc_$i -o pmc -- python3 $R/bench.py --workload $wl --dtype $dt --steps 2 --warmup 1 --other-modes "" --extra-workloads "" --no-roofline --no-cpu-baseline > $O/${tag}_step_$i.log 2>&1
+  timeout 600 rocprofv3 --kernel-trace --pmc $g -d $O/spmc_$i -o pmc -- python3 $R/bench.py --workload $wl --dtype $dt --steps 2 --warmup 1 --other-modes "" --extra-workloads "" --no-roofline --no-cpu-baseline --no-input-compare > $O/${tag}_step_$i.log 2>&1
   cp $(find $O/spmc_$i -name "*.db" | head -1) $O/${tag}_step_pass$i.db 2>/dev/null
   rm -rf $O/spmc_$i
 done
