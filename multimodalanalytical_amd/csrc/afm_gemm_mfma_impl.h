@@ -1605,6 +1605,11 @@ int AFM_E16_FN(afm_gemm_mfma_try)(const afm_gemm_desc* d, hipStream_t st) {
             d->accumulate || d->act != AFM_ACT_NONE || d->pre_act || d->drop.p > 0.f || (d->ldc % 8)) { r = AFM_ERR_UNSUPPORTED; break; }
         r = launch_nt_pp<EPI_PLAIN>(g, st);
         break;
+      case 32:   // (A/B partner of 30: balanced phases, b0 of the next K-tile read one phase early; K % 128 == 0)
+        if ((d->K & 127) || d->K < 128 || (d->M & 255) || (d->N & 255) || d->N > PP_BIAS_MAX || d->c_dtype != AFM_E16 || d->residual ||
+            d->accumulate || d->act != AFM_ACT_NONE || d->pre_act || d->drop.p > 0.f || (d->ldc % 8)) { r = AFM_ERR_UNSUPPORTED; break; }
+        r = launch_nt_pp<EPI_PLAIN, 0, false, true>(g, st);
+        break;
       case 31:   // (A/B partner of 30: the second DMA piece of a phase issued in the wave's MFMA section)
         if ((d->K & 63) || d->K < 128 || (d->M & 255) || (d->N & 255) || d->N > PP_BIAS_MAX || d->c_dtype != AFM_E16 || d->residual ||
             d->accumulate || d->act != AFM_ACT_NONE || d->pre_act || d->drop.p > 0.f || (d->ldc % 8)) { r = AFM_ERR_UNSUPPORTED; break; }
@@ -1674,7 +1679,7 @@ int AFM_E16_FN(afm_gemm_mfma_try)(const afm_gemm_desc* d, hipStream_t st) {
 #undef PRING_CASE
 #undef NT_CASE
     if (r != AFM_OK) return r;
-    afm_set_last_algo(variant == 28 ? "mfma_nt_256" : variant == 30 ? "mfma_nt_pp" : "mfma_nt");     // (_256: the 256 x 256-tile form)
+    afm_set_last_algo(variant == 28 ? "mfma_nt_256" : (variant >= 30 && variant <= 32) ? "mfma_nt_pp" : "mfma_nt");     // (_256: the 256 x 256-tile form)
     return AFM_OK;
   }
   if (d->transA && !d->transB) {  // TN: the wgrad form only

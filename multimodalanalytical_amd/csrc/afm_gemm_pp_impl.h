@@ -57,7 +57,13 @@ __device__ __forceinline__ bool getenv_no_phase_stamps(const MfmaArgs& g) { retu
 #endif
 template <int N> __device__ __forceinline__ void pp_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <int EPI, int ABL = 0, bool SPLIT = false>
+// BAL: the K-tile's stream order is (b0, a0, b1, a1) and b0 of K-tile t + 1 is read one phase EARLY, in phase 3 of K-tile t (which
+// otherwise reads nothing), into a third B register set: 8 / 4 / 8 / 4 fragment reads per phase instead of 12 / 4 / 8 / 0.  With s = {-1, 0,
+// 1, 2} the two hazard conditions of the header (j >= s_j, s_j >= j - 1) hold unchanged.  Needs an even number of K-tiles per tile (the
+// two B sets swap roles every K-tile; the loop is unrolled by two).  Bit-identical results, 246 registers.  Measured against the
+// unbalanced form in one run (two rounds): QKV 206 vs 212 us, N 2048 / K 512 270 vs 276, N 512 / K 1536 196 vs 200, N 512 / K 2048 251 vs
+// 251, N 1024 / K 512 143 vs 138, N 512 / K 512 76 vs 75: +-3 %, the sign depends on the shape.  Kept as dispatch variant 32, not the default.
+template <int EPI, int ABL = 0, bool SPLIT = false, bool BAL = false>
 __global__ __launch_bounds__(512) void k_gemm_nt_pp(MfmaArgs g) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   const int t = threadIdx.x, lane = t & 63;
@@ -117,9 +123,10 @@ __global__ __launch_bounds__(512) void k_gemm_nt_pp(MfmaArgs g) {
   };
   auto issue_h = [&](int j, int h) {  // piece h of this wave's two pieces of sub-block kind j of the issue K-tile (no-op past the end)
     if (is_tile < 0 || (ABL & 2)) return;
-    const char* base = (j == 0 || j == 3) ? is_a : is_b;
+    const int k = BAL ? (j == 0 ? 1 : j == 1 ? 0 : j) : j;      // stream position j -> sub-block kind (0 a0 rows, 1 b0 cols, 2 b1 cols, 3 a1 rows)
+    const char* base = (k == 0 || k == 3) ? is_a : is_b;
     unsigned char* dst = lds + (is_par * 4 + j) * PP_SUB + w * 1024;
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + voff[j][h]),
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + voff[k][h]),
                                      (__attribute__((address_space(3))) void*)(dst + h * 8192), 16, 0, 0);
   };
   auto issue = [&](int j) { issue_h(j, 0); issue_h(j, 1); };
@@ -142,6 +149,12 @@ __global__ __launch_bounds__(512) void k_gemm_nt_pp(MfmaArgs g) {
   issue(0); issue(1); issue(2);
   pp_wait_vm<10>();                    // (fewer were issued if the stream is shorter: the wait is then stricter, never weaker)
   __builtin_amdgcn_s_barrier();
+  e16x8 fbz[2][2];                     // BAL: the third B set
+  if (BAL) {                           // b0 of the stream's first K-tile ("phase -1")
+    const unsigned b0 = b_lane + swz0, b1 = b_lane + swz1;
+    PP_RD(fb0[0][0], b0, 0); PP_RD(fb0[0][1], b1, 0); PP_RD(fb0[1][0], b0, 2048); PP_RD(fb0[1][1], b1, 2048);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
   if (wr == 1) __builtin_amdgcn_s_barrier();   // group 1 runs one barrier behind group 0
 
   // A read section ends with the counted wait: in steady state vmcnt(10).  `slow` > 0 marks the sections where the count differs: the 5
@@ -209,19 +222,24 @@ __global__ __launch_bounds__(512) void k_gemm_nt_pp(MfmaArgs g) {
             for (int i = 0; i < 4; ++i) acc[a * 2 + b][i][j] = bv;
         }
     }
-    for (int kt = 0; kt < nk; ++kt) {
-      const unsigned s0 = par * 4 * PP_SUB;
+    // one K-tile = four phases.  `bx` holds this K-tile's b0 fragments on entry in the BAL form (read one phase early), `bz` receives the
+    // next K-tile's; without BAL both name fb0 and b0 is read in phase 0.
+    auto ktile = [&](e16x8 (&bx)[2][2], e16x8 (&bz)[2][2], int kt, bool have_next) {
+      const unsigned s0 = par * 4 * PP_SUB, s1 = (par ^ 1) * 4 * PP_SUB;
       par ^= 1;
       const unsigned a0 = a_lane + s0 + swz0, a1 = a_lane + s0 + swz1, b0 = b_lane + s0 + swz0, b1 = b_lane + s0 + swz1;
-      // ---------------- phase 0: a0, b0 -> quadrant (0, 0)
+      constexpr int PA0 = BAL ? 1 : 0, PB0 = BAL ? 0 : 1;      // ring positions of the a0 / b0 sub-blocks inside a K-tile
+      // ---------------- phase 0: a0 (, b0) -> quadrant (0, 0)
       PP_STAMP(kt, 0, 0);
       issue_h(3, 0);
-      PP_RD(fb0[0][0], b0, 1 * PP_SUB); PP_RD(fb0[0][1], b1, 1 * PP_SUB);
-      PP_RD(fb0[1][0], b0, 1 * PP_SUB + 2048); PP_RD(fb0[1][1], b1, 1 * PP_SUB + 2048);
-      PP_RD(fa[0][0], a0, 0); PP_RD(fa[0][1], a1, 0);
-      PP_RD(fa[1][0], a0, 2048); PP_RD(fa[1][1], a1, 2048);
-      PP_RD(fa[2][0], a0, 4096); PP_RD(fa[2][1], a1, 4096);
-      PP_RD(fa[3][0], a0, 6144); PP_RD(fa[3][1], a1, 6144);
+      if (!BAL) {
+        PP_RD(bx[0][0], b0, PB0 * PP_SUB); PP_RD(bx[0][1], b1, PB0 * PP_SUB);
+        PP_RD(bx[1][0], b0, PB0 * PP_SUB + 2048); PP_RD(bx[1][1], b1, PB0 * PP_SUB + 2048);
+      }
+      PP_RD(fa[0][0], a0, PA0 * PP_SUB); PP_RD(fa[0][1], a1, PA0 * PP_SUB);
+      PP_RD(fa[1][0], a0, PA0 * PP_SUB + 2048); PP_RD(fa[1][1], a1, PA0 * PP_SUB + 2048);
+      PP_RD(fa[2][0], a0, PA0 * PP_SUB + 4096); PP_RD(fa[2][1], a1, PA0 * PP_SUB + 4096);
+      PP_RD(fa[3][0], a0, PA0 * PP_SUB + 6144); PP_RD(fa[3][1], a1, PA0 * PP_SUB + 6144);
       if (!SPLIT) { issue_h(3, 1); is_advance(); }
       read_end(kt, 0);
       if (!(ABL & 1)) {
@@ -231,7 +249,7 @@ __global__ __launch_bounds__(512) void k_gemm_nt_pp(MfmaArgs g) {
 #pragma unroll
           for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) acc[0][i][j] = mfma16(fb0[j][ks], fa[i][ks], acc[0][i][j]);
+            for (int j = 0; j < 2; ++j) acc[0][i][j] = mfma16(bx[j][ks], fa[i][ks], acc[0][i][j]);
         __builtin_amdgcn_s_setprio(0);
       }
       if (SPLIT) { issue_h(3, 1); is_advance(); }
@@ -276,9 +294,13 @@ __global__ __launch_bounds__(512) void k_gemm_nt_pp(MfmaArgs g) {
       }
       if (SPLIT) issue_h(1, 1);
       mfma_end(kt, 2);
-      // ---------------- phase 3: quadrant (1, 0) from registers
+      // ---------------- phase 3: quadrant (1, 0) from registers (BAL: + the NEXT K-tile's b0, one phase early)
       PP_STAMP(kt, 3, 0);
       issue_h(2, 0);
+      if (BAL && have_next) {
+        const unsigned n0 = b_lane + s1 + swz0, n1 = b_lane + s1 + swz1;
+        PP_RD(bz[0][0], n0, 0); PP_RD(bz[0][1], n1, 0); PP_RD(bz[1][0], n0, 2048); PP_RD(bz[1][1], n1, 2048);
+      }
       if (!SPLIT) issue_h(2, 1);
       read_end(kt, 3);
       if (!(ABL & 1)) {
@@ -288,12 +310,22 @@ __global__ __launch_bounds__(512) void k_gemm_nt_pp(MfmaArgs g) {
 #pragma unroll
           for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) acc[2][i][j] = mfma16(fb0[j][ks], fa[i][ks], acc[2][i][j]);
+            for (int j = 0; j < 2; ++j) acc[2][i][j] = mfma16(bx[j][ks], fa[i][ks], acc[2][i][j]);
         __builtin_amdgcn_s_setprio(0);
       }
       if (SPLIT) issue_h(2, 1);
       mfma_end(kt, 3);
+    };
+    if constexpr (BAL) {
+      const bool more = tile_of(it + 1) >= 0;                 // the stream goes on behind this tile
+      for (int kt = 0; kt < nk; kt += 2) {
+        ktile(fb0, fbz, kt, true);
+        ktile(fbz, fb0, kt + 1, more || kt + 2 < nk);
+      }
+    } else {
+      for (int kt = 0; kt < nk; ++kt) ktile(fb0, fb0, kt, false);
     }
+
 
     // ---------------- epilogue (wave-private; the other group keeps computing)
     PP_TSTAMP(1);
@@ -339,7 +371,7 @@ __global__ __launch_bounds__(512) void k_gemm_nt_pp(MfmaArgs g) {
   if (wr == 0) __builtin_amdgcn_s_barrier();   // group 0's extra barrier: both groups execute the same number
 }
 
-template <int EPI, int ABL = 0, bool SPLIT = false>
+template <int EPI, int ABL = 0, bool SPLIT = false, bool BAL = false>
 static int launch_nt_pp(MfmaArgs& g, hipStream_t st) {
   g.tiles_m = g.M / 256; g.tiles_n = g.N / 256;
   int shm = PP_LIST_OFF;
@@ -351,7 +383,7 @@ static int launch_nt_pp(MfmaArgs& g, hipStream_t st) {
     const int tpx0 = (ntiles + 7) / 8, nbx0 = grid / 8;
     if ((tpx0 + nbx0 - 1) / nbx0 <= NT_LIVE_MAX) { g.live_off = PP_LIST_OFF; shm += NT_LIVE_BYTES; }
   }
-  auto kern = k_gemm_nt_pp<EPI, ABL, SPLIT>;
+  auto kern = k_gemm_nt_pp<EPI, ABL, SPLIT, BAL>;
   static AfmOncePerDevice attr;
   if (attr.need()) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   AFM_LAUNCH(kern, dim3(grid), dim3(512), shm, st, g);
