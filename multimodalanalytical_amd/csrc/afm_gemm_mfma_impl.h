@@ -1577,7 +1577,7 @@ int AFM_E16_FN(afm_gemm_mfma_try)(const afm_gemm_desc* d, hipStream_t st) {
     if (d->reserved == 0 && (variant == 24 || variant == 28) && d->act == AFM_ACT_NONE && !d->pre_act && d->drop.p <= 0.f &&
         !d->residual && !d->accumulate && d->c_dtype == AFM_E16 && !(d->M & 255) && !(d->N & 255) && !(d->K & 63) && d->K >= 128 &&
         !(d->ldc % 8) && d->N <= PP_BIAS_MAX && (int64_t)(d->M >> 8) * (d->N >> 8) >= 512 && (d->K >= 1024 || d->N >= 1024))
-      variant = 30;
+      variant = (d->K & 127) ? 30 : 32;      // balanced phases where the K-tile count is even (+1 .. 5 % on most shapes, two runs)
     if (d->act >= AFM_ACT_GELU_SAVE_GRAD && variant != 24 && variant != 28) return AFM_ERR_UNSUPPORTED;
     int r;
 #define NT_CASE(WM, WN, NWM, NWN, BKT) \
@@ -1604,6 +1604,12 @@ int AFM_E16_FN(afm_gemm_mfma_try)(const afm_gemm_desc* d, hipStream_t st) {
         if ((d->K & 63) || d->K < 128 || (d->M & 255) || (d->N & 255) || d->N > PP_BIAS_MAX || d->c_dtype != AFM_E16 || d->residual ||
             d->accumulate || d->act != AFM_ACT_NONE || d->pre_act || d->drop.p > 0.f || (d->ldc % 8)) { r = AFM_ERR_UNSUPPORTED; break; }
         r = launch_nt_pp<EPI_PLAIN>(g, st);
+        break;
+      case 33:   // (A/B partner of 30: one barrier per phase)
+      case 34:   // (one barrier per phase + balanced phases; K % 128 == 0)
+        if ((d->K & (variant == 34 ? 127 : 63)) || d->K < 128 || (d->M & 255) || (d->N & 255) || d->N > PP_BIAS_MAX || d->c_dtype != AFM_E16 ||
+            d->residual || d->accumulate || d->act != AFM_ACT_NONE || d->pre_act || d->drop.p > 0.f || (d->ldc % 8)) { r = AFM_ERR_UNSUPPORTED; break; }
+        r = variant == 34 ? launch_nt_pp<EPI_PLAIN, 0, false, true, true>(g, st) : launch_nt_pp<EPI_PLAIN, 0, false, false, true>(g, st);
         break;
       case 32:   // (A/B partner of 30: balanced phases, b0 of the next K-tile read one phase early; K % 128 == 0)
         if ((d->K & 127) || d->K < 128 || (d->M & 255) || (d->N & 255) || d->N > PP_BIAS_MAX || d->c_dtype != AFM_E16 || d->residual ||
@@ -1679,7 +1685,7 @@ int AFM_E16_FN(afm_gemm_mfma_try)(const afm_gemm_desc* d, hipStream_t st) {
 #undef PRING_CASE
 #undef NT_CASE
     if (r != AFM_OK) return r;
-    afm_set_last_algo(variant == 28 ? "mfma_nt_256" : (variant >= 30 && variant <= 32) ? "mfma_nt_pp" : "mfma_nt");     // (_256: the 256 x 256-tile form)
+    afm_set_last_algo(variant == 28 ? "mfma_nt_256" : (variant >= 30 && variant <= 34) ? "mfma_nt_pp" : "mfma_nt");     // (_256: the 256 x 256-tile form)
     return AFM_OK;
   }
   if (d->transA && !d->transB) {  // TN: the wgrad form only

@@ -62,8 +62,17 @@ template <int N> __device__ __forceinline__ void pp_wait_vm() { asm volatile("s_
 // 1, 2} the two hazard conditions of the header (j >= s_j, s_j >= j - 1) hold unchanged.  Needs an even number of K-tiles per tile (the
 // two B sets swap roles every K-tile; the loop is unrolled by two).  Bit-identical results, 246 registers.  Measured against the
 // unbalanced form in one run (two rounds): QKV 206 vs 212 us, N 2048 / K 512 270 vs 276, N 512 / K 1536 196 vs 200, N 512 / K 2048 251 vs
-// 251, N 1024 / K 512 143 vs 138, N 512 / K 512 76 vs 75: +-3 %, the sign depends on the shape.  Kept as dispatch variant 32, not the default.
-template <int EPI, int ABL = 0, bool SPLIT = false, bool BAL = false>
+// 251, N 1024 / K 512 143 vs 138, N 512 / K 512 76 vs 75; a second run on another box: 198 vs 208, 257 vs 262, 188 vs 190, 240 vs 248,
+// 137 vs 133, 70 vs 74: +1 .. 5 % on most shapes, -3 % on one.  Dispatch variant 32; picked automatically when K % 128 == 0.
+// ONEBAR: ONE barrier per phase instead of two.  Group 0 runs [read section][MFMA section][barrier], group 1 [read section][barrier]
+// [MFMA section]: between two barriers group 0 reads and then multiplies phase k while group 1 multiplies phase k - 1 and then reads
+// phase k -- the same anti-phase, without the hand-over barrier in the middle of the window (each barrier costs the SIMD ~90 cycles
+// with the matrix pipe idle: in-kernel stamps, interval 390 cycles for a 256-cycle MFMA section even with nothing else in the way).
+// Hazards: a sub-block read in window k (by both groups, group 1 at the window's end, complete before the barrier: lgkmcnt(0)) is
+// overwritten by pieces issued in window >= k + 1 (WAR as before); every wave's counted vmcnt wait sits before its barrier of the
+// window, so pieces of phases <= k - 5 are visible from window k + 1 on (RAW as before, W = 5).  Bit-identical results; measured
+// within +-2 % of the two-barrier form on every shape (variants 33 / 34): the barriers are not what sets the interval either.
+template <int EPI, int ABL = 0, bool SPLIT = false, bool BAL = false, bool ONEBAR = false>
 __global__ __launch_bounds__(512) void k_gemm_nt_pp(MfmaArgs g) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   const int t = threadIdx.x, lane = t & 63;
@@ -155,7 +164,7 @@ __global__ __launch_bounds__(512) void k_gemm_nt_pp(MfmaArgs g) {
     PP_RD(fb0[0][0], b0, 0); PP_RD(fb0[0][1], b1, 0); PP_RD(fb0[1][0], b0, 2048); PP_RD(fb0[1][1], b1, 2048);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   }
-  if (wr == 1) __builtin_amdgcn_s_barrier();   // group 1 runs one barrier behind group 0
+  if (!ONEBAR && wr == 1) __builtin_amdgcn_s_barrier();   // group 1 runs one barrier behind group 0
 
   // A read section ends with the counted wait: in steady state vmcnt(10).  `slow` > 0 marks the sections where the count differs: the 5
   // after an epilogue (its 16 stores sit in the same in-order queue behind the older pieces) and everything after the stream's end.
@@ -165,8 +174,7 @@ __global__ __launch_bounds__(512) void k_gemm_nt_pp(MfmaArgs g) {
 #ifdef AFM_GEMM_ABLATIONS
   bool stamp_on = false, tstamp_on = false;
 #endif
-  auto read_end = [&](int skt, int sph) {   // DMA pieces of 5 phases ago have landed, own LDS reads are complete
-    PP_STAMP(skt, sph, 1);
+  auto counted_wait = [&]() {         // DMA pieces of 5 phases ago have landed (all of this wave's; the barrier publishes them)
     // pieces that may still be in flight: those of the last 5 phases (SPLIT: the MFMA-section piece of this phase is not issued yet:
     // 9), fewer once the stream has ended, plus a recent epilogue's 16 stores
     constexpr int BASE = SPLIT ? 9 : 10;
@@ -181,16 +189,21 @@ __global__ __launch_bounds__(512) void k_gemm_nt_pp(MfmaArgs g) {
       else if (young >= 2) pp_wait_vm<2>(); else pp_wait_vm<0>();
     }
     ++since_epi;
+  };
+  auto read_end = [&](int skt, int sph) {   // end of a read section: own LDS reads complete; (two-barrier form / group 1: wait + barrier)
+    PP_STAMP(skt, sph, 1);
+    if (!ONEBAR || wr == 1) counted_wait();
     PP_STAMP(skt, sph, 2);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     PP_STAMP(skt, sph, 3);
-    __builtin_amdgcn_s_barrier();
+    if (!ONEBAR || wr == 1) __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
     PP_STAMP(skt, sph, 4);
   };
   auto mfma_end = [&](int skt, int sph) {
     PP_STAMP(skt, sph, 5);
-    __builtin_amdgcn_s_barrier();
+    if (ONEBAR && wr == 0) counted_wait();
+    if (!ONEBAR || wr == 0) __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
     PP_STAMP(skt, sph, 6);
   };
@@ -368,10 +381,10 @@ __global__ __launch_bounds__(512) void k_gemm_nt_pp(MfmaArgs g) {
     }
     PP_TSTAMP(2);
   }
-  if (wr == 0) __builtin_amdgcn_s_barrier();   // group 0's extra barrier: both groups execute the same number
+  if (!ONEBAR && wr == 0) __builtin_amdgcn_s_barrier();   // group 0's extra barrier: both groups execute the same number
 }
 
-template <int EPI, int ABL = 0, bool SPLIT = false, bool BAL = false>
+template <int EPI, int ABL = 0, bool SPLIT = false, bool BAL = false, bool ONEBAR = false>
 static int launch_nt_pp(MfmaArgs& g, hipStream_t st) {
   g.tiles_m = g.M / 256; g.tiles_n = g.N / 256;
   int shm = PP_LIST_OFF;
@@ -383,7 +396,7 @@ static int launch_nt_pp(MfmaArgs& g, hipStream_t st) {
     const int tpx0 = (ntiles + 7) / 8, nbx0 = grid / 8;
     if ((tpx0 + nbx0 - 1) / nbx0 <= NT_LIVE_MAX) { g.live_off = PP_LIST_OFF; shm += NT_LIVE_BYTES; }
   }
-  auto kern = k_gemm_nt_pp<EPI, ABL, SPLIT, BAL>;
+  auto kern = k_gemm_nt_pp<EPI, ABL, SPLIT, BAL, ONEBAR>;
   static AfmOncePerDevice attr;
   if (attr.need()) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   AFM_LAUNCH(kern, dim3(grid), dim3(512), shm, st, g);

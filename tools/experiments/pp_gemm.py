@@ -41,9 +41,11 @@ def main():
     for (m, n, k) in [(256, 256, 128), (512, 768, 256), (2048, 768, 512), (16384, 512, 2048), (256 * 37, 256 * 3, 384), (131072, 1536, 512)]:
         a = torch.randn(m, k, device="cuda").half(); w = (torch.randn(n, k, device="cuda") * 0.05).half(); b = torch.randn(n, device="cuda")
         c0 = torch.empty(m, n, dtype=torch.float16, device="cuda"); c1 = torch.full_like(c0, float("nan"))
-        ops.gemm(a, w, c0, bias=b, variant=30); ops.gemm(a, w, c1, bias=b, variant=32)
-        same = bool(torch.equal(c0, c1)); ok &= same
-        print(f"balanced (variant 32) == variant 30 at {m}x{n}x{k}: {same}", flush=True)
+        ops.gemm(a, w, c0, bias=b, variant=30)
+        for v in (32, 33, 34):
+            c1.fill_(float("nan")); ops.gemm(a, w, c1, bias=b, variant=v)
+            same = bool(torch.equal(c0, c1)); ok &= same
+            print(f"variant {v} == variant 30 at {m}x{n}x{k}: {same}", flush=True)
     for rep in range(3):   # races show up as run-to-run differences
         ok &= check(131072, 1536, 512, seed=rep)
     print("ALL OK" if ok else "FAILURES", flush=True)
@@ -51,7 +53,7 @@ def main():
     M = B * S
     shapes = [("qkv fwd", M, 3 * d, d), ("out fwd", M, d, d), ("ffn1 plain", M, f, d), ("ffn2 fwd", M, d, f), ("qkv dgrad", M, d, 3 * d),
               ("mem kv", M, 2 * d, d), ("dec qkv", 16384, 3 * d, d), ("dec ffn2", 16384, d, f)]
-    variants = {30: "pp", 32: "pp balanced", 31: "pp split-dma", 24: "ws 256x128", 28: "256x256"}
+    variants = {30: "pp", 33: "pp one-barrier", 34: "pp 1bar+bal", 32: "pp balanced", 24: "ws 256x128", 28: "256x256"}
     if "--abl" in sys.argv:
         variants.update({304: "pp no-epilogue", 302: "pp no-dma", 306: "pp lds+mfma", 301: "pp no-mfma", 250: "ws no-epilogue", 246: "ws lds+mfma"})
     for rnd in range(2):
