@@ -1,6 +1,7 @@
 // LDS tile images, transposed-read helpers, the LDS-DMA piece and the dropout block of the MFMA flash-attention
 // kernels (afm_attn_mfma.hip: single e16 pass; afm_attn_x3.hip: split-pair operands, three passes per product).
 #pragma once
+#include <type_traits>
 #include "afm_common.h"
 
 #define DH 64

@@ -368,6 +368,46 @@ def test_attention_backward_skips_padded_query_rows_exactly(ops, dt, causal):
     assert float(res[1][0].view(B, T, D)[0, 100:].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("dt", [H16, torch.bfloat16])
+@pytest.mark.parametrize("B,H,Tq,Tk,pad,pdrop", [(2, 2, 64, 128, False, 0.1), (2, 4, 256, 256, True, 0.1), (3, 2, 192, 320, True, 0.1),
+                                                 (2, 4, 512, 512, True, 0.0), (4, 2, 128, 1024, True, 0.1), (1, 8, 1024, 1024, False, 0.1)])
+def test_attention_dkv_pipelined_kernel_is_bit_identical(ops, dt, B, H, Tq, Tk, pad, pdrop):
+    """csrc/afm_attn_pipe_impl.h (software-pipelined dK/dV kernel: no causal mask, Tq % 64 == 0, keep-bit dropout or none) gives every
+    accumulator its products in the round-3 kernel's order: dK and dV equal that kernel's (afm_attn_shape.reserved & 128) bit for bit,
+    in the four-wave form and the eight-wave one (reserved & 256), with and without the padded-query skip."""
+    dh = 64
+    D = H * dh
+    q, k, v, _ = _attn_case(B, H, Tq, Tk, dh, False, False, seed=41)
+    key_pad = torch.zeros(B, Tk, dtype=torch.bool)
+    if pad:
+        key_pad[0, Tk // 3:] = True
+        key_pad[B - 1, Tk - 70:] = True
+    qd, kd, vd = dev(q.reshape(-1, D), dt), dev(k.reshape(-1, D), dt), dev(v.reshape(-1, D), dt)
+    kp = dev(key_pad.to(torch.uint8)) if pad else None
+    dr = ops.drop(pdrop, 5, 2) if pdrop > 0 else ops.NO_DROP
+    do = rnd(B * Tq, D, seed=10)
+    qskip = pad and Tq == Tk
+    if qskip:
+        do[key_pad.reshape(-1)] = 0.0
+    dod = dev(do, dt)
+    o = torch.empty(B * Tq, D, dtype=dt, device=DEV); lse = torch.empty(B * H * Tq, device=DEV)
+    shp = ops.attn_shape(B, H, Tq, Tk, dh, dt, D, D, D, D, kp, False, dr, algo=2)
+    if pdrop > 0:
+        ops.attn_set_drop_bits(shp, torch.zeros(ops.attn_drop_bits_words(B, H, Tq, Tk), dtype=torch.int64, device=DEV))
+    ops.attn_fwd(shp, qd, kd, vd, o, lse)
+    res = {}
+    for name, flag in (("round3", 128), ("pipe4", 0), ("pipe8", 256)):
+        shp.reserved = flag | (64 if qskip else 0)
+        dq = torch.empty(B * Tq, D, dtype=dt, device=DEV)
+        dk, dv = (torch.full((B * Tk, D), float("nan"), dtype=dt, device=DEV) for _ in range(2))
+        ops.attn_bwd(shp, qd, kd, vd, o, dod, lse, torch.empty_like(lse), dq, dk, dv, D, D, D)
+        assert ops.last_algo() == "attn_mfma"
+        res[name] = (dk, dv)
+    assert bool(torch.isfinite(res["pipe4"][0].float()).all()) and bool(torch.isfinite(res["pipe4"][1].float()).all())
+    for name in ("pipe4", "pipe8"):
+        assert torch.equal(res["round3"][0], res[name][0]) and torch.equal(res["round3"][1], res[name][1]), name
+
+
 # ------------------------------------------------------------------ LayerNorm, elementwise, loss
 @pytest.mark.parametrize("d", [64, 512, 768])
 def test_layernorm_f16(ops, d):
