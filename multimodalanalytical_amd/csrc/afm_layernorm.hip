@@ -145,16 +145,32 @@ __global__ __launch_bounds__(256) void k_ln_fwd_vec(const float* x, const float*
     const int c = (lane + 64 * i) * 8;
     if (c < d) { gm[i] = ld8(gamma + c); bt[i] = ld8(beta + c); }
   }
+  // Two rows in flight per wave: row r + nwaves is requested before row r is reduced and stored (one row at a time left the kernel at
+  // 4.5 TB/s of the ~6.3 a streaming kernel reaches: every wave spent a full memory latency per row with nothing outstanding).
+  F8 cx[NC], ca[NC];
+  auto load_row = [&](int64_t r, F8 (&vx)[NC], F8 (&va)[NC]) {
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+      const int c = (lane + 64 * i) * 8;
+      if (c < d) {
+        vx[i] = ld8(x + r * (int64_t)d + c);
+        if (add) va[i] = ld8(add + r * (int64_t)(d * RowMul<TA>::v) + c, d);
+      }
+    }
+  };
+  if (wave < rows) load_row(wave, cx, ca);
   for (int64_t r = wave; r < rows; r += nwaves) {
+    F8 nx[NC], na[NC];
+    load_row(r + nwaves < rows ? r + nwaves : r, nx, na);      // (the last row of a wave is requested twice: no branch around the loads)
     F8 v[NC];
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < NC; ++i) {
       const int c = (lane + 64 * i) * 8;
       if (c < d) {
-        v[i] = ld8(x + r * (int64_t)d + c);
+        v[i] = cx[i];
         if (add) {
-          F8 a = ld8(add + r * (int64_t)(d * RowMul<TA>::v) + c, d);
+          F8 a = ca[i];
           if (adrop.thresh) {   // wave-uniform: dropout of the residual branch, index row-major in `add`
             const uint64_t base = (uint64_t)r * (uint64_t)d + (uint64_t)c;
 #pragma unroll
@@ -166,6 +182,8 @@ __global__ __launch_bounds__(256) void k_ln_fwd_vec(const float* x, const float*
         s += hsum8(v[i]);
       }
     }
+#pragma unroll
+    for (int i = 0; i < NC; ++i) { cx[i] = nx[i]; ca[i] = na[i]; }
     const float mu = wave_sum(s) * inv_d;
     float q = 0.f;
 #pragma unroll
@@ -219,7 +237,27 @@ __global__ __launch_bounds__(256) void k_ln_bwd_vec(const TY* __restrict__ dy, c
     ag[i] = {z, z}; ab[i] = {z, z}; gm[i] = {z, z};
     if (c < d) gm[i] = ld8(gamma + c);
   }
+  // Two rows in flight per wave, as in the forward kernel: dy, x, dres, mean and rstd of row r + nwaves are requested before row r is
+  // reduced (the residual-gradient load used to sit behind the two wave reductions).  Rows in all-padding blocks are neither loaded nor
+  // computed, as before.
+  struct RowIn { F8 dy[NC], x[NC], dr[NC]; float mu, rs; };
+  auto load_row = [&](int64_t r, RowIn& in) {
+    if (row_live && !row_live[r >> 6]) return;
+    in.mu = mean[r]; in.rs = rstd[r];
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+      const int c = (lane + 64 * i) * 8;
+      if (c < d) {
+        in.dy[i] = ld8(dy + ln_out_row(r, seg_len, seg_stride, off) * (int64_t)(d * RowMul<TY>::v) + c, d);
+        in.x[i] = ld8(x + r * (int64_t)d + c);
+        if (dres) in.dr[i] = ld8(dres + r * (int64_t)d + c);
+      }
+    }
+  };
+  RowIn cur, nxt;
+  if (wave < rows) load_row(wave, cur);
   for (int64_t r = wave; r < rows; r += nwaves) {
+    load_row(r + nwaves < rows ? r + nwaves : r, nxt);
     if (row_live && !row_live[r >> 6]) {     // a block of padded positions: dy = dres = 0 there, so dx = 0 and nothing is added to dgamma / dbeta
       const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
       const F8 z = {z4, z4};
@@ -231,17 +269,19 @@ __global__ __launch_bounds__(256) void k_ln_bwd_vec(const TY* __restrict__ dy, c
           if (dx_drop) st8(dx_drop + r * (int64_t)(d * RowMul<TY>::v) + c, z, d);
         }
       }
+      cur = nxt;
       continue;
     }
-    const float mu = mean[r], rs = rstd[r];
-    F8 xh[NC], g[NC];
+    const float mu = cur.mu, rs = cur.rs;
+    F8 xh[NC], g[NC], drv[NC];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int i = 0; i < NC; ++i) {
       const int c = (lane + 64 * i) * 8;
       if (c < d) {
-        const F8 dyv = ld8(dy + ln_out_row(r, seg_len, seg_stride, off) * (int64_t)(d * RowMul<TY>::v) + c, d);
-        const F8 xv = ld8(x + r * (int64_t)d + c);
+        const F8 dyv = cur.dy[i];
+        const F8 xv = cur.x[i];
+        drv[i] = cur.dr[i];
         xh[i] = {(xv.lo - mu) * rs, (xv.hi - mu) * rs};
         g[i] = {dyv.lo * gm[i].lo, dyv.hi * gm[i].hi};
         ag[i].lo += dyv.lo * xh[i].lo; ag[i].hi += dyv.hi * xh[i].hi;
@@ -251,13 +291,14 @@ __global__ __launch_bounds__(256) void k_ln_bwd_vec(const TY* __restrict__ dy, c
         s2 += hsum8(gx);
       }
     }
+    cur = nxt;
     const float m1 = wave_sum(s1) * inv_d, m2 = wave_sum(s2) * inv_d;
 #pragma unroll
     for (int i = 0; i < NC; ++i) {
       const int c = (lane + 64 * i) * 8;
       if (c < d) {
         F8 o = {rs * (g[i].lo - m1 - xh[i].lo * m2), rs * (g[i].hi - m1 - xh[i].hi * m2)};
-        if (dres) { const F8 dr = ld8(dres + r * (int64_t)d + c); o.lo += dr.lo; o.hi += dr.hi; }
+        if (dres) { o.lo += drv[i].lo; o.hi += drv[i].hi; }
         st8(dx + r * (int64_t)d + c, o);
         if (dx_drop) {
           const uint64_t base = (uint64_t)r * (uint64_t)d + (uint64_t)c;
@@ -294,7 +335,8 @@ extern "C" int afm_layernorm_fwd(const afm_ln_shape* s, const float* x, const fl
   if (s->d > 64 * LN_MAXV) return AFM_ERR_UNSUPPORTED;
   if (s->rows == 0) return AFM_OK;
   int64_t g = (s->rows + 3) / 4;
-  if (g > 2048) g = 2048;
+  static const int fwd_cap = getenv("AFM_LN_FWD_BLOCKS") ? atoi(getenv("AFM_LN_FWD_BLOCKS")) : 1280;   // five workgroups per CU: what the vectorised kernel's registers allow (two rows in flight per wave)
+  if (g > fwd_cap) g = fwd_cap;
   hipStream_t st = (hipStream_t)stream;
   if (s->y_dtype < AFM_F32 || s->y_dtype > AFM_F16) return AFM_ERR_ARG;
   if ((s->d % 8) == 0 && s->d <= 2048 && s->rows >= 64 && (!pos || ((uintptr_t)pos & 15) == 0)) {   // vectorised path
@@ -327,7 +369,8 @@ extern "C" int afm_layernorm_fwd(const afm_ln_shape* s, const float* x, const fl
 
 static inline int ln_bwd_blocks(int64_t rows) {
   int64_t g = (rows + 3) / 4;
-  if (g > 1024) g = 1024;  // 4 blocks per CU keep HBM busy; the partial rows are reduced by k_ln_bwd_reduce
+  static const int bwd_cap = getenv("AFM_LN_BWD_BLOCKS") ? atoi(getenv("AFM_LN_BWD_BLOCKS")) : 768;   // three workgroups per CU (the vectorised kernel: 138 registers, two rows in flight per wave)
+  if (g > bwd_cap) g = bwd_cap;
   if (g < 1) g = 1;
   return (int)g;
 }
