@@ -1139,37 +1139,45 @@ int AFM_E16_FN(afm_attn_bwd_mfma_try)(const afm_attn_shape* s, const void* Q, co
     (void)hipFuncSetAttribute((const void*)k_attn_bwd_dkv_mfma<DROP_NONE>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
   }
   // the software-pipelined kernel (afm_attn_pipe_impl.h) where its conditions hold; reserved & 128 keeps the round-3 kernel (A / B tests),
-  // reserved & 256 its eight-wave form (measured slower: 0.72 vs 0.70 ms at the c2 shape)
+  // reserved & 256 the eight-wave form (0.72 vs 0.70 ms at the c2 shape), reserved & 512 the form with 64 keys per wave and one wave per SIMD
+  // (every LDS fragment feeds two MFMAs, but a lone wave hides nothing and its accumulators travel through v_accvgpr: 0.76 ms; 0.53 vs 0.37
+  // over a padded batch) -- both bit-identical, both left as measured
   const bool piped = !s->causal && (s->Tq % KT) == 0 && (!a.dd.thresh16 || a.bits) && !(s->reserved & 128);
   const int pnw = (s->reserved & 256) ? 8 : 4;
-  const int shm_kp = 3 * 2 * KT * DH * 2 + 2 * (2048 + pnw * 1024) + (s->Tq / KT) * 12 + 8;
-  const dim3 gkp(((s->Tk + 32 * pnw - 1) / (32 * pnw)) * s->H * s->B);
+  const int pkb = (pnw == 4 && (s->reserved & 512) && s->Tk >= 256) ? 2 : 1;
+  const int shm_kp = 3 * 2 * KT * DH * 2 + 2 * (2048 + pnw * pkb * 1024) + (s->Tq / KT) * 12 + 8;
+  const dim3 gkp(((s->Tk + 32 * pnw * pkb - 1) / (32 * pnw * pkb)) * s->H * s->B);
   if (run_k && piped) {
     static AfmOncePerDevice attr_kp;
     if (attr_kp.need()) {
-      (void)hipFuncSetAttribute((const void*)k_attn_bwd_dkv_pipe<DROP_BITS, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-      (void)hipFuncSetAttribute((const void*)k_attn_bwd_dkv_pipe<DROP_NONE, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-      (void)hipFuncSetAttribute((const void*)k_attn_bwd_dkv_pipe<DROP_BITS, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-      (void)hipFuncSetAttribute((const void*)k_attn_bwd_dkv_pipe<DROP_NONE, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+      (void)hipFuncSetAttribute((const void*)k_attn_bwd_dkv_pipe<DROP_BITS, 8, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+      (void)hipFuncSetAttribute((const void*)k_attn_bwd_dkv_pipe<DROP_NONE, 8, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+      (void)hipFuncSetAttribute((const void*)k_attn_bwd_dkv_pipe<DROP_BITS, 4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+      (void)hipFuncSetAttribute((const void*)k_attn_bwd_dkv_pipe<DROP_NONE, 4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+      (void)hipFuncSetAttribute((const void*)k_attn_bwd_dkv_pipe<DROP_BITS, 4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+      (void)hipFuncSetAttribute((const void*)k_attn_bwd_dkv_pipe<DROP_NONE, 4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
     }
   }
 #define AFM_PIPE_LAUNCH(KERN, BLK) AFM_LAUNCH(KERN, gkp, dim3(BLK), shm_kp, st, a, (const e16*)Q, (const e16*)K, (const e16*)V, (const e16*)dO, lse, delta, (e16*)dK, (e16*)dV)
 #ifdef AFM_ATTN_ABLATIONS
-#define AFM_PIPE_ABL_CASE(N) case N: (void)hipFuncSetAttribute((const void*)k_attn_bwd_dkv_pipe<DROP_BITS, 4, N>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); \
-    AFM_PIPE_LAUNCH((k_attn_bwd_dkv_pipe<DROP_BITS, 4, N>), 256); return AFM_OK;
-  if (run_k && piped && pnw == 4 && a.dd.thresh16 && ((s->reserved >> 12) & 255)) {
+#define AFM_PIPE_ABL_CASE(N) case N: (void)hipFuncSetAttribute((const void*)k_attn_bwd_dkv_pipe<DROP_BITS, 4, 1, N>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); \
+    AFM_PIPE_LAUNCH((k_attn_bwd_dkv_pipe<DROP_BITS, 4, 1, N>), 256); return AFM_OK;
+  if (run_k && piped && pnw == 4 && pkb == 1 && a.dd.thresh16 && ((s->reserved >> 12) & 255)) {
     switch ((s->reserved >> 12) & 255) {
       AFM_PIPE_ABL_CASE(1) AFM_PIPE_ABL_CASE(2) AFM_PIPE_ABL_CASE(4) AFM_PIPE_ABL_CASE(6) AFM_PIPE_ABL_CASE(3) AFM_PIPE_ABL_CASE(7) AFM_PIPE_ABL_CASE(8)
-      AFM_PIPE_ABL_CASE(16) AFM_PIPE_ABL_CASE(32) AFM_PIPE_ABL_CASE(23) AFM_PIPE_ABL_CASE(31) AFM_PIPE_ABL_CASE(63) AFM_PIPE_ABL_CASE(22) AFM_PIPE_ABL_CASE(54) AFM_PIPE_ABL_CASE(64) AFM_PIPE_ABL_CASE(80) AFM_PIPE_ABL_CASE(112) AFM_PIPE_ABL_CASE(120)
+      AFM_PIPE_ABL_CASE(16) AFM_PIPE_ABL_CASE(32) AFM_PIPE_ABL_CASE(23) AFM_PIPE_ABL_CASE(31) AFM_PIPE_ABL_CASE(63) AFM_PIPE_ABL_CASE(22) AFM_PIPE_ABL_CASE(54)
+      AFM_PIPE_ABL_CASE(64) AFM_PIPE_ABL_CASE(80) AFM_PIPE_ABL_CASE(112) AFM_PIPE_ABL_CASE(120)
       default: return AFM_ERR_UNSUPPORTED;
     }
   }
 #endif
   if (!run_k) {}
-  else if (piped && shm_kp <= 80 * 1024 && a.dd.thresh16 && pnw == 8) AFM_PIPE_LAUNCH((k_attn_bwd_dkv_pipe<DROP_BITS, 8>), 512);
-  else if (piped && shm_kp <= 80 * 1024 && a.dd.thresh16) AFM_PIPE_LAUNCH((k_attn_bwd_dkv_pipe<DROP_BITS, 4>), 256);
-  else if (piped && shm_kp <= 80 * 1024 && pnw == 8) AFM_PIPE_LAUNCH((k_attn_bwd_dkv_pipe<DROP_NONE, 8>), 512);
-  else if (piped && shm_kp <= 80 * 1024) AFM_PIPE_LAUNCH((k_attn_bwd_dkv_pipe<DROP_NONE, 4>), 256);
+  else if (piped && shm_kp <= 80 * 1024 && a.dd.thresh16 && pnw == 8) AFM_PIPE_LAUNCH((k_attn_bwd_dkv_pipe<DROP_BITS, 8, 1>), 512);
+  else if (piped && shm_kp <= 80 * 1024 && a.dd.thresh16 && pkb == 2) AFM_PIPE_LAUNCH((k_attn_bwd_dkv_pipe<DROP_BITS, 4, 2>), 256);
+  else if (piped && shm_kp <= 80 * 1024 && a.dd.thresh16) AFM_PIPE_LAUNCH((k_attn_bwd_dkv_pipe<DROP_BITS, 4, 1>), 256);
+  else if (piped && shm_kp <= 80 * 1024 && pnw == 8) AFM_PIPE_LAUNCH((k_attn_bwd_dkv_pipe<DROP_NONE, 8, 1>), 512);
+  else if (piped && shm_kp <= 80 * 1024 && pkb == 2) AFM_PIPE_LAUNCH((k_attn_bwd_dkv_pipe<DROP_NONE, 4, 2>), 256);
+  else if (piped && shm_kp <= 80 * 1024) AFM_PIPE_LAUNCH((k_attn_bwd_dkv_pipe<DROP_NONE, 4, 1>), 256);
   else if (a.dd.thresh16 && a.bits) AFM_LAUNCH(k_attn_bwd_dkv_mfma<DROP_BITS>, gk, dim3(256), shm_k, st, a, (const e16*)Q, (const e16*)K, (const e16*)V, (const e16*)dO, lse, delta, (e16*)dK, (e16*)dV);
   else if (a.dd.thresh16) AFM_LAUNCH(k_attn_bwd_dkv_mfma<DROP_HASH>, gk, dim3(256), shm_k, st, a, (const e16*)Q, (const e16*)K, (const e16*)V, (const e16*)dO, lse, delta, (e16*)dK, (e16*)dV);
   else AFM_LAUNCH(k_attn_bwd_dkv_mfma<DROP_NONE>, gk, dim3(256), shm_k, st, a, (const e16*)Q, (const e16*)K, (const e16*)V, (const e16*)dO, lse, delta, (e16*)dK, (e16*)dV);

@@ -56,8 +56,8 @@ typedef uint32_t u32x4_ __attribute__((ext_vector_type(4)));
 // AFM_PIPE_ABL (template parameter ABL; an AFM_ATTN_ABLATIONS build instantiates the list in afm_attn_mfma_impl.h and
 // afm_attn_shape.reserved bits 8-15 pick one): timing ablations with wrong results -- 1 no MFMAs, 2 no arithmetic, 4 no slot reads,
 // 8 no barrier, 16 no preamble reads, 32 no LDS-DMA after the prologue, 64 no waits for the slot reads.
-template <int DROP, int NW, int AFM_PIPE_ABL = 0>
-__global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void k_attn_bwd_dkv_pipe(AttnM a, const e16* __restrict__ Q, const e16* __restrict__ K,
+template <int DROP, int NW, int KB = 1, int AFM_PIPE_ABL = 0>
+__global__ __launch_bounds__(64 * NW, (NW == 4 && KB == 1) ? 2 : 1) void k_attn_bwd_dkv_pipe(AttnM a, const e16* __restrict__ Q, const e16* __restrict__ K,
                                                                              const e16* __restrict__ V, const e16* __restrict__ dO,
                                                                              const float* __restrict__ lse, const float* __restrict__ delta,
                                                                              e16* __restrict__ dK, e16* __restrict__ dV) {
@@ -65,53 +65,73 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void k_attn_bwd_dkv_pipe(
   constexpr int STAGE = 2 * IMG, NS = 3;             // main ring: Q image, dO image (stage bases are multiples of 128: the transposed-read addresses XOR below bit 7)
   // aux ring: two slots, each the small per-tile data of FOUR tiles (one 1-KiB LDS-DMA instruction per array instead of four 256-byte
   // ones: what a wave pays for an LDS-DMA instruction does not depend on its size) -- lse[4][64], -delta[4][64], keep bits [NW][4][64 dwords]
-  constexpr int AUX0 = NS * STAGE, AUXSLOT = 2048 + NW * 1024;
+  constexpr int AUX0 = NS * STAGE, AUXSLOT = 2048 + NW * KB * 1024;
   constexpr int LS_OFF = 0, DS_OFF = 1024, KB_OFF = 2048;      // relative to a tile's 256-byte column of its aux slot
-  constexpr int KPB = 32 * NW;                       // keys per workgroup
+  constexpr int KPB = 32 * KB * NW;                  // keys per workgroup (KB 32-key blocks per wave)
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   const int t = threadIdx.x, lane = t & 63, h = lane >> 5;
   const int w = __builtin_amdgcn_readfirstlane(t >> 6);
   const AttnBlock blk_ = attn_block(a.H, a.B, (a.Tk + KPB - 1) / KPB);
   const int hd = blk_.hd, b = blk_.b;
-  const int k0 = blk_.xb * KPB + w * 32;
-  const int key = k0 + (lane & 31);
-  const int kc = key < a.Tk ? key : a.Tk - 1;
-  const bool kmasked = key >= a.Tk || (a.key_pad && a.key_pad[(int64_t)b * a.Tk + kc]);
+  const int k0 = blk_.xb * KPB + w * 32 * KB;             // the wave's first key; key block kb covers k0 + 32 kb ..
   const e16* Qb = Q + (int64_t)b * a.Tq * a.ldq + hd * DH;
   const e16* Db = dO + (int64_t)b * a.Tq * a.ldo + hd * DH;
-  e16x8 kf[4], vf[4];
-  {
+  e16x8 kf[KB][4], vf[KB][4];
+  bool kmasked[KB];
+  bool wave_all_masked = true;
+#pragma unroll
+  for (int kb = 0; kb < KB; ++kb) {
+    const int key = k0 + 32 * kb + (lane & 31);
+    const int kc = key < a.Tk ? key : a.Tk - 1;
+    kmasked[kb] = key >= a.Tk || (a.key_pad && a.key_pad[(int64_t)b * a.Tk + kc]);
+    wave_all_masked = wave_all_masked && __all(kmasked[kb]);
     const e16* kp = K + ((int64_t)b * a.Tk + kc) * a.ldk + hd * DH + 8 * h;
     const e16* vp = V + ((int64_t)b * a.Tk + kc) * a.ldv + hd * DH + 8 * h;
 #pragma unroll
-    for (int s = 0; s < 4; ++s) { kf[s] = *(const e16x8*)(kp + 16 * s); vf[s] = *(const e16x8*)(vp + 16 * s); }
+    for (int s = 0; s < 4; ++s) { kf[kb][s] = *(const e16x8*)(kp + 16 * s); vf[kb][s] = *(const e16x8*)(vp + 16 * s); }
 #pragma unroll
     for (int s = 0; s < 4; ++s)
 #pragma unroll
       for (int j = 0; j < 8; ++j) {      // as in the round-3 kernel: K by scale * log2(e), V by the dropout scale
-        kf[s][j] = (e16)((float)kf[s][j] * a.scale_log2);
-        if (DROP != DROP_NONE) vf[s][j] = (e16)((float)vf[s][j] * a.dd.scale16);
+        kf[kb][s][j] = (e16)((float)kf[kb][s][j] * a.scale_log2);
+        if (DROP != DROP_NONE) vf[kb][s][j] = (e16)((float)vf[kb][s][j] * a.dd.scale16);
       }
   }
-  f32x16 dk[2], dv[2];
+  f32x16 dk[KB][2], dv[KB][2];
 #pragma unroll
-  for (int i = 0; i < 16; ++i) { dk[0][i] = 0.f; dk[1][i] = 0.f; dv[0][i] = 0.f; dv[1][i] = 0.f; }
-  const bool wave_all_masked = __all(kmasked);
+  for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { dk[kb][0][i] = 0.f; dk[kb][1][i] = 0.f; dv[kb][0][i] = 0.f; dv[kb][1][i] = 0.f; }
   const int ntiles = a.Tq / KT;
   const int64_t lbase = ((int64_t)b * a.H + hd) * a.Tq;
   unsigned long long* qmaskw = (unsigned long long*)(lds + AUX0 + 2 * AUXSLOT);
   int* const tl = (int*)(qmaskw + ntiles) + 1;
   if (a.qskip) build_mask_words(qmaskw, a.key_pad, b, a.Tq, ntiles, w, lane);
-  if (__syncthreads_and(wave_all_masked)) {   // 128 padded keys: zero rows, nothing to load
-    if (key < a.Tk) {
-      e16* dkp = dK + ((int64_t)b * a.Tk + key) * a.lddk + hd * DH + 4 * h;
-      e16* dvp = dV + ((int64_t)b * a.Tk + key) * a.lddv + hd * DH + 4 * h;
-      const e16x4 z = {(e16)0.f, (e16)0.f, (e16)0.f, (e16)0.f};
+  auto store_rows = [&](bool zeros) {       // dK (x 1/sqrt(dh)) and dV rows of the wave's keys
 #pragma unroll
-      for (int db = 0; db < 2; ++db)
+    for (int kb = 0; kb < KB; ++kb) {
+      const int key = k0 + 32 * kb + (lane & 31);
+      if (key < a.Tk) {
+        e16* dkp = dK + ((int64_t)b * a.Tk + key) * a.lddk + hd * DH + 4 * h;
+        e16* dvp = dV + ((int64_t)b * a.Tk + key) * a.lddv + hd * DH + 4 * h;
 #pragma unroll
-        for (int g4 = 0; g4 < 4; ++g4) { *(e16x4*)(dkp + 32 * db + 8 * g4) = z; *(e16x4*)(dvp + 32 * db + 8 * g4) = z; }
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+          for (int g4 = 0; g4 < 4; ++g4) {
+            e16x4 x = {(e16)0.f, (e16)0.f, (e16)0.f, (e16)0.f}, y = x;
+            if (!zeros) {
+              x = (e16x4){(e16)(dk[kb][db][4 * g4 + 0] * a.scale), (e16)(dk[kb][db][4 * g4 + 1] * a.scale),
+                          (e16)(dk[kb][db][4 * g4 + 2] * a.scale), (e16)(dk[kb][db][4 * g4 + 3] * a.scale)};
+              y = (e16x4){(e16)dv[kb][db][4 * g4 + 0], (e16)dv[kb][db][4 * g4 + 1], (e16)dv[kb][db][4 * g4 + 2], (e16)dv[kb][db][4 * g4 + 3]};
+            }
+            *(e16x4*)(dkp + 32 * db + 8 * g4) = x;
+            *(e16x4*)(dvp + 32 * db + 8 * g4) = y;
+          }
+      }
     }
+  };
+  if (__syncthreads_and(wave_all_masked)) {   // every key of the workgroup is padding: zero rows, nothing to load
+    store_rows(true);
     return;
   }
   build_tile_list(tl, a.qskip ? qmaskw : nullptr, 0, ntiles, w, lane);
@@ -137,11 +157,14 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void k_attn_bwd_dkv_pipe(
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                        (__attribute__((address_space(3))) void*)(st + w * 1024), 16, 0, 0);
     }
-    if (DROP == DROP_BITS) {          // the tile's two 32-query blocks of this wave's key block: 2 x 128 bytes, eight 16-byte chunks each
-      const int kb32 = min(k0 >> 5, a.nk32 - 1), qb32 = 2 * tq + ((lane >> 3) & 1);
-      const unsigned long long* src = a.bits + (((int64_t)(b * a.H + hd) * a.nq32 + qb32) * a.nk32 + kb32) * 16 + (lane & 7) * 2;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                       (__attribute__((address_space(3))) void*)(st + KB_OFF + w * 1024), 16, 0, 0);
+    if (DROP == DROP_BITS) {          // the tile's two 32-query blocks of each of the wave's key blocks: 2 x 128 bytes, eight 16-byte chunks each
+#pragma unroll
+      for (int kb = 0; kb < KB; ++kb) {
+        const int kb32 = min((k0 >> 5) + kb, a.nk32 - 1), qb32 = 2 * tq + ((lane >> 3) & 1);
+        const unsigned long long* src = a.bits + (((int64_t)(b * a.H + hd) * a.nq32 + qb32) * a.nk32 + kb32) * 16 + (lane & 7) * 2;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(st + KB_OFF + (w * KB + kb) * 1024), 16, 0, 0);
+      }
     }
   };
 
@@ -161,22 +184,27 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void k_attn_bwd_dkv_pipe(
   }
   unsigned aLA = lds0 + AUX0 + 16 * h;                   // lse / -delta of the A target's tile (tile 0's aux column)
   unsigned aLB = lds0 + AUX0 + 16 * h;                   // -delta of the B unit's tile
-  unsigned aW = lds0 + AUX0 + KB_OFF + w * 1024 + 4 * bits_word_of_key(lane & 31);   // keep word of the B unit's tile
+  unsigned aW = lds0 + AUX0 + KB_OFF + w * KB * 1024 + 4 * bits_word_of_key(lane & 31);   // keep word of the B unit's tile (key block kb: + 1024 kb)
 
   auto move_stage = [&](unsigned (&arr)[4], int diff) {
 #pragma unroll
     for (int d = 0; d < 4; ++d) arr[d] += (unsigned)diff;
   };
-  f32x16 s[2], dp[2];
-  uint32_t pfw[2][8], dsw[2][8];                        // B's output: P~ and dS of a unit as packed pairs (word i = scores 2i, 2i + 1)
+  f32x16 s[2][KB], dp[2][KB];
+  uint32_t pfw[2][KB][8], dsw[2][KB][8];                // B's output: P~ and dS of a unit as packed pairs (word i = scores 2i, 2i + 1)
 #pragma unroll
-  for (int i = 0; i < 8; ++i) { pfw[1][i] = 0u; dsw[1][i] = 0u; }   // "C(-1, 1)" of the first group adds exact zeros
+  for (int kb = 0; kb < KB; ++kb) {
 #pragma unroll
-  for (int i = 0; i < 16; ++i) { s[1][i] = 0.f; dp[1][i] = 0.f; }
+    for (int i = 0; i < 8; ++i) { pfw[1][kb][i] = 0u; dsw[1][kb][i] = 0u; }   // "C(-1, 1)" of the first group adds exact zeros
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { s[1][kb][i] = 0.f; dp[1][kb][i] = 0.f; }
+  }
   u32x4_ abuf[2];                                        // slot operands, two deep: slot i + 1's are in flight while slot i computes
   s16x4 clo[2], chi[2];
   f32x4 ndb[2];
-  uint32_t word = 0;
+  uint32_t word[KB];
+#pragma unroll
+  for (int kb = 0; kb < KB; ++kb) word[kb] = 0u;
 
   // operands of slot I (the A fragment, the C fragment pair, -delta of four queries)
   auto reads = [&](auto BB_, auto I_) __attribute__((always_inline)) {
@@ -206,15 +234,25 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void k_attn_bwd_dkv_pipe(
       AFM_LDS_RD128(si[2], aLA, LS_OFF + (32 * BA + 16) * 4); AFM_LDS_RD128(si[3], aLA, LS_OFF + (32 * BA + 24) * 4);
       AFM_LDS_RD128(di[0], aLA, DS_OFF + (32 * BA + 0) * 4);  AFM_LDS_RD128(di[1], aLA, DS_OFF + (32 * BA + 8) * 4);
       AFM_LDS_RD128(di[2], aLA, DS_OFF + (32 * BA + 16) * 4); AFM_LDS_RD128(di[3], aLA, DS_OFF + (32 * BA + 24) * 4);
-      if constexpr (DROP == DROP_BITS) AFM_LDS_RD32(word, aW, 128 * BB);
+      if constexpr (DROP == DROP_BITS) {
+        AFM_LDS_RD32(word[0], aW, 128 * BB);
+        if constexpr (KB == 2) AFM_LDS_RD32(word[KB - 1], aW, 1024 + 128 * BB);
+      }
       }
       if constexpr (!(AFM_PIPE_ABL & 4)) reads(BB_, std::integral_constant<int, 0>{});
       lgk_wait<0>();
 #pragma unroll
       for (int g4 = 0; g4 < 4; ++g4)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { s[BA][4 * g4 + j] = si[g4][j] * -1.4426950408889634f; dp[BA][4 * g4 + j] = di[g4][j]; }
-      if constexpr (DROP == DROP_BITS) word >>= 4 * h;
+        for (int j = 0; j < 4; ++j) {
+          const float sv = si[g4][j] * -1.4426950408889634f;
+#pragma unroll
+          for (int kb = 0; kb < KB; ++kb) { s[BA][kb][4 * g4 + j] = sv; dp[BA][kb][4 * g4 + j] = di[g4][j]; }
+        }
+      if constexpr (DROP == DROP_BITS) {
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) word[kb] >>= 4 * h;
+      }
       __builtin_amdgcn_sched_barrier(0);
     }
     static_for<0, 8>([&](auto I_) __attribute__((always_inline)) {
@@ -231,42 +269,48 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void k_attn_bwd_dkv_pipe(
       }
       if constexpr (!(AFM_PIPE_ABL & 1)) {
         const e16x8 ca = tr_join(clo[i & 1], chi[i & 1]);
-        constexpr int w0 = (i >> 2) * 4;        // words 0-3: scores 0-7 (k-slice 0), words 4-7: k-slice 1
-        if constexpr (((i >> 1) & 1) == 0) {
-          const e16x8 pf = __builtin_bit_cast(e16x8, (u32x4_){pfw[BC][w0], pfw[BC][w0 + 1], pfw[BC][w0 + 2], pfw[BC][w0 + 3]});
-          dv[i & 1] = mfma32(ca, pf, dv[i & 1]);
-        } else {
-          const e16x8 df = __builtin_bit_cast(e16x8, (u32x4_){dsw[BC][w0], dsw[BC][w0 + 1], dsw[BC][w0 + 2], dsw[BC][w0 + 3]});
-          dk[i & 1] = mfma32(ca, df, dk[i & 1]);
-        }
         const e16x8 fa = __builtin_bit_cast(e16x8, abuf[i & 1]);
-        if constexpr (i & 1) dp[BA] = mfma32(fa, vf[ks], dp[BA]);
-        else s[BA] = mfma32(fa, kf[ks], s[BA]);
+        constexpr int w0 = (i >> 2) * 4;        // words 0-3: scores 0-7 (k-slice 0), words 4-7: k-slice 1
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) {       // every fragment read from LDS serves all of the wave's key blocks
+          if constexpr (((i >> 1) & 1) == 0) {
+            const e16x8 pf = __builtin_bit_cast(e16x8, (u32x4_){pfw[BC][kb][w0], pfw[BC][kb][w0 + 1], pfw[BC][kb][w0 + 2], pfw[BC][kb][w0 + 3]});
+            dv[kb][i & 1] = mfma32(ca, pf, dv[kb][i & 1]);
+          } else {
+            const e16x8 df = __builtin_bit_cast(e16x8, (u32x4_){dsw[BC][kb][w0], dsw[BC][kb][w0 + 1], dsw[BC][kb][w0 + 2], dsw[BC][kb][w0 + 3]});
+            dk[kb][i & 1] = mfma32(ca, df, dk[kb][i & 1]);
+          }
+          if constexpr (i & 1) dp[BA][kb] = mfma32(fa, vf[kb][ks], dp[BA][kb]);
+          else s[BA][kb] = mfma32(fa, kf[kb][ks], s[BA][kb]);
+        }
       }
       const f32x4 nd = ndb[(i >> 1) & 1];
+#pragma unroll
+      for (int kb = 0; kb < KB; ++kb) {
       if constexpr (AFM_PIPE_ABL & 2) {
-        pfw[BB][i] = __builtin_bit_cast(uint32_t, s[BB][2 * i]) ^ __builtin_bit_cast(uint32_t, nd[0]); dsw[BB][i] = __builtin_bit_cast(uint32_t, dp[BB][2 * i + 1]);
-      } else {   // two scores of B
+        pfw[BB][kb][i] = __builtin_bit_cast(uint32_t, s[BB][kb][2 * i]) ^ __builtin_bit_cast(uint32_t, nd[0]); dsw[BB][kb][i] = __builtin_bit_cast(uint32_t, dp[BB][kb][2 * i + 1]);
+      } else {   // two scores of B per key block
         constexpr int r0 = 2 * i, r1 = 2 * i + 1;
-        const float p0 = fast_exp2(s[BB][r0]), p1 = fast_exp2(s[BB][r1]);
+        const float p0 = fast_exp2(s[BB][kb][r0]), p1 = fast_exp2(s[BB][kb][r1]);
         float d0, d1, q0, q1;
         if constexpr (DROP == DROP_BITS) {
           // keep bit -> all-ones / zero (v_bfe_i32), then two bit selects: no compare, no condition register
           uint32_t m0, m1, e0, e1, z0, z1;
-          asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(m0) : "v"(word), "n"(ACC_ROW(r0)));
-          asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(m1) : "v"(word), "n"(ACC_ROW(r1)));
-          asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(e0) : "v"(m0), "v"(dp[BB][r0]), "v"(nd[2 * (i & 1)]));
-          asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(e1) : "v"(m1), "v"(dp[BB][r1]), "v"(nd[2 * (i & 1) + 1]));
+          asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(m0) : "v"(word[kb]), "n"(ACC_ROW(r0)));
+          asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(m1) : "v"(word[kb]), "n"(ACC_ROW(r1)));
+          asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(e0) : "v"(m0), "v"(dp[BB][kb][r0]), "v"(nd[2 * (i & 1)]));
+          asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(e1) : "v"(m1), "v"(dp[BB][kb][r1]), "v"(nd[2 * (i & 1) + 1]));
           asm("v_and_b32 %0, %1, %2" : "=v"(z0) : "v"(m0), "v"(p0));
           asm("v_and_b32 %0, %1, %2" : "=v"(z1) : "v"(m1), "v"(p1));
           d0 = p0 * __builtin_bit_cast(float, e0); d1 = p1 * __builtin_bit_cast(float, e1);      // dS = P (keep ? scale dP - delta : -delta)
           q0 = __builtin_bit_cast(float, z0); q1 = __builtin_bit_cast(float, z1);
         } else {
-          d0 = p0 * dp[BB][r0]; d1 = p1 * dp[BB][r1]; q0 = p0; q1 = p1;
+          d0 = p0 * dp[BB][kb][r0]; d1 = p1 * dp[BB][kb][r1]; q0 = p0; q1 = p1;
         }
         uint32_t pw = cvt_pk2(q0, q1), dw = cvt_pk2(d0, d1);
         asm volatile("" : "+v"(pw), "+v"(dw));      // packed HERE (the compiler would otherwise carry the fp32 pairs into the next group)
-        pfw[BB][i] = pw; dsw[BB][i] = dw;
+        pfw[BB][kb][i] = pw; dsw[BB][kb][i] = dw;
+      }
       }
       __builtin_amdgcn_sched_barrier(0);
     });
@@ -306,12 +350,17 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void k_attn_bwd_dkv_pipe(
 #pragma unroll
       for (int g4 = 0; g4 < 4; ++g4)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { s[0][4 * g4 + j] = si[g4][j] * -1.4426950408889634f; dp[0][4 * g4 + j] = di[g4][j]; }
+        for (int j = 0; j < 4; ++j) {
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        s[0] = mfma32(__builtin_bit_cast(e16x8, fq[ks]), kf[ks], s[0]);
-        dp[0] = mfma32(__builtin_bit_cast(e16x8, fd[ks]), vf[ks], dp[0]);
-      }
+          for (int kb = 0; kb < KB; ++kb) { s[0][kb][4 * g4 + j] = si[g4][j] * -1.4426950408889634f; dp[0][kb][4 * g4 + j] = di[g4][j]; }
+        }
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) {
+          s[0][kb] = mfma32(__builtin_bit_cast(e16x8, fq[ks]), kf[kb][ks], s[0][kb]);
+          dp[0][kb] = mfma32(__builtin_bit_cast(e16x8, fd[ks]), vf[kb][ks], dp[0][kb]);
+        }
       __builtin_amdgcn_sched_barrier(0);
     }
     // One tile = two groups with the tile's barrier between them.  The loop body is the same for every tile: the first group of tile
@@ -354,33 +403,26 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void k_attn_bwd_dkv_pipe(
         constexpr int i = decltype(I_)::value, w0 = (i >> 2) * 4;
         (void)pfw; (void)dsw; (void)dk; (void)dv;
         const e16x8 ca = tr_join(lo[i], hi[i]);
-        if constexpr (((i >> 1) & 1) == 0)
-          dv[i & 1] = mfma32(ca, __builtin_bit_cast(e16x8, (u32x4_){pfw[1][w0], pfw[1][w0 + 1], pfw[1][w0 + 2], pfw[1][w0 + 3]}), dv[i & 1]);
-        else
-          dk[i & 1] = mfma32(ca, __builtin_bit_cast(e16x8, (u32x4_){dsw[1][w0], dsw[1][w0 + 1], dsw[1][w0 + 2], dsw[1][w0 + 3]}), dk[i & 1]);
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) {
+          if constexpr (((i >> 1) & 1) == 0)
+            dv[kb][i & 1] = mfma32(ca, __builtin_bit_cast(e16x8, (u32x4_){pfw[1][kb][w0], pfw[1][kb][w0 + 1], pfw[1][kb][w0 + 2], pfw[1][kb][w0 + 3]}), dv[kb][i & 1]);
+          else
+            dk[kb][i & 1] = mfma32(ca, __builtin_bit_cast(e16x8, (u32x4_){dsw[1][kb][w0], dsw[1][kb][w0 + 1], dsw[1][kb][w0 + 2], dsw[1][kb][w0 + 3]}), dk[kb][i & 1]);
+        }
       });
     }
   }
-  if (kmasked) {   // a padded key took no part in any softmax: its dK / dV rows are zero
 #pragma unroll
-    for (int i = 0; i < 16; ++i) { dk[0][i] = 0.f; dk[1][i] = 0.f; dv[0][i] = 0.f; dv[1][i] = 0.f; }
+  for (int kb = 0; kb < KB; ++kb) {
+    if (kmasked[kb]) {   // a padded key took no part in any softmax: its dK / dV rows are zero
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { dk[kb][0][i] = 0.f; dk[kb][1][i] = 0.f; dv[kb][0][i] = 0.f; dv[kb][1][i] = 0.f; }
+    }
+    if (DROP != DROP_NONE) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { dv[kb][0][i] *= a.dd.scale16; dv[kb][1][i] *= a.dd.scale16; }
+    }
   }
-  if (DROP != DROP_NONE) {
-#pragma unroll
-    for (int i = 0; i < 16; ++i) { dv[0][i] *= a.dd.scale16; dv[1][i] *= a.dd.scale16; }
-  }
-  if (key < a.Tk) {
-    e16* dkp = dK + ((int64_t)b * a.Tk + key) * a.lddk + hd * DH + 4 * h;
-    e16* dvp = dV + ((int64_t)b * a.Tk + key) * a.lddv + hd * DH + 4 * h;
-#pragma unroll
-    for (int db = 0; db < 2; ++db)
-#pragma unroll
-      for (int g4 = 0; g4 < 4; ++g4) {
-        e16x4 x = {(e16)(dk[db][4 * g4 + 0] * a.scale), (e16)(dk[db][4 * g4 + 1] * a.scale),
-                    (e16)(dk[db][4 * g4 + 2] * a.scale), (e16)(dk[db][4 * g4 + 3] * a.scale)};
-        e16x4 y = {(e16)dv[db][4 * g4 + 0], (e16)dv[db][4 * g4 + 1], (e16)dv[db][4 * g4 + 2], (e16)dv[db][4 * g4 + 3]};
-        *(e16x4*)(dkp + 32 * db + 8 * g4) = x;
-        *(e16x4*)(dvp + 32 * db + 8 * g4) = y;
-      }
-  }
+  store_rows(false);
 }

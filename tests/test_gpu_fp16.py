@@ -374,7 +374,8 @@ def test_attention_backward_skips_padded_query_rows_exactly(ops, dt, causal):
 def test_attention_dkv_pipelined_kernel_is_bit_identical(ops, dt, B, H, Tq, Tk, pad, pdrop):
     """csrc/afm_attn_pipe_impl.h (software-pipelined dK/dV kernel: no causal mask, Tq % 64 == 0, keep-bit dropout or none) gives every
     accumulator its products in the round-3 kernel's order: dK and dV equal that kernel's (afm_attn_shape.reserved & 128) bit for bit,
-    in the four-wave form and the eight-wave one (reserved & 256), with and without the padded-query skip."""
+    in the default form (four waves x 32 keys), with 64 keys per wave (reserved & 512) and with eight waves (reserved & 256), with and
+    without the padded-query skip."""
     dh = 64
     D = H * dh
     q, k, v, _ = _attn_case(B, H, Tq, Tk, dh, False, False, seed=41)
@@ -396,15 +397,15 @@ def test_attention_dkv_pipelined_kernel_is_bit_identical(ops, dt, B, H, Tq, Tk, 
         ops.attn_set_drop_bits(shp, torch.zeros(ops.attn_drop_bits_words(B, H, Tq, Tk), dtype=torch.int64, device=DEV))
     ops.attn_fwd(shp, qd, kd, vd, o, lse)
     res = {}
-    for name, flag in (("round3", 128), ("pipe4", 0), ("pipe8", 256)):
+    for name, flag in (("round3", 128), ("pipe32", 0), ("pipe64", 512), ("pipe8w", 256)):
         shp.reserved = flag | (64 if qskip else 0)
         dq = torch.empty(B * Tq, D, dtype=dt, device=DEV)
         dk, dv = (torch.full((B * Tk, D), float("nan"), dtype=dt, device=DEV) for _ in range(2))
         ops.attn_bwd(shp, qd, kd, vd, o, dod, lse, torch.empty_like(lse), dq, dk, dv, D, D, D)
         assert ops.last_algo() == "attn_mfma"
         res[name] = (dk, dv)
-    assert bool(torch.isfinite(res["pipe4"][0].float()).all()) and bool(torch.isfinite(res["pipe4"][1].float()).all())
-    for name in ("pipe4", "pipe8"):
+    assert bool(torch.isfinite(res["pipe64"][0].float()).all()) and bool(torch.isfinite(res["pipe64"][1].float()).all())
+    for name in ("pipe64", "pipe32", "pipe8w"):
         assert torch.equal(res["round3"][0], res[name][0]) and torch.equal(res["round3"][1], res[name][1]), name
 
 

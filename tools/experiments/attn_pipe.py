@@ -43,20 +43,20 @@ def case(B, H, Tq, Tk, p, padded, qskip, seed=1, time_it=False, dtype=torch.floa
     delta = torch.empty_like(lse)
     flag = 64 if (qskip and self_attn and padded) else 0
     out = {}
-    for tag, extra in (("r3", 128), ("pipe", 0), ("pipe8", 256)):
+    for tag, extra in (("r3", 128), ("pipe32", 0), ("pipe64", 512), ("pipe8w", 256)):
         dq = torch.zeros(B * Tq, D, dtype=dtype, device=dev)
         dk = torch.full((B * Tk, D), float("nan"), dtype=dtype, device=dev); dv = torch.full_like(dk, float("nan"))
         s.reserved = flag | extra
         ops.attn_bwd(s, q, k, v, o, do, lse, delta, dq, dk, dv, D, D, D)
         torch.cuda.synchronize()
         out[tag] = (dk, dv)
-    same = all(torch.equal(out["r3"][i], out[n][i]) for i in (0, 1) for n in ("pipe", "pipe8"))
-    fin = bool(torch.isfinite(out["pipe"][0]).all() and torch.isfinite(out["pipe"][1]).all())
-    md = max((out["r3"][0].float() - out["pipe"][0].float()).abs().max().item(), (out["r3"][1].float() - out["pipe"][1].float()).abs().max().item())
+    same = all(torch.equal(out["r3"][i], out[n][i]) for i in (0, 1) for n in ("pipe64", "pipe32", "pipe8w"))
+    fin = bool(torch.isfinite(out["pipe64"][0]).all() and torch.isfinite(out["pipe64"][1]).all())
+    md = max((out["r3"][0].float() - out["pipe64"][0].float()).abs().max().item(), (out["r3"][1].float() - out["pipe64"][1].float()).abs().max().item())
     print(f"B{B} H{H} Tq{Tq} Tk{Tk} p{p} padded={padded} qskip={qskip} {str(dtype)[6:]}: identical={same} finite={fin} maxdiff={md:.3e}", flush=True)
     if time_it:
         for rnd in range(2):
-            for tag, extra in (("r3", 128), ("pipe", 0), ("pipe8", 256)):
+            for tag, extra in (("r3", 128), ("pipe32", 0), ("pipe64", 512), ("pipe8w", 256)):
                 s.reserved = 2 | flag | extra
                 ms = t(lambda: ops.attn_bwd(s, q, k, v, o, do, lse, delta, dq, dk, dv, D, D, D))
                 print(f"   dK/dV {tag:5s} {ms:.4f} ms", flush=True)
