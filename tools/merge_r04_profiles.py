@@ -22,6 +22,8 @@ GEMM_WHAT = {"qkv_fwd_default": "QKV projection forward",
 def main():
     M2.SRC = SRC
     M2.pretty = M3.pretty
+    M2.NAMES.update({"k_attn_bwd_dkv_pipe": "attention backward, dK/dV kernel", "k_attn_fwd_st": "attention forward, 8-wave staggered form (opt-in)",
+                     "k_attn_bwd_dq_st": "attention backward, dQ kernel, 8-wave staggered form (opt-in)"})
     src = os.path.join(SRC, "step_fp16_kernel_stats.csv")
     if os.path.exists(src):
         dst = os.path.join(DST, "r04_c2_fp16_kernel_stats.csv")
