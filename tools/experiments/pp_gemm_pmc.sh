@@ -1,6 +1,6 @@
 #!/bin/bash
 # cycles (GRBM_GUI_ACTIVE / 8) and clock of the ping-pong GEMM's timing ablations (AFM_GEMM_ABLATIONS build): 0 full,
-# 2 no LDS-DMA, 4 no epilogue, 6 LDS reads + MFMAs only -- at N 512 / K 2048 (first 40 launches of each kernel) and N 1536 / K 512 (last 40)
+# 2 no LDS-DMA, 4 no epilogue, 6 LDS reads + MFMAs only -- at N 512 / K 2048 (launches 150 .. 299 of each kernel) and N 1536 / K 512 (450 .. 599)
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/r4
 mkdir -p $O
@@ -23,7 +23,7 @@ out = {}
 for k, lst in byk.items():
     m = re.search(r"gemm_nt_ppILi\d+ELi(\d+)E", k)
     abl = int(m.group(1)) if m else -1
-    for shape, part in (("N512_K2048", lst[10:40]), ("N1536_K512", lst[50:80])):
+    for shape, part in (("N512_K2048", lst[150:300]), ("N1536_K512", lst[450:600])):
         if not part: continue
         n = len(part); ns = sum(x["ns"] for x in part) / n; cyc = sum(x.get("GRBM_GUI_ACTIVE", 0) for x in part) / n / 8
         out[f"{shape}_abl{abl}"] = {"us": ns / 1e3, "kcycles": cyc / 1e3, "clock_ghz": cyc / ns,
