@@ -226,7 +226,11 @@ typedef struct {
                              earlier call): lets bench.py / the profiler time the two backward kernels separately.
                              bit 6 (64): afm_attn_bwd, self-attention (Tq == Tk, key_pad given): the caller vouches that dO is zero in the query rows
                              key_pad marks (a training step's padded positions); the single-pass kernels then skip them -- dQ rows stay
-                             zero, dK / dV lose exact zeros.  bit 5 (32): forward reads drop_bits (afm_attn_drop_bits_fill ran before); bit 4 (16): the 8-wave staggered forms of the single-pass forward / dQ kernels (Tq >= 256), see DESIGN.md 4 */
+                             zero, dK / dV lose exact zeros.  bit 5 (32): forward reads drop_bits (afm_attn_drop_bits_fill ran before); bit 4 (16): the 8-wave staggered forms of the single-pass forward / dQ kernels (Tq >= 256), see DESIGN.md 4.
+                             afm_attn_bwd, dK/dV kernel selection (A / B tests; every form gives bit-identical dK / dV): bit 7 (128) the round-3
+                             kernel instead of the software-pipelined one (csrc/afm_attn_pipe_impl.h: default where there is no causal mask, Tq % 64 == 0
+                             and dropout runs through drop_bits or is off); bit 8 (256) its eight-wave form; bit 9 (512) its form with 64 keys per
+                             wave.  Bits 12-19: timing ablations, only in AFM_ATTN_ABLATIONS builds (never in the product library). */
   const uint8_t* key_pad;
   afm_dropout drop;
   /* batch strides in ELEMENTS of Q, K, V, O (0 = dense: Tq*ldq, Tk*ldk, Tk*ldv, Tq*ldo).  Non-dense
