@@ -304,6 +304,17 @@ int afm_cast_x2(const float* src, void* dst, void* dst_t, int32_t rows, int32_t 
  * r (r < f: W1, else Wg) lands in row ((j>>2)<<3) + (j&3) + 4*(r >= f), j = r mod f, of dst (column of dst_t). */
 int afm_cast_weights(const float* src, void* dst, void* dst_t, int32_t rows, int32_t cols, int32_t dtype, int32_t glu_rows,
                      void* stream);
+/* The same for a whole list of matrices in ONE launch (the weight shadows behind an optimiser step: 81 launches of a few
+ * microseconds each at the c2 model otherwise).  `items` is a DEVICE array; item i covers the 64 x 64 tiles [tile0, tile0 +
+ * ceil(rows/64) * ceil(cols/64)) of the launch, tile0 ascending from 0, `tiles` their total.  dst or dst_t may be null per item.
+ * Replaces: the per-parameter `.to(dtype)` casts autocast performs inside every torch Linear (torch/amp/autocast_mode.py). */
+typedef struct afm_cast_item {
+  const float* src;
+  void* dst;
+  void* dst_t;
+  int32_t rows, cols, glu_rows, tile0;
+} afm_cast_item;
+int afm_cast_weights_batch(const afm_cast_item* items, int32_t n, int32_t tiles, int32_t dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Encoder alignment head (custom_modeling.py:363-396 network, 453-475 use).

@@ -14,6 +14,7 @@ extern "C" int afm_struct_size(int which) {
     case 3: return (int)sizeof(afm_attn_shape);
     case 4: return (int)sizeof(afm_patch_desc);
     case 5: return (int)sizeof(afm_beam_desc);
+    case 6: return (int)sizeof(afm_cast_item);
     default: return -1;
   }
 }
@@ -421,6 +422,67 @@ __global__ void k_cast_weights(const float* __restrict__ src, bf16* __restrict__
       }
     }
   }
+}
+// Every weight shadow of an optimiser step in ONE launch (afm_cast_weights_batch): block b finds its item by the running tile count.
+template <int MODE>
+__global__ void k_cast_weights_batch(const afm_cast_item* __restrict__ items, int n) {
+  int lo = 0, hi = n - 1;                     // last item with tile0 <= blockIdx.x
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (items[mid].tile0 <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const afm_cast_item it = items[lo];
+  const int rows = it.rows, cols = it.cols, glu_f = it.glu_rows;
+  const int tpr = (cols + 63) / 64, lt = (int)blockIdx.x - it.tile0;
+  const float* __restrict__ src = it.src;
+  bf16* __restrict__ dst = (bf16*)it.dst;
+  bf16* __restrict__ dst_t = (bf16*)it.dst_t;
+  constexpr bool X2T = MODE == 1;
+  __shared__ float tile[64][65];
+  const int r0 = (lt / tpr) * 64, c0 = (lt % tpr) * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int ldd = X2T ? 2 * cols : cols, ldt = X2T ? 2 * rows : rows;
+  for (int i = ty; i < 64; i += 4) {
+    const int r = r0 + i, c = c0 + tx;
+    float v = 0.f;
+    if (r < rows && c < cols) {
+      v = src[(int64_t)r * cols + c];
+      if (dst) {
+        const int rd = glu_f ? glu_interleave(r, glu_f) : r;
+        if (MODE == 2) ((f16*)dst)[(int64_t)rd * ldd + c] = (f16)v;
+        else {
+          bf16 hi_, lo_;
+          afm_split(v, hi_, lo_);
+          dst[(int64_t)rd * ldd + c] = hi_;
+          if (X2T) dst[(int64_t)rd * ldd + cols + c] = lo_;
+        }
+      }
+    }
+    tile[i][tx] = v;
+  }
+  if (!dst_t) return;
+  __syncthreads();
+  for (int i = ty; i < 64; i += 4) {
+    const int c = c0 + i, r = r0 + tx;
+    if (r < rows && c < cols) {
+      const int rd = glu_f ? glu_interleave(r, glu_f) : r;
+      if (MODE == 2) ((f16*)dst_t)[(int64_t)c * ldt + rd] = (f16)tile[tx][i];
+      else {
+        bf16 hi_, lo_;
+        afm_split(tile[tx][i], hi_, lo_);
+        dst_t[(int64_t)c * ldt + rd] = hi_;
+        if (X2T) dst_t[(int64_t)c * ldt + rows + rd] = lo_;
+      }
+    }
+  }
+}
+extern "C" int afm_cast_weights_batch(const afm_cast_item* items, int32_t n, int32_t tiles, int32_t dtype, void* stream) {
+  if (!items || n <= 0 || tiles <= 0) return AFM_ERR_ARG;
+  if (dtype == AFM_BF16) AFM_LAUNCH(k_cast_weights_batch<0>, dim3(tiles), dim3(256), 0, (hipStream_t)stream, items, n);
+  else if (dtype == AFM_BF16X2) AFM_LAUNCH(k_cast_weights_batch<1>, dim3(tiles), dim3(256), 0, (hipStream_t)stream, items, n);
+  else if (dtype == AFM_F16) AFM_LAUNCH(k_cast_weights_batch<2>, dim3(tiles), dim3(256), 0, (hipStream_t)stream, items, n);
+  else return AFM_ERR_ARG;
+  return AFM_OK;
 }
 extern "C" int afm_cast_weights(const float* src, void* dst, void* dst_t, int32_t rows, int32_t cols, int32_t dtype,
                                 int32_t glu_rows, void* stream) {

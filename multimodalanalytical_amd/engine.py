@@ -98,6 +98,7 @@ class Seq2SeqEngine:
         self.w_glu: Dict[str, Any] = {}        # gated FFN: [W1 ; Wg] with rows interleaved in fours (fused GLU epilogues), and
         self.wt_glu: Dict[str, Any] = {}       # its transpose (d x 2f, columns interleaved) for the data gradient
         self.wt_kv_all = None                  # see _refresh_kv_concat
+        self._cast_batch = None                # ops.CastBatch of refresh_transposes (built on first use; the buffers it points at never move)
         self._graph_states: Dict[Any, dict] = {}   # decode_init_graphed
         self.training = True
         self.dropout_seed = int(seed)
@@ -167,6 +168,21 @@ class Seq2SeqEngine:
             return
         if self.x3:     # the Adam kernel writes no split-pair shadow: both copies are made here
             return self.refresh_shadows()
+        if self.dev.type == "cuda" and os.environ.get("AFM_CAST_BATCH", "1") != "0":
+            # one launch for every transpose and gated-FFN shadow (afm_cast_weights_batch; AFM_CAST_BATCH=0: one launch per matrix, for A/B runs)
+            if self._cast_batch is None:
+                entries = [(self.ps.span(self.ps.flat, name, rows, cols), None, self.wt[name], 0) for name, rows, cols in self._gemm_weight_groups()]
+                if self.gated:
+                    for name, rows, cols in self._gemm_weight_groups():
+                        if name.endswith("linear1.weight"):
+                            if name not in self.w_glu:
+                                self.w_glu[name] = ops.empty(rows, cols, self.cd, self.dev)
+                                self.wt_glu[name] = ops.empty(cols, rows, self.cd, self.dev)
+                            entries.append((self.ps.span(self.ps.flat, name, rows, cols), self.w_glu[name], self.wt_glu[name], rows // 2))
+                self._cast_batch = ops.CastBatch(entries, self.cd)
+            self._cast_batch.run()
+            self._refresh_kv_concat()
+            return
         for name, rows, cols in self._gemm_weight_groups():
             if self.cd == torch.float16:
                 ops.cast_weights(self.ps.span(self.ps.flat, name, rows, cols), None, self.wt[name])

@@ -59,6 +59,12 @@ class LnShape(C.Structure):
     ]
 
 
+class CastItem(C.Structure):
+    """afm_cast_item (afm_cast_weights_batch): one matrix of the batched weight-shadow cast."""
+    _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("dst_t", C.c_void_p),
+                ("rows", C.c_int32), ("cols", C.c_int32), ("glu_rows", C.c_int32), ("tile0", C.c_int32)]
+
+
 class BeamDesc(C.Structure):
     _fields_ = [
         ("B", C.c_int32), ("k", C.c_int32), ("V", C.c_int32), ("ldl", C.c_int32),
@@ -92,6 +98,7 @@ _SIGS = {
     "afm_convert": (C.c_int, [_P, _I32, _I32, _P, _I32, _I32, _I64, _I32, _P]),
     "afm_cast_x2": (C.c_int, [_P, _P, _P, _I32, _I32, _P]),
     "afm_cast_weights": (C.c_int, [_P, _P, _P, _I32, _I32, _I32, _I32, _P]),
+    "afm_cast_weights_batch": (C.c_int, [_P, _I32, _I32, _I32, _P]),
     "afm_error_string": (C.c_char_p, [C.c_int]),
     "afm_last_algo": (C.c_char_p, []),
     "afm_gemm": (C.c_int, [C.POINTER(GemmDesc), _P]),
@@ -177,7 +184,7 @@ def load(build_if_missing: bool = True):
             fn.restype, fn.argtypes = res, args
         if lib.afm_abi_version() != ABI_VERSION:
             raise AfmError(f"libafm_hip.so ABI version {lib.afm_abi_version()} != binding {ABI_VERSION}: rebuild it")
-        for which, st in enumerate((Dropout, GemmDesc, LnShape, AttnShape, PatchDesc, BeamDesc)):
+        for which, st in enumerate((Dropout, GemmDesc, LnShape, AttnShape, PatchDesc, BeamDesc, CastItem)):
             if lib.afm_struct_size(which) != C.sizeof(st):
                 raise AfmError(f"libafm_hip.so was built with a different {st.__name__} layout: rebuild it")
         _lib = lib

@@ -388,6 +388,31 @@ def cast_weights(src, dst=None, dst_t=None, glu_rows: int = 0):
             "afm_cast_weights")
 
 
+class CastBatch:
+    """A fixed list of (src fp32, dst, dst_t, glu_rows) matrices cast by ONE launch (afm_cast_weights_batch).  The item table lives on
+    the device and holds raw pointers: the tensors must stay where they are (parameter spans and shadow buffers do)."""
+
+    def __init__(self, entries, dtype):
+        import numpy as np
+        items = (L.CastItem * len(entries))()
+        tile0 = 0
+        self._keep = []
+        for i, (src, dst, dst_t, glu_rows) in enumerate(entries):
+            rows, cols = src.shape
+            assert src.dtype == torch.float32 and src.is_contiguous()
+            assert (dst is None or is_contig(dst)) and (dst_t is None or is_contig(dst_t)) and (dst is not None or dst_t is not None)
+            items[i].src, items[i].dst, items[i].dst_t = _ptr(src), _ptr(dst), _ptr(dst_t)
+            items[i].rows, items[i].cols, items[i].glu_rows, items[i].tile0 = rows, cols, int(glu_rows), tile0
+            tile0 += ((rows + 63) // 64) * ((cols + 63) // 64)
+            self._keep.append((src, dst, dst_t))
+        self.n, self.tiles, self.dt = len(entries), tile0, _DT[dtype]
+        raw = np.frombuffer(bytes(items), dtype=np.uint8).copy()
+        self.table = torch.from_numpy(raw).to(entries[0][0].device)
+
+    def run(self):
+        L.check(L.load().afm_cast_weights_batch(_ptr(self.table), self.n, self.tiles, self.dt, _stream()), "afm_cast_weights_batch")
+
+
 def cast_bf16(src, dst=None, dst_t=None):
     rows, cols = src.shape
     assert src.dtype == torch.float32 and src.is_contiguous()

@@ -409,6 +409,29 @@ def test_attention_dkv_pipelined_kernel_is_bit_identical(ops, dt, B, H, Tq, Tk, 
         assert torch.equal(res["round3"][0], res[name][0]) and torch.equal(res["round3"][1], res[name][1]), name
 
 
+@pytest.mark.parametrize("dt", [H16, torch.bfloat16])
+def test_cast_weights_batch_equals_the_single_launches(ops, dt):
+    """afm_cast_weights_batch (every weight shadow of an optimiser step in one launch) writes what the per-matrix launches write:
+    plain copies, transposes, the gated-FFN row interleave, shapes that are not multiples of the 64 x 64 tile."""
+    shapes = [(1536, 512, 0), (512, 512, 0), (300, 70, 0), (4096, 512, 2048), (26, 512, 0), (64, 64, 0), (512, 2048, 0)]
+    srcs = [dev(rnd(r, c, seed=60 + i)) for i, (r, c, _) in enumerate(shapes)]
+    want, entries = [], []
+    for i, ((r, c, glu), src) in enumerate(zip(shapes, srcs)):
+        d1 = torch.full((r, c), 7.0, dtype=dt, device=DEV) if i % 3 != 1 else None       # (every third item: transpose only)
+        t1 = torch.full((c, r), 7.0, dtype=dt, device=DEV)
+        if dt == H16 or glu:
+            ops.cast_weights(src, d1, t1, glu_rows=glu)
+        else:
+            ops.cast_bf16(src, d1, t1)
+        want.append((d1, t1))
+        entries.append((src, None if d1 is None else torch.full_like(d1, 3.0), torch.full_like(t1, 3.0), glu))
+    batch = ops.CastBatch(entries, dt)
+    batch.run()
+    for (d1, t1), (_, d2, t2, _) in zip(want, entries):
+        assert torch.equal(t1, t2)
+        assert d1 is None or torch.equal(d1, d2)
+
+
 # ------------------------------------------------------------------ LayerNorm, elementwise, loss
 @pytest.mark.parametrize("d", [64, 512, 768])
 def test_layernorm_f16(ops, d):
