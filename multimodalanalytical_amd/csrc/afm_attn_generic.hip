@@ -76,11 +76,10 @@ __global__ __launch_bounds__(256) void k_attn_fwd_generic(AttnArgs a, const T* _
   l = wave_sum(l);
   if (lane == 0) lse[row] = mx + logf(l);
   const float inv_l = 1.0f / l;
-  const uint64_t didx = (uint64_t)row * (uint64_t)a.Tk;
   for (int j = lane; j < a.dh; j += 64) {
     float acc = 0.f;
     for (int k = 0; k < a.Tk; ++k) {
-      const float p = afm_drop16(a.dd, didx + k, sc[k]);
+      const float p = afm_drop16(a.dd, (uint64_t)row, (uint32_t)k, sc[k]);
       acc = fmaf(p, ldp(V + ((int64_t)b * a.svb + (int64_t)k * a.ldv) + (int64_t)h * a.dh, j, a.ldv >> 1), acc);
     }
     stp(op, j, a.ldo >> 1, acc * inv_l);
@@ -117,7 +116,6 @@ __global__ __launch_bounds__(256) void k_attn_bwd_q_generic(
   dl = wave_sum(dl);
   if (lane == 0) delta[row] = dl;
   const float L = lse[row];
-  const uint64_t didx = (uint64_t)row * (uint64_t)a.Tk;
   for (int k = lane; k < a.Tk; k += 64) {
     float d = 0.f;
     if (!attn_masked(a, b, q, k) && L != INFINITY) {
@@ -129,7 +127,7 @@ __global__ __launch_bounds__(256) void k_attn_bwd_q_generic(
         dp = fmaf(dov[j], ldp(vp, j, a.ldv >> 1), dp);
       }
       const float p = expf(s * a.scale - L);
-      dp = afm_drop16(a.dd, didx + k, dp);
+      dp = afm_drop16(a.dd, (uint64_t)row, (uint32_t)k, dp);
       d = p * (dp - dl) * a.scale;
     }
     ds[k] = d;
@@ -177,9 +175,8 @@ __global__ __launch_bounds__(256) void k_attn_bwd_kv_generic(
         dp = fmaf(ldp(dop, j, a.ldo >> 1), vv[j], dp);
       }
       const float p = expf(s * a.scale - L);
-      const uint64_t di = (uint64_t)qrow * (uint64_t)a.Tk + (uint64_t)k;
-      pdv = afm_drop16(a.dd, di, p);
-      dp = afm_drop16(a.dd, di, dp);
+      pdv = afm_drop16(a.dd, (uint64_t)qrow, (uint32_t)k, p);
+      dp = afm_drop16(a.dd, (uint64_t)qrow, (uint32_t)k, dp);
       dsv = p * (dp - delta[qrow]) * a.scale;
     }
     pd[q] = pdv;
@@ -212,7 +209,7 @@ __global__ __launch_bounds__(256) void k_drop_bits(DropDev dd, int B, int H, int
   for (int r = 0; r < 16; ++r) {
     const int key = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
     const bool in = q < Tq && key < Tk;
-    const bool keep = in && afm_keep16(dd, ((uint64_t)bh * Tq + q) * (uint64_t)Tk + key);
+    const bool keep = in && afm_keep16(dd, (uint64_t)bh * Tq + q, (uint32_t)key);
     const unsigned long long m = __ballot(keep);
     if (lane == 0) bits[blk * 16 + r] = m;
   }

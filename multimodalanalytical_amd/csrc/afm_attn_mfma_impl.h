@@ -73,7 +73,7 @@ __global__ __launch_bounds__(256, AFM_FWD_OCC) void k_attn_fwd_mfma(AttnM a, con
 #pragma unroll
   for (int i = 0; i < 16; ++i) { o[0][i] = 0.f; o[1][i] = 0.f; }
   float m = -INFINITY, l = 0.f;   // running maximum (log2 units; -inf until the row has seen an unmasked key) and row sum
-  const uint32_t rowbase = (uint32_t)(((uint64_t)(b * a.H + hd) * a.Tq + qc) * (uint64_t)a.Tk);
+  const uint32_t rowbase = afm_row_hash(a.dd, (uint64_t)(b * a.H + hd) * a.Tq + qc);   // the lane's ROW HASH (two-level dropout stream, afm_common.h)
 #pragma unroll
   for (int s = 0; s < RS - 1; ++s)
     if (s < nlive) issue(s);
@@ -249,7 +249,7 @@ __global__ __launch_bounds__(512, 2) void k_attn_fwd_st(AttnM a, const e16* __re
   for (int i = 0; i < 16; ++i) { o[0][i] = 0.f; o[1][i] = 0.f; }
   float m = -INFINITY, l = 0.f;   // running maximum (log2 units; -inf until the row has seen an unmasked key) and row sum
   e16x8 pf[4];                    // the tile's probabilities as MFMA operands (written by the vector segment)
-  const uint32_t rowbase = (uint32_t)(((uint64_t)(b * a.H + hd) * a.Tq + qc) * (uint64_t)a.Tk);
+  const uint32_t rowbase = afm_row_hash(a.dd, (uint64_t)(b * a.H + hd) * a.Tq + qc);   // the lane's ROW HASH (two-level dropout stream, afm_common.h)
   issue(0);
   if (ntiles > 1) issue(1);
   attn_wait_vmcnt<0>();
@@ -457,7 +457,7 @@ __global__ __launch_bounds__(256, 3) void k_attn_bwd_dq_mfma(AttnM a, const e16*
   f32x16 dq[2];
 #pragma unroll
   for (int i = 0; i < 16; ++i) { dq[0][i] = 0.f; dq[1][i] = 0.f; }
-  const uint32_t rowbase = (uint32_t)((uint64_t)lrow * (uint64_t)a.Tk);
+  const uint32_t rowbase = afm_row_hash(a.dd, (uint64_t)lrow);   // the lane's ROW HASH (two-level dropout stream, afm_common.h)
 
   int kend = a.Tk;
   if (a.causal) kend = min(a.Tk, blk_.xb * 128 + 128);
@@ -629,7 +629,7 @@ __global__ __launch_bounds__(512, 2) void k_attn_bwd_dq_st(AttnM a, const e16* _
 #pragma unroll
   for (int i = 0; i < 16; ++i) { dq[0][i] = 0.f; dq[1][i] = 0.f; }
   e16x8 ds[4];                       // dS^T of the tile as MFMA operands (written by the vector segment)
-  const uint32_t rowbase = (uint32_t)((uint64_t)lrow * (uint64_t)a.Tk);
+  const uint32_t rowbase = afm_row_hash(a.dd, (uint64_t)lrow);   // the lane's ROW HASH (two-level dropout stream, afm_common.h)
   int kend = a.Tk;
   if (a.causal) kend = min(a.Tk, blk_.xb * 256 + 256);
   const int ntiles = (kend + KT - 1) / KT;
@@ -923,16 +923,16 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd_dkv_mfma(AttnM a, const e16
           }
         }
       } else if (DROP == DROP_HASH) {
-        // Dropout keep bits.  Element (q, key) has index i = (lbase+q)*Tk + key; with Tk even the two
-        // lanes of a key pair (lane, lane^1) share the hash of i>>1 = (lbase+q)*(Tk/2) + key/2 and take
-        // its low / high 16 bits.  The even lane hashes the even register rows, the odd lane the odd
-        // rows, and a quad-permute DPP move hands each lane its partner's hash.
-        const uint32_t htk = (uint32_t)a.Tk >> 1;
-        const uint32_t tb = (uint32_t)(lbase + qb + 32 * blk + 4 * h + (lane & 1)) * htk + ((uint32_t)key >> 1);
+        // Dropout keep bits (two-level stream, afm_common.h).  Element (q, key): the two lanes of a key pair (lane, lane^1) share
+        // the pair mix of row (lbase + q)'s hash and take its low / high 16 bits.  The even lane hashes the even register rows,
+        // the odd lane the odd rows, and a quad-permute DPP move hands each lane its partner's hash.  (The key sits on the lane
+        // here, so every register row costs a row hash as well: this re-hash path is the slow one; training reads the keep bits.)
+        const uint64_t tb = (uint64_t)(lbase + qb + 32 * blk + 4 * h + (lane & 1));
+        const uint32_t po = afm_pair_offset((uint32_t)key >> 1);
         const uint32_t hshift = (lane & 1) << 4;
 #pragma unroll
         for (int r = 0; r < 16; r += 2) {
-          const uint32_t own = hash_pair32(a.dd, tb + (uint32_t)ACC_ROW(r) * htk);   // row r + (lane&1)
+          const uint32_t own = afm_pair_mix(afm_row_hash(a.dd, tb + (uint64_t)ACC_ROW(r)) + po);   // row r + (lane&1)
           const uint32_t oth = (uint32_t)__builtin_amdgcn_mov_dpp((int)own, 0xB1, 0xF, 0xF, true);  // lane^1
           const uint32_t h0 = (lane & 1) ? oth : own, h1 = (lane & 1) ? own : oth;
           const bool k0 = ((h0 >> hshift) & 0xFFFFu) >= a.dd.thresh16, k1 = ((h1 >> hshift) & 0xFFFFu) >= a.dd.thresh16;
@@ -1012,9 +1012,9 @@ __global__ __launch_bounds__(256) void k_attn_bits_fill(AttnM a) {
   const int bh = (int)(wave / a.nq32), qb32 = (int)(wave % a.nq32);
   const int q = qb32 * 32 + (lane & 31);
   const int qc = q < a.Tq ? q : a.Tq - 1;
-  const uint32_t rowbase = (uint32_t)(((uint64_t)bh * a.Tq + qc) * (uint64_t)a.Tk);
+  const uint32_t rowbase = afm_row_hash(a.dd, (uint64_t)bh * a.Tq + qc);
   for (int kb32 = 0; kb32 < a.nk32; ++kb32)
-    bits_emit_rows<0>(a.dd, (rowbase + (uint32_t)(kb32 * 32 + 4 * h)) >> 1, bits_block(a, bh, qb32, kb32));
+    bits_emit_rows<0>(a.dd, pair_base(rowbase, kb32 * 32, h), bits_block(a, bh, qb32, kb32));
   bits_flush();
 }
 

@@ -128,18 +128,18 @@ __device__ __forceinline__ void stage_store(unsigned char* img, const Stage2& s,
   }
 }
 
-// dropout on a 32x32 score block held transposed (rows = keys in registers, query on the lane):
-// keep bits for key pairs (ACC_ROW(r), +1) come from one hash (afm_keep16).
-// The MFMA kernels only run when the whole probability tensor has <= 2^32 elements (eligible()), so
-// the element index fits 32 bits and the high-word term of the hash is zero.
-__device__ __forceinline__ uint32_t hash_pair32(const DropDev& dd, uint32_t half_idx) {
-  return afm_lowbias32(half_idx ^ dd.key);
-}
-__device__ __forceinline__ void drop_block(const DropDev& dd, uint32_t rowbase, int key0, int h, f32x16& x) {
-  const uint32_t base = (rowbase + (uint32_t)(key0 + 4 * h)) >> 1;       // even (Tk even, key0 even)
+// dropout on a 32x32 score block held transposed (rows = keys in registers, query on the lane): the lane's ROW HASH (afm_row_hash of
+// its query's score-matrix row, made once per kernel) plus the key pair's stride offset goes through the four-instruction pair mix
+// (afm_common.h, two-level stream of round 4); keys (ACC_ROW(r), +1) take the low / high 16 bits.
+__device__ __forceinline__ uint32_t hash_pair32(uint32_t rowhash_plus_pair) { return afm_pair_mix(rowhash_plus_pair); }
+// rowhash + stride * (first pair of the lane's keys in the block): key0 a multiple of 32, 4 h even
+__device__ __forceinline__ uint32_t pair_base(uint32_t rowhash, int key0, int h) { return rowhash + afm_pair_offset((uint32_t)(key0 + 4 * h) >> 1); }
+#define AFM_PAIR_OFF(R) ((uint32_t)(ACC_ROW(R) >> 1) * AFM_PAIR_STRIDE)      // compile-time constant per register pair
+__device__ __forceinline__ void drop_block(const DropDev& dd, uint32_t rowhash, int key0, int h, f32x16& x) {
+  const uint32_t base = pair_base(rowhash, key0, h);
 #pragma unroll
   for (int r = 0; r < 16; r += 2) {
-    const uint32_t hsh = hash_pair32(dd, base + (uint32_t)(ACC_ROW(r) >> 1));
+    const uint32_t hsh = hash_pair32(base + AFM_PAIR_OFF(r));
     x[r] = (hsh & 0xFFFFu) >= dd.thresh16 ? x[r] : 0.f;
     x[r + 1] = (hsh >> 16) >= dd.thresh16 ? x[r + 1] : 0.f;
   }
@@ -284,7 +284,7 @@ __device__ __forceinline__ unsigned long long* bits_block(const AttnM& a, int bh
 template <int R>
 __device__ __forceinline__ void drop_emit_rows(const DropDev& dd, uint32_t base, f32x16& x, unsigned long long* blk) {
   if constexpr (R < 16) {
-    const uint32_t hsh = hash_pair32(dd, base + (uint32_t)(ACC_ROW(R) >> 1));
+    const uint32_t hsh = hash_pair32(base + AFM_PAIR_OFF(R));
     const bool k0 = (hsh & 0xFFFFu) >= dd.thresh16, k1 = (hsh >> 16) >= dd.thresh16;
     const unsigned long long m0 = __ballot(k0), m1 = __ballot(k1);
     x[R] = k0 ? x[R] : 0.f;
@@ -294,15 +294,15 @@ __device__ __forceinline__ void drop_emit_rows(const DropDev& dd, uint32_t base,
     drop_emit_rows<R + 2>(dd, base, x, blk);
   }
 }
-__device__ __forceinline__ void drop_block_emit(const DropDev& dd, uint32_t rowbase, int key0, int h, f32x16& x,
+__device__ __forceinline__ void drop_block_emit(const DropDev& dd, uint32_t rowhash, int key0, int h, f32x16& x,
                                                 unsigned long long* blk) {
-  drop_emit_rows<0>(dd, (rowbase + (uint32_t)(key0 + 4 * h)) >> 1, x, blk);
+  drop_emit_rows<0>(dd, pair_base(rowhash, key0, h), x, blk);
 }
 // the same 16 lane masks without a score block to apply them to (k_attn_bits_fill)
 template <int R>
 __device__ __forceinline__ void bits_emit_rows(const DropDev& dd, uint32_t base, unsigned long long* blk) {
   if constexpr (R < 16) {
-    const uint32_t hsh = hash_pair32(dd, base + (uint32_t)(ACC_ROW(R) >> 1));
+    const uint32_t hsh = hash_pair32(base + AFM_PAIR_OFF(R));
     const unsigned long long m0 = __ballot((hsh & 0xFFFFu) >= dd.thresh16), m1 = __ballot((hsh >> 16) >= dd.thresh16);
     asm volatile("s_store_dwordx2 %0, %1, %2" ::"s"(m0), "s"(blk), "n"(R * 8) : "memory");
     asm volatile("s_store_dwordx2 %0, %1, %2" ::"s"(m1), "s"(blk), "n"(R * 8 + 8) : "memory");
@@ -360,11 +360,11 @@ __device__ __forceinline__ void drop_select_masks(f32x16& x, KeepMasks& m, float
   keep_masks_wait(m);
   keep_select_rows<0>(x, m, alt);
 }
-__device__ __forceinline__ void drop_block_select(const DropDev& dd, uint32_t rowbase, int key0, int h, f32x16& x, float alt) {
-  const uint32_t base = (rowbase + (uint32_t)(key0 + 4 * h)) >> 1;
+__device__ __forceinline__ void drop_block_select(const DropDev& dd, uint32_t rowhash, int key0, int h, f32x16& x, float alt) {
+  const uint32_t base = pair_base(rowhash, key0, h);
 #pragma unroll
   for (int r = 0; r < 16; r += 2) {
-    const uint32_t hsh = hash_pair32(dd, base + (uint32_t)(ACC_ROW(r) >> 1));
+    const uint32_t hsh = hash_pair32(base + AFM_PAIR_OFF(r));
     x[r] = (hsh & 0xFFFFu) >= dd.thresh16 ? x[r] : alt;
     x[r + 1] = (hsh >> 16) >= dd.thresh16 ? x[r + 1] : alt;
   }

@@ -82,7 +82,7 @@ __global__ __launch_bounds__(256, 2) void k_attn_fwd_x3(AttnM a, const bf16* __r
 #pragma unroll
   for (int i = 0; i < 16; ++i) { o[0][i] = 0.f; o[1][i] = 0.f; }
   float m = -INFINITY, l = 0.f;
-  const uint32_t rowbase = (uint32_t)(((uint64_t)(b * a.H + hd) * a.Tq + qc) * (uint64_t)a.Tk);
+  const uint32_t rowbase = afm_row_hash(a.dd, (uint64_t)(b * a.H + hd) * a.Tq + qc);   // the lane's ROW HASH (two-level dropout stream, afm_common.h)
   issue(0);
   __builtin_assume(ntiles >= 1);
   for (int kt = 0; kt < ntiles; ++kt) {
@@ -225,7 +225,7 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd_dq_x3(AttnM a, const bf16* 
   f32x16 dq[2];
 #pragma unroll
   for (int i = 0; i < 16; ++i) { dq[0][i] = 0.f; dq[1][i] = 0.f; }
-  const uint32_t rowbase = (uint32_t)((uint64_t)lrow * (uint64_t)a.Tk);
+  const uint32_t rowbase = afm_row_hash(a.dd, (uint64_t)lrow);   // the lane's ROW HASH (two-level dropout stream, afm_common.h)
 
   int kend = a.Tk;
   if (a.causal) kend = min(a.Tk, blk_.xb * 128 + 128);
@@ -440,8 +440,8 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd_dkv_x3(AttnM a, const bf16*
         }
       }
     } else if (DROP == DROP_HASH) {   // keep bits as in k_attn_bwd_dkv_mfma: the lanes of a key pair share one hash (DPP exchange)
-      const uint32_t htk = (uint32_t)a.Tk >> 1;
-      const uint32_t tb = (uint32_t)(lbase + qb + 4 * h + (lane & 1)) * htk + ((uint32_t)key >> 1);
+      const uint64_t tb = (uint64_t)(lbase + qb + 4 * h + (lane & 1));
+      const uint32_t po = afm_pair_offset((uint32_t)key >> 1);
       const uint32_t hshift = (lane & 1) << 4;
 #pragma unroll
       for (int g4 = 0; g4 < 4; ++g4) {
@@ -449,7 +449,7 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd_dkv_x3(AttnM a, const bf16*
 #pragma unroll
         for (int j = 0; j < 4; j += 2) {
           const int r = 4 * g4 + j;
-          const uint32_t own = hash_pair32(a.dd, tb + (uint32_t)ACC_ROW(r) * htk);
+          const uint32_t own = afm_pair_mix(afm_row_hash(a.dd, tb + (uint64_t)ACC_ROW(r)) + po);
           const uint32_t oth = (uint32_t)__builtin_amdgcn_mov_dpp((int)own, 0xB1, 0xF, 0xF, true);
           const uint32_t h0 = (lane & 1) ? oth : own, h1 = (lane & 1) ? own : oth;
           const float kp0 = ((h0 >> hshift) & 0xFFFFu) >= a.dd.thresh16 ? a.dd.scale16 : 0.f;

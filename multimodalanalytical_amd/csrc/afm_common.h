@@ -187,18 +187,34 @@ __device__ __forceinline__ bool afm_keep(const DropDev& d, uint64_t idx) {
   uint32_t h = afm_lowbias32((uint32_t)idx ^ d.key ^ ((uint32_t)(idx >> 32) * 0x9E3779B1u));
   return h >= d.thresh;
 }
-// Attention probabilities (B*H*Tq*Tk of them per layer) use 16 random bits per element: one hash
-// serves the element pair (2i, 2i+1), halving the integer work inside the attention kernels.
-__device__ __forceinline__ uint32_t afm_hash_pair(const DropDev& d, uint64_t half_idx) {
-  return afm_lowbias32((uint32_t)half_idx ^ d.key ^ ((uint32_t)(half_idx >> 32) * 0x9E3779B1u));
+// Attention probabilities (B*H*Tq*Tk of them per layer) use 16 random bits per element, and since round 4 a TWO-LEVEL hash: the full
+// mixer runs once per score-matrix ROW (row = (b H + h) Tq + q: in the flash kernels one per lane and kernel), a key PAIR (2i, 2i+1) of
+// that row takes four instructions -- add of a pair stride, 24-bit multiply-add, xor-shift by 16, 24-bit multiply-add -- and hands its
+// low / high 16 bits to the two keys.  (Before: the full eight-instruction mixer per pair, 46 % of the forward kernel's vector work.)
+// Keep rate, serial correlations along keys, rows and diagonals and field uniformity measured equal to the full mixer's
+// (tools/hash_quality.py).  tests/dropmask.py keep_mask16 restates it.
+#define AFM_PAIR_STRIDE 0x9E3779u      // odd, 24 bits: pair index times stride is one v_mul_u32_u24 (Tk / 2 < 2^24)
+__host__ __device__ __forceinline__ uint32_t afm_row_hash(const DropDev& d, uint64_t row) {
+  return afm_lowbias32((uint32_t)row ^ d.key ^ ((uint32_t)(row >> 32) * 0x9E3779B1u));
 }
-__device__ __forceinline__ bool afm_keep16(const DropDev& d, uint64_t idx) {
-  const uint32_t h = afm_hash_pair(d, idx >> 1);
-  return ((idx & 1) ? (h >> 16) : (h & 0xFFFFu)) >= d.thresh16;
+__host__ __device__ __forceinline__ uint32_t afm_pair_mix(uint32_t x) {       // x = row hash + pair index * AFM_PAIR_STRIDE
+  x = afm_mad24(x, 0x7b352dU); x ^= x >> 16;
+  return afm_mad24(x, 0x6ca68bU);
 }
-__device__ __forceinline__ float afm_drop16(const DropDev& d, uint64_t idx, float x) {
+__host__ __device__ __forceinline__ uint32_t afm_pair_offset(uint32_t pair) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __umul24(pair, AFM_PAIR_STRIDE);
+#else
+  return (uint32_t)((uint64_t)(pair & 0xFFFFFFu) * AFM_PAIR_STRIDE);
+#endif
+}
+__device__ __forceinline__ bool afm_keep16(const DropDev& d, uint64_t row, uint32_t key) {
+  const uint32_t h = afm_pair_mix(afm_row_hash(d, row) + afm_pair_offset(key >> 1));
+  return ((key & 1) ? (h >> 16) : (h & 0xFFFFu)) >= d.thresh16;
+}
+__device__ __forceinline__ float afm_drop16(const DropDev& d, uint64_t row, uint32_t key, float x) {
   if (d.thresh16 == 0) return x;
-  return afm_keep16(d, idx) ? x * d.scale16 : 0.f;
+  return afm_keep16(d, row, key) ? x * d.scale16 : 0.f;
 }
 __device__ __forceinline__ float afm_drop(const DropDev& d, uint64_t idx, float x) {
   if (d.thresh == 0) return x;

@@ -37,15 +37,30 @@ def keep_mask(p: float, seed: int, site: int, n: int, start: int = 0) -> np.ndar
     return h >= thresh
 
 
-def keep_mask16(p: float, seed: int, site: int, n: int, start: int = 0):
-    """Attention-probability stream (afm_keep16): 16 random bits per element, one hash per element
-    pair.  Returns (bool[n] keep, scale) with scale = 1/(1 - thresh16/65536)."""
+PAIR_STRIDE = 0x9E3779
+
+
+def _pair_mix(x):
+    """afm_pair_mix of csrc/afm_common.h: the four-instruction per-pair mix of the two-level attention stream."""
+    x = np.asarray(x, dtype=np.uint64) & M32
+    x = _mad24(x, 0x7b352d); x ^= x >> 16
+    return _mad24(x, 0x6ca68b)
+
+
+def keep_mask16(p: float, seed: int, site: int, n: int, tk: int, start_row: int = 0):
+    """Attention-probability stream (afm_keep16, round 4: two-level): 16 random bits per element; the full mixer once per
+    score-matrix row (row = (b H + h) Tq + q), one four-instruction mix per key pair of that row.  `n` elements = n // tk rows
+    of tk keys, row-major.  Returns (bool[n] keep, scale) with scale = 1/(1 - thresh16/65536)."""
     if p <= 0:
         return np.ones(n, dtype=bool), 1.0
+    assert n % tk == 0
     t16 = min(65535, int(p * 65536.0 + 0.5))
-    idx = np.arange(start, start + n, dtype=np.uint64)
-    half = idx >> np.uint64(1)
-    lo, hi = half & M32, half >> 32
-    h = _lowbias32(lo ^ key_of(seed, site) ^ ((hi * 0x9E3779B1) & M32))
-    v = np.where(idx & 1, h >> 16, h & 0xFFFF)
-    return v >= t16, 1.0 / (1.0 - t16 / 65536.0)
+    rows = np.arange(start_row, start_row + n // tk, dtype=np.uint64)
+    lo, hi = rows & M32, rows >> 32
+    H = _lowbias32(lo ^ key_of(seed, site) ^ ((hi * 0x9E3779B1) & M32))[:, None]
+    pair = np.arange((tk + 1) // 2, dtype=np.uint64)[None, :]
+    h = _pair_mix((H + ((pair & 0xFFFFFF) * PAIR_STRIDE & M32)) & M32)
+    keep = np.empty((n // tk, tk), dtype=bool)
+    keep[:, 0::2] = (h & 0xFFFF) >= t16
+    keep[:, 1::2] = ((h >> 16) >= t16)[:, :tk // 2]
+    return keep.reshape(-1), 1.0 / (1.0 - t16 / 65536.0)

@@ -250,7 +250,7 @@ def test_attention_f16(ops, B, H, Tq, Tk, causal, pad, pdrop):
     seed, site = 4242, 3
     keep, dscale = None, 1.0
     if pdrop > 0:
-        km, dscale = keep_mask16(pdrop, seed, site, B * H * Tq * Tk)
+        km, dscale = keep_mask16(pdrop, seed, site, B * H * Tq * Tk, Tk)
         keep = torch.from_numpy(km).view(B, H, Tq, Tk)
     res = {}
     for algo in (1, 2):

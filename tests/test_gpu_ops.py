@@ -204,7 +204,7 @@ def test_attention_all_masked_row_and_dropout(ops):
     ops.attn_fwd(shp, qd, kd, vd, o, lse)
     assert float(o.view(B, Tq, D)[1].abs().max()) == 0.0           # _safe_softmax zeros
     assert torch.isinf(lse.view(B, H, Tq)[1]).all()
-    keep, dscale = keep_mask16(p, seed, site, B * H * Tq * Tk)
+    keep, dscale = keep_mask16(p, seed, site, B * H * Tq * Tk, Tk)
     keep = torch.from_numpy(keep).view(B, H, Tq, Tk)
     assert abs(float(keep.float().mean()) - (1 - p)) < 0.05
     qr, kr, vr = (t.double().transpose(1, 2).requires_grad_(True) for t in (q, k, v))
@@ -445,7 +445,7 @@ def test_attention_mfma(ops, B, H, Tq, Tk, causal, pad, pdrop):
     seed, site = 4242, 3
     keep, dscale = None, 1.0
     if pdrop > 0:
-        km, dscale = keep_mask16(pdrop, seed, site, B * H * Tq * Tk)
+        km, dscale = keep_mask16(pdrop, seed, site, B * H * Tq * Tk, Tk)
         keep = torch.from_numpy(km).view(B, H, Tq, Tk)
     res = {}
     for algo in (1, 2):

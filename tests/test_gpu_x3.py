@@ -197,7 +197,7 @@ def test_attention_x3(ops, B, H, Tq, Tk, causal, pad, pdrop):
     seed, site = 4242, 3
     keep, dscale = None, 1.0
     if pdrop > 0:
-        km, dscale = keep_mask16(pdrop, seed, site, B * H * Tq * Tk)
+        km, dscale = keep_mask16(pdrop, seed, site, B * H * Tq * Tk, Tk)
         keep = torch.from_numpy(km).view(B, H, Tq, Tk)
     o, lse = X2.empty(B * Tq, D, DEV), torch.empty(B * H * Tq, device=DEV)
     shp = ops.attn_shape(B, H, Tq, Tk, dh, X2.dtype, ops._ld(qd), ops._ld(kd), ops._ld(vd), ops._ld(o), kp, causal,

@@ -76,7 +76,7 @@ def test_dropmask_helpers_are_consistent():
     from tests.dropmask import keep_mask, keep_mask16
     k = keep_mask(0.1, 123, 4, 200000)
     assert abs(k.mean() - 0.9) < 0.005
-    k16, scale = keep_mask16(0.1, 123, 4, 200000)
+    k16, scale = keep_mask16(0.1, 123, 4, 200000, 200)
     assert abs(k16.mean() - 0.9) < 0.005 and abs(scale - 1 / 0.9) < 1e-3
     assert keep_mask(0.0, 1, 1, 10).all()
 
