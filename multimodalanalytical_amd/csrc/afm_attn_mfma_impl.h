@@ -168,7 +168,8 @@ __global__ __launch_bounds__(256, AFM_FWD_OCC) void k_attn_fwd_mfma(AttnM a, con
 #pragma unroll
     for (int i = 0; i < 4; ++i) {   // slice i = 2 blk + ks
       if (i < 3) vq[(i + 1) & 1] = tr_issue(va0, va1, 16 * (i + 1));
-      const e16x8 pf = cvt8(s[i >> 1], i & 1);
+      // packed conversions (half an instruction per score) where they fit the 128 registers: with dropout since the two-level hash
+      const e16x8 pf = DROP == DROP_NONE ? cvt8(s[i >> 1], i & 1) : cvt8_pk(s[i >> 1], i & 1);
       if (i < 3) tr_wait<4>(); else tr_wait<0>();
       o[0] = mfma32(tr_join(vq[i & 1].lo0, vq[i & 1].hi0), pf, o[0]);
       o[1] = mfma32(tr_join(vq[i & 1].lo1, vq[i & 1].hi1), pf, o[1]);

@@ -91,8 +91,8 @@ __device__ __forceinline__ e16x8 cvt8(const f32x16& x, int s) {
 }
 // The same as four PACKED conversions (v_cvt_pk_*: half an instruction per score) whatever precedes them.  The empty asm makes the
 // inputs opaque: where a dropout select precedes the conversion hipcc otherwise converts each value alone, selects on the 16-bit
-// result and re-packs (one instruction per score more).  Used by the dK/dV kernel (-2.5 %); in the forward the two extra live
-// registers per pair cost the 128-register build a spill and the time is unchanged, so it keeps cvt8.
+// result and re-packs (one instruction per score more).  Used by the dK/dV kernels (-2.5 %) and, since the two-level dropout hash freed
+// the registers it needs at four waves per SIMD, by the forward.
 __device__ __forceinline__ e16x8 cvt8_pk(const f32x16& x, int s) {
   typedef float f32x2_ __attribute__((ext_vector_type(2)));
   typedef e16 e16x2_ __attribute__((ext_vector_type(2)));
