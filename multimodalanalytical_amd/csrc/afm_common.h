@@ -183,16 +183,12 @@ static inline DropDev afm_make_drop(const afm_dropout* d) {
   r.key = k;
   return r;
 }
-__device__ __forceinline__ bool afm_keep(const DropDev& d, uint64_t idx) {
-  uint32_t h = afm_lowbias32((uint32_t)idx ^ d.key ^ ((uint32_t)(idx >> 32) * 0x9E3779B1u));
-  return h >= d.thresh;
-}
-// Attention probabilities (B*H*Tq*Tk of them per layer) use 16 random bits per element, and since round 4 a TWO-LEVEL hash: the full
-// mixer runs once per score-matrix ROW (row = (b H + h) Tq + q: in the flash kernels one per lane and kernel), a key PAIR (2i, 2i+1) of
-// that row takes four instructions -- add of a pair stride, 24-bit multiply-add, xor-shift by 16, 24-bit multiply-add -- and hands its
-// low / high 16 bits to the two keys.  (Before: the full eight-instruction mixer per pair, 46 % of the forward kernel's vector work.)
-// Keep rate, serial correlations along keys, rows and diagonals and field uniformity measured equal to the full mixer's
-// (tools/hash_quality.py).  tests/dropmask.py keep_mask16 restates it.
+// Two-level hashing (round 4): the full mixer once per GROUP -- a score-matrix row for the attention stream (below), a block of 64
+// consecutive elements for the element-wise stream -- and a four-instruction mix per element PAIR of the group (add of a pair stride,
+// 24-bit multiply-add, xor-shift by 16, 24-bit multiply-add); the pair's two elements take the low / high 16 bits and compare them
+// with thresh16.  Keep rate, serial correlations along and across groups and field uniformity measured equal to the full mixer per
+// pair (tools/hash_quality.py); before, every element (pair, for attention) ran the eight-instruction mixer: 46 % of the attention
+// forward's vector work, a quarter of the FFN-up epilogue's.  tests/dropmask.py restates both streams.
 #define AFM_PAIR_STRIDE 0x9E3779u      // odd, 24 bits: pair index times stride is one v_mul_u32_u24 (Tk / 2 < 2^24)
 __host__ __device__ __forceinline__ uint32_t afm_row_hash(const DropDev& d, uint64_t row) {
   return afm_lowbias32((uint32_t)row ^ d.key ^ ((uint32_t)(row >> 32) * 0x9E3779B1u));
@@ -208,6 +204,26 @@ __host__ __device__ __forceinline__ uint32_t afm_pair_offset(uint32_t pair) {
   return (uint32_t)((uint64_t)(pair & 0xFFFFFFu) * AFM_PAIR_STRIDE);
 #endif
 }
+// Element-wise stream: element idx (row-major in the tensor the mask applies to) belongs to block idx >> 6, pair (idx & 63) >> 1.
+// The keep probability is 1 - thresh16 / 65536 (within 2^-17 of 1 - p); kept values are scaled by 1 / (1 - p) as before.
+__device__ __forceinline__ bool afm_keep(const DropDev& d, uint64_t idx) {
+  const uint32_t h = afm_pair_mix(afm_row_hash(d, idx >> 6) + afm_pair_offset(((uint32_t)idx & 63u) >> 1));
+  return ((idx & 1) ? (h >> 16) : (h & 0xFFFFu)) >= d.thresh16;
+}
+// N = 2, 4 or 8 consecutive elements from idx0 (a multiple of N): ONE block hash and N / 2 pair mixes; out[k] = scale or 0
+template <int N>
+__device__ __forceinline__ void afm_keep_scale(const DropDev& d, uint64_t idx0, float (&out)[N]) {
+  static_assert(N == 2 || N == 4 || N == 8, "whole pairs inside one 64-element block");
+  const uint32_t base = afm_row_hash(d, idx0 >> 6) + afm_pair_offset(((uint32_t)idx0 & 63u) >> 1);
+#pragma unroll
+  for (int j = 0; j < N / 2; ++j) {
+    const uint32_t h = afm_pair_mix(base + (uint32_t)j * AFM_PAIR_STRIDE);
+    out[2 * j] = (h & 0xFFFFu) >= d.thresh16 ? d.scale : 0.f;
+    out[2 * j + 1] = (h >> 16) >= d.thresh16 ? d.scale : 0.f;
+  }
+}
+// Attention probabilities (B*H*Tq*Tk of them per layer): the group is the score-matrix ROW (row = (b H + h) Tq + q: in the flash kernels
+// one full mixer per lane and kernel), the pair (2i, 2i+1) of that row's keys; kept values are scaled by scale16.
 __device__ __forceinline__ bool afm_keep16(const DropDev& d, uint64_t row, uint32_t key) {
   const uint32_t h = afm_pair_mix(afm_row_hash(d, row) + afm_pair_offset(key >> 1));
   return ((key & 1) ? (h >> 16) : (h & 0xFFFFu)) >= d.thresh16;

@@ -291,10 +291,16 @@ __device__ __forceinline__ void epilogue_staged(const MfmaArgs& g, float* stg, c
         float x[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
         const int64_t ci = (int64_t)mrow * g.ldc + n;
         const uint64_t di = (uint64_t)mrow * (uint64_t)g.N + (uint64_t)n;
+        float kp8[8];      // keep * scale of the lane's eight elements (one block hash, four pair mixes), ones without dropout
+        if (g.dd.thresh) afm_keep_scale<8>(g.dd, di, kp8);
+        else {
+#pragma unroll
+          for (int k = 0; k < 8; ++k) kp8[k] = 1.0f;
+        }
         if (g.act == AFM_ACT_GELU_BWD) {
           const e16x8 u = uu[i * 2 + hf];
 #pragma unroll
-          for (int k = 0; k < 8; ++k) x[k] = afm_drop(g.dd, di + k, x[k]) * afm_gelu_grad((float)u[k]);
+          for (int k = 0; k < 8; ++k) x[k] = x[k] * kp8[k] * afm_gelu_grad((float)u[k]);
         } else {
           if (g.pre_act) {
             e16x8 o = {(e16)x[0], (e16)x[1], (e16)x[2], (e16)x[3], (e16)x[4], (e16)x[5], (e16)x[6], (e16)x[7]};
@@ -306,7 +312,7 @@ __device__ __forceinline__ void epilogue_staged(const MfmaArgs& g, float* stg, c
               float y = x[k];
               if (g.act == AFM_ACT_RELU) y = fmaxf(y, 0.f);
               else if (g.act == AFM_ACT_GELU) y = afm_gelu(y);
-              x[k] = afm_drop(g.dd, di + k, y);
+              x[k] = y * kp8[k];
             }
           }
         }
@@ -330,10 +336,16 @@ __device__ __forceinline__ void epilogue_staged(const MfmaArgs& g, float* stg, c
         f32x4 v = *(const f32x4*)(stg + row * STG_LD + c4) + b0;
         const int64_t ci = (int64_t)mrow * g.ldc + n;
         const uint64_t di = (uint64_t)mrow * (uint64_t)g.N + (uint64_t)n;
+        float kp4[4];
+        if (g.dd.thresh) afm_keep_scale<4>(g.dd, di, kp4);
+        else {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) kp4[k] = 1.0f;
+        }
         if (g.act == AFM_ACT_GELU_BWD) {
           const f32x4 u = *(const f32x4*)((const float*)g.pre_act + ci);
 #pragma unroll
-          for (int k = 0; k < 4; ++k) v[k] = afm_drop(g.dd, di + k, v[k]) * afm_gelu_grad(u[k]);
+          for (int k = 0; k < 4; ++k) v[k] = v[k] * kp4[k] * afm_gelu_grad(u[k]);
         } else {
           if (g.pre_act) *(f32x4*)((float*)g.pre_act + ci) = v;
           if (g.act != AFM_ACT_NONE || g.dd.thresh) {
@@ -342,7 +354,7 @@ __device__ __forceinline__ void epilogue_staged(const MfmaArgs& g, float* stg, c
               float y = v[k];
               if (g.act == AFM_ACT_RELU) y = fmaxf(y, 0.f);
               else if (g.act == AFM_ACT_GELU) y = afm_gelu(y);
-              v[k] = afm_drop(g.dd, di + k, y);
+              v[k] = y * kp4[k];
             }
           }
         }
@@ -370,8 +382,14 @@ __device__ __forceinline__ void epilogue_staged(const MfmaArgs& g, float* stg, c
 //   EPI_GLU_BWD           accumulators = dg (f wide): C (2f wide, interleaved) = [dg * saved_a | dg * saved_b]
 enum { EPI_GENERIC = 0, EPI_PLAIN = 1, EPI_DROP = 2, EPI_GELU = 3, EPI_GELU_BWD = 4, EPI_GELU_SG = 5, EPI_MUL = 6,
        EPI_GLU = 7, EPI_GLU_SG = 8, EPI_GLU_BWD = 9 };
-__device__ __forceinline__ float afm_drop32(const DropDev& d, uint32_t idx, float x) {
-  return afm_lowbias32(idx ^ d.key) >= d.thresh ? x * d.scale : 0.f;
+// keep * scale of N consecutive elements from idx0 (a multiple of N; index below 2^32), or all ones where the site does not drop
+template <int N, bool DROP_ON>
+__device__ __forceinline__ void afm_keep_scale32(const DropDev& d, uint32_t idx0, float (&out)[N]) {
+  if constexpr (DROP_ON) afm_keep_scale<N>(d, (uint64_t)idx0, out);
+  else {
+#pragma unroll
+    for (int k = 0; k < N; ++k) out[k] = 1.0f;
+  }
 }
 // DROP_ON is the wave-uniform "this site drops" bit as a template argument: tested per element (`drop_on ? hash : 1`) it compiled
 // to a scalar branch around every element's hash chain, 128 basic blocks per wave tile that nothing could be scheduled across.
@@ -439,12 +457,13 @@ __device__ __forceinline__ void epilogue_staged_e16(const MfmaArgs& g, float* st
         const int64_t rowi = mw + r8 + q * 8;
         const int hcol = n >> 1;
         const uint32_t dg0 = (uint32_t)rowi * (uint32_t)(g.N >> 1) + (uint32_t)hcol;
-        float gv[4], sa[4], sb[4];
+        float gv[4], sa[4], sb[4], kp[4];
+        afm_keep_scale32<4, drop_on>(g.dd, dg0, kp);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
           float y, yp;
           afm_gelu_both(x[k], y, yp);
-          const float keep = drop_on ? afm_drop32(g.dd, dg0 + k, 1.0f) : 1.0f;
+          const float keep = kp[k];
           gv[k] = y * x[4 + k] * keep; sa[k] = yp * x[4 + k] * keep; sb[k] = y * keep;
         }
         e16x4 o = {(e16)gv[0], (e16)gv[1], (e16)gv[2], (e16)gv[3]};
@@ -481,13 +500,13 @@ __device__ __forceinline__ void epilogue_staged_e16(const MfmaArgs& g, float* st
         for (int k = 0; k < 8; ++k) x[k] = afm_gelu(x[k]);
       }
       if (EPI == EPI_GELU_SG) {
-        float gp[8];
+        float gp[8], kp[8];
+        afm_keep_scale32<8, drop_on>(g.dd, di, kp);
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
           float y, yp;
           afm_gelu_both(x[k], y, yp);
-          const float keep = drop_on ? afm_drop32(g.dd, di + k, 1.0f) : 1.0f;
-          x[k] = y * keep; gp[k] = yp * keep;
+          x[k] = y * kp[k]; gp[k] = yp * kp[k];
         }
         e16x8 o = {(e16)gp[0], (e16)gp[1], (e16)gp[2], (e16)gp[3], (e16)gp[4], (e16)gp[5], (e16)gp[6], (e16)gp[7]};
         store16_policy<CAUX>(g.pre_act, (uint64_t)((pbase + ro - (e16*)g.pre_act) * 2), __builtin_bit_cast(uint4, o));
@@ -502,15 +521,19 @@ __device__ __forceinline__ void epilogue_staged_e16(const MfmaArgs& g, float* st
         const e16x8 u = uu[q];
         if (q + PF < 2 * WM) uu[q + PF < 2 * WM ? q + PF : 0] = *(const e16x8*)(pbase + (int64_t)((q + PF) * 8) * g.ldc);
         if (drop_on) {
+          float kp[8];
+          afm_keep_scale32<8, true>(g.dd, di, kp);
 #pragma unroll
-          for (int k = 0; k < 8; ++k) x[k] = afm_drop32(g.dd, di + k, x[k]) * afm_gelu_grad((float)u[k]);
+          for (int k = 0; k < 8; ++k) x[k] = x[k] * kp[k] * afm_gelu_grad((float)u[k]);
         } else {
 #pragma unroll
           for (int k = 0; k < 8; ++k) x[k] *= afm_gelu_grad((float)u[k]);
         }
       } else if ((EPI == EPI_DROP || EPI == EPI_GELU) && drop_on) {
+        float kp[8];
+        afm_keep_scale32<8, true>(g.dd, di, kp);
 #pragma unroll
-        for (int k = 0; k < 8; ++k) x[k] = afm_drop32(g.dd, di + k, x[k]);
+        for (int k = 0; k < 8; ++k) x[k] *= kp[k];
       }
       e16x8 o = {(e16)x[0], (e16)x[1], (e16)x[2], (e16)x[3], (e16)x[4], (e16)x[5], (e16)x[6], (e16)x[7]};
       store16_policy<CAUX>(g.C, (uint64_t)((cbase + ro - (e16*)g.C) * 2), __builtin_bit_cast(uint4, o));

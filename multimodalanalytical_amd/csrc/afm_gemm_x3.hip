@@ -40,8 +40,15 @@ enum { X3_F32 = 0, X3_X2 = 2 };
 enum { XE_GENERIC = 0, XE_PLAIN = 1, XE_GELU = 3, XE_GELU_BWD = 4, XE_GELU_SG = 5, XE_MUL = 6, XE_GLU = 7, XE_GLU_SG = 8, XE_GLU_BWD = 9 };
 __device__ __forceinline__ int x3_glu_deint(int n, int f) { return ((n >> 3) << 2) + (n & 3) + ((n >> 2) & 1) * f; }
 
-__device__ __forceinline__ float x3_drop32(const DropDev& d, uint32_t idx, float x) {
-  return afm_lowbias32(idx ^ d.key) >= d.thresh ? x * d.scale : 0.f;
+// keep * scale of N consecutive elements from idx0 (a multiple of N): the element-wise stream of afm_common.h (one block hash, N / 2 pair
+// mixes); ones where the site does not drop
+template <int N>
+__device__ __forceinline__ void x3_keep_scale(const DropDev& d, bool drop_on, uint32_t idx0, float (&out)[N]) {
+  if (drop_on) afm_keep_scale<N>(d, (uint64_t)idx0, out);
+  else {
+#pragma unroll
+    for (int k = 0; k < N; ++k) out[k] = 1.0f;
+  }
 }
 
 // ------------------------------------------------------------------------------------------ fragment epilogue
@@ -128,12 +135,13 @@ __device__ __forceinline__ void x3_epilogue_staged(const X3Args& g, float* stg, 
           const int64_t rowi = mw + r8 + q * 8;
           const int hcol = n >> 1;
           const uint32_t dg0 = (uint32_t)rowi * (uint32_t)(g.N >> 1) + (uint32_t)hcol;
-          float gv[4], sv[8];
+          float gv[4], sv[8], kp[4];
+          x3_keep_scale<4>(g.dd, drop_on, dg0, kp);
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
             float y, yp;
             afm_gelu_both(x[k], y, yp);
-            const float keep = drop_on ? x3_drop32(g.dd, dg0 + k, 1.0f) : 1.0f;
+            const float keep = kp[k];
             gv[k] = y * x[4 + k] * keep; sv[k] = yp * x[4 + k] * keep; sv[4 + k] = y * keep;
           }
           bf16 h0, l0, h1, l1, h2, l2, h3, l3;
@@ -186,18 +194,20 @@ __device__ __forceinline__ void x3_epilogue_staged(const X3Args& g, float* stg, 
 #pragma unroll
           for (int k = 0; k < 8; ++k) x[k] = afm_gelu(x[k]);
           if (drop_on) {
+            float kp[8];
+            x3_keep_scale<8>(g.dd, true, di, kp);
 #pragma unroll
-            for (int k = 0; k < 8; ++k) x[k] = x3_drop32(g.dd, di + k, x[k]);
+            for (int k = 0; k < 8; ++k) x[k] *= kp[k];
           }
         }
         if (EPI == XE_GELU_SG) {
-          float gp[8];
+          float gp[8], kp[8];
+          x3_keep_scale<8>(g.dd, drop_on, di, kp);
 #pragma unroll
           for (int k = 0; k < 8; ++k) {
             float y, yp;
             afm_gelu_both(x[k], y, yp);
-            const float keep = drop_on ? x3_drop32(g.dd, di + k, 1.0f) : 1.0f;
-            x[k] = y * keep; gp[k] = yp * keep;
+            x[k] = y * kp[k]; gp[k] = yp * kp[k];
           }
           if (g.sg_hi_only) {
             *(bf16x8*)(pbase + ro) = (bf16x8){(bf16)gp[0], (bf16)gp[1], (bf16)gp[2], (bf16)gp[3], (bf16)gp[4], (bf16)gp[5], (bf16)gp[6], (bf16)gp[7]};
@@ -209,11 +219,13 @@ __device__ __forceinline__ void x3_epilogue_staged(const X3Args& g, float* stg, 
         }
         if (EPI == XE_MUL || EPI == XE_GELU_BWD) {
           const bf16x8 uh = *(const bf16x8*)(pbase + ro), ul = *(const bf16x8*)(pbase + ro + lo);
+          float kp[8];
+          x3_keep_scale<8>(g.dd, drop_on && EPI == XE_GELU_BWD, di, kp);
 #pragma unroll
           for (int k = 0; k < 8; ++k) {
             const float u = (float)uh[k] + (float)ul[k];
             if (EPI == XE_MUL) x[k] *= u;
-            else x[k] = (drop_on ? x3_drop32(g.dd, di + k, x[k]) : x[k]) * afm_gelu_grad(u);
+            else x[k] = x[k] * kp[k] * afm_gelu_grad(u);
           }
         }
         bf16x8 h, l;

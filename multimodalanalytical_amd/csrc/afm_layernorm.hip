@@ -173,8 +173,10 @@ __global__ __launch_bounds__(256) void k_ln_fwd_vec(const float* x, const float*
           F8 a = ca[i];
           if (adrop.thresh) {   // wave-uniform: dropout of the residual branch, index row-major in `add`
             const uint64_t base = (uint64_t)r * (uint64_t)d + (uint64_t)c;
+            float kp[8];      // (one block hash and four pair mixes for the lane's eight elements)
+            afm_keep_scale<8>(adrop, base, kp);
 #pragma unroll
-            for (int k = 0; k < 4; ++k) { a.lo[k] = afm_drop(adrop, base + k, a.lo[k]); a.hi[k] = afm_drop(adrop, base + 4 + k, a.hi[k]); }
+            for (int k = 0; k < 4; ++k) { a.lo[k] *= kp[k]; a.hi[k] *= kp[4 + k]; }
           }
           v[i].lo += a.lo; v[i].hi += a.hi;
           st8s(x_sum + r * (int64_t)d + c, v[i]);
@@ -303,8 +305,14 @@ __global__ __launch_bounds__(256) void k_ln_bwd_vec(const TY* __restrict__ dy, c
         if (dx_drop) {
           const uint64_t base = (uint64_t)r * (uint64_t)d + (uint64_t)c;
           F8 od;
+          float kpd[8];
+          if (dd.thresh) afm_keep_scale<8>(dd, base, kpd);
+          else {
 #pragma unroll
-          for (int k = 0; k < 4; ++k) { od.lo[k] = afm_drop(dd, base + k, o.lo[k]); od.hi[k] = afm_drop(dd, base + 4 + k, o.hi[k]); }
+            for (int k = 0; k < 8; ++k) kpd[k] = 1.0f;
+          }
+#pragma unroll
+          for (int k = 0; k < 4; ++k) { od.lo[k] = o.lo[k] * kpd[k]; od.hi[k] = o.hi[k] * kpd[4 + k]; }
           st8(dx_drop + r * (int64_t)(d * RowMul<TY>::v) + c, od, d);
         }
       }

@@ -26,15 +26,19 @@ def key_of(seed: int, site: int) -> int:
 
 
 def keep_mask(p: float, seed: int, site: int, n: int, start: int = 0) -> np.ndarray:
-    """bool[n]: keep(i) for element indices start .. start+n-1."""
+    """bool[n]: keep(i) for element indices start .. start+n-1 (afm_keep, round 4: two-level -- the full mixer once per block of 64
+    consecutive elements, a four-instruction mix per element pair of the block, 16 bits per element against thresh16; kept values
+    are still scaled by 1 / (1 - p))."""
     if p <= 0:
         return np.ones(n, dtype=bool)
-    t = p * 4294967296.0
-    thresh = M32 if t >= 4294967295.0 else int(t)
+    t16 = min(65535, int(p * 65536.0 + 0.5))
     idx = np.arange(start, start + n, dtype=np.uint64)
-    lo, hi = idx & M32, idx >> 32
-    h = _lowbias32(lo ^ key_of(seed, site) ^ ((hi * 0x9E3779B1) & M32))
-    return h >= thresh
+    blk = idx >> np.uint64(6)
+    lo, hi = blk & M32, blk >> 32
+    H = _lowbias32(lo ^ key_of(seed, site) ^ ((hi * 0x9E3779B1) & M32))
+    pair = (idx & np.uint64(63)) >> np.uint64(1)
+    h = _pair_mix((H + pair * PAIR_STRIDE) & M32)
+    return np.where(idx & np.uint64(1), h >> 16, h & 0xFFFF) >= t16
 
 
 PAIR_STRIDE = 0x9E3779
