@@ -401,6 +401,7 @@ __device__ __forceinline__ void afm_keep_scale32(const DropDev& d, uint32_t idx0
 #ifndef AFM_C_STORE_AUX
 #define AFM_C_STORE_AUX 2
 #endif
+
 // 16-byte store of an output piece with a cache policy (aux: 0 plain, 2 nt, 16 sc1 = written through and dropped from the XCD's L2,
 // MI355X_MICROARCH.md "stores of each flavour"): the output stream of a GEMM is never read again by this kernel, and left in the
 // write-back L2 it evicts the weight tile and the A panels the other column tiles of the row are about to re-read.
@@ -619,7 +620,8 @@ __global__ __launch_bounds__(64 * NWM * NWN) void k_gemm_nt_pring(MfmaArgs g) {
   const int w = __builtin_amdgcn_readfirstlane(t >> 6);
   const int wm = w / NWN, wn = w % NWN;
   const int ntiles = g.tiles_m * g.tiles_n;
-  if (g.bias_in_lds) {   // plain loads, retired (barrier) before the first LDS-DMA piece is issued
+  constexpr bool GLU_EPI = EPI == EPI_GLU || EPI == EPI_GLU_SG || EPI == EPI_GLU_BWD;   // these read the bias from global memory
+  if (g.bias_in_lds && !GLU_EPI) {   // plain loads, retired (barrier) before the first LDS-DMA piece is issued
     for (int n = t; n < g.N; n += 64 * NW) bias_lds[n] = g.bias ? g.bias[n] : 0.f;
     __syncthreads();
   }
@@ -628,7 +630,7 @@ __global__ __launch_bounds__(64 * NWM * NWN) void k_gemm_nt_pring(MfmaArgs g) {
   const int tpx = (ntiles + 7) >> 3;
   const int tlo = xcd * tpx, thi = min(ntiles, tlo + tpx);
   int* const tlist = (int*)(lds + g.live_off);
-  if (g.live_off) nt_tile_lists<TBM, TBN, C_BF16, 64 * NW>(g, tlist, tlo, thi, nbx, bx);
+  if (g.live_off) nt_tile_lists<TBM, TBN, C_BF16, 64 * NW, (EPI == EPI_GLU_BWD ? 2 : 1)>(g, tlist, tlo, thi, nbx, bx);
   auto tile_of = [&](int it) {
     if (g.live_off) return it < tlist[0] ? tlist[1 + it] : -1;
     const int tt = tlo + it * nbx + bx;
@@ -773,8 +775,9 @@ static int launch_nt_pring(MfmaArgs& g, hipStream_t st, int blocks_per_cu) {
   const int bias_bytes = ((g.N * 4 + 15) / 16) * 16;
   const bool rows16 = (g.N % 8) == 0 && (g.ldc % 8) == 0;
   const bool modes_ok = C_BF16 ? (!g.residual && !g.accumulate) : true;
-  g.bias_in_lds = rows16 && modes_ok && ring * blocks_per_cu + bias_bytes * blocks_per_cu <= 160 * 1024 ? 1 : 0;
-  int shm = ring + (g.bias_in_lds ? bias_bytes : 0);
+  constexpr bool GLU_EPI = EPI == EPI_GLU || EPI == EPI_GLU_SG || EPI == EPI_GLU_BWD;
+  g.bias_in_lds = rows16 && modes_ok && (GLU_EPI || ring * blocks_per_cu + bias_bytes * blocks_per_cu <= 160 * 1024) ? 1 : 0;
+  int shm = ring + (g.bias_in_lds && !GLU_EPI ? bias_bytes : 0);
   g.live_off = 0;
   if (g.k_live && TBM % 64 == 0 && (g.M % TBM) == 0 && blocks_per_cu == 1 && shm + NT_LIVE_BYTES <= 160 * 1024) {
     int grid0 = 256;
@@ -1571,7 +1574,17 @@ int AFM_E16_FN(afm_gemm_mfma_try)(const afm_gemm_desc* d, hipStream_t st) {
           (d->act == AFM_ACT_GLU_BWD && (d->bias || d->drop.p > 0.f)))
         return AFM_ERR_UNSUPPORTED;
       int r;
-      if (d->act == AFM_ACT_GLU) r = launch_nt_ws<true, 4, 0, EPI_GLU>(g, st);
+      // 256 x 256 tiles (the round-3 persistent kernel) for the FORWARD forms where there are >= 1 024 of them, as for the other
+      // fused epilogues: bit-identical, 1.545 -> 1.468 ms at the c4 shape (f 3072, d 768), 0.797 -> 0.745 at c5's; the backward
+      // form is 2 .. 3 % slower there (1.033 vs 1.010) and stays on 256 x 128.  reserved = 24 / 28 force one form (A / B tests).
+      const bool big = !(d->N & 255) && (int64_t)(d->M >> 8) * (d->N >> 8) >= 1024;
+      const bool use28 = variant == 28 || (variant == 0 && big && d->act != AFM_ACT_GLU_BWD);
+      if (use28 && big) {
+        if (d->act == AFM_ACT_GLU) r = launch_nt_pring<true, 2, 4, 2, 0, 8, EPI_GLU, false>(g, st, 1);
+        else if (d->act == AFM_ACT_GLU_SAVE) r = launch_nt_pring<true, 2, 4, 2, 0, 8, EPI_GLU_SG, false>(g, st, 1);
+        else r = launch_nt_pring<true, 2, 4, 2, 0, 8, EPI_GLU_BWD, false>(g, st, 1);
+      }
+      else if (d->act == AFM_ACT_GLU) r = launch_nt_ws<true, 4, 0, EPI_GLU>(g, st);
       else if (d->act == AFM_ACT_GLU_SAVE) r = launch_nt_ws<true, 4, 0, EPI_GLU_SG>(g, st);
       else r = launch_nt_ws<true, 4, 0, EPI_GLU_BWD>(g, st);
       if (r != AFM_OK) return r;

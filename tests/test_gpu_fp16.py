@@ -136,6 +136,33 @@ def test_gemm_f16_glu_fused(ops):
     close(g, O.gelu(u) * v, rtol=3e-3, atol=4e-3)
 
 
+def test_gemm_f16_glu_fused_tile_forms_agree(ops):
+    """The gated-FFN epilogues on the 256 x 256 persistent kernel (the default for the forward forms over >= 1 024 such tiles;
+    afm_gemm_desc.reserved = 28 forces it) write what the 256 x 128 loader-wave kernel (reserved = 24) writes, bit for bit: up-projection
+    with GELU pair + dropout + the two stored factors, the same without stored factors, and the data gradient x stored."""
+    M, f, d = 16384, 2048, 256          # 64 x 16 = 1 024 tiles of 256 x 256 over the 2f-wide accumulators
+    h = dev(rnd(M, d, seed=1), H16)
+    w_il, wt_il = torch.empty(2 * f, d, dtype=H16, device=DEV), torch.empty(d, 2 * f, dtype=H16, device=DEV)
+    ops.cast_weights(dev(rnd(2 * f, d, seed=2) * 0.1), w_il, wt_il, glu_rows=f)
+    bias = dev(rnd(2 * f, seed=4) * 0.1)
+    w2t = dev(rnd(f, d, seed=5) * 0.1, H16)
+    dy = dev(rnd(M, d, seed=6) * 0.01, H16)
+    dr = ops.drop(0.1, 7, 3)
+    out = {}
+    for v in (24, 28, 0):
+        g = torch.full((M, f), float("nan"), dtype=H16, device=DEV); uv = torch.full((M, 2 * f), float("nan"), dtype=H16, device=DEV)
+        ops.gemm(h, w_il, g, bias=bias, act=7, pre_act=uv, glu_rows=f, dropout=dr, variant=v)
+        assert "glu" in ops.last_algo()
+        g2 = torch.full_like(g, float("nan"))
+        ops.gemm(h, w_il, g2, bias=bias, act=6, glu_rows=f, dropout=dr, variant=v)
+        duv = torch.full((M, 2 * f), float("nan"), dtype=H16, device=DEV)
+        ops.gemm(dy, w2t, duv, act=8, pre_act=uv, glu_rows=f, variant=v)
+        out[v] = (g, uv, g2, duv)
+    for v in (28, 0):
+        for a, b in zip(out[24], out[v]):
+            assert bool(torch.isfinite(b.float()).all()) and torch.equal(a, b), v
+
+
 @pytest.mark.parametrize("R,M,N", [(512, 128, 128), (4096, 1536, 512), (777, 24, 64), (16384, 520, 200), (131072, 512, 256)])
 def test_gemm_f16_tn_wgrad(ops, R, M, N):
     dy, x = (rnd(R, M, seed=1) * 0.5).half(), rnd(R, N, seed=2).half()
