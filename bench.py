@@ -556,10 +556,20 @@ def main():
             out["roofline_kernels"] = ks[1:]
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(main_run["model"], wl, args.workload, args.cpu_batch, args.cpu_steps, args.cpu_threads)
-        print(json.dumps(out), flush=True)
+    # RCCL writes its version banner through C stdio, which holds it (stdout is a pipe) until the process exits -- behind the JSON
+    # line.  Every rank flushes its C buffers BEFORE the last barrier, rank 0 prints after it: the JSON line is the last line of the
+    # job's stdout, whatever the launcher.
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except OSError:
+        pass
+    sys.stdout.flush()
     if ddp:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":
