@@ -1,7 +1,11 @@
 #!/usr/bin/env python3
 """Headline benchmark: train samples/sec of the spectra->SMILES path on N MI355X.
 
-    python bench.py --gpus 1 --steps K --warmup W            # N > 1: launched by torch.distributed.run
+    python bench.py --gpus N --steps K --warmup W
+
+N > 1 (or --force-ddp) without a launcher environment: bench.py starts `python -m torch.distributed.run --nproc-per-node N bench.py ...`
+itself as a CHILD process before anything touches the GPU, relays the job's one JSON line and exits with its status; under
+torch.distributed.run (RANK set) it is one rank of the job.  WORLD_SIZE != --gpus is an error in every case.
 
 A "step" is one optimiser step of the reference's training configuration: acc_batches (4) micro-batches of
 `batch` (128) samples each through HFWrapper.training_step (forward + backward, dropout 0.1 active), then
@@ -440,13 +444,69 @@ def timed_run(workload, mode, steps, warmup, rank, world, dev, args, keep=False,
     return res
 
 
+def launch_plan(gpus, force_ddp, env, argv, visible_gpus=None):
+    """What this process is (reference trainer/trainer.py:58-71, cli/training.py:47-58: Lightning starts the
+    ranks itself).  Pure: decides from --gpus, the launcher environment and the device count, touches nothing.
+      ("rank", rank, world, local)   one rank of a job (RANK set by torch.distributed.run), or the lone process of a 1-GPU run
+      ("spawn", argv)                no launcher environment and more than one rank wanted (or --force-ddp): the command of the child job
+      ("error", message)             WORLD_SIZE != --gpus (always an error: a 1-rank run must never report itself as N GPUs), bad counts"""
+    if gpus < 1:
+        return ("error", f"--gpus {gpus}")
+    if "RANK" in env:
+        world = int(env.get("WORLD_SIZE", "1"))
+        if world != gpus:
+            return ("error", f"--gpus {gpus} but WORLD_SIZE={world}")
+        rank, local = int(env["RANK"]), int(env.get("LOCAL_RANK", env["RANK"]))
+        if not (0 <= rank < world):
+            return ("error", f"RANK={rank} outside WORLD_SIZE={world}")
+        return ("rank", rank, world, local)
+    if "WORLD_SIZE" in env and int(env["WORLD_SIZE"]) != gpus:
+        return ("error", f"--gpus {gpus} but WORLD_SIZE={env['WORLD_SIZE']} (and no RANK)")
+    if gpus == 1 and not force_ddp:
+        return ("rank", 0, 1, 0)
+    if visible_gpus is not None and visible_gpus < gpus:
+        return ("error", f"--gpus {gpus} but {visible_gpus} device(s) visible")
+    import socket
+    with socket.socket() as sk:                     # a free rendezvous port on the loopback interface
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    return ("spawn", [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}",
+                      "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv))
+
+
+def spawn_job(cmd):
+    """Run the N-rank job as a child process (never exec: this process may not be replaced once a GPU runtime is loaded, and must not
+    touch the GPU before the children do), relay its stderr as it comes and its LAST JSON line on stdout, return its exit status."""
+    import subprocess
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    p = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True)
+    line = None
+    for ln in p.stdout:
+        t = ln.strip()
+        if t.startswith("{") and t.endswith("}"):
+            try:
+                json.loads(t)
+                line = t
+                continue
+            except ValueError:
+                pass
+        sys.stderr.write(ln)                         # banners of the launcher / RCCL: not part of the contract line
+    rc = p.wait()
+    if line is not None:
+        print(line, flush=True)
+    elif rc == 0:
+        rc = 3                                       # a job that printed no JSON line did not measure anything
+    return rc
+
+
 def main():
     args = parse()
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    plan = launch_plan(args.gpus, args.force_ddp, os.environ, sys.argv[1:], torch.cuda.device_count())   # (device_count does not initialise the GPU)
+    if plan[0] == "error":
+        raise SystemExit("bench.py: " + plan[1])
+    if plan[0] == "spawn":
+        raise SystemExit(spawn_job(plan[1]))
+    _, rank, world, local = plan
     import torch.distributed as dist
     torch.cuda.set_device(local)
     dev = f"cuda:{local}"
@@ -514,7 +574,7 @@ def main():
 
     out = {
         "metric": METRIC, "value": round(value, 3), "unit": "samples/s",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(main_run["dt"] / args.steps * 1e3, 3),
+        "n_gpus": main_run.get("rccl_ranks") or world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(main_run["dt"] / args.steps * 1e3, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": f"{args.workload}: {wl['cfg']['encoder_layers']}L d{wl['cfg']['d_model']} "
                                f"f{wl['cfg']['encoder_ffn_dim']} enc_len {S} dec_len {wl['T']} "

@@ -38,7 +38,13 @@
 extern "C" {
 #endif
 
-#define AFM_ABI_VERSION 4
+/* ABI history (a binding compares afm_abi_version() AND afm_struct_size(i) with its own):
+ *   4  afm_gemm_desc.k_live, afm_ln_shape.row_live (padded-row hints)
+ *   5  exports added since 4: afm_cast_weights_batch, afm_comm_count, afm_struct_size(6) = afm_cast_item; afm_layernorm_bwd's
+ *      workspace contract (afm_layernorm_bwd_ws); BOTH dropout streams redefined (two-level hashing: one full mixer per score-matrix
+ *      row / per block of 64 elements, a pair mix per element pair) -- a library older than 5 produces different masks for the same
+ *      (seed, site, index), so checkpoints' dropout positions and tests/dropmask.py belong to version >= 5. */
+#define AFM_ABI_VERSION 5
 
 enum { AFM_OK = 0, AFM_ERR_ARG = -1, AFM_ERR_UNSUPPORTED = -2, AFM_ERR_LAUNCH = -3 };
 enum { AFM_F32 = 0, AFM_BF16 = 1, AFM_BF16X2 = 2, AFM_F16 = 3 };

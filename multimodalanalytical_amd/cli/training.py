@@ -168,14 +168,24 @@ class MixtureLoader:
         yield from interleave_rounds(self.gens)
 
     def epoch(self, epoch: int):     # noqa: ARG002 (the reference's generator reseeds: every epoch is the same stream)
-        pend = None
+        """Batches of one pass over the stream.  Training drops the trailing partial batch (the reference's train DataLoader,
+        data/datamodules.py: drop_last=True); validation / test yield it as a final short batch -- the reference evaluates every
+        record (ShardLoader does the same) -- and a split that yields nothing at all is an error here, not a NaN monitor score later."""
+        pend, n = None, 0
         for r in self.records():
             r = {k: v for k, v in r.items() if k in ("IR", "compound", "IR_target")}
             pend = r if pend is None else {k: torch.cat([pend[k], r[k]]) for k in r}
             while pend["compound"].shape[0] >= self.bs:
                 cut = {k: v[:self.bs] for k, v in pend.items()}
                 pend = {k: v[self.bs:] for k, v in pend.items()}
+                n += 1
                 yield self._collate(cut)
+        if self.key != "train" and pend is not None and pend["compound"].shape[0] > 0:
+            n += 1
+            yield self._collate(pend)
+        if n == 0:
+            raise RuntimeError(f"mixture split '{self.key}' produced no batch (nominal {self.nominal} samples over {self.world} rank(s), "
+                               f"batch size {self.bs}): the table is too small for this mixture configuration")
 
     def _collate(self, rec):
         comp = rec["compound"]

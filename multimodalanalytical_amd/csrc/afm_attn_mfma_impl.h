@@ -50,7 +50,7 @@ __global__ __launch_bounds__(256, AFM_FWD_OCC) void k_attn_fwd_mfma(AttnM a, con
     const e16* qp = Q + ((int64_t)b * a.Tq + qc) * a.ldq + hd * DH + 8 * h;
 #pragma unroll
     for (int s = 0; s < 4; ++s) {     // pre-multiplied by scale * log2(e): S^T comes out of the MFMA chain in log2 units (round 3)
-      const e16x8 x = *(const e16x8*)(qp + 16 * s);
+      const e16x8 x = ld8_once(qp + 16 * s);
 #pragma unroll
       for (int j = 0; j < 8; ++j) qf[s][j] = (e16)((float)x[j] * a.scale_log2);
     }
@@ -233,7 +233,7 @@ __global__ __launch_bounds__(512, 2) void k_attn_fwd_st(AttnM a, const e16* __re
     const e16* qp = Q + ((int64_t)b * a.Tq + qc) * a.ldq + hd * DH + 8 * h;
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-      const e16x8 x = *(const e16x8*)(qp + 16 * s);
+      const e16x8 x = ld8_once(qp + 16 * s);
 #pragma unroll
       for (int j = 0; j < 8; ++j) qf[s][j] = (e16)((float)x[j] * a.scale_log2);
     }
@@ -432,9 +432,9 @@ __global__ __launch_bounds__(256, 3) void k_attn_bwd_dq_mfma(AttnM a, const e16*
     const e16* op = O + ((int64_t)b * a.Tq + qc) * a.ldo + hd * DH + 8 * h;
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-      qf[s] = *(const e16x8*)(qp + 16 * s);
-      dof[s] = *(const e16x8*)(dop + 16 * s);
-      const e16x8 ov = *(const e16x8*)(op + 16 * s);
+      qf[s] = ld8_once(qp + 16 * s);
+      dof[s] = ld8_once(dop + 16 * s);
+      const e16x8 ov = ld8_once(op + 16 * s);
 #pragma unroll
       for (int j = 0; j < 8; ++j) dl += (float)dof[s][j] * (float)ov[j];
     }
@@ -606,9 +606,9 @@ __global__ __launch_bounds__(512, 2) void k_attn_bwd_dq_st(AttnM a, const e16* _
     const e16* op = O + ((int64_t)b * a.Tq + qc) * a.ldo + hd * DH + 8 * h;
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-      qf[s] = *(const e16x8*)(qp + 16 * s);
-      dof[s] = *(const e16x8*)(dop + 16 * s);
-      const e16x8 ov = *(const e16x8*)(op + 16 * s);
+      qf[s] = ld8_once(qp + 16 * s);
+      dof[s] = ld8_once(dop + 16 * s);
+      const e16x8 ov = ld8_once(op + 16 * s);
 #pragma unroll
       for (int j = 0; j < 8; ++j) dl += (float)dof[s][j] * (float)ov[j];
     }
@@ -800,7 +800,7 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd_dkv_mfma(AttnM a, const e16
     const e16* kp = K + ((int64_t)b * a.Tk + kc) * a.ldk + hd * DH + 8 * h;
     const e16* vp = V + ((int64_t)b * a.Tk + kc) * a.ldv + hd * DH + 8 * h;
 #pragma unroll
-    for (int s = 0; s < 4; ++s) { kf[s] = *(const e16x8*)(kp + 16 * s); vf[s] = *(const e16x8*)(vp + 16 * s); }
+    for (int s = 0; s < 4; ++s) { kf[s] = ld8_once(kp + 16 * s); vf[s] = ld8_once(vp + 16 * s); }
     // round 3: K pre-multiplied by scale * log2(e) (S comes out in log2 units, -lse[q] is the chain's initial value: p = exp2(S')
     // is one instruction), V by the dropout scale (dP' = scale * dP with -delta[q] as initial value: dS = p * (keep ? acc : -delta));
     // dV accumulates the UNSCALED dropped probabilities and takes the dropout scale once at the end

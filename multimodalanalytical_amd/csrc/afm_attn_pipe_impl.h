@@ -54,7 +54,7 @@ typedef uint32_t u32x4_ __attribute__((ext_vector_type(4)));
 #define AFM_DKV_PIPE_OCC 2
 #endif
 // AFM_PIPE_ABL (template parameter ABL; an AFM_ATTN_ABLATIONS build instantiates the list in afm_attn_mfma_impl.h and
-// afm_attn_shape.reserved bits 8-15 pick one): timing ablations with wrong results -- 1 no MFMAs, 2 no arithmetic, 4 no slot reads,
+// afm_attn_shape.reserved bits 12-19 pick one; bits 8 and 9 are the live selectors of the 8-wave / 64-key forms): timing ablations with wrong results -- 1 no MFMAs, 2 no arithmetic, 4 no slot reads,
 // 8 no barrier, 16 no preamble reads, 32 no LDS-DMA after the prologue, 64 no waits for the slot reads.
 template <int DROP, int NW, int KB = 1, int AFM_PIPE_ABL = 0>
 __global__ __launch_bounds__(64 * NW, (NW == 4 && KB == 1) ? 2 : 1) void k_attn_bwd_dkv_pipe(AttnM a, const e16* __restrict__ Q, const e16* __restrict__ K,
@@ -88,7 +88,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && KB == 1) ? 2 : 1) void k_attn_
     const e16* kp = K + ((int64_t)b * a.Tk + kc) * a.ldk + hd * DH + 8 * h;
     const e16* vp = V + ((int64_t)b * a.Tk + kc) * a.ldv + hd * DH + 8 * h;
 #pragma unroll
-    for (int s = 0; s < 4; ++s) { kf[kb][s] = *(const e16x8*)(kp + 16 * s); vf[kb][s] = *(const e16x8*)(vp + 16 * s); }
+    for (int s = 0; s < 4; ++s) { kf[kb][s] = ld8_once(kp + 16 * s); vf[kb][s] = ld8_once(vp + 16 * s); }
 #pragma unroll
     for (int s = 0; s < 4; ++s)
 #pragma unroll

@@ -23,6 +23,24 @@ struct AttnM {
 
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 
+// 16-byte load of an operand this kernel reads ONCE per workgroup (the query-side rows of the forward / dQ kernels, the key-side rows
+// of the dK/dV kernel).  AFM_ATTN_NT=1 makes these loads nontemporal -- measured in round 5 and LEFT OFF: one
+// box, alternating processes, c2 encoder shape, fp16: forward 0.431 / 0.437 -> 0.440 / 0.449 ms, dQ 0.535 / 0.533 -> 0.566 / 0.570,
+// dK/dV 0.682 / 0.683 -> 0.710 / 0.713; step 3 192 -> 3 134 samples/s with the GEMM-side loads (which DO pay) in both.  The rows a
+// kernel reads "once" are re-read by the next kernel of the layer (Q and dO by the dK/dV kernel right behind the dQ kernel): marked
+// evict-first they leave the memory-side cache too.
+#ifndef AFM_ATTN_NT
+#define AFM_ATTN_NT 0
+#endif
+__device__ __forceinline__ e16x8 ld8_once(const e16* p) {
+  typedef unsigned int u32x4_nt __attribute__((ext_vector_type(4)));
+#if AFM_ATTN_NT
+  return __builtin_bit_cast(e16x8, __builtin_nontemporal_load((const u32x4_nt*)p));
+#else
+  return *(const e16x8*)p;
+#endif
+}
+
 __device__ __forceinline__ f32x16 mfma32(e16x8 a, e16x8 b, f32x16 c) {
   return mfma32_raw(a, b, c);
 }

@@ -418,6 +418,22 @@ __device__ __forceinline__ void store16_policy(void* base, uint64_t byte_off, ui
   }
 }
 
+// 16-byte load of a READ-ONCE epilogue operand (the stored gradient factors of EPI_MUL / EPI_GLU_BWD, the pre-activations of
+// EPI_GELU_BWD): 537 MB per c2 launch that no workgroup reads twice.  Loaded with the default policy they allocate in the XCD's L2
+// and evict the dY panel the row's other column tiles are about to re-read (round 4: 944-950 MB read per launch against 671 MB
+// algorithmic, L2 hit 0.61); nontemporal marks the lines evict-first, like the output stores above.  AFM_PRE_LOAD_NT=0: A/B builds.
+#ifndef AFM_PRE_LOAD_NT
+#define AFM_PRE_LOAD_NT 1
+#endif
+__device__ __forceinline__ e16x8 load16_once(const e16* p) {
+  typedef unsigned int u32x4_nt __attribute__((ext_vector_type(4)));
+#if AFM_PRE_LOAD_NT
+  return __builtin_bit_cast(e16x8, __builtin_nontemporal_load((const u32x4_nt*)p));
+#else
+  return *(const e16x8*)p;
+#endif
+}
+
 template <int WM, int EPI, bool DROP_ON, int CAUX = 0>
 __device__ __forceinline__ void epilogue_staged_e16(const MfmaArgs& g, float* stg, const float* bias_lds,
                                                     f32x4 (&acc)[4][WM], int mw, int nw, int lane) {
@@ -438,7 +454,7 @@ __device__ __forceinline__ void epilogue_staged_e16(const MfmaArgs& g, float* st
   e16x8 uu[2 * WM];
   if (EPI == EPI_GELU_BWD || EPI == EPI_MUL) {
 #pragma unroll
-    for (int q = 0; q < (PF < 2 * WM ? PF : 2 * WM); ++q) uu[q] = *(const e16x8*)(pbase + (int64_t)(q * 8) * g.ldc);
+    for (int q = 0; q < (PF < 2 * WM ? PF : 2 * WM); ++q) uu[q] = load16_once(pbase + (int64_t)(q * 8) * g.ldc);
   }
 #pragma unroll
   for (int i = 0; i < WM; ++i) {
@@ -481,7 +497,7 @@ __device__ __forceinline__ void epilogue_staged_e16(const MfmaArgs& g, float* st
         const int64_t rowi = mw + r8 + q * 8;
         const e16* sp = (const e16*)g.pre_act + rowi * g.ldc + 2 * n;
         e16* cp = (e16*)g.C + rowi * g.ldc + 2 * n;
-        const e16x8 s0 = *(const e16x8*)sp, s1 = *(const e16x8*)(sp + 8);
+        const e16x8 s0 = load16_once(sp), s1 = load16_once(sp + 8);
         e16x8 o0, o1;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -514,13 +530,13 @@ __device__ __forceinline__ void epilogue_staged_e16(const MfmaArgs& g, float* st
       }
       if (EPI == EPI_MUL) {
         const e16x8 u = uu[q];
-        if (q + PF < 2 * WM) uu[q + PF < 2 * WM ? q + PF : 0] = *(const e16x8*)(pbase + (int64_t)((q + PF) * 8) * g.ldc);
+        if (q + PF < 2 * WM) uu[q + PF < 2 * WM ? q + PF : 0] = load16_once(pbase + (int64_t)((q + PF) * 8) * g.ldc);
 #pragma unroll
         for (int k = 0; k < 8; ++k) x[k] *= (float)u[k];
       }
       if (EPI == EPI_GELU_BWD) {
         const e16x8 u = uu[q];
-        if (q + PF < 2 * WM) uu[q + PF < 2 * WM ? q + PF : 0] = *(const e16x8*)(pbase + (int64_t)((q + PF) * 8) * g.ldc);
+        if (q + PF < 2 * WM) uu[q + PF < 2 * WM ? q + PF : 0] = load16_once(pbase + (int64_t)((q + PF) * 8) * g.ldc);
         if (drop_on) {
           float kp[8];
           afm_keep_scale32<8, true>(g.dd, di, kp);

@@ -4,6 +4,7 @@
 // per-modality placement into the concatenated sequence; the backward fuses the residual
 // gradient add.  dgamma/dbeta: per-block register partials -> LDS -> fp32 atomics (vectorised kernels) or a workspace and a
 // reduce kernel (row-per-wave scalar kernels).
+#include <algorithm>
 #include "afm_common.h"
 
 #define LN_MAXV 32  // up to d = 2048 held in registers (template NV = ceil(d/64) rounded up)
@@ -343,7 +344,7 @@ extern "C" int afm_layernorm_fwd(const afm_ln_shape* s, const float* x, const fl
   if (s->d > 64 * LN_MAXV) return AFM_ERR_UNSUPPORTED;
   if (s->rows == 0) return AFM_OK;
   int64_t g = (s->rows + 3) / 4;
-  static const int fwd_cap = getenv("AFM_LN_FWD_BLOCKS") ? atoi(getenv("AFM_LN_FWD_BLOCKS")) : 1280;   // five workgroups per CU: what the vectorised kernel's registers allow (two rows in flight per wave)
+  static const int fwd_cap = getenv("AFM_LN_FWD_BLOCKS") ? std::max(1, atoi(getenv("AFM_LN_FWD_BLOCKS"))) : 1280;   // five workgroups per CU: what the vectorised kernel's registers allow (two rows in flight per wave)
   if (g > fwd_cap) g = fwd_cap;
   hipStream_t st = (hipStream_t)stream;
   if (s->y_dtype < AFM_F32 || s->y_dtype > AFM_F16) return AFM_ERR_ARG;
@@ -377,7 +378,7 @@ extern "C" int afm_layernorm_fwd(const afm_ln_shape* s, const float* x, const fl
 
 static inline int ln_bwd_blocks(int64_t rows) {
   int64_t g = (rows + 3) / 4;
-  static const int bwd_cap = getenv("AFM_LN_BWD_BLOCKS") ? atoi(getenv("AFM_LN_BWD_BLOCKS")) : 768;   // three workgroups per CU (the vectorised kernel: 138 registers, two rows in flight per wave)
+  static const int bwd_cap = getenv("AFM_LN_BWD_BLOCKS") ? std::max(1, atoi(getenv("AFM_LN_BWD_BLOCKS"))) : 768;   // three workgroups per CU (the vectorised kernel: 138 registers, two rows in flight per wave)
   if (g > bwd_cap) g = bwd_cap;
   if (g < 1) g = 1;
   return (int)g;

@@ -123,7 +123,8 @@ class Seq2SeqEngine:
         self.bits_stream = (torch.cuda.Stream(device=self.dev)
                             if self.dev.type == "cuda" and os.environ.get("AFM_BITS_AHEAD", "0") == "1" else None)
         self._wg_pending = []
-        self._live = {}       # backward only: rows -> uint8 per 64-row block, 0 = nothing but padded positions (_backward)
+        self._live = {}       # backward only: role ("enc" / "dec") -> uint8 per 64-row block, 0 = nothing but padded positions (_backward)
+        self._role = None     # whose rows the backward is working on: set by _backward around the layer stacks (None: no hints)
         self.refresh_shadows()
 
     # ------------------------------------------------------------------ parameters
@@ -291,32 +292,32 @@ class Seq2SeqEngine:
                         pre_act=pre_act, algo=self.algo, sg_hi_only=sg_hi_only)
 
     def _dgrad(self, dy, name, rows, cols, r0=0, r1=None, out=None, out_dtype=None, accumulate=False,
-               act=ACT_NONE, pre_act=None, dropout=ops.NO_DROP):
+               act=ACT_NONE, pre_act=None, dropout=ops.NO_DROP, role=None):
         """dx = dy @ W[r0:r1]  (W rows = output features)."""
         r1 = rows if r1 is None else r1
         if out is None:
             out = self._empty_b(dy.shape[0], cols, out_dtype)
         kw = dict(accumulate=accumulate, algo=self.algo, act=act, pre_act=self._hb(pre_act), dropout=dropout)
         if self.lowp and torch.is_tensor(dy):
-            kw["k_live"] = self._live_hint(dy)      # row tiles of nothing but padded positions: zeros in, zeros out
+            kw["k_live"] = self._live_hint(dy, role)      # row tiles of nothing but padded positions: zeros in, zeros out
         if self.lowp:
             wt = self._hb(self.wt[name][:, r0:r1])  # (cols, n): NT form for the MFMA kernel
             return ops.gemm(dy, wt, out, trans_b=True, **kw)
         w = self.W(name, rows, cols, r0, r1)
         return ops.gemm(dy, w, out, trans_b=False, **kw)
 
-    def _wgrad(self, dy, x, name, rows, cols, r0=0, r1=None, bias_name=None):
+    def _wgrad(self, dy, x, name, rows, cols, r0=0, r1=None, bias_name=None, role=None):
         """dW[r0:r1] += dy^T x ; db[r0:r1] += colsum(dy)."""
         gw = self.G(name, rows, cols, r0, r1)
         gb = None
         if bias_name is not None:
             gb = self.ps.vec_span(self.ps.grad, bias_name, r0, r0 + gw.shape[0])
-        self._wgrad_raw(dy, self._hb(x), gw, gb)
+        self._wgrad_raw(dy, self._hb(x), gw, gb, role=role)
 
-    def _wgrad_raw(self, dy, x, gw, gb, glu_rows=0):
+    def _wgrad_raw(self, dy, x, gw, gb, glu_rows=0, role=None):
         kw = dict(trans_a=True, trans_b=False, accumulate=True, algo=self.algo, a_colsum=gb, glu_rows=glu_rows)
         if torch.is_tensor(dy) and dy.dtype != torch.float32:
-            kw["k_live"] = self._live_hint(dy)      # padded 64-token blocks carry exact zeros: left out of the token axis
+            kw["k_live"] = self._live_hint(dy, role)      # padded 64-token blocks carry exact zeros: left out of the token axis
         if self.group_wgrad and torch.is_tensor(dy) and torch.is_tensor(x) and dy.dtype == x.dtype and dy.dtype != torch.float32:
             # 16-bit operands: the layer's weight gradients go out together at the end of its backward (afm_gemm_group: one
             # launch, one split-K budget); the list keeps dy / x alive until then
@@ -498,7 +499,7 @@ class Seq2SeqEngine:
             dxd = self._empty(x.shape[0], self.d, dy.dtype)
             dr = self._drop(next_site)
         ops.layernorm_bwd(dy, x, self.ps.p(prefix + "weight"), mean, rstd, dx, self.ps.g(prefix + "weight"),
-                          self.ps.g(prefix + "bias"), ws, dres=dres, dx_drop=dxd, dropout=dr, row_live=self._live.get(x.shape[0]))
+                          self.ps.g(prefix + "bias"), ws, dres=dres, dx_drop=dxd, dropout=dr, row_live=self._live_hint(dy))
         return dx, dxd
 
     def _bits_ahead(self, B, H, Tq, Tk, site, saved):
@@ -649,7 +650,7 @@ class Seq2SeqEngine:
                 return None
             if weight_t is not None:
                 dh = self._empty_b(rows, d)
-                ops.gemm(dh_from, weight_t, dh, trans_b=True, algo=self.algo, k_live=self._live.get(rows))
+                ops.gemm(dh_from, weight_t, dh, trans_b=True, algo=self.algo, k_live=self._live_hint(dh_from))
             else:
                 dh = self._dgrad(dh_from, p + "linear1.weight", k * f, d)
             return self._ln_bwd(dh, p + norm, saved, "lnf", dres=dx1, next_site=next_site)
@@ -658,7 +659,7 @@ class Seq2SeqEngine:
             # [du | dv] (interleaved) = (dy W2) * saved factors in the dgrad epilogue; weight gradient rows de-interleaved by
             # the wgrad kernel into the reference's [linear1 ; gate] layout; dh through the interleaved transpose
             ops.gemm(dy, self._hb(self.wt[p + "linear2.weight"]), duv, trans_b=True, act=ACT_GLU_BWD, pre_act=self._hb(uv),
-                     algo=self.algo, glu_rows=f, k_live=self._live.get(rows))
+                     algo=self.algo, glu_rows=f, k_live=self._live_hint(dy))
             gw = self.G(p + "linear1.weight", 2 * f, d)
             gb = self.ps.vec_span(self.ps.grad, p + "linear1.bias", 0, 2 * f)
             self._wgrad_raw(duv, self._hb(h), gw, gb, glu_rows=f)
@@ -713,9 +714,9 @@ class Seq2SeqEngine:
                      ops._ld(dq), ldkv, ldkv)
         w, bname = p + "multihead_attn.in_proj_weight", p + "multihead_attn.in_proj_bias"
         self._wgrad(dq, h, w, 3 * d, d, 0, d, bias_name=bname)
-        self._wgrad(dkv, mem, w, 3 * d, d, d, 3 * d, bias_name=bname)
+        self._wgrad(dkv, mem, w, 3 * d, d, d, 3 * d, bias_name=bname, role="enc")      # memory-side rows: encoder positions
         if dkv_all is None:
-            self._dgrad(dkv, w, 3 * d, d, d, 3 * d, out=dmem, accumulate=True)  # fp32 accumulator
+            self._dgrad(dkv, w, 3 * d, d, d, 3 * d, out=dmem, accumulate=True, role="enc")  # fp32 accumulator
         if acc is not None:
             self._dgrad(dq, w, 3 * d, d, 0, d, out=acc, accumulate=True)
             return None
@@ -1092,7 +1093,8 @@ class Seq2SeqEngine:
             if dmem is None:
                 dmem = torch.empty(B * S, d, dtype=torch.float32, device=self.dev)
             ops.gemm(dkv_all, self._hb(self.wt_kv_all), dmem, trans_b=True, accumulate=had_init, algo=self.algo)
-        self.embed_bwd(dx, saved["emb_dec"])
+        self._embed_bwd_unhinted(dx, saved["emb_dec"])
+        self._role = "enc"
         dx, _ = self._ln_bwd(self._operand(dmem, backward=True), "encoder.norm.", saved, "enc_norm", dres=None, next_site=None)
         for i in range(Le - 1, -1, -1):
             p, sv = f"encoder.layers.{i}.", saved["enc_layers"][i]
@@ -1103,7 +1105,7 @@ class Seq2SeqEngine:
             self._grads_final_from(p + "self_attn.in_proj_weight")
         self._embed_bwd_unhinted(dx, saved["emb_enc"])
         self._wgrad_flush()
-        self._live = {}
+        self._live, self._role = {}, None
         if self.wgrad_stream is not None:
             torch.cuda.current_stream().wait_stream(self.wgrad_stream)
 
@@ -1117,19 +1119,23 @@ class Seq2SeqEngine:
             self.grad_ready_hook(self.ps.specs[first_name].offset)
 
     def _embed_bwd_unhinted(self, dx, saved_emb):
-        """The padded-row hints (`_live`) are keyed by row count and belong to the layer stacks (B * S encoder rows, B * T decoder rows).
-        A modality's own row count may coincide with one of them (a modality as long as the decoder sequence) while its padding
-        differs: the embedder backward therefore runs without hints."""
-        keep, self._live = self._live, {}
+        """The padded-row hints (`_live`) belong to the layer stacks (role "enc": B * S encoder rows, "dec": B * T decoder rows).  A
+        modality's rows are neither (its own padding differs): the embedder backward runs with no role, hence without hints."""
+        keep, self._role = self._role, None
         try:
             self.embed_bwd(dx, saved_emb)
         finally:
-            self._live = keep
+            self._role = keep
 
-    def _live_hint(self, t):
-        """Padded-row hint for a backward operand `t` (one byte per 64-row block; None: no hint).  AFM_DEBUG_LIVE=1 checks, with a
-        host synchronisation, that every row the hint calls dead really is zero."""
-        h = self._live.get(t.shape[0]) if torch.is_tensor(t) else None
+    def _live_hint(self, t, role=None):
+        """Padded-row hint for a backward operand `t` (one byte per 64-row block; None: no hint), keyed by ROLE: `role` where the
+        caller names it (the memory-side operands of the decoder's cross-attention are encoder rows), else the stack `_backward` is
+        in (`_role`).  The row count is only a consistency check -- an operand whose rows are not the role's gets no hint, never another
+        role's.  AFM_DEBUG_LIVE=1 checks, with a host synchronisation, that every row the hint calls dead really is zero."""
+        role = role or self._role
+        h = self._live.get(role) if (role is not None and torch.is_tensor(t)) else None
+        if h is not None and h.numel() * 64 != t.shape[0]:
+            h = None
         if h is not None and _DEBUG_LIVE:
             rows = t.hi if hasattr(t, "hi") else t
             dead = (h == 0).repeat_interleave(64)
@@ -1143,14 +1149,15 @@ class Seq2SeqEngine:
         # Padded positions are masked as keys everywhere and take no part in the loss: their rows of every activation gradient are
         # exact zeros.  One byte per 64-row block tells the weight-gradient kernels (token axis) and the LayerNorm backward which
         # blocks hold nothing else (include/afm_hip.h: afm_gemm_desc.k_live, afm_ln_shape.row_live).
-        self._live = {}
-        if self.row_skip and B * S != B * T:
+        self._live, self._role = {}, None
+        if self.row_skip:
             tgt_pad = saved.get("tgt_pad")
             if tgt_pad is not None:      # a padded decoder row is dead only if it has no label either (the caller's labels are its own)
                 tgt_pad = tgt_pad.view(B, T).bool() & (lab.view(B, T) == -100)
-            for L, pad in ((S, saved.get("key_pad")), (T, tgt_pad)):
+            for role, L, pad in (("enc", S, saved.get("key_pad")), ("dec", T, tgt_pad)):
                 if pad is not None and L % 64 == 0:
-                    self._live[B * L] = (pad.view(B, L // 64, 64) == 0).any(-1).to(torch.uint8).reshape(-1).contiguous()
+                    self._live[role] = (pad.view(B, L // 64, 64) == 0).any(-1).to(torch.uint8).reshape(-1).contiguous()
+        self._role = "dec"             # head, final decoder norm and the decoder stack: B * T rows
         dlog = self._empty_b(B * T, self.V)
         ops.ce_bwd(logits, lab, row_lse, stats, loss_scale, dlog, scale_dev=self.scaler)
         hf = saved["hf"]
@@ -1179,7 +1186,7 @@ class Seq2SeqEngine:
                 # nothing to add to (no alignment head): the GEMM writes the 16-bit operand of the encoder's final LayerNorm
                 # backward itself, instead of an fp32 matrix and a cast kernel behind it (the same rounding, once)
                 dmem_c = self._empty_b(B * S, d)
-                ops.gemm(dkv_all, self._hb(self.wt_kv_all), dmem_c, trans_b=True, algo=self.algo, k_live=self._live.get(B * S))
+                ops.gemm(dkv_all, self._hb(self.wt_kv_all), dmem_c, trans_b=True, algo=self.algo, k_live=self._live_hint(dkv_all, "enc"))
             else:
                 if dmem is None:
                     dmem = torch.empty(B * S, d, dtype=torch.float32, device=self.dev)
@@ -1190,6 +1197,7 @@ class Seq2SeqEngine:
             if self.lowp:
                 dmem_c = self._empty_b(B * S, d)
                 ops.dropout_cast(dmem, dmem_c)
+        self._role = "enc"             # final encoder norm and the encoder stack: B * S rows
         dx, dy = self._ln_bwd(dmem_c, "encoder.norm.", saved, "enc_norm", dres=None, next_site=f"e{Le - 1}res2")
         for i in range(Le - 1, -1, -1):
             p, sv = f"encoder.layers.{i}.", saved["enc_layers"][i]
@@ -1198,6 +1206,6 @@ class Seq2SeqEngine:
             self._grads_final_from(p + "self_attn.in_proj_weight")
         self._embed_bwd_unhinted(dx, saved["emb_enc"])
         self._wgrad_flush()
-        self._live = {}
+        self._live, self._role = {}, None
         if self.wgrad_stream is not None:   # every weight gradient is in before the caller reads the buffer
             torch.cuda.current_stream().wait_stream(self.wgrad_stream)

@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libafm_hip.so")
 
 AFM_F32, AFM_BF16, AFM_BF16X2, AFM_F16 = 0, 1, 2, 3
-ABI_VERSION = 4
+ABI_VERSION = 5
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_GELU_BWD, ACT_GELU_SAVE_GRAD, ACT_MUL_SAVED = 0, 1, 2, 3, 4, 5
 ACT_GLU, ACT_GLU_SAVE, ACT_GLU_BWD = 6, 7, 8
 ALGO_AUTO, ALGO_GENERIC, ALGO_MFMA = 0, 1, 2

@@ -21,7 +21,7 @@ def test_header_symbols_are_exported_and_bound():
     for name in declared:
         assert hasattr(handle, name), f"libafm_hip.so does not export {name}"
     assert sorted(L.exported_symbols()) == declared, "lib.py binding and header disagree"
-    assert handle.afm_abi_version() == L.ABI_VERSION == 4
+    assert handle.afm_abi_version() == L.ABI_VERSION == 5
     for which, st in enumerate((L.Dropout, L.GemmDesc, L.LnShape, L.AttnShape, L.PatchDesc, L.BeamDesc, L.CastItem)):
         assert handle.afm_struct_size(which) == ctypes.sizeof(st)
     assert handle.afm_error_string(-2) == b"unsupported shape/dtype for the requested algorithm"

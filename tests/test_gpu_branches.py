@@ -402,3 +402,43 @@ def test_multimodal_norm_false_forward_backward_vs_oracle():
     lg = eng.decode_step(st, dec[:, 0].to(DEV))
     full = eng.forward(to(enc), am.to(DEV), dec.to(DEV), dm.to(DEV))["logits"][:, 0]
     assert float((lg - full).abs().max()) < 1e-4 * float(full.abs().max())
+
+
+@pytest.mark.gpu
+def test_padded_row_hints_are_keyed_by_role_when_encoder_and_decoder_have_the_same_row_count(monkeypatch):
+    """ADVICE r03 / VERDICT r04 item 9: B * S == B * T with DIFFERENT padding on the two sides.  The hints used to be keyed by row
+    count (and were switched off in this case); keyed by role they stay on, every row a hint calls dead really is zero
+    (AFM_DEBUG_LIVE's check, enabled here) and the gradients equal those of the backward that skips nothing."""
+    _need_gpu()
+    from multimodalanalytical_amd import engine as E
+    from multimodalanalytical_amd import synth
+    monkeypatch.setitem(synth.WORKLOADS, "t_eq", dict(
+        cfg=dict(synth.WORKLOADS["c1"]["cfg"], dropout=0.0),
+        data={"Multiplets": {**synth._text(256), "type": "multiplets"}, "Smiles": synth._text(128, True)},
+        lens={"Multiplets": (256, 10, 50)}, T=256, batch=4))
+    wl = synth.WORKLOADS["t_eq"]
+    batch, _ = synth.make_batch("t_eq", 4, seed=5)
+    enc, am, dec, dm, labels = O.batch_to_model_inputs(batch, "Smiles")
+    assert am.shape == dm.shape and not torch.equal(am.bool(), dm.bool())
+    to = lambda x: {k: to(v) for k, v in x.items()} if isinstance(x, dict) else x.to(DEV)
+    grads, seen = {}, {}
+    for skip in (True, False):
+        eng = E.Seq2SeqEngine(wl["cfg"], wl["data"], "Smiles", 128, device=DEV, compute_dtype=torch.float16, seed=11)
+        eng.row_skip = skip
+        monkeypatch.setattr(E, "_DEBUG_LIVE", skip)
+        roles = []
+        if skip:
+            orig = eng._live_hint
+            def spy(t, role=None, _o=orig, _e=eng, _r=roles):
+                h = _o(t, role)
+                if h is not None:
+                    _r.append(role or _e._role)
+                return h
+            eng._live_hint = spy
+        eng.forward(to(enc), am.to(DEV), dec.to(DEV), dm.to(DEV), labels.to(DEV), backward=True)
+        torch.cuda.synchronize()
+        grads[skip] = eng.ps.grad.clone()
+        seen[skip] = set(roles)
+    assert seen[True] == {"enc", "dec"} and seen[False] == set()       # both stacks were hinted, each with its own mask
+    a, b = grads[True].float(), grads[False].float()
+    assert float((a - b).norm()) <= 1e-5 * float(b.norm())
