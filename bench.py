@@ -63,6 +63,7 @@ def parse():
     ap.add_argument("--set-size", type=int, default=177000, help="samples of the resident synthetic set (SURVEY 8d: synth-177K)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-eval", action="store_true", help="skip the eval / decode section (greedy at the main workload, beam 5 at c5)")
     ap.add_argument("--cpu-batch", type=int, default=8)
     ap.add_argument("--cpu-steps", type=int, default=3)
     ap.add_argument("--cpu-threads", type=int, default=32, help="torch CPU threads of the baseline (more than 32 ran SLOWER on the GPU box; the host's core count is printed beside it)")
@@ -106,7 +107,7 @@ def _rand(rows, cols, cd, dev, scale=1.0):
     return ops.convert(x, ops.empty(rows, cols, cd, dev))
 
 
-def kernel_rooflines(model, wl, B, mode):
+def kernel_rooflines(model, wl, B, mode, wl_name="c2"):
     """Live timings of the kernels that make up the step, at the workload's encoder shapes (the encoder is ~80 % of
     the FLOPs): each entry = one launch of one kernel.  `achieved` = ALGORITHMIC FLOPs of that launch / its average
     duration; algorithmic FLOPs count every matrix product the kernel has to evaluate ONCE at 2 FLOPs per
@@ -224,14 +225,69 @@ def kernel_rooflines(model, wl, B, mode):
             ms = time_kernel(lambda: ops.gemm(dy, w2t, du, trans_b=True, act=ACT_MUL_SAVED, pre_act=preb))
             add("FFN down-projection data gradient (x stored keep*scale*GELU')", f"afm_gemm[{ops.last_algo()}] {M}x{f}x{d}",
                 ms, 2.0 * M * d * f, eb * (M * d + f * d + 2 * M * f), Le, "1 product", bmode)
+    if mode != "fp32" and not mixed:
+        from multimodalanalytical_amd.lib import ACT_GLU_BWD, ACT_GLU_SAVE
+        fh = cfg["encoder_ffn_dim"]                          # hidden width (the gated forms carry 2 fh columns through the up-projection)
+        # --- the long-K plain products (bias only): FFN down-projection forward, QKV data gradient
+        gact = _rand(M, fh, cd, dev)
+        w2 = eng.W("encoder.layers.0.linear2.weight", d, fh)
+        b2 = eng.ps.p("encoder.layers.0.linear2.bias")
+        br = ops.empty(M, d, cd, dev)
+        ms = time_kernel(lambda: ops.gemm(gact, w2, br, trans_b=True, bias=b2))
+        add("FFN down-projection forward", f"afm_gemm[{ops.last_algo()}] {M}x{d}x{fh}", ms, 2.0 * M * d * fh,
+            ef * (M * fh + d * fh + M * d), Le, "1 product", fmode)
+        wqt = eng.wt["encoder.layers.0.self_attn.in_proj_weight"]          # (d x 3d): dgrad of the packed projection as an NT GEMM
+        dx = ops.empty(M, d, cd, dev)
+        ms = time_kernel(lambda: ops.gemm(dqkv, wqt, dx, trans_b=True))
+        add("QKV projection data gradient", f"afm_gemm[{ops.last_algo()}] {M}x{d}x{3 * d}", ms, 2.0 * M * d * 3 * d,
+            eb * (M * 3 * d + 3 * d * d + M * d), Le, "1 product", bmode)
+        # --- an encoder layer's weight gradients as the engine launches them: ONE grouped launch (afm_gemm_group)
+        dy = ops.empty(M, d, cd, dev)
+        ops.convert(torch.randn(M, d, device=dev) * 0.01, dy)
+        k2 = 2 if cfg["gated_linear"] else 1
+        duv = ops.empty(M, k2 * fh, cd, dev)
+        ops.convert(torch.randn(M, k2 * fh, device=dev) * 0.01, duv)
+        p0 = "encoder.layers.0."
+        G, gv = eng.G, lambda n, a0, a1: eng.ps.vec_span(eng.ps.grad, n, a0, a1)
+        kwg = dict(trans_a=True, trans_b=False, accumulate=True)
+        descs = [ops.gemm_desc(dy, gact, G(p0 + "linear2.weight", d, fh), a_colsum=gv(p0 + "linear2.bias", 0, d), **kwg),
+                 ops.gemm_desc(duv, x, G(p0 + "linear1.weight", k2 * fh, d), a_colsum=gv(p0 + "linear1.bias", 0, k2 * fh),
+                               glu_rows=fh if cfg["gated_linear"] else 0, **kwg),
+                 ops.gemm_desc(dy, o, G(p0 + "self_attn.out_proj.weight", d, d), a_colsum=gv(p0 + "self_attn.out_proj.bias", 0, d), **kwg),
+                 ops.gemm_desc(dqkv, x, G(p0 + "self_attn.in_proj_weight", 3 * d, d), a_colsum=gv(p0 + "self_attn.in_proj_bias", 0, 3 * d), **kwg)]
+        ms = time_kernel(lambda: ops.gemm_group(descs))
+        wflops = 2.0 * M * (d * fh + k2 * fh * d + d * d + 3 * d * d)
+        add("weight gradients of one encoder layer, grouped launch (bias gradients fused)", f"afm_gemm_group[{ops.last_algo()}] 4 problems over {M} tokens",
+            ms, wflops, eb * M * (2 * d + fh + k2 * fh + d + 3 * d + d) + 4 * (d * fh + k2 * fh * d + 4 * d * d), Le, "4 products", bmode)
+        eng.ps.grad.zero_()
+        if cfg["gated_linear"]:
+            # --- gated FFN: gelu(u) * v, dropout and the stored factors in the up-projection's epilogue; [du | dv] in the dgrad epilogue
+            wg = eng.w_glu[p0 + "linear1.weight"]
+            bg = eng.ps.vec_span(eng.ps.flat, p0 + "linear1.bias", 0, 2 * fh)
+            uv = ops.empty(M, 2 * fh, cd, dev)
+            gg = ops.empty(M, fh, cd, dev)
+            ms = time_kernel(lambda: ops.gemm(x, wg, gg, trans_b=True, bias=bg, act=ACT_GLU_SAVE, pre_act=uv, dropout=dr, glu_rows=fh))
+            by = ef * (M * d + 2 * fh * d + M * fh + 2 * M * fh)
+            add("gated FFN up-projection forward (bias + gelu(u) v + dropout fused, keep*scale*[gelu'(u) v | gelu(u)] stored)",
+                f"afm_gemm[{ops.last_algo()}] {M}x{2 * fh}x{d}", ms, 2.0 * M * d * 2 * fh, by, Le, "1 product; three M x f outputs", fmode)
+            w2t = eng.wt[p0 + "linear2.weight"]                # (fh x d)
+            ms = time_kernel(lambda: ops.gemm(dy, w2t, duv, trans_b=True, act=ACT_GLU_BWD, pre_act=uv, glu_rows=fh))
+            add("gated FFN down-projection data gradient (x stored factors -> [du | dv])", f"afm_gemm[{ops.last_algo()}] {M}x{fh}x{d}",
+                ms, 2.0 * M * d * fh, eb * (M * d + fh * d + 4 * M * fh), Le, "1 product", bmode)
+            wgt = eng.wt_glu[p0 + "linear1.weight"]            # (d x 2 fh)
+            dh = ops.empty(M, d, cd, dev)
+            ms = time_kernel(lambda: ops.gemm(duv, wgt, dh, trans_b=True))
+            add("gated FFN up-projection data gradient", f"afm_gemm[{ops.last_algo()}] {M}x{d}x{2 * fh}", ms, 2.0 * M * d * 2 * fh,
+                eb * (M * 2 * fh + 2 * fh * d + M * d), Le, "1 product", bmode)
     # traffic from committed PMC passes of the same launches (profiles/r02_*_pmc.json: {kernel what: bytes})
-    if (B, S, d) == (128, 1024, 512):
+    if B == 128 and S == 1024:
         tables = {}
         for e in out:
             km = e["arithmetic"]
             if km not in tables:
                 tables[km] = {}
-                for cand in (f"r04_{km}_pmc.json", f"r03_{km}_pmc.json", f"r02_{km}_pmc.json"):   # PMC passes of the same launches, newest round first
+                old = (f"r04_{km}_pmc.json", f"r03_{km}_pmc.json", f"r02_{km}_pmc.json") if wl_name == "c2" else ()
+                for cand in (f"r05_{wl_name}_{km}_pmc.json",) + old:   # PMC passes of the same launches, newest round first
                     pmc = os.path.join(ROOT, "profiles", cand)
                     if os.path.exists(pmc):
                         tables[km] = json.load(open(pmc))
@@ -329,6 +385,72 @@ def measured_parity(model, wl, name, n=8):
             "ids_equal_where_margin_exceeds_2x_err": bool(torch.equal(ids[sure], rid[sure])),
             "decidable_frac": round(float(sure.double().mean()), 6), "samples": n,
             "note": "measured in this run on the trained weights of the timed steps, eval forward vs oracle/afm_oracle.py (fp32 CPU)"}
+
+
+# ------------------------------------------------------------------------------------------------ eval / decode
+def eval_decode(model, wl, name, n_beams, max_length, B, check_n=8):
+    """The reference's evaluation path on the trained weights of the timed steps (modeling/wrapper.py:409-453: encoder once, then
+    greedy -- every validation batch, :500-507 -- or beam search with num_return_sequences = n_beams, forced EOS at max_length),
+    as this package runs it: KV cache + one HIP graph per position (greedy), afm_beam_step / afm_cache_reorder on the device (beam).
+    Timed on `B` samples; ids checked in the run on `check_n` samples: greedy against the CPU oracle's full-prefix loop
+    (oracle/afm_oracle.py greedy_decode = the reference's use_cache=False control flow), beam device kernels against the host loop
+    that is pinned to transformers' generate (tests/golden/beam_cases.npz)."""
+    from multimodalanalytical_amd import synth
+    from oracle import afm_oracle as O
+    eng = model.hf_model.engine
+    dev = eng.dev
+    old_len = model.max_length
+    model.max_length = max_length
+    batch = synth.make_batch(name, B, seed=777, device=dev)[0]
+    kw = dict(n_beams=n_beams)
+    try:
+        model.generate(batch, **kw)                                   # warm-up (graph capture, allocator)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        ids = model.generate(batch, **kw)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        ntok = ids.shape[1] - 1                                       # positions decoded (the first column is BOS)
+        out = {"what": f"{'greedy' if n_beams == 1 else f'beam {n_beams}'} decode, workload {name}, B = {B}, max_length {max_length}",
+               "path": "KV cache, one HIP graph per position" if n_beams == 1 else "KV cache, beam bookkeeping on the device (afm_beam_step, afm_cache_reorder)",
+               "ms_per_token": round(dt / max(ntok, 1) * 1e3, 4), "tokens": ntok, "samples_per_s": round(B / dt, 2), "ms_total": round(dt * 1e3, 2),
+               "returned_sequences": int(ids.shape[0])}
+        small, _ = synth.make_batch(name, check_n, seed=778)
+        got = model.generate(synth.to_device(small, dev), **kw).cpu()
+        if n_beams == 1:
+            enc, am, dec, dm, labels = O.batch_to_model_inputs(small, "Smiles")
+            sd = {k: v.detach().float().cpu() for k, v in eng.state_dict().items()}
+            cfg = dict(wl["cfg"], dropout=0.0)
+            torch.set_num_threads(min(32, os.cpu_count() or 1))
+            t0 = time.perf_counter()
+            ref = O.greedy_decode(sd, cfg, wl["data"], "Smiles", enc, am, max_length=max_length)
+            cpu_s = time.perf_counter() - t0
+            L = min(got.shape[1], ref.shape[1])
+            eq = (got[:, :L] == ref[:, :L])
+            same_len = got.shape[1] == ref.shape[1]
+            first = [int((~eq[i]).nonzero()[0]) if not bool(eq[i].all()) else -1 for i in range(check_n)]
+            # a sequence that leaves the reference's does so at a position where the reference's own top-2 margin is inside the error band
+            in_band = True
+            for i, pos in enumerate(first):
+                if pos < 0:
+                    continue
+                one = {m: ({k: t[i:i + 1] for k, t in v.items()} if isinstance(v, dict) else v[i:i + 1]) for m, v in enc.items()}
+                o = O.model_forward(sd, cfg, wl["data"], "Smiles", one, am[i:i + 1], ref[i:i + 1, :pos], None)
+                lg = o["logits"][0, -1].double()
+                top2 = lg.topk(2).values
+                in_band &= bool((top2[0] - top2[1]) <= 2e-3 * float(lg.abs().max()))
+            out["ids_check"] = {"against": "oracle/afm_oracle.py greedy_decode (fp32 CPU, full-prefix recompute: the reference's use_cache=False loop)",
+                                "samples": check_n, "sequences_equal": int(sum(p < 0 for p in first)), "same_length": bool(same_len),
+                                "tokens_equal_frac": round(float(eq.double().mean()), 6), "first_divergence": first,
+                                "divergences_inside_the_margin_band": in_band, "oracle_cpu_s": round(cpu_s, 1)}
+        else:
+            host = model.generate(synth.to_device(small, dev), n_beams=n_beams, device_beam=False).cpu()
+            out["ids_check"] = {"against": "the host beam loop (beam.beam_search, pinned to transformers generate by tests/golden/beam_cases.npz)",
+                                "samples": check_n, "sequences_equal": bool(got.shape == host.shape and torch.equal(got, host)),
+                                "stop_rule": model.beam_stop_rule}
+        return out
+    finally:
+        model.max_length = old_len
 
 
 # ------------------------------------------------------------------------------------------------ timed loop
@@ -540,10 +662,11 @@ def main():
         r = timed_run(args.workload, m, args.other_steps, 1, rank, world, dev, args)
         modes[m] = mode_entry(r, m, args.other_steps)
     workloads = {}
+    eval_out = {}
     if world == 1:
         for w in [x for x in args.extra_workloads.split(",") if x and x != args.workload]:
             nst = 5 if w in ("c4", "c5") else args.extra_steps
-            r = timed_run(w, args.dtype, nst, 1, rank, world, dev, args)
+            r = timed_run(w, args.dtype, nst, 1, rank, world, dev, args, keep=w in ("c4", "c5"))
             workloads[w] = {"workload": f"{w}: modalities {'+'.join(k for k in r['wl']['data'] if k != 'Smiles')}, enc_len {r['S']}, dec_len {r['wl']['T']}, "
                                         f"{r['wl']['cfg']['encoder_layers']}L d{r['wl']['cfg']['d_model']}" + (" gated" if r['wl']['cfg']['gated_linear'] else ""),
                             "value": round(r["value"], 3), "unit": "samples/s", "ms_per_step": round(r["dt"] / nst * 1e3, 3),
@@ -557,6 +680,14 @@ def main():
                             "dtype": args.dtype}
             if "parity" in r:
                 workloads[w]["logits_vs_cpu_reference"] = r["parity"]
+            if w == "c4" and not args.no_roofline:
+                # the configuration the 8-GPU target is quoted on: live HIP-event timings of ITS dominant launches
+                workloads[w]["roofline_kernels"] = kernel_rooflines(r["model"], r["wl"], r["B"], args.dtype, w)
+            if w == "c5" and not args.no_eval:
+                eval_out["beam5_c5"] = eval_decode(r["model"], r["wl"], "c5", 5, 256, r["B"])
+            if "model" in r:
+                del r["model"]
+                torch.cuda.empty_cache()
 
     # the same loop over 4 fixed pre-collated batches (rounds 1-3): what the input path costs inside the timed region
     input_cmp = None
@@ -610,8 +741,12 @@ def main():
     if workloads:
         out["workloads"] = workloads
     if rank == 0:
+        if world == 1 and not args.no_eval:
+            eval_out["greedy_c2" if args.workload == "c2" else f"greedy_{args.workload}"] = eval_decode(main_run["model"], wl, args.workload, 1, 128, B)
+        if eval_out:
+            out["eval"] = eval_out
         if not args.no_roofline:
-            ks = kernel_rooflines(main_run["model"], wl, B, args.dtype)
+            ks = kernel_rooflines(main_run["model"], wl, B, args.dtype, args.workload)
             out["roofline"] = ks[0]
             out["roofline_kernels"] = ks[1:]
         if world == 1 and not args.no_cpu_baseline:

@@ -1,0 +1,245 @@
+// The dQ kernel of the single-pass flash-attention backward on v_mfma_f32_16x16x32 (included by afm_attn_mfma_impl.h inside namespace
+// AFM_E16_NS).  Round 5, VERDICT r04 item 1: the three attention kernels run v_mfma_f32_32x32x16; MI355X_MICROARCH.md ("DVFS give-back"
+// item 7) measures the 16x16x32 shape at 1.12-1.15 x the FLOP/s in bare clock-limited loops, so the shape is A/B-tested here on the
+// kernel that is simplest to restate: SAME output tile per wave (32 queries x 32-key blocks, 4 waves = 128 queries per workgroup, three
+// workgroups per CU), same LDS images and LDS-DMA ring, same arithmetic per score; only the MFMA shape and what follows from it differ:
+//   * S^T / dP^T of a 32-key block = 2 x 2 tiles of 16 keys x 16 queries, two k-steps of 32 over dh = 64: 8 + 8 MFMAs (were 4 + 4);
+//     a lane owns TWO queries (columns lane & 15 of the two query tiles) and, per tile, keys 4 (lane >> 4) .. + 3;
+//   * dS^T as the B operand of dQ^T += K^T dS^T: k-index 8 g + j <-> key 16 (j >> 2) + 4 g + (j & 3) of the block, i.e. the four
+//     registers of key tile 0 followed by those of key tile 1 -- no lane movement; the A operand K^T[d][key] takes the same key order
+//     from two ds_read_b64_tr_b16 (rows 4 g .. + 3 and 16 + 4 g .. + 3);
+//   * the transposed K image needs its own swizzle for that read pattern (chunk ^ ((row >> 1) & 3) << 1: the four same-parity rows of a
+//     32-lane half land in four different 32-byte chunk pairs): dma_piece_tr16.
+// Dropout: DROP_NONE and DROP_HASH only -- the keep-bit tensor's 64-bit words are lane masks of the 32x32 accumulator layout, which
+// the forward kernel writes; a 16x16 kernel would have to re-assemble every mask from two words.  The A/B against k_attn_bwd_dq_mfma
+// is therefore run without dropout and with the re-hash path on both sides (tools/experiments/attn_m16.py).
+// Selected by afm_attn_shape.reserved & 1024 (never by default).
+
+__device__ __forceinline__ void dma_piece_tr16(unsigned char* img, const e16* base, int ld, int row0, int nrows, int pi, int lane) {
+  const int r = 8 * pi + (lane >> 3), slot = lane & 7;
+  const int chunk = slot ^ (((r >> 1) & 3) << 1);
+  int gr = row0 + r;
+  gr = gr < nrows ? gr : nrows - 1;   // clamped rows are masked out by the caller
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + (int64_t)gr * ld + chunk * 8),
+                                   (__attribute__((address_space(3))) void*)(img + pi * 1024), 16, 0, 0);
+}
+// A-operand fragment by rows for 16x16x32: lane holds tile[R0 + (lane & 15)][32 ks + 8 (lane >> 4) .. + 7] of a row image
+__device__ __forceinline__ e16x8 frag_row16(const unsigned char* img, int R0, int ks, int lane) {
+  return *(const e16x8*)(img + img_row(R0 + (lane & 15), 4 * ks + (lane >> 4)));
+}
+__device__ __forceinline__ e16x8 cvt8_2x4(const f32x4& lo, const f32x4& hi) {
+  return (e16x8){(e16)lo[0], (e16)lo[1], (e16)lo[2], (e16)lo[3], (e16)hi[0], (e16)hi[1], (e16)hi[2], (e16)hi[3]};
+}
+// keep ? x : alt for the lane's four consecutive keys key0 .. key0 + 3 of score-matrix row `rowhash` (two pair mixes)
+__device__ __forceinline__ void drop_select4(const DropDev& dd, uint32_t rowhash, int key0, f32x4& x, float alt) {
+  const uint32_t base = rowhash + afm_pair_offset((uint32_t)key0 >> 1);
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    const uint32_t hh = afm_pair_mix(base + (uint32_t)p * AFM_PAIR_STRIDE);
+    x[2 * p] = (hh & 0xFFFFu) >= dd.thresh16 ? x[2 * p] : alt;
+    x[2 * p + 1] = (hh >> 16) >= dd.thresh16 ? x[2 * p + 1] : alt;
+  }
+}
+
+template <int DROP>
+__global__ __launch_bounds__(256, 3) void k_attn_bwd_dq_m16(AttnM a, const e16* __restrict__ Q,
+                                                         const e16* __restrict__ K,
+                                                         const e16* __restrict__ V,
+                                                         const e16* __restrict__ O,
+                                                         const e16* __restrict__ dO,
+                                                         const float* __restrict__ lse,
+                                                         float* __restrict__ delta, e16* __restrict__ dQ) {
+  static_assert(DROP == DROP_NONE || DROP == DROP_HASH, "the keep-bit tensor belongs to the 32x32 layout");
+  constexpr int STAGE = 3 * KT * DH * 2;   // K row image, K tr image, V row image
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  unsigned long long* maskw = (unsigned long long*)(lds + RS * STAGE);
+  const int t = threadIdx.x, lane = t & 63, g = lane >> 4, c16 = lane & 15;
+  const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+  const AttnBlock blk_ = attn_block(a.H, a.B, (a.Tq + 127) / 128);
+  const int hd = blk_.hd, b = blk_.b;
+  const int q0 = blk_.xb * 128 + w * 32;
+  const e16* Kb = K + (int64_t)b * a.Tk * a.ldk + hd * DH;
+  const e16* Vb = V + (int64_t)b * a.Tk * a.ldv + hd * DH;
+  int q[2], qc[2];
+  int64_t lrow[2];
+  e16x8 qf[2][2], dof[2][2];
+  float nL2[2], ndl[2];
+  uint32_t rowbase[2];
+#pragma unroll
+  for (int qi = 0; qi < 2; ++qi) {
+    q[qi] = q0 + 16 * qi + c16;
+    qc[qi] = q[qi] < a.Tq ? q[qi] : a.Tq - 1;
+    const e16* qp = Q + ((int64_t)b * a.Tq + qc[qi]) * a.ldq + hd * DH + 8 * g;
+    const e16* dop = dO + ((int64_t)b * a.Tq + qc[qi]) * a.ldo + hd * DH + 8 * g;
+    const e16* op = O + ((int64_t)b * a.Tq + qc[qi]) * a.ldo + hd * DH + 8 * g;
+    float dl = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      qf[qi][ks] = ld8_once(qp + 32 * ks);
+      dof[qi][ks] = ld8_once(dop + 32 * ks);
+      const e16x8 ov = ld8_once(op + 32 * ks);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) dl += (float)dof[qi][ks][j] * (float)ov[j];
+    }
+    dl += __shfl_xor(dl, 16, 64);
+    dl += __shfl_xor(dl, 32, 64);
+    lrow[qi] = ((int64_t)b * a.H + hd) * a.Tq + qc[qi];
+    if (q[qi] < a.Tq && g == 0) delta[lrow[qi]] = -dl;      // the workspace holds -delta (the dK/dV kernel starts its dP accumulators from it)
+    const float L = lse[lrow[qi]];
+    nL2[qi] = L == INFINITY ? -INFINITY : -L * 1.4426950408889634f;
+    ndl[qi] = -dl;
+    rowbase[qi] = afm_row_hash(a.dd, (uint64_t)lrow[qi]);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        qf[qi][ks][j] = (e16)((float)qf[qi][ks][j] * a.scale_log2);
+        if (DROP != DROP_NONE) dof[qi][ks][j] = (e16)((float)dof[qi][ks][j] * a.dd.scale16);
+      }
+  }
+  f32x4 dq[4][2];
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+    for (int qi = 0; qi < 2; ++qi) dq[dt][qi] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  int kend = a.Tk;
+  if (a.causal) kend = min(a.Tk, blk_.xb * 128 + 128);
+  const int ntiles = (kend + KT - 1) / KT;
+  build_mask_words(maskw, a.key_pad, b, a.Tk, ntiles, w, lane);
+  bool wave_qskip = false;
+  if (a.qskip) {                       // (the caller vouches for key_pad and for zero dO at padded query rows)
+    bool lane_pad = true;
+#pragma unroll
+    for (int qi = 0; qi < 2; ++qi) lane_pad = lane_pad && (q[qi] >= a.Tq || a.key_pad[(int64_t)b * a.Tk + qc[qi]] != 0);
+    wave_qskip = __all(lane_pad);
+  }
+  int* const tl = (int*)(maskw + (a.Tk + KT - 1) / KT) + 1;      // key tiles with at least one real key
+  auto store_dq = [&](bool zeros) {
+#pragma unroll
+    for (int qi = 0; qi < 2; ++qi)
+      if (q[qi] < a.Tq) {
+        e16* dqp = dQ + ((int64_t)b * a.Tq + q[qi]) * a.lddq + hd * DH + 4 * g;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+          e16x4 v = {(e16)0.f, (e16)0.f, (e16)0.f, (e16)0.f};
+          if (!zeros) v = (e16x4){(e16)(dq[dt][qi][0] * a.scale), (e16)(dq[dt][qi][1] * a.scale), (e16)(dq[dt][qi][2] * a.scale), (e16)(dq[dt][qi][3] * a.scale)};
+          *(e16x4*)(dqp + 16 * dt) = v;
+        }
+      }
+  };
+  if (__syncthreads_and(wave_qskip)) {   // all 128 queries of the workgroup are padding: their dQ rows are zeros, nothing to load
+    store_dq(true);
+    return;
+  }
+  build_tile_list(tl, a.key_pad ? maskw : nullptr, 0, ntiles, w, lane);
+  __syncthreads();   // retires the plain loads / the delta store before the LDS-DMA ring starts
+  const int nlive = __builtin_amdgcn_readfirstlane(tl[-1]);
+  auto issue = [&](int j) {
+    unsigned char* st = lds + (j % RS) * STAGE;
+    const int kt = tl[j];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      dma_piece<false>(st, Kb, a.ldk, kt * KT, a.Tk, w + 4 * u, lane);
+      dma_piece_tr16(st + KT * DH * 2, Kb, a.ldk, kt * KT, a.Tk, w + 4 * u, lane);
+      dma_piece<false>(st + 2 * KT * DH * 2, Vb, a.ldv, kt * KT, a.Tk, w + 4 * u, lane);
+    }
+  };
+#pragma unroll
+  for (int s = 0; s < RS - 1; ++s)
+    if (s < nlive) issue(s);
+  __builtin_assume(nlive >= 1);
+  // transposed reads of the K image: lane (g, qq, p) supplies row 4 g + qq (+ the block's first row, + 16 for the second read), columns
+  // 16 dt + 4 p .. + 3 of d-tile dt: chunk 2 dt + (p >> 1) at position chunk ^ sw, sw = (2 (g & 1) + (qq >> 1)) << 1, i.e. the chunk PAIR
+  // dt ^ (sw >> 1): one lane address per d-tile, the rows as immediates
+  unsigned tra[4];
+  {
+    const int qq = (lane >> 2) & 3, p = lane & 3;
+    const int s2 = 2 * (g & 1) + (qq >> 1);
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) tra[dt] = (4 * g + qq) * 128 + ((2 * (dt ^ s2) + (p >> 1)) << 4) + ((p & 1) << 3);
+  }
+  for (int j = 0; j < nlive; ++j) {
+    const int kt = __builtin_amdgcn_readfirstlane(tl[j]);
+    const int kb = kt * KT;
+    if (nlive - 1 - j >= RS - 2) attn_wait_vmcnt<6 * (RS - 2)>(); else attn_wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    if (j + RS - 1 < nlive) issue(j + RS - 1);
+    if ((a.causal && kb > q0 + 31) || maskw[kt] == ~0ull || wave_qskip) continue;   // above the diagonal / all-padding key tile / all-padding queries
+    const unsigned char* Krow = lds + (j % RS) * STAGE;
+    const unsigned ktr = (unsigned)(uintptr_t)(Krow + KT * DH * 2);
+    const unsigned char* Vrow = Krow + 2 * KT * DH * 2;
+    const unsigned long long mword = maskw[kt];
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk) {
+      f32x4 s[2][2], dp[2][2];
+#pragma unroll
+      for (int ki = 0; ki < 2; ++ki)
+#pragma unroll
+        for (int qi = 0; qi < 2; ++qi) {
+          s[ki][qi] = (f32x4){nL2[qi], nL2[qi], nL2[qi], nL2[qi]};
+          dp[ki][qi] = (f32x4){ndl[qi], ndl[qi], ndl[qi], ndl[qi]};
+        }
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int ki = 0; ki < 2; ++ki) {
+          const e16x8 kfr = frag_row16(Krow, 32 * blk + 16 * ki, ks, lane);
+          const e16x8 vfr = frag_row16(Vrow, 32 * blk + 16 * ki, ks, lane);
+#pragma unroll
+          for (int qi = 0; qi < 2; ++qi) {
+            s[ki][qi] = mfma16(kfr, qf[qi][ks], s[ki][qi]);
+            dp[ki][qi] = mfma16(vfr, dof[qi][ks], dp[ki][qi]);
+          }
+        }
+      if (DROP == DROP_HASH) {
+#pragma unroll
+        for (int ki = 0; ki < 2; ++ki)
+#pragma unroll
+          for (int qi = 0; qi < 2; ++qi) drop_select4(a.dd, rowbase[qi], kb + 32 * blk + 16 * ki + 4 * g, dp[ki][qi], ndl[qi]);
+      }
+      if (mword != 0ull || (a.causal && (kb + KT - 1 > q0))) {   // wave-uniform: tile has masked keys
+#pragma unroll
+        for (int ki = 0; ki < 2; ++ki)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int ko = 32 * blk + 16 * ki + 4 * g + r;
+            const bool pad = (mword >> ko) & 1ull;
+#pragma unroll
+            for (int qi = 0; qi < 2; ++qi) {
+              bool msk = pad;
+              if (a.causal) msk = msk || (kb + ko > q[qi]);
+              s[ki][qi][r] = msk ? -INFINITY : s[ki][qi][r];
+            }
+          }
+      }
+#pragma unroll
+      for (int ki = 0; ki < 2; ++ki)
+#pragma unroll
+        for (int qi = 0; qi < 2; ++qi)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) s[ki][qi][r] = fast_exp2(s[ki][qi][r]) * dp[ki][qi][r];   // dS^T = P (D dP - delta)
+      {
+        s16x4 lo[4], hi[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+          const unsigned ad = ktr + tra[dt];
+          if (blk == 0) { AFM_TR_RD(lo[dt], ad, 0); AFM_TR_RD(hi[dt], ad, 2048); }
+          else { AFM_TR_RD(lo[dt], ad, 4096); AFM_TR_RD(hi[dt], ad, 6144); }
+        }
+        const e16x8 ds0 = cvt8_2x4(s[0][0], s[1][0]), ds1 = cvt8_2x4(s[0][1], s[1][1]);
+        tr_wait<4>();
+        dq[0][0] = mfma16(tr_join(lo[0], hi[0]), ds0, dq[0][0]);
+        dq[0][1] = mfma16(tr_join(lo[0], hi[0]), ds1, dq[0][1]);
+        dq[1][0] = mfma16(tr_join(lo[1], hi[1]), ds0, dq[1][0]);
+        dq[1][1] = mfma16(tr_join(lo[1], hi[1]), ds1, dq[1][1]);
+        tr_wait<0>();
+        dq[2][0] = mfma16(tr_join(lo[2], hi[2]), ds0, dq[2][0]);
+        dq[2][1] = mfma16(tr_join(lo[2], hi[2]), ds1, dq[2][1]);
+        dq[3][0] = mfma16(tr_join(lo[3], hi[3]), ds0, dq[3][0]);
+        dq[3][1] = mfma16(tr_join(lo[3], hi[3]), ds1, dq[3][1]);
+      }
+    }
+  }
+  store_dq(false);
+}

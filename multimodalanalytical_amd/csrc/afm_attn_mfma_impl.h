@@ -1022,6 +1022,8 @@ __global__ __launch_bounds__(256) void k_attn_bits_fill(AttnM a) {
 }  // namespace AFM_E16_NS
 using namespace AFM_E16_NS;
 
+#include "afm_attn_m16_impl.h"
+
 // ------------------------------------------------------------------------------------------ dispatch
 static bool eligible(const afm_attn_shape* s, const void* const* ptrs, int nptr, const int* lds, int nld) {
   if (s->dtype != AFM_E16 || s->dh != DH) return false;
@@ -1129,6 +1131,15 @@ int AFM_E16_FN(afm_attn_bwd_mfma_try)(const afm_attn_shape* s, const void* Q, co
     else AFM_LAUNCH(k_attn_bwd_dq_st<DROP_NONE>, gq8, dim3(512), shm_q8, st, a, (const e16*)Q, (const e16*)K, (const e16*)V, (const e16*)O, (const e16*)dO, lse, delta, (e16*)dQ);
   }
   else if (!run_q) {}
+  else if ((s->reserved & 1024) && !(a.dd.thresh16 && a.bits)) {     // the 16x16x32 form of the dQ kernel (afm_attn_m16_impl.h: an A/B test, never the default)
+    static AfmOncePerDevice attr_q16;
+    if (attr_q16.need()) {
+      (void)hipFuncSetAttribute((const void*)k_attn_bwd_dq_m16<DROP_HASH>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+      (void)hipFuncSetAttribute((const void*)k_attn_bwd_dq_m16<DROP_NONE>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    }
+    if (a.dd.thresh16) AFM_LAUNCH(k_attn_bwd_dq_m16<DROP_HASH>, gq, dim3(256), shm_q, st, a, (const e16*)Q, (const e16*)K, (const e16*)V, (const e16*)O, (const e16*)dO, lse, delta, (e16*)dQ);
+    else AFM_LAUNCH(k_attn_bwd_dq_m16<DROP_NONE>, gq, dim3(256), shm_q, st, a, (const e16*)Q, (const e16*)K, (const e16*)V, (const e16*)O, (const e16*)dO, lse, delta, (e16*)dQ);
+  }
   else if (a.dd.thresh16 && a.bits) AFM_LAUNCH(k_attn_bwd_dq_mfma<DROP_BITS>, gq, dim3(256), shm_q, st, a, (const e16*)Q, (const e16*)K, (const e16*)V, (const e16*)O, (const e16*)dO, lse, delta, (e16*)dQ);
   else if (a.dd.thresh16) AFM_LAUNCH(k_attn_bwd_dq_mfma<DROP_HASH>, gq, dim3(256), shm_q, st, a, (const e16*)Q, (const e16*)K, (const e16*)V, (const e16*)O, (const e16*)dO, lse, delta, (e16*)dQ);
   else AFM_LAUNCH(k_attn_bwd_dq_mfma<DROP_NONE>, gq, dim3(256), shm_q, st, a, (const e16*)Q, (const e16*)K, (const e16*)V, (const e16*)O, (const e16*)dO, lse, delta, (e16*)dQ);

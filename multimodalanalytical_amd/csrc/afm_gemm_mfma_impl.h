@@ -69,7 +69,7 @@ __device__ __forceinline__ void epilogue4(const MfmaArgs& g, int m, int n0, f32x
       else u = *(const f32x4*)((const float*)g.pre_act + ci);
 #pragma unroll
       for (int r = 0; r < 4; ++r)
-        v[r] = afm_drop(g.dd, (uint64_t)m * (uint64_t)g.N + (uint64_t)(n0 + r), v[r]) * afm_gelu_grad(u[r]);
+        v[r] = afm_drop(g.dd, (uint64_t)m * (uint64_t)g.N + (uint64_t)(n0 + r), v[r]) * afm_gelu_grad_o<C_BF16>(u[r]);
     } else {
       if (g.pre_act) {
         if (C_BF16) { e16x4 o = {(e16)v[0], (e16)v[1], (e16)v[2], (e16)v[3]}; *(e16x4*)((e16*)g.pre_act + ci) = o; }
@@ -79,7 +79,7 @@ __device__ __forceinline__ void epilogue4(const MfmaArgs& g, int m, int n0, f32x
       for (int r = 0; r < 4; ++r) {
         float x = v[r];
         if (g.act == AFM_ACT_RELU) x = fmaxf(x, 0.f);
-        else if (g.act == AFM_ACT_GELU) x = afm_gelu(x);
+        else if (g.act == AFM_ACT_GELU) x = afm_gelu_o<C_BF16>(x);
         v[r] = afm_drop(g.dd, (uint64_t)m * (uint64_t)g.N + (uint64_t)(n0 + r), x);
       }
     }
@@ -101,11 +101,11 @@ __device__ __forceinline__ void epilogue4(const MfmaArgs& g, int m, int n0, f32x
     if (g.bias) x += g.bias[n];
     if (g.act == AFM_ACT_GELU_BWD) {
       const float u = C_BF16 ? (float)((const e16*)g.pre_act)[ci + r] : ((const float*)g.pre_act)[ci + r];
-      x = afm_drop(g.dd, (uint64_t)m * (uint64_t)g.N + (uint64_t)n, x) * afm_gelu_grad(u);
+      x = afm_drop(g.dd, (uint64_t)m * (uint64_t)g.N + (uint64_t)n, x) * afm_gelu_grad_o<C_BF16>(u);
     } else {
       if (g.pre_act) { if (C_BF16) ((e16*)g.pre_act)[ci + r] = (e16)x; else ((float*)g.pre_act)[ci + r] = x; }
       if (g.act == AFM_ACT_RELU) x = fmaxf(x, 0.f);
-      else if (g.act == AFM_ACT_GELU) x = afm_gelu(x);
+      else if (g.act == AFM_ACT_GELU) x = afm_gelu_o<C_BF16>(x);
       x = afm_drop(g.dd, (uint64_t)m * (uint64_t)g.N + (uint64_t)n, x);
     }
     if (g.residual) x += C_BF16 ? (float)((const e16*)g.residual)[ci + r] : ((const float*)g.residual)[ci + r];
@@ -126,7 +126,7 @@ __device__ __forceinline__ void epilogue4_full(const MfmaArgs& g, int m, int n0,
     else u = *(const f32x4*)((const float*)g.pre_act + ci);
 #pragma unroll
     for (int r = 0; r < 4; ++r)
-      v[r] = afm_drop(g.dd, (uint64_t)m * (uint64_t)g.N + (uint64_t)(n0 + r), v[r]) * afm_gelu_grad(u[r]);
+      v[r] = afm_drop(g.dd, (uint64_t)m * (uint64_t)g.N + (uint64_t)(n0 + r), v[r]) * afm_gelu_grad_o<C_BF16>(u[r]);
   } else if (g.pre_act) {
     if (C_BF16) { e16x4 o = {(e16)v[0], (e16)v[1], (e16)v[2], (e16)v[3]}; *(e16x4*)((e16*)g.pre_act + ci) = o; }
     else *(f32x4*)((float*)g.pre_act + ci) = v;
@@ -136,7 +136,7 @@ __device__ __forceinline__ void epilogue4_full(const MfmaArgs& g, int m, int n0,
     for (int r = 0; r < 4; ++r) {
       float x = v[r];
       if (g.act == AFM_ACT_RELU) x = fmaxf(x, 0.f);
-      else if (g.act == AFM_ACT_GELU) x = afm_gelu(x);
+      else if (g.act == AFM_ACT_GELU) x = afm_gelu_o<C_BF16>(x);
       v[r] = afm_drop(g.dd, (uint64_t)m * (uint64_t)g.N + (uint64_t)(n0 + r), x);
     }
   }
@@ -300,7 +300,7 @@ __device__ __forceinline__ void epilogue_staged(const MfmaArgs& g, float* stg, c
         if (g.act == AFM_ACT_GELU_BWD) {
           const e16x8 u = uu[i * 2 + hf];
 #pragma unroll
-          for (int k = 0; k < 8; ++k) x[k] = x[k] * kp8[k] * afm_gelu_grad((float)u[k]);
+          for (int k = 0; k < 8; ++k) x[k] = x[k] * kp8[k] * afm_gelu_grad16((float)u[k]);
         } else {
           if (g.pre_act) {
             e16x8 o = {(e16)x[0], (e16)x[1], (e16)x[2], (e16)x[3], (e16)x[4], (e16)x[5], (e16)x[6], (e16)x[7]};
@@ -311,7 +311,7 @@ __device__ __forceinline__ void epilogue_staged(const MfmaArgs& g, float* stg, c
             for (int k = 0; k < 8; ++k) {
               float y = x[k];
               if (g.act == AFM_ACT_RELU) y = fmaxf(y, 0.f);
-              else if (g.act == AFM_ACT_GELU) y = afm_gelu(y);
+              else if (g.act == AFM_ACT_GELU) y = afm_gelu16(y);
               x[k] = y * kp8[k];
             }
           }
@@ -479,7 +479,7 @@ __device__ __forceinline__ void epilogue_staged_e16(const MfmaArgs& g, float* st
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
           float y, yp;
-          afm_gelu_both(x[k], y, yp);
+          afm_gelu_both16(x[k], y, yp);
           const float keep = kp[k];
           gv[k] = y * x[4 + k] * keep; sa[k] = yp * x[4 + k] * keep; sb[k] = y * keep;
         }
@@ -514,7 +514,7 @@ __device__ __forceinline__ void epilogue_staged_e16(const MfmaArgs& g, float* st
           store16_policy<CAUX>(g.pre_act, (uint64_t)((pbase + ro - (e16*)g.pre_act) * 2), __builtin_bit_cast(uint4, o));
         }
 #pragma unroll
-        for (int k = 0; k < 8; ++k) x[k] = afm_gelu(x[k]);
+        for (int k = 0; k < 8; ++k) x[k] = afm_gelu16(x[k]);
       }
       if (EPI == EPI_GELU_SG) {
         float gp[8], kp[8];
@@ -522,7 +522,7 @@ __device__ __forceinline__ void epilogue_staged_e16(const MfmaArgs& g, float* st
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
           float y, yp;
-          afm_gelu_both(x[k], y, yp);
+          afm_gelu_both16(x[k], y, yp);
           x[k] = y * kp[k]; gp[k] = yp * kp[k];
         }
         e16x8 o = {(e16)gp[0], (e16)gp[1], (e16)gp[2], (e16)gp[3], (e16)gp[4], (e16)gp[5], (e16)gp[6], (e16)gp[7]};
@@ -541,10 +541,10 @@ __device__ __forceinline__ void epilogue_staged_e16(const MfmaArgs& g, float* st
           float kp[8];
           afm_keep_scale32<8, true>(g.dd, di, kp);
 #pragma unroll
-          for (int k = 0; k < 8; ++k) x[k] = x[k] * kp[k] * afm_gelu_grad((float)u[k]);
+          for (int k = 0; k < 8; ++k) x[k] = x[k] * kp[k] * afm_gelu_grad16((float)u[k]);
         } else {
 #pragma unroll
-          for (int k = 0; k < 8; ++k) x[k] *= afm_gelu_grad((float)u[k]);
+          for (int k = 0; k < 8; ++k) x[k] *= afm_gelu_grad16((float)u[k]);
         }
       } else if ((EPI == EPI_DROP || EPI == EPI_GELU) && drop_on) {
         float kp[8];
@@ -1040,6 +1040,7 @@ static int launch_nt_ws(MfmaArgs& g, hipStream_t st) {
 }
 
 #include "afm_gemm_pp_impl.h"
+#include "afm_gemm_w4_impl.h"
 
 // ------------------------------------------------------------------------------------------ TN (wgrad)
 // C[m][n] += sum_k A[k][m] B[k][n]: A is dy (rows = tokens, cols = output features m), B is x
@@ -1628,8 +1629,16 @@ int AFM_E16_FN(afm_gemm_mfma_try)(const afm_gemm_desc* d, hipStream_t st) {
     // 64-row-tile problems (the decoder's 16 384 rows) lose: too few tiles for a 256-CU chip.
     if (d->reserved == 0 && (variant == 24 || variant == 28) && d->act == AFM_ACT_NONE && !d->pre_act && d->drop.p <= 0.f &&
         !d->residual && !d->accumulate && d->c_dtype == AFM_E16 && !(d->M & 255) && !(d->N & 255) && !(d->K & 63) && d->K >= 128 &&
-        !(d->ldc % 8) && d->N <= PP_BIAS_MAX && (int64_t)(d->M >> 8) * (d->N >> 8) >= 512 && (d->K >= 1024 || d->N >= 1024))
+        !(d->ldc % 8) && d->N <= PP_BIAS_MAX && (int64_t)(d->M >> 8) * (d->N >> 8) >= 512 && (d->K >= 768 || d->N >= 1024))
+    {
       variant = (d->K & 127) ? 30 : 32;      // balanced phases where the K-tile count is even (+1 .. 5 % on most shapes, two runs)
+      // K >= 768: four waves of 128 x 128 with the overlap inside the wave (afm_gemm_w4_impl.h; bit-identical to the ping-pong kernel).
+      // One box, one process, order swapped between two rounds (tools/experiments/w4_gemm.py, fp16, M = 131 072): N 512 / K 2048 233-235 us
+      // vs 240-244, N 512 / K 1536 183 vs 189, c4's N 768 / K 3072 486-488 vs 502-510, N 768 / K 2304 375 vs 387-391, N 768 / K 6144 937 vs
+      // 969-988 (-3 .. 4 %); its K = 768 products 0 .. 2 % ahead (400 vs 402-411, 266 vs 268-275, 535 vs 541-548); K = 512 stays where it was
+      // (196-221 vs 195-201 at N 1536: the epilogue, which all four waves reach together, weighs too much there).
+      if (!(d->K & 127) && d->K >= 768 && d->N <= W4_BIAS_MAX) variant = 40;
+    }
     if (d->act >= AFM_ACT_GELU_SAVE_GRAD && variant != 24 && variant != 28) return AFM_ERR_UNSUPPORTED;
     int r;
 #define NT_CASE(WM, WN, NWM, NWN, BKT) \
@@ -1657,6 +1666,17 @@ int AFM_E16_FN(afm_gemm_mfma_try)(const afm_gemm_desc* d, hipStream_t st) {
             d->accumulate || d->act != AFM_ACT_NONE || d->pre_act || d->drop.p > 0.f || (d->ldc % 8)) { r = AFM_ERR_UNSUPPORTED; break; }
         r = launch_nt_pp<EPI_PLAIN>(g, st);
         break;
+      case 40:   // four waves of 128 x 128 with the overlap inside the wave (afm_gemm_w4_impl.h): whole tiles, K % 128 == 0, plain (+ bias)
+        if ((d->K & 127) || d->K < 256 || (d->M & 255) || (d->N & 255) || d->N > W4_BIAS_MAX || d->c_dtype != AFM_E16 || d->residual ||
+            d->accumulate || d->act != AFM_ACT_NONE || d->pre_act || d->drop.p > 0.f || (d->ldc % 8)) { r = AFM_ERR_UNSUPPORTED; break; }
+        r = launch_nt_w4<0>(g, st);
+        break;
+#ifdef AFM_GEMM_ABLATIONS
+      case 401: r = launch_nt_w4<1>(g, st); break;
+      case 402: r = launch_nt_w4<2>(g, st); break;
+      case 404: r = launch_nt_w4<4>(g, st); break;
+      case 406: r = launch_nt_w4<6>(g, st); break;
+#endif
       case 33:   // (A/B partner of 30: one barrier per phase)
       case 34:   // (one barrier per phase + balanced phases; K % 128 == 0)
         if ((d->K & (variant == 34 ? 127 : 63)) || d->K < 128 || (d->M & 255) || (d->N & 255) || d->N > PP_BIAS_MAX || d->c_dtype != AFM_E16 ||
@@ -1737,7 +1757,7 @@ int AFM_E16_FN(afm_gemm_mfma_try)(const afm_gemm_desc* d, hipStream_t st) {
 #undef PRING_CASE
 #undef NT_CASE
     if (r != AFM_OK) return r;
-    afm_set_last_algo(variant == 28 ? "mfma_nt_256" : (variant >= 30 && variant <= 34) ? "mfma_nt_pp" : "mfma_nt");     // (_256: the 256 x 256-tile form)
+    afm_set_last_algo(variant == 28 ? "mfma_nt_256" : (variant >= 30 && variant <= 34) ? "mfma_nt_pp" : (variant == 40 || variant / 100 == 4) ? "mfma_nt_w4" : "mfma_nt");     // (_256: the 256 x 256-tile form)
     return AFM_OK;
   }
   if (d->transA && !d->transB) {  // TN: the wgrad form only

@@ -1,0 +1,329 @@
+// Four-wave NT GEMM for gfx950 (included by afm_gemm_mfma_impl.h inside namespace AFM_E16_NS): C[m][n] = sum_k A[m][k] B[n][k] + bias[n],
+// 16-bit operands, fp32 accumulate, e16 output, whole 256 x 256 tiles, persistent over the tiles of an XCD.  Round 5 (VERDICT r04
+// item 4; DESIGN.md 4.0r4 item 9: the library's long-K kernel is built this way).
+//
+// One wave per SIMD owns 128 x 128 of the tile in 256 accumulator registers (the whole 512-register file of its SIMD is its own):
+//   * a 64-deep K-tile costs a wave 32 fragment reads for 128 MFMAs (16x16x32) -- the ping-pong kernel's 128 x 64 waves read 24 for 64:
+//     a third fewer LDS bytes per MFMA, which is what the power-limited loop is priced in;
+//   * nothing alternates between waves: the overlap is INSIDE the wave.  A phase = 32 MFMAs on one 64 x 64 quadrant of the wave's
+//     block over the K-tile, and between those MFMAs the wave issues the 8 fragment reads of the NEXT phase (into the register set
+//     the previous phase retired) and its 4 LDS-DMA pieces; one barrier per phase (~ every 32 MFMAs);
+//   * the K-tile is staged as FOUR 16-KB sub-blocks in the order the phases consume them, the ping-pong kernel's ring (8 sub-blocks,
+//     128 KB) with one sub-block read per phase:
+//       K-tile T, parity p = T & 1:   stream position 0: a0 (tile rows 0-63 | 128-191)     1: bF     2: bS     3: a1 (rows 64-127 | 192-255)
+//       with (bF, bS) = (b0, b1) for even T and (b1, b0) for odd T  (b0 = tile cols 0-63 | 128-191, b1 = cols 64-127 | 192-255).
+//     MFMA phases of K-tile T: (a0, bF) (a0, bS) (a1, bS) (a1, bF): every phase changes ONE operand set, and the set it retires is
+//     exactly the one the stream needs next -- a0 of T + 1 goes where a0 of T was, bF of T + 1 (= the OTHER b half) where bS of T was:
+//     four register sets of 8 fragments (128 registers), each read once per K-tile.  Needs an even number of K-tiles per tile.
+//   * sub-block g = 4 T + j of the stream is READ in phase g - 2 (global phase P = 4 T + q) and its ring slot (g mod 8) is free at the
+//     barrier that ends that phase; phase P ISSUES sub-block P + 9 into the slot sub-block P + 1 left (read in phase P - 1).  At its
+//     end every phase waits until all but the vector-memory operations of the last six phases have landed (24 pieces; the 32 stores
+//     of an epilogue sit in the same in-order counter), i.e. for the pieces of sub-block P + 3, which phase P + 1 reads: ~6 phases
+//     (~1.5 us) of flight time for every piece, across tile boundaries.
+//   * Epilogue per wave: accumulators (bias is their initial value) -> e16 -> wave-private LDS patch (16 rows x 64 columns) ->
+//     16-byte nontemporal stores of whole 128-byte lines.  All four waves reach it together: this kernel is for long K (the
+//     dispatcher sends K >= 1024), where the epilogue is a few per cent of the tile.
+// Every LDS access behind the first LDS-DMA piece is inline asm (a compiler-visible LDS access beside an LDS-DMA in flight is answered
+// with s_waitcnt vmcnt(0), which would drain the ring): fragment reads, the bias, the patch, the tile list.
+// ABL (timing builds): 1 no MFMAs, 2 no LDS-DMA, 4 no epilogue.
+
+#define W4_SUB 16384              // bytes of one sub-block: 128 rows x 128 B
+#define W4_RING (8 * W4_SUB)
+#define W4_PATCH_LD 144           // bytes per staged row (128 + 16)
+#define W4_PATCH (16 * W4_PATCH_LD)
+#define W4_BIAS_OFF (W4_RING + 4 * W4_PATCH)
+#define W4_BIAS_MAX 3072          // floats of bias behind the patches
+#define W4_LIST_OFF (W4_BIAS_OFF + 4 * W4_BIAS_MAX)
+
+template <int N> __device__ __forceinline__ void w4_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+#define W4_RD(dst, base, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(base), "n"(off) : "memory")
+
+template <int ABL = 0>
+__global__ __launch_bounds__(256) void k_gemm_nt_w4(MfmaArgs g) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  const int t = threadIdx.x, lane = t & 63;
+  const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wr = w >> 1, wc = w & 1;
+  const int fr = lane & 15, fq = lane >> 4;
+  float* const bias_lds = (float*)(lds + W4_BIAS_OFF);
+  for (int n = t; n < g.N; n += 256) bias_lds[n] = g.bias ? g.bias[n] : 0.f;   // plain loads, retired before the first LDS-DMA piece
+  __syncthreads();
+
+  // tiles of this workgroup: XCD x owns [x * tpx, (x+1) * tpx), its workgroups stride through them together (k_gemm_nt_pring)
+  const int ntiles = g.tiles_m * g.tiles_n;
+  const int xcd = blockIdx.x & 7, bx = blockIdx.x >> 3, nbx = gridDim.x >> 3;
+  const int tpx = (ntiles + 7) >> 3;
+  const int tlo = xcd * tpx, thi = min(ntiles, tlo + tpx);
+  if (g.live_off) nt_tile_lists<256, 256, true, 256>(g, (int*)(lds + W4_LIST_OFF), tlo, thi, nbx, bx);   // (ends with a barrier)
+  const unsigned lds0 = (unsigned)(uintptr_t)lds;
+  auto lds_word = [&](int idx) -> int {      // word idx of the tile list, read by asm (see the header) and made scalar
+    unsigned v;
+    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v) : "v"(lds0 + W4_LIST_OFF + 4u * (unsigned)idx) : "memory");
+    return __builtin_amdgcn_readfirstlane((int)v);
+  };
+  const int nlist = g.live_off ? lds_word(0) : 0;
+  auto tile_of = [&](int it) -> int {
+    if (g.live_off) return it < nlist ? lds_word(1 + it) : -1;
+    const int tt = tlo + it * nbx + bx;
+    return tt < thi ? tt : -1;
+  };
+  const int nk = g.K >> 6;
+
+  // ---- LDS-DMA side: this wave's four pieces (8 rows x 128 B each) of every sub-block kind, as byte offsets from the tile's first
+  // A row / B row at the K-tile's first column.  LDS position (lane & 7) of row r8 holds the row's chunk (lane & 7) ^ r8.
+  // Piece h = 0 .. 3 of a wave covers sub-block rows 8 (w + 4 h) + r8, i.e. tile row (col) 8 w + r8 + {0, 32, 128, 160}[h] of half 0 and
+  // + 64 of half 1: ONE lane-dependent offset per operand (va, vb) and wave-uniform row offsets that go into the scalar base -- 16
+  // precomputed lane offsets did not fit beside 128 fragment registers (a spilled one is reloaded with s_waitcnt vmcnt(0), which drains
+  // the ring at every epilogue).
+  uint32_t va, vb;
+  {
+    const int r8 = lane >> 3, ch = (lane & 7) ^ r8;
+    va = (uint32_t)(8 * w + r8) * (uint32_t)g.lda * 2u + ch * 16;
+    vb = (uint32_t)(8 * w + r8) * (uint32_t)g.ldb * 2u + ch * 16;
+  }
+  const uint32_t lda2 = (uint32_t)g.lda * 2u, ldb2 = (uint32_t)g.ldb * 2u;
+#define W4_ROW(h) ((h) == 0 ? 0u : (h) == 1 ? 32u : (h) == 2 ? 128u : 160u)
+  // The issue stream.  Past its end it keeps re-issuing its LAST K-tile (`is_live` = 0: the pointers stay, the ring position keeps
+  // advancing): every slot it then writes has been read for the last time (the WAR argument of the header holds for any stream), the
+  // sources are valid memory and at most 9 sub-blocks (144 KB per workgroup) are fetched in vain -- for that the pieces are issued
+  // WITHOUT a branch, so a phase is one basic block and the per-phase count of vector-memory operations is a constant.
+  int is_it = 0, is_kt = 0, is_par = 0;
+  int is_tile = tile_of(0);
+  const char* is_a = nullptr;
+  const char* is_b = nullptr;
+  auto is_set = [&]() {
+    const int m0 = (is_tile / g.tiles_n) * 256, n0 = (is_tile % g.tiles_n) * 256;
+    is_a = (const char*)(g.A + (int64_t)m0 * g.lda + is_kt * 64);
+    is_b = (const char*)(g.B + (int64_t)n0 * g.ldb + is_kt * 64);
+  };
+  if (is_tile < 0) return;            // (the grid is rounded up to whole XCD groups: a workgroup may own no tile; uniform exit, no barrier pending)
+  is_set();
+  bool is_live = true;
+  auto is_advance = [&]() {           // next K-tile of the stream
+    is_par ^= 1;
+    if (!is_live) return;
+    if (is_kt + 1 == nk) {
+      const int nt = tile_of(is_it + 1);
+      if (nt < 0) { is_live = false; return; }
+      ++is_it; is_kt = 0; is_tile = nt; is_set();
+    } else { ++is_kt; is_a += 128; is_b += 128; }
+  };
+  // piece h of stream position j of the issue K-tile: `base` + `soff` scalar, `voff` the lane's offset
+  auto piece = [&](int j, const char* base, uint32_t soff, uint32_t voff, int h) {
+    if (ABL & 2) return;
+    unsigned char* dst = lds + (is_par * 4 + j) * W4_SUB + (w + 4 * h) * 1024;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + soff + voff),
+                                     (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+  };
+  // the four sub-block kinds: operand base, row offset of the half (scalar), lane offset
+#define W4_A0(h) is_a, W4_ROW(h) * lda2, va
+#define W4_A1(h) is_a, (W4_ROW(h) + 64u) * lda2, va
+#define W4_B0(h) is_b, W4_ROW(h) * ldb2, vb
+#define W4_B1(h) is_b, (W4_ROW(h) + 64u) * ldb2, vb
+
+  // ---- fragment reads (bytes inside a sub-block): row * 128 + ((chunk ^ (row & 7)) << 4), chunk = ks * 4 + fq; fragment rows are
+  // 16-aligned, so row & 7 = fr & 7 and the two k-slices differ by an XOR of 64 on a lane-constant term.
+  const unsigned swz0 = ((fq ^ (fr & 7)) << 4), swz1 = swz0 ^ 64;
+  const unsigned a_lane = lds0 + (wr * 64 + fr) * 128, b_lane = lds0 + (wc * 64 + fr) * 128;
+
+  // The MFMAs of this kernel are inline asm with the accumulator as ONE tied "+a" operand: its 256 accumulators fill a[0:255] exactly,
+  // and left to hipcc (builtin MFMAs) the allocator unties destination and addend of some of them, runs out of accumulation registers
+  // and moves tiles through v_accvgpr copies behind s_nop 5 inside the loop (seen in the ISA: 48 registers, ~6 % of the loop).  What
+  // hipcc would otherwise pad is kept safe by construction: an accumulator is touched again 16 MFMAs later at the earliest; operands
+  // come from ds_reads retired by the previous phase's lgkmcnt(0); the initial v_accvgpr_writes are followed by explicit wait states;
+  // the epilogue's reads sit behind the last phase's barrier.
+#define W4_MFMA(ACC, FB, FA) asm volatile("v_mfma_f32_16x16x32_" AFM_E16_NAME " %0, %1, %2, %0" : "+a"(ACC) : "v"(FB), "v"(FA))
+  f32x4 acc[2][2][4][4];              // [row half][col half][i][j]
+  e16x8 fa0[4][2], fa1[4][2], fbx[4][2], fby[4][2];
+
+  // Every phase issues 4 pieces; an epilogue's 32 stores sit in the same in-order counter.  At the end of phase Q the pieces of phase
+  // Q - 6 must have landed: everything younger may stay in flight = 24 pieces, + 32 while an epilogue lies inside that window (the six
+  // phases that follow it).  (Early phases: fewer than 24 were issued, the wait is a no-op, and what they read the prologue waited for.)
+  int since_epi = 6;                  // phases ended since this wave's last epilogue
+  auto phase_end = [&]() {            // own reads complete; pieces of six phases ago landed; publish both
+    if (__builtin_expect(since_epi >= 6, 1)) w4_wait_vm<24>(); else w4_wait_vm<56>();
+    ++since_epi;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  // ---- prologue: sub-blocks 0 .. 7 of the stream (K-tiles 0 and 1), then the reads of "phases -2 and -1"
+#pragma unroll
+  for (int h = 0; h < 4; ++h) piece(0, W4_A0(h), h);
+#pragma unroll
+  for (int h = 0; h < 4; ++h) piece(1, W4_B0(h), h);
+#pragma unroll
+  for (int h = 0; h < 4; ++h) piece(2, W4_B1(h), h);
+#pragma unroll
+  for (int h = 0; h < 4; ++h) piece(3, W4_A1(h), h);
+  is_advance();
+#pragma unroll
+  for (int h = 0; h < 4; ++h) piece(0, W4_A0(h), h);
+#pragma unroll
+  for (int h = 0; h < 4; ++h) piece(1, W4_B1(h), h);
+#pragma unroll
+  for (int h = 0; h < 4; ++h) piece(2, W4_B0(h), h);
+#pragma unroll
+  for (int h = 0; h < 4; ++h) piece(3, W4_A1(h), h);
+  is_advance();
+  w4_wait_vm<0>();
+  __builtin_amdgcn_s_barrier();
+  {                                   // "phase -2": a0 of K-tile 0
+    const unsigned p0 = a_lane + swz0, p1 = a_lane + swz1;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { W4_RD(fa0[i][0], p0, i * 2048); W4_RD(fa0[i][1], p1, i * 2048); }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  {                                   // "phase -1": bF (= b0) of K-tile 0; sub-block 8 (a0 of K-tile 2) into the slot just read
+#pragma unroll
+    for (int h = 0; h < 4; ++h) piece(0, W4_A0(h), h);
+    const unsigned p0 = b_lane + swz0, p1 = b_lane + swz1;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { W4_RD(fbx[j][0], p0, W4_SUB + j * 2048); W4_RD(fbx[j][1], p1, W4_SUB + j * 2048); }
+    phase_end();
+  }
+
+  for (int it = 0;; ++it) {
+    const int tile = tile_of(it);
+    if (tile < 0) break;
+    const int m0 = (tile / g.tiles_n) * 256, n0 = (tile % g.tiles_n) * 256;
+    {  // accumulators start from the bias of their columns
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          f32x4 bv;
+          const unsigned ba = lds0 + W4_BIAS_OFF + (n0 + wc * 128 + c * 64 + j * 16 + fq * 4) * 4;
+          asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(bv) : "v"(ba) : "memory");
+#pragma unroll
+          for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[r][c][i][j] = bv;
+        }
+      asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");      // v_accvgpr_write -> MFMA addend wait states (the MFMAs are asm: nothing is padded for them)
+    }
+    // One phase: the 8 fragment reads of the next phase (`rd`: set, lane bases, immediate offset) and 4 LDS-DMA pieces (`pj`: stream
+    // position, base, offsets) spread over the 32 MFMAs of quadrant (r, c) with operand sets (fa, fb): 8 groups of 4 MFMAs, a read in
+    // front of each, a piece in front of every second.  sched_barrier(0) pins the interleave.
+#define W4_PHASE(RSET, RP0, RP1, ROFF, PJ, PKIND, R, C, FA, FB)                                                                 \
+    {                                                                                                                          \
+      _Pragma("unroll") for (int s = 0; s < 8; ++s) {                                                                          \
+        if (s & 1) W4_RD(RSET[s >> 1][1], RP1, ROFF + (s >> 1) * 2048); else W4_RD(RSET[s >> 1][0], RP0, ROFF + (s >> 1) * 2048); \
+        if (s & 1) piece(PJ, PKIND(s >> 1), s >> 1);                                                              \
+        if (!(ABL & 1)) {                                                                                                      \
+          const int ks = s >> 2, i = s & 3;                                                                                    \
+          _Pragma("unroll") for (int j = 0; j < 4; ++j) W4_MFMA(acc[R][C][i][j], FB[j][ks], FA[i][ks]);                               \
+        }                                                                                                                      \
+        __builtin_amdgcn_sched_barrier(0);                                                                                     \
+      }                                                                                                                        \
+    }
+#define W4_BF_0 W4_B0
+#define W4_BS_0 W4_B1
+#define W4_BF_1 W4_B1
+#define W4_BS_1 W4_B0
+    // K-tile T of parity PAR: bf = the B set that holds its first half (bF), bs = the other; both roles swap every K-tile.
+#define W4_KTILE(PAR, BF, BS)                                                                                                  \
+    {                                                                                                                          \
+      const unsigned so = (PAR) * 4 * W4_SUB, sn = ((PAR) ^ 1) * 4 * W4_SUB;                                                   \
+      const unsigned ao0 = a_lane + so + swz0, ao1 = a_lane + so + swz1, bo0 = b_lane + so + swz0, bo1 = b_lane + so + swz1;   \
+      const unsigned an0 = a_lane + sn + swz0, an1 = a_lane + sn + swz1, bn0 = b_lane + sn + swz0, bn1 = b_lane + sn + swz1;   \
+      /* phase 0: (a0, bF); reads bS of this K-tile (position 2); issues position 1 (bF) of K-tile T + 2 */                     \
+      W4_PHASE(BS, bo0, bo1, 2 * W4_SUB, 1, W4_BF_##PAR, 0, (PAR), fa0, BF)                                 \
+      phase_end();                                                                                                             \
+      /* phase 1: (a0, bS); reads a1 (position 3); issues position 2 (bS) of K-tile T + 2 */                                    \
+      W4_PHASE(fa1, ao0, ao1, 3 * W4_SUB, 2, W4_BS_##PAR, 0, (PAR) ^ 1, fa0, BS)                                 \
+      phase_end();                                                                                                             \
+      /* phase 2: (a1, bS); reads a0 of K-tile T + 1 (position 0 of the other ring half); issues position 3 (a1) of K-tile T + 2 */ \
+      W4_PHASE(fa0, an0, an1, 0, 3, W4_A1, 1, (PAR) ^ 1, fa1, BS)                                                          \
+      is_advance();                                                                                                            \
+      phase_end();                                                                                                             \
+      /* phase 3: (a1, bF); reads bF of K-tile T + 1 (its position 1) into the set bS left; issues position 0 (a0) of K-tile T + 3 */ \
+      W4_PHASE(BS, bn0, bn1, W4_SUB, 0, W4_A0, 1, (PAR), fa1, BF)                                                          \
+      phase_end();                                                                                                             \
+    }
+    for (int kt = 0; kt < nk; kt += 2) {
+      W4_KTILE(0, fbx, fby)
+      W4_KTILE(1, fby, fbx)
+    }
+
+    // ---------------- epilogue (wave-private patch; the ring keeps its pieces in flight)
+    if (ABL & 4) {
+      float sacc = 0.f;
+#pragma unroll
+      for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) sacc += acc[r][c][i][j][0] + acc[r][c][i][j][1] + acc[r][c][i][j][2] + acc[r][c][i][j][3];
+      if (sacc == 123.456f) ((float*)g.C)[0] = sacc;
+    } else {
+      // lane constants of the epilogue are recomputed per tile from an opaque copy of the lane id: hoisted out of the tile loop they are
+      // spilled around it, and a spill's reload comes with s_waitcnt vmcnt(0) -- the ring drained once per tile
+      int lane_e = lane;
+      asm volatile("" : "+v"(lane_e));
+      const int fr_e = lane_e & 15, fq_e = lane_e >> 4;
+      const unsigned patch = lds0 + W4_RING + w * W4_PATCH;
+      const int r8 = lane_e >> 3, c8 = (lane_e & 7) * 8;
+      const unsigned patch_w = patch + fr_e * W4_PATCH_LD + fq_e * 8;      // this lane's 4 columns of a fragment
+      const unsigned patch_r = patch + r8 * W4_PATCH_LD + c8 * 2;     // this lane's 16 bytes of rows r8, r8 + 8
+      typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+      e16* const cw = (e16*)g.C + (int64_t)(m0 + wr * 128 + r8) * g.ldc + n0 + wc * 128 + c8;
+#pragma unroll
+      for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int c = 0; c < 2; ++c) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const f32x4 v = acc[r][c][i][j];
+              const e16x4 o = {(e16)v[0], (e16)v[1], (e16)v[2], (e16)v[3]};
+              asm volatile("ds_write_b64 %0, %1 offset:%2" ::"v"(patch_w), "v"(__builtin_bit_cast(uint2_t, o)), "n"(j * 32) : "memory");
+            }
+            u32x4_t o0, o1;
+            asm volatile("s_waitcnt lgkmcnt(0)\n\tds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:%3\n\ts_waitcnt lgkmcnt(0)"
+                         : "=&v"(o0), "=&v"(o1) : "v"(patch_r), "n"(8 * W4_PATCH_LD) : "memory");
+            store16_policy<AFM_C_STORE_AUX>(cw, (uint64_t)(((int64_t)(r * 64 + i * 16) * g.ldc + c * 64) * 2), __builtin_bit_cast(uint4, o0));
+            store16_policy<AFM_C_STORE_AUX>(cw, (uint64_t)(((int64_t)(r * 64 + i * 16 + 8) * g.ldc + c * 64) * 2), __builtin_bit_cast(uint4, o1));
+          }
+      since_epi = 0;
+    }
+  }
+  w4_wait_vm<0>();                    // the pieces issued past the stream's end still target this workgroup's LDS: land them before it is given away
+#undef W4_MFMA
+#undef W4_ROW
+#undef W4_A0
+#undef W4_A1
+#undef W4_B0
+#undef W4_B1
+#undef W4_BF_0
+#undef W4_BS_0
+#undef W4_BF_1
+#undef W4_BS_1
+#undef W4_PHASE
+#undef W4_KTILE
+}
+
+template <int ABL = 0>
+static int launch_nt_w4(MfmaArgs& g, hipStream_t st) {
+  g.tiles_m = g.M / 256; g.tiles_n = g.N / 256;
+  int shm = W4_LIST_OFF;
+  g.live_off = 0;
+  const int ntiles = g.tiles_m * g.tiles_n;
+  int grid = 256;
+  if (grid > ((ntiles + 7) / 8) * 8) grid = ((ntiles + 7) / 8) * 8;
+  if (g.k_live) {
+    const int tpx0 = (ntiles + 7) / 8, nbx0 = grid / 8;
+    if ((tpx0 + nbx0 - 1) / nbx0 <= NT_LIVE_MAX) { g.live_off = W4_LIST_OFF; shm += NT_LIVE_BYTES; }
+  }
+  auto kern = k_gemm_nt_w4<ABL>;
+  static AfmOncePerDevice attr;
+  if (attr.need()) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  AFM_LAUNCH(kern, dim3(grid), dim3(256), shm, st, g);
+  return AFM_OK;
+}

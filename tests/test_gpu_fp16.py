@@ -80,9 +80,33 @@ def test_gemm_f16_nt_pingpong(ops, M, N, K, bias):
     assert torch.equal(c, c3)
 
 
-def test_gemm_f16_nt_pingpong_is_selected_and_takes_the_row_hint(ops):
-    """Automatic dispatch at a step-sized shape, and afm_gemm_desc.k_live through the kernel's tile lists (dead tiles written as zeros)."""
-    M, N, K = 65536, 512, 1536
+@pytest.mark.parametrize("M,N,K,bias,dt", [(256, 256, 256, True, H16), (512, 768, 384, True, H16), (256 * 37, 256 * 3, 640, True, H16),
+                                           (4096, 1024, 512, False, H16), (16384, 512, 2048, True, H16), (8192, 768, 3072, True, torch.bfloat16)])
+def test_gemm_nt_four_wave_kernel_is_bit_identical_to_the_pingpong_kernel(ops, M, N, K, bias, dt):
+    """The four-wave 256 x 256 kernel (variant 40, csrc/afm_gemm_w4_impl.h: 128 x 128 per wave, fragment prefetch and LDS-DMA between
+    the wave's own MFMAs, tied inline-asm MFMAs on a[0:255]): stream starts, tile boundaries, workgroups without a tile, tails past the
+    stream's end -- against fp64, bit-equal to the ping-pong kernel (same products, same accumulation order), same bits run to run."""
+    a, w = rnd(M, K, seed=1).to(dt), (rnd(N, K, seed=2) * 0.1).to(dt)
+    b = rnd(N, seed=3) if bias else None
+    c = torch.full((M, N), float("nan"), dtype=dt, device=DEV)
+    ops.gemm(dev(a), dev(w), c, bias=None if b is None else dev(b), variant=40)
+    assert ops.last_algo() == "mfma_nt_w4"
+    ref = a.double() @ w.double().T + (b.double() if bias else 0.0)
+    tol = 2e-3 if dt == H16 else 1.6e-2
+    close(c, ref, rtol=tol, atol=tol * math.sqrt(K) / 4)
+    c2 = torch.empty_like(c)
+    ops.gemm(dev(a), dev(w), c2, bias=None if b is None else dev(b), variant=30)
+    assert ops.last_algo() == "mfma_nt_pp" and torch.equal(c, c2)
+    c3 = torch.full_like(c, float("nan"))
+    ops.gemm(dev(a), dev(w), c3, bias=None if b is None else dev(b), variant=40)
+    assert torch.equal(c, c3)
+
+
+@pytest.mark.parametrize("K,algo", [(512, "mfma_nt_pp"), (1536, "mfma_nt_w4")])
+def test_gemm_f16_nt_pingpong_is_selected_and_takes_the_row_hint(ops, K, algo):
+    """Automatic dispatch at step-sized shapes (K = 512 with a wide N: the ping-pong kernel; K >= 768: the four-wave kernel), and
+    afm_gemm_desc.k_live through the kernels' tile lists (dead tiles written as zeros)."""
+    M, N = 65536, (1024 if K == 512 else 512)
     live = torch.ones(M // 64, dtype=torch.uint8)
     live[8:24] = 0; live[29] = 0; live[400:700] = 0; live[1000:] = 0
     rl = live.repeat_interleave(64).bool()
@@ -92,7 +116,7 @@ def test_gemm_f16_nt_pingpong_is_selected_and_takes_the_row_hint(ops):
     for hint in (None, dev(live)):
         c = torch.full((M, N), 3.0, dtype=H16, device=DEV)
         ops.gemm(ad, wd, c, k_live=hint)
-        assert ops.last_algo() == "mfma_nt_pp"
+        assert ops.last_algo() == algo
         outs.append(c)
     assert torch.equal(outs[0], outs[1])
     assert float(outs[1][~rl.to(DEV)].abs().max()) == 0.0
@@ -556,7 +580,7 @@ def test_nt_gemm_writes_padded_row_tiles_as_zeros(ops, N, K, act):
     for hint in (None, dev(live)):
         c = torch.full((M, N), 3.0, dtype=H16, device=DEV)
         ops.gemm(ad, wd, c, act=act, pre_act=pre, k_live=hint)
-        assert ops.last_algo() in ("mfma_nt", "mfma_nt_256", "mfma_nt_pp")
+        assert ops.last_algo() in ("mfma_nt", "mfma_nt_256", "mfma_nt_pp", "mfma_nt_w4")
         outs.append(c)
     assert torch.equal(outs[0], outs[1])
     assert float(outs[1][~rl.to(DEV)].abs().max()) == 0.0

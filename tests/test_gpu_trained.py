@@ -70,3 +70,72 @@ def test_trained_weights_fp16_ids_equal_the_cpu_oracle(name, B, steps, lr):
     assert torch.equal(ids[keep], rid[keep]), rec      # the ids the accuracy and the decode are made of: exactly equal
     assert float(sure[keep].double().mean()) >= 0.999, rec
     assert torch.equal(ids[sure], rid[sure]), rec
+
+
+def test_fp16_parity_after_training_with_dropout_on_held_in_and_held_out_samples():
+    """the regime the 1.4x margin of the fp16 logits bar had never seen.  A c2-shaped model is trained for 300
+    optimiser steps on 64 DISTINCT samples WITH dropout 0.1 (bf16x3-mixed, the parity-grade training mode), then the same weights run
+    an eval forward in fp16 and on the CPU oracle over 8 held-in and 8 held-out samples: logits within 1e-3 on both sets, ids equal
+    at every labelled held-in position (what the token accuracy and the decode are made of) and wherever the reference's top-2
+    margin exceeds twice the measured error.  Per-set counts go to gpurun_out/parity_records.jsonl."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from multimodalanalytical_amd import synth
+    from multimodalanalytical_amd.engine import Seq2SeqEngine
+    from multimodalanalytical_amd.modeling.wrapper import HFWrapper, SimpleTokenizerInfo
+    from multimodalanalytical_amd.trainer import TrainLoop
+    from multimodalanalytical_amd.x2 import X2
+    name, N, steps, lr = "c2", 64, 300, 5e-4
+    wl = synth.WORKLOADS[name]
+    V = wl["data"]["Smiles"]["vocab_size"]
+    cfg = dict(wl["cfg"])                                   # dropout 0.1 active while training
+    train_cpu, _ = synth.make_batch(name, N, seed=1234)
+    train = synth.to_device(train_cpu, DEV)
+    model = HFWrapper(wl["data"], "CustomModel", "facebook/bart-base", SimpleTokenizerInfo(V), optimiser="adamw", lr=lr,
+                      num_steps=steps + 1, device=DEV, compute_dtype=X2.dtype, backward_dtype=torch.bfloat16, seed=3,
+                      **{k: v for k, v in cfg.items() if k != "multimodal_norm"})
+    loop = TrainLoop(model, acc_batches=1)
+    first = None
+    for i in range(steps):
+        loss = loop.micro_batch(train)
+        if i == 0:
+            first = float(loss)
+    last = float(loss)
+    sd = {k: v.detach().float().cpu() for k, v in model.hf_model.engine.state_dict().items()}
+    del model, loop
+    torch.cuda.empty_cache()
+    ecfg = dict(cfg, dropout=0.0)                           # eval forward: no dropout on either side
+    eng = Seq2SeqEngine(ecfg, wl["data"], "Smiles", V, device=DEV, compute_dtype=torch.float16, seed=5)
+    eng.load_state_dict(sd)
+    to = lambda x: {k: to(v) for k, v in x.items()} if isinstance(x, dict) else x.to(DEV)
+    held_out, _ = synth.make_batch(name, 8, seed=4321)
+    torch.set_num_threads(min(64, torch.get_num_threads()))
+    recs = {}
+    for tag, b in (("held_in", synth.make_batch(name, N, seed=1234)[0]), ("held_out", held_out)):
+        enc, am, dec, dm, labels = O.batch_to_model_inputs(b, "Smiles")
+        take = lambda x: ({k: take(v) for k, v in x.items()} if isinstance(x, dict) else x[:8])
+        enc, am, dec, dm, labels = take(enc), am[:8], dec[:8], dm[:8], labels[:8]
+        out = eng.forward(to(enc), am.to(DEV), dec.to(DEV), dm.to(DEV), labels.to(DEV))
+        with torch.no_grad():
+            ref = O.model_forward(sd, ecfg, wl["data"], "Smiles", enc, am, dec, dm)["logits"].double()
+        got = out["logits"].cpu().double()
+        scale = float(ref.abs().max())
+        err = float((got - ref).abs().max()) / scale
+        ids, rid = out["argmax"].cpu(), ref.argmax(-1)
+        keep = labels != -100
+        top2 = ref.topk(2, -1).values
+        sure = (top2[..., 0] - top2[..., 1]) > 2 * err * scale
+        rec = dict(workload=name, mode="fp16", set=tag, samples=8,
+                   weights=f"trained {steps} steps on {N} samples with dropout {cfg['dropout']} in bf16x3-mixed (loss {first:.3f} -> {last:.3f})",
+                   logits_rel_err=err, logits_abs_max=scale, positions=int(ids.numel()), ids_differ=int((ids != rid).sum()),
+                   ids_differ_at_labelled_positions=int((ids != rid)[keep].sum()), decidable_frac=float(sure.double().mean()),
+                   decidable_frac_at_labelled_positions=float(sure[keep].double().mean()), labelled_positions=int(keep.sum()),
+                   ids_equal_where_decidable=bool(torch.equal(ids[sure], rid[sure])))
+        record_parity("test_fp16_parity_after_training_with_dropout_on_held_in_and_held_out_samples", **rec)
+        print(rec)
+        recs[tag] = rec
+    assert last < first, (first, last)
+    for tag, rec in recs.items():
+        assert rec["logits_rel_err"] < 1e-3, rec
+        assert rec["ids_equal_where_decidable"], rec
+    assert recs["held_in"]["ids_differ_at_labelled_positions"] == 0, recs["held_in"]

@@ -1,0 +1,85 @@
+"""The dQ kernel on v_mfma_f32_16x16x32 (csrc/afm_attn_m16_impl.h, afm_attn_shape.reserved & 1024) against the shipped 32x32x16 kernel:
+dQ / delta against the shipped kernel's over dense, padded, causal, short and cross-attention cases with and without the re-hashed
+dropout, then wall times at the c2 encoder shape, the two kernels alternating in ONE process (keep the faster by
+wall time; the accumulation order differs, so the outputs are close, not bit-equal)."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import torch
+from multimodalanalytical_amd import ops
+
+
+def t(fn, it=40, warm=30):
+    for _ in range(warm): fn()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize(); a.record()
+    for _ in range(it): fn()
+    b.record(); torch.cuda.synchronize()
+    return a.elapsed_time(b) / it
+
+
+def case(B, H, Tq, Tk, p, causal, pad, dt=torch.float16, seed=0):
+    dev, dh = "cuda:0", 64
+    d = H * dh
+    g = torch.Generator(device=dev).manual_seed(seed)
+    rnd = lambda r, c, sc=1.0: (torch.randn(r, c, device=dev, generator=g) * sc).to(dt)
+    q, k, v = rnd(B * Tq, d), rnd(B * Tk, d), rnd(B * Tk, d)
+    o, do = torch.empty(B * Tq, d, dtype=dt, device=dev), rnd(B * Tq, d, 0.05)
+    lse, delta = torch.empty(B * H * Tq, device=dev), torch.empty(B * H * Tq, device=dev)
+    kp = None
+    if pad:
+        n = torch.randint(Tk // 3, Tk + 1, (B,), device=dev, generator=g)
+        kp = (torch.arange(Tk, device=dev)[None, :] >= n[:, None]).to(torch.uint8).contiguous()
+    dr = ops.drop(p, 7, 3)
+    mk = lambda res: _shape(B, H, Tq, Tk, dh, dt, q, k, v, o, kp, causal, dr, res)
+    ops.attn_fwd(mk(0), q, k, v, o, lse)
+    outs = []
+    for res in (1, 1 | 1024):
+        dq, dk, dv = torch.full_like(q, float("nan")), torch.empty_like(k), torch.empty_like(v)
+        delta.fill_(float("nan"))
+        ops.attn_bwd(mk(res), q, k, v, o, do, lse, delta, dq, dk, dv, ops._ld(dq), ops._ld(dk), ops._ld(dv))
+        outs.append((dq.float().clone(), delta.clone()))
+    (a, da), (b, db) = outs
+    err = float((a - b).abs().max() / a.abs().max())
+    derr = float((da - db).abs().max() / da.abs().max())
+    ok = bool(torch.isfinite(b).all()) and err < 4e-3 and derr < 1e-5
+    print(f"B{B} H{H} Tq{Tq} Tk{Tk} p={p} causal={causal} pad={pad} {dt}: dQ 16x16x32 vs 32x32x16 rel {err:.2e}, delta {derr:.1e}  {'ok' if ok else 'FAIL'}", flush=True)
+    return ok
+
+
+def _shape(B, H, Tq, Tk, dh, dt, q, k, v, o, kp, causal, dr, res):
+    s = ops.attn_shape(B, H, Tq, Tk, dh, dt, ops._ld(q), ops._ld(k), ops._ld(v), ops._ld(o), kp, causal, dr)
+    s.reserved = res
+    return s
+
+
+def main():
+    ok = True
+    for (B, H, Tq, Tk, p, causal, pad) in [(2, 4, 128, 128, 0.0, False, False), (2, 4, 256, 256, 0.1, False, False), (3, 2, 128, 384, 0.0, False, True),
+                                            (2, 8, 256, 256, 0.1, True, True), (2, 4, 100, 200, 0.1, False, True), (1, 12, 128, 1024, 0.0, False, True),
+                                            (4, 8, 1024, 1024, 0.1, False, False)]:
+        ok &= case(B, H, Tq, Tk, p, causal, pad)
+    ok &= case(2, 4, 256, 256, 0.1, False, True, dt=torch.bfloat16)
+    print("ALL OK" if ok else "FAILURES", flush=True)
+    B, H, S, dh, dt, dev = 128, 8, 1024, 64, torch.float16, "cuda:0"
+    d = H * dh
+    qkv = (torch.randn(B * S, 3 * d, device=dev)).to(dt)
+    q, k, v = qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:]
+    o = torch.empty(B * S, d, dtype=dt, device=dev); do = (torch.randn(B * S, d, device=dev) * 0.01).to(dt)
+    dqkv = torch.empty_like(qkv); dq, dk, dv = dqkv[:, :d], dqkv[:, d:2 * d], dqkv[:, 2 * d:]
+    lse, delta = torch.empty(B * H * S, device=dev), torch.empty(B * H * S, device=dev)
+    prod = 2.0 * B * H * S * S * dh
+    for p in (0.0, 0.1):
+        dr = ops.drop(p, 1, 3)
+        mk = lambda res: _shape(B, H, S, S, dh, dt, q, k, v, o, None, False, dr, res)
+        ops.attn_fwd(mk(0), q, k, v, o, lse)
+        s32, s16 = mk(1), mk(1 | 1024)
+        f32 = lambda: ops.attn_bwd(s32, q, k, v, o, do, lse, delta, dq, dk, dv, ops._ld(dq), ops._ld(dk), ops._ld(dv))
+        f16 = lambda: ops.attn_bwd(s16, q, k, v, o, do, lse, delta, dq, dk, dv, ops._ld(dq), ops._ld(dk), ops._ld(dv))
+        for rnd in range(3):
+            a, b = (t(f32), t(f16)) if rnd % 2 == 0 else tuple(reversed((t(f16), t(f32))))
+            print(f"c2 encoder shape, dropout {p} ({'re-hash' if p else 'none'}), round {rnd}: dQ 32x32x16 {a:.4f} ms ({3 * prod / a / 1e9:.0f} TF/s)   "
+                  f"16x16x32 {b:.4f} ms ({3 * prod / b / 1e9:.0f} TF/s)   ratio {b / a:.3f}", flush=True)
+
+
+if __name__ == "__main__":
+    main()
