@@ -10,10 +10,11 @@
 //     from two ds_read_b64_tr_b16 (rows 4 g .. + 3 and 16 + 4 g .. + 3);
 //   * the transposed K image needs its own swizzle for that read pattern (chunk ^ ((row >> 1) & 3) << 1: the four same-parity rows of a
 //     32-lane half land in four different 32-byte chunk pairs): dma_piece_tr16.
-// Dropout: DROP_NONE and DROP_HASH only -- the keep-bit tensor's 64-bit words are lane masks of the 32x32 accumulator layout, which
-// the forward kernel writes; a 16x16 kernel would have to re-assemble every mask from two words.  The A/B against k_attn_bwd_dq_mfma
-// is therefore run without dropout and with the re-hash path on both sides (tools/experiments/attn_m16.py).
-// Selected by afm_attn_shape.reserved & 1024 (never by default).
+// Dropout keep bits: the tensor's 64-bit words are lane masks of the 32x32 accumulator layout (the forward kernel writes them: word R of
+// a 32x32 block, bit 32 h + q = keep(key (R & 3) + 8 (R >> 2) + 4 h, query q)).  The lane mask of register r of the 16x16 tile (ki, qi)
+// -- lane 16 g + c <-> key 16 ki + 4 g + r, query 16 qi + c -- is four 16-bit fields of two of those words, Ra = r + 8 ki (g = 0, 1) and
+// Rb = Ra + 4 (g = 2, 3): [Ra.lo | Ra.hi | Rb.lo | Rb.hi] taken at field qi, i.e. two scalar 16-bit packs per mask (keep_mask16x16).
+// The tensor layout, hence the forward and the dK/dV kernels, stay as they are.
 
 __device__ __forceinline__ void dma_piece_tr16(unsigned char* img, const e16* base, int ld, int row0, int nrows, int pi, int lane) {
   const int r = 8 * pi + (lane >> 3), slot = lane & 7;
@@ -41,15 +42,31 @@ __device__ __forceinline__ void drop_select4(const DropDev& dd, uint32_t rowhash
   }
 }
 
-template <int DROP>
-__global__ __launch_bounds__(256, 3) void k_attn_bwd_dq_m16(AttnM a, const e16* __restrict__ Q,
+// lane mask of accumulator register r of the 16 x 16 tile (ki, qi) from the 32 x 32 block's 16 words (see the header)
+__device__ __forceinline__ unsigned long long keep_mask16x16(const KeepMasks& m, int ki, int qi, int r) {
+  const int Ra = r + 8 * ki, Rb = Ra + 4;
+  const u32x16& va = Ra < 8 ? m.a : m.b;
+  const u32x16& vb = Rb < 8 ? m.a : m.b;
+  const uint32_t alo = va[2 * (Ra & 7)], ahi = va[2 * (Ra & 7) + 1], blo = vb[2 * (Rb & 7)], bhi = vb[2 * (Rb & 7) + 1];
+  uint32_t nlo, nhi;      // one scalar pack each (hipcc spells the C form as three to four SALU instructions per half)
+  if (qi) {
+    asm("s_pack_hh_b32_b16 %0, %1, %2" : "=s"(nlo) : "s"(alo), "s"(ahi));
+    asm("s_pack_hh_b32_b16 %0, %1, %2" : "=s"(nhi) : "s"(blo), "s"(bhi));
+  } else {
+    asm("s_pack_ll_b32_b16 %0, %1, %2" : "=s"(nlo) : "s"(alo), "s"(ahi));
+    asm("s_pack_ll_b32_b16 %0, %1, %2" : "=s"(nhi) : "s"(blo), "s"(bhi));
+  }
+  return ((unsigned long long)nhi << 32) | nlo;
+}
+
+template <int DROP, int OCC = 3>
+__global__ __launch_bounds__(256, OCC) void k_attn_bwd_dq_m16(AttnM a, const e16* __restrict__ Q,
                                                          const e16* __restrict__ K,
                                                          const e16* __restrict__ V,
                                                          const e16* __restrict__ O,
                                                          const e16* __restrict__ dO,
                                                          const float* __restrict__ lse,
                                                          float* __restrict__ delta, e16* __restrict__ dQ) {
-  static_assert(DROP == DROP_NONE || DROP == DROP_HASH, "the keep-bit tensor belongs to the 32x32 layout");
   constexpr int STAGE = 3 * KT * DH * 2;   // K row image, K tr image, V row image
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   unsigned long long* maskw = (unsigned long long*)(lds + RS * STAGE);
@@ -152,12 +169,12 @@ __global__ __launch_bounds__(256, 3) void k_attn_bwd_dq_m16(AttnM a, const e16* 
   // transposed reads of the K image: lane (g, qq, p) supplies row 4 g + qq (+ the block's first row, + 16 for the second read), columns
   // 16 dt + 4 p .. + 3 of d-tile dt: chunk 2 dt + (p >> 1) at position chunk ^ sw, sw = (2 (g & 1) + (qq >> 1)) << 1, i.e. the chunk PAIR
   // dt ^ (sw >> 1): one lane address per d-tile, the rows as immediates
-  unsigned tra[4];
+  // (one lane address, d-tile dt = an XOR of dt << 5 on it: the row term has no bits below 128, the chunk-pair term is (dt ^ s2) << 5)
+  unsigned tra0;
   {
     const int qq = (lane >> 2) & 3, p = lane & 3;
     const int s2 = 2 * (g & 1) + (qq >> 1);
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt) tra[dt] = (4 * g + qq) * 128 + ((2 * (dt ^ s2) + (p >> 1)) << 4) + ((p & 1) << 3);
+    tra0 = (4 * g + qq) * 128 + ((2 * s2 + (p >> 1)) << 4) + ((p & 1) << 3);
   }
   for (int j = 0; j < nlive; ++j) {
     const int kt = __builtin_amdgcn_readfirstlane(tl[j]);
@@ -170,6 +187,12 @@ __global__ __launch_bounds__(256, 3) void k_attn_bwd_dq_m16(AttnM a, const e16* 
     const unsigned ktr = (unsigned)(uintptr_t)(Krow + KT * DH * 2);
     const unsigned char* Vrow = Krow + 2 * KT * DH * 2;
     const unsigned long long mword = maskw[kt];
+    KeepMasks km[2];
+    if (DROP == DROP_BITS) {   // both 32-key blocks of the tile now; used after the S / dP products
+      const unsigned long long* kbp = bits_block(a, b * a.H + hd, q0 >> 5, 2 * kt);
+      keep_masks_issue(km[0], kbp);
+      keep_masks_issue(km[1], kbp + 16);
+    }
 #pragma unroll
     for (int blk = 0; blk < 2; ++blk) {
       f32x4 s[2][2], dp[2][2];
@@ -198,17 +221,28 @@ __global__ __launch_bounds__(256, 3) void k_attn_bwd_dq_m16(AttnM a, const e16* 
 #pragma unroll
           for (int qi = 0; qi < 2; ++qi) drop_select4(a.dd, rowbase[qi], kb + 32 * blk + 16 * ki + 4 * g, dp[ki][qi], ndl[qi]);
       }
+      if (DROP == DROP_BITS) {
+        keep_masks_wait(km[blk]);
+#pragma unroll
+        for (int ki = 0; ki < 2; ++ki)
+#pragma unroll
+          for (int qi = 0; qi < 2; ++qi)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              dp[ki][qi][r] = __builtin_amdgcn_inverse_ballot_w64(keep_mask16x16(km[blk], ki, qi, r)) ? dp[ki][qi][r] : ndl[qi];
+      }
       if (mword != 0ull || (a.causal && (kb + KT - 1 > q0))) {   // wave-uniform: tile has masked keys
+        const unsigned long long padg = mword >> (4 * g);          // bit 32 blk + 16 ki + r = this lane's key of register r, tile ki
 #pragma unroll
         for (int ki = 0; ki < 2; ++ki)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const int ko = 32 * blk + 16 * ki + 4 * g + r;
-            const bool pad = (mword >> ko) & 1ull;
+            const int kc = 32 * blk + 16 * ki + r;                 // + 4 g = the key inside the 64-key tile
+            const bool pad = (padg >> kc) & 1ull;
 #pragma unroll
             for (int qi = 0; qi < 2; ++qi) {
               bool msk = pad;
-              if (a.causal) msk = msk || (kb + ko > q[qi]);
+              if (a.causal) msk = msk || (kb + kc + 4 * g > q[qi]);
               s[ki][qi][r] = msk ? -INFINITY : s[ki][qi][r];
             }
           }
@@ -223,7 +257,7 @@ __global__ __launch_bounds__(256, 3) void k_attn_bwd_dq_m16(AttnM a, const e16* 
         s16x4 lo[4], hi[4];
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) {
-          const unsigned ad = ktr + tra[dt];
+          const unsigned ad = ktr + (tra0 ^ (dt << 5));
           if (blk == 0) { AFM_TR_RD(lo[dt], ad, 0); AFM_TR_RD(hi[dt], ad, 2048); }
           else { AFM_TR_RD(lo[dt], ad, 4096); AFM_TR_RD(hi[dt], ad, 6144); }
         }

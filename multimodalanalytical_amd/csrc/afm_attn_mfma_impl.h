@@ -1131,14 +1131,14 @@ int AFM_E16_FN(afm_attn_bwd_mfma_try)(const afm_attn_shape* s, const void* Q, co
     else AFM_LAUNCH(k_attn_bwd_dq_st<DROP_NONE>, gq8, dim3(512), shm_q8, st, a, (const e16*)Q, (const e16*)K, (const e16*)V, (const e16*)O, (const e16*)dO, lse, delta, (e16*)dQ);
   }
   else if (!run_q) {}
-  else if ((s->reserved & 1024) && !(a.dd.thresh16 && a.bits)) {     // the 16x16x32 form of the dQ kernel (afm_attn_m16_impl.h: an A/B test, never the default)
-    static AfmOncePerDevice attr_q16;
-    if (attr_q16.need()) {
-      (void)hipFuncSetAttribute((const void*)k_attn_bwd_dq_m16<DROP_HASH>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-      (void)hipFuncSetAttribute((const void*)k_attn_bwd_dq_m16<DROP_NONE>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-    }
-    if (a.dd.thresh16) AFM_LAUNCH(k_attn_bwd_dq_m16<DROP_HASH>, gq, dim3(256), shm_q, st, a, (const e16*)Q, (const e16*)K, (const e16*)V, (const e16*)O, (const e16*)dO, lse, delta, (e16*)dQ);
-    else AFM_LAUNCH(k_attn_bwd_dq_m16<DROP_NONE>, gq, dim3(256), shm_q, st, a, (const e16*)Q, (const e16*)K, (const e16*)V, (const e16*)O, (const e16*)dO, lse, delta, (e16*)dQ);
+  else if (s->reserved & 1024) {     // the 16x16x32 form of the dQ kernel (afm_attn_m16_impl.h); reserved & 2048: compiled for two workgroups per CU (256 registers)
+#define AFM_M16_LAUNCH(D, OCC) do { static AfmOncePerDevice at_; if (at_.need()) (void)hipFuncSetAttribute((const void*)k_attn_bwd_dq_m16<D, OCC>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); \
+      AFM_LAUNCH((k_attn_bwd_dq_m16<D, OCC>), gq, dim3(256), shm_q, st, a, (const e16*)Q, (const e16*)K, (const e16*)V, (const e16*)O, (const e16*)dO, lse, delta, (e16*)dQ); } while (0)
+    const bool occ2 = (s->reserved & 2048) != 0;
+    if (a.dd.thresh16 && a.bits) { if (occ2) AFM_M16_LAUNCH(DROP_BITS, 2); else AFM_M16_LAUNCH(DROP_BITS, 3); }
+    else if (a.dd.thresh16) { if (occ2) AFM_M16_LAUNCH(DROP_HASH, 2); else AFM_M16_LAUNCH(DROP_HASH, 3); }
+    else { if (occ2) AFM_M16_LAUNCH(DROP_NONE, 2); else AFM_M16_LAUNCH(DROP_NONE, 3); }
+#undef AFM_M16_LAUNCH
   }
   else if (a.dd.thresh16 && a.bits) AFM_LAUNCH(k_attn_bwd_dq_mfma<DROP_BITS>, gq, dim3(256), shm_q, st, a, (const e16*)Q, (const e16*)K, (const e16*)V, (const e16*)O, (const e16*)dO, lse, delta, (e16*)dQ);
   else if (a.dd.thresh16) AFM_LAUNCH(k_attn_bwd_dq_mfma<DROP_HASH>, gq, dim3(256), shm_q, st, a, (const e16*)Q, (const e16*)K, (const e16*)V, (const e16*)O, (const e16*)dO, lse, delta, (e16*)dQ);

@@ -276,14 +276,16 @@ __device__ __forceinline__ float afm_gelu_grad(float x) {
 }
 
 // The same three functions for epilogues whose OUTPUT is a 16-bit float (fp16 / bf16 modes): the results are
-// rounded to 11 / 8 significant bits anyway, so erf needs 2^-15, not 2^-23.  Abramowitz & Stegun 7.1.25 (three terms, |erf error|
-// <= 2.5e-5, i.e. |Phi error| <= 1.25e-5) with the 1/sqrt(2) of the argument and the 0.5 of Phi folded into the constants, and
-// Phi = 0.5 + copysign(0.5 - P e, x) in three instructions: 16 issue slots for the pair instead of 20 (rcp and exp count two).
-// Measured against fp64 over [-12, 12]: |g error| <= 2.6e-5, |g' error| <= 1.1e-5 (an fp16 half-ulp at |g| = 1 is 2.4e-4).
+// rounded to 11 / 8 significant bits anyway.  Same form as Abramowitz & Stegun 7.1.26 with FOUR terms refitted (weighted minimax over
+// |x| <= 9 of Phi(-|x|) = P(t) exp(-x^2 / 2), t = 1 / (1 + 0.27 |x|): |Phi error| <= 8.6e-7), the 1/sqrt(2) of the argument and the 0.5
+// of Phi folded into the constants, and Phi = 0.5 + copysign(0.5 - P e, x) in three instructions: 17 issue slots for the pair instead
+// of 20 (rcp and exp count two).  Measured in fp32 against fp64 over [-12, 12]: |g error| <= 2.5e-6, |g' error| <= 1.0e-6 -- a
+// hundredth of an fp16 half-ulp at |g| = 1.  (The three-term form 7.1.25, one slot cheaper, is 2.6e-5 off: the same size as the fp16
+// rounding of a typical activation, and the c2 logits error against the CPU reference went from 7.2e-4 to 8.1e-4 with it; rejected.)
 // fp32 / split-pair outputs keep the 1.5e-7 forms above.
 __device__ __forceinline__ void afm_gelu_both16(float x, float& g, float& gp) {
-  const float t = __builtin_amdgcn_rcpf(fmaf(0.33267250f, fabsf(x), 1.0f));                 // 0.47047 / sqrt(2)
-  const float p = t * fmaf(fmaf(0.3739278f, t, -0.0479399f), t, 0.1740121f);                 // (a1 t + a2 t^2 + a3 t^3) / 2
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.27f, fabsf(x), 1.0f));
+  const float p = t * fmaf(fmaf(fmaf(0.42752638f, t, -0.30561537f), t, 0.30629668f), t, 0.07179219f);
   const float u = x * 0.84932180f;                                                            // sqrt(log2(e) / 2)
   const float e = __builtin_amdgcn_exp2f(-(u * u));                                           // exp(-x^2 / 2)
   const float cdf = 0.5f + copysignf(fmaf(-p, e, 0.5f), x);
@@ -291,8 +293,8 @@ __device__ __forceinline__ void afm_gelu_both16(float x, float& g, float& gp) {
   gp = fmaf(x * 0.39894228040143267794f, e, cdf);
 }
 __device__ __forceinline__ float afm_gelu16(float x) {
-  const float t = __builtin_amdgcn_rcpf(fmaf(0.33267250f, fabsf(x), 1.0f));
-  const float p = t * fmaf(fmaf(0.3739278f, t, -0.0479399f), t, 0.1740121f);
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.27f, fabsf(x), 1.0f));
+  const float p = t * fmaf(fmaf(fmaf(0.42752638f, t, -0.30561537f), t, 0.30629668f), t, 0.07179219f);
   const float u = x * 0.84932180f;
   return x * (0.5f + copysignf(fmaf(-p, __builtin_amdgcn_exp2f(-(u * u)), 0.5f), x));
 }

@@ -1549,6 +1549,8 @@ __global__ __launch_bounds__(512) void k_gemm_tn_group256(TnGroup gr) {
   tn256_unit(pr, local % pr.ntile, local / pr.ntile, lds);
 }
 
+#include "afm_gemm_tnw4_impl.h"
+
 }  // namespace AFM_E16_NS
 using namespace AFM_E16_NS;
 
@@ -1768,7 +1770,7 @@ int AFM_E16_FN(afm_gemm_mfma_try)(const afm_gemm_desc* d, hipStream_t st) {
     // 256 x 256 tiles when the gradient matrix has at least 8 of them and the token count is long enough for
     // every workgroup to run >= 64 k-steps (measured at 131072 tokens: +4..18 % at 1536x512, 2048x512, 512x2048;
     // -3 % at 512x512, which keeps the 256 x 128 form, as do the decoder's 16 k-token shapes); 105 / 106 force a form
-    const bool want256 = d->reserved == 105 ||
+    const bool want256 = d->reserved == 105 || d->reserved == 107 || d->reserved == 108 ||
                          (d->reserved == 0 && d->K >= 65536 && (int64_t)((d->M + 255) / 256) * ((d->N + 255) / 256) >= 8);
     if (want256 && (d->K & 63) == 0 && d->K >= 4096 && d->M >= 256 && d->N >= 256) {
       // 256 x 256 tiles
@@ -1788,6 +1790,13 @@ int AFM_E16_FN(afm_gemm_mfma_try)(const afm_gemm_desc* d, hipStream_t st) {
       static AfmOncePerDevice attr256;
       if (attr256.need()) {
         (void)hipFuncSetAttribute((const void*)k_gemm_tn_ring256, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 64 * 512 * 2 + TN_LIST_MAX_BYTES);
+        (void)hipFuncSetAttribute((const void*)k_gemm_tn_w4, hipFuncAttributeMaxDynamicSharedMemorySize, TW4_RING + TN_LIST_MAX_BYTES);
+      }
+      // whole 256 x 256 tiles: the four-wave unit (afm_gemm_tnw4_impl.h); reserved = 107 keeps the eight-wave one (A / B tests)
+      if (!(d->M & 255) && !(d->N & 255) && d->reserved == 108) {
+        AFM_LAUNCH(k_gemm_tn_w4, dim3(tiles * ksplit), dim3(256), TW4_RING + TN_LIST_MAX_BYTES, st, g);
+        afm_set_last_algo(ksplit > 1 ? "mfma_tn_w4_splitk" : "mfma_tn_w4");
+        return AFM_OK;
       }
       AFM_LAUNCH(k_gemm_tn_ring256, dim3(tiles * ksplit), dim3(512), 2 * 64 * 512 * 2 + TN_LIST_MAX_BYTES, st, g);
       afm_set_last_algo(ksplit > 1 ? "mfma_tn_ring256_splitk" : "mfma_tn_ring256");
@@ -1853,7 +1862,7 @@ bool AFM_E16_FN(afm_gemm_tn_group_eligible)(const afm_gemm_desc* d) {
   if ((d->M & 7) || (d->N & 7) || d->M < 256 || d->N < 256 || (d->K & 63) || d->K < 1024) return false;
   if (d->lda < d->M || d->ldb < d->N || d->ldc < d->N) return false;     // (afm_gemm reports it)
   if (!aligned16(d->A) || !aligned16(d->B) || (d->lda & 7) || (d->ldb & 7)) return false;
-  if (d->algo == AFM_ALGO_GENERIC || (d->reserved != 0 && d->reserved != 105)) return false;
+  if (d->algo == AFM_ALGO_GENERIC || (d->reserved != 0 && d->reserved != 105 && d->reserved != 107 && d->reserved != 108)) return false;
   return true;
 }
 // count <= AFM_TN_GROUP_MAX eligible problems.  One chunk length (in 64-token k-steps) for all of them: the smallest for which the
@@ -1877,10 +1886,52 @@ int AFM_E16_FN(afm_gemm_tn_group_launch)(const afm_gemm_desc* const* ds, int cou
     work += (int64_t)pr.ntile * steps[i];
     if (steps[i] > max_steps) max_steps = steps[i];
   }
+  // The chunk length (in 64-token steps) that minimises the estimated launch time.  Rounds 3-4 took the smallest chunk whose units fit
+  // ONE wave of 256 workgroups; that leaves the chip half empty where the tile count sits between 128 and 256 -- c4's encoder layer:
+  // 144 tiles, split-K 2 would be 288 units, so every tile ran unsplit on 144 of 256 CUs (784 TF/s where c2's 48-tile layer reaches
+  // 1 000).  Units are dispatched in index order as workgroup slots free up, so several near-full rounds of short units beat one
+  // half-empty round of long ones: cost(chunk) = max(sum of unit lengths / 256, longest unit), every unit charged OVH steps for its
+  // ring fill and its 256 KB of fp32 atomics (~40 steps: 50 us per round of 256 units at the 1.3 TB/s atomic rate + the prologue).
+  // c4 encoder layer: chunk 293 (7 windows, 1 008 units, ~4 rounds): estimated 1 312 steps against 2 083; c2's (48 tiles) keeps split 5.
   int chunk = max_steps;                                   // >= 256 tiles: no split-K at all
-  if (tiles < 256) {
+  static const int ovh = getenv("AFM_TN_OVH") ? atoi(getenv("AFM_TN_OVH")) : 40;
+  if (tiles < 256 && !getenv("AFM_TN_ONE_WAVE")) {
+    // (the plan depends on the shapes only: the last few are remembered)
+    struct Plan { uint64_t key; int chunk; };
+    static thread_local Plan cache[16];
+    static thread_local int cache_n = 0;
+    uint64_t key = 1469598103934665603ull ^ (uint64_t)count;
+    for (int i = 0; i < count; ++i) key = (key * 1099511628211ull) ^ ((uint64_t)gr.p[i].ntile << 32 | (uint32_t)steps[i]);
+    bool hit = false;
+    for (int i = 0; i < cache_n && !hit; ++i)
+      if (cache[i].key == key) { chunk = cache[i].chunk; hit = true; }
+    if (!hit) {
+      double best = 1e30;
+      for (int ks0 = 1; ks0 <= 64; ++ks0) {                // candidate: the longest problem split ks0 ways
+        const int c = (max_steps + ks0 - 1) / ks0;
+        if (c < 16) break;                                 // >= 1024 tokens per unit
+        // greedy schedule of the units in launch order on 256 slots (a min-heap of finish times would do; 256 is small enough to scan)
+        int finish[256] = {0};
+        int makespan = 0;
+        for (int i = 0; i < count; ++i) {
+          int ks = (steps[i] + c - 1) / c;
+          const int per = (steps[i] + ks - 1) / ks;
+          ks = (steps[i] + per - 1) / per;
+          const int n = gr.p[i].ntile * ks;
+          for (int u = 0; u < n; ++u) {
+            int m = 0;
+            for (int q = 1; q < 256; ++q) if (finish[q] < finish[m]) m = q;
+            finish[m] += per + ovh;
+            if (finish[m] > makespan) makespan = finish[m];
+          }
+        }
+        if (makespan < best * 0.97) { best = makespan; chunk = c; }   // (a finer split has to pay by 3 %)
+      }
+      cache[cache_n < 16 ? cache_n++ : (int)(key & 15)] = Plan{key, chunk};
+    }
+  } else if (tiles < 256) {                                // AFM_TN_ONE_WAVE: the rule of rounds 3-4 (A / B runs)
     chunk = (int)((work + 255) / 256);
-    if (chunk < 16) chunk = 16;                            // >= 1024 tokens per unit
+    if (chunk < 16) chunk = 16;
     for (;; ++chunk) {
       int units = 0;
       for (int i = 0; i < count; ++i) units += gr.p[i].ntile * ((steps[i] + chunk - 1) / chunk);
@@ -1899,8 +1950,25 @@ int AFM_E16_FN(afm_gemm_tn_group_launch)(const afm_gemm_desc* const* ds, int cou
   gr.units = units;
   for (int i = count; i < AFM_TN_GROUP_MAX; ++i) { gr.p[i] = gr.p[0]; gr.p[i].unit0 = 0x7fffffff; }
   static AfmOncePerDevice attr;
-  if (attr.need())
+  if (attr.need()) {
     (void)hipFuncSetAttribute((const void*)k_gemm_tn_group256, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 64 * 512 * 2 + TN_LIST_MAX_BYTES);
+    (void)hipFuncSetAttribute((const void*)k_gemm_tn_groupw4, hipFuncAttributeMaxDynamicSharedMemorySize, TW4_RING + TN_LIST_MAX_BYTES);
+  }
+  // every problem made of whole 256 x 256 tiles (all of a layer stack's weight gradients): the four-wave unit; a descriptor with
+  // reserved = 105 / 107 keeps the eight-wave one (A / B tests)
+  // The four-wave unit (afm_gemm_tnw4_impl.h) is NOT the default: measured (tools/experiments/tnw4_gemm.py + r5_tn_ab.sh, one process,
+  // order swapped, 131 072 tokens, fp16) it equals the eight-wave unit within the run-to-run spread on every layer set (c2 encoder layer
+  // 0.81-0.85 ms vs 0.81-0.83, c4's 2.35-2.37 vs 2.35, decoder sets 0.277-0.33 vs 0.277-0.29), and inside bench.py's step the grouped
+  // launch came out SLOWER (1.18 vs 0.81 ms at the c2 encoder layer, c2 2 870 vs 3 130 samples/s): a transposed fragment costs two
+  // LDS instructions, so the lone wave of a SIMD issues 126 instructions beside its 64 MFMAs per slice and has no slack left for the
+  // eight LDS-DMA pieces.  reserved = 108 on every descriptor selects it (tests, A / B runs).
+  bool w4 = true;
+  for (int i = 0; i < count; ++i) w4 = w4 && !(ds[i]->M & 255) && !(ds[i]->N & 255) && ds[i]->reserved == 108;
+  if (w4) {
+    AFM_LAUNCH(k_gemm_tn_groupw4, dim3(units), dim3(256), TW4_RING + TN_LIST_MAX_BYTES, st, gr);
+    afm_set_last_algo("mfma_tn_groupw4");
+    return AFM_OK;
+  }
   AFM_LAUNCH(k_gemm_tn_group256, dim3(units), dim3(512), 2 * 64 * 512 * 2 + TN_LIST_MAX_BYTES, st, gr);
   afm_set_last_algo("mfma_tn_group256");
   return AFM_OK;

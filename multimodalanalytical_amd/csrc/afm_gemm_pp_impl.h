@@ -90,8 +90,16 @@ __global__ __launch_bounds__(512) void k_gemm_nt_pp(MfmaArgs g) {
   const int tlo = xcd * tpx, thi = min(ntiles, tlo + tpx);
   int* const tlist = (int*)(lds + PP_LIST_OFF);
   if (g.live_off) nt_tile_lists<256, 256, true, 512>(g, tlist, tlo, thi, nbx, bx);
+  // The live-tile list is read by inline asm: a compiler-visible LDS load beside the LDS-DMA ring is answered with
+  // s_waitcnt vmcnt(0), which drained the hand-counted ring at every tile change of the padded-row path.
+  auto list_word = [&](int idx) -> int {
+    unsigned v;
+    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v) : "v"((unsigned)(uintptr_t)lds + PP_LIST_OFF + 4u * (unsigned)idx) : "memory");
+    return __builtin_amdgcn_readfirstlane((int)v);
+  };
+  const int nlist = g.live_off ? list_word(0) : 0;
   auto tile_of = [&](int it) -> int {
-    if (g.live_off) return it < __builtin_amdgcn_readfirstlane(tlist[0]) ? __builtin_amdgcn_readfirstlane(tlist[1 + it]) : -1;
+    if (g.live_off) return it < nlist ? list_word(1 + it) : -1;
     const int tt = tlo + it * nbx + bx;
     return tt < thi ? tt : -1;
   };

@@ -1,0 +1,240 @@
+// Four-wave weight-gradient (TN) unit for gfx950 (included by afm_gemm_mfma_impl.h inside namespace AFM_E16_NS):
+// C[m][n] (+)= sum_k A[k][m] B[k][n] over one (256 x 256 tile, token chunk) unit, 16-bit operands, fp32 accumulate into the gradient
+// buffer (split-K by fp32 atomics), bias gradient (column sums of A) fused.  Round 5, VERDICT r04 item 4 ("the same blocking for the
+// weight-gradient loop"): the NT kernel of afm_gemm_w4_impl.h restated for the token-major operands of the wgrad form.
+//
+//   * one wave per SIMD owns 128 x 128 of the tile in 256 accumulator registers (tied inline-asm MFMAs on a[0:255]); a 32-token slice
+//     costs it 16 fragments (32 ds_read_b64_tr_b16) for 64 MFMAs -- the eight-wave kernel's 128 x 64 waves read 12 for 32: a third
+//     fewer LDS bytes per MFMA -- and the wave reads slice p + 1 (into the other fragment set) and issues its 8 LDS-DMA pieces of slice
+//     p + 3 BETWEEN the MFMAs of slice p: the eight-wave kernel reads, waits, then multiplies, and waits for the whole next step's fill
+//     at every barrier.
+//   * LDS: four slots of one slice each (32 tokens x [256 A columns | 256 B columns] = 32 KB), the image of k_gemm_tn_ring256 (512-byte
+//     rows, 16-byte chunks XOR-swizzled with tn_swz(row) on the source side).  Slice p + 3 goes to the slot slice p - 1 left (read in
+//     phase p - 2, complete at that phase's barrier); a phase ends with vmcnt(8): everything but its own 8 pieces has landed, i.e. slice
+//     p + 2, which the next phase reads.  One barrier per phase.
+//   * fragment addresses: ONE lane address per operand; fragment i is an XOR of i << 5 on it (the swizzle permutes the eight 16-column
+//     groups of a wave's 128 columns among themselves).
+//   * needs M % 256 == 0, N % 256 == 0 (every weight gradient of the model's layer stacks; the others keep the eight-wave kernel) and
+//     whole 64-token steps; takes the padded-row hint (k_live: the unit's list of live steps, behind the ring).
+
+#define TW4_SLOT 32768            // one slice: 32 token rows of A (512 B each), then 32 token rows of B
+#define TW4_ABYTES 16384          // A part of a slot: 32 rows x 512 B; the B part follows
+#define TW4_RING (4 * TW4_SLOT)
+
+#define TW4_TR(dst, addr, off) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off) : "memory")
+#define TW4_MFMA(ACC, FA, FB) asm volatile("v_mfma_f32_16x16x32_" AFM_E16_NAME " %0, %1, %2, %0" : "+a"(ACC) : "v"(FA), "v"(FB))
+
+__device__ __forceinline__ void tn_w4_unit(const TnProb& g, int tile, int ks_id, unsigned char* lds) {
+  const int t = threadIdx.x, lane = t & 63;
+  const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wm = w >> 1, wn = w & 1;
+  const int m0 = (tile / g.tiles_n) * 256, n0 = (tile % g.tiles_n) * 256;
+  const int kbeg = ks_id * g.kchunk, kend = min(g.K, kbeg + g.kchunk);
+  int nk = (kend - kbeg) / 64;         // 64-token steps of the unit (two slices each)
+  // live-step list behind the ring (k_live: steps whose 64 token rows are all padding are left out); identity without the hint.
+  // Built with plain LDS stores BEFORE the first LDS-DMA piece; read back through inline asm (a compiler-visible LDS load beside the
+  // ring would be answered with s_waitcnt vmcnt(0)).
+  int* const kl = (int*)(lds + TW4_RING);
+  const bool listed = g.k_live != nullptr && nk <= TN_LIST_MAX;
+  if (listed) {
+    if (w == 0) {
+      int n = 0;
+      for (int t0 = 0; t0 < nk; t0 += 64) {
+        const int tt = t0 + lane;
+        const bool live = tt < nk && g.k_live[kbeg / 64 + tt] != 0;
+        const unsigned long long bal = __ballot(live);
+        if (live) kl[1 + n + __popcll(bal & ((1ull << lane) - 1ull))] = tt;
+        n += __popcll(bal);
+      }
+      if (lane == 0) kl[0] = n;
+    }
+    __syncthreads();
+  }
+  const unsigned lds0 = (unsigned)(uintptr_t)lds;
+  auto list_word = [&](int idx) -> int {
+    unsigned v;
+    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v) : "v"(lds0 + TW4_RING + 4u * (unsigned)idx) : "memory");
+    return __builtin_amdgcn_readfirstlane((int)v);
+  };
+  if (listed) nk = list_word(0);
+  const int ns = 2 * nk;               // slices
+  float* C = g.C;
+  const int fr = lane & 15, fq = lane >> 4;
+
+  // ---- LDS-DMA side.  Piece ii = w + 4 j (j = 0 .. 7) of a slice: j < 4 -> A rows {2 ii, 2 ii + 1}, j >= 4 -> B rows {2 (ii - 16), + 1};
+  // lane l -> row r = 2 (ii & 15) + (l >> 5) = 2 w + (l >> 5) + 8 (j & 3), chunk (l & 31) ^ tn_swz(r): the swizzle's low part depends on
+  // the lane and the wave only, bit 3 on j & 1 -- one lane offset per operand and parity, the rest is scalar.
+  uint32_t va[2], vb[2];
+  {
+    const int r = 2 * w + (lane >> 5);
+#pragma unroll
+    for (int par = 0; par < 2; ++par) {
+      const int c = (lane & 31) ^ tn_swz(r + 8 * par);
+      va[par] = (uint32_t)r * (uint32_t)g.lda * 2u + c * 16;
+      vb[par] = (uint32_t)r * (uint32_t)g.ldb * 2u + c * 16;
+    }
+  }
+  const uint32_t lda2 = (uint32_t)g.lda * 2u, ldb2 = (uint32_t)g.ldb * 2u;
+  const char* const abase = (const char*)(g.A + (int64_t)kbeg * g.lda + m0);
+  const char* const bbase = (const char*)(g.B + (int64_t)kbeg * g.ldb + n0);
+  // token row of slice s relative to kbeg
+  auto slice_row = [&](int s) -> int { return (listed ? list_word(1 + (s >> 1)) : (s >> 1)) * 64 + (s & 1) * 32; };
+  // piece j of this wave for the slice whose first token row is row0: the slice's A / B row pointers are wave-uniform (`arow`, `brow`: one
+  // scalar 64-bit product per slice), a piece adds a scalar multiple of the row pitch and ONE vector add of the lane's offset
+  auto issue_piece = [&](int slot, const char* arow, const char* brow, int j) {
+    const int jj = j & 3;
+    unsigned char* dst = lds + slot * TW4_SLOT + (j < 4 ? 0 : TW4_ABYTES) + (w + 4 * jj) * 1024;
+    const char* src = j < 4 ? arow + (uint32_t)(8 * jj) * lda2 + va[jj & 1] : brow + (uint32_t)(8 * jj) * ldb2 + vb[jj & 1];
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+  };
+  auto rowptr = [&](const char* base, int row0, uint32_t ld2) -> const char* {     // kept scalar: readfirstlane of both halves
+    const uint64_t u = (uint64_t)(base + (int64_t)row0 * ld2);
+    return (const char*)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(u >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)u));
+  };
+
+  // ---- fragment addresses: lane (grp, q, p) supplies row 8 grp + q (second read: + 4 rows = + 2048 B), columns 16 i + 4 p .. + 3 of
+  // its operand's 128 columns: chunk 16 wm + 2 i + (p >> 1) at position chunk ^ tn_swz(row) = 16 wm + 2 (i ^ s) + (p >> 1), s = swz >> 1
+  // One lane address per operand; fragment i is an XOR of i << 5 on (address + slot offset): one add per operand and phase, one XOR per
+  // fragment.  (Tried and left: sixteen precomputed addresses per slot pair -- 32 registers beside 128 of fragments spill, and a spill's
+  // reload waits for vmcnt(0); two copies of the phase pair with the slot offsets as immediates, chosen by a uniform branch -- the tied
+  // accumulators of the asm MFMAs then meet in phis and are copied through scratch.)
+  unsigned fa0, fb0;
+  {
+    const int grp = lane >> 4, q = (lane >> 2) & 3, p = lane & 3;
+    const int lrow = grp * 8 + q, s = tn_swz(lrow) >> 1, sub = (p & 1) << 3;
+    fa0 = lds0 + lrow * 512 + ((16 * wm + 2 * s + (p >> 1)) << 4) + sub;
+    fb0 = lds0 + TW4_ABYTES + lrow * 512 + ((16 * wn + 2 * s + (p >> 1)) << 4) + sub;
+  }
+
+  f32x4 acc[8][8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");      // v_accvgpr_write -> MFMA addend wait states (the MFMAs are asm)
+
+  const bool do_cs = g.a_colsum != nullptr;     // slices dealt over the 2 x tiles_n waves that hold the same A fragments
+  const int cs_slots = 2 * g.tiles_n;
+  int cs_next = (tile % g.tiles_n) * 2 + wn;
+  float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+
+  s16x4 xa[8][2], xb[8][2], ya[8][2], yb[8][2];           // two fragment sets (even / odd slices): [fragment][k half]
+  if (ns > 0) {
+    // ---- prologue: slices 0, 1, 2 in flight; slice 0 landed and read
+#pragma unroll
+    for (int s = 0; s < 3; ++s)
+      if (s < ns) {
+        const int row0 = slice_row(s);
+        const char* ar = rowptr(abase, row0, lda2);
+        const char* br = rowptr(bbase, row0, ldb2);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) issue_piece(s, ar, br, j);
+      }
+    // slices 0 AND 1 landed (phase 0 reads slice 1 while it multiplies slice 0); slice 2 may stay in flight
+    if (ns > 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const unsigned aa = fa0 ^ (i << 5), ab = fb0 ^ (i << 5);
+      TW4_TR(xa[i][0], aa, 0); TW4_TR(xa[i][1], aa, 2048);
+      TW4_TR(xb[i][0], ab, 0); TW4_TR(xb[i][1], ab, 2048);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  // One phase: 64 MFMAs of slice p from fragment set (CA, CB); between them the 32 transposed reads of slice p + 1 into (NA, NB) and the
+  // 8 pieces of slice p + 3.  16 groups of 4 MFMAs (fragment row i = group >> 1, columns 4 (group & 1) .. + 3); a fragment's two reads
+  // in front of each group, a piece in front of every second.
+#define TW4_JOIN(X) __builtin_shufflevector(__builtin_bit_cast(e16x4, X[0]), __builtin_bit_cast(e16x4, X[1]), 0, 1, 2, 3, 4, 5, 6, 7)
+#define TW4_PHASE(P, CA, CB, NA, NB)                                                                                         \
+  {                                                                                                                          \
+    const int p_ = (P);                                                                                                      \
+    /* no branches inside a phase: past the unit's end the reads fetch stale LDS (unused) and the pieces re-fetch the LAST slice */ \
+    /* into a slot nobody reads again (the WAR argument holds for any stream) -- at most 3 slices (96 KB) per unit in vain */    \
+    const int irow_ = slice_row(min(p_ + 3, ns - 1));                                                                        \
+    const unsigned fap_ = fa0 + ((p_ + 1) & 3) * TW4_SLOT, fbp_ = fb0 + ((p_ + 1) & 3) * TW4_SLOT;                           \
+    const char* const ar_ = rowptr(abase, irow_, lda2);                                                                      \
+    const char* const br_ = rowptr(bbase, irow_, ldb2);                                                                      \
+    if (do_cs && p_ == cs_next) {                                                                                            \
+      cs_next += cs_slots;                                                                                                   \
+      _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                                                        \
+        const e16x8 f_ = TW4_JOIN(CA[i]);                                                                                    \
+        _Pragma("unroll") for (int j = 0; j < 8; ++j) cs[i] += (float)f_[j];                                                 \
+      }                                                                                                                      \
+    }                                                                                                                        \
+    _Pragma("unroll") for (int gI = 0; gI < 16; ++gI) {                                                                      \
+      if (gI < 8) { const unsigned ad_ = fap_ ^ (gI << 5); TW4_TR(NA[gI][0], ad_, 0); TW4_TR(NA[gI][1], ad_, 2048); }         \
+      else { const unsigned ad_ = fbp_ ^ ((gI - 8) << 5); TW4_TR(NB[gI - 8][0], ad_, 0); TW4_TR(NB[gI - 8][1], ad_, 2048); } \
+      if (gI & 1) issue_piece((p_ + 3) & 3, ar_, br_, gI >> 1);                                                              \
+      {                                                                                                                      \
+        const int i = gI >> 1;                                                                                               \
+        const e16x8 fa_ = TW4_JOIN(CA[i]);                                                                                   \
+        _Pragma("unroll") for (int jj = 0; jj < 4; ++jj) {                                                                   \
+          const int j = 4 * (gI & 1) + jj;                                                                                   \
+          const e16x8 fb_ = TW4_JOIN(CB[j]);                                                                                 \
+          TW4_MFMA(acc[i][j], fa_, fb_);                                                                                     \
+        }                                                                                                                    \
+      }                                                                                                                      \
+      __builtin_amdgcn_sched_barrier(0);                                                                                     \
+    }                                                                                                                        \
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                                                                         \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                                       \
+    __builtin_amdgcn_s_barrier();                                                                                            \
+    __builtin_amdgcn_sched_barrier(0);                                                                                       \
+  }
+  for (int p = 0; p < ns; p += 2) {
+    TW4_PHASE(p, xa, xb, ya, yb)
+    TW4_PHASE(p + 1, ya, yb, xa, xb)
+  }
+#undef TW4_PHASE
+#undef TW4_JOIN
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the pieces issued past the end still target this workgroup's LDS
+
+  if (do_cs) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      float s = cs[i];
+      s += __shfl_xor(s, 16, 64);
+      s += __shfl_xor(s, 32, 64);
+      const int mm = m0 + wm * 128 + i * 16 + fr;
+      if (fq == 0) atomicAdd(g.a_colsum + (g.glu_f ? glu_deint(mm, g.glu_f) : mm), s);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int n = n0 + wn * 128 + j * 16 + fr;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int mm = m0 + wm * 128 + i * 16 + fq * 4 + r;
+        float* c = C + (int64_t)(g.glu_f ? glu_deint(mm, g.glu_f) : mm) * g.ldc + n;
+        if (g.ksplit > 1) atomicAdd(c, acc[i][j][r]);
+        else *c = acc[i][j][r] + (g.accumulate ? *c : 0.f);
+      }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_gemm_tn_w4(MfmaArgs g) {
+  extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];      // (fragment addresses are XORed: the base must not reach bits 5-7)
+  TnProb pr;
+  pr.A = g.A; pr.B = g.B; pr.C = (float*)g.C; pr.a_colsum = g.a_colsum; pr.k_live = g.k_live;
+  pr.M = g.M; pr.N = g.N; pr.K = g.K; pr.lda = g.lda; pr.ldb = g.ldb; pr.ldc = g.ldc;
+  pr.tiles_n = g.tiles_n; pr.ntile = g.tiles_m * g.tiles_n; pr.ksplit = g.ksplit; pr.kchunk = g.kchunk;
+  pr.glu_f = g.glu_f; pr.accumulate = g.accumulate; pr.unit0 = 0;
+  const int bid = xcd_remap(blockIdx.x, pr.ntile * pr.ksplit);
+  tn_w4_unit(pr, bid % pr.ntile, bid / pr.ntile, lds);     // tile index fastest: an XCD's workgroups share a k-chunk
+}
+
+__global__ __launch_bounds__(256) void k_gemm_tn_groupw4(TnGroup gr) {
+  extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
+  const int bid = xcd_remap(blockIdx.x, gr.units);
+  int pi = 0;
+#pragma unroll
+  for (int i = 1; i < AFM_TN_GROUP_MAX; ++i)
+    if (i < gr.n && bid >= gr.p[i].unit0) pi = i;
+  const TnProb pr = gr.p[pi];
+  const int local = bid - pr.unit0;
+  tn_w4_unit(pr, local % pr.ntile, local / pr.ntile, lds);
+}

@@ -247,6 +247,30 @@ def test_gemm_group_wgrads_share_one_launch(ops, dt, R):
     close(nt_c, nt_a.double() @ nt_w.double().T, 1e-2 if dt == torch.bfloat16 else 2e-3, 0.2 if dt == torch.bfloat16 else 0.03)
 
 
+def test_gemm_group_four_wave_unit_at_the_step_size(ops):
+    """The c2 encoder layer's four weight gradients (131 072 tokens) through the four-wave unit (108: built and measured in round 5,
+    not the default) and the eight-wave one: each against fp64, bias gradients included, and one gated problem with the de-interleave."""
+    R = 131072
+    gen = torch.Generator(device=DEV).manual_seed(5)
+    shapes = [(512, 512, 0), (1536, 512, 0), (512, 2048, 0), (2048, 512, 1024)]
+    ten = [((torch.randn(R, M, device=DEV, generator=gen) * 0.05).half(), torch.randn(R, N, device=DEV, generator=gen).half(), glu) for M, N, glu in shapes]
+    for form, algo in ((108, "mfma_tn_groupw4"), (0, "mfma_tn_group256")):
+        outs = [(torch.zeros(dy.shape[1], x.shape[1], device=DEV), torch.zeros(dy.shape[1], device=DEV)) for dy, x, _ in ten]
+        ops.gemm_group([ops.gemm_desc(dy, x, g, trans_a=True, trans_b=False, accumulate=True, a_colsum=gb, glu_rows=glu, variant=form)
+                        for (dy, x, glu), (g, gb) in zip(ten, outs)])
+        assert ops.last_algo() == algo
+        for (dy, x, glu), (g, gb) in zip(ten, outs):
+            ref, refb = (dy.double().T @ x.double()).cpu(), dy.double().sum(0).cpu()
+            if glu:
+                m = torch.arange(ref.shape[0])
+                dest = ((m >> 3) << 2) + (m & 3) + ((m >> 2) & 1) * glu
+                r2, b2 = torch.empty_like(ref), torch.empty_like(refb)
+                r2[dest], b2[dest] = ref, refb
+                ref, refb = r2, b2
+            close(g, ref, 1e-4, 2e-4 * math.sqrt(R) / 4)
+            close(gb, refb, 1e-4, 2e-4 * math.sqrt(R) / 4, "fused bias gradient")
+
+
 def test_gemm_group_matches_single_launches_at_the_step_size(ops):
     """The c2 encoder layer's four weight gradients (131 072 tokens): grouped == one by one (fp32 atomics in another order)."""
     R = 131072
@@ -535,10 +559,12 @@ def test_convert_cast_and_ce_scale(ops):
     close(d1, d2.cpu().double() * 1024.0, 2e-3, 1e-6)
 
 
+@pytest.mark.parametrize("form", [107, 108])
 @pytest.mark.parametrize("dt", [H16, torch.bfloat16])
-def test_wgrad_leaves_out_padded_token_blocks(ops, dt):
+def test_wgrad_leaves_out_padded_token_blocks(ops, dt, form):
     """afm_gemm_desc.k_live: 64-token blocks whose dy rows are exact zeros (padded positions of a training step) are left out of
-    the token axis -- same weight and bias gradients as the full sweep, one by one and grouped."""
+    the token axis -- same weight and bias gradients as the full sweep, one by one and grouped; in the eight-wave unit (107) and in the
+    four-wave unit of round 5 (108, csrc/afm_gemm_tnw4_impl.h)."""
     R = 8192
     live = torch.ones(R // 64, dtype=torch.uint8)
     live[5:40] = 0; live[77] = 0; live[100:] = 0                 # long dead runs, a single dead block, a dead tail
@@ -551,15 +577,16 @@ def test_wgrad_leaves_out_padded_token_blocks(ops, dt):
         ten += [a, b]
         for descs, outs, kl in ((descs_a, outs_a, None), (descs_b, outs_b, dev(live))):
             g, gb = torch.zeros(M, N, device=DEV), torch.zeros(M, device=DEV)
-            descs.append(ops.gemm_desc(a, b, g, trans_a=True, trans_b=False, accumulate=True, a_colsum=gb, k_live=kl)); outs.append((g, gb))
+            descs.append(ops.gemm_desc(a, b, g, trans_a=True, trans_b=False, accumulate=True, a_colsum=gb, k_live=kl, variant=form)); outs.append((g, gb))
             ten.append(kl)
         g1, gb1 = torch.zeros(M, N, device=DEV), torch.zeros(M, device=DEV)
-        ops.gemm(a, b, g1, trans_a=True, trans_b=False, accumulate=True, a_colsum=gb1, k_live=dev(live), variant=105)   # alone, 256 x 256 form
+        ops.gemm(a, b, g1, trans_a=True, trans_b=False, accumulate=True, a_colsum=gb1, k_live=dev(live), variant=form)   # alone, 256 x 256 tiles
+        assert ("w4" in ops.last_algo()) == (form == 108)
         ref = a.double().T @ b.double()
         close(g1, ref.cpu(), 1e-4, 2e-4 * math.sqrt(R) / 4)
         close(gb1, a.double().sum(0).cpu(), 1e-4, 2e-4 * math.sqrt(R) / 4)
     ops.gemm_group(descs_a); ops.gemm_group(descs_b)
-    assert ops.last_algo() == "mfma_tn_group256"
+    assert ops.last_algo() == ("mfma_tn_groupw4" if form == 108 else "mfma_tn_group256")
     for (g0, b0), (g1, b1) in zip(outs_a, outs_b):
         torch.testing.assert_close(g0, g1, rtol=1e-5, atol=2e-4)
         torch.testing.assert_close(b0, b1, rtol=1e-5, atol=2e-4)

@@ -134,3 +134,19 @@ def test_param_spans_must_be_contiguous():
     ps = ParamStore(build_specs(bad, wl["data"], 128), "cpu", False)
     with pytest.raises(ValueError):
         ps.vec_span(ps.flat, "encoder.layers.0.linear1.bias", 0, 20)
+
+
+def test_elementwise_dropout_stream_statistics():
+    """The two-level element-wise dropout stream (csrc/afm_common.h afm_keep / afm_keep_scale, restated in tests/dropmask.py): keep
+    rate within 3 sigma of 1 - p and serial correlations at lags 1-4, 16, 64 (the block length) inside 4.5 sigma (lag 2 and
+    lag 16 sit at -2 .. -3 sigma, i.e. about -1e-3, on every seed; tools/hash_quality.py prints the table)."""
+    import numpy as np
+    from tests.dropmask import keep_mask
+    n = 1 << 21
+    for seed, site in ((12345, 7), (99, 3)):
+        k = keep_mask(0.1, seed, site, n).astype(np.float64)
+        assert abs(k.mean() - 0.9) < 3 * np.sqrt(0.09 / n) + 2.0 ** -16
+        s = k - k.mean()
+        for lag in (1, 2, 3, 4, 16, 64):
+            c = float((s[:-lag] * s[lag:]).mean() / s.var()) * np.sqrt(n)
+            assert abs(c) < 4.5, (seed, site, lag, c)

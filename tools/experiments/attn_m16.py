@@ -17,7 +17,7 @@ def t(fn, it=40, warm=30):
     return a.elapsed_time(b) / it
 
 
-def case(B, H, Tq, Tk, p, causal, pad, dt=torch.float16, seed=0):
+def case(B, H, Tq, Tk, p, causal, pad, dt=torch.float16, seed=0, bits=False):
     dev, dh = "cuda:0", 64
     d = H * dh
     g = torch.Generator(device=dev).manual_seed(seed)
@@ -30,7 +30,8 @@ def case(B, H, Tq, Tk, p, causal, pad, dt=torch.float16, seed=0):
         n = torch.randint(Tk // 3, Tk + 1, (B,), device=dev, generator=g)
         kp = (torch.arange(Tk, device=dev)[None, :] >= n[:, None]).to(torch.uint8).contiguous()
     dr = ops.drop(p, 7, 3)
-    mk = lambda res: _shape(B, H, Tq, Tk, dh, dt, q, k, v, o, kp, causal, dr, res)
+    kb = torch.zeros(ops.attn_drop_bits_words(B, H, Tq, Tk), dtype=torch.int64, device=dev) if (bits and p > 0) else None
+    mk = lambda res: ops.attn_set_drop_bits(_shape(B, H, Tq, Tk, dh, dt, q, k, v, o, kp, causal, dr, res), kb)
     ops.attn_fwd(mk(0), q, k, v, o, lse)
     outs = []
     for res in (1, 1 | 1024):
@@ -42,7 +43,7 @@ def case(B, H, Tq, Tk, p, causal, pad, dt=torch.float16, seed=0):
     err = float((a - b).abs().max() / a.abs().max())
     derr = float((da - db).abs().max() / da.abs().max())
     ok = bool(torch.isfinite(b).all()) and err < 4e-3 and derr < 1e-5
-    print(f"B{B} H{H} Tq{Tq} Tk{Tk} p={p} causal={causal} pad={pad} {dt}: dQ 16x16x32 vs 32x32x16 rel {err:.2e}, delta {derr:.1e}  {'ok' if ok else 'FAIL'}", flush=True)
+    print(f"B{B} H{H} Tq{Tq} Tk{Tk} p={p} causal={causal} pad={pad} bits={bits} {dt}: dQ 16x16x32 vs 32x32x16 rel {err:.2e}, delta {derr:.1e}  {'ok' if ok else 'FAIL'}", flush=True)
     return ok
 
 
@@ -54,12 +55,21 @@ def _shape(B, H, Tq, Tk, dh, dt, q, k, v, o, kp, causal, dr, res):
 
 def main():
     ok = True
+    if "--time-only" in sys.argv:
+        return times()
     for (B, H, Tq, Tk, p, causal, pad) in [(2, 4, 128, 128, 0.0, False, False), (2, 4, 256, 256, 0.1, False, False), (3, 2, 128, 384, 0.0, False, True),
                                             (2, 8, 256, 256, 0.1, True, True), (2, 4, 100, 200, 0.1, False, True), (1, 12, 128, 1024, 0.0, False, True),
                                             (4, 8, 1024, 1024, 0.1, False, False)]:
         ok &= case(B, H, Tq, Tk, p, causal, pad)
     ok &= case(2, 4, 256, 256, 0.1, False, True, dt=torch.bfloat16)
+    for (B, H, Tq, Tk, p, causal, pad) in [(2, 4, 256, 256, 0.1, False, False), (2, 8, 256, 256, 0.1, True, True), (3, 2, 128, 384, 0.1, False, True),
+                                            (4, 8, 1024, 1024, 0.1, False, True)]:
+        ok &= case(B, H, Tq, Tk, p, causal, pad, bits=True)
     print("ALL OK" if ok else "FAILURES", flush=True)
+    times()
+
+
+def times():
     B, H, S, dh, dt, dev = 128, 8, 1024, 64, torch.float16, "cuda:0"
     d = H * dh
     qkv = (torch.randn(B * S, 3 * d, device=dev)).to(dt)
@@ -68,17 +78,18 @@ def main():
     dqkv = torch.empty_like(qkv); dq, dk, dv = dqkv[:, :d], dqkv[:, d:2 * d], dqkv[:, 2 * d:]
     lse, delta = torch.empty(B * H * S, device=dev), torch.empty(B * H * S, device=dev)
     prod = 2.0 * B * H * S * S * dh
-    for p in (0.0, 0.1):
+    for p, bits in ((0.0, False), (0.1, False), (0.1, True)):
         dr = ops.drop(p, 1, 3)
-        mk = lambda res: _shape(B, H, S, S, dh, dt, q, k, v, o, None, False, dr, res)
+        kb = torch.zeros(ops.attn_drop_bits_words(B, H, S, S), dtype=torch.int64, device=dev) if bits else None
+        mk = lambda res: ops.attn_set_drop_bits(_shape(B, H, S, S, dh, dt, q, k, v, o, None, False, dr, res), kb)
         ops.attn_fwd(mk(0), q, k, v, o, lse)
-        s32, s16 = mk(1), mk(1 | 1024)
-        f32 = lambda: ops.attn_bwd(s32, q, k, v, o, do, lse, delta, dq, dk, dv, ops._ld(dq), ops._ld(dk), ops._ld(dv))
-        f16 = lambda: ops.attn_bwd(s16, q, k, v, o, do, lse, delta, dq, dk, dv, ops._ld(dq), ops._ld(dk), ops._ld(dv))
+        shapes = {"32x32x16": mk(1), "16x16x32": mk(1 | 1024), "16x16x32 occ2": mk(1 | 1024 | 2048)}
+        fns = {n: (lambda sh=sh: ops.attn_bwd(sh, q, k, v, o, do, lse, delta, dq, dk, dv, ops._ld(dq), ops._ld(dk), ops._ld(dv))) for n, sh in shapes.items()}
         for rnd in range(3):
-            a, b = (t(f32), t(f16)) if rnd % 2 == 0 else tuple(reversed((t(f16), t(f32))))
-            print(f"c2 encoder shape, dropout {p} ({'re-hash' if p else 'none'}), round {rnd}: dQ 32x32x16 {a:.4f} ms ({3 * prod / a / 1e9:.0f} TF/s)   "
-                  f"16x16x32 {b:.4f} ms ({3 * prod / b / 1e9:.0f} TF/s)   ratio {b / a:.3f}", flush=True)
+            order = list(fns) if rnd % 2 == 0 else list(fns)[::-1]
+            ms = {n: t(fns[n]) for n in order}
+            print(f"c2 encoder shape, dropout {p} ({'keep bits' if bits else 're-hash' if p else 'none'}), round {rnd}: " +
+                  "   ".join(f"{n} {ms[n]:.4f} ms ({3 * prod / ms[n] / 1e9:.0f} TF/s)" for n in fns), flush=True)
 
 
 if __name__ == "__main__":

@@ -30,7 +30,8 @@ def passes(path, reps):
 
 def main():
     O, tag, reps = sys.argv[1], sys.argv[2], int(sys.argv[3])
-    names = subprocess.run([sys.executable, os.path.join(here, "prof_gemm_run.py"), "--list"], capture_output=True, text=True).stdout.split()
+    which = sys.argv[4] if len(sys.argv) > 4 else "c2"
+    names = subprocess.run([sys.executable, os.path.join(here, "prof_gemm_run.py"), "--list", "--set", which], capture_output=True, text=True).stdout.split()
     merged = {n: {} for n in names}
     for i in range(1, 6):
         p = os.path.join(O, f"{tag}_gemm_pass{i}.db")

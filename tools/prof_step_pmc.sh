@@ -14,7 +14,7 @@ G3="WRITE_SIZE"
 i=0
 for g in "$G1" "$G2" "$G3"; do
   i=$((i+1))
-  timeout 600 rocprofv3 --kernel-trace --pmc $g -d $O/spmc_$i -o pmc -- python3 $R/bench.py --workload $wl --dtype $dt --steps 2 --warmup 1 --other-modes "" --extra-workloads "" --no-roofline --no-cpu-baseline --no-input-compare > $O/${tag}_step_$i.log 2>&1
+  timeout 600 rocprofv3 --kernel-trace --pmc $g -d $O/spmc_$i -o pmc -- python3 $R/bench.py --workload $wl --dtype $dt --steps 2 --warmup 1 --other-modes "" --extra-workloads "" --no-roofline --no-cpu-baseline --no-input-compare --no-eval > $O/${tag}_step_$i.log 2>&1
   cp $(find $O/spmc_$i -name "*.db" | head -1) $O/${tag}_step_pass$i.db 2>/dev/null
   rm -rf $O/spmc_$i
 done
