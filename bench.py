@@ -680,6 +680,11 @@ def main():
                             "dtype": args.dtype}
             if "parity" in r:
                 workloads[w]["logits_vs_cpu_reference"] = r["parity"]
+            wsp = os.path.join(ROOT, "profiles", f"r05_{w}_{args.dtype}_step_pmc.json")       # committed counter passes of this workload's step
+            if os.path.exists(wsp):
+                wp = json.load(open(wsp))
+                workloads[w]["step_counters"] = {"source": os.path.basename(wsp), **{k: wp[k] for k in
+                                                 ("mfma_busy_frac", "hbm_gbs", "clock_ghz", "hbm_bytes_per_step", "kernel_ms_per_step") if k in wp}}
             if w == "c4" and not args.no_roofline:
                 # the configuration the 8-GPU target is quoted on: live HIP-event timings of ITS dominant launches
                 workloads[w]["roofline_kernels"] = kernel_rooflines(r["model"], r["wl"], r["B"], args.dtype, w)
@@ -699,9 +704,11 @@ def main():
 
     # step-level counters (committed rocprofv3 PMC passes of this command, tools/prof_step_pmc.sh): MFMA-busy share and HBM rate of a step
     step_pmc = None
-    sp = os.path.join(ROOT, "profiles", f"r04_{args.workload}_{args.dtype}_step_pmc.json")
-    if os.path.exists(sp):
-        step_pmc = json.load(open(sp))
+    for rnd in ("r05", "r04"):
+        sp = os.path.join(ROOT, "profiles", f"{rnd}_{args.workload}_{args.dtype}_step_pmc.json")
+        if os.path.exists(sp):
+            step_pmc = json.load(open(sp))
+            break
 
     out = {
         "metric": METRIC, "value": round(value, 3), "unit": "samples/s",

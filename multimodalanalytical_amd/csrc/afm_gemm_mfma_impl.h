@@ -33,12 +33,43 @@ struct MfmaArgs {
   int live_off;            // NT, persistent kernels: LDS byte offset of the live / dead tile lists (0: no hint in use)
   int act, accumulate;
   int tiles_m, tiles_n;
+  int xgc;             // persistent NT kernels: column groups of the XCD-aware tile walk (tile_mn below); 0 / 1 = row-major
   int ksplit, kchunk;  // TN only
   int bias_in_lds;     // persistent NT: staged epilogue enabled (bias vector cached in LDS)
   int glu_f;           // gated-FFN interleave (include/afm_hip.h): bias / wgrad rows are translated to the [W1 ; Wg] order
   unsigned long long* stamps;   // ablation builds: per-workgroup phase time stamps (wall_clock64), else null
   DropDev dd;
 };
+
+// Tile index -> (row tile, column tile) of the persistent NT kernels.  XCD x owns the indices [x * tpx, (x + 1) * tpx).  Row-major
+// (xgc <= 1) that is a band of row panels with ALL column tiles: every A panel is fetched once, but the whole weight matrix streams
+// through the XCD's 4-MB L2 once per row panel -- fine while it fits (c2: <= 2 MB), ruinous when it does not: c4's gated FFN
+// up-projection (N 6144, K 768: 9.4 MB) read 3.9 GB per launch for 0.21 GB of operands (profiles/r05_c4_gemm_fp16_pmc.json, L2 hit 0.56).
+// With xgc column groups an XCD owns a RECTANGLE: (tiles_m / (8 / xgc)) row panels x (tiles_n / xgc) column tiles, walked row-major
+// inside it, so its slice of the weights stays in L2 and an A panel is fetched by xgc XCDs instead of one.  The launchers pick xgc
+// (nt_pick_xgc) where the weights exceed what an L2 keeps and the tile grid divides evenly.
+__device__ __forceinline__ void tile_mn(const MfmaArgs& g, int tile, int& mt, int& nt) {
+  if (g.xgc <= 1) { mt = tile / g.tiles_n; nt = tile % g.tiles_n; return; }
+  const int tpx = (g.tiles_m * g.tiles_n) >> 3;
+  const int x = tile / tpx, i = tile - x * tpx;
+  const int cw = g.tiles_n / g.xgc, rh = g.tiles_m / (8 / g.xgc);
+  mt = (x / g.xgc) * rh + i / cw;
+  nt = (x % g.xgc) * cw + i % cw;
+}
+static inline int nt_pick_xgc(int tiles_m, int tiles_n, int64_t weight_bytes) {
+  static const int force = getenv("AFM_NT_XGC") ? atoi(getenv("AFM_NT_XGC")) : -1;     // (A / B runs: 1 = row-major everywhere)
+  const int64_t keep = 5 * 512 * 1024;                           // 2.5 MB of a 4-MB L2 for the weights
+  if (((int64_t)tiles_m * tiles_n) & 7) return 1;
+  int pick = 1;
+  if (force < 0 && weight_bytes <= keep) return 1;
+  for (int gc = 2; gc <= 8; gc *= 2) {
+    if (tiles_n % gc || tiles_m % (8 / gc)) continue;
+    pick = gc;
+    if (force < 0 && weight_bytes / gc <= keep) break;
+    if (force == gc) break;
+  }
+  return force == 1 ? 1 : pick;
+}
 
 #define BM 128
 #define BN 128
@@ -585,7 +616,9 @@ __device__ __forceinline__ void nt_tile_lists(const MfmaArgs& g, int* list, int 
       const bool valid = tt < thi;
       bool live = false;
       if (valid) {
-        const int mb = (tt / g.tiles_n) * (TBM / 64);
+        int mt_, nt_;
+        tile_mn(g, tt, mt_, nt_);
+        const int mb = mt_ * (TBM / 64);
 #pragma unroll
         for (int i = 0; i < TBM / 64; ++i) live |= g.k_live[mb + i] != 0;
       }
@@ -605,7 +638,9 @@ __device__ __forceinline__ void nt_tile_lists(const MfmaArgs& g, int* list, int 
   constexpr int EB = C16 ? 2 : 4, PER = 16 / EB, CPR = CM * TBN / PER;   // 16-byte chunks per tile row
   for (int i = 0; i < nd; ++i) {
     const int tt = dead[1 + i];
-    const int m0 = (tt / g.tiles_n) * TBM, n0 = (tt % g.tiles_n) * TBN * CM;
+    int mt_, nt_;
+    tile_mn(g, tt, mt_, nt_);
+    const int m0 = mt_ * TBM, n0 = nt_ * TBN * CM;
     for (int c = t; c < TBM * CPR; c += NTHREADS) {
       const int r = c / CPR, cc = (c % CPR) * PER;
       if (n0 + cc < CM * g.N) *(uint4*)((char*)g.C + ((int64_t)(m0 + r) * g.ldc + n0 + cc) * EB) = make_uint4(0u, 0u, 0u, 0u);
@@ -656,7 +691,9 @@ __global__ __launch_bounds__(64 * NWM * NWN) void k_gemm_nt_pring(MfmaArgs g) {
 
   const e16* src[NIW];
   auto set_src = [&](int tile) {
-    const int m0 = (tile / g.tiles_n) * TBM, n0 = (tile % g.tiles_n) * TBN;
+    int mt_, nt_;
+    tile_mn(g, tile, mt_, nt_);
+    const int m0 = mt_ * TBM, n0 = nt_ * TBN;
 #pragma unroll
     for (int j = 0; j < NIW; ++j) {
       const int ii = w + NW * j;
@@ -697,7 +734,9 @@ __global__ __launch_bounds__(64 * NWM * NWN) void k_gemm_nt_pring(MfmaArgs g) {
   for (int it = 0;; ++it) {
     const int tile = tile_of(it);
     if (tile < 0) break;
-    const int m0 = (tile / g.tiles_n) * TBM, n0 = (tile % g.tiles_n) * TBN;
+    int mt_, nt_;
+    tile_mn(g, tile, mt_, nt_);
+    const int m0 = mt_ * TBM, n0 = nt_ * TBN;
 #ifdef AFM_GEMM_ABLATIONS
     if (g.stamps && t == 0 && it < 16) g.stamps[(blockIdx.x * 16 + it) * 4 + 0] = wall_clock64();
 #endif
@@ -787,6 +826,7 @@ static int launch_nt_pring(MfmaArgs& g, hipStream_t st, int blocks_per_cu) {
   constexpr int ring = S * (TBM + TBN) * 128;
   static_assert(ring <= 160 * 1024, "ring does not fit the 160 KiB LDS");
   g.tiles_m = (g.M + TBM - 1) / TBM; g.tiles_n = (g.N + TBN - 1) / TBN;
+  g.xgc = (g.M % TBM == 0 && g.N % TBN == 0 && blocks_per_cu == 1) ? nt_pick_xgc(g.tiles_m, g.tiles_n, (int64_t)g.N * g.K * 2) : 1;
   // staged epilogue: needs 16-byte rows everywhere and room for the bias vector behind the ring
   const int bias_bytes = ((g.N * 4 + 15) / 16) * 16;
   const bool rows16 = (g.N % 8) == 0 && (g.ldc % 8) == 0;
@@ -851,7 +891,9 @@ __global__ __launch_bounds__(64 * (8 + NL)) void k_gemm_nt_ws(MfmaArgs g) {
     return tt < thi ? tt : -1;
   };
   auto tile_full = [&](int tile) {
-    const int m0 = (tile / g.tiles_n) * TBM, n0 = (tile % g.tiles_n) * TBN;
+    int mt_, nt_;
+    tile_mn(g, tile, mt_, nt_);
+    const int m0 = mt_ * TBM, n0 = nt_ * TBN;
     return g.bias_in_lds && m0 + TBM <= g.M && n0 + TBN <= g.N;
   };
   const int nk = g.K / 64;
@@ -861,7 +903,9 @@ __global__ __launch_bounds__(64 * (8 + NL)) void k_gemm_nt_ws(MfmaArgs g) {
     const int lw = w - NW;
     const e16* src[NIL];
     auto set_src = [&](int tile) {
-      const int m0 = (tile / g.tiles_n) * TBM, n0 = (tile % g.tiles_n) * TBN;
+      int mt_, nt_;
+    tile_mn(g, tile, mt_, nt_);
+    const int m0 = mt_ * TBM, n0 = nt_ * TBN;
 #pragma unroll
       for (int j = 0; j < NIL; ++j) {
         const int ii = lw + NL * j;
@@ -931,7 +975,9 @@ __global__ __launch_bounds__(64 * (8 + NL)) void k_gemm_nt_ws(MfmaArgs g) {
   for (int it = 0;; ++it) {
     const int tile = tile_of(it);
     if (tile < 0) break;
-    const int m0 = (tile / g.tiles_n) * TBM, n0 = (tile % g.tiles_n) * TBN;
+    int mt_, nt_;
+    tile_mn(g, tile, mt_, nt_);
+    const int m0 = mt_ * TBM, n0 = nt_ * TBN;
     f32x4 acc[4][WM];
 #pragma unroll
     for (int j = 0; j < 4; ++j)
@@ -1010,6 +1056,7 @@ static int launch_nt_ws(MfmaArgs& g, hipStream_t st) {
   constexpr int TBM = 256, TBN = 128, S = 3;
   constexpr int ring = S * (TBM + TBN) * 128;
   g.tiles_m = (g.M + TBM - 1) / TBM; g.tiles_n = (g.N + TBN - 1) / TBN;
+  g.xgc = (g.M % TBM == 0 && g.N % TBN == 0) ? nt_pick_xgc(g.tiles_m, g.tiles_n, (int64_t)g.N * g.K * 2) : 1;
   const int bias_bytes = ((g.N * 4 + 15) / 16) * 16;
   const bool rows16 = (g.N % 8) == 0 && (g.ldc % 8) == 0;
   const bool modes_ok = C_BF16 ? (!g.residual && !g.accumulate) : true;
@@ -1566,7 +1613,7 @@ int AFM_E16_FN(afm_gemm_mfma_try)(const afm_gemm_desc* d, hipStream_t st) {
   g.act = d->act; g.accumulate = d->accumulate;
   g.dd = afm_make_drop(&d->drop);
   g.tiles_m = (d->M + BM - 1) / BM; g.tiles_n = (d->N + BN - 1) / BN;
-  g.ksplit = 1; g.kchunk = d->K; g.bias_in_lds = 0; g.live_off = 0;
+  g.ksplit = 1; g.kchunk = d->K; g.bias_in_lds = 0; g.live_off = 0; g.xgc = 0;
   g.glu_f = d->glu_rows;
   g.stamps = nullptr;
 #ifdef AFM_GEMM_ABLATIONS

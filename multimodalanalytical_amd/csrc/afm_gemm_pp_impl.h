@@ -127,7 +127,9 @@ __global__ __launch_bounds__(512) void k_gemm_nt_pp(MfmaArgs g) {
   const char* is_b = nullptr;
   auto is_set = [&]() {
     if (is_tile < 0) return;
-    const int m0 = (is_tile / g.tiles_n) * 256, n0 = (is_tile % g.tiles_n) * 256;
+    int mt_, nt_;
+    tile_mn(g, is_tile, mt_, nt_);
+    const int m0 = mt_ * 256, n0 = nt_ * 256;
     is_a = (const char*)(g.A + (int64_t)m0 * g.lda + is_kt * 64);
     is_b = (const char*)(g.B + (int64_t)n0 * g.ldb + is_kt * 64);
   };
@@ -219,7 +221,9 @@ __global__ __launch_bounds__(512) void k_gemm_nt_pp(MfmaArgs g) {
   for (int it = 0;; ++it) {
     const int tile = tile_of(it);
     if (tile < 0) break;
-    const int m0 = (tile / g.tiles_n) * 256, n0 = (tile % g.tiles_n) * 256;
+    int mt_, nt_;
+    tile_mn(g, tile, mt_, nt_);
+    const int m0 = mt_ * 256, n0 = nt_ * 256;
 #ifdef AFM_GEMM_ABLATIONS
     tstamp_on = g.stamps && blockIdx.x < 32 && (w & 3) == 0 && lane == 0 && it < 16;
     stamp_on = tstamp_on && it == 3 && nk <= 8;
@@ -395,6 +399,7 @@ __global__ __launch_bounds__(512) void k_gemm_nt_pp(MfmaArgs g) {
 template <int EPI, int ABL = 0, bool SPLIT = false, bool BAL = false, bool ONEBAR = false>
 static int launch_nt_pp(MfmaArgs& g, hipStream_t st) {
   g.tiles_m = g.M / 256; g.tiles_n = g.N / 256;
+  g.xgc = nt_pick_xgc(g.tiles_m, g.tiles_n, (int64_t)g.N * g.K * 2);
   int shm = PP_LIST_OFF;
   g.live_off = 0;
   const int ntiles = g.tiles_m * g.tiles_n;

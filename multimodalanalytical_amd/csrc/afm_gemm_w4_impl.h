@@ -92,7 +92,9 @@ __global__ __launch_bounds__(256) void k_gemm_nt_w4(MfmaArgs g) {
   const char* is_a = nullptr;
   const char* is_b = nullptr;
   auto is_set = [&]() {
-    const int m0 = (is_tile / g.tiles_n) * 256, n0 = (is_tile % g.tiles_n) * 256;
+    int mt_, nt_;
+    tile_mn(g, is_tile, mt_, nt_);
+    const int m0 = mt_ * 256, n0 = nt_ * 256;
     is_a = (const char*)(g.A + (int64_t)m0 * g.lda + is_kt * 64);
     is_b = (const char*)(g.B + (int64_t)n0 * g.ldb + is_kt * 64);
   };
@@ -189,7 +191,9 @@ __global__ __launch_bounds__(256) void k_gemm_nt_w4(MfmaArgs g) {
   for (int it = 0;; ++it) {
     const int tile = tile_of(it);
     if (tile < 0) break;
-    const int m0 = (tile / g.tiles_n) * 256, n0 = (tile % g.tiles_n) * 256;
+    int mt_, nt_;
+    tile_mn(g, tile, mt_, nt_);
+    const int m0 = mt_ * 256, n0 = nt_ * 256;
     {  // accumulators start from the bias of their columns
 #pragma unroll
       for (int c = 0; c < 2; ++c)
@@ -312,6 +316,7 @@ __global__ __launch_bounds__(256) void k_gemm_nt_w4(MfmaArgs g) {
 template <int ABL = 0>
 static int launch_nt_w4(MfmaArgs& g, hipStream_t st) {
   g.tiles_m = g.M / 256; g.tiles_n = g.N / 256;
+  g.xgc = nt_pick_xgc(g.tiles_m, g.tiles_n, (int64_t)g.N * g.K * 2);
   int shm = W4_LIST_OFF;
   g.live_off = 0;
   const int ntiles = g.tiles_m * g.tiles_n;
