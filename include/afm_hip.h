@@ -236,7 +236,10 @@ typedef struct {
                              afm_attn_bwd, dK/dV kernel selection (A / B tests; every form gives bit-identical dK / dV): bit 7 (128) the round-3
                              kernel instead of the software-pipelined one (csrc/afm_attn_pipe_impl.h: default where there is no causal mask, Tq % 64 == 0
                              and dropout runs through drop_bits or is off); bit 8 (256) its eight-wave form; bit 9 (512) its form with 64 keys per
-                             wave.  Bits 12-19: timing ablations, only in AFM_ATTN_ABLATIONS builds (never in the product library). */
+                             wave.  Round 5: the four-wave pipelined kernel runs on v_mfma_f32_16x16x32 by default (csrc/afm_attn_pipe16_impl.h;
+                             equal to the others to rounding, not bit for bit); bit 14 (16384) keeps its 32 x 32 x 16 form, bit 12 (4096) selects the
+                             round-3 kernel restated on 16 x 16 x 32, bits 10-11 (1024, 2048) the 16 x 16 x 32 dQ kernels (the default without dropout and where the
+                             hash is re-evaluated; bit 15 (32768) keeps the 32 x 32 x 16 dQ kernel there).  Bits 12-19 are timing ablations instead in AFM_ATTN_ABLATIONS builds (never in the product library). */
   const uint8_t* key_pad;
   afm_dropout drop;
   /* batch strides in ELEMENTS of Q, K, V, O (0 = dense: Tq*ldq, Tk*ldk, Tk*ldv, Tq*ldo).  Non-dense

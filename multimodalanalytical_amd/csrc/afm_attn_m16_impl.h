@@ -277,3 +277,249 @@ __global__ __launch_bounds__(256, OCC) void k_attn_bwd_dq_m16(AttnM a, const e16
   }
   store_dq(false);
 }
+
+// ------------------------------------------------------------------------------------------ dK, dV on 16x16x32
+// k_attn_bwd_dkv_mfma (the round-3 kernel: workgroup = 4 waves x 32 keys, key on the lane, loops over 64-query tiles) restated on
+// v_mfma_f32_16x16x32 at the same output tile per wave.  For THIS kernel the keep-bit tensor needs no re-assembly: the 32 x 32 layout
+// keeps the 32 query bits of one key in one dword (the round-3 kernel reads exactly that), and a lane of a 16 x 16 tile -- key 16 ki + c,
+// queries 16 qi + 4 g + r -- tests bits 16 qi + 4 g + r of its key's dword.
+//   * K / V fragments of the wave's two 16-key tiles stay in registers (B operands of S = Q K^T and dP = dO V^T);
+//   * S / dP of a 32-query block = 2 x 2 tiles, two k-steps of 32 over dh: 8 + 8 MFMAs; the accumulators start from -lse[q] / -delta[q]
+//     (one 16-byte LDS read per query tile: the lane's four queries are consecutive);
+//   * P~ and dS as B operands of dV^T += dO^T P~ and dK^T += Q^T dS: k-index 8 g + j <-> query 16 (j >> 2) + 4 g + (j & 3) of the
+//     block -- the four registers of query tile 0, then those of tile 1; the A operands take that order from two transposed reads each;
+//   * ONE image per tile for Q and dO, read by rows (S, dP) AND transposed (dK, dV): the swizzle chunk ^ ((row >> 1) & 3) << 1 is
+//     conflict-free for both patterns of the 16 x 16 x 32 shape (row reads: the lane groups of ds_read_b128 see rows {0-3, 12-15} at
+//     chunk c and {4-11} at c ^ 1, i.e. eight different (row parity, position) slots per parity; transposed reads: the four same-parity
+//     rows of a 32-lane half land in four different chunk pairs), so the images and the LDS-DMA are those of the round-3 kernel.
+// DROP_NONE and DROP_BITS; selected by afm_attn_shape.reserved & 4096 (an A/B form, never the default).
+__device__ __forceinline__ e16x8 frag_row16_d(const unsigned char* img, int R0, int ks, int lane) {      // row fragment of a tr16-swizzled image
+  const int c16 = lane & 15;
+  return *(const e16x8*)(img + (R0 + c16) * 128 + (((4 * ks + (lane >> 4)) ^ (((c16 >> 1) & 3) << 1)) << 4));
+}
+
+template <int DROP>
+__global__ __launch_bounds__(256, 2) void k_attn_bwd_dkv_m16(AttnM a, const e16* __restrict__ Q,
+                                                          const e16* __restrict__ K,
+                                                          const e16* __restrict__ V,
+                                                          const e16* __restrict__ dO,
+                                                          const float* __restrict__ lse,
+                                                          const float* __restrict__ delta,
+                                                          e16* __restrict__ dK, e16* __restrict__ dV) {
+  static_assert(DROP == DROP_NONE || DROP == DROP_BITS, "the re-hash path stays with the round-3 kernel");
+  constexpr int IMG = KT * DH * 2;
+  constexpr int STAGE = 2 * IMG + 2 * KT * 4 + 4 * 256;   // Q, dO images; lse, -delta; two 128-byte keep-bit blocks per wave
+  constexpr int DS = 2;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  const int t = threadIdx.x, lane = t & 63, g = lane >> 4, c16 = lane & 15;
+  const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+  const AttnBlock blk_ = attn_block(a.H, a.B, (a.Tk + 127) / 128);
+  const int hd = blk_.hd, b = blk_.b;
+  const int k0 = blk_.xb * 128 + w * 32;
+  const e16* Qb = Q + (int64_t)b * a.Tq * a.ldq + hd * DH;
+  const e16* Db = dO + (int64_t)b * a.Tq * a.ldo + hd * DH;
+  int key[2];
+  bool kmasked[2];
+  e16x8 kf[2][2], vf[2][2];
+  bool wave_all_masked = true;
+#pragma unroll
+  for (int ki = 0; ki < 2; ++ki) {
+    key[ki] = k0 + 16 * ki + c16;
+    const int kc = key[ki] < a.Tk ? key[ki] : a.Tk - 1;
+    kmasked[ki] = key[ki] >= a.Tk || (a.key_pad && a.key_pad[(int64_t)b * a.Tk + kc]);
+    wave_all_masked = wave_all_masked && __all(kmasked[ki]);
+    const e16* kp = K + ((int64_t)b * a.Tk + kc) * a.ldk + hd * DH + 8 * g;
+    const e16* vp = V + ((int64_t)b * a.Tk + kc) * a.ldv + hd * DH + 8 * g;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      kf[ki][ks] = ld8_once(kp + 32 * ks); vf[ki][ks] = ld8_once(vp + 32 * ks);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {      // K by scale * log2(e) (p = exp2(S') is one instruction), V by the dropout scale
+        kf[ki][ks][j] = (e16)((float)kf[ki][ks][j] * a.scale_log2);
+        if (DROP != DROP_NONE) vf[ki][ks][j] = (e16)((float)vf[ki][ks][j] * a.dd.scale16);
+      }
+    }
+  }
+  f32x4 dk[4][2], dv[4][2];
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+    for (int ki = 0; ki < 2; ++ki) { dk[dt][ki] = (f32x4){0.f, 0.f, 0.f, 0.f}; dv[dt][ki] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+
+  int qbeg = 0;
+  if (a.causal) qbeg = (blk_.xb * 128) / KT * KT;   // queries before the block's first key see none of it
+  const int ntiles = (a.Tq - qbeg + KT - 1) / KT;
+  const int64_t lbase = ((int64_t)b * a.H + hd) * a.Tq;
+  unsigned long long* qmaskw = (unsigned long long*)(lds + DS * STAGE);
+  int* const tl = (int*)(qmaskw + (a.Tq + KT - 1) / KT) + 1;
+  if (a.qskip) build_mask_words(qmaskw, a.key_pad, b, a.Tq, (a.Tq + KT - 1) / KT, w, lane);
+  auto store = [&](bool zeros) {
+#pragma unroll
+    for (int ki = 0; ki < 2; ++ki)
+      if (key[ki] < a.Tk) {
+        e16* dkp = dK + ((int64_t)b * a.Tk + key[ki]) * a.lddk + hd * DH + 4 * g;
+        e16* dvp = dV + ((int64_t)b * a.Tk + key[ki]) * a.lddv + hd * DH + 4 * g;
+        const bool z = zeros || kmasked[ki];      // a padded key took no part in any softmax: its dK / dV rows are zero
+        const float sv = DROP != DROP_NONE ? a.dd.scale16 : 1.0f;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+          e16x4 x = {(e16)0.f, (e16)0.f, (e16)0.f, (e16)0.f}, y = x;
+          if (!z) {
+            x = (e16x4){(e16)(dk[dt][ki][0] * a.scale), (e16)(dk[dt][ki][1] * a.scale), (e16)(dk[dt][ki][2] * a.scale), (e16)(dk[dt][ki][3] * a.scale)};
+            y = (e16x4){(e16)(dv[dt][ki][0] * sv), (e16)(dv[dt][ki][1] * sv), (e16)(dv[dt][ki][2] * sv), (e16)(dv[dt][ki][3] * sv)};
+          }
+          *(e16x4*)(dkp + 16 * dt) = x;
+          *(e16x4*)(dvp + 16 * dt) = y;
+        }
+      }
+  };
+  if (__syncthreads_and(wave_all_masked)) {   // 128 padded keys: zeros, nothing to load
+    store(true);
+    return;
+  }
+  build_tile_list(tl, a.qskip ? qmaskw : nullptr, qbeg / KT, qbeg / KT + ntiles, w, lane);
+  __syncthreads();   // K / V fragment loads retired before the LDS-DMA ring starts
+  const int nlive = __builtin_amdgcn_readfirstlane(tl[-1]);
+  auto issue = [&](int j) {
+    unsigned char* st = lds + (j % DS) * STAGE;
+    const int row0 = tl[j] * KT;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      dma_piece_tr16(st, Qb, a.ldq, row0, a.Tq, w + 4 * u, lane);
+      dma_piece_tr16(st + IMG, Db, a.ldo, row0, a.Tq, w + 4 * u, lane);
+    }
+    if (w < 2) {   // lse / -delta of the tile's 64 queries: one 4-byte piece each
+      int qq = row0 + lane;
+      qq = qq < a.Tq ? qq : a.Tq - 1;
+      const float* src = (w == 0 ? lse : delta) + lbase + qq;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(st + 2 * IMG + w * KT * 4), 4, 0, 0);
+    }
+    if (DROP == DROP_BITS) {   // keep-bit blocks (query block of lanes 0-31 / 32-63, this wave's key block): 2 x 32 dwords, as the round-3 kernel
+      const uint32_t* src = (const uint32_t*)bits_block(a, b * a.H + hd, row0 >> 5, min(k0 >> 5, a.nk32 - 1)) + (lane >> 5) * (a.nk32 * 32) + (lane & 31);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(st + 2 * IMG + 2 * KT * 4 + w * 256), 4, 0, 0);
+    }
+  };
+  // transposed reads (as the dQ form above): one lane address, d-tile dt = an XOR of dt << 5; rows as immediates
+  unsigned tra0;
+  {
+    const int qq = (lane >> 2) & 3, p = lane & 3;
+    const int s2 = 2 * (g & 1) + (qq >> 1);
+    tra0 = (4 * g + qq) * 128 + ((2 * s2 + (p >> 1)) << 4) + ((p & 1) << 3);
+  }
+  issue(0);
+  __builtin_assume(nlive >= 1);
+  for (int j = 0; j < nlive; ++j) {
+    const int qb = __builtin_amdgcn_readfirstlane(tl[j]) * KT;
+    attn_wait_vmcnt<0>();          // this tile's pieces (the only ones in flight)
+    __builtin_amdgcn_s_barrier();
+    if (j + 1 < nlive) issue(j + 1);
+    const unsigned char* Qrow = lds + (j % DS) * STAGE;
+    const unsigned char* Drow = Qrow + IMG;
+    const float* Ls = (const float*)(Qrow + 2 * IMG);   // lse (natural log units)
+    const float* Ds = Ls + KT;                          // -delta
+    const bool ragged = qb + KT > a.Tq;
+    if ((a.causal && qb + KT - 1 < k0) || wave_all_masked || (a.qskip && qmaskw[qb / KT] == ~0ull)) continue;
+    const unsigned qtr = (unsigned)(uintptr_t)Qrow, dtr = (unsigned)(uintptr_t)Drow;
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk) {
+      f32x4 s[2][2], dp[2][2];      // [query tile][key tile]
+#pragma unroll
+      for (int qi = 0; qi < 2; ++qi) {
+        const f32x4 Lq = *(const f32x4*)(Ls + 32 * blk + 16 * qi + 4 * g) * -1.4426950408889634f;
+        const f32x4 Dq = *(const f32x4*)(Ds + 32 * blk + 16 * qi + 4 * g);
+#pragma unroll
+        for (int ki = 0; ki < 2; ++ki) { s[qi][ki] = Lq; dp[qi][ki] = Dq; }
+      }
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int qi = 0; qi < 2; ++qi) {
+          const e16x8 qfr = frag_row16_d(Qrow, 32 * blk + 16 * qi, ks, lane);
+          const e16x8 dfr = frag_row16_d(Drow, 32 * blk + 16 * qi, ks, lane);
+#pragma unroll
+          for (int ki = 0; ki < 2; ++ki) {
+            s[qi][ki] = mfma16(qfr, kf[ki][ks], s[qi][ki]);       // S'[q][key] = S log2(e) / sqrt(dh) - lse[q]
+            dp[qi][ki] = mfma16(dfr, vf[ki][ks], dp[qi][ki]);     // scale dP[q][key] - delta[q]
+          }
+        }
+      if (a.causal || ragged) {   // rare: diagonal tiles of the decoder / the last, partly filled tile
+#pragma unroll
+        for (int qi = 0; qi < 2; ++qi)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int qq = qb + 32 * blk + 16 * qi + 4 * g + r;
+#pragma unroll
+            for (int ki = 0; ki < 2; ++ki) {
+              const bool msk = (a.causal && key[ki] > qq) || qq >= a.Tq;
+              s[qi][ki][r] = msk ? -INFINITY : s[qi][ki][r];
+            }
+          }
+      }
+      f32x4 pd[2][2];
+#pragma unroll
+      for (int qi = 0; qi < 2; ++qi)
+#pragma unroll
+        for (int ki = 0; ki < 2; ++ki)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) pd[qi][ki][r] = fast_exp2(s[qi][ki][r]);
+      if (DROP == DROP_BITS) {
+#pragma unroll
+        for (int ki = 0; ki < 2; ++ki) {
+          // this lane's key of tile ki is key 16 ki + c16 of the wave's 32-key block: its dword holds the 32 query bits of the block
+          const uint32_t word = ((const uint32_t*)(Qrow + 2 * IMG + 2 * KT * 4 + w * 256))[32 * blk + bits_word_of_key(16 * ki + c16)] >> (4 * g);
+#pragma unroll
+          for (int qi = 0; qi < 2; ++qi) {
+            const f32x4 nd = *(const f32x4*)(Ds + 32 * blk + 16 * qi + 4 * g);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const bool kp = (int)(word << (31 - (16 * qi + r))) < 0;
+              s[qi][ki][r] = pd[qi][ki][r] * (kp ? dp[qi][ki][r] : nd[r]);      // dS = P (D dP - delta)
+              pd[qi][ki][r] = kp ? pd[qi][ki][r] : 0.f;                           // dropped P for dV
+            }
+          }
+        }
+      } else {
+#pragma unroll
+        for (int qi = 0; qi < 2; ++qi)
+#pragma unroll
+          for (int ki = 0; ki < 2; ++ki)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s[qi][ki][r] = pd[qi][ki][r] * dp[qi][ki][r];
+      }
+      {
+        const e16x8 pf0 = cvt8_2x4(pd[0][0], pd[1][0]), pf1 = cvt8_2x4(pd[0][1], pd[1][1]);      // key tile 0 / 1: [query tile 0 regs | query tile 1 regs]
+        const e16x8 sf0 = cvt8_2x4(s[0][0], s[1][0]), sf1 = cvt8_2x4(s[0][1], s[1][1]);
+        s16x4 dlo[4], dhi[4], qlo[4], qhi[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+          const unsigned ad = dtr + (tra0 ^ (dt << 5));
+          if (blk == 0) { AFM_TR_RD(dlo[dt], ad, 0); AFM_TR_RD(dhi[dt], ad, 2048); }
+          else { AFM_TR_RD(dlo[dt], ad, 4096); AFM_TR_RD(dhi[dt], ad, 6144); }
+        }
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+          const unsigned aq = qtr + (tra0 ^ (dt << 5));
+          if (blk == 0) { AFM_TR_RD(qlo[dt], aq, 0); AFM_TR_RD(qhi[dt], aq, 2048); }
+          else { AFM_TR_RD(qlo[dt], aq, 4096); AFM_TR_RD(qhi[dt], aq, 6144); }
+        }
+        tr_wait<8>();
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+          const e16x8 af = tr_join(dlo[dt], dhi[dt]);
+          dv[dt][0] = mfma16(af, pf0, dv[dt][0]);
+          dv[dt][1] = mfma16(af, pf1, dv[dt][1]);
+        }
+        tr_wait<0>();
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+          const e16x8 af = tr_join(qlo[dt], qhi[dt]);
+          dk[dt][0] = mfma16(af, sf0, dk[dt][0]);
+          dk[dt][1] = mfma16(af, sf1, dk[dt][1]);
+        }
+      }
+    }
+  }
+  store(false);
+}

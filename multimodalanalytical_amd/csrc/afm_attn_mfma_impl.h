@@ -1019,10 +1019,12 @@ __global__ __launch_bounds__(256) void k_attn_bits_fill(AttnM a) {
   bits_flush();
 }
 
+#include "afm_attn_m16_impl.h"
+#include "afm_attn_pipe16_impl.h"
+#include "afm_attn_fwd16_impl.h"
+
 }  // namespace AFM_E16_NS
 using namespace AFM_E16_NS;
-
-#include "afm_attn_m16_impl.h"
 
 // ------------------------------------------------------------------------------------------ dispatch
 static bool eligible(const afm_attn_shape* s, const void* const* ptrs, int nptr, const int* lds, int nld) {
@@ -1077,6 +1079,17 @@ int AFM_E16_FN(afm_attn_fwd_mfma_try)(const afm_attn_shape* s, const void* Q, co
   const dim3 grid(((s->Tq + 127) / 128) * s->H * s->B);
   const int shm = RS * 2 * KT * DH * 2 + ((s->Tk + KT - 1) / KT) * 12 + 8;      // ring, key-mask words, tile list
   if (shm > 64 * 1024) return AFM_ERR_UNSUPPORTED;
+  if (s->reserved & 1024) {      // the forward on v_mfma_f32_16x16x32 (afm_attn_fwd16_impl.h: an A / B form); & 2048: three workgroups per CU (168 registers)
+#define AFM_F16_LAUNCH(D) do { if (s->reserved & 2048) AFM_LAUNCH((k_attn_fwd_m16<D, 3>), grid, dim3(256), shm, st, a, (const e16*)Q, (const e16*)K, (const e16*)V, (e16*)O, lse); \
+      else AFM_LAUNCH((k_attn_fwd_m16<D, 4>), grid, dim3(256), shm, st, a, (const e16*)Q, (const e16*)K, (const e16*)V, (e16*)O, lse); } while (0)
+    if (a.dd.thresh16 && a.bits && (s->reserved & 32)) AFM_F16_LAUNCH(DROP_READ);
+    else if (a.dd.thresh16 && a.bits) AFM_F16_LAUNCH(DROP_BITS);
+    else if (a.dd.thresh16) AFM_F16_LAUNCH(DROP_HASH);
+    else AFM_F16_LAUNCH(DROP_NONE);
+#undef AFM_F16_LAUNCH
+    afm_set_last_algo("attn_mfma");
+    return AFM_OK;
+  }
   if (a.dd.thresh16 && a.bits && (s->reserved & 32)) AFM_LAUNCH(k_attn_fwd_mfma<DROP_READ>, grid, dim3(256), shm, st, a, (const e16*)Q, (const e16*)K, (const e16*)V, (e16*)O, lse);
   else if (a.dd.thresh16 && a.bits) AFM_LAUNCH(k_attn_fwd_mfma<DROP_BITS>, grid, dim3(256), shm, st, a, (const e16*)Q, (const e16*)K, (const e16*)V, (e16*)O, lse);
   else if (a.dd.thresh16) AFM_LAUNCH(k_attn_fwd_mfma<DROP_HASH>, grid, dim3(256), shm, st, a, (const e16*)Q, (const e16*)K, (const e16*)V, (e16*)O, lse);
@@ -1131,10 +1144,15 @@ int AFM_E16_FN(afm_attn_bwd_mfma_try)(const afm_attn_shape* s, const void* Q, co
     else AFM_LAUNCH(k_attn_bwd_dq_st<DROP_NONE>, gq8, dim3(512), shm_q8, st, a, (const e16*)Q, (const e16*)K, (const e16*)V, (const e16*)O, (const e16*)dO, lse, delta, (e16*)dQ);
   }
   else if (!run_q) {}
-  else if (s->reserved & 1024) {     // the 16x16x32 form of the dQ kernel (afm_attn_m16_impl.h); reserved & 2048: compiled for two workgroups per CU (256 registers)
+  // the 16x16x32 form of the dQ kernel (afm_attn_m16_impl.h); reserved & 2048: compiled for two workgroups per CU (256 registers).  Round 5,
+  // c2 encoder shape, one process: without dropout 0.510 ... 0.516 ms (two workgroups per CU) against 0.571 ... 0.574 for the 32 x 32 x 16 kernel,
+  // with the hash re-evaluated 0.556 ... 0.562 against 0.699 ... 0.701 -- the default in those two cases; with the keep bits READ it loses
+  // (0.564 against 0.535: the lane-mask words do not match its score layout and are repacked per tile), so the training step's dropout
+  // path keeps the 32 x 32 x 16 kernel.  reserved & 32768 keeps that kernel everywhere (A / B runs).
+  else if ((s->reserved & 1024) || (!(a.dd.thresh16 && a.bits) && !(s->reserved & 32768))) {
 #define AFM_M16_LAUNCH(D, OCC) do { static AfmOncePerDevice at_; if (at_.need()) (void)hipFuncSetAttribute((const void*)k_attn_bwd_dq_m16<D, OCC>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); \
       AFM_LAUNCH((k_attn_bwd_dq_m16<D, OCC>), gq, dim3(256), shm_q, st, a, (const e16*)Q, (const e16*)K, (const e16*)V, (const e16*)O, (const e16*)dO, lse, delta, (e16*)dQ); } while (0)
-    const bool occ2 = (s->reserved & 2048) != 0;
+    const bool occ2 = (s->reserved & 2048) != 0 || !(s->reserved & 1024);
     if (a.dd.thresh16 && a.bits) { if (occ2) AFM_M16_LAUNCH(DROP_BITS, 2); else AFM_M16_LAUNCH(DROP_BITS, 3); }
     else if (a.dd.thresh16) { if (occ2) AFM_M16_LAUNCH(DROP_HASH, 2); else AFM_M16_LAUNCH(DROP_HASH, 3); }
     else { if (occ2) AFM_M16_LAUNCH(DROP_NONE, 2); else AFM_M16_LAUNCH(DROP_NONE, 3); }
@@ -1183,7 +1201,29 @@ int AFM_E16_FN(afm_attn_bwd_mfma_try)(const afm_attn_shape* s, const void* Q, co
     }
   }
 #endif
-  if (!run_k) {}
+  // Round 5: the software-pipelined kernel on v_mfma_f32_16x16x32 (afm_attn_pipe16_impl.h) is the default where the pipelined kernel
+  // applies in its four-wave form -- one process, order swapped, c2 encoder shape, fp16: 0.652 ... 0.658 ms against 0.690 ... 0.694 with the
+  // keep bits (-5.5 %), 0.564 ... 0.572 against 0.613 ... 0.622 without dropout (-8 %); results agree with the 32 x 32 x 16 kernels to rounding
+  // (another accumulation order).  reserved & 16384 keeps the 32 x 32 x 16 pipelined kernel (A / B runs, its bit-identity test).
+  if (run_k && !(s->reserved & (16384 | 4096)) && piped && shm_kp <= 80 * 1024 && pnw == 4 && pkb == 1) {
+    static AfmOncePerDevice attr_kp16;
+    if (attr_kp16.need()) {
+      (void)hipFuncSetAttribute((const void*)k_attn_bwd_dkv_pipe16<DROP_BITS>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+      (void)hipFuncSetAttribute((const void*)k_attn_bwd_dkv_pipe16<DROP_NONE>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    }
+    if (a.dd.thresh16) AFM_LAUNCH(k_attn_bwd_dkv_pipe16<DROP_BITS>, gkp, dim3(256), shm_kp, st, a, (const e16*)Q, (const e16*)K, (const e16*)V, (const e16*)dO, lse, delta, (e16*)dK, (e16*)dV);
+    else AFM_LAUNCH(k_attn_bwd_dkv_pipe16<DROP_NONE>, gkp, dim3(256), shm_kp, st, a, (const e16*)Q, (const e16*)K, (const e16*)V, (const e16*)dO, lse, delta, (e16*)dK, (e16*)dV);
+  }
+  else if (run_k && (s->reserved & 4096) && (!a.dd.thresh16 || a.bits)) {      // the 16x16x32 form of the round-3 dK/dV kernel (afm_attn_m16_impl.h: an A/B form)
+    static AfmOncePerDevice attr_k16;
+    if (attr_k16.need()) {
+      (void)hipFuncSetAttribute((const void*)k_attn_bwd_dkv_m16<DROP_BITS>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+      (void)hipFuncSetAttribute((const void*)k_attn_bwd_dkv_m16<DROP_NONE>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    }
+    if (a.dd.thresh16) AFM_LAUNCH(k_attn_bwd_dkv_m16<DROP_BITS>, gk, dim3(256), shm_k, st, a, (const e16*)Q, (const e16*)K, (const e16*)V, (const e16*)dO, lse, delta, (e16*)dK, (e16*)dV);
+    else AFM_LAUNCH(k_attn_bwd_dkv_m16<DROP_NONE>, gk, dim3(256), shm_k, st, a, (const e16*)Q, (const e16*)K, (const e16*)V, (const e16*)dO, lse, delta, (e16*)dK, (e16*)dV);
+  }
+  else if (!run_k) {}
   else if (piped && shm_kp <= 80 * 1024 && a.dd.thresh16 && pnw == 8) AFM_PIPE_LAUNCH((k_attn_bwd_dkv_pipe<DROP_BITS, 8, 1>), 512);
   else if (piped && shm_kp <= 80 * 1024 && a.dd.thresh16 && pkb == 2) AFM_PIPE_LAUNCH((k_attn_bwd_dkv_pipe<DROP_BITS, 4, 2>), 256);
   else if (piped && shm_kp <= 80 * 1024 && a.dd.thresh16) AFM_PIPE_LAUNCH((k_attn_bwd_dkv_pipe<DROP_BITS, 4, 1>), 256);

@@ -412,6 +412,46 @@ def test_attention_keep_bits_filled_ahead(ops, dt, B, H, Tq, Tk, causal, pad):
 
 
 @pytest.mark.parametrize("dt", [H16, torch.bfloat16])
+@pytest.mark.parametrize("B,H,Tq,Tk,causal,pad,pdrop", [(2, 2, 128, 256, False, True, 0.1), (1, 2, 160, 160, True, True, 0.1), (2, 2, 130, 520, False, True, 0.0),
+                                                        (2, 2, 256, 56, False, False, 0.1), (1, 8, 1024, 1024, False, False, 0.1)])
+def test_attention_forward_16x16x32_form(ops, dt, B, H, Tq, Tk, causal, pad, pdrop):
+    """The forward restated on v_mfma_f32_16x16x32 (csrc/afm_attn_fwd16_impl.h; afm_attn_shape.reserved & 1024, & 2048 its three-workgroup
+    build: A / B forms, measured slower with dropout and left off) against the shipped forward: O and lse to rounding (another
+    accumulation order), the keep-bit tensor it writes bit for bit, and reading a tensor filled ahead gives the same bits of O."""
+    dh, D = 64, H * 64
+    q, k, v, key_pad = _attn_case(B, H, Tq, Tk, dh, causal, pad, seed=23)
+    qd, kd, vd = (dev(t.reshape(-1, D), dt) for t in (q, k, v))
+    kp = None if key_pad is None else dev(key_pad.to(torch.uint8))
+    dr = ops.drop(pdrop, 778, 5) if pdrop > 0 else ops.NO_DROP
+    nw = ops.attn_drop_bits_words(B, H, Tq, Tk)
+    res = {}
+    for name, flag in (("ref", 0), ("m16", 1024), ("m16occ3", 1024 | 2048)):
+        o = torch.full((B * Tq, D), float("nan"), dtype=dt, device=DEV); lse = torch.full((B * H * Tq,), float("nan"), device=DEV)
+        bits = torch.zeros(nw, dtype=torch.int64, device=DEV)
+        shp = ops.attn_shape(B, H, Tq, Tk, dh, dt, D, D, D, D, kp, causal, dr, algo=2)
+        if pdrop > 0:
+            ops.attn_set_drop_bits(shp, bits)
+        shp.reserved |= flag
+        ops.attn_fwd(shp, qd, kd, vd, o, lse)
+        assert ops.last_algo() == "attn_mfma"
+        res[name] = (o, lse, bits.clone())
+        if pdrop > 0 and flag:
+            o2 = torch.full_like(o, float("nan")); lse2 = torch.full_like(lse, float("nan"))
+            assert ops.attn_fill_drop_bits(shp) and shp.reserved & 32
+            ops.attn_fwd(shp, qd, kd, vd, o2, lse2)
+            assert torch.equal(o, o2) and torch.equal(lse, lse2), name
+    o0, l0, b0 = res["ref"]
+    tol = 4e-3 if dt == H16 else 3e-2
+    for name in ("m16", "m16occ3"):
+        o1, l1, b1 = res[name]
+        assert bool(torch.isfinite(o1.float()).all())
+        assert float((o0.float() - o1.float()).abs().max()) <= tol * float(o0.float().abs().max()), name
+        inf = torch.isinf(l0)
+        assert torch.equal(inf, torch.isinf(l1)) and float((l0[~inf] - l1[~inf]).abs().max()) < 2e-5, name
+        assert torch.equal(b0, b1), name
+
+
+@pytest.mark.parametrize("dt", [H16, torch.bfloat16])
 @pytest.mark.parametrize("causal", [False, True])
 def test_attention_backward_skips_padded_query_rows_exactly(ops, dt, causal):
     """afm_attn_shape.reserved bit 6: self-attention over a padded batch whose padded rows carry zero dO (a training step's
@@ -449,8 +489,10 @@ def test_attention_backward_skips_padded_query_rows_exactly(ops, dt, causal):
 def test_attention_dkv_pipelined_kernel_is_bit_identical(ops, dt, B, H, Tq, Tk, pad, pdrop):
     """csrc/afm_attn_pipe_impl.h (software-pipelined dK/dV kernel: no causal mask, Tq % 64 == 0, keep-bit dropout or none) gives every
     accumulator its products in the round-3 kernel's order: dK and dV equal that kernel's (afm_attn_shape.reserved & 128) bit for bit,
-    in the default form (four waves x 32 keys), with 64 keys per wave (reserved & 512) and with eight waves (reserved & 256), with and
-    without the padded-query skip."""
+    in the four-wave form (reserved & 16384 since round 5: the default is now its 16 x 16 x 32 restatement, which has another
+    accumulation order), with 64 keys per wave (reserved & 512) and with eight waves (reserved & 256), with and without the padded-query
+    skip.  The 16 x 16 x 32 forms -- the pipelined default (csrc/afm_attn_pipe16_impl.h) and the round-3 kernel's restatement (reserved &
+    4096, csrc/afm_attn_m16_impl.h) -- agree with it to rounding."""
     dh = 64
     D = H * dh
     q, k, v, _ = _attn_case(B, H, Tq, Tk, dh, False, False, seed=41)
@@ -472,7 +514,7 @@ def test_attention_dkv_pipelined_kernel_is_bit_identical(ops, dt, B, H, Tq, Tk, 
         ops.attn_set_drop_bits(shp, torch.zeros(ops.attn_drop_bits_words(B, H, Tq, Tk), dtype=torch.int64, device=DEV))
     ops.attn_fwd(shp, qd, kd, vd, o, lse)
     res = {}
-    for name, flag in (("round3", 128), ("pipe32", 0), ("pipe64", 512), ("pipe8w", 256)):
+    for name, flag in (("round3", 128), ("pipe32", 16384), ("pipe64", 512 | 16384), ("pipe8w", 256 | 16384), ("pipe16", 0), ("m16", 4096)):
         shp.reserved = flag | (64 if qskip else 0)
         dq = torch.empty(B * Tq, D, dtype=dt, device=DEV)
         dk, dv = (torch.full((B * Tk, D), float("nan"), dtype=dt, device=DEV) for _ in range(2))
@@ -482,6 +524,12 @@ def test_attention_dkv_pipelined_kernel_is_bit_identical(ops, dt, B, H, Tq, Tk, 
     assert bool(torch.isfinite(res["pipe64"][0].float()).all()) and bool(torch.isfinite(res["pipe64"][1].float()).all())
     for name in ("pipe64", "pipe32", "pipe8w"):
         assert torch.equal(res["round3"][0], res[name][0]) and torch.equal(res["round3"][1], res[name][1]), name
+    tol = 4e-3 if dt == H16 else 3e-2
+    for name in ("pipe16", "m16"):
+        for i in range(2):
+            a_, b_ = res["round3"][i].float(), res[name][i].float()
+            assert bool(torch.isfinite(b_).all()), name
+            assert float((a_ - b_).abs().max()) <= tol * float(a_.abs().max()), (name, i)
 
 
 @pytest.mark.parametrize("dt", [H16, torch.bfloat16])

@@ -33,18 +33,53 @@ def case(B, H, Tq, Tk, p, causal, pad, dt=torch.float16, seed=0, bits=False):
     kb = torch.zeros(ops.attn_drop_bits_words(B, H, Tq, Tk), dtype=torch.int64, device=dev) if (bits and p > 0) else None
     mk = lambda res: ops.attn_set_drop_bits(_shape(B, H, Tq, Tk, dh, dt, q, k, v, o, kp, causal, dr, res), kb)
     ops.attn_fwd(mk(0), q, k, v, o, lse)
+    # the forward on 16x16x32 (reserved 1024; | 2048: three workgroups per CU) against the 32x32x16 forward: O, lse, and the keep-bit tensor
+    # it writes, bit for bit
+    fw_ok, fw_note = True, ""
+    for nm, res in (("fwd16", 1024), ("fwd16 occ3", 1024 | 2048)):
+        o2, lse2 = torch.full_like(o, float("nan")), torch.full_like(lse, float("nan"))
+        kb2 = torch.zeros_like(kb) if kb is not None else None
+        ops.attn_fwd(ops.attn_set_drop_bits(_shape(B, H, Tq, Tk, dh, dt, q, k, v, o2, kp, causal, dr, res), kb2), q, k, v, o2, lse2)
+        eo = float((o.float() - o2.float()).abs().max() / o.float().abs().max())
+        inf = torch.isinf(lse)
+        el = float((lse[~inf] - lse2[~inf]).abs().max()) if bool((~inf).any()) else 0.0
+        good = bool(torch.isfinite(o2.float()).all()) and eo < 4e-3 and el < 2e-5 and bool(torch.equal(inf, torch.isinf(lse2)))
+        if kb is not None:
+            good &= bool(torch.equal(kb, kb2))
+        if kb is not None and good:      # the same kernel READING the tensor (reserved | 32: filled ahead) gives the same bits of O
+            o3, lse3 = torch.full_like(o, float("nan")), torch.full_like(lse, float("nan"))
+            ops.attn_fwd(ops.attn_set_drop_bits(_shape(B, H, Tq, Tk, dh, dt, q, k, v, o3, kp, causal, dr, res | 32), kb), q, k, v, o3, lse3)
+            good &= bool(torch.equal(o2, o3))
+        fw_ok &= good
+        fw_note += f"; {nm} O {eo:.1e} lse {el:.1e}{' bits equal' if kb is not None and torch.equal(kb, kb2) else ''} {'ok' if good else 'FAIL'}"
     outs = []
-    for res in (1, 1 | 1024):
+    for res in (1 | 32768, 1 | 1024):
         dq, dk, dv = torch.full_like(q, float("nan")), torch.empty_like(k), torch.empty_like(v)
         delta.fill_(float("nan"))
         ops.attn_bwd(mk(res), q, k, v, o, do, lse, delta, dq, dk, dv, ops._ld(dq), ops._ld(dk), ops._ld(dv))
         outs.append((dq.float().clone(), delta.clone()))
+    # dK / dV: the 16x16x32 form of the round-3 kernel (reserved 4096) against the shipped kernel, where it applies (no dropout / keep bits)
+    kv_note = ""
+    if p == 0.0 or bits:
+        kv = []
+        for res in (2 | 16384, 2 | 4096, 2):      # the 32x32x16 kernel; round-3 kernel on 16x16x32; the default (the pipelined kernel on 16x16x32 where its conditions hold)
+            dq2, dk, dv = torch.empty_like(q), torch.full_like(k, float("nan")), torch.full_like(v, float("nan"))
+            ops.attn_bwd(mk(res), q, k, v, o, do, lse, delta, dq2, dk, dv, ops._ld(dq2), ops._ld(dk), ops._ld(dv))
+            kv.append((dk.float().clone(), dv.float().clone()))
+        kv_ok, kv_note = True, ""
+        for nm, (k1, v1) in (("m16", kv[1]), ("pipe16", kv[2])):
+            ek = float((kv[0][0] - k1).abs().max() / kv[0][0].abs().max()); ev = float((kv[0][1] - v1).abs().max() / kv[0][1].abs().max())
+            good = bool(torch.isfinite(k1).all() and torch.isfinite(v1).all()) and ek < 4e-3 and ev < 4e-3
+            kv_ok &= good
+            kv_note += f"; {nm} dK {ek:.2e} dV {ev:.2e} {'ok' if good else 'FAIL'}"
+    else:
+        kv_ok = True
     (a, da), (b, db) = outs
     err = float((a - b).abs().max() / a.abs().max())
     derr = float((da - db).abs().max() / da.abs().max())
     ok = bool(torch.isfinite(b).all()) and err < 4e-3 and derr < 1e-5
-    print(f"B{B} H{H} Tq{Tq} Tk{Tk} p={p} causal={causal} pad={pad} bits={bits} {dt}: dQ 16x16x32 vs 32x32x16 rel {err:.2e}, delta {derr:.1e}  {'ok' if ok else 'FAIL'}", flush=True)
-    return ok
+    print(f"B{B} H{H} Tq{Tq} Tk{Tk} p={p} causal={causal} pad={pad} bits={bits} {dt}: dQ 16x16x32 vs 32x32x16 rel {err:.2e}, delta {derr:.1e}  {'ok' if ok else 'FAIL'}{kv_note}{fw_note}", flush=True)
+    return ok and kv_ok and fw_ok
 
 
 def _shape(B, H, Tq, Tk, dh, dt, q, k, v, o, kp, causal, dr, res):
@@ -83,8 +118,23 @@ def times():
         kb = torch.zeros(ops.attn_drop_bits_words(B, H, S, S), dtype=torch.int64, device=dev) if bits else None
         mk = lambda res: ops.attn_set_drop_bits(_shape(B, H, S, S, dh, dt, q, k, v, o, None, False, dr, res), kb)
         ops.attn_fwd(mk(0), q, k, v, o, lse)
-        shapes = {"32x32x16": mk(1), "16x16x32": mk(1 | 1024), "16x16x32 occ2": mk(1 | 1024 | 2048)}
+        shapes = {"32x32x16": mk(1 | 32768), "16x16x32": mk(1 | 1024), "16x16x32 occ2": mk(1 | 1024 | 2048), "default": mk(1)}
         fns = {n: (lambda sh=sh: ops.attn_bwd(sh, q, k, v, o, do, lse, delta, dq, dk, dv, ops._ld(dq), ops._ld(dk), ops._ld(dv))) for n, sh in shapes.items()}
+        if p == 0.0 or bits:      # dK / dV: pipelined (shipped), round-3 kernel, its 16x16x32 form
+            kshapes = {"dkv pipelined": mk(2 | 16384), "dkv round-3 32x32x16": mk(2 | 128), "dkv 16x16x32": mk(2 | 4096), "dkv pipelined 16x16x32 (default)": mk(2)}
+            kfns = {n: (lambda sh=sh: ops.attn_bwd(sh, q, k, v, o, do, lse, delta, dq, dk, dv, ops._ld(dq), ops._ld(dk), ops._ld(dv))) for n, sh in kshapes.items()}
+            for rnd in range(3):
+                order = list(kfns) if rnd % 2 == 0 else list(kfns)[::-1]
+                ms = {n: t(kfns[n]) for n in order}
+                print(f"c2 encoder shape, dropout {p} ({'keep bits' if bits else 'none'}), round {rnd}: " +
+                      "   ".join(f"{n} {ms[n]:.4f} ms ({4 * prod / ms[n] / 1e9:.0f} TF/s)" for n in kfns), flush=True)
+        fshapes = {"fwd 32x32x16": mk(0), "fwd 16x16x32": mk(1024), "fwd 16x16x32 occ3": mk(1024 | 2048)}
+        ffns = {n: (lambda sh=sh: ops.attn_fwd(sh, q, k, v, o, lse)) for n, sh in fshapes.items()}
+        for rnd in range(3):
+            order = list(ffns) if rnd % 2 == 0 else list(ffns)[::-1]
+            ms = {n: t(ffns[n]) for n in order}
+            print(f"c2 encoder shape, dropout {p} ({'writes keep bits' if bits else 'hash' if p else 'none'}), round {rnd}: " +
+                  "   ".join(f"{n} {ms[n]:.4f} ms ({2 * prod / ms[n] / 1e9:.0f} TF/s)" for n in ffns), flush=True)
         for rnd in range(3):
             order = list(fns) if rnd % 2 == 0 else list(fns)[::-1]
             ms = {n: t(fns[n]) for n in order}

@@ -18,6 +18,6 @@ for g in "$G1" "$G2" "$G3"; do
   cp $(find $O/spmc_$i -name "*.db" | head -1) $O/${tag}_step_pass$i.db 2>/dev/null
   rm -rf $O/spmc_$i
 done
-python3 $R/tools/prof_step_reduce.py $O $tag 3 > $O/${tag}_${wl}_${dt}_step_pmc.json
+python3 $R/tools/prof_step_reduce.py $O $tag 3 $wl > $O/${tag}_${wl}_${dt}_step_pmc.json
 rm -f $O/${tag}_step_pass*.db
 head -60 $O/${tag}_${wl}_${dt}_step_pmc.json

@@ -49,7 +49,8 @@ def main():
             for c, v in ev.get(did, {}).items():
                 tot[c] = tot.get(c, 0.0) + v
                 b[c] = b.get(c, 0.0) + v
-    out = {"command": "python3 bench.py --steps 2 --warmup 1 --other-modes '' --extra-workloads '' --no-roofline --no-cpu-baseline --no-input-compare",
+    wl = sys.argv[4] if len(sys.argv) > 4 else "c2"
+    out = {"command": f"python3 bench.py --workload {wl} --dtype fp16 --steps 2 --warmup 1 --other-modes '' --extra-workloads '' --no-roofline --no-cpu-baseline --no-input-compare --no-eval",
            "optimiser_steps_in_trace": steps, "kernel_ms_per_step": round(t_pass.get(1, 0) / steps / 1e6, 3)}
     if "GRBM_GUI_ACTIVE" in tot:
         cyc = tot["GRBM_GUI_ACTIVE"] / 8.0
