@@ -1022,6 +1022,7 @@ __global__ __launch_bounds__(256) void k_attn_bits_fill(AttnM a) {
 #include "afm_attn_m16_impl.h"
 #include "afm_attn_pipe16_impl.h"
 #include "afm_attn_fwd16_impl.h"
+#include "afm_attn_sq_impl.h"
 
 }  // namespace AFM_E16_NS
 using namespace AFM_E16_NS;
@@ -1201,6 +1202,23 @@ int AFM_E16_FN(afm_attn_bwd_mfma_try)(const afm_attn_shape* s, const void* Q, co
     }
   }
 #endif
+  // Round 5: short query sequences (the decoder's cross-attention) -- all query tiles resident, the workgroup walks the head's key blocks
+  // (afm_attn_sq_impl.h)
+  const int ntq = (s->Tq + KT - 1) / KT;
+  if (run_k && (s->reserved & 65536) && !s->causal && ntq <= 3 && s->Tk >= 256 && (!a.dd.thresh16 || a.bits)) {
+    const int nkb = (s->Tk + 127) / 128, nbh = s->B * s->H;
+    int nch = std::min(nkb, std::max(1, (1024 + nbh - 1) / nbh));
+    const int nb = (nkb + nch - 1) / nch;
+    nch = (nkb + nb - 1) / nb;
+    const int shm_sq = ntq * (2 * KT * DH * 2 * 2 + 2 * KT * 4);
+    const dim3 gsq(nch * s->H * s->B);
+#define AFM_SQ_LAUNCH(D, N) AFM_LAUNCH((k_attn_bwd_dkv_sq<D, N>), gsq, dim3(256), shm_sq, st, a, (const e16*)Q, (const e16*)K, (const e16*)V, (const e16*)dO, lse, delta, (e16*)dK, (e16*)dV, nb, nch)
+    if (a.dd.thresh16) { if (ntq == 1) AFM_SQ_LAUNCH(DROP_BITS, 1); else if (ntq == 2) AFM_SQ_LAUNCH(DROP_BITS, 2); else AFM_SQ_LAUNCH(DROP_BITS, 3); }
+    else { if (ntq == 1) AFM_SQ_LAUNCH(DROP_NONE, 1); else if (ntq == 2) AFM_SQ_LAUNCH(DROP_NONE, 2); else AFM_SQ_LAUNCH(DROP_NONE, 3); }
+#undef AFM_SQ_LAUNCH
+    afm_set_last_algo("attn_mfma");
+    return AFM_OK;
+  }
   // Round 5: the software-pipelined kernel on v_mfma_f32_16x16x32 (afm_attn_pipe16_impl.h) is the default where the pipelined kernel
   // applies in its four-wave form -- one process, order swapped, c2 encoder shape, fp16: 0.652 ... 0.658 ms against 0.690 ... 0.694 with the
   // keep bits (-5.5 %), 0.564 ... 0.572 against 0.613 ... 0.622 without dropout (-8 %); results agree with the 32 x 32 x 16 kernels to rounding

@@ -120,6 +120,9 @@ class Seq2SeqEngine:
         # AFM_BITS_AHEAD=1: keep-bit tensors filled ahead of the attention forward on a side stream (_bits_ahead).  Built, verified
         # bit-identical and measured in round 3: the forward drops from 0.52 to 0.44 ms but the fill takes 0.195 ms and does not
         # hide under the LayerNorm (whose grid already holds every wave slot): step -1.1 %.  Off by default.
+        # kernel-selection bits OR-ed into afm_attn_shape.reserved of every attention backward call (include/afm_hip.h: A / B runs; the
+        # keep-bit / re-hash equivalence test pins both paths to the same MFMA shape with it)
+        self.attn_bwd_flags = int(os.environ.get("AFM_ATTN_BWD_FLAGS", "0"), 0)
         self.bits_stream = (torch.cuda.Stream(device=self.dev)
                             if self.dev.type == "cuda" and os.environ.get("AFM_BITS_AHEAD", "0") == "1" else None)
         self._wg_pending = []
@@ -586,6 +589,7 @@ class Seq2SeqEngine:
         # (Not the decoder's: whether its padded rows carry a gradient depends on the labels the caller passes.)
         if self.row_skip and not shp.causal:
             shp.reserved |= 64
+        shp.reserved |= self.attn_bwd_flags
         ops.attn_bwd(shp, qkv_b[:, :d], qkv_b[:, d:2 * d], qkv_b[:, 2 * d:], self._hb(a), da, lse, delta,
                      dqkv[:, :d], dqkv[:, d:2 * d], dqkv[:, 2 * d:], ldg, ldg, ldg)
         self._wgrad(dqkv, h, p + "self_attn.in_proj_weight", 3 * d, d, bias_name=p + "self_attn.in_proj_bias")
@@ -710,7 +714,9 @@ class Seq2SeqEngine:
         ldkv = ops._ld(dkv)
         delta = torch.empty_like(lse)
         kv_b = self._hb(kv)
-        ops.attn_bwd(self._shape_b(shp), self._hb(q), kv_b[:, :d], kv_b[:, d:], self._hb(a), da, lse, delta, dq, dkv[:, :d], dkv[:, d:],
+        shp = self._shape_b(shp)
+        shp.reserved |= self.attn_bwd_flags
+        ops.attn_bwd(shp, self._hb(q), kv_b[:, :d], kv_b[:, d:], self._hb(a), da, lse, delta, dq, dkv[:, :d], dkv[:, d:],
                      ops._ld(dq), ldkv, ldkv)
         w, bname = p + "multihead_attn.in_proj_weight", p + "multihead_attn.in_proj_bias"
         self._wgrad(dq, h, w, 3 * d, d, 0, d, bias_name=bname)

@@ -31,7 +31,8 @@ GEMM_WHAT = {
 def main():
     M2.SRC = SRC
     M2.pretty = M3.pretty
-    M2.NAMES.update({"k_attn_bwd_dkv_pipe": "attention backward, dK/dV kernel", "k_attn_bwd_dq_m16": "attention backward, dQ kernel on v_mfma_f32_16x16x32 (A/B form)"})
+    M2.NAMES.update({"k_attn_bwd_dkv_pipe": "attention backward, dK/dV kernel", "k_attn_bwd_dq_m16": "attention backward, dQ kernel on v_mfma_f32_16x16x32 (A/B form)",
+                     "k_attn_bwd_dkv_pipe16": "attention backward, dK/dV kernel"})
     for wl in ("c2", "c4"):
         src = os.path.join(SRC, f"step_{wl}_fp16_kernel_stats.csv")
         if os.path.exists(src):
@@ -76,9 +77,11 @@ def main():
                 m["valu_per_mfma"] = round(m.get("SQ_INSTS_VALU", 0) / m["SQ_INSTS_MFMA"], 2)
                 m["salu_per_mfma"] = round(m.get("SQ_INSTS_SALU", 0) / m["SQ_INSTS_MFMA"], 2)
             print(k[:70], {c: m.get(c) for c in ("avg_ns_by_pass", "kcycles", "clock_ghz", "mfma_busy_frac", "valu_per_mfma", "salu_per_mfma")})
-        out["_note"] = ("tools/experiments/attn_m16.py --time-only under two rocprofv3 counter passes: means over ALL launches of a kernel name (three dropout "
-                        "paths x three rounds; the 16x16x32 name covers its two occupancy builds): cycles = GRBM_GUI_ACTIVE / 8, clock = cycles / time")
-        json.dump(out, open(os.path.join(DST, "r05_attn_dq_shape_pmc.json"), "w"), indent=1)
+        out["_note"] = ("tools/experiments/attn_m16.py --time-only under two rocprofv3 counter passes: means over all launches of a kernel name; the template "
+                        "arguments are the dropout path (0 none, 1 hash, 2 keep-bit tensor) and the build; k_attn_fwd_mfma / k_attn_bwd_dq_mfma / k_attn_bwd_dkv_pipe / "
+                        "k_attn_bwd_dkv_mfma run v_mfma_f32_32x32x16, k_attn_fwd_m16 / k_attn_bwd_dq_m16 / k_attn_bwd_dkv_pipe16 / k_attn_bwd_dkv_m16 run "
+                        "v_mfma_f32_16x16x32 at the same tile per wave; cycles = GRBM_GUI_ACTIVE / 8, clock = cycles / time")
+        json.dump(out, open(os.path.join(DST, "r05_attn_shape_pmc.json"), "w"), indent=1)
     for wl, fn in (("c2", "r05_gemm_fp16_pmc.json"), ("c4", "r05_c4_gemm_fp16_pmc.json")):
         gp = os.path.join(SRC, fn)
         if not os.path.exists(gp):

@@ -43,12 +43,12 @@ if [[ " $what " == *" attn "* ]]; then
   timeout 300 rocprofv3 --kernel-trace --stats -d $O/attn_stats -o st -- python3 $R/tools/bench_attn_x3.py --mode fp16 > $O/attn_fp16_stats.log 2>&1
   python3 $R/tools/rocpd_stats.py $(find $O/attn_stats -name "*.db" | head -1) $O/attn_fp16_kernel_stats.csv 2> $O/attn_fp16_total.txt
   rm -rf $O/attn_stats
-  # the dQ kernel in both MFMA shapes: cycles, clock, MFMA busy of k_attn_bwd_dq_mfma (32x32x16) and k_attn_bwd_dq_m16 (16x16x32)
+  # the three attention kernels in both MFMA shapes: cycles, clock, MFMA busy per kernel name (template arguments = dropout path, build)
   i=0
   for g in "$G1" "$G2"; do
     i=$((i+1))
     timeout 300 rocprofv3 --kernel-trace --pmc $g -d $O/dqshape_$i -o pmc -- python3 $R/tools/experiments/attn_m16.py --time-only > $O/dqshape_$i.log 2>&1
-    python3 $R/tools/rocpd_pmc.py $(find $O/dqshape_$i -name "*.db" | head -1) k_attn_bwd_dq > $O/dqshape_pmc_$i.json
+    python3 $R/tools/rocpd_pmc.py $(find $O/dqshape_$i -name "*.db" | head -1) k_attn > $O/dqshape_pmc_$i.json
     rm -rf $O/dqshape_$i
   done
 fi
