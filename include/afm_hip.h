@@ -239,7 +239,9 @@ typedef struct {
                              wave.  Round 5: the four-wave pipelined kernel runs on v_mfma_f32_16x16x32 by default (csrc/afm_attn_pipe16_impl.h;
                              equal to the others to rounding, not bit for bit); bit 14 (16384) keeps its 32 x 32 x 16 form, bit 12 (4096) selects the
                              round-3 kernel restated on 16 x 16 x 32, bits 10-11 (1024, 2048) the 16 x 16 x 32 dQ kernels (the default without dropout and where the
-                             hash is re-evaluated; bit 15 (32768) keeps the 32 x 32 x 16 dQ kernel there).  Bits 12-19 are timing ablations instead in AFM_ATTN_ABLATIONS builds (never in the product library). */
+                             hash is re-evaluated; bit 15 (32768) keeps the 32 x 32 x 16 dQ kernel there); bit 16 (65536) the short-query dK/dV kernel
+                             (csrc/afm_attn_sq_impl.h: Tq <= 192 < 256 <= Tk, no causal mask; an A / B form).  afm_attn_fwd: bits 10-11 select
+                             the forward restated on 16 x 16 x 32 (csrc/afm_attn_fwd16_impl.h; bit 11: its three-workgroup build; A / B forms).  Bits 12-19 are timing ablations instead in AFM_ATTN_ABLATIONS builds (never in the product library). */
   const uint8_t* key_pad;
   afm_dropout drop;
   /* batch strides in ELEMENTS of Q, K, V, O (0 = dense: Tq*ldq, Tk*ldk, Tk*ldv, Tq*ldo).  Non-dense

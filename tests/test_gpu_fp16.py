@@ -452,6 +452,46 @@ def test_attention_forward_16x16x32_form(ops, dt, B, H, Tq, Tk, causal, pad, pdr
 
 
 @pytest.mark.parametrize("dt", [H16, torch.bfloat16])
+@pytest.mark.parametrize("B,H,Tq,Tk,pad,pdrop", [(2, 4, 128, 1024, False, 0.1), (3, 2, 128, 1000, True, 0.1), (2, 2, 100, 520, True, 0.1),
+                                                 (2, 4, 64, 256, False, 0.0), (2, 2, 192, 768, True, 0.1), (5, 8, 40, 2048, True, 0.1)])
+def test_attention_dkv_short_query_form(ops, dt, B, H, Tq, Tk, pad, pdrop):
+    """The short-query dK / dV kernel (csrc/afm_attn_sq_impl.h, afm_attn_shape.reserved & 65536: every query tile of a head resident in
+    LDS, the workgroup walks the key blocks; an A / B form for the decoder's cross-attention shapes) against the general kernels:
+    dK / dV to rounding, zero rows at padded keys."""
+    dh, D = 64, H * 64
+    q, k, v, _ = _attn_case(B, H, Tq, Tk, dh, False, False, seed=41)
+    key_pad = torch.zeros(B, Tk, dtype=torch.bool)
+    if pad:
+        key_pad[0, Tk // 3:] = True
+        key_pad[B - 1, Tk - 70:] = True
+    qd, kd, vd = (dev(t.reshape(-1, D), dt) for t in (q, k, v))
+    kp = dev(key_pad.to(torch.uint8)) if pad else None
+    dr = ops.drop(pdrop, 6, 2) if pdrop > 0 else ops.NO_DROP
+    dod = dev(rnd(B * Tq, D, seed=12), dt)
+    o = torch.empty(B * Tq, D, dtype=dt, device=DEV); lse = torch.empty(B * H * Tq, device=DEV)
+    shp = ops.attn_shape(B, H, Tq, Tk, dh, dt, D, D, D, D, kp, False, dr, algo=2)
+    if pdrop > 0:
+        ops.attn_set_drop_bits(shp, torch.zeros(ops.attn_drop_bits_words(B, H, Tq, Tk), dtype=torch.int64, device=DEV))
+    ops.attn_fwd(shp, qd, kd, vd, o, lse)
+    res = []
+    for flag in (0, 65536):
+        shp.reserved = flag
+        dq = torch.empty(B * Tq, D, dtype=dt, device=DEV)
+        dk, dv = (torch.full((B * Tk, D), float("nan"), dtype=dt, device=DEV) for _ in range(2))
+        ops.attn_bwd(shp, qd, kd, vd, o, dod, lse, torch.empty_like(lse), dq, dk, dv, D, D, D)
+        assert ops.last_algo() == "attn_mfma"
+        res.append((dk.float(), dv.float()))
+    tol = 4e-3 if dt == H16 else 3e-2
+    for i in range(2):
+        a_, b_ = res[0][i], res[1][i]
+        assert bool(torch.isfinite(b_).all())
+        assert float((a_ - b_).abs().max()) <= tol * float(a_.abs().max()), i
+    if pad:
+        dead = dev(key_pad.reshape(-1))
+        assert float(res[1][0][dead].abs().max()) == 0.0 and float(res[1][1][dead].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("dt", [H16, torch.bfloat16])
 @pytest.mark.parametrize("causal", [False, True])
 def test_attention_backward_skips_padded_query_rows_exactly(ops, dt, causal):
     """afm_attn_shape.reserved bit 6: self-attention over a padded batch whose padded rows carry zero dO (a training step's

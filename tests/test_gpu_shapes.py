@@ -160,7 +160,7 @@ def test_dropout_keep_bits_equal_rehash(mode):
         eng = Seq2SeqEngine(cfg, wl["data"], "Smiles", wl["data"]["Smiles"]["vocab_size"], device=DEV,
                             compute_dtype=_dtype(mode), seed=5, backward_dtype=_bdtype(mode))
         eng.keep_bits = keep_bits
-        eng.attn_bwd_flags = 16384 | 32768 | 131072   # both paths on the 32 x 32 x 16 backward kernels (round 5: the defaults differ by dropout path)
+        eng.attn_bwd_flags = 16384 | 32768   # both paths on the 32 x 32 x 16 backward kernels (round 5: the defaults differ by dropout path)
         eng.load_state_dict(sd)
         eng.train()
         out = eng.forward(_to(enc), am.to(DEV), dec.to(DEV), dm.to(DEV), labels.to(DEV), backward=True)
