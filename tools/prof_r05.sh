@@ -14,7 +14,7 @@ what="${*:-stats steppmc gemm attn}"
 if [[ " $what " == *" stats "* ]]; then
   for wl in c2 c4; do
     timeout 600 rocprofv3 --kernel-trace --stats -d $O/step_$wl -o step -- python3 $R/bench.py --workload $wl --dtype fp16 --steps 2 --warmup 1 --other-modes "" --extra-workloads "" --no-roofline --no-cpu-baseline --no-input-compare --no-eval > $O/step_${wl}_fp16.log 2>&1
-    python3 $R/tools/rocpd_stats.py $(find $O/step_$wl -name "*.db" | head -1) $O/step_${wl}_fp16_kernel_stats.csv 2> $O/step_${wl}_fp16_total.txt
+    python3 $R/tools/rocpd_stats.py $(find $O/step_$wl -name "*.db" | head -1) $O/step_${wl}_fp16_kernel_stats.csv --from k_patch_ k_gather_rows 2> $O/step_${wl}_fp16_total.txt
     rm -rf $O/step_$wl
   done
 fi

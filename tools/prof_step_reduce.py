@@ -1,5 +1,6 @@
 """Reduce the passes of tools/prof_step_pmc.sh: counters summed over EVERY kernel dispatch of the traced command and divided by the
-number of optimiser steps it ran (model construction adds a few cast / fill kernels: < 0.5 % of the kernel time).
+number of optimiser steps it ran; set-up (parameter initialisation, the synthetic set's generation) is cut off at the first dispatch of
+the device input path.
   mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs / (GRBM_GUI_ACTIVE / 8 XCDs)   (share of the kernels' cycles the matrix pipes are busy)
   hbm bytes      = FETCH_SIZE KB x 1024 x 2 (gfx950 tallies 128-byte read requests at 64 bytes) + WRITE_SIZE KB x 1024
   hbm_gbs        = bytes / kernel time of the same pass."""
@@ -10,9 +11,12 @@ def load(path):
     db = sqlite3.connect(path)
     rows = db.execute("select d.id, s.kernel_name, d.end - d.start, d.start from rocpd_kernel_dispatch d "
                       "join rocpd_info_kernel_symbol s on d.kernel_id = s.id").fetchall()
-    # the optimiser steps begin with the first collated micro-batch: everything before the first k_patch_preprocess dispatch is set-up
-    # (parameter initialisation, the synthetic set's generation: ~200 elementwise launches) and is left out of the step's counters
-    first = min((st for _, name, _, st in rows if "k_patch_preprocess" in name), default=0)
+    # the optimiser steps begin with the first collated micro-batch: everything before the first dispatch of the device input path
+    # (afm_patch_preprocess: k_patch_values / k_patch_mask; k_gather_rows where a workload has no patched modality) is set-up -- parameter
+    # initialisation, the synthetic set's generation: ~200 elementwise launches -- and is left out of the step's counters
+    first = min((st for _, name, _, st in rows if "k_patch_" in name), default=None)
+    if first is None:
+        first = min((st for _, name, _, st in rows if "k_gather_rows" in name), default=0)
     k = {did: (name, dur) for did, name, dur, st in rows if st >= first}
     ev = {}
     for did, cname, val in db.execute(
