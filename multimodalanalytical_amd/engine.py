@@ -278,6 +278,17 @@ class Seq2SeqEngine:
             return torch.empty(rows, like.ld, dtype=dt, device=self.dev)[:, :cols]
         return ops.empty(rows, cols, dt, self.dev)
 
+    def _empty_dkv_all(self, rows, cols):
+        """The all-layers [dK | dV] buffer of the decoder's cross-attention backward (one data-gradient GEMM over K = layers * 2d at the
+        end).  Its rows are 12 KB (c2) ... 36 KB (c4) of 16-bit values, and each layer's dK/dV kernel writes 128-byte pieces of them:
+        pieces of consecutive keys a multiple of 4 KB apart run into a channel pattern of the memory system -- 227 us per launch against
+        189 us with the rows 128 bytes longer (tools/experiments/attn_cross_layout.py; forward and dQ, which only READ such rows, do
+        not care; GEMM operands and the packed Q | K | V of the self-attention do not either, tools/experiments/ld_pad.py).  So the row
+        stride is padded by 64 elements where the buffer is a plain 16-bit matrix."""
+        if self.bd in (torch.float16, torch.bfloat16) and os.environ.get("AFM_DKV_PAD", "1") != "0":
+            return torch.empty(rows, cols + 64, dtype=self.bd, device=self.dev)[:, :cols]
+        return self._empty_b(rows, cols)
+
     def _hb(self, t):
         """Operand of a backward kernel: in mixed mode the hi plane of a pair tensor."""
         return t.hi if (self.mixed and isinstance(t, X2)) else t
@@ -1085,7 +1096,7 @@ class Seq2SeqEngine:
         had_init = dmem is not None
         if dmem is None and not self.lowp:
             dmem = torch.zeros(B * S, d, dtype=torch.float32, device=self.dev)
-        dkv_all = self._empty_b(B * S, Ld * 2 * d) if self.lowp and Ld > 0 else None
+        dkv_all = self._empty_dkv_all(B * S, Ld * 2 * d) if self.lowp and Ld > 0 else None
         for i in range(Ld - 1, -1, -1):
             p, sv = f"decoder.layers.{i}.", saved["dec_layers"][i]
             dx = self._post_sub_bwd(dx, p + "norm3.", sv, "lnf", f"d{i}res2",
@@ -1179,7 +1190,7 @@ class Seq2SeqEngine:
             dmem = torch.zeros(B * S, d, dtype=torch.float32, device=self.dev)
         dkv_all = None
         if self.lowp and Ld > 0:
-            dkv_all = self._empty_b(B * S, Ld * 2 * d)
+            dkv_all = self._empty_dkv_all(B * S, Ld * 2 * d)
         for i in range(Ld - 1, -1, -1):
             p, sv = f"decoder.layers.{i}.", saved["dec_layers"][i]
             dx, dy = self._ffn_bwd(dx, dy, p, self.cfg["decoder_ffn_dim"], "norm3.", sv, f"d{i}xres")

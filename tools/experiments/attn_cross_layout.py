@@ -19,8 +19,10 @@ def main():
     dr = ops.drop(0.1, 1, 3)
     kb = torch.zeros(ops.attn_drop_bits_words(B, H, Tq, Tk), dtype=torch.int64, device=dev)
     prod = 2.0 * B * H * Tq * Tk * dh
-    for name, width, koff, voff in (("separate K, V (1 KB rows)", d, 0, None), ("[K | V] of one layer (2 KB rows)", 2 * d, 0, d),
-                                    ("all six layers (12 KB rows), layer 2", 12 * d, 4 * d, 5 * d)):
+    cases = [("separate K, V (1 KB rows)", d, 0, None), ("[K | V] of one layer (2 KB rows)", 2 * d, 0, d),
+             ("all six layers (12 KB rows), layer 2", 12 * d, 4 * d, 5 * d)]
+    cases += [(f"all six layers, rows padded by {2 * pad} B, layer 2", 12 * d + pad, 4 * d, 5 * d) for pad in (64, 128, 256, 512, 1024, 2048)]
+    for name, width, koff, voff in cases:
         if voff is None:
             kbuf = torch.randn(B * Tk, d, device=dev).to(dt); vbuf = torch.randn(B * Tk, d, device=dev).to(dt)
             k, v = kbuf, vbuf
