@@ -38,6 +38,36 @@ def gemms():
               " / ".join(f"{1e3 * v:.1f}" for v in res[64]) + f" us   [{ops.last_algo()}]", flush=True)
 
 
+def gemms_c4():
+    """c4's gated FFN: the fused up-projection (EPI 8: C = gelu(u) v rows of 6 KB, stored factors rows of 12 KB) and its data gradient
+    (EPI 9: reads the 12-KB rows, writes [du | dv] rows of 12 KB), the down-projection and the 2f data gradient (A rows of 6 / 12 KB)."""
+    M, d, f = 131072, 768, 3072
+    dr = ops.drop(0.1, 1, 1)
+    for name, N, K, kw in [("c4 glu fwd EPI 8 (C 6 KB, factors 12 KB rows)", 2 * f, d, dict(bias=1, act=7, pre=1, drop=1, glu=f)),
+                           ("c4 glu dgrad EPI 9 (factors, C 12 KB rows)", f, d, dict(act=8, pre=1, glu=f)),
+                           ("c4 ffn down (A rows 6 KB)", d, f, dict(bias=1)), ("c4 ffn up dgrad (A rows 12 KB)", d, 2 * f, {}),
+                           ("c4 qkv fwd (C rows 4.5 KB)", 3 * d, d, dict(bias=1))]:
+        res = {}
+        for rnd in range(2):
+            for pad in ((0, 64) if rnd == 0 else (64, 0)):
+                act = kw.get("act", 0)
+                cn = N // 2 if act == 7 else 2 * N if act == 8 else N
+                x = buf(M, K, pad); w = (torch.randn(N, K, device="cuda") * 0.05).half(); c = buf(M, cn, pad, rnd=False)
+                args = {}
+                if kw.get("bias"): args["bias"] = torch.randn(N, device="cuda")
+                if kw.get("pre"): args["pre_act"] = buf(M, 2 * N if act == 8 else N, pad)
+                if act: args["act"] = act
+                if kw.get("drop"): args["dropout"] = dr
+                if kw.get("glu"): args["glu_rows"] = kw["glu"]
+                try:
+                    ms = t(lambda: ops.gemm(x, w, c, **args), it=20, warm=10)
+                except AssertionError:      # the gated forms take contiguous C / factor tensors only
+                    ms = float("nan")
+                res.setdefault(pad, []).append(ms)
+        print(f"{name:48s} N {N:5d} K {K:5d}: natural rows " + " / ".join(f"{1e3 * v:.1f}" for v in res[0]) + " us   rows + 128 B " +
+              " / ".join(f"{1e3 * v:.1f}" for v in res[64]) + f" us   [{ops.last_algo()}]", flush=True)
+
+
 def wgrads():
     M, d, f = 131072, 512, 2048
     for name, group in (("c2 encoder layer weight gradients (grouped)", [(d, f), (f, d), (d, d), (3 * d, d)]),):
@@ -82,6 +112,9 @@ def attention():
 
 
 if __name__ == "__main__":
+    if "--c4" in sys.argv:
+        gemms_c4()
+        sys.exit(0)
     gemms()
     wgrads()
     attention()
