@@ -108,7 +108,11 @@ class Seq2SeqEngine:
         # weight-gradient GEMMs are off the backward critical path (their outputs are only read by the
         # optimiser / all-reduce): they run on a side HIP stream and overlap the LDS-free kernels
         # (LayerNorm backward, casts) of the main stream on the same CUs
-        self.wgrad_stream = torch.cuda.Stream(device=self.dev) if (self.dev.type == "cuda" and side_wgrad) else None
+        # (round 3: nothing gained over the whole backward -- a 240-workgroup launch with 128 KB of LDS leaves no room for a neighbour.
+        # AFM_SIDE_WGRAD=dec: only the DECODER layers' weight gradients, whose critical path is small kernels that do not fill the chip)
+        sw = "all" if side_wgrad else os.environ.get("AFM_SIDE_WGRAD", "")
+        self.side_wgrad_roles = ("dec", "enc", None) if sw == "all" else (("dec",) if sw == "dec" else ())
+        self.wgrad_stream = torch.cuda.Stream(device=self.dev) if (self.dev.type == "cuda" and self.side_wgrad_roles) else None
         self.group_wgrad = os.environ.get("AFM_GROUP_WGRAD", "1") != "0"    # (0: one launch per weight gradient, for A/B timing)
         self.row_skip = os.environ.get("AFM_ROW_SKIP", "1") != "0"          # (0: the backward computes padded rows like any other)
         # layer options of configs/model/*.yaml beside the defaults: the reference's `post_layer_normalisation` IS torch's norm_first
@@ -337,7 +341,7 @@ class Seq2SeqEngine:
             # launch, one split-K budget); the list keeps dy / x alive until then
             self._wg_pending.append((ops.gemm_desc(dy, x, gw, **kw), dy, x))
             return
-        if self.wgrad_stream is None:
+        if self.wgrad_stream is None or self._role not in self.side_wgrad_roles:
             ops.gemm(dy, x, gw, **kw)
             return
         side = self.wgrad_stream
@@ -352,7 +356,7 @@ class Seq2SeqEngine:
         if not pending:
             return
         descs = [p[0] for p in pending]
-        if self.wgrad_stream is None:
+        if self.wgrad_stream is None or self._role not in self.side_wgrad_roles:
             ops.gemm_group(descs)
             return
         side = self.wgrad_stream
