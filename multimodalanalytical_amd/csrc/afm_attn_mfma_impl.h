@@ -404,8 +404,12 @@ __global__ __launch_bounds__(512, 2) void k_attn_fwd_st(AttnM a, const e16* __re
 // ------------------------------------------------------------------------------------------ dQ
 // Per 64-key tile: S^T and dP^T (keys in registers, query on the lane), then
 // dQ^T[d][q] += sum_key K^T[d][key] dS^T[key][q].  Also writes delta = rowsum(dO * O).
+#ifndef AFM_DQ_OCC
+#define AFM_DQ_OCC 3      // workgroups per CU the dQ kernel is compiled for (168 registers, 8 ... 40 bytes of spill).  2 (no spill) was measured in
+                          // round 5 (tools/experiments/r5_dqocc.sh): keep-bit path 0.557 -> 0.611 ms, re-hash 0.706 -> 0.640, step 3 100 -> 3 058: stays 3
+#endif
 template <int DROP>
-__global__ __launch_bounds__(256, 3) void k_attn_bwd_dq_mfma(AttnM a, const e16* __restrict__ Q,
+__global__ __launch_bounds__(256, AFM_DQ_OCC) void k_attn_bwd_dq_mfma(AttnM a, const e16* __restrict__ Q,
                                                           const e16* __restrict__ K,
                                                           const e16* __restrict__ V,
                                                           const e16* __restrict__ O,
