@@ -114,6 +114,9 @@ class Seq2SeqEngine:
         self.side_wgrad_roles = ("dec", "enc", None) if sw == "all" else (("dec",) if sw == "dec" else ())
         self.wgrad_stream = torch.cuda.Stream(device=self.dev) if (self.dev.type == "cuda" and self.side_wgrad_roles) else None
         self.group_wgrad = os.environ.get("AFM_GROUP_WGRAD", "1") != "0"    # (0: one launch per weight gradient, for A/B timing)
+        # AFM_WGRAD_FLUSH_FFN=1: a layer's two FFN weight gradients go out as their own group right behind the FFN's data gradients (their
+        # operands still near the memory-side cache) instead of with the attention block's at the end of the layer (A/B: DESIGN 4.0r5 item 10)
+        self.flush_ffn_wgrads = os.environ.get("AFM_WGRAD_FLUSH_FFN", "0") == "1"
         self.row_skip = os.environ.get("AFM_ROW_SKIP", "1") != "0"          # (0: the backward computes padded rows like any other)
         # layer options of configs/model/*.yaml beside the defaults: the reference's `post_layer_normalisation` IS torch's norm_first
         # (custom_modeling.py:129,176: True = pre-LN, the shipped setting); `activation_function` goes to the torch layers as is
@@ -682,6 +685,8 @@ class Seq2SeqEngine:
             gw = self.G(p + "linear1.weight", 2 * f, d)
             gb = self.ps.vec_span(self.ps.grad, p + "linear1.bias", 0, 2 * f)
             self._wgrad_raw(duv, self._hb(h), gw, gb, glu_rows=f)
+            if self.flush_ffn_wgrads:
+                self._wgrad_flush()
             return tail(duv, self._hb(self.wt_glu[p + "linear1.weight"]))
         if not isinstance(dr, tuple):     # unfused forms (gated shapes outside the fused kernels' domain; activation "relu")
             dg = self._dgrad(dy, p + "linear2.weight", d, f)
@@ -693,6 +698,8 @@ class Seq2SeqEngine:
         else:       # du = dropout'(dy W2) * gelu'(u)
             self._dgrad(dy, p + "linear2.weight", d, f, out=duv, act=ACT_GELU_BWD, pre_act=uv, dropout=dr[0])
         self._wgrad(duv, h, p + "linear1.weight", k * f, d, bias_name=p + "linear1.bias")
+        if self.flush_ffn_wgrads:
+            self._wgrad_flush()
         return tail(duv)
 
     def _cross_attn_fwd(self, x, pend, mem, p, B, T, S, H, mem_pad, saved, site, h=None):
