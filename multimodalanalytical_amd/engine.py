@@ -117,6 +117,8 @@ class Seq2SeqEngine:
         # AFM_WGRAD_FLUSH_FFN=1: a layer's two FFN weight gradients go out as their own group right behind the FFN's data gradients (their
         # operands still near the memory-side cache) instead of with the attention block's at the end of the layer (A/B: DESIGN 4.0r5 item 10)
         self.flush_ffn_wgrads = os.environ.get("AFM_WGRAD_FLUSH_FFN", "0") == "1"
+        self.wgrad_layers = max(1, int(os.environ.get("AFM_WGRAD_LAYERS", "1")))
+        self._wg_layers_pending = 0
         self.row_skip = os.environ.get("AFM_ROW_SKIP", "1") != "0"          # (0: the backward computes padded rows like any other)
         # layer options of configs/model/*.yaml beside the defaults: the reference's `post_layer_normalisation` IS torch's norm_first
         # (custom_modeling.py:129,176: True = pre-LN, the shipped setting); `activation_function` goes to the torch layers as is
@@ -1140,6 +1142,13 @@ class Seq2SeqEngine:
     def _grads_final_from(self, first_name: str) -> None:
         """Parameters are laid out in forward order, so once a layer's backward is done every
         gradient from its first tensor to the end of the flat buffer is final."""
+        # AFM_WGRAD_LAYERS=n: the weight gradients of n consecutive layers in one grouped launch (A/B probe; only without a gradient hook,
+        # whose buckets want every layer's gradients as soon as they are final)
+        if self.wgrad_layers > 1 and self.grad_ready_hook is None:
+            self._wg_layers_pending += 1
+            if self._wg_layers_pending < self.wgrad_layers:
+                return
+            self._wg_layers_pending = 0
         self._wgrad_flush()
         if self.grad_ready_hook is not None:
             if self.wgrad_stream is not None:
@@ -1174,6 +1183,7 @@ class Seq2SeqEngine:
         d = self.d
         B, S, T = saved["B"], saved["S"], saved["T"]
         self._wg_pending = []          # (a backward pass that raised may have left entries behind)
+        self._wg_layers_pending = 0
         # Padded positions are masked as keys everywhere and take no part in the loss: their rows of every activation gradient are
         # exact zeros.  One byte per 64-row block tells the weight-gradient kernels (token axis) and the LayerNorm backward which
         # blocks hold nothing else (include/afm_hip.h: afm_gemm_desc.k_live, afm_ln_shape.row_live).
