@@ -1940,9 +1940,11 @@ int AFM_E16_FN(afm_gemm_tn_group_launch)(const afm_gemm_desc* const* ds, int cou
   // half-empty round of long ones: cost(chunk) = max(sum of unit lengths / 256, longest unit), every unit charged OVH steps for its
   // ring fill and its 256 KB of fp32 atomics (~40 steps: 50 us per round of 256 units at the 1.3 TB/s atomic rate + the prologue).
   // c4 encoder layer: chunk 293 (7 windows, 1 008 units, ~4 rounds): estimated 1 312 steps against 2 083; c2's (48 tiles) keeps split 5.
-  int chunk = max_steps;                                   // >= 256 tiles: no split-K at all
+  // The same estimate serves groups of 256 tiles and more (larger models; several layers in one launch): unsplit, 288 tiles are one full
+  // round and one of 32 units -- the probe that found it lost 8 % of the c4 step (tools/experiments/r5_wgrad_layers.sh).
+  int chunk = max_steps;                                   // (AFM_TN_ONE_WAVE with >= 256 tiles: no split-K at all)
   static const int ovh = getenv("AFM_TN_OVH") ? atoi(getenv("AFM_TN_OVH")) : 40;
-  if (tiles < 256 && !getenv("AFM_TN_ONE_WAVE")) {
+  if (!getenv("AFM_TN_ONE_WAVE")) {
     // (the plan depends on the shapes only: the last few are remembered)
     struct Plan { uint64_t key; int chunk; };
     static thread_local Plan cache[16];
@@ -1957,6 +1959,7 @@ int AFM_E16_FN(afm_gemm_tn_group_launch)(const afm_gemm_desc* const* ds, int cou
       for (int ks0 = 1; ks0 <= 64; ++ks0) {                // candidate: the longest problem split ks0 ways
         const int c = (max_steps + ks0 - 1) / ks0;
         if (c < 16) break;                                 // >= 1024 tokens per unit
+        if ((int64_t)tiles * ks0 > 8192) break;            // (host time of the estimate: units x 256 slots per candidate)
         // greedy schedule of the units in launch order on 256 slots (a min-heap of finish times would do; 256 is small enough to scan)
         int finish[256] = {0};
         int makespan = 0;
