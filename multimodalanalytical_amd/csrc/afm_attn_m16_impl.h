@@ -1,3 +1,6 @@
+// (Dispatch as of the end of round 5: the dQ kernel below is the DEFAULT where no keep-bit tensor is read -- no dropout, or the hash
+// re-evaluated -- in its two-workgroups-per-CU build; with the keep bits the 32 x 32 x 16 kernel stays.  The dK/dV restatement at the end of
+// this file is an A / B form; the default dK/dV kernel is its hand-pipelined sibling, afm_attn_pipe16_impl.h.)
 // The dQ kernel of the single-pass flash-attention backward on v_mfma_f32_16x16x32 (included by afm_attn_mfma_impl.h inside namespace
 // AFM_E16_NS).  Round 5, VERDICT r04 item 1: the three attention kernels run v_mfma_f32_32x32x16; MI355X_MICROARCH.md ("DVFS give-back"
 // item 7) measures the 16x16x32 shape at 1.12-1.15 x the FLOP/s in bare clock-limited loops, so the shape is A/B-tested here on the

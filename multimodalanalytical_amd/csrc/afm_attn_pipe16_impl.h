@@ -11,7 +11,9 @@
 // The keep-bit tensor keeps its 32 x 32 layout: a key's 32 query bits are one dword, which is what this kernel reads anyway.
 // Q and dO images use the swizzle chunk ^ ((row >> 1) & 3) << 1 (dma_piece_tr16): conflict-free for the 16 x 16 x 32 row reads AND the
 // transposed reads.  The accumulation order differs from the 32 x 32 x 16 kernels: results agree to rounding, not bit for bit.
-// Taken for: no causal mask, Tq a multiple of 64, keep bits or no dropout, four waves (afm_attn_shape.reserved & 8192: an A / B form).
+// Taken for: no causal mask, Tq a multiple of 64, keep bits or no dropout, four waves.  THE DEFAULT dK/dV kernel there since round 5
+// (0.652 ... 0.658 ms against the 32 x 32 x 16 pipeline's 0.690 ... 0.694 at the c2 encoder shape with keep bits, +0.9 % on the step);
+// afm_attn_shape.reserved & 16384 keeps the 32 x 32 x 16 pipeline (A / B runs, its bit-identity test).
 
 template <int DROP>
 __global__ __launch_bounds__(256, 2) void k_attn_bwd_dkv_pipe16(AttnM a, const e16* __restrict__ Q, const e16* __restrict__ K,
