@@ -495,8 +495,10 @@ __device__ __forceinline__ void epilogue_staged_e16(const MfmaArgs& g, float* st
     for (int hf = 0; hf < 2; ++hf) {
       const int q = i * 2 + hf;                       // 8-row group of the wave's 16*WM rows
       const int row = hf * 8 + r8;
-      const f32x4 v0 = *(const f32x4*)(stg + row * STG_LD + c8) + b0;
-      const f32x4 v1 = *(const f32x4*)(stg + row * STG_LD + c8 + 4) + b1;
+      // (EPI_GLU_BWD: the lane takes hidden units 4 L .. + 3 and 32 + 4 L .. + 3 of the wave's 64, L = lane & 7 -- see below)
+      constexpr bool GB = EPI == EPI_GLU_BWD;
+      const f32x4 v0 = *(const f32x4*)(stg + row * STG_LD + (GB ? (c8 >> 1) : c8)) + b0;
+      const f32x4 v1 = *(const f32x4*)(stg + row * STG_LD + (GB ? 32 + (c8 >> 1) : c8 + 4)) + b1;
       float x[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
       const int64_t ro = (int64_t)(q * 8) * g.ldc;
       const uint32_t di = dbase + (uint32_t)(q * 8) * (uint32_t)g.N;
@@ -524,11 +526,15 @@ __device__ __forceinline__ void epilogue_staged_e16(const MfmaArgs& g, float* st
         continue;
       }
       if constexpr (EPI == EPI_GLU_BWD) {
-        // x[0..7] = dg of hidden units n .. n+7; saved / output columns 2n .. 2n+15 (two interleave groups), 2f = ldc wide
+        // x[0..3] = dg of hidden units nw + 4 L .. + 3, x[4..7] of nw + 32 + 4 L .. + 3 (L = lane & 7): one interleave group each, i.e. the
+        // 16-byte pieces 8 L and 64 + 8 L of the wave's 128 saved / output columns 2 nw .. 2 nw + 127 (2f = ldc wide).  Round 5: with a
+        // lane on hidden units n .. n + 7 its two pieces were NEIGHBOURS (32 bytes per lane), so each of the two read-once loads touched
+        // every 64-byte granule of the row and HBM delivered the 1.6-GB factor tensor twice (3.6 GB read for 1.8, profiles/r05_*); this way
+        // a load instruction's eight lanes cover 128 contiguous bytes of a row, and so does a store.
         const int64_t rowi = mw + r8 + q * 8;
-        const e16* sp = (const e16*)g.pre_act + rowi * g.ldc + 2 * n;
-        e16* cp = (e16*)g.C + rowi * g.ldc + 2 * n;
-        const e16x8 s0 = load16_once(sp), s1 = load16_once(sp + 8);
+        const e16* sp = (const e16*)g.pre_act + rowi * g.ldc + 2 * nw + c8;
+        e16* cp = (e16*)g.C + rowi * g.ldc + 2 * nw + c8;
+        const e16x8 s0 = load16_once(sp), s1 = load16_once(sp + 64);
         e16x8 o0, o1;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -536,7 +542,7 @@ __device__ __forceinline__ void epilogue_staged_e16(const MfmaArgs& g, float* st
           o1[k] = (e16)(x[4 + k] * (float)s1[k]); o1[4 + k] = (e16)(x[4 + k] * (float)s1[4 + k]);
         }
         store16_policy<CAUX>(g.C, (uint64_t)((cp - (e16*)g.C) * 2), __builtin_bit_cast(uint4, o0));
-        store16_policy<CAUX>(g.C, (uint64_t)((cp + 8 - (e16*)g.C) * 2), __builtin_bit_cast(uint4, o1));
+        store16_policy<CAUX>(g.C, (uint64_t)((cp + 64 - (e16*)g.C) * 2), __builtin_bit_cast(uint4, o1));
         continue;
       }
       if (EPI == EPI_GELU) {
