@@ -349,6 +349,10 @@ extern "C" int afm_layernorm_fwd(const afm_ln_shape* s, const float* x, const fl
   hipStream_t st = (hipStream_t)stream;
   if (s->y_dtype < AFM_F32 || s->y_dtype > AFM_F16) return AFM_ERR_ARG;
   if ((s->d % 8) == 0 && s->d <= 2048 && s->rows >= 64 && (!pos || ((uintptr_t)pos & 15) == 0)) {   // vectorised path
+    // The grid is what is RESIDENT at once (every wave strides over the rows): five workgroups per CU at d <= 512 (92 registers), three
+    // at d <= 1024 (148), one beyond (268).  Until round 5 the 1 280 blocks of the d <= 512 kernel were launched for every d: at d = 768
+    // (c4) that is 1.67 rounds of equal-length blocks on 768 slots -- the kernels ran at 4.6 TB/s there against 5.3 at d = 512.
+    if (!getenv("AFM_LN_FWD_BLOCKS")) g = std::min<int64_t>((s->rows + 3) / 4, 256 * (s->d <= 512 ? 5 : s->d <= 1024 ? 3 : 1));
 #define LN_FV(TY, TA, NC) AFM_LAUNCH((k_ln_fwd_vec<TY, TA, NC>), dim3((int)g), dim3(256), 0, st, x, gamma, beta, (TY*)y, mean, \
                                      rstd, s->rows, s->d, s->eps, (const TA*)add, x_sum, adrop, pos, s->seg_len,   \
                                      s->out_seg_stride, s->out_off)
@@ -493,11 +497,13 @@ extern "C" int afm_layernorm_bwd(const afm_ln_shape* s, const void* dy, const fl
   if (!partial && !ln_bwd_vectorised(s)) return AFM_ERR_ARG;      // (afm_layernorm_bwd_ws_floats says which shapes need it)
   if (s->d > 64 * LN_MAXV) return AFM_ERR_UNSUPPORTED;
   if (s->rows == 0) return AFM_OK;
-  const int g = ln_bwd_blocks(s->rows);
+  const int g0 = ln_bwd_blocks(s->rows), g = g0;
   hipStream_t st = (hipStream_t)stream;
   const size_t shm = sizeof(float) * 8 * s->d;
   if (s->y_dtype < AFM_F32 || s->y_dtype > AFM_F16) return AFM_ERR_ARG;
   if (ln_bwd_vectorised(s)) {   // vectorised path (dy rows follow the embedder's placement, if any)
+    // resident workgroups only, as in the forward: three per CU at d <= 512 (136 registers), two at d <= 1024 (229), one beyond (438)
+    const int g = getenv("AFM_LN_BWD_BLOCKS") ? g0 : (int)std::min<int64_t>((s->rows + 3) / 4, 256 * (s->d <= 512 ? 3 : s->d <= 1024 ? 2 : 1));
 #define LN_BV(TY, NC) AFM_LAUNCH((k_ln_bwd_vec<TY, NC>), dim3(g), dim3(256), shm, st, (const TY*)dy, x, gamma, mean, rstd, dres, dx, \
                                  dgamma, dbeta, s->rows, s->d, (TY*)dx_drop, dd, s->seg_len, s->out_seg_stride, s->out_off,   \
                                  (s->seg_len == 0 && (s->rows & 63) == 0) ? s->row_live : nullptr)

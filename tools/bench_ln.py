@@ -16,6 +16,10 @@ def t(fn, it=30, warm=10):
 
 dev = "cuda:0"
 rows, d = 131072, 512
+for a_ in sys.argv[1:]:      # --d=768 --rows=16384
+    if a_.startswith("--d="): d = int(a_[4:])
+    if a_.startswith("--rows="): rows = int(a_[7:])
+print(f"rows {rows} d {d}  AFM_LN_FWD_BLOCKS={os.environ.get('AFM_LN_FWD_BLOCKS', '(by d)')} AFM_LN_BWD_BLOCKS={os.environ.get('AFM_LN_BWD_BLOCKS', '(by d)')}")
 cd = torch.float16
 x = torch.randn(rows, d, device=dev); br = torch.randn(rows, d, device=dev).to(cd)
 gam, bet = torch.ones(d, device=dev), torch.zeros(d, device=dev)
