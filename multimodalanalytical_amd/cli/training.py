@@ -116,6 +116,17 @@ class ShardLoader:
         self.rank, self.world, self.shuffle, self.drop_last = rank, world, shuffle, drop_last
         self.n = shard_len(shard)
         self.dev_data = {m: {k: v.to(device) for k, v in d.items()} for m, d in shard["data"].items()}   # resident in HBM
+        # AFM_SORT_BATCH=1 / 2 (training shuffles only; A / B probes, OFF by default): the samples of a micro-batch in order of decreasing
+        # encoder length (1), or that order dealt in a snake over the batch's eight contiguous eighths (2).  Which samples share a batch
+        # does not change and neither does the loss.  Measured: 1 loses 4 ... 6 % on the padded workloads (the
+        # live rows pile up in the first XCDs' row ranges of the hinted backward GEMMs), 2 equals the random order.
+        self.sort_len = None
+        self.sort_mode = os.environ.get("AFM_SORT_BATCH", "0")
+        if shuffle and self.sort_mode in ("1", "2"):
+            inputs = set(getattr(collator, "input_modalities", []))
+            masks = [d["attention_mask"].sum(1) for m, d in self.dev_data.items() if m in inputs and "attention_mask" in d]
+            if masks:
+                self.sort_len = torch.stack(masks, 0).sum(0)
 
     def __len__(self):
         per_rank = self.n // self.world
@@ -127,6 +138,14 @@ class ShardLoader:
         order = order[:(self.n // self.world) * self.world][self.rank::self.world].to(self.dev)
         for i in range(len(self)):
             idx = order[i * self.bs:(i + 1) * self.bs]
+            if self.sort_len is not None:
+                idx = idx[torch.argsort(self.sort_len[idx], descending=True, stable=True)]
+                if self.sort_mode == "2" and idx.numel() % 8 == 0:
+                    # snake deal: the sorted samples go round the 8 contiguous eighths of the batch (= the row ranges the persistent
+                    # kernels give an XCD each), forwards and backwards in turn, so every eighth holds the same share of live rows
+                    n8 = idx.numel() // 8
+                    j = torch.arange(8, device=idx.device)[:, None]; r = torch.arange(n8, device=idx.device)[None, :]
+                    idx = idx[(8 * r + torch.where(r % 2 == 0, j, 7 - j)).reshape(-1)]
             yield self.collator({m: {k: v.index_select(0, idx) for k, v in d.items()} for m, d in self.dev_data.items()})
 
 
