@@ -13,7 +13,7 @@ def main():
     tok = SimpleTokenizerInfo(wl["data"]["Smiles"]["vocab_size"])
     from multimodalanalytical_amd.x2 import X2
     mode = sys.argv[3] if len(sys.argv) > 3 else "bf16x3"
-    cd = {"bf16x3": X2.dtype, "bf16": torch.bfloat16, "fp32": torch.float32}[mode]
+    cd = {"bf16x3": X2.dtype, "bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32}[mode]
     model = HFWrapper(wl["data"], "CustomModel", "facebook/bart-base", tok, device=dev, compute_dtype=cd,
                       **{k: v for k, v in wl["cfg"].items() if k != "multimodal_norm"})
     batch = synth.make_batch(name, B, seed=1, device=dev)[0]
