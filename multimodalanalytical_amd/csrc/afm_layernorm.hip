@@ -243,9 +243,13 @@ __global__ __launch_bounds__(256) void k_ln_bwd_vec(const TY* __restrict__ dy, c
   // Two rows in flight per wave, as in the forward kernel: dy, x, dres, mean and rstd of row r + nwaves are requested before row r is
   // reduced (the residual-gradient load used to sit behind the two wave reductions).  Rows in all-padding blocks are neither loaded nor
   // computed, as before.
+  // The padded-row flags run ONE MORE iteration ahead: whether row r + nwaves is loaded at all depends on its block's byte, and read
+  // where it was needed that byte was a dependent round trip to L2 in front of every row's loads -- with hints the kernel moved 4.2 TB/s
+  // in the c3 step against 5.2 without them (profiles/r05_c3_fp16_step_pmc.json before / after).
   struct RowIn { F8 dy[NC], x[NC], dr[NC]; float mu, rs; };
-  auto load_row = [&](int64_t r, RowIn& in) {
-    if (row_live && !row_live[r >> 6]) return;
+  auto live_of = [&](int64_t r) -> bool { return !row_live || row_live[r >> 6] != 0; };
+  auto load_row = [&](int64_t r, RowIn& in, bool live) {
+    if (!live) return;
     in.mu = mean[r]; in.rs = rstd[r];
 #pragma unroll
     for (int i = 0; i < NC; ++i) {
@@ -258,10 +262,16 @@ __global__ __launch_bounds__(256) void k_ln_bwd_vec(const TY* __restrict__ dy, c
     }
   };
   RowIn cur, nxt;
-  if (wave < rows) load_row(wave, cur);
+  bool lv_cur = wave < rows ? live_of(wave) : true;
+  bool lv_nxt = wave < rows ? live_of(wave + nwaves < rows ? wave + nwaves : wave) : true;
+  if (wave < rows) load_row(wave, cur, lv_cur);
   for (int64_t r = wave; r < rows; r += nwaves) {
-    load_row(r + nwaves < rows ? r + nwaves : r, nxt);
-    if (row_live && !row_live[r >> 6]) {     // a block of padded positions: dy = dres = 0 there, so dx = 0 and nothing is added to dgamma / dbeta
+    const int64_t rn = r + nwaves < rows ? r + nwaves : r;
+    const bool lv_nn = live_of(rn + nwaves < rows ? rn + nwaves : rn);      // the flag of the row after next: used one iteration from now
+    load_row(rn, nxt, lv_nxt);
+    const bool dead = !lv_cur;
+    lv_cur = lv_nxt; lv_nxt = lv_nn;
+    if (dead) {     // a block of padded positions: dy = dres = 0 there, so dx = 0 and nothing is added to dgamma / dbeta
       const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
       const F8 z = {z4, z4};
 #pragma unroll
