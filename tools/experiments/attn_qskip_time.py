@@ -22,6 +22,10 @@ g = torch.Generator(device=dev).manual_seed(1)
 qkv = torch.randn(B * T, 3 * D, device=dev, generator=g).half()
 q, k, v = qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:]
 lens = torch.randint(56 + 100, 56 + 760, (B,), generator=torch.Generator().manual_seed(2))
+order = os.environ.get("ORDER", "random")      # the batch order the kernels' workgroups are dispatched in: random | desc | asc
+if order == "desc": lens = torch.sort(lens, descending=True).values
+if order == "asc": lens = torch.sort(lens).values
+print("batch order:", order)
 pad = (torch.arange(T)[None, :] >= lens[:, None])
 print("padded fraction", float(pad.float().mean()))
 kp = pad.to(torch.uint8).to(dev).contiguous()
