@@ -43,8 +43,12 @@ extern "C" {
  *   5  exports added since 4: afm_cast_weights_batch, afm_comm_count, afm_struct_size(6) = afm_cast_item; afm_layernorm_bwd's
  *      workspace contract (afm_layernorm_bwd_ws); BOTH dropout streams redefined (two-level hashing: one full mixer per score-matrix
  *      row / per block of 64 elements, a pair mix per element pair) -- a library older than 5 produces different masks for the same
- *      (seed, site, index), so checkpoints' dropout positions and tests/dropmask.py belong to version >= 5. */
-#define AFM_ABI_VERSION 5
+ *      (seed, site, index), so checkpoints' dropout positions and tests/dropmask.py belong to version >= 5.
+ *   6  padded rows in the FORWARD pass of a training step: afm_gemm_desc.reserved2 bit 1 (k_live in the forward sense), afm_ln_shape.row_live
+ *      read by afm_layernorm_fwd, afm_ln_shape.row_map (per-sample compaction of the live positions at the embedder), afm_attn_fwd honours
+ *      reserved bit 6; exports added: afm_compact_plan, afm_permute_rows.  The ablation selector of AFM_ATTN_ABLATIONS builds moved to
+ *      afm_attn_shape.reserved bits 20-27 (it overlapped the live selectors 16384 / 32768 / 65536). */
+#define AFM_ABI_VERSION 6
 
 enum { AFM_OK = 0, AFM_ERR_ARG = -1, AFM_ERR_UNSUPPORTED = -2, AFM_ERR_LAUNCH = -3 };
 enum { AFM_F32 = 0, AFM_BF16 = 1, AFM_BF16X2 = 2, AFM_F16 = 3 };
@@ -126,12 +130,18 @@ typedef struct {
   afm_dropout drop;
   int32_t glu_rows;       /* f > 0: gated-FFN interleave (see above); wgrad form: rows of C / a_colsum are de-interleaved */
   int32_t reserved2;      /* bit 0 (pair dtype, act GELU_SAVE_GRAD / GLU_SAVE): the stored factors get their hi plane only -- the
-                             consumer is the single-pass bf16 backward of the mixed precision mode, which never reads the lo plane */
+                             consumer is the single-pass bf16 backward of the mixed precision mode, which never reads the lo plane.
+                             bit 1 (2): k_live is meant in the FORWARD sense (below) */
   const uint8_t* k_live;  /* nullable: k_live[i] == 0 says the STORED rows 64 i .. 64 i + 63 of A (64 token positions) are all zero --
                              the padded positions of a training step's backward, whose activation gradients are exact zeros.
                              wgrad form (transA): the MFMA kernels leave those k-steps out (K / 64 bytes).  NT form without bias /
                              residual / accumulate, act NONE, MUL_SAVED or GLU_BWD: 256-row tiles of nothing but such blocks are written as
-                             zeros without being computed (M / 64 bytes).  Same results either way; a hint, ignored elsewhere. */
+                             zeros without being computed (M / 64 bytes).  Same results either way; a hint, ignored elsewhere.
+                             FORWARD sense (reserved2 bit 1, NT form, no residual / accumulate): k_live[i] == 0 says nobody reads rows 64 i ..
+                             64 i + 63 of C (the padded positions of a training step, which are masked as keys everywhere and take no part in the
+                             loss): 256-row tiles of nothing but such blocks are not computed, whatever the epilogue; their rows of C -- and of a
+                             pre_act the epilogue stores -- are written as ZEROS (finite values: later kernels may still load them).  Rows of live
+                             tiles are computed as always.  A hint: kernels without tile lists compute every row. */
 } afm_gemm_desc;
 int afm_gemm(const afm_gemm_desc* d, void* stream);
 
@@ -188,9 +198,15 @@ typedef struct {
   afm_dropout add_drop;   /* forward only: x_sum = x + dropout(add) with this stream (p = 0: plain add); the
                              element index is row-major in `add`, the same index the GEMM epilogue and the
                              backward's dx_drop use for that site */
-  const uint8_t* row_live; /* backward only, nullable: row_live[i] == 0 says rows 64 i .. 64 i + 63 of dy (and of dres) are all zero
-                             (padded positions): their dx / dx_drop rows are written as zeros without reading anything and they
-                             add nothing to dgamma / dbeta.  rows / 64 bytes (rows % 64 == 0), identity row mapping only. */
+  const uint8_t* row_live; /* nullable, rows / 64 bytes (rows % 64 == 0), identity row mapping only.  Backward: row_live[i] == 0 says rows
+                             64 i .. 64 i + 63 of dy (and of dres) are all zero (padded positions): their dx / dx_drop rows are written as
+                             zeros without reading anything and they add nothing to dgamma / dbeta.  Forward (ABI 6): row_live[i] == 0 says
+                             nobody reads those rows of the outputs (padded positions of a training step): nothing is loaded, y / x_sum /
+                             mean / rstd get zeros there.  A hint: the scalar kernels (d % 8 != 0, rows < 64) ignore it. */
+  const int32_t* row_map;  /* nullable, placement form (seg_len != 0) only, forward and backward: position p = out_off + r % seg_len of sample
+                             b = r / seg_len lives in row b * out_seg_stride + row_map[b * out_seg_stride + p] of the concatenated sequence
+                             instead of row b * out_seg_stride + p (afm_compact_plan: the sample's live positions moved to the front of its
+                             slot).  The positional row added stays pos[p]: positions are encoded before the move. */
 } afm_ln_shape;
 int afm_layernorm_fwd(const afm_ln_shape* s, const float* x, const float* gamma, const float* beta,
                       const float* pos, void* y, float* mean, float* rstd, const void* add,
@@ -206,6 +222,28 @@ int afm_layernorm_bwd(const afm_ln_shape* s, const void* dy, const float* x, con
  *                   gather == 1: y[r, :] = x[out_row(r), :]  (backward: the modality's slice of the stream gradient). */
 int afm_place_rows(const float* x, const float* pos, float* y, int64_t rows, int32_t d, int64_t seg_len,
                    int64_t out_seg_stride, int64_t out_off, int32_t gather, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Padded positions out of a training step's forward pass (ABI 6).  The collator pads every modality to its own length, so a sample's
+ * padding sits in several runs inside its S-row slot (data/datamodules.py:230-351 builds the mask, one run per modality); the layer
+ * stacks mask those positions as keys everywhere (custom_modeling.py:238,312-318) and pool them out of the alignment head (:469-470), so
+ * nothing reads their rows.  afm_compact_plan turns a key-padding mask into a per-sample stable partition -- live positions first, in
+ * order -- and the block flags the kernels above take:
+ *   dest[b*S + s]      new position of position s of sample b (compact == 0: s itself)
+ *   pad_out[b*S + p]   the mask in the new order (compact != 0: 1 for p >= n_live[b]); may alias key_pad only when compact == 0
+ *   live64[b*S/64 + i] 1 if positions 64 i .. 64 i + 63 (new order) hold a live one: k_live / row_live of the BACKWARD (exact zeros)
+ *   live_tile[...]     the same widened to whole groups of tile_rows rows (a multiple of 64 dividing S: 256, the tallest GEMM tile):
+ *                      1 if the group holds a live position -- k_live / row_live in the FORWARD sense.  Every forward kernel then
+ *                      agrees on which rows exist, whatever its own tile height.
+ *   n_live[b]          live positions of sample b
+ * S <= 4096, S % tile_rows == 0.  Encoder self-attention, cross-attention over the memory and the masked mean are indifferent to the
+ * order of the key positions once the mask moves with them; positional encodings are added before the move (afm_ln_shape.row_map).
+ * afm_permute_rows moves fp32 rows through such a map where no LayerNorm does it on the way:
+ *   gather == 0: y[b*S + map[b*S + s], :] = x[b*S + s, :]       gather == 1: y[b*S + s, :] = x[b*S + map[b*S + s], :]
+ * ---------------------------------------------------------------------------------------- */
+int afm_compact_plan(const uint8_t* key_pad, int32_t B, int32_t S, int32_t tile_rows, int32_t compact, int32_t* dest,
+                     uint8_t* pad_out, uint8_t* live64, uint8_t* live_tile, int32_t* n_live, void* stream);
+int afm_permute_rows(const float* x, float* y, const int32_t* map, int32_t B, int32_t S, int32_t d, int32_t gather, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Masked multi-head attention, flash style (no T_q x T_k tensor in HBM).
@@ -232,7 +270,9 @@ typedef struct {
                              earlier call): lets bench.py / the profiler time the two backward kernels separately.
                              bit 6 (64): afm_attn_bwd, self-attention (Tq == Tk, key_pad given): the caller vouches that dO is zero in the query rows
                              key_pad marks (a training step's padded positions); the single-pass kernels then skip them -- dQ rows stay
-                             zero, dK / dV lose exact zeros.  bit 5 (32): forward reads drop_bits (afm_attn_drop_bits_fill ran before); bit 4 (16): the 8-wave staggered forms of the single-pass forward / dQ kernels (Tq >= 256), see DESIGN.md 4.
+                             zero, dK / dV lose exact zeros.  afm_attn_fwd (ABI 6), same condition: nobody reads the outputs of the query rows
+                             key_pad marks; workgroups (128 queries) of nothing but such rows write O = 0, lse = +inf (the all-masked-row
+                             convention) and return.  bit 5 (32): forward reads drop_bits (afm_attn_drop_bits_fill ran before); bit 4 (16): the 8-wave staggered forms of the single-pass forward / dQ kernels (Tq >= 256), see DESIGN.md 4.
                              afm_attn_bwd, dK/dV kernel selection (A / B tests; every form gives bit-identical dK / dV): bit 7 (128) the round-3
                              kernel instead of the software-pipelined one (csrc/afm_attn_pipe_impl.h: default where there is no causal mask, Tq % 64 == 0
                              and dropout runs through drop_bits or is off); bit 8 (256) its eight-wave form; bit 9 (512) its form with 64 keys per
@@ -241,7 +281,7 @@ typedef struct {
                              round-3 kernel restated on 16 x 16 x 32, bits 10-11 (1024, 2048) the 16 x 16 x 32 dQ kernels (the default without dropout and where the
                              hash is re-evaluated; bit 15 (32768) keeps the 32 x 32 x 16 dQ kernel there); bit 16 (65536) the short-query dK/dV kernel
                              (csrc/afm_attn_sq_impl.h: Tq <= 192 < 256 <= Tk, no causal mask; an A / B form).  afm_attn_fwd: bits 10-11 select
-                             the forward restated on 16 x 16 x 32 (csrc/afm_attn_fwd16_impl.h; bit 11: its three-workgroup build; A / B forms).  Bits 12-19 are timing ablations instead in AFM_ATTN_ABLATIONS builds (never in the product library). */
+                             the forward restated on 16 x 16 x 32 (csrc/afm_attn_fwd16_impl.h; bit 11: its three-workgroup build; A / B forms).  Bits 20-27 select timing ablations in AFM_ATTN_ABLATIONS builds (never in the product library). */
   const uint8_t* key_pad;
   afm_dropout drop;
   /* batch strides in ELEMENTS of Q, K, V, O (0 = dense: Tq*ldq, Tk*ldk, Tk*ldv, Tq*ldo).  Non-dense

@@ -39,6 +39,21 @@ __global__ __launch_bounds__(256, AFM_FWD_OCC) void k_attn_fwd_mfma(AttnM a, con
   const int q0 = blk_.xb * 128 + w * 32;          // this wave's first query
   const int q = q0 + (lane & 31);
   const int qc = q < a.Tq ? q : a.Tq - 1;
+  // self-attention over a padded batch in a training step: nobody reads the outputs of padded query rows (qskip: afm_attn_shape.reserved
+  // bit 6 in the forward sense).  A workgroup whose 128 queries are all padding writes the all-masked-row convention (O = 0, lse = +inf:
+  // finite values for whoever still loads the rows, P = 0 for a backward that does not skip them) and leaves; no keep bits are written.
+  if (a.qskip && __syncthreads_and(q >= a.Tq || a.key_pad[(int64_t)b * a.Tk + qc] != 0)) {
+    if (q < a.Tq) {
+      e16* op = O + ((int64_t)b * a.Tq + q) * a.ldo + hd * DH + 4 * h;
+      const e16x4 z = {(e16)0.f, (e16)0.f, (e16)0.f, (e16)0.f};
+#pragma unroll
+      for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) *(e16x4*)(op + 32 * db + 8 * g4) = z;
+      if (h == 0) lse[((int64_t)b * a.H + hd) * a.Tq + q] = INFINITY;
+    }
+    return;
+  }
   const e16* Kb = K + (int64_t)b * a.Tk * a.ldk + hd * DH;
   const e16* Vb = V + (int64_t)b * a.Tk * a.ldv + hd * DH;
   int kend = a.Tk;
@@ -1197,8 +1212,8 @@ int AFM_E16_FN(afm_attn_bwd_mfma_try)(const afm_attn_shape* s, const void* Q, co
 #ifdef AFM_ATTN_ABLATIONS
 #define AFM_PIPE_ABL_CASE(N) case N: (void)hipFuncSetAttribute((const void*)k_attn_bwd_dkv_pipe<DROP_BITS, 4, 1, N>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); \
     AFM_PIPE_LAUNCH((k_attn_bwd_dkv_pipe<DROP_BITS, 4, 1, N>), 256); return AFM_OK;
-  if (run_k && piped && pnw == 4 && pkb == 1 && a.dd.thresh16 && ((s->reserved >> 12) & 255)) {
-    switch ((s->reserved >> 12) & 255) {
+  if (run_k && piped && pnw == 4 && pkb == 1 && a.dd.thresh16 && ((s->reserved >> 20) & 255)) {
+    switch ((s->reserved >> 20) & 255) {
       AFM_PIPE_ABL_CASE(1) AFM_PIPE_ABL_CASE(2) AFM_PIPE_ABL_CASE(4) AFM_PIPE_ABL_CASE(6) AFM_PIPE_ABL_CASE(3) AFM_PIPE_ABL_CASE(7) AFM_PIPE_ABL_CASE(8)
       AFM_PIPE_ABL_CASE(16) AFM_PIPE_ABL_CASE(32) AFM_PIPE_ABL_CASE(23) AFM_PIPE_ABL_CASE(31) AFM_PIPE_ABL_CASE(63) AFM_PIPE_ABL_CASE(22) AFM_PIPE_ABL_CASE(54)
       AFM_PIPE_ABL_CASE(64) AFM_PIPE_ABL_CASE(80) AFM_PIPE_ABL_CASE(112) AFM_PIPE_ABL_CASE(120)

@@ -1,5 +1,6 @@
 // HBM-bound elementwise / gather / reduction kernels of the spectra->SMILES path (gfx950).
 // Each kernel moves every byte once; rows are walked with 64-lane waves on contiguous data.
+#include <algorithm>
 #include "afm_common.h"
 
 static thread_local const char* g_last_algo = "none";
@@ -108,6 +109,80 @@ extern "C" int afm_place_rows(const float* x, const float* pos, float* y, int64_
   if (rows == 0) return AFM_OK;
   AFM_LAUNCH(k_place_rows, dim3(grid_for(rows * d, 256)), dim3(256), 0, (hipStream_t)stream, x, pos, y, rows, d, seg_len,
              out_seg_stride, out_off, gather);
+  return AFM_OK;
+}
+
+// ---------------------------------------------------------------- padded positions out of the forward pass (include/afm_hip.h, ABI 6)
+// One workgroup per sample: thread t owns the positions [t * chunk, (t + 1) * chunk); live counts -> block scan -> the stable partition.
+__global__ __launch_bounds__(256) void k_compact_plan(const uint8_t* __restrict__ key_pad, int S, int tile_rows, int compact,
+                                                      int32_t* __restrict__ dest, uint8_t* __restrict__ pad_out,
+                                                      uint8_t* __restrict__ live64, uint8_t* __restrict__ live_tile,
+                                                      int32_t* __restrict__ n_live) {
+  __shared__ int scan[256];
+  __shared__ int blk_any[64];
+  const int b = blockIdx.x, t = threadIdx.x;
+  const uint8_t* kp = key_pad + (int64_t)b * S;
+  const int chunk = (S + 255) / 256;
+  const int s0 = min(S, t * chunk), s1 = min(S, s0 + chunk);
+  if (t < 64) blk_any[t] = 0;
+  int cnt = 0;
+  for (int s = s0; s < s1; ++s) cnt += kp[s] == 0;
+  scan[t] = cnt;
+  __syncthreads();
+  for (int off = 1; off < 256; off <<= 1) {      // Hillis-Steele inclusive scan (256 entries)
+    const int v = t >= off ? scan[t - off] : 0;
+    __syncthreads();
+    scan[t] += v;
+    __syncthreads();
+  }
+  const int L = scan[255];
+  int before = scan[t] - cnt;                    // live positions in front of this thread's range
+  for (int s = s0; s < s1; ++s) {
+    const bool live = kp[s] == 0;
+    if (dest) dest[(int64_t)b * S + s] = !compact ? s : live ? before : L + (s - before);
+    if (!compact && live) blk_any[s >> 6] = 1;   // (benign race: every writer stores 1)
+    before += live;
+  }
+  if (t == 0 && n_live) n_live[b] = L;
+  __syncthreads();
+  if (pad_out) for (int p = t; p < S; p += 256) pad_out[(int64_t)b * S + p] = compact ? (uint8_t)(p >= L) : kp[p];
+  const int nb = S >> 6, per = tile_rows >> 6;
+  for (int i = t; i < nb; i += 256) {
+    bool l64, lt;
+    if (compact) { l64 = 64 * i < L; lt = (i / per) * tile_rows < L; }
+    else {
+      l64 = blk_any[i] != 0; lt = false;
+      for (int j = (i / per) * per; j < (i / per + 1) * per; ++j) lt = lt || blk_any[j] != 0;
+    }
+    if (live64) live64[(int64_t)b * nb + i] = l64;
+    if (live_tile) live_tile[(int64_t)b * nb + i] = lt;
+  }
+}
+extern "C" int afm_compact_plan(const uint8_t* key_pad, int32_t B, int32_t S, int32_t tile_rows, int32_t compact, int32_t* dest,
+                                uint8_t* pad_out, uint8_t* live64, uint8_t* live_tile, int32_t* n_live, void* stream) {
+  if (!key_pad || B <= 0 || S <= 0 || S > 4096 || tile_rows <= 0 || (tile_rows & 63) || (S % tile_rows)) return AFM_ERR_ARG;
+  if (compact && pad_out == key_pad) return AFM_ERR_ARG;      // the kernel re-reads the mask after writing the new one
+  AFM_LAUNCH(k_compact_plan, dim3(B), dim3(256), 0, (hipStream_t)stream, key_pad, S, tile_rows, compact, dest, pad_out, live64, live_tile, n_live);
+  return AFM_OK;
+}
+
+// one wave per row, 16 bytes per lane
+__global__ __launch_bounds__(256) void k_permute_rows(const float* __restrict__ x, float* __restrict__ y, const int32_t* __restrict__ map,
+                                                      int64_t rows, int S, int d, int gather) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t r = wave; r < rows; r += nwaves) {
+    const int64_t m = (r / S) * S + map[r];
+    const float* src = x + (gather ? m : r) * (int64_t)d;
+    float* dst = y + (gather ? r : m) * (int64_t)d;
+    if ((d & 3) == 0) for (int c = lane * 4; c < d; c += 256) *(float4*)(dst + c) = *(const float4*)(src + c);
+    else for (int c = lane; c < d; c += 64) dst[c] = src[c];
+  }
+}
+extern "C" int afm_permute_rows(const float* x, float* y, const int32_t* map, int32_t B, int32_t S, int32_t d, int32_t gather, void* stream) {
+  if (!x || !y || !map || x == y || B <= 0 || S <= 0 || d <= 0) return AFM_ERR_ARG;
+  const int64_t rows = (int64_t)B * S;
+  AFM_LAUNCH(k_permute_rows, dim3((int)std::min<int64_t>((rows + 3) / 4, 2048)), dim3(256), 0, (hipStream_t)stream, x, y, map, rows, S, d, gather);
   return AFM_OK;
 }
 

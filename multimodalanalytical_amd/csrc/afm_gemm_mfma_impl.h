@@ -31,6 +31,7 @@ struct MfmaArgs {
   float* a_colsum;
   const uint8_t* k_live;   // afm_gemm_desc.k_live: 64-row blocks of A's stored rows (TN: k-steps; NT: row blocks of A and C)
   int live_off;            // NT, persistent kernels: LDS byte offset of the live / dead tile lists (0: no hint in use)
+  int dead_pre;            // NT with k_live in the FORWARD sense (afm_gemm_desc.reserved2 bit 1): pre_act is an output, zero-filled with C in dead tiles
   int act, accumulate;
   int tiles_m, tiles_n;
   int xgc;             // persistent NT kernels: column groups of the XCD-aware tile walk (tile_mn below); 0 / 1 = row-major
@@ -609,7 +610,7 @@ __device__ __forceinline__ void epilogue_staged_bf16(const MfmaArgs& g, float* s
 // ring and the main loop only ever see those) and a dead list, whose C tiles it writes as zeros before the ring starts.
 #define NT_LIVE_MAX 120
 #define NT_LIVE_BYTES (4 * (2 * NT_LIVE_MAX + 2))
-template <int TBM, int TBN, bool C16, int NTHREADS, int CM = 1>      // CM = 2: the gated dgrad form, whose C tile is 2 x TBN columns wide
+template <int TBM, int TBN, bool C16, int NTHREADS, int EPI = EPI_PLAIN>      // EPI: the kernel's epilogue kind (which columns of C / pre_act a tile covers)
 __device__ __forceinline__ void nt_tile_lists(const MfmaArgs& g, int* list, int tlo, int thi, int nbx, int bx) {
   const int t = threadIdx.x, lane = t & 63;
   int* dead = list + 1 + NT_LIVE_MAX;        // list[0] / dead[0] = counts
@@ -641,15 +642,27 @@ __device__ __forceinline__ void nt_tile_lists(const MfmaArgs& g, int* list, int 
   }
   __syncthreads();
   const int nd = dead[0];
-  constexpr int EB = C16 ? 2 : 4, PER = 16 / EB, CPR = CM * TBN / PER;   // 16-byte chunks per tile row
+  // columns of C one tile covers: the gated data-gradient form writes 2 x TBN interleaved columns, the gated forward forms TBN / 2
+  constexpr bool GLU_F = EPI == EPI_GLU || EPI == EPI_GLU_SG, GLU_B = EPI == EPI_GLU_BWD;
+  constexpr int EB = C16 ? 2 : 4, PER = 16 / EB;
+  constexpr int CW = GLU_B ? 2 * TBN : GLU_F ? TBN / 2 : TBN, CPR = CW / PER;   // 16-byte chunks per tile row
+  const int cn = GLU_B ? 2 * g.N : GLU_F ? g.N / 2 : g.N;
   for (int i = 0; i < nd; ++i) {
     const int tt = dead[1 + i];
     int mt_, nt_;
     tile_mn(g, tt, mt_, nt_);
-    const int m0 = mt_ * TBM, n0 = nt_ * TBN * CM;
+    const int m0 = mt_ * TBM, n0 = nt_ * CW;
     for (int c = t; c < TBM * CPR; c += NTHREADS) {
       const int r = c / CPR, cc = (c % CPR) * PER;
-      if (n0 + cc < CM * g.N) *(uint4*)((char*)g.C + ((int64_t)(m0 + r) * g.ldc + n0 + cc) * EB) = make_uint4(0u, 0u, 0u, 0u);
+      if (n0 + cc < cn) *(uint4*)((char*)g.C + ((int64_t)(m0 + r) * g.ldc + n0 + cc) * EB) = make_uint4(0u, 0u, 0u, 0u);
+    }
+    if (g.dead_pre) {      // the forward forms that store a second tensor (pre-activations / backward factors: TBN columns per tile, N wide)
+      constexpr int PPR = TBN / PER;
+      const int64_t ldp = EPI == EPI_GLU_SG ? (int64_t)g.N : (int64_t)g.ldc;      // EPI_GLU_SG writes its factors densely (M x N)
+      for (int c = t; c < TBM * PPR; c += NTHREADS) {
+        const int r = c / PPR, cc = (c % PPR) * PER;
+        if (nt_ * TBN + cc < g.N) *(uint4*)((char*)g.pre_act + ((int64_t)(m0 + r) * ldp + nt_ * TBN + cc) * EB) = make_uint4(0u, 0u, 0u, 0u);
+      }
     }
   }
 }
@@ -687,7 +700,7 @@ __global__ __launch_bounds__(64 * NWM * NWN) void k_gemm_nt_pring(MfmaArgs g) {
   const int tpx = (ntiles + 7) >> 3;
   const int tlo = xcd * tpx, thi = min(ntiles, tlo + tpx);
   int* const tlist = (int*)(lds + g.live_off);
-  if (g.live_off) nt_tile_lists<TBM, TBN, C_BF16, 64 * NW, (EPI == EPI_GLU_BWD ? 2 : 1)>(g, tlist, tlo, thi, nbx, bx);
+  if (g.live_off) nt_tile_lists<TBM, TBN, C_BF16, 64 * NW, EPI>(g, tlist, tlo, thi, nbx, bx);
   auto tile_of = [&](int it) {
     if (g.live_off) return it < tlist[0] ? tlist[1 + it] : -1;
     const int tt = tlo + it * nbx + bx;
@@ -890,7 +903,7 @@ __global__ __launch_bounds__(64 * (8 + NL)) void k_gemm_nt_ws(MfmaArgs g) {
   const int tpx = (ntiles + 7) >> 3;
   const int tlo = xcd * tpx, thi = min(ntiles, tlo + tpx);
   int* const tlist = (int*)(lds + g.live_off);
-  if (g.live_off) nt_tile_lists<TBM, TBN, C_BF16, 64 * (NW + NL), (EPI == EPI_GLU_BWD ? 2 : 1)>(g, tlist, tlo, thi, nbx, bx);
+  if (g.live_off) nt_tile_lists<TBM, TBN, C_BF16, 64 * (NW + NL), EPI>(g, tlist, tlo, thi, nbx, bx);
   auto tile_of = [&](int it) {
     if (g.live_off) return it < tlist[0] ? tlist[1 + it] : -1;
     const int tt = tlo + it * nbx + bx;
@@ -1619,7 +1632,7 @@ int AFM_E16_FN(afm_gemm_mfma_try)(const afm_gemm_desc* d, hipStream_t st) {
   g.act = d->act; g.accumulate = d->accumulate;
   g.dd = afm_make_drop(&d->drop);
   g.tiles_m = (d->M + BM - 1) / BM; g.tiles_n = (d->N + BN - 1) / BN;
-  g.ksplit = 1; g.kchunk = d->K; g.bias_in_lds = 0; g.live_off = 0; g.xgc = 0;
+  g.ksplit = 1; g.kchunk = d->K; g.bias_in_lds = 0; g.live_off = 0; g.xgc = 0; g.dead_pre = 0;
   g.glu_f = d->glu_rows;
   g.stamps = nullptr;
 #ifdef AFM_GEMM_ABLATIONS
@@ -1628,9 +1641,17 @@ int AFM_E16_FN(afm_gemm_mfma_try)(const afm_gemm_desc* d, hipStream_t st) {
   if (!aligned16(d->A) || !aligned16(d->B) || (d->lda & 7) || (d->ldb & 7)) return AFM_ERR_UNSUPPORTED;
   if (!d->transA && d->transB) {  // NT
     if ((d->K & 7) || d->K < 32 || d->N < 16) return AFM_ERR_UNSUPPORTED;
-    // row hint (k_live): only where a zero row of A means a zero row of C, and C can be zero-filled in 16-byte pieces
-    if (d->bias || d->residual || d->accumulate || (d->act != AFM_ACT_NONE && d->act != AFM_ACT_MUL_SAVED && d->act != AFM_ACT_GLU_BWD) ||
-        (d->pre_act && d->act == AFM_ACT_NONE) || d->drop.p > 0.f || (d->N & 7) || (d->ldc & 7) || !aligned16(d->C) || (d->M & 63))
+    // row hint (k_live): only where a zero row of A means a zero row of C, and C can be zero-filled in 16-byte pieces ...
+    const bool fill16 = !((d->N & 7) || (d->ldc & 7) || !aligned16(d->C) || (d->M & 63));
+    if (d->reserved2 & 2) {
+      // ... or, in the FORWARD sense (reserved2 bit 1), wherever the caller does not care what the marked rows of C (and of a stored
+      // pre_act) hold: they are written as zeros, whatever bias / activation / dropout the epilogue applies to the others
+      if (d->residual || d->accumulate || !fill16 || (d->pre_act && (!aligned16(d->pre_act) || d->act == AFM_ACT_MUL_SAVED || d->act == AFM_ACT_GELU_BWD || d->act == AFM_ACT_GLU_BWD)))
+        g.k_live = nullptr;
+      else g.dead_pre = d->pre_act != nullptr;
+    }
+    else if (d->bias || d->residual || d->accumulate || (d->act != AFM_ACT_NONE && d->act != AFM_ACT_MUL_SAVED && d->act != AFM_ACT_GLU_BWD) ||
+        (d->pre_act && d->act == AFM_ACT_NONE) || d->drop.p > 0.f || !fill16)
       g.k_live = nullptr;
     if (d->bias && !aligned16(d->bias)) return AFM_ERR_UNSUPPORTED;
     if (!aligned16(d->C) || (d->residual && !aligned16(d->residual)) || (d->pre_act && !aligned16(d->pre_act)))

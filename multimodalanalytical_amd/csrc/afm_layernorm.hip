@@ -9,11 +9,13 @@
 
 #define LN_MAXV 32  // up to d = 2048 held in registers (template NV = ceil(d/64) rounded up)
 
+// `map` (afm_ln_shape.row_map, nullable): position p of a sample's concatenated sequence lives in row map[b * seg_stride + p] of its slot
 __device__ __forceinline__ int64_t ln_out_row(int64_t r, int64_t seg_len, int64_t seg_stride,
-                                              int64_t off) {
+                                              int64_t off, const int32_t* __restrict__ map = nullptr) {
   if (seg_len == 0) return r;
   const int64_t b = r / seg_len;
-  return b * seg_stride + off + (r - b * seg_len);
+  const int64_t p = b * seg_stride + off + (r - b * seg_len);
+  return map ? b * seg_stride + map[p] : p;
 }
 
 template <typename TY, int NV>
@@ -21,7 +23,8 @@ __global__ void k_ln_fwd(const float* x, const float* __restrict__ gamma,
                          const float* __restrict__ beta, const float* __restrict__ pos,
                          TY* __restrict__ y, float* __restrict__ mean, float* __restrict__ rstd,
                          int64_t rows, int d, int64_t seg_len, int64_t seg_stride, int64_t off,
-                         float eps, const void* __restrict__ add, int add_dtype, float* x_sum, DropDev adrop) {
+                         float eps, const void* __restrict__ add, int add_dtype, float* x_sum, DropDev adrop,
+                         const int32_t* __restrict__ map) {
   const int lane = threadIdx.x & 63;
   const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
@@ -56,7 +59,7 @@ __global__ void k_ln_fwd(const float* x, const float* __restrict__ gamma,
       if (mean) mean[r] = mu;
       if (rstd) rstd[r] = rs;
     }
-    const int64_t orow = ln_out_row(r, seg_len, seg_stride, off);
+    const int64_t orow = ln_out_row(r, seg_len, seg_stride, off, map);
     const int64_t prow = seg_len == 0 ? r : off + (r % seg_len);
     const float* pr = pos ? pos + prow * (int64_t)d : nullptr;
 #pragma unroll
@@ -135,7 +138,8 @@ __global__ __launch_bounds__(256) void k_ln_fwd_vec(const float* x, const float*
                                                     float* __restrict__ mean, float* __restrict__ rstd,
                                                     int64_t rows, int d, float eps, const TA* __restrict__ add,
                                                     float* x_sum, DropDev adrop, const float* __restrict__ pos,
-                                                    int64_t seg_len, int64_t seg_stride, int64_t off) {
+                                                    int64_t seg_len, int64_t seg_stride, int64_t off,
+                                                    const int32_t* __restrict__ map, const uint8_t* __restrict__ row_live) {
   const int lane = threadIdx.x & 63;
   const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
@@ -148,8 +152,12 @@ __global__ __launch_bounds__(256) void k_ln_fwd_vec(const float* x, const float*
   }
   // Two rows in flight per wave: row r + nwaves is requested before row r is reduced and stored (one row at a time left the kernel at
   // 4.5 TB/s of the ~6.3 a streaming kernel reaches: every wave spent a full memory latency per row with nothing outstanding).
+  // row_live (forward sense, identity row mapping): rows of all-padding blocks are neither loaded nor normalised -- zeros go to y, x_sum,
+  // mean and rstd; the flags run one iteration ahead of the loads, as in the backward kernel below
   F8 cx[NC], ca[NC];
-  auto load_row = [&](int64_t r, F8 (&vx)[NC], F8 (&va)[NC]) {
+  auto live_of = [&](int64_t r) -> bool { return !row_live || row_live[r >> 6] != 0; };
+  auto load_row = [&](int64_t r, F8 (&vx)[NC], F8 (&va)[NC], bool live) {
+    if (!live) return;
 #pragma unroll
     for (int i = 0; i < NC; ++i) {
       const int c = (lane + 64 * i) * 8;
@@ -159,10 +167,34 @@ __global__ __launch_bounds__(256) void k_ln_fwd_vec(const float* x, const float*
       }
     }
   };
-  if (wave < rows) load_row(wave, cx, ca);
+  bool lv_cur = wave < rows ? live_of(wave) : true;
+  bool lv_nxt = wave < rows ? live_of(wave + nwaves < rows ? wave + nwaves : wave) : true;
+  if (wave < rows) load_row(wave, cx, ca, lv_cur);
   for (int64_t r = wave; r < rows; r += nwaves) {
     F8 nx[NC], na[NC];
-    load_row(r + nwaves < rows ? r + nwaves : r, nx, na);      // (the last row of a wave is requested twice: no branch around the loads)
+    const int64_t rn = r + nwaves < rows ? r + nwaves : r;
+    const bool lv_nn = live_of(rn + nwaves < rows ? rn + nwaves : rn);
+    load_row(rn, nx, na, lv_nxt);      // (the last row of a wave is requested twice: no branch around the loads)
+    const bool dead = !lv_cur;
+    lv_cur = lv_nxt; lv_nxt = lv_nn;
+    if (dead) {
+      const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+      const F8 z = {z4, z4};
+#pragma unroll
+      for (int i = 0; i < NC; ++i) {
+        const int c = (lane + 64 * i) * 8;
+        if (c < d) {
+          if (add) st8s(x_sum + r * (int64_t)d + c, z);
+          st8s(y + r * (int64_t)(d * RowMul<TY>::v) + c, z, d);
+        }
+        cx[i] = nx[i]; ca[i] = na[i];
+      }
+      if (lane == 0) {
+        if (mean) mean[r] = 0.f;
+        if (rstd) rstd[r] = 0.f;
+      }
+      continue;
+    }
     F8 v[NC];
     float s = 0.f;
 #pragma unroll
@@ -204,7 +236,7 @@ __global__ __launch_bounds__(256) void k_ln_fwd_vec(const float* x, const float*
       if (rstd) rstd[r] = rs;
     }
     // the embedder's form: row r of modality rows lands in row orow of the concatenated sequence, plus its positional row
-    const int64_t orow = ln_out_row(r, seg_len, seg_stride, off);
+    const int64_t orow = ln_out_row(r, seg_len, seg_stride, off, map);
     const float* pr = pos ? pos + (seg_len == 0 ? r : off + (r % seg_len)) * (int64_t)d : nullptr;
 #pragma unroll
     for (int i = 0; i < NC; ++i) {
@@ -226,7 +258,7 @@ __global__ __launch_bounds__(256) void k_ln_bwd_vec(const TY* __restrict__ dy, c
                                                     const float* __restrict__ dres, float* __restrict__ dx,
                                                     float* __restrict__ dgamma, float* __restrict__ dbeta, int64_t rows, int d,
                                                     TY* __restrict__ dx_drop, DropDev dd, int64_t seg_len, int64_t seg_stride,
-                                                    int64_t off, const uint8_t* __restrict__ row_live) {
+                                                    int64_t off, const uint8_t* __restrict__ row_live, const int32_t* __restrict__ map) {
   extern __shared__ __attribute__((aligned(16))) float sm[];  // [4 waves][2][d]
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -251,11 +283,12 @@ __global__ __launch_bounds__(256) void k_ln_bwd_vec(const TY* __restrict__ dy, c
   auto load_row = [&](int64_t r, RowIn& in, bool live) {
     if (!live) return;
     in.mu = mean[r]; in.rs = rstd[r];
+    const int64_t dyrow = ln_out_row(r, seg_len, seg_stride, off, map);
 #pragma unroll
     for (int i = 0; i < NC; ++i) {
       const int c = (lane + 64 * i) * 8;
       if (c < d) {
-        in.dy[i] = ld8(dy + ln_out_row(r, seg_len, seg_stride, off) * (int64_t)(d * RowMul<TY>::v) + c, d);
+        in.dy[i] = ld8(dy + dyrow * (int64_t)(d * RowMul<TY>::v) + c, d);
         in.x[i] = ld8(x + r * (int64_t)d + c);
         if (dres) in.dr[i] = ld8(dres + r * (int64_t)d + c);
       }
@@ -358,14 +391,17 @@ extern "C" int afm_layernorm_fwd(const afm_ln_shape* s, const float* x, const fl
   if (g > fwd_cap) g = fwd_cap;
   hipStream_t st = (hipStream_t)stream;
   if (s->y_dtype < AFM_F32 || s->y_dtype > AFM_F16) return AFM_ERR_ARG;
+  const int32_t* map = s->seg_len != 0 ? s->row_map : nullptr;                                         // (a row map belongs to the embedder's placement form)
+  const uint8_t* live = (s->seg_len == 0 && (s->rows & 63) == 0) ? s->row_live : nullptr;            // (a hint: only the vectorised kernel takes it)
   if ((s->d % 8) == 0 && s->d <= 2048 && s->rows >= 64 && (!pos || ((uintptr_t)pos & 15) == 0)) {   // vectorised path
     // The grid is what is RESIDENT at once (every wave strides over the rows): five workgroups per CU at d <= 512 (92 registers), three
     // at d <= 1024 (148), one beyond (268).  Until round 5 the 1 280 blocks of the d <= 512 kernel were launched for every d: at d = 768
     // (c4) that is 1.67 rounds of equal-length blocks on 768 slots -- the kernels ran at 4.6 TB/s there against 5.3 at d = 512.
-    if (!getenv("AFM_LN_FWD_BLOCKS")) g = std::min<int64_t>((s->rows + 3) / 4, 256 * (s->d <= 512 ? 5 : s->d <= 1024 ? 3 : 1));
+    static const bool fwd_forced = getenv("AFM_LN_FWD_BLOCKS") != nullptr;
+    if (!fwd_forced) g = std::min<int64_t>((s->rows + 3) / 4, 256 * (s->d <= 512 ? 5 : s->d <= 1024 ? 3 : 1));
 #define LN_FV(TY, TA, NC) AFM_LAUNCH((k_ln_fwd_vec<TY, TA, NC>), dim3((int)g), dim3(256), 0, st, x, gamma, beta, (TY*)y, mean, \
                                      rstd, s->rows, s->d, s->eps, (const TA*)add, x_sum, adrop, pos, s->seg_len,   \
-                                     s->out_seg_stride, s->out_off)
+                                     s->out_seg_stride, s->out_off, map, live)
 #define LN_FV2(TY, TA) do { if (s->d <= 512) LN_FV(TY, TA, 1); else if (s->d <= 1024) LN_FV(TY, TA, 2); else LN_FV(TY, TA, 4); } while (0)
     // the branch added in front of the norm has the dtype of the mode's activations or fp32
     if (s->y_dtype == AFM_BF16) { if (add_dtype == AFM_BF16) LN_FV2(bf16, bf16); else if (add_dtype == AFM_F32) LN_FV2(bf16, float); else return AFM_ERR_UNSUPPORTED; }
@@ -380,7 +416,7 @@ extern "C" int afm_layernorm_fwd(const afm_ln_shape* s, const float* x, const fl
   do {                                                                                              \
     AFM_DT_SWITCH(s->y_dtype, TY, AFM_LAUNCH((k_ln_fwd<TY, NV>), dim3((int)g), dim3(256), 0, st, x, gamma, beta, pos, \
                          (TY*)y, mean, rstd, s->rows, s->d, s->seg_len, s->out_seg_stride,       \
-                         s->out_off, s->eps, add, add_dtype, x_sum, adrop));                            \
+                         s->out_off, s->eps, add, add_dtype, x_sum, adrop, map));                            \
   } while (0)
   const int nv = (s->d + 63) / 64;
   if (nv <= 1) LN_FWD(1); else if (nv <= 2) LN_FWD(2); else if (nv <= 4) LN_FWD(4);
@@ -411,7 +447,7 @@ __global__ void k_ln_bwd(const TY* __restrict__ dy, const float* __restrict__ x,
                          const float* __restrict__ rstd, const float* __restrict__ dres,
                          float* __restrict__ dx, float* __restrict__ partial, int64_t rows, int d,
                          int64_t seg_len, int64_t seg_stride, int64_t off, TY* __restrict__ dx_drop,
-                         DropDev dd) {
+                         DropDev dd, const int32_t* __restrict__ map) {
   extern __shared__ __attribute__((aligned(16))) float sm[];  // [4 waves][2][d]
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -427,7 +463,7 @@ __global__ void k_ln_bwd(const TY* __restrict__ dy, const float* __restrict__ x,
   for (int64_t r = wave; r < rows; r += nwaves) {
     const float mu = mean[r], rs = rstd[r];
     const float* xr = x + r * (int64_t)d;
-    const int64_t dyrow = ln_out_row(r, seg_len, seg_stride, off);
+    const int64_t dyrow = ln_out_row(r, seg_len, seg_stride, off, map);
     float xh[NV], g[NV];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -507,16 +543,17 @@ extern "C" int afm_layernorm_bwd(const afm_ln_shape* s, const void* dy, const fl
   if (!partial && !ln_bwd_vectorised(s)) return AFM_ERR_ARG;      // (afm_layernorm_bwd_ws_floats says which shapes need it)
   if (s->d > 64 * LN_MAXV) return AFM_ERR_UNSUPPORTED;
   if (s->rows == 0) return AFM_OK;
-  const int g0 = ln_bwd_blocks(s->rows), g = g0;
+  const int g = ln_bwd_blocks(s->rows);
   hipStream_t st = (hipStream_t)stream;
   const size_t shm = sizeof(float) * 8 * s->d;
   if (s->y_dtype < AFM_F32 || s->y_dtype > AFM_F16) return AFM_ERR_ARG;
   if (ln_bwd_vectorised(s)) {   // vectorised path (dy rows follow the embedder's placement, if any)
     // resident workgroups only, as in the forward: three per CU at d <= 512 (136 registers), two at d <= 1024 (229), one beyond (438)
-    const int g = getenv("AFM_LN_BWD_BLOCKS") ? g0 : (int)std::min<int64_t>((s->rows + 3) / 4, 256 * (s->d <= 512 ? 3 : s->d <= 1024 ? 2 : 1));
-#define LN_BV(TY, NC) AFM_LAUNCH((k_ln_bwd_vec<TY, NC>), dim3(g), dim3(256), shm, st, (const TY*)dy, x, gamma, mean, rstd, dres, dx, \
+    static const bool bwd_forced = getenv("AFM_LN_BWD_BLOCKS") != nullptr;
+    const int gv = bwd_forced ? g : (int)std::min<int64_t>((s->rows + 3) / 4, 256 * (s->d <= 512 ? 3 : s->d <= 1024 ? 2 : 1));
+#define LN_BV(TY, NC) AFM_LAUNCH((k_ln_bwd_vec<TY, NC>), dim3(gv), dim3(256), shm, st, (const TY*)dy, x, gamma, mean, rstd, dres, dx, \
                                  dgamma, dbeta, s->rows, s->d, (TY*)dx_drop, dd, s->seg_len, s->out_seg_stride, s->out_off,   \
-                                 (s->seg_len == 0 && (s->rows & 63) == 0) ? s->row_live : nullptr)
+                                 (s->seg_len == 0 && (s->rows & 63) == 0) ? s->row_live : nullptr, s->seg_len != 0 ? s->row_map : nullptr)
 #define LN_BV2(TY) do { if (s->d <= 512) LN_BV(TY, 1); else if (s->d <= 1024) LN_BV(TY, 2); else LN_BV(TY, 4); } while (0)
     if (s->y_dtype == AFM_BF16) LN_BV2(bf16); else if (s->y_dtype == AFM_BF16X2) LN_BV2(x2); else if (s->y_dtype == AFM_F16) LN_BV2(f16); else LN_BV2(float);
 #undef LN_BV2
@@ -527,7 +564,7 @@ extern "C" int afm_layernorm_bwd(const afm_ln_shape* s, const void* dy, const fl
   do {                                                                                               \
     AFM_DT_SWITCH(s->y_dtype, TY, AFM_LAUNCH((k_ln_bwd<TY, NV>), dim3(g), dim3(256), shm, st, (const TY*)dy, x,     \
                          gamma, mean, rstd, dres, dx, partial, s->rows, s->d, s->seg_len,            \
-                         s->out_seg_stride, s->out_off, (TY*)dx_drop, dd));                                             \
+                         s->out_seg_stride, s->out_off, (TY*)dx_drop, dd, s->seg_len != 0 ? s->row_map : nullptr));                  \
   } while (0)
   const int nv = (s->d + 63) / 64;
   if (nv <= 1) LN_BWD(1); else if (nv <= 2) LN_BWD(2); else if (nv <= 4) LN_BWD(4);

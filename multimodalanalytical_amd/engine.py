@@ -135,6 +135,15 @@ class Seq2SeqEngine:
         self.bits_stream = (torch.cuda.Stream(device=self.dev)
                             if self.dev.type == "cuda" and os.environ.get("AFM_BITS_AHEAD", "0") == "1" else None)
         self._wg_pending = []
+        # Padded positions out of the FORWARD pass of a training step (round 6; include/afm_hip.h ABI 6): the live encoder positions of every
+        # sample are moved to the front of its S-row slot at the embedder (afm_compact_plan; AFM_FWD_COMPACT=0: flags only, rows stay
+        # where the collator put them) and the encoder-row kernels of the forward -- LayerNorm, the NT GEMMs with their fused
+        # epilogues, the self-attention's query blocks -- leave 256-row groups of nothing but padding uncomputed (zeros written).
+        # Only with backward pending: eval / generate return the reference's encoder_hidden_states rows.  AFM_FWD_ROW_SKIP=0: off.
+        self.fwd_skip = os.environ.get("AFM_FWD_ROW_SKIP", "1") != "0"
+        self.fwd_compact = os.environ.get("AFM_FWD_COMPACT", "1") != "0"
+        self._fwd_live = {}   # forward of a training step: role -> uint8 per 64-row block, 0 = its whole 256-row group is padding (encode)
+        self._frole = None    # whose rows the forward is working on (set by encode around the encoder stack)
         self._live = {}       # backward only: role ("enc" / "dec") -> uint8 per 64-row block, 0 = nothing but padded positions (_backward)
         self._role = None     # whose rows the backward is working on: set by _backward around the layer stacks (None: no hints)
         self.refresh_shadows()
@@ -302,8 +311,17 @@ class Seq2SeqEngine:
         """Operand of a backward kernel: in mixed mode the hi plane of a pair tensor."""
         return t.hi if (self.mixed and isinstance(t, X2)) else t
 
+    def _fwd_hint(self, t, role=None):
+        """Forward-sense padded-row hint for an operand with the role's rows (None outside a training step's forward): one byte per
+        64-row block, 0 = the block's whole 256-row group is padding, nobody reads its rows of any activation."""
+        role = role or self._frole
+        h = self._fwd_live.get(role) if role is not None else None
+        if h is not None and h.numel() * 64 != t.shape[0]:
+            h = None
+        return h
+
     def _linear(self, x, name, rows, cols, r0=0, r1=None, out=None, out_dtype=None, bias_name=None,
-                residual=None, dropout=ops.NO_DROP, act=ACT_NONE, pre_act=None, sg_hi_only=False):
+                residual=None, dropout=ops.NO_DROP, act=ACT_NONE, pre_act=None, sg_hi_only=False, role=None):
         w = self.W(name, rows, cols, r0, r1)
         n = w.shape[0]
         if out is None:
@@ -311,8 +329,9 @@ class Seq2SeqEngine:
         bias = None
         if bias_name is not None:
             bias = self.ps.vec_span(self.ps.flat, bias_name, r0, r0 + n)
+        unread = self._fwd_hint(x, role) if (self.single16 and residual is None) else None
         return ops.gemm(x, w, out, trans_b=True, bias=bias, residual=residual, dropout=dropout, act=act,
-                        pre_act=pre_act, algo=self.algo, sg_hi_only=sg_hi_only)
+                        pre_act=pre_act, algo=self.algo, sg_hi_only=sg_hi_only, rows_unread=unread)
 
     def _dgrad(self, dy, name, rows, cols, r0=0, r1=None, out=None, out_dtype=None, accumulate=False,
                act=ACT_NONE, pre_act=None, dropout=ops.NO_DROP, role=None):
@@ -388,8 +407,9 @@ class Seq2SeqEngine:
             saved["pe_stats"] = (mean, rstd)
         return pe
 
-    def embed_fwd(self, inputs: Dict[str, Any], saved: Optional[dict]) -> torch.Tensor:
-        """MultimodalEmbedding.forward (modeling/utils.py:142-182) -> (B*S, d) fp32."""
+    def embed_fwd(self, inputs: Dict[str, Any], saved: Optional[dict], row_map: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """MultimodalEmbedding.forward (modeling/utils.py:142-182) -> (B*S, d) fp32.  `row_map` (B*S int32, ops.compact_plan): position p of
+        sample b is written to row b*S + row_map[b*S + p] -- its positional row stays pos[p]."""
         lens = []
         for m, x in inputs.items():
             t = x["tokenized_input"] if isinstance(x, dict) else x
@@ -397,6 +417,9 @@ class Seq2SeqEngine:
             B = int(t.shape[0])
         S = sum(lens)
         x_out = torch.empty(B * S, self.d, dtype=torch.float32, device=self.dev)
+        x_dst = x_out
+        if row_map is not None and not self.norm:      # no LayerNorm to move the rows on the way: placed as collated, then permuted
+            x_dst = torch.empty_like(x_out)
         pe = self._pos_rows(S, saved)
         off = 0
         mods = []
@@ -433,18 +456,26 @@ class Seq2SeqEngine:
                 rstd = torch.empty(B * Sm, dtype=torch.float32, device=self.dev)
                 ops.layernorm_fwd(e, self.ps.p(f"embedding.embedding_norm_dict.{m}.weight"),
                                   self.ps.p(f"embedding.embedding_norm_dict.{m}.bias"), x_out, mean, rstd,
-                                  pos=pe, seg_len=Sm, out_seg_stride=S, out_off=off)
+                                  pos=pe, seg_len=Sm, out_seg_stride=S, out_off=off, row_map=row_map)
                 rec.update(e=e, mean=mean, rstd=rstd)
             else:
-                ops.place_rows(e, x_out, pos=pe, seg_len=Sm, out_seg_stride=S, out_off=off)
+                ops.place_rows(e, x_dst, pos=pe, seg_len=Sm, out_seg_stride=S, out_off=off)
             mods.append(rec)
             off += Sm
+        if x_dst is not x_out:
+            ops.permute_rows(x_dst, x_out, row_map, B, S)
         if saved is not None:
-            saved.update(mods=mods, B=B, S=S)
+            saved.update(mods=mods, B=B, S=S, row_map=row_map)
         return x_out
 
     def embed_bwd(self, dx: torch.Tensor, saved: dict) -> None:
         B, S, d = saved["B"], saved["S"], self.d
+        row_map = saved.get("row_map")
+        if row_map is not None and (self.pos_enc is None or not self.norm):
+            # the batch sum of the learned positional table and the un-normed placement read dx position by position: back to the
+            # collated order first (one pass); the per-modality LayerNorm backward otherwise reads dx through the map itself
+            dx = ops.permute_rows(dx, torch.empty_like(dx), row_map, B, S, gather=True)
+            row_map = None
         if self.pos_enc is None:  # learned table: d pe = sum over the batch, through its LayerNorm
             dpe = torch.empty(S, d, dtype=torch.float32, device=self.dev)
             ops.batch_sum(dx, dpe, B, S, d, accumulate=False)
@@ -467,7 +498,7 @@ class Seq2SeqEngine:
                                   rec["mean"], rec["rstd"], de,
                                   self.ps.g(f"embedding.embedding_norm_dict.{m}.weight"),
                                   self.ps.g(f"embedding.embedding_norm_dict.{m}.bias"), ws,
-                                  seg_len=Sm, out_seg_stride=S, out_off=off)
+                                  seg_len=Sm, out_seg_stride=S, out_off=off, row_map=row_map)
             else:
                 ops.place_rows(dx, de, seg_len=Sm, out_seg_stride=S, out_off=off, gather=True)
             p = f"embedding.embedding_layer_dict.{m}."
@@ -502,10 +533,10 @@ class Seq2SeqEngine:
             br, br_drop = pend if isinstance(pend, tuple) else (pend, ops.NO_DROP)
             xs = torch.empty_like(x)   # x itself is the saved input of an earlier LayerNorm: keep it
             ops.layernorm_fwd(x, self.ps.p(prefix + "weight"), self.ps.p(prefix + "bias"), y, mean, rstd,
-                              add=br, x_sum=xs, add_dropout=br_drop)
+                              add=br, x_sum=xs, add_dropout=br_drop, row_live=self._fwd_hint(x))
             x = xs
         else:
-            ops.layernorm_fwd(x, self.ps.p(prefix + "weight"), self.ps.p(prefix + "bias"), y, mean, rstd)
+            ops.layernorm_fwd(x, self.ps.p(prefix + "weight"), self.ps.p(prefix + "bias"), y, mean, rstd, row_live=self._fwd_hint(x))
         if saved is not None:
             saved[key] = (x, mean, rstd)
         return y, x
@@ -583,7 +614,10 @@ class Seq2SeqEngine:
         shp = ops.attn_shape(B, H, T, T, d // H, self.cd, lq, lq, lq, la, key_pad, causal,
                              self._drop(site + "attn"), self.algo)
         self._attach_drop_bits(shp, saved, ahead)
+        if not causal and key_pad is not None and self._fwd_hint(h) is not None:
+            shp.reserved |= 64      # encoder, training step: padded query rows are read by nobody (afm_attn_fwd: O = 0, lse = +inf there)
         ops.attn_fwd(shp, qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], a, lse)
+        shp.reserved &= ~64         # (the backward sets its own sense of the bit)
         br = self._linear(a, p + "self_attn.out_proj.weight", d, d, bias_name=p + "self_attn.out_proj.bias",
                           out_dtype=self.branch_dtype)
         if saved is not None:
@@ -639,7 +673,7 @@ class Seq2SeqEngine:
             ops.gemm(h, self.w_glu[p + "linear1.weight"], g, trans_b=True,
                      bias=self.ps.vec_span(self.ps.flat, p + "linear1.bias", 0, 2 * f),
                      act=ACT_GLU_SAVE if saved is not None else ACT_GLU, pre_act=uv, dropout=dr, algo=self.algo, glu_rows=f,
-                     sg_hi_only=self.mixed)
+                     sg_hi_only=self.mixed, rows_unread=self._fwd_hint(h) if self.single16 else None)
             dr = (dr, "glu")
         elif self.gated:
             uv = self._linear(h, p + "linear1.weight", k * f, d, bias_name=p + "linear1.bias")
@@ -711,7 +745,7 @@ class Seq2SeqEngine:
             h, x = self._ln_fwd(x, p + "norm2.", saved, "ln2", pend=pend)
         w, bname = p + "multihead_attn.in_proj_weight", p + "multihead_attn.in_proj_bias"
         q = self._linear(h, w, 3 * d, d, 0, d, bias_name=bname)
-        kv = self._linear(mem, w, 3 * d, d, d, 3 * d, bias_name=bname)
+        kv = self._linear(mem, w, 3 * d, d, d, 3 * d, bias_name=bname, role="enc")      # memory-side rows: encoder positions
         a = self._empty(B * T, d)
         lse = torch.empty(B * H * T, dtype=torch.float32, device=self.dev)
         shp = ops.attn_shape(B, H, T, S, d // H, self.cd, ops._ld(q), ops._ld(kv), ops._ld(kv), ops._ld(a), mem_pad, False,
@@ -780,16 +814,28 @@ class Seq2SeqEngine:
         (embedded here, on the engine's schedule) or an already embedded (B, S, d) tensor, as the reference's
         `inputs_embeds` (custom_modeling.py:420-445): forward / generate only, its producer is outside this engine."""
         B, S = attention_mask.shape
+        self._fwd_live, self._frole = {}, None
         if torch.is_tensor(enc_inputs):
             if saved is not None:
                 raise ValueError("a backward pass through externally embedded inputs is not available: pass the modality dict")
             if tuple(enc_inputs.shape) != (B, S, self.d):
                 raise ValueError(f"inputs_embeds must be (B, S, d) = {(B, S, self.d)}, got {tuple(enc_inputs.shape)}")
             x = enc_inputs.to(device=self.dev, dtype=torch.float32).reshape(B * S, self.d).contiguous()
+            key_pad = (attention_mask == 0).to(torch.uint8).contiguous()
         else:
-            x = self.embed_fwd(enc_inputs, None if saved is None else saved.setdefault("emb_enc", {}))
+            key_pad = (attention_mask == 0).to(torch.uint8).contiguous()
+            plan = None
+            if saved is not None and self.fwd_skip and self.single16 and S % 256 == 0:
+                # a training step: live positions to the front of every sample's slot, 256-row groups of nothing but padding left out
+                # of the encoder-row kernels below (and of the decoder's memory-side projections)
+                plan = ops.compact_plan(key_pad, B, S, 256, compact=self.fwd_compact)
+                key_pad = plan.pad.view(B, S)
+                self._fwd_live["enc"] = plan.live_tile
+                saved["plan"] = plan
+            x = self.embed_fwd(enc_inputs, None if saved is None else saved.setdefault("emb_enc", {}),
+                               row_map=plan.dest if (plan is not None and plan.compact) else None)
         assert x.shape[0] == B * S, "attention_mask does not match the concatenated modalities"
-        key_pad = (attention_mask == 0).to(torch.uint8).contiguous()
+        self._frole = "enc" if "enc" in self._fwd_live else None
         H = self.cfg["encoder_attention_heads"]
         layers, pend = [], None
         h = None if self.pre_ln else self._operand(x)
@@ -806,6 +852,7 @@ class Seq2SeqEngine:
                 x, h = self._post_norm(x, br, p + "norm2.", sv, "lnf")
             layers.append(sv)
         mem, _ = self._ln_fwd(x, "encoder.norm.", saved, "enc_norm", pend=pend)
+        self._frole = None
         if saved is not None:
             saved.update(enc_layers=layers, key_pad=key_pad, B=B, S=S)
         return mem, key_pad
@@ -1064,6 +1111,7 @@ class Seq2SeqEngine:
         saved = {} if backward else None
         B, T = dec_ids.shape
         dec_ids = dec_ids.contiguous()
+        self._fwd_live, self._frole = {}, None
         if memory is None:
             mem, mem_pad = self.encode(enc_inputs, attention_mask, saved)
         else:
@@ -1076,9 +1124,14 @@ class Seq2SeqEngine:
             if backward:
                 saved["dmem_init"] = dmem0
         logits = self.decode(dec_ids, mem, mem_pad, dec_attention_mask, S, saved)
+        self._fwd_live = {}
         # (split-pair memory stays a 2-D X2 object: .float() / .cpu() materialise it on demand)
         out = {"logits": logits.view(B, T, self.V),
                "encoder_hidden_states": mem if isinstance(mem, X2) else mem.view(B, S, self.d)}
+        if saved is not None and saved.get("plan") is not None:
+            # a training step with the padded rows out of the forward: position s of sample b is row encoder_row_map[b, s] of
+            # encoder_hidden_states, and rows of nothing but padding hold zeros (AFM_FWD_ROW_SKIP=0: the reference's layout)
+            out["encoder_row_map"] = saved["plan"].dest.view(B, S)
         rows = B * T
         if labels is not None or backward:
             lab = labels.contiguous().view(-1)
@@ -1193,7 +1246,9 @@ class Seq2SeqEngine:
             if tgt_pad is not None:      # a padded decoder row is dead only if it has no label either (the caller's labels are its own)
                 tgt_pad = tgt_pad.view(B, T).bool() & (lab.view(B, T) == -100)
             for role, L, pad in (("enc", S, saved.get("key_pad")), ("dec", T, tgt_pad)):
-                if pad is not None and L % 64 == 0:
+                if role == "enc" and saved.get("plan") is not None:
+                    self._live[role] = saved["plan"].live64      # (afm_compact_plan already made the flags)
+                elif pad is not None and L % 64 == 0:
                     self._live[role] = (pad.view(B, L // 64, 64) == 0).any(-1).to(torch.uint8).reshape(-1).contiguous()
         self._role = "dec"             # head, final decoder norm and the decoder stack: B * T rows
         dlog = self._empty_b(B * T, self.V)

@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libafm_hip.so")
 
 AFM_F32, AFM_BF16, AFM_BF16X2, AFM_F16 = 0, 1, 2, 3
-ABI_VERSION = 5
+ABI_VERSION = 6
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_GELU_BWD, ACT_GELU_SAVE_GRAD, ACT_MUL_SAVED = 0, 1, 2, 3, 4, 5
 ACT_GLU, ACT_GLU_SAVE, ACT_GLU_BWD = 6, 7, 8
 ALGO_AUTO, ALGO_GENERIC, ALGO_MFMA = 0, 1, 2
@@ -55,7 +55,7 @@ class LnShape(C.Structure):
         ("rows", C.c_int64), ("d", C.c_int32), ("y_dtype", C.c_int32),
         ("seg_len", C.c_int64), ("out_seg_stride", C.c_int64), ("out_off", C.c_int64),
         ("eps", C.c_float), ("add_dtype", C.c_int32), ("add_drop", Dropout),
-        ("row_live", C.c_void_p),
+        ("row_live", C.c_void_p), ("row_map", C.c_void_p),
     ]
 
 
@@ -135,6 +135,8 @@ _SIGS = {
     "afm_adam_step": (C.c_int, [_P, _P, _P, _P, _I64, _P, _P, _P, _I32, _I32, _P, _P]),
     "afm_scaler_update": (C.c_int, [_P, _P, _F, _F, _I32, _P]),
     "afm_place_rows": (C.c_int, [_P, _P, _P, _I64, _I32, _I64, _I64, _I64, _I32, _P]),
+    "afm_compact_plan": (C.c_int, [_P, _I32, _I32, _I32, _I32, _P, _P, _P, _P, _P, _P]),
+    "afm_permute_rows": (C.c_int, [_P, _P, _P, _I32, _I32, _I32, _I32, _P]),
     "afm_comm_unique_id": (C.c_int, [_P]),
     "afm_comm_create": (C.c_int, [C.POINTER(_P), _P, _I32, _I32]),
     "afm_allreduce_bucket": (C.c_int, [_P, _P, _I64, _P]),

@@ -142,6 +142,6 @@ class CustomModel:
         loss_dict = None if loss is None else out.get("loss_dict", {"model_only_loss": loss, "alignment_loss": None})
         return CustomLMOutput(loss=loss, logits=out["logits"], decoder_hidden_states=None,
                               encoder_hidden_states=out["encoder_hidden_states"], loss_dict=loss_dict,
-                              argmax=out.get("argmax"))
+                              argmax=out.get("argmax"), encoder_row_map=out.get("encoder_row_map"))
 
     __call__ = forward

@@ -101,7 +101,8 @@ def gemm_desc(a: torch.Tensor, b: torch.Tensor, c: torch.Tensor, *, trans_a=Fals
               bias: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
               pre_act: Optional[torch.Tensor] = None, act: int = ACT_NONE, accumulate: bool = False,
               dropout: Dropout = NO_DROP, algo: int = ALGO_AUTO, a_colsum: Optional[torch.Tensor] = None,
-              variant: int = 0, glu_rows: int = 0, sg_hi_only: bool = False, k_live: Optional[torch.Tensor] = None) -> GemmDesc:
+              variant: int = 0, glu_rows: int = 0, sg_hi_only: bool = False, k_live: Optional[torch.Tensor] = None,
+              rows_unread: Optional[torch.Tensor] = None) -> GemmDesc:
     """The afm_gemm_desc of c = epilogue(op(a) @ op(b)) (arguments as `gemm`); the caller keeps the tensors alive until launch."""
     M, N = c.shape
     if act in (L.ACT_GLU, L.ACT_GLU_SAVE):
@@ -147,6 +148,11 @@ def gemm_desc(a: torch.Tensor, b: torch.Tensor, c: torch.Tensor, *, trans_a=Fals
         assert (trans_a or trans_b) and k_live.dtype == torch.uint8 and k_live.is_contiguous()
         assert nrows % 64 == 0 and k_live.numel() == nrows // 64
     d.k_live = _ptr(k_live)
+    if rows_unread is not None:     # k_live in the FORWARD sense: blocks of 64 output rows nobody reads (0) are written as zeros, not computed
+        assert k_live is None and not trans_a and trans_b and rows_unread.dtype == torch.uint8 and rows_unread.is_contiguous()
+        assert M % 64 == 0 and rows_unread.numel() == M // 64
+        d.k_live = _ptr(rows_unread)
+        d.reserved2 |= 2
     return d
 
 
@@ -196,11 +202,19 @@ def ln_shape(rows, d, y_dtype, seg_len=0, out_seg_stride=0, out_off=0, eps=1e-5)
 
 
 def layernorm_fwd(x, gamma, beta, y, mean=None, rstd=None, pos=None, seg_len=0, out_seg_stride=0,
-                  out_off=0, eps=1e-5, add=None, x_sum=None, add_dropout: Dropout = NO_DROP):
-    """y = LN(x [+ dropout(add)]); with `add` the summed stream is also written to x_sum (fp32, may be x)."""
+                  out_off=0, eps=1e-5, add=None, x_sum=None, add_dropout: Dropout = NO_DROP, row_live=None, row_map=None):
+    """y = LN(x [+ dropout(add)]); with `add` the summed stream is also written to x_sum (fp32, may be x).
+    row_live (identity row mapping): one byte per 64 rows, 0 = nobody reads those rows of the outputs (zeros written, nothing loaded).
+    row_map (placement form): int32 per position of the concatenated sequence, its row inside the sample's slot (afm_compact_plan)."""
     rows, d = x.shape
     assert x.dtype == torch.float32 and x.is_contiguous() and is_contig(y)
     s = ln_shape(rows, d, y.dtype, seg_len, out_seg_stride, out_off, eps)
+    if row_live is not None:
+        assert row_live.dtype == torch.uint8 and row_live.is_contiguous() and rows % 64 == 0 and row_live.numel() == rows // 64 and seg_len == 0
+        s.row_live = _ptr(row_live)
+    if row_map is not None:
+        assert row_map.dtype == torch.int32 and row_map.is_contiguous() and seg_len > 0 and row_map.numel() == (rows // seg_len) * out_seg_stride
+        s.row_map = _ptr(row_map)
     if add is not None:
         assert add.shape == x.shape and is_contig(add) and x_sum is not None and x_sum.dtype == torch.float32
         s.add_dtype = _dt(add)
@@ -217,9 +231,12 @@ def layernorm_bwd_ws(rows, d) -> int:
 
 
 def layernorm_bwd(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, ws, dres=None, seg_len=0,
-                  out_seg_stride=0, out_off=0, dx_drop=None, dropout: Dropout = NO_DROP, row_live=None):
+                  out_seg_stride=0, out_off=0, dx_drop=None, dropout: Dropout = NO_DROP, row_live=None, row_map=None):
     rows, d = x.shape
     s = ln_shape(rows, d, dy.dtype, seg_len, out_seg_stride, out_off)
+    if row_map is not None:      # the embedder's placement through afm_compact_plan's map (as layernorm_fwd)
+        assert row_map.dtype == torch.int32 and row_map.is_contiguous() and seg_len > 0 and row_map.numel() == (rows // seg_len) * out_seg_stride
+        s.row_map = _ptr(row_map)
     if row_live is not None:     # one byte per 64 rows, 0 = dy (and dres) are zero there: skipped, zeros written
         assert row_live.dtype == torch.uint8 and row_live.is_contiguous() and rows % 64 == 0 and row_live.numel() == rows // 64
         assert seg_len == 0
@@ -240,6 +257,36 @@ def place_rows(x, y, pos=None, seg_len=0, out_seg_stride=0, out_off=0, gather=Fa
     rows, d = (y.shape if gather else x.shape)
     L.check(L.load().afm_place_rows(_ptr(x), _ptr(pos), _ptr(y), rows, d, int(seg_len), int(out_seg_stride), int(out_off),
                                     int(gather), _stream()), "afm_place_rows")
+    return y
+
+
+class CompactPlan:
+    """afm_compact_plan's outputs for a (B, S) key-padding mask: `dest` (B*S int32: new position of every position), `pad` (B, S uint8,
+    the mask in the new order), `live64` / `live_tile` (B*S/64 uint8: exact 64-row blocks / whole `tile_rows` groups holding a live
+    position), `n_live` (B int32)."""
+    __slots__ = ("dest", "pad", "live64", "live_tile", "n_live", "compact", "B", "S")
+
+
+def compact_plan(key_pad, B, S, tile_rows=256, compact=True) -> CompactPlan:
+    assert key_pad.dtype == torch.uint8 and key_pad.is_contiguous() and key_pad.numel() == B * S and S % tile_rows == 0
+    dev = key_pad.device
+    p = CompactPlan()
+    p.B, p.S, p.compact = B, S, bool(compact)
+    p.dest = torch.empty(B * S, dtype=torch.int32, device=dev)
+    p.pad = torch.empty(B, S, dtype=torch.uint8, device=dev)
+    p.live64 = torch.empty(B * S // 64, dtype=torch.uint8, device=dev)
+    p.live_tile = torch.empty(B * S // 64, dtype=torch.uint8, device=dev)
+    p.n_live = torch.empty(B, dtype=torch.int32, device=dev)
+    L.check(L.load().afm_compact_plan(_ptr(key_pad), B, S, int(tile_rows), int(bool(compact)), _ptr(p.dest), _ptr(p.pad), _ptr(p.live64),
+                                      _ptr(p.live_tile), _ptr(p.n_live), _stream()), "afm_compact_plan")
+    return p
+
+
+def permute_rows(x, y, row_map, B, S, gather=False):
+    """fp32 rows through a compact_plan map: y[b*S + map[b*S + s]] = x[b*S + s], or the reverse (gather)."""
+    assert x.dtype == torch.float32 and y.dtype == torch.float32 and x.is_contiguous() and y.is_contiguous() and x.shape == y.shape
+    assert row_map.dtype == torch.int32 and row_map.numel() == B * S == x.shape[0]
+    L.check(L.load().afm_permute_rows(_ptr(x), _ptr(y), _ptr(row_map), B, S, x.shape[1], int(gather), _stream()), "afm_permute_rows")
     return y
 
 

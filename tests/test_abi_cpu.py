@@ -21,7 +21,7 @@ def test_header_symbols_are_exported_and_bound():
     for name in declared:
         assert hasattr(handle, name), f"libafm_hip.so does not export {name}"
     assert sorted(L.exported_symbols()) == declared, "lib.py binding and header disagree"
-    assert handle.afm_abi_version() == L.ABI_VERSION == 5
+    assert handle.afm_abi_version() == L.ABI_VERSION == 6
     for which, st in enumerate((L.Dropout, L.GemmDesc, L.LnShape, L.AttnShape, L.PatchDesc, L.BeamDesc, L.CastItem)):
         assert handle.afm_struct_size(which) == ctypes.sizeof(st)
     assert handle.afm_error_string(-2) == b"unsupported shape/dtype for the requested algorithm"
@@ -33,7 +33,7 @@ def test_struct_layouts_match_the_header():
     assert ctypes.sizeof(L.Dropout) == 16
     assert ctypes.sizeof(L.GemmDesc) == 48 + 7 * 8 + 16 + 16 + 8 + 8 and L.GemmDesc.glu_rows.offset == 136 and L.GemmDesc.k_live.offset == 144
     assert L.GemmDesc.A.offset == 48 and L.GemmDesc.a_colsum.offset == 96 and L.GemmDesc.drop.offset == 120
-    assert ctypes.sizeof(L.LnShape) == 72 and L.LnShape.add_drop.offset == 48 and L.LnShape.row_live.offset == 64
+    assert ctypes.sizeof(L.LnShape) == 80 and L.LnShape.add_drop.offset == 48 and L.LnShape.row_live.offset == 64 and L.LnShape.row_map.offset == 72
     assert L.AttnShape.key_pad.offset == 56 and L.AttnShape.sqb.offset == 80 and ctypes.sizeof(L.AttnShape) == 120
     assert L.PatchDesc.mean.offset == 32 and ctypes.sizeof(L.PatchDesc) == 48
 

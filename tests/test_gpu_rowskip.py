@@ -1,0 +1,399 @@
+"""GPU: padded positions out of the FORWARD pass of a training step (round 6; include/afm_hip.h ABI 6).
+
+Kernel level: afm_compact_plan against a stable partition written in torch, afm_permute_rows, the LayerNorm's row map / forward
+row flags, the NT GEMM families with k_live in the forward sense (live tiles bit-identical to the plain launch, dead tiles zeros in
+C and in the stored second tensor), the attention forward's padded query blocks.  Model level: the engine with the skip on against
+the engine with it off (the round-5 path, which tests/test_gpu_shapes.py holds to the CPU oracle) at batch sizes where the
+persistent GEMM kernels really take their tile lists, with labels on padded decoder rows and with a fully masked modality; and
+against the oracle itself at c3 / B = 16.
+
+Reference: the masks come from data/datamodules.py:230-351; the stacks mask those positions as keys (custom_modeling.py:238,312-318)
+and the alignment head pools them out (:469-470).
+"""
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+H16 = torch.float16
+
+
+@pytest.fixture(scope="module")
+def ops():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from multimodalanalytical_amd import ops as _ops
+    return _ops
+
+
+def _mask(B, S, seed, runs=((0, 32, 8, 22), (56, 824, 100, 760), (824, 1024, 20, 190))):
+    """key_pad (B, S) uint8 with one padded tail per modality run (start, end, min live, max live): the collator's shape."""
+    g = torch.Generator().manual_seed(seed)
+    pad = torch.zeros(B, S, dtype=torch.uint8)
+    for lo, hi, a, b in runs:
+        if hi > S:
+            continue
+        n = torch.randint(a, min(b, hi - lo) + 1, (B,), generator=g)
+        pos = torch.arange(hi - lo)[None, :]
+        pad[:, lo:hi] = (pos >= n[:, None]).to(torch.uint8)
+    return pad
+
+
+# ------------------------------------------------------------------ plan / permute
+@pytest.mark.parametrize("B,S", [(3, 256), (8, 1024), (5, 4096)])
+@pytest.mark.parametrize("compact", [True, False])
+def test_compact_plan_is_the_stable_partition(ops, B, S, compact):
+    pad = _mask(B, S, 1)
+    pad[0] = 1                      # a sample of nothing but padding
+    pad[B - 1] = 0                  # and one without any
+    plan = ops.compact_plan(pad.to(DEV), B, S, 256, compact=compact)
+    live = pad == 0
+    n = live.sum(1)
+    assert torch.equal(plan.n_live.cpu().long(), n)
+    if compact:
+        order = torch.argsort((~live).to(torch.int8), dim=1, stable=True)      # live positions first, each group in order
+        dest = torch.empty_like(order)
+        dest.scatter_(1, order, torch.arange(S)[None, :].expand(B, S))
+        pad_new = (torch.arange(S)[None, :] >= n[:, None]).to(torch.uint8)
+    else:
+        dest = torch.arange(S)[None, :].expand(B, S)
+        pad_new = pad
+    assert torch.equal(plan.dest.cpu().long().view(B, S), dest)
+    assert torch.equal(plan.pad.cpu().view(B, S), pad_new)
+    l64 = (pad_new.view(B, S // 64, 64) == 0).any(-1)
+    lt = (pad_new.view(B, S // 256, 256) == 0).any(-1).repeat_interleave(4, dim=1)
+    assert torch.equal(plan.live64.cpu().view(B, -1).bool(), l64)
+    assert torch.equal(plan.live_tile.cpu().view(B, -1).bool(), lt)
+
+
+def test_permute_rows_round_trip(ops):
+    B, S, d = 4, 512, 96
+    pad = _mask(B, S, 2, runs=((0, 32, 8, 22), (56, 512, 10, 400)))
+    plan = ops.compact_plan(pad.to(DEV), B, S, 256)
+    x = torch.randn(B * S, d, device=DEV)
+    y = ops.permute_rows(x, torch.empty_like(x), plan.dest, B, S)
+    dest = plan.dest.long().view(B, S) + (torch.arange(B, device=DEV) * S)[:, None]
+    ref = torch.empty_like(x)
+    ref[dest.view(-1)] = x
+    assert torch.equal(y, ref)
+    assert torch.equal(ops.permute_rows(y, torch.empty_like(x), plan.dest, B, S, gather=True), x)
+
+
+# ------------------------------------------------------------------ LayerNorm
+@pytest.mark.parametrize("d", [512, 768])
+@pytest.mark.parametrize("ydt", [H16, torch.float32])
+def test_layernorm_fwd_row_flags(ops, d, ydt):
+    rows = 4096
+    g = torch.Generator().manual_seed(3)
+    x, add = torch.randn(rows, d, generator=g).to(DEV), torch.randn(rows, d, generator=g).to(DEV).to(ydt)
+    gamma, beta = torch.randn(d, generator=g).to(DEV), torch.randn(d, generator=g).to(DEV)
+    live = (torch.rand(rows // 64, generator=g) > 0.4).to(torch.uint8).to(DEV)
+
+    def run(flags, with_add):
+        y = torch.full((rows, d), 7.0, dtype=ydt, device=DEV)
+        mean, rstd = torch.full((rows,), 7.0, device=DEV), torch.full((rows,), 7.0, device=DEV)
+        xs = torch.full((rows, d), 7.0, device=DEV) if with_add else None
+        ops.layernorm_fwd(x, gamma, beta, y, mean, rstd, add=add if with_add else None, x_sum=xs,
+                          add_dropout=ops.drop(0.1, 5, 3) if with_add else ops.NO_DROP, row_live=flags)
+        return y, mean, rstd, xs
+
+    for with_add in (False, True):
+        full, hinted = run(None, with_add), run(live, with_add)
+        rl = live.bool().repeat_interleave(64)
+        for a, b in zip(full, hinted):
+            if a is None:
+                continue
+            assert torch.equal(a[rl], b[rl])                          # live rows: the same kernel arithmetic, bit for bit
+            assert float(b[~rl].float().abs().max()) == 0.0           # dead rows: zeros
+
+
+def test_layernorm_row_map_forward_and_backward(ops):
+    B, S, Sm, off, d = 6, 512, 200, 56, 256
+    pad = _mask(B, S, 4, runs=((0, 32, 8, 22), (56, 256, 10, 150), (256, 512, 5, 250)))
+    plan = ops.compact_plan(pad.to(DEV), B, S, 256)
+    g = torch.Generator().manual_seed(5)
+    e = torch.randn(B * Sm, d, generator=g).to(DEV)
+    gamma, beta = torch.randn(d, generator=g).to(DEV), torch.randn(d, generator=g).to(DEV)
+    pe = torch.randn(S, d, generator=g).to(DEV)
+
+    def fwd(row_map):
+        out = torch.zeros(B * S, d, device=DEV)
+        mean, rstd = torch.empty(B * Sm, device=DEV), torch.empty(B * Sm, device=DEV)
+        ops.layernorm_fwd(e, gamma, beta, out, mean, rstd, pos=pe, seg_len=Sm, out_seg_stride=S, out_off=off, row_map=row_map)
+        return out, mean, rstd
+
+    plain, mean, rstd = fwd(None)
+    mapped, _, _ = fwd(plan.dest)
+    assert torch.equal(ops.permute_rows(plain, torch.empty_like(plain), plan.dest, B, S)[_touched(plan, B, S, off, Sm)],
+                       mapped[_touched(plan, B, S, off, Sm)])
+    # backward: dy in the compacted order through the map == dy in the collated order without it
+    dy = torch.randn(B * S, d, generator=g).to(DEV)
+    dy_c = ops.permute_rows(dy, torch.empty_like(dy), plan.dest, B, S)
+
+    def bwd(dyt, row_map):
+        dx = torch.empty(B * Sm, d, device=DEV)
+        dg, db = torch.zeros(d, device=DEV), torch.zeros(d, device=DEV)
+        ws = torch.empty(max(1, ops.layernorm_bwd_ws(B * Sm, d)), device=DEV)
+        ops.layernorm_bwd(dyt, e, gamma, mean, rstd, dx, dg, db, ws, seg_len=Sm, out_seg_stride=S, out_off=off, row_map=row_map)
+        return dx, dg, db
+
+    a, b = bwd(dy, None), bwd(dy_c, plan.dest)
+    assert torch.equal(a[0], b[0])
+    torch.testing.assert_close(a[1], b[1], rtol=1e-5, atol=1e-4)      # (block sums meet in atomics: order differs run to run)
+    torch.testing.assert_close(a[2], b[2], rtol=1e-5, atol=1e-4)
+
+
+def _touched(plan, B, S, off, Sm):
+    """Rows of the compacted (B*S) layout that the modality at [off, off + Sm) writes."""
+    dest = plan.dest.long().view(B, S)[:, off:off + Sm] + (torch.arange(B, device=DEV) * S)[:, None]
+    m = torch.zeros(B * S, dtype=torch.bool, device=DEV)
+    m[dest.reshape(-1)] = True
+    return m
+
+
+# ------------------------------------------------------------------ GEMM families
+def _gemm_case(ops, M, N, K, act, pre, drop, glu=False):
+    from multimodalanalytical_amd import lib as L
+    g = torch.Generator().manual_seed(6)
+    a = (torch.randn(M, K, generator=g) * 0.5).to(DEV).half()
+    Nw = 2 * N if glu else N
+    w = (torch.randn(Nw, K, generator=g) * 0.05).to(DEV).half()
+    bias = torch.randn(Nw, generator=g).to(DEV)
+    live = (torch.rand(M // 256, generator=g) > 0.45).to(torch.uint8)
+    live[0], live[1] = 1, 0
+    flags = live.repeat_interleave(4).contiguous().to(DEV)
+
+    def run(hint):
+        c = torch.full((M, N), 3.0, dtype=H16, device=DEV)
+        p = torch.full((M, Nw), 3.0, dtype=H16, device=DEV) if pre else None
+        kw = dict(trans_b=True, bias=bias, act=act, pre_act=p, dropout=ops.drop(0.1, 9, 2) if drop else ops.NO_DROP, algo=L.ALGO_MFMA,
+                  rows_unread=hint)
+        if glu:
+            kw["glu_rows"] = N
+        ops.gemm(a, w, c, **kw)
+        return c, p, ops.last_algo()
+
+    full, hinted = run(None), run(flags)
+    rl = live.bool().repeat_interleave(256).to(DEV)
+    assert full[2] == hinted[2]
+    for x, y in zip(full[:2], hinted[:2]):
+        if x is None:
+            continue
+        assert torch.equal(x[rl], y[rl])
+        assert float(y[~rl].float().abs().max()) == 0.0
+    return hinted[2]
+
+
+@pytest.mark.parametrize("N,K,algo", [(512, 512, "mfma_nt"), (1536, 512, "mfma_nt_pp"), (512, 2048, "mfma_nt_w4"), (768, 3072, "mfma_nt_w4"),
+                                      (2304, 768, "mfma_nt_w4")])
+def test_gemm_forward_row_hint_plain(ops, N, K, algo):
+    from multimodalanalytical_amd import lib as L
+    assert _gemm_case(ops, 65536, N, K, L.ACT_NONE, False, False) == algo
+
+
+def test_gemm_forward_row_hint_gelu_save_grad(ops):
+    from multimodalanalytical_amd import lib as L
+    assert _gemm_case(ops, 65536, 2048, 512, L.ACT_GELU_SAVE_GRAD, True, True) == "mfma_nt_256"
+
+
+@pytest.mark.parametrize("M,f,d", [(65536, 3072, 768), (8192, 2048, 512)])
+def test_gemm_forward_row_hint_glu_save(ops, M, f, d):
+    from multimodalanalytical_amd import lib as L
+    assert _gemm_case(ops, M, f, d, L.ACT_GLU_SAVE, True, True, glu=True) == "mfma_nt_glu"
+
+
+# ------------------------------------------------------------------ attention forward
+@pytest.mark.parametrize("p", [0.0, 0.1])
+def test_attn_fwd_padded_query_blocks(ops, p):
+    B, H, T, dh = 6, 8, 1024, 64
+    d = H * dh
+    g = torch.Generator().manual_seed(8)
+    qkv = (torch.randn(B * T, 3 * d, generator=g) * 0.5).to(DEV).half()
+    n = torch.tensor([1024, 700, 130, 128, 5, 0])
+    pad = (torch.arange(T)[None, :] >= n[:, None]).to(torch.uint8).to(DEV)
+
+    def run(flag):
+        o = torch.full((B * T, d), 3.0, dtype=H16, device=DEV)
+        lse = torch.full((B * H * T,), 3.0, device=DEV)
+        shp = ops.attn_shape(B, H, T, T, dh, H16, 3 * d, 3 * d, 3 * d, d, pad, False, ops.drop(p, 4, 1) if p else ops.NO_DROP)
+        if p:
+            ops.attn_set_drop_bits(shp, torch.zeros(ops.attn_drop_bits_words(B, H, T, T), dtype=torch.int64, device=DEV))
+        shp.reserved |= flag
+        ops.attn_fwd(shp, qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], o, lse)
+        assert ops.last_algo() == "attn_mfma"
+        return o.view(B, T, d), lse.view(B, H, T)
+
+    (o0, l0), (o1, l1) = run(0), run(64)
+    for b in range(B):
+        done = -(-int(n[b]) // 128) * 128                # queries in blocks that hold a live one are computed as always
+        assert torch.equal(o0[b, :done], o1[b, :done]) and torch.equal(l0[b, :, :done], l1[b, :, :done])
+        assert float(o1[b, done:].float().abs().max() if done < T else 0.0) == 0.0
+        assert bool(torch.isinf(l1[b, :, done:]).all())
+
+
+# ------------------------------------------------------------------ the engine, skip on against skip off
+def _engine(name, mode_env, seed=5, dropout=0.0, cfg_over=None):
+    from multimodalanalytical_amd import synth
+    from multimodalanalytical_amd.engine import Seq2SeqEngine
+    wl = synth.WORKLOADS[name]
+    cfg = dict(wl["cfg"], dropout=dropout, **(cfg_over or {}))
+    old = {k: os.environ.get(k) for k in mode_env}
+    os.environ.update(mode_env)
+    try:
+        eng = Seq2SeqEngine(cfg, wl["data"], "Smiles", wl["data"]["Smiles"]["vocab_size"], device=DEV, compute_dtype=H16, seed=seed)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    return wl, eng
+
+
+def _inputs(name, B, seed=11):
+    from multimodalanalytical_amd import synth
+    from oracle import afm_oracle as O
+    batch, _ = synth.make_batch(name, B, seed=seed)
+    return O.batch_to_model_inputs(batch, "Smiles")
+
+
+def _to(x):
+    return {k: _to(v) for k, v in x.items()} if isinstance(x, dict) else x.to(DEV)
+
+
+def _run(eng, inputs, labels=None, **kw):
+    enc, am, dec, dm, lab = inputs
+    eng.ps.grad.zero_()
+    out = eng.forward(_to(enc), am.to(DEV), dec.to(DEV), dm.to(DEV), (lab if labels is None else labels).to(DEV), backward=True, **kw)
+    torch.cuda.synchronize()
+    S = float(eng.scaler[0])
+    return out, {k: eng.ps.g(k).clone() / S for k in eng.ps.specs}
+
+
+def _compare(a, b, ga, gb, logit_tol, grad_tol):
+    la, lb = a["logits"].double(), b["logits"].double()
+    err = float((la - lb).abs().max()) / float(lb.abs().max())
+    assert err <= logit_tol, err
+    assert abs(float(a["loss"]) - float(b["loss"])) <= max(logit_tol, 1e-6) * max(1.0, abs(float(b["loss"])))
+    num = sum(float((ga[k] - gb[k]).double().norm()) ** 2 for k in ga)
+    den = sum(float(gb[k].double().norm()) ** 2 for k in gb)
+    assert (num / den) ** 0.5 <= grad_tol, (num / den) ** 0.5
+    gmax = max(float(v.norm()) for v in gb.values())
+    bad = [(k, float((ga[k] - gb[k]).norm()) / (float(gb[k].norm()) + 1e-30)) for k in ga
+           if float((ga[k] - gb[k]).norm()) > 10 * grad_tol * float(gb[k].norm()) + 1e-4 * gmax]
+    assert not bad, bad[:6]
+    for v in ga.values():
+        assert bool(torch.isfinite(v).all())
+    return err
+
+
+@pytest.mark.parametrize("name,B", [("c3", 64), ("c4", 32)])
+def test_engine_flags_only_equals_unskipped(name, B):
+    """Rows where the collator put them, dead 256-row groups left out: every live row goes through the same kernels on the same
+    operands, so the logits are the un-skipped engine's bit for bit; gradients agree to the order of the atomics."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from multimodalanalytical_amd import ops
+    over = {"encoder_layers": 2, "decoder_layers": 2}
+    inputs = _inputs(name, B)
+    wl, e_off = _engine(name, {"AFM_FWD_ROW_SKIP": "0"}, cfg_over=over)
+    _, e_on = _engine(name, {"AFM_FWD_ROW_SKIP": "1", "AFM_FWD_COMPACT": "0"}, cfg_over=over)
+    e_on.load_state_dict(e_off.state_dict())
+    a, ga = _run(e_on, inputs)
+    assert "encoder_row_map" in a
+    b, gb = _run(e_off, inputs)
+    assert "encoder_row_map" not in b
+    assert torch.equal(a["logits"], b["logits"]) and torch.equal(a["argmax"], b["argmax"])
+    _compare(a, b, ga, gb, 0.0, 2e-4)
+    # the 256-row groups the skip left out are zeros in the returned memory, live positions are the un-skipped engine's (padded
+    # positions inside a live group are whatever their kernels made of them: the attention leaves out padded 128-query blocks)
+    am = inputs[1]
+    grp = (am.view(B, -1, 256) != 0).any(-1).repeat_interleave(256, dim=1).to(DEV)
+    live = (am != 0).to(DEV)
+    ma, mb = a["encoder_hidden_states"], b["encoder_hidden_states"]
+    assert torch.equal(ma[live], mb[live]) and float(ma[~grp].float().abs().max() if bool((~grp).any()) else 0.0) == 0.0
+
+
+@pytest.mark.parametrize("name,B", [("c3", 64), ("c4", 32)])
+def test_engine_compacted_equals_unskipped(name, B):
+    """Live positions moved to the front of every slot: the same function of the batch (keys in another order, so sums round
+    differently): logits and every gradient within a fraction of the fp16 mode's own distance to the oracle."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    over = {"encoder_layers": 2, "decoder_layers": 2}
+    inputs = _inputs(name, B)
+    wl, e_off = _engine(name, {"AFM_FWD_ROW_SKIP": "0"}, cfg_over=over)
+    _, e_on = _engine(name, {"AFM_FWD_ROW_SKIP": "1", "AFM_FWD_COMPACT": "1"}, cfg_over=over)
+    e_on.load_state_dict(e_off.state_dict())
+    a, ga = _run(e_on, inputs)
+    b, gb = _run(e_off, inputs)
+    err = _compare(a, b, ga, gb, 5e-4, 2e-3)
+    print(f"{name} B={B}: compacted vs un-skipped logits {err:.2e}")
+    # memory rows: position s of sample b sits in row encoder_row_map[b, s]
+    dest = a["encoder_row_map"].long()
+    live = inputs[1].to(DEV) != 0
+    ma = torch.gather(a["encoder_hidden_states"].float(), 1, dest[:, :, None].expand(-1, -1, a["encoder_hidden_states"].shape[-1]))
+    mb = b["encoder_hidden_states"].float()
+    assert float((ma[live] - mb[live]).abs().max()) <= 2e-2 * float(mb[live].abs().max())
+
+
+def test_engine_labels_on_padded_decoder_rows_and_masked_modality():
+    """c4 with (a) every decoder position labelled, padded ones included (the caller's labels are its own: those rows then carry a
+    gradient), (b) one sample's Multiplets modality fully masked and another sample with nothing but its formula."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    B = 32
+    over = {"encoder_layers": 2, "decoder_layers": 2}
+    enc, am, dec, dm, lab = _inputs("c4", B)
+    am = am.clone()
+    am[1, 56:824] = 0                  # Multiplets of sample 1: nothing but padding
+    am[2, 32:] = 0                     # sample 2: formula only (IR patches masked too)
+    labels = dec.roll(-1, 1).clone()   # a label everywhere
+    inputs = (enc, am, dec, dm, lab)
+    _, e_off = _engine("c4", {"AFM_FWD_ROW_SKIP": "0"}, cfg_over=over)
+    _, e_on = _engine("c4", {"AFM_FWD_ROW_SKIP": "1"}, cfg_over=over)
+    e_on.load_state_dict(e_off.state_dict())
+    a, ga = _run(e_on, inputs, labels=labels)
+    b, gb = _run(e_off, inputs, labels=labels)
+    _compare(a, b, ga, gb, 5e-4, 2e-3)
+
+
+def test_engine_compacted_vs_oracle_c3():
+    """c3 at B = 16 (16 384 encoder rows: the persistent kernels take their tile lists), skip and compaction on, against the CPU oracle:
+    the bars of tests/test_gpu_shapes.py."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from multimodalanalytical_amd import synth
+    from multimodalanalytical_amd.params import ParamStore, build_specs
+    from oracle import afm_oracle as O
+    B = 16
+    wl = synth.WORKLOADS["c3"]
+    cfg = dict(wl["cfg"], dropout=0.0, encoder_layers=3, decoder_layers=2)
+    V = wl["data"]["Smiles"]["vocab_size"]
+    ps = ParamStore(build_specs(cfg, wl["data"], V), "cpu", False)
+    ps.init_(5)
+    sd = {k: v.clone() for k, v in ps.state_dict().items()}
+    sd["embedding.positional_encodings.pos_enc"] = O.sincos_table(cfg["d_model"], cfg["max_position_embeddings"])
+    inputs = _inputs("c3", B)
+    torch.set_num_threads(min(32, torch.get_num_threads()))
+    leaf = {k: v.clone().requires_grad_(not k.endswith("pos_enc")) for k, v in sd.items()}
+    ref = O.model_forward(leaf, cfg, wl["data"], "Smiles", *inputs)
+    ref["loss"].backward()
+    _, eng = _engine("c3", {"AFM_FWD_ROW_SKIP": "1"}, cfg_over={"encoder_layers": 3, "decoder_layers": 2})
+    eng.load_state_dict(sd)
+    out, grads = _run(eng, inputs)
+    rl = ref["logits"].detach().double()
+    err = float((out["logits"].cpu().double() - rl).abs().max()) / float(rl.abs().max())
+    assert err < 1e-3, err
+    torch.testing.assert_close(out["loss"].cpu(), ref["loss"].detach(), rtol=2e-3, atol=2e-3)
+    num = den = 0.0
+    for k, v in leaf.items():
+        if v.grad is None or k.endswith("in_proj_bias"):
+            continue
+        num += float((grads[k].cpu() - v.grad).norm()) ** 2
+        den += float(v.grad.norm()) ** 2
+    assert (num / den) ** 0.5 < 3e-3, (num / den) ** 0.5
+    print(f"c3 B={B} compacted vs oracle: logits {err:.2e}, gradients {(num / den) ** 0.5:.2e}")

@@ -80,7 +80,7 @@ if "--abl" in sys.argv:      # an AFM_ATTN_ABLATIONS build (AFM_LIB_OVERRIDE): t
              120: "no waits / preamble / dma / barrier"}
     for rnd in range(2):
         for abl in (0, 1, 2, 4, 8, 16, 32, 64, 80, 112, 120, 6, 22, 54, 3, 7, 23, 31, 63):
-            s.reserved = 2 | (abl << 12)
+            s.reserved = 2 | (abl << 20)
             ms = t(lambda: ops.attn_bwd(s, q, k, v, o, do, lse, delta, dq, dk, dv, D, D, D))
             print(f"abl {abl:3d} {names[abl]:36s} {ms:.4f} ms", flush=True)
     sys.exit(0)
