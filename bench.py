@@ -596,6 +596,24 @@ def launch_plan(gpus, force_ddp, env, argv, visible_gpus=None):
                       "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv))
 
 
+def visible_gpu_count(env=os.environ, kfd_nodes="/sys/class/kfd/kfd/topology/nodes"):
+    """GPUs this process's children would see, WITHOUT loading a GPU runtime (torch.cuda.device_count() may fall back to
+    hipGetDeviceCount, which brings up HIP / HSA in the parent and keeps /dev/kfd open beside the ranks): the visibility lists of the
+    environment if set, else the KFD topology (nodes with SIMDs are GPUs).  None when neither is readable: the ranks then find out."""
+    for k in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        if env.get(k) is not None:
+            return len([t for t in env[k].split(",") if t.strip() != ""])
+    try:
+        n = 0
+        for node in os.listdir(kfd_nodes):
+            with open(os.path.join(kfd_nodes, node, "properties")) as fh:
+                props = dict(ln.split()[:2] for ln in fh if len(ln.split()) >= 2)
+            n += int(props.get("simd_count", "0")) > 0
+        return n
+    except OSError:
+        return None
+
+
 def spawn_job(cmd):
     """Run the N-rank job as a child process (never exec: this process may not be replaced once a GPU runtime is loaded, and must not
     touch the GPU before the children do), relay its stderr as it comes and its LAST JSON line on stdout, return its exit status."""
@@ -623,7 +641,8 @@ def spawn_job(cmd):
 
 def main():
     args = parse()
-    plan = launch_plan(args.gpus, args.force_ddp, os.environ, sys.argv[1:], torch.cuda.device_count())   # (device_count does not initialise the GPU)
+    spawning = "RANK" not in os.environ and (args.gpus > 1 or args.force_ddp)
+    plan = launch_plan(args.gpus, args.force_ddp, os.environ, sys.argv[1:], visible_gpu_count() if spawning else None)   # (no GPU runtime in a parent)
     if plan[0] == "error":
         raise SystemExit("bench.py: " + plan[1])
     if plan[0] == "spawn":

@@ -180,16 +180,21 @@ class MixtureLoader:
         self.align = collator.alignment_modality[0] if collator.alignment_modality else None
 
     def __len__(self):
-        return (self.nominal // self.world) // self.bs
+        """Batches of one pass at the NOMINAL length: training drops a trailing partial batch, validation / test keep it (as epoch()
+        below, and as ShardLoader with drop_last=False)."""
+        per_rank = self.nominal // self.world
+        return per_rank // self.bs if self.key == "train" else math.ceil(per_rank / self.bs)
 
     def records(self):
         from ..preprocess import interleave_rounds
         yield from interleave_rounds(self.gens)
 
     def epoch(self, epoch: int):     # noqa: ARG002 (the reference's generator reseeds: every epoch is the same stream)
-        """Batches of one pass over the stream.  Training drops the trailing partial batch (the reference's train DataLoader,
-        data/datamodules.py: drop_last=True); validation / test yield it as a final short batch -- the reference evaluates every
-        record (ShardLoader does the same) -- and a split that yields nothing at all is an error here, not a NaN monitor score later."""
+        """Batches of one pass over the stream.  The reference's DataLoaders all run with drop_last=False (data/datamodules.py:433,467,
+        502).  Validation / test do the same here: the trailing records are a final short batch, every record is evaluated.  TRAINING
+        drops a trailing partial batch -- a deliberate difference, shared with ShardLoader: every rank takes the same number of
+        optimiser steps and every micro-batch has the shape the kernels were planned for; at most batch_size - 1 records of an epoch's
+        stream are not seen.  A split that yields nothing at all is an error here, not a NaN monitor score later."""
         pend, n = None, 0
         for r in self.records():
             r = {k: v for k, v in r.items() if k in ("IR", "compound", "IR_target")}
@@ -217,6 +222,21 @@ class MixtureLoader:
         if self.align is not None:
             inputs[self.align] = {"spectra": rec["IR_target"]}
         return self.collator(inputs)
+
+
+def val_batches(loader, limit):
+    """(index, batch) of one validation pass under Lightning's `limit_val_batches` (an int = that many batches, a float <= 1 = that
+    share of them, at least one; trainer/trainer.py:66).  The count comes from len(loader), which for validation INCLUDES a trailing
+    short batch (drop_last=False in the reference, data/datamodules.py:467); a split without a single batch raises here, before the
+    loop, instead of leaving on_validation_epoch_end without outputs."""
+    total = len(loader)
+    if total <= 0:
+        raise RuntimeError("the validation split yields no batch (fewer records than ranks, or an empty mixture configuration)")
+    nval = min(total, int(limit) if isinstance(limit, int) or float(limit) > 1.0 else max(1, int(total * float(limit))))
+    for i, batch in enumerate(loader.epoch(0)):
+        if i >= nval:
+            break
+        yield i, batch
 
 
 def build_preprocessors(train_shard, data_config, device, mixture_sample=None):
@@ -338,12 +358,7 @@ def run(cfg: Dict[str, Any], own: Dict[str, str]) -> Dict[str, Any]:
             if first_logged is None:      # what Lightning would log at step 0: train_loss (+ model_only / alignment loss with the head)
                 first_logged = {k: float(v) for k, v in model.logged.items() if k.startswith("train_")}
         loop.flush()      # Lightning steps the optimiser on the last batch of an epoch even when the accumulation window is not full
-        nval = len(val)
-        lim = plan["limit_val_batches"]
-        nval = min(nval, int(lim) if isinstance(lim, int) or float(lim) > 1.0 else max(1, int(nval * float(lim))))
-        for i, batch in enumerate(val.epoch(0)):
-            if i >= nval:
-                break
+        for i, batch in val_batches(val, plan["limit_val_batches"]):
             model.validation_step(batch, i)
         avg = {k: float(v) for k, v in model.on_validation_epoch_end().items()}
         history.append({"epoch": epoch, "step": loop.optim.step_count, **avg})

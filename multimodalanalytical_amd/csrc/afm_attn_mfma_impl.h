@@ -1229,9 +1229,10 @@ int AFM_E16_FN(afm_attn_bwd_mfma_try)(const afm_attn_shape* s, const void* Q, co
     int nch = std::min(nkb, std::max(1, (1024 + nbh - 1) / nbh));
     const int nb = (nkb + nch - 1) / nch;
     nch = (nkb + nb - 1) / nb;
-    const int shm_sq = ntq * (2 * KT * DH * 2 * 2 + 2 * KT * 4);
+    const int shm_sq = ntq * (2 * KT * DH * 2 + 2 * KT * 4);      // per query tile: the Q and dO dual-use images, lse and delta (what the kernel lays out; ADVICE r05: twice that was requested)
     const dim3 gsq(nch * s->H * s->B);
-#define AFM_SQ_LAUNCH(D, N) AFM_LAUNCH((k_attn_bwd_dkv_sq<D, N>), gsq, dim3(256), shm_sq, st, a, (const e16*)Q, (const e16*)K, (const e16*)V, (const e16*)dO, lse, delta, (e16*)dK, (e16*)dV, nb, nch)
+#define AFM_SQ_LAUNCH(D, N) do { static AfmOncePerDevice at_; if (at_.need()) (void)hipFuncSetAttribute((const void*)k_attn_bwd_dkv_sq<D, N>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024); \
+    AFM_LAUNCH((k_attn_bwd_dkv_sq<D, N>), gsq, dim3(256), shm_sq, st, a, (const e16*)Q, (const e16*)K, (const e16*)V, (const e16*)dO, lse, delta, (e16*)dK, (e16*)dV, nb, nch); } while (0)
     if (a.dd.thresh16) { if (ntq == 1) AFM_SQ_LAUNCH(DROP_BITS, 1); else if (ntq == 2) AFM_SQ_LAUNCH(DROP_BITS, 2); else AFM_SQ_LAUNCH(DROP_BITS, 3); }
     else { if (ntq == 1) AFM_SQ_LAUNCH(DROP_NONE, 1); else if (ntq == 2) AFM_SQ_LAUNCH(DROP_NONE, 2); else AFM_SQ_LAUNCH(DROP_NONE, 3); }
 #undef AFM_SQ_LAUNCH

@@ -15,6 +15,9 @@
 // the first operand so a lane ends up with 4 consecutive output columns of one row: 8-/16-byte
 // epilogue accesses.  Blocks are renumbered so the 8 XCDs each walk a contiguous range of tiles
 // (all column tiles of a row panel share one L2).
+#include <algorithm>
+#include <functional>
+#include <vector>
 #include "afm_common.h"
 
 namespace AFM_E16_NS {
@@ -1971,11 +1974,13 @@ int AFM_E16_FN(afm_gemm_tn_group_launch)(const afm_gemm_desc* const* ds, int cou
   // round and one of 32 units -- the probe that found it lost 8 % of the c4 step (tools/experiments/r5_wgrad_layers.sh).
   int chunk = max_steps;                                   // (AFM_TN_ONE_WAVE with >= 256 tiles: no split-K at all)
   static const int ovh = getenv("AFM_TN_OVH") ? atoi(getenv("AFM_TN_OVH")) : 40;
-  if (!getenv("AFM_TN_ONE_WAVE")) {
-    // (the plan depends on the shapes only: the last few are remembered)
+  static const bool one_wave = getenv("AFM_TN_ONE_WAVE") != nullptr;      // (read once: this is the launch path of every layer's backward)
+  if (!one_wave) {
+    // (the plan depends on the shapes only: the last 64 are remembered, replaced round-robin -- c2 + c3 + c4 + c5 in one bench process
+    // are ~20 distinct layer sets)
     struct Plan { uint64_t key; int chunk; };
-    static thread_local Plan cache[16];
-    static thread_local int cache_n = 0;
+    static thread_local Plan cache[64];
+    static thread_local int cache_n = 0, cache_next = 0;
     uint64_t key = 1469598103934665603ull ^ (uint64_t)count;
     for (int i = 0; i < count; ++i) key = (key * 1099511628211ull) ^ ((uint64_t)gr.p[i].ntile << 32 | (uint32_t)steps[i]);
     bool hit = false;
@@ -1987,8 +1992,8 @@ int AFM_E16_FN(afm_gemm_tn_group_launch)(const afm_gemm_desc* const* ds, int cou
         const int c = (max_steps + ks0 - 1) / ks0;
         if (c < 16) break;                                 // >= 1024 tokens per unit
         if ((int64_t)tiles * ks0 > 8192) break;            // (host time of the estimate: units x 256 slots per candidate)
-        // greedy schedule of the units in launch order on 256 slots (a min-heap of finish times would do; 256 is small enough to scan)
-        int finish[256] = {0};
+        // greedy schedule of the units in launch order on 256 slots: a min-heap of the slots' finish times (O(units log 256) per candidate)
+        std::vector<int> finish(256, 0);      // (all zeros is a heap)
         int makespan = 0;
         for (int i = 0; i < count; ++i) {
           int ks = (steps[i] + c - 1) / c;
@@ -1996,15 +2001,15 @@ int AFM_E16_FN(afm_gemm_tn_group_launch)(const afm_gemm_desc* const* ds, int cou
           ks = (steps[i] + per - 1) / per;
           const int n = gr.p[i].ntile * ks;
           for (int u = 0; u < n; ++u) {
-            int m = 0;
-            for (int q = 1; q < 256; ++q) if (finish[q] < finish[m]) m = q;
-            finish[m] += per + ovh;
-            if (finish[m] > makespan) makespan = finish[m];
+            std::pop_heap(finish.begin(), finish.end(), std::greater<int>());      // the earliest slot to the back
+            finish.back() += per + ovh;
+            if (finish.back() > makespan) makespan = finish.back();
+            std::push_heap(finish.begin(), finish.end(), std::greater<int>());
           }
         }
         if (makespan < best * 0.97) { best = makespan; chunk = c; }   // (a finer split has to pay by 3 %)
       }
-      cache[cache_n < 16 ? cache_n++ : (int)(key & 15)] = Plan{key, chunk};
+      cache[cache_n < 64 ? cache_n++ : (cache_next++ & 63)] = Plan{key, chunk};
     }
   } else if (tiles < 256) {                                // AFM_TN_ONE_WAVE: the rule of rounds 3-4 (A / B runs)
     chunk = (int)((work + 255) / 256);

@@ -60,3 +60,15 @@ def test_spawned_job_relays_one_json_line_and_the_exit_status(capfd):
     assert "NCCL version banner" in err and "{not json}" in err
     assert bench.spawn_job([sys.executable, "-c", "import sys; sys.exit(7)"]) == 7
     assert bench.spawn_job([sys.executable, "-c", "print('no line')"]) != 0
+
+
+def test_visible_gpu_count_reads_no_gpu_runtime(tmp_path):
+    """The parent of a spawned job counts devices from the environment or the KFD topology files, never through torch / HIP."""
+    assert bench.visible_gpu_count({"HIP_VISIBLE_DEVICES": "0,1,2"}) == 3
+    assert bench.visible_gpu_count({"ROCR_VISIBLE_DEVICES": ""}) == 0
+    for i, simd in enumerate((0, 1024, 1024)):          # a CPU node and two GPU nodes
+        d = tmp_path / str(i)
+        d.mkdir()
+        (d / "properties").write_text(f"cpu_cores_count {64 if simd == 0 else 0}\nsimd_count {simd}\n")
+    assert bench.visible_gpu_count({}, str(tmp_path)) == 2
+    assert bench.visible_gpu_count({}, str(tmp_path / "missing")) is None

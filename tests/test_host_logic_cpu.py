@@ -150,3 +150,28 @@ def test_elementwise_dropout_stream_statistics():
         for lag in (1, 2, 3, 4, 16, 64):
             c = float((s[:-lag] * s[lag:]).mean() / s.var()) * np.sqrt(n)
             assert abs(c) < 4.5, (seed, site, lag, c)
+
+
+def test_validation_pass_counts_the_trailing_short_batch():
+    """a mixture validation split whose nominal length is not a multiple of the batch size has a trailing short batch,
+    which len() counts and the validation pass visits; a split without a single batch raises before the loop (the reference's
+    loaders all run with drop_last=False, data/datamodules.py:433,467,502)."""
+    import pytest
+    from multimodalanalytical_amd.cli import training as T
+
+    def loader(nominal, bs, key, world=1):
+        ld = T.MixtureLoader.__new__(T.MixtureLoader)
+        ld.nominal, ld.bs, ld.world, ld.key = nominal, bs, world, key
+        n_batches = -(-(nominal // world) // bs) if key != "train" else (nominal // world) // bs
+        ld.epoch = lambda epoch: iter(range(n_batches))          # what epoch() yields: full batches, then (not for train) a short one
+        return ld
+
+    assert len(loader(100, 16, "validation")) == 7 and len(loader(100, 16, "train")) == 6 and len(loader(96, 16, "test")) == 6
+    assert len(loader(5, 16, "validation")) == 1 and len(loader(5, 16, "train")) == 0 and len(loader(100, 16, "validation", world=2)) == 4
+    seen = [i for i, _ in T.val_batches(loader(100, 16, "validation"), 1.0)]
+    assert seen == list(range(7))                                  # the short batch (index 6) is validated
+    assert [i for i, _ in T.val_batches(loader(5, 16, "validation"), 1.0)] == [0]      # nominal < batch size: one short batch
+    assert [i for i, _ in T.val_batches(loader(100, 16, "validation"), 3)] == [0, 1, 2]
+    assert [i for i, _ in T.val_batches(loader(100, 16, "validation"), 0.5)] == [0, 1, 2]
+    with pytest.raises(RuntimeError, match="no batch"):
+        list(T.val_batches(loader(0, 16, "validation"), 1.0))
