@@ -279,6 +279,64 @@ def kernel_rooflines(model, wl, B, mode, wl_name="c2"):
             ms = time_kernel(lambda: ops.gemm(duv, wgt, dh, trans_b=True))
             add("gated FFN up-projection data gradient", f"afm_gemm[{ops.last_algo()}] {M}x{d}x{2 * fh}", ms, 2.0 * M * d * 2 * fh,
                 eb * (M * 2 * fh + 2 * fh * d + M * d), Le, "1 product", bmode)
+    # --- HBM-bound kernels of the step (LayerNorm / AdamW on the HBM roofline): bytes every launch must move
+    def add_hbm(name, kern, ms, alg_bytes, calls, note):
+        gbs = alg_bytes / (ms * 1e-3) / 1e9
+        out.append({"bound": "hbm", "kernel": kern, "what": name, "arithmetic": "fp32 statistics / " + mode, "achieved": round(gbs, 1),
+                    "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4), "mfma_frac_executed": None,
+                    "avg_launch_ms": round(ms, 4), "algorithmic_flops": 0.0, "algorithmic_bytes": alg_bytes,
+                    "hbm_time_at_peak_ms": round(alg_bytes / (PEAK_HBM_GBS * 1e9) * 1e3, 4),
+                    "launches_per_micro_batch": calls, "ms_per_micro_batch": round(ms * calls, 3), "counts": note, "traffic": None})
+    if mode != "fp32" and not mixed:
+        xs = torch.randn(M, d, device=dev)
+        branch = _rand(M, d, cd, dev)
+        gam, bet = eng.ps.p("encoder.layers.0.norm1.weight"), eng.ps.p("encoder.layers.0.norm1.bias")
+        yln, xsum = ops.empty(M, d, cd, dev), torch.empty(M, d, device=dev)
+        mean, rstd = torch.empty(M, device=dev), torch.empty(M, device=dev)
+        ms = time_kernel(lambda: ops.layernorm_fwd(xs, gam, bet, yln, mean, rstd, add=branch, x_sum=xsum, add_dropout=dr))
+        add_hbm("LayerNorm forward with the residual add and the branch dropout fused (encoder rows)", f"afm_layernorm_fwd {M}x{d}", ms,
+                M * d * (4 + ef + 4 + ef) + 8 * M, 2 * Le + 1, "reads the fp32 stream and the 16-bit branch, writes the summed stream (fp32) and the operand (16-bit)")
+        dyl = _rand(M, d, cd, dev, 0.01)
+        dres, dxl, dxd = torch.randn(M, d, device=dev) * 0.01, torch.empty(M, d, device=dev), ops.empty(M, d, cd, dev)
+        dgam, dbet = torch.zeros(d, device=dev), torch.zeros(d, device=dev)
+        ws = torch.empty(max(1, ops.layernorm_bwd_ws(M, d)), device=dev)
+        ms = time_kernel(lambda: ops.layernorm_bwd(dyl, xsum, gam, mean, rstd, dxl, dgam, dbet, ws, dres=dres, dx_drop=dxd, dropout=dr))
+        add_hbm("LayerNorm backward with the residual-gradient add and the dropped copy for the preceding branch fused (encoder rows)",
+                f"afm_layernorm_bwd {M}x{d}", ms, M * d * (eb + 4 + 4 + 4 + eb) + 8 * M, 2 * Le + 1,
+                "reads dy (16-bit), the saved stream and the residual gradient (fp32), writes dx (fp32) and dropout'(dx) (16-bit)")
+        del xs, branch, yln, xsum, dyl, dres, dxl, dxd
+        # Adam(W) over the flat parameter buffer, on copies (the weights of the run stay as trained)
+        ps = eng.ps
+        pc, gc, mc, vc = ps.flat.clone(), torch.randn_like(ps.flat) * 1e-3, ps.exp_avg.clone(), ps.exp_avg_sq.clone()
+        lowc = ps.bf16.clone() if ps.bf16 is not None else None
+        hyper = torch.tensor([1e-4, 0.9, 0.999, 1e-8, 0.0, 0.1, 0.001, 1.0, 1.0, 1.0], device=dev)
+        ssq = torch.ones(1, device=dev)
+        ms = time_kernel(lambda: ops.adam_step(pc, gc, mc, vc, hyper, ssq, lowc, zero_grad=True, scaler=None), iters=10, warm=5)
+        add_hbm("AdamW step over the flat parameter buffer (clip factor, 16-bit weight shadow and gradient zeroing fused)",
+                f"afm_adam_step {pc.numel()} parameters", ms, pc.numel() * (16 + 12 + 4 + (2 if lowc is not None else 0)), 0,
+                "per optimiser step, not per micro-batch: reads p, g, m, v; writes p, m, v, zeroes g, writes the 16-bit shadow")
+        out[-1]["launches_per_step"] = 1
+        del pc, gc, mc, vc, lowc
+        # --- decoder-row products (M = B * T rows: 64 row tiles of 256 on 256 CUs)
+        T = wl["T"]
+        Mt = B * T
+        Ld = cfg["decoder_layers"]
+        fd = cfg["decoder_ffn_dim"]
+        xt = _rand(Mt, d, cd, dev)
+        for (nm, N_, K_, wname, calls) in (("decoder self-attention QKV projection forward", 3 * d, d, "decoder.layers.0.self_attn.in_proj_weight", Ld),
+                                          ("decoder output projection forward (self- and cross-attention)", d, d, "decoder.layers.0.self_attn.out_proj.weight", 2 * Ld)):
+            wdec = eng.W(wname, N_, K_)
+            odec = ops.empty(Mt, N_, cd, dev)
+            bdec = eng.ps.p(wname.replace("weight", "bias"))
+            ms = time_kernel(lambda: ops.gemm(xt, wdec, odec, trans_b=True, bias=bdec))
+            add(nm, f"afm_gemm[{ops.last_algo()}] {Mt}x{N_}x{K_}", ms, 2.0 * Mt * N_ * K_, ef * (Mt * K_ + N_ * K_ + Mt * N_), calls, "1 product", fmode)
+        if not cfg["gated_linear"]:
+            gdec = _rand(Mt, fd, cd, dev)
+            w2d, b2d = eng.W("decoder.layers.0.linear2.weight", d, fd), eng.ps.p("decoder.layers.0.linear2.bias")
+            odec = ops.empty(Mt, d, cd, dev)
+            ms = time_kernel(lambda: ops.gemm(gdec, w2d, odec, trans_b=True, bias=b2d))
+            add("decoder FFN down-projection forward", f"afm_gemm[{ops.last_algo()}] {Mt}x{d}x{fd}", ms, 2.0 * Mt * d * fd,
+                ef * (Mt * fd + d * fd + Mt * d), Ld, "1 product", fmode)
     # traffic from committed PMC passes of the same launches (profiles/r02_*_pmc.json: {kernel what: bytes})
     if B == 128 and S == 1024:
         tables = {}
@@ -370,6 +428,12 @@ def measured_parity(model, wl, name, n=8):
     model.hf_model.backward_on_forward(False)
     with torch.no_grad():
         got = model(synth.to_device(batch, eng.dev)).logits.float().cpu().double()
+    # the same batch through the TRAINING-step forward (backward pending: padded rows out of the forward pass, live positions compacted;
+    # dropout is off because the model is in eval mode).  Its gradients land in the buffer the timed steps left empty: zeroed again below.
+    model.hf_model.backward_on_forward(True)
+    got_train = model(synth.to_device(batch, eng.dev)).logits.float().cpu().double()
+    model.hf_model.backward_on_forward(False)
+    eng.ps.grad.zero_()
     model.train(was)
     sd = {k: v.detach().float().cpu() for k, v in eng.state_dict().items()}
     cfg = dict(wl["cfg"], dropout=0.0)
@@ -378,10 +442,11 @@ def measured_parity(model, wl, name, n=8):
         ref = O.model_forward(sd, cfg, wl["data"], "Smiles", enc, am, dec, dm)["logits"].double()
     scale = float(ref.abs().max())
     err = float((got - ref).abs().max()) / scale
+    err_train = float((got_train - ref).abs().max()) / scale
     ids, rid = got.argmax(-1), ref.argmax(-1)
     top2 = ref.topk(2, -1).values
     sure = (top2[..., 0] - top2[..., 1]) > 2 * err * scale
-    return {"logits_rel_err": float(f"{err:.3e}"), "bar": 1e-3, "ids_equal_frac": round(float((ids == rid).double().mean()), 6),
+    return {"logits_rel_err": float(f"{err:.3e}"), "logits_rel_err_training_step_forward": float(f"{err_train:.3e}"), "bar": 1e-3, "ids_equal_frac": round(float((ids == rid).double().mean()), 6),
             "ids_equal_where_margin_exceeds_2x_err": bool(torch.equal(ids[sure], rid[sure])),
             "decidable_frac": round(float(sure.double().mean()), 6), "samples": n,
             "note": "measured in this run on the trained weights of the timed steps, eval forward vs oracle/afm_oracle.py (fp32 CPU)"}
@@ -691,8 +756,8 @@ def main():
                             "value": round(r["value"], 3), "unit": "samples/s", "ms_per_step": round(r["dt"] / nst * 1e3, 3),
                             "steps": nst,
                             "train_gflop_per_sample": round(r["flops"] / 1e9, 2),
-                            # padded workloads: the algorithmic count includes positions whose work the kernels skip; `live` is what they
-                            # evaluate (forward: all rows, live keys; backward: live rows), `live_frac` the share of real encoder positions
+                            # padded workloads: the algorithmic count includes positions whose work the kernels skip; `live` is the work at
+                            # live encoder positions only (what a step cannot leave out), `live_frac` the share of real encoder positions
                             "live_gflop_per_sample": round(r["executed"]["live"] / 1e9, 2),
                             "encoder_live_frac": round(r["live_frac"], 4),
                             "mfma_frac_of_live_work": round(PASSES[args.dtype] * r["value"] * r["executed"]["live"] / (PEAK_BF16_TFLOPS * 1e12), 4),
@@ -774,6 +839,23 @@ def main():
         "final_loss": round(main_run["loss"], 4),
         "modes": modes,
     }
+    # the driver's record keeps `config` whole and only the NAMES of the nested sections: the other workloads' rates and the headline
+    # mode's in-run parity go there as short scalars too
+    for w, e in workloads.items():
+        out["config"][f"{w}_samples_per_s"] = e["value"]
+    par = main_run.get("parity")
+    parity_ok = None
+    if par is not None:
+        worst = max(par["logits_rel_err"], par["logits_rel_err_training_step_forward"])
+        parity_ok = bool(worst < par["bar"] and par["ids_equal_where_margin_exceeds_2x_err"])
+        out["config"].update(logits_rel_err=par["logits_rel_err"], logits_rel_err_training_step_forward=par["logits_rel_err_training_step_forward"],
+                             logits_bar=par["bar"], ids_equal_frac=par["ids_equal_frac"])
+        for w, e in workloads.items():
+            if "logits_vs_cpu_reference" in e:
+                pw = e["logits_vs_cpu_reference"]
+                out["config"][f"{w}_logits_rel_err"] = max(pw["logits_rel_err"], pw["logits_rel_err_training_step_forward"])
+                parity_ok = parity_ok and bool(out["config"][f"{w}_logits_rel_err"] < pw["bar"] and pw["ids_equal_where_margin_exceeds_2x_err"])
+    out["parity_ok"] = parity_ok      # None: the in-run check was switched off (--no-parity / --no-cpu-baseline)
     if input_cmp is not None:
         out["input_path"] = input_cmp
     if mb_alt is not None:
@@ -789,6 +871,9 @@ def main():
             ks = kernel_rooflines(main_run["model"], wl, B, args.dtype, args.workload)
             out["roofline"] = ks[0]
             out["roofline_kernels"] = ks[1:]
+            # share of the timed step the listed launches account for (their live timings x launches per step / the step's wall time)
+            per_step = sum(e["ms_per_micro_batch"] * args.acc + e["avg_launch_ms"] * e.get("launches_per_step", 0) for e in ks)
+            out["roofline_coverage_of_step"] = round(per_step / (main_run["dt"] / args.steps * 1e3), 4)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(main_run["model"], wl, args.workload, args.cpu_batch, args.cpu_steps, args.cpu_threads)
     # RCCL writes its version banner through C stdio, which holds it (stdout is a pipe) until the process exits -- behind the JSON
@@ -805,6 +890,9 @@ def main():
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(out), flush=True)
+    if out.get("parity_ok") is False:      # the line is printed first; a headline whose in-run logits miss the bar exits with status 4
+        sys.stderr.write("bench.py: the in-run logits / ids check against the CPU oracle missed its bar (parity_ok: false)\n")
+        raise SystemExit(4)
 
 
 if __name__ == "__main__":

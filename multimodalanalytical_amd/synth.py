@@ -75,9 +75,10 @@ def executed_flops_per_sample(cfg, S, T, V, enc_live=None, enc_live_sq=None) -> 
       executed  the algorithmic count + the products the attention BACKWARD recomputes: the two backward kernels evaluate 7 products
                 of S x S x dh per head where the algorithm has 4 (Q K^T and dO V^T once more in each of them minus the shared one),
                 so an attention instance costs 9 products per layer instead of 6.
-      live      the same with the padded encoder positions left out wherever the kernels leave them out ("Padded
-                batches"): the forward computes every position (the reference returns their hidden states) but only LIVE keys;
-                the backward touches live rows only.  enc_live = mean live encoder length, enc_live_sq = mean of its square."""
+      live      the same over the LIVE encoder positions only: the work a training step cannot leave out.  Since round 6 both
+                directions leave padded rows out (the forward in whole 256-row groups after per-sample compaction, the
+                backward in 64-row blocks / 256-row tiles), so what the kernels execute lies between `live` and `executed`.
+                enc_live = mean live encoder length, enc_live_sq = mean of its square."""
     d, g = cfg["d_model"], (6 if cfg["gated_linear"] else 4)
     fe, fd, Le, Ld = cfg["encoder_ffn_dim"], cfg["decoder_ffn_dim"], cfg["encoder_layers"], cfg["decoder_layers"]
     alg = train_flops_per_sample(cfg, S, T, V)
@@ -85,8 +86,8 @@ def executed_flops_per_sample(cfg, S, T, V, enc_live=None, enc_live_sq=None) -> 
     out = {"algorithmic": alg, "executed": alg + extra}
     if enc_live is not None:
         s1, s2 = float(enc_live), float(enc_live_sq if enc_live_sq is not None else enc_live * enc_live)
-        fwd = Le * (8 * S * d * d + 4 * S * s1 * d + g * S * d * fe) + \
-            Ld * (12 * T * d * d + 4 * S * d * d + 4 * T * T * d + 4 * T * s1 * d + g * T * d * fd) + 2 * T * d * V
+        fwd = Le * (8 * s1 * d * d + 4 * s2 * d + g * s1 * d * fe) + \
+            Ld * (12 * T * d * d + 4 * s1 * d * d + 4 * T * T * d + 4 * T * s1 * d + g * T * d * fd) + 2 * T * d * V
         bwd_gemm = 2 * (Le * (8 * s1 * d * d + g * s1 * d * fe) + Ld * (12 * T * d * d + 4 * s1 * d * d + g * T * d * fd) + 2 * T * d * V)
         bwd_attn = Le * 7 * 2 * s2 * d + Ld * 7 * (2 * T * T * d + 2 * T * s1 * d)
         out["live"] = fwd + bwd_gemm + bwd_attn
