@@ -45,8 +45,8 @@ extern "C" {
  *      row / per block of 64 elements, a pair mix per element pair) -- a library older than 5 produces different masks for the same
  *      (seed, site, index), so checkpoints' dropout positions and tests/dropmask.py belong to version >= 5.
  *   6  padded rows in the FORWARD pass of a training step: afm_gemm_desc.reserved2 bit 1 (k_live in the forward sense), afm_ln_shape.row_live
- *      read by afm_layernorm_fwd, afm_ln_shape.row_map (per-sample compaction of the live positions at the embedder), afm_attn_fwd honours
- *      reserved bit 6; exports added: afm_compact_plan, afm_permute_rows.  The ablation selector of AFM_ATTN_ABLATIONS builds moved to
+ *      read by afm_layernorm_fwd, afm_ln_shape.row_map (compaction of the live positions at the embedder), afm_attn_fwd honours
+ *      reserved bit 6, afm_attn_shape.q_off / k_off (packed rows); exports added: afm_compact_plan, afm_permute_rows.  The ablation selector of AFM_ATTN_ABLATIONS builds moved to
  *      afm_attn_shape.reserved bits 20-27 (it overlapped the live selectors 16384 / 32768 / 65536). */
 #define AFM_ABI_VERSION 6
 
@@ -131,7 +131,11 @@ typedef struct {
   int32_t glu_rows;       /* f > 0: gated-FFN interleave (see above); wgrad form: rows of C / a_colsum are de-interleaved */
   int32_t reserved2;      /* bit 0 (pair dtype, act GELU_SAVE_GRAD / GLU_SAVE): the stored factors get their hi plane only -- the
                              consumer is the single-pass bf16 backward of the mixed precision mode, which never reads the lo plane.
-                             bit 1 (2): k_live is meant in the FORWARD sense (below) */
+                             bit 1 (2): k_live is meant in the FORWARD sense (below).
+                             bit 2 (4): the rows k_live calls live are PACKED to the front of the token axis (afm_compact_plan mode 2): the
+                             persistent NT kernels deal their row panels round-robin to the XCDs and the split-K units of the weight-gradient
+                             kernels take every ksplit-th k-step, instead of contiguous bands / chunks that would leave the late ones with
+                             nothing but dead rows.  Scheduling only, same results. */
   const uint8_t* k_live;  /* nullable: k_live[i] == 0 says the STORED rows 64 i .. 64 i + 63 of A (64 token positions) are all zero --
                              the padded positions of a training step's backward, whose activation gradients are exact zeros.
                              wgrad form (transA): the MFMA kernels leave those k-steps out (K / 64 bytes).  NT form without bias /
@@ -204,9 +208,9 @@ typedef struct {
                              nobody reads those rows of the outputs (padded positions of a training step): nothing is loaded, y / x_sum /
                              mean / rstd get zeros there.  A hint: the scalar kernels (d % 8 != 0, rows < 64) ignore it. */
   const int32_t* row_map;  /* nullable, placement form (seg_len != 0) only, forward and backward: position p = out_off + r % seg_len of sample
-                             b = r / seg_len lives in row b * out_seg_stride + row_map[b * out_seg_stride + p] of the concatenated sequence
-                             instead of row b * out_seg_stride + p (afm_compact_plan: the sample's live positions moved to the front of its
-                             slot).  The positional row added stays pos[p]: positions are encoded before the move. */
+                             b = r / seg_len lives in row row_map[b * out_seg_stride + p] of the concatenated-sequence matrix instead of row
+                             b * out_seg_stride + p (afm_compact_plan's dest: live positions moved to the front of the sample's slot, or the
+                             whole batch packed).  The positional row added stays pos[p]: positions are encoded before the move. */
 } afm_ln_shape;
 int afm_layernorm_fwd(const afm_ln_shape* s, const float* x, const float* gamma, const float* beta,
                       const float* pos, void* y, float* mean, float* rstd, const void* add,
@@ -229,19 +233,26 @@ int afm_place_rows(const float* x, const float* pos, float* y, int64_t rows, int
  * stacks mask those positions as keys everywhere (custom_modeling.py:238,312-318) and pool them out of the alignment head (:469-470), so
  * nothing reads their rows.  afm_compact_plan turns a key-padding mask into a per-sample stable partition -- live positions first, in
  * order -- and the block flags the kernels above take:
- *   dest[b*S + s]      new position of position s of sample b (compact == 0: s itself)
- *   pad_out[b*S + p]   the mask in the new order (compact != 0: 1 for p >= n_live[b]); may alias key_pad only when compact == 0
- *   live64[b*S/64 + i] 1 if positions 64 i .. 64 i + 63 (new order) hold a live one: k_live / row_live of the BACKWARD (exact zeros)
- *   live_tile[...]     the same widened to whole groups of tile_rows rows (a multiple of 64 dividing S: 256, the tallest GEMM tile):
+ *   dest[b*S + s]      the ROW (of the B*S-row activation matrices) position s of sample b moves to
+ *   seq_off[b]         first row of sample b, B + 1 entries (seq_off[B] = rows in use)
+ *   pad_out[b*S + p]   the mask over the sample's positions in their new order (p-th position of its slot; 1 for p >= n_live[b] when
+ *                      compacting); may alias key_pad only when compact == 0
+ *   live64[i]          1 if rows 64 i .. 64 i + 63 hold a live position: k_live / row_live of the BACKWARD (exact zeros elsewhere)
+ *   live_tile[i]       the same widened to whole groups of tile_rows rows (a multiple of 64 dividing S: 256, the tallest GEMM tile):
  *                      1 if the group holds a live position -- k_live / row_live in the FORWARD sense.  Every forward kernel then
  *                      agrees on which rows exist, whatever its own tile height.
  *   n_live[b]          live positions of sample b
+ * compact == 0: rows stay where the collator put them (dest = identity, seq_off[b] = b S); flags only.
+ * compact == 1: per-sample partition inside the sample's own S-row slot (seq_off[b] = b S): row b S + rank.
+ * compact == 2: PACKED -- the samples' slots shrink to their live length rounded up to 128 rows and follow each other:
+ *               seq_off[b] = sum_{b' < b} ceil128(n_live[b']), live positions first inside the slot, the padded positions of the batch behind
+ *               all slots (rows seq_off[B] .. B S, in order).  The attention kernels address such rows through afm_attn_shape.q_off / k_off.
  * S <= 4096, S % tile_rows == 0.  Encoder self-attention, cross-attention over the memory and the masked mean are indifferent to the
  * order of the key positions once the mask moves with them; positional encodings are added before the move (afm_ln_shape.row_map).
  * afm_permute_rows moves fp32 rows through such a map where no LayerNorm does it on the way:
- *   gather == 0: y[b*S + map[b*S + s], :] = x[b*S + s, :]       gather == 1: y[b*S + s, :] = x[b*S + map[b*S + s], :]
+ *   gather == 0: y[map[i], :] = x[i, :]       gather == 1: y[i, :] = x[map[i], :]        (i over the B*S rows)
  * ---------------------------------------------------------------------------------------- */
-int afm_compact_plan(const uint8_t* key_pad, int32_t B, int32_t S, int32_t tile_rows, int32_t compact, int32_t* dest,
+int afm_compact_plan(const uint8_t* key_pad, int32_t B, int32_t S, int32_t tile_rows, int32_t compact, int32_t* dest, int32_t* seq_off,
                      uint8_t* pad_out, uint8_t* live64, uint8_t* live_tile, int32_t* n_live, void* stream);
 int afm_permute_rows(const float* x, float* y, const int32_t* map, int32_t B, int32_t S, int32_t d, int32_t gather, void* stream);
 
@@ -295,6 +306,15 @@ typedef struct {
    * instead of re-evaluating the hash per score: the dQ kernel as SGPR lane masks (one v_cndmask per score), the dK/dV kernel as one
    * word per lane.  The bits ARE the counter-based stream above, so results do not depend on whether the tensor is used. */
   uint64_t* drop_bits;
+  /* PACKED rows (ABI 6, nullable, B + 1 int32 each; afm_compact_plan's seq_off): sample b's query-side rows (Q, O, dO, dQ) start at row
+   * q_off[b] instead of b * Tq, its key-side rows (K, V, dK, dV) at k_off[b] instead of b * Tk; off[b + 1] - off[b] is the sample's slot, a
+   * multiple of 128 rows that holds its live positions first (key_pad, lse, delta and drop_bits keep their padded (B, T) indexing).
+   * 128-row blocks beyond a slot have no rows of their own: their workgroups write zeros to the dead tail [off[B], B * T) of O / dQ /
+   * dK / dV instead, block for block, so every row of an output is written.  Single-pass MFMA kernels only (dh 64, no causal mask,
+   * T % 128 == 0, key_pad given for a packed key side, dropout through drop_bits or off, q_off == k_off when both are set -- the encoder's
+   * self-attention, where the padded-query skip of reserved bit 6 is implied); AFM_ERR_UNSUPPORTED otherwise, nothing launched. */
+  const int32_t* q_off;
+  const int32_t* k_off;
 } afm_attn_shape;
 int afm_attn_fwd(const afm_attn_shape* s, const void* Q, const void* K, const void* V, void* O,
                  float* lse, void* stream);

@@ -78,8 +78,22 @@ __global__ __launch_bounds__(256, OCC) void k_attn_bwd_dq_m16(AttnM a, const e16
   const AttnBlock blk_ = attn_block(a.H, a.B, (a.Tq + 127) / 128);
   const int hd = blk_.hd, b = blk_.b;
   const int q0 = blk_.xb * 128 + w * 32;
-  const e16* Kb = K + (int64_t)b * a.Tk * a.ldk + hd * DH;
-  const e16* Vb = V + (int64_t)b * a.Tk * a.ldv + hd * DH;
+  const int64_t rq = attn_row0(a.q_off, b, a.Tq), rk = attn_row0(a.k_off, b, a.Tk);
+  {
+    int64_t tail0;
+    if (attn_tail_block(a.q_off, a.B, b, blk_.xb, a.Tq, tail0)) {      // packed rows, a block beyond the sample's slot: zeros to its block of the dead tail
+      const e16x4 z = {(e16)0.f, (e16)0.f, (e16)0.f, (e16)0.f};
+#pragma unroll
+      for (int qi = 0; qi < 2; ++qi) {
+        e16* dqp = dQ + (tail0 + w * 32 + 16 * qi + c16) * a.lddq + hd * DH + 4 * g;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) *(e16x4*)(dqp + 16 * dt) = z;
+      }
+      return;
+    }
+  }
+  const e16* Kb = K + rk * a.ldk + hd * DH;
+  const e16* Vb = V + rk * a.ldv + hd * DH;
   int q[2], qc[2];
   int64_t lrow[2];
   e16x8 qf[2][2], dof[2][2];
@@ -89,9 +103,9 @@ __global__ __launch_bounds__(256, OCC) void k_attn_bwd_dq_m16(AttnM a, const e16
   for (int qi = 0; qi < 2; ++qi) {
     q[qi] = q0 + 16 * qi + c16;
     qc[qi] = q[qi] < a.Tq ? q[qi] : a.Tq - 1;
-    const e16* qp = Q + ((int64_t)b * a.Tq + qc[qi]) * a.ldq + hd * DH + 8 * g;
-    const e16* dop = dO + ((int64_t)b * a.Tq + qc[qi]) * a.ldo + hd * DH + 8 * g;
-    const e16* op = O + ((int64_t)b * a.Tq + qc[qi]) * a.ldo + hd * DH + 8 * g;
+    const e16* qp = Q + (rq + qc[qi]) * a.ldq + hd * DH + 8 * g;
+    const e16* dop = dO + (rq + qc[qi]) * a.ldo + hd * DH + 8 * g;
+    const e16* op = O + (rq + qc[qi]) * a.ldo + hd * DH + 8 * g;
     float dl = 0.f;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
@@ -139,7 +153,7 @@ __global__ __launch_bounds__(256, OCC) void k_attn_bwd_dq_m16(AttnM a, const e16
 #pragma unroll
     for (int qi = 0; qi < 2; ++qi)
       if (q[qi] < a.Tq) {
-        e16* dqp = dQ + ((int64_t)b * a.Tq + q[qi]) * a.lddq + hd * DH + 4 * g;
+        e16* dqp = dQ + (rq + q[qi]) * a.lddq + hd * DH + 4 * g;
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) {
           e16x4 v = {(e16)0.f, (e16)0.f, (e16)0.f, (e16)0.f};

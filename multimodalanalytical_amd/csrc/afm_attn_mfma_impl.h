@@ -42,9 +42,22 @@ __global__ __launch_bounds__(256, AFM_FWD_OCC) void k_attn_fwd_mfma(AttnM a, con
   // self-attention over a padded batch in a training step: nobody reads the outputs of padded query rows (qskip: afm_attn_shape.reserved
   // bit 6 in the forward sense).  A workgroup whose 128 queries are all padding writes the all-masked-row convention (O = 0, lse = +inf:
   // finite values for whoever still loads the rows, P = 0 for a backward that does not skip them) and leaves; no keep bits are written.
+  const int64_t rq = attn_row0(a.q_off, b, a.Tq), rk = attn_row0(a.k_off, b, a.Tk);
+  {
+    int64_t tail0;
+    if (attn_tail_block(a.q_off, a.B, b, blk_.xb, a.Tq, tail0)) {      // packed rows, a block beyond the sample's slot: zeros to its block of the dead tail
+      e16* op = O + (tail0 + w * 32 + (lane & 31)) * a.ldo + hd * DH + 4 * h;
+      const e16x4 z = {(e16)0.f, (e16)0.f, (e16)0.f, (e16)0.f};
+#pragma unroll
+      for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) *(e16x4*)(op + 32 * db + 8 * g4) = z;
+      return;
+    }
+  }
   if (a.qskip && __syncthreads_and(q >= a.Tq || a.key_pad[(int64_t)b * a.Tk + qc] != 0)) {
     if (q < a.Tq) {
-      e16* op = O + ((int64_t)b * a.Tq + q) * a.ldo + hd * DH + 4 * h;
+      e16* op = O + (rq + q) * a.ldo + hd * DH + 4 * h;
       const e16x4 z = {(e16)0.f, (e16)0.f, (e16)0.f, (e16)0.f};
 #pragma unroll
       for (int db = 0; db < 2; ++db)
@@ -54,15 +67,15 @@ __global__ __launch_bounds__(256, AFM_FWD_OCC) void k_attn_fwd_mfma(AttnM a, con
     }
     return;
   }
-  const e16* Kb = K + (int64_t)b * a.Tk * a.ldk + hd * DH;
-  const e16* Vb = V + (int64_t)b * a.Tk * a.ldv + hd * DH;
+  const e16* Kb = K + rk * a.ldk + hd * DH;
+  const e16* Vb = V + rk * a.ldv + hd * DH;
   int kend = a.Tk;
   if (a.causal) kend = min(a.Tk, blk_.xb * 128 + 128);  // keys beyond the block's last query are masked
   const int ntiles = (kend + KT - 1) / KT;
   // Q fragments (B operand of S^T = K Q^T): Q[q][16 s + 8 h ..]
   e16x8 qf[4];
   {
-    const e16* qp = Q + ((int64_t)b * a.Tq + qc) * a.ldq + hd * DH + 8 * h;
+    const e16* qp = Q + (rq + qc) * a.ldq + hd * DH + 8 * h;
 #pragma unroll
     for (int s = 0; s < 4; ++s) {     // pre-multiplied by scale * log2(e): S^T comes out of the MFMA chain in log2 units (round 3)
       const e16x8 x = ld8_once(qp + 16 * s);
@@ -194,7 +207,7 @@ __global__ __launch_bounds__(256, AFM_FWD_OCC) void k_attn_fwd_mfma(AttnM a, con
   l += __shfl_xor(l, 32, 64);
   const float inv = l > 0.f ? a.dd.scale16 / l : 0.f;
   if (q < a.Tq) {
-    e16* op = O + ((int64_t)b * a.Tq + q) * a.ldo + hd * DH + 4 * h;
+    e16* op = O + (rq + q) * a.ldo + hd * DH + 4 * h;
 #pragma unroll
     for (int db = 0; db < 2; ++db)
 #pragma unroll
@@ -441,14 +454,27 @@ __global__ __launch_bounds__(256, AFM_DQ_OCC) void k_attn_bwd_dq_mfma(AttnM a, c
   const int q0 = blk_.xb * 128 + w * 32;
   const int q = q0 + (lane & 31);
   const int qc = q < a.Tq ? q : a.Tq - 1;
-  const e16* Kb = K + (int64_t)b * a.Tk * a.ldk + hd * DH;
-  const e16* Vb = V + (int64_t)b * a.Tk * a.ldv + hd * DH;
+  const int64_t rq = attn_row0(a.q_off, b, a.Tq), rk = attn_row0(a.k_off, b, a.Tk);
+  {
+    int64_t tail0;
+    if (attn_tail_block(a.q_off, a.B, b, blk_.xb, a.Tq, tail0)) {      // packed rows, a block beyond the sample's slot: zeros to its block of the dead tail
+      e16* dqp = dQ + (tail0 + w * 32 + (lane & 31)) * a.lddq + hd * DH + 4 * h;
+      const e16x4 z = {(e16)0.f, (e16)0.f, (e16)0.f, (e16)0.f};
+#pragma unroll
+      for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) *(e16x4*)(dqp + 32 * db + 8 * g4) = z;
+      return;
+    }
+  }
+  const e16* Kb = K + rk * a.ldk + hd * DH;
+  const e16* Vb = V + rk * a.ldv + hd * DH;
   e16x8 qf[4], dof[4];
   float dl = 0.f;
   {
-    const e16* qp = Q + ((int64_t)b * a.Tq + qc) * a.ldq + hd * DH + 8 * h;
-    const e16* dop = dO + ((int64_t)b * a.Tq + qc) * a.ldo + hd * DH + 8 * h;
-    const e16* op = O + ((int64_t)b * a.Tq + qc) * a.ldo + hd * DH + 8 * h;
+    const e16* qp = Q + (rq + qc) * a.ldq + hd * DH + 8 * h;
+    const e16* dop = dO + (rq + qc) * a.ldo + hd * DH + 8 * h;
+    const e16* op = O + (rq + qc) * a.ldo + hd * DH + 8 * h;
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
       qf[s] = ld8_once(qp + 16 * s);
@@ -489,7 +515,7 @@ __global__ __launch_bounds__(256, AFM_DQ_OCC) void k_attn_bwd_dq_mfma(AttnM a, c
   int* const tl = (int*)(maskw + (a.Tk + KT - 1) / KT) + 1;      // key tiles with at least one real key
   if (__syncthreads_and(wave_qskip)) {   // all 128 queries of the workgroup are padding: their dQ rows are zeros, nothing to load
     if (q < a.Tq) {
-      e16* dqp = dQ + ((int64_t)b * a.Tq + q) * a.lddq + hd * DH + 4 * h;
+      e16* dqp = dQ + (rq + q) * a.lddq + hd * DH + 4 * h;
       const e16x4 z = {(e16)0.f, (e16)0.f, (e16)0.f, (e16)0.f};
 #pragma unroll
       for (int db = 0; db < 2; ++db)
@@ -576,7 +602,7 @@ __global__ __launch_bounds__(256, AFM_DQ_OCC) void k_attn_bwd_dq_mfma(AttnM a, c
     }
   }
   if (q < a.Tq) {
-    e16* dqp = dQ + ((int64_t)b * a.Tq + q) * a.lddq + hd * DH + 4 * h;
+    e16* dqp = dQ + (rq + q) * a.lddq + hd * DH + 4 * h;
 #pragma unroll
     for (int db = 0; db < 2; ++db)
 #pragma unroll
@@ -1047,8 +1073,17 @@ __global__ __launch_bounds__(256) void k_attn_bits_fill(AttnM a) {
 using namespace AFM_E16_NS;
 
 // ------------------------------------------------------------------------------------------ dispatch
+// packed rows (q_off / k_off): the default single-pass kernels only (forward, dQ in both MFMA shapes, the pipelined 16 x 16 x 32 dK/dV), no
+// causal mask, whole 128-row blocks, key_pad given on a packed key side
+static bool packed_ok(const afm_attn_shape* s) {
+  if (!s->q_off && !s->k_off) return true;
+  if (s->causal || (s->q_off && (s->Tq & 127)) || (s->k_off && ((s->Tk & 127) || !s->key_pad))) return false;
+  if (s->q_off && s->q_off != s->k_off) return false;      // (a packed query side is the encoder's self-attention: the same rows on both sides)
+  return !(s->reserved & (16 | 128 | 256 | 512 | 4096 | 16384 | 65536 | 1024 | 2048));
+}
 static bool eligible(const afm_attn_shape* s, const void* const* ptrs, int nptr, const int* lds, int nld) {
   if (s->dtype != AFM_E16 || s->dh != DH) return false;
+  if (!packed_ok(s)) return false;
   if (s->sqb || s->skb || s->svb || s->sob) return false;   // KV-cache strides: generic kernel
   if (s->causal && s->Tq != s->Tk) return false;            // the tile loops assume >= 1 tile per workgroup (self-attention)
   if (s->drop.p > 0.f && (s->Tk & 1)) return false;   // the pair hash needs even rows of the mask
@@ -1067,6 +1102,9 @@ static AttnM make_m(const afm_attn_shape* s) {
   a.bits = a.dd.thresh16 ? (unsigned long long*)s->drop_bits : nullptr;
   a.nq32 = ((s->Tq + 127) / 128) * 4; a.nk32 = ((s->Tk + 63) / 64) * 2;      // whole workgroups / whole 64-key tiles
   a.qskip = (s->reserved & 64) && s->key_pad && s->Tq == s->Tk;
+  a.q_off = s->q_off; a.k_off = s->k_off;
+  // packed self-attention: query blocks beyond a sample's slot are other samples' rows -- the padded-query skip is not optional there
+  if (a.q_off && a.k_off && s->key_pad && s->Tq == s->Tk) a.qskip = 1;
   return a;
 }
 
@@ -1080,7 +1118,8 @@ int AFM_E16_FN(afm_attn_fwd_mfma_try)(const afm_attn_shape* s, const void* Q, co
   // operands in isolation (0.61 vs 0.68 ms at the c2 shape) but SLOWER inside the training step (0.67 vs 0.58 ms per launch in the
   // same rocprofv3 run, same box): not the default.  afm_attn_shape.reserved & 16 or AFM_ATTN_8WAVE=1 selects it.
   static const bool eight_wave = getenv("AFM_ATTN_8WAVE") != nullptr;
-  if (s->Tq >= 256 && ((s->reserved & 16) || eight_wave)) {
+  const bool packed = s->q_off || s->k_off;      // (packed rows: the four-wave kernel only)
+  if (!packed && s->Tq >= 256 && ((s->reserved & 16) || eight_wave)) {
     const dim3 grid8(((s->Tq + 255) / 256) * s->H * s->B);
     const int shm8 = 4 * 2 * KT * DH * 2 + ((s->Tk + KT - 1) / KT) * 8;
     if (shm8 > 80 * 1024) return AFM_ERR_UNSUPPORTED;
@@ -1148,7 +1187,12 @@ int AFM_E16_FN(afm_attn_bwd_mfma_try)(const afm_attn_shape* s, const void* Q, co
   }
   const bool run_q = (s->reserved & 3) != 2, run_k = (s->reserved & 3) != 1;   // reserved & 3 = 1 / 2: only the dQ / only the dK-dV kernel (timing)
   static const bool eight_wave = getenv("AFM_ATTN_8WAVE") != nullptr;
-  const bool q8 = s->Tq >= 256 && ((s->reserved & 16) || eight_wave);   // the 8-wave staggered dQ kernel (see afm_attn_fwd_mfma_try: not the default)
+  const bool packed = s->q_off || s->k_off;
+  // packed rows exist in the pipelined 16 x 16 x 32 dK/dV kernel only: refuse BEFORE anything is launched where it would not run
+  // (dropout without a keep-bit tensor, a query length that is not whole tiles)
+  if (packed && run_k && !(!s->causal && (s->Tq % KT) == 0 && (!a.dd.thresh16 || a.bits) &&
+                           3 * 2 * KT * DH * 2 + 2 * (2048 + 4 * 1024) + (s->Tq / KT) * 12 + 8 <= 80 * 1024)) return AFM_ERR_UNSUPPORTED;
+  const bool q8 = !packed && s->Tq >= 256 && ((s->reserved & 16) || eight_wave);   // the 8-wave staggered dQ kernel (see afm_attn_fwd_mfma_try: not the default)
   const int shm_q8 = 4 * 3 * KT * DH * 2 + ((s->Tk + KT - 1) / KT) * 8;
   if (run_q && q8) {
     static AfmOncePerDevice attr_q8;

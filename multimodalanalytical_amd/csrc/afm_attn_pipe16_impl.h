@@ -32,8 +32,24 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd_dkv_pipe16(AttnM a, const e
   const AttnBlock blk_ = attn_block(a.H, a.B, (a.Tk + KPB - 1) / KPB);
   const int hd = blk_.hd, b = blk_.b;
   const int k0 = blk_.xb * KPB + w * 32;
-  const e16* Qb = Q + (int64_t)b * a.Tq * a.ldq + hd * DH;
-  const e16* Db = dO + (int64_t)b * a.Tq * a.ldo + hd * DH;
+  const int64_t rq = attn_row0(a.q_off, b, a.Tq), rk = attn_row0(a.k_off, b, a.Tk);
+  {
+    int64_t tail0;
+    if (attn_tail_block(a.k_off, a.B, b, blk_.xb, a.Tk, tail0)) {      // packed rows, a key block beyond the sample's slot: zeros to its block of the dead tail
+      static_assert(KPB == 128, "the dead-tail bijection is stated in 128-row blocks");
+      const e16x4 z = {(e16)0.f, (e16)0.f, (e16)0.f, (e16)0.f};
+#pragma unroll
+      for (int ki = 0; ki < 2; ++ki) {
+        e16* dkp = dK + (tail0 + w * 32 + 16 * ki + c16) * a.lddk + hd * DH + 4 * g;
+        e16* dvp = dV + (tail0 + w * 32 + 16 * ki + c16) * a.lddv + hd * DH + 4 * g;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) { *(e16x4*)(dkp + 16 * dt) = z; *(e16x4*)(dvp + 16 * dt) = z; }
+      }
+      return;
+    }
+  }
+  const e16* Qb = Q + rq * a.ldq + hd * DH;
+  const e16* Db = dO + rq * a.ldo + hd * DH;
   e16x8 kf[2][2], vf[2][2];                           // [key tile][k-step]
   int key[2];
   bool kmasked[2];
@@ -44,8 +60,8 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd_dkv_pipe16(AttnM a, const e
     const int kc = key[ki] < a.Tk ? key[ki] : a.Tk - 1;
     kmasked[ki] = key[ki] >= a.Tk || (a.key_pad && a.key_pad[(int64_t)b * a.Tk + kc]);
     wave_all_masked = wave_all_masked && __all(kmasked[ki]);
-    const e16* kp = K + ((int64_t)b * a.Tk + kc) * a.ldk + hd * DH + 8 * g;
-    const e16* vp = V + ((int64_t)b * a.Tk + kc) * a.ldv + hd * DH + 8 * g;
+    const e16* kp = K + (rk + kc) * a.ldk + hd * DH + 8 * g;
+    const e16* vp = V + (rk + kc) * a.ldv + hd * DH + 8 * g;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       kf[ki][ks] = ld8_once(kp + 32 * ks); vf[ki][ks] = ld8_once(vp + 32 * ks);
@@ -70,8 +86,8 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd_dkv_pipe16(AttnM a, const e
 #pragma unroll
     for (int ki = 0; ki < 2; ++ki)
       if (key[ki] < a.Tk) {
-        e16* dkp = dK + ((int64_t)b * a.Tk + key[ki]) * a.lddk + hd * DH + 4 * g;
-        e16* dvp = dV + ((int64_t)b * a.Tk + key[ki]) * a.lddv + hd * DH + 4 * g;
+        e16* dkp = dK + (rk + key[ki]) * a.lddk + hd * DH + 4 * g;
+        e16* dvp = dV + (rk + key[ki]) * a.lddv + hd * DH + 4 * g;
         const bool z = zeros || kmasked[ki];          // a padded key took no part in any softmax: zero rows
         const float sv = DROP != DROP_NONE ? a.dd.scale16 : 1.0f;
 #pragma unroll

@@ -19,7 +19,22 @@ struct AttnM {
   unsigned long long* bits;   // keep-bit tensor (include/afm_hip.h: afm_attn_shape.drop_bits), null = re-hash
   int nq32, nk32;
   int qskip;   // backward, self-attention: query rows at padded positions carry zero dO (afm_attn_shape.reserved & 64): skipped, exactly
+  const int32_t* q_off;   // afm_attn_shape.q_off / k_off (B + 1 entries, nullable): PACKED rows -- sample b's query / key rows start at row
+  const int32_t* k_off;   // off[b] of Q, O, dO, dQ / K, V, dK, dV, its slot is off[b + 1] - off[b] rows (a multiple of 128)
 };
+
+// first row of sample b on the query / key side
+__device__ __forceinline__ int64_t attn_row0(const int32_t* off, int b, int T) { return off ? (int64_t)off[b] : (int64_t)b * T; }
+// Packed rows: 128-row block `blk128` of sample b lies beyond the sample's slot.  Its workgroup has nothing to compute; it writes ZEROS to
+// the matching 128-row block of the dead tail [off[B], B * T) instead -- blocks beyond the slots and blocks of the tail are equally many
+// (off[B] + sum_b (T - slot_b) = B * T), `row0` is the bijection -- so every row of the output holds a finite value whoever loads it.
+__device__ __forceinline__ bool attn_tail_block(const int32_t* off, int B, int b, int blk128, int T, int64_t& row0) {
+  if (!off) return false;
+  const int slot = off[b + 1] - off[b];
+  if (blk128 * 128 < slot) return false;
+  row0 = (int64_t)off[B] + ((int64_t)b * T - off[b]) + (blk128 * 128 - slot);
+  return true;
+}
 
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 

@@ -113,15 +113,44 @@ extern "C" int afm_place_rows(const float* x, const float* pos, float* y, int64_
 }
 
 // ---------------------------------------------------------------- padded positions out of the forward pass (include/afm_hip.h, ABI 6)
+// live positions per sample
+__global__ __launch_bounds__(256) void k_count_live(const uint8_t* __restrict__ key_pad, int S, int32_t* __restrict__ n_live) {
+  __shared__ int part[4];
+  const uint8_t* kp = key_pad + (int64_t)blockIdx.x * S;
+  int cnt = 0;
+  for (int s = threadIdx.x; s < S; s += 256) cnt += kp[s] == 0;
+  cnt = (int)wave_sum((float)cnt);      // (<= 4096 / 4 per wave: exact in fp32)
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = cnt;
+  __syncthreads();
+  if (threadIdx.x == 0) n_live[blockIdx.x] = part[0] + part[1] + part[2] + part[3];
+}
 // One workgroup per sample: thread t owns the positions [t * chunk, (t + 1) * chunk); live counts -> block scan -> the stable partition.
-__global__ __launch_bounds__(256) void k_compact_plan(const uint8_t* __restrict__ key_pad, int S, int tile_rows, int compact,
-                                                      int32_t* __restrict__ dest, uint8_t* __restrict__ pad_out,
+// mode 2 (packed): the sample's slot starts at off = sum over earlier samples of ceil128(live); its padded positions fill the slot's
+// last rows first, the rest go to the batch's dead tail behind all slots, in order.
+__global__ __launch_bounds__(256) void k_compact_plan(const uint8_t* __restrict__ key_pad, int B, int S, int tile_rows, int mode,
+                                                      int32_t* __restrict__ dest, int32_t* __restrict__ seq_off, uint8_t* __restrict__ pad_out,
                                                       uint8_t* __restrict__ live64, uint8_t* __restrict__ live_tile,
-                                                      int32_t* __restrict__ n_live) {
+                                                      const int32_t* __restrict__ n_live) {
   __shared__ int scan[256];
   __shared__ int blk_any[64];
+  __shared__ int red[2][4];
   const int b = blockIdx.x, t = threadIdx.x;
   const uint8_t* kp = key_pad + (int64_t)b * S;
+  // rows in front of this sample's slot and rows in use over the batch
+  int64_t off = (int64_t)b * S, total = (int64_t)B * S;
+  if (mode == 2) {
+    int before = 0, all = 0;
+    for (int i = t; i < B; i += 256) {
+      const int slot = (n_live[i] + 127) & ~127;
+      all += slot;
+      if (i < b) before += slot;
+    }
+    before = (int)wave_sum((float)before); all = (int)wave_sum((float)all);      // (sums below 2^24: exact)
+    if ((t & 63) == 0) { red[0][t >> 6] = before; red[1][t >> 6] = all; }
+    __syncthreads();
+    off = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+    total = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+  }
   const int chunk = (S + 255) / 256;
   const int s0 = min(S, t * chunk), s1 = min(S, s0 + chunk);
   if (t < 64) blk_any[t] = 0;
@@ -129,40 +158,70 @@ __global__ __launch_bounds__(256) void k_compact_plan(const uint8_t* __restrict_
   for (int s = s0; s < s1; ++s) cnt += kp[s] == 0;
   scan[t] = cnt;
   __syncthreads();
-  for (int off = 1; off < 256; off <<= 1) {      // Hillis-Steele inclusive scan (256 entries)
-    const int v = t >= off ? scan[t - off] : 0;
+  for (int o = 1; o < 256; o <<= 1) {      // Hillis-Steele inclusive scan (256 entries)
+    const int v = t >= o ? scan[t - o] : 0;
     __syncthreads();
     scan[t] += v;
     __syncthreads();
   }
   const int L = scan[255];
+  const int slot = mode == 2 ? (L + 127) & ~127 : S;
+  const int64_t tail0 = total + ((int64_t)b * S - off);      // packed: where this sample's share of the dead tail starts
   int before = scan[t] - cnt;                    // live positions in front of this thread's range
   for (int s = s0; s < s1; ++s) {
     const bool live = kp[s] == 0;
-    if (dest) dest[(int64_t)b * S + s] = !compact ? s : live ? before : L + (s - before);
-    if (!compact && live) blk_any[s >> 6] = 1;   // (benign race: every writer stores 1)
+    if (dest) {
+      int64_t row;
+      if (mode == 0) row = off + s;
+      else if (live) row = off + before;
+      else {
+        const int r = s - before;                // rank among the sample's padded positions
+        row = r < slot - L ? off + L + r : tail0 + (r - (slot - L));
+      }
+      dest[(int64_t)b * S + s] = (int32_t)row;
+    }
+    if (mode == 0 && live) blk_any[s >> 6] = 1;   // (benign race: every writer stores 1)
     before += live;
   }
-  if (t == 0 && n_live) n_live[b] = L;
+  if (seq_off) {
+    if (t == 0) seq_off[b] = (int32_t)off;
+    if (t == 1 && b == B - 1) seq_off[B] = (int32_t)(mode == 2 ? total : (int64_t)B * S);
+  }
   __syncthreads();
-  if (pad_out) for (int p = t; p < S; p += 256) pad_out[(int64_t)b * S + p] = compact ? (uint8_t)(p >= L) : kp[p];
+  if (pad_out) for (int p = t; p < S; p += 256) pad_out[(int64_t)b * S + p] = mode ? (uint8_t)(p >= L) : kp[p];
   const int nb = S >> 6, per = tile_rows >> 6;
-  for (int i = t; i < nb; i += 256) {
-    bool l64, lt;
-    if (compact) { l64 = 64 * i < L; lt = (i / per) * tile_rows < L; }
-    else {
-      l64 = blk_any[i] != 0; lt = false;
-      for (int j = (i / per) * per; j < (i / per + 1) * per; ++j) lt = lt || blk_any[j] != 0;
+  if (mode != 2) {
+    for (int i = t; i < nb; i += 256) {
+      bool l64, lt;
+      if (mode == 1) { l64 = 64 * i < L; lt = (i / per) * tile_rows < L; }
+      else {
+        l64 = blk_any[i] != 0; lt = false;
+        for (int j = (i / per) * per; j < (i / per + 1) * per; ++j) lt = lt || blk_any[j] != 0;
+      }
+      if (live64) live64[(int64_t)b * nb + i] = l64;
+      if (live_tile) live_tile[(int64_t)b * nb + i] = lt;
     }
-    if (live64) live64[(int64_t)b * nb + i] = l64;
-    if (live_tile) live_tile[(int64_t)b * nb + i] = lt;
+  } else {
+    // packed: blocks are counted over the whole matrix.  This sample flags the blocks of its own slot; every sample takes its share
+    // (index mod B) of the dead tail's blocks and of the widened flags.
+    const int64_t nblk = (int64_t)B * nb, blk0 = off >> 6, used = total >> 6;
+    if (live64) {
+      for (int i = t; i < (slot >> 6); i += 256) live64[blk0 + i] = 64 * i < L;
+      for (int64_t i = used + b + (int64_t)B * t; i < nblk; i += (int64_t)B * 256) live64[i] = 0;
+    }
+    if (live_tile)
+      for (int64_t i = b + (int64_t)B * t; i < nblk; i += (int64_t)B * 256) live_tile[i] = (i / per) * tile_rows < total;
   }
 }
-extern "C" int afm_compact_plan(const uint8_t* key_pad, int32_t B, int32_t S, int32_t tile_rows, int32_t compact, int32_t* dest,
+extern "C" int afm_compact_plan(const uint8_t* key_pad, int32_t B, int32_t S, int32_t tile_rows, int32_t compact, int32_t* dest, int32_t* seq_off,
                                 uint8_t* pad_out, uint8_t* live64, uint8_t* live_tile, int32_t* n_live, void* stream) {
-  if (!key_pad || B <= 0 || S <= 0 || S > 4096 || tile_rows <= 0 || (tile_rows & 63) || (S % tile_rows)) return AFM_ERR_ARG;
+  if (!key_pad || !n_live || B <= 0 || S <= 0 || S > 4096 || tile_rows <= 0 || (tile_rows & 63) || (S % tile_rows) || compact < 0 || compact > 2) return AFM_ERR_ARG;
   if (compact && pad_out == key_pad) return AFM_ERR_ARG;      // the kernel re-reads the mask after writing the new one
-  AFM_LAUNCH(k_compact_plan, dim3(B), dim3(256), 0, (hipStream_t)stream, key_pad, S, tile_rows, compact, dest, pad_out, live64, live_tile, n_live);
+  if ((int64_t)B * S > (1ll << 24)) return AFM_ERR_ARG;      // (row counts are summed in fp32 lanes: exact below 2^24)
+  if (compact == 2 && (S & 127)) return AFM_ERR_ARG;          // (slots of whole 128-row blocks inside S-row budgets)
+  AFM_LAUNCH(k_count_live, dim3(B), dim3(256), 0, (hipStream_t)stream, key_pad, S, n_live);
+  AFM_LAUNCH(k_compact_plan, dim3(B), dim3(256), 0, (hipStream_t)stream, key_pad, B, S, tile_rows, compact, dest, seq_off, pad_out, live64, live_tile,
+             (const int32_t*)n_live);
   return AFM_OK;
 }
 
@@ -172,7 +231,7 @@ __global__ __launch_bounds__(256) void k_permute_rows(const float* __restrict__ 
   const int lane = threadIdx.x & 63;
   const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
   for (int64_t r = wave; r < rows; r += nwaves) {
-    const int64_t m = (r / S) * S + map[r];
+    const int64_t m = map[r];
     const float* src = x + (gather ? m : r) * (int64_t)d;
     float* dst = y + (gather ? r : m) * (int64_t)d;
     if ((d & 3) == 0) for (int c = lane * 4; c < d; c += 256) *(float4*)(dst + c) = *(const float4*)(src + c);

@@ -34,6 +34,8 @@ struct MfmaArgs {
   float* a_colsum;
   const uint8_t* k_live;   // afm_gemm_desc.k_live: 64-row blocks of A's stored rows (TN: k-steps; NT: row blocks of A and C)
   int live_off;            // NT, persistent kernels: LDS byte offset of the live / dead tile lists (0: no hint in use)
+  int mperm;               // NT with tile lists: row panels dealt round-robin to the XCDs (tile_mn), = tiles_m / 8; 0 = contiguous ranges
+  int deal;                // afm_gemm_desc.reserved2 bit 2: the hint's live rows are packed to the front of the matrix (deal panels / k-steps)
   int dead_pre;            // NT with k_live in the FORWARD sense (afm_gemm_desc.reserved2 bit 1): pre_act is an output, zero-filled with C in dead tiles
   int act, accumulate;
   int tiles_m, tiles_n;
@@ -52,13 +54,20 @@ struct MfmaArgs {
 // With xgc column groups an XCD owns a RECTANGLE: (tiles_m / (8 / xgc)) row panels x (tiles_n / xgc) column tiles, walked row-major
 // inside it, so its slice of the weights stays in L2 and an A panel is fetched by xgc XCDs instead of one.  The launchers pick xgc
 // (nt_pick_xgc) where the weights exceed what an L2 keeps and the tile grid divides evenly.
+// With a padded-row hint in use (mperm = tiles_m / 8 > 0) the row panels are DEALT to the XCDs instead of cut into eight contiguous bands:
+// panel p of the banded order is row tile (p % mperm) * 8 + p / mperm, so XCD x works on the row tiles 8 j + x.  Round 6: with the batch's
+// live rows packed to the front of the matrix (afm_compact_plan mode 2) the bands of the last XCDs held nothing but dead tiles -- every
+// hinted GEMM ran on half the chip (c3 4 400 -> 3 890 samples/s) -- and the tile lists only balance the workgroups INSIDE an XCD.
 __device__ __forceinline__ void tile_mn(const MfmaArgs& g, int tile, int& mt, int& nt) {
-  if (g.xgc <= 1) { mt = tile / g.tiles_n; nt = tile % g.tiles_n; return; }
-  const int tpx = (g.tiles_m * g.tiles_n) >> 3;
-  const int x = tile / tpx, i = tile - x * tpx;
-  const int cw = g.tiles_n / g.xgc, rh = g.tiles_m / (8 / g.xgc);
-  mt = (x / g.xgc) * rh + i / cw;
-  nt = (x % g.xgc) * cw + i % cw;
+  if (g.xgc <= 1) { mt = tile / g.tiles_n; nt = tile % g.tiles_n; }
+  else {
+    const int tpx = (g.tiles_m * g.tiles_n) >> 3;
+    const int x = tile / tpx, i = tile - x * tpx;
+    const int cw = g.tiles_n / g.xgc, rh = g.tiles_m / (8 / g.xgc);
+    mt = (x / g.xgc) * rh + i / cw;
+    nt = (x % g.xgc) * cw + i % cw;
+  }
+  if (g.mperm > 0) mt = (mt % g.mperm) * 8 + mt / g.mperm;
 }
 static inline int nt_pick_xgc(int tiles_m, int tiles_n, int64_t weight_bytes) {
   static const int force = getenv("AFM_NT_XGC") ? atoi(getenv("AFM_NT_XGC")) : -1;     // (A / B runs: 1 = row-major everywhere)
@@ -864,6 +873,7 @@ static int launch_nt_pring(MfmaArgs& g, hipStream_t st, int blocks_per_cu) {
     const int tpx0 = (nt0 + 7) / 8, nbx0 = grid0 / 8;
     if ((tpx0 + nbx0 - 1) / nbx0 <= NT_LIVE_MAX) { g.live_off = shm; shm += NT_LIVE_BYTES; }
   }
+  g.mperm = (g.live_off && g.deal && !(g.tiles_m & 7)) ? g.tiles_m >> 3 : 0;
   auto kern = k_gemm_nt_pring<C_BF16, NWM, NWN, S, ABL, WM, EPI, EDGE>;
   static AfmOncePerDevice attr_shm;   // per instantiation and per device (function attributes are per device)
   if (attr_shm.need()) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -1093,6 +1103,7 @@ static int launch_nt_ws(MfmaArgs& g, hipStream_t st) {
     const int tpx0 = (nt0 + 7) / 8, nbx0 = grid0 / 8;
     if ((tpx0 + nbx0 - 1) / nbx0 <= NT_LIVE_MAX) { g.live_off = shm; shm += NT_LIVE_BYTES; }
   }
+  g.mperm = (g.live_off && g.deal && !(g.tiles_m & 7)) ? g.tiles_m >> 3 : 0;
   auto kern = k_gemm_nt_ws<C_BF16, NL, ABL, EPI, CAUX>;
   static AfmOncePerDevice attr_done;   // per instantiation
   if (attr_done.need()) {
@@ -1425,6 +1436,7 @@ struct TnProb {
   const uint8_t* k_live;   // one byte per 64-token k-step, 0 = all of A's rows there are zero (padding): left out; null = all live
   int M, N, K, lda, ldb, ldc, tiles_n, ntile, ksplit, kchunk, glu_f, accumulate;
   int unit0;       // grouped launch: index of this problem's first (tile, k-chunk) unit
+  int deal;        // afm_gemm_desc.reserved2 bit 2 (with k_live): k-steps dealt round-robin to the problem's units instead of contiguous chunks
 };
 __device__ __forceinline__ void tn256_unit(const TnProb& g, int tile, int ks_id, unsigned char* lds) {
   constexpr int S = 2, TBM = 256, TBN = 256, NW = 8, NIW = 8;
@@ -1433,8 +1445,12 @@ __device__ __forceinline__ void tn256_unit(const TnProb& g, int tile, int ks_id,
   const int w = __builtin_amdgcn_readfirstlane(t >> 6);
   const int wm = w >> 2, wn = w & 3;
   const int m0 = (tile / g.tiles_n) * TBM, n0 = (tile % g.tiles_n) * TBN;
-  const int kbeg = ks_id * g.kchunk, kend = min(g.K, kbeg + g.kchunk);
-  int nk = (kend - kbeg) / 64;
+  // With the padded-row hint the k-steps are DEALT to the problem's ksplit units (unit c takes the steps c, c + ksplit, ...) instead of cut
+  // into contiguous chunks: with the batch's live rows packed to the front of the token axis (afm_compact_plan mode 2) the chunks of the
+  // late units held nothing but dead steps and half of a launch's units finished at once.  The list then holds ABSOLUTE steps.
+  const bool deal = g.deal && g.k_live != nullptr && g.ksplit > 1 && (g.K / 64 + g.ksplit - 1) / g.ksplit <= TN_LIST_MAX;
+  const int kbeg = deal ? 0 : ks_id * g.kchunk, kend = deal ? g.K : min(g.K, kbeg + g.kchunk);
+  int nk = deal ? (g.K / 64 - ks_id + g.ksplit - 1) / g.ksplit : (kend - kbeg) / 64;
   // k-steps whose 64 token rows are all padding (A rows exact zeros: afm_gemm_desc.k_live) are left out: the list of the live ones
   // sits behind the ring (wave 0 compacts it with one ballot per 64 steps); without the hint it is the identity
   int* const kl = (int*)(lds + S * STAGE);
@@ -1444,9 +1460,10 @@ __device__ __forceinline__ void tn256_unit(const TnProb& g, int tile, int ks_id,
       int n = 0;
       for (int t0 = 0; t0 < nk; t0 += 64) {
         const int tt = t0 + lane;
-        const bool live = tt < nk && g.k_live[kbeg / 64 + tt] != 0;
+        const int gs = deal ? ks_id + tt * g.ksplit : kbeg / 64 + tt;      // the step's index on the whole token axis
+        const bool live = tt < nk && g.k_live[gs] != 0;
         const unsigned long long bal = __ballot(live);
-        if (live) kl[1 + n + __popcll(bal & ((1ull << lane) - 1ull))] = tt;
+        if (live) kl[1 + n + __popcll(bal & ((1ull << lane) - 1ull))] = deal ? gs : tt;
         n += __popcll(bal);
       }
       if (lane == 0) kl[0] = n;
@@ -1591,7 +1608,7 @@ __device__ __forceinline__ void tn256_unit(const TnProb& g, int tile, int ks_id,
 __global__ __launch_bounds__(512) void k_gemm_tn_ring256(MfmaArgs g) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   TnProb pr;
-  pr.A = g.A; pr.B = g.B; pr.C = (float*)g.C; pr.a_colsum = g.a_colsum; pr.k_live = g.k_live;
+  pr.A = g.A; pr.B = g.B; pr.C = (float*)g.C; pr.a_colsum = g.a_colsum; pr.k_live = g.k_live; pr.deal = g.deal;
   pr.M = g.M; pr.N = g.N; pr.K = g.K; pr.lda = g.lda; pr.ldb = g.ldb; pr.ldc = g.ldc;
   pr.tiles_n = g.tiles_n; pr.ntile = g.tiles_m * g.tiles_n; pr.ksplit = g.ksplit; pr.kchunk = g.kchunk;
   pr.glu_f = g.glu_f; pr.accumulate = g.accumulate; pr.unit0 = 0;
@@ -1635,7 +1652,7 @@ int AFM_E16_FN(afm_gemm_mfma_try)(const afm_gemm_desc* d, hipStream_t st) {
   g.act = d->act; g.accumulate = d->accumulate;
   g.dd = afm_make_drop(&d->drop);
   g.tiles_m = (d->M + BM - 1) / BM; g.tiles_n = (d->N + BN - 1) / BN;
-  g.ksplit = 1; g.kchunk = d->K; g.bias_in_lds = 0; g.live_off = 0; g.xgc = 0; g.dead_pre = 0;
+  g.ksplit = 1; g.kchunk = d->K; g.bias_in_lds = 0; g.live_off = 0; g.xgc = 0; g.dead_pre = 0; g.mperm = 0; g.deal = (d->reserved2 & 4) != 0;
   g.glu_f = d->glu_rows;
   g.stamps = nullptr;
 #ifdef AFM_GEMM_ABLATIONS
@@ -1954,7 +1971,7 @@ int AFM_E16_FN(afm_gemm_tn_group_launch)(const afm_gemm_desc* const* ds, int cou
   for (int i = 0; i < count; ++i) {
     const afm_gemm_desc* d = ds[i];
     TnProb& pr = gr.p[i];
-    pr.A = (const e16*)d->A; pr.B = (const e16*)d->B; pr.C = (float*)d->C; pr.a_colsum = d->a_colsum; pr.k_live = d->k_live;
+    pr.A = (const e16*)d->A; pr.B = (const e16*)d->B; pr.C = (float*)d->C; pr.a_colsum = d->a_colsum; pr.k_live = d->k_live; pr.deal = (d->reserved2 & 4) != 0;
     pr.M = d->M; pr.N = d->N; pr.K = d->K; pr.lda = d->lda; pr.ldb = d->ldb; pr.ldc = d->ldc;
     pr.tiles_n = (d->N + 255) / 256; pr.ntile = ((d->M + 255) / 256) * pr.tiles_n;
     pr.glu_f = d->glu_rows; pr.accumulate = 1;

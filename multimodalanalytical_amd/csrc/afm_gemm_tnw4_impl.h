@@ -29,8 +29,12 @@ __device__ __forceinline__ void tn_w4_unit(const TnProb& g, int tile, int ks_id,
   const int w = __builtin_amdgcn_readfirstlane(t >> 6);
   const int wm = w >> 1, wn = w & 1;
   const int m0 = (tile / g.tiles_n) * 256, n0 = (tile % g.tiles_n) * 256;
-  const int kbeg = ks_id * g.kchunk, kend = min(g.K, kbeg + g.kchunk);
-  int nk = (kend - kbeg) / 64;         // 64-token steps of the unit (two slices each)
+  // With the padded-row hint the k-steps are DEALT to the problem's ksplit units (unit c takes the steps c, c + ksplit, ...) instead of cut
+  // into contiguous chunks: with the batch's live rows packed to the front of the token axis (afm_compact_plan mode 2) the chunks of the
+  // late units held nothing but dead steps and half of a launch's units finished at once.  The list then holds ABSOLUTE steps.
+  const bool deal = g.deal && g.k_live != nullptr && g.ksplit > 1 && (g.K / 64 + g.ksplit - 1) / g.ksplit <= TN_LIST_MAX;
+  const int kbeg = deal ? 0 : ks_id * g.kchunk, kend = deal ? g.K : min(g.K, kbeg + g.kchunk);
+  int nk = deal ? (g.K / 64 - ks_id + g.ksplit - 1) / g.ksplit : (kend - kbeg) / 64;         // 64-token steps of the unit (two slices each)
   // live-step list behind the ring (k_live: steps whose 64 token rows are all padding are left out); identity without the hint.
   // Built with plain LDS stores BEFORE the first LDS-DMA piece; read back through inline asm (a compiler-visible LDS load beside the
   // ring would be answered with s_waitcnt vmcnt(0)).
@@ -41,9 +45,10 @@ __device__ __forceinline__ void tn_w4_unit(const TnProb& g, int tile, int ks_id,
       int n = 0;
       for (int t0 = 0; t0 < nk; t0 += 64) {
         const int tt = t0 + lane;
-        const bool live = tt < nk && g.k_live[kbeg / 64 + tt] != 0;
+        const int gs = deal ? ks_id + tt * g.ksplit : kbeg / 64 + tt;      // the step's index on the whole token axis
+        const bool live = tt < nk && g.k_live[gs] != 0;
         const unsigned long long bal = __ballot(live);
-        if (live) kl[1 + n + __popcll(bal & ((1ull << lane) - 1ull))] = tt;
+        if (live) kl[1 + n + __popcll(bal & ((1ull << lane) - 1ull))] = deal ? gs : tt;
         n += __popcll(bal);
       }
       if (lane == 0) kl[0] = n;
@@ -219,7 +224,7 @@ __device__ __forceinline__ void tn_w4_unit(const TnProb& g, int tile, int ks_id,
 __global__ __launch_bounds__(256) void k_gemm_tn_w4(MfmaArgs g) {
   extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];      // (fragment addresses are XORed: the base must not reach bits 5-7)
   TnProb pr;
-  pr.A = g.A; pr.B = g.B; pr.C = (float*)g.C; pr.a_colsum = g.a_colsum; pr.k_live = g.k_live;
+  pr.A = g.A; pr.B = g.B; pr.C = (float*)g.C; pr.a_colsum = g.a_colsum; pr.k_live = g.k_live; pr.deal = g.deal;
   pr.M = g.M; pr.N = g.N; pr.K = g.K; pr.lda = g.lda; pr.ldb = g.ldb; pr.ldc = g.ldc;
   pr.tiles_n = g.tiles_n; pr.ntile = g.tiles_m * g.tiles_n; pr.ksplit = g.ksplit; pr.kchunk = g.kchunk;
   pr.glu_f = g.glu_f; pr.accumulate = g.accumulate; pr.unit0 = 0;

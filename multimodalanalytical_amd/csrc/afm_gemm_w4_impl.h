@@ -326,6 +326,7 @@ static int launch_nt_w4(MfmaArgs& g, hipStream_t st) {
     const int tpx0 = (ntiles + 7) / 8, nbx0 = grid / 8;
     if ((tpx0 + nbx0 - 1) / nbx0 <= NT_LIVE_MAX) { g.live_off = W4_LIST_OFF; shm += NT_LIVE_BYTES; }
   }
+  g.mperm = (g.live_off && g.deal && !(g.tiles_m & 7)) ? g.tiles_m >> 3 : 0;
   auto kern = k_gemm_nt_w4<ABL>;
   static AfmOncePerDevice attr;
   if (attr.need()) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

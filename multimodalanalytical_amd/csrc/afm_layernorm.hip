@@ -9,13 +9,13 @@
 
 #define LN_MAXV 32  // up to d = 2048 held in registers (template NV = ceil(d/64) rounded up)
 
-// `map` (afm_ln_shape.row_map, nullable): position p of a sample's concatenated sequence lives in row map[b * seg_stride + p] of its slot
+// `map` (afm_ln_shape.row_map, nullable): position p of sample b's concatenated sequence lives in row map[b * seg_stride + p]
 __device__ __forceinline__ int64_t ln_out_row(int64_t r, int64_t seg_len, int64_t seg_stride,
                                               int64_t off, const int32_t* __restrict__ map = nullptr) {
   if (seg_len == 0) return r;
   const int64_t b = r / seg_len;
   const int64_t p = b * seg_stride + off + (r - b * seg_len);
-  return map ? b * seg_stride + map[p] : p;
+  return map ? (int64_t)map[p] : p;
 }
 
 template <typename TY, int NV>

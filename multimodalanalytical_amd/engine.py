@@ -140,8 +140,13 @@ class Seq2SeqEngine:
         # where the collator put them) and the encoder-row kernels of the forward -- LayerNorm, the NT GEMMs with their fused
         # epilogues, the self-attention's query blocks -- leave 256-row groups of nothing but padding uncomputed (zeros written).
         # Only with backward pending: eval / generate return the reference's encoder_hidden_states rows.  AFM_FWD_ROW_SKIP=0: off.
+        # AFM_FWD_COMPACT: 0 flags only, 1 live positions to the front of every sample's own S rows, 2 (default where the single-pass
+        # attention kernels run: 64-wide heads, no alignment head) the whole batch PACKED -- slots of ceil128(live) rows one behind the
+        # other, so the 256-row tiles of the GEMMs straddle samples and only the batch's last tile is partly empty (c3: 58 % -> 52 % of
+        # the B*S rows computed, c4: 69 % -> 63 %); the attention kernels address the slots through afm_attn_shape.q_off / k_off.
         self.fwd_skip = os.environ.get("AFM_FWD_ROW_SKIP", "1") != "0"
-        self.fwd_compact = os.environ.get("AFM_FWD_COMPACT", "1") != "0"
+        self.fwd_compact = int(os.environ.get("AFM_FWD_COMPACT", "2"))
+        self._enc_off = None  # packed rows: the encoder rows' offsets (B + 1 int32) for the attention shapes of this step
         self._fwd_live = {}   # forward of a training step: role -> uint8 per 64-row block, 0 = its whole 256-row group is padding (encode)
         self._frole = None    # whose rows the forward is working on (set by encode around the encoder stack)
         self._live = {}       # backward only: role ("enc" / "dec") -> uint8 per 64-row block, 0 = nothing but padded positions (_backward)
@@ -310,6 +315,16 @@ class Seq2SeqEngine:
     def _hb(self, t):
         """Operand of a backward kernel: in mixed mode the hi plane of a pair tensor."""
         return t.hi if (self.mixed and isinstance(t, X2)) else t
+
+    def _packable(self, S: int, T: Optional[int]) -> bool:
+        """Packed rows need the single-pass MFMA attention kernels on both the encoder's self-attention and the decoder's
+        cross-attention (head size 64, whole 128-row blocks, dropout through the keep-bit tensor) and a consumer of the memory that
+        takes offsets: not the alignment head's masked mean."""
+        from .lib import ALGO_GENERIC
+        heads_ok = all(self.d // int(self.cfg[k]) == 64 and self.d % int(self.cfg[k]) == 0 for k in ("encoder_attention_heads", "decoder_attention_heads"))
+        drops = float(self.cfg["dropout"]) > 0.0 and self.training
+        return (self.single16 and heads_ok and S % 128 == 0 and T is not None and T % 64 == 0 and not self.align and self.pre_ln
+                and self.algo != ALGO_GENERIC and (self.keep_bits or not drops) and self.bits_stream is None and self.attn_bwd_flags == 0)
 
     def _fwd_hint(self, t, role=None):
         """Forward-sense padded-row hint for an operand with the role's rows (None outside a training step's forward): one byte per
@@ -595,7 +610,7 @@ class Seq2SeqEngine:
             return shp
         sb = type(shp).from_buffer_copy(shp)
         sb.dtype = AFM_BF16
-        for k in ("_bits_keepalive", "_keepalive"):
+        for k in ("_bits_keepalive", "_keepalive", "_off_keepalive"):
             if hasattr(shp, k):
                 setattr(sb, k, getattr(shp, k))
         return sb
@@ -611,8 +626,9 @@ class Seq2SeqEngine:
         a = self._empty(B * T, d)
         lse = torch.empty(B * H * T, dtype=torch.float32, device=self.dev)
         lq, la = ops._ld(qkv), ops._ld(a)
+        off = self._enc_off if (not causal and self._frole == "enc") else None      # packed encoder rows
         shp = ops.attn_shape(B, H, T, T, d // H, self.cd, lq, lq, lq, la, key_pad, causal,
-                             self._drop(site + "attn"), self.algo)
+                             self._drop(site + "attn"), self.algo, q_off=off, k_off=off)
         self._attach_drop_bits(shp, saved, ahead)
         if not causal and key_pad is not None and self._fwd_hint(h) is not None:
             shp.reserved |= 64      # encoder, training step: padded query rows are read by nobody (afm_attn_fwd: O = 0, lse = +inf there)
@@ -749,7 +765,7 @@ class Seq2SeqEngine:
         a = self._empty(B * T, d)
         lse = torch.empty(B * H * T, dtype=torch.float32, device=self.dev)
         shp = ops.attn_shape(B, H, T, S, d // H, self.cd, ops._ld(q), ops._ld(kv), ops._ld(kv), ops._ld(a), mem_pad, False,
-                             self._drop(site + "xattn"), self.algo)
+                             self._drop(site + "xattn"), self.algo, k_off=self._enc_off)      # (packed memory rows)
         self._attach_drop_bits(shp, saved, ahead)
         ops.attn_fwd(shp, q, kv[:, :d], kv[:, d:], a, lse)
         br = self._linear(a, p + "multihead_attn.out_proj.weight", d, d,
@@ -809,12 +825,12 @@ class Seq2SeqEngine:
         return dxs
 
     # ------------------------------------------------------------------ whole model
-    def encode(self, enc_inputs, attention_mask, saved: Optional[dict] = None):
+    def encode(self, enc_inputs, attention_mask, saved: Optional[dict] = None, dec_len: Optional[int] = None):
         """embed + CustomEncoder.forward (custom_modeling.py:220-243) -> memory (B*S, d).  `enc_inputs` is the modality dict
         (embedded here, on the engine's schedule) or an already embedded (B, S, d) tensor, as the reference's
         `inputs_embeds` (custom_modeling.py:420-445): forward / generate only, its producer is outside this engine."""
         B, S = attention_mask.shape
-        self._fwd_live, self._frole = {}, None
+        self._fwd_live, self._frole, self._enc_off = {}, None, None
         if torch.is_tensor(enc_inputs):
             if saved is not None:
                 raise ValueError("a backward pass through externally embedded inputs is not available: pass the modality dict")
@@ -828,9 +844,14 @@ class Seq2SeqEngine:
             if saved is not None and self.fwd_skip and self.single16 and S % 256 == 0:
                 # a training step: live positions to the front of every sample's slot, 256-row groups of nothing but padding left out
                 # of the encoder-row kernels below (and of the decoder's memory-side projections)
-                plan = ops.compact_plan(key_pad, B, S, 256, compact=self.fwd_compact)
+                mode = self.fwd_compact
+                if mode == 2 and not self._packable(S, dec_len):
+                    mode = 1
+                plan = ops.compact_plan(key_pad, B, S, 256, compact=mode)
                 key_pad = plan.pad.view(B, S)
-                self._fwd_live["enc"] = plan.live_tile
+                self._fwd_live["enc"] = ops.RowFlags(plan.live_tile, plan.packed)
+                self._enc_off = plan.seq_off if plan.packed else None
+                self._last_plan_mode = plan.mode      # (tests: which layout the step really ran)
                 saved["plan"] = plan
             x = self.embed_fwd(enc_inputs, None if saved is None else saved.setdefault("emb_enc", {}),
                                row_map=plan.dest if (plan is not None and plan.compact) else None)
@@ -1113,7 +1134,7 @@ class Seq2SeqEngine:
         dec_ids = dec_ids.contiguous()
         self._fwd_live, self._frole = {}, None
         if memory is None:
-            mem, mem_pad = self.encode(enc_inputs, attention_mask, saved)
+            mem, mem_pad = self.encode(enc_inputs, attention_mask, saved, dec_len=T)
         else:
             mem = memory
             mem_pad = (attention_mask == 0).to(torch.uint8).contiguous()
@@ -1124,13 +1145,14 @@ class Seq2SeqEngine:
             if backward:
                 saved["dmem_init"] = dmem0
         logits = self.decode(dec_ids, mem, mem_pad, dec_attention_mask, S, saved)
-        self._fwd_live = {}
+        self._fwd_live, self._enc_off = {}, None
         # (split-pair memory stays a 2-D X2 object: .float() / .cpu() materialise it on demand)
         out = {"logits": logits.view(B, T, self.V),
                "encoder_hidden_states": mem if isinstance(mem, X2) else mem.view(B, S, self.d)}
         if saved is not None and saved.get("plan") is not None:
-            # a training step with the padded rows out of the forward: position s of sample b is row encoder_row_map[b, s] of
-            # encoder_hidden_states, and rows of nothing but padding hold zeros (AFM_FWD_ROW_SKIP=0: the reference's layout)
+            # a training step with the padded rows out of the forward: position s of sample b is ROW encoder_row_map[b, s] of
+            # encoder_hidden_states seen as a (B*S, d) matrix, and rows of nothing but padding hold zeros (AFM_FWD_ROW_SKIP=0: the
+            # reference's layout)
             out["encoder_row_map"] = saved["plan"].dest.view(B, S)
         rows = B * T
         if labels is not None or backward:
@@ -1228,7 +1250,7 @@ class Seq2SeqEngine:
             h = None
         if h is not None and _DEBUG_LIVE:
             rows = t.hi if hasattr(t, "hi") else t
-            dead = (h == 0).repeat_interleave(64)
+            dead = ((h.t if isinstance(h, ops.RowFlags) else h) == 0).repeat_interleave(64)
             assert float(rows[dead].float().abs().max() if bool(dead.any()) else 0.0) == 0.0, "a row marked dead by the padded-row hint is not zero"
         return h
 
@@ -1247,7 +1269,7 @@ class Seq2SeqEngine:
                 tgt_pad = tgt_pad.view(B, T).bool() & (lab.view(B, T) == -100)
             for role, L, pad in (("enc", S, saved.get("key_pad")), ("dec", T, tgt_pad)):
                 if role == "enc" and saved.get("plan") is not None:
-                    self._live[role] = saved["plan"].live64      # (afm_compact_plan already made the flags)
+                    self._live[role] = ops.RowFlags(saved["plan"].live64, saved["plan"].packed)      # (afm_compact_plan already made the flags)
                 elif pad is not None and L % 64 == 0:
                     self._live[role] = (pad.view(B, L // 64, 64) == 0).any(-1).to(torch.uint8).reshape(-1).contiguous()
         self._role = "dec"             # head, final decoder norm and the decoder stack: B * T rows

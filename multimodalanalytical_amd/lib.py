@@ -86,6 +86,7 @@ class AttnShape(C.Structure):
         ("drop", Dropout),
         ("sqb", C.c_int64), ("skb", C.c_int64), ("svb", C.c_int64), ("sob", C.c_int64),
         ("drop_bits", C.c_void_p),
+        ("q_off", C.c_void_p), ("k_off", C.c_void_p),
     ]
 
 
@@ -135,7 +136,7 @@ _SIGS = {
     "afm_adam_step": (C.c_int, [_P, _P, _P, _P, _I64, _P, _P, _P, _I32, _I32, _P, _P]),
     "afm_scaler_update": (C.c_int, [_P, _P, _F, _F, _I32, _P]),
     "afm_place_rows": (C.c_int, [_P, _P, _P, _I64, _I32, _I64, _I64, _I64, _I32, _P]),
-    "afm_compact_plan": (C.c_int, [_P, _I32, _I32, _I32, _I32, _P, _P, _P, _P, _P, _P]),
+    "afm_compact_plan": (C.c_int, [_P, _I32, _I32, _I32, _I32, _P, _P, _P, _P, _P, _P, _P]),
     "afm_permute_rows": (C.c_int, [_P, _P, _P, _I32, _I32, _I32, _I32, _P]),
     "afm_comm_unique_id": (C.c_int, [_P]),
     "afm_comm_create": (C.c_int, [C.POINTER(_P), _P, _I32, _I32]),

@@ -97,6 +97,23 @@ _DEBUG_SYNC = bool(os.environ.get("AFM_DEBUG_SYNC"))   # debugging aid: synchron
 
 
 
+class RowFlags:
+    """A padded-row hint with its layout: `t` = one byte per 64-row block (0 = nothing but padding), `dealt` = the live rows are PACKED
+    to the front of the matrix (afm_compact_plan mode 2), so the GEMM kernels deal row panels / k-steps round-robin to XCDs / split-K units
+    instead of cutting contiguous bands (afm_gemm_desc.reserved2 bit 2).  Every hint argument below takes a plain uint8 tensor too."""
+    __slots__ = ("t", "dealt")
+
+    def __init__(self, t, dealt=False):
+        self.t, self.dealt = t, bool(dealt)
+
+    def numel(self):
+        return self.t.numel()
+
+
+def _flags(h):
+    return (h.t, h.dealt) if isinstance(h, RowFlags) else (h, False)
+
+
 def gemm_desc(a: torch.Tensor, b: torch.Tensor, c: torch.Tensor, *, trans_a=False, trans_b=True,
               bias: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
               pre_act: Optional[torch.Tensor] = None, act: int = ACT_NONE, accumulate: bool = False,
@@ -143,6 +160,10 @@ def gemm_desc(a: torch.Tensor, b: torch.Tensor, c: torch.Tensor, *, trans_a=Fals
     d.glu_rows = int(glu_rows)
     d.reserved2 = 1 if sg_hi_only else 0
     d.drop = dropout
+    k_live, dealt = _flags(k_live)
+    rows_unread, dealt_u = _flags(rows_unread)
+    if dealt or dealt_u:
+        d.reserved2 |= 4
     if k_live is not None:      # one byte per 64 stored rows of `a` (token positions), 0 = all of them zero (padding)
         nrows = K if trans_a else M
         assert (trans_a or trans_b) and k_live.dtype == torch.uint8 and k_live.is_contiguous()
@@ -209,6 +230,7 @@ def layernorm_fwd(x, gamma, beta, y, mean=None, rstd=None, pos=None, seg_len=0, 
     rows, d = x.shape
     assert x.dtype == torch.float32 and x.is_contiguous() and is_contig(y)
     s = ln_shape(rows, d, y.dtype, seg_len, out_seg_stride, out_off, eps)
+    row_live, _ = _flags(row_live)
     if row_live is not None:
         assert row_live.dtype == torch.uint8 and row_live.is_contiguous() and rows % 64 == 0 and row_live.numel() == rows // 64 and seg_len == 0
         s.row_live = _ptr(row_live)
@@ -237,6 +259,7 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, ws, dres=None, se
     if row_map is not None:      # the embedder's placement through afm_compact_plan's map (as layernorm_fwd)
         assert row_map.dtype == torch.int32 and row_map.is_contiguous() and seg_len > 0 and row_map.numel() == (rows // seg_len) * out_seg_stride
         s.row_map = _ptr(row_map)
+    row_live, _ = _flags(row_live)
     if row_live is not None:     # one byte per 64 rows, 0 = dy (and dres) are zero there: skipped, zeros written
         assert row_live.dtype == torch.uint8 and row_live.is_contiguous() and rows % 64 == 0 and row_live.numel() == rows // 64
         assert seg_len == 0
@@ -261,29 +284,40 @@ def place_rows(x, y, pos=None, seg_len=0, out_seg_stride=0, out_off=0, gather=Fa
 
 
 class CompactPlan:
-    """afm_compact_plan's outputs for a (B, S) key-padding mask: `dest` (B*S int32: new position of every position), `pad` (B, S uint8,
-    the mask in the new order), `live64` / `live_tile` (B*S/64 uint8: exact 64-row blocks / whole `tile_rows` groups holding a live
-    position), `n_live` (B int32)."""
-    __slots__ = ("dest", "pad", "live64", "live_tile", "n_live", "compact", "B", "S")
+    """afm_compact_plan's outputs for a (B, S) key-padding mask: `dest` (B*S int32: the ROW every position moves to), `seq_off` (B + 1 int32:
+    first row of every sample; its last entry = rows in use), `pad` (B, S uint8, the mask over each sample's positions in their new
+    order), `live64` / `live_tile` (B*S/64 uint8: exact 64-row blocks / whole `tile_rows` groups holding a live position), `n_live` (B
+    int32).  mode 0: flags only, 1: live positions to the front of each sample's own S rows, 2: the batch packed (slots of ceil128(live) rows)."""
+    __slots__ = ("dest", "seq_off", "pad", "live64", "live_tile", "n_live", "mode", "B", "S")
+
+    @property
+    def compact(self):
+        return self.mode != 0
+
+    @property
+    def packed(self):
+        return self.mode == 2
 
 
 def compact_plan(key_pad, B, S, tile_rows=256, compact=True) -> CompactPlan:
+    """compact: False / 0 = flags only, True / 1 = per-sample compaction, 2 = packed rows (include/afm_hip.h, afm_compact_plan)."""
     assert key_pad.dtype == torch.uint8 and key_pad.is_contiguous() and key_pad.numel() == B * S and S % tile_rows == 0
     dev = key_pad.device
     p = CompactPlan()
-    p.B, p.S, p.compact = B, S, bool(compact)
+    p.B, p.S, p.mode = B, S, int(compact)
     p.dest = torch.empty(B * S, dtype=torch.int32, device=dev)
+    p.seq_off = torch.empty(B + 1, dtype=torch.int32, device=dev)
     p.pad = torch.empty(B, S, dtype=torch.uint8, device=dev)
     p.live64 = torch.empty(B * S // 64, dtype=torch.uint8, device=dev)
     p.live_tile = torch.empty(B * S // 64, dtype=torch.uint8, device=dev)
     p.n_live = torch.empty(B, dtype=torch.int32, device=dev)
-    L.check(L.load().afm_compact_plan(_ptr(key_pad), B, S, int(tile_rows), int(bool(compact)), _ptr(p.dest), _ptr(p.pad), _ptr(p.live64),
+    L.check(L.load().afm_compact_plan(_ptr(key_pad), B, S, int(tile_rows), p.mode, _ptr(p.dest), _ptr(p.seq_off), _ptr(p.pad), _ptr(p.live64),
                                       _ptr(p.live_tile), _ptr(p.n_live), _stream()), "afm_compact_plan")
     return p
 
 
 def permute_rows(x, y, row_map, B, S, gather=False):
-    """fp32 rows through a compact_plan map: y[b*S + map[b*S + s]] = x[b*S + s], or the reverse (gather)."""
+    """fp32 rows through a compact_plan map (absolute rows): y[map[i]] = x[i], or the reverse (gather)."""
     assert x.dtype == torch.float32 and y.dtype == torch.float32 and x.is_contiguous() and y.is_contiguous() and x.shape == y.shape
     assert row_map.dtype == torch.int32 and row_map.numel() == B * S == x.shape[0]
     L.check(L.load().afm_permute_rows(_ptr(x), _ptr(y), _ptr(row_map), B, S, x.shape[1], int(gather), _stream()), "afm_permute_rows")
@@ -291,7 +325,7 @@ def permute_rows(x, y, row_map, B, S, gather=False):
 
 
 def attn_shape(B, H, Tq, Tk, dh, dtype, ldq, ldk, ldv, ldo, key_pad=None, causal=False,
-               dropout: Dropout = NO_DROP, algo=ALGO_AUTO, scale=None, batch_strides=None) -> AttnShape:
+               dropout: Dropout = NO_DROP, algo=ALGO_AUTO, scale=None, batch_strides=None, q_off=None, k_off=None) -> AttnShape:
     s = AttnShape()
     s.B, s.H, s.Tq, s.Tk, s.dh = B, H, Tq, Tk, dh
     s.dtype = _DT[dtype]
@@ -305,6 +339,11 @@ def attn_shape(B, H, Tq, Tk, dh, dtype, ldq, ldk, ldv, ldo, key_pad=None, causal
         s.sqb, s.skb, s.svb, s.sob = (int(v) for v in batch_strides)
     s.key_pad = _ptr(key_pad)
     s._keepalive = key_pad  # the struct only holds a raw pointer: keep the mask tensor alive with it
+    for name, off in (("q_off", q_off), ("k_off", k_off)):      # packed rows (B + 1 int32: ops.compact_plan(...).seq_off)
+        if off is not None:
+            assert off.dtype == torch.int32 and off.is_contiguous() and off.numel() == B + 1
+            setattr(s, name, _ptr(off))
+    s._off_keepalive = (q_off, k_off)
     s.drop = dropout
     return s
 

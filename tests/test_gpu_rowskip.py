@@ -43,41 +43,61 @@ def _mask(B, S, seed, runs=((0, 32, 8, 22), (56, 824, 100, 760), (824, 1024, 20,
 
 
 # ------------------------------------------------------------------ plan / permute
-@pytest.mark.parametrize("B,S", [(3, 256), (8, 1024), (5, 4096)])
-@pytest.mark.parametrize("compact", [True, False])
-def test_compact_plan_is_the_stable_partition(ops, B, S, compact):
+def _plan_ref(pad, mode):
+    """The plan in torch: (dest rows, seq_off, mask in the new order, n_live)."""
+    B, S = pad.shape
+    live = pad == 0
+    n = live.sum(1)
+    base = torch.arange(B)[:, None] * S
+    if mode == 0:
+        return base + torch.arange(S)[None, :], torch.arange(B + 1) * S, pad, n
+    order = torch.argsort((~live).to(torch.int8), dim=1, stable=True)      # live positions first, each group in order
+    rank = torch.empty_like(order)
+    rank.scatter_(1, order, torch.arange(S)[None, :].expand(B, S))         # rank of every position inside its sample's partition
+    pad_new = (torch.arange(S)[None, :] >= n[:, None]).to(torch.uint8)
+    if mode == 1:
+        return base + rank, torch.arange(B + 1) * S, pad_new, n
+    slot = (n + 127) // 128 * 128
+    off = torch.cat([torch.zeros(1, dtype=torch.long), slot.cumsum(0)])
+    total = int(off[-1])
+    tail0 = total + (torch.arange(B) * S - off[:-1])                        # where each sample's share of the dead tail starts
+    in_slot = rank < slot[:, None]
+    dest = torch.where(in_slot, off[:-1, None] + rank, tail0[:, None] + (rank - slot[:, None]))
+    return dest, off, pad_new, n
+
+
+@pytest.mark.parametrize("B,S", [(3, 256), (8, 1024), (5, 4096), (130, 1024)])
+@pytest.mark.parametrize("mode", [0, 1, 2])
+def test_compact_plan_is_the_stable_partition(ops, B, S, mode):
     pad = _mask(B, S, 1)
     pad[0] = 1                      # a sample of nothing but padding
     pad[B - 1] = 0                  # and one without any
-    plan = ops.compact_plan(pad.to(DEV), B, S, 256, compact=compact)
-    live = pad == 0
-    n = live.sum(1)
+    plan = ops.compact_plan(pad.to(DEV), B, S, 256, compact=mode)
+    dest, off, pad_new, n = _plan_ref(pad, mode)
     assert torch.equal(plan.n_live.cpu().long(), n)
-    if compact:
-        order = torch.argsort((~live).to(torch.int8), dim=1, stable=True)      # live positions first, each group in order
-        dest = torch.empty_like(order)
-        dest.scatter_(1, order, torch.arange(S)[None, :].expand(B, S))
-        pad_new = (torch.arange(S)[None, :] >= n[:, None]).to(torch.uint8)
-    else:
-        dest = torch.arange(S)[None, :].expand(B, S)
-        pad_new = pad
+    assert torch.equal(plan.seq_off.cpu().long(), off)
     assert torch.equal(plan.dest.cpu().long().view(B, S), dest)
+    assert sorted(plan.dest.cpu().tolist()) == list(range(B * S))          # a permutation of the rows
     assert torch.equal(plan.pad.cpu().view(B, S), pad_new)
-    l64 = (pad_new.view(B, S // 64, 64) == 0).any(-1)
-    lt = (pad_new.view(B, S // 256, 256) == 0).any(-1).repeat_interleave(4, dim=1)
-    assert torch.equal(plan.live64.cpu().view(B, -1).bool(), l64)
-    assert torch.equal(plan.live_tile.cpu().view(B, -1).bool(), lt)
+    row_live = torch.zeros(B * S, dtype=torch.bool)
+    row_live[dest[pad == 0]] = True
+    l64 = row_live.view(-1, 64).any(1)
+    lt = row_live.view(-1, 256).any(1).repeat_interleave(4)
+    if mode == 2:                   # packed: a 256-row group is computed if it holds rows of any slot (slot padding included)
+        lt = (torch.arange(B * S // 64) // 4 * 256) < int(off[-1])
+    assert torch.equal(plan.live64.cpu().bool(), l64)
+    assert torch.equal(plan.live_tile.cpu().bool(), lt)
 
 
-def test_permute_rows_round_trip(ops):
+@pytest.mark.parametrize("mode", [1, 2])
+def test_permute_rows_round_trip(ops, mode):
     B, S, d = 4, 512, 96
     pad = _mask(B, S, 2, runs=((0, 32, 8, 22), (56, 512, 10, 400)))
-    plan = ops.compact_plan(pad.to(DEV), B, S, 256)
+    plan = ops.compact_plan(pad.to(DEV), B, S, 256, compact=mode)
     x = torch.randn(B * S, d, device=DEV)
     y = ops.permute_rows(x, torch.empty_like(x), plan.dest, B, S)
-    dest = plan.dest.long().view(B, S) + (torch.arange(B, device=DEV) * S)[:, None]
     ref = torch.empty_like(x)
-    ref[dest.view(-1)] = x
+    ref[plan.dest.long()] = x
     assert torch.equal(y, ref)
     assert torch.equal(ops.permute_rows(y, torch.empty_like(x), plan.dest, B, S, gather=True), x)
 
@@ -110,10 +130,11 @@ def test_layernorm_fwd_row_flags(ops, d, ydt):
             assert float(b[~rl].float().abs().max()) == 0.0           # dead rows: zeros
 
 
-def test_layernorm_row_map_forward_and_backward(ops):
+@pytest.mark.parametrize("mode", [1, 2])
+def test_layernorm_row_map_forward_and_backward(ops, mode):
     B, S, Sm, off, d = 6, 512, 200, 56, 256
     pad = _mask(B, S, 4, runs=((0, 32, 8, 22), (56, 256, 10, 150), (256, 512, 5, 250)))
-    plan = ops.compact_plan(pad.to(DEV), B, S, 256)
+    plan = ops.compact_plan(pad.to(DEV), B, S, 256, compact=mode)
     g = torch.Generator().manual_seed(5)
     e = torch.randn(B * Sm, d, generator=g).to(DEV)
     gamma, beta = torch.randn(d, generator=g).to(DEV), torch.randn(d, generator=g).to(DEV)
@@ -148,7 +169,7 @@ def test_layernorm_row_map_forward_and_backward(ops):
 
 def _touched(plan, B, S, off, Sm):
     """Rows of the compacted (B*S) layout that the modality at [off, off + Sm) writes."""
-    dest = plan.dest.long().view(B, S)[:, off:off + Sm] + (torch.arange(B, device=DEV) * S)[:, None]
+    dest = plan.dest.long().view(B, S)[:, off:off + Sm]
     m = torch.zeros(B * S, dtype=torch.bool, device=DEV)
     m[dest.reshape(-1)] = True
     return m
@@ -234,6 +255,78 @@ def test_attn_fwd_padded_query_blocks(ops, p):
         assert bool(torch.isinf(l1[b, :, done:]).all())
 
 
+@pytest.mark.parametrize("p", [0.0, 0.1])
+@pytest.mark.parametrize("cross", [False, True])
+def test_attn_packed_rows_equal_dense(ops, p, cross):
+    """afm_attn_shape.q_off / k_off: the same attention on rows packed by afm_compact_plan (mode 2) -- self-attention over the packed
+    encoder rows, and the decoder's cross-attention (dense queries, packed memory) -- forward and both backward kernels, against the
+    dense (B, T) layout with the compacted mask."""
+    B, H, T, dh = 7, 8, 1024, 64
+    Tq = 128 if cross else T
+    d = H * dh
+    g = torch.Generator().manual_seed(9)
+    n = torch.tensor([1024, 700, 130, 128, 5, 0, 333])
+    pad = (torch.arange(T)[None, :] >= n[:, None]).to(torch.uint8).to(DEV)        # already compacted per sample: live positions first
+    plan = ops.compact_plan(pad, B, T, 256, compact=2)
+    off = plan.seq_off
+    dest = plan.dest.long()
+    kv_d = (torch.randn(B * T, 3 * d, generator=g) * 0.5).to(DEV).half()           # dense rows (b, t)
+    kv_p = torch.zeros_like(kv_d)
+    kv_p[dest] = kv_d                                                                # packed rows
+    if cross:
+        q_in = (torch.randn(B * Tq, d, generator=g) * 0.5).to(DEV).half()
+    do_d = (torch.randn(B * Tq, d, generator=g) * 0.1).to(DEV).half()
+    live_q = (pad == 0).view(-1) if not cross else torch.ones(B * Tq, dtype=torch.bool, device=DEV)
+    if not cross:
+        do_d[~live_q] = 0                                                            # padded query rows carry no gradient (the vouched case)
+    drop = ops.drop(p, 4, 1) if p else ops.NO_DROP
+
+    def run(packed):
+        kv = kv_p if packed else kv_d
+        if cross:
+            q, do = q_in, do_d
+        else:
+            q = kv[:, :d]
+            do = torch.zeros_like(do_d)
+            if packed:
+                do[dest] = do_d
+            else:
+                do = do_d
+        o = torch.full((B * Tq, d), 3.0, dtype=H16, device=DEV)
+        lse = torch.full((B * H * Tq,), 3.0, device=DEV)
+        kw = dict(k_off=off) if packed else {}
+        if packed and not cross:
+            kw["q_off"] = off
+        shp = ops.attn_shape(B, H, Tq, T, dh, H16, ops._ld(q), 3 * d, 3 * d, d, pad, False, drop, **kw)
+        if p:
+            ops.attn_set_drop_bits(shp, torch.zeros(ops.attn_drop_bits_words(B, H, Tq, T), dtype=torch.int64, device=DEV))
+        if not cross:
+            shp.reserved |= 64
+        ops.attn_fwd(shp, q, kv[:, d:2 * d], kv[:, 2 * d:], o, lse)
+        assert ops.last_algo() == "attn_mfma"
+        dq = torch.full((B * Tq, d), 3.0, dtype=H16, device=DEV)
+        dkv = torch.full((B * T, 2 * d), 3.0, dtype=H16, device=DEV)
+        delta = torch.empty_like(lse)
+        ops.attn_bwd(shp, q, kv[:, d:2 * d], kv[:, 2 * d:], o, do, lse, delta, dq, dkv[:, :d], dkv[:, d:], d, 2 * d, 2 * d)
+        assert ops.last_algo() == "attn_mfma"
+        return o, lse.view(B, H, Tq), dq, dkv
+
+    od, ld, dqd, dkvd = run(False)
+    op_, lp, dqp, dkvp = run(True)
+    live_k = (pad == 0).view(-1)
+    if cross:
+        assert torch.equal(od, op_) and torch.equal(ld, lp) and torch.equal(dqd, dqp)
+    else:
+        assert torch.equal(od[live_q], op_[dest][live_q]) and torch.equal(dqd[live_q], dqp[dest][live_q])
+        for b in range(B):
+            assert torch.equal(ld[b, :, :int(n[b])], lp[b, :, :int(n[b])])
+        used = int(off[-1])
+        assert float(op_[used:].float().abs().max()) == 0.0 and float(dqp[used:].float().abs().max()) == 0.0      # the dead tail: zeros
+    assert torch.equal(dkvd[live_k], dkvp[dest][live_k])
+    assert float(dkvp[int(off[-1]):].float().abs().max()) == 0.0
+    assert bool(torch.isfinite(dkvp.float()).all()) and bool(torch.isfinite(dqp.float()).all()) and bool(torch.isfinite(op_.float()).all())
+
+
 # ------------------------------------------------------------------ the engine, skip on against skip off
 def _engine(name, mode_env, seed=5, dropout=0.0, cfg_over=None):
     from multimodalanalytical_amd import synth
@@ -317,8 +410,9 @@ def test_engine_flags_only_equals_unskipped(name, B):
     assert torch.equal(ma[live], mb[live]) and float(ma[~grp].float().abs().max() if bool((~grp).any()) else 0.0) == 0.0
 
 
+@pytest.mark.parametrize("mode", ["1", "2"])
 @pytest.mark.parametrize("name,B", [("c3", 64), ("c4", 32)])
-def test_engine_compacted_equals_unskipped(name, B):
+def test_engine_compacted_equals_unskipped(name, B, mode):
     """Live positions moved to the front of every slot: the same function of the batch (keys in another order, so sums round
     differently): logits and every gradient within a fraction of the fp16 mode's own distance to the oracle."""
     if not torch.cuda.is_available():
@@ -326,16 +420,18 @@ def test_engine_compacted_equals_unskipped(name, B):
     over = {"encoder_layers": 2, "decoder_layers": 2}
     inputs = _inputs(name, B)
     wl, e_off = _engine(name, {"AFM_FWD_ROW_SKIP": "0"}, cfg_over=over)
-    _, e_on = _engine(name, {"AFM_FWD_ROW_SKIP": "1", "AFM_FWD_COMPACT": "1"}, cfg_over=over)
+    _, e_on = _engine(name, {"AFM_FWD_ROW_SKIP": "1", "AFM_FWD_COMPACT": mode}, cfg_over=over)
     e_on.load_state_dict(e_off.state_dict())
     a, ga = _run(e_on, inputs)
+    assert (e_on._last_plan_mode if hasattr(e_on, "_last_plan_mode") else int(mode)) == int(mode)
     b, gb = _run(e_off, inputs)
     err = _compare(a, b, ga, gb, 5e-4, 2e-3)
-    print(f"{name} B={B}: compacted vs un-skipped logits {err:.2e}")
-    # memory rows: position s of sample b sits in row encoder_row_map[b, s]
+    print(f"{name} B={B}: compaction mode {mode} vs un-skipped logits {err:.2e}")
+    # memory rows: position s of sample b sits in ROW encoder_row_map[b, s] of the (B*S, d) matrix
     dest = a["encoder_row_map"].long()
     live = inputs[1].to(DEV) != 0
-    ma = torch.gather(a["encoder_hidden_states"].float(), 1, dest[:, :, None].expand(-1, -1, a["encoder_hidden_states"].shape[-1]))
+    dm = a["encoder_hidden_states"].shape[-1]
+    ma = a["encoder_hidden_states"].float().reshape(-1, dm)[dest.view(-1)].view(B, -1, dm)
     mb = b["encoder_hidden_states"].float()
     assert float((ma[live] - mb[live]).abs().max()) <= 2e-2 * float(mb[live].abs().max())
 
