@@ -135,7 +135,10 @@ typedef struct {
                              bit 2 (4): the rows k_live calls live are PACKED to the front of the token axis (afm_compact_plan mode 2): the
                              persistent NT kernels deal their row panels round-robin to the XCDs and the split-K units of the weight-gradient
                              kernels take every ksplit-th k-step, instead of contiguous bands / chunks that would leave the late ones with
-                             nothing but dead rows.  Scheduling only, same results. */
+                             nothing but dead rows.  Scheduling only, same results.
+                             bit 3 (8), with bit 1: the dead tiles of C (and of a stored pre_act) are NOT written -- the caller vouches that its
+                             buffers already hold finite values there (persistent buffers only these kernels ever write: stale rows of an earlier
+                             step), so the zero fill -- HBM writes for rows nobody reads -- is left out. */
   const uint8_t* k_live;  /* nullable: k_live[i] == 0 says the STORED rows 64 i .. 64 i + 63 of A (64 token positions) are all zero --
                              the padded positions of a training step's backward, whose activation gradients are exact zeros.
                              wgrad form (transA): the MFMA kernels leave those k-steps out (K / 64 bytes).  NT form without bias /
@@ -207,6 +210,9 @@ typedef struct {
                              zeros without reading anything and they add nothing to dgamma / dbeta.  Forward (ABI 6): row_live[i] == 0 says
                              nobody reads those rows of the outputs (padded positions of a training step): nothing is loaded, y / x_sum /
                              mean / rstd get zeros there.  A hint: the scalar kernels (d % 8 != 0, rows < 64) ignore it. */
+  int32_t flags;           /* bit 0 (forward, with row_live): the rows row_live calls dead are NOT written (no zeros): the caller's y / x_sum / mean /
+                             rstd already hold finite values there (a persistent buffer only these kernels ever write) */
+  int32_t reserved;
   const int32_t* row_map;  /* nullable, placement form (seg_len != 0) only, forward and backward: position p = out_off + r % seg_len of sample
                              b = r / seg_len lives in row row_map[b * out_seg_stride + p] of the concatenated-sequence matrix instead of row
                              b * out_seg_stride + p (afm_compact_plan's dest: live positions moved to the front of the sample's slot, or the
@@ -283,7 +289,8 @@ typedef struct {
                              key_pad marks (a training step's padded positions); the single-pass kernels then skip them -- dQ rows stay
                              zero, dK / dV lose exact zeros.  afm_attn_fwd (ABI 6), same condition: nobody reads the outputs of the query rows
                              key_pad marks; workgroups (128 queries) of nothing but such rows write O = 0, lse = +inf (the all-masked-row
-                             convention) and return.  bit 5 (32): forward reads drop_bits (afm_attn_drop_bits_fill ran before); bit 4 (16): the 8-wave staggered forms of the single-pass forward / dQ kernels (Tq >= 256), see DESIGN.md 4.
+                             convention) and return.  bit 17 (131072), afm_attn_fwd with q_off: the blocks beyond the slots write nothing to the dead
+                             tail of O (the caller's O already holds finite values there).  bit 5 (32): forward reads drop_bits (afm_attn_drop_bits_fill ran before); bit 4 (16): the 8-wave staggered forms of the single-pass forward / dQ kernels (Tq >= 256), see DESIGN.md 4.
                              afm_attn_bwd, dK/dV kernel selection (A / B tests; every form gives bit-identical dK / dV): bit 7 (128) the round-3
                              kernel instead of the software-pipelined one (csrc/afm_attn_pipe_impl.h: default where there is no causal mask, Tq % 64 == 0
                              and dropout runs through drop_bits or is off); bit 8 (256) its eight-wave form; bit 9 (512) its form with 64 keys per

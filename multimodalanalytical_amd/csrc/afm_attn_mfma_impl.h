@@ -46,6 +46,7 @@ __global__ __launch_bounds__(256, AFM_FWD_OCC) void k_attn_fwd_mfma(AttnM a, con
   {
     int64_t tail0;
     if (attn_tail_block(a.q_off, a.B, b, blk_.xb, a.Tq, tail0)) {      // packed rows, a block beyond the sample's slot: zeros to its block of the dead tail
+      if (a.nofill) return;
       e16* op = O + (tail0 + w * 32 + (lane & 31)) * a.ldo + hd * DH + 4 * h;
       const e16x4 z = {(e16)0.f, (e16)0.f, (e16)0.f, (e16)0.f};
 #pragma unroll
@@ -1103,6 +1104,7 @@ static AttnM make_m(const afm_attn_shape* s) {
   a.nq32 = ((s->Tq + 127) / 128) * 4; a.nk32 = ((s->Tk + 63) / 64) * 2;      // whole workgroups / whole 64-key tiles
   a.qskip = (s->reserved & 64) && s->key_pad && s->Tq == s->Tk;
   a.q_off = s->q_off; a.k_off = s->k_off;
+  a.nofill = (s->reserved & 131072) != 0;
   // packed self-attention: query blocks beyond a sample's slot are other samples' rows -- the padded-query skip is not optional there
   if (a.q_off && a.k_off && s->key_pad && s->Tq == s->Tk) a.qskip = 1;
   return a;

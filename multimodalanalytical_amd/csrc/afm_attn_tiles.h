@@ -21,6 +21,7 @@ struct AttnM {
   int qskip;   // backward, self-attention: query rows at padded positions carry zero dO (afm_attn_shape.reserved & 64): skipped, exactly
   const int32_t* q_off;   // afm_attn_shape.q_off / k_off (B + 1 entries, nullable): PACKED rows -- sample b's query / key rows start at row
   const int32_t* k_off;   // off[b] of Q, O, dO, dQ / K, V, dK, dV, its slot is off[b + 1] - off[b] rows (a multiple of 128)
+  int nofill;             // forward (afm_attn_shape.reserved bit 17): blocks without rows of their own write nothing (the caller's O is finite there)
 };
 
 // first row of sample b on the query / key side

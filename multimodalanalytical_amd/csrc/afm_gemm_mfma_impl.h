@@ -37,6 +37,7 @@ struct MfmaArgs {
   int mperm;               // NT with tile lists: row panels dealt round-robin to the XCDs (tile_mn), = tiles_m / 8; 0 = contiguous ranges
   int deal;                // afm_gemm_desc.reserved2 bit 2: the hint's live rows are packed to the front of the matrix (deal panels / k-steps)
   int dead_pre;            // NT with k_live in the FORWARD sense (afm_gemm_desc.reserved2 bit 1): pre_act is an output, zero-filled with C in dead tiles
+  int dead_nofill;         // ... reserved2 bit 3: dead tiles are not written at all (the caller's buffers hold finite values there already)
   int act, accumulate;
   int tiles_m, tiles_n;
   int xgc;             // persistent NT kernels: column groups of the XCD-aware tile walk (tile_mn below); 0 / 1 = row-major
@@ -653,7 +654,7 @@ __device__ __forceinline__ void nt_tile_lists(const MfmaArgs& g, int* list, int 
     if (lane == 0) { list[0] = nl; dead[0] = nd; }
   }
   __syncthreads();
-  const int nd = dead[0];
+  const int nd = g.dead_nofill ? 0 : dead[0];
   // columns of C one tile covers: the gated data-gradient form writes 2 x TBN interleaved columns, the gated forward forms TBN / 2
   constexpr bool GLU_F = EPI == EPI_GLU || EPI == EPI_GLU_SG, GLU_B = EPI == EPI_GLU_BWD;
   constexpr int EB = C16 ? 2 : 4, PER = 16 / EB;
@@ -1652,7 +1653,7 @@ int AFM_E16_FN(afm_gemm_mfma_try)(const afm_gemm_desc* d, hipStream_t st) {
   g.act = d->act; g.accumulate = d->accumulate;
   g.dd = afm_make_drop(&d->drop);
   g.tiles_m = (d->M + BM - 1) / BM; g.tiles_n = (d->N + BN - 1) / BN;
-  g.ksplit = 1; g.kchunk = d->K; g.bias_in_lds = 0; g.live_off = 0; g.xgc = 0; g.dead_pre = 0; g.mperm = 0; g.deal = (d->reserved2 & 4) != 0;
+  g.ksplit = 1; g.kchunk = d->K; g.bias_in_lds = 0; g.live_off = 0; g.xgc = 0; g.dead_pre = 0; g.dead_nofill = 0; g.mperm = 0; g.deal = (d->reserved2 & 4) != 0;
   g.glu_f = d->glu_rows;
   g.stamps = nullptr;
 #ifdef AFM_GEMM_ABLATIONS
@@ -1668,7 +1669,7 @@ int AFM_E16_FN(afm_gemm_mfma_try)(const afm_gemm_desc* d, hipStream_t st) {
       // pre_act) hold: they are written as zeros, whatever bias / activation / dropout the epilogue applies to the others
       if (d->residual || d->accumulate || !fill16 || (d->pre_act && (!aligned16(d->pre_act) || d->act == AFM_ACT_MUL_SAVED || d->act == AFM_ACT_GELU_BWD || d->act == AFM_ACT_GLU_BWD)))
         g.k_live = nullptr;
-      else g.dead_pre = d->pre_act != nullptr;
+      else { g.dead_pre = d->pre_act != nullptr; g.dead_nofill = (d->reserved2 & 8) != 0; }
     }
     else if (d->bias || d->residual || d->accumulate || (d->act != AFM_ACT_NONE && d->act != AFM_ACT_MUL_SAVED && d->act != AFM_ACT_GLU_BWD) ||
         (d->pre_act && d->act == AFM_ACT_NONE) || d->drop.p > 0.f || !fill16)

@@ -139,7 +139,7 @@ __global__ __launch_bounds__(256) void k_ln_fwd_vec(const float* x, const float*
                                                     int64_t rows, int d, float eps, const TA* __restrict__ add,
                                                     float* x_sum, DropDev adrop, const float* __restrict__ pos,
                                                     int64_t seg_len, int64_t seg_stride, int64_t off,
-                                                    const int32_t* __restrict__ map, const uint8_t* __restrict__ row_live) {
+                                                    const int32_t* __restrict__ map, const uint8_t* __restrict__ row_live, int nofill) {
   const int lane = threadIdx.x & 63;
   const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
@@ -183,13 +183,13 @@ __global__ __launch_bounds__(256) void k_ln_fwd_vec(const float* x, const float*
 #pragma unroll
       for (int i = 0; i < NC; ++i) {
         const int c = (lane + 64 * i) * 8;
-        if (c < d) {
+        if (c < d && !nofill) {      // (nofill: the caller's buffers already hold finite values in these rows, nothing is written)
           if (add) st8s(x_sum + r * (int64_t)d + c, z);
           st8s(y + r * (int64_t)(d * RowMul<TY>::v) + c, z, d);
         }
         cx[i] = nx[i]; ca[i] = na[i];
       }
-      if (lane == 0) {
+      if (lane == 0 && !nofill) {
         if (mean) mean[r] = 0.f;
         if (rstd) rstd[r] = 0.f;
       }
@@ -401,7 +401,7 @@ extern "C" int afm_layernorm_fwd(const afm_ln_shape* s, const float* x, const fl
     if (!fwd_forced) g = std::min<int64_t>((s->rows + 3) / 4, 256 * (s->d <= 512 ? 5 : s->d <= 1024 ? 3 : 1));
 #define LN_FV(TY, TA, NC) AFM_LAUNCH((k_ln_fwd_vec<TY, TA, NC>), dim3((int)g), dim3(256), 0, st, x, gamma, beta, (TY*)y, mean, \
                                      rstd, s->rows, s->d, s->eps, (const TA*)add, x_sum, adrop, pos, s->seg_len,   \
-                                     s->out_seg_stride, s->out_off, map, live)
+                                     s->out_seg_stride, s->out_off, map, live, (s->flags & 1) != 0)
 #define LN_FV2(TY, TA) do { if (s->d <= 512) LN_FV(TY, TA, 1); else if (s->d <= 1024) LN_FV(TY, TA, 2); else LN_FV(TY, TA, 4); } while (0)
     // the branch added in front of the norm has the dtype of the mode's activations or fp32
     if (s->y_dtype == AFM_BF16) { if (add_dtype == AFM_BF16) LN_FV2(bf16, bf16); else if (add_dtype == AFM_F32) LN_FV2(bf16, float); else return AFM_ERR_UNSUPPORTED; }

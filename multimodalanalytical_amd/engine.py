@@ -144,9 +144,24 @@ class Seq2SeqEngine:
         # attention kernels run: 64-wide heads, no alignment head) the whole batch PACKED -- slots of ceil128(live) rows one behind the
         # other, so the 256-row tiles of the GEMMs straddle samples and only the batch's last tile is partly empty (c3: 58 % -> 52 % of
         # the B*S rows computed, c4: 69 % -> 63 %); the attention kernels address the slots through afm_attn_shape.q_off / k_off.
-        self.fwd_skip = os.environ.get("AFM_FWD_ROW_SKIP", "1") != "0"
+        # AFM_FWD_ROW_SKIP: 1 on, 0 off, "auto" (default): on, but PROBED -- every 64th planned step (the first included) reads back how many
+        # rows the plan put in use (one int, one host synchronisation per 64 micro-batches); where that is more than 15/16 of B * S -- c2: the
+        # IR patches carry no padding, not one 256-row group is dead -- the next steps of that shape run without plan, hints and tile lists,
+        # which cost 0.6 % of the c2 step and had nothing to leave out.
+        _fs = os.environ.get("AFM_FWD_ROW_SKIP", "auto")
+        self.fwd_skip = _fs != "0"
+        self.fwd_skip_auto = _fs == "auto"
+        self._skip_probe: Dict[Any, list] = {}      # (B, S) -> [planned calls so far, skip is worth it]
         self.fwd_compact = int(os.environ.get("AFM_FWD_COMPACT", "2"))
         self._enc_off = None  # packed rows: the encoder rows' offsets (B + 1 int32) for the attention shapes of this step
+        # AFM_FWD_ARENA (default 1, packed rows only): the encoder-row activations of a training step's forward live in PERSISTENT buffers
+        # (one per layer and tensor, zero-filled when first allocated, written by nothing but these kernels).  The dead tail of every such
+        # tensor then already holds finite values -- zeros, or rows an earlier step computed -- so the forward kernels write NOTHING there
+        # (RowFlags.nofill) instead of zeros: the LayerNorm forward alone spent 40 % of its c3 time filling rows nobody reads.  The
+        # backward keeps its zero fills: ITS dead rows must be exact zeros for any consumer that runs without the hints.
+        self.fwd_arena = os.environ.get("AFM_FWD_ARENA", "1") != "0"
+        self._arena: Dict[str, torch.Tensor] = {}
+        self._arena_rows = 0  # > 0 while a packed training-step forward is under way: tensors of that many rows come from the arena
         self._fwd_live = {}   # forward of a training step: role -> uint8 per 64-row block, 0 = its whole 256-row group is padding (encode)
         self._frole = None    # whose rows the forward is working on (set by encode around the encoder stack)
         self._live = {}       # backward only: role ("enc" / "dec") -> uint8 per 64-row block, 0 = nothing but padded positions (_backward)
@@ -293,6 +308,19 @@ class Seq2SeqEngine:
     def _empty(self, rows, cols, dtype=None):
         return ops.empty(rows, cols, dtype or self.cd, self.dev)
 
+    def _fbuf(self, key: str, rows, cols=None, dtype=None):
+        """An encoder-row activation of the forward pass: from the persistent arena while a packed training step is under way (see
+        `fwd_arena`), else a fresh tensor.  cols = None: a vector of `rows` fp32 (LayerNorm statistics, lse)."""
+        dt = torch.float32 if cols is None else (dtype or self.cd)
+        if not (self._arena_rows and key is not None):
+            return torch.empty(rows, dtype=dt, device=self.dev) if cols is None else ops.empty(rows, cols, dt, self.dev)
+        shape = (rows,) if cols is None else (rows, cols)
+        t = self._arena.get(key)
+        if t is None or tuple(t.shape) != shape or t.dtype != dt:
+            t = torch.zeros(shape, dtype=dt, device=self.dev)
+            self._arena[key] = t
+        return t
+
     def _empty_b(self, rows, cols, dtype=None, like=None):
         """Backward-pass activation gradient.  `like`: a saved tensor read by the same GEMM epilogue as `pre_act` (which
         shares C's row stride): in mixed mode that is the hi plane of a pair tensor, so C gets the pair's row stride."""
@@ -336,11 +364,12 @@ class Seq2SeqEngine:
         return h
 
     def _linear(self, x, name, rows, cols, r0=0, r1=None, out=None, out_dtype=None, bias_name=None,
-                residual=None, dropout=ops.NO_DROP, act=ACT_NONE, pre_act=None, sg_hi_only=False, role=None):
+                residual=None, dropout=ops.NO_DROP, act=ACT_NONE, pre_act=None, sg_hi_only=False, role=None, key=None):
         w = self.W(name, rows, cols, r0, r1)
         n = w.shape[0]
         if out is None:
-            out = self._empty(x.shape[0], n, out_dtype)
+            arena = key is not None and self._arena_rows == x.shape[0] and (out_dtype or self.cd) == self.cd
+            out = self._fbuf(key, x.shape[0], n) if arena else self._empty(x.shape[0], n, out_dtype)
         bias = None
         if bias_name is not None:
             bias = self.ps.vec_span(self.ps.flat, bias_name, r0, r0 + n)
@@ -539,14 +568,15 @@ class Seq2SeqEngine:
         """y = LN(x + pend).  `pend` is the previous block's (dropped-out) branch output: the residual
         add is fused here, the summed stream is materialised once (fp32) and returned."""
         rows = x.shape[0]
-        y = self._empty(rows, self.d, out_dtype)
-        mean = torch.empty(rows, dtype=torch.float32, device=self.dev)
-        rstd = torch.empty(rows, dtype=torch.float32, device=self.dev)
+        ak = prefix if (self._arena_rows == rows and out_dtype is None and saved is not None) else None      # arena key (packed training step)
+        y = self._fbuf(ak and ak + "y", rows, self.d, out_dtype)
+        mean = self._fbuf(ak and ak + "mean", rows)
+        rstd = self._fbuf(ak and ak + "rstd", rows)
         if pend is not None:
             # `pend` = (branch, its dropout stream): the GEMM that produced the branch wrote it plain, the
             # dropout is applied here on the way into the stream (this kernel is HBM-bound, the hash is free)
             br, br_drop = pend if isinstance(pend, tuple) else (pend, ops.NO_DROP)
-            xs = torch.empty_like(x)   # x itself is the saved input of an earlier LayerNorm: keep it
+            xs = self._fbuf(ak and ak + "xs", rows, self.d, torch.float32)   # x itself is the saved input of an earlier LayerNorm: keep it
             ops.layernorm_fwd(x, self.ps.p(prefix + "weight"), self.ps.p(prefix + "bias"), y, mean, rstd,
                               add=br, x_sum=xs, add_dropout=br_drop, row_live=self._fwd_hint(x))
             x = xs
@@ -622,8 +652,9 @@ class Seq2SeqEngine:
         ahead = self._bits_ahead(B, H, T, T, site + "attn", saved)
         if h is None:
             h, x = self._ln_fwd(x, p + "norm1.", saved, "ln1", pend=pend)
-        qkv = self._linear(h, p + "self_attn.in_proj_weight", 3 * d, d, bias_name=p + "self_attn.in_proj_bias")
-        a = self._empty(B * T, d)
+        qkv = self._linear(h, p + "self_attn.in_proj_weight", 3 * d, d, bias_name=p + "self_attn.in_proj_bias", key=p + "qkv")
+        arena = self._arena_rows == B * T and not causal
+        a = self._fbuf(p + "a", B * T, d) if arena else self._empty(B * T, d)
         lse = torch.empty(B * H * T, dtype=torch.float32, device=self.dev)
         lq, la = ops._ld(qkv), ops._ld(a)
         off = self._enc_off if (not causal and self._frole == "enc") else None      # packed encoder rows
@@ -632,10 +663,12 @@ class Seq2SeqEngine:
         self._attach_drop_bits(shp, saved, ahead)
         if not causal and key_pad is not None and self._fwd_hint(h) is not None:
             shp.reserved |= 64      # encoder, training step: padded query rows are read by nobody (afm_attn_fwd: O = 0, lse = +inf there)
+            if arena and off is not None:
+                shp.reserved |= 131072      # ... and O is a persistent buffer: the dead tail is left as it is
         ops.attn_fwd(shp, qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], a, lse)
-        shp.reserved &= ~64         # (the backward sets its own sense of the bit)
+        shp.reserved &= ~(64 | 131072)      # (the backward sets its own sense of the bits)
         br = self._linear(a, p + "self_attn.out_proj.weight", d, d, bias_name=p + "self_attn.out_proj.bias",
-                          out_dtype=self.branch_dtype)
+                          out_dtype=self.branch_dtype, key=p + "sa_br")
         if saved is not None:
             saved["sa"] = (h, qkv, a, lse, shp)
         return x, (br, self._drop(site + "res"))
@@ -675,7 +708,8 @@ class Seq2SeqEngine:
             h, x = self._ln_fwd(x, p + norm, saved, "lnf", pend=pend)
         rows = h.shape[0]
         dr = self._drop(site + "ffn")
-        g = self._empty(rows, f)
+        arena = self._arena_rows == rows and saved is not None
+        g = self._fbuf(p + "ffn_g", rows, f) if arena else self._empty(rows, f)
         if self.act != "gelu":
             # activation "relu": the projection, then act(u) [* v] + dropout in one elementwise kernel (afm_glu_fwd with its
             # activation selector); the fused epilogues below are GELU's
@@ -685,7 +719,7 @@ class Seq2SeqEngine:
             # gelu(u) * v (+ dropout) in the epilogue of ONE GEMM over the interleaved [W1 ; Wg]; with backward pending the
             # epilogue stores keep*scale*[gelu'(u) v | gelu(u)] instead of u and v, so the data-gradient epilogue of the
             # down-projection is two multiplies and afm_glu_fwd / afm_glu_bwd drop out of the step
-            uv = self._empty(rows, 2 * f) if saved is not None else None
+            uv = (self._fbuf(p + "ffn_uv", rows, 2 * f) if arena else self._empty(rows, 2 * f)) if saved is not None else None
             ops.gemm(h, self.w_glu[p + "linear1.weight"], g, trans_b=True,
                      bias=self.ps.vec_span(self.ps.flat, p + "linear1.bias", 0, 2 * f),
                      act=ACT_GLU_SAVE if saved is not None else ACT_GLU, pre_act=uv, dropout=dr, algo=self.algo, glu_rows=f,
@@ -698,11 +732,11 @@ class Seq2SeqEngine:
             # also stores keep * scale * gelu'(u) (same keep bits), so the dgrad epilogue is one multiply.
             # (whole 256 x 256 tiles only: other shapes keep u and the GELU' epilogue)
             sg = saved is not None and self.lowp and rows % 256 == 0 and f % 256 == 0
-            uv = self._empty(rows, f) if saved is not None else None
+            uv = (self._fbuf(p + "ffn_uv", rows, f) if arena else self._empty(rows, f)) if saved is not None else None
             self._linear(h, p + "linear1.weight", f, d, out=g, bias_name=p + "linear1.bias",
                          act=ACT_GELU_SAVE_GRAD if sg else ACT_GELU, pre_act=uv, dropout=dr, sg_hi_only=self.mixed and sg)
             dr = (dr, sg)
-        br = self._linear(g, p + "linear2.weight", d, f, bias_name=p + "linear2.bias", out_dtype=self.branch_dtype)
+        br = self._linear(g, p + "linear2.weight", d, f, bias_name=p + "linear2.bias", out_dtype=self.branch_dtype, key=p + "ffn_br")
         if saved is not None:
             saved["ffn"] = (h, uv, g, dr)
         return x, (br, self._drop(site + "res2"))
@@ -761,7 +795,7 @@ class Seq2SeqEngine:
             h, x = self._ln_fwd(x, p + "norm2.", saved, "ln2", pend=pend)
         w, bname = p + "multihead_attn.in_proj_weight", p + "multihead_attn.in_proj_bias"
         q = self._linear(h, w, 3 * d, d, 0, d, bias_name=bname)
-        kv = self._linear(mem, w, 3 * d, d, d, 3 * d, bias_name=bname, role="enc")      # memory-side rows: encoder positions
+        kv = self._linear(mem, w, 3 * d, d, d, 3 * d, bias_name=bname, role="enc", key=p + "xkv")      # memory-side rows: encoder positions
         a = self._empty(B * T, d)
         lse = torch.empty(B * H * T, dtype=torch.float32, device=self.dev)
         shp = ops.attn_shape(B, H, T, S, d // H, self.cd, ops._ld(q), ops._ld(kv), ops._ld(kv), ops._ld(a), mem_pad, False,
@@ -830,7 +864,7 @@ class Seq2SeqEngine:
         (embedded here, on the engine's schedule) or an already embedded (B, S, d) tensor, as the reference's
         `inputs_embeds` (custom_modeling.py:420-445): forward / generate only, its producer is outside this engine."""
         B, S = attention_mask.shape
-        self._fwd_live, self._frole, self._enc_off = {}, None, None
+        self._fwd_live, self._frole, self._enc_off, self._arena_rows = {}, None, None, 0
         if torch.is_tensor(enc_inputs):
             if saved is not None:
                 raise ValueError("a backward pass through externally embedded inputs is not available: pass the modality dict")
@@ -841,7 +875,10 @@ class Seq2SeqEngine:
         else:
             key_pad = (attention_mask == 0).to(torch.uint8).contiguous()
             plan = None
-            if saved is not None and self.fwd_skip and self.single16 and S % 256 == 0:
+            probe = self._skip_probe.setdefault((B, S), [0, True]) if self.fwd_skip_auto else None
+            if probe is not None:
+                probe[0] += 1
+            if saved is not None and self.fwd_skip and self.single16 and S % 256 == 0 and (probe is None or probe[1] or probe[0] % 64 == 1):
                 # a training step: live positions to the front of every sample's slot, 256-row groups of nothing but padding left out
                 # of the encoder-row kernels below (and of the decoder's memory-side projections)
                 mode = self.fwd_compact
@@ -849,10 +886,18 @@ class Seq2SeqEngine:
                     mode = 1
                 plan = ops.compact_plan(key_pad, B, S, 256, compact=mode)
                 key_pad = plan.pad.view(B, S)
-                self._fwd_live["enc"] = ops.RowFlags(plan.live_tile, plan.packed)
+                # packed rows + arena: the forward kernels leave the dead tail unwritten (the unfused FFN forms write through kernels that
+                # take no hint: they stay on fresh tensors with the zero fill)
+                nofill = plan.packed and self.fwd_arena and self.act == "gelu" and (not self.gated or self._glu_fusable(B * S, int(self.cfg["encoder_ffn_dim"])))
+                self._arena_rows = B * S if nofill else 0
+                self._fwd_live["enc"] = ops.RowFlags(plan.live_tile, plan.packed, nofill)
                 self._enc_off = plan.seq_off if plan.packed else None
                 self._last_plan_mode = plan.mode      # (tests: which layout the step really ran)
                 saved["plan"] = plan
+                if probe is not None and probe[0] % 64 == 1:
+                    # rows in 256-row groups that hold something: the share of the forward's encoder-row work that remains
+                    groups = plan.live_tile.view(-1, 4)[:, 0]
+                    probe[1] = float(groups.float().mean()) <= 15.0 / 16.0
             x = self.embed_fwd(enc_inputs, None if saved is None else saved.setdefault("emb_enc", {}),
                                row_map=plan.dest if (plan is not None and plan.compact) else None)
         assert x.shape[0] == B * S, "attention_mask does not match the concatenated modalities"
@@ -1145,7 +1190,7 @@ class Seq2SeqEngine:
             if backward:
                 saved["dmem_init"] = dmem0
         logits = self.decode(dec_ids, mem, mem_pad, dec_attention_mask, S, saved)
-        self._fwd_live, self._enc_off = {}, None
+        self._fwd_live, self._enc_off, self._arena_rows = {}, None, 0
         # (split-pair memory stays a 2-D X2 object: .float() / .cpu() materialise it on demand)
         out = {"logits": logits.view(B, T, self.V),
                "encoder_hidden_states": mem if isinstance(mem, X2) else mem.view(B, S, self.d)}

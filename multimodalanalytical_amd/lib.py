@@ -55,7 +55,7 @@ class LnShape(C.Structure):
         ("rows", C.c_int64), ("d", C.c_int32), ("y_dtype", C.c_int32),
         ("seg_len", C.c_int64), ("out_seg_stride", C.c_int64), ("out_off", C.c_int64),
         ("eps", C.c_float), ("add_dtype", C.c_int32), ("add_drop", Dropout),
-        ("row_live", C.c_void_p), ("row_map", C.c_void_p),
+        ("row_live", C.c_void_p), ("flags", C.c_int32), ("reserved", C.c_int32), ("row_map", C.c_void_p),
     ]
 
 

@@ -101,10 +101,12 @@ class RowFlags:
     """A padded-row hint with its layout: `t` = one byte per 64-row block (0 = nothing but padding), `dealt` = the live rows are PACKED
     to the front of the matrix (afm_compact_plan mode 2), so the GEMM kernels deal row panels / k-steps round-robin to XCDs / split-K units
     instead of cutting contiguous bands (afm_gemm_desc.reserved2 bit 2).  Every hint argument below takes a plain uint8 tensor too."""
-    __slots__ = ("t", "dealt")
+    __slots__ = ("t", "dealt", "nofill")
 
-    def __init__(self, t, dealt=False):
-        self.t, self.dealt = t, bool(dealt)
+    def __init__(self, t, dealt=False, nofill=False):
+        # nofill (forward sense only): dead rows are not written at all -- the outputs are persistent buffers that already hold finite
+        # values there (afm_gemm_desc.reserved2 bit 3, afm_ln_shape.flags bit 0)
+        self.t, self.dealt, self.nofill = t, bool(dealt), bool(nofill)
 
     def numel(self):
         return self.t.numel()
@@ -160,10 +162,13 @@ def gemm_desc(a: torch.Tensor, b: torch.Tensor, c: torch.Tensor, *, trans_a=Fals
     d.glu_rows = int(glu_rows)
     d.reserved2 = 1 if sg_hi_only else 0
     d.drop = dropout
+    nofill = isinstance(rows_unread, RowFlags) and rows_unread.nofill
     k_live, dealt = _flags(k_live)
     rows_unread, dealt_u = _flags(rows_unread)
     if dealt or dealt_u:
         d.reserved2 |= 4
+    if nofill:
+        d.reserved2 |= 8
     if k_live is not None:      # one byte per 64 stored rows of `a` (token positions), 0 = all of them zero (padding)
         nrows = K if trans_a else M
         assert (trans_a or trans_b) and k_live.dtype == torch.uint8 and k_live.is_contiguous()
@@ -230,6 +235,8 @@ def layernorm_fwd(x, gamma, beta, y, mean=None, rstd=None, pos=None, seg_len=0, 
     rows, d = x.shape
     assert x.dtype == torch.float32 and x.is_contiguous() and is_contig(y)
     s = ln_shape(rows, d, y.dtype, seg_len, out_seg_stride, out_off, eps)
+    if isinstance(row_live, RowFlags) and row_live.nofill:
+        s.flags |= 1
     row_live, _ = _flags(row_live)
     if row_live is not None:
         assert row_live.dtype == torch.uint8 and row_live.is_contiguous() and rows % 64 == 0 and row_live.numel() == rows // 64 and seg_len == 0

@@ -159,6 +159,9 @@ class BucketedReducer:
         self.stream = torch.cuda.Stream() if self.is_cuda else None
         self.handles: List = []
         self.launched: List[Tuple[int, int]] = []
+        import os as _os
+        self._standin = self.is_cuda and _os.environ.get("AFM_DDP_STANDIN", "0") == "1" and (not dist.is_initialized() or dist.get_world_size(group) == 1)
+        self._scratch = None
         if native is None:
             import os
             native = self.is_cuda and os.environ.get("AFM_NATIVE_RCCL", "1") != "0" and dist.is_initialized() and \
@@ -203,6 +206,15 @@ class BucketedReducer:
             self.stream.wait_event(ev)                 # gradients in [lo, hi) are produced before this point
             if self.comm is not None:
                 self.comm.all_reduce(view, self.stream)    # enqueued on the side stream; finish() orders the compute stream behind it
+                if self._standin:
+                    # profiling aid (AFM_DDP_STANDIN=1, one rank only): RCCL enqueues NOTHING for an in-place all-reduce over one rank, so a
+                    # trace of `bench.py --force-ddp` on a 1-GPU box shows no exchange at all.  A device copy of the bucket on the same side
+                    # stream stands in for it -- the bucket's bytes read and written once, about what a ring all-reduce moves per GPU --
+                    # so the timeline shows where the buckets are launched and what runs beside them (tools/rocpd_overlap.py --standin).
+                    if self._scratch is None or self._scratch.numel() < view.numel():
+                        self._scratch = torch.empty(self.bucket, dtype=view.dtype, device=view.device)
+                    with torch.cuda.stream(self.stream):
+                        self._scratch[:view.numel()].copy_(view)
             else:
                 with torch.cuda.stream(self.stream):
                     self.handles.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))

@@ -33,7 +33,7 @@ def test_struct_layouts_match_the_header():
     assert ctypes.sizeof(L.Dropout) == 16
     assert ctypes.sizeof(L.GemmDesc) == 48 + 7 * 8 + 16 + 16 + 8 + 8 and L.GemmDesc.glu_rows.offset == 136 and L.GemmDesc.k_live.offset == 144
     assert L.GemmDesc.A.offset == 48 and L.GemmDesc.a_colsum.offset == 96 and L.GemmDesc.drop.offset == 120
-    assert ctypes.sizeof(L.LnShape) == 80 and L.LnShape.add_drop.offset == 48 and L.LnShape.row_live.offset == 64 and L.LnShape.row_map.offset == 72
+    assert ctypes.sizeof(L.LnShape) == 88 and L.LnShape.add_drop.offset == 48 and L.LnShape.row_live.offset == 64 and L.LnShape.flags.offset == 72 and L.LnShape.row_map.offset == 80
     assert L.AttnShape.key_pad.offset == 56 and L.AttnShape.sqb.offset == 80 and ctypes.sizeof(L.AttnShape) == 136
     assert L.PatchDesc.mean.offset == 32 and ctypes.sizeof(L.PatchDesc) == 48
 

@@ -226,6 +226,39 @@ def test_gemm_forward_row_hint_glu_save(ops, M, f, d):
     assert _gemm_case(ops, M, f, d, L.ACT_GLU_SAVE, True, True, glu=True) == "mfma_nt_glu"
 
 
+def test_nofill_leaves_dead_rows_untouched(ops):
+    """RowFlags.nofill (persistent output buffers: afm_gemm_desc.reserved2 bit 3, afm_ln_shape.flags bit 0): live rows as always,
+    dead rows keep whatever the buffer held."""
+    from multimodalanalytical_amd import lib as L
+    g = torch.Generator().manual_seed(12)
+    M, N, K = 65536, 512, 512
+    live = (torch.rand(M // 256, generator=g) > 0.45).to(torch.uint8)
+    flags = live.repeat_interleave(4).contiguous().to(DEV)
+    rl = live.bool().repeat_interleave(256).to(DEV)
+    a = (torch.randn(M, K, generator=g) * 0.5).to(DEV).half()
+    w = (torch.randn(N, K, generator=g) * 0.05).to(DEV).half()
+    bias = torch.randn(N, generator=g).to(DEV)
+    ref = torch.full((M, N), 3.0, dtype=H16, device=DEV)
+    ops.gemm(a, w, ref, trans_b=True, bias=bias, algo=L.ALGO_MFMA)
+    out = torch.full((M, N), 3.0, dtype=H16, device=DEV)
+    ops.gemm(a, w, out, trans_b=True, bias=bias, algo=L.ALGO_MFMA, rows_unread=ops.RowFlags(flags, True, True))
+    assert torch.equal(out[rl], ref[rl]) and bool((out[~rl] == 3.0).all())
+    # LayerNorm
+    rows, d = 8192, 512
+    x, add = torch.randn(rows, d, generator=g).to(DEV), torch.randn(rows, d, generator=g).to(DEV).half()
+    gamma, beta = torch.randn(d, generator=g).to(DEV), torch.randn(d, generator=g).to(DEV)
+    lv = (torch.rand(rows // 64, generator=g) > 0.4).to(torch.uint8).to(DEV)
+    rr = lv.bool().repeat_interleave(64)
+
+    def run(fl):
+        y = torch.full((rows, d), 7.0, dtype=H16, device=DEV)
+        mean, rstd, xs = torch.full((rows,), 7.0, device=DEV), torch.full((rows,), 7.0, device=DEV), torch.full((rows, d), 7.0, device=DEV)
+        ops.layernorm_fwd(x, gamma, beta, y, mean, rstd, add=add, x_sum=xs, row_live=fl)
+        return y, mean, rstd, xs
+    for p_, q_ in zip(run(None), run(ops.RowFlags(lv, True, True))):
+        assert torch.equal(p_[rr], q_[rr]) and bool((q_[~rr] == 7.0).all())
+
+
 # ------------------------------------------------------------------ attention forward
 @pytest.mark.parametrize("p", [0.0, 0.1])
 def test_attn_fwd_padded_query_blocks(ops, p):
@@ -410,7 +443,7 @@ def test_engine_flags_only_equals_unskipped(name, B):
     assert torch.equal(ma[live], mb[live]) and float(ma[~grp].float().abs().max() if bool((~grp).any()) else 0.0) == 0.0
 
 
-@pytest.mark.parametrize("mode", ["1", "2"])
+@pytest.mark.parametrize("mode", ["1", "2", "2-fill"])
 @pytest.mark.parametrize("name,B", [("c3", 64), ("c4", 32)])
 def test_engine_compacted_equals_unskipped(name, B, mode):
     """Live positions moved to the front of every slot: the same function of the batch (keys in another order, so sums round
@@ -420,10 +453,16 @@ def test_engine_compacted_equals_unskipped(name, B, mode):
     over = {"encoder_layers": 2, "decoder_layers": 2}
     inputs = _inputs(name, B)
     wl, e_off = _engine(name, {"AFM_FWD_ROW_SKIP": "0"}, cfg_over=over)
-    _, e_on = _engine(name, {"AFM_FWD_ROW_SKIP": "1", "AFM_FWD_COMPACT": mode}, cfg_over=over)
+    arena = "0" if mode.endswith("-fill") else "1"      # (2-fill: packed rows with the zero fill, no persistent buffers)
+    mode = mode[0]
+    _, e_on = _engine(name, {"AFM_FWD_ROW_SKIP": "1", "AFM_FWD_COMPACT": mode, "AFM_FWD_ARENA": arena}, cfg_over=over)
     e_on.load_state_dict(e_off.state_dict())
+    if mode == "2" and arena == "1":
+        # a first step on ANOTHER batch: the persistent buffers then hold that batch's rows where this one's dead tail lies
+        _run(e_on, _inputs(name, B, seed=23))
+        assert len(e_on._arena) > 0
     a, ga = _run(e_on, inputs)
-    assert (e_on._last_plan_mode if hasattr(e_on, "_last_plan_mode") else int(mode)) == int(mode)
+    assert e_on._last_plan_mode == int(mode)
     b, gb = _run(e_off, inputs)
     err = _compare(a, b, ga, gb, 5e-4, 2e-3)
     print(f"{name} B={B}: compaction mode {mode} vs un-skipped logits {err:.2e}")
