@@ -1723,10 +1723,12 @@ int AFM_E16_FN(afm_gemm_mfma_try)(const afm_gemm_desc* d, hipStream_t st) {
     // plain (bias-only) products over many whole 256 x 256 tiles: the ping-pong kernel (afm_gemm_pp_impl.h).  Measured against the
     // 256 x 128 loader-wave form at the c2 step's shapes, same box: N = 512 / K = 2048  +5 %, N = 512 / K = 1536  +9 %,
     // N = 1024 / K = 512  +6 %, N = 2048 / K = 512  +4 %, N = 1536 / K = 512 and N = 512 / K = 512  equal (left where they were);
-    // 64-row-tile problems (the decoder's 16 384 rows) lose: too few tiles for a 256-CU chip.
+    // 64-row-tile problems (the decoder's 16 384 rows) lose: too few tiles for a 256-CU chip.  Round 6 (tools/experiments/dec_rows_gemm.py, all tile
+    // shapes at M = 16 384): the 256 x 128 loader-wave form wins every decoder-row shape (N 2304 / K 768: 61 us against the four-wave kernel's 69,
+    // N 2048 / K 512: 37 against the ping-pong kernel's 41), so these kernels also want M >= 32 768 rows (the tile count alone let c4's decoder QKV in).
     if (d->reserved == 0 && (variant == 24 || variant == 28) && d->act == AFM_ACT_NONE && !d->pre_act && d->drop.p <= 0.f &&
         !d->residual && !d->accumulate && d->c_dtype == AFM_E16 && !(d->M & 255) && !(d->N & 255) && !(d->K & 63) && d->K >= 128 &&
-        !(d->ldc % 8) && d->N <= PP_BIAS_MAX && (int64_t)(d->M >> 8) * (d->N >> 8) >= 512 && (d->K >= 768 || d->N >= 1024))
+        !(d->ldc % 8) && d->N <= PP_BIAS_MAX && (int64_t)(d->M >> 8) * (d->N >> 8) >= 512 && d->M >= 32768 && (d->K >= 768 || d->N >= 1024))
     {
       variant = (d->K & 127) ? 30 : 32;      // balanced phases where the K-tile count is even (+1 .. 5 % on most shapes, two runs)
       // K >= 768: four waves of 128 x 128 with the overlap inside the wave (afm_gemm_w4_impl.h; bit-identical to the ping-pong kernel).

@@ -161,6 +161,12 @@ class Seq2SeqEngine:
         # backward keeps its zero fills: ITS dead rows must be exact zeros for any consumer that runs without the hints.
         self.fwd_arena = os.environ.get("AFM_FWD_ARENA", "1") != "0"
         self._arena: Dict[str, torch.Tensor] = {}
+        # AFM_HEAD_X3 (default 1, single-pass 16-bit modes): token_ff's FORWARD on split bf16 pairs (three MFMA passes, fp32-grade) from the
+        # final decoder LayerNorm's fp32 output.  The head is 0.02 % of the step's FLOPs and what the parity bar is stated on: measured
+        # (tools/experiments/head_precision.py, fresh init, B = 2) an exact head takes the fp16 mode's logits error from 6.4e-4 to 5.7e-4 at c2,
+        # 5.3e-4 to 5.0e-4 at c3, 7.4e-4 to 5.9e-4 at c4.  The backward is unchanged (fp16 operands, as every other product of the mode).
+        self.head_x3 = self.single16 and os.environ.get("AFM_HEAD_X3", "1") != "0"
+        self._head_w = X2.empty(self.V, self.d, self.dev) if (self.head_x3 and self.dev.type == "cuda") else None
         self._arena_rows = 0  # > 0 while a packed training-step forward is under way: tensors of that many rows come from the arena
         self._fwd_live = {}   # forward of a training step: role -> uint8 per 64-row block, 0 = its whole 256-row group is padding (encode)
         self._frole = None    # whose rows the forward is working on (set by encode around the encoder stack)
@@ -203,6 +209,12 @@ class Seq2SeqEngine:
                 ops.cast_bf16(src, self.ps.span(self.ps.bf16, name, rows, cols), self.wt[name])
         self._refresh_glu()
         self._refresh_kv_concat()
+        self._refresh_head()
+
+    def _refresh_head(self) -> None:
+        """Split-pair copy of token_ff.weight for the x3 head of the single-pass modes (`head_x3`)."""
+        if self._head_w is not None:
+            ops.cast_x2(self.ps.span(self.ps.flat, "token_ff.weight", self.V, self.d), self._head_w, None)
 
     def refresh_transposes(self) -> None:
         """After an optimiser step (which already wrote the flat bf16 shadow)."""
@@ -224,6 +236,7 @@ class Seq2SeqEngine:
                 self._cast_batch = ops.CastBatch(entries, self.cd)
             self._cast_batch.run()
             self._refresh_kv_concat()
+            self._refresh_head()
             return
         for name, rows, cols in self._gemm_weight_groups():
             if self.cd == torch.float16:
@@ -232,6 +245,7 @@ class Seq2SeqEngine:
                 ops.cast_bf16(self.ps.span(self.ps.flat, name, rows, cols), None, self.wt[name])
         self._refresh_glu()
         self._refresh_kv_concat()
+        self._refresh_head()
 
     def _refresh_glu(self) -> None:
         """Interleaved shadows of the gated up-projections [linear1 ; gate] (include/afm_hip.h, AFM_ACT_GLU*)."""
@@ -948,13 +962,27 @@ class Seq2SeqEngine:
                 _, br = self._ffn_fwd(None, None, p, self.cfg["decoder_ffn_dim"], "norm3.", sv, f"d{i}", h=h)
                 x, h = self._post_norm(x, br, p + "norm3.", sv, "lnf")
             layers.append(sv)
-        hf, _ = self._ln_fwd(x, "decoder.norm.", saved, "dec_norm", pend=pend)
-        logits = self._linear(hf, "token_ff.weight", self.V, self.d, out_dtype=torch.float32,
-                              bias_name="token_ff.bias")
+        hf, logits = self._head(x, pend, saved)
         if saved is not None:
             saved.update(dec_layers=layers, hf=hf, T=T, tgt_pad=tgt_pad)
         return logits
 
+
+    def _head(self, x, pend, saved):
+        """Final decoder LayerNorm + token_ff (custom_modeling.py:318,486) -> (hf in the compute dtype for the backward, fp32 logits).
+        `head_x3`: the LayerNorm writes fp32, the product runs on split pairs (three MFMA passes); hf is then a cast of that output."""
+        if self._head_w is None:
+            hf, _ = self._ln_fwd(x, "decoder.norm.", saved, "dec_norm", pend=pend)
+            return hf, self._linear(hf, "token_ff.weight", self.V, self.d, out_dtype=torch.float32, bias_name="token_ff.bias")
+        hf32, _ = self._ln_fwd(x, "decoder.norm.", saved, "dec_norm", out_dtype=torch.float32, pend=pend)
+        rows = hf32.shape[0]
+        hx = ops.convert(hf32, X2.empty(rows, self.d, self.dev))
+        logits = torch.empty(rows, self.V, dtype=torch.float32, device=self.dev)
+        # variant 33: ONE kernel form (the small-tile split-pair kernel) whatever the row count, so a sample's logits do not depend on the
+        # size of the batch it is in (tests/test_gpu_model.py: a micro-batch equals its two halves, bit for bit)
+        ops.gemm(hx, self._head_w, logits, trans_b=True, bias=self.ps.vec_span(self.ps.flat, "token_ff.bias", 0, self.V), algo=self.algo, variant=33)
+        hf = ops.convert(hf32, self._empty(rows, self.d)) if saved is not None else None
+        return hf, logits
 
     # ------------------------------------------------------------------ incremental decode (KV cache)
     def _mem_rows(self, mem, B, S):
@@ -1105,8 +1133,7 @@ class Seq2SeqEngine:
                 _, pend = self._ffn_fwd(None, None, p, self.cfg["decoder_ffn_dim"], "norm3.", None, f"d{i}", h=h)
                 x, h = self._post_norm(x, pend, p + "norm3.", None, None)
                 pend = None
-        hf, _ = self._ln_fwd(x, "decoder.norm.", None, None, pend=pend)
-        logits = self._linear(hf, "token_ff.weight", self.V, d, out_dtype=torch.float32, bias_name="token_ff.bias")
+        _, logits = self._head(x, pend, None)
         st["t"] = t + 1
         return logits
 

@@ -407,7 +407,7 @@ def test_c2_shape_parity_vs_oracle():
             assert torch.equal(out["argmax"].cpu(), ref["logits"].argmax(-1))
             torch.testing.assert_close(out["loss"].cpu(), ref["loss"], rtol=1e-4, atol=1e-4)
         else:
-            assert ops.last_algo() in ("mfma_nt", "generic")          # the LM head / MFMA path ran
+            assert ops.last_algo() in ("mfma_nt", "generic", "mfma_nt_x3_small")          # the LM head / MFMA path ran (round 6: the head on split pairs)
             assert err < 5e-2, err
             agree = (out["argmax"].cpu() == ref["logits"].argmax(-1)).float().mean()
             assert float(agree) > 0.97

@@ -403,7 +403,7 @@ def _compare(a, b, ga, gb, logit_tol, grad_tol):
     la, lb = a["logits"].double(), b["logits"].double()
     err = float((la - lb).abs().max()) / float(lb.abs().max())
     assert err <= logit_tol, err
-    assert abs(float(a["loss"]) - float(b["loss"])) <= max(logit_tol, 1e-6) * max(1.0, abs(float(b["loss"])))
+    assert abs(float(a["loss"]) - float(b["loss"])) <= max(logit_tol, 1e-5) * max(1.0, abs(float(b["loss"])))      # (the loss sum meets in fp32 atomics)
     num = sum(float((ga[k] - gb[k]).double().norm()) ** 2 for k in ga)
     den = sum(float(gb[k].double().norm()) ** 2 for k in gb)
     assert (num / den) ** 0.5 <= grad_tol, (num / den) ** 0.5
