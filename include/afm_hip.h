@@ -65,6 +65,11 @@ const char* afm_error_string(int code);
 /* Name of the kernel family the last afm_gemm / afm_attn_* call on this thread dispatched to
  * ("generic", "mfma_nt", "mfma_tn", ...): lets tests assert the fast path really ran. */
 const char* afm_last_algo(void);
+/* Padded-row hint of the last afm_gemm / afm_gemm_group / afm_layernorm_bwd call on this thread: 0 none given, 1 the kernels took it (tile /
+ * k-step lists, row flags), -1 given but IGNORED (a kernel form without lists, an ineligible shape).  A caller that wants to stop filling
+ * dead rows in its backward (reserved2 bit 3 / afm_ln_shape.flags bit 0 / afm_attn_shape.reserved bit 17 there) first runs a step WITH the
+ * fills and checks that every hinted call answers 1: only then does nothing ever load those rows. */
+int afm_last_hint(void);
 
 /* ------------------------------------------------------------------------------------------
  * Dropout stream.  Every dropout site of the reference (torch `dropout`/`bernoulli_`,
@@ -138,7 +143,8 @@ typedef struct {
                              nothing but dead rows.  Scheduling only, same results.
                              bit 3 (8), with bit 1: the dead tiles of C (and of a stored pre_act) are NOT written -- the caller vouches that its
                              buffers already hold finite values there (persistent buffers only these kernels ever write: stale rows of an earlier
-                             step), so the zero fill -- HBM writes for rows nobody reads -- is left out. */
+                             step), so the zero fill -- HBM writes for rows nobody reads -- is left out.  Without bit 1 (the backward's hint): the same for the
+                             zero tiles of the data-gradient forms, on the caller's word (afm_last_hint) that every consumer of C takes the hint too. */
   const uint8_t* k_live;  /* nullable: k_live[i] == 0 says the STORED rows 64 i .. 64 i + 63 of A (64 token positions) are all zero --
                              the padded positions of a training step's backward, whose activation gradients are exact zeros.
                              wgrad form (transA): the MFMA kernels leave those k-steps out (K / 64 bytes).  NT form without bias /
@@ -210,8 +216,9 @@ typedef struct {
                              zeros without reading anything and they add nothing to dgamma / dbeta.  Forward (ABI 6): row_live[i] == 0 says
                              nobody reads those rows of the outputs (padded positions of a training step): nothing is loaded, y / x_sum /
                              mean / rstd get zeros there.  A hint: the scalar kernels (d % 8 != 0, rows < 64) ignore it. */
-  int32_t flags;           /* bit 0 (forward, with row_live): the rows row_live calls dead are NOT written (no zeros): the caller's y / x_sum / mean /
-                             rstd already hold finite values there (a persistent buffer only these kernels ever write) */
+  int32_t flags;           /* bit 0, with row_live: the rows row_live calls dead are NOT written (no zeros).  Forward: the caller's y / x_sum / mean /
+                             rstd already hold finite values there (a persistent buffer only these kernels ever write).  Backward: the caller has
+                             checked (afm_last_hint) that every consumer of dx / dx_drop takes the hint too, so nothing loads those rows. */
   int32_t reserved;
   const int32_t* row_map;  /* nullable, placement form (seg_len != 0) only, forward and backward: position p = out_off + r % seg_len of sample
                              b = r / seg_len lives in row row_map[b * out_seg_stride + p] of the concatenated-sequence matrix instead of row
@@ -290,7 +297,8 @@ typedef struct {
                              zero, dK / dV lose exact zeros.  afm_attn_fwd (ABI 6), same condition: nobody reads the outputs of the query rows
                              key_pad marks; workgroups (128 queries) of nothing but such rows write O = 0, lse = +inf (the all-masked-row
                              convention) and return.  bit 17 (131072), afm_attn_fwd with q_off: the blocks beyond the slots write nothing to the dead
-                             tail of O (the caller's O already holds finite values there).  bit 5 (32): forward reads drop_bits (afm_attn_drop_bits_fill ran before); bit 4 (16): the 8-wave staggered forms of the single-pass forward / dQ kernels (Tq >= 256), see DESIGN.md 4.
+                             tail of O (the caller's O already holds finite values there); afm_attn_bwd with q_off / k_off: nothing to the dead tail of dQ / dK /
+                             dV (every consumer takes the hint: afm_last_hint).  bit 5 (32): forward reads drop_bits (afm_attn_drop_bits_fill ran before); bit 4 (16): the 8-wave staggered forms of the single-pass forward / dQ kernels (Tq >= 256), see DESIGN.md 4.
                              afm_attn_bwd, dK/dV kernel selection (A / B tests; every form gives bit-identical dK / dV): bit 7 (128) the round-3
                              kernel instead of the software-pipelined one (csrc/afm_attn_pipe_impl.h: default where there is no causal mask, Tq % 64 == 0
                              and dropout runs through drop_bits or is off); bit 8 (256) its eight-wave form; bit 9 (512) its form with 64 keys per

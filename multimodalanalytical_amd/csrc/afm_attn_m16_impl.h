@@ -82,6 +82,7 @@ __global__ __launch_bounds__(256, OCC) void k_attn_bwd_dq_m16(AttnM a, const e16
   {
     int64_t tail0;
     if (attn_tail_block(a.q_off, a.B, b, blk_.xb, a.Tq, tail0)) {      // packed rows, a block beyond the sample's slot: zeros to its block of the dead tail
+      if (a.nofill) return;
       const e16x4 z = {(e16)0.f, (e16)0.f, (e16)0.f, (e16)0.f};
 #pragma unroll
       for (int qi = 0; qi < 2; ++qi) {

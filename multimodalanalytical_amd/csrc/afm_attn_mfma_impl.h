@@ -459,6 +459,7 @@ __global__ __launch_bounds__(256, AFM_DQ_OCC) void k_attn_bwd_dq_mfma(AttnM a, c
   {
     int64_t tail0;
     if (attn_tail_block(a.q_off, a.B, b, blk_.xb, a.Tq, tail0)) {      // packed rows, a block beyond the sample's slot: zeros to its block of the dead tail
+      if (a.nofill) return;
       e16* dqp = dQ + (tail0 + w * 32 + (lane & 31)) * a.lddq + hd * DH + 4 * h;
       const e16x4 z = {(e16)0.f, (e16)0.f, (e16)0.f, (e16)0.f};
 #pragma unroll

@@ -36,6 +36,7 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd_dkv_pipe16(AttnM a, const e
   {
     int64_t tail0;
     if (attn_tail_block(a.k_off, a.B, b, blk_.xb, a.Tk, tail0)) {      // packed rows, a key block beyond the sample's slot: zeros to its block of the dead tail
+      if (a.nofill) return;
       static_assert(KPB == 128, "the dead-tail bijection is stated in 128-row blocks");
       const e16x4 z = {(e16)0.f, (e16)0.f, (e16)0.f, (e16)0.f};
 #pragma unroll

@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "afm_hip.h"
+// padded-row hint bookkeeping of the last call on this thread (afm_last_hint): 0 no hint given, 1 honoured, -1 given but ignored
+extern "C" void afm_note_hint(int state);
 
 typedef __bf16 bf16;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;

@@ -6,6 +6,9 @@
 static thread_local const char* g_last_algo = "none";
 extern "C" void afm_set_last_algo(const char* name) { g_last_algo = name; }
 extern "C" const char* afm_last_algo(void) { return g_last_algo; }
+static thread_local int g_last_hint = 0;
+extern "C" void afm_note_hint(int state) { g_last_hint = state; }
+extern "C" int afm_last_hint(void) { return g_last_hint; }
 extern "C" int afm_abi_version(void) { return AFM_ABI_VERSION; }
 extern "C" int afm_struct_size(int which) {
   switch (which) {

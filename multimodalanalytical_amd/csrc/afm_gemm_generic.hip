@@ -290,6 +290,7 @@ static int gemm_generic(const afm_gemm_desc* d, hipStream_t st) {
   return AFM_OK;
 }
 
+extern "C" int afm_last_hint(void);
 extern "C" int afm_gemm(const afm_gemm_desc* d, void* stream) {
   if (!d || !d->A || !d->B || !d->C) return AFM_ERR_ARG;
   if (d->M < 0 || d->N < 0 || d->K < 0) return AFM_ERR_ARG;
@@ -310,6 +311,7 @@ extern "C" int afm_gemm(const afm_gemm_desc* d, void* stream) {
     if ((ca == 2 && (d->lda & 1)) || (cb == 2 && (d->ldb & 1))) return AFM_ERR_ARG;
   }
   if (d->a_colsum && !d->transA) return AFM_ERR_ARG;
+  afm_note_hint(d->k_live ? -1 : 0);      // (a kernel that takes the hint notes 1)
   if (d->M == 0 || d->N == 0) return AFM_OK;
   hipStream_t st = (hipStream_t)stream;
   if (d->algo != AFM_ALGO_GENERIC) {
@@ -331,21 +333,24 @@ extern "C" int afm_gemm_group(const afm_gemm_desc* descs, int32_t count, void* s
   hipStream_t st = (hipStream_t)stream;
   const afm_gemm_desc* grp[2][8];
   int ng[2] = {0, 0};
+  int hint = 0;      // over all problems: -1 if any given hint was ignored, else 1 if any was honoured (afm_last_hint)
+  auto fold = [&]() { const int s = afm_last_hint(); if (s < 0) hint = -1; else if (s > 0 && hint == 0) hint = 1; };
   auto flush = [&](int t) -> int {
     int r = AFM_OK;
-    if (ng[t] == 1) r = afm_gemm(grp[t][0], stream);          // alone it keeps its own tile / split-K choice
-    else if (ng[t] > 1) r = t ? afm_gemm_tn_group_launch_f16(grp[t], ng[t], st) : afm_gemm_tn_group_launch(grp[t], ng[t], st);
+    if (ng[t] == 1) { r = afm_gemm(grp[t][0], stream); fold(); }          // alone it keeps its own tile / split-K choice
+    else if (ng[t] > 1) { r = t ? afm_gemm_tn_group_launch_f16(grp[t], ng[t], st) : afm_gemm_tn_group_launch(grp[t], ng[t], st); fold(); }
     ng[t] = 0;
     return r;
   };
   for (int i = 0; i < count; ++i) {
     const afm_gemm_desc* d = descs + i;
-    if (!d->A || !d->B || !d->C || d->M <= 0 || d->N <= 0 || d->K < 0) { const int r = afm_gemm(d, stream); if (r != AFM_OK) return r; continue; }
+    if (!d->A || !d->B || !d->C || d->M <= 0 || d->N <= 0 || d->K < 0) { const int r = afm_gemm(d, stream); fold(); if (r != AFM_OK) return r; continue; }
     const int t = afm_gemm_tn_group_eligible_f16(d) ? 1 : afm_gemm_tn_group_eligible(d) ? 0 : -1;
-    if (t < 0) { const int r = afm_gemm(d, stream); if (r != AFM_OK) return r; continue; }
+    if (t < 0) { const int r = afm_gemm(d, stream); fold(); if (r != AFM_OK) return r; continue; }
     grp[t][ng[t]++] = d;
     if (ng[t] == 8) { const int r = flush(t); if (r != AFM_OK) return r; }
   }
   for (int t = 0; t < 2; ++t) { const int r = flush(t); if (r != AFM_OK) return r; }
+  afm_note_hint(hint);
   return AFM_OK;
 }

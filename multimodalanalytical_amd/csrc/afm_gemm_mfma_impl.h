@@ -875,6 +875,7 @@ static int launch_nt_pring(MfmaArgs& g, hipStream_t st, int blocks_per_cu) {
     if ((tpx0 + nbx0 - 1) / nbx0 <= NT_LIVE_MAX) { g.live_off = shm; shm += NT_LIVE_BYTES; }
   }
   g.mperm = (g.live_off && g.deal && !(g.tiles_m & 7)) ? g.tiles_m >> 3 : 0;
+  if (g.k_live && g.live_off) afm_note_hint(1);
   auto kern = k_gemm_nt_pring<C_BF16, NWM, NWN, S, ABL, WM, EPI, EDGE>;
   static AfmOncePerDevice attr_shm;   // per instantiation and per device (function attributes are per device)
   if (attr_shm.need()) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -1105,6 +1106,7 @@ static int launch_nt_ws(MfmaArgs& g, hipStream_t st) {
     if ((tpx0 + nbx0 - 1) / nbx0 <= NT_LIVE_MAX) { g.live_off = shm; shm += NT_LIVE_BYTES; }
   }
   g.mperm = (g.live_off && g.deal && !(g.tiles_m & 7)) ? g.tiles_m >> 3 : 0;
+  if (g.k_live && g.live_off) afm_note_hint(1);
   auto kern = k_gemm_nt_ws<C_BF16, NL, ABL, EPI, CAUX>;
   static AfmOncePerDevice attr_done;   // per instantiation
   if (attr_done.need()) {
@@ -1674,6 +1676,7 @@ int AFM_E16_FN(afm_gemm_mfma_try)(const afm_gemm_desc* d, hipStream_t st) {
     else if (d->bias || d->residual || d->accumulate || (d->act != AFM_ACT_NONE && d->act != AFM_ACT_MUL_SAVED && d->act != AFM_ACT_GLU_BWD) ||
         (d->pre_act && d->act == AFM_ACT_NONE) || d->drop.p > 0.f || !fill16)
       g.k_live = nullptr;
+    else g.dead_nofill = (d->reserved2 & 8) != 0;      // (backward sense: the caller has checked that every consumer takes the hint too)
     if (d->bias && !aligned16(d->bias)) return AFM_ERR_UNSUPPORTED;
     if (!aligned16(d->C) || (d->residual && !aligned16(d->residual)) || (d->pre_act && !aligned16(d->pre_act)))
       return AFM_ERR_UNSUPPORTED;
@@ -1890,6 +1893,7 @@ int AFM_E16_FN(afm_gemm_mfma_try)(const afm_gemm_desc* d, hipStream_t st) {
         (void)hipFuncSetAttribute((const void*)k_gemm_tn_w4, hipFuncAttributeMaxDynamicSharedMemorySize, TW4_RING + TN_LIST_MAX_BYTES);
       }
       // whole 256 x 256 tiles: the four-wave unit (afm_gemm_tnw4_impl.h); reserved = 107 keeps the eight-wave one (A / B tests)
+      if (g.k_live && (d->K / 64 + ksplit - 1) / ksplit <= TN_LIST_MAX && kchunk / 64 <= TN_LIST_MAX) afm_note_hint(1);
       if (!(d->M & 255) && !(d->N & 255) && d->reserved == 108) {
         AFM_LAUNCH(k_gemm_tn_w4, dim3(tiles * ksplit), dim3(256), TW4_RING + TN_LIST_MAX_BYTES, st, g);
         afm_set_last_algo(ksplit > 1 ? "mfma_tn_w4_splitk" : "mfma_tn_w4");
@@ -2050,6 +2054,15 @@ int AFM_E16_FN(afm_gemm_tn_group_launch)(const afm_gemm_desc* const* ds, int cou
     units += pr.ntile * ks;
   }
   gr.units = units;
+  {   // hint bookkeeping: every hinted problem's units keep their live-step lists (<= TN_LIST_MAX steps per unit)
+    int st_ = 0;
+    for (int i = 0; i < count; ++i)
+      if (gr.p[i].k_live) {
+        const bool ok = gr.p[i].kchunk / 64 <= TN_LIST_MAX && (steps[i] + gr.p[i].ksplit - 1) / gr.p[i].ksplit <= TN_LIST_MAX;
+        st_ = ok ? (st_ < 0 ? -1 : 1) : -1;
+      }
+    afm_note_hint(st_);
+  }
   for (int i = count; i < AFM_TN_GROUP_MAX; ++i) { gr.p[i] = gr.p[0]; gr.p[i].unit0 = 0x7fffffff; }
   static AfmOncePerDevice attr;
   if (attr.need()) {

@@ -410,6 +410,7 @@ static int launch_nt_pp(MfmaArgs& g, hipStream_t st) {
     if ((tpx0 + nbx0 - 1) / nbx0 <= NT_LIVE_MAX) { g.live_off = PP_LIST_OFF; shm += NT_LIVE_BYTES; }
   }
   g.mperm = (g.live_off && g.deal && !(g.tiles_m & 7)) ? g.tiles_m >> 3 : 0;
+  if (g.k_live && g.live_off) afm_note_hint(1);
   auto kern = k_gemm_nt_pp<EPI, ABL, SPLIT, BAL, ONEBAR>;
   static AfmOncePerDevice attr;
   if (attr.need()) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

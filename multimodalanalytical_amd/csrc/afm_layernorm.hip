@@ -258,7 +258,7 @@ __global__ __launch_bounds__(256) void k_ln_bwd_vec(const TY* __restrict__ dy, c
                                                     const float* __restrict__ dres, float* __restrict__ dx,
                                                     float* __restrict__ dgamma, float* __restrict__ dbeta, int64_t rows, int d,
                                                     TY* __restrict__ dx_drop, DropDev dd, int64_t seg_len, int64_t seg_stride,
-                                                    int64_t off, const uint8_t* __restrict__ row_live, const int32_t* __restrict__ map) {
+                                                    int64_t off, const uint8_t* __restrict__ row_live, const int32_t* __restrict__ map, int nofill) {
   extern __shared__ __attribute__((aligned(16))) float sm[];  // [4 waves][2][d]
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -310,7 +310,7 @@ __global__ __launch_bounds__(256) void k_ln_bwd_vec(const TY* __restrict__ dy, c
 #pragma unroll
       for (int i = 0; i < NC; ++i) {
         const int c = (lane + 64 * i) * 8;
-        if (c < d) {
+        if (c < d && !nofill) {      // (nofill: the caller has checked that every consumer of dx / dx_drop takes the hint too)
           st8(dx + r * (int64_t)d + c, z);
           if (dx_drop) st8(dx_drop + r * (int64_t)(d * RowMul<TY>::v) + c, z, d);
         }
@@ -547,13 +547,14 @@ extern "C" int afm_layernorm_bwd(const afm_ln_shape* s, const void* dy, const fl
   hipStream_t st = (hipStream_t)stream;
   const size_t shm = sizeof(float) * 8 * s->d;
   if (s->y_dtype < AFM_F32 || s->y_dtype > AFM_F16) return AFM_ERR_ARG;
+  afm_note_hint(s->row_live ? ((ln_bwd_vectorised(s) && s->seg_len == 0 && (s->rows & 63) == 0) ? 1 : -1) : 0);
   if (ln_bwd_vectorised(s)) {   // vectorised path (dy rows follow the embedder's placement, if any)
     // resident workgroups only, as in the forward: three per CU at d <= 512 (136 registers), two at d <= 1024 (229), one beyond (438)
     static const bool bwd_forced = getenv("AFM_LN_BWD_BLOCKS") != nullptr;
     const int gv = bwd_forced ? g : (int)std::min<int64_t>((s->rows + 3) / 4, 256 * (s->d <= 512 ? 3 : s->d <= 1024 ? 2 : 1));
 #define LN_BV(TY, NC) AFM_LAUNCH((k_ln_bwd_vec<TY, NC>), dim3(gv), dim3(256), shm, st, (const TY*)dy, x, gamma, mean, rstd, dres, dx, \
                                  dgamma, dbeta, s->rows, s->d, (TY*)dx_drop, dd, s->seg_len, s->out_seg_stride, s->out_off,   \
-                                 (s->seg_len == 0 && (s->rows & 63) == 0) ? s->row_live : nullptr, s->seg_len != 0 ? s->row_map : nullptr)
+                                 (s->seg_len == 0 && (s->rows & 63) == 0) ? s->row_live : nullptr, s->seg_len != 0 ? s->row_map : nullptr, (s->flags & 1) != 0)
 #define LN_BV2(TY) do { if (s->d <= 512) LN_BV(TY, 1); else if (s->d <= 1024) LN_BV(TY, 2); else LN_BV(TY, 4); } while (0)
     if (s->y_dtype == AFM_BF16) LN_BV2(bf16); else if (s->y_dtype == AFM_BF16X2) LN_BV2(x2); else if (s->y_dtype == AFM_F16) LN_BV2(f16); else LN_BV2(float);
 #undef LN_BV2

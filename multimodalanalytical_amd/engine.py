@@ -161,6 +161,14 @@ class Seq2SeqEngine:
         # backward keeps its zero fills: ITS dead rows must be exact zeros for any consumer that runs without the hints.
         self.fwd_arena = os.environ.get("AFM_FWD_ARENA", "1") != "0"
         self._arena: Dict[str, torch.Tensor] = {}
+        # AFM_BWD_NOFILL (default 1, packed rows only): the BACKWARD's hinted kernels stop zero-filling dead rows too -- but only after a
+        # step of the same (B, S, T) shape ran WITH the fills and every hinted call reported that its kernels took the hint
+        # (ops.hint_log / afm_last_hint): then nothing ever loads those rows.  From there on an ignored hint raises.  The gradient of the
+        # stream that reaches the embedder's backward (which reads every position) keeps its zeros.
+        self.bwd_nofill = os.environ.get("AFM_BWD_NOFILL", "1") != "0"
+        self.debug_poison = os.environ.get("AFM_DEBUG_POISON", "0") == "1"      # (tests) backward tensors start as NaN
+        self._bwd_verified: Dict[Any, bool] = {}      # (B, S, T) -> every hint of a filled backward was honoured
+        self._verify_key = None
         # AFM_HEAD_X3 (default 1, single-pass 16-bit modes): token_ff's FORWARD on split bf16 pairs (three MFMA passes, fp32-grade) from the
         # final decoder LayerNorm's fp32 output.  The head is 0.02 % of the step's FLOPs and what the parity bar is stated on: measured
         # (tools/experiments/head_precision.py, fresh init, B = 2) an exact head takes the fp16 mode's logits error from 6.4e-4 to 5.7e-4 at c2,
@@ -341,7 +349,10 @@ class Seq2SeqEngine:
         dt = dtype or self.bd
         if self.mixed and like is not None and isinstance(like, X2) and dt == torch.bfloat16:
             return torch.empty(rows, like.ld, dtype=dt, device=self.dev)[:, :cols]
-        return ops.empty(rows, cols, dt, self.dev)
+        t = ops.empty(rows, cols, dt, self.dev)
+        if self.debug_poison and torch.is_tensor(t):      # tests: a backward tensor starts as NaN, so a row that is read without having been written shows
+            t.fill_(float("nan"))
+        return t
 
     def _empty_dkv_all(self, rows, cols):
         """The all-layers [dK | dV] buffer of the decoder's cross-attention backward (one data-gradient GEMM over K = layers * 2d at the
@@ -416,8 +427,10 @@ class Seq2SeqEngine:
 
     def _wgrad_raw(self, dy, x, gw, gb, glu_rows=0, role=None):
         kw = dict(trans_a=True, trans_b=False, accumulate=True, algo=self.algo, a_colsum=gb, glu_rows=glu_rows)
-        if torch.is_tensor(dy) and dy.dtype != torch.float32:
-            kw["k_live"] = self._live_hint(dy, role)      # padded 64-token blocks carry exact zeros: left out of the token axis
+        if torch.is_tensor(dy) and dy.dtype != torch.float32 and gw.shape[0] >= 256 and gw.shape[1] >= 256:
+            # padded 64-token blocks carry exact zeros: left out of the token axis (matrices the list-keeping kernels take: the LM head's
+            # 128-row gradient runs on a kernel without lists, where a hint would only count as ignored)
+            kw["k_live"] = self._live_hint(dy, role)
         if self.group_wgrad and torch.is_tensor(dy) and torch.is_tensor(x) and dy.dtype == x.dtype and dy.dtype != torch.float32:
             # 16-bit operands: the layer's weight gradients go out together at the end of its backward (afm_gemm_group: one
             # launch, one split-K budget); the list keeps dy / x alive until then
@@ -600,7 +613,7 @@ class Seq2SeqEngine:
             saved[key] = (x, mean, rstd)
         return y, x
 
-    def _ln_bwd(self, dy, prefix, saved, key, dres, next_site=None):
+    def _ln_bwd(self, dy, prefix, saved, key, dres, next_site=None, fill=False):
         """Returns (dx, dx_dropped): dx is the fp32 stream gradient; dx_dropped (compute dtype) is
         dropout'(dx) for the residual branch that precedes this LayerNorm (dropout site `next_site`),
         produced by the same kernel so dx is not read again."""
@@ -611,8 +624,15 @@ class Seq2SeqEngine:
         if next_site is not None:
             dxd = self._empty(x.shape[0], self.d, dy.dtype)
             dr = self._drop(next_site)
+        if self.debug_poison:
+            dx.fill_(float("nan"))
+            if torch.is_tensor(dxd):
+                dxd.fill_(float("nan"))
+        hint = self._live_hint(dy)
+        if fill and isinstance(hint, ops.RowFlags) and hint.nofill:      # this dx is read by a kernel without hints: its dead rows stay zeros
+            hint = ops.RowFlags(hint.t, hint.dealt, False)
         ops.layernorm_bwd(dy, x, self.ps.p(prefix + "weight"), mean, rstd, dx, self.ps.g(prefix + "weight"),
-                          self.ps.g(prefix + "bias"), ws, dres=dres, dx_drop=dxd, dropout=dr, row_live=self._live_hint(dy))
+                          self.ps.g(prefix + "bias"), ws, dres=dres, dx_drop=dxd, dropout=dr, row_live=hint)
         return dx, dxd
 
     def _bits_ahead(self, B, H, Tq, Tk, site, saved):
@@ -706,6 +726,9 @@ class Seq2SeqEngine:
         # (Not the decoder's: whether its padded rows carry a gradient depends on the labels the caller passes.)
         if self.row_skip and not shp.causal:
             shp.reserved |= 64
+        hint_e = self._live.get("enc")
+        if not shp.causal and shp.q_off and isinstance(hint_e, ops.RowFlags) and hint_e.nofill:
+            shp.reserved |= 131072      # packed rows, verified hints: the dead tail of dQ / dK / dV is left unwritten
         shp.reserved |= self.attn_bwd_flags
         ops.attn_bwd(shp, qkv_b[:, :d], qkv_b[:, d:2 * d], qkv_b[:, 2 * d:], self._hb(a), da, lse, delta,
                      dqkv[:, :d], dqkv[:, d:2 * d], dqkv[:, 2 * d:], ldg, ldg, ldg)
@@ -714,7 +737,8 @@ class Seq2SeqEngine:
             self._dgrad(dqkv, p + "self_attn.in_proj_weight", 3 * d, d, out=acc, accumulate=True)
             return None
         dh = self._dgrad(dqkv, p + "self_attn.in_proj_weight", 3 * d, d)
-        return self._ln_bwd(dh, p + "norm1.", saved, "ln1", dres=dx1, next_site=next_site)
+        # (next_site None: the stack's first layer -- its dx goes to the embedder's backward, which reads every position)
+        return self._ln_bwd(dh, p + "norm1.", saved, "ln1", dres=dx1, next_site=next_site, fill=next_site is None)
 
     def _ffn_fwd(self, x, pend, p, f, norm, saved, site, h=None):
         d, k = self.d, (2 if self.gated else 1)
@@ -837,6 +861,9 @@ class Seq2SeqEngine:
         delta = torch.empty_like(lse)
         kv_b = self._hb(kv)
         shp = self._shape_b(shp)
+        hint_e = self._live.get("enc")
+        if shp.k_off and isinstance(hint_e, ops.RowFlags) and hint_e.nofill:
+            shp.reserved |= 131072      # packed memory rows, verified hints: the dead tail of dK / dV is left unwritten
         shp.reserved |= self.attn_bwd_flags
         ops.attn_bwd(shp, self._hb(q), kv_b[:, :d], kv_b[:, d:], self._hb(a), da, lse, delta, dq, dkv[:, :d], dkv[:, d:],
                      ops._ld(dq), ldkv, ldkv)
@@ -1341,9 +1368,16 @@ class Seq2SeqEngine:
                 tgt_pad = tgt_pad.view(B, T).bool() & (lab.view(B, T) == -100)
             for role, L, pad in (("enc", S, saved.get("key_pad")), ("dec", T, tgt_pad)):
                 if role == "enc" and saved.get("plan") is not None:
-                    self._live[role] = ops.RowFlags(saved["plan"].live64, saved["plan"].packed)      # (afm_compact_plan already made the flags)
+                    pl = saved["plan"]
+                    nofill = pl.packed and self.bwd_nofill and self._bwd_verified.get((B, S, T)) is True
+                    self._live[role] = ops.RowFlags(pl.live64, pl.packed, nofill, "enc")      # (afm_compact_plan already made the flags)
                 elif pad is not None and L % 64 == 0:
-                    self._live[role] = (pad.view(B, L // 64, 64) == 0).any(-1).to(torch.uint8).reshape(-1).contiguous()
+                    self._live[role] = ops.RowFlags((pad.view(B, L // 64, 64) == 0).any(-1).to(torch.uint8).reshape(-1).contiguous(), False, False, role)
+        verify = (self.bwd_nofill and saved.get("plan") is not None and saved["plan"].packed and (B, S, T) not in self._bwd_verified
+                  and self.wgrad_stream is None)
+        if verify:
+            ops.reset_hint_log()
+        self._verify_key = (B, S, T) if verify else None
         self._role = "dec"             # head, final decoder norm and the decoder stack: B * T rows
         dlog = self._empty_b(B * T, self.V)
         ops.ce_bwd(logits, lab, row_lse, stats, loss_scale, dlog, scale_dev=self.scaler)
@@ -1393,6 +1427,10 @@ class Seq2SeqEngine:
             self._grads_final_from(p + "self_attn.in_proj_weight")
         self._embed_bwd_unhinted(dx, saved["emb_enc"])
         self._wgrad_flush()
+        if self._verify_key is not None:      # this backward ran WITH its zero fills: did every hinted call take its hint?
+            took, ignored = ops.hint_log("enc")      # (the encoder rows' hints: the decoder rows keep their fills, ignored or not)
+            self._bwd_verified[self._verify_key] = ignored == 0 and took > 0
+            self._verify_key = None
         self._live, self._role = {}, None
         if self.wgrad_stream is not None:   # every weight gradient is in before the caller reads the buffer
             torch.cuda.current_stream().wait_stream(self.wgrad_stream)

@@ -102,6 +102,7 @@ _SIGS = {
     "afm_cast_weights_batch": (C.c_int, [_P, _I32, _I32, _I32, _P]),
     "afm_error_string": (C.c_char_p, [C.c_int]),
     "afm_last_algo": (C.c_char_p, []),
+    "afm_last_hint": (C.c_int, []),
     "afm_gemm": (C.c_int, [C.POINTER(GemmDesc), _P]),
     "afm_gemm_group": (C.c_int, [_P, C.c_int32, _P]),
     "afm_gather_rows": (C.c_int, [_P, _P, _P, _P, _I64, _I32, _I32, _P]),

@@ -101,9 +101,10 @@ class RowFlags:
     """A padded-row hint with its layout: `t` = one byte per 64-row block (0 = nothing but padding), `dealt` = the live rows are PACKED
     to the front of the matrix (afm_compact_plan mode 2), so the GEMM kernels deal row panels / k-steps round-robin to XCDs / split-K units
     instead of cutting contiguous bands (afm_gemm_desc.reserved2 bit 2).  Every hint argument below takes a plain uint8 tensor too."""
-    __slots__ = ("t", "dealt", "nofill")
+    __slots__ = ("t", "dealt", "nofill", "tag")
 
-    def __init__(self, t, dealt=False, nofill=False):
+    def __init__(self, t, dealt=False, nofill=False, tag=""):
+        self.tag = tag      # whose rows (the engine's role): the hint log below is kept per tag
         # nofill (forward sense only): dead rows are not written at all -- the outputs are persistent buffers that already hold finite
         # values there (afm_gemm_desc.reserved2 bit 3, afm_ln_shape.flags bit 0)
         self.t, self.dealt, self.nofill = t, bool(dealt), bool(nofill)
@@ -114,6 +115,35 @@ class RowFlags:
 
 def _flags(h):
     return (h.t, h.dealt) if isinstance(h, RowFlags) else (h, False)
+
+
+# Padded-row hints of the calls since reset_hint_log(): [honoured, ignored] (afm_last_hint after every hinted afm_gemm / afm_gemm_group /
+# afm_layernorm_bwd).  The engine runs a backward WITH the zero fills, reads this, and only where nothing was ignored lets the next steps'
+# backward kernels leave dead rows unwritten (RowFlags.nofill): from then on an ignored hint is an error, not a slower path.
+_HINT_LOG: dict = {}
+
+
+def reset_hint_log() -> None:
+    _HINT_LOG.clear()
+
+
+def hint_log(tag=""):
+    return tuple(_HINT_LOG.get(tag, (0, 0)))
+
+
+def _note_hint(tags, nofill: bool, what: str) -> None:
+    """`tags`: the tags of the hints the call was given (empty: none)."""
+    if not tags:
+        return
+    st = L.load().afm_last_hint()
+    for tag in set(tags):
+        e = _HINT_LOG.setdefault(tag, [0, 0])
+        e[0 if st > 0 else 1] += 1
+    if st <= 0:
+        if os.environ.get("AFM_DEBUG_HINTS"):
+            print(f"[afm] hint ignored: {what} ({last_algo()})", flush=True)
+        if nofill:
+            raise L.AfmError(f"{what}: a padded-row hint was ignored while dead rows are left unwritten (nofill): results would be undefined")
 
 
 def gemm_desc(a: torch.Tensor, b: torch.Tensor, c: torch.Tensor, *, trans_a=False, trans_b=True,
@@ -162,7 +192,8 @@ def gemm_desc(a: torch.Tensor, b: torch.Tensor, c: torch.Tensor, *, trans_a=Fals
     d.glu_rows = int(glu_rows)
     d.reserved2 = 1 if sg_hi_only else 0
     d.drop = dropout
-    nofill = isinstance(rows_unread, RowFlags) and rows_unread.nofill
+    nofill = (isinstance(rows_unread, RowFlags) and rows_unread.nofill) or (isinstance(k_live, RowFlags) and k_live.nofill and not trans_a)
+    d._hint_tag = k_live.tag if isinstance(k_live, RowFlags) else (rows_unread.tag if isinstance(rows_unread, RowFlags) else "")
     k_live, dealt = _flags(k_live)
     rows_unread, dealt_u = _flags(rows_unread)
     if dealt or dealt_u:
@@ -189,6 +220,7 @@ def gemm(a: torch.Tensor, b: torch.Tensor, c: torch.Tensor, **kw) -> torch.Tenso
     d = gemm_desc(a, b, c, **kw)
     L.check(L.load().afm_gemm(C.byref(d), _stream()), "afm_gemm")
     _log_algo()
+    _note_hint([d._hint_tag] if d.k_live else [], bool(d.reserved2 & 8) and not (d.reserved2 & 2), f"afm_gemm M={d.M} N={d.N} K={d.K} ta={d.transA} act={d.act}")
     if _DEBUG_SYNC:
         print(f"[afm] gemm {last_algo()} M={d.M} N={d.N} K={d.K} ta={d.transA} tb={d.transB} ld=({d.lda},{d.ldb},{d.ldc}) dt=({d.a_dtype},{d.b_dtype},{d.c_dtype}) "
               f"act={d.act} glu={d.glu_rows}", flush=True)
@@ -203,6 +235,7 @@ def gemm_group(descs) -> None:
     arr = (GemmDesc * len(descs))(*descs)
     L.check(L.load().afm_gemm_group(C.cast(arr, C.c_void_p), len(descs), _stream()), "afm_gemm_group")
     _log_algo()
+    _note_hint([d._hint_tag for d in descs if d.k_live], False, "afm_gemm_group " + " ".join(f"{d.M}x{d.N}x{d.K}" for d in descs))
 
 
 def gather_rows(ids, table, out, scale=None):
@@ -266,8 +299,12 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, ws, dres=None, se
     if row_map is not None:      # the embedder's placement through afm_compact_plan's map (as layernorm_fwd)
         assert row_map.dtype == torch.int32 and row_map.is_contiguous() and seg_len > 0 and row_map.numel() == (rows // seg_len) * out_seg_stride
         s.row_map = _ptr(row_map)
+    ln_nofill = isinstance(row_live, RowFlags) and row_live.nofill
+    ln_tag = row_live.tag if isinstance(row_live, RowFlags) else ""
+    if ln_nofill:
+        s.flags |= 1
     row_live, _ = _flags(row_live)
-    if row_live is not None:     # one byte per 64 rows, 0 = dy (and dres) are zero there: skipped, zeros written
+    if row_live is not None:     # one byte per 64 rows, 0 = dy (and dres) are zero there: skipped, zeros written (nofill: left as they are)
         assert row_live.dtype == torch.uint8 and row_live.is_contiguous() and rows % 64 == 0 and row_live.numel() == rows // 64
         assert seg_len == 0
         s.row_live = _ptr(row_live)
@@ -278,6 +315,7 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, ws, dres=None, se
                                        _ptr(dres), _ptr(dx), _ptr(dgamma), _ptr(dbeta), _ptr(ws),
                                        _ptr(dx_drop), C.byref(dropout), _stream()),
             "afm_layernorm_bwd")
+    _note_hint([ln_tag] if row_live is not None else [], ln_nofill, f"afm_layernorm_bwd rows={rows} d={d}")
     return dx
 
 

@@ -453,14 +453,17 @@ def test_engine_compacted_equals_unskipped(name, B, mode):
     over = {"encoder_layers": 2, "decoder_layers": 2}
     inputs = _inputs(name, B)
     wl, e_off = _engine(name, {"AFM_FWD_ROW_SKIP": "0"}, cfg_over=over)
-    arena = "0" if mode.endswith("-fill") else "1"      # (2-fill: packed rows with the zero fill, no persistent buffers)
+    arena = "0" if mode.endswith("-fill") else "1"      # (2-fill: packed rows with the zero fills in both directions, no persistent buffers)
     mode = mode[0]
-    _, e_on = _engine(name, {"AFM_FWD_ROW_SKIP": "1", "AFM_FWD_COMPACT": mode, "AFM_FWD_ARENA": arena}, cfg_over=over)
+    # AFM_DEBUG_POISON: every backward tensor starts as NaN -- a dead row that is read although nobody wrote it would reach the gradients
+    _, e_on = _engine(name, {"AFM_FWD_ROW_SKIP": "1", "AFM_FWD_COMPACT": mode, "AFM_FWD_ARENA": arena, "AFM_BWD_NOFILL": arena, "AFM_DEBUG_POISON": "1"},
+                      cfg_over=over)
     e_on.load_state_dict(e_off.state_dict())
     if mode == "2" and arena == "1":
-        # a first step on ANOTHER batch: the persistent buffers then hold that batch's rows where this one's dead tail lies
+        # a first step on ANOTHER batch: the persistent buffers then hold that batch's rows where this one's dead tail lies, and the
+        # backward (run with its zero fills) finds every hint honoured, so the step compared below runs without them
         _run(e_on, _inputs(name, B, seed=23))
-        assert len(e_on._arena) > 0
+        assert len(e_on._arena) > 0 and list(e_on._bwd_verified.values()) == [True]
     a, ga = _run(e_on, inputs)
     assert e_on._last_plan_mode == int(mode)
     b, gb = _run(e_off, inputs)
