@@ -257,8 +257,8 @@ int afm_place_rows(const float* x, const float* pos, float* y, int64_t rows, int
  *   n_live[b]          live positions of sample b
  * compact == 0: rows stay where the collator put them (dest = identity, seq_off[b] = b S); flags only.
  * compact == 1: per-sample partition inside the sample's own S-row slot (seq_off[b] = b S): row b S + rank.
- * compact == 2: PACKED -- the samples' slots shrink to their live length rounded up to 128 rows and follow each other:
- *               seq_off[b] = sum_{b' < b} ceil128(n_live[b']), live positions first inside the slot, the padded positions of the batch behind
+ * compact == 2: PACKED -- the samples' slots shrink to their live length rounded up to 32 rows (what one wave of the attention kernels owns)
+ *               and follow each other: seq_off[b] = sum_{b' < b} ceil32(n_live[b']), live positions first inside the slot, the padded positions of the batch behind
  *               all slots (rows seq_off[B] .. B S, in order).  The attention kernels address such rows through afm_attn_shape.q_off / k_off.
  * S <= 4096, S % tile_rows == 0.  Encoder self-attention, cross-attention over the memory and the masked mean are indifferent to the
  * order of the key positions once the mask moves with them; positional encodings are added before the move (afm_ln_shape.row_map).
@@ -323,9 +323,10 @@ typedef struct {
   uint64_t* drop_bits;
   /* PACKED rows (ABI 6, nullable, B + 1 int32 each; afm_compact_plan's seq_off): sample b's query-side rows (Q, O, dO, dQ) start at row
    * q_off[b] instead of b * Tq, its key-side rows (K, V, dK, dV) at k_off[b] instead of b * Tk; off[b + 1] - off[b] is the sample's slot, a
-   * multiple of 128 rows that holds its live positions first (key_pad, lse, delta and drop_bits keep their padded (B, T) indexing).
-   * 128-row blocks beyond a slot have no rows of their own: their workgroups write zeros to the dead tail [off[B], B * T) of O / dQ /
-   * dK / dV instead, block for block, so every row of an output is written.  Single-pass MFMA kernels only (dh 64, no causal mask,
+   * multiple of 32 rows that holds its live positions first (key_pad, lse, delta and drop_bits keep their padded (B, T) indexing).
+   * 128-row blocks (and, in a slot's partly used last block, 32-row waves) beyond a slot have no rows of their own: they write zeros to
+   * the dead tail [off[B], B * T) of O / dQ / dK / dV instead (in-sample row r >= slot <-> tail row off[B] + (b T - off[b]) + (r - slot)),
+   * so every row of an output is written.  Single-pass MFMA kernels only (dh 64, no causal mask,
    * T % 128 == 0, key_pad given for a packed key side, dropout through drop_bits or off, q_off == k_off when both are set -- the encoder's
    * self-attention, where the padded-query skip of reserved bit 6 is implied); AFM_ERR_UNSUPPORTED otherwise, nothing launched. */
   const int32_t* q_off;

@@ -79,14 +79,17 @@ __global__ __launch_bounds__(256, OCC) void k_attn_bwd_dq_m16(AttnM a, const e16
   const int hd = blk_.hd, b = blk_.b;
   const int q0 = blk_.xb * 128 + w * 32;
   const int64_t rq = attn_row0(a.q_off, b, a.Tq), rk = attn_row0(a.k_off, b, a.Tk);
+  const int lim_q = attn_slot(a.q_off, b, a.Tq);      // rows of this sample that are its own (packed: its slot)
   {
     int64_t tail0;
     if (attn_tail_block(a.q_off, a.B, b, blk_.xb, a.Tq, tail0)) {      // packed rows, a block beyond the sample's slot: zeros to its block of the dead tail
-      if (a.nofill) return;
+      const int64_t fe = attn_fill_end(a.nofill, a.q_off, a.B);
       const e16x4 z = {(e16)0.f, (e16)0.f, (e16)0.f, (e16)0.f};
 #pragma unroll
       for (int qi = 0; qi < 2; ++qi) {
-        e16* dqp = dQ + (tail0 + w * 32 + 16 * qi + c16) * a.lddq + hd * DH + 4 * g;
+        const int64_t trow = tail0 + w * 32 + 16 * qi + c16;
+        if (trow >= fe) continue;
+        e16* dqp = dQ + trow * a.lddq + hd * DH + 4 * g;
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) *(e16x4*)(dqp + 16 * dt) = z;
       }
@@ -119,7 +122,7 @@ __global__ __launch_bounds__(256, OCC) void k_attn_bwd_dq_m16(AttnM a, const e16
     dl += __shfl_xor(dl, 16, 64);
     dl += __shfl_xor(dl, 32, 64);
     lrow[qi] = ((int64_t)b * a.H + hd) * a.Tq + qc[qi];
-    if (q[qi] < a.Tq && g == 0) delta[lrow[qi]] = -dl;      // the workspace holds -delta (the dK/dV kernel starts its dP accumulators from it)
+    if (q[qi] < a.Tq && g == 0) delta[lrow[qi]] = q[qi] < lim_q ? -dl : 0.f;      // the workspace holds -delta (the dK/dV kernel starts its dP accumulators from it; rows beyond a packed slot: 0)
     const float L = lse[lrow[qi]];
     nL2[qi] = L == INFINITY ? -INFINITY : -L * 1.4426950408889634f;
     ndl[qi] = -dl;
@@ -152,16 +155,20 @@ __global__ __launch_bounds__(256, OCC) void k_attn_bwd_dq_m16(AttnM a, const e16
   int* const tl = (int*)(maskw + (a.Tk + KT - 1) / KT) + 1;      // key tiles with at least one real key
   auto store_dq = [&](bool zeros) {
 #pragma unroll
-    for (int qi = 0; qi < 2; ++qi)
-      if (q[qi] < a.Tq) {
-        e16* dqp = dQ + (rq + q[qi]) * a.lddq + hd * DH + 4 * g;
+    for (int qi = 0; qi < 2; ++qi) {
+      // packed rows: a wave whose rows lie beyond the slot (a partly used last block) zeroes its rows of the dead tail instead
+      const bool own = q[qi] < lim_q;
+      const int64_t drow = attn_out_row(a.q_off, a.B, b, a.Tq, rq, q[qi], lim_q);
+      if (drow >= 0 && (own || drow < attn_fill_end(a.nofill, a.q_off, a.B))) {
+        e16* dqp = dQ + drow * a.lddq + hd * DH + 4 * g;
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) {
           e16x4 v = {(e16)0.f, (e16)0.f, (e16)0.f, (e16)0.f};
-          if (!zeros) v = (e16x4){(e16)(dq[dt][qi][0] * a.scale), (e16)(dq[dt][qi][1] * a.scale), (e16)(dq[dt][qi][2] * a.scale), (e16)(dq[dt][qi][3] * a.scale)};
+          if (!zeros && own) v = (e16x4){(e16)(dq[dt][qi][0] * a.scale), (e16)(dq[dt][qi][1] * a.scale), (e16)(dq[dt][qi][2] * a.scale), (e16)(dq[dt][qi][3] * a.scale)};
           *(e16x4*)(dqp + 16 * dt) = v;
         }
       }
+    }
   };
   if (__syncthreads_and(wave_qskip)) {   // all 128 queries of the workgroup are padding: their dQ rows are zeros, nothing to load
     store_dq(true);

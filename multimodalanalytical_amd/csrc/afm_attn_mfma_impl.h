@@ -43,11 +43,13 @@ __global__ __launch_bounds__(256, AFM_FWD_OCC) void k_attn_fwd_mfma(AttnM a, con
   // bit 6 in the forward sense).  A workgroup whose 128 queries are all padding writes the all-masked-row convention (O = 0, lse = +inf:
   // finite values for whoever still loads the rows, P = 0 for a backward that does not skip them) and leaves; no keep bits are written.
   const int64_t rq = attn_row0(a.q_off, b, a.Tq), rk = attn_row0(a.k_off, b, a.Tk);
+  const int lim_q = attn_slot(a.q_off, b, a.Tq);      // rows of this sample that are its own (packed: its slot)
   {
     int64_t tail0;
     if (attn_tail_block(a.q_off, a.B, b, blk_.xb, a.Tq, tail0)) {      // packed rows, a block beyond the sample's slot: zeros to its block of the dead tail
-      if (a.nofill) return;
-      e16* op = O + (tail0 + w * 32 + (lane & 31)) * a.ldo + hd * DH + 4 * h;
+      const int64_t trow = tail0 + w * 32 + (lane & 31);
+      if (trow >= attn_fill_end(a.nofill, a.q_off, a.B)) return;
+      e16* op = O + trow * a.ldo + hd * DH + 4 * h;
       const e16x4 z = {(e16)0.f, (e16)0.f, (e16)0.f, (e16)0.f};
 #pragma unroll
       for (int db = 0; db < 2; ++db)
@@ -57,7 +59,7 @@ __global__ __launch_bounds__(256, AFM_FWD_OCC) void k_attn_fwd_mfma(AttnM a, con
     }
   }
   if (a.qskip && __syncthreads_and(q >= a.Tq || a.key_pad[(int64_t)b * a.Tk + qc] != 0)) {
-    if (q < a.Tq) {
+    if (q < lim_q) {
       e16* op = O + (rq + q) * a.ldo + hd * DH + 4 * h;
       const e16x4 z = {(e16)0.f, (e16)0.f, (e16)0.f, (e16)0.f};
 #pragma unroll
@@ -208,16 +210,25 @@ __global__ __launch_bounds__(256, AFM_FWD_OCC) void k_attn_fwd_mfma(AttnM a, con
   l += __shfl_xor(l, 32, 64);
   const float inv = l > 0.f ? a.dd.scale16 / l : 0.f;
   if (q < a.Tq) {
-    e16* op = O + (rq + q) * a.ldo + hd * DH + 4 * h;
+    // packed rows: a wave whose rows lie beyond the slot (a partly used last block) zeroes its rows of the dead tail instead
+    const bool own = q < lim_q;
+    const int64_t orow = own ? rq + q : attn_tail0(a.q_off, a.B, b, a.Tq) + (q - lim_q);
+    if (own || orow < attn_fill_end(a.nofill, a.q_off, a.B)) {
+      e16* op = O + orow * a.ldo + hd * DH + 4 * h;
+      const float sc = own ? inv : 0.f;
 #pragma unroll
-    for (int db = 0; db < 2; ++db)
+      for (int db = 0; db < 2; ++db)
 #pragma unroll
-      for (int g4 = 0; g4 < 4; ++g4) {
-        e16x4 v = {(e16)(o[db][4 * g4 + 0] * inv), (e16)(o[db][4 * g4 + 1] * inv),
-                    (e16)(o[db][4 * g4 + 2] * inv), (e16)(o[db][4 * g4 + 3] * inv)};
-        *(e16x4*)(op + 32 * db + 8 * g4) = v;
-      }
-    if (h == 0) lse[((int64_t)b * a.H + hd) * a.Tq + q] = l > 0.f ? (m + __log2f(l)) * 0.69314718055994531f : INFINITY;
+        for (int g4 = 0; g4 < 4; ++g4) {
+          e16x4 v = {(e16)(o[db][4 * g4 + 0] * sc), (e16)(o[db][4 * g4 + 1] * sc),
+                      (e16)(o[db][4 * g4 + 2] * sc), (e16)(o[db][4 * g4 + 3] * sc)};
+          if (!own) v = (e16x4){(e16)0.f, (e16)0.f, (e16)0.f, (e16)0.f};      // (o may hold anything for rows of another sample)
+          *(e16x4*)(op + 32 * db + 8 * g4) = v;
+        }
+    }
+    // (rows beyond a packed slot are another sample's: +inf, the all-masked-row convention, makes them P = 0 for the dK/dV kernel, whose
+    // 64-query tiles may reach past a slot that ends on a 32-row boundary)
+    if (h == 0) lse[((int64_t)b * a.H + hd) * a.Tq + q] = (l > 0.f && own) ? (m + __log2f(l)) * 0.69314718055994531f : INFINITY;
   }
 }
 
@@ -456,11 +467,13 @@ __global__ __launch_bounds__(256, AFM_DQ_OCC) void k_attn_bwd_dq_mfma(AttnM a, c
   const int q = q0 + (lane & 31);
   const int qc = q < a.Tq ? q : a.Tq - 1;
   const int64_t rq = attn_row0(a.q_off, b, a.Tq), rk = attn_row0(a.k_off, b, a.Tk);
+  const int lim_q = attn_slot(a.q_off, b, a.Tq);      // rows of this sample that are its own (packed: its slot)
   {
     int64_t tail0;
     if (attn_tail_block(a.q_off, a.B, b, blk_.xb, a.Tq, tail0)) {      // packed rows, a block beyond the sample's slot: zeros to its block of the dead tail
-      if (a.nofill) return;
-      e16* dqp = dQ + (tail0 + w * 32 + (lane & 31)) * a.lddq + hd * DH + 4 * h;
+      const int64_t trow = tail0 + w * 32 + (lane & 31);
+      if (trow >= attn_fill_end(a.nofill, a.q_off, a.B)) return;
+      e16* dqp = dQ + trow * a.lddq + hd * DH + 4 * h;
       const e16x4 z = {(e16)0.f, (e16)0.f, (e16)0.f, (e16)0.f};
 #pragma unroll
       for (int db = 0; db < 2; ++db)
@@ -488,7 +501,7 @@ __global__ __launch_bounds__(256, AFM_DQ_OCC) void k_attn_bwd_dq_mfma(AttnM a, c
   }
   dl += __shfl_xor(dl, 32, 64);
   const int64_t lrow = ((int64_t)b * a.H + hd) * a.Tq + qc;
-  if (q < a.Tq && h == 0) delta[lrow] = -dl;      // the workspace holds -delta: the dK/dV kernel starts its dP accumulators from it as is
+  if (q < a.Tq && h == 0) delta[lrow] = q < lim_q ? -dl : 0.f;      // the workspace holds -delta: the dK/dV kernel starts its dP accumulators from it as is (rows beyond a packed slot: 0)
   const float L = lse[lrow];
   // Row constants as the initial accumulators (round 3): Q is pre-multiplied by scale * log2(e) and S^T starts at -lse (log2
   // units), so p = exp2(S') is one instruction; dO is pre-multiplied by the dropout scale and dP^T starts at -delta, so
@@ -516,8 +529,9 @@ __global__ __launch_bounds__(256, AFM_DQ_OCC) void k_attn_bwd_dq_mfma(AttnM a, c
   const bool wave_qskip = a.qskip && __all(q >= a.Tq || a.key_pad[(int64_t)b * a.Tk + qc] != 0);
   int* const tl = (int*)(maskw + (a.Tk + KT - 1) / KT) + 1;      // key tiles with at least one real key
   if (__syncthreads_and(wave_qskip)) {   // all 128 queries of the workgroup are padding: their dQ rows are zeros, nothing to load
-    if (q < a.Tq) {
-      e16* dqp = dQ + (rq + q) * a.lddq + hd * DH + 4 * h;
+    const int64_t zrow = attn_out_row(a.q_off, a.B, b, a.Tq, rq, q, lim_q);      // (rows beyond a packed slot: their share of the dead tail)
+    if (zrow >= 0 && (q < lim_q || zrow < attn_fill_end(a.nofill, a.q_off, a.B))) {
+      e16* dqp = dQ + zrow * a.lddq + hd * DH + 4 * h;
       const e16x4 z = {(e16)0.f, (e16)0.f, (e16)0.f, (e16)0.f};
 #pragma unroll
       for (int db = 0; db < 2; ++db)
@@ -603,14 +617,18 @@ __global__ __launch_bounds__(256, AFM_DQ_OCC) void k_attn_bwd_dq_mfma(AttnM a, c
       }
     }
   }
-  if (q < a.Tq) {
-    e16* dqp = dQ + (rq + q) * a.lddq + hd * DH + 4 * h;
+  // packed rows: a wave whose rows lie beyond the slot (a partly used last block) zeroes its rows of the dead tail instead
+  const bool own = q < lim_q;
+  const int64_t drow = attn_out_row(a.q_off, a.B, b, a.Tq, rq, q, lim_q);
+  if (drow >= 0 && (own || drow < attn_fill_end(a.nofill, a.q_off, a.B))) {
+    e16* dqp = dQ + drow * a.lddq + hd * DH + 4 * h;
 #pragma unroll
     for (int db = 0; db < 2; ++db)
 #pragma unroll
       for (int g4 = 0; g4 < 4; ++g4) {
         e16x4 v = {(e16)(dq[db][4 * g4 + 0] * a.scale), (e16)(dq[db][4 * g4 + 1] * a.scale),
                     (e16)(dq[db][4 * g4 + 2] * a.scale), (e16)(dq[db][4 * g4 + 3] * a.scale)};
+        if (!own) v = (e16x4){(e16)0.f, (e16)0.f, (e16)0.f, (e16)0.f};
         *(e16x4*)(dqp + 32 * db + 8 * g4) = v;
       }
   }

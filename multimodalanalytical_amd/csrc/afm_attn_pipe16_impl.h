@@ -33,16 +33,22 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd_dkv_pipe16(AttnM a, const e
   const int hd = blk_.hd, b = blk_.b;
   const int k0 = blk_.xb * KPB + w * 32;
   const int64_t rq = attn_row0(a.q_off, b, a.Tq), rk = attn_row0(a.k_off, b, a.Tk);
+  const int lim_k = attn_slot(a.k_off, b, a.Tk);      // key rows of this sample that are its own (packed: its slot)
+  // query rows of this sample that are its own: the Q / dO tile loads clamp to the slot's last row beyond it (a 64-query tile may reach 32
+  // rows past a slot; those queries are P = 0 -- lse +inf, delta 0 -- but 0 x whatever the rows behind the LAST slot hold must stay 0)
+  const int lim_q = max(1, attn_slot(a.q_off, b, a.Tq));
   {
     int64_t tail0;
     if (attn_tail_block(a.k_off, a.B, b, blk_.xb, a.Tk, tail0)) {      // packed rows, a key block beyond the sample's slot: zeros to its block of the dead tail
-      if (a.nofill) return;
       static_assert(KPB == 128, "the dead-tail bijection is stated in 128-row blocks");
+      const int64_t fe = attn_fill_end(a.nofill, a.k_off, a.B);
       const e16x4 z = {(e16)0.f, (e16)0.f, (e16)0.f, (e16)0.f};
 #pragma unroll
       for (int ki = 0; ki < 2; ++ki) {
-        e16* dkp = dK + (tail0 + w * 32 + 16 * ki + c16) * a.lddk + hd * DH + 4 * g;
-        e16* dvp = dV + (tail0 + w * 32 + 16 * ki + c16) * a.lddv + hd * DH + 4 * g;
+        const int64_t trow = tail0 + w * 32 + 16 * ki + c16;
+        if (trow >= fe) continue;
+        e16* dkp = dK + trow * a.lddk + hd * DH + 4 * g;
+        e16* dvp = dV + trow * a.lddv + hd * DH + 4 * g;
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) { *(e16x4*)(dkp + 16 * dt) = z; *(e16x4*)(dvp + 16 * dt) = z; }
       }
@@ -85,11 +91,14 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd_dkv_pipe16(AttnM a, const e
   if (a.qskip) build_mask_words(qmaskw, a.key_pad, b, a.Tq, ntiles, w, lane);
   auto store_rows = [&](bool zeros) {
 #pragma unroll
-    for (int ki = 0; ki < 2; ++ki)
-      if (key[ki] < a.Tk) {
-        e16* dkp = dK + (rk + key[ki]) * a.lddk + hd * DH + 4 * g;
-        e16* dvp = dV + (rk + key[ki]) * a.lddv + hd * DH + 4 * g;
-        const bool z = zeros || kmasked[ki];          // a padded key took no part in any softmax: zero rows
+    for (int ki = 0; ki < 2; ++ki) {
+      // packed rows: keys beyond the slot (a partly used last block) are the next sample's rows: zeros go to their share of the dead tail
+      const bool own = key[ki] < lim_k;
+      const int64_t row = attn_out_row(a.k_off, a.B, b, a.Tk, rk, key[ki], lim_k);
+      if (row >= 0 && (own || row < attn_fill_end(a.nofill, a.k_off, a.B))) {
+        e16* dkp = dK + row * a.lddk + hd * DH + 4 * g;
+        e16* dvp = dV + row * a.lddv + hd * DH + 4 * g;
+        const bool z = zeros || kmasked[ki] || !own;          // a padded key took no part in any softmax: zero rows
         const float sv = DROP != DROP_NONE ? a.dd.scale16 : 1.0f;
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) {
@@ -102,6 +111,7 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd_dkv_pipe16(AttnM a, const e
           *(e16x4*)(dvp + 16 * dt) = y;
         }
       }
+    }
   };
   if (__syncthreads_and(wave_all_masked)) {
     store_rows(true);
@@ -115,8 +125,8 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd_dkv_pipe16(AttnM a, const e
     const int row0 = tl[j] * KT;
 #pragma unroll
     for (int u = 0; u < 8 / NW; ++u) {
-      dma_piece_tr16(st, Qb, a.ldq, row0, a.Tq, w + NW * u, lane);
-      dma_piece_tr16(st + IMG, Db, a.ldo, row0, a.Tq, w + NW * u, lane);
+      dma_piece_tr16(st, Qb, a.ldq, row0, lim_q, w + NW * u, lane);
+      dma_piece_tr16(st + IMG, Db, a.ldo, row0, lim_q, w + NW * u, lane);
     }
   };
   auto auxo = [&](int j) { return AUX0 + ((j >> 2) & 1) * AUXSLOT + (j & 3) * 256; };

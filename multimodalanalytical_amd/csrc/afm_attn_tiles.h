@@ -20,15 +20,33 @@ struct AttnM {
   int nq32, nk32;
   int qskip;   // backward, self-attention: query rows at padded positions carry zero dO (afm_attn_shape.reserved & 64): skipped, exactly
   const int32_t* q_off;   // afm_attn_shape.q_off / k_off (B + 1 entries, nullable): PACKED rows -- sample b's query / key rows start at row
-  const int32_t* k_off;   // off[b] of Q, O, dO, dQ / K, V, dK, dV, its slot is off[b + 1] - off[b] rows (a multiple of 128)
+  const int32_t* k_off;   // off[b] of Q, O, dO, dQ / K, V, dK, dV, its slot is off[b + 1] - off[b] rows (a multiple of 32)
   int nofill;             // forward (afm_attn_shape.reserved bit 17): blocks without rows of their own write nothing (the caller's O is finite there)
 };
 
+// rows of sample b's slot on a packed side (a multiple of 32: a wave's rows never straddle samples), else T
+__device__ __forceinline__ int attn_slot(const int32_t* off, int b, int T) { return off ? off[b + 1] - off[b] : T; }
+// first row of the dead tail that belongs to sample b's rows beyond its slot: in-sample row r >= slot <-> tail row attn_tail0 + (r - slot)
+__device__ __forceinline__ int64_t attn_tail0(const int32_t* off, int B, int b, int T) { return (int64_t)off[B] + ((int64_t)b * T - off[b]); }
+// Without fills (AttnM.nofill): tail rows at or beyond this row are not written.  The end of the slots (off[B]) is a multiple of 32, the
+// kernels that work on 64-row blocks (LayerNorm, the weight gradients' k-steps) treat the block around it as live and READ its upper half:
+// those <= 32 tail rows always get their zeros.
+__device__ __forceinline__ int64_t attn_fill_end(int nofill, const int32_t* off, int B) {
+  return nofill ? (((int64_t)off[B] + 63) & ~(int64_t)63) : ((int64_t)1 << 62);
+}
+// the row an output of in-sample row r goes to: the sample's own row, or (packed, r beyond the slot) its row of the dead tail; -1: none (r >= T unpacked)
+__device__ __forceinline__ int64_t attn_out_row(const int32_t* off, int B, int b, int T, int64_t row0, int r, int lim) {
+  if (r < lim) return row0 + r;
+  return (off && r < T) ? attn_tail0(off, B, b, T) + (r - lim) : -1;
+}
 // first row of sample b on the query / key side
 __device__ __forceinline__ int64_t attn_row0(const int32_t* off, int b, int T) { return off ? (int64_t)off[b] : (int64_t)b * T; }
 // Packed rows: 128-row block `blk128` of sample b lies beyond the sample's slot.  Its workgroup has nothing to compute; it writes ZEROS to
-// the matching 128-row block of the dead tail [off[B], B * T) instead -- blocks beyond the slots and blocks of the tail are equally many
-// (off[B] + sum_b (T - slot_b) = B * T), `row0` is the bijection -- so every row of the output holds a finite value whoever loads it.
+// the matching rows of the dead tail [off[B], B * T) instead -- the in-sample rows beyond the slots and the rows of the tail are equally
+// many (off[B] + sum_b (T - slot_b) = B * T), in-sample row r of sample b <-> tail row attn_tail0(b) + (r - slot_b) is the bijection -- so
+// every row of the output holds a finite value whoever loads it.  A block that is only PARTLY beyond the slot (slots are multiples of 32
+// rows, blocks 128) runs as usual; its waves whose 32 rows lie beyond the slot must not store there (those are the next sample's rows):
+// they zero their share of the tail through the same bijection (the kernels' final stores).
 __device__ __forceinline__ bool attn_tail_block(const int32_t* off, int B, int b, int blk128, int T, int64_t& row0) {
   if (!off) return false;
   const int slot = off[b + 1] - off[b];

@@ -117,8 +117,12 @@ extern "C" int afm_place_rows(const float* x, const float* pos, float* y, int64_
 
 // ---------------------------------------------------------------- padded positions out of the forward pass (include/afm_hip.h, ABI 6)
 // live positions per sample
-__global__ __launch_bounds__(256) void k_count_live(const uint8_t* __restrict__ key_pad, int S, int32_t* __restrict__ n_live) {
+#define AFM_SLOT_ROWS 32      // a packed sample's slot = its live length rounded up to this (a wave of the attention kernels owns 32 rows)
+__global__ __launch_bounds__(256) void k_count_live(const uint8_t* __restrict__ key_pad, int S, int32_t* __restrict__ n_live,
+                                                    uint8_t* __restrict__ clear, int64_t nclear) {
   __shared__ int part[4];
+  // (packed mode: the block flags are MARKED by the samples that own rows in them -- blocks straddle samples -- so they start cleared)
+  if (clear) for (int64_t i = blockIdx.x + (int64_t)gridDim.x * threadIdx.x; i < nclear; i += (int64_t)gridDim.x * 256) clear[i] = 0;
   const uint8_t* kp = key_pad + (int64_t)blockIdx.x * S;
   int cnt = 0;
   for (int s = threadIdx.x; s < S; s += 256) cnt += kp[s] == 0;
@@ -128,7 +132,7 @@ __global__ __launch_bounds__(256) void k_count_live(const uint8_t* __restrict__ 
   if (threadIdx.x == 0) n_live[blockIdx.x] = part[0] + part[1] + part[2] + part[3];
 }
 // One workgroup per sample: thread t owns the positions [t * chunk, (t + 1) * chunk); live counts -> block scan -> the stable partition.
-// mode 2 (packed): the sample's slot starts at off = sum over earlier samples of ceil128(live); its padded positions fill the slot's
+// mode 2 (packed): the sample's slot starts at off = sum over earlier samples of ceil32(live); its padded positions fill the slot's
 // last rows first, the rest go to the batch's dead tail behind all slots, in order.
 __global__ __launch_bounds__(256) void k_compact_plan(const uint8_t* __restrict__ key_pad, int B, int S, int tile_rows, int mode,
                                                       int32_t* __restrict__ dest, int32_t* __restrict__ seq_off, uint8_t* __restrict__ pad_out,
@@ -144,7 +148,7 @@ __global__ __launch_bounds__(256) void k_compact_plan(const uint8_t* __restrict_
   if (mode == 2) {
     int before = 0, all = 0;
     for (int i = t; i < B; i += 256) {
-      const int slot = (n_live[i] + 127) & ~127;
+      const int slot = (n_live[i] + AFM_SLOT_ROWS - 1) & ~(AFM_SLOT_ROWS - 1);
       all += slot;
       if (i < b) before += slot;
     }
@@ -168,7 +172,7 @@ __global__ __launch_bounds__(256) void k_compact_plan(const uint8_t* __restrict_
     __syncthreads();
   }
   const int L = scan[255];
-  const int slot = mode == 2 ? (L + 127) & ~127 : S;
+  const int slot = mode == 2 ? (L + AFM_SLOT_ROWS - 1) & ~(AFM_SLOT_ROWS - 1) : S;
   const int64_t tail0 = total + ((int64_t)b * S - off);      // packed: where this sample's share of the dead tail starts
   int before = scan[t] - cnt;                    // live positions in front of this thread's range
   for (int s = s0; s < s1; ++s) {
@@ -207,11 +211,9 @@ __global__ __launch_bounds__(256) void k_compact_plan(const uint8_t* __restrict_
   } else {
     // packed: blocks are counted over the whole matrix.  This sample flags the blocks of its own slot; every sample takes its share
     // (index mod B) of the dead tail's blocks and of the widened flags.
-    const int64_t nblk = (int64_t)B * nb, blk0 = off >> 6, used = total >> 6;
-    if (live64) {
-      for (int i = t; i < (slot >> 6); i += 256) live64[blk0 + i] = 64 * i < L;
-      for (int64_t i = used + b + (int64_t)B * t; i < nblk; i += (int64_t)B * 256) live64[i] = 0;
-    }
+    const int64_t nblk = (int64_t)B * nb;
+    if (live64 && L > 0)      // (cleared by k_count_live) every 64-row block that holds one of this sample's live rows [off, off + L)
+      for (int64_t i = (off >> 6) + t; i <= ((off + L - 1) >> 6); i += 256) live64[i] = 1;
     if (live_tile)
       for (int64_t i = b + (int64_t)B * t; i < nblk; i += (int64_t)B * 256) live_tile[i] = (i / per) * tile_rows < total;
   }
@@ -221,8 +223,9 @@ extern "C" int afm_compact_plan(const uint8_t* key_pad, int32_t B, int32_t S, in
   if (!key_pad || !n_live || B <= 0 || S <= 0 || S > 4096 || tile_rows <= 0 || (tile_rows & 63) || (S % tile_rows) || compact < 0 || compact > 2) return AFM_ERR_ARG;
   if (compact && pad_out == key_pad) return AFM_ERR_ARG;      // the kernel re-reads the mask after writing the new one
   if ((int64_t)B * S > (1ll << 24)) return AFM_ERR_ARG;      // (row counts are summed in fp32 lanes: exact below 2^24)
-  if (compact == 2 && (S & 127)) return AFM_ERR_ARG;          // (slots of whole 128-row blocks inside S-row budgets)
-  AFM_LAUNCH(k_count_live, dim3(B), dim3(256), 0, (hipStream_t)stream, key_pad, S, n_live);
+  if (compact == 2 && (S & 127)) return AFM_ERR_ARG;          // (the attention kernels' 128-row blocks inside S-row budgets)
+  AFM_LAUNCH(k_count_live, dim3(B), dim3(256), 0, (hipStream_t)stream, key_pad, S, n_live, compact == 2 ? live64 : (uint8_t*)nullptr,
+             (int64_t)B * (S >> 6));
   AFM_LAUNCH(k_compact_plan, dim3(B), dim3(256), 0, (hipStream_t)stream, key_pad, B, S, tile_rows, compact, dest, seq_off, pad_out, live64, live_tile,
              (const int32_t*)n_live);
   return AFM_OK;

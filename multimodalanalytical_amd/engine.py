@@ -141,7 +141,7 @@ class Seq2SeqEngine:
         # epilogues, the self-attention's query blocks -- leave 256-row groups of nothing but padding uncomputed (zeros written).
         # Only with backward pending: eval / generate return the reference's encoder_hidden_states rows.  AFM_FWD_ROW_SKIP=0: off.
         # AFM_FWD_COMPACT: 0 flags only, 1 live positions to the front of every sample's own S rows, 2 (default where the single-pass
-        # attention kernels run: 64-wide heads, no alignment head) the whole batch PACKED -- slots of ceil128(live) rows one behind the
+        # attention kernels run: 64-wide heads, no alignment head) the whole batch PACKED -- slots of ceil32(live) rows one behind the
         # other, so the 256-row tiles of the GEMMs straddle samples and only the batch's last tile is partly empty (c3: 58 % -> 52 % of
         # the B*S rows computed, c4: 69 % -> 63 %); the attention kernels address the slots through afm_attn_shape.q_off / k_off.
         # AFM_FWD_ROW_SKIP: 1 on, 0 off, "auto" (default): on, but PROBED -- every 64th planned step (the first included) reads back how many

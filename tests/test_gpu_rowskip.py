@@ -57,7 +57,7 @@ def _plan_ref(pad, mode):
     pad_new = (torch.arange(S)[None, :] >= n[:, None]).to(torch.uint8)
     if mode == 1:
         return base + rank, torch.arange(B + 1) * S, pad_new, n
-    slot = (n + 127) // 128 * 128
+    slot = (n + 31) // 32 * 32                                               # (a sample's slot: its live length rounded up to a wave's 32 rows)
     off = torch.cat([torch.zeros(1, dtype=torch.long), slot.cumsum(0)])
     total = int(off[-1])
     tail0 = total + (torch.arange(B) * S - off[:-1])                        # where each sample's share of the dead tail starts
@@ -288,9 +288,10 @@ def test_attn_fwd_padded_query_blocks(ops, p):
         assert bool(torch.isinf(l1[b, :, done:]).all())
 
 
+@pytest.mark.parametrize("lens", [(1024, 700, 130, 128, 5, 0, 333), (1024, 700, 130, 128, 5, 32, 333)])
 @pytest.mark.parametrize("p", [0.0, 0.1])
 @pytest.mark.parametrize("cross", [False, True])
-def test_attn_packed_rows_equal_dense(ops, p, cross):
+def test_attn_packed_rows_equal_dense(ops, p, cross, lens):
     """afm_attn_shape.q_off / k_off: the same attention on rows packed by afm_compact_plan (mode 2) -- self-attention over the packed
     encoder rows, and the decoder's cross-attention (dense queries, packed memory) -- forward and both backward kernels, against the
     dense (B, T) layout with the compacted mask."""
@@ -298,7 +299,9 @@ def test_attn_packed_rows_equal_dense(ops, p, cross):
     Tq = 128 if cross else T
     d = H * dh
     g = torch.Generator().manual_seed(9)
-    n = torch.tensor([1024, 700, 130, 128, 5, 0, 333])
+    # (slots of ceil32(live) rows: the second set ends the LAST slot on an odd 32-row boundary with the slots' end on a 64-row one -- the
+    # dK/dV kernel's last 64-query tile then reaches 32 rows into the dead tail, which this test fills with NaN in dO)
+    n = torch.tensor(lens)
     pad = (torch.arange(T)[None, :] >= n[:, None]).to(torch.uint8).to(DEV)        # already compacted per sample: live positions first
     plan = ops.compact_plan(pad, B, T, 256, compact=2)
     off = plan.seq_off
@@ -323,6 +326,7 @@ def test_attn_packed_rows_equal_dense(ops, p, cross):
             do = torch.zeros_like(do_d)
             if packed:
                 do[dest] = do_d
+                do[int(off[-1]):] = float("nan")      # the dead tail of dO: whatever an unfilled backward left there
             else:
                 do = do_d
         o = torch.full((B * Tq, d), 3.0, dtype=H16, device=DEV)
