@@ -764,8 +764,9 @@ def main():
                             "dtype": args.dtype}
             if "parity" in r:
                 workloads[w]["logits_vs_cpu_reference"] = r["parity"]
-            wsp = os.path.join(ROOT, "profiles", f"r05_{w}_{args.dtype}_step_pmc.json")       # committed counter passes of this workload's step
-            if os.path.exists(wsp):
+            wsp = next((q for q in (os.path.join(ROOT, "profiles", f"{rnd}_{w}_{args.dtype}_step_pmc.json") for rnd in ("r06", "r05"))
+                        if os.path.exists(q)), "")       # committed counter passes of this workload's step, newest round first
+            if wsp:
                 wp = json.load(open(wsp))
                 workloads[w]["step_counters"] = {"source": os.path.basename(wsp), **{k: wp[k] for k in
                                                  ("mfma_busy_frac", "hbm_gbs", "clock_ghz", "hbm_bytes_per_step", "kernel_ms_per_step") if k in wp}}
@@ -800,7 +801,7 @@ def main():
 
     # step-level counters (committed rocprofv3 PMC passes of this command, tools/prof_step_pmc.sh): MFMA-busy share and HBM rate of a step
     step_pmc = None
-    for rnd in ("r05", "r04"):
+    for rnd in ("r06", "r05", "r04"):
         sp = os.path.join(ROOT, "profiles", f"{rnd}_{args.workload}_{args.dtype}_step_pmc.json")
         if os.path.exists(sp):
             step_pmc = json.load(open(sp))
