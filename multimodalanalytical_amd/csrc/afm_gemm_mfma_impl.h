@@ -1741,13 +1741,23 @@ int AFM_E16_FN(afm_gemm_mfma_try)(const afm_gemm_desc* d, hipStream_t st) {
       // (196-221 vs 195-201 at N 1536: the epilogue, which all four waves reach together, weighs too much there).
       if (!(d->K & 127) && d->K >= 768 && d->N <= W4_BIAS_MAX) variant = 40;
     }
-    if (d->act >= AFM_ACT_GELU_SAVE_GRAD && variant != 24 && variant != 28) return AFM_ERR_UNSUPPORTED;
+    if (d->act >= AFM_ACT_GELU_SAVE_GRAD && variant != 24 && variant != 28 && variant != 213 && variant != 214) return AFM_ERR_UNSUPPORTED;
     int r;
 #define NT_CASE(WM, WN, NWM, NWN, BKT) \
     (d->c_dtype == AFM_E16 ? launch_nt<true, WM, WN, NWM, NWN, BKT>(g, st) : launch_nt<false, WM, WN, NWM, NWN, BKT>(g, st))
 #define PRING_CASE(NWM, NWN, S, BPC) \
     (d->c_dtype == AFM_E16 ? launch_nt_pring<true, NWM, NWN, S>(g, st, BPC) : launch_nt_pring<false, NWM, NWN, S>(g, st, BPC))
     switch (variant) {
+      case 213:   // (round-6 probe) the save-grad epilogues on 128 x 128 tiles, four waves, TWO workgroups per CU: one's epilogue under the other's main loop
+      case 214: { // (214: 256 x 128 tiles, eight waves, 2 stages = 96 KB: one per CU, for comparison)
+        if ((d->K & 63) || (d->M & 255) || (d->N & 127) || d->c_dtype != AFM_E16 || d->residual || d->accumulate || (d->ldc % 8) ||
+            (d->act != AFM_ACT_GELU_SAVE_GRAD && d->act != AFM_ACT_MUL_SAVED) || (uint64_t)d->M * (uint64_t)d->N > 0x100000000ull) { r = AFM_ERR_UNSUPPORTED; break; }
+        if (variant == 213) r = d->act == AFM_ACT_GELU_SAVE_GRAD ? launch_nt_pring<true, 2, 2, 2, 0, 4, EPI_GELU_SG, false>(g, st, 2)
+                                                                 : launch_nt_pring<true, 2, 2, 2, 0, 4, EPI_MUL, false>(g, st, 2);
+        else r = d->act == AFM_ACT_GELU_SAVE_GRAD ? launch_nt_pring<true, 4, 2, 2, 0, 4, EPI_GELU_SG, false>(g, st, 1)
+                                                  : launch_nt_pring<true, 4, 2, 2, 0, 4, EPI_MUL, false>(g, st, 1);
+        break;
+      }
       case 12: r = (d->K & 63) ? AFM_ERR_UNSUPPORTED : PRING_CASE(4, 2, 3, 1); break;   // persistent 256x128, 8 waves, 3 stages
       case 13: r = (d->K & 63) ? AFM_ERR_UNSUPPORTED : PRING_CASE(2, 2, 2, 2); break;   // persistent 128x128, 4 waves, 2 per CU
       case 28: {   // persistent 256x256 (8 waves of 128x64, 2 stages), whole tiles only, e16 output
