@@ -927,18 +927,23 @@ class Seq2SeqEngine:
                     mode = 1
                 plan = ops.compact_plan(key_pad, B, S, 256, compact=mode)
                 key_pad = plan.pad.view(B, S)
+                if probe is not None and probe[0] % 64 == 1:
+                    # rows in 256-row groups that hold something: the share of the forward's encoder-row work that remains (one 4-byte
+                    # readback per 64 planned steps of a shape; the plan of THIS step is used either way)
+                    groups = plan.live_tile.view(-1, 4)[:, 0]
+                    probe[1] = float(groups.float().mean()) <= 15.0 / 16.0
+                    if not probe[1]:
+                        self._arena.clear()
                 # packed rows + arena: the forward kernels leave the dead tail unwritten (the unfused FFN forms write through kernels that
-                # take no hint: they stay on fresh tensors with the zero fill)
-                nofill = plan.packed and self.fwd_arena and self.act == "gelu" and (not self.gated or self._glu_fusable(B * S, int(self.cfg["encoder_ffn_dim"])))
+                # take no hint: they stay on fresh tensors with the zero fill).  A shape the probe has turned off runs its probing steps on
+                # plain tensors with the zero fill: no 16 ... 47 GB of persistent buffers for one step in 64.
+                nofill = (plan.packed and self.fwd_arena and self.act == "gelu" and (not self.gated or self._glu_fusable(B * S, int(self.cfg["encoder_ffn_dim"])))
+                          and (probe is None or probe[1]))
                 self._arena_rows = B * S if nofill else 0
                 self._fwd_live["enc"] = ops.RowFlags(plan.live_tile, plan.packed, nofill)
                 self._enc_off = plan.seq_off if plan.packed else None
                 self._last_plan_mode = plan.mode      # (tests: which layout the step really ran)
                 saved["plan"] = plan
-                if probe is not None and probe[0] % 64 == 1:
-                    # rows in 256-row groups that hold something: the share of the forward's encoder-row work that remains
-                    groups = plan.live_tile.view(-1, 4)[:, 0]
-                    probe[1] = float(groups.float().mean()) <= 15.0 / 16.0
             x = self.embed_fwd(enc_inputs, None if saved is None else saved.setdefault("emb_enc", {}),
                                row_map=plan.dest if (plan is not None and plan.compact) else None)
         assert x.shape[0] == B * S, "attention_mask does not match the concatenated modalities"
