@@ -392,13 +392,17 @@ class Seq2SeqEngine:
                 residual=None, dropout=ops.NO_DROP, act=ACT_NONE, pre_act=None, sg_hi_only=False, role=None, key=None):
         w = self.W(name, rows, cols, r0, r1)
         n = w.shape[0]
+        fresh = False
         if out is None:
             arena = key is not None and self._arena_rows == x.shape[0] and (out_dtype or self.cd) == self.cd
             out = self._fbuf(key, x.shape[0], n) if arena else self._empty(x.shape[0], n, out_dtype)
+            fresh = not arena
         bias = None
         if bias_name is not None:
             bias = self.ps.vec_span(self.ps.flat, bias_name, r0, r0 + n)
         unread = self._fwd_hint(x, role) if (self.single16 and residual is None) else None
+        if fresh and isinstance(unread, ops.RowFlags) and unread.nofill:      # a fresh output tensor: its dead rows get the zero fill
+            unread = ops.RowFlags(unread.t, unread.dealt, False, unread.tag)
         return ops.gemm(x, w, out, trans_b=True, bias=bias, residual=residual, dropout=dropout, act=act,
                         pre_act=pre_act, algo=self.algo, sg_hi_only=sg_hi_only, rows_unread=unread)
 
@@ -591,11 +595,15 @@ class Seq2SeqEngine:
                         g = gi
 
     # ------------------------------------------------------------------ blocks
-    def _ln_fwd(self, x, prefix, saved, key, out_dtype=None, pend=None):
+    def _ln_fwd(self, x, prefix, saved, key, out_dtype=None, pend=None, arena=True):
         """y = LN(x + pend).  `pend` is the previous block's (dropped-out) branch output: the residual
-        add is fused here, the summed stream is materialised once (fp32) and returned."""
+        add is fused here, the summed stream is materialised once (fp32) and returned.  arena=False: fresh output tensors even in a
+        packed training step (their dead rows then get the zero fill): for outputs that leave the engine."""
         rows = x.shape[0]
-        ak = prefix if (self._arena_rows == rows and out_dtype is None and saved is not None) else None      # arena key (packed training step)
+        ak = prefix if (arena and self._arena_rows == rows and out_dtype is None and saved is not None) else None      # arena key (packed training step)
+        hint = self._fwd_hint(x)
+        if ak is None and isinstance(hint, ops.RowFlags) and hint.nofill:
+            hint = ops.RowFlags(hint.t, hint.dealt, False, hint.tag)
         y = self._fbuf(ak and ak + "y", rows, self.d, out_dtype)
         mean = self._fbuf(ak and ak + "mean", rows)
         rstd = self._fbuf(ak and ak + "rstd", rows)
@@ -605,10 +613,10 @@ class Seq2SeqEngine:
             br, br_drop = pend if isinstance(pend, tuple) else (pend, ops.NO_DROP)
             xs = self._fbuf(ak and ak + "xs", rows, self.d, torch.float32)   # x itself is the saved input of an earlier LayerNorm: keep it
             ops.layernorm_fwd(x, self.ps.p(prefix + "weight"), self.ps.p(prefix + "bias"), y, mean, rstd,
-                              add=br, x_sum=xs, add_dropout=br_drop, row_live=self._fwd_hint(x))
+                              add=br, x_sum=xs, add_dropout=br_drop, row_live=hint)
             x = xs
         else:
-            ops.layernorm_fwd(x, self.ps.p(prefix + "weight"), self.ps.p(prefix + "bias"), y, mean, rstd, row_live=self._fwd_hint(x))
+            ops.layernorm_fwd(x, self.ps.p(prefix + "weight"), self.ps.p(prefix + "bias"), y, mean, rstd, row_live=hint)
         if saved is not None:
             saved[key] = (x, mean, rstd)
         return y, x
@@ -963,7 +971,8 @@ class Seq2SeqEngine:
                 _, br = self._ffn_fwd(None, None, p, self.cfg["encoder_ffn_dim"], "norm2.", sv, f"e{i}", h=h)
                 x, h = self._post_norm(x, br, p + "norm2.", sv, "lnf")
             layers.append(sv)
-        mem, _ = self._ln_fwd(x, "encoder.norm.", saved, "enc_norm", pend=pend)
+        # (the memory leaves the engine as `encoder_hidden_states`: a fresh tensor, dead rows zero-filled, never a view of a persistent buffer)
+        mem, _ = self._ln_fwd(x, "encoder.norm.", saved, "enc_norm", pend=pend, arena=False)
         self._frole = None
         if saved is not None:
             saved.update(enc_layers=layers, key_pad=key_pad, B=B, S=S)
