@@ -175,3 +175,43 @@ def test_validation_pass_counts_the_trailing_short_batch():
     assert [i for i, _ in T.val_batches(loader(100, 16, "validation"), 0.5)] == [0, 1, 2]
     with pytest.raises(RuntimeError, match="no batch"):
         list(T.val_batches(loader(0, 16, "validation"), 1.0))
+
+
+def test_profile_tools_on_a_synthetic_trace(tmp_path):
+    """tools/rocpd_stats.py --by-grid --cluster and tools/rocpd_overlap.py --standin on a hand-made rocpd database: rows split by grid and by
+    duration band; the exchange's stand-in copies are found on the side queue and matched with the compute kernels that run meanwhile."""
+    import os
+    import sqlite3
+    import subprocess
+    import sys
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    db = tmp_path / "t.db"
+    con = sqlite3.connect(db)
+    con.execute("create table rocpd_info_kernel_symbol (id integer, kernel_name text)")
+    con.execute("create table rocpd_kernel_dispatch (kernel_id integer, start integer, end integer, queue_id integer, grid_size_x integer, "
+                "grid_size_y integer, grid_size_z integer, workgroup_size_x integer, group_segment_size integer)")
+    names = {1: "k_gemm", 2: "k_attn", 3: "__amd_rocclr_copyBuffer.kd", 4: "k_adam", 5: "k_sumsq", 6: "k_patch_x"}
+    for i, n in names.items():
+        con.execute("insert into rocpd_info_kernel_symbol values (?, ?)", (i, n))
+    t = 1000
+    rows = []
+    for step in range(2):
+        rows.append((6, t, t + 10, 4, 256, 1, 1, 256, 0)); t += 20
+        for layer in range(4):
+            rows.append((1, t, t + 100_000, 4, 65536, 1, 1, 256, 1000)); t += 100_010          # persistent GEMM: one grid, two bands
+            rows.append((1, t, t + 300_000, 4, 65536, 1, 1, 256, 1000)); t += 300_010
+            rows.append((2, t, t + 50_000, 4, 8192 * 256 if layer % 2 else 1024 * 256, 1, 1, 256, 500)); t += 50_010
+            rows.append((3, t - 40_000, t - 30_000, 1, 1024, 1, 1, 256, 0))                      # a bucket's stand-in copy on queue 1, beside the attention kernel
+        rows.append((3, t + 5, t + 4000, 1, 1024, 1, 1, 256, 0))                                 # the last bucket: after the backward
+        rows.append((5, t + 4100, t + 4200, 4, 64, 1, 1, 256, 0))
+        rows.append((4, t + 5000, t + 6000, 4, 4096 * 256, 1, 1, 256, 0)); t += 7000
+    con.executemany("insert into rocpd_kernel_dispatch values (?,?,?,?,?,?,?,?,?)", rows)
+    con.commit(); con.close()
+    tools = os.path.join(ROOT, "tools")
+    out = subprocess.run([sys.executable, os.path.join(tools, "rocpd_stats.py"), str(db), "--by-grid", "--cluster", "1.3"], capture_output=True, text=True, check=True).stdout
+    lines = [ln.lstrip('"') for ln in out.splitlines() if ln.lstrip('"').startswith("k_")]
+    assert sum("k_gemm" in ln and "#band0" in ln for ln in lines) == 1 and sum("k_gemm" in ln and "#band1" in ln for ln in lines) == 1
+    assert sum("k_attn [grid 8192 x 256" in ln for ln in lines) == 1 and sum("k_attn [grid 1024 x 256" in ln for ln in lines) == 1
+    ov = subprocess.run([sys.executable, os.path.join(tools, "rocpd_overlap.py"), str(db), "--standin"], capture_output=True, text=True, check=True).stdout
+    assert "5 RCCL kernels on queue(s) [1], compute on queue(s) [4]" in ov
+    assert ov.count("k_attn x1") == 4 and "0 kernels: -" in ov            # four buckets beside backward kernels, the last one alone
