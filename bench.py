@@ -773,6 +773,9 @@ def main():
             if w == "c4" and not args.no_roofline:
                 # the configuration the 8-GPU target is quoted on: live HIP-event timings of ITS dominant launches
                 workloads[w]["roofline_kernels"] = kernel_rooflines(r["model"], r["wl"], r["B"], args.dtype, w)
+                workloads[w]["roofline_note"] = ("each entry times ONE launch over all B*S rows with every row live: the kernel's rate.  In the timed step of this "
+                                                 "padded workload the encoder-row launches run over the packed live rows only (slots of ceil32(live) rows: "
+                                                 f"about {min(1.0, r['live_frac'] + 16.0 / r['S']):.2f} of B*S), so their time per micro-batch is that share of ms_per_micro_batch")
             if w == "c5" and not args.no_eval:
                 eval_out["beam5_c5"] = eval_decode(r["model"], r["wl"], "c5", 5, 256, r["B"])
             if "model" in r:
