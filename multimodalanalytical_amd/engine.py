@@ -165,6 +165,14 @@ class Seq2SeqEngine:
         # step of the same (B, S, T) shape ran WITH the fills and every hinted call reported that its kernels took the hint
         # (ops.hint_log / afm_last_hint): then nothing ever loads those rows.  From there on an ignored hint raises.  The gradient of the
         # stream that reaches the embedder's backward (which reads every position) keeps its zeros.
+        # AFM_XATTN_SIDE=1 (A / B probe of round 6, OFF by default): the decoder's cross-attention dK/dV kernel -- 128 queries against 1 024
+        # keys: a workgroup's life is its prologue, 2.7 TB/s and 0.13 of the MFMA peak, 3 ... 5 % of a step -- on a SIDE stream.  Nothing of the
+        # layer needs dK | dV before the weight-gradient group at the layer's end, so the kernel could overlap the chain of small launches
+        # behind it.  Measured (tools/r6_ab.sh, one box, alternating): c2 3 188 vs 3 195, c3 5 673 vs 5 615, c4 1 210 vs 1 207 samples/s
+        # (off vs on): nothing, as for the side-stream weight gradients of round 3 -- two queues do not fill each other's gaps here.
+        self.xattn_stream = (torch.cuda.Stream(device=self.dev)
+                             if self.dev.type == "cuda" and os.environ.get("AFM_XATTN_SIDE", "0") == "1" else None)
+        self._xattn_pending = False
         self.bwd_nofill = os.environ.get("AFM_BWD_NOFILL", "1") != "0"
         self.debug_poison = os.environ.get("AFM_DEBUG_POISON", "0") == "1"      # (tests) backward tensors start as NaN
         self._bwd_verified: Dict[Any, bool] = {}      # (B, S, T) -> every hint of a filled backward was honoured
@@ -451,6 +459,9 @@ class Seq2SeqEngine:
 
     def _wgrad_flush(self) -> None:
         """Launch the weight gradients collected since the last flush (afm_gemm_group)."""
+        if self._xattn_pending:      # the cross-attention dK | dV of this layer (side stream) are operands of the group below
+            torch.cuda.current_stream().wait_stream(self.xattn_stream)
+            self._xattn_pending = False
         pending, self._wg_pending = self._wg_pending, []
         if not pending:
             return
@@ -873,8 +884,28 @@ class Seq2SeqEngine:
         if shp.k_off and isinstance(hint_e, ops.RowFlags) and hint_e.nofill:
             shp.reserved |= 131072      # packed memory rows, verified hints: the dead tail of dK / dV is left unwritten
         shp.reserved |= self.attn_bwd_flags
-        ops.attn_bwd(shp, self._hb(q), kv_b[:, :d], kv_b[:, d:], self._hb(a), da, lse, delta, dq, dkv[:, :d], dkv[:, d:],
-                     ops._ld(dq), ldkv, ldkv)
+        args = (self._hb(q), kv_b[:, :d], kv_b[:, d:], self._hb(a), da, lse, delta, dq, dkv[:, :d], dkv[:, d:], ops._ld(dq), ldkv, ldkv)
+        side = self.xattn_stream if (dkv_all is not None and self.single16 and self.group_wgrad and self.wgrad_stream is None) else None
+        if side is None:
+            ops.attn_bwd(shp, *args)
+        else:
+            # delta and dQ here; dK | dV on the side stream behind them (they read delta), joined in front of the layer's weight gradients
+            def part(bits):
+                sp = type(shp).from_buffer_copy(shp)
+                sp.reserved = (shp.reserved & ~3) | bits
+                for k in ("_bits_keepalive", "_keepalive", "_off_keepalive"):
+                    if hasattr(shp, k):
+                        setattr(sp, k, getattr(shp, k))
+                return sp
+            ops.attn_bwd(part(1), *args)
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream())
+            side.wait_event(ev)
+            with torch.cuda.stream(side):
+                ops.attn_bwd(part(2), *args)
+            for t in (da, delta):      # (locals of this call: their memory must outlive the side kernel; everything else lives in `saved`)
+                t.record_stream(side)
+            self._xattn_pending = True
         w, bname = p + "multihead_attn.in_proj_weight", p + "multihead_attn.in_proj_bias"
         self._wgrad(dq, h, w, 3 * d, d, 0, d, bias_name=bname)
         self._wgrad(dkv, mem, w, 3 * d, d, d, 3 * d, bias_name=bname, role="enc")      # memory-side rows: encoder positions
@@ -1371,6 +1402,9 @@ class Seq2SeqEngine:
         d = self.d
         B, S, T = saved["B"], saved["S"], saved["T"]
         self._wg_pending = []          # (a backward pass that raised may have left entries behind)
+        if self._xattn_pending:
+            torch.cuda.current_stream().wait_stream(self.xattn_stream)
+            self._xattn_pending = False
         self._wg_layers_pending = 0
         # Padded positions are masked as keys everywhere and take no part in the loss: their rows of every activation gradient are
         # exact zeros.  One byte per 64-row block tells the weight-gradient kernels (token axis) and the LayerNorm backward which
