@@ -1088,6 +1088,7 @@ __global__ __launch_bounds__(256) void k_attn_bits_fill(AttnM a) {
 #include "afm_attn_pipe16_impl.h"
 #include "afm_attn_fwd16_impl.h"
 #include "afm_attn_sq_impl.h"
+#include "afm_attn_fsq_impl.h"
 
 }  // namespace AFM_E16_NS
 using namespace AFM_E16_NS;
@@ -1207,6 +1208,33 @@ int AFM_E16_FN(afm_attn_bwd_mfma_try)(const afm_attn_shape* s, const void* Q, co
     (void)hipFuncSetAttribute((const void*)k_attn_bwd_dq_mfma<DROP_NONE>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
   }
   const bool run_q = (s->reserved & 3) != 2, run_k = (s->reserved & 3) != 1;   // reserved & 3 = 1 / 2: only the dQ / only the dK-dV kernel (timing)
+  // Round 6: short query sequences (the decoder's cross-attention), dQ, dK and dV in ONE kernel (afm_attn_fsq_impl.h): reserved & 262144
+  if ((s->reserved & 262144) && (s->reserved & 3) == 0 && !s->causal && s->Tq <= 128 && !s->q_off && (!s->k_off || s->key_pad) &&
+      (!a.dd.thresh16 || a.bits)) {
+    const int shm_f = RS * 2 * KT * DH * 2 + 4 * KT * DH * 2 + ((s->Tk + KT - 1) / KT) * 12 + 16;      // ring, P / dS tiles, key-mask words and tile list
+    if (shm_f <= 80 * 1024) {
+      static AfmOncePerDevice attr_f;
+      if (attr_f.need()) {
+        (void)hipFuncSetAttribute((const void*)k_attn_bwd_fsq<DROP_BITS>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+        (void)hipFuncSetAttribute((const void*)k_attn_bwd_fsq<DROP_NONE>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+      }
+      const dim3 gf(s->H * s->B);
+#ifdef AFM_ATTN_ABLATIONS
+#define AFM_FSQ_ABL_CASE(N) case N: (void)hipFuncSetAttribute((const void*)k_attn_bwd_fsq<DROP_BITS, N>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); \
+      AFM_LAUNCH((k_attn_bwd_fsq<DROP_BITS, N>), gf, dim3(256), shm_f, st, a, (const e16*)Q, (const e16*)K, (const e16*)V, (const e16*)O, (const e16*)dO, lse, delta, (e16*)dQ, (e16*)dK, (e16*)dV); return AFM_OK;
+      if (a.dd.thresh16 && ((s->reserved >> 20) & 255)) {
+        switch ((s->reserved >> 20) & 255) {
+          AFM_FSQ_ABL_CASE(1) AFM_FSQ_ABL_CASE(2) AFM_FSQ_ABL_CASE(3) AFM_FSQ_ABL_CASE(4) AFM_FSQ_ABL_CASE(7) AFM_FSQ_ABL_CASE(8) AFM_FSQ_ABL_CASE(15) AFM_FSQ_ABL_CASE(16) AFM_FSQ_ABL_CASE(23) AFM_FSQ_ABL_CASE(31)
+          default: return AFM_ERR_UNSUPPORTED;
+        }
+      }
+#endif
+      if (a.dd.thresh16) AFM_LAUNCH(k_attn_bwd_fsq<DROP_BITS>, gf, dim3(256), shm_f, st, a, (const e16*)Q, (const e16*)K, (const e16*)V, (const e16*)O, (const e16*)dO, lse, delta, (e16*)dQ, (e16*)dK, (e16*)dV);
+      else AFM_LAUNCH(k_attn_bwd_fsq<DROP_NONE>, gf, dim3(256), shm_f, st, a, (const e16*)Q, (const e16*)K, (const e16*)V, (const e16*)O, (const e16*)dO, lse, delta, (e16*)dQ, (e16*)dK, (e16*)dV);
+      afm_set_last_algo("attn_fsq");
+      return AFM_OK;
+    }
+  }
   static const bool eight_wave = getenv("AFM_ATTN_8WAVE") != nullptr;
   const bool packed = s->q_off || s->k_off;
   // packed rows exist in the pipelined 16 x 16 x 32 dK/dV kernel only: refuse BEFORE anything is launched where it would not run

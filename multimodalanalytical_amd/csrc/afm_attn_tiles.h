@@ -32,7 +32,7 @@ __device__ __forceinline__ int64_t attn_tail0(const int32_t* off, int B, int b, 
 // kernels that work on 64-row blocks (LayerNorm, the weight gradients' k-steps) treat the block around it as live and READ its upper half:
 // those <= 32 tail rows always get their zeros.
 __device__ __forceinline__ int64_t attn_fill_end(int nofill, const int32_t* off, int B) {
-  return nofill ? (((int64_t)off[B] + 63) & ~(int64_t)63) : ((int64_t)1 << 62);
+  return (nofill && off) ? (((int64_t)off[B] + 63) & ~(int64_t)63) : ((int64_t)1 << 62);
 }
 // the row an output of in-sample row r goes to: the sample's own row, or (packed, r beyond the slot) its row of the dead tail; -1: none (r >= T unpacked)
 __device__ __forceinline__ int64_t attn_out_row(const int32_t* off, int B, int b, int T, int64_t row0, int r, int lim) {

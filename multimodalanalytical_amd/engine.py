@@ -132,6 +132,9 @@ class Seq2SeqEngine:
         # kernel-selection bits OR-ed into afm_attn_shape.reserved of every attention backward call (include/afm_hip.h: A / B runs; the
         # keep-bit / re-hash equivalence test pins both paths to the same MFMA shape with it)
         self.attn_bwd_flags = int(os.environ.get("AFM_ATTN_BWD_FLAGS", "0"), 0)
+        # the decoder's cross-attention backward as ONE kernel (csrc/afm_attn_fsq_impl.h; afm_attn_shape.reserved bit 18) where its
+        # conditions hold (<= 128 decoder positions, keep-bit dropout or none); the library falls back to the two kernels elsewhere
+        self.xattn_fused = os.environ.get("AFM_XATTN_FUSED", "0") == "1"
         self.bits_stream = (torch.cuda.Stream(device=self.dev)
                             if self.dev.type == "cuda" and os.environ.get("AFM_BITS_AHEAD", "0") == "1" else None)
         self._wg_pending = []
@@ -883,7 +886,7 @@ class Seq2SeqEngine:
         hint_e = self._live.get("enc")
         if shp.k_off and isinstance(hint_e, ops.RowFlags) and hint_e.nofill:
             shp.reserved |= 131072      # packed memory rows, verified hints: the dead tail of dK / dV is left unwritten
-        shp.reserved |= self.attn_bwd_flags
+        shp.reserved |= self.attn_bwd_flags | (262144 if self.xattn_fused else 0)
         args = (self._hb(q), kv_b[:, :d], kv_b[:, d:], self._hb(a), da, lse, delta, dq, dkv[:, :d], dkv[:, d:], ops._ld(dq), ldkv, ldkv)
         side = self.xattn_stream if (dkv_all is not None and self.single16 and self.group_wgrad and self.wgrad_stream is None) else None
         if side is None:
