@@ -161,6 +161,8 @@ def test_dropout_keep_bits_equal_rehash(mode):
                             compute_dtype=_dtype(mode), seed=5, backward_dtype=_bdtype(mode))
         eng.keep_bits = keep_bits
         eng.attn_bwd_flags = 16384 | 32768   # both paths on the 32 x 32 x 16 backward kernels (round 5: the defaults differ by dropout path)
+        eng.xattn_fused = False              # (round 6: the fused cross-attention backward exists for the keep-bit path only and keeps dO unrounded --
+                                             # another rounding of dQ, 4 % of decoder.layers.0.norm2.weight's small bf16 gradient: not "the same kernels")
         eng.load_state_dict(sd)
         eng.train()
         out = eng.forward(_to(enc), am.to(DEV), dec.to(DEV), dm.to(DEV), labels.to(DEV), backward=True)
