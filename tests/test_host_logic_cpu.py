@@ -215,3 +215,22 @@ def test_profile_tools_on_a_synthetic_trace(tmp_path):
     ov = subprocess.run([sys.executable, os.path.join(tools, "rocpd_overlap.py"), str(db), "--standin"], capture_output=True, text=True, check=True).stdout
     assert "5 RCCL kernels on queue(s) [1], compute on queue(s) [4]" in ov
     assert ov.count("k_attn x1") == 4 and "0 kernels: -" in ov            # four buckets beside backward kernels, the last one alone
+
+
+def test_isa_spill_check_flags_a_spill_of_an_inflight_asm_read(tmp_path):
+    """tools/isa_asm_spill_check.py on hand-made ISA: a scratch store of a register an asm `ds_read_b64_tr_b16` wrote, with no
+    `s_waitcnt lgkmcnt(0)` in between, is a hazard (the compiler does not know the read is asynchronous); behind the wait it is not."""
+    import os
+    import sys
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from isa_asm_spill_check import check
+    bad = tmp_path / "bad.s"
+    bad.write_text("_Z5k_badv: ; @k\n\tds_read_b64_tr_b16 v[46:47], v35 offset:0\n\tds_read_b64_tr_b16 v[48:49], v35 offset:1024\n"
+                   "\tscratch_store_dwordx4 off, v[46:49], off ; 16-byte Folded Spill\n\ts_endpgm\n.Lfunc_end0:\n")
+    good = tmp_path / "good.s"
+    good.write_text("_Z6k_goodv: ; @k\n\tds_read_b64_tr_b16 v[46:47], v35 offset:0\n\ts_waitcnt lgkmcnt(0)\n"
+                    "\tscratch_store_dwordx2 off, v[46:47], off ; 8-byte Folded Spill\n\tds_read_b64_tr_b16 v[10:11], v35 offset:0\n"
+                    "\tscratch_store_dword off, v12, off offset:8\n\ts_endpgm\n.Lfunc_end0:\n")
+    assert check(str(bad)) == 1
+    assert check(str(good)) == 0
