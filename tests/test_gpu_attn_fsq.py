@@ -62,9 +62,10 @@ def _torch_ref(q, k, v, do, pad, H, scale, keep=None, p_drop=0.0):
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("p", [0.0, 0.1])
 @pytest.mark.parametrize("Tq,Tk,lens", [(128, 1024, (1024, 700, 130, 64, 5, 0, 333, 960)), (100, 1024, (1024, 2, 63, 65, 512, 200, 999, 128)),
-                                        (128, 56, (56, 3, 17, 40, 0, 56, 1, 33)), (37, 200, (200, 64, 129, 7, 0, 199, 128, 100))])
+                                        (128, 56, (56, 3, 17, 40, 0, 56, 1, 33)), (37, 200, (200, 64, 129, 7, 0, 199, 128, 100)),
+                                        (64, 320, (320, 100, 31))])
 def test_fused_equals_two_kernels(ops, dtype, p, Tq, Tk, lens):
-    B, H, dh = 8, 8, 64
+    B, H, dh = len(lens), (8 if len(lens) == 8 else 5), 64          # (3 x 5 heads: not a multiple of 8, the block map's other branch)
     d = H * dh
     g = torch.Generator().manual_seed(3)
     n = torch.tensor(lens)
