@@ -45,20 +45,21 @@ template <int SL> __device__ __forceinline__ FsqPS fsq_ps_issue(const unsigned (
   return r;
 }
 template <int SL>
-__device__ __forceinline__ void fsq_phase_b(const unsigned (&x)[4], const e16x8 (&dT)[8], const e16x8 (&qT)[8], const FsqPS cur, f32x16& dv, f32x16& dk) {
+__device__ __forceinline__ void fsq_phase_b(const unsigned (&x)[4], const e16x8 (&dT)[5], const e16x8* park, const e16x8 (&qT)[8], const FsqPS cur, f32x16& dv, f32x16& dk) {
+  e16x8 dfrag;
+  if constexpr (SL >= 5) dfrag = park[(SL - 5) * 256]; else dfrag = dT[SL];      // (slices 5-7 of dO^T wait in LDS: see the kernel)
   if constexpr (SL < 7) {
     const FsqPS nxt = fsq_ps_issue<SL + 1>(x);
     tr_wait<4>();
-    dv = mfma32(dT[SL], tr_join(cur.plo, cur.phi), dv);
+    dv = mfma32(dfrag, tr_join(cur.plo, cur.phi), dv);
     dk = mfma32(qT[SL], tr_join(cur.slo, cur.shi), dk);
-    fsq_phase_b<SL + 1>(x, dT, qT, nxt, dv, dk);
+    fsq_phase_b<SL + 1>(x, dT, park, qT, nxt, dv, dk);
   } else {
     tr_wait<0>();
-    dv = mfma32(dT[SL], tr_join(cur.plo, cur.phi), dv);
+    dv = mfma32(dfrag, tr_join(cur.plo, cur.phi), dv);
     dk = mfma32(qT[SL], tr_join(cur.slo, cur.shi), dk);
   }
 }
-
 // ABL (AFM_ATTN_ABLATIONS builds, timing only -- results wrong by construction): 1 no dK / dV stores, 2 no phase B (reads and products),
 // 4 no P / dS stores to LDS, 8 no dQ product (transposed K reads and MFMAs), 16 no exp2 / dropout / mask work on the scores
 template <int DROP, int ABL = 0>
@@ -70,7 +71,7 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd_fsq(AttnM a, const e16* __r
   static_assert(DROP == DROP_NONE || DROP == DROP_BITS, "keep-bit tensor or no dropout");
   constexpr int IMG = KT * DH * 2;            // one [64][64] e16 image
   constexpr int STAGE = 2 * IMG;              // K dual-use image, V row image
-  constexpr int PIMG = RS * STAGE, QIMG = PIMG, DOIMG = PIMG + 2 * IMG, MASK = PIMG + 4 * IMG;      // (dS tile: PIMG + 2 IMG; Q / dO images: prologue only)
+  constexpr int PIMG = RS * STAGE, QIMG = PIMG, DOIMG = PIMG + 2 * IMG, PARK = PIMG + 4 * IMG, MASK = PARK + 3 * 4096;      // (dS tile: PIMG + 2 IMG; Q / dO images: prologue only)
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   unsigned long long* maskw = (unsigned long long*)(lds + MASK);
   const int t = threadIdx.x, lane = t & 63, h = lane >> 5;
@@ -80,8 +81,11 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd_fsq(AttnM a, const e16* __r
   const int q0 = w * 32;
   const int q = q0 + (lane & 31);
   const int qc = q < a.Tq ? q : a.Tq - 1;
-  const int64_t rq = (int64_t)b * a.Tq, rk = attn_row0(a.k_off, b, a.Tk);
-  const int lim_k = attn_slot(a.k_off, b, a.Tk);
+  // (the packed offsets come out of memory: told to be wave-uniform, the tile bases below stay in scalar registers.  As lane values they
+  // were spilled, and the reload of a spilled base in front of every LDS-DMA piece came with `s_waitcnt vmcnt(0)`: the ring's pieces
+  // went out one full memory latency apart)
+  const int64_t rq = (int64_t)b * a.Tq, rk = (int64_t)__builtin_amdgcn_readfirstlane((int)attn_row0(a.k_off, b, a.Tk));
+  const int lim_k = __builtin_amdgcn_readfirstlane(attn_slot(a.k_off, b, a.Tk));
   const e16* Kb = K + rk * a.ldk + hd * DH;
   const e16* Vb = V + rk * a.ldv + hd * DH;
   const e16* Qb = Q + rq * a.ldq + hd * DH;
@@ -135,16 +139,16 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd_fsq(AttnM a, const e16* __r
   for (int m = 0; m < 2; ++m)
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
-      dma_piece<true>(lds + QIMG + m * IMG, Qb, a.ldq, 64 * m, a.Tq, w + 4 * u, lane);
-      dma_piece<true>(lds + DOIMG + m * IMG, Db, a.ldo, 64 * m, a.Tq, w + 4 * u, lane);
+      dma_piece_s<1>(lds + QIMG + m * IMG, Qb, a.ldq, 64 * m, a.Tq, w + 4 * u, lane);
+      dma_piece_s<1>(lds + DOIMG + m * IMG, Db, a.ldo, 64 * m, a.Tq, w + 4 * u, lane);
     }
   auto issue = [&](int j) {
     unsigned char* st = lds + (j % RS) * STAGE;
     const int kt = tl[j + rot < nlive ? j + rot : j + rot - nlive];
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
-      dma_piece_dual(st, Kb, a.ldk, kt * KT, a.Tk, w + 4 * u, lane);
-      dma_piece<false>(st + IMG, Vb, a.ldv, kt * KT, a.Tk, w + 4 * u, lane);
+      dma_piece_s<2>(st, Kb, a.ldk, kt * KT, a.Tk, w + 4 * u, lane);
+      dma_piece_s<0>(st + IMG, Vb, a.ldv, kt * KT, a.Tk, w + 4 * u, lane);
     }
   };
 #pragma unroll
@@ -165,7 +169,7 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd_fsq(AttnM a, const e16* __r
     for (int i = 0; i < 4; ++i) xps[i] = rb + (cp ^ (16 * i));
   }
   // dO^T / Q^T fragments of this wave's d-block over the 128 queries
-  e16x8 dT[8], qT[8];
+  e16x8 dT[5], qT[8];
   attn_wait_vmcnt<4>();          // the image pieces are older than the first stage's four
   __builtin_amdgcn_s_barrier();
   // (read AND waited for inside one asm statement each: the compiler does not know these reads are asynchronous, and a fragment it decides
@@ -177,9 +181,15 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd_fsq(AttnM a, const e16* __r
     const unsigned aD = (w >> 1) ? x1 : x0;
     tr_lane_addr(lds + QIMG + m * IMG, lane, x0, x1);
     const unsigned aQ = (w >> 1) ? x1 : x0;
-    dT[4 * m] = fsq_frag_sync<0>(aD); dT[4 * m + 1] = fsq_frag_sync<2048>(aD); dT[4 * m + 2] = fsq_frag_sync<4096>(aD); dT[4 * m + 3] = fsq_frag_sync<6144>(aD);
+    e16x8* const park = (e16x8*)(lds + PARK) + t;      // (slices 5-7: straight to their place in LDS, below)
+    if (m == 0) { dT[0] = fsq_frag_sync<0>(aD); dT[1] = fsq_frag_sync<2048>(aD); dT[2] = fsq_frag_sync<4096>(aD); dT[3] = fsq_frag_sync<6144>(aD); }
+    else { dT[4] = fsq_frag_sync<0>(aD); park[0] = fsq_frag_sync<2048>(aD); park[256] = fsq_frag_sync<4096>(aD); park[512] = fsq_frag_sync<6144>(aD); }
     qT[4 * m] = fsq_frag_sync<0>(aQ); qT[4 * m + 1] = fsq_frag_sync<2048>(aQ); qT[4 * m + 2] = fsq_frag_sync<4096>(aQ); qT[4 * m + 3] = fsq_frag_sync<6144>(aQ);
   }
+  // Three of the sixteen fragments wait in LDS (16 bytes per lane each, 12 KB) and come back at the start of every phase B: phase A is 12
+  // registers over the 256 a wave has at two workgroups per CU, and what the compiler spilled instead were these same fragments -- to
+  // scratch, three dependent reloads per tile, each behind an `s_waitcnt vmcnt(0)`.
+  const e16x8* const park = (const e16x8*)(lds + PARK) + t;
   const bool qlive = q < a.Tq;
   const unsigned kt0 = tr_dual_t0(lane);
   const int64_t fill_end = attn_fill_end(a.nofill, a.k_off, a.B);
@@ -268,14 +278,15 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd_fsq(AttnM a, const e16* __r
         if (blk == 0) AFM_FSQ_DQ(0) else AFM_FSQ_DQ(32 * 128)
 #undef AFM_FSQ_DQ
       }
+
     }
     __syncthreads();      // the head's P / dS tiles of this key tile are complete
     // ---- phase B: dV^T (d-block dblk, key-block kblk) = dO^T P_drop, dK^T = Q^T dS over the 128 queries
     f32x16 dv, dk;
 #pragma unroll
     for (int i = 0; i < 16; ++i) { dv[i] = 0.f; dk[i] = 0.f; }
-    if (!(ABL & 2)) fsq_phase_b<0>(xps, dT, qT, fsq_ps_issue<0>(xps), dv, dk);
-    else { dv[0] = (float)dT[0][0] + (float)dT[7][3]; dk[0] = (float)qT[0][1] + (float)qT[7][2]; }
+    if (!(ABL & 2)) fsq_phase_b<0>(xps, dT, park, qT, fsq_ps_issue<0>(xps), dv, dk);
+    else { dv[0] = (float)dT[0][0] + (float)dT[4][3]; dk[0] = (float)qT[0][1] + (float)qT[7][2]; }
     if (!(ABL & 1) || j == 0) {
       // The accumulators hold dK^T / dV^T with the key on the lane: stored from there, a lane would write 8 bytes into each of four 64-byte
       // row pieces (measured: the stores were over half of the kernel).  They turn through LDS instead -- this wave's 4 KB of the ring

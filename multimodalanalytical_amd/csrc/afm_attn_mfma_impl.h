@@ -466,7 +466,8 @@ __global__ __launch_bounds__(256, AFM_DQ_OCC) void k_attn_bwd_dq_mfma(AttnM a, c
   const int q0 = blk_.xb * 128 + w * 32;
   const int q = q0 + (lane & 31);
   const int qc = q < a.Tq ? q : a.Tq - 1;
-  const int64_t rq = attn_row0(a.q_off, b, a.Tq), rk = attn_row0(a.k_off, b, a.Tk);
+  // (rk through readfirstlane: the K / V tile bases are then scalar for the compiler and the ring's pieces take the saddr form, dma_piece_s)
+  const int64_t rq = attn_row0(a.q_off, b, a.Tq), rk = (int64_t)__builtin_amdgcn_readfirstlane((int)attn_row0(a.k_off, b, a.Tk));
   const int lim_q = attn_slot(a.q_off, b, a.Tq);      // rows of this sample that are its own (packed: its slot)
   {
     int64_t tail0;
@@ -548,9 +549,15 @@ __global__ __launch_bounds__(256, AFM_DQ_OCC) void k_attn_bwd_dq_mfma(AttnM a, c
     const int kt = tl[j];
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
+#ifdef AFM_DQ_OLD_DMA      // (A / B builds: the 64-bit lane addresses of rounds 2-5)
       dma_piece<false>(st, Kb, a.ldk, kt * KT, a.Tk, w + 4 * u, lane);
       dma_piece<true>(st + KT * DH * 2, Kb, a.ldk, kt * KT, a.Tk, w + 4 * u, lane);
       dma_piece<false>(st + 2 * KT * DH * 2, Vb, a.ldv, kt * KT, a.Tk, w + 4 * u, lane);
+#else
+      dma_piece_s<0>(st, Kb, a.ldk, kt * KT, a.Tk, w + 4 * u, lane);
+      dma_piece_s<1>(st + KT * DH * 2, Kb, a.ldk, kt * KT, a.Tk, w + 4 * u, lane);
+      dma_piece_s<0>(st + 2 * KT * DH * 2, Vb, a.ldv, kt * KT, a.Tk, w + 4 * u, lane);
+#endif
     }
   };
 #pragma unroll
@@ -1211,7 +1218,7 @@ int AFM_E16_FN(afm_attn_bwd_mfma_try)(const afm_attn_shape* s, const void* Q, co
   // Round 6: short query sequences (the decoder's cross-attention), dQ, dK and dV in ONE kernel (afm_attn_fsq_impl.h): reserved & 262144
   if ((s->reserved & 262144) && (s->reserved & 3) == 0 && !s->causal && s->Tq <= 128 && !s->q_off && (!s->k_off || s->key_pad) &&
       (!a.dd.thresh16 || a.bits)) {
-    const int shm_f = RS * 2 * KT * DH * 2 + 4 * KT * DH * 2 + ((s->Tk + KT - 1) / KT) * 12 + 16;      // ring, P / dS tiles, key-mask words and tile list
+    const int shm_f = RS * 2 * KT * DH * 2 + 4 * KT * DH * 2 + 3 * 4096 + ((s->Tk + KT - 1) / KT) * 12 + 16;      // ring, P / dS tiles, parked fragments, key-mask words and tile list
     if (shm_f <= 80 * 1024) {
       static AfmOncePerDevice attr_f;
       if (attr_f.need()) {

@@ -320,6 +320,21 @@ __device__ __forceinline__ TrQuad tr_quad_dual(const unsigned (&xa)[4], const un
   return q;
 }
 
+// dma_piece / dma_piece_dual with the address as (wave-uniform base) + (32-bit lane offset) (round 6): the base stays in scalar registers and
+// the load takes its saddr form.  With 64-bit lane addresses the compiler hoists base + chunk per piece out of the tile loop (two registers
+// per piece) and, where registers are short, spills them -- and ANY scratch reload inside a ring loop comes with `s_waitcnt vmcnt(0)`, i.e.
+// waits for every piece in flight (tools/isa_ring_drain_check.py lists them).  `base` must be wave-uniform for the compiler to see (a row
+// offset read from memory goes through readfirstlane first); the offset must stay below 4 GB (rows of ONE sample).
+template <int KIND>      // 0 row image, 1 transposed-read image, 2 dual-use image
+__device__ __forceinline__ void dma_piece_s(unsigned char* img, const e16* base, int ld, int row0, int nrows, int pi, int lane) {
+  const int r = 8 * pi + (lane >> 3), slot = lane & 7;
+  const int chunk = KIND == 2 ? (slot ^ dual_f(r)) : KIND == 1 ? (slot ^ (((r >> 1) & 1) << 2)) : (slot ^ ((r >> 1) & 7));
+  int gr = row0 + r;
+  gr = gr < nrows ? gr : nrows - 1;   // clamped rows are masked out by the caller
+  const uint32_t off = ((uint32_t)gr * (uint32_t)ld + (uint32_t)chunk * 8u) * 2u;
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)((const char*)base + off),
+                                   (__attribute__((address_space(3))) void*)(img + pi * 1024), 16, 0, 0);
+}
 // ------------------------------------------------------------------------------------------ keep-bit tensor
 // DROP template values of the MFMA attention kernels: 0 no dropout, 1 hash per score pair, 2 keep-bit tensor (forward:
 // hash + emit the lane masks; backward: read them).
