@@ -189,6 +189,34 @@ def kernel_rooflines(model, wl, B, mode, wl_name="c2"):
     add("attention backward, dK/dV kernel", f"afm_attn_bwd[{algo}] dK/dV", ms, 4 * prod, eb * 6 * M * d + bits_bytes, Le,
         "4 products: Q K^T and dO V^T recomputed, P^T dO, dS^T Q" + ("; reads the dropout keep bits" if bits is not None else ""), bmode)
 
+    # --- the decoder's cross-attention backward (T queries against the S memory positions): one fused kernel where the library has one
+    # (round 6, csrc/afm_attn_fsq_impl.h: T <= 128, keep-bit dropout or none), the dQ / dK-dV pair elsewhere
+    T = int(wl["T"])
+    if not mixed and mode in ("fp16", "bf16"):
+        Ld = cfg["decoder_layers"]
+        qx = _rand(B * T, d, cd, dev)
+        kvx = _rand(M, 2 * d, cd, dev)
+        ox = ops.empty(B * T, d, cd, dev)
+        dox = ops.empty(B * T, d, cd, dev)
+        ops.convert(torch.randn(B * T, d, device=dev) * 0.01, dox)
+        dqx, dkvx = ops.empty(B * T, d, cd, dev), ops.empty(M, 2 * d, cd, dev)
+        lsex = torch.empty(B * H * T, device=dev)
+        deltax = torch.empty_like(lsex)
+        sx = ops.attn_shape(B, H, T, S, dh, cd, d, 2 * d, 2 * d, d, torch.zeros(B, S, dtype=torch.uint8, device=dev), False, dr)
+        bitsx = None
+        if eng.keep_bits and cfg["dropout"] > 0:
+            bitsx = torch.zeros(ops.attn_drop_bits_words(B, H, T, S), dtype=torch.int64, device=dev)
+            ops.attn_set_drop_bits(sx, bitsx)
+        ops.attn_fwd(sx, qx, kvx[:, :d], kvx[:, d:], ox, lsex)
+        sx.reserved |= 262144 if getattr(eng, "xattn_fused", False) else 0
+        ms = time_kernel(lambda: ops.attn_bwd(sx, qx, kvx[:, :d], kvx[:, d:], ox, dox, lsex, deltax, dqx, dkvx[:, :d], dkvx[:, d:], d, 2 * d, 2 * d))
+        algo = ops.last_algo()
+        prodx = 2.0 * B * H * T * S * dh
+        add("cross-attention backward (decoder queries x encoder memory), dQ + dK + dV", f"afm_attn_bwd[{algo}] cross", ms, 5 * prodx,
+            ESZ[mode] * (4 * M * d + 4 * B * T * d) + (0 if bitsx is None else bitsx.numel() * 8), Ld,
+            ("5 products in one kernel: K Q^T, V dO^T, K^T dS^T, dO^T P, Q^T dS" if algo == "attn_fsq" else "7 products in two kernels (S and dP twice)")
+            + ("; reads the dropout keep bits" if bitsx is not None else ""), mode)
+
     # --- GEMMs of one encoder layer at their training epilogues
     x = _rand(M, d, cd, dev)
     pre = ops.empty(M, f, cd, dev)                       # stored keep*scale*GELU' (forward output, backward input)
