@@ -78,7 +78,7 @@ __global__ __launch_bounds__(256, OCC) void k_attn_bwd_dq_m16(AttnM a, const e16
   const AttnBlock blk_ = attn_block(a.H, a.B, (a.Tq + 127) / 128);
   const int hd = blk_.hd, b = blk_.b;
   const int q0 = blk_.xb * 128 + w * 32;
-  const int64_t rq = attn_row0(a.q_off, b, a.Tq), rk = attn_row0(a.k_off, b, a.Tk);
+  const int64_t rq = attn_row0(a.q_off, b, a.Tq), rk = (int64_t)__builtin_amdgcn_readfirstlane((int)attn_row0(a.k_off, b, a.Tk));      // (scalar tile bases: dma_piece_s)
   const int lim_q = attn_slot(a.q_off, b, a.Tq);      // rows of this sample that are its own (packed: its slot)
   {
     int64_t tail0;
@@ -182,9 +182,9 @@ __global__ __launch_bounds__(256, OCC) void k_attn_bwd_dq_m16(AttnM a, const e16
     const int kt = tl[j];
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
-      dma_piece<false>(st, Kb, a.ldk, kt * KT, a.Tk, w + 4 * u, lane);
-      dma_piece_tr16(st + KT * DH * 2, Kb, a.ldk, kt * KT, a.Tk, w + 4 * u, lane);
-      dma_piece<false>(st + 2 * KT * DH * 2, Vb, a.ldv, kt * KT, a.Tk, w + 4 * u, lane);
+      dma_piece_s<0>(st, Kb, a.ldk, kt * KT, a.Tk, w + 4 * u, lane);
+      dma_piece_s<3>(st + KT * DH * 2, Kb, a.ldk, kt * KT, a.Tk, w + 4 * u, lane);
+      dma_piece_s<0>(st + 2 * KT * DH * 2, Vb, a.ldv, kt * KT, a.Tk, w + 4 * u, lane);
     }
   };
 #pragma unroll

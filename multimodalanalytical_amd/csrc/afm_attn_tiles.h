@@ -325,10 +325,10 @@ __device__ __forceinline__ TrQuad tr_quad_dual(const unsigned (&xa)[4], const un
 // per piece) and, where registers are short, spills them -- and ANY scratch reload inside a ring loop comes with `s_waitcnt vmcnt(0)`, i.e.
 // waits for every piece in flight (tools/isa_ring_drain_check.py lists them).  `base` must be wave-uniform for the compiler to see (a row
 // offset read from memory goes through readfirstlane first); the offset must stay below 4 GB (rows of ONE sample).
-template <int KIND>      // 0 row image, 1 transposed-read image, 2 dual-use image
+template <int KIND>      // 0 row image, 1 transposed-read image, 2 dual-use image, 3 the 16 x 16 x 32 kernels' transposed-read image (dma_piece_tr16)
 __device__ __forceinline__ void dma_piece_s(unsigned char* img, const e16* base, int ld, int row0, int nrows, int pi, int lane) {
   const int r = 8 * pi + (lane >> 3), slot = lane & 7;
-  const int chunk = KIND == 2 ? (slot ^ dual_f(r)) : KIND == 1 ? (slot ^ (((r >> 1) & 1) << 2)) : (slot ^ ((r >> 1) & 7));
+  const int chunk = KIND == 3 ? (slot ^ (((r >> 1) & 3) << 1)) : KIND == 2 ? (slot ^ dual_f(r)) : KIND == 1 ? (slot ^ (((r >> 1) & 1) << 2)) : (slot ^ ((r >> 1) & 7));
   int gr = row0 + r;
   gr = gr < nrows ? gr : nrows - 1;   // clamped rows are masked out by the caller
   const uint32_t off = ((uint32_t)gr * (uint32_t)ld + (uint32_t)chunk * 8u) * 2u;

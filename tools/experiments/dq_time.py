@@ -21,6 +21,9 @@ for name, B, H, Tq, Tk, p in [("enc self", 128, 8, 1024, 1024, 0.1), ("enc self 
     if p:
         ops.attn_set_drop_bits(shp, torch.zeros(ops.attn_drop_bits_words(B, H, Tq, Tk), dtype=torch.int64, device=dev))
     ops.attn_fwd(shp, q, kv[:, :d], kv[:, d:], o, lse)
-    shp.reserved |= 1 | 32768
-    ms = t(lambda: ops.attn_bwd(shp, q, kv[:, :d], kv[:, d:], o, do, lse, delta, dq, dkv[:, :d], dkv[:, d:], d, 2 * d, 2 * d))
-    print(f"dQ {name:16s} {ms*1e3:7.1f} us  checksum {float(dq.float().abs().sum()):.6e}", flush=True)
+    base = shp.reserved
+    forms = (("32x32x16", 32768), ("16x16x32 occ3", 1024), ("16x16x32 occ2", 1024 | 2048)) if "--forms" in sys.argv else (("32x32x16", 32768),)
+    for fname, fl in forms:
+        shp.reserved = base | 1 | fl
+        ms = t(lambda: ops.attn_bwd(shp, q, kv[:, :d], kv[:, d:], o, do, lse, delta, dq, dkv[:, :d], dkv[:, d:], d, 2 * d, 2 * d))
+        print(f"dQ {name:16s} {fname:14s} {ms*1e3:7.1f} us  checksum {float(dq.float().abs().sum()):.6e}", flush=True)
