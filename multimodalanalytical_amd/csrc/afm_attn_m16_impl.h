@@ -280,9 +280,11 @@ __global__ __launch_bounds__(256, OCC) void k_attn_bwd_dq_m16(AttnM a, const e16
           for (int r = 0; r < 4; ++r) s[ki][qi][r] = fast_exp2(s[ki][qi][r]) * dp[ki][qi][r];   // dS^T = P (D dP - delta)
       {
         s16x4 lo[4], hi[4];
+        unsigned tra = tra0;
+        asm volatile("" : "+v"(tra));      // opaque: tra0 ^ (dt << 5) is one instruction here; hoisted out of the tile loop the four of them were spilled (and reloaded behind vmcnt(0))
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) {
-          const unsigned ad = ktr + (tra0 ^ (dt << 5));
+          const unsigned ad = ktr + (tra ^ (dt << 5));
           if (blk == 0) { AFM_TR_RD(lo[dt], ad, 0); AFM_TR_RD(hi[dt], ad, 2048); }
           else { AFM_TR_RD(lo[dt], ad, 4096); AFM_TR_RD(hi[dt], ad, 6144); }
         }

@@ -1269,10 +1269,15 @@ int AFM_E16_FN(afm_attn_bwd_mfma_try)(const afm_attn_shape* s, const void* Q, co
   // with the hash re-evaluated 0.556 ... 0.562 against 0.699 ... 0.701 -- the default in those two cases; with the keep bits READ it loses
   // (0.564 against 0.535: the lane-mask words do not match its score layout and are repacked per tile), so the training step's dropout
   // path keeps the 32 x 32 x 16 kernel.  reserved & 32768 keeps that kernel everywhere (A / B runs).
+  // Round 6: with its ring pieces in saddr form and the transposed-read addresses recomputed per tile the three-workgroup build of the
+  // 16 x 16 x 32 kernel spills nothing (168 registers), and with the keep bits it edges out the 32 x 32 x 16 kernel on long query
+  // sequences (c2 encoder shape 591 ... 612 against 624 ... 627 us, c4's 229 against 250; at 128 queries it loses, 110 against 96) --
+  // +0.2 % of the c2 step (3 189 -> 3 196).  NOT made the default for the keep-bit path: another rounding of dQ in every training step for
+  // a gain inside the box-to-box spread (reserved & 1024 selects it).
   else if ((s->reserved & 1024) || (!(a.dd.thresh16 && a.bits) && !(s->reserved & 32768))) {
 #define AFM_M16_LAUNCH(D, OCC) do { static AfmOncePerDevice at_; if (at_.need()) (void)hipFuncSetAttribute((const void*)k_attn_bwd_dq_m16<D, OCC>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); \
       AFM_LAUNCH((k_attn_bwd_dq_m16<D, OCC>), gq, dim3(256), shm_q, st, a, (const e16*)Q, (const e16*)K, (const e16*)V, (const e16*)O, (const e16*)dO, lse, delta, (e16*)dQ); } while (0)
-    const bool occ2 = (s->reserved & 2048) != 0 || !(s->reserved & 1024);
+    const bool occ2 = (s->reserved & 2048) != 0 || (!(s->reserved & 1024) && !(a.dd.thresh16 && a.bits));      // (keep bits: the three-workgroup build)
     if (a.dd.thresh16 && a.bits) { if (occ2) AFM_M16_LAUNCH(DROP_BITS, 2); else AFM_M16_LAUNCH(DROP_BITS, 3); }
     else if (a.dd.thresh16) { if (occ2) AFM_M16_LAUNCH(DROP_HASH, 2); else AFM_M16_LAUNCH(DROP_HASH, 3); }
     else { if (occ2) AFM_M16_LAUNCH(DROP_NONE, 2); else AFM_M16_LAUNCH(DROP_NONE, 3); }

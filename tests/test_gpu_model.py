@@ -322,10 +322,17 @@ def test_fp16_checkpoint_resume_continues_the_run(tmp_path):
         loop_bad.micro_batch(_dev_batch(t, i % 4))
         torch.testing.assert_close(a, c, rtol=2e-5, atol=2e-5)
     e1, e2, e3 = w.hf_model.engine, w2.hf_model.engine, w_bad.hf_model.engine
-    d_good = float((e1.ps.flat - e2.ps.flat).abs().max())
-    d_bad = float((e1.ps.flat - e3.ps.flat).abs().max())
-    assert d_good < 2e-5 and d_bad > 50 * max(d_good, 1e-6), (d_good, d_bad)
-    torch.testing.assert_close(e1.ps.exp_avg_sq, e2.ps.exp_avg_sq, rtol=1e-3, atol=1e-12)
+    # Parameters whose exact gradient is ZERO -- the key projection's bias: a softmax does not see a constant added to every key -- receive
+    # the rounding noise of an atomic column sum, and Adam turns noise into steps of +-lr whatever its size (m / sqrt(v) is scale-free above
+    # eps): two runs of the SAME program differ there by a fraction of lr (seen: 1e-4 ... 4e-4 in one run of eight, with and without the
+    # round-6 kernels).  The comparison is over the parameters that have a gradient (second moment above the noise floor).
+    has_grad = e1.ps.exp_avg_sq > 1e-14
+    d_good = float((e1.ps.flat - e2.ps.flat)[has_grad].abs().max())
+    d_bad = float((e1.ps.flat - e3.ps.flat)[has_grad].abs().max())
+    d_all = float((e1.ps.flat - e2.ps.flat).abs().max())
+    assert float(has_grad.float().mean()) > 0.9, float(has_grad.float().mean())
+    assert d_good < 2e-5 and d_bad > 50 * max(d_good, 1e-6) and d_all < 2e-3, (d_good, d_bad, d_all)
+    torch.testing.assert_close(e1.ps.exp_avg_sq, e2.ps.exp_avg_sq, rtol=1e-2, atol=1e-10)      # (a handful of entries move by 0.2 ... 0.5 % in the runs where the zero-gradient parameters above parted)
     assert torch.equal(e1.scaler, e2.scaler) and loop.optim.step_count == loop2.optim.step_count == 5
     # a checkpoint from before the scaler was stored
     del raw["optimizer_states"][0]["loss_scaler"]
