@@ -271,12 +271,15 @@ extern "C" int afm_attn_fwd(const afm_attn_shape* s, const void* Q, const void* 
   if (r != AFM_OK) return r;
   if (!Q || !K || !V || !O || !lse) return AFM_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
+  const bool packed = s->q_off || s->k_off;      // packed rows exist in the single-pass MFMA kernels only (include/afm_hip.h)
   if (s->algo != AFM_ALGO_GENERIC) {
-    r = s->dtype == AFM_BF16X2 ? afm_attn_fwd_x3_try(s, Q, K, V, O, lse, st)
+    r = (s->dtype == AFM_BF16X2 && packed) ? AFM_ERR_UNSUPPORTED
+        : s->dtype == AFM_BF16X2 ? afm_attn_fwd_x3_try(s, Q, K, V, O, lse, st)
         : s->dtype == AFM_F16 ? afm_attn_fwd_mfma_try_f16(s, Q, K, V, O, lse, st) : afm_attn_fwd_mfma_try(s, Q, K, V, O, lse, st);
     if (r != AFM_ERR_UNSUPPORTED) return r;
     if (s->algo == AFM_ALGO_MFMA) return r;
   }
+  if (packed) return AFM_ERR_UNSUPPORTED;      // the kernels below know nothing of q_off / k_off: refuse, never compute on the wrong rows
   const AttnArgs a = make_args(s);
   const size_t shm = sizeof(float) * 4 * (size_t)(s->dh + s->Tk);
   if (shm > 160 * 1024) return AFM_ERR_UNSUPPORTED;
@@ -306,13 +309,16 @@ extern "C" int afm_attn_bwd(const afm_attn_shape* s, const void* Q, const void* 
   if (lddq < w || lddk < w || lddv < w) return AFM_ERR_ARG;
   if (s->sqb || s->skb || s->svb || s->sob) return AFM_ERR_UNSUPPORTED;   // strided batches: forward (decode) only
   hipStream_t st = (hipStream_t)stream;
+  const bool packed = s->q_off || s->k_off;
   if (s->algo != AFM_ALGO_GENERIC) {
-    r = s->dtype == AFM_BF16X2 ? afm_attn_bwd_x3_try(s, Q, K, V, O, dO, lse, delta, dQ, dK, dV, lddq, lddk, lddv, st)
+    r = (s->dtype == AFM_BF16X2 && packed) ? AFM_ERR_UNSUPPORTED
+        : s->dtype == AFM_BF16X2 ? afm_attn_bwd_x3_try(s, Q, K, V, O, dO, lse, delta, dQ, dK, dV, lddq, lddk, lddv, st)
         : s->dtype == AFM_F16 ? afm_attn_bwd_mfma_try_f16(s, Q, K, V, O, dO, lse, delta, dQ, dK, dV, lddq, lddk, lddv, st)
                               : afm_attn_bwd_mfma_try(s, Q, K, V, O, dO, lse, delta, dQ, dK, dV, lddq, lddk, lddv, st);
     if (r != AFM_ERR_UNSUPPORTED) return r;
     if (s->algo == AFM_ALGO_MFMA) return r;
   }
+  if (packed) return AFM_ERR_UNSUPPORTED;      // (as in afm_attn_fwd)
   const AttnArgs a = make_args(s);
   const size_t shm_q = sizeof(float) * 4 * (size_t)(2 * s->dh + s->Tk);
   const size_t shm_k = sizeof(float) * 4 * (size_t)(2 * s->dh + 2 * s->Tq);

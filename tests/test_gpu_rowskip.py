@@ -364,6 +364,31 @@ def test_attn_packed_rows_equal_dense(ops, p, cross, lens):
     assert bool(torch.isfinite(dkvp.float()).all()) and bool(torch.isfinite(dqp.float()).all()) and bool(torch.isfinite(op_.float()).all())
 
 
+def test_packed_rows_are_refused_where_no_kernel_takes_them(ops):
+    """q_off / k_off exist in the single-pass MFMA kernels only.  A call those kernels decline (here: a backward over 100 queries without the
+    fused short-query bit -- the packed dK/dV kernel wants whole 64-query tiles; an fp32 call) must come back as an error, never fall through
+    to the generic kernels, which would compute on the dense layout's rows (found by tools/experiments/fsq_fuzz.py in round 6)."""
+    from multimodalanalytical_amd.lib import AfmError
+    B, H, T, dh, Tq = 3, 2, 256, 64, 100
+    d = H * dh
+    pad = (torch.arange(T)[None, :] >= torch.tensor([256, 40, 130])[:, None]).to(torch.uint8).to(DEV)
+    plan = ops.compact_plan(pad, B, T, 256, compact=2)
+    for dt in (H16, torch.float32):
+        q = torch.randn(B * Tq, d, device=DEV).to(dt)
+        kv = torch.randn(B * T, 2 * d, device=DEV).to(dt)
+        o, lse = torch.empty_like(q), torch.empty(B * H * Tq, device=DEV)
+        shp = ops.attn_shape(B, H, Tq, T, dh, dt, d, 2 * d, 2 * d, d, pad, False, ops.NO_DROP, k_off=plan.seq_off)
+        if dt == H16:
+            ops.attn_fwd(shp, q, kv[:, :d], kv[:, d:], o, lse)          # (the forward takes packed key rows at any query count)
+            assert ops.last_algo() == "attn_mfma"
+        else:
+            with pytest.raises(AfmError):
+                ops.attn_fwd(shp, q, kv[:, :d], kv[:, d:], o, lse)
+        dq, dkv, delta = torch.empty_like(q), torch.empty_like(kv), torch.empty_like(lse)
+        with pytest.raises(AfmError):
+            ops.attn_bwd(shp, q, kv[:, :d], kv[:, d:], o, torch.randn_like(q), lse, delta, dq, dkv[:, :d], dkv[:, d:], d, 2 * d, 2 * d)
+
+
 # ------------------------------------------------------------------ the engine, skip on against skip off
 def _engine(name, mode_env, seed=5, dropout=0.0, cfg_over=None):
     from multimodalanalytical_amd import synth
