@@ -8,20 +8,24 @@
 // Here ONE workgroup owns a (batch, head) with ALL its queries resident: 4 waves x 32 queries, the query on the lane as in the dQ kernel.
 // Per 64-key tile:
 //   phase A (the dQ kernel's tile body):  S^T = K Q^T, dP^T = V dO^T  ->  P, dS^T = P (D dP - delta)  ->  dQ^T += K^T dS^T;
-//            the wave also writes its 32 rows of P_drop = D P and of dS, as fp16, into two [128 q][64 key] LDS tiles in the
-//            transposed-read image format (img_tr: what dma_piece<true> produces for K / V tiles)
+//            the wave also writes its 32 rows of P_drop = D P and of dS, as 16-bit values, into two [128 q][64 key] LDS tiles laid out for
+//            transposed reads (swizzle fsq_f below)
 //   barrier
 //   phase B: wave w takes the 32 x 32 block (d-block w >> 1, key-block w & 1) of dV^T = dO^T P_drop and of dK^T = Q^T dS over all 128
-//            queries: 8 slices of 16 queries, both operands by ds_read_b64_tr_b16 -- dO^T / Q^T from images staged once per kernel,
-//            P / dS from the tiles of phase A -- and stores those dK / dV rows: every query of the head is in the workgroup, so a key
-//            tile's dK / dV is complete after its own iteration (no atomics, no accumulation across tiles).
+//            queries: 8 slices of 16 queries -- dO^T / Q^T fragments read once per kernel (13 of the 16 live in registers, 3 wait in LDS),
+//            P / dS by ds_read_b64_tr_b16 from the tiles of phase A -- and hands on those dK / dV rows: every query of the head is in the
+//            workgroup, so a key tile's dK / dV is complete after its own iteration (no atomics, no accumulation across tiles).  The rows
+//            turn through 4 KB of the just-consumed ring stage (16 bytes per lane, four lanes to a row's 64 bytes) and are STORED at the top
+//            of the next iteration, behind its wait for the ring (stores count in vmcnt: see the loop).
 // 5 products, one softmax chain, K / V / Q / dO / keep bits read once.  Key tiles of nothing but padding never enter the loop; their dK / dV
 // rows are written as zeros behind it (packed key rows: through attn_out_row, honouring the no-fill limit).
 // The dO^T / Q^T operands of phase B do not depend on the key tile: the wave reads its 2 x 8 fragments from the images ONCE, before the loop.
 // LDS: ring 2 x 16 KB (K as ONE dual-use image for the row and the transposed reads, V row image) + P, dS tiles 32 KB (the Q / dO images
-// of the prologue lie in the same 32 KB: read out before the first tile's P is written) + masks = 64.3 KB: two workgroups per CU, 256
-// registers each.  (First form, 113 KB and one workgroup per CU: 279 us at the c2 shape against 356 for the two kernels.)  Dropout through the keep-bit
-// tensor or off; no causal mask; Tq <= 128; dense query rows (q_off unsupported), packed key rows supported.
+// of the prologue lie in the same 32 KB: read out before the first tile's P is written) + 12 KB of parked fragments + masks = 76.3 KB: two
+// workgroups per CU, 256 registers each.  (First form, 113 KB and one workgroup per CU: 279 us at the c2 shape against 356 for the two
+// kernels; this form 198 us -- DESIGN.md 4.0r6 item 10b has every step.)  Dropout through the keep-bit tensor or off; no causal mask;
+// Tq <= 128; dense query rows (q_off unsupported), packed key rows supported.  No atomics: two runs give the same bits
+// (tools/experiments/fsq_fuzz.py checks exactly that over random shapes).
 //
 // The P / dS tiles are [128 q][64 keys] e16, 128-byte rows, the 8-byte unit u of row r at unit  u ^ f(r),  f(r) = 8 ((r >> 1) & 1) | ((r >> 2) & 7):
 // phase A's lane (query r, half h) stores 8 bytes per register group -- 32 consecutive rows of one half-wave land on 32 different 8-byte
