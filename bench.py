@@ -639,7 +639,9 @@ def timed_run(workload, mode, steps, warmup, rank, world, dev, args, keep=False,
     S = batches[0]["encoder_pad_mask"].shape[0]
     flops = synth.train_flops_per_sample(wl["cfg"], S, wl["T"], tok.vocab_size)
     live = torch.cat([(~b["encoder_pad_mask"]).sum(0).double() for b in batches])          # live encoder positions per sample
-    ex = synth.executed_flops_per_sample(wl["cfg"], S, wl["T"], tok.vocab_size, float(live.mean()), float((live * live).mean()))
+    eng_ = model.hf_model.engine
+    ex = synth.executed_flops_per_sample(wl["cfg"], S, wl["T"], tok.vocab_size, float(live.mean()), float((live * live).mean()),
+                                         fused_cross=bool(getattr(eng_, "xattn_fused", False)) and wl["T"] <= 128 and eng_.bd in (torch.float16, torch.bfloat16))
     res = {"value": steps * args.acc * B * world / dt, "dt": dt, "loss": float(loss), "S": S, "B": B, "flops": flops, "wl": wl,
            "executed": ex, "live_frac": float(live.mean()) / S, "input_path": input_path}
     if rank == 0 and world == 1 and not args.no_parity and not args.no_cpu_baseline:

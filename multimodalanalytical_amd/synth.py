@@ -70,7 +70,7 @@ def train_flops_per_sample(cfg, S, T, V, patch_flops=0.0) -> float:
     return 3.0 * (enc + dec + 2 * T * d * V + patch_flops)
 
 
-def executed_flops_per_sample(cfg, S, T, V, enc_live=None, enc_live_sq=None) -> Dict[str, float]:
+def executed_flops_per_sample(cfg, S, T, V, enc_live=None, enc_live_sq=None, fused_cross=None) -> Dict[str, float]:
     """What the kernels really multiply per trained sample (bench.py `step_mfma_frac_executed`, `live_gflop_per_sample`).
       executed  the algorithmic count + the products the attention BACKWARD recomputes: the two backward kernels evaluate 7 products
                 of S x S x dh per head where the algorithm has 4 (Q K^T and dO V^T once more in each of them minus the shared one),
@@ -78,18 +78,23 @@ def executed_flops_per_sample(cfg, S, T, V, enc_live=None, enc_live_sq=None) -> 
       live      the same over the LIVE encoder positions only: the work a training step cannot leave out.  Since round 6 both
                 directions leave padded rows out (the forward in whole 256-row groups after per-sample compaction, the
                 backward in 64-row blocks / 256-row tiles), so what the kernels execute lies between `live` and `executed`.
-                enc_live = mean live encoder length, enc_live_sq = mean of its square."""
+                enc_live = mean live encoder length, enc_live_sq = mean of its square.
+      fused_cross  the decoder's cross-attention backward runs as ONE kernel (round 6: 5 products, one recomputed, instead of 7;
+                default: where the engine's default takes that kernel, T <= 128)."""
+    if fused_cross is None:
+        fused_cross = T <= 128
+    xb = 5 if fused_cross else 7          # products of a cross-attention instance's backward
     d, g = cfg["d_model"], (6 if cfg["gated_linear"] else 4)
     fe, fd, Le, Ld = cfg["encoder_ffn_dim"], cfg["decoder_ffn_dim"], cfg["encoder_layers"], cfg["decoder_layers"]
     alg = train_flops_per_sample(cfg, S, T, V)
-    extra = Le * 3 * 2 * S * S * d + Ld * 3 * (2 * T * T * d + 2 * T * S * d)       # 3 recomputed products per attention instance
+    extra = Le * 3 * 2 * S * S * d + Ld * (3 * 2 * T * T * d + (xb - 4) * 2 * T * S * d)       # recomputed products per attention instance: 3 (two kernels), 1 (fused cross)
     out = {"algorithmic": alg, "executed": alg + extra}
     if enc_live is not None:
         s1, s2 = float(enc_live), float(enc_live_sq if enc_live_sq is not None else enc_live * enc_live)
         fwd = Le * (8 * s1 * d * d + 4 * s2 * d + g * s1 * d * fe) + \
             Ld * (12 * T * d * d + 4 * s1 * d * d + 4 * T * T * d + 4 * T * s1 * d + g * T * d * fd) + 2 * T * d * V
         bwd_gemm = 2 * (Le * (8 * s1 * d * d + g * s1 * d * fe) + Ld * (12 * T * d * d + 4 * s1 * d * d + g * T * d * fd) + 2 * T * d * V)
-        bwd_attn = Le * 7 * 2 * s2 * d + Ld * 7 * (2 * T * T * d + 2 * T * s1 * d)
+        bwd_attn = Le * 7 * 2 * s2 * d + Ld * (7 * 2 * T * T * d + xb * 2 * T * s1 * d)
         out["live"] = fwd + bwd_gemm + bwd_attn
     return out
 
