@@ -114,7 +114,7 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd_fsq(AttnM a, const e16* __r
   const int64_t lrow = ((int64_t)b * a.H + hd) * a.Tq + qc;
   if (q < a.Tq && h == 0) delta[lrow] = -dl;
   const float L = lse[lrow];
-  const float nL2 = L == INFINITY ? -INFINITY : -L * 1.4426950408889634f;
+  const float nL2 = (L == INFINITY || q >= a.Tq) ? -INFINITY : -L * 1.4426950408889634f;      // (rows past Tq take no part: their scores start, and stay, at -inf)
   // dO stays as loaded (the dQ kernel multiplies it by the dropout scale and rounds again: 2^-11 of |dP| left in dS, visible where the
   // softmax is one-hot and dS cancels to nothing).  Here the chain starts from -delta / scale and the scale rides on P:
   // dS = (scale P) (keep ? dP - delta / scale : -delta / scale)
@@ -194,7 +194,6 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd_fsq(AttnM a, const e16* __r
   // registers over the 256 a wave has at two workgroups per CU, and what the compiler spilled instead were these same fragments -- to
   // scratch, three dependent reloads per tile, each behind an `s_waitcnt vmcnt(0)`.
   const e16x8* const park = (const e16x8*)(lds + PARK) + t;
-  const bool qlive = q < a.Tq;
   const unsigned kt0 = tr_dual_t0(lane);
   const int64_t fill_end = attn_fill_end(a.nofill, a.k_off, a.B);
   const int kblk = w & 1, dblk = w >> 1;
@@ -254,7 +253,7 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd_fsq(AttnM a, const e16* __r
       f32x16 pd;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float p = (ABL & 16) ? s[r] : qlive ? fast_exp2(s[r]) : 0.f;   // masked: exp2(-inf) = 0; rows past Tq take no part
+        const float p = (ABL & 16) ? s[r] : fast_exp2(s[r]);   // masked keys and rows past Tq: exp2(-inf) = 0
         pd[r] = DROP != DROP_NONE ? p * a.dd.scale16 : p;
         s[r] = pd[r] * dp[r];   // dS^T = P (D dP - delta)
       }
