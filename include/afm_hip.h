@@ -307,8 +307,9 @@ typedef struct {
                              round-3 kernel restated on 16 x 16 x 32, bits 10-11 (1024, 2048) the 16 x 16 x 32 dQ kernels (the default without dropout and where the
                              hash is re-evaluated; bit 15 (32768) keeps the 32 x 32 x 16 dQ kernel there); bit 16 (65536) the short-query dK/dV kernel
                              (csrc/afm_attn_sq_impl.h: Tq <= 192 < 256 <= Tk, no causal mask; an A / B form); bit 18 (262144), round 6: dQ, dK and dV in ONE
-                             kernel where Tq <= 128, no causal mask, dense query rows (k_off allowed), dropout through drop_bits or off, bits 0-1 zero
-                             (csrc/afm_attn_fsq_impl.h: the decoder's cross-attention; the two kernels elsewhere; delta as always, dQ / dK / dV to rounding).  afm_attn_fwd: bits 10-11 select
+                             kernel where Tq <= 128, dense query rows (k_off allowed without a causal mask), a causal mask only with Tq == Tk, dropout through drop_bits
+                             or off, bits 0-1 zero (csrc/afm_attn_fsq_impl.h: the decoder's cross- and self-attention; the two kernels elsewhere; delta as always,
+                             dQ / dK / dV to rounding).  afm_attn_fwd: bits 10-11 select
                              the forward restated on 16 x 16 x 32 (csrc/afm_attn_fwd16_impl.h; bit 11: its three-workgroup build; A / B forms).  Bits 20-27 select timing ablations in AFM_ATTN_ABLATIONS builds (never in the product library). */
   const uint8_t* key_pad;
   afm_dropout drop;

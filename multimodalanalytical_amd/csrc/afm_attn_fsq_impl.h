@@ -23,8 +23,9 @@
 // LDS: ring 2 x 16 KB (K as ONE dual-use image for the row and the transposed reads, V row image) + P, dS tiles 32 KB (the Q / dO images
 // of the prologue lie in the same 32 KB: read out before the first tile's P is written) + 12 KB of parked fragments + masks = 76.3 KB: two
 // workgroups per CU, 256 registers each.  (First form, 113 KB and one workgroup per CU: 279 us at the c2 shape against 356 for the two
-// kernels; this form 198 us -- DESIGN.md 4.0r6 item 10b has every step.)  Dropout through the keep-bit tensor or off; no causal mask;
-// Tq <= 128; dense query rows (q_off unsupported), packed key rows supported.  No atomics: two runs give the same bits
+// kernels; this form 198 us -- DESIGN.md 4.0r6 item 10b has every step.)  Dropout through the keep-bit tensor or off; Tq <= 128; a causal
+// mask where Tq == Tk (the decoder's self-attention: its one or two key tiles are walked by every wave, masked above the diagonal);
+// dense query rows (q_off unsupported), packed key rows supported.  No atomics: two runs give the same bits
 // (tools/experiments/fsq_fuzz.py checks exactly that over random shapes).
 //
 // The P / dS tiles are [128 q][64 keys] e16, 128-byte rows, the 8-byte unit u of row r at unit  u ^ f(r),  f(r) = 8 ((r >> 1) & 1) | ((r >> 2) & 7):
@@ -243,11 +244,13 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd_fsq(AttnM a, const e16* __r
         dp = mfma32(frag_row(Vrow, 32 * blk, ks, lane), dof[ks], dp);
       }
       if (DROP == DROP_BITS && !(ABL & 16)) drop_select_masks(dp, km[blk], ndl);
-      if (mword != 0ull && !(ABL & 16)) {   // wave-uniform: tile has masked keys
+      if ((mword != 0ull || (a.causal && kb + KT - 1 > q0)) && !(ABL & 16)) {   // wave-uniform: tile has masked keys (padding / above the diagonal)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int ko = 32 * blk + ACC_ROW(r);
-          s[r] = ((pad >> ko) & 1ull) ? -INFINITY : s[r];
+          bool msk = (pad >> ko) & 1ull;
+          if (a.causal) msk = msk || (kb + ko + 4 * h > q);
+          s[r] = msk ? -INFINITY : s[r];
         }
       }
       f32x16 pd;

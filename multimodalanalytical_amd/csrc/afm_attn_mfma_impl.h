@@ -1216,7 +1216,7 @@ int AFM_E16_FN(afm_attn_bwd_mfma_try)(const afm_attn_shape* s, const void* Q, co
   }
   const bool run_q = (s->reserved & 3) != 2, run_k = (s->reserved & 3) != 1;   // reserved & 3 = 1 / 2: only the dQ / only the dK-dV kernel (timing)
   // Round 6: short query sequences (the decoder's cross-attention), dQ, dK and dV in ONE kernel (afm_attn_fsq_impl.h): reserved & 262144
-  if ((s->reserved & 262144) && (s->reserved & 3) == 0 && !s->causal && s->Tq <= 128 && !s->q_off && (!s->k_off || s->key_pad) &&
+  if ((s->reserved & 262144) && (s->reserved & 3) == 0 && (!s->causal || (s->Tq == s->Tk && !s->k_off)) && s->Tq <= 128 && !s->q_off && (!s->k_off || s->key_pad) &&
       (!a.dd.thresh16 || a.bits)) {
     const int shm_f = RS * 2 * KT * DH * 2 + 4 * KT * DH * 2 + 3 * 4096 + ((s->Tk + KT - 1) / KT) * 12 + 16;      // ring, P / dS tiles, parked fragments, key-mask words and tile list
     if (shm_f <= 80 * 1024) {

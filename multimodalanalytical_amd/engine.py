@@ -752,7 +752,7 @@ class Seq2SeqEngine:
         hint_e = self._live.get("enc")
         if not shp.causal and shp.q_off and isinstance(hint_e, ops.RowFlags) and hint_e.nofill:
             shp.reserved |= 131072      # packed rows, verified hints: the dead tail of dQ / dK / dV is left unwritten
-        shp.reserved |= self.attn_bwd_flags
+        shp.reserved |= self.attn_bwd_flags | (262144 if (self.xattn_fused and shp.causal) else 0)      # (decoder self-attention: the fused backward where T <= 128)
         ops.attn_bwd(shp, qkv_b[:, :d], qkv_b[:, d:2 * d], qkv_b[:, 2 * d:], self._hb(a), da, lse, delta,
                      dqkv[:, :d], dqkv[:, d:2 * d], dqkv[:, 2 * d:], ldg, ldg, ldg)
         self._wgrad(dqkv, h, p + "self_attn.in_proj_weight", 3 * d, d, bias_name=p + "self_attn.in_proj_bias")

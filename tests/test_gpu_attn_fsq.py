@@ -40,7 +40,7 @@ def _keep_from_bits(bits, B, H, Tq, Tk):
     return keep[:, :, :Tq, :Tk]
 
 
-def _torch_ref(q, k, v, do, pad, H, scale, keep=None, p_drop=0.0):
+def _torch_ref(q, k, v, do, pad, H, scale, keep=None, p_drop=0.0, causal=False):
     """fp32 attention forward + backward, (B, T, H dh) tensors, pad (B, Tk) bool; dropout through a given keep mask."""
     B, Tq, d = q.shape
     Tk = k.shape[1]
@@ -49,6 +49,8 @@ def _torch_ref(q, k, v, do, pad, H, scale, keep=None, p_drop=0.0):
     qh.requires_grad_(True); kh.requires_grad_(True); vh.requires_grad_(True)
     s = (qh @ kh.transpose(-1, -2)) * scale
     s = s.masked_fill(pad[:, None, None, :], float("-inf"))
+    if causal:
+        s = s.masked_fill(torch.ones(Tq, Tk, dtype=torch.bool, device=s.device).triu(1)[None, None], float("-inf"))
     p = torch.softmax(s, -1)
     p = torch.nan_to_num(p, nan=0.0)          # a sample with no live key: zeros, as the kernels define it
     if keep is not None:
@@ -63,8 +65,12 @@ def _torch_ref(q, k, v, do, pad, H, scale, keep=None, p_drop=0.0):
 @pytest.mark.parametrize("p", [0.0, 0.1])
 @pytest.mark.parametrize("Tq,Tk,lens", [(128, 1024, (1024, 700, 130, 64, 5, 0, 333, 960)), (100, 1024, (1024, 2, 63, 65, 512, 200, 999, 128)),
                                         (128, 56, (56, 3, 17, 40, 0, 56, 1, 33)), (37, 200, (200, 64, 129, 7, 0, 199, 128, 100)),
-                                        (64, 320, (320, 100, 31))])
+                                        (64, 320, (320, 100, 31)),
+                                        # the decoder's self-attention: causal, Tq == Tk, padded tails
+                                        (-128, 128, (128, 90, 17, 64, 2, 0, 128, 33)), (-100, 100, (100, 2, 63, 65, 50, 99, 7, 100)), (-38, 38, (38, 5, 30))])
 def test_fused_equals_two_kernels(ops, dtype, p, Tq, Tk, lens):
+    causal = Tq < 0
+    Tq = abs(Tq)
     B, H, dh = len(lens), (8 if len(lens) == 8 else 5), 64          # (3 x 5 heads: not a multiple of 8, the block map's other branch)
     d = H * dh
     g = torch.Generator().manual_seed(3)
@@ -76,7 +82,7 @@ def test_fused_equals_two_kernels(ops, dtype, p, Tq, Tk, lens):
     drop = ops.drop(p, 4, 1) if p else ops.NO_DROP
 
     def run(flag, bits=True):
-        shp = ops.attn_shape(B, H, Tq, Tk, dh, dtype, d, 2 * d, 2 * d, d, pad, False, drop)
+        shp = ops.attn_shape(B, H, Tq, Tk, dh, dtype, d, 2 * d, 2 * d, d, pad, causal, drop)
         if p and bits:
             ops.attn_set_drop_bits(shp, torch.zeros(ops.attn_drop_bits_words(B, H, Tq, Tk), dtype=torch.int64, device=DEV))
         o = torch.full((B * Tq, d), 3.0, dtype=dtype, device=DEV)
@@ -109,9 +115,10 @@ def test_fused_equals_two_kernels(ops, dtype, p, Tq, Tk, lens):
     if True:      # (block kept flat for the diff's sake)
         keep = _keep_from_bits(run.bits, B, H, Tq, Tk) if p else None
         ro, rdq, rdk, rdv = _torch_ref(q.view(B, Tq, d), kv[:, :d].reshape(B, Tk, d), kv[:, d:].reshape(B, Tk, d), do.view(B, Tq, d),
-                                       pad.bool(), H, dh ** -0.5, keep, p)
+                                       pad.bool(), H, dh ** -0.5, keep, p, causal)
         if p:
-            assert 0.85 < float(keep[0].float().mean()) < 0.95          # (sample 0 has no padded key in any of the cases: every block was written)
+            seen = torch.ones(Tq, Tk, dtype=torch.bool, device=keep.device).tril() if causal else torch.ones(Tq, Tk, dtype=torch.bool, device=keep.device)
+            assert 0.85 < float(keep[0][:, seen].float().mean()) < 0.95          # (sample 0 has no padded key in any of the cases: every block at or below the diagonal was written)
             assert float((o1.view(B, Tq, d).float() - ro).abs().max() / ro.abs().max()) < (4e-3 if dtype == torch.float16 else 3e-2)
         for name, a, b in (("dQ", dq1.view(B, Tq, d), rdq), ("dK", dkv1[:, :d].reshape(B, Tk, d), rdk), ("dV", dkv1[:, d:].reshape(B, Tk, d), rdv)):
             err = float((a.float() - b).abs().max() / b.abs().max())
@@ -121,7 +128,9 @@ def test_fused_equals_two_kernels(ops, dtype, p, Tq, Tk, lens):
     # arithmetic, and what every kernel here computes instead is dO . (O - round16(O)) -- delta is taken from the ROUNDED output -- which
     # the dK/dV kernel happens to cancel exactly (it rounds scale * V the same way) and the dQ chain does not: noise of 2^-11 |dP|,
     # 1e-2 of this test's small max |dK|, in the fused kernel as in the dQ kernel's dQ since round 3)
-    assert all(e < tol for e in errs.values()), errs
+    # (causal rows are the same case in small: the first queries see one or two keys.  Under dropout the two-kernel comparison gets twice the
+    # tolerance there; the torch comparison above keeps its bar)
+    assert all(e < (2 * tol if (causal and p) else tol) for e in errs.values()), errs
     if not p:
         assert errs["dQ"] < tol / 4, errs
 

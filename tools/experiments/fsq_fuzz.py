@@ -20,6 +20,9 @@ for case in range(n_cases):
     if ri(0, 3) == 0:
         Tk = 128 * ri(1, 10)
         packed = ri(0, 1) == 1
+    causal = ri(0, 3) == 0          # the decoder's self-attention: Tq == Tk <= 128, dense rows
+    if causal:
+        Tq = 2 * ri(1, 64); Tk = Tq; packed = False
     d = H * dh
     n = torch.randint(0, Tk + 1, (B,), generator=g)
     if ri(0, 2) == 0:
@@ -43,7 +46,7 @@ for case in range(n_cases):
 
     def run(flag, dense=False):
         kv, kw = (kv_d, {}) if dense else (kv_run, kw_run)
-        shp = ops.attn_shape(B, H, Tq, Tk, dh, dtype, d, 2 * d, 2 * d, d, pad, False, drop, **kw)
+        shp = ops.attn_shape(B, H, Tq, Tk, dh, dtype, d, 2 * d, 2 * d, d, pad, causal, drop, **kw)
         if p:
             ops.attn_set_drop_bits(shp, torch.zeros(ops.attn_drop_bits_words(B, H, Tq, Tk), dtype=torch.int64, device=DEV))
         o = torch.full((B * Tq, d), 3.0, dtype=dtype, device=DEV)
@@ -69,7 +72,7 @@ for case in range(n_cases):
         if not bool(torch.isfinite(dkv1.float()).all() and torch.isfinite(dq1.float()).all()):
             msg.append("non-finite")
         tol = 4e-3 if dtype == torch.float16 else 3e-2
-        one_hot = bool((n == 1).any()) and p > 0          # (see tests/test_gpu_attn_fsq.py: the rounded-output noise of one-hot softmax rows)
+        one_hot = (bool((n == 1).any()) or causal) and p > 0          # (see tests/test_gpu_attn_fsq.py: the rounded-output noise of one-hot softmax rows)
         if packed:      # packed -> dense order; the dead tail must hold zeros
             used = int(plan.seq_off[-1])
             if float(dkv1[used:].float().abs().max() if used < B * Tk else 0.0) != 0.0:
@@ -79,12 +82,12 @@ for case in range(n_cases):
             dkv1 = back
             dkv0 = dkv0.clone(); dkv0[~live] = 0
         for nm, x, y in (("dQ", dq0, dq1), ("dK", dkv0[:, :d], dkv1[:, :d]), ("dV", dkv0[:, d:], dkv1[:, d:])):
-            e = float((x.float() - y.float()).abs().max() / x.float().abs().max().clamp_min(1e-6))
+            e = float((x.float() - y.float()).abs().max() / x.float().abs().max().clamp_min(5e-3))      # (floor: where every row is one-hot the exact gradient is 0 and both kernels return noise)
             if e > (10 * tol if one_hot else tol):
                 msg.append(f"{nm} {e:.2e}")
         if not torch.equal(dl0, dl1):
             msg.append("delta differs")
     if msg:
         bad += 1
-        print(f"case {case}: B{B} H{H} Tq{Tq} Tk{Tk} p{p} {dtype} packed={packed} lens={n.tolist()}: {'; '.join(msg)}", flush=True)
+        print(f"case {case}: B{B} H{H} Tq{Tq} Tk{Tk} p{p} {dtype} packed={packed} causal={causal} lens={n.tolist()}: {'; '.join(msg)}", flush=True)
 print(f"{n_cases} cases, {bad} with findings", flush=True)
